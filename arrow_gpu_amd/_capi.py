@@ -1,0 +1,165 @@
+"""ctypes binding of the C ABI in include/arrow_gpu.h (libarrow_gpu_hip.so).
+
+This is the Python-side equivalent of the `extern "C"` block a Rust shim would declare.  There is
+no CPU fallback: if the shared library is missing this module raises at import of the first symbol, and on a box
+without a gfx950 device `agpu_device_create` returns AGPU_ERR_NO_DEVICE, surfaced as ArrowErrorGPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libarrow_gpu_hip.so")
+
+# status codes
+OK, ERR_UNSUPPORTED, ERR_SHAPE, ERR_HIP, ERR_ARG, ERR_NO_DEVICE = range(6)
+
+# agpu_dtype
+BOOL, F32, U32, U16, U8, I32, I16, I8, DATE32 = range(9)
+# agpu_binary_op
+OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_REM, OP_MIN, OP_MAX, OP_AND, OP_OR, OP_XOR, OP_SHL, OP_SHR, OP_POW = range(13)
+# agpu_unary_op
+(UN_NEG, UN_ABS, UN_NOT, UN_SQRT, UN_CBRT, UN_EXP, UN_EXP2, UN_LOG, UN_LOG2, UN_SIN, UN_COS, UN_ACOS, UN_SINH) = range(13)
+# agpu_cmp_op
+CMP_GT, CMP_GTEQ, CMP_LT, CMP_LTEQ, CMP_EQ = range(5)
+# agpu_reduce_op
+RED_SUM, RED_MIN, RED_MAX = range(3)
+
+_vp, _u64, _i32, _u32, _i64, _sz = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_int64, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+
+# name -> argtypes (restype is agpu_status = int32 unless listed in _RESTYPES)
+SIGNATURES = {
+    "agpu_abi_version": [],
+    "agpu_last_error": [],
+    "agpu_build_info": [],
+    "agpu_dtype_size": [_i32],
+    "agpu_bitmap_bytes": [_u64],
+    "agpu_device_count": [C.POINTER(_i32)],
+    "agpu_device_create": [_i32, _pp],
+    "agpu_device_destroy": [_vp],
+    "agpu_device_sync": [_vp],
+    "agpu_device_name": [_vp, C.c_char_p, _sz],
+    "agpu_device_ordinal": [_vp, C.POINTER(_i32)],
+    "agpu_device_mem_info": [_vp, C.POINTER(_u64), C.POINTER(_u64)],
+    "agpu_malloc": [_vp, _sz, _i32, _pp],
+    "agpu_free": [_vp, _vp],
+    "agpu_upload": [_vp, _vp, _vp, _sz],
+    "agpu_download": [_vp, _vp, _vp, _sz],
+    "agpu_copy": [_vp, _vp, _vp, _sz],
+    "agpu_memset": [_vp, _vp, _i32, _sz],
+    "agpu_pipeline_create": [_vp, _pp],
+    "agpu_pipeline_wrap_stream": [_vp, _vp, _pp],
+    "agpu_pipeline_finish": [_vp],
+    "agpu_pipeline_sync": [_vp],
+    "agpu_pipeline_destroy": [_vp],
+    "agpu_pipeline_device": [_vp, _pp],
+    "agpu_pipeline_stream": [_vp, _pp],
+    "agpu_pipeline_begin_capture": [_vp],
+    "agpu_pipeline_end_capture": [_vp, _pp],
+    "agpu_graph_launch": [_vp, _vp],
+    "agpu_graph_destroy": [_vp],
+    "agpu_event_create": [_vp, _pp],
+    "agpu_event_record": [_vp, _vp],
+    "agpu_event_elapsed_ms": [_vp, _vp, C.POINTER(C.c_float)],
+    "agpu_event_destroy": [_vp],
+    "agpu_set_tuning": [C.c_char_p, _i64],
+    "agpu_get_tuning": [C.c_char_p, C.POINTER(_i64)],
+    "agpu_binary": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
+    "agpu_scalar": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
+    "agpu_unary": [_vp, _i32, _i32, _vp, _vp, _u64],
+    "agpu_cast": [_vp, _i32, _i32, _vp, _vp, _u64],
+    "agpu_broadcast": [_vp, _i32, _u32, _vp, _u64],
+    "agpu_broadcast_from_device": [_vp, _i32, _vp, _vp, _u64],
+    "agpu_compare": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
+    "agpu_compare_validity": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u64],
+    "agpu_bitmap_binary": [_vp, _i32, _vp, _vp, _vp, _u64],
+    "agpu_bitmap_not": [_vp, _vp, _vp, _u64],
+    "agpu_bitmap_popcount": [_vp, _vp, _u64, _vp],
+    "agpu_bitmap_any": [_vp, _vp, _u64, _vp],
+    "agpu_bitmap_merge_validity": [_vp, _vp, _vp, _vp, _vp, _vp, _u64],
+    "agpu_reduce": [_vp, _i32, _i32, _vp, _vp, _u64, _vp],
+    "agpu_reduce_sum_f64": [_vp, _vp, _vp, _u64, _vp],
+    "agpu_take": [_vp, _i32, _vp, _u64, _vp, _vp, _u64],
+    "agpu_take_bits": [_vp, _vp, _u64, _vp, _vp, _u64],
+    "agpu_put": [_vp, _i32, _vp, _vp, _vp, _vp, _u64],
+    "agpu_put_bits": [_vp, _vp, _vp, _vp, _vp, _u64],
+    "agpu_merge": [_vp, _i32, _vp, _vp, _vp, _vp, _u64],
+    "agpu_merge_bits": [_vp, _vp, _vp, _vp, _vp, _u64],
+    "agpu_index_max": [_vp, _vp, _u64, _vp],
+    "agpu_launch_by_name": [_vp, C.c_char_p, C.c_char_p, _pp, _i32, _vp, _u64],
+    "agpu_synth_f32": [_vp, _vp, _u64, _u64, _u64, C.c_float, C.c_float],
+    "agpu_synth_i32": [_vp, _vp, _u64, _u64, _u64, _u32],
+    "agpu_synth_u8": [_vp, _vp, _u64, _u64, _u64],
+    "agpu_synth_bits": [_vp, _vp, _u64, _u64, _u64, C.c_double],
+    "agpu_checksum": [_vp, _vp, _u64, _vp],
+}
+_RESTYPES = {
+    "agpu_abi_version": _i32,
+    "agpu_last_error": C.c_char_p,
+    "agpu_build_info": C.c_char_p,
+    "agpu_dtype_size": _sz,
+    "agpu_bitmap_bytes": _sz,
+}
+# functions whose int result is NOT an agpu_status
+_NOT_STATUS = set(_RESTYPES)
+
+
+class ArrowErrorGPU(RuntimeError):
+    """Mirror of `enum ArrowErrorGPU` (crates/array/src/lib.rs:11-14) plus device/runtime failures."""
+
+    def __init__(self, kind: str, message: str, status: int = -1):
+        super().__init__(f"{kind}: {message}")
+        self.kind = kind
+        self.status = status
+
+
+class OperationNotSupported(ArrowErrorGPU):
+    def __init__(self, message, status=ERR_UNSUPPORTED):
+        super().__init__("OperationNotSupported", message, status)
+
+
+class CastingNotSupported(ArrowErrorGPU):
+    def __init__(self, message, status=ERR_UNSUPPORTED):
+        super().__init__("CastingNotSupported", message, status)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libarrow_gpu_hip.so; fail loudly if it was not built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ArrowErrorGPU(
+                "LibraryMissing",
+                f"{LIB_PATH} not found: build it with `make -C arrow_gpu_amd/csrc` — there is no CPU fallback",
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, _i32)
+        _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    return lib().agpu_last_error().decode()
+
+
+def check(status: int, what: str = "") -> None:
+    if status == OK:
+        return
+    msg = last_error()
+    if status == ERR_UNSUPPORTED:
+        raise OperationNotSupported(msg or what, status)
+    kinds = {ERR_SHAPE: "ShapeError", ERR_HIP: "HipError", ERR_ARG: "ArgumentError", ERR_NO_DEVICE: "NoDevice"}
+    raise ArrowErrorGPU(kinds.get(status, "Error"), f"{what}: {msg}", status)
+
+
+def call(name: str, *args) -> None:
+    """Call a status-returning entry point and raise on failure."""
+    check(getattr(lib(), name)(*args), name)

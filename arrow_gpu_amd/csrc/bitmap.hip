@@ -1,0 +1,181 @@
+// bitmap.hip — validity / Boolean bitmap kernels: and/or/xor/not, merge, popcount, any.
+//
+// Replaces crates/logical/compute_shaders/u32/{logical,not,any,countbitones}.wgsl as used by
+// NullBitBufferGpu::merge_null_bit_buffer (crates/array/src/array/null_bit_buffer.rs:168-243 — the validity AND),
+// BooleanArrayGPU's Logical/LogicalContains impls (crates/logical/src/boolean.rs:18-147) and
+// merge_null_buffers_op (crates/routines/src/merge.rs:17-86, routines/compute_shaders/u32/merge_null_buffer.wgsl,
+// bool/merge.wgsl).
+//
+// MI355X design: bitmaps are 1/32 of the column traffic, so these are short HBM-bound streams: 16-byte vector
+// loads/stores per lane, grid-stride; popcount uses v_bcnt on 64-bit words + a wave shuffle reduce + ONE integer
+// atomic per block (integer adds are order-independent ⇒ deterministic).  The reference's 4-dispatch validity merge
+// for `merge` is one fused kernel here.
+#include "common.hpp"
+
+enum { BM_AND = 0, BM_OR = 1, BM_XOR = 2, BM_NOT = 3, BM_SELECT = 4, BM_MERGE_VALIDITY = 5, BM_ANDNOT = 6 };
+
+template <int OP>
+__device__ __forceinline__ uint64_t bm_apply(uint64_t a, uint64_t b, uint64_t c, uint64_t d) {
+  if constexpr (OP == BM_AND) return a & b;
+  else if constexpr (OP == BM_OR) return a | b;
+  else if constexpr (OP == BM_XOR) return a ^ b;
+  else if constexpr (OP == BM_NOT) return ~a;
+  else if constexpr (OP == BM_ANDNOT) return a & ~b;
+  else if constexpr (OP == BM_SELECT) return (a & c) | (b & ~c);          // c = mask
+  else return ((a & c) | (b & ~c)) & d;                                    // d = mask validity
+}
+
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
+// inputs a,b,c,d may be null (treated as all-ones) when NULLABLE
+template <int OP, bool NULLABLE>
+__global__ __launch_bounds__(AGPU_BLOCK) void bitmap_kernel(const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                                           const uint64_t* d, uint64_t* out, uint64_t n_words,
+                                                           int vec_ok) {
+  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  const uint64_t n_pairs = vec_ok ? n_words / 2 : 0;
+  const u64x2 ones = {~0ull, ~0ull};
+  for (uint64_t i = tid; i < n_pairs; i += stride) {
+    u64x2 x = ones, y = ones, z = ones, w = ones;
+    if (!NULLABLE || a) x = reinterpret_cast<const u64x2*>(a)[i];
+    if (OP != BM_NOT && (!NULLABLE || b)) y = reinterpret_cast<const u64x2*>(b)[i];
+    if ((OP == BM_SELECT || OP == BM_MERGE_VALIDITY) && (!NULLABLE || c)) z = reinterpret_cast<const u64x2*>(c)[i];
+    if (OP == BM_MERGE_VALIDITY && (!NULLABLE || d)) w = reinterpret_cast<const u64x2*>(d)[i];
+    u64x2 r = {bm_apply<OP>(x.x, y.x, z.x, w.x), bm_apply<OP>(x.y, y.y, z.y, w.y)};
+    reinterpret_cast<u64x2*>(out)[i] = r;
+  }
+  for (uint64_t i = n_pairs * 2 + tid; i < n_words; i += stride) {
+    const uint64_t x = (!NULLABLE || a) ? a[i] : ~0ull;
+    const uint64_t y = (OP != BM_NOT && (!NULLABLE || b)) ? b[i] : ~0ull;
+    const uint64_t z = ((OP == BM_SELECT || OP == BM_MERGE_VALIDITY) && (!NULLABLE || c)) ? c[i] : ~0ull;
+    const uint64_t w = (OP == BM_MERGE_VALIDITY && (!NULLABLE || d)) ? d[i] : ~0ull;
+    out[i] = bm_apply<OP>(x, y, z, w);
+  }
+}
+
+template <int OP, bool NULLABLE>
+static agpu_status launch_bitmap(agpu_pipeline* p, const void* a, const void* b, const void* c, const void* d,
+                                 void* out, uint64_t n_bits) {
+  AGPU_BIND(p);
+  if (n_bits == 0) return AGPU_OK;
+  AGPU_REQUIRE(out, AGPU_ERR_ARG, "null output");
+  const void* ptrs[5] = {a, b, c, d, out};
+  int vec_ok = 1;
+  for (const void* q : ptrs) {
+    if (!q) continue;
+    AGPU_REQUIRE(aligned_to(q, 8), AGPU_ERR_SHAPE, "bitmaps must be 8-byte aligned");
+    if (!aligned16(q)) vec_ok = 0;
+  }
+  const uint64_t n_words = (n_bits + 63) / 64;
+  const int grid = stream_grid_for(p, (n_words / 2 + AGPU_BLOCK - 1) / AGPU_BLOCK);
+  hipLaunchKernelGGL((bitmap_kernel<OP, NULLABLE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
+                     static_cast<const uint64_t*>(a), static_cast<const uint64_t*>(b), static_cast<const uint64_t*>(c),
+                     static_cast<const uint64_t*>(d), static_cast<uint64_t*>(out), n_words, vec_ok);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- popcount / any over the first n_bits
+template <bool ANY>
+__global__ __launch_bounds__(AGPU_BLOCK) void popcount_kernel(const uint64_t* bits, uint64_t n_bits,
+                                                             unsigned long long* out_count, uint32_t* out_any) {
+  const uint64_t n_full = n_bits / 64;
+  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  uint64_t c = 0;
+  for (uint64_t i = tid; i < n_full; i += stride) {
+    const uint64_t w = bits[i];
+    c += ANY ? (uint64_t)(w != 0) : (uint64_t)__popcll(w);
+  }
+  if (tid == 0 && (n_bits & 63)) {
+    const uint64_t w = bits[n_full] & ((1ull << (n_bits & 63)) - 1ull);
+    c += ANY ? (uint64_t)(w != 0) : (uint64_t)__popcll(w);
+  }
+  // wave reduce (64 lanes), then one atomic per wave-leader via LDS block reduce
+#pragma unroll
+  for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) c += __shfl_down(c, off);
+  __shared__ uint64_t wsum[AGPU_BLOCK / AGPU_WAVE];
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  if (lane == 0) wsum[wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t s = 0;
+    for (int k = 0; k < AGPU_BLOCK / AGPU_WAVE; k++) s += wsum[k];
+    if (ANY) {
+      if (s) atomicOr(out_any, 1u);
+    } else if (s) {
+      atomicAdd(out_count, (unsigned long long)s);
+    }
+  }
+}
+
+// merge_not_selected of routines/compute_shaders/u32/merge_null_buffer.wgsl (only reachable through by_name)
+agpu_status agpu_bitmap_andnot_internal(agpu_pipeline* p, const void* a, const void* b, void* out, uint64_t n_bits) {
+  AGPU_REQUIRE(n_bits == 0 || (a && b), AGPU_ERR_ARG, "null input");
+  return launch_bitmap<BM_ANDNOT, false>(p, a, b, nullptr, nullptr, out, n_bits);
+}
+
+extern "C" {
+
+agpu_status agpu_bitmap_binary(agpu_pipeline* p, agpu_binary_op op, const void* a, const void* b, void* out,
+                               uint64_t n_bits) {
+  AGPU_REQUIRE(n_bits == 0 || (a && b), AGPU_ERR_ARG, "null input");
+  switch (op) {
+    case AGPU_OP_AND: return launch_bitmap<BM_AND, false>(p, a, b, nullptr, nullptr, out, n_bits);
+    case AGPU_OP_OR: return launch_bitmap<BM_OR, false>(p, a, b, nullptr, nullptr, out, n_bits);
+    case AGPU_OP_XOR: return launch_bitmap<BM_XOR, false>(p, a, b, nullptr, nullptr, out, n_bits);
+    default: break;
+  }
+  agpu_set_error("bitmap op %d not supported (and/or/xor only)", (int)op);
+  return AGPU_ERR_UNSUPPORTED;
+}
+
+agpu_status agpu_bitmap_not(agpu_pipeline* p, const void* in, void* out, uint64_t n_bits) {
+  AGPU_REQUIRE(n_bits == 0 || in, AGPU_ERR_ARG, "null input");
+  return launch_bitmap<BM_NOT, false>(p, in, nullptr, nullptr, nullptr, out, n_bits);
+}
+
+agpu_status agpu_merge_bits(agpu_pipeline* p, const void* a, const void* b, const void* mask_bits, void* out,
+                            uint64_t n_bits) {
+  AGPU_REQUIRE(n_bits == 0 || (a && b && mask_bits), AGPU_ERR_ARG, "null input");
+  return launch_bitmap<BM_SELECT, false>(p, a, b, mask_bits, nullptr, out, n_bits);
+}
+
+agpu_status agpu_bitmap_merge_validity(agpu_pipeline* p, const void* va, const void* vb, const void* mask,
+                                       const void* vmask, void* out, uint64_t n_bits) {
+  AGPU_REQUIRE(mask, AGPU_ERR_ARG, "null mask");
+  AGPU_REQUIRE(va || vb || vmask, AGPU_ERR_ARG, "all validity inputs are null: the result is None, nothing to compute");
+  return launch_bitmap<BM_MERGE_VALIDITY, true>(p, va, vb, mask, vmask, out, n_bits);
+}
+
+agpu_status agpu_bitmap_popcount(agpu_pipeline* p, const void* bits, uint64_t n_bits, uint64_t* out_count_dev) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(out_count_dev, AGPU_ERR_ARG, "null output");
+  AGPU_HIP(hipMemsetAsync(out_count_dev, 0, sizeof(uint64_t), p->stream));
+  if (n_bits == 0) return AGPU_OK;
+  AGPU_REQUIRE(bits && aligned_to(bits, 8), AGPU_ERR_SHAPE, "bitmap must be 8-byte aligned");
+  const uint64_t n_words = (n_bits + 63) / 64;
+  const int grid = stream_grid_for(p, (n_words + AGPU_BLOCK * 4 - 1) / (AGPU_BLOCK * 4));
+  hipLaunchKernelGGL((popcount_kernel<false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
+                     static_cast<const uint64_t*>(bits), n_bits, reinterpret_cast<unsigned long long*>(out_count_dev),
+                     (uint32_t*)nullptr);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+agpu_status agpu_bitmap_any(agpu_pipeline* p, const void* bits, uint64_t n_bits, uint32_t* out_any_dev) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(out_any_dev, AGPU_ERR_ARG, "null output");
+  AGPU_HIP(hipMemsetAsync(out_any_dev, 0, sizeof(uint32_t), p->stream));
+  if (n_bits == 0) return AGPU_OK;
+  AGPU_REQUIRE(bits && aligned_to(bits, 8), AGPU_ERR_SHAPE, "bitmap must be 8-byte aligned");
+  const uint64_t n_words = (n_bits + 63) / 64;
+  const int grid = stream_grid_for(p, (n_words + AGPU_BLOCK * 4 - 1) / (AGPU_BLOCK * 4));
+  hipLaunchKernelGGL((popcount_kernel<true>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
+                     static_cast<const uint64_t*>(bits), n_bits, (unsigned long long*)nullptr, out_any_dev);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+// common.hpp — shared internals of libarrow_gpu_hip.so (gfx950 only; no CPU path, no CUDA shims).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/arrow_gpu.h"
+
+#define AGPU_STR2(x) #x
+#define AGPU_STR(x) AGPU_STR2(x)
+
+// ---------------------------------------------------------------- handles
+struct agpu_device {
+  int ordinal;
+  hipDeviceProp_t props;
+  int num_cus;
+};
+
+struct agpu_pipeline {
+  agpu_device* dev;
+  hipStream_t stream;
+  bool owns_stream;
+  bool capturing;
+  // scratch for reductions / popcount partials (allocated on first use, reused; stream-ordered so one per pipeline)
+  void* scratch;
+  size_t scratch_bytes;
+};
+
+struct agpu_event {
+  agpu_device* dev;
+  hipEvent_t ev;
+};
+
+struct agpu_graph {
+  agpu_device* dev;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+// ---------------------------------------------------------------- errors
+void agpu_set_error(const char* fmt, ...);
+
+#define AGPU_HIP(call)                                                                             \
+  do {                                                                                             \
+    hipError_t _e = (call);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      agpu_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__);   \
+      return AGPU_ERR_HIP;                                                                         \
+    }                                                                                              \
+  } while (0)
+
+#define AGPU_REQUIRE(cond, code, msg)              \
+  do {                                             \
+    if (!(cond)) {                                 \
+      agpu_set_error("%s: %s", __func__, msg);     \
+      return code;                                 \
+    }                                              \
+  } while (0)
+
+// post-launch check that does not synchronise
+#define AGPU_LAUNCH_CHECK()                                                          \
+  do {                                                                               \
+    hipError_t _e = hipGetLastError();                                               \
+    if (_e != hipSuccess) {                                                          \
+      agpu_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return AGPU_ERR_HIP;                                                           \
+    }                                                                                \
+  } while (0)
+
+static inline agpu_status agpu_bind(agpu_pipeline* p) {
+  if (!p || !p->dev) {
+    agpu_set_error("null pipeline");
+    return AGPU_ERR_ARG;
+  }
+  AGPU_HIP(hipSetDevice(p->dev->ordinal));
+  return AGPU_OK;
+}
+#define AGPU_BIND(p)                         \
+  do {                                       \
+    agpu_status _s = agpu_bind(p);           \
+    if (_s != AGPU_OK) return _s;            \
+  } while (0)
+
+agpu_status agpu_scratch(agpu_pipeline* p, size_t bytes, void** out);
+
+// ---------------------------------------------------------------- tuning knobs (bench sweeps; see agpu_set_tuning)
+struct agpu_tuning {
+  int64_t stream_grid;    // blocks for streaming kernels (0 = auto: CUs * stream_blocks_per_cu)
+  int64_t stream_bpc;     // blocks per CU when stream_grid == 0
+  int64_t stream_unroll;  // 16-byte vectors in flight per lane per array: 1, 2, 4 or 8
+  int64_t stream_nt;      // bit0: nontemporal loads, bit1: nontemporal stores
+  int64_t cmp_variant;    // 0 = ballot (dword loads), 1 = vector loads + nibble shuffle
+  int64_t reduce_grid;    // blocks for reductions (0 = auto)
+};
+extern agpu_tuning g_tune;
+
+static inline int stream_grid_for(const agpu_pipeline* p, uint64_t tiles) {
+  int64_t g = g_tune.stream_grid > 0 ? g_tune.stream_grid : (int64_t)p->dev->num_cus * g_tune.stream_bpc;
+  if ((uint64_t)g > tiles) g = (int64_t)tiles;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------- device helpers
+#define AGPU_BLOCK 256
+#define AGPU_WAVE 64
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+#ifdef __HIPCC__
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT, typename V>
+__device__ __forceinline__ V ld_vec(const V* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void st_vec(V* p, V v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t row_hash_dev(uint64_t seed, uint64_t row) {
+  return splitmix64_dev(seed ^ (row * 0x9E3779B97F4A7C15ull));
+}
+#endif

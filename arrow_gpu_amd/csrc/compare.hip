@@ -1,0 +1,236 @@
+// compare.hip — compare → LSB-first packed bitmap, optionally fused with the validity AND.
+//
+// Replaces crates/compare/compute_shaders/{f32,i32,u32,u16,i16,u8,i8}/cmp.wgsl (entry points gt gteq lt lteq eq:
+// one invocation per element, atomicOr into 8 workgroup words, barrier, lanes gid%32==0 store) and the host step
+// that follows it, NullBitBufferGpu::merge_null_bit_buffer_op (crates/compare/src/lib.rs:85-111,
+// crates/array/src/array/null_bit_buffer.rs:206-243).
+//
+// MI355X design (HBM-bound: 8 B in + 1 bit out per row for 32-bit types, +3 bits with validity):
+//   variant 0 "ballot"  (32-bit types): lane r-th load covers element e0 + r*64 + lane, so `__ballot(pred)` IS the
+//       output word for those 64 rows — no LDS, no atomics, no barrier.  16 rounds are kept in flight per wave
+//       (16 dword loads per input array per lane), the 16 masks are steered to lanes 0..15 and stored as one
+//       contiguous 128-byte row; the same 16 lanes AND the two validity words.
+//   variant 1 "vector"  (all types; default for sub-word types): lane loads 16-byte vectors (4/8/16 elements),
+//       builds an N-bit mask, and G = 32/N neighbouring lanes OR their shifted masks with xor-shuffles.
+// Bits past n in the last word(s) are written as 0 (the reference leaves them unspecified).
+#include <type_traits>
+
+#include "common.hpp"
+
+template <int OP, typename T>
+__device__ __forceinline__ bool cmp_pred(T x, T y) {
+  if constexpr (OP == AGPU_CMP_GT) return x > y;
+  else if constexpr (OP == AGPU_CMP_GTEQ) return x >= y;
+  else if constexpr (OP == AGPU_CMP_LT) return x < y;
+  else if constexpr (OP == AGPU_CMP_LTEQ) return x <= y;
+  else return x == y;
+}
+
+// one 64-bit output word computed element by element with bounds (tails only)
+template <int OP, typename T>
+__device__ __forceinline__ uint64_t cmp_word_guarded(const T* a, const T* b, uint64_t w, uint64_t n) {
+  uint64_t m = 0;
+  const uint64_t lo = w * 64;
+  for (uint32_t k = 0; k < 64 && lo + k < n; k++) m |= (uint64_t)cmp_pred<OP, T>(a[lo + k], b[lo + k]) << k;
+  return m;
+}
+
+__device__ __forceinline__ uint64_t validity_word(const uint64_t* va, const uint64_t* vb, uint64_t w) {
+  const uint64_t x = va ? va[w] : ~0ull;
+  const uint64_t y = vb ? vb[w] : ~0ull;
+  return x & y;
+}
+
+// ---------------------------------------------------------------- variant 0: ballot
+template <typename T, int OP>
+__global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, const T* b, const uint64_t* va,
+                                                               const uint64_t* vb, uint64_t* out, uint64_t* outv,
+                                                               uint64_t n) {
+  constexpr int R = 16;                                   // rounds per wave tile → 16 output u64 words
+  constexpr uint64_t WAVE_TILE = (uint64_t)AGPU_WAVE * R;  // 1024 rows
+  constexpr uint64_t TILE = WAVE_TILE * (AGPU_BLOCK / AGPU_WAVE);
+  const uint64_t ntiles = n / TILE;
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
+  const uint32_t wave = threadIdx.x / AGPU_WAVE;
+  const bool do_v = outv != nullptr;
+
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t e0 = t * TILE + wave * WAVE_TILE;
+    const uint64_t w0 = e0 / 64;
+    T xa[R], xb[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      xa[r] = a[e0 + (uint64_t)r * AGPU_WAVE + lane];
+      xb[r] = b[e0 + (uint64_t)r * AGPU_WAVE + lane];
+    }
+    uint64_t vword = 0;
+    if (do_v && lane < R) vword = validity_word(va, vb, w0 + lane);
+    uint64_t word = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const uint64_t m = __ballot(cmp_pred<OP, T>(xa[r], xb[r]));
+      if (lane == (uint32_t)r) word = m;
+    }
+    if (lane < R) {
+      out[w0 + lane] = word;
+      if (do_v) outv[w0 + lane] = vword;
+    }
+  }
+  if (blockIdx.x == ntiles % gridDim.x) {  // < TILE rows left: one guarded word per thread
+    const uint64_t nwords = (n + 63) / 64;
+    for (uint64_t w = ntiles * TILE / 64 + threadIdx.x; w < nwords; w += AGPU_BLOCK) {
+      out[w] = cmp_word_guarded<OP, T>(a, b, w, n);
+      if (do_v) outv[w] = validity_word(va, vb, w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- variant 1: 16-byte vector loads + lane-group OR
+template <typename T, int N>
+struct CmpPack {
+  T v[N];
+};
+
+template <typename T, int OP, int U>
+__global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T* b, const uint32_t* va,
+                                                            const uint32_t* vb, uint32_t* out, uint32_t* outv,
+                                                            uint64_t n) {
+  constexpr int N = 16 / sizeof(T);  // rows per lane per vector: 4, 8 or 16
+  constexpr int G = 32 / N;          // lanes per 32-bit output word: 8, 4 or 2
+  constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;
+  constexpr uint64_t TILE = TILE_PACKS * N;
+  const uint64_t ntiles = n / TILE;
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
+  const bool do_v = outv != nullptr;
+
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
+    CmpPack<T, N> xa[U], xb[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint64_t pk = p0 + (uint64_t)u * AGPU_BLOCK;
+      xa[u] = __builtin_bit_cast(CmpPack<T, N>, *reinterpret_cast<const u32x4*>(a + pk * N));
+      xb[u] = __builtin_bit_cast(CmpPack<T, N>, *reinterpret_cast<const u32x4*>(b + pk * N));
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint64_t pk = p0 + (uint64_t)u * AGPU_BLOCK;
+      uint32_t m = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++) m |= (uint32_t)cmp_pred<OP, T>(xa[u].v[k], xb[u].v[k]) << k;
+      uint32_t v = m << (N * (lane % G));
+#pragma unroll
+      for (int s = 1; s < G; s <<= 1) v |= (uint32_t)__shfl_xor((int)v, s);
+      if (lane % G == 0) {
+        const uint64_t w = pk / G;
+        out[w] = v;
+        if (do_v) outv[w] = (va ? va[w] : ~0u) & (vb ? vb[w] : ~0u);
+      }
+    }
+  }
+  if (blockIdx.x == ntiles % gridDim.x) {
+    const uint64_t nwords = (n + 63) / 64;  // 64-bit granules so the 8-byte padded bitmap is fully written
+    const uint64_t* va64 = reinterpret_cast<const uint64_t*>(va);
+    const uint64_t* vb64 = reinterpret_cast<const uint64_t*>(vb);
+    for (uint64_t w = ntiles * TILE / 64 + threadIdx.x; w < nwords; w += AGPU_BLOCK) {
+      reinterpret_cast<uint64_t*>(out)[w] = cmp_word_guarded<OP, T>(a, b, w, n);
+      if (do_v) reinterpret_cast<uint64_t*>(outv)[w] = validity_word(va64, vb64, w);
+    }
+  }
+}
+
+// element-granular fallback (inputs not 16-byte aligned): one 64-bit word per thread
+template <typename T, int OP>
+__global__ __launch_bounds__(AGPU_BLOCK) void cmp_word_kernel(const T* a, const T* b, const uint64_t* va,
+                                                             const uint64_t* vb, uint64_t* out, uint64_t* outv,
+                                                             uint64_t n) {
+  const uint64_t nwords = (n + 63) / 64;
+  for (uint64_t w = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; w < nwords; w += (uint64_t)gridDim.x * AGPU_BLOCK) {
+    out[w] = cmp_word_guarded<OP, T>(a, b, w, n);
+    if (outv) outv[w] = validity_word(va, vb, w);
+  }
+}
+
+template <typename T, int OP>
+static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, const void* va, const void* vb,
+                              void* out, void* outv, uint64_t n) {
+  const T* pa = static_cast<const T*>(a);
+  const T* pb = static_cast<const T*>(b);
+  constexpr int U = 4;
+  const bool use_ballot = sizeof(T) == 4 && g_tune.cmp_variant == 0;
+  if (use_ballot) {
+    const uint64_t ntiles = n / (1024 * (AGPU_BLOCK / AGPU_WAVE));
+    const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
+    hipLaunchKernelGGL((cmp_ballot_kernel<T, OP>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb,
+                       static_cast<const uint64_t*>(va), static_cast<const uint64_t*>(vb), static_cast<uint64_t*>(out),
+                       static_cast<uint64_t*>(outv), n);
+  } else if (aligned16(a) && aligned16(b)) {
+    constexpr int N = 16 / sizeof(T);
+    const uint64_t ntiles = n / ((uint64_t)AGPU_BLOCK * U * N);
+    const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
+    hipLaunchKernelGGL((cmp_vec_kernel<T, OP, U>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb,
+                       static_cast<const uint32_t*>(va), static_cast<const uint32_t*>(vb), static_cast<uint32_t*>(out),
+                       static_cast<uint32_t*>(outv), n);
+  } else {
+    const uint64_t nwords = (n + 63) / 64;
+    const int grid = stream_grid_for(p, (nwords + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL((cmp_word_kernel<T, OP>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb,
+                       static_cast<const uint64_t*>(va), static_cast<const uint64_t*>(vb), static_cast<uint64_t*>(out),
+                       static_cast<uint64_t*>(outv), n);
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+template <typename T>
+static agpu_status dispatch_cmp_op(agpu_pipeline* p, agpu_cmp_op op, const void* a, const void* b, const void* va,
+                                   const void* vb, void* out, void* outv, uint64_t n) {
+  switch (op) {
+    case AGPU_CMP_GT: return launch_cmp<T, AGPU_CMP_GT>(p, a, b, va, vb, out, outv, n);
+    case AGPU_CMP_GTEQ: return launch_cmp<T, AGPU_CMP_GTEQ>(p, a, b, va, vb, out, outv, n);
+    case AGPU_CMP_LT: return launch_cmp<T, AGPU_CMP_LT>(p, a, b, va, vb, out, outv, n);
+    case AGPU_CMP_LTEQ: return launch_cmp<T, AGPU_CMP_LTEQ>(p, a, b, va, vb, out, outv, n);
+    case AGPU_CMP_EQ: return launch_cmp<T, AGPU_CMP_EQ>(p, a, b, va, vb, out, outv, n);
+    default: break;
+  }
+  agpu_set_error("bad compare op %d", (int)op);
+  return AGPU_ERR_ARG;
+}
+
+static agpu_status compare_impl(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
+                                const void* va, const void* vb, void* out, void* outv, uint64_t n) {
+  AGPU_BIND(p);
+  if (n == 0) return AGPU_OK;
+  AGPU_REQUIRE(a && b && out, AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(aligned_to(out, 8) && (!outv || aligned_to(outv, 8)) && (!va || aligned_to(va, 8)) &&
+                   (!vb || aligned_to(vb, 8)),
+               AGPU_ERR_SHAPE, "bitmaps must be 8-byte aligned");
+  if (!va && !vb) outv = nullptr;  // (None, None) → None [null_bit_buffer.rs:211]
+  AGPU_REQUIRE(!(va || vb) || outv, AGPU_ERR_ARG, "out_validity required when an input validity is given");
+  switch (dtype) {
+    case AGPU_F32: return dispatch_cmp_op<float>(p, op, a, b, va, vb, out, outv, n);
+    case AGPU_I32: case AGPU_DATE32: return dispatch_cmp_op<int32_t>(p, op, a, b, va, vb, out, outv, n);
+    case AGPU_U32: return dispatch_cmp_op<uint32_t>(p, op, a, b, va, vb, out, outv, n);
+    case AGPU_I16: return dispatch_cmp_op<int16_t>(p, op, a, b, va, vb, out, outv, n);
+    case AGPU_U16: return dispatch_cmp_op<uint16_t>(p, op, a, b, va, vb, out, outv, n);
+    case AGPU_I8: return dispatch_cmp_op<int8_t>(p, op, a, b, va, vb, out, outv, n);
+    case AGPU_U8: return dispatch_cmp_op<uint8_t>(p, op, a, b, va, vb, out, outv, n);
+    default: break;
+  }
+  agpu_set_error("dtype %d not supported for compare", (int)dtype);
+  return AGPU_ERR_UNSUPPORTED;
+}
+
+extern "C" {
+
+agpu_status agpu_compare(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
+                         void* out_bits, uint64_t n) {
+  return compare_impl(p, op, dtype, a, b, nullptr, nullptr, out_bits, nullptr, n);
+}
+
+agpu_status agpu_compare_validity(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
+                                  const void* va, const void* vb, void* out_bits, void* out_validity, uint64_t n) {
+  return compare_impl(p, op, dtype, a, b, va, vb, out_bits, out_validity, n);
+}
+
+}  // extern "C"

@@ -1,0 +1,636 @@
+// elementwise.hip — streaming element-wise kernels: binary, scalar, unary, shifts, casts, broadcast.
+//
+// Replaces the one-invocation-per-32-bit-word WGSL entry points of
+//   crates/arithmetic/compute_shaders/{f32,i32,u32,u16}/{array,scalar,neg}.wgsl
+//   crates/compare/compute_shaders/*/min_max.wgsl
+//   crates/logical/compute_shaders/*/{logical,not,shift}.wgsl
+//   crates/math/compute_shaders/{f32/floatunary,f32/floatbinary,i32/unary,i32/binary}.wgsl
+//   crates/trigonometry/compute_shaders/*/{trigonometry,hyperbolic}.wgsl
+//   crates/cast/compute_shaders/**, crates/array/compute_shaders/*/broadcast.wgsl
+// and the launch shape the Rust macros compute (ceil(n/256) workgroups, no tail guard:
+// crates/arithmetic/src/lib.rs:24,67).
+//
+// MI355X design: every kernel is HBM-bound (roofline = 8 TB/s HBM3E; algorithmic bytes per row are listed in
+// DESIGN.md).  Each lane moves 16-byte vectors (global_load/store_dwordx4 = 1 KiB per wave instruction), keeps
+// AGPU_STREAM_U of them per input array in flight before the first use, and the grid is a fixed number of
+// blocks per CU that strides over tiles, so 256 CUs × 8 XCDs stay full without launching millions of blocks.
+// Sub-word columns are read natively as packed bytes/halfwords (the WGSL u8/i8/u16/i16 unpack helpers vanish).
+// No LDS, no MFMA: there is no reuse and no contraction on this path.
+#include <type_traits>
+
+#include "common.hpp"
+
+#ifndef AGPU_STREAM_U
+#define AGPU_STREAM_U 4  // 16-byte vectors in flight per lane per input array (measured best: profiles/)
+#endif
+#ifndef AGPU_STREAM_NT
+#define AGPU_STREAM_NT 0  // bit0 nontemporal loads, bit1 nontemporal stores
+#endif
+
+enum { MODE_UNARY = 0, MODE_BINARY = 1, MODE_SCALAR = 2 };
+
+template <typename T, int N>
+struct PackN {
+  T v[N];
+};
+template <int B> struct RawBytes;
+template <> struct RawBytes<16> { typedef u32x4 type; };
+template <> struct RawBytes<8> { typedef u32x2 type; };
+template <> struct RawBytes<4> { typedef uint32_t type; };
+
+template <bool NT, typename T, int N>
+__device__ __forceinline__ PackN<T, N> load_pack(const T* p) {
+  typedef typename RawBytes<sizeof(T) * N>::type R;
+  R r = ld_vec<NT>(reinterpret_cast<const R*>(p));
+  return __builtin_bit_cast(PackN<T, N>, r);
+}
+template <bool NT, typename T, int N>
+__device__ __forceinline__ void store_pack(T* p, const PackN<T, N>& v) {
+  typedef typename RawBytes<sizeof(T) * N>::type R;
+  st_vec<NT>(reinterpret_cast<R*>(p), __builtin_bit_cast(R, v));
+}
+
+// ---------------------------------------------------------------- scalar semantics (mirrors oracle/agpu_oracle.c)
+template <typename T> using U_of = typename std::make_unsigned<T>::type;
+
+__device__ __forceinline__ float f32_max_dev(float a, float b) {  // NaN-ignoring, -0 < +0 [compare/src/f32.rs:260-352]
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == b) return __builtin_signbit(a) ? b : a;
+  return a > b ? a : b;
+}
+__device__ __forceinline__ float f32_min_dev(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == b) return __builtin_signbit(a) ? a : b;
+  return a < b ? a : b;
+}
+__device__ __forceinline__ int32_t i32_pow_dev(int32_t x, int32_t p) {  // math/compute_shaders/i32/binary.wgsl:13-29
+  if (p >= 0) {
+    uint32_t r = 1, b = (uint32_t)x, e = (uint32_t)p;
+    while (e) {
+      if (e & 1) r *= b;
+      b *= b;
+      e >>= 1;
+    }
+    return (int32_t)r;
+  }
+  if (p == INT32_MIN) return 1;
+  uint32_t k = (uint32_t)(-p);
+  if (x == 0 || x == 1) return 1;
+  if (x == -1) return (k & 1) ? -1 : 1;
+  return 0;
+}
+
+struct OpAdd {
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
+    if constexpr (std::is_floating_point<T>::value) return x + y;
+    else return (T)((U_of<T>)x + (U_of<T>)y);
+  }
+};
+struct OpSub {
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
+    if constexpr (std::is_floating_point<T>::value) return x - y;
+    else return (T)((U_of<T>)x - (U_of<T>)y);
+  }
+};
+struct OpMul {
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
+    if constexpr (std::is_floating_point<T>::value) return x * y;
+    else return (T)((uint32_t)(U_of<T>)x * (uint32_t)(U_of<T>)y);
+  }
+};
+struct OpDiv {  // WGSL: x/0 = x, MIN/-1 = MIN; f32: correctly rounded
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
+    if constexpr (std::is_floating_point<T>::value) return x / y;
+    else if constexpr (std::is_signed<T>::value) {
+      if (y == 0) return x;
+      if (x == INT32_MIN && y == -1) return x;
+      return x / y;
+    } else return y == 0 ? x : x / y;
+  }
+};
+struct OpRem {  // WGSL: x%0 = 0, MIN%-1 = 0; f32: x - y*trunc(x/y), each step rounded
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
+    if constexpr (std::is_floating_point<T>::value) {
+      float q = __fdiv_rn(x, y);
+      float t = truncf(q);
+      float m = __fmul_rn(y, t);
+      return __fsub_rn(x, m);
+    } else if constexpr (std::is_signed<T>::value) {
+      if (y == 0) return 0;
+      if (x == INT32_MIN && y == -1) return 0;
+      return x % y;
+    } else return y == 0 ? 0 : x % y;
+  }
+};
+struct OpMin {
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
+    if constexpr (std::is_floating_point<T>::value) return f32_min_dev(x, y);
+    else return x < y ? x : y;
+  }
+};
+struct OpMax {
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
+    if constexpr (std::is_floating_point<T>::value) return f32_max_dev(x, y);
+    else return x > y ? x : y;
+  }
+};
+struct OpAnd { template <typename T> __device__ static __forceinline__ T ap(T x, T y) { return (T)(x & y); } };
+struct OpOr { template <typename T> __device__ static __forceinline__ T ap(T x, T y) { return (T)(x | y); } };
+struct OpXor { template <typename T> __device__ static __forceinline__ T ap(T x, T y) { return (T)(x ^ y); } };
+struct OpPow {  // f32: NaN for negative/NaN base (math/src/f32.rs:209-271), else powf; i32: closed form of the WGSL loop
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
+    if constexpr (std::is_floating_point<T>::value) {
+      if (x != x || y != y || x < 0.0f || (x == 0.0f && __builtin_signbit(x))) return __builtin_nanf("");
+      return powf(x, y);
+    } else return (T)i32_pow_dev((int32_t)x, (int32_t)y);
+  }
+};
+
+struct UnNeg {
+  template <typename T> __device__ static __forceinline__ T ap(T x, T) {
+    if constexpr (std::is_floating_point<T>::value) return -x;
+    else return (T)((U_of<T>)0 - (U_of<T>)x);
+  }
+};
+struct UnAbs {
+  template <typename T> __device__ static __forceinline__ T ap(T x, T) {
+    if constexpr (std::is_floating_point<T>::value) return fabsf(x);
+    else if constexpr (std::is_signed<T>::value) return x < 0 ? (T)((U_of<T>)0 - (U_of<T>)x) : x;
+    else return x;
+  }
+};
+struct UnNot { template <typename T> __device__ static __forceinline__ T ap(T x, T) { return (T)~x; } };
+struct UnSqrt { __device__ static __forceinline__ float ap(float x, float) { return sqrtf(x); } };
+struct UnCbrt { __device__ static __forceinline__ float ap(float x, float) { return cbrtf(x); } };
+struct UnExp { __device__ static __forceinline__ float ap(float x, float) { return expf(x); } };
+struct UnExp2 { __device__ static __forceinline__ float ap(float x, float) { return exp2f(x); } };
+struct UnLog { __device__ static __forceinline__ float ap(float x, float) { return logf(x); } };
+struct UnLog2 { __device__ static __forceinline__ float ap(float x, float) { return log2f(x); } };
+struct UnSin { __device__ static __forceinline__ float ap(float x, float) { return sinf(x); } };
+struct UnCos { __device__ static __forceinline__ float ap(float x, float) { return cosf(x); } };
+struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { return acosf(x); } };
+struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return sinhf(x); } };
+
+// ---------------------------------------------------------------- same-width streaming kernel
+// out[i] = Op(a[i], b[i] | *b | -) ; lane moves U packs of 16 B per array per iteration; block tile = 256*U packs.
+template <typename T, typename Op, int MODE, int U, int NT>
+__global__ __launch_bounds__(AGPU_BLOCK) void ew_kernel(const T* a, const T* b, T* out, uint64_t n) {
+  constexpr int N = 16 / sizeof(T);
+  constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0;
+  const uint64_t npacks = n / N;
+  const uint64_t tile = (uint64_t)AGPU_BLOCK * U;
+  const uint64_t ntiles = npacks / tile;
+  T sv = T();
+  if constexpr (MODE == MODE_SCALAR) sv = b[0];
+
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t p0 = t * tile + threadIdx.x;
+    PackN<T, N> va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      va[u] = load_pack<NTL, T, N>(a + (p0 + (uint64_t)u * AGPU_BLOCK) * N);
+      if constexpr (MODE == MODE_BINARY) vb[u] = load_pack<NTL, T, N>(b + (p0 + (uint64_t)u * AGPU_BLOCK) * N);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      PackN<T, N> r;
+#pragma unroll
+      for (int k = 0; k < N; k++) r.v[k] = Op::ap(va[u].v[k], MODE == MODE_BINARY ? vb[u].v[k] : sv);
+      store_pack<NTS, T, N>(out + (p0 + (uint64_t)u * AGPU_BLOCK) * N, r);
+    }
+  }
+  // packs past the last full tile, then the < N-element tail: one block, the next owner in the round-robin
+  if (blockIdx.x == ntiles % gridDim.x) {
+    for (uint64_t pk = ntiles * tile + threadIdx.x; pk < npacks; pk += AGPU_BLOCK) {
+      PackN<T, N> x = load_pack<false, T, N>(a + pk * N), y, r;
+      if constexpr (MODE == MODE_BINARY) y = load_pack<false, T, N>(b + pk * N);
+#pragma unroll
+      for (int k = 0; k < N; k++) r.v[k] = Op::ap(x.v[k], MODE == MODE_BINARY ? y.v[k] : sv);
+      store_pack<false, T, N>(out + pk * N, r);
+    }
+    const uint64_t i = npacks * N + threadIdx.x;
+    if (i < n) out[i] = Op::ap(a[i], MODE == MODE_BINARY ? b[i] : sv);
+  }
+}
+
+// element-granular fallback for pointers that are not 16-byte aligned (e.g. odd shard offsets)
+template <typename T, typename Op, int MODE>
+__global__ __launch_bounds__(AGPU_BLOCK) void ew_kernel_unaligned(const T* a, const T* b, T* out, uint64_t n) {
+  T sv = T();
+  if constexpr (MODE == MODE_SCALAR) sv = b[0];
+  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_BLOCK)
+    out[i] = Op::ap(a[i], MODE == MODE_BINARY ? b[i] : sv);
+}
+
+template <typename T, typename Op, int MODE>
+static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, void* out, uint64_t n) {
+  if (n == 0) return AGPU_OK;
+  const T* pa = static_cast<const T*>(a);
+  const T* pb = static_cast<const T*>(b);
+  T* po = static_cast<T*>(out);
+  const bool vec_ok = aligned16(a) && aligned16(out) && (MODE != MODE_BINARY || aligned16(b));
+  if (vec_ok) {
+    constexpr int N = 16 / sizeof(T);
+    const uint64_t ntiles = n / N / ((uint64_t)AGPU_BLOCK * AGPU_STREAM_U);
+    const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
+    hipLaunchKernelGGL((ew_kernel<T, Op, MODE, AGPU_STREAM_U, AGPU_STREAM_NT>), dim3(grid), dim3(AGPU_BLOCK), 0,
+                       p->stream, pa, pb, po, n);
+  } else {
+    const int grid = stream_grid_for(p, (n + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL((ew_kernel_unaligned<T, Op, MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po, n);
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- shifts: lhs T[n], rhs u32[n] (or 1 scalar)
+// value extended to 32 bits, amount mod 32, result truncated to T
+// [logical/compute_shaders/{u32,i32,u16,i16,u8,i8}/shift.wgsl]
+template <typename T, bool LEFT, int MODE>
+__global__ __launch_bounds__(AGPU_BLOCK) void shift_kernel(const T* a, const uint32_t* s, T* out, uint64_t n) {
+  uint32_t sv = 0;
+  if constexpr (MODE == MODE_SCALAR) sv = s[0] & 31u;
+  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_BLOCK) {
+    const uint32_t sh = MODE == MODE_SCALAR ? sv : (s[i] & 31u);
+    const T x = a[i];
+    T r;
+    if constexpr (LEFT) r = (T)((uint32_t)(int32_t)x << sh);
+    else if constexpr (std::is_signed<T>::value) r = (T)((int32_t)x >> sh);
+    else r = (T)((uint32_t)x >> sh);
+    out[i] = r;
+  }
+}
+template <typename T, int MODE>
+static agpu_status launch_shift(agpu_pipeline* p, bool left, const void* a, const void* s, void* out, uint64_t n) {
+  if (n == 0) return AGPU_OK;
+  const int grid = stream_grid_for(p, (n + AGPU_BLOCK - 1) / AGPU_BLOCK);
+  if (left)
+    hipLaunchKernelGGL((shift_kernel<T, true, MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
+                       static_cast<const T*>(a), static_cast<const uint32_t*>(s), static_cast<T*>(out), n);
+  else
+    hipLaunchKernelGGL((shift_kernel<T, false, MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
+                       static_cast<const T*>(a), static_cast<const uint32_t*>(s), static_cast<T*>(out), n);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- dispatch: op × dtype
+template <typename T, int MODE>
+static agpu_status dispatch_int_op(agpu_pipeline* p, agpu_binary_op op, const void* a, const void* b, void* out,
+                                   uint64_t n) {
+  constexpr bool W32 = sizeof(T) == 4;
+  switch (op) {
+    case AGPU_OP_ADD: return launch_ew<T, OpAdd, MODE>(p, a, b, out, n);
+    case AGPU_OP_SUB: return launch_ew<T, OpSub, MODE>(p, a, b, out, n);
+    case AGPU_OP_MUL: return launch_ew<T, OpMul, MODE>(p, a, b, out, n);
+    case AGPU_OP_MIN: return launch_ew<T, OpMin, MODE>(p, a, b, out, n);
+    case AGPU_OP_MAX: return launch_ew<T, OpMax, MODE>(p, a, b, out, n);
+    case AGPU_OP_AND: return launch_ew<T, OpAnd, MODE>(p, a, b, out, n);
+    case AGPU_OP_OR: return launch_ew<T, OpOr, MODE>(p, a, b, out, n);
+    case AGPU_OP_XOR: return launch_ew<T, OpXor, MODE>(p, a, b, out, n);
+    case AGPU_OP_SHL: return launch_shift<T, MODE>(p, true, a, b, out, n);
+    case AGPU_OP_SHR: return launch_shift<T, MODE>(p, false, a, b, out, n);
+    case AGPU_OP_DIV:
+      if constexpr (W32) return launch_ew<T, OpDiv, MODE>(p, a, b, out, n);
+      break;
+    case AGPU_OP_REM:
+      if constexpr (W32) return launch_ew<T, OpRem, MODE>(p, a, b, out, n);
+      break;
+    case AGPU_OP_POW:
+      if constexpr (W32 && std::is_signed<T>::value) return launch_ew<T, OpPow, MODE>(p, a, b, out, n);
+      break;
+    default: break;
+  }
+  agpu_set_error("binary op %d not supported for this integer dtype", (int)op);
+  return AGPU_ERR_UNSUPPORTED;
+}
+
+template <int MODE>
+static agpu_status dispatch_f32_op(agpu_pipeline* p, agpu_binary_op op, const void* a, const void* b, void* out,
+                                   uint64_t n) {
+  switch (op) {
+    case AGPU_OP_ADD: return launch_ew<float, OpAdd, MODE>(p, a, b, out, n);
+    case AGPU_OP_SUB: return launch_ew<float, OpSub, MODE>(p, a, b, out, n);
+    case AGPU_OP_MUL: return launch_ew<float, OpMul, MODE>(p, a, b, out, n);
+    case AGPU_OP_DIV: return launch_ew<float, OpDiv, MODE>(p, a, b, out, n);
+    case AGPU_OP_REM: return launch_ew<float, OpRem, MODE>(p, a, b, out, n);
+    case AGPU_OP_MIN: return launch_ew<float, OpMin, MODE>(p, a, b, out, n);
+    case AGPU_OP_MAX: return launch_ew<float, OpMax, MODE>(p, a, b, out, n);
+    case AGPU_OP_POW: return launch_ew<float, OpPow, MODE>(p, a, b, out, n);
+    default: break;
+  }
+  agpu_set_error("binary op %d not supported for f32", (int)op);
+  return AGPU_ERR_UNSUPPORTED;
+}
+
+template <int MODE>
+static agpu_status dispatch_binary(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, const void* a, const void* b,
+                                   void* out, uint64_t n) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(n == 0 || (a && b && out), AGPU_ERR_ARG, "null pointer");
+  switch (dtype) {
+    case AGPU_F32: return dispatch_f32_op<MODE>(p, op, a, b, out, n);
+    case AGPU_I32: case AGPU_DATE32: return dispatch_int_op<int32_t, MODE>(p, op, a, b, out, n);
+    case AGPU_U32: return dispatch_int_op<uint32_t, MODE>(p, op, a, b, out, n);
+    case AGPU_I16: return dispatch_int_op<int16_t, MODE>(p, op, a, b, out, n);
+    case AGPU_U16: return dispatch_int_op<uint16_t, MODE>(p, op, a, b, out, n);
+    case AGPU_I8: return dispatch_int_op<int8_t, MODE>(p, op, a, b, out, n);
+    case AGPU_U8: return dispatch_int_op<uint8_t, MODE>(p, op, a, b, out, n);
+    default: break;
+  }
+  agpu_set_error("dtype %d not supported for element-wise binary ops", (int)dtype);
+  return AGPU_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------- width-changing kernel (casts, fused int→f32 trig)
+// lane handles N = 16/max(sizeof(TI),sizeof(TO)) elements per step: the wide side moves 16 B/lane, the narrow
+// side N*sizeof bytes (4 or 8) — both sides stay fully coalesced (the reference's cast shaders store with stride 4).
+template <typename TI, typename TO, typename Conv, int U>
+__global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel(const TI* in, TO* out, uint64_t n) {
+  constexpr int N = 16 / (sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
+  const uint64_t npacks = n / N;
+  const uint64_t tile = (uint64_t)AGPU_BLOCK * U;
+  const uint64_t ntiles = npacks / tile;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t p0 = t * tile + threadIdx.x;
+    PackN<TI, N> v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = load_pack<false, TI, N>(in + (p0 + (uint64_t)u * AGPU_BLOCK) * N);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      PackN<TO, N> r;
+#pragma unroll
+      for (int k = 0; k < N; k++) r.v[k] = Conv::ap(v[u].v[k]);
+      store_pack<false, TO, N>(out + (p0 + (uint64_t)u * AGPU_BLOCK) * N, r);
+    }
+  }
+  if (blockIdx.x == ntiles % gridDim.x) {
+    for (uint64_t pk = ntiles * tile + threadIdx.x; pk < npacks; pk += AGPU_BLOCK) {
+      PackN<TI, N> x = load_pack<false, TI, N>(in + pk * N);
+      PackN<TO, N> r;
+#pragma unroll
+      for (int k = 0; k < N; k++) r.v[k] = Conv::ap(x.v[k]);
+      store_pack<false, TO, N>(out + pk * N, r);
+    }
+    const uint64_t i = npacks * N + threadIdx.x;
+    if (i < n) out[i] = Conv::ap(in[i]);
+  }
+}
+template <typename TI, typename TO, typename Conv>
+__global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel_unaligned(const TI* in, TO* out, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_BLOCK)
+    out[i] = Conv::ap(in[i]);
+}
+
+template <typename TI, typename TO, typename Conv>
+static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
+  if (n == 0) return AGPU_OK;
+  constexpr int N = 16 / (sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
+  const TI* pi = static_cast<const TI*>(in);
+  TO* po = static_cast<TO*>(out);
+  if (aligned_to(in, sizeof(TI) * N) && aligned_to(out, sizeof(TO) * N)) {
+    const uint64_t ntiles = n / N / ((uint64_t)AGPU_BLOCK * AGPU_STREAM_U);
+    const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
+    hipLaunchKernelGGL((cvt_kernel<TI, TO, Conv, AGPU_STREAM_U>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, n);
+  } else {
+    const int grid = stream_grid_for(p, (n + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL((cvt_kernel_unaligned<TI, TO, Conv>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, n);
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+template <typename TI, typename TO>
+struct CvtStatic {  // widen by source signedness, then reinterpret [cast/src/i8_cast.rs:72-89]; int→f32 exact
+  __device__ static __forceinline__ TO ap(TI x) { return (TO)x; }
+};
+struct CvtF32ToU8 {  // trunc toward 0, clamp to [0, 2^32-1], NaN→0, then mod 256 [cast/compute_shaders/f32/cast_u8.wgsl]
+  __device__ static __forceinline__ uint8_t ap(float x) {
+    uint32_t u;
+    if (!(x > 0.0f)) u = 0;
+    else if (x >= 4294967296.0f) u = 0xFFFFFFFFu;
+    else u = (uint32_t)x;
+    return (uint8_t)(u & 255u);
+  }
+};
+template <typename TI, typename F>
+struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders/{u8,i8,u16,i16}/*.wgsl]
+  __device__ static __forceinline__ float ap(TI x) { return F::ap((float)x, 0.0f); }
+};
+
+// bool bitmap → f32 [cast/compute_shaders/boolean/cast_f32.wgsl:9-20]: lane expands 4 bits into one 16-byte store
+__global__ __launch_bounds__(AGPU_BLOCK) void bool_to_f32_kernel(const uint32_t* bits, float* out, uint64_t n) {
+  const uint64_t npacks = n / 4;
+  for (uint64_t pk = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; pk < npacks; pk += (uint64_t)gridDim.x * AGPU_BLOCK) {
+    const uint32_t w = bits[pk >> 3] >> ((pk & 7) * 4);
+    f32x4 r = {(w & 1) ? 1.0f : 0.0f, (w & 2) ? 1.0f : 0.0f, (w & 4) ? 1.0f : 0.0f, (w & 8) ? 1.0f : 0.0f};
+    *reinterpret_cast<f32x4*>(out + pk * 4) = r;
+  }
+  if (blockIdx.x == 0) {
+    const uint64_t i = npacks * 4 + threadIdx.x;
+    if (i < n) out[i] = ((bits[i >> 5] >> (i & 31)) & 1) ? 1.0f : 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------- broadcast (store-only)
+__global__ __launch_bounds__(AGPU_BLOCK) void fill_kernel(uint8_t* out, uint32_t pattern, uint64_t bytes) {
+  const uint64_t npacks = bytes / 16;
+  u32x4 v = {pattern, pattern, pattern, pattern};
+  for (uint64_t pk = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; pk < npacks; pk += (uint64_t)gridDim.x * AGPU_BLOCK)
+    *reinterpret_cast<u32x4*>(out + pk * 16) = v;
+  if (blockIdx.x == 0) {
+    const uint64_t i = npacks * 16 + threadIdx.x;
+    if (i < bytes) out[i] = (uint8_t)(pattern >> ((i & 3) * 8));
+  }
+}
+// scalar read from a 1-element device buffer (the reference binds it as a storage buffer)
+template <typename E>
+__global__ __launch_bounds__(AGPU_BLOCK) void fill_from_device_kernel(uint8_t* out, const E* scalar, uint64_t bytes) {
+  const E s = scalar[0];
+  uint32_t pattern;
+  if constexpr (sizeof(E) == 1) pattern = (uint32_t)s * 0x01010101u;
+  else if constexpr (sizeof(E) == 2) pattern = (uint32_t)s * 0x00010001u;
+  else pattern = (uint32_t)s;
+  const uint64_t npacks = bytes / 16;
+  u32x4 v = {pattern, pattern, pattern, pattern};
+  for (uint64_t pk = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; pk < npacks; pk += (uint64_t)gridDim.x * AGPU_BLOCK)
+    *reinterpret_cast<u32x4*>(out + pk * 16) = v;
+  if (blockIdx.x == 0) {
+    const uint64_t i = npacks * 16 + threadIdx.x;
+    if (i < bytes) out[i] = (uint8_t)(pattern >> ((i & 3) * 8));
+  }
+}
+// Boolean broadcast: first n_bits set to `value`, padding bits of the 8-byte-granular bitmap zero
+__global__ __launch_bounds__(AGPU_BLOCK) void fill_bits_kernel(uint32_t* out, uint32_t value, uint64_t n_bits,
+                                                              uint64_t n_words) {
+  for (uint64_t w = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * AGPU_BLOCK) {
+    const uint64_t lo = w * 32;
+    uint32_t m = 0;
+    if (value) {
+      if (lo + 32 <= n_bits) m = 0xFFFFFFFFu;
+      else if (lo < n_bits) m = (1u << (uint32_t)(n_bits - lo)) - 1u;
+    }
+    out[w] = m;
+  }
+}
+
+extern "C" {
+
+agpu_status agpu_binary(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, const void* a, const void* b, void* out,
+                        uint64_t n) {
+  return dispatch_binary<MODE_BINARY>(p, op, dtype, a, b, out, n);
+}
+
+agpu_status agpu_scalar(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, const void* a, const void* scalar,
+                        void* out, uint64_t n) {
+  return dispatch_binary<MODE_SCALAR>(p, op, dtype, a, scalar, out, n);
+}
+
+agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, const void* in, void* out, uint64_t n) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(n == 0 || (in && out), AGPU_ERR_ARG, "null pointer");
+#define UN_F32(OP) return launch_ew<float, OP, MODE_UNARY>(p, in, nullptr, out, n)
+#define UN_INT(T)                                                               \
+  switch (op) {                                                                 \
+    case AGPU_UN_NEG: return launch_ew<T, UnNeg, MODE_UNARY>(p, in, nullptr, out, n); \
+    case AGPU_UN_ABS: return launch_ew<T, UnAbs, MODE_UNARY>(p, in, nullptr, out, n); \
+    case AGPU_UN_NOT: return launch_ew<T, UnNot, MODE_UNARY>(p, in, nullptr, out, n); \
+    default: break;                                                             \
+  }
+#define UN_FUSED(T)                                                                          \
+  switch (op) {                                                                              \
+    case AGPU_UN_SIN: return launch_cvt<T, float, CvtThenF32<T, UnSin>>(p, in, out, n);      \
+    case AGPU_UN_COS: return launch_cvt<T, float, CvtThenF32<T, UnCos>>(p, in, out, n);      \
+    case AGPU_UN_SINH: return launch_cvt<T, float, CvtThenF32<T, UnSinh>>(p, in, out, n);    \
+    default: break;                                                                          \
+  }
+  switch (dtype) {
+    case AGPU_F32:
+      switch (op) {
+        case AGPU_UN_NEG: UN_F32(UnNeg);
+        case AGPU_UN_ABS: UN_F32(UnAbs);
+        case AGPU_UN_SQRT: UN_F32(UnSqrt);
+        case AGPU_UN_CBRT: UN_F32(UnCbrt);
+        case AGPU_UN_EXP: UN_F32(UnExp);
+        case AGPU_UN_EXP2: UN_F32(UnExp2);
+        case AGPU_UN_LOG: UN_F32(UnLog);
+        case AGPU_UN_LOG2: UN_F32(UnLog2);
+        case AGPU_UN_SIN: UN_F32(UnSin);
+        case AGPU_UN_COS: UN_F32(UnCos);
+        case AGPU_UN_ACOS: UN_F32(UnAcos);
+        case AGPU_UN_SINH: UN_F32(UnSinh);
+        default: break;
+      }
+      break;
+    case AGPU_I32: case AGPU_DATE32: UN_INT(int32_t) break;
+    case AGPU_U32: UN_INT(uint32_t) break;
+    case AGPU_I16: UN_FUSED(int16_t) UN_INT(int16_t) break;
+    case AGPU_U16: UN_FUSED(uint16_t) UN_INT(uint16_t) break;
+    case AGPU_I8: UN_FUSED(int8_t) UN_INT(int8_t) break;
+    case AGPU_U8: UN_FUSED(uint8_t) UN_INT(uint8_t) break;
+    default: break;
+  }
+#undef UN_F32
+#undef UN_INT
+#undef UN_FUSED
+  agpu_set_error("unary op %d not supported for dtype %d", (int)op, (int)dtype);
+  return AGPU_ERR_UNSUPPORTED;
+}
+
+agpu_status agpu_cast(agpu_pipeline* p, agpu_dtype from, agpu_dtype to, const void* in, void* out, uint64_t n) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(n == 0 || (in && out), AGPU_ERR_ARG, "null pointer");
+  if (from == AGPU_DATE32) from = AGPU_I32;
+  if (to == AGPU_DATE32) to = AGPU_I32;
+  if (from == AGPU_BOOL && to == AGPU_F32) {
+    if (n == 0) return AGPU_OK;
+    AGPU_REQUIRE(aligned_to(in, 4) && aligned16(out), AGPU_ERR_SHAPE, "bool→f32 needs 4-byte aligned bits and 16-byte aligned output");
+    const int grid = stream_grid_for(p, (n / 4 + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL(bool_to_f32_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
+                       static_cast<const uint32_t*>(in), static_cast<float*>(out), n);
+    AGPU_LAUNCH_CHECK();
+    return AGPU_OK;
+  }
+  if (from == AGPU_F32 && to == AGPU_U8) return launch_cvt<float, uint8_t, CvtF32ToU8>(p, in, out, n);
+#define CAST_CASE(F, FT, T, TT) \
+  if (from == F && to == T) return launch_cvt<FT, TT, CvtStatic<FT, TT>>(p, in, out, n)
+  CAST_CASE(AGPU_I8, int8_t, AGPU_U16, uint16_t);
+  CAST_CASE(AGPU_I8, int8_t, AGPU_U32, uint32_t);
+  CAST_CASE(AGPU_I8, int8_t, AGPU_I16, int16_t);
+  CAST_CASE(AGPU_I8, int8_t, AGPU_I32, int32_t);
+  CAST_CASE(AGPU_I8, int8_t, AGPU_F32, float);
+  CAST_CASE(AGPU_I16, int16_t, AGPU_I32, int32_t);
+  CAST_CASE(AGPU_I16, int16_t, AGPU_U32, uint32_t);
+  CAST_CASE(AGPU_I16, int16_t, AGPU_F32, float);
+  CAST_CASE(AGPU_U8, uint8_t, AGPU_U16, uint16_t);
+  CAST_CASE(AGPU_U8, uint8_t, AGPU_U32, uint32_t);
+  CAST_CASE(AGPU_U8, uint8_t, AGPU_I16, int16_t);
+  CAST_CASE(AGPU_U8, uint8_t, AGPU_I32, int32_t);
+  CAST_CASE(AGPU_U8, uint8_t, AGPU_F32, float);
+  CAST_CASE(AGPU_U16, uint16_t, AGPU_U32, uint32_t);
+  CAST_CASE(AGPU_U16, uint16_t, AGPU_I32, int32_t);
+  CAST_CASE(AGPU_U16, uint16_t, AGPU_F32, float);
+#undef CAST_CASE
+  // same-width sign reinterprets are a device copy in the reference [cast/src/lib.rs:69-86]
+  if (from != AGPU_BOOL && to != AGPU_BOOL && from != AGPU_F32 && to != AGPU_F32 &&
+      agpu_dtype_size(from) == agpu_dtype_size(to)) {
+    if (in != out && n) AGPU_HIP(hipMemcpyAsync(out, in, n * agpu_dtype_size(from), hipMemcpyDeviceToDevice, p->stream));
+    return AGPU_OK;
+  }
+  agpu_set_error("Casting not supported for type %d -> %d", (int)from, (int)to);
+  return AGPU_ERR_UNSUPPORTED;
+}
+
+agpu_status agpu_broadcast(agpu_pipeline* p, agpu_dtype dtype, uint32_t value_bits, void* out, uint64_t n) {
+  AGPU_BIND(p);
+  if (n == 0) return AGPU_OK;
+  AGPU_REQUIRE(out, AGPU_ERR_ARG, "null pointer");
+  if (dtype == AGPU_BOOL) {
+    AGPU_REQUIRE(aligned_to(out, 4), AGPU_ERR_SHAPE, "bitmap must be 4-byte aligned");
+    const uint64_t n_words = agpu_bitmap_bytes(n) / 4;
+    const int grid = stream_grid_for(p, (n_words + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL(fill_bits_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<uint32_t*>(out),
+                       value_bits ? 1u : 0u, n, n_words);
+    AGPU_LAUNCH_CHECK();
+    return AGPU_OK;
+  }
+  const size_t w = agpu_dtype_size(dtype);
+  AGPU_REQUIRE(w != 0, AGPU_ERR_UNSUPPORTED, "unsupported dtype");
+  AGPU_REQUIRE(aligned16(out), AGPU_ERR_SHAPE, "broadcast output must be 16-byte aligned");
+  uint32_t pattern = value_bits;
+  if (w == 1) pattern = (value_bits & 0xFFu) * 0x01010101u;
+  else if (w == 2) pattern = (value_bits & 0xFFFFu) * 0x00010001u;
+  const uint64_t bytes = n * w;
+  const int grid = stream_grid_for(p, (bytes / 16 + AGPU_BLOCK - 1) / AGPU_BLOCK);
+  hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<uint8_t*>(out), pattern, bytes);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+agpu_status agpu_broadcast_from_device(agpu_pipeline* p, agpu_dtype dtype, const void* scalar_dev, void* out,
+                                       uint64_t n) {
+  AGPU_BIND(p);
+  if (n == 0) return AGPU_OK;
+  AGPU_REQUIRE(out && scalar_dev, AGPU_ERR_ARG, "null pointer");
+  const size_t w = agpu_dtype_size(dtype);
+  AGPU_REQUIRE(w != 0, AGPU_ERR_UNSUPPORTED, "unsupported dtype");
+  AGPU_REQUIRE(aligned16(out), AGPU_ERR_SHAPE, "broadcast output must be 16-byte aligned");
+  const uint64_t bytes = n * w;
+  const int grid = stream_grid_for(p, (bytes / 16 + AGPU_BLOCK - 1) / AGPU_BLOCK);
+  uint8_t* po = static_cast<uint8_t*>(out);
+  if (w == 4)
+    hipLaunchKernelGGL((fill_from_device_kernel<uint32_t>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, po,
+                       static_cast<const uint32_t*>(scalar_dev), bytes);
+  else if (w == 2)
+    hipLaunchKernelGGL((fill_from_device_kernel<uint16_t>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, po,
+                       static_cast<const uint16_t*>(scalar_dev), bytes);
+  else
+    hipLaunchKernelGGL((fill_from_device_kernel<uint8_t>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, po,
+                       static_cast<const uint8_t*>(scalar_dev), bytes);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+// reduce.hip — whole-column reductions: sum (reference order for f32), min, max, f64-accumulated sum.
+//
+// Replaces crates/arithmetic/compute_shaders/{f32,i32,u32}/aggregate.wgsl ("sum": 256-wide LDS tree with a barrier
+// per step, one dispatch per level) driven by Sum::sum_op (crates/arithmetic/src/aggregate_kernels.rs:24-51).
+// min/max reductions do not exist in the reference (its MinMax is element-wise); they are north_star config 5 and
+// follow Arrow min_max semantics.
+//
+// f32 SUM keeps the reference's summation ORDER so the result is bit-identical to its tree: an adjacent-pair binary
+// tree inside each aligned 256-row block (missing rows count as +0.0), then the same tree over the block sums, level
+// by level.  That tree is associative-free but it IS a perfect binary tree over aligned power-of-two spans, so it
+// maps onto the machine without LDS barriers:
+//   rows 4l..4l+3 of a 256-row block : one 16-byte load per lane, (x0+x1)+(x2+x3) in registers      (levels 1-2)
+//   64 lanes                         : shift-down shuffle adds, offsets 1,2,4..32                     (levels 3-8)
+//   64 consecutive blocks per wave   : block sums parked in lanes 0..63, same 6 shuffle steps          (levels 9-14)
+//   4 waves per workgroup            : (w0+w1)+(w2+w3) through LDS                                     (levels 15-16)
+// so one workgroup retires an aligned 65,536-row span = exactly two of the reference's 256-ary levels, and a tiny
+// single-workgroup kernel finishes the remaining levels over the per-span partials with the reference's own LDS
+// tree.  HBM-bound: 4 B/row, every byte read once.
+#include <type_traits>
+
+#include "common.hpp"
+
+#define SPAN_ROWS 65536u   // rows per workgroup span (256 * 256)
+#define WAVE_ROWS 16384u   // rows per wave inside a span (64 blocks of 256)
+
+__device__ __forceinline__ float wave_tree_sum(float v) {  // lane 0 gets the adjacent-pair tree sum of the 64 lanes
+#pragma unroll
+  for (int off = 1; off < AGPU_WAVE; off <<= 1) v = v + __shfl_down(v, off);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t validity_nibble(const uint8_t* validity, uint64_t row) {  // rows row..row+3, row%4==0
+  return ((uint32_t)validity[row >> 3] >> (row & 4)) & 0xFu;
+}
+
+template <bool GUARD, bool HASV>
+__device__ __forceinline__ float load4_tree(const float* in, const uint8_t* validity, uint64_t row, uint64_t n) {
+  float x0, x1, x2, x3;
+  if constexpr (GUARD) {
+    x0 = row + 0 < n ? in[row + 0] : 0.0f;
+    x1 = row + 1 < n ? in[row + 1] : 0.0f;
+    x2 = row + 2 < n ? in[row + 2] : 0.0f;
+    x3 = row + 3 < n ? in[row + 3] : 0.0f;
+    if constexpr (HASV) {
+      if (row + 0 < n && !((validity[(row + 0) >> 3] >> ((row + 0) & 7)) & 1)) x0 = 0.0f;
+      if (row + 1 < n && !((validity[(row + 1) >> 3] >> ((row + 1) & 7)) & 1)) x1 = 0.0f;
+      if (row + 2 < n && !((validity[(row + 2) >> 3] >> ((row + 2) & 7)) & 1)) x2 = 0.0f;
+      if (row + 3 < n && !((validity[(row + 3) >> 3] >> ((row + 3) & 7)) & 1)) x3 = 0.0f;
+    }
+  } else {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + row);
+    x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w;
+    if constexpr (HASV) {
+      const uint32_t nib = validity_nibble(validity, row);
+      if (!(nib & 1)) x0 = 0.0f;
+      if (!(nib & 2)) x1 = 0.0f;
+      if (!(nib & 4)) x2 = 0.0f;
+      if (!(nib & 8)) x3 = 0.0f;
+    }
+  }
+  return (x0 + x1) + (x2 + x3);
+}
+
+template <bool GUARD, bool HASV>
+__device__ __forceinline__ float span_tree_sum(const float* in, const uint8_t* validity, uint64_t span_base, uint64_t n,
+                                               float* lds) {
+  constexpr int UNR = 8;
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  const uint64_t wave_base = span_base + (uint64_t)wave * WAVE_ROWS;
+  float acc = 0.0f;  // lane j ends up holding the sum of this wave's j-th 256-row block
+  for (int j0 = 0; j0 < AGPU_WAVE; j0 += UNR) {
+    float s[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++)
+      s[u] = load4_tree<GUARD, HASV>(in, validity, wave_base + (uint64_t)(j0 + u) * 256 + lane * 4, n);
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const float tot = wave_tree_sum(s[u]);
+      const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tot)));
+      if (lane == (uint32_t)(j0 + u)) acc = b;
+    }
+  }
+  const float wsum = wave_tree_sum(acc);
+  __syncthreads();
+  if (lane == 0) lds[wave] = wsum;
+  __syncthreads();
+  return (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+template <bool HASV>
+__global__ __launch_bounds__(AGPU_BLOCK) void sum_tree_span_kernel(const float* in, const uint8_t* validity, uint64_t n,
+                                                                  float* partials) {
+  __shared__ float lds[AGPU_BLOCK / AGPU_WAVE];
+  const uint64_t nspans = (n + SPAN_ROWS - 1) / SPAN_ROWS;
+  for (uint64_t sp = blockIdx.x; sp < nspans; sp += gridDim.x) {
+    const uint64_t base = sp * SPAN_ROWS;
+    float r;
+    if (base + SPAN_ROWS <= n) r = span_tree_sum<false, HASV>(in, validity, base, n, lds);
+    else r = span_tree_sum<true, HASV>(in, validity, base, n, lds);
+    if (threadIdx.x == 0) partials[sp] = r;
+  }
+}
+
+// remaining 256-ary levels over m values, exactly the reference's workgroup tree (aggregate.wgsl:21-41); one workgroup
+__global__ __launch_bounds__(AGPU_BLOCK) void sum_tree_finish_kernel(const float* first, const uint8_t* validity,
+                                                                    float* buf0, float* buf1, uint64_t m, float* out,
+                                                                    int at_least_one) {
+  __shared__ float sh[AGPU_BLOCK];
+  const uint32_t tid = threadIdx.x;
+  const float* src = first;
+  float* dst = buf0;
+  int levels = 0;
+  while (m > 1 || (at_least_one && levels == 0)) {
+    const uint64_t groups = (m + 255) / 256;
+    for (uint64_t g = 0; g < groups; g++) {
+      const uint64_t i = g * 256 + tid;
+      float x = i < m ? src[i] : 0.0f;
+      if (levels == 0 && validity && i < m && !((validity[i >> 3] >> (i & 7)) & 1)) x = 0.0f;
+      sh[tid] = x;
+      __syncthreads();
+      for (uint32_t s = 1; s < 256; s *= 2) {
+        const uint32_t idx = 2 * s * tid;
+        if (idx + s < 256) sh[idx] = sh[idx] + sh[idx + s];
+        __syncthreads();
+      }
+      if (tid == 0) dst[g] = sh[0];
+      __syncthreads();
+    }
+    src = dst;
+    dst = (dst == buf0) ? buf1 : buf0;
+    m = groups;
+    levels++;
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = (m == 0) ? 0.0f : src[0];
+}
+
+// ---------------------------------------------------------------- generic two-stage reductions (order-free results)
+struct MinMaxF32 {
+  float r;
+  uint32_t flags;  // bit0: saw a non-NaN value, bit1: saw a NaN
+};
+
+template <typename T> struct RedSumWrap {  // wrapping integer sum [aggregate.wgsl i32/u32]
+  typedef uint32_t Acc;
+  __device__ static Acc identity() { return 0u; }
+  __device__ static Acc load(T x) { return (uint32_t)x; }
+  __device__ static Acc combine(Acc a, Acc b) { return a + b; }
+  __device__ static T finish(Acc a) { return (T)a; }
+  typedef T Out;
+};
+struct RedSumF64 {
+  typedef double Acc;
+  typedef double Out;
+  __device__ static Acc identity() { return 0.0; }
+  __device__ static Acc load(float x) { return (double)x; }
+  __device__ static Acc combine(Acc a, Acc b) { return a + b; }
+  __device__ static Out finish(Acc a) { return a; }
+};
+template <typename T, bool MAX> struct RedMinMaxInt {
+  typedef T Acc;
+  typedef T Out;
+  __device__ static Acc identity() {
+    if constexpr (std::is_signed<T>::value) return MAX ? INT32_MIN : INT32_MAX;
+    else return MAX ? 0u : 0xFFFFFFFFu;
+  }
+  __device__ static Acc load(T x) { return x; }
+  __device__ static Acc combine(Acc a, Acc b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); }
+  __device__ static Out finish(Acc a) { return a; }
+};
+template <bool MAX> struct RedMinMaxF32 {  // Arrow min_max: NaN skipped unless every value is NaN; -0 < +0
+  typedef MinMaxF32 Acc;
+  typedef float Out;
+  __device__ static Acc identity() { return MinMaxF32{MAX ? -__builtin_inff() : __builtin_inff(), 0u}; }
+  __device__ static Acc load(float x) {
+    if (x != x) return MinMaxF32{MAX ? -__builtin_inff() : __builtin_inff(), 2u};
+    return MinMaxF32{x, 1u};
+  }
+  __device__ static float pick(float a, float b) {
+    if (a == b) return MAX ? (__builtin_signbit(a) ? b : a) : (__builtin_signbit(a) ? a : b);
+    return MAX ? (a > b ? a : b) : (a < b ? a : b);
+  }
+  __device__ static Acc combine(Acc a, Acc b) { return MinMaxF32{pick(a.r, b.r), a.flags | b.flags}; }
+  __device__ static Out finish(Acc a) {
+    if (!(a.flags & 1u) && (a.flags & 2u)) return __builtin_nanf("");
+    return a.r;
+  }
+};
+
+template <typename A> __device__ __forceinline__ A shfl_down_acc(A v, int off) {
+  if constexpr (std::is_same<A, MinMaxF32>::value) return MinMaxF32{__shfl_down(v.r, off), (uint32_t)__shfl_down((int)v.flags, off)};
+  else if constexpr (std::is_same<A, uint32_t>::value) return (uint32_t)__shfl_down((int)v, off);
+  else return __shfl_down(v, off);
+}
+
+template <typename Red, typename A>
+__device__ __forceinline__ A block_reduce(A v, A* lds) {
+#pragma unroll
+  for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) v = Red::combine(v, shfl_down_acc(v, off));
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  __syncthreads();
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  A r = lds[0];
+  for (int k = 1; k < AGPU_BLOCK / AGPU_WAVE; k++) r = Red::combine(r, lds[k]);
+  return r;
+}
+
+template <typename T, typename Red, int U>
+__global__ __launch_bounds__(AGPU_BLOCK) void reduce_partial_kernel(const T* in, const uint8_t* validity, uint64_t n,
+                                                                   typename Red::Acc* partials, int vec_ok) {
+  typedef typename Red::Acc A;
+  __shared__ A lds[AGPU_BLOCK / AGPU_WAVE];
+  A acc = Red::identity();
+  const uint64_t npacks = vec_ok ? n / 4 : 0;
+  const uint64_t tile = (uint64_t)AGPU_BLOCK * U;
+  const uint64_t ntiles = npacks / tile;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t p0 = t * tile + threadIdx.x;
+    u32x4 v[U];
+    uint32_t nib[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint64_t pk = p0 + (uint64_t)u * AGPU_BLOCK;
+      v[u] = *reinterpret_cast<const u32x4*>(in + pk * 4);
+      nib[u] = validity ? validity_nibble(validity, pk * 4) : 0xFu;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (nib[u] & 1) acc = Red::combine(acc, Red::load(__builtin_bit_cast(T, v[u].x)));
+      if (nib[u] & 2) acc = Red::combine(acc, Red::load(__builtin_bit_cast(T, v[u].y)));
+      if (nib[u] & 4) acc = Red::combine(acc, Red::load(__builtin_bit_cast(T, v[u].z)));
+      if (nib[u] & 8) acc = Red::combine(acc, Red::load(__builtin_bit_cast(T, v[u].w)));
+    }
+  }
+  // rows past the last full tile: element-granular, spread over the whole grid
+  for (uint64_t i = ntiles * tile * 4 + (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * AGPU_BLOCK) {
+    if (!validity || ((validity[i >> 3] >> (i & 7)) & 1)) acc = Red::combine(acc, Red::load(in[i]));
+  }
+  const A r = block_reduce<Red, A>(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+template <typename Red>
+__global__ __launch_bounds__(AGPU_BLOCK) void reduce_finish_kernel(const typename Red::Acc* partials, uint32_t m,
+                                                                  typename Red::Out* out) {
+  typedef typename Red::Acc A;
+  __shared__ A lds[AGPU_BLOCK / AGPU_WAVE];
+  A acc = Red::identity();
+  for (uint32_t i = threadIdx.x; i < m; i += AGPU_BLOCK) acc = Red::combine(acc, partials[i]);
+  const A r = block_reduce<Red, A>(acc, lds);
+  if (threadIdx.x == 0) out[0] = Red::finish(r);
+}
+
+static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks) {
+  int64_t g = g_tune.reduce_grid > 0 ? g_tune.reduce_grid : (int64_t)p->dev->num_cus * 8;
+  if ((uint64_t)g > work_blocks) g = (int64_t)work_blocks;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename T, typename Red>
+static agpu_status launch_reduce(agpu_pipeline* p, const void* in, const void* validity, uint64_t n, void* out) {
+  typedef typename Red::Acc A;
+  constexpr int U = 4;
+  const int grid = reduce_grid_for(p, (n / 4 + (uint64_t)AGPU_BLOCK * U - 1) / ((uint64_t)AGPU_BLOCK * U));
+  void* scratch = nullptr;
+  agpu_status st = agpu_scratch(p, sizeof(A) * (size_t)grid, &scratch);
+  if (st != AGPU_OK) return st;
+  hipLaunchKernelGGL((reduce_partial_kernel<T, Red, U>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
+                     static_cast<const T*>(in), static_cast<const uint8_t*>(validity), n, static_cast<A*>(scratch),
+                     aligned16(in) ? 1 : 0);
+  AGPU_LAUNCH_CHECK();
+  hipLaunchKernelGGL((reduce_finish_kernel<Red>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream,
+                     static_cast<const A*>(scratch), (uint32_t)grid, static_cast<typename Red::Out*>(out));
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const uint8_t* validity, uint64_t n,
+                                       float* out) {
+  const uint64_t nspans = (n + SPAN_ROWS - 1) / SPAN_ROWS;
+  // scratch: partials[nspans] + two ping-pong buffers for the finishing levels
+  const size_t level_cap = (size_t)((nspans + 255) / 256 + 1);
+  const size_t floats = (size_t)nspans + 2 * level_cap + 8;
+  void* scratch = nullptr;
+  agpu_status st = agpu_scratch(p, floats * sizeof(float), &scratch);
+  if (st != AGPU_OK) return st;
+  float* partials = static_cast<float*>(scratch);
+  float* buf0 = partials + nspans + 4;
+  float* buf1 = buf0 + level_cap;
+  if (n <= 256 || !aligned16(in)) {
+    // one (or more) plain reference levels straight from the input; also the unaligned fallback
+    hipLaunchKernelGGL(sum_tree_finish_kernel, dim3(1), dim3(AGPU_BLOCK), 0, p->stream, in, validity, buf0, buf1, n, out, 1);
+    AGPU_LAUNCH_CHECK();
+    return AGPU_OK;
+  }
+  const int grid = reduce_grid_for(p, nspans);
+  if (validity)
+    hipLaunchKernelGGL((sum_tree_span_kernel<true>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, in, validity, n, partials);
+  else
+    hipLaunchKernelGGL((sum_tree_span_kernel<false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, in, validity, n, partials);
+  AGPU_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_tree_finish_kernel, dim3(1), dim3(AGPU_BLOCK), 0, p->stream, (const float*)partials,
+                     (const uint8_t*)nullptr, buf0, buf1, nspans, out, 0);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+extern "C" {
+
+agpu_status agpu_reduce(agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, const void* in, const void* validity,
+                        uint64_t n, void* out_dev) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(out_dev && (n == 0 || in), AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(n == 0 || aligned_to(in, 4), AGPU_ERR_SHAPE, "input must be 4-byte aligned");
+  if (dtype == AGPU_DATE32) dtype = AGPU_I32;
+  if (op == AGPU_RED_SUM) {
+    switch (dtype) {
+      case AGPU_F32:
+        return launch_sum_tree_f32(p, static_cast<const float*>(in), static_cast<const uint8_t*>(validity), n,
+                                   static_cast<float*>(out_dev));
+      case AGPU_I32: return launch_reduce<int32_t, RedSumWrap<int32_t>>(p, in, validity, n, out_dev);
+      case AGPU_U32: return launch_reduce<uint32_t, RedSumWrap<uint32_t>>(p, in, validity, n, out_dev);
+      default: break;
+    }
+  } else if (op == AGPU_RED_MIN) {
+    switch (dtype) {
+      case AGPU_F32: return launch_reduce<float, RedMinMaxF32<false>>(p, in, validity, n, out_dev);
+      case AGPU_I32: return launch_reduce<int32_t, RedMinMaxInt<int32_t, false>>(p, in, validity, n, out_dev);
+      case AGPU_U32: return launch_reduce<uint32_t, RedMinMaxInt<uint32_t, false>>(p, in, validity, n, out_dev);
+      default: break;
+    }
+  } else if (op == AGPU_RED_MAX) {
+    switch (dtype) {
+      case AGPU_F32: return launch_reduce<float, RedMinMaxF32<true>>(p, in, validity, n, out_dev);
+      case AGPU_I32: return launch_reduce<int32_t, RedMinMaxInt<int32_t, true>>(p, in, validity, n, out_dev);
+      case AGPU_U32: return launch_reduce<uint32_t, RedMinMaxInt<uint32_t, true>>(p, in, validity, n, out_dev);
+      default: break;
+    }
+  } else {
+    agpu_set_error("bad reduce op %d", (int)op);
+    return AGPU_ERR_ARG;
+  }
+  agpu_set_error("reduce op %d not supported for dtype %d (32-bit types only, like the reference's Sum32Bit)", (int)op,
+                 (int)dtype);
+  return AGPU_ERR_UNSUPPORTED;
+}
+
+agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* validity, uint64_t n, double* out_dev) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(out_dev && (n == 0 || in), AGPU_ERR_ARG, "null pointer");
+  return launch_reduce<float, RedSumF64>(p, in, validity, n, out_dev);
+}
+
+}  // extern "C"

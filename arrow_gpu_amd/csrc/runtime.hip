@@ -1,0 +1,364 @@
+// runtime.hip — device / buffer / pipeline / event / graph half of the C ABI (include/arrow_gpu.h).
+// Replaces arrow_gpu_array::gpu_utils::{GpuDevice, ArrowComputePipeline, CmpQuery}
+// [ref: crates/array/src/gpu_utils/gpu_device.rs:29-514, compute_pipeline.rs:8-300, compute_query.rs:7-90].
+// A pipeline is a HIP stream: launches are eager and ordered, `finish` is the (already satisfied) submit point.
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void agpu_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+agpu_tuning g_tune = {
+    /*stream_grid*/ 0, /*stream_bpc*/ 8, /*stream_unroll*/ 4, /*stream_nt*/ 0, /*cmp_variant*/ 0, /*reduce_grid*/ 0};
+
+extern "C" {
+
+int32_t agpu_abi_version(void) { return AGPU_ABI_VERSION; }
+const char* agpu_last_error(void) { return g_err; }
+const char* agpu_build_info(void) {
+  return "arrow_gpu_hip gfx950 hip-" AGPU_STR(HIP_VERSION_MAJOR) "." AGPU_STR(HIP_VERSION_MINOR);
+}
+
+size_t agpu_dtype_size(agpu_dtype t) {
+  switch (t) {
+    case AGPU_F32: case AGPU_U32: case AGPU_I32: case AGPU_DATE32: return 4;
+    case AGPU_U16: case AGPU_I16: return 2;
+    case AGPU_U8: case AGPU_I8: return 1;
+    default: return 0;
+  }
+}
+size_t agpu_bitmap_bytes(uint64_t n_bits) { return (size_t)((n_bits + 63) / 64 * 8); }
+
+// ---------------------------------------------------------------- device
+agpu_status agpu_device_count(int32_t* out_count) {
+  AGPU_REQUIRE(out_count, AGPU_ERR_ARG, "null out_count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *out_count = n;
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
+  AGPU_REQUIRE(out_device, AGPU_ERR_ARG, "null out_device");
+  *out_device = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    agpu_set_error("no HIP device visible (%s); this library has no CPU fallback",
+                   e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return AGPU_ERR_NO_DEVICE;
+  }
+  AGPU_REQUIRE(ordinal >= 0 && ordinal < n, AGPU_ERR_ARG, "device ordinal out of range");
+  agpu_device* d = new agpu_device();
+  d->ordinal = ordinal;
+  AGPU_HIP(hipSetDevice(ordinal));
+  AGPU_HIP(hipGetDeviceProperties(&d->props, ordinal));
+  d->num_cus = d->props.multiProcessorCount;
+  if (strncmp(d->props.gcnArchName, "gfx950", 6) != 0) {
+    agpu_set_error("device %d is %s; this library is built for gfx950 only", ordinal, d->props.gcnArchName);
+    delete d;
+    return AGPU_ERR_NO_DEVICE;
+  }
+  *out_device = d;
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_destroy(agpu_device* dev) {
+  delete dev;
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_sync(agpu_device* dev) {
+  AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  AGPU_HIP(hipDeviceSynchronize());
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_name(agpu_device* dev, char* out, size_t out_cap) {
+  AGPU_REQUIRE(dev && out && out_cap, AGPU_ERR_ARG, "null argument");
+  snprintf(out, out_cap, "%s", dev->props.gcnArchName);
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_ordinal(agpu_device* dev, int32_t* out_ordinal) {
+  AGPU_REQUIRE(dev && out_ordinal, AGPU_ERR_ARG, "null argument");
+  *out_ordinal = dev->ordinal;
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_mem_info(agpu_device* dev, uint64_t* out_free, uint64_t* out_total) {
+  AGPU_REQUIRE(dev && out_free && out_total, AGPU_ERR_ARG, "null argument");
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  size_t f = 0, t = 0;
+  AGPU_HIP(hipMemGetInfo(&f, &t));
+  *out_free = f;
+  *out_total = t;
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- buffers
+agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void** out_ptr) {
+  AGPU_REQUIRE(dev && out_ptr, AGPU_ERR_ARG, "null argument");
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  // pad to 16 B so vector tails of sub-word columns and bitmap words are always addressable
+  size_t padded = (bytes + 15) & ~(size_t)15;
+  if (padded == 0) padded = 16;
+  void* p = nullptr;
+  AGPU_HIP(hipMalloc(&p, padded));
+  if (zero_fill) {
+    hipError_t e = hipMemset(p, 0, padded);
+    if (e != hipSuccess) {
+      (void)hipFree(p);
+      agpu_set_error("hipMemset failed: %s", hipGetErrorString(e));
+      return AGPU_ERR_HIP;
+    }
+  }
+  *out_ptr = p;
+  return AGPU_OK;
+}
+
+agpu_status agpu_free(agpu_device* dev, void* ptr) {
+  AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
+  if (!ptr) return AGPU_OK;
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  AGPU_HIP(hipFree(ptr));
+  return AGPU_OK;
+}
+
+agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, size_t bytes) {
+  AGPU_BIND(p);
+  if (!bytes) return AGPU_OK;
+  AGPU_REQUIRE(dst_dev && src_host, AGPU_ERR_ARG, "null pointer");
+  // pageable source: hipMemcpyAsync stages synchronously w.r.t. the host buffer, ordered on the stream
+  AGPU_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, p->stream));
+  AGPU_HIP(hipStreamSynchronize(p->stream));
+  return AGPU_OK;
+}
+
+agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev, size_t bytes) {
+  AGPU_BIND(p);
+  if (!bytes) {
+    AGPU_HIP(hipStreamSynchronize(p->stream));
+    return AGPU_OK;
+  }
+  AGPU_REQUIRE(dst_host && src_dev, AGPU_ERR_ARG, "null pointer");
+  AGPU_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));
+  AGPU_HIP(hipStreamSynchronize(p->stream));
+  return AGPU_OK;
+}
+
+agpu_status agpu_copy(agpu_pipeline* p, void* dst_dev, const void* src_dev, size_t bytes) {
+  AGPU_BIND(p);
+  if (!bytes) return AGPU_OK;
+  AGPU_REQUIRE(dst_dev && src_dev, AGPU_ERR_ARG, "null pointer");
+  AGPU_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, p->stream));
+  return AGPU_OK;
+}
+
+agpu_status agpu_memset(agpu_pipeline* p, void* dst_dev, int32_t byte_value, size_t bytes) {
+  AGPU_BIND(p);
+  if (!bytes) return AGPU_OK;
+  AGPU_REQUIRE(dst_dev, AGPU_ERR_ARG, "null pointer");
+  AGPU_HIP(hipMemsetAsync(dst_dev, byte_value, bytes, p->stream));
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- pipeline
+static agpu_status pipeline_new(agpu_device* dev, hipStream_t s, bool owns, agpu_pipeline** out) {
+  agpu_pipeline* p = new agpu_pipeline();
+  p->dev = dev;
+  p->stream = s;
+  p->owns_stream = owns;
+  p->capturing = false;
+  p->scratch = nullptr;
+  p->scratch_bytes = 0;
+  *out = p;
+  return AGPU_OK;
+}
+
+agpu_status agpu_pipeline_create(agpu_device* dev, agpu_pipeline** out_pipeline) {
+  AGPU_REQUIRE(dev && out_pipeline, AGPU_ERR_ARG, "null argument");
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  hipStream_t s;
+  AGPU_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  return pipeline_new(dev, s, true, out_pipeline);
+}
+
+agpu_status agpu_pipeline_wrap_stream(agpu_device* dev, void* hip_stream, agpu_pipeline** out_pipeline) {
+  AGPU_REQUIRE(dev && out_pipeline, AGPU_ERR_ARG, "null argument");
+  return pipeline_new(dev, reinterpret_cast<hipStream_t>(hip_stream), false, out_pipeline);
+}
+
+agpu_status agpu_pipeline_finish(agpu_pipeline* p) {
+  AGPU_REQUIRE(p, AGPU_ERR_ARG, "null pipeline");
+  return AGPU_OK;  // everything recorded so far is already enqueued in order; like the reference, do not wait
+}
+
+agpu_status agpu_pipeline_sync(agpu_pipeline* p) {
+  AGPU_BIND(p);
+  AGPU_HIP(hipStreamSynchronize(p->stream));
+  return AGPU_OK;
+}
+
+agpu_status agpu_pipeline_destroy(agpu_pipeline* p) {
+  if (!p) return AGPU_OK;
+  (void)hipSetDevice(p->dev->ordinal);
+  if (p->scratch) {
+    (void)hipStreamSynchronize(p->stream);
+    (void)hipFree(p->scratch);
+  }
+  if (p->owns_stream) (void)hipStreamDestroy(p->stream);
+  delete p;
+  return AGPU_OK;
+}
+
+agpu_status agpu_pipeline_device(agpu_pipeline* p, agpu_device** out_device) {
+  AGPU_REQUIRE(p && out_device, AGPU_ERR_ARG, "null argument");
+  *out_device = p->dev;
+  return AGPU_OK;
+}
+
+agpu_status agpu_pipeline_stream(agpu_pipeline* p, void** out_hip_stream) {
+  AGPU_REQUIRE(p && out_hip_stream, AGPU_ERR_ARG, "null argument");
+  *out_hip_stream = reinterpret_cast<void*>(p->stream);
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- graphs
+agpu_status agpu_pipeline_begin_capture(agpu_pipeline* p) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "already capturing");
+  AGPU_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+  p->capturing = true;
+  return AGPU_OK;
+}
+
+agpu_status agpu_pipeline_end_capture(agpu_pipeline* p, agpu_graph** out_graph) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(out_graph, AGPU_ERR_ARG, "null out_graph");
+  AGPU_REQUIRE(p->capturing, AGPU_ERR_ARG, "not capturing");
+  p->capturing = false;
+  hipGraph_t g = nullptr;
+  AGPU_HIP(hipStreamEndCapture(p->stream, &g));
+  hipGraphExec_t ex = nullptr;
+  hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    agpu_set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return AGPU_ERR_HIP;
+  }
+  agpu_graph* gr = new agpu_graph();
+  gr->dev = p->dev;
+  gr->graph = g;
+  gr->exec = ex;
+  *out_graph = gr;
+  return AGPU_OK;
+}
+
+agpu_status agpu_graph_launch(agpu_graph* g, agpu_pipeline* p) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(g, AGPU_ERR_ARG, "null graph");
+  AGPU_HIP(hipGraphLaunch(g->exec, p->stream));
+  return AGPU_OK;
+}
+
+agpu_status agpu_graph_destroy(agpu_graph* g) {
+  if (!g) return AGPU_OK;
+  (void)hipSetDevice(g->dev->ordinal);
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- events
+agpu_status agpu_event_create(agpu_device* dev, agpu_event** out_event) {
+  AGPU_REQUIRE(dev && out_event, AGPU_ERR_ARG, "null argument");
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  hipEvent_t ev;
+  AGPU_HIP(hipEventCreate(&ev));
+  agpu_event* e = new agpu_event();
+  e->dev = dev;
+  e->ev = ev;
+  *out_event = e;
+  return AGPU_OK;
+}
+
+agpu_status agpu_event_record(agpu_event* e, agpu_pipeline* p) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(e, AGPU_ERR_ARG, "null event");
+  AGPU_HIP(hipEventRecord(e->ev, p->stream));
+  return AGPU_OK;
+}
+
+agpu_status agpu_event_elapsed_ms(agpu_event* start, agpu_event* stop, float* out_ms) {
+  AGPU_REQUIRE(start && stop && out_ms, AGPU_ERR_ARG, "null argument");
+  AGPU_HIP(hipSetDevice(stop->dev->ordinal));
+  AGPU_HIP(hipEventSynchronize(stop->ev));
+  AGPU_HIP(hipEventElapsedTime(out_ms, start->ev, stop->ev));
+  return AGPU_OK;
+}
+
+agpu_status agpu_event_destroy(agpu_event* e) {
+  if (!e) return AGPU_OK;
+  (void)hipSetDevice(e->dev->ordinal);
+  (void)hipEventDestroy(e->ev);
+  delete e;
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- tuning
+static int64_t* tune_slot(const char* key) {
+  if (!key) return nullptr;
+  if (!strcmp(key, "stream_grid")) return &g_tune.stream_grid;
+  if (!strcmp(key, "stream_bpc")) return &g_tune.stream_bpc;
+  if (!strcmp(key, "stream_unroll")) return &g_tune.stream_unroll;
+  if (!strcmp(key, "stream_nt")) return &g_tune.stream_nt;
+  if (!strcmp(key, "cmp_variant")) return &g_tune.cmp_variant;
+  if (!strcmp(key, "reduce_grid")) return &g_tune.reduce_grid;
+  return nullptr;
+}
+
+agpu_status agpu_set_tuning(const char* key, int64_t value) {
+  int64_t* s = tune_slot(key);
+  AGPU_REQUIRE(s, AGPU_ERR_ARG, "unknown tuning key");
+  *s = value;
+  return AGPU_OK;
+}
+
+agpu_status agpu_get_tuning(const char* key, int64_t* out_value) {
+  int64_t* s = tune_slot(key);
+  AGPU_REQUIRE(s && out_value, AGPU_ERR_ARG, "unknown tuning key");
+  *out_value = *s;
+  return AGPU_OK;
+}
+
+}  // extern "C"
+
+agpu_status agpu_scratch(agpu_pipeline* p, size_t bytes, void** out) {
+  if (p->scratch_bytes < bytes) {
+    AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "scratch growth during graph capture; run the op once before capturing");
+    if (p->scratch) {
+      AGPU_HIP(hipStreamSynchronize(p->stream));
+      AGPU_HIP(hipFree(p->scratch));
+      p->scratch = nullptr;
+      p->scratch_bytes = 0;
+    }
+    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    AGPU_HIP(hipMalloc(&p->scratch, want));
+    p->scratch_bytes = want;
+  }
+  *out = p->scratch;
+  return AGPU_OK;
+}

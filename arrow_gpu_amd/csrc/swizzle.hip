@@ -1,0 +1,267 @@
+// swizzle.hip — take (gather), put (scatter), merge (select by mask) over values and bitmaps.
+//
+// Replaces crates/routines/compute_shaders/{32bit,16bit,8bit,bool}/{take,put,merge}.wgsl and the launch helpers
+// apply_take_op (crates/routines/src/take.rs:9-55), apply_put_op (put.rs:9-56), Swizzle::merge_op
+// (crates/routines/src/lib.rs:82-120), bool take/put (crates/routines/src/bool.rs:15-128).
+// The reference implements take/put for 32-bit values and Boolean only (TAKE_SHADER = "todo!()" for 8/16-bit:
+// crates/routines/src/u8.rs:3-7); here widths 1, 2 and 4 share one template.
+//
+// MI355X design: the index stream and the output stream are coalesced 16-byte accesses; the gather/scatter side is
+// element-granular by nature (each 4-byte access pulls a whole 64/128-byte line), so these kernels are bound by
+// line fetches, not by algorithmic bytes — DESIGN.md reports them honestly against 12/16 B per row.  Several
+// independent gathers per lane are kept in flight.  Bit gathers use the wave ballot exactly like the compare kernel.
+#include "common.hpp"
+
+template <int W> struct ElemOf;
+template <> struct ElemOf<1> { typedef uint8_t type; };
+template <> struct ElemOf<2> { typedef uint16_t type; };
+template <> struct ElemOf<4> { typedef uint32_t type; };
+
+template <typename E, int N> struct OutPack { E v[N]; };
+
+// ---------------------------------------------------------------- take
+template <int W>
+__global__ __launch_bounds__(AGPU_BLOCK) void take_kernel(const typename ElemOf<W>::type* values, const uint32_t* idx,
+                                                         typename ElemOf<W>::type* out, uint64_t n, int vec_ok) {
+  typedef typename ElemOf<W>::type E;
+  constexpr int N = 16 / W;  // output elements per lane (one 16-byte store)
+  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  const uint64_t npacks = vec_ok ? n / N : 0;
+  for (uint64_t pk = tid; pk < npacks; pk += stride) {
+    uint32_t ix[N];
+#pragma unroll
+    for (int q = 0; q < N / 4; q++) {
+      const u32x4 t = *reinterpret_cast<const u32x4*>(idx + pk * N + q * 4);
+      ix[q * 4 + 0] = t.x; ix[q * 4 + 1] = t.y; ix[q * 4 + 2] = t.z; ix[q * 4 + 3] = t.w;
+    }
+    OutPack<E, N> r;
+#pragma unroll
+    for (int k = 0; k < N; k++) r.v[k] = values[ix[k]];
+    *reinterpret_cast<u32x4*>(out + pk * N) = __builtin_bit_cast(u32x4, r);
+  }
+  for (uint64_t i = npacks * N + tid; i < n; i += stride) out[i] = values[idx[i]];
+}
+
+// out bit i = bits[idx[i]]: lane handles one index per round, ballot = 64 output bits
+__global__ __launch_bounds__(AGPU_BLOCK) void take_bits_kernel(const uint32_t* bits, const uint32_t* idx, uint64_t* out,
+                                                              uint64_t n) {
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
+  const uint64_t wave_id = ((uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x) / AGPU_WAVE;
+  const uint64_t n_waves = (uint64_t)gridDim.x * (AGPU_BLOCK / AGPU_WAVE);
+  const uint64_t nwords = (n + 63) / 64;
+  for (uint64_t w = wave_id; w < nwords; w += n_waves) {
+    const uint64_t i = w * 64 + lane;
+    bool bit = false;
+    if (i < n) {
+      const uint32_t ix = idx[i];
+      bit = (bits[ix >> 5] >> (ix & 31)) & 1u;
+    }
+    const uint64_t m = __ballot(bit);
+    if (lane == 0) out[w] = m;
+  }
+}
+
+// ---------------------------------------------------------------- put (in place on dst)
+template <int W>
+__global__ __launch_bounds__(AGPU_BLOCK) void put_kernel(const typename ElemOf<W>::type* src, const uint32_t* src_idx,
+                                                        typename ElemOf<W>::type* dst, const uint32_t* dst_idx,
+                                                        uint64_t n, int vec_ok) {
+  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  const uint64_t npacks = vec_ok ? n / 4 : 0;
+  for (uint64_t pk = tid; pk < npacks; pk += stride) {
+    const u32x4 si = *reinterpret_cast<const u32x4*>(src_idx + pk * 4);
+    const u32x4 di = *reinterpret_cast<const u32x4*>(dst_idx + pk * 4);
+    const auto v0 = src[si.x], v1 = src[si.y], v2 = src[si.z], v3 = src[si.w];
+    dst[di.x] = v0; dst[di.y] = v1; dst[di.z] = v2; dst[di.w] = v3;
+  }
+  for (uint64_t i = npacks * 4 + tid; i < n; i += stride) dst[dst_idx[i]] = src[src_idx[i]];
+}
+
+// bit scatter: clear then set, word atomics like the reference (bool/put.wgsl:17-34)
+__global__ __launch_bounds__(AGPU_BLOCK) void put_bits_kernel(const uint32_t* src, const uint32_t* src_idx, uint32_t* dst,
+                                                             const uint32_t* dst_idx, uint64_t n) {
+  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  for (uint64_t i = tid; i < n; i += stride) {
+    const uint32_t s = src_idx[i], d = dst_idx[i];
+    const uint32_t bit = (src[s >> 5] >> (s & 31)) & 1u;
+    if (bit) atomicOr(&dst[d >> 5], 1u << (d & 31));
+    else atomicAnd(&dst[d >> 5], ~(1u << (d & 31)));
+  }
+}
+
+// ---------------------------------------------------------------- merge: out[i] = mask bit i ? a[i] : b[i]
+template <int W>
+__global__ __launch_bounds__(AGPU_BLOCK) void merge_kernel(const typename ElemOf<W>::type* a,
+                                                          const typename ElemOf<W>::type* b, const uint32_t* mask,
+                                                          typename ElemOf<W>::type* out, uint64_t n, int vec_ok) {
+  typedef typename ElemOf<W>::type E;
+  constexpr int N = 16 / W;  // 4, 8, 16 rows per lane; N divides 32 so a pack's mask bits sit in one word
+  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  const uint64_t npacks = vec_ok ? n / N : 0;
+  for (uint64_t pk = tid; pk < npacks; pk += stride) {
+    const OutPack<E, N> x = __builtin_bit_cast(OutPack<E, N>, *reinterpret_cast<const u32x4*>(a + pk * N));
+    const OutPack<E, N> y = __builtin_bit_cast(OutPack<E, N>, *reinterpret_cast<const u32x4*>(b + pk * N));
+    const uint64_t row = pk * N;
+    const uint32_t m = mask[row >> 5] >> (row & 31);
+    OutPack<E, N> r;
+#pragma unroll
+    for (int k = 0; k < N; k++) r.v[k] = ((m >> k) & 1u) ? x.v[k] : y.v[k];
+    *reinterpret_cast<u32x4*>(out + pk * N) = __builtin_bit_cast(u32x4, r);
+  }
+  for (uint64_t i = npacks * N + tid; i < n; i += stride)
+    out[i] = ((mask[i >> 5] >> (i & 31)) & 1u) ? a[i] : b[i];
+}
+
+__global__ __launch_bounds__(AGPU_BLOCK) void index_max_kernel(const uint32_t* idx, uint64_t n, uint32_t* out) {
+  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  uint32_t m = 0;
+  for (uint64_t i = tid; i < n; i += stride) m = idx[i] > m ? idx[i] : m;
+#pragma unroll
+  for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_down((int)m, off);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & (AGPU_WAVE - 1)) == 0 && m) atomicMax(out, m);
+}
+
+static int gs_grid(const agpu_pipeline* p, uint64_t items) {
+  return stream_grid_for(p, (items + AGPU_BLOCK - 1) / AGPU_BLOCK);
+}
+
+extern "C" {
+
+agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const uint32_t* idx,
+                      void* out, uint64_t n_idx) {
+  AGPU_BIND(p);
+  if (n_idx == 0) return AGPU_OK;
+  AGPU_REQUIRE(values && idx && out, AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
+  const int vec_ok = aligned16(idx) && aligned16(out);
+  const int grid = gs_grid(p, n_idx / (16 / (width > 0 ? width : 1)) + 1);
+  switch (width) {
+    case 4:
+      hipLaunchKernelGGL((take_kernel<4>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(values),
+                         idx, static_cast<uint32_t*>(out), n_idx, vec_ok);
+      break;
+    case 2:
+      hipLaunchKernelGGL((take_kernel<2>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(values),
+                         idx, static_cast<uint16_t*>(out), n_idx, vec_ok);
+      break;
+    case 1:
+      hipLaunchKernelGGL((take_kernel<1>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(values),
+                         idx, static_cast<uint8_t*>(out), n_idx, vec_ok);
+      break;
+    default:
+      agpu_set_error("take: width %d not supported (1, 2, 4)", width);
+      return AGPU_ERR_UNSUPPORTED;
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+agpu_status agpu_take_bits(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits,
+                           uint64_t n_idx) {
+  AGPU_BIND(p);
+  if (n_idx == 0) return AGPU_OK;
+  AGPU_REQUIRE(bits && idx && out_bits, AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(n_bits > 0, AGPU_ERR_SHAPE, "take from an empty bitmap");
+  AGPU_REQUIRE(aligned_to(bits, 4) && aligned_to(out_bits, 8), AGPU_ERR_SHAPE, "bitmap alignment");
+  const uint64_t nwords = (n_idx + 63) / 64;
+  const int grid = stream_grid_for(p, (nwords + 3) / 4);
+  hipLaunchKernelGGL(take_bits_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(bits),
+                     idx, static_cast<uint64_t*>(out_bits), n_idx);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+agpu_status agpu_put(agpu_pipeline* p, int32_t width, const void* src, const uint32_t* src_idx, void* dst,
+                     const uint32_t* dst_idx, uint64_t n) {
+  AGPU_BIND(p);
+  if (n == 0) return AGPU_OK;
+  AGPU_REQUIRE(src && src_idx && dst && dst_idx, AGPU_ERR_ARG, "null pointer");
+  const int vec_ok = aligned16(src_idx) && aligned16(dst_idx);
+  const int grid = gs_grid(p, n / 4 + 1);
+  switch (width) {
+    case 4:
+      hipLaunchKernelGGL((put_kernel<4>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(src),
+                         src_idx, static_cast<uint32_t*>(dst), dst_idx, n, vec_ok);
+      break;
+    case 2:
+      hipLaunchKernelGGL((put_kernel<2>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(src),
+                         src_idx, static_cast<uint16_t*>(dst), dst_idx, n, vec_ok);
+      break;
+    case 1:
+      hipLaunchKernelGGL((put_kernel<1>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(src),
+                         src_idx, static_cast<uint8_t*>(dst), dst_idx, n, vec_ok);
+      break;
+    default:
+      agpu_set_error("put: width %d not supported (1, 2, 4)", width);
+      return AGPU_ERR_UNSUPPORTED;
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+agpu_status agpu_put_bits(agpu_pipeline* p, const void* src_bits, const uint32_t* src_idx, void* dst_bits,
+                          const uint32_t* dst_idx, uint64_t n) {
+  AGPU_BIND(p);
+  if (n == 0) return AGPU_OK;
+  AGPU_REQUIRE(src_bits && src_idx && dst_bits && dst_idx, AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(aligned_to(src_bits, 4) && aligned_to(dst_bits, 4), AGPU_ERR_SHAPE, "bitmap alignment");
+  const int grid = gs_grid(p, n);
+  hipLaunchKernelGGL(put_bits_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(src_bits),
+                     src_idx, static_cast<uint32_t*>(dst_bits), dst_idx, n);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+agpu_status agpu_merge(agpu_pipeline* p, int32_t width, const void* a, const void* b, const void* mask_bits, void* out,
+                       uint64_t n) {
+  AGPU_BIND(p);
+  if (n == 0) return AGPU_OK;
+  AGPU_REQUIRE(a && b && mask_bits && out, AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(aligned_to(mask_bits, 4), AGPU_ERR_SHAPE, "mask bitmap must be 4-byte aligned");
+  const int vec_ok = aligned16(a) && aligned16(b) && aligned16(out);
+  const int grid = gs_grid(p, n / (16 / (width > 0 ? width : 1)) + 1);
+  switch (width) {
+    case 4:
+      hipLaunchKernelGGL((merge_kernel<4>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(a),
+                         static_cast<const uint32_t*>(b), static_cast<const uint32_t*>(mask_bits),
+                         static_cast<uint32_t*>(out), n, vec_ok);
+      break;
+    case 2:
+      hipLaunchKernelGGL((merge_kernel<2>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(a),
+                         static_cast<const uint16_t*>(b), static_cast<const uint32_t*>(mask_bits),
+                         static_cast<uint16_t*>(out), n, vec_ok);
+      break;
+    case 1:
+      hipLaunchKernelGGL((merge_kernel<1>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(a),
+                         static_cast<const uint8_t*>(b), static_cast<const uint32_t*>(mask_bits),
+                         static_cast<uint8_t*>(out), n, vec_ok);
+      break;
+    default:
+      agpu_set_error("merge: width %d not supported (1, 2, 4)", width);
+      return AGPU_ERR_UNSUPPORTED;
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+agpu_status agpu_index_max(agpu_pipeline* p, const uint32_t* idx, uint64_t n, uint32_t* out_max_dev) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(out_max_dev, AGPU_ERR_ARG, "null output");
+  AGPU_HIP(hipMemsetAsync(out_max_dev, 0, sizeof(uint32_t), p->stream));
+  if (n == 0) return AGPU_OK;
+  AGPU_REQUIRE(idx, AGPU_ERR_ARG, "null pointer");
+  const int grid = gs_grid(p, (n + 7) / 8);
+  hipLaunchKernelGGL(index_max_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, idx, n, out_max_dev);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+}  // extern "C"

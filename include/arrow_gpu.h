@@ -1,0 +1,314 @@
+/*
+ * arrow_gpu.h — C ABI of the MI355X-native Arrow compute-kernel library
+ * (libarrow_gpu_hip.so, hand-written HIP kernels built for gfx950).
+ *
+ * This header is the drop-in seam for psvri/arrow-gpu's device runtime:
+ * it replaces `arrow_gpu_array::gpu_utils::{GpuDevice, ArrowComputePipeline}`
+ * and the `compute_shaders/ **.wgsl` entry points they dispatch.  Every entry
+ * point cites the reference interface it replaces as
+ *   [ref: <path under psvri/arrow-gpu>:<lines>].
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw DEVICE pointers (`void*` returned by
+ *     agpu_malloc, or any hipMalloc'ed / torch-owned HBM pointer) and element
+ *     counts.  No C++/torch types cross this boundary.
+ *   - every call returns agpu_status; 0 = AGPU_OK.  Nothing aborts; the text of
+ *     the last failure on the calling thread is agpu_last_error().
+ *   - kernel calls are ASYNCHRONOUS on the pipeline's HIP stream and execute in
+ *     call order (the reference records passes into one wgpu CommandEncoder and
+ *     submits them in order; a HIP stream gives the same ordering eagerly).
+ *     The only blocking calls are agpu_download, agpu_pipeline_sync,
+ *     agpu_device_sync and agpu_event_elapsed_ms.
+ *   - Arrow layout: values are contiguous little-endian; Boolean data and
+ *     validity are LSB-first bitmaps, bit i at byte i/8 mask 1<<(i%8), bit set =
+ *     true/valid [ref: crates/array/src/array/null_bit_buffer.rs:47-61].
+ *     Bitmap buffers handed to kernels must be readable/writable up to the next
+ *     multiple of 8 bytes (agpu_bitmap_bytes(n_bits)); kernels write 0 to the
+ *     padding bits past n_bits unless stated (the reference leaves them
+ *     unspecified).
+ *   - there is NO CPU fallback in this library: without a gfx950 device
+ *     agpu_device_create fails with AGPU_ERR_NO_DEVICE.
+ */
+#ifndef ARROW_GPU_H
+#define ARROW_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGPU_ABI_VERSION 1
+
+typedef int32_t agpu_status;
+enum {
+  AGPU_OK = 0,
+  AGPU_ERR_UNSUPPORTED = 1, /* op/dtype pair the reference panics on ("Operation not supported") */
+  AGPU_ERR_SHAPE = 2,       /* length / alignment / index-range violation */
+  AGPU_ERR_HIP = 3,         /* a HIP runtime call failed; see agpu_last_error() */
+  AGPU_ERR_ARG = 4,         /* null handle / null pointer / bad enum */
+  AGPU_ERR_NO_DEVICE = 5    /* no gfx950 device visible */
+};
+
+/* [ref: crates/array/src/array/mod.rs:40-50  enum ArrowType] */
+typedef enum {
+  AGPU_BOOL = 0,
+  AGPU_F32 = 1,
+  AGPU_U32 = 2,
+  AGPU_U16 = 3,
+  AGPU_U8 = 4,
+  AGPU_I32 = 5,
+  AGPU_I16 = 6,
+  AGPU_I8 = 7,
+  AGPU_DATE32 = 8 /* i32 storage [ref: crates/array/src/array/mod.rs:90] */
+} agpu_dtype;
+
+/* Binary / scalar ops.  [ref: crates/arithmetic/compute_shaders/{f32,i32,u32}/{array,scalar}.wgsl,
+ * crates/compare/compute_shaders/ * /min_max.wgsl, crates/logical/compute_shaders/ * /{logical,shift}.wgsl,
+ * crates/math/compute_shaders/{f32/floatbinary,i32/binary}.wgsl] */
+typedef enum {
+  AGPU_OP_ADD = 0,
+  AGPU_OP_SUB = 1,
+  AGPU_OP_MUL = 2,
+  AGPU_OP_DIV = 3,
+  AGPU_OP_REM = 4,
+  AGPU_OP_MIN = 5,
+  AGPU_OP_MAX = 6,
+  AGPU_OP_AND = 7,
+  AGPU_OP_OR = 8,
+  AGPU_OP_XOR = 9,
+  AGPU_OP_SHL = 10, /* rhs is always a u32 array */
+  AGPU_OP_SHR = 11, /* rhs is always a u32 array; arithmetic for signed types */
+  AGPU_OP_POW = 12
+} agpu_binary_op;
+
+/* Unary ops.  [ref: crates/arithmetic/compute_shaders/f32/neg.wgsl, crates/logical/compute_shaders/ * /not.wgsl,
+ * crates/math/compute_shaders/f32/floatunary.wgsl, crates/math/compute_shaders/i32/unary.wgsl,
+ * crates/trigonometry/compute_shaders/ * /{trigonometry,hyperbolic}.wgsl] */
+typedef enum {
+  AGPU_UN_NEG = 0,
+  AGPU_UN_ABS = 1,
+  AGPU_UN_NOT = 2,
+  AGPU_UN_SQRT = 3,
+  AGPU_UN_CBRT = 4,
+  AGPU_UN_EXP = 5,
+  AGPU_UN_EXP2 = 6,
+  AGPU_UN_LOG = 7,
+  AGPU_UN_LOG2 = 8,
+  AGPU_UN_SIN = 9,   /* for u8/i8/u16/i16 inputs: fused cast+sin, output f32 */
+  AGPU_UN_COS = 10,  /* idem */
+  AGPU_UN_ACOS = 11, /* f32 only */
+  AGPU_UN_SINH = 12  /* for small ints: fused, output f32 */
+} agpu_unary_op;
+
+/* [ref: crates/compare/src/lib.rs:17-21 entry points "gt","gteq","lt","lteq","eq"] */
+typedef enum { AGPU_CMP_GT = 0, AGPU_CMP_GTEQ = 1, AGPU_CMP_LT = 2, AGPU_CMP_LTEQ = 3, AGPU_CMP_EQ = 4 } agpu_cmp_op;
+
+/* Whole-column reductions.  SUM is the reference's `Sum` [ref: crates/arithmetic/src/aggregate_kernels.rs:24-51];
+ * MIN/MAX reductions are new (north_star config 5), Arrow min_max semantics: NaN is ignored unless all NaN. */
+typedef enum { AGPU_RED_SUM = 0, AGPU_RED_MIN = 1, AGPU_RED_MAX = 2 } agpu_reduce_op;
+
+typedef struct agpu_device agpu_device;     /* replaces GpuDevice  [ref: crates/array/src/gpu_utils/gpu_device.rs:29-33] */
+typedef struct agpu_pipeline agpu_pipeline; /* replaces ArrowComputePipeline [ref: crates/array/src/gpu_utils/compute_pipeline.rs:8-12] */
+typedef struct agpu_event agpu_event;       /* replaces CmpQuery timestamps [ref: crates/array/src/gpu_utils/compute_query.rs:7-52] */
+
+/* ---------------------------------------------------------------- misc */
+int32_t agpu_abi_version(void);
+const char* agpu_last_error(void);  /* thread-local, never NULL */
+const char* agpu_build_info(void);  /* e.g. "arrow_gpu_hip gfx950 hip-7.2" */
+size_t agpu_dtype_size(agpu_dtype t); /* bytes per element; 0 for AGPU_BOOL (bit-packed) */
+size_t agpu_bitmap_bytes(uint64_t n_bits); /* ceil(n_bits/64)*8 : allocation size every bitmap argument must have */
+
+/* ---------------------------------------------------------------- device
+ * [ref: GpuDevice::new / from_adapter, crates/array/src/gpu_utils/gpu_device.rs:46-106;
+ *       global GPU_DEVICE, crates/array/src/lib.rs:17] */
+agpu_status agpu_device_count(int32_t* out_count);
+agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device);
+agpu_status agpu_device_destroy(agpu_device* dev);
+agpu_status agpu_device_sync(agpu_device* dev);
+agpu_status agpu_device_name(agpu_device* dev, char* out, size_t out_cap); /* e.g. "gfx950:sramecc+:xnack-" */
+agpu_status agpu_device_ordinal(agpu_device* dev, int32_t* out_ordinal);
+agpu_status agpu_device_mem_info(agpu_device* dev, uint64_t* out_free, uint64_t* out_total);
+
+/* ---------------------------------------------------------------- buffers (raw HBM pointers)
+ * agpu_malloc          [ref: GpuDevice::create_empty_buffer gpu_device.rs:183-192] — zero_fill!=0 reproduces wgpu's
+ *                      zero-initialised buffers; kernels here never rely on it.
+ * agpu_upload          [ref: create_gpu_buffer_with_data gpu_device.rs:171-181, create_scalar_buffer :203-210]
+ * agpu_download        [ref: retrive_data gpu_device.rs:232-265] — blocks until `pipeline` (may be NULL = device sync) drained.
+ * agpu_copy            [ref: clone_buffer(_pass) gpu_device.rs:212-230; ArrowComputePipeline::{clone_buffer,
+ *                      copy_buffer_to_buffer} compute_pipeline.rs:275-299] — ordered on the pipeline's stream. */
+agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void** out_ptr);
+agpu_status agpu_free(agpu_device* dev, void* ptr);
+agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, size_t bytes);
+agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev, size_t bytes);
+agpu_status agpu_copy(agpu_pipeline* p, void* dst_dev, const void* src_dev, size_t bytes);
+agpu_status agpu_memset(agpu_pipeline* p, void* dst_dev, int32_t byte_value, size_t bytes);
+
+/* ---------------------------------------------------------------- pipeline = one HIP stream
+ * [ref: ArrowComputePipeline::new compute_pipeline.rs:15-22; finish :259-273 (submit, no wait)].
+ * One pipeline per host thread; many pipelines may share a device concurrently.
+ * agpu_pipeline_wrap_stream adopts an existing hipStream_t (e.g. torch's current stream); it is not destroyed. */
+agpu_status agpu_pipeline_create(agpu_device* dev, agpu_pipeline** out_pipeline);
+agpu_status agpu_pipeline_wrap_stream(agpu_device* dev, void* hip_stream, agpu_pipeline** out_pipeline);
+agpu_status agpu_pipeline_finish(agpu_pipeline* p); /* submit point: work is already enqueued; does NOT wait */
+agpu_status agpu_pipeline_sync(agpu_pipeline* p);   /* host waits for everything enqueued so far */
+agpu_status agpu_pipeline_destroy(agpu_pipeline* p);
+agpu_status agpu_pipeline_device(agpu_pipeline* p, agpu_device** out_device);
+agpu_status agpu_pipeline_stream(agpu_pipeline* p, void** out_hip_stream);
+
+/* hipGraph capture of a launch-bound op chain (examples/simple.rs-style `*_op` chains).
+ * begin → enqueue ops on p → end (returns a replayable graph) → agpu_graph_launch any number of times. */
+typedef struct agpu_graph agpu_graph;
+agpu_status agpu_pipeline_begin_capture(agpu_pipeline* p);
+agpu_status agpu_pipeline_end_capture(agpu_pipeline* p, agpu_graph** out_graph);
+agpu_status agpu_graph_launch(agpu_graph* g, agpu_pipeline* p);
+agpu_status agpu_graph_destroy(agpu_graph* g);
+
+/* HIP events on the pipeline's own stream [ref: CmpQuery, compute_query.rs:15-75 — 2-slot timestamp query per pass] */
+agpu_status agpu_event_create(agpu_device* dev, agpu_event** out_event);
+agpu_status agpu_event_record(agpu_event* e, agpu_pipeline* p);
+agpu_status agpu_event_elapsed_ms(agpu_event* start, agpu_event* stop, float* out_ms); /* syncs on `stop` */
+agpu_status agpu_event_destroy(agpu_event* e);
+
+/* Launch tuning (bench sweeps; defaults are the measured best).  key ∈ {"stream_grid","stream_unroll","stream_nt",
+ * "cmp_variant","reduce_grid"}; unknown key → AGPU_ERR_ARG. */
+agpu_status agpu_set_tuning(const char* key, int64_t value);
+agpu_status agpu_get_tuning(const char* key, int64_t* out_value);
+
+/* ---------------------------------------------------------------- element-wise kernels
+ * All take element counts `n` (rows).  in/out pointers must be aligned to the element size; 16-byte alignment
+ * selects the vectorised path.  `out` may alias an input exactly (in place), never partially overlap. */
+
+/* out[i] = a[i] op b[i].
+ * [ref: ArrowComputePipeline::apply_binary_function compute_pipeline.rs:68-113 as called by
+ *  impl_arithmetic_array_op! crates/arithmetic/src/lib.rs:54-94 (add_f32/sub_f32/mul_f32/div_f32, add_i32, add_u32),
+ *  apply_function_min_max! crates/compare/src/lib.rs:113-140, Logical crates/logical/src/lib.rs:88-158, MathBinary
+ *  crates/math/src/lib.rs].  Supported: f32 {ADD,SUB,MUL,DIV,REM,MIN,MAX,POW}; i32/u32/date32 {ADD,SUB,MUL,DIV,REM,MIN,MAX,
+ *  AND,OR,XOR,SHL,SHR} (+POW i32); u16/i16/u8/i8 {ADD,SUB,MUL,MIN,MAX,AND,OR,XOR,SHL,SHR}.  For SHL/SHR `b` is u32[n]. */
+agpu_status agpu_binary(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, const void* a, const void* b, void* out,
+                        uint64_t n);
+
+/* out[i] = a[i] op *scalar, `scalar` = DEVICE pointer to a 1-element array of `dtype` (the reference binds a
+ * 1-element storage buffer) [ref: apply_scalar_function compute_pipeline.rs:167-213 as called by impl_arithmetic_op!
+ * crates/arithmetic/src/lib.rs:11-50; entry points f32_add.. i32_rem.. u32_div.. u16_add]. */
+agpu_status agpu_scalar(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, const void* a, const void* scalar,
+                        void* out, uint64_t n);
+
+/* out[i] = op(in[i]).  Output dtype = input dtype, except SIN/COS/SINH on u8/i8/u16/i16 which write f32[n]
+ * (the reference's fused sin_u8-style kernels).
+ * [ref: apply_unary_function compute_pipeline.rs:24-66 as called by Neg arithmetic_kernels.rs:270-319, bitwise_not
+ *  logical/src/lib.rs:135-158, apply_unary_function_op! crates/math/src/lib.rs:138-193 and
+ *  crates/trigonometry/src/lib.rs:85-137]. */
+agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, const void* in, void* out, uint64_t n);
+
+/* out[i] = (to)in[i].  Table = cast_dyn's [ref: crates/cast/src/lib.rs:135-161] plus identity-width sign
+ * reinterprets (memcpy in the reference :69-86).  from=AGPU_BOOL,to=F32: `in` is a bitmap of n bits.
+ * f32→u8: trunc toward 0, clamp to [0,2^32-1], then mod 256; NaN→0 [ref: crates/cast/compute_shaders/f32/cast_u8.wgsl]. */
+agpu_status agpu_cast(agpu_pipeline* p, agpu_dtype from, agpu_dtype to, const void* in, void* out, uint64_t n);
+
+/* out[i] = value (n elements of dtype); `value_bits` holds the scalar's little-endian bytes in its low bits.
+ * [ref: apply_broadcast_function compute_pipeline.rs:215-256; crates/array/compute_shaders/{f32,i32,u32}/broadcast.wgsl]
+ * dtype=AGPU_BOOL fills a bitmap of n bits (padding zero) [ref: boolean_gpu.rs:173-194]. */
+agpu_status agpu_broadcast(agpu_pipeline* p, agpu_dtype dtype, uint32_t value_bits, void* out, uint64_t n);
+/* Same, with the scalar read from a 1-element DEVICE buffer — the literal shape of the reference call
+ * apply_broadcast_function(&scalar_buffer, ...) [ref: crates/array/src/array/f32_gpu.rs:14-37]; not for AGPU_BOOL. */
+agpu_status agpu_broadcast_from_device(agpu_pipeline* p, agpu_dtype dtype, const void* scalar_dev, void* out, uint64_t n);
+
+/* ---------------------------------------------------------------- compare → bitmap
+ * out_bits bit i = a[i] cmp b[i], LSB-first, agpu_bitmap_bytes(n) bytes written, padding bits 0.
+ * [ref: apply_function! crates/compare/src/lib.rs:85-111; crates/compare/compute_shaders/ * /cmp.wgsl
+ *  (atomicOr into workgroup words, lanes gid%32==0 store)]. f32: IEEE compare, NaN ⇒ false. */
+agpu_status agpu_compare(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
+                         void* out_bits, uint64_t n);
+
+/* Fused form of the reference's two steps (compare dispatch + NullBitBufferGpu::merge_null_bit_buffer_op,
+ * [ref: crates/compare/src/lib.rs:98-103, null_bit_buffer.rs:206-243]): also writes out_validity = va & vb.
+ * va / vb may each be NULL (= all valid): both NULL → out_validity untouched (may be NULL); one NULL → copy. */
+agpu_status agpu_compare_validity(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
+                                  const void* va, const void* vb, void* out_bits, void* out_validity, uint64_t n);
+
+/* ---------------------------------------------------------------- bitmaps (Boolean data and validity)
+ * op ∈ {AND, OR, XOR} word-wise over n_bits.  This is NullBitBufferGpu::merge_null_bit_buffer's kernel
+ * [ref: crates/array/src/array/null_bit_buffer.rs:168-204 → crates/logical/compute_shaders/u32/logical.wgsl:13-29]
+ * and BooleanArrayGPU's Logical impl [ref: crates/logical/src/boolean.rs:18-75]. Padding bits: op applied as-is. */
+agpu_status agpu_bitmap_binary(agpu_pipeline* p, agpu_binary_op op, const void* a, const void* b, void* out,
+                               uint64_t n_bits);
+/* out = ~in on every whole word covering n_bits (padding flipped too, like the reference) [ref: u32/not.wgsl:9-13] */
+agpu_status agpu_bitmap_not(agpu_pipeline* p, const void* in, void* out, uint64_t n_bits);
+/* *out_count (device u64) = number of set bits among the first n_bits.  Null counts, `all()`
+ * [ref: crates/logical/src/boolean.rs:120-146 countob + Sum] */
+agpu_status agpu_bitmap_popcount(agpu_pipeline* p, const void* bits, uint64_t n_bits, uint64_t* out_count_dev);
+/* *out_any (device u32) = 1 if any of the first n_bits is set else 0 [ref: boolean.rs:106-118, u32/any.wgsl] */
+agpu_status agpu_bitmap_any(agpu_pipeline* p, const void* bits, uint64_t n_bits, uint32_t* out_any_dev);
+/* merge validity: out = ((va & m) | (vb & ~m)) & vm; va/vb/vm may be NULL (= all ones); all three NULL → AGPU_ERR_ARG.
+ * [ref: merge_null_buffers_op crates/routines/src/merge.rs:17-86, u32/merge_null_buffer.wgsl] */
+agpu_status agpu_bitmap_merge_validity(agpu_pipeline* p, const void* va, const void* vb, const void* mask,
+                                       const void* vmask, void* out, uint64_t n_bits);
+
+/* ---------------------------------------------------------------- reductions
+ * out_dev → 1 element: SUM f32→f32, i32→i32 (wrapping), u32→u32 (wrapping); MIN/MAX → same dtype.
+ * f32 SUM reproduces the reference's summation ORDER bit-exactly: adjacent-pair binary tree inside 256-element
+ * blocks, then recursively over block sums [ref: crates/arithmetic/compute_shaders/f32/aggregate.wgsl:28-37,
+ * aggregate_kernels.rs:26-43]; like the reference it ignores validity when `validity`==NULL.  With a validity
+ * bitmap, null slots contribute the identity (0 / +inf / -inf) — an extension the reference lacks.
+ * agpu_reduce_f64: SUM of f32 accumulated and returned in f64 (used for the multi-GPU final reduce). */
+agpu_status agpu_reduce(agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, const void* in, const void* validity,
+                        uint64_t n, void* out_dev);
+agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* validity, uint64_t n, double* out_dev);
+
+/* ---------------------------------------------------------------- swizzle: take / put / merge
+ * width = bytes per element (1, 2 or 4; the reference implements 4 and Boolean only).
+ * take: out[i] = values[idx[i]], i < n_idx; every idx must be < n_values (checked only by agpu_check_indices).
+ * [ref: apply_take_op crates/routines/src/take.rs:9-55, 32bit/take.wgsl:13-17] */
+agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const uint32_t* idx,
+                      void* out, uint64_t n_idx);
+/* out bit i = bits[idx[i]]  [ref: crates/routines/src/bool.rs:15-46, bool/take.wgsl:13-33] — data and validity */
+agpu_status agpu_take_bits(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits,
+                           uint64_t n_idx);
+/* dst[dst_idx[i]] = src[src_idx[i]] in place; duplicate dst_idx ⇒ unspecified winner
+ * [ref: apply_put_op crates/routines/src/put.rs:9-56, 32bit/put.wgsl:17-23] */
+agpu_status agpu_put(agpu_pipeline* p, int32_t width, const void* src, const uint32_t* src_idx, void* dst,
+                     const uint32_t* dst_idx, uint64_t n);
+/* bit scatter (atomic and/or) [ref: crates/routines/src/bool.rs:48-128, bool/put.wgsl:17-34] */
+agpu_status agpu_put_bits(agpu_pipeline* p, const void* src_bits, const uint32_t* src_idx, void* dst_bits,
+                          const uint32_t* dst_idx, uint64_t n);
+/* out[i] = mask bit i ? a[i] : b[i]  [ref: Swizzle::merge_op crates/routines/src/lib.rs:82-120, {32,16,8}bit/merge.wgsl] */
+agpu_status agpu_merge(agpu_pipeline* p, int32_t width, const void* a, const void* b, const void* mask_bits, void* out,
+                       uint64_t n);
+/* Boolean data merge: out = (a & m) | (b & ~m) [ref: bool/merge.wgsl:17-21] */
+agpu_status agpu_merge_bits(agpu_pipeline* p, const void* a, const void* b, const void* mask_bits, void* out,
+                            uint64_t n_bits);
+/* *out_max (device u32) = max(idx[0..n)) — lets a host wrapper reject out-of-range indices (HIP has no robust access) */
+agpu_status agpu_index_max(agpu_pipeline* p, const uint32_t* idx, uint64_t n, uint32_t* out_max_dev);
+
+/* ---------------------------------------------------------------- reference entry-point names
+ * Keeps the reference's kernel identity for a thin shim: shader_key = the WGSL file's path under crates/ without
+ * "compute_shaders/" and ".wgsl" (e.g. "arithmetic/f32/array", "compare/i32/cmp", "logical/u32/logical"),
+ * entry_point = the @compute fn name ("add_f32", "eq", "bitwise_and", ...).  inputs[] are the read bindings in
+ * binding order (for `put`: src, src_indexes, dst_indexes); out is the read_write binding; n = number of OUTPUT
+ * elements the dispatch covers (bits for Boolean/bitmap kernels, index count for take/put, INPUT rows for "sum").
+ * [ref: GpuDevice::create_compute_pipeline(shader, entry_point) gpu_device.rs:145-168 — (shader, entry) is the cache key] */
+agpu_status agpu_launch_by_name(agpu_pipeline* p, const char* shader_key, const char* entry_point,
+                                const void* const* inputs, int32_t n_inputs, void* out, uint64_t n);
+
+/* ---------------------------------------------------------------- synthetic columns (bench / parity inputs)
+ * Counter-based: element i of a column depends only on (seed, row0+i), so any shard of a column can be generated
+ * independently on any GPU and re-generated bit-identically by the CPU oracle (oracle/agpu_oracle.c: synth_*).
+ *   h = splitmix64(seed ^ (row * 0x9E3779B97F4A7C15))
+ *   f32 : lo + (hi-lo) * ((h >> 40) * 2^-24)            (24-bit uniform, exact in f32 arithmetic order as written)
+ *   i32 : (int32)(h >> 32) mod `modulus` (modulus>0) else the raw 32 bits
+ *   u8  : h >> 56
+ *   bits: bit = ((h >> 11) * 2^-53) < p_set                (Bernoulli validity / Boolean data) */
+agpu_status agpu_synth_f32(agpu_pipeline* p, float* out, uint64_t n, uint64_t seed, uint64_t row0, float lo, float hi);
+agpu_status agpu_synth_i32(agpu_pipeline* p, int32_t* out, uint64_t n, uint64_t seed, uint64_t row0, uint32_t modulus);
+agpu_status agpu_synth_u8(agpu_pipeline* p, uint8_t* out, uint64_t n, uint64_t seed, uint64_t row0);
+agpu_status agpu_synth_bits(agpu_pipeline* p, void* out_bits, uint64_t n_bits, uint64_t seed, uint64_t row0,
+                            double p_set);
+/* Order-independent 64-bit checksum of a byte range (sum of splitmix64(word ^ index)) for full-size parity checks. */
+agpu_status agpu_checksum(agpu_pipeline* p, const void* data, uint64_t bytes, uint64_t* out_sum_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARROW_GPU_H */
