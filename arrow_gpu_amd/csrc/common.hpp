@@ -98,9 +98,16 @@ struct agpu_tuning {
 };
 extern agpu_tuning g_tune;
 
+// Grid for a streaming kernel that owns `tiles` block-tiles.  Measured on MI355X at 1e9 rows (profiles/
+// r01_sweep_add_f32_1e9.json): ONE tile per block beats every persistent grid (6.54 vs ≤6.52 TB/s at 32768 blocks,
+// 5.3 TB/s at 2048), so the default is grid = tiles; stream_grid > 0 forces a persistent grid-stride launch and
+// stream_bpc > 0 a blocks-per-CU one (both kept for sweeps).  Kernels still grid-stride, so any grid is correct.
 static inline int stream_grid_for(const agpu_pipeline* p, uint64_t tiles) {
-  int64_t g = g_tune.stream_grid > 0 ? g_tune.stream_grid : (int64_t)p->dev->num_cus * g_tune.stream_bpc;
-  if ((uint64_t)g > tiles) g = (int64_t)tiles;
+  uint64_t g = tiles;
+  if (g_tune.stream_grid > 0) g = (uint64_t)g_tune.stream_grid;
+  else if (g_tune.stream_bpc > 0) g = (uint64_t)p->dev->num_cus * (uint64_t)g_tune.stream_bpc;
+  if (g > tiles) g = tiles;
+  if (g > 0x3FFFFFFFull) g = 0x3FFFFFFFull;  // hipDim3.x limit headroom
   if (g < 1) g = 1;
   return (int)g;
 }

@@ -42,7 +42,7 @@ __device__ __forceinline__ uint64_t validity_word(const uint64_t* va, const uint
 }
 
 // ---------------------------------------------------------------- variant 0: ballot
-template <typename T, int OP>
+template <typename T, int OP, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, const T* b, const uint64_t* va,
                                                                const uint64_t* vb, uint64_t* out, uint64_t* outv,
                                                                uint64_t n) {
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, cons
     T xa[R], xb[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-      xa[r] = a[e0 + (uint64_t)r * AGPU_WAVE + lane];
-      xb[r] = b[e0 + (uint64_t)r * AGPU_WAVE + lane];
+      xa[r] = ld_vec<NT, T>(a + e0 + (uint64_t)r * AGPU_WAVE + lane);
+      xb[r] = ld_vec<NT, T>(b + e0 + (uint64_t)r * AGPU_WAVE + lane);
     }
     uint64_t vword = 0;
     if (do_v && lane < R) vword = validity_word(va, vb, w0 + lane);
@@ -91,7 +91,7 @@ struct CmpPack {
   T v[N];
 };
 
-template <typename T, int OP, int U>
+template <typename T, int OP, int U, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T* b, const uint32_t* va,
                                                             const uint32_t* vb, uint32_t* out, uint32_t* outv,
                                                             uint64_t n) {
@@ -109,8 +109,10 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint64_t pk = p0 + (uint64_t)u * AGPU_BLOCK;
-      xa[u] = __builtin_bit_cast(CmpPack<T, N>, *reinterpret_cast<const u32x4*>(a + pk * N));
-      xb[u] = __builtin_bit_cast(CmpPack<T, N>, *reinterpret_cast<const u32x4*>(b + pk * N));
+      const u32x4 ra = ld_vec<NT, u32x4>(reinterpret_cast<const u32x4*>(a + pk * N));
+      const u32x4 rb = ld_vec<NT, u32x4>(reinterpret_cast<const u32x4*>(b + pk * N));
+      xa[u] = __builtin_bit_cast(CmpPack<T, N>, ra);
+      xb[u] = __builtin_bit_cast(CmpPack<T, N>, rb);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
@@ -156,21 +158,22 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
                               void* out, void* outv, uint64_t n) {
   const T* pa = static_cast<const T*>(a);
   const T* pb = static_cast<const T*>(b);
-  constexpr int U = 4;
+  constexpr int U = 2;
   const bool use_ballot = sizeof(T) == 4 && g_tune.cmp_variant == 0;
+  const bool nt = (g_tune.stream_nt & 1) != 0;  // inputs are read exactly once: nontemporal loads (+measured, profiles/)
   if (use_ballot) {
     const uint64_t ntiles = n / (1024 * (AGPU_BLOCK / AGPU_WAVE));
     const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
-    hipLaunchKernelGGL((cmp_ballot_kernel<T, OP>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb,
-                       static_cast<const uint64_t*>(va), static_cast<const uint64_t*>(vb), static_cast<uint64_t*>(out),
-                       static_cast<uint64_t*>(outv), n);
+    auto k = nt ? cmp_ballot_kernel<T, OP, true> : cmp_ballot_kernel<T, OP, false>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, static_cast<const uint64_t*>(va),
+                       static_cast<const uint64_t*>(vb), static_cast<uint64_t*>(out), static_cast<uint64_t*>(outv), n);
   } else if (aligned16(a) && aligned16(b)) {
     constexpr int N = 16 / sizeof(T);
     const uint64_t ntiles = n / ((uint64_t)AGPU_BLOCK * U * N);
     const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
-    hipLaunchKernelGGL((cmp_vec_kernel<T, OP, U>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb,
-                       static_cast<const uint32_t*>(va), static_cast<const uint32_t*>(vb), static_cast<uint32_t*>(out),
-                       static_cast<uint32_t*>(outv), n);
+    auto k = nt ? cmp_vec_kernel<T, OP, U, true> : cmp_vec_kernel<T, OP, U, false>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, static_cast<const uint32_t*>(va),
+                       static_cast<const uint32_t*>(vb), static_cast<uint32_t*>(out), static_cast<uint32_t*>(outv), n);
   } else {
     const uint64_t nwords = (n + 63) / 64;
     const int grid = stream_grid_for(p, (nwords + AGPU_BLOCK - 1) / AGPU_BLOCK);

@@ -21,10 +21,10 @@
 #include "common.hpp"
 
 #ifndef AGPU_STREAM_U
-#define AGPU_STREAM_U 4  // 16-byte vectors in flight per lane per input array (measured best: profiles/)
+#define AGPU_STREAM_U 1  // 16-byte vectors per lane per input array per tile (measured best: profiles/r01_sweep_add_f32_1e9.json)
 #endif
 #ifndef AGPU_STREAM_NT
-#define AGPU_STREAM_NT 0  // bit0 nontemporal loads, bit1 nontemporal stores
+#define AGPU_STREAM_NT 3  // bit0 nontemporal loads, bit1 nontemporal stores (both: +7 % at 1e9 rows)
 #endif
 
 enum { MODE_UNARY = 0, MODE_BINARY = 1, MODE_SCALAR = 2 };
@@ -357,13 +357,14 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel(const TI* in, TO* out, 
     const uint64_t p0 = t * tile + threadIdx.x;
     PackN<TI, N> v[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) v[u] = load_pack<false, TI, N>(in + (p0 + (uint64_t)u * AGPU_BLOCK) * N);
+    for (int u = 0; u < U; u++)
+      v[u] = load_pack<(AGPU_STREAM_NT & 1) != 0, TI, N>(in + (p0 + (uint64_t)u * AGPU_BLOCK) * N);
 #pragma unroll
     for (int u = 0; u < U; u++) {
       PackN<TO, N> r;
 #pragma unroll
       for (int k = 0; k < N; k++) r.v[k] = Conv::ap(v[u].v[k]);
-      store_pack<false, TO, N>(out + (p0 + (uint64_t)u * AGPU_BLOCK) * N, r);
+      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, N>(out + (p0 + (uint64_t)u * AGPU_BLOCK) * N, r);
     }
   }
   if (blockIdx.x == ntiles % gridDim.x) {

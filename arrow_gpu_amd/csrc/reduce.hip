@@ -48,7 +48,7 @@ __device__ __forceinline__ float load4_tree(const float* in, const uint8_t* vali
       if (row + 3 < n && !((validity[(row + 3) >> 3] >> ((row + 3) & 7)) & 1)) x3 = 0.0f;
     }
   } else {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(in + row);
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(in + row));  // read-once stream
     x0 = v.x; x1 = v.y; x2 = v.z; x3 = v.w;
     if constexpr (HASV) {
       const uint32_t nib = validity_nibble(validity, row);
@@ -207,6 +207,11 @@ __device__ __forceinline__ A block_reduce(A v, A* lds) {
   return r;
 }
 
+template <typename T>
+__device__ __forceinline__ T word_as(uint32_t w) {
+  return __builtin_bit_cast(T, w);
+}
+
 template <typename T, typename Red, int U>
 __global__ __launch_bounds__(AGPU_BLOCK) void reduce_partial_kernel(const T* in, const uint8_t* validity, uint64_t n,
                                                                    typename Red::Acc* partials, int vec_ok) {
@@ -223,15 +228,18 @@ __global__ __launch_bounds__(AGPU_BLOCK) void reduce_partial_kernel(const T* in,
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const uint64_t pk = p0 + (uint64_t)u * AGPU_BLOCK;
-      v[u] = *reinterpret_cast<const u32x4*>(in + pk * 4);
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in + pk * 4));  // read-once stream
       nib[u] = validity ? validity_nibble(validity, pk * 4) : 0xFu;
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      if (nib[u] & 1) acc = Red::combine(acc, Red::load(__builtin_bit_cast(T, v[u].x)));
-      if (nib[u] & 2) acc = Red::combine(acc, Red::load(__builtin_bit_cast(T, v[u].y)));
-      if (nib[u] & 4) acc = Red::combine(acc, Red::load(__builtin_bit_cast(T, v[u].z)));
-      if (nib[u] & 8) acc = Red::combine(acc, Red::load(__builtin_bit_cast(T, v[u].w)));
+      // NB: copy the lanes out first — __builtin_bit_cast applied directly to a vector-element expression
+      // (v[u].y) reads the vector's first element on this compiler.
+      const uint32_t e0 = v[u].x, e1 = v[u].y, e2 = v[u].z, e3 = v[u].w;
+      if (nib[u] & 1) acc = Red::combine(acc, Red::load(word_as<T>(e0)));
+      if (nib[u] & 2) acc = Red::combine(acc, Red::load(word_as<T>(e1)));
+      if (nib[u] & 4) acc = Red::combine(acc, Red::load(word_as<T>(e2)));
+      if (nib[u] & 8) acc = Red::combine(acc, Red::load(word_as<T>(e3)));
     }
   }
   // rows past the last full tile: element-granular, spread over the whole grid
@@ -255,7 +263,8 @@ __global__ __launch_bounds__(AGPU_BLOCK) void reduce_finish_kernel(const typenam
 }
 
 static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks) {
-  int64_t g = g_tune.reduce_grid > 0 ? g_tune.reduce_grid : (int64_t)p->dev->num_cus * 8;
+  // many small blocks stream better than a few persistent ones on this chip (profiles/r01_sweep_add_f32_1e9.json)
+  int64_t g = g_tune.reduce_grid > 0 ? g_tune.reduce_grid : (int64_t)p->dev->num_cus * 64;
   if ((uint64_t)g > work_blocks) g = (int64_t)work_blocks;
   if (g < 1) g = 1;
   return (int)g;

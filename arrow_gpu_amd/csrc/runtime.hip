@@ -14,7 +14,7 @@ void agpu_set_error(const char* fmt, ...) {
 }
 
 agpu_tuning g_tune = {
-    /*stream_grid*/ 0, /*stream_bpc*/ 8, /*stream_unroll*/ 4, /*stream_nt*/ 0, /*cmp_variant*/ 0, /*reduce_grid*/ 0};
+    /*stream_grid*/ 0, /*stream_bpc*/ 0, /*stream_unroll*/ 1, /*stream_nt*/ 1, /*cmp_variant*/ 0, /*reduce_grid*/ 0};
 
 extern "C" {
 

@@ -1,0 +1,97 @@
+"""arrow_gpu_cast: Cast<T>, BitCast<T>, cast_dyn, bitcast_dyn.
+
+Mirror of crates/cast/src/lib.rs (traits :15-38, impl_cast! :40-87, table :135-161, bitcast :187-192).  In Rust the
+target is a type parameter (`<UInt8ArrayGPU as Cast<Float32ArrayGPU>>::cast(&a)`); here it is an argument:
+`a.cast(Float32ArrayGPU)` / `a.cast_op(Float32ArrayGPU, pipeline)`.
+"""
+from __future__ import annotations
+
+from .. import _capi as capi
+from .._capi import CastingNotSupported
+from ..array import (ARRAY_OF_TYPE, ArrowArrayGPU, ArrowType, BooleanArrayGPU, Float32ArrayGPU, Int8ArrayGPU,
+                     Int16ArrayGPU, Int32ArrayGPU, NullBitBufferGpu, UInt8ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU)
+from ..gpu_utils import ArrowComputePipeline
+from ._ops import vp
+
+# cast_dyn's table [crates/cast/src/lib.rs:135-161]
+CAST_TABLE = {
+    Int8ArrayGPU: (UInt8ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU, Int16ArrayGPU, Int32ArrayGPU, Float32ArrayGPU),
+    Int16ArrayGPU: (Int32ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU, Float32ArrayGPU),
+    UInt8ArrayGPU: (UInt16ArrayGPU, UInt32ArrayGPU, Int8ArrayGPU, Int16ArrayGPU, Int32ArrayGPU, Float32ArrayGPU),
+    UInt16ArrayGPU: (UInt32ArrayGPU, Int16ArrayGPU, Int32ArrayGPU, Float32ArrayGPU),
+    Float32ArrayGPU: (UInt8ArrayGPU,),
+    BooleanArrayGPU: (Float32ArrayGPU,),
+}
+BITCAST_TABLE = {UInt32ArrayGPU: (Float32ArrayGPU,)}
+
+
+def _cast_op(self: ArrowArrayGPU, into, pipeline: ArrowComputePipeline):
+    if into not in CAST_TABLE.get(type(self), ()):
+        raise CastingNotSupported(f"Casting not supported for type {self.get_dtype().name} {into.ARROW_TYPE.name}")
+    dev = self.gpu_device
+    out = dev.create_empty_buffer(max(self.len * into.ITEM_SIZE, 1))
+    capi.call("agpu_cast", pipeline._handle, self.DTYPE, into.DTYPE, vp(self.data), vp(out), self.len)
+    pipeline.keep(self.data, out)
+    nulls = NullBitBufferGpu.clone_null_bit_buffer_op(self.null_buffer, pipeline)
+    return into(out, dev, self.len, nulls)
+
+
+def _cast(self, into):
+    p = ArrowComputePipeline(self.get_gpu_device(), "cast")
+    out = _cast_op(self, into, p)
+    p.finish()
+    return out
+
+
+def _bitcast_op(self, into, pipeline: ArrowComputePipeline):
+    """Reinterpret: a device copy of the buffer [crates/cast/src/lib.rs:90-107]."""
+    if into not in BITCAST_TABLE.get(type(self), ()):
+        raise CastingNotSupported(f"Casting not supported for type {self.get_dtype().name} {into.ARROW_TYPE.name}")
+    data = pipeline.clone_buffer(self.data)
+    return into(data, self.gpu_device, self.len, NullBitBufferGpu.clone_null_bit_buffer_op(self.null_buffer, pipeline))
+
+
+def _bitcast(self, into):
+    p = ArrowComputePipeline(self.get_gpu_device(), "bitcast")
+    out = _bitcast_op(self, into, p)
+    p.finish()
+    return out
+
+
+for _cls in CAST_TABLE:
+    _cls.cast = _cast
+    _cls.cast_op = _cast_op
+for _cls in BITCAST_TABLE:
+    _cls.bitcast = _bitcast
+    _cls.bitcast_op = _bitcast_op
+
+
+def cast_op_dyn(from_: ArrowArrayGPU, into: ArrowType, pipeline: ArrowComputePipeline) -> ArrowArrayGPU:
+    target = ARRAY_OF_TYPE[into]
+    if target not in CAST_TABLE.get(type(from_), ()):
+        raise CastingNotSupported(f"Casting not supported for type {from_.get_dtype().name} {into.name}")
+    return from_.cast_op(target, pipeline)
+
+
+def cast_dyn(from_: ArrowArrayGPU, into: ArrowType) -> ArrowArrayGPU:
+    p = ArrowComputePipeline(from_.get_gpu_device(), "cast_dyn")
+    out = cast_op_dyn(from_, into, p)
+    p.finish()
+    return out
+
+
+def bitcast_op_dyn(from_: ArrowArrayGPU, into: ArrowType, pipeline: ArrowComputePipeline) -> ArrowArrayGPU:
+    target = ARRAY_OF_TYPE[into]
+    if target not in BITCAST_TABLE.get(type(from_), ()):
+        raise CastingNotSupported(f"Casting not supported for type {from_.get_dtype().name} {into.name}")
+    return from_.bitcast_op(target, pipeline)
+
+
+def bitcast_dyn(from_: ArrowArrayGPU, into: ArrowType) -> ArrowArrayGPU:
+    p = ArrowComputePipeline(from_.get_gpu_device(), "bitcast_dyn")
+    out = bitcast_op_dyn(from_, into, p)
+    p.finish()
+    return out
+
+
+__all__ = ["cast_dyn", "cast_op_dyn", "bitcast_dyn", "bitcast_op_dyn", "CAST_TABLE", "BITCAST_TABLE"]

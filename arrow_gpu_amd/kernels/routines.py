@@ -1,0 +1,192 @@
+"""arrow_gpu_routines: Swizzle — merge (select by mask), take (gather), put (scatter).
+
+Mirror of crates/routines/src/{lib,merge,take,put,bool}.rs.  Differences that are deliberate:
+the taken validity bitmap has the INDEX length (the reference stores the source length, bool.rs:40-44); absent
+validity bitmaps count as all-valid in `merge`; indices are range-checked on the host side of `take`/`put` because
+HIP has no robust buffer access (out-of-range → ArrowErrorGPU ShapeError instead of an unspecified value).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _capi as capi
+from .._capi import ArrowErrorGPU, OperationNotSupported
+from ..array import (ArrowArrayGPU, BooleanArrayGPU, Date32ArrayGPU, Float32ArrayGPU, Int8ArrayGPU, Int16ArrayGPU,
+                     Int32ArrayGPU, NullBitBufferGpu, PrimitiveArrayGpu, UInt8ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU,
+                     bitmap_bytes)
+from ..gpu_utils import ArrowComputePipeline
+from ._ops import check_same_len, impl, vp
+
+_PRIMS = (Date32ArrayGPU, Int32ArrayGPU, Int16ArrayGPU, Int8ArrayGPU, UInt32ArrayGPU, UInt16ArrayGPU, UInt8ArrayGPU,
+          Float32ArrayGPU)
+
+
+def merge_null_buffers_op(op1, op2, mask: BooleanArrayGPU, pipeline: ArrowComputePipeline, n: int):
+    """validity = ((v1 & m) | (v2 & ~m)) & v_mask in ONE kernel (the reference: up to 4 dispatches, merge.rs:17-86).
+    All three absent → None."""
+    vm = mask.null_buffer
+    if op1 is None and op2 is None and vm is None:
+        return None
+    dev = mask.gpu_device
+    out = dev.create_empty_buffer(max(bitmap_bytes(n), 8))
+    capi.call("agpu_bitmap_merge_validity", pipeline._handle, vp(op1.bit_buffer) if op1 else None,
+              vp(op2.bit_buffer) if op2 else None, vp(mask.data), vp(vm.bit_buffer) if vm else None, vp(out), n)
+    pipeline.keep(op1.bit_buffer if op1 else None, op2.bit_buffer if op2 else None, mask.data,
+                  vm.bit_buffer if vm else None, out)
+    return NullBitBufferGpu(out, n, dev)
+
+
+def _check_indices(indexes: UInt32ArrayGPU, limit: int, pipeline: ArrowComputePipeline, what: str) -> None:
+    if indexes.len == 0:
+        return
+    dev = indexes.gpu_device
+    out = dev.create_empty_buffer(16)
+    capi.call("agpu_index_max", pipeline._handle, vp(indexes.data), indexes.len, vp(out))
+    mx = int(dev.retrive_data(out, 4, pipeline=pipeline).view(np.uint32)[0])
+    if mx >= limit:
+        raise ArrowErrorGPU("ShapeError", f"{what}: index {mx} out of range for length {limit}", capi.ERR_SHAPE)
+
+
+def take_null_buffer(null_buffer, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipeline):
+    """[ref: crates/routines/src/bool.rs:33-46]"""
+    if null_buffer is None:
+        return None
+    dev = indexes.gpu_device
+    out = dev.create_empty_buffer(max(bitmap_bytes(indexes.len), 8))
+    capi.call("agpu_take_bits", pipeline._handle, vp(null_buffer.bit_buffer), null_buffer.len, vp(indexes.data), vp(out),
+              indexes.len)
+    pipeline.keep(null_buffer.bit_buffer, indexes.data, out)
+    return NullBitBufferGpu(out, indexes.len, dev)
+
+
+# ---- PrimitiveArrayGpu<T>  [crates/routines/src/lib.rs:81-171]
+def _merge_op(self: PrimitiveArrayGpu, other, mask: BooleanArrayGPU, pipeline: ArrowComputePipeline):
+    check_same_len(self, other, "merge")
+    check_same_len(self, mask, "merge mask")
+    dev = self.gpu_device
+    out = dev.create_empty_buffer(max(self.len * self.ITEM_SIZE, 1))
+    capi.call("agpu_merge", pipeline._handle, self.ITEM_SIZE, vp(self.data), vp(other.data), vp(mask.data), vp(out), self.len)
+    pipeline.keep(self.data, other.data, mask.data, out)
+    nulls = merge_null_buffers_op(self.null_buffer, other.null_buffer, mask, pipeline, self.len)
+    return type(self)(out, dev, self.len, nulls)
+
+
+def _take_op(self: PrimitiveArrayGpu, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipeline):
+    _check_indices(indexes, self.len, pipeline, "take")
+    dev = self.gpu_device
+    out = dev.create_empty_buffer(max(indexes.len * self.ITEM_SIZE, 1))
+    capi.call("agpu_take", pipeline._handle, self.ITEM_SIZE, vp(self.data), self.len, vp(indexes.data), vp(out), indexes.len)
+    pipeline.keep(self.data, indexes.data, out)
+    nulls = take_null_buffer(self.null_buffer, indexes, pipeline)
+    return type(self)(out, dev, indexes.len, nulls)
+
+
+def _put_op(self: PrimitiveArrayGpu, src_indexes: UInt32ArrayGPU, dst, dst_indexes: UInt32ArrayGPU,
+            pipeline: ArrowComputePipeline) -> None:
+    if self.null_buffer is not None or dst.null_buffer is not None:
+        raise OperationNotSupported("put with null buffers is todo!() in the reference (routines/src/lib.rs:164-169)")
+    check_same_len(src_indexes, dst_indexes, "put indexes")
+    _check_indices(src_indexes, self.len, pipeline, "put src")
+    _check_indices(dst_indexes, dst.len, pipeline, "put dst")
+    capi.call("agpu_put", pipeline._handle, self.ITEM_SIZE, vp(self.data), vp(src_indexes.data), vp(dst.data),
+              vp(dst_indexes.data), src_indexes.len)
+    pipeline.keep(self.data, src_indexes.data, dst.data, dst_indexes.data)
+
+
+def _put(self, src_indexes, dst, dst_indexes) -> None:
+    p = ArrowComputePipeline(self.get_gpu_device(), "put")
+    self.put_op(src_indexes, dst, dst_indexes, p)
+    p.finish()
+
+
+impl(_PRIMS, "merge", _merge_op)
+impl(_PRIMS, "take", _take_op)
+for _c in _PRIMS:
+    _c.put_op = _put_op
+    _c.put = _put
+
+
+# ---- BooleanArrayGPU  [crates/routines/src/bool.rs:48-128]
+def _bool_merge_op(self: BooleanArrayGPU, other, mask: BooleanArrayGPU, pipeline: ArrowComputePipeline):
+    check_same_len(self, other, "merge")
+    check_same_len(self, mask, "merge mask")
+    dev = self.gpu_device
+    out = dev.create_empty_buffer(max(bitmap_bytes(self.len), 8))
+    capi.call("agpu_merge_bits", pipeline._handle, vp(self.data), vp(other.data), vp(mask.data), vp(out), self.len)
+    pipeline.keep(self.data, other.data, mask.data, out)
+    nulls = merge_null_buffers_op(self.null_buffer, other.null_buffer, mask, pipeline, self.len)
+    return BooleanArrayGPU(out, dev, self.len, nulls)
+
+
+def _bool_take_op(self: BooleanArrayGPU, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipeline):
+    _check_indices(indexes, self.len, pipeline, "take")
+    dev = self.gpu_device
+    out = dev.create_empty_buffer(max(bitmap_bytes(indexes.len), 8))
+    capi.call("agpu_take_bits", pipeline._handle, vp(self.data), self.len, vp(indexes.data), vp(out), indexes.len)
+    pipeline.keep(self.data, indexes.data, out)
+    return BooleanArrayGPU(out, dev, indexes.len, take_null_buffer(self.null_buffer, indexes, pipeline))
+
+
+def _bool_put_op(self: BooleanArrayGPU, src_indexes, dst: BooleanArrayGPU, dst_indexes, pipeline: ArrowComputePipeline):
+    if self.null_buffer is not None or dst.null_buffer is not None:
+        raise OperationNotSupported("put with null buffers is todo!() in the reference (routines/src/bool.rs)")
+    check_same_len(src_indexes, dst_indexes, "put indexes")
+    _check_indices(src_indexes, self.len, pipeline, "put src")
+    _check_indices(dst_indexes, dst.len, pipeline, "put dst")
+    capi.call("agpu_put_bits", pipeline._handle, vp(self.data), vp(src_indexes.data), vp(dst.data), vp(dst_indexes.data),
+              src_indexes.len)
+    pipeline.keep(self.data, src_indexes.data, dst.data, dst_indexes.data)
+
+
+impl((BooleanArrayGPU,), "merge", _bool_merge_op)
+impl((BooleanArrayGPU,), "take", _bool_take_op)
+BooleanArrayGPU.put_op = _bool_put_op
+BooleanArrayGPU.put = _put
+
+# ---- dyn  [merge.rs:92-140, take.rs:58-94, put.rs:59-110]
+_MERGE_DYN = _PRIMS + (BooleanArrayGPU,)
+_TAKE_DYN = (Date32ArrayGPU, UInt32ArrayGPU, Int32ArrayGPU, Float32ArrayGPU, BooleanArrayGPU)
+_PUT_DYN = (Float32ArrayGPU, Int32ArrayGPU, UInt32ArrayGPU, Date32ArrayGPU, BooleanArrayGPU)
+
+
+def merge_op_dyn(operand_1: ArrowArrayGPU, operand_2: ArrowArrayGPU, mask: BooleanArrayGPU, pipeline):
+    if type(operand_1) is type(operand_2) and type(operand_1) in _MERGE_DYN:
+        return operand_1.merge_op(operand_2, mask, pipeline)
+    raise OperationNotSupported(
+        f"Operation merge_dyn not supported for type {operand_1.get_dtype().name} {operand_2.get_dtype().name}")
+
+
+def merge_dyn(operand_1, operand_2, mask):
+    p = ArrowComputePipeline(operand_1.get_gpu_device(), "merge")
+    out = merge_op_dyn(operand_1, operand_2, mask, p)
+    p.finish()
+    return out
+
+
+def take_op_dyn(operand_1: ArrowArrayGPU, indexes: UInt32ArrayGPU, pipeline):
+    if type(operand_1) in _TAKE_DYN:
+        return operand_1.take_op(indexes, pipeline)
+    raise OperationNotSupported(f"Operation take_dyn not supported for type {operand_1.get_dtype().name}")
+
+
+def take_dyn(operand_1, indexes):
+    p = ArrowComputePipeline(operand_1.get_gpu_device(), "take")
+    out = take_op_dyn(operand_1, indexes, p)
+    p.finish()
+    return out
+
+
+def put_op_dyn(src: ArrowArrayGPU, src_indexes, dst: ArrowArrayGPU, dst_indexes, pipeline) -> None:
+    if type(src) is type(dst) and type(src) in _PUT_DYN:
+        return src.put_op(src_indexes, dst, dst_indexes, pipeline)
+    raise OperationNotSupported(
+        f"Operation put_dyn not supported for type {src.get_dtype().name} {dst.get_dtype().name}")
+
+
+def put_dyn(src, src_indexes, dst, dst_indexes) -> None:
+    p = ArrowComputePipeline(src.get_gpu_device(), "put")
+    put_op_dyn(src, src_indexes, dst, dst_indexes, p)
+    p.finish()
+
+
+__all__ = ["merge_dyn", "merge_op_dyn", "take_dyn", "take_op_dyn", "put_dyn", "put_op_dyn", "merge_null_buffers_op"]

@@ -1,0 +1,498 @@
+"""GPU parity tests proper: every kernel family of the C ABI against the CPU oracle on the same seeded inputs —
+bit-exact for integer / compare / cast / logical / bitmap / swizzle / f32 + − × ÷ % min max / f32 SUM (reference
+order), ≤ MAX_ULP for the transcendental f32 functions (tolerance stated in golden_runner.MAX_ULP).
+Sizes cover empty, ragged tails around every tile boundary (64, 256, 1024, 4096, 65536) and ≈1 M rows; pointers
+are also deliberately mis-aligned to force the element-granular fallbacks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_runner as G
+import oracle as O
+from arrow_gpu_amd import _capi as capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def D():
+    from gpu_util import Dev
+
+    return Dev()
+
+
+from gpu_util import (ALL_DTYPES, INT_DTYPES, NP, SIZES, SMALL_SIZES, bits_equal, max_ulp, nan_aware_bits_equal,  # noqa: E402
+                      rand_values)
+
+F32_BIN = [capi.OP_ADD, capi.OP_SUB, capi.OP_MUL, capi.OP_DIV, capi.OP_REM, capi.OP_MIN, capi.OP_MAX]
+INT32_BIN = [capi.OP_ADD, capi.OP_SUB, capi.OP_MUL, capi.OP_DIV, capi.OP_REM, capi.OP_MIN, capi.OP_MAX, capi.OP_AND,
+             capi.OP_OR, capi.OP_XOR]
+SMALL_BIN = [capi.OP_ADD, capi.OP_SUB, capi.OP_MUL, capi.OP_MIN, capi.OP_MAX, capi.OP_AND, capi.OP_OR, capi.OP_XOR]
+
+
+def ops_for(dtype):
+    if dtype == capi.F32:
+        return F32_BIN
+    return INT32_BIN if NP[dtype]().itemsize == 4 else SMALL_BIN
+
+
+# ------------------------------------------------------------------ element-wise
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_binary_and_scalar_all_ops(D, dtype):
+    for n in SIZES:
+        a, b = rand_values(dtype, n, 100 + n), rand_values(dtype, n, 200 + n)
+        if n > 4 and dtype != capi.F32:
+            b[:4] = 0  # division by zero / shift edge
+            if NP[dtype]().itemsize == 4 and np.issubdtype(NP[dtype], np.signedinteger):
+                a[0], b[0] = np.iinfo(np.int32).min, -1
+        da, db = D.up(a), D.up(b)
+        out = D.empty(max(a.nbytes, 1))
+        s = rand_values(dtype, 1, 7, special=False)
+        ds = D.up(s)
+        for op in ops_for(dtype):
+            D.call("agpu_binary", op, dtype, da.vp, db.vp, out.vp, n)
+            assert nan_aware_bits_equal(D.down(out, NP[dtype], n), O.binary(op, dtype, a, b)), (op, n)
+            D.call("agpu_scalar", op, dtype, da.vp, ds.vp, out.vp, n)
+            assert nan_aware_bits_equal(D.down(out, NP[dtype], n), O.scalar(op, dtype, a, s)), ("scalar", op, n)
+
+
+@pytest.mark.parametrize("dtype", [capi.F32, capi.I32, capi.U8, capi.I16])
+def test_binary_unaligned_pointers_and_in_place(D, dtype):
+    n = 10007
+    w = NP[dtype]().itemsize
+    a, b = rand_values(dtype, n, 1), rand_values(dtype, n, 2)
+    da, db = D.up(a, offset_bytes=w), D.up(b, offset_bytes=w)  # aligned to the element only
+    out = D.empty(a.nbytes, offset_bytes=w)
+    D.call("agpu_binary", capi.OP_ADD, dtype, da.vp, db.vp, out.vp, n)
+    assert nan_aware_bits_equal(D.down(out, NP[dtype], n), O.binary(capi.OP_ADD, dtype, a, b))
+    # in place on an aligned buffer: out aliases a exactly
+    da2 = D.up(a)
+    D.call("agpu_binary", capi.OP_MUL, dtype, da2.vp, D.up(b).vp, da2.vp, n)
+    assert nan_aware_bits_equal(D.down(da2, NP[dtype], n), O.binary(capi.OP_MUL, dtype, a, b))
+
+
+@pytest.mark.parametrize("dtype", INT_DTYPES)
+def test_shifts(D, dtype):
+    for n in SMALL_SIZES:
+        a = rand_values(dtype, n, 5)
+        s = np.random.default_rng(n).integers(0, 40, n).astype(np.uint32)  # includes amounts ≥ width and ≥ 32
+        da, dsh, out = D.up(a), D.up(s), D.empty(max(a.nbytes, 1))
+        for op in (capi.OP_SHL, capi.OP_SHR):
+            D.call("agpu_binary", op, dtype, da.vp, dsh.vp, out.vp, n)
+            assert bits_equal(D.down(out, NP[dtype], n), O.binary(op, dtype, a, s)), (op, n)
+
+
+def test_int32_power(D):
+    n = 5003
+    rng = np.random.default_rng(3)
+    a = rng.integers(-6, 7, n).astype(np.int32)
+    p = rng.integers(-5, 12, n).astype(np.int32)
+    p[:3] = [np.iinfo(np.int32).min, 31, 0]
+    out = D.empty(4 * n)
+    D.call("agpu_binary", capi.OP_POW, capi.I32, D.up(a).vp, D.up(p).vp, out.vp, n)
+    assert bits_equal(D.down(out, np.int32, n), O.binary(O.OP_POW, O.I32, a, p))
+
+
+def test_f32_power_domain_and_accuracy(D):
+    rng = np.random.default_rng(4)
+    n = 100003
+    a = np.abs(rng.standard_normal(n)).astype(np.float32) * 10
+    b = (rng.standard_normal(n) * 3).astype(np.float32)
+    a[:8] = [1.0, -1.0, 10.0, -10.0, np.nan, np.inf, -np.inf, 0.0]
+    b[:8] = [0.0, 0.0, 0.0, 0.0, np.nan, np.inf, -np.inf, 2.0]
+    out = D.empty(4 * n)
+    D.call("agpu_binary", capi.OP_POW, capi.F32, D.up(a).vp, D.up(b).vp, out.vp, n)
+    got, exp = D.down(out, np.float32, n), O.binary(O.OP_POW, O.F32, a, b)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))  # negative / NaN base → NaN, like the reference's GPUs
+    assert max_ulp(got, exp) <= 2
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+def test_unary_exact_ops(D, dtype):
+    ops = [capi.UN_NEG, capi.UN_ABS] + ([capi.UN_SQRT] if dtype == capi.F32 else [capi.UN_NOT])
+    for n in SMALL_SIZES:
+        a = rand_values(dtype, n, 9)
+        da, out = D.up(a), D.empty(max(a.nbytes, 1))
+        for op in ops:
+            D.call("agpu_unary", op, dtype, da.vp, out.vp, n)
+            assert nan_aware_bits_equal(D.down(out, NP[dtype], n), O.unary(op, dtype, a)), (op, n)
+
+
+@pytest.mark.parametrize("op,name,lo,hi", [
+    (capi.UN_SIN, "sin", -20.0, 15.0), (capi.UN_COS, "cos", -20.0, 15.0), (capi.UN_EXP, "exp", -20.0, 6.0),
+    (capi.UN_EXP2, "exp2", -20.0, 6.0), (capi.UN_LOG, "log", -30.0, 30.0), (capi.UN_LOG2, "log2", -30.0, 30.0),
+    (capi.UN_CBRT, "cbrt", -30.0, 30.0), (capi.UN_SINH, "sinh", -20.0, 6.0), (capi.UN_ACOS, "acos", -20.0, 0.0)])
+def test_f32_transcendentals_within_ulp(D, op, name, lo, hi):
+    """|x| log-uniform in [2^lo, 2^hi] both signs, plus ±0, ±inf, NaN, denormals; oracle = f64 libm rounded to f32."""
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    x = (2.0 ** rng.uniform(lo, hi, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    x[:8] = [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-42, -1e-42, 1.0]
+    out = D.empty(4 * n)
+    D.call("agpu_unary", op, capi.F32, D.up(x).vp, out.vp, n)
+    got, exp = D.down(out, np.float32, n), O.unary(op, O.F32, x)
+    assert max_ulp(got, exp) <= G.MAX_ULP, f"{name}: {max_ulp(got, exp)} ULP"
+
+
+@pytest.mark.parametrize("dtype", [capi.U8, capi.I8, capi.U16, capi.I16])
+@pytest.mark.parametrize("op", [capi.UN_SIN, capi.UN_COS, capi.UN_SINH])
+def test_fused_small_int_trig_exhaustive(D, dtype, op):
+    info = np.iinfo(NP[dtype])
+    x = np.arange(info.min, info.max + 1, dtype=np.int64).astype(NP[dtype])  # every representable input
+    x = np.concatenate([x, x[: 4097 - len(x) % 4096]])
+    out = D.empty(4 * len(x))
+    D.call("agpu_unary", op, dtype, D.up(x).vp, out.vp, len(x))
+    got, exp = D.down(out, np.float32, len(x)), O.unary(op, dtype, x)
+    assert max_ulp(got, exp) <= G.MAX_ULP
+
+
+CASTS = [(capi.I8, t) for t in (capi.U8, capi.U16, capi.U32, capi.I16, capi.I32, capi.F32)] + \
+        [(capi.I16, t) for t in (capi.I32, capi.U16, capi.U32, capi.F32)] + \
+        [(capi.U8, t) for t in (capi.U16, capi.U32, capi.I8, capi.I16, capi.I32, capi.F32)] + \
+        [(capi.U16, t) for t in (capi.U32, capi.I16, capi.I32, capi.F32)] + [(capi.F32, capi.U8)]
+
+
+@pytest.mark.parametrize("frm,to", CASTS)
+def test_casts_exact(D, frm, to):
+    for n in SMALL_SIZES + [1048576 + 5]:
+        a = rand_values(frm, n, 13)
+        if frm == capi.F32 and n > 8:
+            a[:8] = [0, 1, -1, 5713, -5713, 255, 256, 4.3e9]
+        out = D.empty(max(n * NP[to]().itemsize, 1))
+        D.call("agpu_cast", frm, to, D.up(a).vp, out.vp, n)
+        got = D.down(out, NP[to], n)
+        if NP[frm]().itemsize == NP[to]().itemsize and frm != capi.F32:
+            exp = a.view(NP[to])
+        else:
+            exp = O.cast(frm, to, a)
+        assert bits_equal(got, exp), (frm, to, n)
+
+
+def test_cast_bool_to_f32_and_unsupported(D):
+    for n in SMALL_SIZES:
+        bits = O.synth_bits(n, 3, 0, 0.5)
+        out = D.empty(max(4 * n, 1))
+        D.call("agpu_cast", capi.BOOL, capi.F32, D.up(bits).vp, out.vp, n)
+        assert bits_equal(D.down(out, np.float32, n), O.cast(O.BOOL, O.F32, bits, n))
+    x = D.up(np.zeros(4, np.float32))
+    assert D.status("agpu_cast", capi.F32, capi.I32, x.vp, x.vp, 4) == capi.ERR_UNSUPPORTED
+    assert D.status("agpu_binary", capi.OP_DIV, capi.U8, x.vp, x.vp, x.vp, 4) == capi.ERR_UNSUPPORTED
+    assert D.status("agpu_unary", capi.UN_SQRT, capi.I32, x.vp, x.vp, 4) == capi.ERR_UNSUPPORTED
+    assert b"not supported" in capi.lib().agpu_last_error()
+
+
+@pytest.mark.parametrize("dtype", ALL_DTYPES + [capi.BOOL])
+def test_broadcast(D, dtype):
+    for n in SMALL_SIZES:
+        if dtype == capi.BOOL:
+            for v in (0, 1):
+                out = D.empty(O.bitmap_bytes(n) + 8)
+                D.call("agpu_broadcast", capi.BOOL, v, out.vp, n)
+                assert bits_equal(D.down(out, np.uint8, O.bitmap_bytes(n)), O.broadcast(O.BOOL, v, n))
+            continue
+        v = rand_values(dtype, 1, 21, special=False)
+        raw = np.zeros(4, np.uint8)
+        raw[: v.nbytes] = v.view(np.uint8)
+        nbytes = n * v.itemsize
+        out = D.empty(nbytes + 16)
+        D.call("agpu_broadcast", dtype, int(raw.view(np.uint32)[0]), out.vp, n)
+        assert bits_equal(D.down(out, NP[dtype], n), np.full(n, v[0], NP[dtype]))
+        D.call("agpu_broadcast_from_device", dtype, D.up(v).vp, out.vp, n)
+        assert bits_equal(D.down(out, NP[dtype], n), np.full(n, v[0], NP[dtype]))
+        # nothing past the last element was touched
+        assert (D.down(out, np.uint8, nbytes + 16)[nbytes:] == 0xCD).all()
+
+
+# ------------------------------------------------------------------ compare → bitmap (+ fused validity)
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
+@pytest.mark.parametrize("variant", [0, 1])
+def test_compare_all_ops(D, dtype, variant):
+    capi.call("agpu_set_tuning", b"cmp_variant", variant)
+    try:
+        for n in SIZES:
+            a, b = rand_values(dtype, n, 31), rand_values(dtype, n, 32)
+            if n:
+                b[::3] = a[::3]
+            nb = O.bitmap_bytes(n)
+            da, db = D.up(a), D.up(b)
+            va, vb = O.synth_bits(n, 41, 0, 0.9), O.synth_bits(n, 42, 0, 0.9)
+            dva, dvb = D.up(va), D.up(vb)
+            out, outv = D.empty(nb + 8), D.empty(nb + 8)
+            for op in range(5):
+                D.call("agpu_compare", op, dtype, da.vp, db.vp, out.vp, n)
+                exp = O.compare(op, dtype, a, b)
+                assert bits_equal(D.down(out, np.uint8, nb), exp), (op, n)  # padding bits are zero too
+                D.call("agpu_compare_validity", op, dtype, da.vp, db.vp, dva.vp, dvb.vp, out.vp, outv.vp, n)
+                assert bits_equal(D.down(out, np.uint8, nb), exp), ("fused", op, n)
+                assert bits_equal(D.down(outv, np.uint8, nb), O.bitmap_binary(O.OP_AND, va, vb, n)), ("validity", op, n)
+            # one side without validity → copy of the other; both absent → out_validity untouched
+            D.call("agpu_compare_validity", capi.CMP_EQ, dtype, da.vp, db.vp, None, dvb.vp, out.vp, outv.vp, n)
+            assert bits_equal(D.down(outv, np.uint8, nb), vb[:nb])
+    finally:
+        capi.call("agpu_set_tuning", b"cmp_variant", 0)
+
+
+def test_compare_f32_nan_inf_table(D):
+    a = np.array([-1, 3, np.nan, np.inf, -np.inf, -np.inf, np.inf, np.nan, 0.0, -0.0], dtype=np.float32)
+    b = np.array([0, 2, np.nan, np.inf, -np.inf, np.inf, -np.inf, 3, -0.0, 0.0], dtype=np.float32)
+    out = D.empty(16)
+    for op in range(5):
+        D.call("agpu_compare", op, capi.F32, D.up(a).vp, D.up(b).vp, out.vp, len(a))
+        assert bits_equal(D.down(out, np.uint8, 8), O.compare(op, O.F32, a, b))
+
+
+def test_compare_unaligned_inputs(D):
+    n = 70001
+    a, b = rand_values(capi.I16, n, 1), rand_values(capi.I16, n, 2)
+    out = D.empty(O.bitmap_bytes(n))
+    D.call("agpu_compare", capi.CMP_LT, capi.I16, D.up(a, 2).vp, D.up(b, 2).vp, out.vp, n)
+    assert bits_equal(D.down(out, np.uint8, O.bitmap_bytes(n)), O.compare(O.CMP_LT, O.I16, a, b))
+
+
+# ------------------------------------------------------------------ bitmaps
+def test_bitmap_ops_popcount_any(D):
+    for n in SIZES:
+        a, b, m, vm = (O.synth_bits(n, s, 0, p) for s, p in ((1, 0.5), (2, 0.5), (3, 0.5), (4, 0.9)))
+        nb = O.bitmap_bytes(n)
+        da, db, dm, dvm = D.up(a), D.up(b), D.up(m), D.up(vm)
+        out = D.empty(nb + 8)
+        for op in (capi.OP_AND, capi.OP_OR, capi.OP_XOR):
+            D.call("agpu_bitmap_binary", op, da.vp, db.vp, out.vp, n)
+            assert bits_equal(D.down(out, np.uint8, nb), O.bitmap_binary(op, a, b, n))
+        D.call("agpu_bitmap_not", da.vp, out.vp, n)
+        assert bits_equal(D.down(out, np.uint8, nb), O.bitmap_not(a, n))
+        D.call("agpu_merge_bits", da.vp, db.vp, dm.vp, out.vp, n)
+        assert bits_equal(D.down(out, np.uint8, nb), O.merge_bits(a, b, m, n))
+        for va, vb, vmm in ((a, b, vm), (None, b, vm), (a, None, None), (None, None, vm), (a, b, None)):
+            D.call("agpu_bitmap_merge_validity", da.vp if va is not None else None, db.vp if vb is not None else None,
+                   dm.vp, dvm.vp if vmm is not None else None, out.vp, n)
+            assert bits_equal(D.down(out, np.uint8, nb), O.merge_validity(va, vb, m, vmm, n))
+        cnt = D.empty(16)
+        # set the padding bits on purpose: only the first n bits may count
+        dirty = a.copy()
+        if n % 64:
+            dirty[n // 8] |= np.uint8((0xFF << (n % 8)) & 0xFF)
+            dirty[n // 8 + 1: nb] = 0xFF
+        D.call("agpu_bitmap_popcount", D.up(dirty).vp, n, cnt.vp)
+        assert int(D.down(cnt, np.uint64, 1)[0]) == O.bitmap_popcount(a, n)
+        D.call("agpu_bitmap_any", da.vp, n, cnt.vp)
+        assert bool(D.down(cnt, np.uint32, 1)[0]) == O.bitmap_any(a, n)
+    zero = np.zeros(O.bitmap_bytes(100000), np.uint8)
+    cnt = D.empty(16)
+    D.call("agpu_bitmap_any", D.up(zero).vp, 100000, cnt.vp)
+    assert D.down(cnt, np.uint32, 1)[0] == 0
+    assert D.status("agpu_bitmap_merge_validity", None, None, D.up(zero).vp, None, cnt.vp, 8) == capi.ERR_ARG
+
+
+# ------------------------------------------------------------------ reductions
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 511, 65535, 65536, 65537, 131072, 200001, 16777216 + 7])
+def test_f32_sum_is_bit_identical_to_the_reference_tree(D, n):
+    x = O.synth_f32(n, 77, 0, -1000.0, 1000.0)
+    out = D.empty(16)
+    D.call("agpu_reduce", capi.RED_SUM, capi.F32, D.up(x).vp, None, n, out.vp)
+    got = D.down(out, np.float32, 1)
+    exp = np.array([O.reduce(O.RED_SUM, O.F32, x)], np.float32)
+    assert bits_equal(got, exp), (n, got, exp)
+
+
+def test_f32_sum_reference_kats_and_specials(D):
+    out = D.empty(16)
+    for n in (65536, 4 * 1024 * 1024):  # test_f32_sum / test_f32_sum_large (crates/arithmetic/src/f32.rs:267-289)
+        D.call("agpu_reduce", capi.RED_SUM, capi.F32, D.up(np.full(n, 5.0, np.float32)).vp, None, n, out.vp)
+        assert D.down(out, np.float32, 1)[0] == np.float32(5.0 * n)
+    for special in ([-0.0] * 256, [-0.0] * 257, [np.inf, 1.0, 2.0], [np.inf, -np.inf], [np.nan, 1.0], [3.0e38] * 4):
+        x = np.array(special, np.float32)
+        D.call("agpu_reduce", capi.RED_SUM, capi.F32, D.up(x).vp, None, len(x), out.vp)
+        assert nan_aware_bits_equal(D.down(out, np.float32, 1), np.array([O.reduce(O.RED_SUM, O.F32, x)], np.float32)), special
+
+
+@pytest.mark.parametrize("dtype", [capi.F32, capi.I32, capi.U32])
+def test_reduce_min_max_sum_with_and_without_validity(D, dtype):
+    out = D.empty(16)
+    for n in SIZES:
+        x = rand_values(dtype, n, 55)
+        v = O.synth_bits(n, 56, 0, 0.8)
+        dx, dv = D.up(x), D.up(v)
+        ops = [capi.RED_MIN, capi.RED_MAX] + ([capi.RED_SUM] if dtype != capi.F32 else [])
+        for op in ops:
+            for val, dval in ((None, None), (v, dv.vp)):
+                D.call("agpu_reduce", op, dtype, dx.vp, dval, n, out.vp)
+                got = D.down(out, NP[dtype], 1)
+                exp = np.array([O.reduce(op, dtype, x, val)], NP[dtype])
+                assert nan_aware_bits_equal(got, exp), (op, n, val is not None, got, exp)
+        if dtype == capi.F32:  # null-aware tree sum (extension): nulls count as +0.0
+            xf = np.where(np.isnan(x), np.float32(1.0), x)  # keep the comparison finite
+            D.call("agpu_reduce", capi.RED_SUM, dtype, D.up(xf).vp, dv.vp, n, out.vp)
+            got = D.down(out, np.float32, 1)
+            assert nan_aware_bits_equal(got, np.array([O.reduce(O.RED_SUM, O.F32, xf, v)], np.float32)), n
+
+
+def test_reduce_all_nan_and_unaligned(D):
+    out = D.empty(16)
+    x = np.full(1000, np.nan, np.float32)
+    for op in (capi.RED_MIN, capi.RED_MAX):
+        D.call("agpu_reduce", op, capi.F32, D.up(x).vp, None, len(x), out.vp)
+        assert np.isnan(D.down(out, np.float32, 1)[0])
+    y = O.synth_f32(100003, 5, 0, -1, 1)
+    for op in (capi.RED_SUM, capi.RED_MIN, capi.RED_MAX):
+        D.call("agpu_reduce", op, capi.F32, D.up(y, 4).vp, None, len(y), out.vp)
+        assert bits_equal(D.down(out, np.float32, 1), np.array([O.reduce(op, O.F32, y)], np.float32)), op
+
+
+def test_sum_f64_accumulator(D):
+    out = D.empty(16)
+    for n in (0, 1, 4097, 1 << 22):
+        x = O.synth_f32(n, 9, 0, -1, 1)
+        D.call("agpu_reduce_sum_f64", D.up(x).vp, None, n, out.vp)
+        got = float(D.down(out, np.float64, 1)[0])
+        exact = float(np.sum(x.astype(np.float64)))
+        assert abs(got - exact) <= 1e-9 * max(1.0, float(np.sum(np.abs(x.astype(np.float64)))))
+
+
+# ------------------------------------------------------------------ swizzle
+@pytest.mark.parametrize("width,npd", [(4, np.uint32), (2, np.uint16), (1, np.uint8)])
+def test_take_put_merge_values(D, width, npd):
+    rng = np.random.default_rng(width)
+    for n_values, n_idx in ((1, 100), (1000, 0), (1000, 1), (5000, 4099), (100000, 300007)):
+        values = rng.integers(0, np.iinfo(npd).max, n_values).astype(npd)
+        idx = rng.integers(0, n_values, n_idx).astype(np.uint32)
+        out = D.empty(max(n_idx * width, 1))
+        D.call("agpu_take", width, D.up(values).vp, n_values, D.up(idx).vp, out.vp, n_idx)
+        assert bits_equal(D.down(out, npd, n_idx), O.take(width, values, idx))
+        # put with unique destinations (duplicates are unspecified in the reference)
+        n_dst = n_values + 17
+        dst = rng.integers(0, np.iinfo(npd).max, n_dst).astype(npd)
+        k = min(n_idx, n_dst)
+        di = rng.permutation(n_dst)[:k].astype(np.uint32)
+        si = idx[:k]
+        ddst = D.up(dst)
+        D.call("agpu_put", width, D.up(values).vp, D.up(si).vp, ddst.vp, D.up(di).vp, k)
+        assert bits_equal(D.down(ddst, npd, n_dst), O.put(width, values, si, dst, di))
+    for n in SIZES:
+        a = rng.integers(0, np.iinfo(npd).max, n).astype(npd)
+        b = rng.integers(0, np.iinfo(npd).max, n).astype(npd)
+        m = O.synth_bits(n, 8, 0, 0.5)
+        out = D.empty(max(n * width, 1))
+        D.call("agpu_merge", width, D.up(a).vp, D.up(b).vp, D.up(m).vp, out.vp, n)
+        assert bits_equal(D.down(out, npd, n), O.merge(width, a, b, m))
+
+
+def test_take_put_bits_and_index_max(D):
+    rng = np.random.default_rng(99)
+    for n_bits, n_idx in ((1, 100), (77, 64), (10000, 65), (100000, 200001)):
+        bits = O.synth_bits(n_bits, 1, 0, 0.5)
+        idx = rng.integers(0, n_bits, n_idx).astype(np.uint32)
+        out = D.empty(O.bitmap_bytes(n_idx) + 8)
+        D.call("agpu_take_bits", D.up(bits).vp, n_bits, D.up(idx).vp, out.vp, n_idx)
+        assert bits_equal(D.down(out, np.uint8, O.bitmap_bytes(n_idx)), O.take_bits(bits, n_bits, idx))
+        n_dst = n_bits + 100
+        dst = O.synth_bits(n_dst, 2, 0, 0.5)
+        k = min(n_idx, n_dst)
+        di = rng.permutation(n_dst)[:k].astype(np.uint32)
+        ddst = D.up(dst)
+        D.call("agpu_put_bits", D.up(bits).vp, D.up(idx[:k]).vp, ddst.vp, D.up(di).vp, k)
+        assert bits_equal(D.down(ddst, np.uint8, O.bitmap_bytes(n_dst)), O.put_bits(bits, idx[:k], dst, di))
+        mx = D.empty(16)
+        D.call("agpu_index_max", D.up(idx).vp, n_idx, mx.vp)
+        assert int(D.down(mx, np.uint32, 1)[0]) == O.index_max(idx)
+
+
+# ------------------------------------------------------------------ by-name shim, synth, checksum, graphs
+def test_launch_by_name_matches_typed_entry_points(D):
+    n = 4099
+    a, b = rand_values(capi.F32, n, 1), rand_values(capi.F32, n, 2)
+    ia, ib = rand_values(capi.I32, n, 3), rand_values(capi.I32, n, 4)
+    u8 = rand_values(capi.U8, n, 5)
+    out = D.empty(4 * n + 64)
+    lib = capi.lib()
+
+    def by_name(key, entry, inputs, n_out):
+        arr = (C.c_void_p * len(inputs))(*[p.vp for p in inputs])
+        capi.check(lib.agpu_launch_by_name(D.h, key, entry, arr, len(inputs), out.vp, n_out), entry.decode())
+
+    by_name(b"arithmetic/f32/array", b"add_f32", [D.up(a), D.up(b)], n)
+    assert nan_aware_bits_equal(D.down(out, np.float32, n), O.binary(O.OP_ADD, O.F32, a, b))
+    by_name(b"arithmetic/i32/scalar", b"i32_mul", [D.up(ia), D.up(ib[:1])], n)
+    assert bits_equal(D.down(out, np.int32, n), O.scalar(O.OP_MUL, O.I32, ia, ib[:1]))
+    by_name(b"compare/i32/cmp", b"lteq", [D.up(ia), D.up(ib)], n)
+    assert bits_equal(D.down(out, np.uint8, O.bitmap_bytes(n)), O.compare(O.CMP_LTEQ, O.I32, ia, ib))
+    by_name(b"cast/u8/cast_f32", b"cast_f32", [D.up(u8)], n)
+    assert bits_equal(D.down(out, np.float32, n), O.cast(O.U8, O.F32, u8))
+    by_name(b"logical/u32/logical", b"bitwise_xor", [D.up(ia.view(np.uint32)), D.up(ib.view(np.uint32))], n)
+    assert bits_equal(D.down(out, np.uint32, n), O.binary(O.OP_XOR, O.U32, ia.view(np.uint32), ib.view(np.uint32)))
+    by_name(b"arithmetic/f32/aggregate", b"sum", [D.up(a)], n)
+    af = np.where(np.isfinite(a), a, np.float32(0))
+    by_name(b"arithmetic/f32/aggregate", b"sum", [D.up(af)], n)
+    assert bits_equal(D.down(out, np.float32, 1), np.array([O.reduce(O.RED_SUM, O.F32, af)], np.float32))
+    by_name(b"array/f32/broadcast", b"broadcast", [D.up(a[:1] * 0 + np.float32(2.5))], n)
+    assert (D.down(out, np.float32, n) == 2.5).all()
+    arr = (C.c_void_p * 1)(D.up(a).vp)
+    assert lib.agpu_launch_by_name(D.h, b"arithmetic/f32/array", b"nope", arr, 1, out.vp, n) == capi.ERR_UNSUPPORTED
+
+
+def test_synthetic_generators_and_checksum_match_oracle(D):
+    for n, row0 in ((0, 0), (1, 5), (4099, 0), (100003, 1 << 33)):
+        out = D.empty(max(4 * n, 8))
+        D.call("agpu_synth_f32", out.vp, n, 20250418, row0, C.c_float(-1000.0), C.c_float(1000.0))
+        assert bits_equal(D.down(out, np.float32, n), O.synth_f32(n, 20250418, row0, -1000.0, 1000.0))
+        D.call("agpu_synth_i32", out.vp, n, 7, row0, 1024)
+        assert bits_equal(D.down(out, np.int32, n), O.synth_i32(n, 7, row0, 1024))
+        D.call("agpu_synth_u8", out.vp, n, 8, row0)
+        assert bits_equal(D.down(out, np.uint8, n), O.synth_u8(n, 8, row0))
+        bout = D.empty(O.bitmap_bytes(n) + 8)
+        D.call("agpu_synth_bits", bout.vp, n, 9, row0, C.c_double(0.9))
+        assert bits_equal(D.down(bout, np.uint8, O.bitmap_bytes(n)), O.synth_bits(n, 9, row0, 0.9))
+        x = O.synth_u8(n, 10, 0)
+        cs = D.empty(16)
+        D.call("agpu_checksum", D.up(x).vp, x.nbytes, cs.vp)
+        assert int(D.down(cs, np.uint64, 1)[0]) == O.checksum(x)
+
+
+def test_graph_capture_replays_an_op_chain(D):
+    """examples/simple.rs-style chain ((a + s) * s) captured once into a hipGraph and replayed."""
+    n = 100000
+    a = O.synth_f32(n, 1, 0, -10, 10)
+    s = np.array([20.0], np.float32)
+    da, ds = D.up(a), D.up(s)
+    t, out = D.empty(4 * n), D.empty(4 * n)
+    g = C.c_void_p()
+    D.call("agpu_pipeline_begin_capture")
+    D.call("agpu_scalar", capi.OP_ADD, capi.F32, da.vp, ds.vp, t.vp, n)
+    D.call("agpu_scalar", capi.OP_MUL, capi.F32, t.vp, ds.vp, out.vp, n)
+    D.call("agpu_pipeline_end_capture", C.byref(g))
+    exp = O.scalar(O.OP_MUL, O.F32, O.scalar(O.OP_ADD, O.F32, a, s), s)
+    for _ in range(3):
+        capi.call("agpu_memset", D.h, out.vp, 0, 4 * n)
+        capi.call("agpu_graph_launch", g, D.h)
+        assert bits_equal(D.down(out, np.float32, n), exp)
+    capi.call("agpu_graph_destroy", g)
+
+
+def test_two_pipelines_from_two_threads(D):
+    import threading
+
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline
+
+    errs = []
+
+    def work(seed):
+        try:
+            p = ArrowComputePipeline(D.dev, f"t{seed}")
+            n = 200003
+            a, b = O.synth_f32(n, seed, 0, -1, 1), O.synth_f32(n, seed + 100, 0, -1, 1)
+            da, db = D.dev.create_gpu_buffer_with_data(a), D.dev.create_gpu_buffer_with_data(b)
+            out = D.dev.create_empty_buffer(4 * n)
+            for _ in range(20):
+                capi.call("agpu_binary", p._handle, capi.OP_ADD, capi.F32, C.c_void_p(da.ptr), C.c_void_p(db.ptr),
+                          C.c_void_p(out.ptr), n)
+            got = np.empty(n, np.float32)
+            capi.call("agpu_download", p._handle, C.c_void_p(got.ctypes.data), C.c_void_p(out.ptr), 4 * n)
+            assert bits_equal(got, a + b)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
