@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch of synthetic 1-billion-row columns resident in HBM:
+    1. f32 add      : Float32ArrayGPU + Float32ArrayGPU, 1e9 rows, no nulls              → 12.0 GB algorithmic
+    2. i32 eq       : Int32ArrayGPU == Int32ArrayGPU → packed bitmap, fused validity AND,
+                      1e9 rows, 10 % nulls on each side                                   →  8.5 GB algorithmic
+(BASELINE.json configs[1] and configs[2]; both are what `metric` is quoted on.)  value = algorithmic GB moved by all
+ranks per second.  Inputs are generated on the device (counter-based hash, include/arrow_gpu.h agpu_synth_*), outputs
+are pre-allocated; nothing but the two kernel launches per step is inside the timed region.
+
+N > 1 (launched by torch.distributed.run, one process per GPU): every rank owns its own 1e9-row shard of a
+N×1e9-row column (row0 = rank·1e9) — chunk-sharded, no data-path collective, "scaling": "weak".  RCCL (torch
+"nccl" backend) is used only for the barrier/timing reduction and, after the timed region, for the final reduce of the
+per-shard sum/min/max (config 5), reported under "extra".
+
+Also printed in the same JSON line:
+  roofline     — the dominant kernel (f32 add), algorithmic bytes per launch ÷ its mean duration measured with HIP
+                 events on the launch stream over the timed region, against 8 TB/s HBM3E.
+  cpu_baseline — the CPU port (oracle/cpu_baseline.c, arrow-rs-style single pass) timed on this box's host cores on
+                 a bounded sample (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ROWS = 1_000_000_000
+SEED = 20250418
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ADD_BYTES_PER_ROW = 12.0
+EQ_BYTES_PER_ROW = 8.5  # 8 data + 0.125 result bits + 0.375 validity in/out
+
+
+def cpu_baseline(sample_rows: int):
+    """Time the CPU port on a bounded sample of the same workload.  Test/bench infrastructure only (oracle/)."""
+    import numpy as np
+
+    import oracle as O
+
+    build_dir = os.path.join(ROOT, "oracle", "_build")
+    os.makedirs(build_dir, exist_ok=True)
+    so = os.path.join(build_dir, "libcpu_baseline_native.so")
+    src = os.path.join(ROOT, "oracle", "cpu_baseline.c")
+    try:  # build for THIS host's ISA (the prebuilt copy was compiled on another machine)
+        subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-fopenmp", "-shared",
+                        "-o", so, src, "-lm"], check=True, capture_output=True, timeout=120)
+    except Exception:
+        so = os.path.join(build_dir, "libcpu_baseline.so")
+    lib = C.CDLL(so)
+    n = sample_rows
+    a = O.synth_f32(n, SEED, 0, -1000.0, 1000.0)
+    b = O.synth_f32(n, SEED + 1, 0, -1000.0, 1000.0)
+    out = np.empty(n, np.float32)
+    ia = O.synth_i32(n, SEED + 2, 0, 1024)
+    ib = O.synth_i32(n, SEED + 3, 0, 1024)
+    va = O.synth_bits(n, SEED + 4, 0, 0.9)
+    vb = O.synth_bits(n, SEED + 5, 0, 0.9)
+    ob = np.empty(O.bitmap_bytes(n), np.uint8)
+    ov = np.empty(O.bitmap_bytes(n), np.uint8)
+    p = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
+    cores = os.cpu_count() or 1
+
+    def one_pass(threads):
+        lib.base_add_f32(p(a), p(b), p(out), None, None, None, C.c_uint64(n), threads)
+        lib.base_eq_i32(p(ia), p(ib), p(ob), p(va), p(vb), p(ov), C.c_uint64(n), threads)
+
+    def rate(threads, budget_s):
+        one_pass(threads)
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            one_pass(threads)
+            k += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or k >= 50:
+                break
+        return (ADD_BYTES_PER_ROW + EQ_BYTES_PER_ROW) * n * k / dt / 1e9
+
+    # spot-check the port against the oracle before timing it
+    m = min(n, 1 << 16)
+    one_pass(1)
+    assert np.array_equal(out[:m], O.binary(O.OP_ADD, O.F32, a[:m], b[:m]))
+    assert np.array_equal(ob[: m // 8], O.compare(O.CMP_EQ, O.I32, ia[:m], ib[:m])[: m // 8])
+    v1 = rate(1, 8.0)
+    vall = rate(cores, 5.0)
+    return {"value": round(v1, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{n} rows of the same synthetic columns (f32 add + i32 eq with validity), repeated passes, "
+                      f"single thread like arrow-rs's kernels",
+            "all_cores": {"value": round(vall, 3), "cores": cores}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=ROWS, help="rows per GPU shard (default 1e9 = the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from arrow_gpu_amd import _capi as capi
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+
+    n = args.rows
+    dev = GpuDevice(local_rank)
+    p = ArrowComputePipeline(dev, "bench")
+    h = p._handle
+    row0 = rank * n  # this rank's shard of the world×n-row column
+    vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
+    nb = (n + 63) // 64 * 8
+
+    fa, fb, fo = (dev.create_empty_buffer(4 * n) for _ in range(3))
+    ia, ib = dev.create_empty_buffer(4 * n), dev.create_empty_buffer(4 * n)
+    va, vb, ob, ov = (dev.create_empty_buffer(nb) for _ in range(4))
+    capi.call("agpu_synth_f32", h, vp(fa), n, SEED, row0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_f32", h, vp(fb), n, SEED + 1, row0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_i32", h, vp(ia), n, SEED + 2, row0, 1024)
+    capi.call("agpu_synth_i32", h, vp(ib), n, SEED + 3, row0, 1024)
+    capi.call("agpu_synth_bits", h, vp(va), n, SEED + 4, row0, C.c_double(0.9))
+    capi.call("agpu_synth_bits", h, vp(vb), n, SEED + 5, row0, C.c_double(0.9))
+    p.sync()
+
+    def ev():
+        e = C.c_void_p()
+        capi.call("agpu_event_create", dev._handle, C.byref(e))
+        return e
+
+    add_ev = [(ev(), ev()) for _ in range(args.steps)]
+    eq_ev = [(ev(), ev()) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            capi.call("agpu_event_record", add_ev[i][0], h)
+        capi.call("agpu_binary", h, capi.OP_ADD, capi.F32, vp(fa), vp(fb), vp(fo), n)
+        if i is not None:
+            capi.call("agpu_event_record", add_ev[i][1], h)
+            capi.call("agpu_event_record", eq_ev[i][0], h)
+        capi.call("agpu_compare_validity", h, capi.CMP_EQ, capi.I32, vp(ia), vp(ib), vp(va), vp(vb), vp(ob), vp(ov), n)
+        if i is not None:
+            capi.call("agpu_event_record", eq_ev[i][1], h)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    def mean_ms(pairs):
+        tot = 0.0
+        for s, e in pairs:
+            ms = C.c_float()
+            capi.call("agpu_event_elapsed_ms", s, e, C.byref(ms))
+            tot += ms.value
+        return tot / max(len(pairs), 1)
+
+    add_ms, eq_ms = mean_ms(add_ev), mean_ms(eq_ev)
+    step_bytes = (ADD_BYTES_PER_ROW + EQ_BYTES_PER_ROW) * n
+    value = step_bytes * args.steps * world / elapsed / 1e9
+    add_gbps = ADD_BYTES_PER_ROW * n / add_ms / 1e6
+    eq_gbps = EQ_BYTES_PER_ROW * n / eq_ms / 1e6
+
+    # ---- parity guard on the benchmarked buffers: windows of the 1e9-row outputs vs the oracle (rank 0 only)
+    parity = None
+    if rank == 0:
+        import numpy as np
+
+        import oracle as O
+
+        ok = True
+        w = 1 << 16
+        for start in (0, (n // 2) // 64 * 64, max(0, (n - w) // 64 * 64)):
+            cnt = min(w, n - start)
+            got = np.empty(cnt, np.float32)
+            capi.call("agpu_download", h, C.c_void_p(got.ctypes.data), C.c_void_p(fo.ptr + 4 * start), 4 * cnt)
+            exp = O.binary(O.OP_ADD, O.F32, O.synth_f32(cnt, SEED, row0 + start, -1000.0, 1000.0),
+                           O.synth_f32(cnt, SEED + 1, row0 + start, -1000.0, 1000.0))
+            ok &= bool(np.array_equal(got.view(np.uint32), exp.view(np.uint32)))
+            nbytes = (cnt + 7) // 8
+            gb = np.empty(nbytes, np.uint8)
+            gv = np.empty(nbytes, np.uint8)
+            capi.call("agpu_download", h, C.c_void_p(gb.ctypes.data), C.c_void_p(ob.ptr + start // 8), nbytes)
+            capi.call("agpu_download", h, C.c_void_p(gv.ctypes.data), C.c_void_p(ov.ptr + start // 8), nbytes)
+            eb = O.compare(O.CMP_EQ, O.I32, O.synth_i32(cnt, SEED + 2, row0 + start, 1024), O.synth_i32(cnt, SEED + 3, row0 + start, 1024))
+            evd = O.bitmap_binary(O.OP_AND, O.synth_bits(cnt, SEED + 4, row0 + start, 0.9), O.synth_bits(cnt, SEED + 5, row0 + start, 0.9), cnt)
+            full = cnt // 8
+            ok &= bool(np.array_equal(gb[:full], eb[:full]) and np.array_equal(gv[:full], evd[:full]))
+        parity = "bit-exact vs oracle on 3 windows of 65536 rows (first/middle/last)" if ok else "MISMATCH"
+
+    # ---- config 5: per-shard sum/min/max + final reduce over RCCL (outside the timed region)
+    extra = {}
+    red = torch.zeros(1, dtype=torch.float64, device="cuda")
+    mn = torch.zeros(1, dtype=torch.float32, device="cuda")
+    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+    rs, re_ = ev(), ev()
+    capi.call("agpu_event_record", rs, h)
+    capi.call("agpu_reduce_sum_f64", h, vp(fa), None, n, C.c_void_p(red.data_ptr()))
+    capi.call("agpu_reduce", h, capi.RED_MIN, capi.F32, vp(fa), None, n, C.c_void_p(mn.data_ptr()))
+    capi.call("agpu_reduce", h, capi.RED_MAX, capi.F32, vp(fa), None, n, C.c_void_p(mx.data_ptr()))
+    capi.call("agpu_event_record", re_, h)
+    p.sync()
+    ms = C.c_float()
+    capi.call("agpu_event_elapsed_ms", rs, re_, C.byref(ms))
+    if world > 1:
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    extra["reduce_sum_min_max"] = {"rows_total": n * world, "sum": float(red.item()), "min": float(mn.item()),
+                                   "max": float(mx.item()), "per_gpu_GBps": round(3 * 4.0 * n / ms.value / 1e6, 1),
+                                   "final_reduce": "RCCL all_reduce of 1 element per statistic" if world > 1 else "none (1 GPU)"}
+    extra["kernels"] = {"add_f32": {"ms": round(add_ms, 4), "GBps": round(add_gbps, 1), "frac_hbm_peak": round(add_gbps / HBM_PEAK_GBPS, 4)},
+                        "eq_i32_validity": {"ms": round(eq_ms, 4), "GBps": round(eq_gbps, 1), "frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4)}}
+    extra["parity"] = parity
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        if os.path.exists(tpath) and n == ROWS:
+            try:
+                traffic = json.load(open(tpath)).get("add_f32_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "GB/s on 1B-row f32 add + i32 eq (algorithmic bytes, inputs resident in HBM)",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32+i32", "data": "synthetic",
+            "config": {"workload": "f32 add (1e9 rows, no nulls) + i32 eq -> bitmap with fused validity AND (1e9 rows, 10% nulls/side)",
+                       "rows_per_gpu": n, "sharding": f"chunk-sharded x{world}, no data-path collective",
+                       "frac_hbm_peak_per_gpu": round(value / world / HBM_PEAK_GBPS, 4)},
+            "roofline": {"bound": "hbm", "kernel": "ew_kernel<float, OpAdd> (agpu_binary ADD f32)",
+                         "achieved": round(add_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(add_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ADD_BYTES_PER_ROW * n, "launch_ms": round(add_ms, 4)},
+            "extra": extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows)
+            except Exception as e:  # noqa: BLE001
+                line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

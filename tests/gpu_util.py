@@ -21,6 +21,7 @@ class Dev:
     def __init__(self):
         self.dev = GpuDevice(0)
         self.p = ArrowComputePipeline(self.dev, "tests")
+        self._keep = []  # buffers stay alive until release(): `D.up(x).vp` temporaries must not be freed before the launch
 
     @property
     def h(self):
@@ -32,13 +33,21 @@ class Dev:
         buf = self.dev.create_empty_buffer(arr.nbytes + offset_bytes + 16)
         if arr.nbytes:
             capi.call("agpu_upload", self.h, C.c_void_p(buf.ptr + offset_bytes), C.c_void_p(arr.ctypes.data), arr.nbytes)
-        return _Ptr(buf, offset_bytes)
+        return self._hold(_Ptr(buf, offset_bytes))
+
+    def _hold(self, ptr):
+        self._keep.append(ptr)
+        return ptr
+
+    def release(self):
+        self.p.sync()
+        self._keep.clear()
 
     def empty(self, nbytes: int, offset_bytes: int = 0, fill: int | None = 0xCD):
         buf = self.dev.create_empty_buffer(nbytes + offset_bytes + 16)
         if fill is not None:
             capi.call("agpu_memset", self.h, C.c_void_p(buf.ptr), fill, nbytes + offset_bytes + 16)
-        return _Ptr(buf, offset_bytes)
+        return self._hold(_Ptr(buf, offset_bytes))
 
     def down(self, ptr, dtype, count: int) -> np.ndarray:
         out = np.empty(count, dtype=dtype)

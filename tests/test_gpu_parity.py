@@ -16,10 +16,16 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def D():
+def _dev():
     from gpu_util import Dev
 
     return Dev()
+
+
+@pytest.fixture()
+def D(_dev):
+    yield _dev
+    _dev.release()  # buffers created by a test live until its end (kernels are asynchronous)
 
 
 from gpu_util import (ALL_DTYPES, INT_DTYPES, NP, SIZES, SMALL_SIZES, bits_equal, max_ulp, nan_aware_bits_equal,  # noqa: E402
@@ -427,8 +433,9 @@ def test_launch_by_name_matches_typed_entry_points(D):
     assert bits_equal(D.down(out, np.float32, 1), np.array([O.reduce(O.RED_SUM, O.F32, af)], np.float32))
     by_name(b"array/f32/broadcast", b"broadcast", [D.up(a[:1] * 0 + np.float32(2.5))], n)
     assert (D.down(out, np.float32, n) == 2.5).all()
-    arr = (C.c_void_p * 1)(D.up(a).vp)
-    assert lib.agpu_launch_by_name(D.h, b"arithmetic/f32/array", b"nope", arr, 1, out.vp, n) == capi.ERR_UNSUPPORTED
+    arr = (C.c_void_p * 2)(D.up(a).vp, D.up(b).vp)
+    assert lib.agpu_launch_by_name(D.h, b"arithmetic/f32/array", b"nope", arr, 2, out.vp, n) == capi.ERR_UNSUPPORTED
+    assert lib.agpu_launch_by_name(D.h, b"arithmetic/f32/array", b"add_f32", arr, 1, out.vp, n) == capi.ERR_ARG
 
 
 def test_synthetic_generators_and_checksum_match_oracle(D):
