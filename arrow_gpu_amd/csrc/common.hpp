@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <utility>
 
 #include "../../include/arrow_gpu.h"
 
@@ -133,6 +134,18 @@ template <bool NT, typename V>
 __device__ __forceinline__ void st_vec(V* p, V v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p);
   else *p = v;
+}
+
+// Compile-time unrolled `for (u = 0; u < U; u++) f(u)`.  NOT a `#pragma unroll` loop on purpose: with U == 1 LICM sees a
+// single-trip loop whose store address is loop-invariant, promotes the store out of it and the re-created store loses
+// its !nontemporal metadata (found by diffing the ISA: the `nt` bit vanished and the add stream lost 7 %).
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int U, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, U>{});
 }
 
 __device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {

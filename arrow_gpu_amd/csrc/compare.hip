@@ -42,14 +42,17 @@ __device__ __forceinline__ uint64_t validity_word(const uint64_t* va, const uint
 }
 
 // ---------------------------------------------------------------- variant 0: ballot
+// R = rounds per wave tile (R output u64 words per wave).  R = 4 with 256-thread blocks (1024 rows per block) measured
+// best at 1e9 rows (6.07 TB/s vs 5.89 at R = 16: profiles/r01_sweep_add_eq_1e9_b.json).  Full tiles only; the
+// remainder is a separate tiny launch of cmp_word_kernel.
+#define CMP_R 4
 template <typename T, int OP, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, const T* b, const uint64_t* va,
                                                                const uint64_t* vb, uint64_t* out, uint64_t* outv,
-                                                               uint64_t n) {
-  constexpr int R = 16;                                   // rounds per wave tile → 16 output u64 words
-  constexpr uint64_t WAVE_TILE = (uint64_t)AGPU_WAVE * R;  // 1024 rows
+                                                               uint64_t ntiles) {
+  constexpr int R = CMP_R;
+  constexpr uint64_t WAVE_TILE = (uint64_t)AGPU_WAVE * R;
   constexpr uint64_t TILE = WAVE_TILE * (AGPU_BLOCK / AGPU_WAVE);
-  const uint64_t ntiles = n / TILE;
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
   const uint32_t wave = threadIdx.x / AGPU_WAVE;
   const bool do_v = outv != nullptr;
@@ -76,13 +79,6 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, cons
       if (do_v) outv[w0 + lane] = vword;
     }
   }
-  if (blockIdx.x == ntiles % gridDim.x) {  // < TILE rows left: one guarded word per thread
-    const uint64_t nwords = (n + 63) / 64;
-    for (uint64_t w = ntiles * TILE / 64 + threadIdx.x; w < nwords; w += AGPU_BLOCK) {
-      out[w] = cmp_word_guarded<OP, T>(a, b, w, n);
-      if (do_v) outv[w] = validity_word(va, vb, w);
-    }
-  }
 }
 
 // ---------------------------------------------------------------- variant 1: 16-byte vector loads + lane-group OR
@@ -94,12 +90,10 @@ struct CmpPack {
 template <typename T, int OP, int U, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T* b, const uint32_t* va,
                                                             const uint32_t* vb, uint32_t* out, uint32_t* outv,
-                                                            uint64_t n) {
+                                                            uint64_t ntiles) {
   constexpr int N = 16 / sizeof(T);  // rows per lane per vector: 4, 8 or 16
   constexpr int G = 32 / N;          // lanes per 32-bit output word: 8, 4 or 2
   constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;
-  constexpr uint64_t TILE = TILE_PACKS * N;
-  const uint64_t ntiles = n / TILE;
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
   const bool do_v = outv != nullptr;
 
@@ -130,24 +124,17 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T
       }
     }
   }
-  if (blockIdx.x == ntiles % gridDim.x) {
-    const uint64_t nwords = (n + 63) / 64;  // 64-bit granules so the 8-byte padded bitmap is fully written
-    const uint64_t* va64 = reinterpret_cast<const uint64_t*>(va);
-    const uint64_t* vb64 = reinterpret_cast<const uint64_t*>(vb);
-    for (uint64_t w = ntiles * TILE / 64 + threadIdx.x; w < nwords; w += AGPU_BLOCK) {
-      reinterpret_cast<uint64_t*>(out)[w] = cmp_word_guarded<OP, T>(a, b, w, n);
-      if (do_v) reinterpret_cast<uint64_t*>(outv)[w] = validity_word(va64, vb64, w);
-    }
-  }
 }
 
-// element-granular fallback (inputs not 16-byte aligned): one 64-bit word per thread
+// one guarded 64-bit output word per thread, words [first_word, ceil(n/64)): the tail of the tiled kernels and the
+// element-granular fallback for inputs that are not 16-byte aligned (whole 8-byte padded bitmap is written)
 template <typename T, int OP>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_word_kernel(const T* a, const T* b, const uint64_t* va,
                                                              const uint64_t* vb, uint64_t* out, uint64_t* outv,
-                                                             uint64_t n) {
+                                                             uint64_t first_word, uint64_t n) {
   const uint64_t nwords = (n + 63) / 64;
-  for (uint64_t w = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; w < nwords; w += (uint64_t)gridDim.x * AGPU_BLOCK) {
+  for (uint64_t w = first_word + (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; w < nwords;
+       w += (uint64_t)gridDim.x * AGPU_BLOCK) {
     out[w] = cmp_word_guarded<OP, T>(a, b, w, n);
     if (outv) outv[w] = validity_word(va, vb, w);
   }
@@ -158,28 +145,41 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
                               void* out, void* outv, uint64_t n) {
   const T* pa = static_cast<const T*>(a);
   const T* pb = static_cast<const T*>(b);
-  constexpr int U = 2;
+  constexpr int U = 1;
   const bool use_ballot = sizeof(T) == 4 && g_tune.cmp_variant == 0;
-  const bool nt = (g_tune.stream_nt & 1) != 0;  // inputs are read exactly once: nontemporal loads (+measured, profiles/)
+  const bool nt = (g_tune.stream_nt & 1) != 0;  // inputs are read exactly once: nontemporal loads
+  const uint64_t* va64 = static_cast<const uint64_t*>(va);
+  const uint64_t* vb64 = static_cast<const uint64_t*>(vb);
+  uint64_t* out64 = static_cast<uint64_t*>(out);
+  uint64_t* outv64 = static_cast<uint64_t*>(outv);
+  uint64_t done_rows = 0;  // rows covered by the tiled kernel (a multiple of 64)
   if (use_ballot) {
-    const uint64_t ntiles = n / (1024 * (AGPU_BLOCK / AGPU_WAVE));
-    const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
-    auto k = nt ? cmp_ballot_kernel<T, OP, true> : cmp_ballot_kernel<T, OP, false>;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, static_cast<const uint64_t*>(va),
-                       static_cast<const uint64_t*>(vb), static_cast<uint64_t*>(out), static_cast<uint64_t*>(outv), n);
+    constexpr uint64_t TILE = (uint64_t)AGPU_WAVE * CMP_R * (AGPU_BLOCK / AGPU_WAVE);
+    const uint64_t ntiles = n / TILE;
+    if (ntiles) {
+      const int grid = stream_grid_for(p, ntiles);
+      auto k = nt ? cmp_ballot_kernel<T, OP, true> : cmp_ballot_kernel<T, OP, false>;
+      hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, va64, vb64, out64, outv64, ntiles);
+    }
+    done_rows = ntiles * TILE;
   } else if (aligned16(a) && aligned16(b)) {
     constexpr int N = 16 / sizeof(T);
-    const uint64_t ntiles = n / ((uint64_t)AGPU_BLOCK * U * N);
-    const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
-    auto k = nt ? cmp_vec_kernel<T, OP, U, true> : cmp_vec_kernel<T, OP, U, false>;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, static_cast<const uint32_t*>(va),
-                       static_cast<const uint32_t*>(vb), static_cast<uint32_t*>(out), static_cast<uint32_t*>(outv), n);
-  } else {
-    const uint64_t nwords = (n + 63) / 64;
-    const int grid = stream_grid_for(p, (nwords + AGPU_BLOCK - 1) / AGPU_BLOCK);
-    hipLaunchKernelGGL((cmp_word_kernel<T, OP>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb,
-                       static_cast<const uint64_t*>(va), static_cast<const uint64_t*>(vb), static_cast<uint64_t*>(out),
-                       static_cast<uint64_t*>(outv), n);
+    constexpr uint64_t TILE = (uint64_t)AGPU_BLOCK * U * N;
+    const uint64_t ntiles = n / TILE;
+    if (ntiles) {
+      const int grid = stream_grid_for(p, ntiles);
+      auto k = nt ? cmp_vec_kernel<T, OP, U, true> : cmp_vec_kernel<T, OP, U, false>;
+      hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, static_cast<const uint32_t*>(va),
+                         static_cast<const uint32_t*>(vb), static_cast<uint32_t*>(out), static_cast<uint32_t*>(outv),
+                         ntiles);
+    }
+    done_rows = ntiles * TILE;
+  }
+  if (done_rows < n) {
+    const uint64_t first_word = done_rows / 64, nwords = (n + 63) / 64;
+    const int grid = stream_grid_for(p, (nwords - first_word + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL((cmp_word_kernel<T, OP>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, va64, vb64, out64,
+                       outv64, first_word, n);
   }
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;

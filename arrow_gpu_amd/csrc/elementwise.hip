@@ -11,9 +11,11 @@
 // crates/arithmetic/src/lib.rs:24,67).
 //
 // MI355X design: every kernel is HBM-bound (roofline = 8 TB/s HBM3E; algorithmic bytes per row are listed in
-// DESIGN.md).  Each lane moves 16-byte vectors (global_load/store_dwordx4 = 1 KiB per wave instruction), keeps
-// AGPU_STREAM_U of them per input array in flight before the first use, and the grid is a fixed number of
-// blocks per CU that strides over tiles, so 256 CUs × 8 XCDs stay full without launching millions of blocks.
+// DESIGN.md).  Each lane moves 16-byte vectors (global_load/store_dwordx4 = 1 KiB per wave instruction) with the
+// nontemporal hint (every byte is touched once), AGPU_STREAM_U vectors per input array per lane, and — measured,
+// profiles/r01_sweep_add_f32_1e9.json — ONE 4 KiB-per-array tile per 256-thread block: ~10^6 small blocks at 1e9 rows
+// beat every persistent grid on this chip (6.5 vs 5.3 TB/s at 2048 blocks).  The kernels still grid-stride, so a
+// capped grid (agpu_set_tuning "stream_grid") stays correct.
 // Sub-word columns are read natively as packed bytes/halfwords (the WGSL u8/i8/u16/i16 unpack helpers vanish).
 // No LDS, no MFMA: there is no reuse and no contraction on this path.
 #include <type_traits>
@@ -33,21 +35,30 @@ template <typename T, int N>
 struct PackN {
   T v[N];
 };
-template <int B> struct RawBytes;
-template <> struct RawBytes<16> { typedef u32x4 type; };
-template <> struct RawBytes<8> { typedef u32x2 type; };
-template <> struct RawBytes<4> { typedef uint32_t type; };
+// Loads/stores go through the NATIVE vector type of T (float4, char16, short8 …), not a bit-cast u32x4: when the
+// value is bit-cast first, LLVM rewrites the store and DROPS the !nontemporal hint (the `nt` bit vanished from
+// global_store_dwordx4 and cost 7 % of the add bandwidth — caught by diffing the ISA against tools/probe).
+template <typename T, int N>
+struct VecOf {
+  typedef T type __attribute__((ext_vector_type(N)));
+};
 
 template <bool NT, typename T, int N>
 __device__ __forceinline__ PackN<T, N> load_pack(const T* p) {
-  typedef typename RawBytes<sizeof(T) * N>::type R;
-  R r = ld_vec<NT>(reinterpret_cast<const R*>(p));
-  return __builtin_bit_cast(PackN<T, N>, r);
+  typedef typename VecOf<T, N>::type V;
+  const V r = ld_vec<NT>(reinterpret_cast<const V*>(p));
+  PackN<T, N> out;
+#pragma unroll
+  for (int k = 0; k < N; k++) out.v[k] = r[k];
+  return out;
 }
 template <bool NT, typename T, int N>
 __device__ __forceinline__ void store_pack(T* p, const PackN<T, N>& v) {
-  typedef typename RawBytes<sizeof(T) * N>::type R;
-  st_vec<NT>(reinterpret_cast<R*>(p), __builtin_bit_cast(R, v));
+  typedef typename VecOf<T, N>::type V;
+  V r;
+#pragma unroll
+  for (int k = 0; k < N; k++) r[k] = v.v[k];
+  st_vec<NT>(reinterpret_cast<V*>(p), r);
 }
 
 // ---------------------------------------------------------------- scalar semantics (mirrors oracle/agpu_oracle.c)
@@ -174,45 +185,52 @@ struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { ret
 struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return sinhf(x); } };
 
 // ---------------------------------------------------------------- same-width streaming kernel
-// out[i] = Op(a[i], b[i] | *b | -) ; lane moves U packs of 16 B per array per iteration; block tile = 256*U packs.
+// out[i] = Op(a[i], b[i] | *b | -).  The hot kernel covers FULL tiles only and carries no tail code (the tail costs
+// registers and a branch in ~10^6 tiny blocks: −3 % measured); a second, tiny launch finishes the < 1-tile remainder.
+// Block = ONE wave (64 lanes), one 16-byte pack per lane per array: 1 KiB per array per block — the best shape of the
+// sweep in profiles/r01_sweep_add_eq_1e9_b.json (6.7 TB/s vs 6.4 at 256 threads, ≤5.9 persistent).
+#define AGPU_EW_BLOCK 64
+
 template <typename T, typename Op, int MODE, int U, int NT>
-__global__ __launch_bounds__(AGPU_BLOCK) void ew_kernel(const T* a, const T* b, T* out, uint64_t n) {
+__global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_kernel(const T* a, const T* b, T* out, uint64_t ntiles) {
   constexpr int N = 16 / sizeof(T);
   constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0;
-  const uint64_t npacks = n / N;
-  const uint64_t tile = (uint64_t)AGPU_BLOCK * U;
-  const uint64_t ntiles = npacks / tile;
+  constexpr uint64_t tile = (uint64_t)AGPU_EW_BLOCK * U;
   T sv = T();
   if constexpr (MODE == MODE_SCALAR) sv = b[0];
 
   for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const uint64_t p0 = t * tile + threadIdx.x;
     PackN<T, N> va[U], vb[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      va[u] = load_pack<NTL, T, N>(a + (p0 + (uint64_t)u * AGPU_BLOCK) * N);
-      if constexpr (MODE == MODE_BINARY) vb[u] = load_pack<NTL, T, N>(b + (p0 + (uint64_t)u * AGPU_BLOCK) * N);
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
+    static_for<U>([&](auto u) {
+      va[u] = load_pack<NTL, T, N>(a + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N);
+      if constexpr (MODE == MODE_BINARY) vb[u] = load_pack<NTL, T, N>(b + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N);
+    });
+    static_for<U>([&](auto u) {
       PackN<T, N> r;
 #pragma unroll
       for (int k = 0; k < N; k++) r.v[k] = Op::ap(va[u].v[k], MODE == MODE_BINARY ? vb[u].v[k] : sv);
-      store_pack<NTS, T, N>(out + (p0 + (uint64_t)u * AGPU_BLOCK) * N, r);
-    }
+      store_pack<NTS, T, N>(out + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N, r);
+    });
   }
-  // packs past the last full tile, then the < N-element tail: one block, the next owner in the round-robin
-  if (blockIdx.x == ntiles % gridDim.x) {
-    for (uint64_t pk = ntiles * tile + threadIdx.x; pk < npacks; pk += AGPU_BLOCK) {
-      PackN<T, N> x = load_pack<false, T, N>(a + pk * N), y, r;
-      if constexpr (MODE == MODE_BINARY) y = load_pack<false, T, N>(b + pk * N);
+}
+
+// rows [first, n): whole packs while they last, then single elements.  One small block; also serves tiny arrays.
+template <typename T, typename Op, int MODE>
+__global__ __launch_bounds__(AGPU_BLOCK) void ew_tail_kernel(const T* a, const T* b, T* out, uint64_t first, uint64_t n) {
+  constexpr int N = 16 / sizeof(T);
+  T sv = T();
+  if constexpr (MODE == MODE_SCALAR) sv = b[0];
+  const uint64_t npacks = n / N;
+  for (uint64_t pk = first / N + threadIdx.x; pk < npacks; pk += AGPU_BLOCK) {
+    PackN<T, N> x = load_pack<false, T, N>(a + pk * N), y, r;
+    if constexpr (MODE == MODE_BINARY) y = load_pack<false, T, N>(b + pk * N);
 #pragma unroll
-      for (int k = 0; k < N; k++) r.v[k] = Op::ap(x.v[k], MODE == MODE_BINARY ? y.v[k] : sv);
-      store_pack<false, T, N>(out + pk * N, r);
-    }
-    const uint64_t i = npacks * N + threadIdx.x;
-    if (i < n) out[i] = Op::ap(a[i], MODE == MODE_BINARY ? b[i] : sv);
+    for (int k = 0; k < N; k++) r.v[k] = Op::ap(x.v[k], MODE == MODE_BINARY ? y.v[k] : sv);
+    store_pack<false, T, N>(out + pk * N, r);
   }
+  const uint64_t i = npacks * N + threadIdx.x;
+  if (i >= first && i < n) out[i] = Op::ap(a[i], MODE == MODE_BINARY ? b[i] : sv);
 }
 
 // element-granular fallback for pointers that are not 16-byte aligned (e.g. odd shard offsets)
@@ -233,10 +251,16 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
   const bool vec_ok = aligned16(a) && aligned16(out) && (MODE != MODE_BINARY || aligned16(b));
   if (vec_ok) {
     constexpr int N = 16 / sizeof(T);
-    const uint64_t ntiles = n / N / ((uint64_t)AGPU_BLOCK * AGPU_STREAM_U);
-    const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
-    hipLaunchKernelGGL((ew_kernel<T, Op, MODE, AGPU_STREAM_U, AGPU_STREAM_NT>), dim3(grid), dim3(AGPU_BLOCK), 0,
-                       p->stream, pa, pb, po, n);
+    constexpr uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * AGPU_STREAM_U * N;
+    const uint64_t ntiles = n / tile_rows;
+    if (ntiles) {
+      const int grid = stream_grid_for(p, ntiles);
+      hipLaunchKernelGGL((ew_kernel<T, Op, MODE, AGPU_STREAM_U, AGPU_STREAM_NT>), dim3(grid), dim3(AGPU_EW_BLOCK), 0,
+                         p->stream, pa, pb, po, ntiles);
+    }
+    if (ntiles * tile_rows < n)
+      hipLaunchKernelGGL((ew_tail_kernel<T, Op, MODE>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
+                         ntiles * tile_rows, n);
   } else {
     const int grid = stream_grid_for(p, (n + AGPU_BLOCK - 1) / AGPU_BLOCK);
     hipLaunchKernelGGL((ew_kernel_unaligned<T, Op, MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po, n);
@@ -348,36 +372,36 @@ static agpu_status dispatch_binary(agpu_pipeline* p, agpu_binary_op op, agpu_dty
 // lane handles N = 16/max(sizeof(TI),sizeof(TO)) elements per step: the wide side moves 16 B/lane, the narrow
 // side N*sizeof bytes (4 or 8) — both sides stay fully coalesced (the reference's cast shaders store with stride 4).
 template <typename TI, typename TO, typename Conv, int U>
-__global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel(const TI* in, TO* out, uint64_t n) {
+__global__ __launch_bounds__(AGPU_EW_BLOCK) void cvt_kernel(const TI* in, TO* out, uint64_t ntiles) {
   constexpr int N = 16 / (sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
-  const uint64_t npacks = n / N;
-  const uint64_t tile = (uint64_t)AGPU_BLOCK * U;
-  const uint64_t ntiles = npacks / tile;
+  constexpr uint64_t tile = (uint64_t)AGPU_EW_BLOCK * U;
   for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const uint64_t p0 = t * tile + threadIdx.x;
     PackN<TI, N> v[U];
-#pragma unroll
-    for (int u = 0; u < U; u++)
-      v[u] = load_pack<(AGPU_STREAM_NT & 1) != 0, TI, N>(in + (p0 + (uint64_t)u * AGPU_BLOCK) * N);
-#pragma unroll
-    for (int u = 0; u < U; u++) {
+    static_for<U>([&](auto u) {
+      v[u] = load_pack<(AGPU_STREAM_NT & 1) != 0, TI, N>(in + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N);
+    });
+    static_for<U>([&](auto u) {
       PackN<TO, N> r;
 #pragma unroll
       for (int k = 0; k < N; k++) r.v[k] = Conv::ap(v[u].v[k]);
-      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, N>(out + (p0 + (uint64_t)u * AGPU_BLOCK) * N, r);
-    }
+      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, N>(out + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N, r);
+    });
   }
-  if (blockIdx.x == ntiles % gridDim.x) {
-    for (uint64_t pk = ntiles * tile + threadIdx.x; pk < npacks; pk += AGPU_BLOCK) {
-      PackN<TI, N> x = load_pack<false, TI, N>(in + pk * N);
-      PackN<TO, N> r;
+}
+template <typename TI, typename TO, typename Conv>
+__global__ __launch_bounds__(AGPU_BLOCK) void cvt_tail_kernel(const TI* in, TO* out, uint64_t first, uint64_t n) {
+  constexpr int N = 16 / (sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
+  const uint64_t npacks = n / N;
+  for (uint64_t pk = first / N + threadIdx.x; pk < npacks; pk += AGPU_BLOCK) {
+    PackN<TI, N> x = load_pack<false, TI, N>(in + pk * N);
+    PackN<TO, N> r;
 #pragma unroll
-      for (int k = 0; k < N; k++) r.v[k] = Conv::ap(x.v[k]);
-      store_pack<false, TO, N>(out + pk * N, r);
-    }
-    const uint64_t i = npacks * N + threadIdx.x;
-    if (i < n) out[i] = Conv::ap(in[i]);
+    for (int k = 0; k < N; k++) r.v[k] = Conv::ap(x.v[k]);
+    store_pack<false, TO, N>(out + pk * N, r);
   }
+  const uint64_t i = npacks * N + threadIdx.x;
+  if (i >= first && i < n) out[i] = Conv::ap(in[i]);
 }
 template <typename TI, typename TO, typename Conv>
 __global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel_unaligned(const TI* in, TO* out, uint64_t n) {
@@ -392,9 +416,16 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
   const TI* pi = static_cast<const TI*>(in);
   TO* po = static_cast<TO*>(out);
   if (aligned_to(in, sizeof(TI) * N) && aligned_to(out, sizeof(TO) * N)) {
-    const uint64_t ntiles = n / N / ((uint64_t)AGPU_BLOCK * AGPU_STREAM_U);
-    const int grid = stream_grid_for(p, ntiles ? ntiles : 1);
-    hipLaunchKernelGGL((cvt_kernel<TI, TO, Conv, AGPU_STREAM_U>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, n);
+    constexpr uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * AGPU_STREAM_U * N;
+    const uint64_t ntiles = n / tile_rows;
+    if (ntiles) {
+      const int grid = stream_grid_for(p, ntiles);
+      hipLaunchKernelGGL((cvt_kernel<TI, TO, Conv, AGPU_STREAM_U>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, po,
+                         ntiles);
+    }
+    if (ntiles * tile_rows < n)
+      hipLaunchKernelGGL((cvt_tail_kernel<TI, TO, Conv>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pi, po,
+                         ntiles * tile_rows, n);
   } else {
     const int grid = stream_grid_for(p, (n + AGPU_BLOCK - 1) / AGPU_BLOCK);
     hipLaunchKernelGGL((cvt_kernel_unaligned<TI, TO, Conv>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, n);

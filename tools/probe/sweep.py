@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""DEV TOOL: sweep launch shapes of the f32 add stream on the GPU box.  python tools/probe/sweep.py --rows 1000000000"""
+"""DEV TOOL: sweep launch shapes of the two headline streams on the GPU box, with the product kernels timed in the
+same process (interleaved A/B).   python tools/probe/sweep.py --rows 1000000000 [--what add,eq]"""
 from __future__ import annotations
 
 import argparse
@@ -19,25 +20,31 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1_000_000_000)
     ap.add_argument("--iters", type=int, default=7)
+    ap.add_argument("--what", default="add,eq")
+    ap.add_argument("--tag", default="r01b")
     args = ap.parse_args()
     n = args.rows
     here = os.path.dirname(os.path.abspath(__file__))
     lib = C.CDLL(os.path.join(here, "libstream_probe.so"))
-    lib.probe_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    vpt = C.c_void_p
+    lib.probe_add.argtypes = [vpt, vpt, vpt, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vpt]
+    lib.probe_eq.argtypes = [vpt, vpt, vpt, vpt, vpt, vpt, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vpt]
     dev = GpuDevice(0)
     p = ArrowComputePipeline(dev, "sweep")
     q = CmpQuery(dev)
+    h = p._handle
     A, B, O = (dev.create_empty_buffer(4 * n) for _ in range(3))
-    capi.call("agpu_synth_f32", p._handle, C.c_void_p(A.ptr), n, 1, 0, C.c_float(-1000), C.c_float(1000))
-    capi.call("agpu_synth_f32", p._handle, C.c_void_p(B.ptr), n, 2, 0, C.c_float(-1000), C.c_float(1000))
+    nb = (n + 63) // 64 * 8
+    VA, VB, OB, OV = (dev.create_empty_buffer(nb) for _ in range(4))
+    capi.call("agpu_synth_f32", h, vpt(A.ptr), n, 1, 0, C.c_float(-1000), C.c_float(1000))
+    capi.call("agpu_synth_f32", h, vpt(B.ptr), n, 2, 0, C.c_float(-1000), C.c_float(1000))
+    capi.call("agpu_synth_bits", h, vpt(VA.ptr), n, 3, 0, C.c_double(0.9))
+    capi.call("agpu_synth_bits", h, vpt(VB.ptr), n, 4, 0, C.c_double(0.9))
     p.sync()
-    stream = C.c_void_p(p.stream())
+    stream = vpt(p.stream())
     rows = []
 
-    def run(u, nt, block, grid):
-        def f():
-            rc = lib.probe_add(C.c_void_p(A.ptr), C.c_void_p(B.ptr), C.c_void_p(O.ptr), n, u, nt, block, grid, stream)
-            assert rc == 0, rc
+    def timeit(label, f, alg_bytes, extra=None):
         f()
         p.sync()
         ts = []
@@ -47,24 +54,61 @@ def main():
             q.end(p)
             ts.append(q.wait_for_results())
         ms = float(np.median(ts))
-        r = {"u": u, "nt": nt, "block": block, "grid": grid, "ms": round(ms, 4), "TBps": round(12 * n / ms / 1e9, 3),
-             "min_ms": round(min(ts), 4)}
+        r = {"kernel": label, "ms": round(ms, 4), "TBps": round(alg_bytes / ms / 1e9, 3), "min_ms": round(min(ts), 4)}
+        if extra:
+            r.update(extra)
         rows.append(r)
         print(r, flush=True)
 
-    for block in (256, 512, 1024):
-        for u in (1, 2, 4, 8):
-            for nt in (0, 1, 2, 3):
-                run(u, nt, block, 0)
-    for grid in (2048, 4096, 8192, 16384, 32768):
-        for u in (2, 4):
-            for nt in (0, 3):
-                run(u, nt, 256, grid)
-    rows.sort(key=lambda r: r["ms"])
+    what = args.what.split(",")
+    if "add" in what:
+        def product_add():
+            capi.call("agpu_binary", h, capi.OP_ADD, capi.F32, vpt(A.ptr), vpt(B.ptr), vpt(O.ptr), n)
+
+        def probe_add(u, nt, block, grid, xcd):
+            def f():
+                rc = lib.probe_add(vpt(A.ptr), vpt(B.ptr), vpt(O.ptr), n, u, nt, block, grid, xcd, stream)
+                assert rc == 0, rc
+            return f
+
+        timeit("PRODUCT add_f32", product_add, 12 * n)
+        for block in (64, 128, 256, 512):
+            for u in (1, 2):
+                for xcd in (0, 1):
+                    timeit("probe add", probe_add(u, 3, block, 0, xcd), 12 * n, {"u": u, "nt": 3, "block": block, "grid": 0, "xcd": xcd})
+        timeit("PRODUCT add_f32", product_add, 12 * n)
+        for grid in (32768, 65536, 131072, 262144):
+            for u in (1, 2, 4):
+                timeit("probe add", probe_add(u, 3, 256, grid, 0), 12 * n, {"u": u, "nt": 3, "block": 256, "grid": grid, "xcd": 0})
+        timeit("PRODUCT add_f32", product_add, 12 * n)
+
+    if "eq" in what:
+        def product_eq():
+            capi.call("agpu_compare_validity", h, capi.CMP_EQ, capi.I32, vpt(A.ptr), vpt(B.ptr), vpt(VA.ptr), vpt(VB.ptr),
+                      vpt(OB.ptr), vpt(OV.ptr), n)
+
+        def probe_eq(variant, ru, nt, block, grid):
+            def f():
+                rc = lib.probe_eq(vpt(A.ptr), vpt(B.ptr), vpt(VA.ptr), vpt(VB.ptr), vpt(OB.ptr), vpt(OV.ptr), n, variant, ru,
+                                  nt, block, grid, stream)
+                assert rc == 0, rc
+            return f
+
+        timeit("PRODUCT eq_i32+validity", product_eq, 8.5 * n)
+        for block in (64, 128, 256, 512):
+            for r in (1, 2, 4, 8, 16):
+                timeit("probe eq ballot", probe_eq(0, r, 1, block, 0), 8.5 * n, {"variant": 0, "R": r, "nt": 1, "block": block, "grid": 0})
+        for block in (64, 128, 256, 512):
+            for u in (1, 2, 4):
+                timeit("probe eq vec", probe_eq(1, u, 1, block, 0), 8.5 * n, {"variant": 1, "U": u, "nt": 1, "block": block, "grid": 0})
+        for r in (4, 16):
+            timeit("probe eq ballot", probe_eq(0, r, 0, 256, 0), 8.5 * n, {"variant": 0, "R": r, "nt": 0, "block": 256, "grid": 0})
+        timeit("PRODUCT eq_i32+validity", product_eq, 8.5 * n)
+
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/sweep_add.json", "w") as f:
+    with open(f"gpurun_out/sweep_{args.tag}.json", "w") as f:
         json.dump(rows, f, indent=1)
-    print("BEST", rows[:8])
+    print("BEST", sorted(rows, key=lambda r: -r["TBps"])[:10])
 
 
 if __name__ == "__main__":
