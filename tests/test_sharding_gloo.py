@@ -1,0 +1,88 @@
+"""CPU: the N>1 path — shard planning + final reduce over torch.distributed — with world_size 2 on the gloo backend.
+Per-shard partials come from the ORACLE here (no GPU in this container); on the GPU box bench.py feeds the same
+`sharding.final_reduce` with partials computed by the HIP kernels, backend "nccl" (= RCCL over xGMI)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from arrow_gpu_amd import sharding
+
+
+def test_shard_plan_properties():
+    for total in (0, 1, 511, 512, 513, 10_000, 1_000_000_007, 8_000_000_000):
+        for world in (1, 2, 3, 4, 8):
+            shards = sharding.all_shards(total, world)
+            assert shards[0].row0 == 0 and shards[-1].row_end == total
+            for a, b in zip(shards, shards[1:]):
+                assert a.row_end == b.row0          # contiguous, no gap, no overlap
+            for s in shards[:-1]:
+                assert s.row_end % 512 == 0 or s.row_end == total  # whole bitmap words / 16-byte vectors per rank
+            sizes = [s.rows for s in shards]
+            assert max(sizes) - min(sizes) <= 1024  # ≤ one 512-row chunk of imbalance + the ragged last chunk
+    s = sharding.shard_rows(8_000_000_000, 8, 3)
+    assert (s.row0, s.rows) == (3_000_000_000, 1_000_000_000)  # config 5: 8 × 1e9-row shards
+    with pytest.raises(ValueError):
+        sharding.shard_rows(10, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, q):
+    import torch
+    import torch.distributed as dist
+
+    import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = sharding.shard_rows(total, world, rank)
+        x = O.synth_f32(sh.rows, 20250418, sh.row0, -1.0, 1.0)        # this rank's shard of the column
+        bits = O.synth_bits(sh.rows, 7, sh.row0, 0.9)
+        s = torch.tensor([O.reduce_sum_f64(x)], dtype=torch.float64)
+        mn = torch.tensor([float(O.reduce(O.RED_MIN, O.F32, x))], dtype=torch.float32)
+        mx = torch.tensor([float(O.reduce(O.RED_MAX, O.F32, x))], dtype=torch.float32)
+        cnt = torch.tensor([O.bitmap_popcount(bits, sh.rows)], dtype=torch.int64)
+        sharding.final_reduce(s, mn, mx, cnt)
+        q.put((rank, s.item(), mn.item(), mx.item(), cnt.item(), sh.row0, sh.rows))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(2, 1_000_003), (2, 512 * 4096)])
+def test_final_reduce_world2_gloo(world, total):
+    import torch.multiprocessing as mp
+
+    import oracle as O
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    whole = O.synth_f32(total, 20250418, 0, -1.0, 1.0)
+    bits = O.synth_bits(total, 7, 0, 0.9)
+    exp_sum = float(np.sum(whole.astype(np.float64)))
+    for rank, s, mn, mx, cnt, row0, rows in res:
+        assert abs(s - exp_sum) <= 1e-9 * float(np.sum(np.abs(whole.astype(np.float64))))
+        assert mn == float(whole.min()) and mx == float(whole.max())          # exact
+        assert cnt == O.bitmap_popcount(bits, total)                            # exact
+    assert sorted(r[5] for r in res) == [s.row0 for s in sharding.all_shards(total, world)]
+
+
+def test_final_reduce_single_process_is_identity():
+    import torch
+
+    s = torch.tensor([1.5], dtype=torch.float64)
+    out = sharding.final_reduce(s, None, None, None)
+    assert out[0] is s and s.item() == 1.5
