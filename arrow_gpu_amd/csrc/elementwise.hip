@@ -154,7 +154,7 @@ struct OpPow {  // f32: NaN for negative/NaN base (math/src/f32.rs:209-271), els
   template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
     if constexpr (std::is_floating_point<T>::value) {
       if (x != x || y != y || x < 0.0f || (x == 0.0f && __builtin_signbit(x))) return __builtin_nanf("");
-      return powf(x, y);
+      return (float)pow((double)x, (double)y);
     } else return (T)i32_pow_dev((int32_t)x, (int32_t)y);
   }
 };
@@ -173,16 +173,55 @@ struct UnAbs {
   }
 };
 struct UnNot { template <typename T> __device__ static __forceinline__ T ap(T x, T) { return (T)~x; } };
-struct UnSqrt { __device__ static __forceinline__ float ap(float x, float) { return sqrtf(x); } };
-struct UnCbrt { __device__ static __forceinline__ float ap(float x, float) { return cbrtf(x); } };
-struct UnExp { __device__ static __forceinline__ float ap(float x, float) { return expf(x); } };
-struct UnExp2 { __device__ static __forceinline__ float ap(float x, float) { return exp2f(x); } };
-struct UnLog { __device__ static __forceinline__ float ap(float x, float) { return logf(x); } };
-struct UnLog2 { __device__ static __forceinline__ float ap(float x, float) { return log2f(x); } };
-struct UnSin { __device__ static __forceinline__ float ap(float x, float) { return sinf(x); } };
-struct UnCos { __device__ static __forceinline__ float ap(float x, float) { return cosf(x); } };
-struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { return acosf(x); } };
-struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return sinhf(x); } };
+// ---- transcendental f32 functions: evaluated in f64 and rounded ONCE to f32 (≤ 1 ULP, in practice ≤ 0.5 ULP + 2^-30).
+// The f32 device-library versions measure 2 ULP for sin/cos/log on gfx950 (profiles/r01_probe_first_contact.json);
+// MI355X runs v_fma_f64 at half the f32 rate (78 TFLOP/s), and an 8 B/row stream at 6 TB/s leaves ≈50 f64 FMAs per
+// row, so the f64 evaluation stays under the memory roof for sin/cos (hand-written below, ≈20 FMAs).
+//
+// sin/cos: Cody–Waite reduction by π/2 in f64 (π/2 = P1 + P1t; P1 has 33 significant bits, so k·P1 is exact for
+// k < 2^20), then minimax polynomials on [−π/4, π/4]:
+//     sin r = r + r·z·(S1 + z·ps(z)),   cos r = 1 + z·(C1 + z·pc(z)),   z = r²
+// The inner ps / pc (terms ≥ r⁵ / r⁴, ≤ 0.5 % / 2.6 % of the result) are evaluated in f32, the two outer steps in f64,
+// then ONE rounding to f32: pre-rounding error ≤ 0.02 f32-ULP (emulated over 2·10⁶ points), i.e. ≤ 0.52 ULP total,
+// with half the f64 work of an all-f64 Horner chain.  |x| ≥ 1e6, inf and NaN take the f64 library path
+// (Payne–Hanek inside), out of line so the hot path stays small.
+__device__ __attribute__((noinline)) float sincos_f32_slow(float x, int want_cos) {
+  return (float)(want_cos ? cos((double)x) : sin((double)x));
+}
+__device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
+  if (!(fabsf(x) < 1.0e6f)) return sincos_f32_slow(x, want_cos);
+  const double xd = (double)x;
+  const double kd = rint(xd * 0x1.45f306dc9c883p-1);  // x · 2/π
+  const int k = (int)kd;
+  double r = fma(kd, -0x1.921fb54400000p+0, xd);
+  r = fma(kd, -0x1.0b4611a626331p-34, r);
+  r = (kd == 0.0) ? xd : r;  // keeps sin(−0.0) = −0.0
+  const float zf = (float)r * (float)r;
+  float ps = __builtin_fmaf(zf, (float)-0x1.aa12ed611087fp-26, (float)0x1.71d97b66aa967p-19);
+  ps = __builtin_fmaf(zf, ps, (float)-0x1.a019fd5d6492ep-13);
+  ps = __builtin_fmaf(zf, ps, (float)0x1.1111110fba75dp-7);
+  float pc = __builtin_fmaf(zf, (float)-0x1.24635bc27779cp-22, (float)0x1.a0124c744e1f9p-16);
+  pc = __builtin_fmaf(zf, pc, (float)-0x1.6c16ba7ffec5ep-10);
+  pc = __builtin_fmaf(zf, pc, (float)0x1.55555550fad1cp-5);
+  const double z = r * r;
+  const double s = fma(r * z, fma(z, (double)ps, -0x1.555555555510cp-3), r);
+  const double c = fma(z, fma(z, (double)pc, -0x1.fffffffffe3f1p-2), 1.0);
+  const int q = k + want_cos;  // cos(x) = sin(x + π/2)
+  double v = (q & 1) ? c : s;
+  v = (q & 2) ? -v : v;
+  return (float)v;
+}
+
+struct UnSqrt { __device__ static __forceinline__ float ap(float x, float) { return sqrtf(x); } };  // correctly rounded
+struct UnCbrt { __device__ static __forceinline__ float ap(float x, float) { return (float)cbrt((double)x); } };
+struct UnExp { __device__ static __forceinline__ float ap(float x, float) { return (float)exp((double)x); } };
+struct UnExp2 { __device__ static __forceinline__ float ap(float x, float) { return (float)exp2((double)x); } };
+struct UnLog { __device__ static __forceinline__ float ap(float x, float) { return (float)log((double)x); } };
+struct UnLog2 { __device__ static __forceinline__ float ap(float x, float) { return (float)log2((double)x); } };
+struct UnSin { __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 0); } };
+struct UnCos { __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 1); } };
+struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { return (float)acos((double)x); } };
+struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return (float)sinh((double)x); } };
 
 // ---------------------------------------------------------------- same-width streaming kernel
 // out[i] = Op(a[i], b[i] | *b | -).  The hot kernel covers FULL tiles only and carries no tail code (the tail costs
@@ -371,21 +410,25 @@ static agpu_status dispatch_binary(agpu_pipeline* p, agpu_binary_op op, agpu_dty
 // ---------------------------------------------------------------- width-changing kernel (casts, fused int→f32 trig)
 // lane handles N = 16/max(sizeof(TI),sizeof(TO)) elements per step: the wide side moves 16 B/lane, the narrow
 // side N*sizeof bytes (4 or 8) — both sides stay fully coalesced (the reference's cast shaders store with stride 4).
+// Shape: the narrow side moves only 4–8 B per lane, so a one-wave block would issue 256-byte loads; 256-thread blocks
+// with 4 steps per lane (what the 8-bit table kernel below uses: 5.64 vs 5.47 TB/s on the 5 B/row stream) do better.
+#define AGPU_CVT_BLOCK 256
+#define AGPU_CVT_U 4
 template <typename TI, typename TO, typename Conv, int U>
-__global__ __launch_bounds__(AGPU_EW_BLOCK) void cvt_kernel(const TI* in, TO* out, uint64_t ntiles) {
+__global__ __launch_bounds__(AGPU_CVT_BLOCK) void cvt_kernel(const TI* in, TO* out, uint64_t ntiles) {
   constexpr int N = 16 / (sizeof(TI) > sizeof(TO) ? sizeof(TI) : sizeof(TO));
-  constexpr uint64_t tile = (uint64_t)AGPU_EW_BLOCK * U;
+  constexpr uint64_t tile = (uint64_t)AGPU_CVT_BLOCK * U;
   for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const uint64_t p0 = t * tile + threadIdx.x;
     PackN<TI, N> v[U];
     static_for<U>([&](auto u) {
-      v[u] = load_pack<(AGPU_STREAM_NT & 1) != 0, TI, N>(in + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N);
+      v[u] = load_pack<(AGPU_STREAM_NT & 1) != 0, TI, N>(in + (p0 + (uint64_t)u * AGPU_CVT_BLOCK) * N);
     });
     static_for<U>([&](auto u) {
       PackN<TO, N> r;
 #pragma unroll
       for (int k = 0; k < N; k++) r.v[k] = Conv::ap(v[u].v[k]);
-      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, N>(out + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N, r);
+      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, N>(out + (p0 + (uint64_t)u * AGPU_CVT_BLOCK) * N, r);
     });
   }
 }
@@ -416,11 +459,11 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
   const TI* pi = static_cast<const TI*>(in);
   TO* po = static_cast<TO*>(out);
   if (aligned_to(in, sizeof(TI) * N) && aligned_to(out, sizeof(TO) * N)) {
-    constexpr uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * AGPU_STREAM_U * N;
+    constexpr uint64_t tile_rows = (uint64_t)AGPU_CVT_BLOCK * AGPU_CVT_U * N;
     const uint64_t ntiles = n / tile_rows;
     if (ntiles) {
       const int grid = stream_grid_for(p, ntiles);
-      hipLaunchKernelGGL((cvt_kernel<TI, TO, Conv, AGPU_STREAM_U>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, po,
+      hipLaunchKernelGGL((cvt_kernel<TI, TO, Conv, AGPU_CVT_U>), dim3(grid), dim3(AGPU_CVT_BLOCK), 0, p->stream, pi, po,
                          ntiles);
     }
     if (ntiles * tile_rows < n)
@@ -451,6 +494,58 @@ template <typename TI, typename F>
 struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders/{u8,i8,u16,i16}/*.wgsl]
   __device__ static __forceinline__ float ap(TI x) { return F::ap((float)x, 0.0f); }
 };
+
+// 8-bit sources (sin_u8 / cos_i8 / sinh_u8 …): only 256 distinct inputs exist, so evaluating the function per row
+// makes a 5 B/row stream VALU-bound (3.5 TB/s measured).  Each 256-thread block builds the 256-entry result table in
+// LDS once (one evaluation per thread, the SAME device function as the f32 kernel ⇒ identical bits), then streams a
+// 4096-row tile: one 4-byte load (4 rows) and one nontemporal 16-byte store per lane per step, 4 LDS reads per store.
+template <typename TI, typename F>
+__global__ __launch_bounds__(AGPU_BLOCK) void lut8_kernel(const TI* in, float* out, uint64_t ntiles) {
+  constexpr int U = 4;
+  constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;  // packs of 4 rows
+  __shared__ float lut[256];
+  lut[threadIdx.x] = F::ap((float)(TI)(uint8_t)threadIdx.x, 0.0f);  // indexed by the raw byte
+  __syncthreads();
+  const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in);
+  f32x4* out4 = reinterpret_cast<f32x4*>(out);
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
+    uint32_t w[U];
+    static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in32 + p0 + (uint64_t)u * AGPU_BLOCK); });
+    static_for<U>([&](auto u) {
+      const uint32_t x = w[u];
+      f32x4 r = {lut[x & 255u], lut[(x >> 8) & 255u], lut[(x >> 16) & 255u], lut[x >> 24]};
+      __builtin_nontemporal_store(r, out4 + p0 + (uint64_t)u * AGPU_BLOCK);
+    });
+  }
+}
+
+template <typename TI, typename F>
+static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
+  static_assert(sizeof(TI) == 1, "8-bit sources only");
+  if (n == 0) return AGPU_OK;
+  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_BLOCK * 4 * 4;
+  const TI* pi = static_cast<const TI*>(in);
+  float* po = static_cast<float*>(out);
+  uint64_t done = 0;
+  if (aligned_to(in, 4) && aligned16(out)) {
+    const uint64_t ntiles = n / TILE_ROWS;
+    if (ntiles) {
+      const int grid = stream_grid_for(p, ntiles);
+      hipLaunchKernelGGL((lut8_kernel<TI, F>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, ntiles);
+      done = ntiles * TILE_ROWS;
+    }
+    if (done < n)
+      hipLaunchKernelGGL((cvt_tail_kernel<TI, float, CvtThenF32<TI, F>>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pi, po,
+                         done, n);
+  } else {
+    const int grid = stream_grid_for(p, (n + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL((cvt_kernel_unaligned<TI, float, CvtThenF32<TI, F>>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
+                       pi, po, n);
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
 
 // bool bitmap → f32 [cast/compute_shaders/boolean/cast_f32.wgsl:9-20]: lane expands 4 bits into one 16-byte store
 __global__ __launch_bounds__(AGPU_BLOCK) void bool_to_f32_kernel(const uint32_t* bits, float* out, uint64_t n) {
@@ -560,13 +655,21 @@ agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, con
     case AGPU_U32: UN_INT(uint32_t) break;
     case AGPU_I16: UN_FUSED(int16_t) UN_INT(int16_t) break;
     case AGPU_U16: UN_FUSED(uint16_t) UN_INT(uint16_t) break;
-    case AGPU_I8: UN_FUSED(int8_t) UN_INT(int8_t) break;
-    case AGPU_U8: UN_FUSED(uint8_t) UN_INT(uint8_t) break;
+#define UN_FUSED8(T)                                                         \
+  switch (op) {                                                              \
+    case AGPU_UN_SIN: return launch_lut8<T, UnSin>(p, in, out, n);           \
+    case AGPU_UN_COS: return launch_lut8<T, UnCos>(p, in, out, n);           \
+    case AGPU_UN_SINH: return launch_lut8<T, UnSinh>(p, in, out, n);         \
+    default: break;                                                          \
+  }
+    case AGPU_I8: UN_FUSED8(int8_t) UN_INT(int8_t) break;
+    case AGPU_U8: UN_FUSED8(uint8_t) UN_INT(uint8_t) break;
     default: break;
   }
 #undef UN_F32
 #undef UN_INT
 #undef UN_FUSED
+#undef UN_FUSED8
   agpu_set_error("unary op %d not supported for dtype %d", (int)op, (int)dtype);
   return AGPU_ERR_UNSUPPORTED;
 }

@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
-MAX_ULP = 2  # TODO(round 2): 1 once sin/cos/log are hand-written (ocml sinf/cosf/logf measure 2 ULP on gfx950)
+MAX_ULP = 1  # north_star: f32 math/trig within 1 ULP (kernels evaluate in f64 and round once; oracle = f64 libm rounded)
 
 
 def load(name):
