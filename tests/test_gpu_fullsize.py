@@ -1,0 +1,242 @@
+"""GPU: BASELINE.json's full sizes (1e9 rows per column) — too big for the scalar oracle in a test's time budget, so
+parity is asserted through size-independent PROPERTIES of the domain (exact, integer-checkable), plus oracle windows:
+
+  * wrapping-sum linearity      sum(a) + sum(b) == sum(a + b)  (mod 2^32)            [i32 add + Sum]
+  * min/max partition           sum(min(a,b)) + sum(max(a,b)) == sum(a) + sum(b)       [MinMax]
+  * compare complements         popcount(a < b) + popcount(a >= b) == n;  eq(a, a) is all ones
+  * bitmap inclusion–exclusion  |va & vb| + |va | vb| == |va| + |vb|                   [validity AND]
+  * cast round trip             u8 → f32 → u8 is the identity (checksum equality)
+  * commutativity               checksum(a + b) == checksum(b + a)                     [f32 add]
+  * gather/scatter inverses     take(a, perm) scattered back by put(perm) == a; merge(a, a, m) == a
+  * windows                     first / middle / last 65 536 rows of the outputs, bit-exact vs the oracle on the same
+                                counter-based generator
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from arrow_gpu_amd import _capi as capi
+
+pytestmark = pytest.mark.gpu
+
+N = 1_000_000_000
+SEED = 20250418
+WINDOW = 1 << 16
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+
+    dev = GpuDevice(0)
+    p = ArrowComputePipeline(dev, "fullsize")
+    return dev, p
+
+
+def vp(buf, off=0):
+    return C.c_void_p(buf.ptr + off)
+
+
+def scalar_u64(dev, p, buf):
+    return int(dev.retrive_data(buf, 8, pipeline=p).view(np.uint64)[0])
+
+
+def scalar_u32(dev, p, buf):
+    return int(dev.retrive_data(buf, 4, pipeline=p).view(np.uint32)[0])
+
+
+def windows(n):
+    return (0, (n // 2) // 64 * 64, (n - WINDOW) // 64 * 64)
+
+
+def download(dev, p, buf, byte_off, nbytes):
+    out = np.empty(nbytes, np.uint8)
+    capi.call("agpu_download", p._handle, C.c_void_p(out.ctypes.data), C.c_void_p(buf.ptr + byte_off), nbytes)
+    return out
+
+
+def test_i32_add_sum_linearity_minmax_partition_and_compare(ctx):
+    dev, p = ctx
+    h = p._handle
+    a, b, out = (dev.create_empty_buffer(4 * N) for _ in range(3))
+    res = dev.create_empty_buffer(16)
+    capi.call("agpu_synth_i32", h, vp(a), N, SEED + 2, 0, 1024)
+    capi.call("agpu_synth_i32", h, vp(b), N, SEED + 3, 0, 1024)
+
+    def wsum(buf):
+        capi.call("agpu_reduce", h, capi.RED_SUM, capi.I32, vp(buf), None, N, vp(res))
+        return scalar_u32(dev, p, res)
+
+    sa, sb = wsum(a), wsum(b)
+    capi.call("agpu_binary", h, capi.OP_ADD, capi.I32, vp(a), vp(b), vp(out), N)
+    assert wsum(out) == (sa + sb) & 0xFFFFFFFF
+    for start in windows(N):
+        got = download(dev, p, out, 4 * start, 4 * WINDOW).view(np.int32)
+        exp = O.binary(O.OP_ADD, O.I32, O.synth_i32(WINDOW, SEED + 2, start, 1024), O.synth_i32(WINDOW, SEED + 3, start, 1024))
+        assert np.array_equal(got, exp)
+    capi.call("agpu_binary", h, capi.OP_MIN, capi.I32, vp(a), vp(b), vp(out), N)
+    smin = wsum(out)
+    capi.call("agpu_binary", h, capi.OP_MAX, capi.I32, vp(a), vp(b), vp(out), N)
+    smax = wsum(out)
+    assert (smin + smax) & 0xFFFFFFFF == (sa + sb) & 0xFFFFFFFF
+
+    nb = (N + 63) // 64 * 8
+    bits, cnt = dev.create_empty_buffer(nb), dev.create_empty_buffer(16)
+
+    def popcount_of(op, x, y):
+        capi.call("agpu_compare", h, op, capi.I32, vp(x), vp(y), vp(bits), N)
+        capi.call("agpu_bitmap_popcount", h, vp(bits), N, vp(cnt))
+        return scalar_u64(dev, p, cnt)
+
+    lt, gteq, eq = popcount_of(capi.CMP_LT, a, b), popcount_of(capi.CMP_GTEQ, a, b), popcount_of(capi.CMP_EQ, a, b)
+    assert lt + gteq == N
+    assert popcount_of(capi.CMP_EQ, a, a) == N
+    assert popcount_of(capi.CMP_GT, a, a) == 0
+    # values are uniform on 0..1023 ⇒ P(eq) = 1/1024; a loose sanity band on the count
+    assert abs(eq - N / 1024) < 5 * (N / 1024) ** 0.5 + 1000
+    for variant in (0, 1):  # both compare kernels agree on the full column
+        capi.call("agpu_set_tuning", b"cmp_variant", variant)
+        try:
+            assert popcount_of(capi.CMP_LTEQ, a, b) == lt + eq
+        finally:
+            capi.call("agpu_set_tuning", b"cmp_variant", 0)
+
+
+def test_eq_with_validity_fullsize_windows_and_bitmap_identities(ctx):
+    dev, p = ctx
+    h = p._handle
+    nb = (N + 63) // 64 * 8
+    a, b = dev.create_empty_buffer(4 * N), dev.create_empty_buffer(4 * N)
+    va, vb, ob, ov, tmp = (dev.create_empty_buffer(nb) for _ in range(5))
+    cnt = dev.create_empty_buffer(16)
+    capi.call("agpu_synth_i32", h, vp(a), N, SEED + 2, 0, 1024)
+    capi.call("agpu_synth_i32", h, vp(b), N, SEED + 3, 0, 1024)
+    capi.call("agpu_synth_bits", h, vp(va), N, SEED + 4, 0, C.c_double(0.9))
+    capi.call("agpu_synth_bits", h, vp(vb), N, SEED + 5, 0, C.c_double(0.9))
+    capi.call("agpu_compare_validity", h, capi.CMP_EQ, capi.I32, vp(a), vp(b), vp(va), vp(vb), vp(ob), vp(ov), N)
+
+    def pop(buf):
+        capi.call("agpu_bitmap_popcount", h, vp(buf), N, vp(cnt))
+        return scalar_u64(dev, p, cnt)
+
+    n_va, n_vb, n_and = pop(va), pop(vb), pop(ov)
+    capi.call("agpu_bitmap_binary", h, capi.OP_OR, vp(va), vp(vb), vp(tmp), N)
+    assert n_and + pop(tmp) == n_va + n_vb                      # inclusion–exclusion
+    capi.call("agpu_bitmap_binary", h, capi.OP_AND, vp(va), vp(vb), vp(tmp), N)
+    cs1, cs2 = dev.create_empty_buffer(16), dev.create_empty_buffer(16)
+    capi.call("agpu_checksum", h, vp(tmp), nb, vp(cs1))
+    capi.call("agpu_checksum", h, vp(ov), nb, vp(cs2))
+    assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)   # fused validity == stand-alone bitmap AND
+    assert abs(n_va / N - 0.9) < 1e-3 and abs(n_and / N - 0.81) < 1e-3  # 10 % nulls per side ⇒ ≈19 % null output
+    for start in windows(N):
+        wb = WINDOW // 8
+        eb = O.compare(O.CMP_EQ, O.I32, O.synth_i32(WINDOW, SEED + 2, start, 1024), O.synth_i32(WINDOW, SEED + 3, start, 1024))
+        ev = O.bitmap_binary(O.OP_AND, O.synth_bits(WINDOW, SEED + 4, start, 0.9), O.synth_bits(WINDOW, SEED + 5, start, 0.9), WINDOW)
+        assert np.array_equal(download(dev, p, ob, start // 8, wb), eb[:wb])
+        assert np.array_equal(download(dev, p, ov, start // 8, wb), ev[:wb])
+
+
+def test_f32_arithmetic_fullsize(ctx):
+    dev, p = ctx
+    h = p._handle
+    a, b, o1, o2 = (dev.create_empty_buffer(4 * N) for _ in range(4))
+    cs1, cs2 = dev.create_empty_buffer(16), dev.create_empty_buffer(16)
+    capi.call("agpu_synth_f32", h, vp(a), N, SEED, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_f32", h, vp(b), N, SEED + 1, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    for op in (capi.OP_ADD, capi.OP_MUL):  # commutative ops: a∘b and b∘a are bitwise equal
+        capi.call("agpu_binary", h, op, capi.F32, vp(a), vp(b), vp(o1), N)
+        capi.call("agpu_binary", h, op, capi.F32, vp(b), vp(a), vp(o2), N)
+        capi.call("agpu_checksum", h, vp(o1), 4 * N, vp(cs1))
+        capi.call("agpu_checksum", h, vp(o2), 4 * N, vp(cs2))
+        assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
+    for op in (capi.OP_ADD, capi.OP_SUB, capi.OP_MUL, capi.OP_DIV):
+        capi.call("agpu_binary", h, op, capi.F32, vp(a), vp(b), vp(o1), N)
+        for start in windows(N):
+            got = download(dev, p, o1, 4 * start, 4 * WINDOW).view(np.uint32)
+            exp = O.binary(op, O.F32, O.synth_f32(WINDOW, SEED, start, -1000.0, 1000.0), O.synth_f32(WINDOW, SEED + 1, start, -1000.0, 1000.0))
+            assert np.array_equal(got, exp.view(np.uint32)), (op, start)
+    # a − a == +0.0 everywhere, a / a == 1.0 wherever a != 0
+    capi.call("agpu_binary", h, capi.OP_SUB, capi.F32, vp(a), vp(a), vp(o1), N)
+    mx = dev.create_empty_buffer(16)
+    capi.call("agpu_unary", h, capi.UN_ABS, capi.F32, vp(o1), vp(o2), N)
+    capi.call("agpu_reduce", h, capi.RED_MAX, capi.F32, vp(o2), None, N, vp(mx))
+    assert dev.retrive_data(mx, 4, pipeline=p).view(np.float32)[0] == 0.0
+    # f32 sum in the reference's order is deterministic: two runs, identical bits
+    capi.call("agpu_reduce", h, capi.RED_SUM, capi.F32, vp(a), None, N, vp(cs1))
+    s1 = scalar_u32(dev, p, cs1)
+    capi.call("agpu_reduce", h, capi.RED_SUM, capi.F32, vp(a), None, N, vp(cs1))
+    assert scalar_u32(dev, p, cs1) == s1
+
+
+def test_cast_roundtrip_and_trig_fullsize(ctx):
+    dev, p = ctx
+    h = p._handle
+    u = dev.create_empty_buffer(N)
+    f, g = dev.create_empty_buffer(4 * N), dev.create_empty_buffer(4 * N)
+    u2 = dev.create_empty_buffer(N)
+    cs1, cs2 = dev.create_empty_buffer(16), dev.create_empty_buffer(16)
+    capi.call("agpu_synth_u8", h, vp(u), N, SEED + 6, 0)
+    capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u), vp(f), N)
+    capi.call("agpu_cast", h, capi.F32, capi.U8, vp(f), vp(u2), N)
+    capi.call("agpu_checksum", h, vp(u), N, vp(cs1))
+    capi.call("agpu_checksum", h, vp(u2), N, vp(cs2))
+    assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)           # u8 → f32 → u8 is the identity
+    # fused sin_u8 == sin_f32(cast(u8)) bit for bit (same device function behind the table)
+    capi.call("agpu_unary", h, capi.UN_SIN, capi.U8, vp(u), vp(g), N)
+    capi.call("agpu_unary", h, capi.UN_SIN, capi.F32, vp(f), vp(f), N)  # in place
+    capi.call("agpu_checksum", h, vp(g), 4 * N, vp(cs1))
+    capi.call("agpu_checksum", h, vp(f), 4 * N, vp(cs2))
+    assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
+    for start in windows(N):
+        got = download(dev, p, g, 4 * start, 4 * WINDOW).view(np.float32)
+        exp = O.unary(O.UN_SIN, O.U8, O.synth_u8(WINDOW, SEED + 6, start))
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64)).max()
+        assert ulp <= 1
+    # |sin| ≤ 1 over the whole column
+    mx = dev.create_empty_buffer(16)
+    capi.call("agpu_reduce", h, capi.RED_MAX, capi.F32, vp(g), None, N, vp(mx))
+    assert dev.retrive_data(mx, 4, pipeline=p).view(np.float32)[0] <= 1.0
+
+
+def test_take_put_merge_inverses_fullsize(ctx):
+    """2^28 rows (the index arrays make 1e9 rows a 16 GB test for no extra coverage)."""
+    dev, p = ctx
+    h = p._handle
+    n = 1 << 28
+    a, t, back = (dev.create_empty_buffer(4 * n) for _ in range(3))
+    idx = dev.create_empty_buffer(4 * n)
+    iota = dev.create_empty_buffer(4 * n)
+    cs1, cs2 = dev.create_empty_buffer(16), dev.create_empty_buffer(16)
+    capi.call("agpu_synth_i32", h, vp(a), n, 1, 0, 0)
+    # a permutation of 0..n-1: i → (i * odd + c) mod 2^28, built with the integer kernels themselves
+    host_iota = np.arange(1 << 20, dtype=np.uint32)
+    small = dev.create_gpu_buffer_with_data(host_iota)
+    one = dev.create_gpu_buffer_with_data(np.array([1 << 20], np.uint32))
+    capi.call("agpu_copy", h, vp(iota), vp(small), 4 << 20)
+    filled = 1 << 20
+    while filled < n:  # doubling: iota[filled:2*filled] = iota[:filled] + filled
+        cur = dev.create_gpu_buffer_with_data(np.array([filled], np.uint32))
+        capi.call("agpu_scalar", h, capi.OP_ADD, capi.U32, vp(iota), vp(cur), vp(iota, 4 * filled), filled)
+        p.sync()
+        filled *= 2
+    mul = dev.create_gpu_buffer_with_data(np.array([2654435761], np.uint32))   # odd ⇒ bijection mod 2^32
+    msk = dev.create_gpu_buffer_with_data(np.array([n - 1], np.uint32))
+    capi.call("agpu_scalar", h, capi.OP_MUL, capi.U32, vp(iota), vp(mul), vp(idx), n)
+    capi.call("agpu_scalar", h, capi.OP_AND, capi.U32, vp(idx), vp(msk), vp(idx), n)  # low 28 bits: still a bijection
+    mx = dev.create_empty_buffer(16)
+    capi.call("agpu_index_max", h, vp(idx), n, vp(mx))
+    assert scalar_u32(dev, p, mx) == n - 1
+    capi.call("agpu_take", h, 4, vp(a), n, vp(idx), vp(t), n)                  # t[i] = a[perm[i]]
+    capi.call("agpu_memset", h, vp(back), 0, 4 * n)
+    capi.call("agpu_put", h, 4, vp(t), vp(iota), vp(back), vp(idx), n)         # back[perm[i]] = t[i]
+    capi.call("agpu_checksum", h, vp(a), 4 * n, vp(cs1))
+    capi.call("agpu_checksum", h, vp(back), 4 * n, vp(cs2))
+    assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
+    m = dev.create_empty_buffer((n + 63) // 64 * 8)
+    capi.call("agpu_synth_bits", h, vp(m), n, 3, 0, C.c_double(0.5))
+    capi.call("agpu_merge", h, 4, vp(a), vp(a), vp(m), vp(t), n)               # merge(a, a, mask) == a
+    capi.call("agpu_checksum", h, vp(t), 4 * n, vp(cs2))
+    assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
+    del one
