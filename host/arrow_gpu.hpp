@@ -1,0 +1,835 @@
+// arrow_gpu.hpp — C++17 host layer over the C ABI (include/arrow_gpu.h), mirroring psvri/arrow-gpu's Rust API 1:1.
+//
+// The reference's host is Rust (crates/array, crates/arithmetic, crates/compare, crates/logical, crates/cast,
+// crates/math, crates/trigonometry, crates/routines); no Rust toolchain exists in the build image, so the compiled-
+// language host is this header.  Names are the reference's:
+//   GpuDevice, ArrowComputePipeline                      crates/array/src/gpu_utils/{gpu_device,compute_pipeline}.rs
+//   PrimitiveArrayGpu<T>, Float32ArrayGPU … Date32ArrayGPU, BooleanArrayGPU, NullBitBufferGpu, BooleanBufferBuilder,
+//   ArrowArrayGPU (enum → std::variant), ArrowType       crates/array/src/array/*.rs
+//   x.add(y) / x.add_op(y, pipeline) / add_dyn(a, b) / add_op_dyn(a, b, pipeline) …   the op traits + dyn_fn! tables
+// Rust trait bounds become static_asserts (an op a type does not implement fails to compile, as in Rust); the *_dyn
+// functions throw ArrowErrorGPU where the reference panics.  Header-only; link with -larrow_gpu_hip.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <variant>
+#include <vector>
+
+#include "../include/arrow_gpu.h"
+
+namespace arrow_gpu {
+
+// ------------------------------------------------------------------ errors  [crates/array/src/lib.rs:11-14]
+struct ArrowErrorGPU : std::runtime_error {
+  enum Kind { OperationNotSupported, CastingNotSupported, Runtime } kind;
+  ArrowErrorGPU(Kind k, const std::string& m) : std::runtime_error(m), kind(k) {}
+};
+inline void check(agpu_status s, const char* what) {
+  if (s == AGPU_OK) return;
+  const std::string msg = std::string(what) + ": " + agpu_last_error();
+  throw ArrowErrorGPU(s == AGPU_ERR_UNSUPPORTED ? ArrowErrorGPU::OperationNotSupported : ArrowErrorGPU::Runtime, msg);
+}
+
+enum class ArrowType { BooleanType, Float32Type, UInt32Type, UInt16Type, UInt8Type, Int32Type, Int16Type, Int8Type, Date32Type };
+
+// ------------------------------------------------------------------ device, buffers, pipeline
+class GpuDevice;
+using DevicePtr = std::shared_ptr<GpuDevice>;
+
+struct Buffer {  // Arc<wgpu::Buffer> stand-in [crates/array/src/array/buffer.rs:5-53]
+  void* ptr = nullptr;
+  uint64_t bytes = 0;
+  DevicePtr dev;
+  uint64_t size() const { return bytes; }
+  ~Buffer();
+};
+using BufferPtr = std::shared_ptr<Buffer>;
+
+class ArrowComputePipeline;
+
+class GpuDevice : public std::enable_shared_from_this<GpuDevice> {
+ public:
+  agpu_device* raw = nullptr;
+  agpu_pipeline* io = nullptr;  // uploads / read-backs
+  static DevicePtr create(int ordinal = 0) {  // GpuDevice::new() [gpu_device.rs:46-85]
+    auto d = std::shared_ptr<GpuDevice>(new GpuDevice());
+    check(agpu_device_create(ordinal, &d->raw), "agpu_device_create");
+    check(agpu_pipeline_create(d->raw, &d->io), "agpu_pipeline_create");
+    return d;
+  }
+  ~GpuDevice() {
+    if (io) agpu_pipeline_destroy(io);
+    if (raw) agpu_device_destroy(raw);
+  }
+  BufferPtr create_empty_buffer(uint64_t size) {  // [gpu_device.rs:183-192]
+    auto b = std::make_shared<Buffer>();
+    check(agpu_malloc(raw, size ? size : 1, 0, &b->ptr), "agpu_malloc");
+    b->bytes = size;
+    b->dev = shared_from_this();
+    return b;
+  }
+  template <typename N>
+  BufferPtr create_gpu_buffer_with_data(const N* data, size_t count) {  // [gpu_device.rs:171-181]
+    auto b = create_empty_buffer(count * sizeof(N));
+    if (count) check(agpu_upload(io, b->ptr, data, count * sizeof(N)), "agpu_upload");
+    return b;
+  }
+  std::vector<uint8_t> retrive_data(const BufferPtr& b, uint64_t nbytes) {  // the only blocking call [gpu_device.rs:232-265]
+    std::vector<uint8_t> out(nbytes);
+    check(agpu_device_sync(raw), "agpu_device_sync");
+    if (nbytes) check(agpu_download(io, out.data(), b->ptr, nbytes), "agpu_download");
+    return out;
+  }
+  BufferPtr clone_buffer(const BufferPtr& b) {  // [gpu_device.rs:212-222]
+    auto out = create_empty_buffer(b->bytes);
+    if (b->bytes) check(agpu_copy(io, out->ptr, b->ptr, b->bytes), "agpu_copy");
+    return out;
+  }
+
+ private:
+  GpuDevice() = default;
+};
+inline Buffer::~Buffer() {
+  if (ptr && dev) agpu_free(dev->raw, ptr);
+}
+inline DevicePtr GPU_DEVICE() {  // static GPU_DEVICE: LazyLock<Arc<GpuDevice>> [crates/array/src/lib.rs:17]
+  static DevicePtr* d = new DevicePtr(GpuDevice::create(0));  // intentionally leaked: outlives static destruction of HIP
+  return *d;
+}
+
+class ArrowComputePipeline {  // [compute_pipeline.rs:8-300]; one HIP stream, ops run in recorded order
+ public:
+  DevicePtr device;
+  agpu_pipeline* raw = nullptr;
+  std::vector<BufferPtr> keep;  // buffers referenced by in-flight work
+  explicit ArrowComputePipeline(DevicePtr d, const char* /*label*/ = nullptr) : device(std::move(d)) {
+    check(agpu_pipeline_create(device->raw, &raw), "agpu_pipeline_create");
+  }
+  ArrowComputePipeline(const ArrowComputePipeline&) = delete;
+  ~ArrowComputePipeline() {
+    if (raw) agpu_pipeline_destroy(raw);
+  }
+  void finish() { check(agpu_pipeline_finish(raw), "agpu_pipeline_finish"); }  // submit; does not wait
+  void sync() {
+    check(agpu_pipeline_sync(raw), "agpu_pipeline_sync");
+    keep.clear();
+  }
+  BufferPtr clone_buffer(const BufferPtr& b) {
+    auto out = device->create_empty_buffer(b->bytes);
+    if (b->bytes) check(agpu_copy(raw, out->ptr, b->ptr, b->bytes), "agpu_copy");
+    keep.push_back(b);
+    keep.push_back(out);
+    return out;
+  }
+};
+
+// ------------------------------------------------------------------ bitmaps
+inline uint64_t bitmap_bytes(uint64_t n_bits) { return (n_bits + 63) / 64 * 8; }
+
+struct BooleanBufferBuilder {  // [crates/array/src/array/null_bit_buffer.rs:10-62]
+  std::vector<uint8_t> data;
+  size_t len = 0;
+  bool contains_nulls = true;
+  static BooleanBufferBuilder new_with_capacity(size_t size) {
+    BooleanBufferBuilder b;
+    b.data.assign((size + 7) / 8, 0);
+    b.len = size;
+    return b;
+  }
+  static BooleanBufferBuilder new_set_with_capacity(size_t size) {
+    BooleanBufferBuilder b;
+    b.data.assign((size + 7) / 8, 0xFF);
+    if (size % 8) b.data.back() = (uint8_t)(0xFF >> (8 - size % 8));
+    b.len = size;
+    b.contains_nulls = false;
+    return b;
+  }
+  void set_bit(size_t pos) { data[pos / 8] |= (uint8_t)(1u << (pos % 8)); }
+  void unset_bit(size_t pos) { data[pos / 8] &= (uint8_t)~(1u << (pos % 8)); }
+  bool is_set(size_t pos) const { return data[pos / 8] & (1u << (pos % 8)); }
+  static bool is_set_in_slice(const uint8_t* d, size_t pos) { return d[pos / 8] & (1u << (pos % 8)); }
+};
+
+inline BufferPtr upload_bitmap(const DevicePtr& dev, const std::vector<uint8_t>& bytes, size_t n_bits) {
+  std::vector<uint8_t> padded(bitmap_bytes(n_bits) ? bitmap_bytes(n_bits) : 8, 0);
+  std::memcpy(padded.data(), bytes.data(), bytes.size());
+  return dev->create_gpu_buffer_with_data(padded.data(), padded.size());
+}
+
+struct NullBitBufferGpu {  // [null_bit_buffer.rs:92-243]
+  BufferPtr bit_buffer;
+  size_t len = 0;
+  DevicePtr gpu_device;
+  static std::optional<NullBitBufferGpu> make(const DevicePtr& dev, const BooleanBufferBuilder& b) {
+    if (!b.contains_nulls) return std::nullopt;
+    return NullBitBufferGpu{upload_bitmap(dev, b.data, b.len), b.len, dev};
+  }
+  std::vector<uint8_t> raw_values() const {
+    auto raw = gpu_device->retrive_data(bit_buffer, (len + 7) / 8);
+    return raw;
+  }
+  static std::optional<NullBitBufferGpu> clone_null_bit_buffer_op(const std::optional<NullBitBufferGpu>& d,
+                                                                   ArrowComputePipeline& p) {
+    if (!d) return std::nullopt;
+    return NullBitBufferGpu{p.clone_buffer(d->bit_buffer), d->len, d->gpu_device};
+  }
+  // (None,None)→None; one side → copy; both → AND  [null_bit_buffer.rs:206-243]
+  static std::optional<NullBitBufferGpu> merge_null_bit_buffer_op(const std::optional<NullBitBufferGpu>& l,
+                                                                   const std::optional<NullBitBufferGpu>& r,
+                                                                   ArrowComputePipeline& p) {
+    if (!l && !r) return std::nullopt;
+    if (!l || !r) return clone_null_bit_buffer_op(l ? l : r, p);
+    auto out = l->gpu_device->create_empty_buffer(l->bit_buffer->bytes);
+    check(agpu_bitmap_binary(p.raw, AGPU_OP_AND, l->bit_buffer->ptr, r->bit_buffer->ptr, out->ptr, l->len), "bitmap and");
+    p.keep.insert(p.keep.end(), {l->bit_buffer, r->bit_buffer, out});
+    return NullBitBufferGpu{out, l->len, l->gpu_device};
+  }
+  static std::optional<NullBitBufferGpu> merge_null_bit_buffer(const std::optional<NullBitBufferGpu>& l,
+                                                                const std::optional<NullBitBufferGpu>& r) {
+    if (!l && !r) return std::nullopt;
+    ArrowComputePipeline p((l ? l : r)->gpu_device);
+    auto out = merge_null_bit_buffer_op(l, r, p);
+    p.finish();
+    return out;
+  }
+};
+
+// ------------------------------------------------------------------ primitive types
+struct Date32Type {};  // i32 storage [crates/array/src/array/date32_gpu.rs]
+template <typename T> struct Prim;
+#define AGPU_PRIM(T, NATIVE, CODE, TYPE)                       \
+  template <> struct Prim<T> {                                 \
+    using Native = NATIVE;                                     \
+    static constexpr agpu_dtype dtype = CODE;                  \
+    static constexpr ArrowType arrow_type = ArrowType::TYPE;   \
+  };
+AGPU_PRIM(float, float, AGPU_F32, Float32Type)
+AGPU_PRIM(uint32_t, uint32_t, AGPU_U32, UInt32Type)
+AGPU_PRIM(uint16_t, uint16_t, AGPU_U16, UInt16Type)
+AGPU_PRIM(uint8_t, uint8_t, AGPU_U8, UInt8Type)
+AGPU_PRIM(int32_t, int32_t, AGPU_I32, Int32Type)
+AGPU_PRIM(int16_t, int16_t, AGPU_I16, Int16Type)
+AGPU_PRIM(int8_t, int8_t, AGPU_I8, Int8Type)
+AGPU_PRIM(Date32Type, int32_t, AGPU_DATE32, Date32Type)
+#undef AGPU_PRIM
+
+template <typename T, typename... Ts> inline constexpr bool is_one_of = (std::is_same_v<T, Ts> || ...);
+template <typename T> inline constexpr bool is_int32ish = is_one_of<T, int32_t, uint32_t, Date32Type>;
+template <typename T> inline constexpr bool is_small_int = is_one_of<T, int16_t, uint16_t, int8_t, uint8_t>;
+template <typename T> inline constexpr bool is_int_type = is_int32ish<T> || is_small_int<T>;
+
+class BooleanArrayGPU;
+
+template <typename T>
+class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-117]
+ public:
+  using Native = typename Prim<T>::Native;
+  static constexpr agpu_dtype DTYPE = Prim<T>::dtype;
+  BufferPtr data;
+  DevicePtr gpu_device;
+  size_t len = 0;
+  std::optional<NullBitBufferGpu> null_buffer;
+
+  PrimitiveArrayGpu() = default;
+  PrimitiveArrayGpu(BufferPtr d, DevicePtr dev, size_t n, std::optional<NullBitBufferGpu> nb)
+      : data(std::move(d)), gpu_device(std::move(dev)), len(n), null_buffer(std::move(nb)) {}
+
+  static PrimitiveArrayGpu from_optional_slice(const std::vector<std::optional<Native>>& v, const DevicePtr& dev) {
+    std::vector<Native> host(v.size(), Native());
+    auto nulls = BooleanBufferBuilder::new_with_capacity(v.size());
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i]) {
+        host[i] = *v[i];
+        nulls.set_bit(i);
+      }
+    return PrimitiveArrayGpu(dev->create_gpu_buffer_with_data(host.data(), host.size()), dev, v.size(),
+                             NullBitBufferGpu::make(dev, nulls));
+  }
+  static PrimitiveArrayGpu from_slice(const std::vector<Native>& v, const DevicePtr& dev) {
+    return PrimitiveArrayGpu(dev->create_gpu_buffer_with_data(v.data(), v.size()), dev, v.size(), std::nullopt);
+  }
+  std::vector<Native> raw_values() const {
+    auto raw = gpu_device->retrive_data(data, len * sizeof(Native));
+    std::vector<Native> out(len);
+    if (len) std::memcpy(out.data(), raw.data(), len * sizeof(Native));
+    return out;
+  }
+  std::vector<std::optional<Native>> values() const {
+    auto raw = raw_values();
+    std::vector<std::optional<Native>> out(len);
+    std::vector<uint8_t> nulls;
+    if (null_buffer) nulls = null_buffer->raw_values();
+    for (size_t i = 0; i < len; i++)
+      if (!null_buffer || BooleanBufferBuilder::is_set_in_slice(nulls.data(), i)) out[i] = raw[i];
+    return out;
+  }
+  PrimitiveArrayGpu clone_array() const {
+    ArrowComputePipeline p(gpu_device);
+    auto out = PrimitiveArrayGpu(p.clone_buffer(data), gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
+    p.finish();
+    return out;
+  }
+  ArrowType get_dtype() const { return Prim<T>::arrow_type; }
+
+  // Broadcast<T> [crates/array/src/kernels/broadcast.rs:6-17]
+  static PrimitiveArrayGpu broadcast_op(Native value, size_t n, ArrowComputePipeline& p) {
+    auto out = p.device->create_empty_buffer(n * sizeof(Native));
+    uint32_t bits = 0;
+    std::memcpy(&bits, &value, sizeof(Native));
+    check(agpu_broadcast(p.raw, DTYPE, bits, out->ptr, n), "agpu_broadcast");
+    p.keep.push_back(out);
+    return PrimitiveArrayGpu(out, p.device, n, std::nullopt);
+  }
+  static PrimitiveArrayGpu broadcast(Native value, size_t n, const DevicePtr& dev) {
+    ArrowComputePipeline p(dev);
+    auto a = broadcast_op(value, n, p);
+    p.finish();
+    return a;
+  }
+
+  // ---- generic launch helpers (impl_arithmetic_array_op!, impl_arithmetic_op!, apply_unary_function_op!)
+  template <typename Rhs>
+  PrimitiveArrayGpu binary_op_(agpu_binary_op op, const PrimitiveArrayGpu<Rhs>& v, ArrowComputePipeline& p) const {
+    if (len != v.len) throw ArrowErrorGPU(ArrowErrorGPU::Runtime, "binary op: arrays of different length");
+    auto out = gpu_device->create_empty_buffer(len * sizeof(Native));
+    check(agpu_binary(p.raw, op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_binary");
+    p.keep.insert(p.keep.end(), {data, v.data, out});
+    return PrimitiveArrayGpu(out, gpu_device, len, NullBitBufferGpu::merge_null_bit_buffer_op(null_buffer, v.null_buffer, p));
+  }
+  template <typename Rhs>
+  PrimitiveArrayGpu scalar_op_(agpu_binary_op op, const PrimitiveArrayGpu<Rhs>& v, ArrowComputePipeline& p) const {
+    auto out = gpu_device->create_empty_buffer(len * sizeof(Native));
+    check(agpu_scalar(p.raw, op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_scalar");
+    p.keep.insert(p.keep.end(), {data, v.data, out});
+    return PrimitiveArrayGpu(out, gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
+  }
+  template <typename Out = T>
+  PrimitiveArrayGpu<Out> unary_op_(agpu_unary_op op, ArrowComputePipeline& p) const {
+    auto out = gpu_device->create_empty_buffer(len * sizeof(typename Prim<Out>::Native));
+    check(agpu_unary(p.raw, op, DTYPE, data->ptr, out->ptr, len), "agpu_unary");
+    p.keep.insert(p.keep.end(), {data, out});
+    return PrimitiveArrayGpu<Out>(out, gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
+  }
+  BooleanArrayGPU compare_op_(agpu_cmp_op op, const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const;
+
+#define AGPU_DEFAULT_IMPL(NAME, ARGS_DECL, ARGS_USE)  \
+  auto NAME ARGS_DECL const {                         \
+    ArrowComputePipeline p(gpu_device);               \
+    auto out = NAME##_op ARGS_USE;                    \
+    p.finish();                                       \
+    return out;                                       \
+  }
+  // ---- arrow_gpu_arithmetic [crates/arithmetic/src/arithmetic_kernels.rs; f32.rs, i32.rs, u32.rs, u16.rs]
+  template <typename R> auto add_op(const PrimitiveArrayGpu<R>& v, ArrowComputePipeline& p) const {
+    static_assert((std::is_same_v<T, R> && (std::is_same_v<T, float> || is_int32ish<T>)) ||
+                      (is_one_of<T, int32_t, Date32Type> && is_one_of<R, int32_t, Date32Type>),
+                  "ArrowAdd is implemented for f32, u32, i32, Date32 (and i32<->Date32)");
+    return binary_op_(AGPU_OP_ADD, v, p);
+  }
+  auto sub_op(const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const {
+    static_assert(std::is_same_v<T, float> || is_int32ish<T>, "ArrowSub: f32 (reference) + 32-bit ints");
+    return binary_op_(AGPU_OP_SUB, v, p);
+  }
+  auto mul_op(const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const {
+    static_assert(std::is_same_v<T, float> || is_int32ish<T>, "ArrowMul: f32 (reference) + 32-bit ints");
+    return binary_op_(AGPU_OP_MUL, v, p);
+  }
+  auto div_op(const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const {
+    static_assert(std::is_same_v<T, float>, "ArrowDiv is implemented for f32 only");
+    return binary_op_(AGPU_OP_DIV, v, p);
+  }
+  template <typename R> auto add_scalar_op(const PrimitiveArrayGpu<R>& v, ArrowComputePipeline& p) const {
+    static_assert(std::is_same_v<T, float> || is_int32ish<T> || std::is_same_v<T, uint16_t>, "ArrowScalarAdd: f32, i32, Date32, u32, u16");
+    return scalar_op_(AGPU_OP_ADD, v, p);
+  }
+#define AGPU_SCALAR(NAME, OP)                                                                                   \
+  template <typename R> auto NAME##_op(const PrimitiveArrayGpu<R>& v, ArrowComputePipeline& p) const {          \
+    static_assert(std::is_same_v<T, float> || is_int32ish<T>, #NAME ": f32, i32, u32, Date32");                 \
+    return scalar_op_(OP, v, p);                                                                                \
+  }                                                                                                             \
+  template <typename R> AGPU_DEFAULT_IMPL(NAME, (const PrimitiveArrayGpu<R>& v), (v, p))
+  AGPU_SCALAR(sub_scalar, AGPU_OP_SUB)
+  AGPU_SCALAR(mul_scalar, AGPU_OP_MUL)
+  AGPU_SCALAR(div_scalar, AGPU_OP_DIV)
+  AGPU_SCALAR(rem_scalar, AGPU_OP_REM)
+#undef AGPU_SCALAR
+  template <typename R> AGPU_DEFAULT_IMPL(add, (const PrimitiveArrayGpu<R>& v), (v, p))
+  template <typename R> AGPU_DEFAULT_IMPL(add_scalar, (const PrimitiveArrayGpu<R>& v), (v, p))
+  AGPU_DEFAULT_IMPL(sub, (const PrimitiveArrayGpu& v), (v, p))
+  AGPU_DEFAULT_IMPL(mul, (const PrimitiveArrayGpu& v), (v, p))
+  AGPU_DEFAULT_IMPL(div, (const PrimitiveArrayGpu& v), (v, p))
+  auto neg_op(ArrowComputePipeline& p) const {
+    static_assert(std::is_same_v<T, float>, "Neg is implemented for f32");
+    return unary_op_(AGPU_UN_NEG, p);
+  }
+  AGPU_DEFAULT_IMPL(neg, (), (p))
+  // Sum → 1-element array, validity ignored, f32 in the reference's summation order [aggregate_kernels.rs:24-51]
+  auto sum_op(ArrowComputePipeline& p) const {
+    static_assert(is_one_of<T, float, int32_t, uint32_t>, "Sum32Bit: f32, i32, u32");
+    auto out = gpu_device->create_empty_buffer(16);
+    check(agpu_reduce(p.raw, AGPU_RED_SUM, DTYPE, data->ptr, nullptr, len, out->ptr), "agpu_reduce");
+    p.keep.insert(p.keep.end(), {data, out});
+    return PrimitiveArrayGpu(out, gpu_device, 1, std::nullopt);
+  }
+  AGPU_DEFAULT_IMPL(sum, (), (p))
+
+  // ---- arrow_gpu_compare [crates/compare/src/lib.rs:41-172]
+#define AGPU_CMP(NAME, OP)                                                                                  \
+  BooleanArrayGPU NAME##_op(const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const;                     \
+  BooleanArrayGPU NAME(const PrimitiveArrayGpu& v) const;
+  AGPU_CMP(gt, AGPU_CMP_GT)
+  AGPU_CMP(gteq, AGPU_CMP_GTEQ)
+  AGPU_CMP(lt, AGPU_CMP_LT)
+  AGPU_CMP(lteq, AGPU_CMP_LTEQ)
+  AGPU_CMP(eq, AGPU_CMP_EQ)
+#undef AGPU_CMP
+  auto max_op(const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const { return binary_op_(AGPU_OP_MAX, v, p); }
+  auto min_op(const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const { return binary_op_(AGPU_OP_MIN, v, p); }
+  AGPU_DEFAULT_IMPL(max, (const PrimitiveArrayGpu& v), (v, p))
+  AGPU_DEFAULT_IMPL(min, (const PrimitiveArrayGpu& v), (v, p))
+
+  // ---- arrow_gpu_logical [crates/logical/src/lib.rs:44-187]
+#define AGPU_LOGICAL(NAME, OP)                                                                       \
+  auto NAME##_op(const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const {                        \
+    static_assert(is_int_type<T> && !std::is_same_v<T, Date32Type>, #NAME ": integer arrays");       \
+    return binary_op_(OP, v, p);                                                                     \
+  }                                                                                                  \
+  AGPU_DEFAULT_IMPL(NAME, (const PrimitiveArrayGpu& v), (v, p))
+  AGPU_LOGICAL(bitwise_and, AGPU_OP_AND)
+  AGPU_LOGICAL(bitwise_or, AGPU_OP_OR)
+  AGPU_LOGICAL(bitwise_xor, AGPU_OP_XOR)
+#undef AGPU_LOGICAL
+  auto bitwise_not_op(ArrowComputePipeline& p) const {
+    static_assert(is_int_type<T> && !std::is_same_v<T, Date32Type>, "bitwise_not: integer arrays");
+    return unary_op_(AGPU_UN_NOT, p);
+  }
+  AGPU_DEFAULT_IMPL(bitwise_not, (), (p))
+  auto bitwise_shl_op(const PrimitiveArrayGpu<uint32_t>& v, ArrowComputePipeline& p) const {
+    static_assert(is_int_type<T> && !std::is_same_v<T, Date32Type>, "bitwise_shl: integer arrays");
+    return binary_op_(AGPU_OP_SHL, v, p);
+  }
+  auto bitwise_shr_op(const PrimitiveArrayGpu<uint32_t>& v, ArrowComputePipeline& p) const {
+    static_assert(is_int_type<T> && !std::is_same_v<T, Date32Type>, "bitwise_shr: integer arrays");
+    return binary_op_(AGPU_OP_SHR, v, p);
+  }
+  AGPU_DEFAULT_IMPL(bitwise_shl, (const PrimitiveArrayGpu<uint32_t>& v), (v, p))
+  AGPU_DEFAULT_IMPL(bitwise_shr, (const PrimitiveArrayGpu<uint32_t>& v), (v, p))
+
+  // ---- arrow_gpu_math / arrow_gpu_trigonometry [crates/math/src/lib.rs:37-236, crates/trigonometry/src/lib.rs:22-137]
+#define AGPU_FLOAT_UNARY(NAME, OP)                                                \
+  auto NAME##_op(ArrowComputePipeline& p) const {                                 \
+    static_assert(std::is_same_v<T, float>, #NAME " is implemented for f32");     \
+    return unary_op_(OP, p);                                                      \
+  }                                                                               \
+  AGPU_DEFAULT_IMPL(NAME, (), (p))
+  AGPU_FLOAT_UNARY(sqrt, AGPU_UN_SQRT)
+  AGPU_FLOAT_UNARY(cbrt, AGPU_UN_CBRT)
+  AGPU_FLOAT_UNARY(exp, AGPU_UN_EXP)
+  AGPU_FLOAT_UNARY(exp2, AGPU_UN_EXP2)
+  AGPU_FLOAT_UNARY(log, AGPU_UN_LOG)
+  AGPU_FLOAT_UNARY(log2, AGPU_UN_LOG2)
+  AGPU_FLOAT_UNARY(acos, AGPU_UN_ACOS)
+#undef AGPU_FLOAT_UNARY
+  auto abs_op(ArrowComputePipeline& p) const {
+    static_assert(is_one_of<T, float, int32_t>, "abs: f32, i32");
+    return unary_op_(AGPU_UN_ABS, p);
+  }
+  AGPU_DEFAULT_IMPL(abs, (), (p))
+  auto power_op(const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const {
+    static_assert(is_one_of<T, float, int32_t>, "power: f32, i32");
+    return binary_op_(AGPU_OP_POW, v, p);
+  }
+  AGPU_DEFAULT_IMPL(power, (const PrimitiveArrayGpu& v), (v, p))
+#define AGPU_TRIG(NAME, OP)                                                                                    \
+  PrimitiveArrayGpu<float> NAME##_op(ArrowComputePipeline& p) const {                                          \
+    static_assert(std::is_same_v<T, float> || is_small_int<T>, #NAME ": f32 and the fused u8/i8/u16/i16 kernels"); \
+    return unary_op_<float>(OP, p);                                                                            \
+  }                                                                                                            \
+  AGPU_DEFAULT_IMPL(NAME, (), (p))
+  AGPU_TRIG(sin, AGPU_UN_SIN)
+  AGPU_TRIG(cos, AGPU_UN_COS)
+  AGPU_TRIG(sinh, AGPU_UN_SINH)
+#undef AGPU_TRIG
+
+  // ---- arrow_gpu_cast: `a.cast<Float32ArrayGPU>()` ≙ `<A as Cast<Float32ArrayGPU>>::cast(&a)` [crates/cast/src/lib.rs]
+  template <typename OutArray> OutArray cast_op(ArrowComputePipeline& p) const {
+    using O = typename OutArray::ElemTag;
+    auto out = gpu_device->create_empty_buffer(len * sizeof(typename Prim<O>::Native));
+    agpu_status s = agpu_cast(p.raw, DTYPE, Prim<O>::dtype, data->ptr, out->ptr, len);
+    if (s == AGPU_ERR_UNSUPPORTED) throw ArrowErrorGPU(ArrowErrorGPU::CastingNotSupported, agpu_last_error());
+    check(s, "agpu_cast");
+    p.keep.insert(p.keep.end(), {data, out});
+    return OutArray(out, gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
+  }
+  template <typename OutArray> OutArray cast() const {
+    ArrowComputePipeline p(gpu_device);
+    auto out = cast_op<OutArray>(p);
+    p.finish();
+    return out;
+  }
+  using ElemTag = T;
+
+  // ---- arrow_gpu_routines: Swizzle [crates/routines/src/lib.rs:28-171]
+  PrimitiveArrayGpu merge_op(const PrimitiveArrayGpu& other, const BooleanArrayGPU& mask, ArrowComputePipeline& p) const;
+  PrimitiveArrayGpu merge(const PrimitiveArrayGpu& other, const BooleanArrayGPU& mask) const;
+  PrimitiveArrayGpu take_op(const PrimitiveArrayGpu<uint32_t>& indexes, ArrowComputePipeline& p) const;
+  PrimitiveArrayGpu take(const PrimitiveArrayGpu<uint32_t>& indexes) const {
+    ArrowComputePipeline p(gpu_device);
+    auto out = take_op(indexes, p);
+    p.finish();
+    return out;
+  }
+  void put_op(const PrimitiveArrayGpu<uint32_t>& src_indexes, PrimitiveArrayGpu& dst,
+              const PrimitiveArrayGpu<uint32_t>& dst_indexes, ArrowComputePipeline& p) const {
+    if (null_buffer || dst.null_buffer)
+      throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "put with null buffers is todo!() in the reference");
+    check(agpu_put(p.raw, (int)sizeof(Native), data->ptr, (const uint32_t*)src_indexes.data->ptr, dst.data->ptr,
+                   (const uint32_t*)dst_indexes.data->ptr, src_indexes.len), "agpu_put");
+    p.keep.insert(p.keep.end(), {data, src_indexes.data, dst.data, dst_indexes.data});
+  }
+  void put(const PrimitiveArrayGpu<uint32_t>& si, PrimitiveArrayGpu& dst, const PrimitiveArrayGpu<uint32_t>& di) const {
+    ArrowComputePipeline p(gpu_device);
+    put_op(si, dst, di, p);
+    p.finish();
+  }
+};
+
+using Float32ArrayGPU = PrimitiveArrayGpu<float>;
+using UInt32ArrayGPU = PrimitiveArrayGpu<uint32_t>;
+using UInt16ArrayGPU = PrimitiveArrayGpu<uint16_t>;
+using UInt8ArrayGPU = PrimitiveArrayGpu<uint8_t>;
+using Int32ArrayGPU = PrimitiveArrayGpu<int32_t>;
+using Int16ArrayGPU = PrimitiveArrayGpu<int16_t>;
+using Int8ArrayGPU = PrimitiveArrayGpu<int8_t>;
+using Date32ArrayGPU = PrimitiveArrayGpu<Date32Type>;
+
+// ------------------------------------------------------------------ BooleanArrayGPU [crates/array/src/array/boolean_gpu.rs]
+class BooleanArrayGPU {
+ public:
+  BufferPtr data;
+  DevicePtr gpu_device;
+  size_t len = 0;
+  std::optional<NullBitBufferGpu> null_buffer;
+  BooleanArrayGPU() = default;
+  BooleanArrayGPU(BufferPtr d, DevicePtr dev, size_t n, std::optional<NullBitBufferGpu> nb)
+      : data(std::move(d)), gpu_device(std::move(dev)), len(n), null_buffer(std::move(nb)) {}
+  static BooleanArrayGPU from_optional_slice(const std::vector<std::optional<bool>>& v, const DevicePtr& dev) {
+    auto buf = BooleanBufferBuilder::new_with_capacity(v.size());
+    auto nulls = BooleanBufferBuilder::new_with_capacity(v.size());
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i]) {
+        nulls.set_bit(i);
+        if (*v[i]) buf.set_bit(i);
+      }
+    return BooleanArrayGPU(upload_bitmap(dev, buf.data, v.size()), dev, v.size(), NullBitBufferGpu::make(dev, nulls));
+  }
+  static BooleanArrayGPU from_slice(const std::vector<bool>& v, const DevicePtr& dev) {
+    auto buf = BooleanBufferBuilder::new_with_capacity(v.size());
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i]) buf.set_bit(i);
+    return BooleanArrayGPU(upload_bitmap(dev, buf.data, v.size()), dev, v.size(), std::nullopt);
+  }
+  std::vector<bool> raw_values() const {
+    auto raw = gpu_device->retrive_data(data, (len + 7) / 8);
+    std::vector<bool> out(len);
+    for (size_t i = 0; i < len; i++) out[i] = BooleanBufferBuilder::is_set_in_slice(raw.data(), i);
+    return out;
+  }
+  std::vector<std::optional<bool>> values() const {
+    auto raw = raw_values();
+    std::vector<std::optional<bool>> out(len);
+    std::vector<uint8_t> nulls;
+    if (null_buffer) nulls = null_buffer->raw_values();
+    for (size_t i = 0; i < len; i++)
+      if (!null_buffer || BooleanBufferBuilder::is_set_in_slice(nulls.data(), i)) out[i] = raw[i];
+    return out;
+  }
+  static BooleanArrayGPU broadcast(bool value, size_t n, const DevicePtr& dev) {
+    ArrowComputePipeline p(dev);
+    auto out = dev->create_empty_buffer(bitmap_bytes(n) ? bitmap_bytes(n) : 8);
+    check(agpu_broadcast(p.raw, AGPU_BOOL, value ? 1u : 0u, out->ptr, n), "agpu_broadcast");
+    p.finish();
+    return BooleanArrayGPU(out, dev, n, std::nullopt);
+  }
+  ArrowType get_dtype() const { return ArrowType::BooleanType; }
+
+  // Logical / LogicalContains [crates/logical/src/boolean.rs:12-147]
+  BooleanArrayGPU logical_(agpu_binary_op op, const BooleanArrayGPU& v, ArrowComputePipeline& p) const {
+    auto out = gpu_device->create_empty_buffer(bitmap_bytes(len) ? bitmap_bytes(len) : 8);
+    check(agpu_bitmap_binary(p.raw, op, data->ptr, v.data->ptr, out->ptr, len), "agpu_bitmap_binary");
+    p.keep.insert(p.keep.end(), {data, v.data, out});
+    return BooleanArrayGPU(out, gpu_device, len, NullBitBufferGpu::merge_null_bit_buffer_op(null_buffer, v.null_buffer, p));
+  }
+  BooleanArrayGPU bitwise_and_op(const BooleanArrayGPU& v, ArrowComputePipeline& p) const { return logical_(AGPU_OP_AND, v, p); }
+  BooleanArrayGPU bitwise_or_op(const BooleanArrayGPU& v, ArrowComputePipeline& p) const { return logical_(AGPU_OP_OR, v, p); }
+  BooleanArrayGPU bitwise_xor_op(const BooleanArrayGPU& v, ArrowComputePipeline& p) const { return logical_(AGPU_OP_XOR, v, p); }
+  BooleanArrayGPU bitwise_not_op(ArrowComputePipeline& p) const {
+    auto out = gpu_device->create_empty_buffer(bitmap_bytes(len) ? bitmap_bytes(len) : 8);
+    check(agpu_bitmap_not(p.raw, data->ptr, out->ptr, len), "agpu_bitmap_not");
+    p.keep.insert(p.keep.end(), {data, out});
+    return BooleanArrayGPU(out, gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
+  }
+  AGPU_DEFAULT_IMPL(bitwise_and, (const BooleanArrayGPU& v), (v, p))
+  AGPU_DEFAULT_IMPL(bitwise_or, (const BooleanArrayGPU& v), (v, p))
+  AGPU_DEFAULT_IMPL(bitwise_xor, (const BooleanArrayGPU& v), (v, p))
+  AGPU_DEFAULT_IMPL(bitwise_not, (), (p))
+  bool any() const {
+    ArrowComputePipeline p(gpu_device);
+    auto out = gpu_device->create_empty_buffer(16);
+    check(agpu_bitmap_any(p.raw, data->ptr, len, (uint32_t*)out->ptr), "agpu_bitmap_any");
+    p.sync();
+    uint32_t v = 0;
+    std::memcpy(&v, gpu_device->retrive_data(out, 4).data(), 4);
+    return v != 0;
+  }
+  bool all() const {
+    ArrowComputePipeline p(gpu_device);
+    auto out = gpu_device->create_empty_buffer(16);
+    check(agpu_bitmap_popcount(p.raw, data->ptr, len, (uint64_t*)out->ptr), "agpu_bitmap_popcount");
+    p.sync();
+    uint64_t v = 0;
+    std::memcpy(&v, gpu_device->retrive_data(out, 8).data(), 8);
+    return v == len;
+  }
+  PrimitiveArrayGpu<float> cast_f32() const {  // Cast<Float32ArrayGPU> for BooleanArrayGPU [cast/src/boolean_cast.rs]
+    ArrowComputePipeline p(gpu_device);
+    auto out = gpu_device->create_empty_buffer(len * 4);
+    check(agpu_cast(p.raw, AGPU_BOOL, AGPU_F32, data->ptr, out->ptr, len), "agpu_cast");
+    auto nb = NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p);
+    p.finish();
+    return PrimitiveArrayGpu<float>(out, gpu_device, len, nb);
+  }
+};
+#undef AGPU_DEFAULT_IMPL
+
+// ---- out-of-class definitions that need BooleanArrayGPU complete
+template <typename T>
+BooleanArrayGPU PrimitiveArrayGpu<T>::compare_op_(agpu_cmp_op op, const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const {
+  if (len != v.len) throw ArrowErrorGPU(ArrowErrorGPU::Runtime, "compare: arrays of different length");
+  const uint64_t nb = bitmap_bytes(len) ? bitmap_bytes(len) : 8;
+  auto out = gpu_device->create_empty_buffer(nb);
+  std::optional<NullBitBufferGpu> nulls;
+  if (!null_buffer && !v.null_buffer) {
+    check(agpu_compare(p.raw, op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_compare");
+  } else {  // fused validity AND (the reference: a second, separately submitted dispatch)
+    auto outv = gpu_device->create_empty_buffer(nb);
+    check(agpu_compare_validity(p.raw, op, DTYPE, data->ptr, v.data->ptr,
+                                null_buffer ? null_buffer->bit_buffer->ptr : nullptr,
+                                v.null_buffer ? v.null_buffer->bit_buffer->ptr : nullptr, out->ptr, outv->ptr, len),
+          "agpu_compare_validity");
+    nulls = NullBitBufferGpu{outv, len, gpu_device};
+    if (null_buffer) p.keep.push_back(null_buffer->bit_buffer);
+    if (v.null_buffer) p.keep.push_back(v.null_buffer->bit_buffer);
+    p.keep.push_back(outv);
+  }
+  p.keep.insert(p.keep.end(), {data, v.data, out});
+  return BooleanArrayGPU(out, gpu_device, len, nulls);
+}
+#define AGPU_CMP_DEF(NAME, OP)                                                                                           \
+  template <typename T>                                                                                                  \
+  BooleanArrayGPU PrimitiveArrayGpu<T>::NAME##_op(const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const {           \
+    return compare_op_(OP, v, p);                                                                                        \
+  }                                                                                                                      \
+  template <typename T> BooleanArrayGPU PrimitiveArrayGpu<T>::NAME(const PrimitiveArrayGpu& v) const {                   \
+    ArrowComputePipeline p(gpu_device);                                                                                  \
+    auto out = NAME##_op(v, p);                                                                                          \
+    p.finish();                                                                                                          \
+    return out;                                                                                                          \
+  }
+AGPU_CMP_DEF(gt, AGPU_CMP_GT)
+AGPU_CMP_DEF(gteq, AGPU_CMP_GTEQ)
+AGPU_CMP_DEF(lt, AGPU_CMP_LT)
+AGPU_CMP_DEF(lteq, AGPU_CMP_LTEQ)
+AGPU_CMP_DEF(eq, AGPU_CMP_EQ)
+#undef AGPU_CMP_DEF
+
+inline std::optional<NullBitBufferGpu> take_null_buffer(const std::optional<NullBitBufferGpu>& nb,
+                                                        const UInt32ArrayGPU& indexes, ArrowComputePipeline& p) {
+  if (!nb) return std::nullopt;
+  auto out = indexes.gpu_device->create_empty_buffer(bitmap_bytes(indexes.len) ? bitmap_bytes(indexes.len) : 8);
+  check(agpu_take_bits(p.raw, nb->bit_buffer->ptr, nb->len, (const uint32_t*)indexes.data->ptr, out->ptr, indexes.len), "agpu_take_bits");
+  p.keep.insert(p.keep.end(), {nb->bit_buffer, indexes.data, out});
+  return NullBitBufferGpu{out, indexes.len, indexes.gpu_device};
+}
+inline void check_indices(const UInt32ArrayGPU& idx, size_t limit, ArrowComputePipeline& p, const char* what) {
+  if (!idx.len) return;
+  auto out = idx.gpu_device->create_empty_buffer(16);
+  check(agpu_index_max(p.raw, (const uint32_t*)idx.data->ptr, idx.len, (uint32_t*)out->ptr), "agpu_index_max");
+  p.sync();
+  uint32_t mx = 0;
+  std::memcpy(&mx, idx.gpu_device->retrive_data(out, 4).data(), 4);
+  if (mx >= limit) throw ArrowErrorGPU(ArrowErrorGPU::Runtime, std::string(what) + ": index out of range");
+}
+template <typename T>
+PrimitiveArrayGpu<T> PrimitiveArrayGpu<T>::take_op(const UInt32ArrayGPU& indexes, ArrowComputePipeline& p) const {
+  check_indices(indexes, len, p, "take");
+  auto out = gpu_device->create_empty_buffer(indexes.len * sizeof(Native));
+  check(agpu_take(p.raw, (int)sizeof(Native), data->ptr, len, (const uint32_t*)indexes.data->ptr, out->ptr, indexes.len), "agpu_take");
+  p.keep.insert(p.keep.end(), {data, indexes.data, out});
+  return PrimitiveArrayGpu(out, gpu_device, indexes.len, take_null_buffer(null_buffer, indexes, p));
+}
+// validity of merge: ((v1 & m) | (v2 & ~m)) & v_mask in one kernel [crates/routines/src/merge.rs:17-86]
+inline std::optional<NullBitBufferGpu> merge_null_buffers_op(const std::optional<NullBitBufferGpu>& a,
+                                                             const std::optional<NullBitBufferGpu>& b,
+                                                             const BooleanArrayGPU& mask, ArrowComputePipeline& p, size_t n) {
+  if (!a && !b && !mask.null_buffer) return std::nullopt;
+  auto out = mask.gpu_device->create_empty_buffer(bitmap_bytes(n) ? bitmap_bytes(n) : 8);
+  check(agpu_bitmap_merge_validity(p.raw, a ? a->bit_buffer->ptr : nullptr, b ? b->bit_buffer->ptr : nullptr, mask.data->ptr,
+                                   mask.null_buffer ? mask.null_buffer->bit_buffer->ptr : nullptr, out->ptr, n),
+        "agpu_bitmap_merge_validity");
+  p.keep.push_back(out);
+  return NullBitBufferGpu{out, n, mask.gpu_device};
+}
+template <typename T>
+PrimitiveArrayGpu<T> PrimitiveArrayGpu<T>::merge_op(const PrimitiveArrayGpu& other, const BooleanArrayGPU& mask,
+                                                    ArrowComputePipeline& p) const {
+  auto out = gpu_device->create_empty_buffer(len * sizeof(Native));
+  check(agpu_merge(p.raw, (int)sizeof(Native), data->ptr, other.data->ptr, mask.data->ptr, out->ptr, len), "agpu_merge");
+  p.keep.insert(p.keep.end(), {data, other.data, mask.data, out});
+  return PrimitiveArrayGpu(out, gpu_device, len, merge_null_buffers_op(null_buffer, other.null_buffer, mask, p, len));
+}
+template <typename T>
+PrimitiveArrayGpu<T> PrimitiveArrayGpu<T>::merge(const PrimitiveArrayGpu& other, const BooleanArrayGPU& mask) const {
+  ArrowComputePipeline p(gpu_device);
+  auto out = merge_op(other, mask, p);
+  p.finish();
+  return out;
+}
+
+// ------------------------------------------------------------------ enum ArrowArrayGPU + *_dyn [crates/array/src/array/mod.rs:104-186]
+using ArrowArrayGPU = std::variant<Float32ArrayGPU, UInt32ArrayGPU, UInt16ArrayGPU, UInt8ArrayGPU, Int32ArrayGPU, Int16ArrayGPU,
+                                   Int8ArrayGPU, Date32ArrayGPU, BooleanArrayGPU>;
+
+inline DevicePtr get_gpu_device(const ArrowArrayGPU& a) {
+  return std::visit([](const auto& x) { return x.gpu_device; }, a);
+}
+inline size_t len(const ArrowArrayGPU& a) {
+  return std::visit([](const auto& x) { return x.len; }, a);
+}
+inline ArrowType get_dtype(const ArrowArrayGPU& a) {
+  return std::visit([](const auto& x) { return x.get_dtype(); }, a);
+}
+template <typename A> const A& try_from(const ArrowArrayGPU& a) {  // TryFrom<ArrowArrayGPU>
+  if (auto p = std::get_if<A>(&a)) return *p;
+  throw ArrowErrorGPU(ArrowErrorGPU::CastingNotSupported, "could not cast ArrowArrayGPU into the requested array type");
+}
+[[noreturn]] inline void not_supported(const char* fn) {
+  throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, std::string("Operation ") + fn + " not supported for these types");
+}
+
+// dyn_fn! with a same-type list: dispatch when both operands hold the same listed alternative
+#define AGPU_DYN_SAME(NAME, METHOD, ...)                                                                        \
+  inline ArrowArrayGPU NAME##_op_dyn(const ArrowArrayGPU& a, const ArrowArrayGPU& b, ArrowComputePipeline& p) { \
+    return std::visit(                                                                                          \
+        [&](const auto& x, const auto& y) -> ArrowArrayGPU {                                                    \
+          using X = std::decay_t<decltype(x)>;                                                                  \
+          using Y = std::decay_t<decltype(y)>;                                                                  \
+          if constexpr (std::is_same_v<X, Y> && is_one_of<X, __VA_ARGS__>) return ArrowArrayGPU(x.METHOD(y, p)); \
+          else not_supported(#NAME "_dyn");                                                                     \
+        },                                                                                                      \
+        a, b);                                                                                                  \
+  }                                                                                                             \
+  inline ArrowArrayGPU NAME##_dyn(const ArrowArrayGPU& a, const ArrowArrayGPU& b) {                             \
+    ArrowComputePipeline p(get_gpu_device(a));                                                                  \
+    auto out = NAME##_op_dyn(a, b, p);                                                                          \
+    p.finish();                                                                                                 \
+    return out;                                                                                                 \
+  }
+// [crates/arithmetic/src/arithmetic_kernels.rs:122-175, 225-260] (the i32<->Date32 mixes are reachable through the typed API)
+AGPU_DYN_SAME(add_scalar, add_scalar_op, Float32ArrayGPU, Int32ArrayGPU, Date32ArrayGPU, UInt32ArrayGPU, UInt16ArrayGPU)
+AGPU_DYN_SAME(sub_scalar, sub_scalar_op, Float32ArrayGPU, Int32ArrayGPU, UInt32ArrayGPU)
+AGPU_DYN_SAME(mul_scalar, mul_scalar_op, Float32ArrayGPU, Int32ArrayGPU, UInt32ArrayGPU)
+AGPU_DYN_SAME(div_scalar, div_scalar_op, Float32ArrayGPU, Int32ArrayGPU, UInt32ArrayGPU)
+AGPU_DYN_SAME(rem_scalar, rem_scalar_op, Float32ArrayGPU, Int32ArrayGPU, UInt32ArrayGPU, Date32ArrayGPU)
+AGPU_DYN_SAME(add_array, add_op, Float32ArrayGPU, UInt32ArrayGPU, Int32ArrayGPU, Date32ArrayGPU)
+AGPU_DYN_SAME(sub_array, sub_op, Float32ArrayGPU)
+AGPU_DYN_SAME(mul_array, mul_op, Float32ArrayGPU)
+AGPU_DYN_SAME(div_array, div_op, Float32ArrayGPU)
+// [crates/compare/src/lib.rs:174-334]
+#define AGPU_ALL_PRIMS Float32ArrayGPU, UInt32ArrayGPU, UInt16ArrayGPU, UInt8ArrayGPU, Int32ArrayGPU, Int16ArrayGPU, Int8ArrayGPU, Date32ArrayGPU
+AGPU_DYN_SAME(gt, gt_op, AGPU_ALL_PRIMS)
+AGPU_DYN_SAME(gteq, gteq_op, AGPU_ALL_PRIMS)
+AGPU_DYN_SAME(lt, lt_op, AGPU_ALL_PRIMS)
+AGPU_DYN_SAME(lteq, lteq_op, AGPU_ALL_PRIMS)
+AGPU_DYN_SAME(eq, eq_op, AGPU_ALL_PRIMS)
+AGPU_DYN_SAME(max, max_op, AGPU_ALL_PRIMS)
+AGPU_DYN_SAME(min, min_op, AGPU_ALL_PRIMS)
+// [crates/logical/src/lib.rs:189-349]
+#define AGPU_LOGICAL_TYPES Int32ArrayGPU, UInt32ArrayGPU, UInt16ArrayGPU, Int16ArrayGPU, UInt8ArrayGPU, Int8ArrayGPU, BooleanArrayGPU
+AGPU_DYN_SAME(bitwise_and, bitwise_and_op, AGPU_LOGICAL_TYPES)
+AGPU_DYN_SAME(bitwise_or, bitwise_or_op, AGPU_LOGICAL_TYPES)
+AGPU_DYN_SAME(bitwise_xor, bitwise_xor_op, AGPU_LOGICAL_TYPES)
+AGPU_DYN_SAME(power, power_op, Int32ArrayGPU, Float32ArrayGPU)
+#undef AGPU_DYN_SAME
+
+// add_dyn & co: array∘array when both or neither have len 1, else scalar with the len-1 side as the scalar
+// [crates/arithmetic/src/arithmetic_kernels.rs:101-119]
+#define AGPU_DYN_LEN(NAME)                                                                                      \
+  inline ArrowArrayGPU NAME##_op_dyn(const ArrowArrayGPU& a, const ArrowArrayGPU& b, ArrowComputePipeline& p) { \
+    const size_t x = len(a), y = len(b);                                                                        \
+    if ((x == 1 && y == 1) || (x != 1 && y != 1)) return NAME##_array_op_dyn(a, b, p);                          \
+    if (y == 1) return NAME##_scalar_op_dyn(a, b, p);                                                           \
+    return NAME##_scalar_op_dyn(b, a, p);                                                                       \
+  }                                                                                                             \
+  inline ArrowArrayGPU NAME##_dyn(const ArrowArrayGPU& a, const ArrowArrayGPU& b) {                             \
+    ArrowComputePipeline p(get_gpu_device(a));                                                                  \
+    auto out = NAME##_op_dyn(a, b, p);                                                                          \
+    p.finish();                                                                                                 \
+    return out;                                                                                                 \
+  }
+AGPU_DYN_LEN(add)
+AGPU_DYN_LEN(sub)
+AGPU_DYN_LEN(mul)
+AGPU_DYN_LEN(div)
+#undef AGPU_DYN_LEN
+
+#define AGPU_DYN_UNARY(NAME, METHOD, ...)                                                      \
+  inline ArrowArrayGPU NAME##_op_dyn(const ArrowArrayGPU& a, ArrowComputePipeline& p) {        \
+    return std::visit(                                                                         \
+        [&](const auto& x) -> ArrowArrayGPU {                                                  \
+          using X = std::decay_t<decltype(x)>;                                                 \
+          if constexpr (is_one_of<X, __VA_ARGS__>) return ArrowArrayGPU(x.METHOD(p));          \
+          else not_supported(#NAME "_dyn");                                                    \
+        },                                                                                     \
+        a);                                                                                    \
+  }                                                                                            \
+  inline ArrowArrayGPU NAME##_dyn(const ArrowArrayGPU& a) {                                    \
+    ArrowComputePipeline p(get_gpu_device(a));                                                 \
+    auto out = NAME##_op_dyn(a, p);                                                            \
+    p.finish();                                                                                \
+    return out;                                                                                \
+  }
+AGPU_DYN_UNARY(neg, neg_op, Float32ArrayGPU)
+AGPU_DYN_UNARY(abs, abs_op, Float32ArrayGPU, Int32ArrayGPU)
+AGPU_DYN_UNARY(sqrt, sqrt_op, Float32ArrayGPU)
+AGPU_DYN_UNARY(cbrt, cbrt_op, Float32ArrayGPU)
+AGPU_DYN_UNARY(exp, exp_op, Float32ArrayGPU)
+AGPU_DYN_UNARY(exp2, exp2_op, Float32ArrayGPU)
+AGPU_DYN_UNARY(log, log_op, Float32ArrayGPU)
+AGPU_DYN_UNARY(log2, log2_op, Float32ArrayGPU)
+AGPU_DYN_UNARY(acos, acos_op, Float32ArrayGPU)
+AGPU_DYN_UNARY(sin, sin_op, Float32ArrayGPU, UInt16ArrayGPU, UInt8ArrayGPU, Int16ArrayGPU, Int8ArrayGPU)
+AGPU_DYN_UNARY(cos, cos_op, Float32ArrayGPU, UInt16ArrayGPU, UInt8ArrayGPU, Int16ArrayGPU, Int8ArrayGPU)
+AGPU_DYN_UNARY(sinh, sinh_op, Float32ArrayGPU, UInt16ArrayGPU, UInt8ArrayGPU, Int16ArrayGPU, Int8ArrayGPU)
+AGPU_DYN_UNARY(bitwise_not, bitwise_not_op, AGPU_LOGICAL_TYPES)
+#undef AGPU_DYN_UNARY
+#undef AGPU_ALL_PRIMS
+#undef AGPU_LOGICAL_TYPES
+
+inline ArrowArrayGPU take_dyn(const ArrowArrayGPU& a, const UInt32ArrayGPU& idx) {  // [crates/routines/src/take.rs:58-94]
+  return std::visit(
+      [&](const auto& x) -> ArrowArrayGPU {
+        using X = std::decay_t<decltype(x)>;
+        if constexpr (is_one_of<X, Date32ArrayGPU, UInt32ArrayGPU, Int32ArrayGPU, Float32ArrayGPU>) return ArrowArrayGPU(x.take(idx));
+        else not_supported("take_dyn");
+      },
+      a);
+}
+
+}  // namespace arrow_gpu

@@ -1,0 +1,184 @@
+// C++ host layer test: a port of the reference's examples/simple.rs plus a cross-section of its unit-test vectors
+// (values transcribed in SURVEY.md Appendix B; file:line cited per case), through host/arrow_gpu.hpp → C ABI → HIP.
+// Build + run: tests/test_gpu_cpp_host.py.  Prints "ALL OK" and exits 0 on success.
+#include <cmath>
+#include <cstdio>
+#include <limits>
+
+#include "../../host/arrow_gpu.hpp"
+
+using namespace arrow_gpu;
+template <typename T> using Opt = std::optional<T>;
+static int failures = 0;
+#define CHECK(cond)                                                   \
+  do {                                                                \
+    if (!(cond)) {                                                    \
+      std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);     \
+      failures++;                                                     \
+    }                                                                 \
+  } while (0)
+
+template <typename T> bool same(const std::vector<T>& a, const std::vector<T>& b) { return a == b; }
+constexpr std::nullopt_t N = std::nullopt;
+
+// crates/arrow/examples/simple.rs:10-41
+static void run_basic_add(const DevicePtr& device) {
+  std::vector<float> float_values;
+  for (int i = 0; i < 10; i++) float_values.push_back((float)i);
+  auto gpu_float_array = Float32ArrayGPU::from_slice(float_values, device);
+  auto gpu_float_array_scalar = Float32ArrayGPU::from_slice({20.0f}, device);
+  auto add_scalar_result = gpu_float_array.add_scalar(gpu_float_array_scalar);
+  auto vals = add_scalar_result.values();
+  for (size_t i = 0; i < vals.size(); i++) CHECK(vals[i].value() == float_values[i] + 20.0f);
+  ArrowArrayGPU lhs = gpu_float_array, rhs = gpu_float_array_scalar;
+  auto dyn_result = add_scalar_dyn(lhs, rhs);
+  CHECK(std::holds_alternative<Float32ArrayGPU>(dyn_result));
+  auto dv = try_from<Float32ArrayGPU>(dyn_result).values();
+  for (size_t i = 0; i < dv.size(); i++) CHECK(dv[i].value() == float_values[i] + 20.0f);
+}
+
+// crates/arrow/examples/simple.rs:45-72 — one pipeline, two ops, one finish()
+static void run_compute_pipeline_ops(const DevicePtr& device) {
+  ArrowComputePipeline pipeline(device, "example");
+  std::vector<float> float_values;
+  for (int i = 0; i < 100; i++) float_values.push_back((float)i);
+  ArrowArrayGPU lhs = Float32ArrayGPU::from_slice(float_values, device);
+  ArrowArrayGPU rhs = Float32ArrayGPU::from_slice({20.0f}, device);
+  auto r1 = add_scalar_op_dyn(lhs, rhs, pipeline);
+  auto r2 = mul_scalar_op_dyn(r1, rhs, pipeline);
+  pipeline.finish();
+  auto v = try_from<Float32ArrayGPU>(r2).values();
+  for (size_t i = 0; i < v.size(); i++) CHECK(v[i].value() == (float_values[i] + 20.0f) * 20.0f);
+}
+
+int main() {
+  DevicePtr device;
+  try {
+    device = GPU_DEVICE();
+  } catch (const ArrowErrorGPU& e) {
+    std::printf("no device: %s\n", e.what());
+    return 2;
+  }
+  run_basic_add(device);
+  run_compute_pipeline_ops(device);
+
+  {  // crates/arithmetic/src/f32.rs:209-255 — f32 array ops with nulls, typed + dyn
+    auto a = Float32ArrayGPU::from_optional_slice({0.0f, 1.0f, N, N, 4.0f}, device);
+    auto b = Float32ArrayGPU::from_optional_slice({1.0f, 2.0f, N, 4.0f, N}, device);
+    CHECK(same(a.add(b).values(), {Opt<float>(1.0f), 3.0f, N, N, N}));
+    CHECK(same(a.mul(b).values(), {Opt<float>(0.0f), 2.0f, N, N, N}));
+    CHECK(same(a.div(b).values(), {Opt<float>(0.0f), 0.5f, N, N, N}));
+    CHECK(same(try_from<Float32ArrayGPU>(add_dyn(ArrowArrayGPU(a), ArrowArrayGPU(b))).values(), {Opt<float>(1.0f), 3.0f, N, N, N}));
+    // crates/array/src/array/f32_gpu.rs:91-123 — raw values, validity bytes, validity AND
+    CHECK(same(a.raw_values(), {0.0f, 1.0f, 0.0f, 0.0f, 4.0f}));
+    CHECK(a.null_buffer->raw_values() == std::vector<uint8_t>{0b00010011});
+    CHECK(b.null_buffer->raw_values() == std::vector<uint8_t>{0b00001011});
+    CHECK(NullBitBufferGpu::merge_null_bit_buffer(b.null_buffer, a.null_buffer)->raw_values() == std::vector<uint8_t>{0b00000011});
+  }
+  {  // crates/arithmetic/src/i32.rs:152-162 (wrap), u32.rs:85-95 (underflow), f32.rs:257-265 (neg)
+    auto a = Int32ArrayGPU::from_slice({0, std::numeric_limits<int32_t>::max(), 2, 3, 4}, device);
+    auto s = Int32ArrayGPU::from_slice({100}, device);
+    CHECK(same(a.mul_scalar(s).raw_values(), {0, -100, 200, 300, 400}));
+    auto u = UInt32ArrayGPU::from_slice({0, 100, 200, 3, 104}, device);
+    auto us = UInt32ArrayGPU::from_slice({100}, device);
+    CHECK(same(u.sub_scalar(us).raw_values(), {0xFFFFFFFFu - 99, 0u, 100u, 0xFFFFFFFFu - 96, 4u}));
+    auto f = Float32ArrayGPU::from_slice({0.f, 1.f, 2.f, 3.f, -1.f, -2.f, -3.f}, device);
+    CHECK(same(f.neg().raw_values(), {-0.f, -1.f, -2.f, -3.f, 1.f, 2.f, 3.f}));
+    // i32 + Date32 keeps Output = Self (crates/arithmetic/src/i32.rs:246-255)
+    auto d = Date32ArrayGPU::from_optional_slice({1, 2, N, 4, N}, device);
+    auto ia = Int32ArrayGPU::from_optional_slice({0, 1, N, N, 4}, device);
+    CHECK(same(ia.add(d).values(), {Opt<int32_t>(1), 3, N, N, N}));
+  }
+  {  // crates/arithmetic/src/lib.rs:100-113 — Sum KATs (f32 in the reference's tree order)
+    CHECK(Float32ArrayGPU::broadcast(5.0f, 256 * 256, device).sum().raw_values() == std::vector<float>{327680.0f});
+    CHECK(Float32ArrayGPU::broadcast(5.0f, 4 * 1024 * 1024, device).sum().raw_values() == std::vector<float>{20971520.0f});
+    CHECK(Int32ArrayGPU::broadcast(-5, 256 * 256, device).sum().raw_values() == std::vector<int32_t>{-327680});
+  }
+  {  // crates/compare/src/i32.rs:250-293 — eq with nulls (fused validity AND); f32.rs NaN table
+    auto a = Int32ArrayGPU::from_optional_slice({0, 3, 3, 0, 3, N, N, 4, 40, 7}, device);
+    auto b = Int32ArrayGPU::from_optional_slice({1, 2, 1, 2, 3, N, 4, N, 4, 7}, device);
+    CHECK(same(a.eq(b).values(), {Opt<bool>(false), false, false, false, true, N, N, N, false, true}));
+    CHECK(same(a.gteq(b).values(), {Opt<bool>(false), true, true, false, true, N, N, N, true, true}));
+    CHECK(same(try_from<BooleanArrayGPU>(lt_dyn(ArrowArrayGPU(a), ArrowArrayGPU(b))).values(),
+               {Opt<bool>(true), false, false, true, false, N, N, N, false, false}));
+    const float nan = std::nanf(""), inf = INFINITY;
+    auto fa = Float32ArrayGPU::from_slice({-1.f, 3.f, nan, inf, -inf, nan}, device);
+    auto fb = Float32ArrayGPU::from_slice({0.f, 2.f, nan, inf, inf, 3.f}, device);
+    CHECK(same(fa.gt(fb).raw_values(), {false, true, false, false, false, false}));
+    auto mx = fa.max(fb).raw_values();
+    CHECK(mx[0] == 0.f && mx[1] == 3.f && std::isnan(mx[2]) && mx[3] == inf && mx[4] == inf && mx[5] == 3.f);
+  }
+  {  // crates/logical/src/i32.rs:18-116, boolean.rs:154-319
+    auto a = Int32ArrayGPU::from_optional_slice({0, 1, 100, 100, 260, N}, device);
+    auto b = Int32ArrayGPU::from_optional_slice({0, -1, 100, ~100, N, ~450}, device);
+    CHECK(same(a.bitwise_and(b).values(), {Opt<int32_t>(0), 1, 100, 0, N, N}));
+    CHECK(same(a.bitwise_xor(b).values(), {Opt<int32_t>(0), 1 ^ -1, 0, -1, N, N}));
+    CHECK(same(Int32ArrayGPU::from_slice({0, 1, 2, 3, 4}, device).bitwise_not().raw_values(), {-1, -2, -3, -4, -5}));
+    auto ba = BooleanArrayGPU::from_optional_slice({true, true, false, false, true, N}, device);
+    auto bb = BooleanArrayGPU::from_optional_slice({true, false, true, false, N, true}, device);
+    CHECK(same(ba.bitwise_or(bb).values(), {Opt<bool>(true), true, true, false, N, N}));
+    CHECK(BooleanArrayGPU::from_slice(std::vector<bool>(16384, false), device).any() == false);
+    CHECK(BooleanArrayGPU::from_slice(std::vector<bool>(100, true), device).all() == true);
+    std::vector<bool> big(2 * 1024 * 1024, true);
+    big.push_back(false);
+    CHECK(BooleanArrayGPU::from_slice(big, device).all() == false);
+  }
+  {  // crates/cast/src/{u8_cast,i8_cast,f32_cast,boolean_cast}.rs
+    auto u8 = UInt8ArrayGPU::from_slice({0, 1, 2, 3, 255, 250, 7}, device);
+    CHECK(same(u8.cast<Float32ArrayGPU>().raw_values(), {0.f, 1.f, 2.f, 3.f, 255.f, 250.f, 7.f}));
+    auto i8 = Int8ArrayGPU::from_slice({0, 1, 2, 3, -1, -2, -3, -7, 7}, device);
+    CHECK(same(i8.cast<UInt32ArrayGPU>().raw_values(), {0u, 1u, 2u, 3u, 0xFFFFFFFFu, 0xFFFFFFFEu, 0xFFFFFFFDu, 0xFFFFFFF9u, 7u}));
+    auto f = Float32ArrayGPU::from_slice({0.f, 1.f, -1.f, 5713.f, -5713.f, 255.f, 256.f}, device);
+    CHECK(same(f.cast<UInt8ArrayGPU>().raw_values(), {(uint8_t)0, 1, 0, 81, 0, 255, 0}));
+    bool threw = false;
+    try { (void)f.cast<Int32ArrayGPU>(); } catch (const ArrowErrorGPU& e) { threw = e.kind == ArrowErrorGPU::CastingNotSupported; }
+    CHECK(threw);
+    auto bl = BooleanArrayGPU::from_slice({true, false, true, true, false, false, true, true, false}, device);
+    CHECK(same(bl.cast_f32().raw_values(), {1.f, 0.f, 1.f, 1.f, 0.f, 0.f, 1.f, 1.f, 0.f}));
+  }
+  {  // crates/trigonometry/src/{f32,u8}_kernel.rs (reference tolerance 0.01; here ≤ 1 ULP of the f64-rounded value)
+    auto f = Float32ArrayGPU::from_slice({0.f, 1.f, 2.f, 3.f, -1.f, -2.f, -3.f}, device);
+    auto s = f.sin().raw_values();
+    auto c = f.cos().raw_values();
+    const float xs[] = {0.f, 1.f, 2.f, 3.f, -1.f, -2.f, -3.f};
+    for (int i = 0; i < 7; i++) {
+      CHECK(std::fabs(s[i] - (float)std::sin((double)xs[i])) <= std::fabs(std::nextafter(s[i], 2.f) - s[i]));
+      CHECK(std::fabs(c[i] - (float)std::cos((double)xs[i])) <= std::fabs(std::nextafter(c[i], 2.f) - c[i]));
+    }
+    auto su = UInt8ArrayGPU::from_slice({0, 1, 2, 3, 5}, device).sin().raw_values();
+    CHECK(su[0] == 0.f && std::fabs(su[4] - (float)std::sin(5.0)) < 1e-6f);
+    bool threw = false;
+    try { (void)sqrt_dyn(ArrowArrayGPU(Int32ArrayGPU::from_slice({1}, device))); } catch (const ArrowErrorGPU& e) { threw = e.kind == ArrowErrorGPU::OperationNotSupported; }
+    CHECK(threw);
+  }
+  {  // crates/routines/src/f32.rs:14-99 — merge / take / put
+    auto a = Float32ArrayGPU::from_optional_slice({0.f, 1.f, N, N, 4.f, 4.f, 10.f, N, 50.f}, device);
+    auto b = Float32ArrayGPU::from_optional_slice({1.f, 2.f, N, 4.f, N, N, 20.f, 30.f, N}, device);
+    auto m = BooleanArrayGPU::from_optional_slice({true, true, false, false, true, false, N, N, false}, device);
+    CHECK(same(a.merge(b, m).values(), {Opt<float>(0.f), 1.f, N, 4.f, 4.f, N, N, N, N}));
+    auto v = Float32ArrayGPU::from_optional_slice({0.f, 1.f, N, 3.f}, device);
+    auto idx = UInt32ArrayGPU::from_slice({0, 1, 2, 3, 0, 1, 2, 3}, device);
+    CHECK(same(v.take(idx).values(), {Opt<float>(0.f), 1.f, N, 3.f, 0.f, 1.f, N, 3.f}));
+    auto src = Float32ArrayGPU::from_slice({10.f, 1.f, 2.f, 3.f}, device);
+    auto dst = Float32ArrayGPU::from_slice({100.f, 0.f, 101.f, 0.f, 102.f, 0.f, 103.f, 0.f}, device);
+    src.put(UInt32ArrayGPU::from_slice({0, 1, 2, 3}, device), dst, UInt32ArrayGPU::from_slice({1, 3, 5, 7}, device));
+    CHECK(same(dst.raw_values(), {100.f, 10.f, 101.f, 1.f, 102.f, 2.f, 103.f, 3.f}));
+    bool threw = false;
+    try { (void)v.take(UInt32ArrayGPU::from_slice({9}, device)); } catch (const ArrowErrorGPU&) { threw = true; }
+    CHECK(threw);  // HIP has no robust buffer access: out-of-range indices are rejected
+  }
+  {  // builder (crates/array/src/array/null_bit_buffer.rs:68-87)
+    auto b = BooleanBufferBuilder::new_with_capacity(10);
+    b.set_bit(0);
+    b.set_bit(9);
+    CHECK(b.data.size() == 2 && b.data[0] == 1 && b.data[1] == 2 && !b.is_set(5) && b.is_set(9));
+    auto s = BooleanBufferBuilder::new_set_with_capacity(10);
+    CHECK(s.data[0] == 0xFF && s.data[1] == 0b00000011);
+  }
+  if (failures) {
+    std::printf("%d check(s) failed\n", failures);
+    return 1;
+  }
+  std::printf("ALL OK\n");
+  return 0;
+}
