@@ -156,7 +156,9 @@ agpu_status agpu_bitmap_popcount(agpu_pipeline* p, const void* bits, uint64_t n_
   if (n_bits == 0) return AGPU_OK;
   AGPU_REQUIRE(bits && aligned_to(bits, 8), AGPU_ERR_SHAPE, "bitmap must be 8-byte aligned");
   const uint64_t n_words = (n_bits + 63) / 64;
-  const int grid = stream_grid_for(p, (n_words + AGPU_BLOCK * 4 - 1) / (AGPU_BLOCK * 4));
+  // ≤ 1024 blocks: every block ends with ONE atomic on the same word, and same-address atomics serialise
+  // (15 259 blocks → 0.19 ms for a 125 MB bitmap; 1024 → bandwidth-bound)
+  const int grid = atomic_grid_for(p, (n_words + AGPU_BLOCK * 4 - 1) / (AGPU_BLOCK * 4));
   hipLaunchKernelGGL((popcount_kernel<false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
                      static_cast<const uint64_t*>(bits), n_bits, reinterpret_cast<unsigned long long*>(out_count_dev),
                      (uint32_t*)nullptr);
@@ -171,7 +173,9 @@ agpu_status agpu_bitmap_any(agpu_pipeline* p, const void* bits, uint64_t n_bits,
   if (n_bits == 0) return AGPU_OK;
   AGPU_REQUIRE(bits && aligned_to(bits, 8), AGPU_ERR_SHAPE, "bitmap must be 8-byte aligned");
   const uint64_t n_words = (n_bits + 63) / 64;
-  const int grid = stream_grid_for(p, (n_words + AGPU_BLOCK * 4 - 1) / (AGPU_BLOCK * 4));
+  // ≤ 1024 blocks: every block ends with ONE atomic on the same word, and same-address atomics serialise
+  // (15 259 blocks → 0.19 ms for a 125 MB bitmap; 1024 → bandwidth-bound)
+  const int grid = atomic_grid_for(p, (n_words + AGPU_BLOCK * 4 - 1) / (AGPU_BLOCK * 4));
   hipLaunchKernelGGL((popcount_kernel<true>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
                      static_cast<const uint64_t*>(bits), n_bits, (unsigned long long*)nullptr, out_any_dev);
   AGPU_LAUNCH_CHECK();

@@ -113,6 +113,15 @@ static inline int stream_grid_for(const agpu_pipeline* p, uint64_t tiles) {
   return (int)g;
 }
 
+// Grid for kernels that finish with an atomic on ONE word per block/wave (popcount, any, index max, checksum):
+// same-address atomics serialise at ≈12 ns each, so the block count is capped and the kernels grid-stride.
+static inline int atomic_grid_for(const agpu_pipeline* p, uint64_t work_blocks) {
+  uint64_t g = (uint64_t)p->dev->num_cus * 4;
+  if (g > work_blocks) g = work_blocks;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 // ---------------------------------------------------------------- device helpers
 #define AGPU_BLOCK 256
 #define AGPU_WAVE 64

@@ -154,7 +154,7 @@ struct OpPow {  // f32: NaN for negative/NaN base (math/src/f32.rs:209-271), els
   template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
     if constexpr (std::is_floating_point<T>::value) {
       if (x != x || y != y || x < 0.0f || (x == 0.0f && __builtin_signbit(x))) return __builtin_nanf("");
-      return (float)pow((double)x, (double)y);
+      return powf(x, y);  // ≤ 1 ULP measured (tools/probe/math_ulp.py); the f64 pow is 4× slower than the stream
     } else return (T)i32_pow_dev((int32_t)x, (int32_t)y);
   }
 };
@@ -212,16 +212,48 @@ __device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
   return (float)v;
 }
 
+// log: x = m·2^e with m ∈ [√½, √2), s = (m−1)/(m+1), log m = 2s + s·z·P(z), z = s² (|s| ≤ 0.172), P = 2/3 + 2/5 z + …
+// + 2/11 z⁴ evaluated in f32 (it weighs < 1 % of the result), the division as an f32 reciprocal + one f64 Newton step,
+// the rest in f64, ONE rounding to f32.  (The f32 library logf measures 2 ULP on gfx950; the f64 library log is
+// VALU-bound at 37 % of HBM — tools/probe/math_ulp.py, profiles/r01_kernel_table.json.)
+__device__ __forceinline__ float log_f32_dev(float x) {
+  if (!(x > 0.0f) || !(x < __builtin_inff())) {  // 0, negatives, NaN, +inf
+    if (x == 0.0f) return -__builtin_inff();
+    if (x < 0.0f || x != x) return __builtin_nanf("");
+    return x;
+  }
+  int e;
+  double m = frexp((double)x, &e);  // m ∈ [0.5, 1)
+  if (m < 0x1.6a09e667f3bcdp-1) {   // < √½ : use [√½, √2)
+    m *= 2.0;
+    e -= 1;
+  }
+  const double f = m - 1.0, d = m + 1.0;
+  const double r0 = (double)(1.0f / (float)d);
+  const double r = r0 * fma(-d, r0, 2.0);  // 1/d to 2^-46
+  const double s = f * r;
+  const double z = s * s;
+  const float zf = (float)z;
+  float pf = __builtin_fmaf(zf, 0.18181818f, 0.22222222f);
+  pf = __builtin_fmaf(zf, pf, 0.2857143f);
+  pf = __builtin_fmaf(zf, pf, 0.4f);
+  pf = __builtin_fmaf(zf, pf, 0.6666667f);
+  const double t = fma(s * z, (double)pf, s + s);
+  return (float)fma((double)e, 0x1.62e42fefa39efp-1, t);
+}
+
+// The remaining functions use the f32 device library where it measures ≤ 1 ULP on gfx950 over 4 M log-uniform samples
+// (tools/probe/math_ulp.py: sinhf, acosf, cbrtf, exp2f, log2f, expf, powf = 1 ULP).
 struct UnSqrt { __device__ static __forceinline__ float ap(float x, float) { return sqrtf(x); } };  // correctly rounded
-struct UnCbrt { __device__ static __forceinline__ float ap(float x, float) { return (float)cbrt((double)x); } };
-struct UnExp { __device__ static __forceinline__ float ap(float x, float) { return (float)exp((double)x); } };
-struct UnExp2 { __device__ static __forceinline__ float ap(float x, float) { return (float)exp2((double)x); } };
-struct UnLog { __device__ static __forceinline__ float ap(float x, float) { return (float)log((double)x); } };
-struct UnLog2 { __device__ static __forceinline__ float ap(float x, float) { return (float)log2((double)x); } };
+struct UnCbrt { __device__ static __forceinline__ float ap(float x, float) { return cbrtf(x); } };
+struct UnExp { __device__ static __forceinline__ float ap(float x, float) { return expf(x); } };
+struct UnExp2 { __device__ static __forceinline__ float ap(float x, float) { return exp2f(x); } };
+struct UnLog { __device__ static __forceinline__ float ap(float x, float) { return log_f32_dev(x); } };
+struct UnLog2 { __device__ static __forceinline__ float ap(float x, float) { return log2f(x); } };
 struct UnSin { __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 0); } };
 struct UnCos { __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 1); } };
-struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { return (float)acos((double)x); } };
-struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return (float)sinh((double)x); } };
+struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { return acosf(x); } };
+struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return sinhf(x); } };
 
 // ---------------------------------------------------------------- same-width streaming kernel
 // out[i] = Op(a[i], b[i] | *b | -).  The hot kernel covers FULL tiles only and carries no tail code (the tail costs

@@ -258,7 +258,7 @@ agpu_status agpu_index_max(agpu_pipeline* p, const uint32_t* idx, uint64_t n, ui
   AGPU_HIP(hipMemsetAsync(out_max_dev, 0, sizeof(uint32_t), p->stream));
   if (n == 0) return AGPU_OK;
   AGPU_REQUIRE(idx, AGPU_ERR_ARG, "null pointer");
-  const int grid = gs_grid(p, (n + 7) / 8);
+  const int grid = atomic_grid_for(p, (n + AGPU_BLOCK * 8 - 1) / (AGPU_BLOCK * 8));  // few blocks: same-address atomics
   hipLaunchKernelGGL(index_max_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, idx, n, out_max_dev);
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;

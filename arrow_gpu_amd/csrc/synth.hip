@@ -156,7 +156,7 @@ agpu_status agpu_checksum(agpu_pipeline* p, const void* data, uint64_t bytes, ui
   AGPU_HIP(hipMemsetAsync(out_sum_dev, 0, sizeof(uint64_t), p->stream));
   if (bytes == 0) return AGPU_OK;
   AGPU_REQUIRE(data && aligned_to(data, 8), AGPU_ERR_SHAPE, "data must be 8-byte aligned");
-  const int grid = stream_grid_for(p, (bytes / 8 + AGPU_BLOCK * 4 - 1) / (AGPU_BLOCK * 4));
+  const int grid = atomic_grid_for(p, (bytes / 8 + AGPU_BLOCK * 4 - 1) / (AGPU_BLOCK * 4));  // same-address atomics
   hipLaunchKernelGGL(checksum_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(data),
                      bytes, reinterpret_cast<unsigned long long*>(out_sum_dev));
   AGPU_LAUNCH_CHECK();

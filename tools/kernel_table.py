@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""DEV TOOL: time every kernel family at BASELINE size on the GPU box and print the DESIGN.md §4 table
+(algorithmic bytes ÷ median HIP-event time).   python tools/kernel_table.py [--rows 1000000000] [--tag r01]
+Writes gpurun_out/kernel_table_<tag>.json (copy into profiles/)."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from arrow_gpu_amd import _capi as capi  # noqa: E402
+from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, CmpQuery, GpuDevice  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1_000_000_000)
+    ap.add_argument("--iters", type=int, default=9)
+    ap.add_argument("--tag", default="r01")
+    args = ap.parse_args()
+    n = args.rows
+    dev = GpuDevice(0)
+    p = ArrowComputePipeline(dev, "table")
+    q = CmpQuery(dev)
+    h = p._handle
+    vp = lambda b, off=0: C.c_void_p(b.ptr + off)  # noqa: E731
+    nb = (n + 63) // 64 * 8
+    A, B, O = (dev.create_empty_buffer(4 * n) for _ in range(3))
+    VA, VB, OB, OV, M = (dev.create_empty_buffer(nb) for _ in range(5))
+    R = dev.create_empty_buffer(64)
+    S = dev.create_gpu_buffer_with_data(np.array([3.0], np.float32))
+    SI = dev.create_gpu_buffer_with_data(np.array([3], np.int32))
+    capi.call("agpu_synth_f32", h, vp(A), n, 1, 0, C.c_float(-1000), C.c_float(1000))
+    capi.call("agpu_synth_f32", h, vp(B), n, 2, 0, C.c_float(-1000), C.c_float(1000))
+    for buf, seed in ((VA, 3), (VB, 4), (M, 5)):
+        capi.call("agpu_synth_bits", h, vp(buf), n, seed, 0, C.c_double(0.9 if buf is not M else 0.5))
+    p.sync()
+    rows = []
+
+    def t(label, bytes_per_row, f, note=""):
+        f()
+        p.sync()
+        ts = []
+        for _ in range(args.iters):
+            q.begin(p)
+            f()
+            q.end(p)
+            ts.append(q.wait_for_results())
+        ms = float(np.median(ts))
+        r = {"kernel": label, "alg_B_per_row": bytes_per_row, "ms": round(ms, 4), "GBps": round(bytes_per_row * n / ms / 1e6, 1),
+             "frac_8TBs": round(bytes_per_row * n / ms / 1e6 / 8000, 4), "note": note}
+        rows.append(r)
+        print(r, flush=True)
+
+    F32, I32, U8 = capi.F32, capi.I32, capi.U8
+    for name, op in (("add", capi.OP_ADD), ("sub", capi.OP_SUB), ("mul", capi.OP_MUL), ("div", capi.OP_DIV), ("min", capi.OP_MIN), ("max", capi.OP_MAX)):
+        t(f"f32 {name} (array∘array)", 12, lambda op=op: capi.call("agpu_binary", h, op, F32, vp(A), vp(B), vp(O), n))
+    t("i32 add (wrapping)", 12, lambda: capi.call("agpu_binary", h, capi.OP_ADD, I32, vp(A), vp(B), vp(O), n))
+    t("u32 and", 12, lambda: capi.call("agpu_binary", h, capi.OP_AND, capi.U32, vp(A), vp(B), vp(O), n))
+    t("f32 add_scalar", 8, lambda: capi.call("agpu_scalar", h, capi.OP_ADD, F32, vp(A), vp(S), vp(O), n))
+    t("i32 mul_scalar", 8, lambda: capi.call("agpu_scalar", h, capi.OP_MUL, I32, vp(A), vp(SI), vp(O), n))
+    t("f32 rem_scalar", 8, lambda: capi.call("agpu_scalar", h, capi.OP_REM, F32, vp(A), vp(S), vp(O), n))
+    for name, op in (("neg", capi.UN_NEG), ("abs", capi.UN_ABS), ("sqrt", capi.UN_SQRT), ("sin", capi.UN_SIN), ("cos", capi.UN_COS),
+                     ("exp", capi.UN_EXP), ("log", capi.UN_LOG), ("sinh", capi.UN_SINH), ("cbrt", capi.UN_CBRT), ("acos", capi.UN_ACOS)):
+        t(f"f32 {name}", 8, lambda op=op: capi.call("agpu_unary", h, op, F32, vp(A), vp(O), n))
+    t("f32 power", 12, lambda: capi.call("agpu_binary", h, capi.OP_POW, F32, vp(A), vp(B), vp(O), n))
+    for name, op in (("eq", capi.CMP_EQ), ("lt", capi.CMP_LT), ("gt", capi.CMP_GT)):
+        t(f"i32 {name} → bitmap + validity AND (fused)", 8.5,
+          lambda op=op: capi.call("agpu_compare_validity", h, op, I32, vp(A), vp(B), vp(VA), vp(VB), vp(OB), vp(OV), n))
+    t("i32 eq → bitmap (no validity)", 8.125, lambda: capi.call("agpu_compare", h, capi.CMP_EQ, I32, vp(A), vp(B), vp(OB), n))
+    t("f32 lt → bitmap", 8.125, lambda: capi.call("agpu_compare", h, capi.CMP_LT, F32, vp(A), vp(B), vp(OB), n))
+    t("u8 eq → bitmap (vector variant)", 2.125, lambda: capi.call("agpu_compare", h, capi.CMP_EQ, U8, vp(A), vp(B), vp(OB), n))
+    t("validity AND (bitmap)", 0.375, lambda: capi.call("agpu_bitmap_binary", h, capi.OP_AND, vp(VA), vp(VB), vp(OV), n))
+    t("bitmap not", 0.25, lambda: capi.call("agpu_bitmap_not", h, vp(VA), vp(OV), n))
+    t("popcount (null count)", 0.125, lambda: capi.call("agpu_bitmap_popcount", h, vp(VA), n, vp(R)))
+    t("merge validity (fused 4-input)", 0.625, lambda: capi.call("agpu_bitmap_merge_validity", h, vp(VA), vp(VB), vp(M), vp(VA), vp(OV), n))
+    t("cast u8→f32", 5, lambda: capi.call("agpu_cast", h, U8, F32, vp(B), vp(O), n))
+    t("cast i16→f32", 6, lambda: capi.call("agpu_cast", h, capi.I16, F32, vp(B), vp(O), n))
+    t("cast f32→u8", 5, lambda: capi.call("agpu_cast", h, F32, U8, vp(A), vp(O), n))
+    t("cast u8→u32", 5, lambda: capi.call("agpu_cast", h, U8, capi.U32, vp(B), vp(O), n))
+    t("fused sin_u8 (LDS table)", 5, lambda: capi.call("agpu_unary", h, capi.UN_SIN, U8, vp(B), vp(O), n))
+    t("fused cos_i8 (LDS table)", 5, lambda: capi.call("agpu_unary", h, capi.UN_COS, capi.I8, vp(B), vp(O), n))
+    t("fused sin_u16", 6, lambda: capi.call("agpu_unary", h, capi.UN_SIN, capi.U16, vp(B), vp(O), n))
+    t("broadcast f32", 4, lambda: capi.call("agpu_broadcast", h, F32, 0x40400000, vp(O), n))
+    t("f32 sum (reference tree order)", 4, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, F32, vp(A), None, n, vp(R)))
+    t("f32 sum, null-aware", 4.125, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, F32, vp(A), vp(VA), n, vp(R)))
+    t("f32 sum f64-accumulated", 4, lambda: capi.call("agpu_reduce_sum_f64", h, vp(A), None, n, vp(R)))
+    t("f32 min", 4, lambda: capi.call("agpu_reduce", h, capi.RED_MIN, F32, vp(A), None, n, vp(R)))
+    t("f32 max", 4, lambda: capi.call("agpu_reduce", h, capi.RED_MAX, F32, vp(A), None, n, vp(R)))
+    t("i32 sum (wrapping)", 4, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, I32, vp(A), None, n, vp(R)))
+    t("merge f32 by mask", 12.125, lambda: capi.call("agpu_merge", h, 4, vp(A), vp(B), vp(M), vp(O), n))
+    # gather / scatter: sequential indices (best case) and a pseudo-random permutation (worst case)
+    m = min(n, 1 << 28)
+    IDX = dev.create_empty_buffer(4 * m)
+    capi.call("agpu_synth_i32", h, vp(IDX), m, 9, 0, m)  # uniform random indices in [0, m)
+    t("take f32, random idx (2^28 rows)", 12 * m / n, lambda: capi.call("agpu_take", h, 4, vp(A), m, vp(IDX), vp(O), m),
+      note="bytes/row quoted per 1e9-row column; rate = 12 B × 2^28 rows ÷ time")
+    rows[-1]["GBps"] = round(12 * m / rows[-1]["ms"] / 1e6, 1)
+    rows[-1]["frac_8TBs"] = round(rows[-1]["GBps"] / 8000, 4)
+    t("put f32, random idx (2^28 rows)", 16 * m / n, lambda: capi.call("agpu_put", h, 4, vp(A), vp(IDX), vp(O), vp(IDX), m))
+    rows[-1]["GBps"] = round(16 * m / rows[-1]["ms"] / 1e6, 1)
+    rows[-1]["frac_8TBs"] = round(rows[-1]["GBps"] / 8000, 4)
+    t("take_bits, random idx (2^28 rows)", 4.25 * m / n, lambda: capi.call("agpu_take_bits", h, vp(VA), m, vp(IDX), vp(OB), m))
+    rows[-1]["GBps"] = round(4.25 * m / rows[-1]["ms"] / 1e6, 1)
+    rows[-1]["frac_8TBs"] = round(rows[-1]["GBps"] / 8000, 4)
+    t("hipMemcpy D2D 4 GB (context)", 8, lambda: capi.call("agpu_copy", h, vp(O), vp(A), 4 * n))
+
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/kernel_table_{args.tag}.json", "w") as f:
+        json.dump({"rows": n, "device": dev.name, "kernels": rows}, f, indent=1)
+    print("\n| kernel | alg. B/row | ms @1e9 | GB/s | frac of 8 TB/s |\n|---|---|---|---|---|")
+    for r in rows:
+        print(f"| {r['kernel']} | {r['alg_B_per_row']:.4g} | {r['ms']} | {r['GBps']} | {r['frac_8TBs']} |")
+
+
+if __name__ == "__main__":
+    main()
