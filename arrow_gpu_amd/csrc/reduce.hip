@@ -73,12 +73,37 @@ __device__ __forceinline__ float span_tree_sum(const float* in, const uint8_t* v
 #pragma unroll
     for (int u = 0; u < UNR; u++)
       s[u] = load4_tree<GUARD, HASV>(in, validity, wave_base + (uint64_t)(j0 + u) * 256 + lane * 4, n);
+    // Reduce EIGHT 256-row blocks at once ("transpose-reduce"): at butterfly step k the two registers of a pair are
+    // merged so that lanes with bit k clear keep the even block and lanes with bit k set keep the odd one.  Every add
+    // still pairs lane l with lane l^2^k in the order 1, 2, 4, … — the reference's adjacent-pair tree (f32 addition is
+    // commutative, so which side is "left" does not change the bits) — but 8 blocks cost 10 shuffles instead of 48.
+    float t4[4], t2[2];
 #pragma unroll
-    for (int u = 0; u < UNR; u++) {
-      const float tot = wave_tree_sum(s[u]);
-      const float b = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, tot)));
-      if (lane == (uint32_t)(j0 + u)) acc = b;
+    for (int j = 0; j < 4; j++) {
+      const bool odd = lane & 1;
+      const float keep = odd ? s[2 * j + 1] : s[2 * j];
+      const float send = odd ? s[2 * j] : s[2 * j + 1];
+      t4[j] = keep + __shfl_xor(send, 1);
     }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const bool odd = lane & 2;
+      const float keep = odd ? t4[2 * j + 1] : t4[2 * j];
+      const float send = odd ? t4[2 * j] : t4[2 * j + 1];
+      t2[j] = keep + __shfl_xor(send, 2);
+    }
+    float v;
+    {
+      const bool odd = lane & 4;
+      const float keep = odd ? t2[1] : t2[0];
+      const float send = odd ? t2[0] : t2[1];
+      v = keep + __shfl_xor(send, 4);
+    }
+    v = v + __shfl_xor(v, 8);
+    v = v + __shfl_xor(v, 16);
+    v = v + __shfl_xor(v, 32);
+    // every lane now holds the sum of block j0 + (lane & 7); park it in lane j0 + (lane & 7)
+    if ((lane >> 3) == (uint32_t)(j0 >> 3)) acc = v;
   }
   const float wsum = wave_tree_sum(acc);
   __syncthreads();

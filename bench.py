@@ -120,7 +120,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (RANK set) → join the RCCL process group even at world size 1, so the exact
+    # code path the 2/4/8-GPU runs take (init, barrier, all_reduce) is exercised on a single-GPU box too
+    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -169,7 +172,7 @@ def main():
             capi.call("agpu_event_record", eq_ev[i][1], h)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -181,7 +184,7 @@ def main():
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -244,7 +247,7 @@ def main():
     sharding.final_reduce(red, mn, mx)  # RCCL all_reduce of one element per statistic when world > 1
     extra["reduce_sum_min_max"] = {"rows_total": n * world, "sum": float(red.item()), "min": float(mn.item()),
                                    "max": float(mx.item()), "per_gpu_GBps": round(3 * 4.0 * n / ms.value / 1e6, 1),
-                                   "final_reduce": "RCCL all_reduce of 1 element per statistic" if world > 1 else "none (1 GPU)"}
+                                   "final_reduce": "RCCL all_reduce of 1 element per statistic" if distributed else "none (single process)"}
     extra["kernels"] = {"add_f32": {"ms": round(add_ms, 4), "GBps": round(add_gbps, 1), "frac_hbm_peak": round(add_gbps / HBM_PEAK_GBPS, 4)},
                         "eq_i32_validity": {"ms": round(eq_ms, 4), "GBps": round(eq_gbps, 1), "frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4)}}
     extra["parity"] = parity
@@ -279,7 +282,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 
