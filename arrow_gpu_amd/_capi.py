@@ -49,6 +49,11 @@ SIGNATURES = {
     "agpu_download": [_vp, _vp, _vp, _sz],
     "agpu_copy": [_vp, _vp, _vp, _sz],
     "agpu_memset": [_vp, _vp, _i32, _sz],
+    "agpu_host_alloc": [_vp, _sz, _pp],
+    "agpu_host_free": [_vp, _vp],
+    "agpu_upload_async": [_vp, _vp, _vp, _sz],
+    "agpu_download_async": [_vp, _vp, _vp, _sz],
+    "agpu_bitmap_copy_bits": [_vp, _vp, _u64, _vp, _u64],
     "agpu_pipeline_create": [_vp, _pp],
     "agpu_pipeline_wrap_stream": [_vp, _vp, _pp],
     "agpu_pipeline_finish": [_vp],

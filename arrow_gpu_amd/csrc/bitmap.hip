@@ -110,6 +110,22 @@ __global__ __launch_bounds__(AGPU_BLOCK) void popcount_kernel(const uint64_t* bi
   }
 }
 
+// out word w = src bits [off + 64w, off + 64w + 64): funnel shift of two source words; padding bits zeroed
+__global__ __launch_bounds__(AGPU_BLOCK) void bitmap_copy_bits_kernel(const uint64_t* src, uint64_t bit_off, uint64_t* out,
+                                                                     uint64_t n_bits) {
+  const uint64_t n_words = (n_bits + 63) / 64;
+  const uint64_t w0 = bit_off / 64;
+  const uint32_t sh = (uint32_t)(bit_off & 63);
+  const uint64_t last_src_word = (bit_off + n_bits - 1) / 64;  // never read past the word holding the last bit
+  for (uint64_t w = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * AGPU_BLOCK) {
+    uint64_t v = src[w0 + w] >> sh;
+    if (sh && w0 + w + 1 <= last_src_word) v |= src[w0 + w + 1] << (64 - sh);
+    const uint64_t remaining = n_bits - w * 64;
+    if (remaining < 64) v &= (1ull << remaining) - 1ull;
+    out[w] = v;
+  }
+}
+
 // merge_not_selected of routines/compute_shaders/u32/merge_null_buffer.wgsl (only reachable through by_name)
 agpu_status agpu_bitmap_andnot_internal(agpu_pipeline* p, const void* a, const void* b, void* out, uint64_t n_bits) {
   AGPU_REQUIRE(n_bits == 0 || (a && b), AGPU_ERR_ARG, "null input");
@@ -129,6 +145,19 @@ agpu_status agpu_bitmap_binary(agpu_pipeline* p, agpu_binary_op op, const void* 
   }
   agpu_set_error("bitmap op %d not supported (and/or/xor only)", (int)op);
   return AGPU_ERR_UNSUPPORTED;
+}
+
+agpu_status agpu_bitmap_copy_bits(agpu_pipeline* p, const void* src, uint64_t src_bit_offset, void* out, uint64_t n_bits) {
+  AGPU_BIND(p);
+  if (n_bits == 0) return AGPU_OK;
+  AGPU_REQUIRE(src && out, AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(aligned_to(src, 8) && aligned_to(out, 8), AGPU_ERR_SHAPE, "bitmaps must be 8-byte aligned");
+  const uint64_t n_words = (n_bits + 63) / 64;
+  const int grid = stream_grid_for(p, (n_words + AGPU_BLOCK - 1) / AGPU_BLOCK);
+  hipLaunchKernelGGL(bitmap_copy_bits_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint64_t*>(src),
+                     src_bit_offset, static_cast<uint64_t*>(out), n_bits);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
 }
 
 agpu_status agpu_bitmap_not(agpu_pipeline* p, const void* in, void* out, uint64_t n_bits) {

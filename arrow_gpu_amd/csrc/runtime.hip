@@ -117,7 +117,10 @@ agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void*
   void* p = nullptr;
   AGPU_HIP(hipMalloc(&p, padded));
   if (zero_fill) {
+    // hipMemset on device memory runs asynchronously on the NULL stream, and pipelines are non-blocking streams that
+    // do not order against it: wait, or a later upload could be overwritten by the zero fill
     hipError_t e = hipMemset(p, 0, padded);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
       (void)hipFree(p);
       agpu_set_error("hipMemset failed: %s", hipGetErrorString(e));
@@ -155,6 +158,39 @@ agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev,
   AGPU_REQUIRE(dst_host && src_dev, AGPU_ERR_ARG, "null pointer");
   AGPU_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));
   AGPU_HIP(hipStreamSynchronize(p->stream));
+  return AGPU_OK;
+}
+
+agpu_status agpu_host_alloc(agpu_device* dev, size_t bytes, void** out_host_ptr) {
+  AGPU_REQUIRE(dev && out_host_ptr, AGPU_ERR_ARG, "null argument");
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  void* h = nullptr;
+  AGPU_HIP(hipHostMalloc(&h, bytes ? bytes : 1, hipHostMallocDefault));
+  *out_host_ptr = h;
+  return AGPU_OK;
+}
+
+agpu_status agpu_host_free(agpu_device* dev, void* host_ptr) {
+  AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
+  if (!host_ptr) return AGPU_OK;
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  AGPU_HIP(hipHostFree(host_ptr));
+  return AGPU_OK;
+}
+
+agpu_status agpu_upload_async(agpu_pipeline* p, void* dst_dev, const void* src_pinned, size_t bytes) {
+  AGPU_BIND(p);
+  if (!bytes) return AGPU_OK;
+  AGPU_REQUIRE(dst_dev && src_pinned, AGPU_ERR_ARG, "null pointer");
+  AGPU_HIP(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, p->stream));
+  return AGPU_OK;
+}
+
+agpu_status agpu_download_async(agpu_pipeline* p, void* dst_pinned, const void* src_dev, size_t bytes) {
+  AGPU_BIND(p);
+  if (!bytes) return AGPU_OK;
+  AGPU_REQUIRE(dst_pinned && src_dev, AGPU_ERR_ARG, "null pointer");
+  AGPU_HIP(hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));
   return AGPU_OK;
 }
 

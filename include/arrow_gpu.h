@@ -145,6 +145,15 @@ agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev,
 agpu_status agpu_copy(agpu_pipeline* p, void* dst_dev, const void* src_dev, size_t bytes);
 agpu_status agpu_memset(agpu_pipeline* p, void* dst_dev, int32_t byte_value, size_t bytes);
 
+/* Pinned-host staging for ingest/egress (the reference moves every array through pageable host Vecs,
+ * [ref: PrimitiveArrayGpu::from_slice / raw_values, crates/array/src/array/primitive_array_gpu.rs:55-74]).
+ * agpu_host_alloc returns page-locked memory; the *_async copies only ENQUEUE on the pipeline's stream (the host
+ * buffer must stay untouched until agpu_pipeline_sync) so H2D, kernels and D2H of different pipelines overlap. */
+agpu_status agpu_host_alloc(agpu_device* dev, size_t bytes, void** out_host_ptr);
+agpu_status agpu_host_free(agpu_device* dev, void* host_ptr);
+agpu_status agpu_upload_async(agpu_pipeline* p, void* dst_dev, const void* src_pinned, size_t bytes);
+agpu_status agpu_download_async(agpu_pipeline* p, void* dst_pinned, const void* src_dev, size_t bytes);
+
 /* ---------------------------------------------------------------- pipeline = one HIP stream
  * [ref: ArrowComputePipeline::new compute_pipeline.rs:15-22; finish :259-273 (submit, no wait)].
  * One pipeline per host thread; many pipelines may share a device concurrently.
@@ -241,6 +250,10 @@ agpu_status agpu_bitmap_not(agpu_pipeline* p, const void* in, void* out, uint64_
 agpu_status agpu_bitmap_popcount(agpu_pipeline* p, const void* bits, uint64_t n_bits, uint64_t* out_count_dev);
 /* *out_any (device u32) = 1 if any of the first n_bits is set else 0 [ref: boolean.rs:106-118, u32/any.wgsl] */
 agpu_status agpu_bitmap_any(agpu_pipeline* p, const void* bits, uint64_t n_bits, uint32_t* out_any_dev);
+/* out bits [0, n_bits) = src bits [src_bit_offset, src_bit_offset + n_bits); padding bits of out are 0.  Re-aligns the
+ * validity / Boolean bitmap of a SLICED Arrow array (Arrow C Data Interface `offset` ≠ 0) to the word-aligned layout the
+ * kernels use.  `src` must be readable up to the 8-byte word holding the last addressed bit. */
+agpu_status agpu_bitmap_copy_bits(agpu_pipeline* p, const void* src, uint64_t src_bit_offset, void* out, uint64_t n_bits);
 /* merge validity: out = ((va & m) | (vb & ~m)) & vm; va/vb/vm may be NULL (= all ones); all three NULL → AGPU_ERR_ARG.
  * [ref: merge_null_buffers_op crates/routines/src/merge.rs:17-86, u32/merge_null_buffer.wgsl] */
 agpu_status agpu_bitmap_merge_validity(agpu_pipeline* p, const void* va, const void* vb, const void* mask,

@@ -174,6 +174,12 @@ def bitmap_binary(op, a, b, n_bits):
     return out
 
 
+def bitmap_copy_bits(src, bit_offset, n_bits):
+    out = np.empty(bitmap_bytes(n_bits), dtype=np.uint8)
+    _chk(lib().orc_bitmap_copy_bits(_p(src), C.c_uint64(bit_offset), _p(out), C.c_uint64(n_bits)), "bitmap_copy_bits")
+    return out
+
+
 def bitmap_not(a, n_bits):
     out = np.empty(bitmap_bytes(n_bits), dtype=np.uint8)
     _chk(lib().orc_bitmap_not(_p(a), _p(out), C.c_uint64(n_bits)), "bitmap_not")

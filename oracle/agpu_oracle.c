@@ -373,6 +373,14 @@ int orc_bitmap_binary(int op, const void* a, const void* b, void* out, uint64_t 
   }
   return ORC_OK;
 }
+/* out bits [0,n) = src bits [off, off+n), padding zero (re-aligning the bitmap of a sliced Arrow array; not in the
+ * reference, whose arrays always start at bit 0) */
+int orc_bitmap_copy_bits(const void* src, uint64_t off, void* out, uint64_t n_bits) {
+  memset(out, 0, orc_bitmap_bytes(n_bits));
+  for (uint64_t i = 0; i < n_bits; i++)
+    if (bit_get((const uint8_t*)src, off + i)) bit_put((uint8_t*)out, i, 1);
+  return ORC_OK;
+}
 int orc_bitmap_not(const void* in, void* out, uint64_t n_bits) { /* u32/not.wgsl:9-13 — flips padding too */
   size_t nb = orc_bitmap_bytes(n_bits);
   for (size_t i = 0; i < nb; i++) ((uint8_t*)out)[i] = (uint8_t)~((const uint8_t*)in)[i];

@@ -291,6 +291,15 @@ def test_bitmap_ops_popcount_any(D):
     assert D.status("agpu_bitmap_merge_validity", None, None, D.up(zero).vp, None, cnt.vp, 8) == capi.ERR_ARG
 
 
+def test_bitmap_copy_bits_realigns_sliced_bitmaps(D):
+    src = O.synth_bits(300_000, 17, 0, 0.5)
+    dsrc = D.up(src)
+    for off, n in ((0, 0), (0, 1), (1, 63), (7, 64), (13, 65), (63, 1000), (64, 4096), (100_001, 199_999), (5, 299_995)):
+        out = D.empty(O.bitmap_bytes(n) + 8)
+        D.call("agpu_bitmap_copy_bits", dsrc.vp, off, out.vp, n)
+        assert bits_equal(D.down(out, np.uint8, O.bitmap_bytes(n)), O.bitmap_copy_bits(src, off, n)), (off, n)
+
+
 # ------------------------------------------------------------------ reductions
 @pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 511, 65535, 65536, 65537, 131072, 200001, 16777216 + 7])
 def test_f32_sum_is_bit_identical_to_the_reference_tree(D, n):

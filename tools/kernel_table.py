@@ -110,9 +110,29 @@ def main():
     rows[-1]["frac_8TBs"] = round(rows[-1]["GBps"] / 8000, 4)
     t("hipMemcpy D2D 4 GB (context)", 8, lambda: capi.call("agpu_copy", h, vp(O), vp(A), 4 * n))
 
+    # host link (what the boundary costs when it is handed HOST buffers): pinned staging, 1 GiB each way
+    from arrow_gpu_amd.interop import PinnedStaging
+
+    gib = 1 << 30
+    st = PinnedStaging(dev, gib)
+    st.view[:] = 1
+    pcie = {}
+    for label, f in (("H2D pinned 1 GiB", lambda: st.upload(p, O, gib)), ("D2H pinned 1 GiB", lambda: st.download(p, O, gib))):
+        f()
+        p.sync()
+        ts = []
+        for _ in range(5):
+            q.begin(p)
+            f()
+            q.end(p)
+            ts.append(q.wait_for_results())
+        ms = float(np.median(ts))
+        pcie[label] = {"ms": round(ms, 3), "GBps": round(gib / ms / 1e6, 1)}
+        print(label, pcie[label], flush=True)
+
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/kernel_table_{args.tag}.json", "w") as f:
-        json.dump({"rows": n, "device": dev.name, "kernels": rows}, f, indent=1)
+        json.dump({"rows": n, "device": dev.name, "kernels": rows, "host_link": pcie}, f, indent=1)
     print("\n| kernel | alg. B/row | ms @1e9 | GB/s | frac of 8 TB/s |\n|---|---|---|---|---|")
     for r in rows:
         print(f"| {r['kernel']} | {r['alg_B_per_row']:.4g} | {r['ms']} | {r['GBps']} | {r['frac_8TBs']} |")
