@@ -1,0 +1,73 @@
+// DEV TOOL: shapes for the 1-byte → 4-byte widening stream (cast u8→f32: 1 B read + 4 B written per row).
+//   variant 0: lane loads 4 B (4 rows), stores one 16-byte vector            (what cvt_kernel does)
+//   variant 1: lane loads 16 B (16 rows); 4 ds_bpermute redistribute the words so that each of the 4 stores of the
+//              wave is a fully coalesced 1 KiB row (lane l of store j writes rows 256j + 4l .. +3)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 cvt4(uint32_t w) {
+  f32x4 r = {(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24)};
+  return r;
+}
+
+template <int BLOCK, int U>
+__global__ __launch_bounds__(BLOCK) void cast_v0(const uint32_t* in, f32x4* out, uint64_t ntiles) {
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t p0 = t * (uint64_t)(BLOCK * U) + threadIdx.x;
+    uint32_t w[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) w[u] = __builtin_nontemporal_load(in + p0 + (uint64_t)u * BLOCK);
+#pragma unroll
+    for (int u = 0; u < U; u++) __builtin_nontemporal_store(cvt4(w[u]), out + p0 + (uint64_t)u * BLOCK);
+  }
+}
+
+// one wave handles 1024 rows per step: 1 KiB in, 4 KiB out
+template <int BLOCK, int U>
+__global__ __launch_bounds__(BLOCK) void cast_v1(const u32x4* in, f32x4* out, uint64_t ntiles) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int WAVES = BLOCK / 64;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint64_t chunk = (t * U + u) * WAVES + wave;  // 1024-row chunk index
+      const u32x4 v = __builtin_nontemporal_load(in + chunk * 64 + lane);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        // store j, lane l needs word (l & 3) of source lane 16 j + (l >> 2)
+        const int src = (16 * j + (int)(lane >> 2)) * 4;
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.x);
+        const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.y);
+        const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.z);
+        const uint32_t w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.w);
+        const uint32_t sel = lane & 3;
+        const uint32_t w = sel == 0 ? w0 : sel == 1 ? w1 : sel == 2 ? w2 : w3;
+        __builtin_nontemporal_store(cvt4(w), out + chunk * 256 + j * 64 + lane);
+      }
+    }
+  }
+}
+
+extern "C" int probe_cast(const void* in, void* out, uint64_t n, int variant, int block, int u, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+#define GO0(B, U_)                                                                                         \
+  {                                                                                                        \
+    uint64_t nt = n / 4 / ((uint64_t)B * U_);                                                              \
+    hipLaunchKernelGGL((cast_v0<B, U_>), dim3((unsigned)nt), dim3(B), 0, s, (const uint32_t*)in, (f32x4*)out, nt); \
+  }
+#define GO1(B, U_)                                                                                         \
+  {                                                                                                        \
+    uint64_t nt = n / 1024 / ((uint64_t)(B / 64) * U_);                                                    \
+    hipLaunchKernelGGL((cast_v1<B, U_>), dim3((unsigned)nt), dim3(B), 0, s, (const u32x4*)in, (f32x4*)out, nt); \
+  }
+  if (variant == 0) {
+    if (block == 64 && u == 1) GO0(64, 1) else if (block == 64 && u == 4) GO0(64, 4) else if (block == 256 && u == 1) GO0(256, 1)
+    else if (block == 256 && u == 4) GO0(256, 4) else if (block == 256 && u == 2) GO0(256, 2) else return 1;
+  } else {
+    if (block == 64 && u == 1) GO1(64, 1) else if (block == 64 && u == 2) GO1(64, 2) else if (block == 256 && u == 1) GO1(256, 1)
+    else if (block == 256 && u == 2) GO1(256, 2) else if (block == 128 && u == 1) GO1(128, 1) else return 1;
+  }
+  return (int)hipGetLastError();
+}
