@@ -77,6 +77,7 @@ SIGNATURES = {
     "agpu_cast": [_vp, _i32, _i32, _vp, _vp, _u64],
     "agpu_broadcast": [_vp, _i32, _u32, _vp, _u64],
     "agpu_broadcast_from_device": [_vp, _i32, _vp, _vp, _u64],
+    "agpu_fused_chain": [_vp, _i32, _vp, _vp, _i32, _vp, _u64],
     "agpu_compare": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
     "agpu_compare_validity": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u64],
     "agpu_bitmap_binary": [_vp, _i32, _vp, _vp, _vp, _u64],

@@ -686,7 +686,236 @@ __global__ __launch_bounds__(AGPU_BLOCK) void fill_bits_kernel(uint32_t* out, ui
   }
 }
 
+// ---------------------------------------------------------------- fused linear chains (agpu_fused_chain)
+// acc = in[i]; acc = op_s(acc, operand_s) for s = 0..n-1 — one pass over HBM for the whole chain.  The step list is
+// wave-uniform (kernel argument), so op/kind selection is scalar branching; operands of ARRAY steps are all loaded up
+// front (static_for over the 8 slots: registers are addressed at compile time, no dynamic VGPR indexing) before the
+// first use, so the chain keeps as many loads in flight as a stand-alone binary kernel.  Each step calls the SAME
+// functor as the stand-alone kernel ⇒ bit-identical results.
+template <typename T>
+__device__ __forceinline__ T chain_apply_binary(int op, T x, T y) {
+  switch (op) {
+    case AGPU_OP_ADD: return OpAdd::ap(x, y);
+    case AGPU_OP_SUB: return OpSub::ap(x, y);
+    case AGPU_OP_MUL: return OpMul::ap(x, y);
+    case AGPU_OP_DIV: return OpDiv::ap(x, y);
+    case AGPU_OP_REM: return OpRem::ap(x, y);
+    case AGPU_OP_MIN: return OpMin::ap(x, y);
+    case AGPU_OP_MAX: return OpMax::ap(x, y);
+    default: break;
+  }
+  if constexpr (!std::is_floating_point<T>::value) {
+    switch (op) {
+      case AGPU_OP_AND: return OpAnd::ap(x, y);
+      case AGPU_OP_OR: return OpOr::ap(x, y);
+      case AGPU_OP_XOR: return OpXor::ap(x, y);
+      default: break;
+    }
+  }
+  return x;
+}
+template <typename T, bool HEAVY>
+__device__ __forceinline__ T chain_apply_unary(int op, T x) {
+  if constexpr (std::is_floating_point<T>::value && !HEAVY) {
+    switch (op) {
+      case AGPU_UN_NEG: return UnNeg::ap(x, x);
+      case AGPU_UN_ABS: return UnAbs::ap(x, x);
+      case AGPU_UN_SQRT: return UnSqrt::ap(x, x);
+      default: return x;
+    }
+  } else if constexpr (std::is_floating_point<T>::value) {
+    switch (op) {
+      case AGPU_UN_NEG: return UnNeg::ap(x, x);
+      case AGPU_UN_ABS: return UnAbs::ap(x, x);
+      case AGPU_UN_SQRT: return UnSqrt::ap(x, x);
+      case AGPU_UN_CBRT: return UnCbrt::ap(x, x);
+      case AGPU_UN_EXP: return UnExp::ap(x, x);
+      case AGPU_UN_EXP2: return UnExp2::ap(x, x);
+      case AGPU_UN_LOG: return UnLog::ap(x, x);
+      case AGPU_UN_LOG2: return UnLog2::ap(x, x);
+      case AGPU_UN_SIN: return UnSin::ap(x, x);
+      case AGPU_UN_COS: return UnCos::ap(x, x);
+      default: return x;
+    }
+  } else {
+    switch (op) {
+      case AGPU_UN_NEG: return UnNeg::ap(x, x);
+      case AGPU_UN_ABS: return UnAbs::ap(x, x);
+      case AGPU_UN_NOT: return UnNot::ap(x, x);
+      default: return x;
+    }
+  }
+}
+
+// Step codes travel as ONE 64-bit scalar (8 × {4-bit op, 2-bit kind}); operand pointers as kernel arguments, twice: by
+// step (scalars, tail kernel) and compacted to the ARRAY steps only (`arrs`).  Nothing is indexed at run time except by
+// wave-uniform scalar shifts / selects.
+//
+// What bounds this kernel is bytes in flight: one-wave blocks with ONE 16-B load per lane and stream need every wave
+// slot of the CU (8 per SIMD ⇒ ≤ 64 VGPRs) to cover HBM latency.  The first version (one kernel for everything: 8 operand
+// packs + inlined sin/log/exp) needed 86 VGPRs ⇒ 5 waves/SIMD ⇒ 3.7 TB/s on an 8 B/row chain.  So the kernel is
+// specialised on what costs registers: NARR = operand-pack slots (0/2/4/8, smallest that fits the chain's ARRAY steps)
+// and HEAVY = the chain contains a transcendental step (cbrt/exp/exp2/log/log2/sin/cos).  Scalar operands live in SGPRs
+// (readfirstlane).  The APPLY loop is a real (uniform) loop over the steps with a single copy of the op switch —
+// unrolling it 8× inlined 32 copies of sin/log/exp and ran out of the instruction cache.
+struct ChainPtrs {
+  const void* p[AGPU_CHAIN_MAX_STEPS];
+};
+__host__ __device__ __forceinline__ int chain_op(uint64_t code, int s) { return (int)((code >> (6 * s)) & 15u); }
+__host__ __device__ __forceinline__ int chain_kind(uint64_t code, int s) { return (int)((code >> (6 * s + 4)) & 3u); }
+
+template <typename T, bool HEAVY, int NARR>
+__global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_kernel(const T* in, T* out, uint64_t ntiles, int n_steps,
+                                                             int n_arrs, uint64_t code, ChainPtrs ptrs, ChainPtrs arrs) {
+  constexpr int N = 4;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const uint64_t pk = t * AGPU_EW_BLOCK + threadIdx.x;
+    PackN<T, N> acc = load_pack<true, T, N>(in + pk * N);
+    PackN<T, N> ya[NARR > 0 ? NARR : 1];
+    static_for<NARR>([&](auto a) {
+      if (a < n_arrs) ya[a] = load_pack<true, T, N>(static_cast<const T*>(arrs.p[a]) + pk * N);
+    });
+    // Scalar operands: eight unconditional s_load_dword through the constant address space (the host points unused
+    // slots at `in`), one lgkmcnt wait for all of them.  A per-lane global load + readfirstlane here serialised one
+    // full HBM latency per scalar step (4.4 TB/s).
+    uint32_t sc[AGPU_CHAIN_MAX_STEPS];
+    static_for<AGPU_CHAIN_MAX_STEPS>([&](auto s) {
+      sc[s] = *(const __attribute__((address_space(4))) uint32_t*)(ptrs.p[s]);
+    });
+    int ai = 0;
+    for (int s = 0; s < n_steps; s++) {
+      const int op = chain_op(code, s), kind = chain_kind(code, s);
+      if (kind == AGPU_CHAIN_UNARY) {
+#pragma unroll
+        for (int k = 0; k < N; k++) acc.v[k] = chain_apply_unary<T, HEAVY>(op, acc.v[k]);
+      } else {
+        PackN<T, N> y;
+        if (kind == AGPU_CHAIN_ARRAY) {
+          y = ya[0];
+          static_for<NARR>([&](auto j) {
+            if (j == ai) y = ya[j];  // wave-uniform select
+          });
+          ai++;
+        } else {
+          uint32_t w = 0;
+          static_for<AGPU_CHAIN_MAX_STEPS>([&](auto j) {
+            if (j == s) w = sc[j];
+          });
+          const T v = __builtin_bit_cast(T, w);
+#pragma unroll
+          for (int k = 0; k < N; k++) y.v[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) acc.v[k] = chain_apply_binary<T>(op, acc.v[k], y.v[k]);
+      }
+    }
+    store_pack<true, T, N>(out + pk * N, acc);
+  }
+}
+
+// rows [first, n): one element per lane, same arithmetic (also the whole column when a pointer is not 16-B aligned)
+template <typename T>
+__global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_tail_kernel(const T* in, T* out, uint64_t first, uint64_t n,
+                                                                  int n_steps, uint64_t code, ChainPtrs ptrs) {
+  for (uint64_t i = first + (uint64_t)blockIdx.x * AGPU_EW_BLOCK + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * AGPU_EW_BLOCK) {
+    T acc = in[i];
+    for (int s = 0; s < n_steps; s++) {
+      const int op = chain_op(code, s), kind = chain_kind(code, s);
+      if (kind == AGPU_CHAIN_UNARY) {
+        acc = chain_apply_unary<T, true>(op, acc);
+      } else {
+        const T* q = nullptr;
+        static_for<AGPU_CHAIN_MAX_STEPS>([&](auto j) {
+          if (j == s) q = static_cast<const T*>(ptrs.p[j]);
+        });
+        acc = chain_apply_binary<T>(op, acc, kind == AGPU_CHAIN_ARRAY ? q[i] : q[0]);
+      }
+    }
+    out[i] = acc;
+  }
+}
+
+template <typename T, bool HEAVY, int NARR>
+static void launch_chain_full(agpu_pipeline* p, const T* pi, T* po, uint64_t ntiles, int n_steps, int n_arrs, uint64_t code,
+                              const ChainPtrs& ptrs, const ChainPtrs& arrs) {
+  const int grid = stream_grid_for(p, ntiles);
+  hipLaunchKernelGGL((chain_kernel<T, HEAVY, NARR>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, po, ntiles, n_steps,
+                     n_arrs, code, ptrs, arrs);
+}
+
+template <typename T>
+static agpu_status launch_chain(agpu_pipeline* p, const void* in, void* out, uint64_t n, int n_steps, uint64_t code,
+                                const ChainPtrs& ptrs, bool vec_ok, bool heavy) {
+  const T* pi = static_cast<const T*>(in);
+  T* po = static_cast<T*>(out);
+  constexpr uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * 4;
+  const uint64_t ntiles = vec_ok ? n / tile_rows : 0;
+  if (ntiles) {
+    ChainPtrs arrs{}, scal;
+    int n_arrs = 0;
+    for (int s = 0; s < AGPU_CHAIN_MAX_STEPS; s++) {
+      scal.p[s] = (s < n_steps && ptrs.p[s]) ? ptrs.p[s] : in;  // every slot readable: the kernel loads all eight
+      if (s < n_steps && chain_kind(code, s) == AGPU_CHAIN_ARRAY) arrs.p[n_arrs++] = ptrs.p[s];
+    }
+    const int slots = n_arrs == 0 ? 0 : n_arrs <= 2 ? 2 : n_arrs <= 4 ? 4 : 8;
+#define AGPU_CHAIN_CASE(H, A)                                                                   \
+  if (heavy == H && slots == A) launch_chain_full<T, H, A>(p, pi, po, ntiles, n_steps, n_arrs, code, scal, arrs);
+    if constexpr (std::is_floating_point<T>::value) {
+      AGPU_CHAIN_CASE(true, 0) AGPU_CHAIN_CASE(true, 2) AGPU_CHAIN_CASE(true, 4) AGPU_CHAIN_CASE(true, 8)
+    }
+    AGPU_CHAIN_CASE(false, 0) AGPU_CHAIN_CASE(false, 2) AGPU_CHAIN_CASE(false, 4) AGPU_CHAIN_CASE(false, 8)
+#undef AGPU_CHAIN_CASE
+  }
+  if (ntiles * tile_rows < n) {
+    const uint64_t rest = n - ntiles * tile_rows;
+    const int grid = stream_grid_for(p, (rest + AGPU_EW_BLOCK - 1) / AGPU_EW_BLOCK);
+    hipLaunchKernelGGL((chain_tail_kernel<T>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, po, ntiles * tile_rows, n,
+                       n_steps, code, ptrs);
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
 extern "C" {
+
+agpu_status agpu_fused_chain(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
+                             int32_t n_steps, void* out, uint64_t n) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(n_steps >= 0 && n_steps <= AGPU_CHAIN_MAX_STEPS, AGPU_ERR_ARG, "0..8 steps per chain");
+  AGPU_REQUIRE(n == 0 || (in && out && (n_steps == 0 || steps)), AGPU_ERR_ARG, "null pointer");
+  if (n == 0) return AGPU_OK;
+  if (dtype == AGPU_DATE32) dtype = AGPU_I32;
+  AGPU_REQUIRE(dtype == AGPU_F32 || dtype == AGPU_I32 || dtype == AGPU_U32, AGPU_ERR_UNSUPPORTED,
+               "fused chains: f32, i32, u32 columns");
+  ChainPtrs ptrs{};
+  uint64_t code = 0;
+  bool vec_ok = aligned16(in) && aligned16(out), heavy = false;
+  for (int s = 0; s < n_steps; s++) {
+    code |= ((uint64_t)(steps[s].op & 15) | ((uint64_t)(steps[s].kind & 3) << 4)) << (6 * s);
+    ptrs.p[s] = steps[s].operand;
+    const bool is_f = dtype == AGPU_F32;
+    if (steps[s].kind == AGPU_CHAIN_UNARY) {
+      const int o = steps[s].op;
+      const bool ok = is_f ? (o == AGPU_UN_NEG || o == AGPU_UN_ABS || (o >= AGPU_UN_SQRT && o <= AGPU_UN_COS))
+                           : (o == AGPU_UN_NEG || o == AGPU_UN_ABS || o == AGPU_UN_NOT);
+      AGPU_REQUIRE(ok, AGPU_ERR_UNSUPPORTED, "unary op not available in fused chains for this dtype");
+      if (is_f && o >= AGPU_UN_CBRT) heavy = true;
+    } else {
+      AGPU_REQUIRE(steps[s].kind == AGPU_CHAIN_SCALAR || steps[s].kind == AGPU_CHAIN_ARRAY, AGPU_ERR_ARG, "bad step kind");
+      AGPU_REQUIRE(steps[s].operand, AGPU_ERR_ARG, "null operand");
+      const int o = steps[s].op;
+      const bool ok = (o >= AGPU_OP_ADD && o <= AGPU_OP_MAX) || (!is_f && o >= AGPU_OP_AND && o <= AGPU_OP_XOR);
+      AGPU_REQUIRE(ok, AGPU_ERR_UNSUPPORTED, "binary op not available in fused chains for this dtype");
+      if (steps[s].kind == AGPU_CHAIN_ARRAY && !aligned16(steps[s].operand)) vec_ok = false;
+    }
+  }
+  switch (dtype) {
+    case AGPU_F32: return launch_chain<float>(p, in, out, n, n_steps, code, ptrs, vec_ok, heavy);
+    case AGPU_I32: return launch_chain<int32_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, false);
+    default: return launch_chain<uint32_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, false);
+  }
+}
 
 agpu_status agpu_binary(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, const void* a, const void* b, void* out,
                         uint64_t n) {

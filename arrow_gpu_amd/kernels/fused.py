@@ -1,0 +1,125 @@
+"""Fused element-wise chains — one kernel, one pass over HBM for a whole `*_op` chain.
+
+The reference batches the dispatches of a chain into one command buffer (`examples/simple.rs:45-72`:
+`add_scalar_op_dyn` → `mul_scalar_op_dyn` → one `finish()`), but each op still reads and writes the full column.
+`FusedChain` records the same chain explicitly and runs it through `agpu_fused_chain`:
+
+    out = ag.FusedChain(a).add_scalar(s).mul_scalar(s).finish()          # (a + s) * s, 8 B/row instead of 16
+    out = ag.FusedChain(a).mul(b).add(c).abs().sqrt().finish_op(pipeline)
+
+Each step applies the same scalar operation with the same rounding as the stand-alone kernel, so the result is
+bit-identical to `a.add_scalar(s).mul_scalar(s)`; validity follows the reference's rules step by step (clone for
+unary/scalar steps, AND with every array operand's validity).  f32 / i32 / u32 / Date32 columns, ≤ 8 steps.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+from .. import _capi as capi
+from .._capi import ArrowErrorGPU, OperationNotSupported
+from ..array import Date32ArrayGPU, Float32ArrayGPU, Int32ArrayGPU, NullBitBufferGpu, UInt32ArrayGPU
+from ..gpu_utils import ArrowComputePipeline
+from ._ops import vp
+
+MAX_STEPS = 8
+UNARY, SCALAR, ARRAY = 0, 1, 2
+
+
+class _Step(C.Structure):
+    _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+
+_BINARY = {"add": capi.OP_ADD, "sub": capi.OP_SUB, "mul": capi.OP_MUL, "div": capi.OP_DIV, "rem": capi.OP_REM,
+           "min": capi.OP_MIN, "max": capi.OP_MAX, "bitwise_and": capi.OP_AND, "bitwise_or": capi.OP_OR,
+           "bitwise_xor": capi.OP_XOR}
+_UNARY = {"neg": capi.UN_NEG, "abs": capi.UN_ABS, "bitwise_not": capi.UN_NOT, "sqrt": capi.UN_SQRT, "cbrt": capi.UN_CBRT,
+          "exp": capi.UN_EXP, "exp2": capi.UN_EXP2, "log": capi.UN_LOG, "log2": capi.UN_LOG2, "sin": capi.UN_SIN,
+          "cos": capi.UN_COS}
+_TYPES = (Float32ArrayGPU, Int32ArrayGPU, UInt32ArrayGPU, Date32ArrayGPU)
+
+
+class FusedChain:
+    def __init__(self, array):
+        if type(array) not in _TYPES:
+            raise OperationNotSupported(f"FusedChain not supported for type {array.get_dtype().name}")
+        self.src = array
+        self.steps = []  # (op, kind, operand array or None)
+
+    def _push(self, op, kind, operand):
+        if len(self.steps) >= MAX_STEPS:
+            raise ArrowErrorGPU("ShapeError", f"a fused chain holds at most {MAX_STEPS} steps", capi.ERR_SHAPE)
+        self.steps.append((op, kind, operand))
+        return self
+
+    def _binary(self, name, other, force_scalar=False):
+        if type(other).NP_DTYPE != type(self.src).NP_DTYPE:
+            raise OperationNotSupported(
+                f"Operation {name} not supported for type {self.src.get_dtype().name} {other.get_dtype().name}")
+        scalar = force_scalar or (other.len == 1 and self.src.len != 1)
+        if not scalar and other.len != self.src.len:
+            raise ArrowErrorGPU("ShapeError", f"{name}: arrays of different length", capi.ERR_SHAPE)
+        return self._push(_BINARY[name], SCALAR if scalar else ARRAY, other)
+
+    def finish_op(self, pipeline: ArrowComputePipeline):
+        a = self.src
+        dev = a.gpu_device
+        out = dev.create_empty_buffer(max(a.len * a.ITEM_SIZE, 1))
+        steps = (_Step * max(len(self.steps), 1))()
+        nulls = a.null_buffer  # validity: AND with every ARRAY operand's bitmap; unary / scalar steps clone
+        for i, (op, kind, operand) in enumerate(self.steps):
+            steps[i].op, steps[i].kind = op, kind
+            steps[i].operand = operand.data.ptr if operand is not None else None
+            if kind == ARRAY and operand.null_buffer is not None:
+                nulls = NullBitBufferGpu.merge_null_bit_buffer_op(nulls, operand.null_buffer, pipeline)
+            if operand is not None:
+                pipeline.keep(operand.data)
+        if nulls is a.null_buffer:  # never merged: the output owns a copy, like every unary/scalar op
+            nulls = NullBitBufferGpu.clone_null_bit_buffer_op(nulls, pipeline)
+        capi.call("agpu_fused_chain", pipeline._handle, a.DTYPE, vp(a.data), C.cast(steps, C.c_void_p), len(self.steps),
+                  vp(out), a.len)
+        pipeline.keep(a.data, out)
+        return type(a)(out, dev, a.len, nulls)
+
+    def finish(self):
+        p = ArrowComputePipeline(self.src.get_gpu_device(), "fused_chain")
+        out = self.finish_op(p)
+        p.finish()
+        return out
+
+
+def _make_binary(name):
+    def method(self, other):
+        return self._binary(name, other)
+
+    method.__name__ = name
+    return method
+
+
+def _make_scalar(name):
+    def method(self, other):
+        return self._binary(name, other, force_scalar=True)
+
+    method.__name__ = name + "_scalar"
+    return method
+
+
+def _make_unary(name):
+    def method(self):
+        if name == "bitwise_not" and type(self.src) is Float32ArrayGPU:
+            raise OperationNotSupported("Operation bitwise_not not supported for type Float32Type")
+        if name not in ("neg", "abs", "bitwise_not") and type(self.src) is not Float32ArrayGPU:
+            raise OperationNotSupported(f"Operation {name} not supported for type {self.src.get_dtype().name}")
+        return self._push(_UNARY[name], UNARY, None)
+
+    method.__name__ = name
+    return method
+
+
+for _n in _BINARY:
+    setattr(FusedChain, _n, _make_binary(_n))
+for _n in ("add", "sub", "mul", "div", "rem"):
+    setattr(FusedChain, _n + "_scalar", _make_scalar(_n))
+for _n in _UNARY:
+    setattr(FusedChain, _n, _make_unary(_n))
+
+__all__ = ["FusedChain"]

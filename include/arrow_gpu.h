@@ -224,6 +224,24 @@ agpu_status agpu_broadcast(agpu_pipeline* p, agpu_dtype dtype, uint32_t value_bi
  * apply_broadcast_function(&scalar_buffer, ...) [ref: crates/array/src/array/f32_gpu.rs:14-37]; not for AGPU_BOOL. */
 agpu_status agpu_broadcast_from_device(agpu_pipeline* p, agpu_dtype dtype, const void* scalar_dev, void* out, uint64_t n);
 
+/* ---------------------------------------------------------------- fused element-wise chains
+ * The reference's `*_op(&mut pipeline)` API lets callers record op chains ((a + s) * s in examples/simple.rs:45-72)
+ * but still runs one dispatch — one full pass over HBM — per op.  agpu_fused_chain evaluates a LINEAR chain
+ *     acc = in[i];  for each step: acc = op(acc, operand_i)   (operand = none | 1-element scalar buffer | array[n])
+ * in ONE kernel: the column is read once and written once however long the chain is.  Every step applies exactly the
+ * same scalar operation, in the same order and with the same rounding, as the stand-alone kernel, so the result is
+ * bit-identical to running the ops one by one.  dtype ∈ {F32, I32, U32, DATE32}; all arrays have n rows.
+ * kind == AGPU_CHAIN_UNARY: `op` is an agpu_unary_op and `operand` is ignored; otherwise `op` is an agpu_binary_op. */
+typedef enum { AGPU_CHAIN_UNARY = 0, AGPU_CHAIN_SCALAR = 1, AGPU_CHAIN_ARRAY = 2 } agpu_chain_kind;
+typedef struct {
+  int32_t op;          /* agpu_unary_op or agpu_binary_op, see kind */
+  int32_t kind;        /* agpu_chain_kind */
+  const void* operand; /* device pointer: 1 element (SCALAR) or n elements (ARRAY); NULL for UNARY */
+} agpu_chain_step;
+#define AGPU_CHAIN_MAX_STEPS 8
+agpu_status agpu_fused_chain(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
+                             int32_t n_steps, void* out, uint64_t n);
+
 /* ---------------------------------------------------------------- compare → bitmap
  * out_bits bit i = a[i] cmp b[i], LSB-first, agpu_bitmap_bytes(n) bytes written, padding bits 0.
  * [ref: apply_function! crates/compare/src/lib.rs:85-111; crates/compare/compute_shaders/ * /cmp.wgsl
