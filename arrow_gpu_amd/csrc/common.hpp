@@ -19,7 +19,11 @@ struct agpu_device {
   int ordinal;
   hipDeviceProp_t props;
   int num_cus;
+  // 8 KiB of f64 {sin, cos} pairs for the 16-bit fused trig kernels (elementwise.hip: trig16_kernel), built once at
+  // device creation: [l] = sincos(l), [256 + h] = sincos(256·h), l, h ∈ 0..255
+  void* trig16_table;
 };
+agpu_status agpu_internal_build_trig16(void* table);  // elementwise.hip; synchronous
 
 struct agpu_pipeline {
   agpu_device* dev;

@@ -242,8 +242,38 @@ __device__ __forceinline__ float log_f32_dev(float x) {
   return (float)fma((double)e, 0x1.62e42fefa39efp-1, t);
 }
 
+// sinh: a = |x| = k·ln2 + r (|r| ≤ ln2/2); cosh r = C and sinh r = S from the even / odd Taylor halves (inner terms in
+// f32, they weigh < 6 % of C and < 2 % of S; outer step in f64), then sinh a = 2^(k−1)(C+S) − 2^(−k−1)(C−S) in f64 and
+// ONE rounding to f32.  k = 0 returns S itself (no cancellation for tiny |x|, keeps ±0 and denormals).  |x| is clamped
+// to 128 (sinh overflows f32 from 89.42 on; the f64 result converts to ±inf); NaN is passed through at the end.
+// The f32 library sinhf is ≤ 1 ULP too but VALU-bound at 2.8 TB/s (profiles/r01_kernel_table.json).
+__device__ __forceinline__ float sinh_f32_dev(float x) {
+  float a = fabsf(x);
+  a = (a < 128.0f) ? a : 128.0f;
+  const double ad = (double)a;
+  const double kd = rint(ad * 0x1.71547652b82fep+0);  // a · log2 e
+  const int k = (int)kd;
+  const double r = fma(kd, -0x1.62e42fefa39efp-1, ad);
+  const float rf = (float)r, zf = rf * rf;
+  float qs = __builtin_fmaf(zf, 0x1.71de3a556c734p-19f, 0x1.a01a01a01a01ap-13f);  // 1/9!, 1/7!
+  qs = __builtin_fmaf(zf, qs, 0x1.1111111111111p-7f);                             // 1/5!
+  qs = __builtin_fmaf(zf, qs, 0x1.5555555555555p-3f);                             // 1/3!
+  float qc = __builtin_fmaf(zf, 0x1.a01a01a01a01ap-16f, 0x1.6c16c16c16c17p-10f);  // 1/8!, 1/6!
+  qc = __builtin_fmaf(zf, qc, 0x1.5555555555555p-5f);                             // 1/4!
+  qc = __builtin_fmaf(zf, qc, 0.5f);
+  const double z = r * r;
+  const double S = fma(r * z, (double)qs, r);
+  const double C = fma(z, (double)qc, 1.0);
+  const double up = __builtin_bit_cast(double, (uint64_t)(uint32_t)(1022 + k) << 52);  // 2^(k−1)
+  const double dn = __builtin_bit_cast(double, (uint64_t)(uint32_t)(1022 - k) << 52);  // 2^(−k−1)
+  double v = fma(up, C + S, -(dn * (C - S)));
+  v = (k == 0) ? S : v;
+  const float f = __builtin_copysignf((float)v, x);
+  return (x != x) ? x : f;
+}
+
 // The remaining functions use the f32 device library where it measures ≤ 1 ULP on gfx950 over 4 M log-uniform samples
-// (tools/probe/math_ulp.py: sinhf, acosf, cbrtf, exp2f, log2f, expf, powf = 1 ULP).
+// (tools/probe/math_ulp.py: acosf, cbrtf, exp2f, log2f, expf, powf = 1 ULP).
 struct UnSqrt { __device__ static __forceinline__ float ap(float x, float) { return sqrtf(x); } };  // correctly rounded
 struct UnCbrt { __device__ static __forceinline__ float ap(float x, float) { return cbrtf(x); } };
 struct UnExp { __device__ static __forceinline__ float ap(float x, float) { return expf(x); } };
@@ -253,7 +283,7 @@ struct UnLog2 { __device__ static __forceinline__ float ap(float x, float) { ret
 struct UnSin { __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 0); } };
 struct UnCos { __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 1); } };
 struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { return acosf(x); } };
-struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return sinhf(x); } };
+struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return sinh_f32_dev(x); } };
 
 // ---------------------------------------------------------------- same-width streaming kernel
 // out[i] = Op(a[i], b[i] | *b | -).  The hot kernel covers FULL tiles only and carries no tail code (the tail costs
@@ -630,6 +660,109 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
   return AGPU_OK;
 }
 
+// 16-bit sources (sin_u16 / cos_i16 …): 65 536 distinct inputs — too many for an LDS result table, and evaluating sin
+// per row is VALU-bound (4.6 TB/s of a 6 B/row stream).  The inputs are INTEGERS, so |x| = 256·h + l and
+//   sin x = sin(256h)·cos l + cos(256h)·sin l,   cos x = cos(256h)·cos l − sin(256h)·sin l
+// need two 16-byte LDS reads ({sin, cos} pairs in f64 — 8 KiB, copied per block from the table built once at device
+// creation) and three f64 operations, then ONE rounding to f32: |error| ≲ 2⁻⁵² absolute, and |sin n|, |cos n| ≥ 1e-6
+// for integer |n| ≤ 65 535, so the result is correctly rounded except in 1-in-10⁷-style ties (≤ 1 ULP always).
+struct alignas(16) SinCos64 {
+  double s, c;
+};
+__global__ void trig16_build_kernel(SinCos64* tab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 512) return;
+  const double a = i < 256 ? (double)i : (double)((i - 256) * 256);
+  tab[i].s = sin(a);
+  tab[i].c = cos(a);
+}
+agpu_status agpu_internal_build_trig16(void* table) {
+  hipLaunchKernelGGL(trig16_build_kernel, dim3(2), dim3(256), 0, nullptr, static_cast<SinCos64*>(table));
+  AGPU_HIP(hipGetLastError());
+  AGPU_HIP(hipStreamSynchronize(nullptr));
+  return AGPU_OK;
+}
+
+template <typename TI, int WANT_COS, typename TabPtr>
+__device__ __forceinline__ float trig16_eval(TabPtr tab, uint32_t raw16) {
+  const int v = (int)(TI)(uint16_t)raw16;  // sign- or zero-extends by the source type
+  const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+  const SinCos64 L = tab[a & 255u], H = tab[256u + (a >> 8)];
+  double r;
+  if constexpr (WANT_COS) {
+    r = fma(H.c, L.c, -(H.s * L.s));
+  } else {
+    r = fma(H.s, L.c, H.c * L.s);
+    r = v < 0 ? -r : r;
+  }
+  return (float)r;
+}
+
+template <typename TI, int WANT_COS>
+__global__ __launch_bounds__(AGPU_BLOCK) void trig16_kernel(const TI* in, float* out, uint64_t ntiles,
+                                                           const SinCos64* gtab) {
+  constexpr int U = 4;
+  constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;  // packs of 4 rows (8 bytes in, 16 bytes out)
+  __shared__ SinCos64 tab[512];
+  const u32x2* in2 = reinterpret_cast<const u32x2*>(in);
+  f32x4* out4 = reinterpret_cast<f32x4*>(out);
+  uint64_t t = blockIdx.x;
+  u32x2 w[U];
+  if (t < ntiles)  // the first tile's loads go out before the table copy so the two latencies overlap
+    static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in2 + t * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
+  {
+    const u32x4* g = reinterpret_cast<const u32x4*>(gtab);
+    u32x4* l = reinterpret_cast<u32x4*>(tab);
+    l[threadIdx.x] = g[threadIdx.x];
+    l[threadIdx.x + AGPU_BLOCK] = g[threadIdx.x + AGPU_BLOCK];
+  }
+  __syncthreads();
+  while (t < ntiles) {
+    const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
+    static_for<U>([&](auto u) {
+      const u32x2 x = w[u];
+      f32x4 r = {trig16_eval<TI, WANT_COS>(tab, x.x & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, x.x >> 16),
+                 trig16_eval<TI, WANT_COS>(tab, x.y & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, x.y >> 16)};
+      __builtin_nontemporal_store(r, out4 + p0 + (uint64_t)u * AGPU_BLOCK);
+    });
+    t += gridDim.x;
+    if (t < ntiles)
+      static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in2 + t * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
+  }
+}
+// rows [first, n), one per lane, same arithmetic straight from the global table (tails and unaligned columns)
+template <typename TI, int WANT_COS>
+__global__ __launch_bounds__(AGPU_BLOCK) void trig16_tail_kernel(const TI* in, float* out, uint64_t first, uint64_t n,
+                                                                const SinCos64* gtab) {
+  for (uint64_t i = first + (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_BLOCK)
+    out[i] = trig16_eval<TI, WANT_COS>(gtab, (uint32_t)(uint16_t)in[i]);
+}
+
+template <typename TI, int WANT_COS>
+static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
+  static_assert(sizeof(TI) == 2, "16-bit sources only");
+  if (n == 0) return AGPU_OK;
+  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_BLOCK * 4 * 4;
+  const TI* pi = static_cast<const TI*>(in);
+  float* po = static_cast<float*>(out);
+  const SinCos64* tab = static_cast<const SinCos64*>(p->dev->trig16_table);
+  uint64_t done = 0;
+  if (aligned_to(in, 8) && aligned16(out)) {
+    const uint64_t ntiles = n / TILE_ROWS;
+    if (ntiles) {
+      hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS>), dim3(stream_grid_for(p, ntiles)), dim3(AGPU_BLOCK), 0, p->stream, pi,
+                         po, ntiles, tab);
+      done = ntiles * TILE_ROWS;
+    }
+  }
+  if (done < n) {
+    const int grid = stream_grid_for(p, (n - done + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL((trig16_tail_kernel<TI, WANT_COS>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, done, n, tab);
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
 // bool bitmap → f32 [cast/compute_shaders/boolean/cast_f32.wgsl:9-20]: lane expands 4 bits into one 16-byte store
 __global__ __launch_bounds__(AGPU_BLOCK) void bool_to_f32_kernel(const uint32_t* bits, float* out, uint64_t n) {
   const uint64_t npacks = n / 4;
@@ -940,8 +1073,8 @@ agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, con
   }
 #define UN_FUSED(T)                                                                          \
   switch (op) {                                                                              \
-    case AGPU_UN_SIN: return launch_cvt<T, float, CvtThenF32<T, UnSin>>(p, in, out, n);      \
-    case AGPU_UN_COS: return launch_cvt<T, float, CvtThenF32<T, UnCos>>(p, in, out, n);      \
+    case AGPU_UN_SIN: return launch_trig16<T, 0>(p, in, out, n);                             \
+    case AGPU_UN_COS: return launch_trig16<T, 1>(p, in, out, n);                             \
     case AGPU_UN_SINH: return launch_cvt<T, float, CvtThenF32<T, UnSinh>>(p, in, out, n);    \
     default: break;                                                                          \
   }

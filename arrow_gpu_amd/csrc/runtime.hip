@@ -69,11 +69,24 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
     delete d;
     return AGPU_ERR_NO_DEVICE;
   }
+  d->trig16_table = nullptr;
+  hipError_t me = hipMalloc(&d->trig16_table, 512 * 16);
+  agpu_status ts = me == hipSuccess ? agpu_internal_build_trig16(d->trig16_table) : AGPU_ERR_HIP;
+  if (ts != AGPU_OK) {
+    if (me != hipSuccess) agpu_set_error("hipMalloc of the trig table failed: %s", hipGetErrorString(me));
+    if (d->trig16_table) (void)hipFree(d->trig16_table);
+    delete d;
+    return ts;
+  }
   *out_device = d;
   return AGPU_OK;
 }
 
 agpu_status agpu_device_destroy(agpu_device* dev) {
+  if (dev && dev->trig16_table) {
+    (void)hipSetDevice(dev->ordinal);
+    (void)hipFree(dev->trig16_table);
+  }
   delete dev;
   return AGPU_OK;
 }
