@@ -22,8 +22,11 @@ struct agpu_device {
   // 8 KiB of f64 {sin, cos} pairs for the 16-bit fused trig kernels (elementwise.hip: trig16_kernel), built once at
   // device creation: [l] = sincos(l), [256 + h] = sincos(256·h), l, h ∈ 0..255
   void* trig16_table;
+  // 2 KiB of f64 {1/c, −log2(1/c)} pairs for f32 pow (elementwise.hip: pow_f32_dev); same allocation, + 8 KiB
+  void* pow_table;
 };
-agpu_status agpu_internal_build_trig16(void* table);  // elementwise.hip; synchronous
+#define AGPU_TABLE_BYTES (512 * 16 + 128 * 16)
+agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table);  // elementwise.hip; synchronous
 
 struct agpu_pipeline {
   agpu_device* dev;

@@ -401,6 +401,144 @@ static agpu_status launch_shift(agpu_pipeline* p, bool left, const void* a, cons
   return AGPU_OK;
 }
 
+// ---------------------------------------------------------------- f32 pow (x > 0): 2^(y · log2 x), ≤ 1 ULP
+// The result's relative error is ln2 · |error of y·log2 x| and |y·log2 x| reaches 150, so log2 x needs ~2⁻³³ relative
+// accuracy: f32 arithmetic cannot carry it, the f64 library pow runs at a quarter of the stream and the f32 library
+// powf (compensated f32) at 40 %.  Here: x = 2^e · m with m ∈ [0.707, 1.414); a 128-entry f64 table (LDS) gives
+// rc ≈ 1/c and lc = −log2 rc for the centre c of m's interval, so u = m·rc − 1 is EXACT-ish (one fma) with |u| ≤ 2⁻⁷ and
+//   log2 x = (e + lc) + log2e · (u − u²/2 + u³·q(u)),   q = 1/3 − u/4 + u²/5 − u³/6 in f32 (weighs < 2⁻¹⁵ of the sum).
+// The intervals touching 1 use rc = 1, lc = 0 exactly, so log2 x keeps its RELATIVE accuracy as x → 1 (where y may be
+// 1e9).  Then w = y·log2 x = k + r, 2^r = 1 + t + t²·Q(t) with t = r·ln2 and Q (1/2 … 1/9!) in f32 (weighs < 4 %),
+// v_ldexp_f64 by k (handles overflow / underflow / denormal results) and ONE rounding to f32.
+// Validated against f64 pow over 6 × 4 M samples (generic, full exponent range, x → 1 with huge y, denormal x,
+// |y| ≤ 60) in tools/probe/pow_emul.py and on the device in tests/test_gpu_parity.py.
+struct alignas(16) PowTab {
+  double rc, lc;
+};
+__global__ void pow_build_kernel(PowTab* tab) {
+  const int j = threadIdx.x;  // interval j of the f64 mantissa: [1 + j/128, 1 + (j+1)/128)
+  if (j >= 128) return;
+  const double c = 1.0 + (j + 0.5) / 128.0;
+  double rc = 1.0 / (j >= 53 ? 0.5 * c : c);  // j ≥ 53 (m ≥ 1.414): the mantissa is halved into [0.707, 1)
+  if (j == 0 || j == 127) rc = 1.0;
+  tab[j].rc = rc;
+  tab[j].lc = -log2(rc);
+}
+
+template <typename TabPtr>
+__device__ __forceinline__ float pow_f32_dev(TabPtr tab, float x, float y) {
+  const uint64_t bits = __builtin_bit_cast(uint64_t, (double)x);
+  const uint32_t hi = (uint32_t)(bits >> 32);
+  const uint32_t j = (hi >> 13) & 127u;
+  const bool big = j >= 53u;
+  const int e = (int)((hi >> 20) & 0x7ffu) - 1023 + (big ? 1 : 0);
+  const uint32_t mhi = (hi & 0x000fffffu) | (big ? 0x3fe00000u : 0x3ff00000u);
+  const double m = __builtin_bit_cast(double, ((uint64_t)mhi << 32) | (uint64_t)(uint32_t)bits);
+  const PowTab T = tab[j];
+  const double u = fma(m, T.rc, -1.0);
+  const float uf = (float)u;
+  float q = __builtin_fmaf(uf, -0x1.5555555555555p-3f, 0x1.999999999999ap-3f);  // −1/6, 1/5
+  q = __builtin_fmaf(uf, q, -0.25f);
+  q = __builtin_fmaf(uf, q, 0x1.5555555555555p-2f);  // 1/3
+  const double u2 = u * u;
+  const double l1p = fma(u2 * u, (double)q, fma(u2, -0.5, u));
+  const double L = fma(l1p, 0x1.71547652b82fep+0, (double)e + T.lc);
+  double w = (double)y * L;
+  w = w < 2000.0 ? w : 2000.0;  // keeps k inside v_ldexp's range; NaN cannot occur here (specials handled below)
+  w = w > -2000.0 ? w : -2000.0;
+  const double kd = rint(w);
+  const double t = (w - kd) * 0x1.62e42fefa39efp-1;
+  const float tf = (float)t;
+  float Q = __builtin_fmaf(tf, 0x1.71de3a556c734p-19f, 0x1.a01a01a01a01ap-16f);  // 1/9!, 1/8!
+  Q = __builtin_fmaf(tf, Q, 0x1.a01a01a01a01ap-13f);                             // 1/7!
+  Q = __builtin_fmaf(tf, Q, 0x1.6c16c16c16c17p-10f);                             // 1/6!
+  Q = __builtin_fmaf(tf, Q, 0x1.1111111111111p-7f);                              // 1/5!
+  Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-5f);                              // 1/4!
+  Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-3f);                              // 1/3!
+  Q = __builtin_fmaf(tf, Q, 0.5f);
+  const double pw = fma(t * t, (double)Q, 1.0 + t);
+  float r = (float)ldexp(pw, (int)kd);
+  // specials, IEEE pow restricted to the reference's domain [math/src/f32.rs:209-271]: negative or NaN base → NaN
+  const float inf = __builtin_inff();
+  if (!(x > 0.0f && x < inf)) r = ((x != 0.0f) == (y > 0.0f)) ? inf : 0.0f;  // 0^y, inf^y
+  if (y == 0.0f || x == 1.0f) r = 1.0f;
+  if (x != x || y != y || x < 0.0f || (x == 0.0f && __builtin_signbit(x))) r = __builtin_nanf("");
+  return r;
+}
+
+#define AGPU_POW_U 2
+template <int MODE>
+__global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const float* b, float* out, uint64_t ntiles,
+                                                        const PowTab* gtab) {
+  constexpr int U = AGPU_POW_U;
+  constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;
+  __shared__ PowTab tab[128];
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out);
+  uint64_t t = blockIdx.x;
+  f32x4 xa[U], xb[U];
+  float sv = 0.0f;
+  if constexpr (MODE == MODE_SCALAR) sv = b[0];
+  auto load_tile = [&](uint64_t tile) {
+    static_for<U>([&](auto u) {
+      const uint64_t pk = tile * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK;
+      xa[u] = __builtin_nontemporal_load(a4 + pk);
+      if constexpr (MODE == MODE_BINARY) xb[u] = __builtin_nontemporal_load(b4 + pk);
+    });
+  };
+  if (t < ntiles) load_tile(t);
+  if (threadIdx.x < 128)
+    reinterpret_cast<u32x4*>(tab)[threadIdx.x] = reinterpret_cast<const u32x4*>(gtab)[threadIdx.x];
+  __syncthreads();
+  while (t < ntiles) {
+    const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
+    static_for<U>([&](auto u) {
+      f32x4 r;
+      if constexpr (MODE == MODE_BINARY) {
+        r = f32x4{pow_f32_dev(tab, xa[u].x, xb[u].x), pow_f32_dev(tab, xa[u].y, xb[u].y),
+                  pow_f32_dev(tab, xa[u].z, xb[u].z), pow_f32_dev(tab, xa[u].w, xb[u].w)};
+      } else {
+        r = f32x4{pow_f32_dev(tab, xa[u].x, sv), pow_f32_dev(tab, xa[u].y, sv), pow_f32_dev(tab, xa[u].z, sv),
+                  pow_f32_dev(tab, xa[u].w, sv)};
+      }
+      __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
+    });
+    t += gridDim.x;
+    if (t < ntiles) load_tile(t);
+  }
+}
+template <int MODE>
+__global__ __launch_bounds__(AGPU_BLOCK) void pow_tail_kernel(const float* a, const float* b, float* out, uint64_t first,
+                                                             uint64_t n, const PowTab* gtab) {
+  for (uint64_t i = first + (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_BLOCK)
+    out[i] = pow_f32_dev(gtab, a[i], MODE == MODE_BINARY ? b[i] : b[0]);
+}
+template <int MODE>
+static agpu_status launch_pow_f32(agpu_pipeline* p, const void* a, const void* b, void* out, uint64_t n) {
+  if (n == 0) return AGPU_OK;
+  const float* pa = static_cast<const float*>(a);
+  const float* pb = static_cast<const float*>(b);
+  float* po = static_cast<float*>(out);
+  const PowTab* tab = static_cast<const PowTab*>(p->dev->pow_table);
+  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_BLOCK * AGPU_POW_U * 4;
+  uint64_t done = 0;
+  if (aligned16(a) && aligned16(out) && (MODE != MODE_BINARY || aligned16(b))) {
+    const uint64_t ntiles = n / TILE_ROWS;
+    if (ntiles) {
+      hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, ntiles)), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
+                         ntiles, tab);
+      done = ntiles * TILE_ROWS;
+    }
+  }
+  if (done < n) {
+    const int grid = stream_grid_for(p, (n - done + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL((pow_tail_kernel<MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po, done, n, tab);
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
 // ---------------------------------------------------------------- dispatch: op × dtype
 template <typename T, int MODE>
 static agpu_status dispatch_int_op(agpu_pipeline* p, agpu_binary_op op, const void* a, const void* b, void* out,
@@ -443,7 +581,7 @@ static agpu_status dispatch_f32_op(agpu_pipeline* p, agpu_binary_op op, const vo
     case AGPU_OP_REM: return launch_ew<float, OpRem, MODE>(p, a, b, out, n);
     case AGPU_OP_MIN: return launch_ew<float, OpMin, MODE>(p, a, b, out, n);
     case AGPU_OP_MAX: return launch_ew<float, OpMax, MODE>(p, a, b, out, n);
-    case AGPU_OP_POW: return launch_ew<float, OpPow, MODE>(p, a, b, out, n);
+    case AGPU_OP_POW: return launch_pow_f32<MODE>(p, a, b, out, n);
     default: break;
   }
   agpu_set_error("binary op %d not supported for f32", (int)op);
@@ -676,8 +814,9 @@ __global__ void trig16_build_kernel(SinCos64* tab) {
   tab[i].s = sin(a);
   tab[i].c = cos(a);
 }
-agpu_status agpu_internal_build_trig16(void* table) {
-  hipLaunchKernelGGL(trig16_build_kernel, dim3(2), dim3(256), 0, nullptr, static_cast<SinCos64*>(table));
+agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table) {
+  hipLaunchKernelGGL(trig16_build_kernel, dim3(2), dim3(256), 0, nullptr, static_cast<SinCos64*>(trig16_table));
+  hipLaunchKernelGGL(pow_build_kernel, dim3(1), dim3(128), 0, nullptr, static_cast<PowTab*>(pow_table));
   AGPU_HIP(hipGetLastError());
   AGPU_HIP(hipStreamSynchronize(nullptr));
   return AGPU_OK;

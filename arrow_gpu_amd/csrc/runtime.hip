@@ -70,10 +70,11 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
     return AGPU_ERR_NO_DEVICE;
   }
   d->trig16_table = nullptr;
-  hipError_t me = hipMalloc(&d->trig16_table, 512 * 16);
-  agpu_status ts = me == hipSuccess ? agpu_internal_build_trig16(d->trig16_table) : AGPU_ERR_HIP;
+  hipError_t me = hipMalloc(&d->trig16_table, AGPU_TABLE_BYTES);
+  d->pow_table = me == hipSuccess ? static_cast<char*>(d->trig16_table) + 512 * 16 : nullptr;
+  agpu_status ts = me == hipSuccess ? agpu_internal_build_tables(d->trig16_table, d->pow_table) : AGPU_ERR_HIP;
   if (ts != AGPU_OK) {
-    if (me != hipSuccess) agpu_set_error("hipMalloc of the trig table failed: %s", hipGetErrorString(me));
+    if (me != hipSuccess) agpu_set_error("hipMalloc of the function tables failed: %s", hipGetErrorString(me));
     if (d->trig16_table) (void)hipFree(d->trig16_table);
     delete d;
     return ts;

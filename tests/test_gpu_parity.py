@@ -114,6 +114,41 @@ def test_f32_power_domain_and_accuracy(D):
     assert max_ulp(got, exp) <= G.MAX_ULP
 
 
+@pytest.mark.parametrize("domain", ["wide", "near1", "near1_huge_y", "denormal_x", "big_exponent", "specials"])
+def test_f32_power_hard_domains(D, domain):
+    """pow needs log2 x to ~2^-33 relative: exercise the full exponent range, x -> 1 with |y| up to 1e9, denormal
+    bases, results across overflow/underflow, and the IEEE special-case grid (array and scalar exponent)."""
+    rng = np.random.default_rng(17)
+    n = 1 << 20
+    f32 = np.float32
+    sgn = rng.choice([-1.0, 1.0], n)
+    if domain == "wide":
+        a, b = (2.0 ** rng.uniform(-126, 127, n)).astype(f32), rng.uniform(-1.2, 1.2, n).astype(f32)
+    elif domain == "near1":
+        a, b = (1 + rng.uniform(-1e-3, 1e-3, n)).astype(f32), (2.0 ** rng.uniform(0, 16, n) * sgn).astype(f32)
+    elif domain == "near1_huge_y":
+        a, b = (1 + rng.uniform(-6e-7, 6e-7, n)).astype(f32), (2.0 ** rng.uniform(10, 30, n) * sgn).astype(f32)
+    elif domain == "denormal_x":
+        a, b = (2.0 ** rng.uniform(-149, -120, n)).astype(f32), rng.uniform(-0.9, 0.9, n).astype(f32)
+    elif domain == "big_exponent":
+        a, b = (2.0 ** rng.uniform(-3, 3, n)).astype(f32), rng.uniform(-60, 60, n).astype(f32)
+    else:
+        v = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 2.0, np.inf, -np.inf, np.nan, 1e-45, 3.4e38, 0.99999994, 1.0000001,
+                      -2.0, 1e-20, 1e20, 3.0, -3.0, 0.33333334], f32)
+        a, b = [x.ravel().astype(f32) for x in np.meshgrid(v, v)]
+        n = len(a)
+    out = D.empty(4 * n)
+    D.call("agpu_binary", capi.OP_POW, capi.F32, D.up(a).vp, D.up(b).vp, out.vp, n)
+    got, exp = D.down(out, np.float32, n), O.binary(O.OP_POW, O.F32, a, b)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    assert max_ulp(got, exp) <= G.MAX_ULP, domain
+    s = np.array([b[n // 2]], f32)  # scalar exponent: same arithmetic
+    D.call("agpu_scalar", capi.OP_POW, capi.F32, D.up(a).vp, D.up(s).vp, out.vp, n)
+    got, exp = D.down(out, np.float32, n), O.scalar(O.OP_POW, O.F32, a, s)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+    assert max_ulp(got, exp) <= G.MAX_ULP, domain
+
+
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_unary_exact_ops(D, dtype):
     ops = [capi.UN_NEG, capi.UN_ABS] + ([capi.UN_SQRT] if dtype == capi.F32 else [capi.UN_NOT])
