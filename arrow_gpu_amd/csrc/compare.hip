@@ -7,9 +7,9 @@
 //
 // MI355X design (HBM-bound: 8 B in + 1 bit out per row for 32-bit types, +3 bits with validity):
 //   variant 0 "ballot"  (32-bit types): lane r-th load covers element e0 + r*64 + lane, so `__ballot(pred)` IS the
-//       output word for those 64 rows — no LDS, no atomics, no barrier.  16 rounds are kept in flight per wave
-//       (16 dword loads per input array per lane), the 16 masks are steered to lanes 0..15 and stored as one
-//       contiguous 128-byte row; the same 16 lanes AND the two validity words.
+//       output word for those 64 rows — no LDS, no atomics, no barrier.  R = 4 rounds are kept in flight per wave
+//       (4 dword loads per input array per lane), the masks are steered to lanes 0..3 and stored as one 32-byte row.
+//       The validity AND runs in dedicated blocks of the same launch (validity_block below).
 //   variant 1 "vector"  (all types; default for sub-word types): lane loads 16-byte vectors (4/8/16 elements),
 //       builds an N-bit mask, and G = 32/N neighbouring lanes OR their shifted masks with xor-shuffles.
 // Bits past n in the last word(s) are written as 0 (the reference leaves them unspecified).
@@ -41,6 +41,27 @@ __device__ __forceinline__ uint64_t validity_word(const uint64_t* va, const uint
   return x & y;
 }
 
+// Validity AND inside the compare launch.  The two jobs share no bytes, so "fusing" them per tile (every compare block
+// also moving its 16 validity words) only adds 3 small memory instructions to 10^6 short blocks: 1.395 ms fused vs
+// 1.252 + 0.067 ms as two launches at 1e9 rows.  Instead the grid gets DEDICATED validity blocks in front of the compare
+// tiles (virtual block ids [0, nvb) of the same launch): each moves 4 KiB per bitmap with 16-byte accesses, the shape
+// the stand-alone bitmap kernel uses, and overlaps with the first compare tiles.
+typedef uint64_t cmp_u64x2 __attribute__((ext_vector_type(2)));
+#define CMP_VBLOCK_WORDS (2 * AGPU_BLOCK)  // u64 words of each bitmap per validity block
+__device__ __forceinline__ void validity_block(const uint64_t* va, const uint64_t* vb, uint64_t* outv, uint64_t vblk,
+                                               uint64_t n_words, bool vec16) {
+  const uint64_t w = vblk * CMP_VBLOCK_WORDS + 2 * threadIdx.x;
+  if (vec16 && w + 2 <= n_words) {
+    const cmp_u64x2 ones = {~0ull, ~0ull};
+    const cmp_u64x2 x = va ? *reinterpret_cast<const cmp_u64x2*>(va + w) : ones;
+    const cmp_u64x2 y = vb ? *reinterpret_cast<const cmp_u64x2*>(vb + w) : ones;
+    *reinterpret_cast<cmp_u64x2*>(outv + w) = x & y;
+  } else {
+    if (w < n_words) outv[w] = validity_word(va, vb, w);
+    if (w + 1 < n_words) outv[w + 1] = validity_word(va, vb, w + 1);
+  }
+}
+
 // ---------------------------------------------------------------- variant 0: ballot
 // R = rounds per wave tile (R output u64 words per wave).  R = 4 with 256-thread blocks (1024 rows per block) measured
 // best at 1e9 rows (6.07 TB/s vs 5.89 at R = 16: profiles/r01_sweep_add_eq_1e9_b.json).  Full tiles only; the
@@ -49,15 +70,19 @@ __device__ __forceinline__ uint64_t validity_word(const uint64_t* va, const uint
 template <typename T, int OP, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, const T* b, const uint64_t* va,
                                                                const uint64_t* vb, uint64_t* out, uint64_t* outv,
-                                                               uint64_t ntiles) {
+                                                               uint64_t ntiles, uint64_t nvb, int vec16) {
   constexpr int R = CMP_R;
   constexpr uint64_t WAVE_TILE = (uint64_t)AGPU_WAVE * R;
   constexpr uint64_t TILE = WAVE_TILE * (AGPU_BLOCK / AGPU_WAVE);
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
   const uint32_t wave = threadIdx.x / AGPU_WAVE;
-  const bool do_v = outv != nullptr;
 
-  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  for (uint64_t v = blockIdx.x; v < nvb + ntiles; v += gridDim.x) {
+    if (v < nvb) {  // validity words of the tiled rows: [0, ntiles * TILE / 64); interleaving these blocks with the
+      validity_block(va, vb, outv, v, ntiles * (TILE / 64), vec16 != 0);  // tiles (every 33rd) measured 3 % slower
+      continue;
+    }
+    const uint64_t t = v - nvb;
     const uint64_t e0 = t * TILE + wave * WAVE_TILE;
     const uint64_t w0 = e0 / 64;
     T xa[R], xb[R];
@@ -66,12 +91,6 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, cons
       xa[r] = ld_vec<NT, T>(a + e0 + (uint64_t)r * AGPU_WAVE + lane);
       xb[r] = ld_vec<NT, T>(b + e0 + (uint64_t)r * AGPU_WAVE + lane);
     }
-    // validity: the block's TILE/64 = 16 words are one 128-byte line per bitmap — lanes 0..15 of wave 0 move them with
-    // 3 memory instructions per block (per-wave 32-byte pieces cost 12 and 17 % of the kernel: 1.41 vs 1.21 ms)
-    constexpr uint32_t VWORDS = (uint32_t)(TILE / 64);
-    uint64_t vword = 0;
-    const bool v_lane = do_v && threadIdx.x < VWORDS;
-    if (v_lane) vword = validity_word(va, vb, t * VWORDS + threadIdx.x);
     uint64_t word = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -79,7 +98,6 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, cons
       if (lane == (uint32_t)r) word = m;
     }
     if (lane < R) out[w0 + lane] = word;
-    if (v_lane) outv[t * VWORDS + threadIdx.x] = vword;
   }
 }
 
@@ -92,14 +110,19 @@ struct CmpPack {
 template <typename T, int OP, int U, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T* b, const uint32_t* va,
                                                             const uint32_t* vb, uint32_t* out, uint32_t* outv,
-                                                            uint64_t ntiles) {
+                                                            uint64_t ntiles, uint64_t nvb, int vec16) {
   constexpr int N = 16 / sizeof(T);  // rows per lane per vector: 4, 8 or 16
   constexpr int G = 32 / N;          // lanes per 32-bit output word: 8, 4 or 2
   constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
-  const bool do_v = outv != nullptr;
 
-  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  for (uint64_t vid = blockIdx.x; vid < nvb + ntiles; vid += gridDim.x) {
+    if (vid < nvb) {  // validity words of the tiled rows: [0, ntiles * TILE_PACKS * N / 64)
+      validity_block(reinterpret_cast<const uint64_t*>(va), reinterpret_cast<const uint64_t*>(vb),
+                     reinterpret_cast<uint64_t*>(outv), vid, ntiles * (TILE_PACKS * N / 64), vec16 != 0);
+      continue;
+    }
+    const uint64_t t = vid - nvb;
     const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
     CmpPack<T, N> xa[U], xb[U];
 #pragma unroll
@@ -122,7 +145,6 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T
       if (lane % G == 0) {
         const uint64_t w = pk / G;
         out[w] = v;
-        if (do_v) outv[w] = (va ? va[w] : ~0u) & (vb ? vb[w] : ~0u);
       }
     }
   }
@@ -155,13 +177,16 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
   uint64_t* out64 = static_cast<uint64_t*>(out);
   uint64_t* outv64 = static_cast<uint64_t*>(outv);
   uint64_t done_rows = 0;  // rows covered by the tiled kernel (a multiple of 64)
+  const int vec16 = (!va || aligned16(va)) && (!vb || aligned16(vb)) && (!outv || aligned16(outv));
   if (use_ballot) {
     constexpr uint64_t TILE = (uint64_t)AGPU_WAVE * CMP_R * (AGPU_BLOCK / AGPU_WAVE);
     const uint64_t ntiles = n / TILE;
     if (ntiles) {
-      const int grid = stream_grid_for(p, ntiles);
+      const uint64_t nvb = outv ? (ntiles * (TILE / 64) + CMP_VBLOCK_WORDS - 1) / CMP_VBLOCK_WORDS : 0;
+      const int grid = stream_grid_for(p, ntiles + nvb);
       auto k = nt ? cmp_ballot_kernel<T, OP, true> : cmp_ballot_kernel<T, OP, false>;
-      hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, va64, vb64, out64, outv64, ntiles);
+      hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, va64, vb64, out64, outv64, ntiles, nvb,
+                         vec16);
     }
     done_rows = ntiles * TILE;
   } else if (aligned16(a) && aligned16(b)) {
@@ -169,11 +194,12 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
     constexpr uint64_t TILE = (uint64_t)AGPU_BLOCK * U * N;
     const uint64_t ntiles = n / TILE;
     if (ntiles) {
-      const int grid = stream_grid_for(p, ntiles);
+      const uint64_t nvb = outv ? (ntiles * (TILE / 64) + CMP_VBLOCK_WORDS - 1) / CMP_VBLOCK_WORDS : 0;
+      const int grid = stream_grid_for(p, ntiles + nvb);
       auto k = nt ? cmp_vec_kernel<T, OP, U, true> : cmp_vec_kernel<T, OP, U, false>;
       hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, static_cast<const uint32_t*>(va),
                          static_cast<const uint32_t*>(vb), static_cast<uint32_t*>(out), static_cast<uint32_t*>(outv),
-                         ntiles);
+                         ntiles, nvb, vec16);
     }
     done_rows = ntiles * TILE;
   }
