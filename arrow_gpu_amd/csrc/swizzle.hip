@@ -8,8 +8,12 @@
 //
 // MI355X design: the index stream and the output stream are coalesced 16-byte accesses; the gather/scatter side is
 // element-granular by nature (each 4-byte access pulls a whole 64/128-byte line), so these kernels are bound by
-// line fetches, not by algorithmic bytes — DESIGN.md reports them honestly against 12/16 B per row.  Several
-// independent gathers per lane are kept in flight.  Bit gathers use the wave ballot exactly like the compare kernel.
+// line fetches, not by algorithmic bytes — DESIGN.md reports them honestly against 12/16 B per row.  Measured
+// (profiles/r01_gather_sweep.json): a random 4-byte gather from a 1 GiB column runs at 52 G rows/s and exactly doubles
+// when index pairs share a 128-byte line, whichever half or sector they hit ⇒ every miss moves a full 128-byte line and
+// 52 G × 128 B = 6.7 TB/s is the HBM roof; 4 / 8 / 16 gathers in flight per lane, one-wave blocks and nontemporal
+// gathers change nothing (nt: −7 %).  Sorted indices reach 245–720 G rows/s.  The index and output streams are
+// nontemporal so they do not evict a cache-resident source (4 MiB source: 165 → 183 G rows/s).  Bit gathers use the wave ballot exactly like the compare kernel.
 #include "common.hpp"
 
 template <int W> struct ElemOf;
@@ -32,13 +36,13 @@ __global__ __launch_bounds__(AGPU_BLOCK) void take_kernel(const typename ElemOf<
     uint32_t ix[N];
 #pragma unroll
     for (int q = 0; q < N / 4; q++) {
-      const u32x4 t = *reinterpret_cast<const u32x4*>(idx + pk * N + q * 4);
+      const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(idx + pk * N + q * 4));
       ix[q * 4 + 0] = t.x; ix[q * 4 + 1] = t.y; ix[q * 4 + 2] = t.z; ix[q * 4 + 3] = t.w;
     }
     OutPack<E, N> r;
 #pragma unroll
     for (int k = 0; k < N; k++) r.v[k] = values[ix[k]];
-    *reinterpret_cast<u32x4*>(out + pk * N) = __builtin_bit_cast(u32x4, r);
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, r), reinterpret_cast<u32x4*>(out + pk * N));
   }
   for (uint64_t i = npacks * N + tid; i < n; i += stride) out[i] = values[idx[i]];
 }
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void take_bits_kernel(const uint32_t* b
     const uint64_t i = w * 64 + lane;
     bool bit = false;
     if (i < n) {
-      const uint32_t ix = idx[i];
+      const uint32_t ix = __builtin_nontemporal_load(idx + i);
       bit = (bits[ix >> 5] >> (ix & 31)) & 1u;
     }
     const uint64_t m = __ballot(bit);
@@ -71,8 +75,8 @@ __global__ __launch_bounds__(AGPU_BLOCK) void put_kernel(const typename ElemOf<W
   const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
   const uint64_t npacks = vec_ok ? n / 4 : 0;
   for (uint64_t pk = tid; pk < npacks; pk += stride) {
-    const u32x4 si = *reinterpret_cast<const u32x4*>(src_idx + pk * 4);
-    const u32x4 di = *reinterpret_cast<const u32x4*>(dst_idx + pk * 4);
+    const u32x4 si = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src_idx + pk * 4));
+    const u32x4 di = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dst_idx + pk * 4));
     const auto v0 = src[si.x], v1 = src[si.y], v2 = src[si.z], v3 = src[si.w];
     dst[di.x] = v0; dst[di.y] = v1; dst[di.z] = v2; dst[di.w] = v3;
   }
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void merge_kernel(const typename ElemOf
     OutPack<E, N> r;
 #pragma unroll
     for (int k = 0; k < N; k++) r.v[k] = ((m >> k) & 1u) ? x.v[k] : y.v[k];
-    *reinterpret_cast<u32x4*>(out + pk * N) = __builtin_bit_cast(u32x4, r);
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, r), reinterpret_cast<u32x4*>(out + pk * N));
   }
   for (uint64_t i = npacks * N + tid; i < n; i += stride)
     out[i] = ((mask[i >> 5] >> (i & 31)) & 1u) ? a[i] : b[i];

@@ -49,6 +49,19 @@ static void run_compute_pipeline_ops(const DevicePtr& device) {
   pipeline.finish();
   auto v = try_from<Float32ArrayGPU>(r2).values();
   for (size_t i = 0; i < v.size(); i++) CHECK(v[i].value() == (float_values[i] + 20.0f) * 20.0f);
+  // the same chain as ONE kernel (FusedChain): bit-identical values, validity rules of the step-by-step chain
+  auto a = try_from<Float32ArrayGPU>(lhs), s = try_from<Float32ArrayGPU>(rhs);
+  auto fused = FusedChain(a).add_scalar(s).mul_scalar(s).finish();
+  CHECK(fused.raw_values() == try_from<Float32ArrayGPU>(r2).raw_values());
+  CHECK(!fused.null_buffer.has_value());
+  auto x = Float32ArrayGPU::from_optional_slice({0.0f, 1.0f, N, N, 4.0f}, device);
+  auto y = Float32ArrayGPU::from_optional_slice({1.0f, 2.0f, N, 4.0f, N}, device);
+  auto fz = FusedChain(x).add(y).neg().abs().sqrt().finish();
+  auto uz = x.add(y).neg().abs().sqrt();
+  CHECK(fz.values() == uz.values());
+  auto ia = Int32ArrayGPU::from_slice({1, -2, 3, std::numeric_limits<int32_t>::max()}, device);
+  auto ib = Int32ArrayGPU::from_slice({100}, device);
+  CHECK(FusedChain(ia).mul(ib).abs().finish().raw_values() == ia.mul_scalar(ib).abs().raw_values());
 }
 
 int main() {
