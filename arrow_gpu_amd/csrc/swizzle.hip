@@ -24,7 +24,10 @@ template <> struct ElemOf<4> { typedef uint32_t type; };
 template <typename E, int N> struct OutPack { E v[N]; };
 
 // ---------------------------------------------------------------- take
-template <int W>
+template <typename V>
+__device__ __forceinline__ V swz_ld(const V* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
+
+template <int W, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void take_kernel(const typename ElemOf<W>::type* values, const uint32_t* idx,
                                                          typename ElemOf<W>::type* out, uint64_t n, int vec_ok) {
   typedef typename ElemOf<W>::type E;
@@ -36,13 +39,14 @@ __global__ __launch_bounds__(AGPU_BLOCK) void take_kernel(const typename ElemOf<
     uint32_t ix[N];
 #pragma unroll
     for (int q = 0; q < N / 4; q++) {
-      const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(idx + pk * N + q * 4));
+      const u32x4 t = swz_ld(reinterpret_cast<const u32x4*>(idx + pk * N + q * 4), NT);
       ix[q * 4 + 0] = t.x; ix[q * 4 + 1] = t.y; ix[q * 4 + 2] = t.z; ix[q * 4 + 3] = t.w;
     }
     OutPack<E, N> r;
 #pragma unroll
     for (int k = 0; k < N; k++) r.v[k] = values[ix[k]];
-    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, r), reinterpret_cast<u32x4*>(out + pk * N));
+    if (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, r), reinterpret_cast<u32x4*>(out + pk * N));
+    else *reinterpret_cast<u32x4*>(out + pk * N) = __builtin_bit_cast(u32x4, r);
   }
   for (uint64_t i = npacks * N + tid; i < n; i += stride) out[i] = values[idx[i]];
 }
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void take_bits_kernel(const uint32_t* b
 }
 
 // ---------------------------------------------------------------- put (in place on dst)
-template <int W>
+template <int W, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void put_kernel(const typename ElemOf<W>::type* src, const uint32_t* src_idx,
                                                         typename ElemOf<W>::type* dst, const uint32_t* dst_idx,
                                                         uint64_t n, int vec_ok) {
@@ -75,8 +79,8 @@ __global__ __launch_bounds__(AGPU_BLOCK) void put_kernel(const typename ElemOf<W
   const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
   const uint64_t npacks = vec_ok ? n / 4 : 0;
   for (uint64_t pk = tid; pk < npacks; pk += stride) {
-    const u32x4 si = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src_idx + pk * 4));
-    const u32x4 di = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dst_idx + pk * 4));
+    const u32x4 si = swz_ld(reinterpret_cast<const u32x4*>(src_idx + pk * 4), NT);
+    const u32x4 di = swz_ld(reinterpret_cast<const u32x4*>(dst_idx + pk * 4), NT);
     const auto v0 = src[si.x], v1 = src[si.y], v2 = src[si.z], v3 = src[si.w];
     dst[di.x] = v0; dst[di.y] = v1; dst[di.z] = v2; dst[di.w] = v3;
   }
@@ -97,18 +101,21 @@ __global__ __launch_bounds__(AGPU_BLOCK) void put_bits_kernel(const uint32_t* sr
 }
 
 // ---------------------------------------------------------------- merge: out[i] = mask bit i ? a[i] : b[i]
+// Shape of the element-wise stream (elementwise.hip): one-wave blocks, one 16-byte pack per lane, nontemporal loads and
+// stores; the wave's 8 mask words are one 32-byte row read through 8-lane broadcasts.
+#define AGPU_MERGE_BLOCK 64
 template <int W>
-__global__ __launch_bounds__(AGPU_BLOCK) void merge_kernel(const typename ElemOf<W>::type* a,
+__global__ __launch_bounds__(AGPU_MERGE_BLOCK) void merge_kernel(const typename ElemOf<W>::type* a,
                                                           const typename ElemOf<W>::type* b, const uint32_t* mask,
                                                           typename ElemOf<W>::type* out, uint64_t n, int vec_ok) {
   typedef typename ElemOf<W>::type E;
   constexpr int N = 16 / W;  // 4, 8, 16 rows per lane; N divides 32 so a pack's mask bits sit in one word
-  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_MERGE_BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * AGPU_MERGE_BLOCK;
   const uint64_t npacks = vec_ok ? n / N : 0;
   for (uint64_t pk = tid; pk < npacks; pk += stride) {
-    const OutPack<E, N> x = __builtin_bit_cast(OutPack<E, N>, *reinterpret_cast<const u32x4*>(a + pk * N));
-    const OutPack<E, N> y = __builtin_bit_cast(OutPack<E, N>, *reinterpret_cast<const u32x4*>(b + pk * N));
+    const OutPack<E, N> x = __builtin_bit_cast(OutPack<E, N>, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a + pk * N)));
+    const OutPack<E, N> y = __builtin_bit_cast(OutPack<E, N>, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(b + pk * N)));
     const uint64_t row = pk * N;
     const uint32_t m = mask[row >> 5] >> (row & 31);
     OutPack<E, N> r;
@@ -124,7 +131,14 @@ __global__ __launch_bounds__(AGPU_BLOCK) void index_max_kernel(const uint32_t* i
   const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
   uint32_t m = 0;
-  for (uint64_t i = tid; i < n; i += stride) m = idx[i] > m ? idx[i] : m;
+  const uint64_t npacks = ((reinterpret_cast<uintptr_t>(idx) & 15u) == 0) ? n / 4 : 0;  // 16-byte loads when aligned
+  for (uint64_t pk = tid; pk < npacks; pk += stride) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(idx) + pk);
+    const uint32_t a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+    const uint32_t c = a > b ? a : b;
+    m = c > m ? c : m;
+  }
+  for (uint64_t i = npacks * 4 + tid; i < n; i += stride) m = idx[i] > m ? idx[i] : m;
 #pragma unroll
   for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) {
     const uint32_t o = (uint32_t)__shfl_down((int)m, off);
@@ -133,6 +147,9 @@ __global__ __launch_bounds__(AGPU_BLOCK) void index_max_kernel(const uint32_t* i
   if ((threadIdx.x & (AGPU_WAVE - 1)) == 0 && m) atomicMax(out, m);
 }
 
+// nontemporal index / output streams: neutral for HBM-resident sources (A/B on one box: 638 vs 637 GB/s), +10 % when the
+// source fits in L2 (they stop evicting it)
+static constexpr bool swz_nt() { return true; }
 static int gs_grid(const agpu_pipeline* p, uint64_t items) {
   return stream_grid_for(p, (items + AGPU_BLOCK - 1) / AGPU_BLOCK);
 }
@@ -149,15 +166,15 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   const int grid = gs_grid(p, n_idx / (16 / (width > 0 ? width : 1)) + 1);
   switch (width) {
     case 4:
-      hipLaunchKernelGGL((take_kernel<4>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(values),
+      hipLaunchKernelGGL((swz_nt() ? take_kernel<4, true> : take_kernel<4, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(values),
                          idx, static_cast<uint32_t*>(out), n_idx, vec_ok);
       break;
     case 2:
-      hipLaunchKernelGGL((take_kernel<2>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(values),
+      hipLaunchKernelGGL((swz_nt() ? take_kernel<2, true> : take_kernel<2, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(values),
                          idx, static_cast<uint16_t*>(out), n_idx, vec_ok);
       break;
     case 1:
-      hipLaunchKernelGGL((take_kernel<1>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(values),
+      hipLaunchKernelGGL((swz_nt() ? take_kernel<1, true> : take_kernel<1, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(values),
                          idx, static_cast<uint8_t*>(out), n_idx, vec_ok);
       break;
     default:
@@ -192,15 +209,15 @@ agpu_status agpu_put(agpu_pipeline* p, int32_t width, const void* src, const uin
   const int grid = gs_grid(p, n / 4 + 1);
   switch (width) {
     case 4:
-      hipLaunchKernelGGL((put_kernel<4>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(src),
+      hipLaunchKernelGGL((swz_nt() ? put_kernel<4, true> : put_kernel<4, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(src),
                          src_idx, static_cast<uint32_t*>(dst), dst_idx, n, vec_ok);
       break;
     case 2:
-      hipLaunchKernelGGL((put_kernel<2>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(src),
+      hipLaunchKernelGGL((swz_nt() ? put_kernel<2, true> : put_kernel<2, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(src),
                          src_idx, static_cast<uint16_t*>(dst), dst_idx, n, vec_ok);
       break;
     case 1:
-      hipLaunchKernelGGL((put_kernel<1>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(src),
+      hipLaunchKernelGGL((swz_nt() ? put_kernel<1, true> : put_kernel<1, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(src),
                          src_idx, static_cast<uint8_t*>(dst), dst_idx, n, vec_ok);
       break;
     default:
@@ -231,20 +248,20 @@ agpu_status agpu_merge(agpu_pipeline* p, int32_t width, const void* a, const voi
   AGPU_REQUIRE(a && b && mask_bits && out, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(aligned_to(mask_bits, 4), AGPU_ERR_SHAPE, "mask bitmap must be 4-byte aligned");
   const int vec_ok = aligned16(a) && aligned16(b) && aligned16(out);
-  const int grid = gs_grid(p, n / (16 / (width > 0 ? width : 1)) + 1);
+  const int grid = stream_grid_for(p, (n / (16 / (width > 0 ? width : 1)) + AGPU_MERGE_BLOCK) / AGPU_MERGE_BLOCK);
   switch (width) {
     case 4:
-      hipLaunchKernelGGL((merge_kernel<4>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(a),
+      hipLaunchKernelGGL((merge_kernel<4>), dim3(grid), dim3(AGPU_MERGE_BLOCK), 0, p->stream, static_cast<const uint32_t*>(a),
                          static_cast<const uint32_t*>(b), static_cast<const uint32_t*>(mask_bits),
                          static_cast<uint32_t*>(out), n, vec_ok);
       break;
     case 2:
-      hipLaunchKernelGGL((merge_kernel<2>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(a),
+      hipLaunchKernelGGL((merge_kernel<2>), dim3(grid), dim3(AGPU_MERGE_BLOCK), 0, p->stream, static_cast<const uint16_t*>(a),
                          static_cast<const uint16_t*>(b), static_cast<const uint32_t*>(mask_bits),
                          static_cast<uint16_t*>(out), n, vec_ok);
       break;
     case 1:
-      hipLaunchKernelGGL((merge_kernel<1>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(a),
+      hipLaunchKernelGGL((merge_kernel<1>), dim3(grid), dim3(AGPU_MERGE_BLOCK), 0, p->stream, static_cast<const uint8_t*>(a),
                          static_cast<const uint8_t*>(b), static_cast<const uint32_t*>(mask_bits),
                          static_cast<uint8_t*>(out), n, vec_ok);
       break;
