@@ -150,7 +150,18 @@ struct OpMax {
 struct OpAnd { template <typename T> __device__ static __forceinline__ T ap(T x, T y) { return (T)(x & y); } };
 struct OpOr { template <typename T> __device__ static __forceinline__ T ap(T x, T y) { return (T)(x | y); } };
 struct OpXor { template <typename T> __device__ static __forceinline__ T ap(T x, T y) { return (T)(x ^ y); } };
-struct OpPow {  // f32: NaN for negative/NaN base (math/src/f32.rs:209-271), else powf; i32: closed form of the WGSL loop
+// 32-bit shifts ride the same stream kernel: the u32 shift-amount column is read as T (same width), amount mod 32
+// [logical/compute_shaders/{u32,i32}/shift.wgsl]; sub-word columns keep shift_kernel (4-byte amounts per 1–2-byte row)
+struct OpShl {
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) { return (T)((uint32_t)x << ((uint32_t)y & 31u)); }
+};
+struct OpShr {
+  template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
+    if constexpr (std::is_signed<T>::value) return (T)((int32_t)x >> ((uint32_t)y & 31u));
+    else return (T)((uint32_t)x >> ((uint32_t)y & 31u));
+  }
+};
+struct OpPow {  // i32: closed form of the WGSL loop.  (f32 pow runs in pow_kernel below; the float branch here is unused)
   template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
     if constexpr (std::is_floating_point<T>::value) {
       if (x != x || y != y || x < 0.0f || (x == 0.0f && __builtin_signbit(x))) return __builtin_nanf("");
@@ -343,6 +354,12 @@ __global__ __launch_bounds__(AGPU_BLOCK) void ew_kernel_unaligned(const T* a, co
     out[i] = Op::ap(a[i], MODE == MODE_BINARY ? b[i] : sv);
 }
 
+template <typename Op> struct EwUnroll { static constexpr int value = AGPU_STREAM_U; };
+template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };
+template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };
+template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
+template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };
+
 template <typename T, typename Op, int MODE>
 static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, void* out, uint64_t n) {
   if (n == 0) return AGPU_OK;
@@ -352,12 +369,16 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
   const bool vec_ok = aligned16(a) && aligned16(out) && (MODE != MODE_BINARY || aligned16(b));
   if (vec_ok) {
     constexpr int N = 16 / sizeof(T);
-    constexpr uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * AGPU_STREAM_U * N;
+    // 16-byte packs per lane per block: 1 for everything that is purely HBM-bound; the VALU-heavy functors hide their
+    // dependent f64 chains better with 2–4 independent rows of work per lane (A/B on one box at 1e9 rows: sin/cos/log
+    // 5.9 → 6.25 TB/s at U = 2, sinh 5.95 → 6.44 at U = 4, while add_scalar/neg/exp LOSE 10 % at U = 2)
+    constexpr int U = EwUnroll<Op>::value;
+    constexpr uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * U * N;
     const uint64_t ntiles = n / tile_rows;
     if (ntiles) {
       const int grid = stream_grid_for(p, ntiles);
-      hipLaunchKernelGGL((ew_kernel<T, Op, MODE, AGPU_STREAM_U, AGPU_STREAM_NT>), dim3(grid), dim3(AGPU_EW_BLOCK), 0,
-                         p->stream, pa, pb, po, ntiles);
+      hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, AGPU_STREAM_NT>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pa, pb,
+                         po, ntiles);
     }
     if (ntiles * tile_rows < n)
       hipLaunchKernelGGL((ew_tail_kernel<T, Op, MODE>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
@@ -373,30 +394,45 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
 // ---------------------------------------------------------------- shifts: lhs T[n], rhs u32[n] (or 1 scalar)
 // value extended to 32 bits, amount mod 32, result truncated to T
 // [logical/compute_shaders/{u32,i32,u16,i16,u8,i8}/shift.wgsl]
+template <typename T, bool LEFT>
+__device__ __forceinline__ T shift_one(T x, uint32_t sh) {
+  if constexpr (LEFT) return (T)((uint32_t)(int32_t)x << sh);
+  else if constexpr (std::is_signed<T>::value) return (T)((int32_t)x >> sh);
+  else return (T)((uint32_t)x >> sh);
+}
+// sub-word columns: 4 rows per lane per step — one 16-byte load of amounts, one 4/8-byte load and store of values
 template <typename T, bool LEFT, int MODE>
-__global__ __launch_bounds__(AGPU_BLOCK) void shift_kernel(const T* a, const uint32_t* s, T* out, uint64_t n) {
+__global__ __launch_bounds__(AGPU_BLOCK) void shift_kernel(const T* a, const uint32_t* s, T* out, uint64_t n, int vec_ok) {
   uint32_t sv = 0;
   if constexpr (MODE == MODE_SCALAR) sv = s[0] & 31u;
-  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_BLOCK) {
-    const uint32_t sh = MODE == MODE_SCALAR ? sv : (s[i] & 31u);
-    const T x = a[i];
-    T r;
-    if constexpr (LEFT) r = (T)((uint32_t)(int32_t)x << sh);
-    else if constexpr (std::is_signed<T>::value) r = (T)((int32_t)x >> sh);
-    else r = (T)((uint32_t)x >> sh);
-    out[i] = r;
+  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  const uint64_t npacks = vec_ok ? n / 4 : 0;
+  for (uint64_t pk = tid; pk < npacks; pk += stride) {
+    const PackN<T, 4> x = load_pack<true, T, 4>(a + pk * 4);
+    u32x4 sh = {sv, sv, sv, sv};
+    if constexpr (MODE != MODE_SCALAR) sh = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(s) + pk) & 31u;
+    PackN<T, 4> r;
+    r.v[0] = shift_one<T, LEFT>(x.v[0], sh.x);
+    r.v[1] = shift_one<T, LEFT>(x.v[1], sh.y);
+    r.v[2] = shift_one<T, LEFT>(x.v[2], sh.z);
+    r.v[3] = shift_one<T, LEFT>(x.v[3], sh.w);
+    store_pack<true, T, 4>(out + pk * 4, r);
   }
+  for (uint64_t i = npacks * 4 + tid; i < n; i += stride)
+    out[i] = shift_one<T, LEFT>(a[i], MODE == MODE_SCALAR ? sv : (s[i] & 31u));
 }
 template <typename T, int MODE>
 static agpu_status launch_shift(agpu_pipeline* p, bool left, const void* a, const void* s, void* out, uint64_t n) {
   if (n == 0) return AGPU_OK;
-  const int grid = stream_grid_for(p, (n + AGPU_BLOCK - 1) / AGPU_BLOCK);
+  const int vec_ok = aligned_to(a, 4 * sizeof(T)) && aligned_to(out, 4 * sizeof(T)) && (MODE == MODE_SCALAR || aligned16(s));
+  const int grid = stream_grid_for(p, (n / 4 + AGPU_BLOCK) / AGPU_BLOCK);
   if (left)
     hipLaunchKernelGGL((shift_kernel<T, true, MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
-                       static_cast<const T*>(a), static_cast<const uint32_t*>(s), static_cast<T*>(out), n);
+                       static_cast<const T*>(a), static_cast<const uint32_t*>(s), static_cast<T*>(out), n, vec_ok);
   else
     hipLaunchKernelGGL((shift_kernel<T, false, MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
-                       static_cast<const T*>(a), static_cast<const uint32_t*>(s), static_cast<T*>(out), n);
+                       static_cast<const T*>(a), static_cast<const uint32_t*>(s), static_cast<T*>(out), n, vec_ok);
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
 }
@@ -553,8 +589,12 @@ static agpu_status dispatch_int_op(agpu_pipeline* p, agpu_binary_op op, const vo
     case AGPU_OP_AND: return launch_ew<T, OpAnd, MODE>(p, a, b, out, n);
     case AGPU_OP_OR: return launch_ew<T, OpOr, MODE>(p, a, b, out, n);
     case AGPU_OP_XOR: return launch_ew<T, OpXor, MODE>(p, a, b, out, n);
-    case AGPU_OP_SHL: return launch_shift<T, MODE>(p, true, a, b, out, n);
-    case AGPU_OP_SHR: return launch_shift<T, MODE>(p, false, a, b, out, n);
+    case AGPU_OP_SHL:
+      if constexpr (W32) return launch_ew<T, OpShl, MODE>(p, a, b, out, n);
+      else return launch_shift<T, MODE>(p, true, a, b, out, n);
+    case AGPU_OP_SHR:
+      if constexpr (W32) return launch_ew<T, OpShr, MODE>(p, a, b, out, n);
+      else return launch_shift<T, MODE>(p, false, a, b, out, n);
     case AGPU_OP_DIV:
       if constexpr (W32) return launch_ew<T, OpDiv, MODE>(p, a, b, out, n);
       break;
@@ -902,13 +942,22 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
   return AGPU_OK;
 }
 
-// bool bitmap → f32 [cast/compute_shaders/boolean/cast_f32.wgsl:9-20]: lane expands 4 bits into one 16-byte store
-__global__ __launch_bounds__(AGPU_BLOCK) void bool_to_f32_kernel(const uint32_t* bits, float* out, uint64_t n) {
+// bool bitmap → f32 [cast/compute_shaders/boolean/cast_f32.wgsl:9-20]: lane expands 4 bits into one nontemporal
+// 16-byte store, 4 stores per lane per one-wave block (a pure store stream: with one store per block the launch is
+// bound by block dispatch, ≈4.7 G blocks/s, not by HBM)
+#define AGPU_B2F_U 4
+__global__ __launch_bounds__(AGPU_EW_BLOCK) void bool_to_f32_kernel(const uint32_t* bits, float* out, uint64_t n) {
   const uint64_t npacks = n / 4;
-  for (uint64_t pk = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; pk < npacks; pk += (uint64_t)gridDim.x * AGPU_BLOCK) {
-    const uint32_t w = bits[pk >> 3] >> ((pk & 7) * 4);
-    f32x4 r = {(w & 1) ? 1.0f : 0.0f, (w & 2) ? 1.0f : 0.0f, (w & 4) ? 1.0f : 0.0f, (w & 8) ? 1.0f : 0.0f};
-    *reinterpret_cast<f32x4*>(out + pk * 4) = r;
+  constexpr uint64_t TILE = (uint64_t)AGPU_EW_BLOCK * AGPU_B2F_U;
+  for (uint64_t t = blockIdx.x; t * TILE < npacks; t += gridDim.x) {
+    static_for<AGPU_B2F_U>([&](auto u) {
+      const uint64_t pk = t * TILE + (uint64_t)u * AGPU_EW_BLOCK + threadIdx.x;
+      if (pk < npacks) {
+        const uint32_t w = bits[pk >> 3] >> ((pk & 7) * 4);
+        f32x4 r = {(w & 1) ? 1.0f : 0.0f, (w & 2) ? 1.0f : 0.0f, (w & 4) ? 1.0f : 0.0f, (w & 8) ? 1.0f : 0.0f};
+        __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(out + pk * 4));
+      }
+    });
   }
   if (blockIdx.x == 0) {
     const uint64_t i = npacks * 4 + threadIdx.x;
@@ -1266,8 +1315,8 @@ agpu_status agpu_cast(agpu_pipeline* p, agpu_dtype from, agpu_dtype to, const vo
   if (from == AGPU_BOOL && to == AGPU_F32) {
     if (n == 0) return AGPU_OK;
     AGPU_REQUIRE(aligned_to(in, 4) && aligned16(out), AGPU_ERR_SHAPE, "bool→f32 needs 4-byte aligned bits and 16-byte aligned output");
-    const int grid = stream_grid_for(p, (n / 4 + AGPU_BLOCK - 1) / AGPU_BLOCK);
-    hipLaunchKernelGGL(bool_to_f32_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
+    const int grid = stream_grid_for(p, (n / 4 + AGPU_EW_BLOCK * AGPU_B2F_U - 1) / (AGPU_EW_BLOCK * AGPU_B2F_U));
+    hipLaunchKernelGGL(bool_to_f32_kernel, dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream,
                        static_cast<const uint32_t*>(in), static_cast<float*>(out), n);
     AGPU_LAUNCH_CHECK();
     return AGPU_OK;

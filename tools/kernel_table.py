@@ -62,6 +62,10 @@ def main():
         t(f"f32 {name} (array∘array)", 12, lambda op=op: capi.call("agpu_binary", h, op, F32, vp(A), vp(B), vp(O), n))
     t("i32 add (wrapping)", 12, lambda: capi.call("agpu_binary", h, capi.OP_ADD, I32, vp(A), vp(B), vp(O), n))
     t("u32 and", 12, lambda: capi.call("agpu_binary", h, capi.OP_AND, capi.U32, vp(A), vp(B), vp(O), n))
+    t("i32 shl (array of u32 amounts)", 12, lambda: capi.call("agpu_binary", h, capi.OP_SHL, I32, vp(A), vp(B), vp(O), n))
+    t("u16 shr (array of u32 amounts)", 8, lambda: capi.call("agpu_binary", h, capi.OP_SHR, capi.U16, vp(A), vp(B), vp(O), n))
+    t("u8 add (array∘array)", 3, lambda: capi.call("agpu_binary", h, capi.OP_ADD, U8, vp(A), vp(B), vp(O), n))
+    t("bool → f32 cast", 4.125, lambda: capi.call("agpu_cast", h, capi.BOOL, F32, vp(VA), vp(O), n))
     t("f32 add_scalar", 8, lambda: capi.call("agpu_scalar", h, capi.OP_ADD, F32, vp(A), vp(S), vp(O), n))
     t("i32 mul_scalar", 8, lambda: capi.call("agpu_scalar", h, capi.OP_MUL, I32, vp(A), vp(SI), vp(O), n))
     t("f32 rem_scalar", 8, lambda: capi.call("agpu_scalar", h, capi.OP_REM, F32, vp(A), vp(S), vp(O), n))
