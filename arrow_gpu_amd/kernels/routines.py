@@ -81,16 +81,37 @@ def _take_op(self: PrimitiveArrayGpu, indexes: UInt32ArrayGPU, pipeline: ArrowCo
     return type(self)(out, dev, indexes.len, nulls)
 
 
+def _all_valid(dev, n: int, pipeline: ArrowComputePipeline) -> NullBitBufferGpu:
+    out = dev.create_empty_buffer(max(bitmap_bytes(n), 8))
+    capi.call("agpu_broadcast", pipeline._handle, capi.BOOL, 1, vp(out), n)
+    pipeline.keep(out)
+    return NullBitBufferGpu(out, n, dev)
+
+
+def _put_validity(src, src_indexes, dst, dst_indexes, pipeline: ArrowComputePipeline) -> None:
+    """Null-aware put (`todo!()` in the reference, routines/src/lib.rs:164-169): the validity bit travels
+    with the value, dst.validity[dst_idx[i]] = src.validity[src_idx[i]].  An absent bitmap counts as all-valid; `dst`
+    gains a validity bitmap when `src` has one.  Duplicate destination indices: unspecified winner, like the values."""
+    if src.null_buffer is None and dst.null_buffer is None:
+        return
+    dev = dst.gpu_device
+    sv = src.null_buffer if src.null_buffer is not None else _all_valid(dev, src.len, pipeline)
+    if dst.null_buffer is None:
+        dst.null_buffer = _all_valid(dev, dst.len, pipeline)
+    capi.call("agpu_put_bits", pipeline._handle, vp(sv.bit_buffer), vp(src_indexes.data), vp(dst.null_buffer.bit_buffer),
+              vp(dst_indexes.data), src_indexes.len)
+    pipeline.keep(sv.bit_buffer, dst.null_buffer.bit_buffer, src_indexes.data, dst_indexes.data)
+
+
 def _put_op(self: PrimitiveArrayGpu, src_indexes: UInt32ArrayGPU, dst, dst_indexes: UInt32ArrayGPU,
             pipeline: ArrowComputePipeline) -> None:
-    if self.null_buffer is not None or dst.null_buffer is not None:
-        raise OperationNotSupported("put with null buffers is todo!() in the reference (routines/src/lib.rs:164-169)")
     check_same_len(src_indexes, dst_indexes, "put indexes")
     _check_indices(src_indexes, self.len, pipeline, "put src")
     _check_indices(dst_indexes, dst.len, pipeline, "put dst")
     capi.call("agpu_put", pipeline._handle, self.ITEM_SIZE, vp(self.data), vp(src_indexes.data), vp(dst.data),
               vp(dst_indexes.data), src_indexes.len)
     pipeline.keep(self.data, src_indexes.data, dst.data, dst_indexes.data)
+    _put_validity(self, src_indexes, dst, dst_indexes, pipeline)
 
 
 def _put(self, src_indexes, dst, dst_indexes) -> None:
@@ -128,14 +149,13 @@ def _bool_take_op(self: BooleanArrayGPU, indexes: UInt32ArrayGPU, pipeline: Arro
 
 
 def _bool_put_op(self: BooleanArrayGPU, src_indexes, dst: BooleanArrayGPU, dst_indexes, pipeline: ArrowComputePipeline):
-    if self.null_buffer is not None or dst.null_buffer is not None:
-        raise OperationNotSupported("put with null buffers is todo!() in the reference (routines/src/bool.rs)")
     check_same_len(src_indexes, dst_indexes, "put indexes")
     _check_indices(src_indexes, self.len, pipeline, "put src")
     _check_indices(dst_indexes, dst.len, pipeline, "put dst")
     capi.call("agpu_put_bits", pipeline._handle, vp(self.data), vp(src_indexes.data), vp(dst.data), vp(dst_indexes.data),
               src_indexes.len)
     pipeline.keep(self.data, src_indexes.data, dst.data, dst_indexes.data)
+    _put_validity(self, src_indexes, dst, dst_indexes, pipeline)
 
 
 impl((BooleanArrayGPU,), "merge", _bool_merge_op)

@@ -329,8 +329,13 @@ def _take(self, indexes):
 
 
 def _put(self, src_indexes, dst, dst_indexes):
+    # null buffers are `todo!()` in the reference (routines/src/lib.rs:164-169); the build's extension:
+    # the validity bit travels with the value, an absent bitmap counts as all-valid
     if self.validity is not None or dst.validity is not None:
-        raise OracleUnsupported("put with null buffers is todo!() in the reference")
+        ones = lambda n: np.full((n + 7) // 8, 0xFF, np.uint8)  # noqa: E731
+        sv = self.validity if self.validity is not None else ones(self.len)
+        dv = dst.validity if dst.validity is not None else ones(dst.len)
+        dst.validity = O.put_bits(sv, src_indexes.data, dv, dst_indexes.data)
     if isinstance(self, BooleanArrayGPU):
         dst.data = O.put_bits(self.data, src_indexes.data, dst.data, dst_indexes.data)
     else:
