@@ -43,6 +43,8 @@ SIGNATURES = {
     "agpu_device_name": [_vp, C.c_char_p, _sz],
     "agpu_device_ordinal": [_vp, C.POINTER(_i32)],
     "agpu_device_mem_info": [_vp, C.POINTER(_u64), C.POINTER(_u64)],
+    "agpu_device_trim": [_vp],
+    "agpu_device_pool_info": [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)],
     "agpu_malloc": [_vp, _sz, _i32, _pp],
     "agpu_free": [_vp, _vp],
     "agpu_upload": [_vp, _vp, _vp, _sz],

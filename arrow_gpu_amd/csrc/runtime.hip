@@ -14,7 +14,8 @@ void agpu_set_error(const char* fmt, ...) {
 }
 
 agpu_tuning g_tune = {
-    /*stream_grid*/ 0, /*stream_bpc*/ 0, /*stream_unroll*/ 1, /*stream_nt*/ 1, /*cmp_variant*/ 0, /*reduce_grid*/ 0};
+    /*stream_grid*/ 0, /*stream_bpc*/ 0, /*stream_unroll*/ 1, /*stream_nt*/ 1, /*cmp_variant*/ 0, /*reduce_grid*/ 0,
+    /*mem_pool*/ 1};
 
 extern "C" {
 
@@ -79,15 +80,57 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
     delete d;
     return ts;
   }
+  d->cache_cap = d->props.totalGlobalMem / 2;  // cached (idle) blocks never hold more than half of HBM
   *out_device = d;
   return AGPU_OK;
 }
 
-agpu_status agpu_device_destroy(agpu_device* dev) {
-  if (dev && dev->trig16_table) {
-    (void)hipSetDevice(dev->ordinal);
-    (void)hipFree(dev->trig16_table);
+// release every cached block and the scratch of idle streams; blocks until the device is idle
+static void device_trim_locked(agpu_device* dev) {
+  (void)hipDeviceSynchronize();
+  for (auto& kv : dev->cache) {
+    for (hipEvent_t e : kv.second.pending) dev->event_pool.push_back(e);
+    (void)hipFree(kv.second.ptr);
   }
+  dev->cache.clear();
+  dev->cached_bytes = 0;
+  for (auto& s : dev->idle_streams) {
+    if (s.scratch) (void)hipFree(s.scratch);
+    s.scratch = nullptr;
+    s.scratch_bytes = 0;
+  }
+}
+
+agpu_status agpu_device_trim(agpu_device* dev) {
+  AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  std::lock_guard<std::mutex> lock(dev->mu);
+  device_trim_locked(dev);
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_pool_info(agpu_device* dev, uint64_t* out_cached_bytes, uint64_t* out_cached_blocks,
+                                  uint64_t* out_idle_streams) {
+  AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
+  std::lock_guard<std::mutex> lock(dev->mu);
+  if (out_cached_bytes) *out_cached_bytes = dev->cached_bytes;
+  if (out_cached_blocks) *out_cached_blocks = dev->cache.size();
+  if (out_idle_streams) *out_idle_streams = dev->idle_streams.size();
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_destroy(agpu_device* dev) {
+  if (!dev) return AGPU_OK;
+  (void)hipSetDevice(dev->ordinal);
+  {
+    std::lock_guard<std::mutex> lock(dev->mu);
+    device_trim_locked(dev);
+    for (auto& s : dev->idle_streams) (void)hipStreamDestroy(s.stream);
+    dev->idle_streams.clear();
+    for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
+    dev->event_pool.clear();
+  }
+  if (dev->trig16_table) (void)hipFree(dev->trig16_table);
   delete dev;
   return AGPU_OK;
 }
@@ -122,21 +165,74 @@ agpu_status agpu_device_mem_info(agpu_device* dev, uint64_t* out_free, uint64_t*
 }
 
 // ---------------------------------------------------------------- buffers
+// Blocks ≥ 1 MiB are rounded up to 2 MiB multiples and recycled through dev->cache.  A freed block may still be read or
+// written by work queued on some stream (the host layers drop their references when a pipeline is released, not when
+// the GPU is done; hipFree used to cover that with its implicit device sync), so agpu_free records one event per stream
+// and agpu_malloc waits for them before handing the block out again — normally they completed long ago.
+#define AGPU_POOL_MIN_BYTES ((size_t)1 << 20)
+#define AGPU_POOL_GRANULE ((size_t)2 << 20)
+
 agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void** out_ptr) {
   AGPU_REQUIRE(dev && out_ptr, AGPU_ERR_ARG, "null argument");
   AGPU_HIP(hipSetDevice(dev->ordinal));
   // pad to 16 B so vector tails of sub-word columns and bitmap words are always addressable
   size_t padded = (bytes + 15) & ~(size_t)15;
   if (padded == 0) padded = 16;
+  const bool pooled = g_tune.mem_pool != 0 && padded >= AGPU_POOL_MIN_BYTES;
+  if (pooled) padded = (padded + AGPU_POOL_GRANULE - 1) / AGPU_POOL_GRANULE * AGPU_POOL_GRANULE;
   void* p = nullptr;
-  AGPU_HIP(hipMalloc(&p, padded));
+  if (pooled) {
+    std::vector<hipEvent_t> pending;
+    {
+      std::lock_guard<std::mutex> lock(dev->mu);
+      auto it = dev->cache.lower_bound(padded);
+      if (it != dev->cache.end() && it->first <= padded + padded / 8) {  // accept up to 12.5 % slack
+        p = it->second.ptr;
+        pending = std::move(it->second.pending);
+        dev->cached_bytes -= it->first;
+        dev->block_size[p] = it->first;
+        dev->cache.erase(it);
+      }
+    }
+    if (p) {
+      hipError_t e = hipSuccess;
+      for (hipEvent_t ev : pending)
+        if (e == hipSuccess) e = hipEventSynchronize(ev);
+      {
+        std::lock_guard<std::mutex> lock(dev->mu);
+        for (hipEvent_t ev : pending) dev->event_pool.push_back(ev);
+      }
+      if (e != hipSuccess) {
+        agpu_set_error("hipEventSynchronize failed: %s", hipGetErrorString(e));
+        return AGPU_ERR_HIP;
+      }
+    }
+  }
+  if (!p) {
+    hipError_t e = hipMalloc(&p, padded);
+    if (e == hipErrorOutOfMemory) {  // give the cached blocks back and retry once
+      (void)hipGetLastError();
+      std::lock_guard<std::mutex> lock(dev->mu);
+      device_trim_locked(dev);
+      e = hipMalloc(&p, padded);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      agpu_set_error("hipMalloc(%zu) failed: %s", padded, hipGetErrorString(e));
+      return AGPU_ERR_HIP;
+    }
+    if (pooled) {
+      std::lock_guard<std::mutex> lock(dev->mu);
+      dev->block_size[p] = padded;
+    }
+  }
   if (zero_fill) {
     // hipMemset on device memory runs asynchronously on the NULL stream, and pipelines are non-blocking streams that
     // do not order against it: wait, or a later upload could be overwritten by the zero fill
     hipError_t e = hipMemset(p, 0, padded);
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {
-      (void)hipFree(p);
+      (void)agpu_free(dev, p);
       agpu_set_error("hipMemset failed: %s", hipGetErrorString(e));
       return AGPU_ERR_HIP;
     }
@@ -149,6 +245,47 @@ agpu_status agpu_free(agpu_device* dev, void* ptr) {
   AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
   if (!ptr) return AGPU_OK;
   AGPU_HIP(hipSetDevice(dev->ordinal));
+  {
+    std::unique_lock<std::mutex> lock(dev->mu);
+    auto it = dev->block_size.find(ptr);
+    if (it != dev->block_size.end()) {
+      const size_t size = it->second;
+      dev->block_size.erase(it);
+      if (g_tune.mem_pool != 0 && dev->cached_bytes + size <= dev->cache_cap) {
+        agpu_device::CachedBlock blk{ptr, {}};
+        bool ok = true;
+        for (hipStream_t s : dev->all_streams) {
+          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();  // an event recorded now would become a graph node: do not pool this block
+            ok = false;
+            break;
+          }
+          hipEvent_t ev = nullptr;
+          if (!dev->event_pool.empty()) {
+            ev = dev->event_pool.back();
+            dev->event_pool.pop_back();
+          } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            ok = false;
+            break;
+          }
+          if (hipEventRecord(ev, s) != hipSuccess) {  // e.g. the stream is being captured into a graph
+            (void)hipGetLastError();
+            dev->event_pool.push_back(ev);
+            ok = false;
+            break;
+          }
+          blk.pending.push_back(ev);
+        }
+        if (ok) {
+          dev->cached_bytes += size;
+          dev->cache.emplace(size, std::move(blk));
+          return AGPU_OK;
+        }
+        for (hipEvent_t ev : blk.pending) dev->event_pool.push_back(ev);
+      }
+    }
+  }
   AGPU_HIP(hipFree(ptr));
   return AGPU_OK;
 }
@@ -240,13 +377,33 @@ static agpu_status pipeline_new(agpu_device* dev, hipStream_t s, bool owns, agpu
 agpu_status agpu_pipeline_create(agpu_device* dev, agpu_pipeline** out_pipeline) {
   AGPU_REQUIRE(dev && out_pipeline, AGPU_ERR_ARG, "null argument");
   AGPU_HIP(hipSetDevice(dev->ordinal));
-  hipStream_t s;
-  AGPU_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  return pipeline_new(dev, s, true, out_pipeline);
+  agpu_device::StreamSlot slot{nullptr, nullptr, 0};
+  {
+    std::lock_guard<std::mutex> lock(dev->mu);
+    if (!dev->idle_streams.empty()) {  // work still queued on a recycled stream simply runs first: same ordering
+      slot = dev->idle_streams.back();
+      dev->idle_streams.pop_back();
+    }
+  }
+  if (!slot.stream) {
+    AGPU_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
+    std::lock_guard<std::mutex> lock(dev->mu);
+    dev->all_streams.push_back(slot.stream);
+  }
+  agpu_status st = pipeline_new(dev, slot.stream, true, out_pipeline);
+  if (st == AGPU_OK) {
+    (*out_pipeline)->scratch = slot.scratch;
+    (*out_pipeline)->scratch_bytes = slot.scratch_bytes;
+  }
+  return st;
 }
 
 agpu_status agpu_pipeline_wrap_stream(agpu_device* dev, void* hip_stream, agpu_pipeline** out_pipeline) {
   AGPU_REQUIRE(dev && out_pipeline, AGPU_ERR_ARG, "null argument");
+  {
+    std::lock_guard<std::mutex> lock(dev->mu);
+    dev->all_streams.push_back(reinterpret_cast<hipStream_t>(hip_stream));
+  }
   return pipeline_new(dev, reinterpret_cast<hipStream_t>(hip_stream), false, out_pipeline);
 }
 
@@ -263,10 +420,26 @@ agpu_status agpu_pipeline_sync(agpu_pipeline* p) {
 
 agpu_status agpu_pipeline_destroy(agpu_pipeline* p) {
   if (!p) return AGPU_OK;
-  (void)hipSetDevice(p->dev->ordinal);
+  agpu_device* dev = p->dev;
+  (void)hipSetDevice(dev->ordinal);
+  if (p->owns_stream && g_tune.mem_pool != 0 && !p->capturing) {
+    // back to the pool WITHOUT waiting: queued work keeps running, the next owner's launches are ordered behind it
+    std::lock_guard<std::mutex> lock(dev->mu);
+    dev->idle_streams.push_back(agpu_device::StreamSlot{p->stream, p->scratch, p->scratch_bytes});
+    delete p;
+    return AGPU_OK;
+  }
   if (p->scratch) {
     (void)hipStreamSynchronize(p->stream);
     (void)hipFree(p->scratch);
+  }
+  {
+    std::lock_guard<std::mutex> lock(dev->mu);
+    for (size_t i = 0; i < dev->all_streams.size(); i++)
+      if (dev->all_streams[i] == p->stream) {
+        dev->all_streams.erase(dev->all_streams.begin() + (long)i);
+        break;
+      }
   }
   if (p->owns_stream) (void)hipStreamDestroy(p->stream);
   delete p;
@@ -377,6 +550,7 @@ static int64_t* tune_slot(const char* key) {
   if (!strcmp(key, "stream_nt")) return &g_tune.stream_nt;
   if (!strcmp(key, "cmp_variant")) return &g_tune.cmp_variant;
   if (!strcmp(key, "reduce_grid")) return &g_tune.reduce_grid;
+  if (!strcmp(key, "mem_pool")) return &g_tune.mem_pool;
   return nullptr;
 }
 

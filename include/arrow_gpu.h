@@ -130,12 +130,21 @@ agpu_status agpu_device_sync(agpu_device* dev);
 agpu_status agpu_device_name(agpu_device* dev, char* out, size_t out_cap); /* e.g. "gfx950:sramecc+:xnack-" */
 agpu_status agpu_device_ordinal(agpu_device* dev, int32_t* out_ordinal);
 agpu_status agpu_device_mem_info(agpu_device* dev, uint64_t* out_free, uint64_t* out_total);
+/* Resource pools.  The reference allocates an output buffer and (in its default, non-`_op` API) a command encoder per
+ * operation [ref: impl_arithmetic_op! crates/arithmetic/src/lib.rs:11-50 — `ArrowComputePipeline::new` … `finish()`
+ * around every op].  On ROCm a stream costs 4.3 ms to create and 2.6 ms to destroy and hipFree synchronises the device,
+ * so idle streams and freed blocks >= 1 MiB are recycled (tuning key "mem_pool", default 1).  agpu_device_trim returns
+ * the cached blocks to the driver (also done automatically when hipMalloc runs out of memory); cached bytes never
+ * exceed half of the device memory. */
+agpu_status agpu_device_trim(agpu_device* dev);
+agpu_status agpu_device_pool_info(agpu_device* dev, uint64_t* out_cached_bytes, uint64_t* out_cached_blocks,
+                                  uint64_t* out_idle_streams);
 
 /* ---------------------------------------------------------------- buffers (raw HBM pointers)
  * agpu_malloc          [ref: GpuDevice::create_empty_buffer gpu_device.rs:183-192] — zero_fill!=0 reproduces wgpu's
  *                      zero-initialised buffers; kernels here never rely on it.
  * agpu_upload          [ref: create_gpu_buffer_with_data gpu_device.rs:171-181, create_scalar_buffer :203-210]
- * agpu_download        [ref: retrive_data gpu_device.rs:232-265] — blocks until `pipeline` (may be NULL = device sync) drained.
+ * agpu_download        [ref: retrive_data gpu_device.rs:232-265] — blocks until the work queued on `p` (required, non-NULL) has drained.
  * agpu_copy            [ref: clone_buffer(_pass) gpu_device.rs:212-230; ArrowComputePipeline::{clone_buffer,
  *                      copy_buffer_to_buffer} compute_pipeline.rs:275-299] — ordered on the pipeline's stream. */
 agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void** out_ptr);
