@@ -134,9 +134,47 @@ def main():
         pcie[label] = {"ms": round(ms, 3), "GBps": round(gib / ms / 1e6, 1)}
         print(label, pcie[label], flush=True)
 
+    # config 1 (1 048 576-row i32 columns, 12 MiB of traffic per op): launch-bound regime.  200 eager launches back to
+    # back, and the same 200 ops replayed from one hipGraph (agpu_pipeline_begin_capture / agpu_graph_launch).
+    small = 1 << 20
+    reps = 200
+
+    def burst():
+        for _ in range(reps):
+            capi.call("agpu_binary", h, capi.OP_ADD, I32, vp(A), vp(B), vp(O), small)
+
+    def timed(f, k=9):
+        f()
+        p.sync()
+        ts = []
+        for _ in range(k):
+            q.begin(p)
+            f()
+            q.end(p)
+            ts.append(q.wait_for_results())
+        return float(np.median(ts))
+
+    import time as _time
+
+    eager_ms = timed(burst)
+    t0 = _time.perf_counter()
+    burst()
+    host_ms = (_time.perf_counter() - t0) * 1e3  # host-side cost of issuing the launches through ctypes
+    p.sync()
+    capi.call("agpu_pipeline_begin_capture", h)
+    burst()
+    g = C.c_void_p()
+    capi.call("agpu_pipeline_end_capture", h, C.byref(g))
+    graph_ms = timed(lambda: capi.call("agpu_graph_launch", g, h))
+    capi.call("agpu_graph_destroy", g)
+    small_n = {"rows": small, "ops": reps, "eager_us_per_op_gpu": round(eager_ms / reps * 1e3, 3),
+               "eager_us_per_op_host_ctypes": round(host_ms / reps * 1e3, 3), "graph_us_per_op_gpu": round(graph_ms / reps * 1e3, 3),
+               "hbm_floor_us_per_op": round(12 * small / 8e12 * 1e6, 3)}
+    print("config-1 size (launch-bound):", small_n, flush=True)
+
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/kernel_table_{args.tag}.json", "w") as f:
-        json.dump({"rows": n, "device": dev.name, "kernels": rows, "host_link": pcie}, f, indent=1)
+        json.dump({"rows": n, "device": dev.name, "kernels": rows, "host_link": pcie, "small_n": small_n}, f, indent=1)
     print("\n| kernel | alg. B/row | ms @1e9 | GB/s | frac of 8 TB/s |\n|---|---|---|---|---|")
     for r in rows:
         print(f"| {r['kernel']} | {r['alg_B_per_row']:.4g} | {r['ms']} | {r['GBps']} | {r['frac_8TBs']} |")
