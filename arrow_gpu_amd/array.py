@@ -129,7 +129,7 @@ class NullBitBufferGpu:
     def clone_null_bit_buffer_op(data, pipeline: ArrowComputePipeline):
         if data is None:
             return None
-        return NullBitBufferGpu(pipeline.clone_buffer(data.bit_buffer), data.len, data.gpu_device)
+        return NullBitBufferGpu(pipeline.clone_buffer(data.bit_buffer, bitmap=True), data.len, data.gpu_device)
 
     clone_null_bit_buffer_pass = clone_null_bit_buffer_op
 
@@ -141,11 +141,11 @@ class NullBitBufferGpu:
             return None
         if left is None or right is None:
             x = left if left is not None else right
-            return NullBitBufferGpu(pipeline.clone_buffer(x.bit_buffer), x.len, x.gpu_device)
+            return NullBitBufferGpu(pipeline.clone_buffer(x.bit_buffer, bitmap=True), x.len, x.gpu_device)
         assert left.len == right.len, "validity bitmaps of different length"
         assert left.gpu_device is right.gpu_device
         out = left.gpu_device.create_empty_buffer(left.bit_buffer.nbytes)
-        capi.call("agpu_bitmap_binary", pipeline._handle, capi.OP_AND, C.c_void_p(left.bit_buffer.ptr),
+        capi.call("agpu_bitmap_binary", pipeline._bitmap_handle, capi.OP_AND, C.c_void_p(left.bit_buffer.ptr),
                   C.c_void_p(right.bit_buffer.ptr), C.c_void_p(out.ptr), left.len)
         pipeline.keep(left.bit_buffer, right.bit_buffer, out)
         return NullBitBufferGpu(out, left.len, left.gpu_device)

@@ -9,6 +9,8 @@ contract as `queue.submit`, compute_pipeline.rs:259-273); `retrive_data` is the 
 from __future__ import annotations
 
 import ctypes as C
+import os
+import sys
 import threading
 
 import numpy as np
@@ -106,10 +108,35 @@ class GpuDevice:
         return f"GpuDevice(ordinal={self.ordinal}, name={self.name!r})"
 
 
-class ArrowComputePipeline:
-    """Ordered command stream.  [ref: ArrowComputePipeline compute_pipeline.rs:8-22]"""
+class _LazyNode:
+    """One recorded element-wise op of a fusing pipeline (see ArrowComputePipeline.record_elementwise)."""
 
-    def __init__(self, device: GpuDevice, label: str | None = None, hip_stream: int | None = None):
+    __slots__ = ("kind", "op", "dtype", "a", "operand", "out", "n", "out_ref")
+
+    def __init__(self, kind, op, dtype, a, operand, out, n, out_ref):
+        self.kind, self.op, self.dtype, self.a, self.operand, self.out, self.n, self.out_ref = kind, op, dtype, a, operand, out, n, out_ref
+
+
+class _ChainStep(C.Structure):
+    _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+
+_FUSE_DEFAULT = os.environ.get("AGPU_FUSE", "0") not in ("", "0")
+_CHAIN_MAX = 8
+_UNARY, _SCALAR, _ARRAY = 0, 1, 2
+
+
+class ArrowComputePipeline:
+    """Ordered command stream.  [ref: ArrowComputePipeline compute_pipeline.rs:8-22]
+
+    `fuse=True` makes the pipeline behave like the reference's command encoder for same-width
+    element-wise ops on f32 / i32 / u32 / Date32 columns: `*_op` calls are only RECORDED and run at `finish()` (or as
+    soon as anything else needs the stream), and a run of ops where each consumes the previous result — whose array
+    object the caller has already dropped, e.g. `a.add_scalar_op(s, p).mul_scalar_op(s, p)` — is issued as ONE
+    `agpu_fused_chain` kernel that never materialises the intermediates.  Intermediates the caller still holds, or that a
+    later op reads again, are computed as usual.  As in the reference, results are defined only after `finish()`."""
+
+    def __init__(self, device: GpuDevice, label: str | None = None, hip_stream: int | None = None, fuse: bool | None = None):
         self.device = device
         self.label = label
         h = C.c_void_p()
@@ -117,8 +144,81 @@ class ArrowComputePipeline:
             capi.call("agpu_pipeline_create", device._handle, C.byref(h))
         else:
             capi.call("agpu_pipeline_wrap_stream", device._handle, C.c_void_p(hip_stream), C.byref(h))
-        self._handle = h
+        self._h = h
         self._keepalive = []  # buffers referenced by in-flight work (the reference's encoder holds Arc<Buffer>s)
+        self.fuse = _FUSE_DEFAULT if fuse is None else bool(fuse)
+        self._pending = []    # _LazyNode list (fuse=True only)
+        self.stats = {"recorded": 0, "kernels": 0, "fused_chains": 0, "fused_ops": 0}
+
+    # Every launch, copy, sync or timing call reaches the stream through `_handle`: reading it first issues whatever
+    # is still only recorded, so eager and recorded work stay in program order.
+    @property
+    def _handle(self):
+        if self._pending:
+            self._flush_pending()
+        return self._h
+
+    @_handle.setter
+    def _handle(self, value):
+        self._h = value
+
+    @property
+    def _bitmap_handle(self):
+        """Raw handle for validity-bitmap work, which never touches the value buffers of recorded ops: no flush."""
+        return self._h
+
+    # ---- recording / fusion
+    def record_elementwise(self, kind: int, op: int, dtype: int, a: DeviceBuffer, operand, out: DeviceBuffer, n: int) -> _LazyNode:
+        node = _LazyNode(kind, op, dtype, a, operand, out, n, None)
+        self._pending.append(node)
+        self.stats["recorded"] += 1
+        return node
+
+    def _launch_single(self, nd: _LazyNode) -> None:
+        vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
+        if nd.kind == _UNARY:
+            capi.call("agpu_unary", self._h, nd.op, nd.dtype, vp(nd.a), vp(nd.out), nd.n)
+        elif nd.kind == _SCALAR:
+            capi.call("agpu_scalar", self._h, nd.op, nd.dtype, vp(nd.a), vp(nd.operand), vp(nd.out), nd.n)
+        else:
+            capi.call("agpu_binary", self._h, nd.op, nd.dtype, vp(nd.a), vp(nd.operand), vp(nd.out), nd.n)
+        self.stats["kernels"] += 1
+
+    def _flush_pending(self) -> None:
+        nodes, self._pending = self._pending, []
+
+        def read_later(buf, start):
+            return any(m.a is buf or m.operand is buf for m in nodes[start:])
+
+        i = 0
+        while i < len(nodes):
+            chain = [nodes[i]]
+            while len(chain) < _CHAIN_MAX and i + len(chain) < len(nodes):
+                last, nxt = chain[-1], nodes[i + len(chain)]
+                # dead intermediate: the caller dropped the array object AND nothing else holds its buffer — exactly
+                # three references remain (last.out, nxt.a, getrefcount's argument).  A bitcast view sharing the
+                # buffer, a later node reading it or a keep-alive entry all add one and keep it materialised.
+                dead = (last.out_ref is not None and last.out_ref() is None and sys.getrefcount(last.out) == 3)
+                if (nxt.a is last.out and nxt.operand is not last.out and nxt.n == last.n and nxt.dtype == last.dtype
+                        and dead and not read_later(last.out, i + len(chain) + 1)):
+                    chain.append(nxt)
+                else:
+                    break
+            if len(chain) == 1:
+                self._launch_single(chain[0])
+            else:
+                steps = (_ChainStep * len(chain))()
+                for k, nd in enumerate(chain):
+                    steps[k].op, steps[k].kind = nd.op, nd.kind
+                    steps[k].operand = nd.operand.ptr if nd.operand is not None else None
+                capi.call("agpu_fused_chain", self._h, chain[0].dtype, C.c_void_p(chain[0].a.ptr), C.cast(steps, C.c_void_p),
+                          len(chain), C.c_void_p(chain[-1].out.ptr), chain[0].n)
+                self.stats["kernels"] += 1
+                self.stats["fused_chains"] += 1
+                self.stats["fused_ops"] += len(chain)
+            for nd in chain:
+                self.keep(nd.a, nd.operand, nd.out)
+            i += len(chain)
 
     def finish(self) -> None:
         """Submit; does NOT wait.  [ref: compute_pipeline.rs:259-273]"""
@@ -131,15 +231,17 @@ class ArrowComputePipeline:
     def keep(self, *bufs) -> None:
         self._keepalive.extend(b for b in bufs if b is not None)
 
-    def clone_buffer(self, buf: DeviceBuffer) -> DeviceBuffer:
+    def clone_buffer(self, buf: DeviceBuffer, bitmap: bool = False) -> DeviceBuffer:
         """[ref: ArrowComputePipeline::clone_buffer compute_pipeline.rs:275-282]"""
         out = self.device.create_empty_buffer(buf.nbytes)
-        self.copy_buffer_to_buffer(buf, 0, out, 0, buf.nbytes)
+        self.copy_buffer_to_buffer(buf, 0, out, 0, buf.nbytes, bitmap=bitmap)
         return out
 
-    def copy_buffer_to_buffer(self, src: DeviceBuffer, src_off: int, dst: DeviceBuffer, dst_off: int, size: int) -> None:
+    def copy_buffer_to_buffer(self, src: DeviceBuffer, src_off: int, dst: DeviceBuffer, dst_off: int, size: int,
+                              bitmap: bool = False) -> None:
         """[ref: copy_buffer_to_buffer compute_pipeline.rs:284-299]"""
-        capi.call("agpu_copy", self._handle, C.c_void_p(dst.ptr + dst_off), C.c_void_p(src.ptr + src_off), size)
+        h = self._bitmap_handle if bitmap else self._handle
+        capi.call("agpu_copy", h, C.c_void_p(dst.ptr + dst_off), C.c_void_p(src.ptr + src_off), size)
         self.keep(src, dst)
 
     def stream(self) -> int:
@@ -148,13 +250,13 @@ class ArrowComputePipeline:
         return s.value or 0
 
     def __del__(self):
-        h = getattr(self, "_handle", None)
+        h = getattr(self, "_h", None)
         if h:
             try:
                 capi.lib().agpu_pipeline_destroy(h)
             except Exception:
                 pass
-            self._handle = None
+            self._h = None
 
 
 class CmpQuery:

@@ -9,6 +9,7 @@ returns a new array object without waiting.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 from .. import _capi as capi
 from .._capi import OperationNotSupported
@@ -45,6 +46,33 @@ def check_same_len(a, b, what: str) -> None:
         raise capi.ArrowErrorGPU("ShapeError", f"{what}: arrays of different length {a.len} vs {b.len}", capi.ERR_SHAPE)
 
 
+_FUSABLE_DTYPES = (capi.F32, capi.I32, capi.U32, capi.DATE32)
+_FUSABLE_BINARY_F32 = (capi.OP_ADD, capi.OP_SUB, capi.OP_MUL, capi.OP_DIV, capi.OP_REM, capi.OP_MIN, capi.OP_MAX)
+_FUSABLE_BINARY_INT = _FUSABLE_BINARY_F32 + (capi.OP_AND, capi.OP_OR, capi.OP_XOR)
+_FUSABLE_UNARY_F32 = (capi.UN_NEG, capi.UN_ABS, capi.UN_SQRT, capi.UN_CBRT, capi.UN_EXP, capi.UN_EXP2, capi.UN_LOG, capi.UN_LOG2,
+                      capi.UN_SIN, capi.UN_COS)
+_FUSABLE_UNARY_INT = (capi.UN_NEG, capi.UN_ABS, capi.UN_NOT)
+_KIND_UNARY, _KIND_SCALAR, _KIND_ARRAY = 0, 1, 2
+
+
+def _recordable(pipeline, kind: int, op: int, dtype: int, same_class: bool) -> bool:
+    """Can this op wait in a fusing pipeline (ArrowComputePipeline(fuse=True)) instead of launching now?"""
+    if not getattr(pipeline, "fuse", False) or not same_class or dtype not in _FUSABLE_DTYPES:
+        return False
+    is_f = dtype == capi.F32
+    if kind == _KIND_UNARY:
+        return op in (_FUSABLE_UNARY_F32 if is_f else _FUSABLE_UNARY_INT)
+    return op in (_FUSABLE_BINARY_F32 if is_f else _FUSABLE_BINARY_INT)
+
+
+def _finish_record(node, result):
+    """Tie a recorded node to the array object handed to the caller: when that object is gone by flush time the
+    intermediate is dead and the chain may skip materialising it."""
+    if node is not None:
+        node.out_ref = weakref.ref(result)
+    return result
+
+
 def binary_values(pipeline, op: int, dtype: int, a, b, out_cls, n: int):
     dev = a.gpu_device
     out = dev.create_empty_buffer(max(n * out_cls.ITEM_SIZE, 1))
@@ -59,9 +87,14 @@ def array_op(op: int, out_cls=None):
     def fn(self, value, pipeline: ArrowComputePipeline):
         check_same_len(self, value, "binary op")
         cls = out_cls or type(self)
-        out = binary_values(pipeline, op, self.DTYPE, self, value, cls, self.len)
+        node = None
+        if _recordable(pipeline, _KIND_ARRAY, op, self.DTYPE, cls is type(self) and value.ITEM_SIZE == self.ITEM_SIZE):
+            out = self.gpu_device.create_empty_buffer(max(self.len * cls.ITEM_SIZE, 1))
+            node = pipeline.record_elementwise(_KIND_ARRAY, op, self.DTYPE, self.data, value.data, out, self.len)
+        else:
+            out = binary_values(pipeline, op, self.DTYPE, self, value, cls, self.len)
         nulls = NullBitBufferGpu.merge_null_bit_buffer_op(self.null_buffer, value.null_buffer, pipeline)
-        return cls(out, self.gpu_device, self.len, nulls)
+        return _finish_record(node, cls(out, self.gpu_device, self.len, nulls))
 
     return fn
 
@@ -72,10 +105,14 @@ def scalar_op(op: int):
     def fn(self, value, pipeline: ArrowComputePipeline):
         dev = self.gpu_device
         out = dev.create_empty_buffer(max(self.len * self.ITEM_SIZE, 1))
-        capi.call("agpu_scalar", pipeline._handle, op, self.DTYPE, vp(self.data), vp(value.data), vp(out), self.len)
-        pipeline.keep(self.data, value.data, out)
+        node = None
+        if _recordable(pipeline, _KIND_SCALAR, op, self.DTYPE, value.ITEM_SIZE == self.ITEM_SIZE):
+            node = pipeline.record_elementwise(_KIND_SCALAR, op, self.DTYPE, self.data, value.data, out, self.len)
+        else:
+            capi.call("agpu_scalar", pipeline._handle, op, self.DTYPE, vp(self.data), vp(value.data), vp(out), self.len)
+            pipeline.keep(self.data, value.data, out)
         nulls = NullBitBufferGpu.clone_null_bit_buffer_op(self.null_buffer, pipeline)
-        return type(self)(out, dev, self.len, nulls)
+        return _finish_record(node, type(self)(out, dev, self.len, nulls))
 
     return fn
 
@@ -87,10 +124,14 @@ def unary_op(op: int, out_cls=None):
         dev = self.gpu_device
         cls = out_cls or type(self)
         out = dev.create_empty_buffer(max(self.len * cls.ITEM_SIZE, 1))
-        capi.call("agpu_unary", pipeline._handle, op, self.DTYPE, vp(self.data), vp(out), self.len)
-        pipeline.keep(self.data, out)
+        node = None
+        if _recordable(pipeline, _KIND_UNARY, op, self.DTYPE, cls is type(self)):
+            node = pipeline.record_elementwise(_KIND_UNARY, op, self.DTYPE, self.data, None, out, self.len)
+        else:
+            capi.call("agpu_unary", pipeline._handle, op, self.DTYPE, vp(self.data), vp(out), self.len)
+            pipeline.keep(self.data, out)
         nulls = NullBitBufferGpu.clone_null_bit_buffer_op(self.null_buffer, pipeline)
-        return cls(out, dev, self.len, nulls)
+        return _finish_record(node, cls(out, dev, self.len, nulls))
 
     return fn
 

@@ -111,3 +111,76 @@ def test_fusion_cuts_time(ag):
     t_fused = time(fused)
     print(f"unfused {t_unfused:.3f} ms, fused {t_fused:.3f} ms ({8 * n / t_fused / 1e9:.2f} TB/s)")
     assert t_fused < 0.7 * t_unfused
+
+
+# ---------------------------------------------------------------- fusing pipelines: ArrowComputePipeline(fuse=True)
+def _rand(ag, dev, n, seed, nulls=False):
+    vals = O.synth_f32(n, seed, 0, -50, 50)
+    if not nulls:
+        return ag.Float32ArrayGPU.from_slice(vals, dev)
+    rng = np.random.default_rng(seed)
+    return ag.Float32ArrayGPU.from_optional_slice([None if rng.random() < 0.2 else float(v) for v in vals], dev)
+
+
+def test_fusing_pipeline_runs_simple_rs_chain_as_one_kernel(ag):
+    """examples/simple.rs:45-72 written in call-chain style: the intermediate dies at once, finish() issues ONE kernel."""
+    dev = ag.GPU_DEVICE()
+    a = ag.Float32ArrayGPU.from_slice([float(i) for i in range(100)], dev)
+    s = ag.Float32ArrayGPU.from_slice([20.0], dev)
+    p = ag.ArrowComputePipeline(dev, "example", fuse=True)
+    r = ag.mul_scalar_op_dyn(ag.add_scalar_op_dyn(a, s, p), s, p)
+    assert p.stats["recorded"] == 2 and p.stats["kernels"] == 0  # nothing has run yet, like a wgpu encoder
+    p.finish()
+    assert p.stats == {"recorded": 2, "kernels": 1, "fused_chains": 1, "fused_ops": 2}
+    assert r.values() == [(float(i) + 20.0) * 20.0 for i in range(100)]
+
+
+@pytest.mark.parametrize("n", [1, 257, 70_001])
+def test_fusing_pipeline_matches_eager_pipeline(ag, n):
+    dev = ag.GPU_DEVICE()
+    a, b, c = _rand(ag, dev, n, 1, nulls=n < 5000), _rand(ag, dev, n, 2, nulls=n < 5000), _rand(ag, dev, n, 3)
+    s = ag.Float32ArrayGPU.from_slice([3.5], dev)
+
+    def program(p):
+        x = a.mul_op(b, p).add_op(c, p).abs_op(p).sqrt_op(p)           # 4 fusable ops, intermediates dropped
+        kept = x.add_scalar_op(s, p)                                    # caller keeps `kept` AND uses it twice below
+        y = kept.neg_op(p).sin_op(p)
+        z = kept.mul_op(kept, p)                                        # operand aliases the input
+        m = y.lt_op(z, p)                                               # not element-wise-fusable: forces a flush
+        w = z.sub_scalar_op(s, p).exp2_op(p).log2_op(p).cbrt_op(p).cos_op(p).neg_op(p).abs_op(p).sqrt_op(p).neg_op(p).neg_op(p)
+        p.finish()
+        return kept, y, z, m, w
+
+    pf = ag.ArrowComputePipeline(dev, "fused", fuse=True)
+    pe = ag.ArrowComputePipeline(dev, "eager", fuse=False)
+    got, exp = program(pf), program(pe)
+    for g, e in zip(got, exp):
+        assert bits(g.raw_values()) == bits(e.raw_values())
+        assert n > 5000 or [v is None for v in g.values()] == [v is None for v in e.values()]
+    assert pf.stats["fused_chains"] >= 3 and pf.stats["kernels"] < pe.stats["kernels"] + 100
+    assert pe.stats["recorded"] == 0
+
+
+def test_fusing_pipeline_keeps_live_and_reused_intermediates(ag):
+    dev = ag.GPU_DEVICE()
+    n = 4099
+    a, b = _rand(ag, dev, n, 5), _rand(ag, dev, n, 6)
+    p = ag.ArrowComputePipeline(dev, "live", fuse=True)
+    r1 = a.add_op(b, p)          # kept alive by the caller → must be materialised
+    r2 = r1.mul_op(b, p)
+    r3 = r1.sub_op(a, p)         # reads r1 again
+    del r1
+    p.finish()
+    assert p.stats["fused_chains"] == 0 and p.stats["kernels"] == 3
+    assert bits(r2.raw_values()) == bits(a.add(b).mul(b).raw_values())
+    assert bits(r3.raw_values()) == bits(a.add(b).sub(a).raw_values())
+    # int chains, > 8 steps split into 8 + rest
+    ia = ag.Int32ArrayGPU.from_slice(O.synth_i32(n, 1, 0, 0), dev)
+    s = ag.Int32ArrayGPU.from_slice([3], dev)
+    q = ag.ArrowComputePipeline(dev, "long", fuse=True)
+    x = ia
+    for _ in range(11):
+        x = x.add_scalar_op(s, q)
+    q.sync()  # sync (like anything that needs the stream) issues what is recorded
+    assert q.stats["fused_chains"] == 2 and q.stats["fused_ops"] == 11 and q.stats["kernels"] == 2
+    assert np.array_equal(x.raw_values(), (O.synth_i32(n, 1, 0, 0).astype(np.int64) + 33).astype(np.int32))
