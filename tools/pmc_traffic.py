@@ -23,7 +23,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def find(pattern):
-    return sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True))
+    """Newest matching file only: gpurun merges every call's outputs into gpurun_out/, so older passes pile up there."""
+    hits = glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True)
+    return [max(hits, key=os.path.getmtime)] if hits else []
 
 
 def short(name: str) -> str:
