@@ -92,10 +92,35 @@ def cpu_baseline(sample_rows: int):
     assert np.array_equal(ob[: m // 8], O.compare(O.CMP_EQ, O.I32, ia[:m], ib[:m])[: m // 8])
     v1 = rate(1, 8.0)
     vall = rate(cores, 5.0)
-    return {"value": round(v1, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"{n} rows of the same synthetic columns (f32 add + i32 eq with validity), repeated passes, "
-                      f"single thread like arrow-rs's kernels",
-            "all_cores": {"value": round(vall, 3), "cores": cores}}
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    res = {"value": round(v1, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": f"{n} rows of the same synthetic columns (f32 add + i32 eq with validity), repeated passes, "
+                     f"single thread like arrow-rs's kernels",
+           "all_cores": {"value": round(vall, 3), "cores": cores}, "cpu_model": model, "nproc": os.cpu_count()}
+    try:  # third-party sanity line: Arrow C++ through pyarrow on the same columns, same byte accounting
+        import pyarrow as pa
+        import pyarrow.compute as pc
+
+        pa.set_cpu_count(1)
+        fa, fb = pa.array(a), pa.array(b)
+        xa = pa.Array.from_buffers(pa.int32(), n, [pa.py_buffer(va), pa.py_buffer(ia)])
+        xb = pa.Array.from_buffers(pa.int32(), n, [pa.py_buffer(vb), pa.py_buffer(ib)])
+        pc.add(fa, fb), pc.equal(xa, xb)
+        t0, k = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 3.0 and k < 20:
+            pc.add(fa, fb)
+            pc.equal(xa, xb)
+            k += 1
+        res["pyarrow"] = {"value": round((ADD_BYTES_PER_ROW + EQ_BYTES_PER_ROW) * n * k / (time.perf_counter() - t0) / 1e9, 3),
+                          "version": pa.__version__, "cores": 1, "what": "pc.add(f32) + pc.equal(i32 with nulls)"}
+    except Exception as e:  # noqa: BLE001 — context only
+        res["pyarrow"] = {"value": None, "what": f"unavailable: {type(e).__name__}"}
+    return res
 
 
 def main():
