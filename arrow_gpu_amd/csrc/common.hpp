@@ -31,10 +31,11 @@ struct agpu_device {
   // ---- resource pools (runtime.hip).  Measured on MI355X / ROCm 7: hipStreamCreate 4.3 ms + hipStreamDestroy 2.6 ms,
   // hipFree 0.2 ms (implicit device sync), hipMalloc of a 4 GB block 0.2–60 ms — against 0.19 ms for the kernel of a
   // 1e8-row add.  The reference's default API creates a pipeline and an output buffer PER OP, so both are pooled.
-  struct StreamSlot {  // an idle owned stream with the reduction scratch that travels with it
+  struct StreamSlot {  // an idle owned stream with the reduction scratch and the error word that travel with it
     hipStream_t stream;
     void* scratch;
     size_t scratch_bytes;
+    uint32_t* flags;
   };
   struct CachedBlock {  // a freed device block; `pending` = events recorded on every stream at free time
     void* ptr;
@@ -59,7 +60,11 @@ struct agpu_pipeline {
   // scratch for reductions / popcount partials (allocated on first use, reused; stream-ordered so one per pipeline)
   void* scratch;
   size_t scratch_bytes;
+  // sticky error word in pinned host memory, written by kernels (bit 0: take/put index out of range), read and cleared
+  // by agpu_pipeline_sync — no pre-pass over the index column, no readback, the pipeline stays asynchronous
+  uint32_t* flags;
 };
+#define AGPU_FLAG_INDEX_RANGE 1u
 
 struct agpu_event {
   agpu_device* dev;

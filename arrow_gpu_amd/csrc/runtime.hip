@@ -125,7 +125,10 @@ agpu_status agpu_device_destroy(agpu_device* dev) {
   {
     std::lock_guard<std::mutex> lock(dev->mu);
     device_trim_locked(dev);
-    for (auto& s : dev->idle_streams) (void)hipStreamDestroy(s.stream);
+    for (auto& s : dev->idle_streams) {
+      (void)hipStreamDestroy(s.stream);
+      if (s.flags) (void)hipHostFree(s.flags);
+    }
     dev->idle_streams.clear();
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     dev->event_pool.clear();
@@ -370,14 +373,23 @@ static agpu_status pipeline_new(agpu_device* dev, hipStream_t s, bool owns, agpu
   p->capturing = false;
   p->scratch = nullptr;
   p->scratch_bytes = 0;
+  p->flags = nullptr;
   *out = p;
+  return AGPU_OK;
+}
+
+static agpu_status flags_new(uint32_t** out) {
+  void* f = nullptr;
+  AGPU_HIP(hipHostMalloc(&f, 64, hipHostMallocDefault));  // pinned + device-visible under unified addressing
+  *static_cast<uint32_t*>(f) = 0;
+  *out = static_cast<uint32_t*>(f);
   return AGPU_OK;
 }
 
 agpu_status agpu_pipeline_create(agpu_device* dev, agpu_pipeline** out_pipeline) {
   AGPU_REQUIRE(dev && out_pipeline, AGPU_ERR_ARG, "null argument");
   AGPU_HIP(hipSetDevice(dev->ordinal));
-  agpu_device::StreamSlot slot{nullptr, nullptr, 0};
+  agpu_device::StreamSlot slot{nullptr, nullptr, 0, nullptr};
   {
     std::lock_guard<std::mutex> lock(dev->mu);
     if (!dev->idle_streams.empty()) {  // work still queued on a recycled stream simply runs first: same ordering
@@ -390,10 +402,16 @@ agpu_status agpu_pipeline_create(agpu_device* dev, agpu_pipeline** out_pipeline)
     std::lock_guard<std::mutex> lock(dev->mu);
     dev->all_streams.push_back(slot.stream);
   }
+  if (!slot.flags) {
+    agpu_status fs = flags_new(&slot.flags);
+    if (fs != AGPU_OK) return fs;
+  }
+  *slot.flags = 0;  // a new owner starts clean (its predecessor synchronised or gave up its right to the report)
   agpu_status st = pipeline_new(dev, slot.stream, true, out_pipeline);
   if (st == AGPU_OK) {
     (*out_pipeline)->scratch = slot.scratch;
     (*out_pipeline)->scratch_bytes = slot.scratch_bytes;
+    (*out_pipeline)->flags = slot.flags;
   }
   return st;
 }
@@ -404,7 +422,9 @@ agpu_status agpu_pipeline_wrap_stream(agpu_device* dev, void* hip_stream, agpu_p
     std::lock_guard<std::mutex> lock(dev->mu);
     dev->all_streams.push_back(reinterpret_cast<hipStream_t>(hip_stream));
   }
-  return pipeline_new(dev, reinterpret_cast<hipStream_t>(hip_stream), false, out_pipeline);
+  agpu_status st = pipeline_new(dev, reinterpret_cast<hipStream_t>(hip_stream), false, out_pipeline);
+  if (st == AGPU_OK) st = flags_new(&(*out_pipeline)->flags);
+  return st;
 }
 
 agpu_status agpu_pipeline_finish(agpu_pipeline* p) {
@@ -415,6 +435,14 @@ agpu_status agpu_pipeline_finish(agpu_pipeline* p) {
 agpu_status agpu_pipeline_sync(agpu_pipeline* p) {
   AGPU_BIND(p);
   AGPU_HIP(hipStreamSynchronize(p->stream));
+  if (p->flags && *p->flags) {  // sticky kernel-side errors surface here, once
+    const uint32_t f = *p->flags;
+    *p->flags = 0;
+    if (f & AGPU_FLAG_INDEX_RANGE) {
+      agpu_set_error("take/put: an index was out of range (the element was skipped / read as 0)");
+      return AGPU_ERR_SHAPE;
+    }
+  }
   return AGPU_OK;
 }
 
@@ -425,14 +453,13 @@ agpu_status agpu_pipeline_destroy(agpu_pipeline* p) {
   if (p->owns_stream && g_tune.mem_pool != 0 && !p->capturing) {
     // back to the pool WITHOUT waiting: queued work keeps running, the next owner's launches are ordered behind it
     std::lock_guard<std::mutex> lock(dev->mu);
-    dev->idle_streams.push_back(agpu_device::StreamSlot{p->stream, p->scratch, p->scratch_bytes});
+    dev->idle_streams.push_back(agpu_device::StreamSlot{p->stream, p->scratch, p->scratch_bytes, p->flags});
     delete p;
     return AGPU_OK;
   }
-  if (p->scratch) {
-    (void)hipStreamSynchronize(p->stream);
-    (void)hipFree(p->scratch);
-  }
+  if (p->scratch || p->flags) (void)hipStreamSynchronize(p->stream);
+  if (p->scratch) (void)hipFree(p->scratch);
+  if (p->flags) (void)hipHostFree(p->flags);
   {
     std::lock_guard<std::mutex> lock(dev->mu);
     for (size_t i = 0; i < dev->all_streams.size(); i++)

@@ -27,14 +27,20 @@ template <typename E, int N> struct OutPack { E v[N]; };
 template <typename V>
 __device__ __forceinline__ V swz_ld(const V* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 
+// Index ranges are checked IN the kernels (the reference leans on WGSL's robust buffer access: an out-of-range read
+// yields 0, an out-of-range write is dropped).  Same result here, plus a sticky bit in the pipeline's pinned error word
+// that agpu_pipeline_sync turns into AGPU_ERR_SHAPE — no separate max-reduction pass over the index column and no
+// readback before the gather (that pre-check cost a 4 B/row pass and a device sync per take).
 template <int W, bool NT>
-__global__ __launch_bounds__(AGPU_BLOCK) void take_kernel(const typename ElemOf<W>::type* values, const uint32_t* idx,
-                                                         typename ElemOf<W>::type* out, uint64_t n, int vec_ok) {
+__global__ __launch_bounds__(AGPU_BLOCK) void take_kernel(const typename ElemOf<W>::type* values, uint64_t n_values,
+                                                         const uint32_t* idx, typename ElemOf<W>::type* out, uint64_t n,
+                                                         int vec_ok, uint32_t* flags) {
   typedef typename ElemOf<W>::type E;
   constexpr int N = 16 / W;  // output elements per lane (one 16-byte store)
   const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
   const uint64_t npacks = vec_ok ? n / N : 0;
+  bool bad = false;
   for (uint64_t pk = tid; pk < npacks; pk += stride) {
     uint32_t ix[N];
 #pragma unroll
@@ -44,60 +50,88 @@ __global__ __launch_bounds__(AGPU_BLOCK) void take_kernel(const typename ElemOf<
     }
     OutPack<E, N> r;
 #pragma unroll
-    for (int k = 0; k < N; k++) r.v[k] = values[ix[k]];
+    for (int k = 0; k < N; k++) {
+      const bool ok = ix[k] < n_values;
+      bad |= !ok;
+      r.v[k] = values[ok ? ix[k] : 0];
+      if (!ok) r.v[k] = E(0);
+    }
     if (NT) __builtin_nontemporal_store(__builtin_bit_cast(u32x4, r), reinterpret_cast<u32x4*>(out + pk * N));
     else *reinterpret_cast<u32x4*>(out + pk * N) = __builtin_bit_cast(u32x4, r);
   }
-  for (uint64_t i = npacks * N + tid; i < n; i += stride) out[i] = values[idx[i]];
+  for (uint64_t i = npacks * N + tid; i < n; i += stride) {
+    const uint32_t ix = idx[i];
+    const bool ok = ix < n_values;
+    bad |= !ok;
+    out[i] = ok ? values[ix] : E(0);
+  }
+  if (bad) *reinterpret_cast<volatile uint32_t*>(flags) = AGPU_FLAG_INDEX_RANGE;
 }
 
 // out bit i = bits[idx[i]]: lane handles one index per round, ballot = 64 output bits
-__global__ __launch_bounds__(AGPU_BLOCK) void take_bits_kernel(const uint32_t* bits, const uint32_t* idx, uint64_t* out,
-                                                              uint64_t n) {
+__global__ __launch_bounds__(AGPU_BLOCK) void take_bits_kernel(const uint32_t* bits, uint64_t n_bits, const uint32_t* idx,
+                                                              uint64_t* out, uint64_t n, uint32_t* flags) {
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
   const uint64_t wave_id = ((uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x) / AGPU_WAVE;
   const uint64_t n_waves = (uint64_t)gridDim.x * (AGPU_BLOCK / AGPU_WAVE);
   const uint64_t nwords = (n + 63) / 64;
+  bool bad = false;
   for (uint64_t w = wave_id; w < nwords; w += n_waves) {
     const uint64_t i = w * 64 + lane;
     bool bit = false;
     if (i < n) {
       const uint32_t ix = __builtin_nontemporal_load(idx + i);
-      bit = (bits[ix >> 5] >> (ix & 31)) & 1u;
+      if (ix < n_bits) bit = (bits[ix >> 5] >> (ix & 31)) & 1u;
+      else bad = true;
     }
     const uint64_t m = __ballot(bit);
     if (lane == 0) out[w] = m;
   }
+  if (bad) *reinterpret_cast<volatile uint32_t*>(flags) = AGPU_FLAG_INDEX_RANGE;
 }
 
 // ---------------------------------------------------------------- put (in place on dst)
+// n_src / n_dst = UINT64_MAX for the unchecked entry points (agpu_put / agpu_put_bits: lengths unknown to the ABI call)
 template <int W, bool NT>
-__global__ __launch_bounds__(AGPU_BLOCK) void put_kernel(const typename ElemOf<W>::type* src, const uint32_t* src_idx,
-                                                        typename ElemOf<W>::type* dst, const uint32_t* dst_idx,
-                                                        uint64_t n, int vec_ok) {
+__global__ __launch_bounds__(AGPU_BLOCK) void put_kernel(const typename ElemOf<W>::type* src, uint64_t n_src,
+                                                        const uint32_t* src_idx, typename ElemOf<W>::type* dst,
+                                                        uint64_t n_dst, const uint32_t* dst_idx, uint64_t n, int vec_ok,
+                                                        uint32_t* flags) {
   const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
   const uint64_t npacks = vec_ok ? n / 4 : 0;
+  bool bad = false;
+  auto move = [&](uint32_t s, uint32_t d) {
+    if (s < n_src && d < n_dst) dst[d] = src[s];
+    else bad = true;
+  };
   for (uint64_t pk = tid; pk < npacks; pk += stride) {
     const u32x4 si = swz_ld(reinterpret_cast<const u32x4*>(src_idx + pk * 4), NT);
     const u32x4 di = swz_ld(reinterpret_cast<const u32x4*>(dst_idx + pk * 4), NT);
-    const auto v0 = src[si.x], v1 = src[si.y], v2 = src[si.z], v3 = src[si.w];
-    dst[di.x] = v0; dst[di.y] = v1; dst[di.z] = v2; dst[di.w] = v3;
+    move(si.x, di.x); move(si.y, di.y); move(si.z, di.z); move(si.w, di.w);
   }
-  for (uint64_t i = npacks * 4 + tid; i < n; i += stride) dst[dst_idx[i]] = src[src_idx[i]];
+  for (uint64_t i = npacks * 4 + tid; i < n; i += stride) move(src_idx[i], dst_idx[i]);
+  if (bad) *reinterpret_cast<volatile uint32_t*>(flags) = AGPU_FLAG_INDEX_RANGE;
 }
 
 // bit scatter: clear then set, word atomics like the reference (bool/put.wgsl:17-34)
-__global__ __launch_bounds__(AGPU_BLOCK) void put_bits_kernel(const uint32_t* src, const uint32_t* src_idx, uint32_t* dst,
-                                                             const uint32_t* dst_idx, uint64_t n) {
+__global__ __launch_bounds__(AGPU_BLOCK) void put_bits_kernel(const uint32_t* src, uint64_t n_src, const uint32_t* src_idx,
+                                                             uint32_t* dst, uint64_t n_dst, const uint32_t* dst_idx,
+                                                             uint64_t n, uint32_t* flags) {
   const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  bool bad = false;
   for (uint64_t i = tid; i < n; i += stride) {
     const uint32_t s = src_idx[i], d = dst_idx[i];
+    if (!(s < n_src && d < n_dst)) {
+      bad = true;
+      continue;
+    }
     const uint32_t bit = (src[s >> 5] >> (s & 31)) & 1u;
     if (bit) atomicOr(&dst[d >> 5], 1u << (d & 31));
     else atomicAnd(&dst[d >> 5], ~(1u << (d & 31)));
   }
+  if (bad) *reinterpret_cast<volatile uint32_t*>(flags) = AGPU_FLAG_INDEX_RANGE;
 }
 
 // ---------------------------------------------------------------- merge: out[i] = mask bit i ? a[i] : b[i]
@@ -167,15 +201,15 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   switch (width) {
     case 4:
       hipLaunchKernelGGL((swz_nt() ? take_kernel<4, true> : take_kernel<4, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(values),
-                         idx, static_cast<uint32_t*>(out), n_idx, vec_ok);
+                         n_values, idx, static_cast<uint32_t*>(out), n_idx, vec_ok, p->flags);
       break;
     case 2:
       hipLaunchKernelGGL((swz_nt() ? take_kernel<2, true> : take_kernel<2, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(values),
-                         idx, static_cast<uint16_t*>(out), n_idx, vec_ok);
+                         n_values, idx, static_cast<uint16_t*>(out), n_idx, vec_ok, p->flags);
       break;
     case 1:
       hipLaunchKernelGGL((swz_nt() ? take_kernel<1, true> : take_kernel<1, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(values),
-                         idx, static_cast<uint8_t*>(out), n_idx, vec_ok);
+                         n_values, idx, static_cast<uint8_t*>(out), n_idx, vec_ok, p->flags);
       break;
     default:
       agpu_set_error("take: width %d not supported (1, 2, 4)", width);
@@ -195,50 +229,58 @@ agpu_status agpu_take_bits(agpu_pipeline* p, const void* bits, uint64_t n_bits, 
   const uint64_t nwords = (n_idx + 63) / 64;
   const int grid = stream_grid_for(p, (nwords + 3) / 4);
   hipLaunchKernelGGL(take_bits_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(bits),
-                     idx, static_cast<uint64_t*>(out_bits), n_idx);
+                     n_bits, idx, static_cast<uint64_t*>(out_bits), n_idx, p->flags);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+agpu_status agpu_put_bounded(agpu_pipeline* p, int32_t width, const void* src, uint64_t n_src, const uint32_t* src_idx,
+                             void* dst, uint64_t n_dst, const uint32_t* dst_idx, uint64_t n) {
+  AGPU_BIND(p);
+  if (n == 0) return AGPU_OK;
+  AGPU_REQUIRE(src && src_idx && dst && dst_idx, AGPU_ERR_ARG, "null pointer");
+  const int vec_ok = aligned16(src_idx) && aligned16(dst_idx);
+  const int grid = gs_grid(p, n / 4 + 1);
+#define AGPU_PUT_CASE(W, E)                                                                                              \
+  case W:                                                                                                                \
+    hipLaunchKernelGGL((swz_nt() ? put_kernel<W, true> : put_kernel<W, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, \
+                       static_cast<const E*>(src), n_src, src_idx, static_cast<E*>(dst), n_dst, dst_idx, n, vec_ok,     \
+                       p->flags);                                                                                        \
+    break;
+  switch (width) {
+    AGPU_PUT_CASE(4, uint32_t)
+    AGPU_PUT_CASE(2, uint16_t)
+    AGPU_PUT_CASE(1, uint8_t)
+    default:
+      agpu_set_error("put: width %d not supported (1, 2, 4)", width);
+      return AGPU_ERR_UNSUPPORTED;
+  }
+#undef AGPU_PUT_CASE
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
 }
 
 agpu_status agpu_put(agpu_pipeline* p, int32_t width, const void* src, const uint32_t* src_idx, void* dst,
                      const uint32_t* dst_idx, uint64_t n) {
-  AGPU_BIND(p);
-  if (n == 0) return AGPU_OK;
-  AGPU_REQUIRE(src && src_idx && dst && dst_idx, AGPU_ERR_ARG, "null pointer");
-  const int vec_ok = aligned16(src_idx) && aligned16(dst_idx);
-  const int grid = gs_grid(p, n / 4 + 1);
-  switch (width) {
-    case 4:
-      hipLaunchKernelGGL((swz_nt() ? put_kernel<4, true> : put_kernel<4, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(src),
-                         src_idx, static_cast<uint32_t*>(dst), dst_idx, n, vec_ok);
-      break;
-    case 2:
-      hipLaunchKernelGGL((swz_nt() ? put_kernel<2, true> : put_kernel<2, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(src),
-                         src_idx, static_cast<uint16_t*>(dst), dst_idx, n, vec_ok);
-      break;
-    case 1:
-      hipLaunchKernelGGL((swz_nt() ? put_kernel<1, true> : put_kernel<1, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(src),
-                         src_idx, static_cast<uint8_t*>(dst), dst_idx, n, vec_ok);
-      break;
-    default:
-      agpu_set_error("put: width %d not supported (1, 2, 4)", width);
-      return AGPU_ERR_UNSUPPORTED;
-  }
-  AGPU_LAUNCH_CHECK();
-  return AGPU_OK;
+  return agpu_put_bounded(p, width, src, UINT64_MAX, src_idx, dst, UINT64_MAX, dst_idx, n);
 }
 
-agpu_status agpu_put_bits(agpu_pipeline* p, const void* src_bits, const uint32_t* src_idx, void* dst_bits,
-                          const uint32_t* dst_idx, uint64_t n) {
+agpu_status agpu_put_bits_bounded(agpu_pipeline* p, const void* src_bits, uint64_t n_src_bits, const uint32_t* src_idx,
+                                  void* dst_bits, uint64_t n_dst_bits, const uint32_t* dst_idx, uint64_t n) {
   AGPU_BIND(p);
   if (n == 0) return AGPU_OK;
   AGPU_REQUIRE(src_bits && src_idx && dst_bits && dst_idx, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(aligned_to(src_bits, 4) && aligned_to(dst_bits, 4), AGPU_ERR_SHAPE, "bitmap alignment");
   const int grid = gs_grid(p, n);
   hipLaunchKernelGGL(put_bits_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(src_bits),
-                     src_idx, static_cast<uint32_t*>(dst_bits), dst_idx, n);
+                     n_src_bits, src_idx, static_cast<uint32_t*>(dst_bits), n_dst_bits, dst_idx, n, p->flags);
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
+}
+
+agpu_status agpu_put_bits(agpu_pipeline* p, const void* src_bits, const uint32_t* src_idx, void* dst_bits,
+                          const uint32_t* dst_idx, uint64_t n) {
+  return agpu_put_bits_bounded(p, src_bits, UINT64_MAX, src_idx, dst_bits, UINT64_MAX, dst_idx, n);
 }
 
 agpu_status agpu_merge(agpu_pipeline* p, int32_t width, const void* a, const void* b, const void* mask_bits, void* out,

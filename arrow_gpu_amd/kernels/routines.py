@@ -2,15 +2,14 @@
 
 Mirror of crates/routines/src/{lib,merge,take,put,bool}.rs.  Differences that are deliberate:
 the taken validity bitmap has the INDEX length (the reference stores the source length, bool.rs:40-44); absent
-validity bitmaps count as all-valid in `merge`; indices are range-checked on the host side of `take`/`put` because
-HIP has no robust buffer access (out-of-range → ArrowErrorGPU ShapeError instead of an unspecified value).
+validity bitmaps count as all-valid in `merge`; index ranges are checked inside the `take`/`put` kernels (HIP has no
+robust buffer access: out-of-range reads yield 0 and writes are dropped, as WGSL would, and the pipeline's next `sync()`
+raises ArrowErrorGPU ShapeError).
 """
 from __future__ import annotations
 
-import numpy as np
-
 from .. import _capi as capi
-from .._capi import ArrowErrorGPU, OperationNotSupported
+from .._capi import OperationNotSupported
 from ..array import (ArrowArrayGPU, BooleanArrayGPU, Date32ArrayGPU, Float32ArrayGPU, Int8ArrayGPU, Int16ArrayGPU,
                      Int32ArrayGPU, NullBitBufferGpu, PrimitiveArrayGpu, UInt8ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU,
                      bitmap_bytes)
@@ -34,17 +33,6 @@ def merge_null_buffers_op(op1, op2, mask: BooleanArrayGPU, pipeline: ArrowComput
     pipeline.keep(op1.bit_buffer if op1 else None, op2.bit_buffer if op2 else None, mask.data,
                   vm.bit_buffer if vm else None, out)
     return NullBitBufferGpu(out, n, dev)
-
-
-def _check_indices(indexes: UInt32ArrayGPU, limit: int, pipeline: ArrowComputePipeline, what: str) -> None:
-    if indexes.len == 0:
-        return
-    dev = indexes.gpu_device
-    out = dev.create_empty_buffer(16)
-    capi.call("agpu_index_max", pipeline._handle, vp(indexes.data), indexes.len, vp(out))
-    mx = int(dev.retrive_data(out, 4, pipeline=pipeline).view(np.uint32)[0])
-    if mx >= limit:
-        raise ArrowErrorGPU("ShapeError", f"{what}: index {mx} out of range for length {limit}", capi.ERR_SHAPE)
 
 
 def take_null_buffer(null_buffer, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipeline):
@@ -72,7 +60,6 @@ def _merge_op(self: PrimitiveArrayGpu, other, mask: BooleanArrayGPU, pipeline: A
 
 
 def _take_op(self: PrimitiveArrayGpu, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipeline):
-    _check_indices(indexes, self.len, pipeline, "take")
     dev = self.gpu_device
     out = dev.create_empty_buffer(max(indexes.len * self.ITEM_SIZE, 1))
     capi.call("agpu_take", pipeline._handle, self.ITEM_SIZE, vp(self.data), self.len, vp(indexes.data), vp(out), indexes.len)
@@ -98,31 +85,43 @@ def _put_validity(src, src_indexes, dst, dst_indexes, pipeline: ArrowComputePipe
     sv = src.null_buffer if src.null_buffer is not None else _all_valid(dev, src.len, pipeline)
     if dst.null_buffer is None:
         dst.null_buffer = _all_valid(dev, dst.len, pipeline)
-    capi.call("agpu_put_bits", pipeline._handle, vp(sv.bit_buffer), vp(src_indexes.data), vp(dst.null_buffer.bit_buffer),
-              vp(dst_indexes.data), src_indexes.len)
+    capi.call("agpu_put_bits_bounded", pipeline._handle, vp(sv.bit_buffer), src.len, vp(src_indexes.data),
+              vp(dst.null_buffer.bit_buffer), dst.len, vp(dst_indexes.data), src_indexes.len)
     pipeline.keep(sv.bit_buffer, dst.null_buffer.bit_buffer, src_indexes.data, dst_indexes.data)
 
 
 def _put_op(self: PrimitiveArrayGpu, src_indexes: UInt32ArrayGPU, dst, dst_indexes: UInt32ArrayGPU,
             pipeline: ArrowComputePipeline) -> None:
     check_same_len(src_indexes, dst_indexes, "put indexes")
-    _check_indices(src_indexes, self.len, pipeline, "put src")
-    _check_indices(dst_indexes, dst.len, pipeline, "put dst")
-    capi.call("agpu_put", pipeline._handle, self.ITEM_SIZE, vp(self.data), vp(src_indexes.data), vp(dst.data),
-              vp(dst_indexes.data), src_indexes.len)
+    capi.call("agpu_put_bounded", pipeline._handle, self.ITEM_SIZE, vp(self.data), self.len, vp(src_indexes.data),
+              vp(dst.data), dst.len, vp(dst_indexes.data), src_indexes.len)
     pipeline.keep(self.data, src_indexes.data, dst.data, dst_indexes.data)
     _put_validity(self, src_indexes, dst, dst_indexes, pipeline)
 
 
+# Index ranges are checked inside the take / put kernels (out-of-range read → 0, out-of-range write dropped, like the
+# reference's robust buffer access) and reported by the next `pipeline.sync()` as ShapeError.  The `_op` forms therefore
+# never block; the default forms below synchronise before returning so the error surfaces at the call, as it did when
+# the indices were pre-checked with a separate pass.
 def _put(self, src_indexes, dst, dst_indexes) -> None:
     p = ArrowComputePipeline(self.get_gpu_device(), "put")
     self.put_op(src_indexes, dst, dst_indexes, p)
     p.finish()
+    p.sync()
+
+
+def _take(self, indexes):
+    p = ArrowComputePipeline(self.get_gpu_device(), "take")
+    out = self.take_op(indexes, p)
+    p.finish()
+    p.sync()
+    return out
 
 
 impl(_PRIMS, "merge", _merge_op)
-impl(_PRIMS, "take", _take_op)
 for _c in _PRIMS:
+    _c.take_op = _take_op
+    _c.take = _take
     _c.put_op = _put_op
     _c.put = _put
 
@@ -140,7 +139,6 @@ def _bool_merge_op(self: BooleanArrayGPU, other, mask: BooleanArrayGPU, pipeline
 
 
 def _bool_take_op(self: BooleanArrayGPU, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipeline):
-    _check_indices(indexes, self.len, pipeline, "take")
     dev = self.gpu_device
     out = dev.create_empty_buffer(max(bitmap_bytes(indexes.len), 8))
     capi.call("agpu_take_bits", pipeline._handle, vp(self.data), self.len, vp(indexes.data), vp(out), indexes.len)
@@ -150,16 +148,15 @@ def _bool_take_op(self: BooleanArrayGPU, indexes: UInt32ArrayGPU, pipeline: Arro
 
 def _bool_put_op(self: BooleanArrayGPU, src_indexes, dst: BooleanArrayGPU, dst_indexes, pipeline: ArrowComputePipeline):
     check_same_len(src_indexes, dst_indexes, "put indexes")
-    _check_indices(src_indexes, self.len, pipeline, "put src")
-    _check_indices(dst_indexes, dst.len, pipeline, "put dst")
-    capi.call("agpu_put_bits", pipeline._handle, vp(self.data), vp(src_indexes.data), vp(dst.data), vp(dst_indexes.data),
-              src_indexes.len)
+    capi.call("agpu_put_bits_bounded", pipeline._handle, vp(self.data), self.len, vp(src_indexes.data), vp(dst.data), dst.len,
+              vp(dst_indexes.data), src_indexes.len)
     pipeline.keep(self.data, src_indexes.data, dst.data, dst_indexes.data)
     _put_validity(self, src_indexes, dst, dst_indexes, pipeline)
 
 
 impl((BooleanArrayGPU,), "merge", _bool_merge_op)
-impl((BooleanArrayGPU,), "take", _bool_take_op)
+BooleanArrayGPU.take_op = _bool_take_op
+BooleanArrayGPU.take = _take
 BooleanArrayGPU.put_op = _bool_put_op
 BooleanArrayGPU.put = _put
 
@@ -193,6 +190,7 @@ def take_dyn(operand_1, indexes):
     p = ArrowComputePipeline(operand_1.get_gpu_device(), "take")
     out = take_op_dyn(operand_1, indexes, p)
     p.finish()
+    p.sync()  # surfaces an out-of-range index here (see _take)
     return out
 
 
@@ -207,6 +205,7 @@ def put_dyn(src, src_indexes, dst, dst_indexes) -> None:
     p = ArrowComputePipeline(src.get_gpu_device(), "put")
     put_op_dyn(src, src_indexes, dst, dst_indexes, p)
     p.finish()
+    p.sync()
 
 
 __all__ = ["merge_dyn", "merge_op_dyn", "take_dyn", "take_op_dyn", "put_dyn", "put_op_dyn", "merge_null_buffers_op"]

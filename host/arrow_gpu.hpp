@@ -483,20 +483,22 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
     ArrowComputePipeline p(gpu_device);
     auto out = take_op(indexes, p);
     p.finish();
+    p.sync();
     return out;
   }
   void put_op(const PrimitiveArrayGpu<uint32_t>& src_indexes, PrimitiveArrayGpu& dst,
               const PrimitiveArrayGpu<uint32_t>& dst_indexes, ArrowComputePipeline& p) const {
     if (null_buffer || dst.null_buffer)
       throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "put with null buffers is todo!() in the reference");
-    check(agpu_put(p.raw, (int)sizeof(Native), data->ptr, (const uint32_t*)src_indexes.data->ptr, dst.data->ptr,
-                   (const uint32_t*)dst_indexes.data->ptr, src_indexes.len), "agpu_put");
+    check(agpu_put_bounded(p.raw, (int)sizeof(Native), data->ptr, len, (const uint32_t*)src_indexes.data->ptr, dst.data->ptr,
+                           dst.len, (const uint32_t*)dst_indexes.data->ptr, src_indexes.len), "agpu_put_bounded");
     p.keep.insert(p.keep.end(), {data, src_indexes.data, dst.data, dst_indexes.data});
   }
   void put(const PrimitiveArrayGpu<uint32_t>& si, PrimitiveArrayGpu& dst, const PrimitiveArrayGpu<uint32_t>& di) const {
     ArrowComputePipeline p(gpu_device);
     put_op(si, dst, di, p);
     p.finish();
+    p.sync();
   }
 };
 
@@ -657,18 +659,10 @@ inline std::optional<NullBitBufferGpu> take_null_buffer(const std::optional<Null
   p.keep.insert(p.keep.end(), {nb->bit_buffer, indexes.data, out});
   return NullBitBufferGpu{out, indexes.len, indexes.gpu_device};
 }
-inline void check_indices(const UInt32ArrayGPU& idx, size_t limit, ArrowComputePipeline& p, const char* what) {
-  if (!idx.len) return;
-  auto out = idx.gpu_device->create_empty_buffer(16);
-  check(agpu_index_max(p.raw, (const uint32_t*)idx.data->ptr, idx.len, (uint32_t*)out->ptr), "agpu_index_max");
-  p.sync();
-  uint32_t mx = 0;
-  std::memcpy(&mx, idx.gpu_device->retrive_data(out, 4).data(), 4);
-  if (mx >= limit) throw ArrowErrorGPU(ArrowErrorGPU::Runtime, std::string(what) + ": index out of range");
-}
+// Index ranges are checked inside the take / put kernels (out-of-range read -> 0, write dropped, like WGSL robust
+// access); the pipeline's next sync() throws.  The *_op forms never block, the default forms sync before returning.
 template <typename T>
 PrimitiveArrayGpu<T> PrimitiveArrayGpu<T>::take_op(const UInt32ArrayGPU& indexes, ArrowComputePipeline& p) const {
-  check_indices(indexes, len, p, "take");
   auto out = gpu_device->create_empty_buffer(indexes.len * sizeof(Native));
   check(agpu_take(p.raw, (int)sizeof(Native), data->ptr, len, (const uint32_t*)indexes.data->ptr, out->ptr, indexes.len), "agpu_take");
   p.keep.insert(p.keep.end(), {data, indexes.data, out});

@@ -299,7 +299,10 @@ agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* v
 
 /* ---------------------------------------------------------------- swizzle: take / put / merge
  * width = bytes per element (1, 2 or 4; the reference implements 4 and Boolean only).
- * take: out[i] = values[idx[i]], i < n_idx; every idx must be < n_values (checked only by agpu_check_indices).
+ * Index ranges are checked inside the kernels with the reference's robust-buffer-access outcome (WGSL): an
+ * out-of-range read yields 0, an out-of-range write is dropped — and additionally a sticky bit is set in the pipeline,
+ * which the next agpu_pipeline_sync reports once as AGPU_ERR_SHAPE.  No pre-pass over the indices, no readback.
+ * take: out[i] = values[idx[i]], i < n_idx.
  * [ref: apply_take_op crates/routines/src/take.rs:9-55, 32bit/take.wgsl:13-17] */
 agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const uint32_t* idx,
                       void* out, uint64_t n_idx);
@@ -307,10 +310,15 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
 agpu_status agpu_take_bits(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits,
                            uint64_t n_idx);
 /* dst[dst_idx[i]] = src[src_idx[i]] in place; duplicate dst_idx ⇒ unspecified winner
- * [ref: apply_put_op crates/routines/src/put.rs:9-56, 32bit/put.wgsl:17-23] */
+ * [ref: apply_put_op crates/routines/src/put.rs:9-56, 32bit/put.wgsl:17-23].  The *_bounded forms take the two array
+ * lengths and range-check as described above; agpu_put / agpu_put_bits trust the caller (lengths unknown). */
+agpu_status agpu_put_bounded(agpu_pipeline* p, int32_t width, const void* src, uint64_t n_src, const uint32_t* src_idx,
+                             void* dst, uint64_t n_dst, const uint32_t* dst_idx, uint64_t n);
 agpu_status agpu_put(agpu_pipeline* p, int32_t width, const void* src, const uint32_t* src_idx, void* dst,
                      const uint32_t* dst_idx, uint64_t n);
 /* bit scatter (atomic and/or) [ref: crates/routines/src/bool.rs:48-128, bool/put.wgsl:17-34] */
+agpu_status agpu_put_bits_bounded(agpu_pipeline* p, const void* src_bits, uint64_t n_src_bits, const uint32_t* src_idx,
+                                  void* dst_bits, uint64_t n_dst_bits, const uint32_t* dst_idx, uint64_t n);
 agpu_status agpu_put_bits(agpu_pipeline* p, const void* src_bits, const uint32_t* src_idx, void* dst_bits,
                           const uint32_t* dst_idx, uint64_t n);
 /* out[i] = mask bit i ? a[i] : b[i]  [ref: Swizzle::merge_op crates/routines/src/lib.rs:82-120, {32,16,8}bit/merge.wgsl] */

@@ -449,6 +449,50 @@ def test_take_put_bits_and_index_max(D):
         assert int(D.down(mx, np.uint32, 1)[0]) == O.index_max(idx)
 
 
+def test_out_of_range_indices_are_handled_in_the_kernels(D):
+    """Robust-access outcome (out-of-range read -> 0, write dropped) + one sticky AGPU_ERR_SHAPE at the next sync,
+    with no pre-pass over the indices and no blocking call at take/put time."""
+    rng = np.random.default_rng(5)
+    n_values, n_idx = 5000, 20_003
+    values = rng.integers(1, 1000, n_values).astype(np.uint32)
+    idx = rng.integers(0, n_values, n_idx).astype(np.uint32)
+    bad = rng.choice(n_idx, 37, replace=False)
+    idx[bad] = n_values + rng.integers(0, 1 << 20, 37).astype(np.uint32)
+    idx[bad[0]] = 0xFFFFFFFF
+    out = D.empty(4 * n_idx)
+    D.call("agpu_take", 4, D.up(values).vp, n_values, D.up(idx).vp, out.vp, n_idx)
+    assert D.status("agpu_pipeline_sync") == capi.ERR_SHAPE and "out of range" in capi.last_error()
+    assert D.status("agpu_pipeline_sync") == capi.OK  # reported once
+    exp = np.where(idx < n_values, values[np.minimum(idx, n_values - 1)], 0).astype(np.uint32)
+    assert bits_equal(D.down(out, np.uint32, n_idx), exp)
+    # bits
+    bits = O.synth_bits(n_values, 1, 0, 0.5)
+    outb = D.empty(O.bitmap_bytes(n_idx) + 8)
+    D.call("agpu_take_bits", D.up(bits).vp, n_values, D.up(idx).vp, outb.vp, n_idx)
+    assert D.status("agpu_pipeline_sync") == capi.ERR_SHAPE
+    ok_idx = np.where(idx < n_values, idx, 0).astype(np.uint32)
+    expb = np.unpackbits(O.take_bits(bits, n_values, ok_idx), bitorder="little")[:n_idx] & (idx < n_values)
+    gotb = np.unpackbits(D.down(outb, np.uint8, O.bitmap_bytes(n_idx)), bitorder="little")[:n_idx]
+    assert np.array_equal(gotb, expb)
+    # put: out-of-range source or destination ⇒ that element is skipped
+    n_dst, k = 7000, 3000
+    dst = rng.integers(1, 1000, n_dst).astype(np.uint32)
+    si = rng.integers(0, n_values, k).astype(np.uint32)
+    di = rng.permutation(n_dst)[:k].astype(np.uint32)
+    si[::97] = n_values + 5
+    di[5::101] = n_dst
+    ddst = D.up(dst)
+    D.call("agpu_put_bounded", 4, D.up(values).vp, n_values, D.up(si).vp, ddst.vp, n_dst, D.up(di).vp, k)
+    assert D.status("agpu_pipeline_sync") == capi.ERR_SHAPE
+    keep = (si < n_values) & (di < n_dst)
+    exp = dst.copy()
+    exp[di[keep]] = values[si[keep]]
+    assert bits_equal(D.down(ddst, np.uint32, n_dst), exp)
+    # in range: no flag
+    D.call("agpu_put_bounded", 4, D.up(values).vp, n_values, D.up(si[keep]).vp, ddst.vp, n_dst, D.up(di[keep]).vp, int(keep.sum()))
+    assert D.status("agpu_pipeline_sync") == capi.OK
+
+
 # ------------------------------------------------------------------ by-name shim, synth, checksum, graphs
 def test_launch_by_name_matches_typed_entry_points(D):
     n = 4099
