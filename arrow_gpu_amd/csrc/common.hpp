@@ -131,6 +131,7 @@ struct agpu_tuning {
   int64_t stream_nt;      // bit0: nontemporal loads, bit1: nontemporal stores
   int64_t cmp_variant;    // 0 = ballot (dword loads), 1 = vector loads + nibble shuffle
   int64_t reduce_grid;    // blocks for reductions (0 = auto)
+  int64_t table_tiles;    // tiles per block for kernels that stage a lookup table in LDS (lut8 / trig16 / pow)
   int64_t mem_pool;       // 1 = cache freed device blocks ≥ 1 MiB and idle streams (default), 0 = hipMalloc/hipFree every time
 };
 extern agpu_tuning g_tune;

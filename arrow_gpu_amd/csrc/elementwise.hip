@@ -22,6 +22,9 @@
 
 #include "common.hpp"
 
+// tiles per block for the kernels that stage a table in LDS (lut8, trig16, pow): tuning key "table_tiles"
+static inline uint64_t tab_k() { return g_tune.table_tiles > 0 ? (uint64_t)g_tune.table_tiles : 1; }
+
 #ifndef AGPU_STREAM_U
 #define AGPU_STREAM_U 1  // 16-byte vectors per lane per input array per tile (measured best: profiles/r01_sweep_add_f32_1e9.json)
 #endif
@@ -562,7 +565,7 @@ static agpu_status launch_pow_f32(agpu_pipeline* p, const void* a, const void* b
   if (aligned16(a) && aligned16(out) && (MODE != MODE_BINARY || aligned16(b))) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, ntiles)), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
+      hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, (ntiles + tab_k() - 1) / tab_k())), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
                          ntiles, tab);
       done = ntiles * TILE_ROWS;
     }
@@ -822,7 +825,7 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
   if (aligned_to(in, 4) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      const int grid = stream_grid_for(p, ntiles);
+      const int grid = stream_grid_for(p, (ntiles + tab_k() - 1) / tab_k());
       hipLaunchKernelGGL((lut8_kernel<TI, F>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, ntiles);
       done = ntiles * TILE_ROWS;
     }
@@ -929,7 +932,7 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
   if (aligned_to(in, 8) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS>), dim3(stream_grid_for(p, ntiles)), dim3(AGPU_BLOCK), 0, p->stream, pi,
+      hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS>), dim3(stream_grid_for(p, (ntiles + tab_k() - 1) / tab_k())), dim3(AGPU_BLOCK), 0, p->stream, pi,
                          po, ntiles, tab);
       done = ntiles * TILE_ROWS;
     }
