@@ -1088,16 +1088,41 @@ struct ChainPtrs {
 __host__ __device__ __forceinline__ int chain_op(uint64_t code, int s) { return (int)((code >> (6 * s)) & 15u); }
 __host__ __device__ __forceinline__ int chain_kind(uint64_t code, int s) { return (int)((code >> (6 * s + 4)) & 3u); }
 
-template <typename T, bool HEAVY, int NARR>
+template <typename T>
+__device__ __forceinline__ bool chain_cmp_pred(int op, T x, T y) {
+  switch (op) {
+    case AGPU_CMP_GT: return x > y;
+    case AGPU_CMP_GTEQ: return x >= y;
+    case AGPU_CMP_LT: return x < y;
+    case AGPU_CMP_LTEQ: return x <= y;
+    default: return x == y;
+  }
+}
+
+// CMP = the chain ends in a compare (agpu_fused_chain_compare): step slot n_steps carries the compare's operand, the
+// result is not stored but compared, and the wave's 256 predicate bits leave as eight 32-bit words (4 bits per lane,
+// OR-reduced over 8-lane groups) — `out` then points at the packed bitmap.
+// The CMP form is (almost) read-only, and a read-only stream of this shape is bound by bytes in flight, not by HBM:
+// stores retire without holding the wave, loads do not, and with one 16-byte load per lane and stream a 4-input
+// predicate ran at 4.9 TB/s.  It therefore keeps U = 2 packs per lane and stream in flight (6.x TB/s); the storing
+// form stays at U = 1 (tools/probe/chain_probe.py).
+#define AGPU_CHAIN_CMP_U 2
+template <typename T, bool HEAVY, int NARR, bool CMP>
 __global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_kernel(const T* in, T* out, uint64_t ntiles, int n_steps,
-                                                             int n_arrs, uint64_t code, ChainPtrs ptrs, ChainPtrs arrs) {
+                                                             int n_arrs, uint64_t code, ChainPtrs ptrs, ChainPtrs arrs,
+                                                             int cmp_op) {
   constexpr int N = 4;
+  constexpr int U = CMP ? AGPU_CHAIN_CMP_U : 1;  // a tile = U × 256 rows
   for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const uint64_t pk = t * AGPU_EW_BLOCK + threadIdx.x;
-    PackN<T, N> acc = load_pack<true, T, N>(in + pk * N);
-    PackN<T, N> ya[NARR > 0 ? NARR : 1];
+    const uint64_t pk0 = t * (uint64_t)(AGPU_EW_BLOCK * U) + threadIdx.x;
+    PackN<T, N> acc[U];
+    static_for<U>([&](auto u) { acc[u] = load_pack<true, T, N>(in + (pk0 + (uint64_t)u * AGPU_EW_BLOCK) * N); });
+    PackN<T, N> ya[NARR > 0 ? NARR : 1][U];
     static_for<NARR>([&](auto a) {
-      if (a < n_arrs) ya[a] = load_pack<true, T, N>(static_cast<const T*>(arrs.p[a]) + pk * N);
+      if (a < n_arrs)
+        static_for<U>([&](auto u) {
+          ya[a][u] = load_pack<true, T, N>(static_cast<const T*>(arrs.p[a]) + (pk0 + (uint64_t)u * AGPU_EW_BLOCK) * N);
+        });
     });
     // Scalar operands: eight unconditional s_load_dword through the constant address space (the host points unused
     // slots at `in`), one lgkmcnt wait for all of them.  A per-lane global load + readfirstlane here serialised one
@@ -1107,33 +1132,98 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_kernel(const T* in, T* ou
       sc[s] = *(const __attribute__((address_space(4))) uint32_t*)(ptrs.p[s]);
     });
     int ai = 0;
+    PackN<T, N> y[U];
+    auto fetch = [&](int s, int kind) {  // y = what step s combines with (array slot in order of use, or scalar s)
+      if (kind == AGPU_CHAIN_ARRAY) {
+        static_for<U>([&](auto u) { y[u] = ya[0][u]; });
+        static_for<NARR>([&](auto j) {
+          if (j == ai) static_for<U>([&](auto u) { y[u] = ya[j][u]; });  // wave-uniform select
+        });
+        ai++;
+      } else {
+        uint32_t w = 0;
+        static_for<AGPU_CHAIN_MAX_STEPS>([&](auto j) {
+          if (j == s) w = sc[j];
+        });
+        const T v = __builtin_bit_cast(T, w);
+        static_for<U>([&](auto u) {
+#pragma unroll
+          for (int k = 0; k < N; k++) y[u].v[k] = v;
+        });
+      }
+    };
     for (int s = 0; s < n_steps; s++) {
       const int op = chain_op(code, s), kind = chain_kind(code, s);
       if (kind == AGPU_CHAIN_UNARY) {
+        static_for<U>([&](auto u) {
 #pragma unroll
-        for (int k = 0; k < N; k++) acc.v[k] = chain_apply_unary<T, HEAVY>(op, acc.v[k]);
+          for (int k = 0; k < N; k++) acc[u].v[k] = chain_apply_unary<T, HEAVY>(op, acc[u].v[k]);
+        });
       } else {
-        PackN<T, N> y;
-        if (kind == AGPU_CHAIN_ARRAY) {
-          y = ya[0];
-          static_for<NARR>([&](auto j) {
-            if (j == ai) y = ya[j];  // wave-uniform select
-          });
-          ai++;
-        } else {
-          uint32_t w = 0;
-          static_for<AGPU_CHAIN_MAX_STEPS>([&](auto j) {
-            if (j == s) w = sc[j];
-          });
-          const T v = __builtin_bit_cast(T, w);
+        fetch(s, kind);
+        static_for<U>([&](auto u) {
 #pragma unroll
-          for (int k = 0; k < N; k++) y.v[k] = v;
-        }
-#pragma unroll
-        for (int k = 0; k < N; k++) acc.v[k] = chain_apply_binary<T>(op, acc.v[k], y.v[k]);
+          for (int k = 0; k < N; k++) acc[u].v[k] = chain_apply_binary<T>(op, acc[u].v[k], y[u].v[k]);
+        });
       }
     }
-    store_pack<true, T, N>(out + pk * N, acc);
+    if constexpr (CMP) {
+      fetch(n_steps, chain_kind(code, n_steps));
+      static_for<U>([&](auto u) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) m |= (uint32_t)chain_cmp_pred<T>(cmp_op, acc[u].v[k], y[u].v[k]) << k;
+        uint32_t v = m << (4 * (threadIdx.x & 7));
+        v |= (uint32_t)__shfl_xor((int)v, 1);
+        v |= (uint32_t)__shfl_xor((int)v, 2);
+        v |= (uint32_t)__shfl_xor((int)v, 4);
+        if ((threadIdx.x & 7) == 0)
+          reinterpret_cast<uint32_t*>(out)[(t * U + u) * (AGPU_EW_BLOCK / 8) + threadIdx.x / 8] = v;
+      });
+    } else {
+      store_pack<true, T, N>(out + pk0 * N, acc[0]);
+    }
+  }
+}
+
+// one row of the chain, element-granular (tails, unaligned columns)
+template <typename T>
+__device__ __forceinline__ T chain_eval_row(const T* in, uint64_t i, int n_steps, uint64_t code, const ChainPtrs& ptrs) {
+  T acc = in[i];
+  for (int s = 0; s < n_steps; s++) {
+    const int op = chain_op(code, s), kind = chain_kind(code, s);
+    if (kind == AGPU_CHAIN_UNARY) {
+      acc = chain_apply_unary<T, true>(op, acc);
+    } else {
+      const T* q = nullptr;
+      static_for<AGPU_CHAIN_MAX_STEPS>([&](auto j) {
+        if (j == s) q = static_cast<const T*>(ptrs.p[j]);
+      });
+      acc = chain_apply_binary<T>(op, acc, kind == AGPU_CHAIN_ARRAY ? q[i] : q[0]);
+    }
+  }
+  return acc;
+}
+
+// compare tail: one 32-bit output word per thread, words [first_word, n_words); bits past n are written as 0
+template <typename T>
+__global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_cmp_tail_kernel(const T* in, uint32_t* out, uint64_t first_word,
+                                                                      uint64_t n_words, uint64_t n, int n_steps,
+                                                                      uint64_t code, ChainPtrs ptrs, int cmp_op) {
+  for (uint64_t w = first_word + (uint64_t)blockIdx.x * AGPU_EW_BLOCK + threadIdx.x; w < n_words;
+       w += (uint64_t)gridDim.x * AGPU_EW_BLOCK) {
+    const T* q = nullptr;
+    static_for<AGPU_CHAIN_MAX_STEPS>([&](auto j) {
+      if (j == n_steps) q = static_cast<const T*>(ptrs.p[j]);
+    });
+    const bool arr = chain_kind(code, n_steps) == AGPU_CHAIN_ARRAY;
+    uint32_t m = 0;
+    for (uint32_t k = 0; k < 32 && w * 32 + k < n; k++) {
+      const uint64_t i = w * 32 + k;
+      const T acc = chain_eval_row<T>(in, i, n_steps, code, ptrs);
+      m |= (uint32_t)chain_cmp_pred<T>(cmp_op, acc, arr ? q[i] : q[0]) << k;
+    }
+    out[w] = m;
   }
 }
 
@@ -1143,55 +1233,56 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_tail_kernel(const T* in, 
                                                                   int n_steps, uint64_t code, ChainPtrs ptrs) {
   for (uint64_t i = first + (uint64_t)blockIdx.x * AGPU_EW_BLOCK + threadIdx.x; i < n;
        i += (uint64_t)gridDim.x * AGPU_EW_BLOCK) {
-    T acc = in[i];
-    for (int s = 0; s < n_steps; s++) {
-      const int op = chain_op(code, s), kind = chain_kind(code, s);
-      if (kind == AGPU_CHAIN_UNARY) {
-        acc = chain_apply_unary<T, true>(op, acc);
-      } else {
-        const T* q = nullptr;
-        static_for<AGPU_CHAIN_MAX_STEPS>([&](auto j) {
-          if (j == s) q = static_cast<const T*>(ptrs.p[j]);
-        });
-        acc = chain_apply_binary<T>(op, acc, kind == AGPU_CHAIN_ARRAY ? q[i] : q[0]);
-      }
-    }
-    out[i] = acc;
+    out[i] = chain_eval_row<T>(in, i, n_steps, code, ptrs);
   }
 }
 
-template <typename T, bool HEAVY, int NARR>
+template <typename T, bool HEAVY, int NARR, bool CMP>
 static void launch_chain_full(agpu_pipeline* p, const T* pi, T* po, uint64_t ntiles, int n_steps, int n_arrs, uint64_t code,
-                              const ChainPtrs& ptrs, const ChainPtrs& arrs) {
+                              const ChainPtrs& ptrs, const ChainPtrs& arrs, int cmp_op) {
   const int grid = stream_grid_for(p, ntiles);
-  hipLaunchKernelGGL((chain_kernel<T, HEAVY, NARR>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, po, ntiles, n_steps,
-                     n_arrs, code, ptrs, arrs);
+  hipLaunchKernelGGL((chain_kernel<T, HEAVY, NARR, CMP>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, po, ntiles,
+                     n_steps, n_arrs, code, ptrs, arrs, cmp_op);
 }
 
+// cmp_op < 0: plain chain, `out` is a T column.  cmp_op ≥ 0: slot n_steps of code / ptrs describes the compare's operand
+// and `out` is the packed result bitmap (whole 64-bit words are written, bits past n as 0).
 template <typename T>
 static agpu_status launch_chain(agpu_pipeline* p, const void* in, void* out, uint64_t n, int n_steps, uint64_t code,
-                                const ChainPtrs& ptrs, bool vec_ok, bool heavy) {
+                                const ChainPtrs& ptrs, bool vec_ok, bool heavy, int cmp_op) {
   const T* pi = static_cast<const T*>(in);
   T* po = static_cast<T*>(out);
-  constexpr uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * 4;
+  const bool cmp = cmp_op >= 0;
+  const int n_slots = n_steps + (cmp ? 1 : 0);  // step slots in use, including the compare's operand
+  const uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * 4 * (cmp ? AGPU_CHAIN_CMP_U : 1);
   const uint64_t ntiles = vec_ok ? n / tile_rows : 0;
   if (ntiles) {
     ChainPtrs arrs{}, scal;
     int n_arrs = 0;
     for (int s = 0; s < AGPU_CHAIN_MAX_STEPS; s++) {
-      scal.p[s] = (s < n_steps && ptrs.p[s]) ? ptrs.p[s] : in;  // every slot readable: the kernel loads all eight
-      if (s < n_steps && chain_kind(code, s) == AGPU_CHAIN_ARRAY) arrs.p[n_arrs++] = ptrs.p[s];
+      scal.p[s] = (s < n_slots && ptrs.p[s]) ? ptrs.p[s] : in;  // every slot readable: the kernel loads all eight
+      if (s < n_slots && chain_kind(code, s) == AGPU_CHAIN_ARRAY) arrs.p[n_arrs++] = ptrs.p[s];
     }
     const int slots = n_arrs == 0 ? 0 : n_arrs <= 2 ? 2 : n_arrs <= 4 ? 4 : 8;
-#define AGPU_CHAIN_CASE(H, A)                                                                   \
-  if (heavy == H && slots == A) launch_chain_full<T, H, A>(p, pi, po, ntiles, n_steps, n_arrs, code, scal, arrs);
+#define AGPU_CHAIN_CASE(H, A)                                                                                           \
+  if (heavy == H && slots == A) {                                                                                       \
+    if (cmp) launch_chain_full<T, H, A, true>(p, pi, po, ntiles, n_steps, n_arrs, code, scal, arrs, cmp_op);            \
+    else launch_chain_full<T, H, A, false>(p, pi, po, ntiles, n_steps, n_arrs, code, scal, arrs, cmp_op);              \
+  }
     if constexpr (std::is_floating_point<T>::value) {
       AGPU_CHAIN_CASE(true, 0) AGPU_CHAIN_CASE(true, 2) AGPU_CHAIN_CASE(true, 4) AGPU_CHAIN_CASE(true, 8)
     }
     AGPU_CHAIN_CASE(false, 0) AGPU_CHAIN_CASE(false, 2) AGPU_CHAIN_CASE(false, 4) AGPU_CHAIN_CASE(false, 8)
 #undef AGPU_CHAIN_CASE
   }
-  if (ntiles * tile_rows < n) {
+  if (cmp) {
+    const uint64_t first_word = ntiles * (tile_rows / 32), n_words = (n + 63) / 64 * 2;
+    if (first_word < n_words) {
+      const int grid = stream_grid_for(p, (n_words - first_word + AGPU_EW_BLOCK - 1) / AGPU_EW_BLOCK);
+      hipLaunchKernelGGL((chain_cmp_tail_kernel<T>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi,
+                         static_cast<uint32_t*>(out), first_word, n_words, n, n_steps, code, ptrs, cmp_op);
+    }
+  } else if (ntiles * tile_rows < n) {
     const uint64_t rest = n - ntiles * tile_rows;
     const int grid = stream_grid_for(p, (rest + AGPU_EW_BLOCK - 1) / AGPU_EW_BLOCK);
     hipLaunchKernelGGL((chain_tail_kernel<T>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, po, ntiles * tile_rows, n,
@@ -1203,10 +1294,13 @@ static agpu_status launch_chain(agpu_pipeline* p, const void* in, void* out, uin
 
 extern "C" {
 
-agpu_status agpu_fused_chain(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
-                             int32_t n_steps, void* out, uint64_t n) {
+// cmp_op < 0: agpu_fused_chain.  cmp_op ≥ 0: agpu_fused_chain_compare — the compare's operand rides in step slot n_steps.
+static agpu_status chain_dispatch(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
+                                  int32_t n_steps, void* out, uint64_t n, int cmp_op, int cmp_kind, const void* cmp_operand) {
   AGPU_BIND(p);
-  AGPU_REQUIRE(n_steps >= 0 && n_steps <= AGPU_CHAIN_MAX_STEPS, AGPU_ERR_ARG, "0..8 steps per chain");
+  const bool cmp = cmp_op >= 0;
+  AGPU_REQUIRE(n_steps >= 0 && n_steps + (cmp ? 1 : 0) <= AGPU_CHAIN_MAX_STEPS, AGPU_ERR_ARG,
+               "0..8 steps per chain (0..7 before a compare)");
   AGPU_REQUIRE(n == 0 || (in && out && (n_steps == 0 || steps)), AGPU_ERR_ARG, "null pointer");
   if (n == 0) return AGPU_OK;
   if (dtype == AGPU_DATE32) dtype = AGPU_I32;
@@ -1214,7 +1308,16 @@ agpu_status agpu_fused_chain(agpu_pipeline* p, agpu_dtype dtype, const void* in,
                "fused chains: f32, i32, u32 columns");
   ChainPtrs ptrs{};
   uint64_t code = 0;
-  bool vec_ok = aligned16(in) && aligned16(out), heavy = false;
+  bool vec_ok = aligned16(in) && (cmp ? aligned_to(out, 8) : aligned16(out)), heavy = false;
+  if (cmp) {
+    AGPU_REQUIRE(cmp_op <= AGPU_CMP_EQ, AGPU_ERR_ARG, "bad compare op");
+    AGPU_REQUIRE(cmp_kind == AGPU_CHAIN_SCALAR || cmp_kind == AGPU_CHAIN_ARRAY, AGPU_ERR_ARG, "bad compare operand kind");
+    AGPU_REQUIRE(cmp_operand, AGPU_ERR_ARG, "null compare operand");
+    AGPU_REQUIRE(aligned_to(out, 8), AGPU_ERR_SHAPE, "bitmaps must be 8-byte aligned");
+    code |= ((uint64_t)(cmp_kind & 3) << 4) << (6 * n_steps);
+    ptrs.p[n_steps] = cmp_operand;
+    if (cmp_kind == AGPU_CHAIN_ARRAY && !aligned16(cmp_operand)) vec_ok = false;
+  }
   for (int s = 0; s < n_steps; s++) {
     code |= ((uint64_t)(steps[s].op & 15) | ((uint64_t)(steps[s].kind & 3) << 4)) << (6 * s);
     ptrs.p[s] = steps[s].operand;
@@ -1235,10 +1338,21 @@ agpu_status agpu_fused_chain(agpu_pipeline* p, agpu_dtype dtype, const void* in,
     }
   }
   switch (dtype) {
-    case AGPU_F32: return launch_chain<float>(p, in, out, n, n_steps, code, ptrs, vec_ok, heavy);
-    case AGPU_I32: return launch_chain<int32_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, false);
-    default: return launch_chain<uint32_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, false);
+    case AGPU_F32: return launch_chain<float>(p, in, out, n, n_steps, code, ptrs, vec_ok, heavy, cmp_op);
+    case AGPU_I32: return launch_chain<int32_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, false, cmp_op);
+    default: return launch_chain<uint32_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, false, cmp_op);
   }
+}
+
+agpu_status agpu_fused_chain(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
+                             int32_t n_steps, void* out, uint64_t n) {
+  return chain_dispatch(p, dtype, in, steps, n_steps, out, n, -1, 0, nullptr);
+}
+
+agpu_status agpu_fused_chain_compare(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
+                                     int32_t n_steps, agpu_cmp_op cmp_op, int32_t operand_kind, const void* operand,
+                                     void* out_bits, uint64_t n) {
+  return chain_dispatch(p, dtype, in, steps, n_steps, out_bits, n, (int)cmp_op, operand_kind, operand);
 }
 
 agpu_status agpu_binary(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, const void* a, const void* b, void* out,

@@ -86,6 +86,44 @@ class FusedChain:
         p.finish()
         return out
 
+    # ---- terminal compare: the predicate (chain(a) cmp other) → BooleanArrayGPU without storing the chain's result
+    def _compare_op(self, name: str, op: int, other, pipeline: ArrowComputePipeline):
+        from ..array import BooleanArrayGPU, bitmap_bytes
+
+        a = self.src
+        if type(other).NP_DTYPE != type(a).NP_DTYPE:
+            raise OperationNotSupported(f"Operation {name} not supported for type {a.get_dtype().name} {other.get_dtype().name}")
+        if len(self.steps) >= MAX_STEPS:
+            raise ArrowErrorGPU("ShapeError", f"a fused chain holds at most {MAX_STEPS - 1} steps before a compare", capi.ERR_SHAPE)
+        scalar = other.len == 1 and a.len != 1
+        if not scalar and other.len != a.len:
+            raise ArrowErrorGPU("ShapeError", f"{name}: arrays of different length", capi.ERR_SHAPE)
+        dev = a.gpu_device
+        out = dev.create_empty_buffer(max(bitmap_bytes(a.len), 8))
+        steps = (_Step * max(len(self.steps), 1))()
+        nulls, merged = a.null_buffer, False
+        for i, (sop, kind, operand) in enumerate(self.steps):
+            steps[i].op, steps[i].kind = sop, kind
+            steps[i].operand = operand.data.ptr if operand is not None else None
+            if kind == ARRAY and operand.null_buffer is not None:
+                nulls, merged = NullBitBufferGpu.merge_null_bit_buffer_op(nulls, operand.null_buffer, pipeline), True
+            if operand is not None:
+                pipeline.keep(operand.data)
+        if not scalar and other.null_buffer is not None:  # compare: validity AND with the array operand's
+            nulls, merged = NullBitBufferGpu.merge_null_bit_buffer_op(nulls, other.null_buffer, pipeline), True
+        if not merged:
+            nulls = NullBitBufferGpu.clone_null_bit_buffer_op(nulls, pipeline)
+        capi.call("agpu_fused_chain_compare", pipeline._handle, a.DTYPE, vp(a.data), C.cast(steps, C.c_void_p), len(self.steps),
+                  op, SCALAR if scalar else ARRAY, vp(other.data), vp(out), a.len)
+        pipeline.keep(a.data, other.data, out)
+        return BooleanArrayGPU(out, dev, a.len, nulls)
+
+    def _compare(self, name: str, op: int, other):
+        p = ArrowComputePipeline(self.src.get_gpu_device(), "fused_chain_compare")
+        out = self._compare_op(name, op, other, p)
+        p.finish()
+        return out
+
 
 def _make_binary(name):
     def method(self, other):
@@ -121,5 +159,22 @@ for _n in ("add", "sub", "mul", "div", "rem"):
     setattr(FusedChain, _n + "_scalar", _make_scalar(_n))
 for _n in _UNARY:
     setattr(FusedChain, _n, _make_unary(_n))
+
+
+def _make_compare(name, op):
+    def method(self, other):
+        return self._compare(name, op, other)
+
+    def method_op(self, other, pipeline):
+        return self._compare_op(name, op, other, pipeline)
+
+    method.__name__, method_op.__name__ = name, name + "_op"
+    return method, method_op
+
+
+for _n, _op in (("gt", capi.CMP_GT), ("gteq", capi.CMP_GTEQ), ("lt", capi.CMP_LT), ("lteq", capi.CMP_LTEQ), ("eq", capi.CMP_EQ)):
+    _m, _mop = _make_compare(_n, _op)
+    setattr(FusedChain, _n, _m)
+    setattr(FusedChain, _n + "_op", _mop)
 
 __all__ = ["FusedChain"]

@@ -250,6 +250,13 @@ typedef struct {
 #define AGPU_CHAIN_MAX_STEPS 8
 agpu_status agpu_fused_chain(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
                              int32_t n_steps, void* out, uint64_t n);
+/* The same chain ending in a compare — a predicate such as (a * b + c) > d in one pass: the chain's result is never
+ * stored, out_bits bit i = chain(in)[i] cmp operand (operand_kind AGPU_CHAIN_SCALAR: 1 element, AGPU_CHAIN_ARRAY: n
+ * elements), packed like agpu_compare (agpu_bitmap_bytes(n) bytes, padding bits 0).  n_steps ≤ 7 (0 = plain compare).
+ * Bit-identical to agpu_fused_chain followed by agpu_compare [ref: Compare::*_op crates/compare/src/lib.rs:142-162]. */
+agpu_status agpu_fused_chain_compare(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
+                                     int32_t n_steps, agpu_cmp_op cmp_op, int32_t operand_kind, const void* operand,
+                                     void* out_bits, uint64_t n);
 
 /* ---------------------------------------------------------------- compare → bitmap
  * out_bits bit i = a[i] cmp b[i], LSB-first, agpu_bitmap_bytes(n) bytes written, padding bits 0.

@@ -184,3 +184,81 @@ def test_fusing_pipeline_keeps_live_and_reused_intermediates(ag):
     q.sync()  # sync (like anything that needs the stream) issues what is recorded
     assert q.stats["fused_chains"] == 2 and q.stats["fused_ops"] == 11 and q.stats["kernels"] == 2
     assert np.array_equal(x.raw_values(), (O.synth_i32(n, 1, 0, 0).astype(np.int64) + 33).astype(np.int32))
+
+
+# ---------------------------------------------------------------- chains ending in a compare (agpu_fused_chain_compare)
+@pytest.mark.parametrize("n", [1, 63, 256, 257, 4099, 1_000_003])
+def test_chain_compare_equals_unfused_predicate(ag, n):
+    dev = ag.GPU_DEVICE()
+    nulls = n < 5000
+    a, b, c, d = (_rand(ag, dev, n, s, nulls=nulls and s != 3) for s in (1, 2, 3, 4))
+    s = ag.Float32ArrayGPU.from_slice([0.25], dev)
+    for name in ("gt", "gteq", "lt", "lteq", "eq"):
+        fused = getattr(ag.FusedChain(a).mul(b).add(c), name)(d)
+        unfused = getattr(a.mul(b).add(c), name)(d)
+        assert bits(fused.raw_values()) == bits(unfused.raw_values()), (name, n)
+        assert (fused.null_buffer is None) == (unfused.null_buffer is None)
+        if fused.null_buffer is not None:
+            assert bits(fused.null_buffer.raw_values()) == bits(unfused.null_buffer.raw_values())
+    # scalar operand, heavy chain, and the zero-step form (a plain compare)
+    f2, u2 = ag.FusedChain(a).abs().sqrt().sin().lt(s), a.abs().sqrt().sin().lt(ag.Float32ArrayGPU.broadcast(0.25, n, dev))
+    assert bits(f2.raw_values()) == bits(u2.raw_values())
+    assert bits(ag.FusedChain(a).gteq(b).raw_values()) == bits(a.gteq(b).raw_values())
+    ia = ag.Int32ArrayGPU.from_slice(O.synth_i32(n, 1, 0, 100), dev)
+    ib = ag.Int32ArrayGPU.from_slice(O.synth_i32(n, 2, 0, 100), dev)
+    k = ag.Int32ArrayGPU.from_slice([50], dev)
+    assert bits(ag.FusedChain(ia).add(ib).rem_scalar(k).eq(ib).raw_values()) == bits(ia.add(ib).rem_scalar(k).eq(ib).raw_values())
+
+
+def test_chain_compare_limits_and_timing(ag):
+    dev = ag.GPU_DEVICE()
+    x = ag.Float32ArrayGPU.from_slice([1.0, 2.0], dev)
+    ch = ag.FusedChain(x)
+    for _ in range(8):
+        ch.abs()
+    with pytest.raises(ag.ArrowErrorGPU):
+        ch.gt(x)  # at most 7 steps before a compare
+    with pytest.raises(ag.OperationNotSupported):
+        ag.FusedChain(x).gt(ag.Int32ArrayGPU.from_slice([1, 2], dev))
+    # (a * b + c) > d at 2^28 rows: 16 B/row + 1 bit instead of 12 + 12 + 8.125 B/row
+    n = 1 << 28
+    p = ag.ArrowComputePipeline(dev, "pred-timing")
+    q = ag.CmpQuery(dev)
+    a, b, c, d, t1, t2 = (dev.create_empty_buffer(4 * n) for _ in range(6))
+    ob1, ob2 = dev.create_empty_buffer(n // 8), dev.create_empty_buffer(n // 8)
+    for buf, seed in ((a, 1), (b, 2), (c, 3), (d, 4)):
+        capi.call("agpu_synth_f32", p._handle, C.c_void_p(buf.ptr), n, seed, 0, C.c_float(-1), C.c_float(1))
+
+    class Step(C.Structure):
+        _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+    steps = (Step * 2)()
+    steps[0].op, steps[0].kind, steps[0].operand = capi.OP_MUL, 2, b.ptr
+    steps[1].op, steps[1].kind, steps[1].operand = capi.OP_ADD, 2, c.ptr
+    vp = lambda x: C.c_void_p(x.ptr)  # noqa: E731
+
+    def unfused():
+        capi.call("agpu_binary", p._handle, capi.OP_MUL, capi.F32, vp(a), vp(b), vp(t1), n)
+        capi.call("agpu_binary", p._handle, capi.OP_ADD, capi.F32, vp(t1), vp(c), vp(t2), n)
+        capi.call("agpu_compare", p._handle, capi.CMP_GT, capi.F32, vp(t2), vp(d), vp(ob1), n)
+
+    def fused():
+        capi.call("agpu_fused_chain_compare", p._handle, capi.F32, vp(a), C.cast(steps, C.c_void_p), 2, capi.CMP_GT, 2, vp(d),
+                  vp(ob2), n)
+
+    def time(f):
+        f()
+        p.sync()
+        ts = []
+        for _ in range(5):
+            q.begin(p)
+            f()
+            q.end(p)
+            ts.append(q.wait_for_results())
+        return float(np.median(ts))
+
+    t_unfused, t_fused = time(unfused), time(fused)
+    assert bits(dev.retrive_data(ob1, n // 8, pipeline=p)) == bits(dev.retrive_data(ob2, n // 8, pipeline=p))
+    print(f"predicate (a*b+c)>d, 2^28 rows: unfused {t_unfused:.3f} ms, fused {t_fused:.3f} ms "
+          f"({16.125 * n / t_fused / 1e9:.2f} TB/s)")
+    assert t_fused < 0.62 * t_unfused
