@@ -124,6 +124,7 @@ class _ChainStep(C.Structure):
 _FUSE_DEFAULT = os.environ.get("AGPU_FUSE", "0") not in ("", "0")
 _CHAIN_MAX = 8
 _UNARY, _SCALAR, _ARRAY = 0, 1, 2
+_CMP = 3  # recorded compare (array operand): may only END a chain; `op` is an agpu_cmp_op, `out` the result bitmap
 
 
 class ArrowComputePipeline:
@@ -176,7 +177,9 @@ class ArrowComputePipeline:
 
     def _launch_single(self, nd: _LazyNode) -> None:
         vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
-        if nd.kind == _UNARY:
+        if nd.kind == _CMP:
+            capi.call("agpu_compare", self._h, nd.op, nd.dtype, vp(nd.a), vp(nd.operand), vp(nd.out), nd.n)
+        elif nd.kind == _UNARY:
             capi.call("agpu_unary", self._h, nd.op, nd.dtype, vp(nd.a), vp(nd.out), nd.n)
         elif nd.kind == _SCALAR:
             capi.call("agpu_scalar", self._h, nd.op, nd.dtype, vp(nd.a), vp(nd.operand), vp(nd.out), nd.n)
@@ -193,7 +196,7 @@ class ArrowComputePipeline:
         i = 0
         while i < len(nodes):
             chain = [nodes[i]]
-            while len(chain) < _CHAIN_MAX and i + len(chain) < len(nodes):
+            while len(chain) < _CHAIN_MAX and chain[-1].kind != _CMP and i + len(chain) < len(nodes):
                 last, nxt = chain[-1], nodes[i + len(chain)]
                 # dead intermediate: the caller dropped the array object AND nothing else holds its buffer — exactly
                 # three references remain (last.out, nxt.a, getrefcount's argument).  A bitcast view sharing the
@@ -207,12 +210,19 @@ class ArrowComputePipeline:
             if len(chain) == 1:
                 self._launch_single(chain[0])
             else:
-                steps = (_ChainStep * len(chain))()
-                for k, nd in enumerate(chain):
+                body = chain[:-1] if chain[-1].kind == _CMP else chain
+                steps = (_ChainStep * len(body))()
+                for k, nd in enumerate(body):
                     steps[k].op, steps[k].kind = nd.op, nd.kind
                     steps[k].operand = nd.operand.ptr if nd.operand is not None else None
-                capi.call("agpu_fused_chain", self._h, chain[0].dtype, C.c_void_p(chain[0].a.ptr), C.cast(steps, C.c_void_p),
-                          len(chain), C.c_void_p(chain[-1].out.ptr), chain[0].n)
+                if chain[-1].kind == _CMP:  # the chain's value is only compared, never stored
+                    cmp = chain[-1]
+                    capi.call("agpu_fused_chain_compare", self._h, chain[0].dtype, C.c_void_p(chain[0].a.ptr),
+                              C.cast(steps, C.c_void_p), len(body), cmp.op, _ARRAY, C.c_void_p(cmp.operand.ptr),
+                              C.c_void_p(cmp.out.ptr), chain[0].n)
+                else:
+                    capi.call("agpu_fused_chain", self._h, chain[0].dtype, C.c_void_p(chain[0].a.ptr), C.cast(steps, C.c_void_p),
+                              len(chain), C.c_void_p(chain[-1].out.ptr), chain[0].n)
                 self.stats["kernels"] += 1
                 self.stats["fused_chains"] += 1
                 self.stats["fused_ops"] += len(chain)

@@ -11,7 +11,7 @@ from .. import _capi as capi
 from ..array import (BooleanArrayGPU, Date32ArrayGPU, Float32ArrayGPU, Int8ArrayGPU, Int16ArrayGPU, Int32ArrayGPU,
                      NullBitBufferGpu, UInt8ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU, bitmap_bytes)
 from ..gpu_utils import ArrowComputePipeline
-from ._ops import array_op, check_same_len, dyn_binary, impl, vp
+from ._ops import _finish_record, _recordable, array_op, check_same_len, dyn_binary, impl, vp
 
 _ALL = (Float32ArrayGPU, UInt32ArrayGPU, UInt16ArrayGPU, UInt8ArrayGPU, Int32ArrayGPU, Int16ArrayGPU, Int8ArrayGPU,
         Date32ArrayGPU)
@@ -25,6 +25,12 @@ def _cmp_op(op: int):
         out = dev.create_empty_buffer(max(bitmap_bytes(n), 8))
         va, vb = self.null_buffer, operand.null_buffer
         nulls = None
+        if _recordable(pipeline, 2, capi.OP_ADD, self.DTYPE, operand.ITEM_SIZE == self.ITEM_SIZE):
+            # fusing pipeline: the compare is only recorded — it may end a fused chain (agpu_fused_chain_compare) whose
+            # value is then never stored; validity is bitmap work and does not wait for the recorded value kernels
+            node = pipeline.record_elementwise(3, op, self.DTYPE, self.data, operand.data, out, n)
+            result = BooleanArrayGPU(out, dev, n, NullBitBufferGpu.merge_null_bit_buffer_op(va, vb, pipeline))
+            return _finish_record(node, result)
         if va is None and vb is None:
             capi.call("agpu_compare", pipeline._handle, op, self.DTYPE, vp(self.data), vp(operand.data), vp(out), n)
         else:

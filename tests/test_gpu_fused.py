@@ -262,3 +262,18 @@ def test_chain_compare_limits_and_timing(ag):
     print(f"predicate (a*b+c)>d, 2^28 rows: unfused {t_unfused:.3f} ms, fused {t_fused:.3f} ms "
           f"({16.125 * n / t_fused / 1e9:.2f} TB/s)")
     assert t_fused < 0.62 * t_unfused
+
+
+def test_fusing_pipeline_ends_chains_in_compares(ag):
+    dev = ag.GPU_DEVICE()
+    n = 70_001
+    a, b, c, d = (_rand(ag, dev, n, s) for s in (11, 12, 13, 14))
+    p = ag.ArrowComputePipeline(dev, "predicate", fuse=True)
+    m = a.mul_op(b, p).add_op(c, p).gt_op(d, p)      # (a * b + c) > d — nothing is stored but the bitmap
+    keep = a.sub_op(b, p)
+    m2 = keep.lteq_op(c, p)                          # `keep` is alive: materialised, compare runs on its own
+    p.finish()
+    assert p.stats == {"recorded": 5, "kernels": 3, "fused_chains": 1, "fused_ops": 3}
+    assert bits(m.raw_values()) == bits(a.mul(b).add(c).gt(d).raw_values())
+    assert bits(m2.raw_values()) == bits(a.sub(b).lteq(c).raw_values())
+    assert bits(keep.raw_values()) == bits(a.sub(b).raw_values())
