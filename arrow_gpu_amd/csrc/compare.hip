@@ -164,12 +164,28 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_word_kernel(const T* a, const 
   }
 }
 
+template <typename T, int OP, int U>
+static uint64_t launch_cmp_vec(agpu_pipeline* p, const T* pa, const T* pb, const void* va, const void* vb, void* out,
+                               void* outv, uint64_t n, bool nt, int vec16) {
+  constexpr int N = 16 / sizeof(T);
+  constexpr uint64_t TILE = (uint64_t)AGPU_BLOCK * U * N;
+  const uint64_t ntiles = n / TILE;
+  if (ntiles) {
+    const uint64_t nvb = outv ? (ntiles * (TILE / 64) + CMP_VBLOCK_WORDS - 1) / CMP_VBLOCK_WORDS : 0;
+    const int grid = stream_grid_for(p, ntiles + nvb);
+    auto k = nt ? cmp_vec_kernel<T, OP, U, true> : cmp_vec_kernel<T, OP, U, false>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, static_cast<const uint32_t*>(va),
+                       static_cast<const uint32_t*>(vb), static_cast<uint32_t*>(out), static_cast<uint32_t*>(outv), ntiles,
+                       nvb, vec16);
+  }
+  return ntiles * TILE;
+}
+
 template <typename T, int OP>
 static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, const void* va, const void* vb,
                               void* out, void* outv, uint64_t n) {
   const T* pa = static_cast<const T*>(a);
   const T* pb = static_cast<const T*>(b);
-  constexpr int U = 1;
   const bool use_ballot = sizeof(T) == 4 && g_tune.cmp_variant == 0;
   const bool nt = (g_tune.stream_nt & 1) != 0;  // inputs are read exactly once: nontemporal loads
   const uint64_t* va64 = static_cast<const uint64_t*>(va);
@@ -190,18 +206,11 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
     }
     done_rows = ntiles * TILE;
   } else if (aligned16(a) && aligned16(b)) {
-    constexpr int N = 16 / sizeof(T);
-    constexpr uint64_t TILE = (uint64_t)AGPU_BLOCK * U * N;
-    const uint64_t ntiles = n / TILE;
-    if (ntiles) {
-      const uint64_t nvb = outv ? (ntiles * (TILE / 64) + CMP_VBLOCK_WORDS - 1) / CMP_VBLOCK_WORDS : 0;
-      const int grid = stream_grid_for(p, ntiles + nvb);
-      auto k = nt ? cmp_vec_kernel<T, OP, U, true> : cmp_vec_kernel<T, OP, U, false>;
-      hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, static_cast<const uint32_t*>(va),
-                         static_cast<const uint32_t*>(vb), static_cast<uint32_t*>(out), static_cast<uint32_t*>(outv),
-                         ntiles, nvb, vec16);
-    }
-    done_rows = ntiles * TILE;
+    // packs per lane and array in flight: 1 by default; "stream_unroll" = 2 / 4 for sweeps
+    const int u = g_tune.stream_unroll == 2 || g_tune.stream_unroll == 4 ? (int)g_tune.stream_unroll : 1;
+    if (u == 4) done_rows = launch_cmp_vec<T, OP, 4>(p, pa, pb, va, vb, out, outv, n, nt, vec16);
+    else if (u == 2) done_rows = launch_cmp_vec<T, OP, 2>(p, pa, pb, va, vb, out, outv, n, nt, vec16);
+    else done_rows = launch_cmp_vec<T, OP, 1>(p, pa, pb, va, vb, out, outv, n, nt, vec16);
   }
   if (done_rows < n) {
     const uint64_t first_word = done_rows / 64, nwords = (n + 63) / 64;
