@@ -84,10 +84,22 @@ __global__ __launch_bounds__(AGPU_BLOCK) void popcount_kernel(const uint64_t* bi
   const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
   uint64_t c = 0;
-  for (uint64_t i = tid; i < n_full; i += stride) {
-    const uint64_t w = bits[i];
-    c += ANY ? (uint64_t)(w != 0) : (uint64_t)__popcll(w);
+  auto count = [](uint64_t w) { return ANY ? (uint64_t)(w != 0) : (uint64_t)__popcll(w); };
+  // read-only and grid-capped (one atomic per block): keep 4 × 16 bytes per lane in flight or the kernel is bound by
+  // latency, not HBM (0.037 → 0.02x ms on a 125 MB bitmap)
+  const uint64_t n_pairs = ((reinterpret_cast<uintptr_t>(bits) & 15u) == 0) ? n_full / 2 : 0;
+  const u64x2* b2 = reinterpret_cast<const u64x2*>(bits);
+  uint64_t i = tid;
+  for (; i + 3 * stride < n_pairs; i += 4 * stride) {
+    const u64x2 w0 = __builtin_nontemporal_load(b2 + i), w1 = __builtin_nontemporal_load(b2 + i + stride),
+                w2 = __builtin_nontemporal_load(b2 + i + 2 * stride), w3 = __builtin_nontemporal_load(b2 + i + 3 * stride);
+    c += count(w0.x) + count(w0.y) + count(w1.x) + count(w1.y) + count(w2.x) + count(w2.y) + count(w3.x) + count(w3.y);
   }
+  for (; i < n_pairs; i += stride) {
+    const u64x2 w = b2[i];
+    c += count(w.x) + count(w.y);
+  }
+  for (uint64_t j = n_pairs * 2 + tid; j < n_full; j += stride) c += count(bits[j]);
   if (tid == 0 && (n_bits & 63)) {
     const uint64_t w = bits[n_full] & ((1ull << (n_bits & 63)) - 1ull);
     c += ANY ? (uint64_t)(w != 0) : (uint64_t)__popcll(w);

@@ -287,9 +287,11 @@ __global__ __launch_bounds__(AGPU_BLOCK) void reduce_finish_kernel(const typenam
   if (threadIdx.x == 0) out[0] = Red::finish(r);
 }
 
-static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks) {
-  // many small blocks stream better than a few persistent ones on this chip (profiles/r01_sweep_add_f32_1e9.json)
-  int64_t g = g_tune.reduce_grid > 0 ? g_tune.reduce_grid : (int64_t)p->dev->num_cus * 64;
+// blocks_per_cu: 16 for the partial reductions (read-only grid-stride loops with 4 packs per lane in flight: 6.47 / 6.65 /
+// 6.70 TB/s for min / f64 sum / i32 sum vs 6.31 / 6.45 / 6.58 at 64 per CU), 64 for the span-per-block tree sum (6.18 vs
+// 5.96–6.07 at 8–32 per CU) — tools/probe/reduce_sweep.py, one process, same buffer.
+static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks, int blocks_per_cu) {
+  int64_t g = g_tune.reduce_grid > 0 ? g_tune.reduce_grid : (int64_t)p->dev->num_cus * blocks_per_cu;
   if ((uint64_t)g > work_blocks) g = (int64_t)work_blocks;
   if (g < 1) g = 1;
   return (int)g;
@@ -299,7 +301,7 @@ template <typename T, typename Red>
 static agpu_status launch_reduce(agpu_pipeline* p, const void* in, const void* validity, uint64_t n, void* out) {
   typedef typename Red::Acc A;
   constexpr int U = 4;
-  const int grid = reduce_grid_for(p, (n / 4 + (uint64_t)AGPU_BLOCK * U - 1) / ((uint64_t)AGPU_BLOCK * U));
+  const int grid = reduce_grid_for(p, (n / 4 + (uint64_t)AGPU_BLOCK * U - 1) / ((uint64_t)AGPU_BLOCK * U), 16);
   void* scratch = nullptr;
   agpu_status st = agpu_scratch(p, sizeof(A) * (size_t)grid, &scratch);
   if (st != AGPU_OK) return st;
@@ -331,7 +333,7 @@ static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const 
     AGPU_LAUNCH_CHECK();
     return AGPU_OK;
   }
-  const int grid = reduce_grid_for(p, nspans);
+  const int grid = reduce_grid_for(p, nspans, 64);
   if (validity)
     hipLaunchKernelGGL((sum_tree_span_kernel<true>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, in, validity, n, partials);
   else
