@@ -903,6 +903,50 @@ class FusedChain {
     p.finish();
     return out;
   }
+
+  // terminal compare: the predicate chain(a) cmp other → BooleanArrayGPU, the chain's value is never stored
+  BooleanArrayGPU compare_op(agpu_cmp_op op, const Arr& other, ArrowComputePipeline& p) const {
+    if (steps_.size() >= AGPU_CHAIN_MAX_STEPS) throw ArrowErrorGPU(ArrowErrorGPU::Runtime, "at most 7 steps before a compare");
+    const bool scalar = other.len == 1 && src_.len != 1;
+    if (!scalar && other.len != src_.len) throw ArrowErrorGPU(ArrowErrorGPU::Runtime, "compare: arrays of different length");
+    auto out = src_.gpu_device->create_empty_buffer(bitmap_bytes(src_.len) ? bitmap_bytes(src_.len) : 8);
+    std::optional<NullBitBufferGpu> nulls = src_.null_buffer;
+    bool merged = false;
+    size_t k = 0;
+    for (const auto& st : steps_) {
+      if (st.kind == AGPU_CHAIN_UNARY) continue;
+      const Arr& operand = operands_[k++];
+      p.keep.push_back(operand.data);
+      if (st.kind == AGPU_CHAIN_ARRAY && operand.null_buffer) {
+        nulls = NullBitBufferGpu::merge_null_bit_buffer_op(nulls, operand.null_buffer, p);
+        merged = true;
+      }
+    }
+    if (!scalar && other.null_buffer) {
+      nulls = NullBitBufferGpu::merge_null_bit_buffer_op(nulls, other.null_buffer, p);
+      merged = true;
+    }
+    if (!merged) nulls = NullBitBufferGpu::clone_null_bit_buffer_op(nulls, p);
+    check(agpu_fused_chain_compare(p.raw, Arr::DTYPE, src_.data->ptr, steps_.data(), (int32_t)steps_.size(), op,
+                                   scalar ? AGPU_CHAIN_SCALAR : AGPU_CHAIN_ARRAY, other.data->ptr, out->ptr, src_.len),
+          "agpu_fused_chain_compare");
+    p.keep.insert(p.keep.end(), {src_.data, other.data, out});
+    return BooleanArrayGPU(out, src_.gpu_device, src_.len, nulls);
+  }
+#define AGPU_CHAIN_CMP(NAME, OP)                                                                                  \
+  BooleanArrayGPU NAME##_op(const Arr& v, ArrowComputePipeline& p) const { return compare_op(OP, v, p); }         \
+  BooleanArrayGPU NAME(const Arr& v) const {                                                                      \
+    ArrowComputePipeline p(src_.gpu_device);                                                                      \
+    auto out = compare_op(OP, v, p);                                                                              \
+    p.finish();                                                                                                   \
+    return out;                                                                                                   \
+  }
+  AGPU_CHAIN_CMP(gt, AGPU_CMP_GT)
+  AGPU_CHAIN_CMP(gteq, AGPU_CMP_GTEQ)
+  AGPU_CHAIN_CMP(lt, AGPU_CMP_LT)
+  AGPU_CHAIN_CMP(lteq, AGPU_CMP_LTEQ)
+  AGPU_CHAIN_CMP(eq, AGPU_CMP_EQ)
+#undef AGPU_CHAIN_CMP
 };
 template <typename T> FusedChain(const PrimitiveArrayGpu<T>&) -> FusedChain<T>;
 

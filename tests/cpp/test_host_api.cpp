@@ -62,6 +62,10 @@ static void run_compute_pipeline_ops(const DevicePtr& device) {
   auto ia = Int32ArrayGPU::from_slice({1, -2, 3, std::numeric_limits<int32_t>::max()}, device);
   auto ib = Int32ArrayGPU::from_slice({100}, device);
   CHECK(FusedChain(ia).mul(ib).abs().finish().raw_values() == ia.mul_scalar(ib).abs().raw_values());
+  // chain ending in a compare: (x + y) > x  as one pass, same bits and validity as the three-kernel form
+  auto fp = FusedChain(x).add(y).gt(x);
+  auto up = x.add(y).gt(x);
+  CHECK(fp.values() == up.values());
 }
 
 int main() {

@@ -149,6 +149,18 @@ def test_f32_power_hard_domains(D, domain):
     assert max_ulp(got, exp) <= G.MAX_ULP, domain
 
 
+def test_f32_power_exact_for_exponents_one_and_two(D):
+    rng = np.random.default_rng(23)
+    n = 1 << 20
+    a = (2.0 ** rng.uniform(-70, 70, n)).astype(np.float32)
+    out = D.empty(4 * n)
+    with np.errstate(over="ignore"):
+        sq = a * a
+    for e, exp in ((1.0, a), (2.0, sq)):
+        D.call("agpu_scalar", capi.OP_POW, capi.F32, D.up(a).vp, D.up(np.array([e], np.float32)).vp, out.vp, n)
+        assert bits_equal(D.down(out, np.float32, n), exp)  # x^1 = x, x^2 = RN(x·x) (incl. overflow to inf)
+
+
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_unary_exact_ops(D, dtype):
     ops = [capi.UN_NEG, capi.UN_ABS] + ([capi.UN_SQRT] if dtype == capi.F32 else [capi.UN_NOT])
