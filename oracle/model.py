@@ -297,10 +297,14 @@ UInt32ArrayGPU.bitcast_op = lambda self, into, pipeline: _bitcast(self, into)
 
 
 def cast_dyn(a, into):
+    if type(a) not in CAST_TABLE:  # the reference's dyn match falls through to its panic arm
+        raise OracleUnsupported("Casting not supported")
     return a.cast(into)
 
 
 def bitcast_dyn(a, into):
+    if type(a) is not UInt32ArrayGPU:
+        raise OracleUnsupported("Casting not supported")
     return a.bitcast(into)
 
 

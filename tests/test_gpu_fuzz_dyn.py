@@ -5,6 +5,7 @@ which (op, type, type) combinations are rejected (the reference's dyn tables), r
 values (bit-exact; single-step transcendental results within 1 ULP and not fed forward).
 Runs with eager pipelines and with fusing pipelines (AGPU_FUSE behaviour) — the results must not depend on it."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -75,7 +76,7 @@ def compare(got, exp, ulp, what):
 
 
 @pytest.mark.parametrize("fuse", [False, True])
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AGPU_FUZZ_SEEDS", "30"))))
 def test_random_dyn_programs_agree_with_the_model(ag, seed, fuse, monkeypatch):
     import arrow_gpu_amd.gpu_utils as gu
 
@@ -91,8 +92,39 @@ def test_random_dyn_programs_agree_with_the_model(ag, seed, fuse, monkeypatch):
         vals = random_values(rng, name, length)
         pool.append((build(ag, name, vals, dev), build(M, name, vals, None)))
     accepted = rejected = 0
+    type_names = ["BooleanType", "Float32Type", "UInt32Type", "UInt16Type", "UInt8Type", "Int32Type", "Int16Type", "Int8Type",
+                  "Date32Type"]
     for step in range(120):
         r = rng.random()
+        if r < 0.18:  # the other dyn tables: cast / bitcast (type → type), take (gather), merge (select by mask)
+            kind = ("cast_dyn", "bitcast_dyn", "take_dyn", "merge_dyn")[rng.integers(4)]
+            src = pool[rng.integers(len(pool))]
+            if kind in ("cast_dyn", "bitcast_dyn"):
+                tn = type_names[rng.integers(len(type_names))]
+                margs, gargs = (src[1], getattr(M.ArrowType, tn)), (src[0], getattr(ag.ArrowType, tn))
+            elif kind == "take_dyn":
+                idx = rng.integers(0, src[0].len, int(rng.integers(1, 300))).astype(np.uint32)
+                margs, gargs = (src[1], M.UInt32ArrayGPU.from_slice(idx)), (src[0], ag.UInt32ArrayGPU.from_slice(idx, dev))
+            else:
+                same = [q for q in pool if type(q[0]) is type(src[0]) and q[0].len == src[0].len]
+                other = same[rng.integers(len(same))]
+                mvals = random_values(rng, "BooleanArrayGPU", src[0].len)
+                margs = (src[1], other[1], build(M, "BooleanArrayGPU", mvals, None))
+                gargs = (src[0], other[0], build(ag, "BooleanArrayGPU", mvals, dev))
+            what = f"seed {seed} step {step}: {kind}({type(src[0]).__name__}, …)"
+            try:
+                exp = getattr(M, kind)(*margs)
+            except M.OracleUnsupported:
+                with pytest.raises(ag.ArrowErrorGPU):  # OperationNotSupported / CastingNotSupported
+                    getattr(ag, kind)(*gargs)
+                rejected += 1
+                continue
+            got = getattr(ag, kind)(*gargs)
+            compare(got, exp, 0, what)
+            accepted += 1
+            if len(pool) < 40 and got.len == n:
+                pool.append((got, exp))
+            continue
         if r < 0.6:
             fn, ulp, arity = EXACT_BINARY[rng.integers(len(EXACT_BINARY))], 0, 2
         elif r < 0.8:
