@@ -59,7 +59,7 @@ def test_random_abi_calls_match_the_oracle(D, seed):
     rng = np.random.default_rng(5000 + seed)
     for it in range(12):
         fam = ("binary", "scalar", "unary", "compare", "compare_validity", "cast", "bitmap", "reduce", "take", "merge",
-               "chain")[rng.integers(11)]
+               "chain", "shift", "put", "take_bits")[rng.integers(14)]
         n = pick_n(rng)
         dtype = ALL_DTYPES[rng.integers(len(ALL_DTYPES))]
         w = NP[dtype]().itemsize
@@ -136,6 +136,37 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             out = D.empty(max(n * w, 1), offset_bytes=off(rng, w) if w == 4 else 0)
             D.call("agpu_merge", w, D.up(a, off(rng, w) if w == 4 else 0).vp, D.up(b).vp, D.up(m).vp, out.vp, n)
             assert bits_equal(D.down(out, NP[dtype], n), O.merge(w, a, b, m)), what
+        elif fam == "shift":
+            st = INT_DTYPES[rng.integers(len(INT_DTYPES))]
+            ws = NP[st]().itemsize
+            x = rand_values(st, n, seed * 5 + it)
+            amounts = rng.integers(0, 40, n).astype(np.uint32)  # includes amounts ≥ the type width and ≥ 32
+            op = (capi.OP_SHL, capi.OP_SHR)[rng.integers(2)]
+            out = D.empty(max(n * ws, 1), offset_bytes=off(rng, ws))
+            D.call("agpu_binary", op, st, D.up(x, off(rng, ws)).vp, D.up(amounts, off(rng, 4)).vp, out.vp, n)
+            assert bits_equal(D.down(out, NP[st], n), O.binary(op, st, x, amounts)), what
+        elif fam == "put":
+            if n == 0:
+                continue
+            n_dst = n + int(rng.integers(0, 100))
+            k = min(pick_n(rng), n_dst)
+            dst = rand_values(dtype, n_dst, seed * 19 + it)
+            si = rng.integers(0, n, k).astype(np.uint32)
+            di = rng.permutation(n_dst)[:k].astype(np.uint32)  # unique destinations
+            ddst = D.up(dst, off(rng, w))
+            D.call("agpu_put_bounded", w, D.up(a, off(rng, w)).vp, n, D.up(si, off(rng, 4)).vp, ddst.vp, n_dst,
+                   D.up(di, off(rng, 4)).vp, k)
+            assert bits_equal(D.down(ddst, NP[dtype], n_dst), O.put(w, a, si, dst, di)), what
+            assert D.status("agpu_pipeline_sync") == capi.OK
+        elif fam == "take_bits":
+            if n == 0:
+                continue
+            bits_in = O.synth_bits(n, seed, it + 7, 0.5)
+            k = pick_n(rng)
+            idx = rng.integers(0, n, k).astype(np.uint32)
+            outb = D.empty(O.bitmap_bytes(k) + 8)
+            D.call("agpu_take_bits", D.up(bits_in).vp, n, D.up(idx, off(rng, 4)).vp, outb.vp, k)
+            assert bits_equal(D.down(outb, np.uint8, O.bitmap_bytes(k)), O.take_bits(bits_in, n, idx)), what
         else:  # chain of 2–5 exact steps on a 32-bit column, with or without a terminal compare
             import ctypes as C
 
