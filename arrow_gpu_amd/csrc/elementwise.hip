@@ -168,7 +168,7 @@ struct OpPow {  // i32: closed form of the WGSL loop.  (f32 pow runs in pow_kern
   template <typename T> __device__ static __forceinline__ T ap(T x, T y) {
     if constexpr (std::is_floating_point<T>::value) {
       if (x != x || y != y || x < 0.0f || (x == 0.0f && __builtin_signbit(x))) return __builtin_nanf("");
-      return powf(x, y);  // ≤ 1 ULP measured (tools/probe/math_ulp.py); the f64 pow is 4× slower than the stream
+      return powf(x, y);  // ≤ 1 ULP measured (tests/tools/math_ulp.py); the f64 pow is 4× slower than the stream
     } else return (T)i32_pow_dev((int32_t)x, (int32_t)y);
   }
 };
@@ -229,7 +229,7 @@ __device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
 // log: x = m·2^e with m ∈ [√½, √2), s = (m−1)/(m+1), log m = 2s + s·z·P(z), z = s² (|s| ≤ 0.172), P = 2/3 + 2/5 z + …
 // + 2/11 z⁴ evaluated in f32 (it weighs < 1 % of the result), the division as an f32 reciprocal + one f64 Newton step,
 // the rest in f64, ONE rounding to f32.  (The f32 library logf measures 2 ULP on gfx950; the f64 library log is
-// VALU-bound at 37 % of HBM — tools/probe/math_ulp.py, profiles/r01_kernel_table.json.)
+// VALU-bound at 37 % of HBM — tests/tools/math_ulp.py, profiles/r01_kernel_table.json.)
 __device__ __forceinline__ float log_f32_dev(float x) {
   if (!(x > 0.0f) || !(x < __builtin_inff())) {  // 0, negatives, NaN, +inf
     if (x == 0.0f) return -__builtin_inff();
@@ -287,7 +287,7 @@ __device__ __forceinline__ float sinh_f32_dev(float x) {
 }
 
 // The remaining functions use the f32 device library where it measures ≤ 1 ULP on gfx950 over 4 M log-uniform samples
-// (tools/probe/math_ulp.py: acosf, cbrtf, exp2f, log2f, expf, powf = 1 ULP).
+// (tests/tools/math_ulp.py: acosf, cbrtf, exp2f, log2f, expf, powf = 1 ULP).
 struct UnSqrt { __device__ static __forceinline__ float ap(float x, float) { return sqrtf(x); } };  // correctly rounded
 struct UnCbrt { __device__ static __forceinline__ float ap(float x, float) { return cbrtf(x); } };
 struct UnExp { __device__ static __forceinline__ float ap(float x, float) { return expf(x); } };

@@ -6,9 +6,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 import oracle as O
 from arrow_gpu_amd import _capi as capi
 from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from gpu_util import max_ulp
-lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmath_probe.so"))
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tools", "probe", "libmath_probe.so"))
 lib.probe_math.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
 dev = GpuDevice(0); p = ArrowComputePipeline(dev, "m")
 rng = np.random.default_rng(5); n = 1 << 22
