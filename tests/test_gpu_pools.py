@@ -21,7 +21,10 @@ def pool_info(dev):
 
 
 def test_blocks_are_recycled_and_trim_releases_them(ag):
+    import gc
+
     dev = ag.GPU_DEVICE()
+    gc.collect()  # buffers of earlier tests that sit in reference cycles would otherwise land in the pool mid-test
     capi.call("agpu_device_trim", dev._handle)
     assert pool_info(dev)[:2] == (0, 0)
     a = dev.create_empty_buffer(64 << 20)
@@ -57,6 +60,9 @@ def test_recycled_block_waits_for_work_queued_at_free_time(ag):
     a = dev.create_empty_buffer(4 * n)
     capi.call("agpu_synth_f32", p1._handle, vp(a), n, 1, 0, C.c_float(-1), C.c_float(1))
     p1.sync()
+    import gc
+
+    gc.collect()
     capi.call("agpu_device_trim", dev._handle)
     for _ in range(3):
         out = dev.create_empty_buffer(4 * n)
