@@ -206,12 +206,11 @@ class PrimitiveArrayGpu(ArrowArrayGPU):
     @classmethod
     def from_optional_slice(cls, value: Sequence, gpu_device: GpuDevice):
         n = len(value)
-        host = np.zeros(n, dtype=cls.NP_DTYPE)
+        valid = np.fromiter((v is not None for v in value), dtype=bool, count=n)
+        host = np.array([cls._to_native(v) if v is not None else 0 for v in value], dtype=cls.NP_DTYPE).reshape(n)
         builder = BooleanBufferBuilder.new_with_capacity(n)
-        for i, v in enumerate(value):
-            if v is not None:
-                host[i] = cls._to_native(v)
-                builder.set_bit(i)
+        packed = np.packbits(valid, bitorder="little")  # bit i at byte i/8, mask 1 << (i % 8); null slots hold 0
+        builder.data[: len(packed)] = packed
         data = gpu_device.create_gpu_buffer_with_data(host)
         return cls(data, gpu_device, n, NullBitBufferGpu.new(gpu_device, builder))
 
@@ -241,9 +240,9 @@ class PrimitiveArrayGpu(ArrowArrayGPU):
     def values(self) -> list:
         vals = self.raw_values()
         if self.null_buffer is None:
-            return [v.item() for v in vals]
-        nulls = self.null_buffer.raw_values()
-        return [vals[i].item() if (nulls[i // 8] >> (i % 8)) & 1 else None for i in range(self.len)]
+            return vals.tolist()
+        valid = np.unpackbits(self.null_buffer.raw_values(), bitorder="little")[: self.len].tolist()
+        return [v if ok else None for v, ok in zip(vals.tolist(), valid)]
 
     def clone_array(self):
         data = self.gpu_device.clone_buffer(self.data)
