@@ -1,5 +1,7 @@
 """GPU: the reference's own unit-test vectors through the product (host layer → C ABI → HIP kernels), via both the
 typed methods and the `_dyn` functions — the same runner tests/test_oracle_golden.py uses for the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -49,3 +51,13 @@ def test_unsupported_pairs_raise_like_the_reference_panics(ag):
         ag.take_dyn(u8, ag.UInt32ArrayGPU.from_slice([0], dev))
     with pytest.raises(ag.ArrowErrorGPU):
         f.take(ag.UInt32ArrayGPU.from_slice([5], dev))  # out of range: HIP has no robust buffer access
+
+
+def test_examples_simple_py_runs():
+    """examples/simple.py — the reference's examples/simple.rs in the Python host layer."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "simple.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK on" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
