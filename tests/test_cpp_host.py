@@ -37,3 +37,33 @@ def test_cpp_host_layer_on_gpu():
     build()
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ---- the C ABI from plain C (what a cgo / JNI / Rust-FFI shim binds): the header must be valid strict C11
+C_SRC = os.path.join(ROOT, "examples", "simple.c")
+C_EXE = os.path.join(ROOT, "tests", "cpp", "build", "simple_c")
+
+
+def build_c():
+    os.makedirs(os.path.dirname(C_EXE), exist_ok=True)
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", C_SRC, "-I" + os.path.join(ROOT, "include"),
+           f"-L{LIBDIR}", "-larrow_gpu_hip", "-Wl,-rpath," + LIBDIR, "-o", C_EXE]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_c_example_compiles_as_strict_c11_and_fails_loudly_without_gpu():
+    import torch
+
+    build_c()
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present; the run is covered by the gpu-marked test")
+    r = subprocess.run([C_EXE], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_example_on_gpu():
+    build_c()
+    r = subprocess.run([C_EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "simple.c OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
