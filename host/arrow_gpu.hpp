@@ -106,27 +106,108 @@ inline DevicePtr GPU_DEVICE() {  // static GPU_DEVICE: LazyLock<Arc<GpuDevice>> 
 class ArrowComputePipeline {  // [compute_pipeline.rs:8-300]; one HIP stream, ops run in recorded order
  public:
   DevicePtr device;
-  agpu_pipeline* raw = nullptr;
-  std::vector<BufferPtr> keep;  // buffers referenced by in-flight work
-  explicit ArrowComputePipeline(DevicePtr d, const char* /*label*/ = nullptr) : device(std::move(d)) {
+  agpu_pipeline* raw = nullptr;  // the stream handle; use h() for anything that must run after recorded ops
+  std::vector<BufferPtr> keep;   // buffers referenced by in-flight work
+
+  // fuse = true: same-width element-wise ops on f32 / i32 / u32 / Date32 columns are only RECORDED, like
+  // commands in the reference's encoder, and issued at finish() / sync() / the next non-recordable op.  A run of ops
+  // that each consume the previous result — whose array the caller already dropped, e.g.
+  // `a.add_scalar_op(s, p).mul_scalar_op(s, p)` — becomes ONE agpu_fused_chain launch; intermediates that are still
+  // referenced anywhere (use_count) are materialised as usual.
+  bool fuse = false;
+  struct Stats {
+    size_t recorded = 0, kernels = 0, fused_chains = 0, fused_ops = 0;
+  } stats;
+
+  explicit ArrowComputePipeline(DevicePtr d, const char* /*label*/ = nullptr, bool fuse_ops = false)
+      : device(std::move(d)), fuse(fuse_ops) {
     check(agpu_pipeline_create(device->raw, &raw), "agpu_pipeline_create");
   }
   ArrowComputePipeline(const ArrowComputePipeline&) = delete;
   ~ArrowComputePipeline() {
-    if (raw) agpu_pipeline_destroy(raw);
+    if (raw) agpu_pipeline_destroy(raw);  // like an unsubmitted encoder, recorded-but-unfinished ops are dropped
   }
-  void finish() { check(agpu_pipeline_finish(raw), "agpu_pipeline_finish"); }  // submit; does not wait
+  agpu_pipeline* h() {  // handle for work that must be ordered after everything recorded so far
+    flush();
+    return raw;
+  }
+  void finish() { check(agpu_pipeline_finish(h()), "agpu_pipeline_finish"); }  // submit; does not wait
   void sync() {
-    check(agpu_pipeline_sync(raw), "agpu_pipeline_sync");
+    check(agpu_pipeline_sync(h()), "agpu_pipeline_sync");
     keep.clear();
   }
-  BufferPtr clone_buffer(const BufferPtr& b) {
+  BufferPtr clone_buffer(const BufferPtr& b, bool bitmap = false) {  // bitmap copies never depend on recorded value ops
     auto out = device->create_empty_buffer(b->bytes);
-    if (b->bytes) check(agpu_copy(raw, out->ptr, b->ptr, b->bytes), "agpu_copy");
+    if (b->bytes) check(agpu_copy(bitmap ? raw : h(), out->ptr, b->ptr, b->bytes), "agpu_copy");
     keep.push_back(b);
     keep.push_back(out);
     return out;
   }
+
+  // ---- recording (fuse == true)
+  static bool recordable(int kind, int op, agpu_dtype dtype) {
+    const bool is_f = dtype == AGPU_F32;
+    if (!(is_f || dtype == AGPU_I32 || dtype == AGPU_U32 || dtype == AGPU_DATE32)) return false;
+    if (kind == AGPU_CHAIN_UNARY)
+      return op == AGPU_UN_NEG || op == AGPU_UN_ABS || (is_f ? (op >= AGPU_UN_SQRT && op <= AGPU_UN_COS) : op == AGPU_UN_NOT);
+    return (op >= AGPU_OP_ADD && op <= AGPU_OP_MAX) || (!is_f && op >= AGPU_OP_AND && op <= AGPU_OP_XOR);
+  }
+  void record(int kind, int op, agpu_dtype dtype, BufferPtr a, BufferPtr operand, BufferPtr out, size_t n) {
+    pending_.push_back(Node{kind, op, dtype, std::move(a), std::move(operand), std::move(out), n});
+    stats.recorded++;
+  }
+  void flush() {
+    if (pending_.empty()) return;
+    std::vector<Node> nodes;
+    nodes.swap(pending_);
+    size_t i = 0;
+    while (i < nodes.size()) {
+      size_t len = 1;
+      while (len < AGPU_CHAIN_MAX_STEPS && i + len < nodes.size()) {
+        const Node& last = nodes[i + len - 1];
+        const Node& nxt = nodes[i + len];
+        // dead intermediate: only `last.out` and `nxt.a` still reference the buffer (the caller dropped the array, no
+        // later node reads it, nothing else keeps it alive)
+        const bool dead = last.out.use_count() == 2;
+        if (nxt.a == last.out && nxt.operand != last.out && nxt.n == last.n && nxt.dtype == last.dtype && dead) len++;
+        else break;
+      }
+      if (len == 1) {
+        const Node& nd = nodes[i];
+        if (nd.kind == AGPU_CHAIN_UNARY)
+          check(agpu_unary(raw, (agpu_unary_op)nd.op, nd.dtype, nd.a->ptr, nd.out->ptr, nd.n), "agpu_unary");
+        else if (nd.kind == AGPU_CHAIN_SCALAR)
+          check(agpu_scalar(raw, (agpu_binary_op)nd.op, nd.dtype, nd.a->ptr, nd.operand->ptr, nd.out->ptr, nd.n), "agpu_scalar");
+        else
+          check(agpu_binary(raw, (agpu_binary_op)nd.op, nd.dtype, nd.a->ptr, nd.operand->ptr, nd.out->ptr, nd.n), "agpu_binary");
+      } else {
+        std::vector<agpu_chain_step> steps(len);
+        for (size_t k = 0; k < len; k++)
+          steps[k] = agpu_chain_step{nodes[i + k].op, nodes[i + k].kind, nodes[i + k].operand ? nodes[i + k].operand->ptr : nullptr};
+        check(agpu_fused_chain(raw, nodes[i].dtype, nodes[i].a->ptr, steps.data(), (int32_t)len, nodes[i + len - 1].out->ptr,
+                               nodes[i].n),
+              "agpu_fused_chain");
+        stats.fused_chains++;
+        stats.fused_ops += len;
+      }
+      stats.kernels++;
+      for (size_t k = 0; k < len; k++) {
+        keep.push_back(nodes[i + k].a);
+        if (nodes[i + k].operand) keep.push_back(nodes[i + k].operand);
+        keep.push_back(nodes[i + k].out);
+      }
+      i += len;
+    }
+  }
+
+ private:
+  struct Node {
+    int kind, op;
+    agpu_dtype dtype;
+    BufferPtr a, operand, out;
+    size_t n;
+  };
+  std::vector<Node> pending_;
 };
 
 // ------------------------------------------------------------------ bitmaps
@@ -177,7 +258,7 @@ struct NullBitBufferGpu {  // [null_bit_buffer.rs:92-243]
   static std::optional<NullBitBufferGpu> clone_null_bit_buffer_op(const std::optional<NullBitBufferGpu>& d,
                                                                    ArrowComputePipeline& p) {
     if (!d) return std::nullopt;
-    return NullBitBufferGpu{p.clone_buffer(d->bit_buffer), d->len, d->gpu_device};
+    return NullBitBufferGpu{p.clone_buffer(d->bit_buffer, true), d->len, d->gpu_device};
   }
   // (None,None)→None; one side → copy; both → AND  [null_bit_buffer.rs:206-243]
   static std::optional<NullBitBufferGpu> merge_null_bit_buffer_op(const std::optional<NullBitBufferGpu>& l,
@@ -282,7 +363,7 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
     auto out = p.device->create_empty_buffer(n * sizeof(Native));
     uint32_t bits = 0;
     std::memcpy(&bits, &value, sizeof(Native));
-    check(agpu_broadcast(p.raw, DTYPE, bits, out->ptr, n), "agpu_broadcast");
+    check(agpu_broadcast(p.h(), DTYPE, bits, out->ptr, n), "agpu_broadcast");
     p.keep.push_back(out);
     return PrimitiveArrayGpu(out, p.device, n, std::nullopt);
   }
@@ -298,22 +379,34 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
   PrimitiveArrayGpu binary_op_(agpu_binary_op op, const PrimitiveArrayGpu<Rhs>& v, ArrowComputePipeline& p) const {
     if (len != v.len) throw ArrowErrorGPU(ArrowErrorGPU::Runtime, "binary op: arrays of different length");
     auto out = gpu_device->create_empty_buffer(len * sizeof(Native));
-    check(agpu_binary(p.raw, op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_binary");
-    p.keep.insert(p.keep.end(), {data, v.data, out});
+    if (p.fuse && sizeof(typename Prim<Rhs>::Native) == sizeof(Native) && ArrowComputePipeline::recordable(AGPU_CHAIN_ARRAY, op, DTYPE)) {
+      p.record(AGPU_CHAIN_ARRAY, op, DTYPE, data, v.data, out, len);
+    } else {
+      check(agpu_binary(p.h(), op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_binary");
+      p.keep.insert(p.keep.end(), {data, v.data, out});
+    }
     return PrimitiveArrayGpu(out, gpu_device, len, NullBitBufferGpu::merge_null_bit_buffer_op(null_buffer, v.null_buffer, p));
   }
   template <typename Rhs>
   PrimitiveArrayGpu scalar_op_(agpu_binary_op op, const PrimitiveArrayGpu<Rhs>& v, ArrowComputePipeline& p) const {
     auto out = gpu_device->create_empty_buffer(len * sizeof(Native));
-    check(agpu_scalar(p.raw, op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_scalar");
-    p.keep.insert(p.keep.end(), {data, v.data, out});
+    if (p.fuse && sizeof(typename Prim<Rhs>::Native) == sizeof(Native) && ArrowComputePipeline::recordable(AGPU_CHAIN_SCALAR, op, DTYPE)) {
+      p.record(AGPU_CHAIN_SCALAR, op, DTYPE, data, v.data, out, len);
+    } else {
+      check(agpu_scalar(p.h(), op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_scalar");
+      p.keep.insert(p.keep.end(), {data, v.data, out});
+    }
     return PrimitiveArrayGpu(out, gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
   }
   template <typename Out = T>
   PrimitiveArrayGpu<Out> unary_op_(agpu_unary_op op, ArrowComputePipeline& p) const {
     auto out = gpu_device->create_empty_buffer(len * sizeof(typename Prim<Out>::Native));
-    check(agpu_unary(p.raw, op, DTYPE, data->ptr, out->ptr, len), "agpu_unary");
-    p.keep.insert(p.keep.end(), {data, out});
+    if (p.fuse && std::is_same_v<Out, T> && ArrowComputePipeline::recordable(AGPU_CHAIN_UNARY, op, DTYPE)) {
+      p.record(AGPU_CHAIN_UNARY, op, DTYPE, data, nullptr, out, len);
+    } else {
+      check(agpu_unary(p.h(), op, DTYPE, data->ptr, out->ptr, len), "agpu_unary");
+      p.keep.insert(p.keep.end(), {data, out});
+    }
     return PrimitiveArrayGpu<Out>(out, gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
   }
   BooleanArrayGPU compare_op_(agpu_cmp_op op, const PrimitiveArrayGpu& v, ArrowComputePipeline& p) const;
@@ -373,7 +466,7 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
   auto sum_op(ArrowComputePipeline& p) const {
     static_assert(is_one_of<T, float, int32_t, uint32_t>, "Sum32Bit: f32, i32, u32");
     auto out = gpu_device->create_empty_buffer(16);
-    check(agpu_reduce(p.raw, AGPU_RED_SUM, DTYPE, data->ptr, nullptr, len, out->ptr), "agpu_reduce");
+    check(agpu_reduce(p.h(), AGPU_RED_SUM, DTYPE, data->ptr, nullptr, len, out->ptr), "agpu_reduce");
     p.keep.insert(p.keep.end(), {data, out});
     return PrimitiveArrayGpu(out, gpu_device, 1, std::nullopt);
   }
@@ -461,7 +554,7 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
   template <typename OutArray> OutArray cast_op(ArrowComputePipeline& p) const {
     using O = typename OutArray::ElemTag;
     auto out = gpu_device->create_empty_buffer(len * sizeof(typename Prim<O>::Native));
-    agpu_status s = agpu_cast(p.raw, DTYPE, Prim<O>::dtype, data->ptr, out->ptr, len);
+    agpu_status s = agpu_cast(p.h(), DTYPE, Prim<O>::dtype, data->ptr, out->ptr, len);
     if (s == AGPU_ERR_UNSUPPORTED) throw ArrowErrorGPU(ArrowErrorGPU::CastingNotSupported, agpu_last_error());
     check(s, "agpu_cast");
     p.keep.insert(p.keep.end(), {data, out});
@@ -490,7 +583,7 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
               const PrimitiveArrayGpu<uint32_t>& dst_indexes, ArrowComputePipeline& p) const {
     if (null_buffer || dst.null_buffer)
       throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "put with null buffers is todo!() in the reference");
-    check(agpu_put_bounded(p.raw, (int)sizeof(Native), data->ptr, len, (const uint32_t*)src_indexes.data->ptr, dst.data->ptr,
+    check(agpu_put_bounded(p.h(), (int)sizeof(Native), data->ptr, len, (const uint32_t*)src_indexes.data->ptr, dst.data->ptr,
                            dst.len, (const uint32_t*)dst_indexes.data->ptr, src_indexes.len), "agpu_put_bounded");
     p.keep.insert(p.keep.end(), {data, src_indexes.data, dst.data, dst_indexes.data});
   }
@@ -555,7 +648,7 @@ class BooleanArrayGPU {
   static BooleanArrayGPU broadcast(bool value, size_t n, const DevicePtr& dev) {
     ArrowComputePipeline p(dev);
     auto out = dev->create_empty_buffer(bitmap_bytes(n) ? bitmap_bytes(n) : 8);
-    check(agpu_broadcast(p.raw, AGPU_BOOL, value ? 1u : 0u, out->ptr, n), "agpu_broadcast");
+    check(agpu_broadcast(p.h(), AGPU_BOOL, value ? 1u : 0u, out->ptr, n), "agpu_broadcast");
     p.finish();
     return BooleanArrayGPU(out, dev, n, std::nullopt);
   }
@@ -564,7 +657,7 @@ class BooleanArrayGPU {
   // Logical / LogicalContains [crates/logical/src/boolean.rs:12-147]
   BooleanArrayGPU logical_(agpu_binary_op op, const BooleanArrayGPU& v, ArrowComputePipeline& p) const {
     auto out = gpu_device->create_empty_buffer(bitmap_bytes(len) ? bitmap_bytes(len) : 8);
-    check(agpu_bitmap_binary(p.raw, op, data->ptr, v.data->ptr, out->ptr, len), "agpu_bitmap_binary");
+    check(agpu_bitmap_binary(p.h(), op, data->ptr, v.data->ptr, out->ptr, len), "agpu_bitmap_binary");
     p.keep.insert(p.keep.end(), {data, v.data, out});
     return BooleanArrayGPU(out, gpu_device, len, NullBitBufferGpu::merge_null_bit_buffer_op(null_buffer, v.null_buffer, p));
   }
@@ -573,7 +666,7 @@ class BooleanArrayGPU {
   BooleanArrayGPU bitwise_xor_op(const BooleanArrayGPU& v, ArrowComputePipeline& p) const { return logical_(AGPU_OP_XOR, v, p); }
   BooleanArrayGPU bitwise_not_op(ArrowComputePipeline& p) const {
     auto out = gpu_device->create_empty_buffer(bitmap_bytes(len) ? bitmap_bytes(len) : 8);
-    check(agpu_bitmap_not(p.raw, data->ptr, out->ptr, len), "agpu_bitmap_not");
+    check(agpu_bitmap_not(p.h(), data->ptr, out->ptr, len), "agpu_bitmap_not");
     p.keep.insert(p.keep.end(), {data, out});
     return BooleanArrayGPU(out, gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
   }
@@ -584,7 +677,7 @@ class BooleanArrayGPU {
   bool any() const {
     ArrowComputePipeline p(gpu_device);
     auto out = gpu_device->create_empty_buffer(16);
-    check(agpu_bitmap_any(p.raw, data->ptr, len, (uint32_t*)out->ptr), "agpu_bitmap_any");
+    check(agpu_bitmap_any(p.h(), data->ptr, len, (uint32_t*)out->ptr), "agpu_bitmap_any");
     p.sync();
     uint32_t v = 0;
     std::memcpy(&v, gpu_device->retrive_data(out, 4).data(), 4);
@@ -593,7 +686,7 @@ class BooleanArrayGPU {
   bool all() const {
     ArrowComputePipeline p(gpu_device);
     auto out = gpu_device->create_empty_buffer(16);
-    check(agpu_bitmap_popcount(p.raw, data->ptr, len, (uint64_t*)out->ptr), "agpu_bitmap_popcount");
+    check(agpu_bitmap_popcount(p.h(), data->ptr, len, (uint64_t*)out->ptr), "agpu_bitmap_popcount");
     p.sync();
     uint64_t v = 0;
     std::memcpy(&v, gpu_device->retrive_data(out, 8).data(), 8);
@@ -602,7 +695,7 @@ class BooleanArrayGPU {
   PrimitiveArrayGpu<float> cast_f32() const {  // Cast<Float32ArrayGPU> for BooleanArrayGPU [cast/src/boolean_cast.rs]
     ArrowComputePipeline p(gpu_device);
     auto out = gpu_device->create_empty_buffer(len * 4);
-    check(agpu_cast(p.raw, AGPU_BOOL, AGPU_F32, data->ptr, out->ptr, len), "agpu_cast");
+    check(agpu_cast(p.h(), AGPU_BOOL, AGPU_F32, data->ptr, out->ptr, len), "agpu_cast");
     auto nb = NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p);
     p.finish();
     return PrimitiveArrayGpu<float>(out, gpu_device, len, nb);
@@ -618,10 +711,10 @@ BooleanArrayGPU PrimitiveArrayGpu<T>::compare_op_(agpu_cmp_op op, const Primitiv
   auto out = gpu_device->create_empty_buffer(nb);
   std::optional<NullBitBufferGpu> nulls;
   if (!null_buffer && !v.null_buffer) {
-    check(agpu_compare(p.raw, op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_compare");
+    check(agpu_compare(p.h(), op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_compare");
   } else {  // fused validity AND (the reference: a second, separately submitted dispatch)
     auto outv = gpu_device->create_empty_buffer(nb);
-    check(agpu_compare_validity(p.raw, op, DTYPE, data->ptr, v.data->ptr,
+    check(agpu_compare_validity(p.h(), op, DTYPE, data->ptr, v.data->ptr,
                                 null_buffer ? null_buffer->bit_buffer->ptr : nullptr,
                                 v.null_buffer ? v.null_buffer->bit_buffer->ptr : nullptr, out->ptr, outv->ptr, len),
           "agpu_compare_validity");
@@ -655,7 +748,7 @@ inline std::optional<NullBitBufferGpu> take_null_buffer(const std::optional<Null
                                                         const UInt32ArrayGPU& indexes, ArrowComputePipeline& p) {
   if (!nb) return std::nullopt;
   auto out = indexes.gpu_device->create_empty_buffer(bitmap_bytes(indexes.len) ? bitmap_bytes(indexes.len) : 8);
-  check(agpu_take_bits(p.raw, nb->bit_buffer->ptr, nb->len, (const uint32_t*)indexes.data->ptr, out->ptr, indexes.len), "agpu_take_bits");
+  check(agpu_take_bits(p.h(), nb->bit_buffer->ptr, nb->len, (const uint32_t*)indexes.data->ptr, out->ptr, indexes.len), "agpu_take_bits");
   p.keep.insert(p.keep.end(), {nb->bit_buffer, indexes.data, out});
   return NullBitBufferGpu{out, indexes.len, indexes.gpu_device};
 }
@@ -664,7 +757,7 @@ inline std::optional<NullBitBufferGpu> take_null_buffer(const std::optional<Null
 template <typename T>
 PrimitiveArrayGpu<T> PrimitiveArrayGpu<T>::take_op(const UInt32ArrayGPU& indexes, ArrowComputePipeline& p) const {
   auto out = gpu_device->create_empty_buffer(indexes.len * sizeof(Native));
-  check(agpu_take(p.raw, (int)sizeof(Native), data->ptr, len, (const uint32_t*)indexes.data->ptr, out->ptr, indexes.len), "agpu_take");
+  check(agpu_take(p.h(), (int)sizeof(Native), data->ptr, len, (const uint32_t*)indexes.data->ptr, out->ptr, indexes.len), "agpu_take");
   p.keep.insert(p.keep.end(), {data, indexes.data, out});
   return PrimitiveArrayGpu(out, gpu_device, indexes.len, take_null_buffer(null_buffer, indexes, p));
 }
@@ -674,7 +767,7 @@ inline std::optional<NullBitBufferGpu> merge_null_buffers_op(const std::optional
                                                              const BooleanArrayGPU& mask, ArrowComputePipeline& p, size_t n) {
   if (!a && !b && !mask.null_buffer) return std::nullopt;
   auto out = mask.gpu_device->create_empty_buffer(bitmap_bytes(n) ? bitmap_bytes(n) : 8);
-  check(agpu_bitmap_merge_validity(p.raw, a ? a->bit_buffer->ptr : nullptr, b ? b->bit_buffer->ptr : nullptr, mask.data->ptr,
+  check(agpu_bitmap_merge_validity(p.h(), a ? a->bit_buffer->ptr : nullptr, b ? b->bit_buffer->ptr : nullptr, mask.data->ptr,
                                    mask.null_buffer ? mask.null_buffer->bit_buffer->ptr : nullptr, out->ptr, n),
         "agpu_bitmap_merge_validity");
   p.keep.push_back(out);
@@ -684,7 +777,7 @@ template <typename T>
 PrimitiveArrayGpu<T> PrimitiveArrayGpu<T>::merge_op(const PrimitiveArrayGpu& other, const BooleanArrayGPU& mask,
                                                     ArrowComputePipeline& p) const {
   auto out = gpu_device->create_empty_buffer(len * sizeof(Native));
-  check(agpu_merge(p.raw, (int)sizeof(Native), data->ptr, other.data->ptr, mask.data->ptr, out->ptr, len), "agpu_merge");
+  check(agpu_merge(p.h(), (int)sizeof(Native), data->ptr, other.data->ptr, mask.data->ptr, out->ptr, len), "agpu_merge");
   p.keep.insert(p.keep.end(), {data, other.data, mask.data, out});
   return PrimitiveArrayGpu(out, gpu_device, len, merge_null_buffers_op(null_buffer, other.null_buffer, mask, p, len));
 }
@@ -892,7 +985,7 @@ class FusedChain {
       }
     }
     if (!merged) nulls = NullBitBufferGpu::clone_null_bit_buffer_op(nulls, p);
-    check(agpu_fused_chain(p.raw, Arr::DTYPE, src_.data->ptr, steps_.data(), (int32_t)steps_.size(), out->ptr, src_.len),
+    check(agpu_fused_chain(p.h(), Arr::DTYPE, src_.data->ptr, steps_.data(), (int32_t)steps_.size(), out->ptr, src_.len),
           "agpu_fused_chain");
     p.keep.insert(p.keep.end(), {src_.data, out});
     return Arr(out, src_.gpu_device, src_.len, nulls);
@@ -927,7 +1020,7 @@ class FusedChain {
       merged = true;
     }
     if (!merged) nulls = NullBitBufferGpu::clone_null_bit_buffer_op(nulls, p);
-    check(agpu_fused_chain_compare(p.raw, Arr::DTYPE, src_.data->ptr, steps_.data(), (int32_t)steps_.size(), op,
+    check(agpu_fused_chain_compare(p.h(), Arr::DTYPE, src_.data->ptr, steps_.data(), (int32_t)steps_.size(), op,
                                    scalar ? AGPU_CHAIN_SCALAR : AGPU_CHAIN_ARRAY, other.data->ptr, out->ptr, src_.len),
           "agpu_fused_chain_compare");
     p.keep.insert(p.keep.end(), {src_.data, other.data, out});

@@ -62,6 +62,24 @@ static void run_compute_pipeline_ops(const DevicePtr& device) {
   auto ia = Int32ArrayGPU::from_slice({1, -2, 3, std::numeric_limits<int32_t>::max()}, device);
   auto ib = Int32ArrayGPU::from_slice({100}, device);
   CHECK(FusedChain(ia).mul(ib).abs().finish().raw_values() == ia.mul_scalar(ib).abs().raw_values());
+  // fusing pipeline: ops are recorded like commands in the reference's encoder and fused at finish()
+  {
+    ArrowComputePipeline fp(device, "fusing", true);
+    auto fr = a.add_scalar_op(s, fp).mul_scalar_op(s, fp);  // the intermediate dies with the full expression
+    CHECK(fp.stats.recorded == 2 && fp.stats.kernels == 0);
+    fp.finish();
+    CHECK(fp.stats.kernels == 1 && fp.stats.fused_chains == 1 && fp.stats.fused_ops == 2);
+    CHECK(fr.raw_values() == try_from<Float32ArrayGPU>(r2).raw_values());
+    ArrowComputePipeline lp(device, "live", true);
+    auto k1 = a.add_scalar_op(s, lp);  // kept alive by the caller: must be materialised
+    auto k2 = k1.mul_scalar_op(s, lp);
+    auto k3 = k2.neg_op(lp).abs_op(lp).sqrt_op(lp);  // dead intermediates again: one more fused chain
+    lp.sync();
+    CHECK(lp.stats.recorded == 5 && lp.stats.kernels == 3 && lp.stats.fused_chains == 1);
+    CHECK(k1.raw_values() == a.add_scalar(s).raw_values());
+    CHECK(k2.raw_values() == fr.raw_values());
+    CHECK(k3.raw_values() == fr.neg().abs().sqrt().raw_values());
+  }
   // chain ending in a compare: (x + y) > x  as one pass, same bits and validity as the three-kernel form
   auto fp = FusedChain(x).add(y).gt(x);
   auto up = x.add(y).gt(x);
