@@ -97,3 +97,37 @@ def test_default_api_ops_do_not_pay_for_stream_creation(ag):
     print(f"a.add(b), 1 Mi rows, default API: {med_ms:.3f} ms per call, idle streams {pool_info(dev)[2]}")
     assert med_ms < 2.0  # 7 ms of hipStreamCreate/Destroy per call without the pool
     assert np.array_equal(a.add(b).raw_values(), O.binary(O.OP_ADD, O.I32, a.raw_values(), b.raw_values()))
+
+
+def test_pools_under_concurrent_threads(ag):
+    """8 host threads hammer one device: new pipeline + new buffers per op (the reference's default API shape), results
+    checked every time.  ctypes releases the GIL inside the C calls, so the pools' locking is really exercised."""
+    import threading
+
+    dev = ag.GPU_DEVICE()
+    n = 300_000  # 1.2 MB columns: pooled blocks
+    errors = []
+
+    def worker(tid):
+        try:
+            rng = np.random.default_rng(tid)
+            a_host = rng.integers(-1000, 1000, n).astype(np.int32)
+            b_host = rng.integers(-1000, 1000, n).astype(np.int32)
+            a = ag.Int32ArrayGPU.from_slice(a_host, dev)
+            b = ag.Int32ArrayGPU.from_slice(b_host, dev)
+            for it in range(40):
+                c = a.add(b)                      # own pipeline, own output, freed right after
+                m = c.gt(a)
+                if it % 8 == 0:
+                    assert np.array_equal(c.raw_values(), a_host + b_host)
+                    assert np.array_equal(m.raw_values(), (a_host + b_host) > a_host)
+                del c, m
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
