@@ -240,3 +240,37 @@ def test_take_put_merge_inverses_fullsize(ctx):
     capi.call("agpu_checksum", h, vp(t), 4 * n, vp(cs2))
     assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
     del one
+
+
+def test_columns_longer_than_2_pow_32_rows(ctx):
+    """u8 columns of 2^32 + 70 001 rows (4.3 GB each): every index is 64-bit — windows past row 2^32 are bit-exact
+    against the oracle for add, eq -> bitmap, cast u8 -> f32 (17 GB output) and the popcount of the compare result."""
+    dev, p = ctx
+    h = p._handle
+    n = (1 << 32) + 70_001
+    a, b, o = (dev.create_empty_buffer(n) for _ in range(3))
+    bits = dev.create_empty_buffer((n + 63) // 64 * 8)
+    cnt = dev.create_empty_buffer(16)
+    capi.call("agpu_synth_u8", h, vp(a), n, SEED, 0)
+    capi.call("agpu_synth_u8", h, vp(b), n, SEED + 1, 0)
+    capi.call("agpu_binary", h, capi.OP_ADD, capi.U8, vp(a), vp(b), vp(o), n)
+    capi.call("agpu_compare", h, capi.CMP_EQ, capi.U8, vp(a), vp(b), vp(bits), n)
+    capi.call("agpu_bitmap_popcount", h, vp(bits), n, vp(cnt))
+    n_eq = scalar_u64(dev, p, cnt)
+    assert abs(n_eq / n - 1 / 256) < 1e-4  # independent uniform bytes agree 1 time in 256
+    wide = dev.create_empty_buffer(4 * n)
+    capi.call("agpu_cast", h, capi.U8, capi.F32, vp(a), vp(wide), n)
+    for start in ((1 << 32) - 4096, (1 << 32) + 1024, (n - WINDOW) // 64 * 64):
+        cntw = min(WINDOW, n - start)
+        ea, eb = O.synth_u8(cntw, SEED, start), O.synth_u8(cntw, SEED + 1, start)
+        got = download(dev, p, o, start, cntw)
+        assert np.array_equal(got, O.binary(O.OP_ADD, O.U8, ea, eb)), start
+        gb = download(dev, p, bits, start // 8, cntw // 8)
+        assert np.array_equal(gb, O.compare(O.CMP_EQ, O.U8, ea, eb)[: cntw // 8]), start
+        gw = download(dev, p, wide, 4 * start, 4 * cntw).view(np.float32)
+        assert np.array_equal(gw, ea.astype(np.float32)), start
+    # the very last rows (ragged tail of every kernel)
+    tail = 70_001 % 4096 + 4096
+    ea, eb = O.synth_u8(tail, SEED, n - tail), O.synth_u8(tail, SEED + 1, n - tail)
+    assert np.array_equal(download(dev, p, o, n - tail, tail), O.binary(O.OP_ADD, O.U8, ea, eb))
+    assert np.array_equal(download(dev, p, wide, 4 * (n - tail), 4 * tail).view(np.float32), ea.astype(np.float32))
