@@ -20,11 +20,15 @@ BOOL, F32, U32, U16, U8, I32, I16, I8, DATE32 = range(9)
 # agpu_binary_op
 OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_REM, OP_MIN, OP_MAX, OP_AND, OP_OR, OP_XOR, OP_SHL, OP_SHR, OP_POW = range(13)
 # agpu_unary_op
-(UN_NEG, UN_ABS, UN_NOT, UN_SQRT, UN_CBRT, UN_EXP, UN_EXP2, UN_LOG, UN_LOG2, UN_SIN, UN_COS, UN_ACOS, UN_SINH) = range(13)
+(UN_NEG, UN_ABS, UN_NOT, UN_SQRT, UN_CBRT, UN_EXP, UN_EXP2, UN_LOG, UN_LOG2, UN_SIN, UN_COS, UN_ACOS, UN_SINH,
+ UN_POPCOUNT) = range(14)
 # agpu_cmp_op
 CMP_GT, CMP_GTEQ, CMP_LT, CMP_LTEQ, CMP_EQ = range(5)
 # agpu_reduce_op
 RED_SUM, RED_MIN, RED_MAX = range(3)
+# agpu_comm_dtype
+COMM_F32, COMM_F64, COMM_I32, COMM_U32, COMM_I64, COMM_U64 = range(6)
+COMM_ID_BYTES = 128
 
 _vp, _u64, _i32, _u32, _i64, _sz = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32, C.c_int64, C.c_size_t
 _pp = C.POINTER(C.c_void_p)
@@ -45,6 +49,7 @@ SIGNATURES = {
     "agpu_device_mem_info": [_vp, C.POINTER(_u64), C.POINTER(_u64)],
     "agpu_device_trim": [_vp],
     "agpu_device_pool_info": [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)],
+    "agpu_device_small_pool_info": [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)],
     "agpu_malloc": [_vp, _sz, _i32, _pp],
     "agpu_free": [_vp, _vp],
     "agpu_upload": [_vp, _vp, _vp, _sz],
@@ -73,6 +78,24 @@ SIGNATURES = {
     "agpu_event_destroy": [_vp],
     "agpu_set_tuning": [C.c_char_p, _i64],
     "agpu_get_tuning": [C.c_char_p, C.POINTER(_i64)],
+    "agpu_pipeline_set_tuning": [_vp, C.c_char_p, _i64],
+    "agpu_pipeline_get_tuning": [_vp, C.c_char_p, C.POINTER(_i64)],
+    "agpu_pipeline_wait_pipeline": [_vp, _vp],
+    "agpu_pipeline_enable_timing": [_vp, _i32],
+    "agpu_pipeline_last_kernel_ns": [_vp, C.POINTER(_u64), C.POINTER(C.c_char_p)],
+    "agpu_comm_get_unique_id": [_vp],
+    "agpu_comm_init_rank": [_vp, _vp, _i32, _i32, _pp],
+    "agpu_comm_destroy": [_vp],
+    "agpu_comm_rank": [_vp, C.POINTER(_i32), C.POINTER(_i32)],
+    "agpu_comm_reduce": [_vp, _vp, _i32, _i32, _vp, _vp, _u64, _vp],
+    "agpu_comm_reduce_sum_f64": [_vp, _vp, _vp, _vp, _u64, _vp],
+    "agpu_comm_final_reduce": [_vp, _vp, _i32, _i32, _i32, _vp, _u64, _vp],
+    "agpu_comm_all_reduce": [_vp, _vp, _i32, _i32, _vp, _u64],
+    "agpu_comm_barrier": [_vp, _vp],
+    "agpu_import_arrow": [_vp, _vp, _vp, _vp],
+    "agpu_export_arrow": [_vp, _vp, _vp, _vp],
+    "agpu_arrow_column_free": [_vp, _vp],
+    "agpu_staged_copy": [_vp, _vp, _vp, _sz, _i32],
     "agpu_binary": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
     "agpu_scalar": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
     "agpu_unary": [_vp, _i32, _i32, _vp, _vp, _u64],

@@ -1,0 +1,345 @@
+// arrow_cdata.hip — Arrow C Data Interface at the C ABI + the host↔HBM staging engine.
+//
+// The reference moves every array through pageable host Vecs: `from_slice` → `create_gpu_buffer_with_data`
+// (wgpu create_buffer_init: a mapped-at-creation copy) and `raw_values` → `retrive_data` (copy to a MAP_READ buffer,
+// map, memcpy into a Vec) [ref: crates/array/src/array/primitive_array_gpu.rs:22-104, gpu_device.rs:171-181,232-265].
+// Here a producer's ArrowArray/ArrowSchema pair is consumed as it is: values from `offset` on, bitmaps re-aligned on
+// the GPU, and pageable memory crosses the link through page-locked chunks that several host threads fill while the
+// previous chunks are already in flight.
+#include <thread>
+
+#include "common.hpp"
+
+// ---------------------------------------------------------------- staging engine
+// mode 1: one hipMemcpy of the pageable range (the runtime stages internally, single-threaded).
+// mode 2: T host threads; thread t owns two page-locked 4 MiB slots and moves chunks t, t+T, t+2T, …: memcpy into a
+//         slot (host DRAM bandwidth, parallel), hipMemcpyAsync slot → HBM on the pipeline's stream (the DMA engine,
+//         overlapped with the next memcpy), event per slot so a slot is refilled only after its DMA has finished.
+//         Chunks land in disjoint destinations, so their order on the stream does not matter.
+// mode 3: hipHostRegister the caller's range in place, one async DMA, unregister (no CPU copy; pays the pinning).
+static int stage_threads_for(const agpu_pipeline* p, size_t bytes) {
+  int64_t t = p->tune.h2d_threads;
+  if (t <= 0) t = 8;
+  const size_t chunks = (bytes + AGPU_STAGE_CHUNK - 1) / AGPU_STAGE_CHUNK;
+  if ((size_t)t > chunks) t = (int64_t)chunks;
+  if (t > 32) t = 32;
+  if (t < 1) t = 1;
+  return (int)t;
+}
+
+static agpu_status stage_reserve_locked(agpu_device* dev, size_t slots) {
+  while (dev->stage.size() < slots) {
+    agpu_device::StageSlot s{nullptr, nullptr, false};
+    AGPU_HIP(hipHostMalloc(&s.host, AGPU_STAGE_CHUNK, hipHostMallocDefault));
+    hipError_t e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      (void)hipHostFree(s.host);
+      agpu_set_error("hipEventCreate failed: %s", hipGetErrorString(e));
+      return AGPU_ERR_HIP;
+    }
+    dev->stage.push_back(s);
+  }
+  return AGPU_OK;
+}
+
+void agpu_internal_free_staging(agpu_device* dev) {
+  std::lock_guard<std::mutex> lock(dev->stage_mu);
+  for (auto& s : dev->stage) {
+    (void)hipEventSynchronize(s.ev);
+    (void)hipEventDestroy(s.ev);
+    (void)hipHostFree(s.host);
+  }
+  dev->stage.clear();
+}
+
+static agpu_status staged_copy_threads(agpu_pipeline* p, char* dev_ptr, char* host_ptr, size_t bytes, bool to_device) {
+  agpu_device* dev = p->dev;
+  const int T = stage_threads_for(p, bytes);
+  std::lock_guard<std::mutex> lock(dev->stage_mu);  // the slots serve one transfer at a time
+  agpu_status st = stage_reserve_locked(dev, (size_t)T * 2);
+  if (st != AGPU_OK) return st;
+  const size_t nchunks = (bytes + AGPU_STAGE_CHUNK - 1) / AGPU_STAGE_CHUNK;
+  std::vector<hipError_t> errs((size_t)T, hipSuccess);
+  auto worker = [&](int t) {
+    hipError_t e = hipSetDevice(dev->ordinal);
+    int k = 0;
+    for (size_t c = (size_t)t; c < nchunks && e == hipSuccess; c += (size_t)T, k ^= 1) {
+      agpu_device::StageSlot& s = dev->stage[(size_t)t * 2 + (size_t)k];
+      const size_t off = c * AGPU_STAGE_CHUNK;
+      const size_t len = bytes - off < AGPU_STAGE_CHUNK ? bytes - off : AGPU_STAGE_CHUNK;
+      if (to_device) {
+        if (s.used) e = hipEventSynchronize(s.ev);  // the DMA that last read this slot
+        if (e != hipSuccess) break;
+        memcpy(s.host, host_ptr + off, len);
+        e = hipMemcpyAsync(dev_ptr + off, s.host, len, hipMemcpyHostToDevice, p->stream);
+        if (e == hipSuccess) e = hipEventRecord(s.ev, p->stream);
+        s.used = true;
+      } else {
+        // two chunks in flight per thread: issue this one, then drain the other slot while it travels
+        if (s.used) e = hipEventSynchronize(s.ev);
+        if (e != hipSuccess) break;
+        e = hipMemcpyAsync(s.host, dev_ptr + off, len, hipMemcpyDeviceToHost, p->stream);
+        if (e == hipSuccess) e = hipEventRecord(s.ev, p->stream);
+        s.used = true;
+        if (c >= (size_t)T) {  // previous chunk of this thread sits in the other slot
+          agpu_device::StageSlot& o = dev->stage[(size_t)t * 2 + (size_t)(k ^ 1)];
+          const size_t poff = (c - (size_t)T) * AGPU_STAGE_CHUNK;
+          if (e == hipSuccess) e = hipEventSynchronize(o.ev);
+          if (e == hipSuccess) memcpy(host_ptr + poff, o.host, AGPU_STAGE_CHUNK);
+        }
+      }
+    }
+    if (!to_device && e == hipSuccess) {  // drain the last chunk this thread issued
+      size_t last = nchunks;
+      for (size_t c = (size_t)t; c < nchunks; c += (size_t)T) last = c;
+      if (last < nchunks) {
+        const int lk = (int)(((last - (size_t)t) / (size_t)T) & 1);
+        agpu_device::StageSlot& o = dev->stage[(size_t)t * 2 + (size_t)lk];
+        const size_t off = last * AGPU_STAGE_CHUNK;
+        const size_t len = bytes - off < AGPU_STAGE_CHUNK ? bytes - off : AGPU_STAGE_CHUNK;
+        e = hipEventSynchronize(o.ev);
+        if (e == hipSuccess) memcpy(host_ptr + off, o.host, len);
+      }
+    }
+    errs[(size_t)t] = e;
+  };
+  std::vector<std::thread> threads;
+  for (int t = 1; t < T; t++) threads.emplace_back(worker, t);
+  worker(0);
+  for (auto& th : threads) th.join();
+  for (hipError_t e : errs)
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      agpu_set_error("staged copy failed: %s", hipGetErrorString(e));
+      return AGPU_ERR_HIP;
+    }
+  return AGPU_OK;
+}
+
+static agpu_status staged_copy_impl(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device) {
+  if (!bytes) return AGPU_OK;
+  int64_t mode = p->tune.h2d_mode;
+  if (mode <= 0 || mode > 3) mode = bytes >= ((size_t)1 << 20) ? 2 : 1;
+  if (mode == 2) return staged_copy_threads(p, static_cast<char*>(dev_ptr), static_cast<char*>(host_ptr), bytes, to_device);
+  if (mode == 3) {
+    hipError_t e = hipHostRegister(host_ptr, bytes, hipHostRegisterDefault);
+    if (e == hipSuccess) {
+      e = to_device ? hipMemcpyAsync(dev_ptr, host_ptr, bytes, hipMemcpyHostToDevice, p->stream)
+                    : hipMemcpyAsync(host_ptr, dev_ptr, bytes, hipMemcpyDeviceToHost, p->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(p->stream);
+      (void)hipHostUnregister(host_ptr);
+      if (e != hipSuccess) {
+        agpu_set_error("registered copy failed: %s", hipGetErrorString(e));
+        return AGPU_ERR_HIP;
+      }
+      return AGPU_OK;
+    }
+    (void)hipGetLastError();  // e.g. read-only mapping: fall back to the pageable copy
+  }
+  if (to_device) AGPU_HIP(hipMemcpyAsync(dev_ptr, host_ptr, bytes, hipMemcpyHostToDevice, p->stream));
+  else AGPU_HIP(hipMemcpyAsync(host_ptr, dev_ptr, bytes, hipMemcpyDeviceToHost, p->stream));
+  AGPU_HIP(hipStreamSynchronize(p->stream));
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- Arrow C Data Interface
+static bool dtype_of_format(const char* f, agpu_dtype* out) {
+  if (!f) return false;
+  if (!strcmp(f, "c")) *out = AGPU_I8;
+  else if (!strcmp(f, "C")) *out = AGPU_U8;
+  else if (!strcmp(f, "s")) *out = AGPU_I16;
+  else if (!strcmp(f, "S")) *out = AGPU_U16;
+  else if (!strcmp(f, "i")) *out = AGPU_I32;
+  else if (!strcmp(f, "I")) *out = AGPU_U32;
+  else if (!strcmp(f, "f")) *out = AGPU_F32;
+  else if (!strcmp(f, "b")) *out = AGPU_BOOL;
+  else if (!strcmp(f, "tdD")) *out = AGPU_DATE32;
+  else return false;
+  return true;
+}
+static const char* format_of_dtype(agpu_dtype t) {
+  switch (t) {
+    case AGPU_I8: return "c";
+    case AGPU_U8: return "C";
+    case AGPU_I16: return "s";
+    case AGPU_U16: return "S";
+    case AGPU_I32: return "i";
+    case AGPU_U32: return "I";
+    case AGPU_F32: return "f";
+    case AGPU_BOOL: return "b";
+    case AGPU_DATE32: return "tdD";
+  }
+  return nullptr;
+}
+
+// Arrow bitmap (byte-granular, arbitrary bit offset) → word-aligned device bitmap, padding bits 0
+static agpu_status import_bitmap(agpu_pipeline* p, const uint8_t* host_bits, uint64_t bit_offset, uint64_t n_bits,
+                                 void** out_dev, uint64_t* out_bytes) {
+  agpu_device* dev = p->dev;
+  const size_t out_b = agpu_bitmap_bytes(n_bits) ? agpu_bitmap_bytes(n_bits) : 8;
+  void* out = nullptr;
+  agpu_status st = agpu_malloc(dev, out_b, 0, &out);
+  if (st != AGPU_OK) return st;
+  if (n_bits) {
+    const uint64_t first = bit_offset / 8, last = (bit_offset + n_bits + 7) / 8, span = last - first;
+    if ((bit_offset & 7) == 0) {  // byte-aligned slice: the bytes are the bitmap; only the padding needs clearing
+      AGPU_HIP(hipMemsetAsync(static_cast<char*>(out) + (out_b - 8), 0, 8, p->stream));
+      st = staged_copy_impl(p, out, const_cast<uint8_t*>(host_bits + first), span, true);
+      if (st == AGPU_OK && (n_bits & 7)) st = agpu_bitmap_copy_bits(p, out, 0, out, n_bits);  // mask the tail bits
+    } else {
+      void* tmp = nullptr;
+      st = agpu_malloc(dev, agpu_bitmap_bytes(span * 8) + 8, 0, &tmp);
+      if (st == AGPU_OK) {
+        AGPU_HIP(hipMemsetAsync(static_cast<char*>(tmp) + agpu_bitmap_bytes(span * 8) - 8, 0, 16, p->stream));
+        st = staged_copy_impl(p, tmp, const_cast<uint8_t*>(host_bits + first), span, true);
+        if (st == AGPU_OK) st = agpu_bitmap_copy_bits(p, tmp, bit_offset & 7, out, n_bits);
+        (void)agpu_free(dev, tmp);  // recycled only after the stream has passed the kernel above (runtime.hip markers)
+      }
+    }
+  }
+  if (st != AGPU_OK) {
+    (void)agpu_free(dev, out);
+    return st;
+  }
+  *out_dev = out;
+  *out_bytes = out_b;
+  return AGPU_OK;
+}
+
+struct ExportPrivate {
+  void* values;
+  void* validity;
+  const void* buffers[2];
+};
+
+static void release_exported_array(struct ArrowArray* a) {
+  if (!a || !a->release) return;
+  ExportPrivate* pd = static_cast<ExportPrivate*>(a->private_data);
+  if (pd) {
+    free(pd->values);
+    free(pd->validity);
+    delete pd;
+  }
+  a->release = nullptr;
+}
+static void release_exported_schema(struct ArrowSchema* s) {
+  if (!s || !s->release) return;
+  s->release = nullptr;  // format / name point at static storage
+}
+
+extern "C" {
+
+agpu_status agpu_staged_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, int32_t to_device) {
+  AGPU_BIND(p);
+  if (!bytes) return AGPU_OK;
+  AGPU_REQUIRE(dev_ptr && host_ptr, AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "not during graph capture");
+  return staged_copy_impl(p, dev_ptr, host_ptr, bytes, to_device != 0);
+}
+
+agpu_status agpu_import_arrow(agpu_pipeline* p, const struct ArrowArray* array, const struct ArrowSchema* schema,
+                              agpu_arrow_column* out_column) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(array && schema && out_column, AGPU_ERR_ARG, "null argument");
+  AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "not during graph capture");
+  AGPU_REQUIRE(array->release && schema->release, AGPU_ERR_ARG, "released ArrowArray / ArrowSchema");
+  memset(out_column, 0, sizeof(*out_column));
+  agpu_dtype dt;
+  if (!dtype_of_format(schema->format, &dt)) {
+    agpu_set_error("Arrow format '%s' has no GPU array type (c C s S i I f b tdD)", schema->format ? schema->format : "(null)");
+    return AGPU_ERR_UNSUPPORTED;
+  }
+  AGPU_REQUIRE(!array->dictionary && array->n_children == 0, AGPU_ERR_UNSUPPORTED, "nested / dictionary arrays are not supported");
+  AGPU_REQUIRE(array->n_buffers == 2 && array->buffers, AGPU_ERR_SHAPE, "a primitive array has exactly 2 buffers");
+  AGPU_REQUIRE(array->length >= 0 && array->offset >= 0, AGPU_ERR_SHAPE, "negative length / offset");
+  const uint64_t n = (uint64_t)array->length, off = (uint64_t)array->offset;
+  const uint8_t* vbits = static_cast<const uint8_t*>(array->buffers[0]);
+  const uint8_t* data = static_cast<const uint8_t*>(array->buffers[1]);
+  AGPU_REQUIRE(n == 0 || data, AGPU_ERR_SHAPE, "null data buffer");
+  agpu_device* dev = p->dev;
+  agpu_arrow_column col;
+  memset(&col, 0, sizeof(col));
+  col.dtype = dt;
+  col.length = n;
+  col.null_count = array->null_count;
+  agpu_status st = AGPU_OK;
+  if (vbits && array->null_count != 0 && n) {
+    st = import_bitmap(p, vbits, off, n, &col.validity, &col.validity_bytes);
+    if (st != AGPU_OK) return st;
+  } else {
+    col.null_count = 0;
+  }
+  if (dt == AGPU_BOOL) {
+    st = import_bitmap(p, data, off, n, &col.values, &col.values_bytes);
+  } else {
+    const size_t w = agpu_dtype_size(dt);
+    col.values_bytes = n * w ? n * w : 16;
+    st = agpu_malloc(dev, col.values_bytes, 0, &col.values);
+    if (st == AGPU_OK) st = staged_copy_impl(p, col.values, const_cast<uint8_t*>(data + off * w), n * w, true);
+  }
+  if (st != AGPU_OK) {
+    (void)agpu_arrow_column_free(dev, &col);
+    return st;
+  }
+  *out_column = col;
+  return AGPU_OK;
+}
+
+agpu_status agpu_export_arrow(agpu_pipeline* p, const agpu_arrow_column* column, struct ArrowArray* out_array,
+                              struct ArrowSchema* out_schema) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(column && out_array && out_schema, AGPU_ERR_ARG, "null argument");
+  AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "not during graph capture");
+  const char* fmt = format_of_dtype(column->dtype);
+  AGPU_REQUIRE(fmt, AGPU_ERR_ARG, "bad dtype");
+  const uint64_t n = column->length;
+  AGPU_REQUIRE(n == 0 || column->values, AGPU_ERR_ARG, "null values");
+  const size_t vbytes = column->dtype == AGPU_BOOL ? agpu_bitmap_bytes(n) : (size_t)n * agpu_dtype_size(column->dtype);
+  const size_t nbytes = column->validity ? agpu_bitmap_bytes(n) : 0;
+  ExportPrivate* pd = new ExportPrivate{nullptr, nullptr, {nullptr, nullptr}};
+  // 64-byte aligned, padded to 64 B as the Arrow spec recommends
+  if (posix_memalign(&pd->values, 64, ((vbytes + 63) / 64 * 64) ? (vbytes + 63) / 64 * 64 : 64) != 0) pd->values = nullptr;
+  if (nbytes && posix_memalign(&pd->validity, 64, (nbytes + 63) / 64 * 64) != 0) pd->validity = nullptr;
+  agpu_status st = (!pd->values || (nbytes && !pd->validity)) ? AGPU_ERR_ARG : AGPU_OK;
+  if (st != AGPU_OK) agpu_set_error("host allocation of %zu bytes failed", vbytes + nbytes);
+  if (st == AGPU_OK) st = staged_copy_impl(p, column->values, pd->values, vbytes, false);
+  if (st == AGPU_OK && nbytes) st = staged_copy_impl(p, column->validity, pd->validity, nbytes, false);
+  if (st == AGPU_OK) {  // modes 1 and 3 have synchronised already; mode 2 drained its slots — make it unconditional
+    hipError_t e = hipStreamSynchronize(p->stream);
+    if (e != hipSuccess) {
+      agpu_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(e));
+      st = AGPU_ERR_HIP;
+    }
+  }
+  if (st != AGPU_OK) {
+    free(pd->values);
+    free(pd->validity);
+    delete pd;
+    return st;
+  }
+  pd->buffers[0] = pd->validity;
+  pd->buffers[1] = pd->values;
+  memset(out_array, 0, sizeof(*out_array));
+  out_array->length = (int64_t)n;
+  out_array->null_count = column->validity ? column->null_count : 0;
+  out_array->offset = 0;
+  out_array->n_buffers = 2;
+  out_array->buffers = pd->buffers;
+  out_array->release = release_exported_array;
+  out_array->private_data = pd;
+  memset(out_schema, 0, sizeof(*out_schema));
+  out_schema->format = fmt;
+  out_schema->name = "";
+  out_schema->flags = ARROW_FLAG_NULLABLE;
+  out_schema->release = release_exported_schema;
+  return AGPU_OK;
+}
+
+agpu_status agpu_arrow_column_free(agpu_device* dev, agpu_arrow_column* column) {
+  AGPU_REQUIRE(dev && column, AGPU_ERR_ARG, "null argument");
+  agpu_status a = agpu_free(dev, column->values), b = agpu_free(dev, column->validity);
+  column->values = column->validity = nullptr;
+  return a != AGPU_OK ? a : b;
+}
+
+}  // extern "C"

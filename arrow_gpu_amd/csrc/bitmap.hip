@@ -57,7 +57,8 @@ __global__ __launch_bounds__(AGPU_BLOCK) void bitmap_kernel(const uint64_t* a, c
 template <int OP, bool NULLABLE>
 static agpu_status launch_bitmap(agpu_pipeline* p, const void* a, const void* b, const void* c, const void* d,
                                  void* out, uint64_t n_bits) {
-  AGPU_BIND(p);
+  AGPU_BIND_AS(p, OP == BM_MERGE_VALIDITY ? "agpu_bitmap_merge_validity" : OP == BM_SELECT ? "agpu_merge_bits"
+                  : OP == BM_NOT ? "agpu_bitmap_not" : "agpu_bitmap_binary");
   if (n_bits == 0) return AGPU_OK;
   AGPU_REQUIRE(out, AGPU_ERR_ARG, "null output");
   const void* ptrs[5] = {a, b, c, d, out};

@@ -2,10 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -17,54 +19,134 @@
 #define AGPU_STR2(x) #x
 #define AGPU_STR(x) AGPU_STR2(x)
 
+// ---------------------------------------------------------------- tuning knobs (bench sweeps; see agpu_set_tuning)
+// A pipeline carries its OWN copy (taken from the process defaults when it is created, changed by
+// agpu_pipeline_set_tuning), so one thread's sweep never changes the kernels another pipeline launches.
+struct agpu_tuning {
+  int64_t stream_grid;    // blocks for streaming kernels (0 = auto: one tile per block)
+  int64_t stream_bpc;     // blocks per CU when stream_grid == 0
+  int64_t stream_unroll;  // 16-byte vectors in flight per lane per array: 1, 2, 4 or 8
+  int64_t stream_nt;      // bit0: nontemporal loads, bit1: nontemporal stores
+  int64_t cmp_variant;    // 0 = ballot (dword loads), 1 = vector loads + nibble shuffle
+  int64_t reduce_grid;    // blocks for reductions (0 = auto)
+  int64_t table_tiles;    // tiles per block for kernels that stage a lookup table in LDS (lut8 / trig16 / pow)
+  int64_t gather_bucket;  // take/put: 0 = auto (bucketed above the measured crossover), 1 = always direct, 2 = always bucketed
+  int64_t h2d_mode;       // host↔device staging of agpu_import/export_arrow: 0 = auto, 1 = pageable hipMemcpy, 2 = threaded pinned staging, 3 = hipHostRegister in place
+  int64_t h2d_threads;    // staging threads for mode 2 (0 = auto)
+};
+#define AGPU_TUNE_KEYS 10
+agpu_tuning agpu_tuning_defaults();  // snapshot of the process-wide defaults (atomics, runtime.hip)
+bool agpu_mem_pool_enabled();        // process-wide "mem_pool" switch (device-level behaviour, not per pipeline)
+
 // ---------------------------------------------------------------- handles
+// A pooled HIP event that several waiters share.  All fields are guarded by agpu_device::mu.
+struct agpu_event_ref {
+  hipEvent_t ev;
+  int refs;
+  bool done;  // someone observed hipEventQuery == hipSuccess
+};
+
+// Reduction scratch.  Ref-counted (under agpu_device::mu) because a captured hipGraph bakes the pointer into its
+// kernel nodes: the block outlives the stream's next, larger scratch for as long as such a graph exists.
+struct agpu_scratch_block {
+  void* ptr;
+  size_t bytes;
+  int refs;
+};
+
+// One HIP stream the library may have queued work on (owned + wrapped, live or idle).
+struct agpu_stream_slot {
+  hipStream_t stream = nullptr;
+  bool owned = false;
+  agpu_scratch_block* scratch = nullptr;  // travels with the stream through the idle pool
+  std::atomic<uint64_t> enq{0};           // +1 when an ABI call on this stream starts, +1 when it has enqueued its work (odd = in progress)
+  // ---- guarded by agpu_device::mu
+  uint64_t mark_seq = 0;                  // value of `enq` the newest marker covers
+  agpu_event_ref* mark = nullptr;         // newest marker event recorded on the stream (free / finish / destroy)
+  uint64_t finish_gen = 0;                // device generation at which `finish_ev` was published
+  agpu_event_ref* finish_ev = nullptr;    // marker of the last agpu_pipeline_finish / destroy on this stream
+};
+
 struct agpu_device {
   int ordinal;
   hipDeviceProp_t props;
   int num_cus;
   // 8 KiB of f64 {sin, cos} pairs for the 16-bit fused trig kernels (elementwise.hip: trig16_kernel), built once at
   // device creation: [l] = sincos(l), [256 + h] = sincos(256·h), l, h ∈ 0..255
-  void* trig16_table;
+  void* trig16_table = nullptr;
   // 2 KiB of f64 {1/c, −log2(1/c)} pairs for f32 pow (elementwise.hip: pow_f32_dev); same allocation, + 8 KiB
-  void* pow_table;
+  void* pow_table = nullptr;
 
   // ---- resource pools (runtime.hip).  Measured on MI355X / ROCm 7: hipStreamCreate 4.3 ms + hipStreamDestroy 2.6 ms,
   // hipFree 0.2 ms (implicit device sync), hipMalloc of a 4 GB block 0.2–60 ms — against 0.19 ms for the kernel of a
   // 1e8-row add.  The reference's default API creates a pipeline and an output buffer PER OP, so both are pooled.
-  struct StreamSlot {  // an idle owned stream with the reduction scratch and the error word that travel with it
-    hipStream_t stream;
-    void* scratch;
-    size_t scratch_bytes;
-    uint32_t* flags;
-  };
-  struct CachedBlock {  // a freed device block; `pending` = events recorded on every stream at free time
+  struct CachedBlock {  // a freed device block; `pending` = markers of the streams that were busy at free time
     void* ptr;
-    std::vector<hipEvent_t> pending;
+    std::vector<agpu_event_ref*> pending;
+    bool sync_all;  // freed while a stream was capturing (no marker could be recorded): device-sync before reuse
+  };
+  struct Slab {  // 2 MiB of HBM carved into equal blocks of one small size class
+    void* base;
+    int cls;
+    uint32_t nblocks, nfree;
   };
   std::mutex mu;
-  std::vector<StreamSlot> idle_streams;
-  std::vector<hipStream_t> all_streams;             // every stream work may be queued on (owned + wrapped, live or idle)
-  std::unordered_map<void*, size_t> block_size;     // live pooled-size blocks handed out by agpu_malloc
-  std::multimap<size_t, CachedBlock> cache;         // size → freed blocks
+  std::vector<agpu_stream_slot*> slots;             // every stream work may be queued on
+  std::vector<agpu_stream_slot*> idle;              // owned streams without a live pipeline
+  std::atomic<uint64_t> finish_gen{0};              // bumped by every published finish (cross-pipeline ordering)
+  std::unordered_map<void*, size_t> block_size;     // live pooled blocks handed out by agpu_malloc (large and small)
+  std::multimap<size_t, CachedBlock> cache;         // size → freed blocks ≥ 1 MiB
   size_t cached_bytes = 0, cache_cap = 0;
+  static constexpr int kSmallClasses = 12;          // 256 B … 512 KiB, powers of two
+  std::deque<CachedBlock> small_free[kSmallClasses];
+  std::map<uintptr_t, Slab> slabs;                  // base address → slab
+  size_t slab_bytes = 0;
   std::vector<hipEvent_t> event_pool;
+  // sticky error words (pinned host memory, 64 B apart): one per live pipeline, recycled only once the stream has
+  // passed every kernel of the previous owner
+  struct RetiredFlag {
+    uint32_t* word;
+    agpu_event_ref* after;
+  };
+  std::vector<uint32_t*> flag_free;
+  std::vector<RetiredFlag> flag_retired;
+  std::vector<void*> flag_slabs;
+  // page-locked staging chunks for host↔HBM transfers of pageable memory (arrow_cdata.hip); one transfer at a time
+  struct StageSlot {
+    void* host;
+    hipEvent_t ev;  // recorded after the DMA that last used the slot
+    bool used;
+  };
+  std::mutex stage_mu;
+  std::vector<StageSlot> stage;
 };
+#define AGPU_STAGE_CHUNK ((size_t)4 << 20)
+void agpu_internal_free_staging(agpu_device* dev);  // arrow_cdata.hip
 #define AGPU_TABLE_BYTES (512 * 16 + 128 * 16)
 agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table);  // elementwise.hip; synchronous
 
 struct agpu_pipeline {
   agpu_device* dev;
-  hipStream_t stream;
+  agpu_stream_slot* slot;
+  hipStream_t stream;  // == slot->stream
   bool owns_stream;
   bool capturing;
-  // scratch for reductions / popcount partials (allocated on first use, reused; stream-ordered so one per pipeline)
-  void* scratch;
-  size_t scratch_bytes;
+  uint64_t seen_gen;   // device finish generation this stream has already ordered itself behind
+  agpu_tuning tune;
   // sticky error word in pinned host memory, written by kernels (bit 0: take/put index out of range), read and cleared
   // by agpu_pipeline_sync — no pre-pass over the index column, no readback, the pipeline stays asynchronous
   uint32_t* flags;
+  // profiling [ref: CmpQuery compute_query.rs:7-89, insert_debug_marker gpu_device.rs:132]
+  uint32_t profile;    // AGPU_PROF_* bits
+  int scope_depth;
+  hipEvent_t t0, t1;   // event pair around the outermost ABI call (created on first use)
+  bool t_valid;
+  const char* last_name;
 };
 #define AGPU_FLAG_INDEX_RANGE 1u
+#define AGPU_PROF_ROCTX 1u   // roctx range named after the ABI call / reference entry point around every launch
+#define AGPU_PROF_TIMING 2u  // HIP event pair around every launch (agpu_pipeline_last_kernel_ns)
+#define AGPU_PROF_LOG 4u     // wait + log "Time taken for compute pass" to stderr after every launch
 
 struct agpu_event {
   agpu_device* dev;
@@ -75,6 +157,7 @@ struct agpu_graph {
   agpu_device* dev;
   hipGraph_t graph;
   hipGraphExec_t exec;
+  agpu_scratch_block* scratch;  // the capturing pipeline's scratch block, kept alive for the graph's lifetime
 };
 
 // ---------------------------------------------------------------- errors
@@ -107,34 +190,29 @@ void agpu_set_error(const char* fmt, ...);
     }                                                                                \
   } while (0)
 
-static inline agpu_status agpu_bind(agpu_pipeline* p) {
-  if (!p || !p->dev) {
-    agpu_set_error("null pipeline");
-    return AGPU_ERR_ARG;
+// Every ABI call that takes a pipeline opens a scope: bind the device, order the stream behind whatever other
+// pipelines have finished since it last looked (runtime.hip: cross-pipeline ordering), open the profiling range;
+// leaving the scope counts the call on the stream and closes the range.
+agpu_status agpu_scope_enter(agpu_pipeline* p, const char* name);
+void agpu_scope_exit(agpu_pipeline* p);
+struct agpu_call_scope {
+  agpu_pipeline* p = nullptr;
+  ~agpu_call_scope() {
+    if (p) agpu_scope_exit(p);
   }
-  AGPU_HIP(hipSetDevice(p->dev->ordinal));
-  return AGPU_OK;
-}
-#define AGPU_BIND(p)                         \
-  do {                                       \
-    agpu_status _s = agpu_bind(p);           \
-    if (_s != AGPU_OK) return _s;            \
+};
+#define AGPU_BIND_AS(p, name)                              \
+  agpu_call_scope _agpu_scope;                             \
+  do {                                                     \
+    agpu_status _s = agpu_scope_enter((p), (name));        \
+    if (_s != AGPU_OK) return _s;                          \
+    _agpu_scope.p = (p);                                   \
   } while (0)
+#define AGPU_BIND(p) AGPU_BIND_AS(p, __func__)  // internal helpers that open the scope name the ABI call explicitly
 
 agpu_status agpu_scratch(agpu_pipeline* p, size_t bytes, void** out);
+void agpu_scope_label(agpu_pipeline* p, const char* label);
 
-// ---------------------------------------------------------------- tuning knobs (bench sweeps; see agpu_set_tuning)
-struct agpu_tuning {
-  int64_t stream_grid;    // blocks for streaming kernels (0 = auto: CUs * stream_blocks_per_cu)
-  int64_t stream_bpc;     // blocks per CU when stream_grid == 0
-  int64_t stream_unroll;  // 16-byte vectors in flight per lane per array: 1, 2, 4 or 8
-  int64_t stream_nt;      // bit0: nontemporal loads, bit1: nontemporal stores
-  int64_t cmp_variant;    // 0 = ballot (dword loads), 1 = vector loads + nibble shuffle
-  int64_t reduce_grid;    // blocks for reductions (0 = auto)
-  int64_t table_tiles;    // tiles per block for kernels that stage a lookup table in LDS (lut8 / trig16 / pow)
-  int64_t mem_pool;       // 1 = cache freed device blocks ≥ 1 MiB and idle streams (default), 0 = hipMalloc/hipFree every time
-};
-extern agpu_tuning g_tune;
 
 // Grid for a streaming kernel that owns `tiles` block-tiles.  Measured on MI355X at 1e9 rows (profiles/
 // r01_sweep_add_f32_1e9.json): ONE tile per block beats every persistent grid (6.54 vs ≤6.52 TB/s at 32768 blocks,
@@ -142,8 +220,8 @@ extern agpu_tuning g_tune;
 // stream_bpc > 0 a blocks-per-CU one (both kept for sweeps).  Kernels still grid-stride, so any grid is correct.
 static inline int stream_grid_for(const agpu_pipeline* p, uint64_t tiles) {
   uint64_t g = tiles;
-  if (g_tune.stream_grid > 0) g = (uint64_t)g_tune.stream_grid;
-  else if (g_tune.stream_bpc > 0) g = (uint64_t)p->dev->num_cus * (uint64_t)g_tune.stream_bpc;
+  if (p->tune.stream_grid > 0) g = (uint64_t)p->tune.stream_grid;
+  else if (p->tune.stream_bpc > 0) g = (uint64_t)p->dev->num_cus * (uint64_t)p->tune.stream_bpc;
   if (g > tiles) g = tiles;
   if (g > 0x3FFFFFFFull) g = 0x3FFFFFFFull;  // hipDim3.x limit headroom
   if (g < 1) g = 1;

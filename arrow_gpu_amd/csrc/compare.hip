@@ -186,8 +186,8 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
                               void* out, void* outv, uint64_t n) {
   const T* pa = static_cast<const T*>(a);
   const T* pb = static_cast<const T*>(b);
-  const bool use_ballot = sizeof(T) == 4 && g_tune.cmp_variant == 0;
-  const bool nt = (g_tune.stream_nt & 1) != 0;  // inputs are read exactly once: nontemporal loads
+  const bool use_ballot = sizeof(T) == 4 && p->tune.cmp_variant == 0;
+  const bool nt = (p->tune.stream_nt & 1) != 0;  // inputs are read exactly once: nontemporal loads
   const uint64_t* va64 = static_cast<const uint64_t*>(va);
   const uint64_t* vb64 = static_cast<const uint64_t*>(vb);
   uint64_t* out64 = static_cast<uint64_t*>(out);
@@ -207,7 +207,7 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
     done_rows = ntiles * TILE;
   } else if (aligned16(a) && aligned16(b)) {
     // packs per lane and array in flight: 1 by default; "stream_unroll" = 2 / 4 for sweeps
-    const int u = g_tune.stream_unroll == 2 || g_tune.stream_unroll == 4 ? (int)g_tune.stream_unroll : 1;
+    const int u = p->tune.stream_unroll == 2 || p->tune.stream_unroll == 4 ? (int)p->tune.stream_unroll : 1;
     if (u == 4) done_rows = launch_cmp_vec<T, OP, 4>(p, pa, pb, va, vb, out, outv, n, nt, vec16);
     else if (u == 2) done_rows = launch_cmp_vec<T, OP, 2>(p, pa, pb, va, vb, out, outv, n, nt, vec16);
     else done_rows = launch_cmp_vec<T, OP, 1>(p, pa, pb, va, vb, out, outv, n, nt, vec16);
@@ -239,7 +239,7 @@ static agpu_status dispatch_cmp_op(agpu_pipeline* p, agpu_cmp_op op, const void*
 
 static agpu_status compare_impl(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
                                 const void* va, const void* vb, void* out, void* outv, uint64_t n) {
-  AGPU_BIND(p);
+  AGPU_BIND_AS(p, outv ? "agpu_compare_validity" : "agpu_compare");
   if (n == 0) return AGPU_OK;
   AGPU_REQUIRE(a && b && out, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(aligned_to(out, 8) && (!outv || aligned_to(outv, 8)) && (!va || aligned_to(va, 8)) &&

@@ -23,7 +23,7 @@
 #include "common.hpp"
 
 // tiles per block for the kernels that stage a table in LDS (lut8, trig16, pow): tuning key "table_tiles"
-static inline uint64_t tab_k() { return g_tune.table_tiles > 0 ? (uint64_t)g_tune.table_tiles : 1; }
+static inline uint64_t tab_k(const agpu_pipeline* p) { return p->tune.table_tiles > 0 ? (uint64_t)p->tune.table_tiles : 1; }
 
 #ifndef AGPU_STREAM_U
 #define AGPU_STREAM_U 1  // 16-byte vectors per lane per input array per tile (measured best: profiles/r01_sweep_add_f32_1e9.json)
@@ -187,6 +187,9 @@ struct UnAbs {
   }
 };
 struct UnNot { template <typename T> __device__ static __forceinline__ T ap(T x, T) { return (T)~x; } };
+struct UnPopc {  // countOneBits per element [logical/compute_shaders/u32/countbitones.wgsl:9-15]
+  template <typename T> __device__ static __forceinline__ T ap(T x, T) { return (T)__builtin_popcount((uint32_t)(U_of<T>)x); }
+};
 // ---- transcendental f32 functions: evaluated in f64 and rounded ONCE to f32 (≤ 1 ULP, in practice ≤ 0.5 ULP + 2^-30).
 // The f32 device-library versions measure 2 ULP for sin/cos/log on gfx950 (profiles/r01_probe_first_contact.json);
 // MI355X runs v_fma_f64 at half the f32 rate (78 TFLOP/s), and an 8 B/row stream at 6 TB/s leaves ≈50 f64 FMAs per
@@ -591,7 +594,7 @@ static agpu_status launch_pow_f32(agpu_pipeline* p, const void* a, const void* b
   if (aligned16(a) && aligned16(out) && (MODE != MODE_BINARY || aligned16(b))) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, (ntiles + tab_k() - 1) / tab_k())), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
+      hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p))), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
                          ntiles, tab);
       done = ntiles * TILE_ROWS;
     }
@@ -660,7 +663,7 @@ static agpu_status dispatch_f32_op(agpu_pipeline* p, agpu_binary_op op, const vo
 template <int MODE>
 static agpu_status dispatch_binary(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, const void* a, const void* b,
                                    void* out, uint64_t n) {
-  AGPU_BIND(p);
+  AGPU_BIND_AS(p, MODE == MODE_SCALAR ? "agpu_scalar" : "agpu_binary");
   AGPU_REQUIRE(n == 0 || (a && b && out), AGPU_ERR_ARG, "null pointer");
   switch (dtype) {
     case AGPU_F32: return dispatch_f32_op<MODE>(p, op, a, b, out, n);
@@ -810,6 +813,27 @@ struct CvtF32ToU8 {  // trunc toward 0, clamp to [0, 2^32-1], NaN→0, then mod 
     return (uint8_t)(u & 255u);
   }
 };
+// f32 → i8 / i16 / u16 / i32 / u32: REFERENCE-ABSENT (include/arrow_gpu.h agpu_cast) — WGSL u32(x) / i32(x) by the target's
+// signedness (trunc toward 0, clamp, NaN → 0), then the low bits of the target width; f32 → u8 above is the same rule.
+template <typename TO>
+struct CvtF32ToInt {
+  __device__ static __forceinline__ TO ap(float x) {
+    uint32_t bits;
+    if constexpr (std::is_signed<TO>::value) {
+      int32_t i;
+      if (x != x) i = 0;
+      else if (x >= 2147483648.0f) i = INT32_MAX;
+      else if (x <= -2147483648.0f) i = INT32_MIN;
+      else i = (int32_t)x;
+      bits = (uint32_t)i;
+    } else {
+      if (!(x > 0.0f)) bits = 0;
+      else if (x >= 4294967296.0f) bits = 0xFFFFFFFFu;
+      else bits = (uint32_t)x;
+    }
+    return (TO)(U_of<TO>)bits;
+  }
+};
 template <typename TI, typename F>
 struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders/{u8,i8,u16,i16}/*.wgsl]
   __device__ static __forceinline__ float ap(TI x) { return F::ap((float)x, 0.0f); }
@@ -851,7 +875,7 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
   if (aligned_to(in, 4) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      const int grid = stream_grid_for(p, (ntiles + tab_k() - 1) / tab_k());
+      const int grid = stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p));
       hipLaunchKernelGGL((lut8_kernel<TI, F>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, ntiles);
       done = ntiles * TILE_ROWS;
     }
@@ -958,7 +982,7 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
   if (aligned_to(in, 8) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS>), dim3(stream_grid_for(p, (ntiles + tab_k() - 1) / tab_k())), dim3(AGPU_BLOCK), 0, p->stream, pi,
+      hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS>), dim3(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p))), dim3(AGPU_BLOCK), 0, p->stream, pi,
                          po, ntiles, tab);
       done = ntiles * TILE_ROWS;
     }
@@ -1323,7 +1347,7 @@ extern "C" {
 // cmp_op < 0: agpu_fused_chain.  cmp_op ≥ 0: agpu_fused_chain_compare — the compare's operand rides in step slot n_steps.
 static agpu_status chain_dispatch(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
                                   int32_t n_steps, void* out, uint64_t n, int cmp_op, int cmp_kind, const void* cmp_operand) {
-  AGPU_BIND(p);
+  AGPU_BIND_AS(p, cmp_op >= 0 ? "agpu_fused_chain_compare" : "agpu_fused_chain");
   const bool cmp = cmp_op >= 0;
   AGPU_REQUIRE(n_steps >= 0 && n_steps + (cmp ? 1 : 0) <= AGPU_CHAIN_MAX_STEPS, AGPU_ERR_ARG,
                "0..8 steps per chain (0..7 before a compare)");
@@ -1400,6 +1424,7 @@ agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, con
     case AGPU_UN_NEG: return launch_ew<T, UnNeg, MODE_UNARY>(p, in, nullptr, out, n); \
     case AGPU_UN_ABS: return launch_ew<T, UnAbs, MODE_UNARY>(p, in, nullptr, out, n); \
     case AGPU_UN_NOT: return launch_ew<T, UnNot, MODE_UNARY>(p, in, nullptr, out, n); \
+    case AGPU_UN_POPCOUNT: return launch_ew<T, UnPopc, MODE_UNARY>(p, in, nullptr, out, n); \
     default: break;                                                             \
   }
 #define UN_FUSED(T)                                                                          \
@@ -1465,6 +1490,16 @@ agpu_status agpu_cast(agpu_pipeline* p, agpu_dtype from, agpu_dtype to, const vo
     return AGPU_OK;
   }
   if (from == AGPU_F32 && to == AGPU_U8) return launch_cvt<float, uint8_t, CvtF32ToU8>(p, in, out, n);
+  if (from == AGPU_F32) {  // reference-absent narrowing casts (see CvtF32ToInt)
+    switch (to) {
+      case AGPU_I8: return launch_cvt<float, int8_t, CvtF32ToInt<int8_t>>(p, in, out, n);
+      case AGPU_I16: return launch_cvt<float, int16_t, CvtF32ToInt<int16_t>>(p, in, out, n);
+      case AGPU_U16: return launch_cvt<float, uint16_t, CvtF32ToInt<uint16_t>>(p, in, out, n);
+      case AGPU_I32: return launch_cvt<float, int32_t, CvtF32ToInt<int32_t>>(p, in, out, n);
+      case AGPU_U32: return launch_cvt<float, uint32_t, CvtF32ToInt<uint32_t>>(p, in, out, n);
+      default: break;
+    }
+  }
 #define CAST_CASE(F, FT, T, TT) \
   if (from == F && to == T) return launch_cvt<FT, TT, CvtStatic<FT, TT>>(p, in, out, n)
   CAST_CASE(AGPU_I8, int8_t, AGPU_U16, uint16_t);

@@ -114,13 +114,14 @@ __device__ __forceinline__ float span_tree_sum(const float* in, const uint8_t* v
 
 template <bool HASV>
 __global__ __launch_bounds__(AGPU_BLOCK) void sum_tree_span_kernel(const float* in, const uint8_t* validity, uint64_t n,
-                                                                  float* partials) {
+                                                                  float* partials, int vec_ok) {
   __shared__ float lds[AGPU_BLOCK / AGPU_WAVE];
   const uint64_t nspans = (n + SPAN_ROWS - 1) / SPAN_ROWS;
   for (uint64_t sp = blockIdx.x; sp < nspans; sp += gridDim.x) {
     const uint64_t base = sp * SPAN_ROWS;
     float r;
-    if (base + SPAN_ROWS <= n) r = span_tree_sum<false, HASV>(in, validity, base, n, lds);
+    // vec_ok == 0: the column is only 4-byte aligned (a slice, an odd shard offset) — same spans, same tree, scalar loads
+    if (vec_ok && base + SPAN_ROWS <= n) r = span_tree_sum<false, HASV>(in, validity, base, n, lds);
     else r = span_tree_sum<true, HASV>(in, validity, base, n, lds);
     if (threadIdx.x == 0) partials[sp] = r;
   }
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void reduce_finish_kernel(const typenam
 // 6.70 TB/s for min / f64 sum / i32 sum vs 6.31 / 6.45 / 6.58 at 64 per CU), 64 for the span-per-block tree sum (6.18 vs
 // 5.96–6.07 at 8–32 per CU) — tools/probe/reduce_sweep.py, one process, same buffer.
 static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks, int blocks_per_cu) {
-  int64_t g = g_tune.reduce_grid > 0 ? g_tune.reduce_grid : (int64_t)p->dev->num_cus * blocks_per_cu;
+  int64_t g = p->tune.reduce_grid > 0 ? p->tune.reduce_grid : (int64_t)p->dev->num_cus * blocks_per_cu;
   if ((uint64_t)g > work_blocks) g = (int64_t)work_blocks;
   if (g < 1) g = 1;
   return (int)g;
@@ -327,22 +328,118 @@ static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const 
   float* partials = static_cast<float*>(scratch);
   float* buf0 = partials + nspans + 4;
   float* buf1 = buf0 + level_cap;
-  if (n <= 256 || !aligned16(in)) {
-    // one (or more) plain reference levels straight from the input; also the unaligned fallback
+  if (n <= 256) {
+    // one plain reference level straight from the input (a single 256-row workgroup)
     hipLaunchKernelGGL(sum_tree_finish_kernel, dim3(1), dim3(AGPU_BLOCK), 0, p->stream, in, validity, buf0, buf1, n, out, 1);
     AGPU_LAUNCH_CHECK();
     return AGPU_OK;
   }
   const int grid = reduce_grid_for(p, nspans, 64);
+  const int vec_ok = aligned16(in) ? 1 : 0;
   if (validity)
-    hipLaunchKernelGGL((sum_tree_span_kernel<true>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, in, validity, n, partials);
+    hipLaunchKernelGGL((sum_tree_span_kernel<true>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, in, validity, n, partials, vec_ok);
   else
-    hipLaunchKernelGGL((sum_tree_span_kernel<false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, in, validity, n, partials);
+    hipLaunchKernelGGL((sum_tree_span_kernel<false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, in, validity, n, partials, vec_ok);
   AGPU_LAUNCH_CHECK();
   hipLaunchKernelGGL(sum_tree_finish_kernel, dim3(1), dim3(AGPU_BLOCK), 0, p->stream, (const float*)partials,
                      (const uint8_t*)nullptr, buf0, buf1, nspans, out, 0);
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU final reduce (comm.hip)
+// One 16-byte record per rank {statistic in the low 4 / 8 bytes, n_local}, gathered over RCCL, combined here IN RANK
+// ORDER by one workgroup on every rank — deterministic and identical everywhere, independent of RCCL's ring order.
+struct CommRecord {
+  uint64_t bits;
+  uint64_t n_local;
+};
+
+__global__ void comm_pack_kernel(CommRecord* rec, uint64_t n_local) {
+  rec->bits = 0;
+  rec->n_local = n_local;
+}
+
+// f32 SUM: the shard sums are one more level of the reference's tree — adjacent pairs, zero-padded to 256 entries
+// [ref: aggregate.wgsl:21-41].  Shards of 256^k rows therefore reproduce the reference's whole-column tree bit for bit.
+__global__ __launch_bounds__(AGPU_BLOCK) void comm_finish_sum_f32_kernel(const CommRecord* rec, int world, float* out) {
+  __shared__ float sh[AGPU_BLOCK];
+  const uint32_t tid = threadIdx.x;
+  sh[tid] = (int)tid < world ? __builtin_bit_cast(float, (uint32_t)rec[tid].bits) : 0.0f;
+  __syncthreads();
+  for (uint32_t s = 1; s < 256; s *= 2) {
+    const uint32_t idx = 2 * s * tid;
+    if (idx + s < 256) sh[idx] = sh[idx] + sh[idx + s];
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = sh[0];
+}
+
+template <typename T, typename Red>
+__global__ void comm_finish_kernel(const CommRecord* rec, int world, typename Red::Out* out) {
+  if (threadIdx.x != 0) return;
+  typename Red::Acc acc = Red::identity();
+  for (int r = 0; r < world; r++) {
+    if (rec[r].n_local == 0) continue;  // an empty shard contributes the identity
+    T x;
+    if constexpr (sizeof(T) == 8) x = __builtin_bit_cast(T, rec[r].bits);
+    else x = __builtin_bit_cast(T, (uint32_t)rec[r].bits);
+    acc = Red::combine(acc, Red::load(x));
+  }
+  out[0] = Red::finish(acc);
+}
+
+struct RedSumF64Plain {  // rank-ordered f64 sum of f64 partials
+  typedef double Acc;
+  typedef double Out;
+  __device__ static Acc identity() { return 0.0; }
+  __device__ static Acc load(double x) { return x; }
+  __device__ static Acc combine(Acc a, Acc b) { return a + b; }
+  __device__ static Out finish(Acc a) { return a; }
+};
+
+agpu_status agpu_internal_comm_pack(agpu_pipeline* p, void* record, uint64_t n_local) {
+  hipLaunchKernelGGL(comm_pack_kernel, dim3(1), dim3(1), 0, p->stream, static_cast<CommRecord*>(record), n_local);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+agpu_status agpu_internal_comm_finish(agpu_pipeline* p, int kind, agpu_dtype dtype, const void* records, int world,
+                                      void* out_dev) {
+  const CommRecord* rec = static_cast<const CommRecord*>(records);
+  typedef RedMinMaxInt<int32_t, false> MinI32;
+  typedef RedMinMaxInt<uint32_t, false> MinU32;
+  typedef RedMinMaxInt<int32_t, true> MaxI32;
+  typedef RedMinMaxInt<uint32_t, true> MaxU32;
+#define FIN(T, RED) \
+  hipLaunchKernelGGL((comm_finish_kernel<T, RED>), dim3(1), dim3(AGPU_WAVE), 0, p->stream, rec, world, static_cast<typename RED::Out*>(out_dev))
+  if (kind == 3) {
+    FIN(double, RedSumF64Plain);
+  } else if (kind == AGPU_RED_SUM) {
+    if (dtype == AGPU_F32)
+      hipLaunchKernelGGL(comm_finish_sum_f32_kernel, dim3(1), dim3(AGPU_BLOCK), 0, p->stream, rec, world, static_cast<float*>(out_dev));
+    else if (dtype == AGPU_I32) FIN(int32_t, RedSumWrap<int32_t>);
+    else if (dtype == AGPU_U32) FIN(uint32_t, RedSumWrap<uint32_t>);
+    else goto unsupported;
+  } else if (kind == AGPU_RED_MIN) {
+    if (dtype == AGPU_F32) FIN(float, RedMinMaxF32<false>);
+    else if (dtype == AGPU_I32) FIN(int32_t, MinI32);
+    else if (dtype == AGPU_U32) FIN(uint32_t, MinU32);
+    else goto unsupported;
+  } else if (kind == AGPU_RED_MAX) {
+    if (dtype == AGPU_F32) FIN(float, RedMinMaxF32<true>);
+    else if (dtype == AGPU_I32) FIN(int32_t, MaxI32);
+    else if (dtype == AGPU_U32) FIN(uint32_t, MaxU32);
+    else goto unsupported;
+  } else {
+    goto unsupported;
+  }
+#undef FIN
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+unsupported:
+  agpu_set_error("final reduce: op %d not supported for dtype %d", kind, (int)dtype);
+  return AGPU_ERR_UNSUPPORTED;
 }
 
 extern "C" {

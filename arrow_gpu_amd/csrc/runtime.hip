@@ -2,7 +2,19 @@
 // Replaces arrow_gpu_array::gpu_utils::{GpuDevice, ArrowComputePipeline, CmpQuery}
 // [ref: crates/array/src/gpu_utils/gpu_device.rs:29-514, compute_pipeline.rs:8-300, compute_query.rs:7-90].
 // A pipeline is a HIP stream: launches are eager and ordered, `finish` is the (already satisfied) submit point.
+#include <rocprofiler-sdk-roctx/roctx.h>
+
+#include <cstdlib>
+#include <memory>
+
 #include "common.hpp"
+
+#define AGPU_SMALL_MAX ((size_t)512 << 10)      // largest size class of the slab pool
+#define AGPU_POOL_MIN_BYTES (AGPU_SMALL_MAX + 1) // larger blocks: size-keyed cache of whole hipMalloc'ed blocks (2 MiB granules)
+#define AGPU_POOL_GRANULE ((size_t)2 << 20)
+#define AGPU_SMALL_MIN ((size_t)256)            // smallest size class of the slab pool
+#define AGPU_SLAB_BYTES ((size_t)2 << 20)
+#define AGPU_SLAB_CAP ((size_t)1 << 30)         // never more than 1 GiB of slabs just to avoid waiting on a marker
 
 static thread_local char g_err[512] = "";
 
@@ -13,10 +25,103 @@ void agpu_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-agpu_tuning g_tune = {
-    /*stream_grid*/ 0, /*stream_bpc*/ 0, /*stream_unroll*/ 1, /*stream_nt*/ 1, /*cmp_variant*/ 0, /*reduce_grid*/ 0,
-    /*table_tiles*/ 4,  // profiles/r01_sweep_table_tiles.json: sin_u8 5.74 → 6.02, sin_u16 5.85 → 6.16 TB/s vs 1 tile per block
-    /*mem_pool*/ 1};
+// ---------------------------------------------------------------- process-wide tuning defaults
+// Plain atomics: agpu_set_tuning may be called from any thread; a pipeline snapshots them when it is created.
+static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
+    /*stream_grid*/ {0}, /*stream_bpc*/ {0}, /*stream_unroll*/ {1}, /*stream_nt*/ {1}, /*cmp_variant*/ {0}, /*reduce_grid*/ {0},
+    /*table_tiles*/ {4},  // profiles/r01_sweep_table_tiles.json: sin_u8 5.74 → 6.02, sin_u16 5.85 → 6.16 TB/s vs 1 tile per block
+    /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}};
+static std::atomic<int64_t> g_mem_pool{1};  // 1 = recycle device blocks and idle streams (default), 0 = hipMalloc/hipFree every time
+static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "stream_bpc", "stream_unroll", "stream_nt",
+                                                         "cmp_variant", "reduce_grid", "table_tiles", "gather_bucket",
+                                                         "h2d_mode", "h2d_threads"};
+
+agpu_tuning agpu_tuning_defaults() {
+  agpu_tuning t;
+  int64_t* f = reinterpret_cast<int64_t*>(&t);
+  for (int i = 0; i < AGPU_TUNE_KEYS; i++) f[i] = g_tune_default[i].load(std::memory_order_relaxed);
+  return t;
+}
+bool agpu_mem_pool_enabled() { return g_mem_pool.load(std::memory_order_relaxed) != 0; }
+static int tune_index(const char* key) {
+  if (!key) return -1;
+  for (int i = 0; i < AGPU_TUNE_KEYS; i++)
+    if (!strcmp(key, g_tune_keys[i])) return i;
+  return -1;
+}
+static_assert(sizeof(agpu_tuning) == AGPU_TUNE_KEYS * sizeof(int64_t), "agpu_tuning is indexed as an int64 array");
+
+// AGPU_PROFILE=<bits>: 1 = roctx ranges, 2 = per-launch HIP-event timing, 4 = also wait + log every launch (stderr)
+static uint32_t env_profile() {
+  static const uint32_t v = [] {
+    const char* e = getenv("AGPU_PROFILE");
+    if (!e || !*e) return 0u;
+    uint32_t b = (uint32_t)strtoul(e, nullptr, 0);
+    if (b & AGPU_PROF_LOG) b |= AGPU_PROF_TIMING;
+    return b;
+  }();
+  return v;
+}
+
+// ---------------------------------------------------------------- shared events (all under dev->mu)
+static hipEvent_t event_get_locked(agpu_device* dev) {
+  hipEvent_t ev = nullptr;
+  if (!dev->event_pool.empty()) {
+    ev = dev->event_pool.back();
+    dev->event_pool.pop_back();
+  } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    ev = nullptr;
+  }
+  return ev;
+}
+static void ref_release_locked(agpu_device* dev, agpu_event_ref* r) {
+  if (r && --r->refs == 0) {
+    dev->event_pool.push_back(r->ev);
+    delete r;
+  }
+}
+static bool ref_done_locked(agpu_event_ref* r) {
+  if (!r || r->done) return true;
+  hipError_t e = hipEventQuery(r->ev);
+  if (e == hipSuccess) r->done = true;
+  else (void)hipGetLastError();
+  return r->done;
+}
+// Newest marker of a stream, recording a fresh one if ABI calls completed on it since the last (wrapped streams are
+// always treated as dirty: their owner enqueues work the library does not see).  *ok = false if it could not be
+// recorded (the stream is being captured into a graph).
+static agpu_event_ref* slot_mark_locked(agpu_device* dev, agpu_stream_slot* s, bool* ok) {
+  *ok = true;
+  // `enq` is odd while an ABI call is in progress on the stream (it may have enqueued part of its work already, e.g. a
+  // call that frees its own temporary): record a fresh marker and leave the stream dirty
+  const uint64_t e = s->enq.load(std::memory_order_acquire);
+  if (s->owned && !(e & 1) && e == s->mark_seq) return s->mark;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();  // an event recorded now would become a graph node
+    *ok = false;
+    return s->mark;
+  }
+  hipEvent_t ev = event_get_locked(dev);
+  if (!ev || hipEventRecord(ev, s->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    if (ev) dev->event_pool.push_back(ev);
+    *ok = false;
+    return s->mark;
+  }
+  ref_release_locked(dev, s->mark);
+  s->mark = new agpu_event_ref{ev, 1, false};
+  s->mark_seq = e & ~(uint64_t)1;  // an in-progress call is never counted as covered
+  return s->mark;
+}
+
+static void scratch_release_locked(agpu_scratch_block* b) {  // the caller made sure no queued work still uses it
+  if (b && --b->refs == 0) {
+    (void)hipFree(b->ptr);
+    delete b;
+  }
+}
 
 extern "C" {
 
@@ -61,28 +166,25 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
     return AGPU_ERR_NO_DEVICE;
   }
   AGPU_REQUIRE(ordinal >= 0 && ordinal < n, AGPU_ERR_ARG, "device ordinal out of range");
-  agpu_device* d = new agpu_device();
+  std::unique_ptr<agpu_device> d(new agpu_device());  // released on every early-error return below
   d->ordinal = ordinal;
   AGPU_HIP(hipSetDevice(ordinal));
   AGPU_HIP(hipGetDeviceProperties(&d->props, ordinal));
   d->num_cus = d->props.multiProcessorCount;
   if (strncmp(d->props.gcnArchName, "gfx950", 6) != 0) {
     agpu_set_error("device %d is %s; this library is built for gfx950 only", ordinal, d->props.gcnArchName);
-    delete d;
     return AGPU_ERR_NO_DEVICE;
   }
-  d->trig16_table = nullptr;
   hipError_t me = hipMalloc(&d->trig16_table, AGPU_TABLE_BYTES);
   d->pow_table = me == hipSuccess ? static_cast<char*>(d->trig16_table) + 512 * 16 : nullptr;
   agpu_status ts = me == hipSuccess ? agpu_internal_build_tables(d->trig16_table, d->pow_table) : AGPU_ERR_HIP;
   if (ts != AGPU_OK) {
     if (me != hipSuccess) agpu_set_error("hipMalloc of the function tables failed: %s", hipGetErrorString(me));
     if (d->trig16_table) (void)hipFree(d->trig16_table);
-    delete d;
     return ts;
   }
   d->cache_cap = d->props.totalGlobalMem / 2;  // cached (idle) blocks never hold more than half of HBM
-  *out_device = d;
+  *out_device = d.release();
   return AGPU_OK;
 }
 
@@ -90,15 +192,36 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
 static void device_trim_locked(agpu_device* dev) {
   (void)hipDeviceSynchronize();
   for (auto& kv : dev->cache) {
-    for (hipEvent_t e : kv.second.pending) dev->event_pool.push_back(e);
+    for (agpu_event_ref* r : kv.second.pending) ref_release_locked(dev, r);
     (void)hipFree(kv.second.ptr);
   }
   dev->cache.clear();
   dev->cached_bytes = 0;
-  for (auto& s : dev->idle_streams) {
-    if (s.scratch) (void)hipFree(s.scratch);
-    s.scratch = nullptr;
-    s.scratch_bytes = 0;
+  // small blocks: a slab goes back to the driver when every block carved from it is free
+  for (auto it = dev->slabs.begin(); it != dev->slabs.end();) {
+    agpu_device::Slab& sl = it->second;
+    if (sl.nfree != sl.nblocks) {
+      ++it;
+      continue;
+    }
+    const uintptr_t lo = it->first, hi = lo + AGPU_SLAB_BYTES;
+    auto& fl = dev->small_free[sl.cls];
+    for (auto b = fl.begin(); b != fl.end();) {
+      const uintptr_t a = reinterpret_cast<uintptr_t>(b->ptr);
+      if (a >= lo && a < hi) {
+        for (agpu_event_ref* r : b->pending) ref_release_locked(dev, r);
+        b = fl.erase(b);
+      } else {
+        ++b;
+      }
+    }
+    (void)hipFree(sl.base);
+    dev->slab_bytes -= AGPU_SLAB_BYTES;
+    it = dev->slabs.erase(it);
+  }
+  for (agpu_stream_slot* s : dev->idle) {
+    if (s->scratch) scratch_release_locked(s->scratch);
+    s->scratch = nullptr;
   }
 }
 
@@ -116,7 +239,22 @@ agpu_status agpu_device_pool_info(agpu_device* dev, uint64_t* out_cached_bytes, 
   std::lock_guard<std::mutex> lock(dev->mu);
   if (out_cached_bytes) *out_cached_bytes = dev->cached_bytes;
   if (out_cached_blocks) *out_cached_blocks = dev->cache.size();
-  if (out_idle_streams) *out_idle_streams = dev->idle_streams.size();
+  if (out_idle_streams) *out_idle_streams = dev->idle.size();
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_small_pool_info(agpu_device* dev, uint64_t* out_slab_bytes, uint64_t* out_free_blocks,
+                                        uint64_t* out_live_blocks) {
+  AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
+  std::lock_guard<std::mutex> lock(dev->mu);
+  uint64_t nfree = 0, total = 0;
+  for (auto& kv : dev->slabs) {
+    nfree += kv.second.nfree;
+    total += kv.second.nblocks;
+  }
+  if (out_slab_bytes) *out_slab_bytes = dev->slab_bytes;
+  if (out_free_blocks) *out_free_blocks = nfree;
+  if (out_live_blocks) *out_live_blocks = total - nfree;
   return AGPU_OK;
 }
 
@@ -126,14 +264,25 @@ agpu_status agpu_device_destroy(agpu_device* dev) {
   {
     std::lock_guard<std::mutex> lock(dev->mu);
     device_trim_locked(dev);
-    for (auto& s : dev->idle_streams) {
-      (void)hipStreamDestroy(s.stream);
-      if (s.flags) (void)hipHostFree(s.flags);
+    for (agpu_stream_slot* s : dev->slots) {
+      ref_release_locked(dev, s->mark);
+      ref_release_locked(dev, s->finish_ev);
+      if (s->scratch) scratch_release_locked(s->scratch);
+      if (s->owned) (void)hipStreamDestroy(s->stream);
+      delete s;
     }
-    dev->idle_streams.clear();
+    dev->slots.clear();
+    dev->idle.clear();
+    for (auto& rf : dev->flag_retired) ref_release_locked(dev, rf.after);
+    dev->flag_retired.clear();
+    for (auto& kv : dev->slabs) (void)hipFree(kv.second.base);  // blocks the caller leaked
+    dev->slabs.clear();
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     dev->event_pool.clear();
+    for (void* f : dev->flag_slabs) (void)hipHostFree(f);
+    dev->flag_slabs.clear();
   }
+  agpu_internal_free_staging(dev);
   if (dev->trig16_table) (void)hipFree(dev->trig16_table);
   delete dev;
   return AGPU_OK;
@@ -169,12 +318,60 @@ agpu_status agpu_device_mem_info(agpu_device* dev, uint64_t* out_free, uint64_t*
 }
 
 // ---------------------------------------------------------------- buffers
-// Blocks ≥ 1 MiB are rounded up to 2 MiB multiples and recycled through dev->cache.  A freed block may still be read or
-// written by work queued on some stream (the host layers drop their references when a pipeline is released, not when
-// the GPU is done; hipFree used to cover that with its implicit device sync), so agpu_free records one event per stream
-// and agpu_malloc waits for them before handing the block out again — normally they completed long ago.
-#define AGPU_POOL_MIN_BYTES ((size_t)1 << 20)
-#define AGPU_POOL_GRANULE ((size_t)2 << 20)
+// Two pools, both keyed by size.  Blocks > 512 KiB are rounded up to 2 MiB multiples and recycled through dev->cache.
+// Smaller blocks — the reference's whole test-suite and examples/simple.rs live at 5–100 elements — come from 2 MiB
+// slabs carved into one power-of-two size class each (256 B … 512 KiB), so a tiny array costs neither a hipMalloc nor
+// hipFree's device-wide synchronisation.  A freed block may still be read or written by work queued on some stream (the
+// host layers drop their references when a pipeline is released, not when the GPU is done; hipFree used to cover that
+// by synchronising), so agpu_free attaches the marker event of every stream that has work outstanding and agpu_malloc
+// waits for those before handing the block out again — idle streams cost nothing, and small blocks are reused oldest
+// first so the markers have normally completed long ago.
+static void collect_pending_locked(agpu_device* dev, std::vector<agpu_event_ref*>* pending, bool* ok) {
+  *ok = true;
+  for (agpu_stream_slot* s : dev->slots) {
+    bool rec = true;
+    agpu_event_ref* m = slot_mark_locked(dev, s, &rec);
+    if (!rec) {
+      *ok = false;
+      return;
+    }
+    if (m && !ref_done_locked(m)) {
+      m->refs++;
+      pending->push_back(m);
+    }
+  }
+}
+
+static agpu_status wait_pending(agpu_device* dev, std::vector<agpu_event_ref*>& pending) {
+  hipError_t e = hipSuccess;
+  for (agpu_event_ref* r : pending)
+    if (e == hipSuccess && !r->done) e = hipEventSynchronize(r->ev);
+  {
+    std::lock_guard<std::mutex> lock(dev->mu);
+    for (agpu_event_ref* r : pending) {
+      if (e == hipSuccess) r->done = true;
+      ref_release_locked(dev, r);
+    }
+  }
+  pending.clear();
+  if (e != hipSuccess) {
+    agpu_set_error("hipEventSynchronize failed: %s", hipGetErrorString(e));
+    return AGPU_ERR_HIP;
+  }
+  return AGPU_OK;
+}
+
+static int small_class(size_t padded) {  // 256 B → 0 … 512 KiB → 11
+  int c = 0;
+  while (((size_t)AGPU_SMALL_MIN << c) < padded) c++;
+  return c;
+}
+
+static bool all_done_locked(const std::vector<agpu_event_ref*>& v) {
+  for (agpu_event_ref* r : v)
+    if (!ref_done_locked(r)) return false;
+  return true;
+}
 
 agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void** out_ptr) {
   AGPU_REQUIRE(dev && out_ptr, AGPU_ERR_ARG, "null argument");
@@ -182,35 +379,61 @@ agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void*
   // pad to 16 B so vector tails of sub-word columns and bitmap words are always addressable
   size_t padded = (bytes + 15) & ~(size_t)15;
   if (padded == 0) padded = 16;
-  const bool pooled = g_tune.mem_pool != 0 && padded >= AGPU_POOL_MIN_BYTES;
-  if (pooled) padded = (padded + AGPU_POOL_GRANULE - 1) / AGPU_POOL_GRANULE * AGPU_POOL_GRANULE;
+  const bool pool = agpu_mem_pool_enabled();
+  const bool large = pool && padded >= AGPU_POOL_MIN_BYTES;
+  const bool small = pool && !large;
   void* p = nullptr;
-  if (pooled) {
-    std::vector<hipEvent_t> pending;
-    {
-      std::lock_guard<std::mutex> lock(dev->mu);
-      auto it = dev->cache.lower_bound(padded);
-      if (it != dev->cache.end() && it->first <= padded + padded / 8) {  // accept up to 12.5 % slack
-        p = it->second.ptr;
-        pending = std::move(it->second.pending);
-        dev->cached_bytes -= it->first;
-        dev->block_size[p] = it->first;
-        dev->cache.erase(it);
+  std::vector<agpu_event_ref*> pending;
+  bool sync_all = false;
+  if (large) {
+    padded = (padded + AGPU_POOL_GRANULE - 1) / AGPU_POOL_GRANULE * AGPU_POOL_GRANULE;
+    std::lock_guard<std::mutex> lock(dev->mu);
+    auto it = dev->cache.lower_bound(padded);
+    if (it != dev->cache.end() && it->first <= padded + padded / 8) {  // accept up to 12.5 % slack
+      p = it->second.ptr;
+      pending = std::move(it->second.pending);
+      dev->cached_bytes -= it->first;
+      dev->block_size[p] = it->first;
+      padded = it->first;
+      dev->cache.erase(it);
+    }
+  } else if (small) {
+    const int cls = small_class(padded < AGPU_SMALL_MIN ? AGPU_SMALL_MIN : padded);
+    padded = (size_t)AGPU_SMALL_MIN << cls;
+    std::lock_guard<std::mutex> lock(dev->mu);
+    auto& fl = dev->small_free[cls];
+    // oldest first; a block whose markers are still running goes to the back of the queue once — a fresh slab is
+    // cheaper than stalling the host behind the GPU (bounded: at most AGPU_SLAB_CAP of slabs)
+    if (!fl.empty() && !all_done_locked(fl.front().pending) && fl.size() > 1) {
+      fl.push_back(std::move(fl.front()));
+      fl.pop_front();
+    }
+    if (fl.empty() || (!all_done_locked(fl.front().pending) && dev->slab_bytes + AGPU_SLAB_BYTES <= AGPU_SLAB_CAP)) {
+      void* base = nullptr;
+      if (hipMalloc(&base, AGPU_SLAB_BYTES) == hipSuccess) {
+        const uint32_t nb = (uint32_t)(AGPU_SLAB_BYTES / padded);
+        dev->slabs[reinterpret_cast<uintptr_t>(base)] = agpu_device::Slab{base, cls, nb, nb};
+        dev->slab_bytes += AGPU_SLAB_BYTES;
+        for (uint32_t i = nb; i-- > 0;) fl.push_front(agpu_device::CachedBlock{static_cast<char*>(base) + (size_t)i * padded, {}, false});
+      } else {
+        (void)hipGetLastError();  // fall through: reuse a busy block, or a plain hipMalloc below
       }
     }
-    if (p) {
-      hipError_t e = hipSuccess;
-      for (hipEvent_t ev : pending)
-        if (e == hipSuccess) e = hipEventSynchronize(ev);
-      {
-        std::lock_guard<std::mutex> lock(dev->mu);
-        for (hipEvent_t ev : pending) dev->event_pool.push_back(ev);
-      }
-      if (e != hipSuccess) {
-        agpu_set_error("hipEventSynchronize failed: %s", hipGetErrorString(e));
-        return AGPU_ERR_HIP;
-      }
+    if (!fl.empty()) {
+      p = fl.front().ptr;
+      pending = std::move(fl.front().pending);
+      sync_all = fl.front().sync_all;
+      fl.pop_front();
+      auto sl = dev->slabs.upper_bound(reinterpret_cast<uintptr_t>(p));
+      --sl;
+      sl->second.nfree--;
+      dev->block_size[p] = padded;
     }
+  }
+  if (p && sync_all) (void)hipDeviceSynchronize();
+  if (p && !pending.empty()) {
+    agpu_status ws = wait_pending(dev, pending);
+    if (ws != AGPU_OK) return ws;
   }
   if (!p) {
     hipError_t e = hipMalloc(&p, padded);
@@ -225,7 +448,7 @@ agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void*
       agpu_set_error("hipMalloc(%zu) failed: %s", padded, hipGetErrorString(e));
       return AGPU_ERR_HIP;
     }
-    if (pooled) {
+    if (large) {
       std::lock_guard<std::mutex> lock(dev->mu);
       dev->block_size[p] = padded;
     }
@@ -254,39 +477,34 @@ agpu_status agpu_free(agpu_device* dev, void* ptr) {
     auto it = dev->block_size.find(ptr);
     if (it != dev->block_size.end()) {
       const size_t size = it->second;
-      dev->block_size.erase(it);
-      if (g_tune.mem_pool != 0 && dev->cached_bytes + size <= dev->cache_cap) {
-        agpu_device::CachedBlock blk{ptr, {}};
+      const bool small = size < AGPU_POOL_MIN_BYTES;
+      if (small) {  // part of a slab: can only go back to its free list
+        dev->block_size.erase(it);
+        agpu_device::CachedBlock blk{ptr, {}, false};
         bool ok = true;
-        for (hipStream_t s : dev->all_streams) {
-          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-          if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-            (void)hipGetLastError();  // an event recorded now would become a graph node: do not pool this block
-            ok = false;
-            break;
-          }
-          hipEvent_t ev = nullptr;
-          if (!dev->event_pool.empty()) {
-            ev = dev->event_pool.back();
-            dev->event_pool.pop_back();
-          } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-            ok = false;
-            break;
-          }
-          if (hipEventRecord(ev, s) != hipSuccess) {  // e.g. the stream is being captured into a graph
-            (void)hipGetLastError();
-            dev->event_pool.push_back(ev);
-            ok = false;
-            break;
-          }
-          blk.pending.push_back(ev);
+        collect_pending_locked(dev, &blk.pending, &ok);
+        if (!ok) {  // a stream is being captured: no marker can be recorded now; the next owner waits for the device
+          for (agpu_event_ref* r : blk.pending) ref_release_locked(dev, r);
+          blk.pending.clear();
+          blk.sync_all = true;
         }
+        auto sl = dev->slabs.upper_bound(reinterpret_cast<uintptr_t>(ptr));
+        --sl;
+        sl->second.nfree++;
+        dev->small_free[sl->second.cls].push_back(std::move(blk));
+        return AGPU_OK;
+      }
+      dev->block_size.erase(it);
+      if (agpu_mem_pool_enabled() && dev->cached_bytes + size <= dev->cache_cap) {
+        agpu_device::CachedBlock blk{ptr, {}, false};
+        bool ok = true;
+        collect_pending_locked(dev, &blk.pending, &ok);
         if (ok) {
           dev->cached_bytes += size;
           dev->cache.emplace(size, std::move(blk));
           return AGPU_OK;
         }
-        for (hipEvent_t ev : blk.pending) dev->event_pool.push_back(ev);
+        for (agpu_event_ref* r : blk.pending) ref_release_locked(dev, r);
       }
     }
   }
@@ -366,71 +584,132 @@ agpu_status agpu_memset(agpu_pipeline* p, void* dst_dev, int32_t byte_value, siz
 }
 
 // ---------------------------------------------------------------- pipeline
-static agpu_status pipeline_new(agpu_device* dev, hipStream_t s, bool owns, agpu_pipeline** out) {
-  agpu_pipeline* p = new agpu_pipeline();
-  p->dev = dev;
-  p->stream = s;
-  p->owns_stream = owns;
-  p->capturing = false;
-  p->scratch = nullptr;
-  p->scratch_bytes = 0;
-  p->flags = nullptr;
-  *out = p;
-  return AGPU_OK;
+// Sticky error words: each LIVE pipeline owns one; a destroyed pipeline's word is handed to the next owner only after
+// the stream has passed every kernel the old owner queued (its last marker completed), so a late take/put of the
+// previous owner can neither raise an error in the new owner's sync nor be wiped by the new owner's reset.
+static uint32_t* flag_get_locked(agpu_device* dev) {
+  for (size_t i = 0; i < dev->flag_retired.size();) {
+    if (ref_done_locked(dev->flag_retired[i].after)) {
+      ref_release_locked(dev, dev->flag_retired[i].after);
+      dev->flag_free.push_back(dev->flag_retired[i].word);
+      dev->flag_retired[i] = dev->flag_retired.back();
+      dev->flag_retired.pop_back();
+    } else {
+      i++;
+    }
+  }
+  if (dev->flag_free.empty()) {
+    void* slab = nullptr;  // pinned + device-visible under unified addressing; 64 words, 64 B apart
+    if (hipHostMalloc(&slab, 4096, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    memset(slab, 0, 4096);
+    dev->flag_slabs.push_back(slab);
+    for (int i = 63; i >= 0; i--) dev->flag_free.push_back(reinterpret_cast<uint32_t*>(static_cast<char*>(slab) + 64 * i));
+  }
+  uint32_t* w = dev->flag_free.back();
+  dev->flag_free.pop_back();
+  *w = 0;
+  return w;
 }
 
-static agpu_status flags_new(uint32_t** out) {
-  void* f = nullptr;
-  AGPU_HIP(hipHostMalloc(&f, 64, hipHostMallocDefault));  // pinned + device-visible under unified addressing
-  *static_cast<uint32_t*>(f) = 0;
-  *out = static_cast<uint32_t*>(f);
-  return AGPU_OK;
+static agpu_pipeline* pipeline_new(agpu_device* dev, agpu_stream_slot* slot, bool owns, uint32_t* flags) {
+  agpu_pipeline* p = new agpu_pipeline();
+  p->dev = dev;
+  p->slot = slot;
+  p->stream = slot->stream;
+  p->owns_stream = owns;
+  p->capturing = false;
+  p->seen_gen = 0;  // first call orders the stream behind everything other pipelines have finished so far
+  p->tune = agpu_tuning_defaults();
+  p->flags = flags;
+  p->profile = env_profile();
+  p->scope_depth = 0;
+  p->t0 = p->t1 = nullptr;
+  p->t_valid = false;
+  p->last_name = "";
+  return p;
 }
 
 agpu_status agpu_pipeline_create(agpu_device* dev, agpu_pipeline** out_pipeline) {
   AGPU_REQUIRE(dev && out_pipeline, AGPU_ERR_ARG, "null argument");
   AGPU_HIP(hipSetDevice(dev->ordinal));
-  agpu_device::StreamSlot slot{nullptr, nullptr, 0, nullptr};
+  agpu_stream_slot* slot = nullptr;
+  uint32_t* flags = nullptr;
   {
     std::lock_guard<std::mutex> lock(dev->mu);
-    if (!dev->idle_streams.empty()) {  // work still queued on a recycled stream simply runs first: same ordering
-      slot = dev->idle_streams.back();
-      dev->idle_streams.pop_back();
+    if (!dev->idle.empty()) {  // work still queued on a recycled stream simply runs first: same ordering
+      slot = dev->idle.back();
+      dev->idle.pop_back();
     }
+    flags = flag_get_locked(dev);
   }
-  if (!slot.stream) {
-    AGPU_HIP(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
+  if (!flags) {
+    agpu_set_error("hipHostMalloc of the pipeline error words failed");
+    return AGPU_ERR_HIP;
+  }
+  if (!slot) {
+    hipStream_t s = nullptr;
+    AGPU_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    slot = new agpu_stream_slot();
+    slot->stream = s;
+    slot->owned = true;
     std::lock_guard<std::mutex> lock(dev->mu);
-    dev->all_streams.push_back(slot.stream);
+    dev->slots.push_back(slot);
   }
-  if (!slot.flags) {
-    agpu_status fs = flags_new(&slot.flags);
-    if (fs != AGPU_OK) return fs;
-  }
-  *slot.flags = 0;  // a new owner starts clean (its predecessor synchronised or gave up its right to the report)
-  agpu_status st = pipeline_new(dev, slot.stream, true, out_pipeline);
-  if (st == AGPU_OK) {
-    (*out_pipeline)->scratch = slot.scratch;
-    (*out_pipeline)->scratch_bytes = slot.scratch_bytes;
-    (*out_pipeline)->flags = slot.flags;
-  }
-  return st;
+  *out_pipeline = pipeline_new(dev, slot, true, flags);
+  return AGPU_OK;
 }
 
 agpu_status agpu_pipeline_wrap_stream(agpu_device* dev, void* hip_stream, agpu_pipeline** out_pipeline) {
   AGPU_REQUIRE(dev && out_pipeline, AGPU_ERR_ARG, "null argument");
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  agpu_stream_slot* slot = new agpu_stream_slot();
+  slot->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  slot->owned = false;
+  uint32_t* flags = nullptr;
   {
     std::lock_guard<std::mutex> lock(dev->mu);
-    dev->all_streams.push_back(reinterpret_cast<hipStream_t>(hip_stream));
+    dev->slots.push_back(slot);
+    flags = flag_get_locked(dev);
   }
-  agpu_status st = pipeline_new(dev, reinterpret_cast<hipStream_t>(hip_stream), false, out_pipeline);
-  if (st == AGPU_OK) st = flags_new(&(*out_pipeline)->flags);
-  return st;
+  if (!flags) {
+    agpu_set_error("hipHostMalloc of the pipeline error words failed");
+    return AGPU_ERR_HIP;
+  }
+  *out_pipeline = pipeline_new(dev, slot, false, flags);
+  return AGPU_OK;
+}
+
+// Cross-pipeline ordering.  The reference has ONE wgpu queue: everything a later submit records runs after everything
+// an earlier `finish()` submitted [ref: compute_pipeline.rs:259-263 queue.submit].  Pipelines here are independent HIP
+// streams, so `finish` PUBLISHES the stream's position (a marker event + a device-wide generation number) and every
+// pipeline, before its next call enqueues anything, makes its stream wait for the positions other pipelines have
+// published since it last looked (agpu_scope_enter).  Cost when nothing was published: one atomic load per call.
+// Contract: a pipeline may consume buffers another pipeline produced once that pipeline has finished (or was
+// destroyed) — exactly the reference's rule that results are defined after `finish()`.
+static void publish_finish_locked(agpu_pipeline* p) {
+  agpu_device* dev = p->dev;
+  agpu_stream_slot* s = p->slot;
+  bool ok = true;
+  agpu_event_ref* m = slot_mark_locked(dev, s, &ok);
+  if (!ok || !m || m == s->finish_ev) return;  // capturing, nothing ever ran, or nothing new since the last finish
+  m->refs++;
+  ref_release_locked(dev, s->finish_ev);
+  s->finish_ev = m;
+  s->finish_gen = dev->finish_gen.load(std::memory_order_relaxed) + 1;
+  dev->finish_gen.store(s->finish_gen, std::memory_order_release);
 }
 
 agpu_status agpu_pipeline_finish(agpu_pipeline* p) {
-  AGPU_REQUIRE(p, AGPU_ERR_ARG, "null pipeline");
-  return AGPU_OK;  // everything recorded so far is already enqueued in order; like the reference, do not wait
+  AGPU_REQUIRE(p && p->dev, AGPU_ERR_ARG, "null pipeline");
+  AGPU_HIP(hipSetDevice(p->dev->ordinal));
+  if (p->capturing) return AGPU_OK;
+  // everything recorded so far is already enqueued in order; like the reference, do not wait
+  std::lock_guard<std::mutex> lock(p->dev->mu);
+  publish_finish_locked(p);
+  return AGPU_OK;
 }
 
 agpu_status agpu_pipeline_sync(agpu_pipeline* p) {
@@ -451,25 +730,49 @@ agpu_status agpu_pipeline_destroy(agpu_pipeline* p) {
   if (!p) return AGPU_OK;
   agpu_device* dev = p->dev;
   (void)hipSetDevice(dev->ordinal);
-  if (p->owns_stream && g_tune.mem_pool != 0 && !p->capturing) {
-    // back to the pool WITHOUT waiting: queued work keeps running, the next owner's launches are ordered behind it
+  if (p->t0) (void)hipEventDestroy(p->t0);
+  if (p->t1) (void)hipEventDestroy(p->t1);
+  agpu_stream_slot* s = p->slot;
+  if (p->capturing) {  // abandon the capture so the stream is usable again
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(p->stream, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    p->capturing = false;
+  }
+  if (p->owns_stream && agpu_mem_pool_enabled()) {
+    // back to the pool WITHOUT waiting: queued work keeps running, the next owner's launches are ordered behind it.
+    // Destroying a pipeline is a submit point like finish(): other pipelines order themselves behind its work.
     std::lock_guard<std::mutex> lock(dev->mu);
-    dev->idle_streams.push_back(agpu_device::StreamSlot{p->stream, p->scratch, p->scratch_bytes, p->flags});
+    publish_finish_locked(p);
+    bool ok = true;
+    agpu_event_ref* m = slot_mark_locked(dev, s, &ok);
+    if (m && !ref_done_locked(m)) {
+      m->refs++;
+      dev->flag_retired.push_back(agpu_device::RetiredFlag{p->flags, m});
+    } else {
+      dev->flag_free.push_back(p->flags);
+    }
+    dev->idle.push_back(s);
     delete p;
     return AGPU_OK;
   }
-  if (p->scratch || p->flags) (void)hipStreamSynchronize(p->stream);
-  if (p->scratch) (void)hipFree(p->scratch);
-  if (p->flags) (void)hipHostFree(p->flags);
+  (void)hipStreamSynchronize(p->stream);
   {
     std::lock_guard<std::mutex> lock(dev->mu);
-    for (size_t i = 0; i < dev->all_streams.size(); i++)
-      if (dev->all_streams[i] == p->stream) {
-        dev->all_streams.erase(dev->all_streams.begin() + (long)i);
+    dev->flag_free.push_back(p->flags);
+    if (s->scratch) scratch_release_locked(s->scratch);
+    s->scratch = nullptr;
+    ref_release_locked(dev, s->mark);
+    ref_release_locked(dev, s->finish_ev);
+    for (size_t i = 0; i < dev->slots.size(); i++)
+      if (dev->slots[i] == s) {
+        dev->slots.erase(dev->slots.begin() + (long)i);
         break;
       }
   }
   if (p->owns_stream) (void)hipStreamDestroy(p->stream);
+  delete s;
   delete p;
   return AGPU_OK;
 }
@@ -486,9 +789,26 @@ agpu_status agpu_pipeline_stream(agpu_pipeline* p, void** out_hip_stream) {
   return AGPU_OK;
 }
 
+// Explicit cross-pipeline dependency for hosts that overlap pipelines on purpose (double-buffered staging): work
+// enqueued on `p` after this call runs after everything enqueued on `other` before it.  Does not block the host.
+agpu_status agpu_pipeline_wait_pipeline(agpu_pipeline* p, agpu_pipeline* other) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(other && other->dev == p->dev, AGPU_ERR_ARG, "pipelines must share a device");
+  if (other->slot == p->slot) return AGPU_OK;
+  AGPU_REQUIRE(!p->capturing && !other->capturing, AGPU_ERR_ARG, "not during graph capture");
+  std::lock_guard<std::mutex> lock(p->dev->mu);
+  bool ok = true;
+  agpu_event_ref* m = slot_mark_locked(p->dev, other->slot, &ok);
+  AGPU_REQUIRE(ok, AGPU_ERR_HIP, "could not record a marker on the other pipeline's stream");
+  if (m && !ref_done_locked(m)) AGPU_HIP(hipStreamWaitEvent(p->stream, m->ev, 0));
+  return AGPU_OK;
+}
+
 // ---------------------------------------------------------------- graphs
 agpu_status agpu_pipeline_begin_capture(agpu_pipeline* p) {
-  AGPU_BIND(p);
+  {
+    AGPU_BIND(p);  // orders the stream behind other pipelines' finished work BEFORE the capture starts
+  }
   AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "already capturing");
   AGPU_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
   p->capturing = true;
@@ -496,7 +816,8 @@ agpu_status agpu_pipeline_begin_capture(agpu_pipeline* p) {
 }
 
 agpu_status agpu_pipeline_end_capture(agpu_pipeline* p, agpu_graph** out_graph) {
-  AGPU_BIND(p);
+  AGPU_REQUIRE(p && p->dev, AGPU_ERR_ARG, "null pipeline");
+  AGPU_HIP(hipSetDevice(p->dev->ordinal));
   AGPU_REQUIRE(out_graph, AGPU_ERR_ARG, "null out_graph");
   AGPU_REQUIRE(p->capturing, AGPU_ERR_ARG, "not capturing");
   p->capturing = false;
@@ -513,6 +834,12 @@ agpu_status agpu_pipeline_end_capture(agpu_pipeline* p, agpu_graph** out_graph) 
   gr->dev = p->dev;
   gr->graph = g;
   gr->exec = ex;
+  {
+    // kernel nodes of reductions carry the scratch POINTER: keep that block alive as long as the graph
+    std::lock_guard<std::mutex> lock(p->dev->mu);
+    gr->scratch = p->slot->scratch;
+    if (gr->scratch) gr->scratch->refs++;
+  }
   *out_graph = gr;
   return AGPU_OK;
 }
@@ -529,6 +856,11 @@ agpu_status agpu_graph_destroy(agpu_graph* g) {
   (void)hipSetDevice(g->dev->ordinal);
   (void)hipGraphExecDestroy(g->exec);
   (void)hipGraphDestroy(g->graph);
+  if (g->scratch) {
+    std::lock_guard<std::mutex> lock(g->dev->mu);
+    if (g->scratch->refs == 1) (void)hipDeviceSynchronize();  // last owner: replays may still be running
+    scratch_release_locked(g->scratch);
+  }
   delete g;
   return AGPU_OK;
 }
@@ -547,8 +879,8 @@ agpu_status agpu_event_create(agpu_device* dev, agpu_event** out_event) {
 }
 
 agpu_status agpu_event_record(agpu_event* e, agpu_pipeline* p) {
-  AGPU_BIND(p);
-  AGPU_REQUIRE(e, AGPU_ERR_ARG, "null event");
+  AGPU_REQUIRE(p && p->dev && e, AGPU_ERR_ARG, "null argument");
+  AGPU_HIP(hipSetDevice(p->dev->ordinal));
   AGPU_HIP(hipEventRecord(e->ev, p->stream));
   return AGPU_OK;
 }
@@ -569,49 +901,140 @@ agpu_status agpu_event_destroy(agpu_event* e) {
   return AGPU_OK;
 }
 
-// ---------------------------------------------------------------- tuning
-static int64_t* tune_slot(const char* key) {
-  if (!key) return nullptr;
-  if (!strcmp(key, "stream_grid")) return &g_tune.stream_grid;
-  if (!strcmp(key, "stream_bpc")) return &g_tune.stream_bpc;
-  if (!strcmp(key, "stream_unroll")) return &g_tune.stream_unroll;
-  if (!strcmp(key, "stream_nt")) return &g_tune.stream_nt;
-  if (!strcmp(key, "cmp_variant")) return &g_tune.cmp_variant;
-  if (!strcmp(key, "reduce_grid")) return &g_tune.reduce_grid;
-  if (!strcmp(key, "mem_pool")) return &g_tune.mem_pool;
-  if (!strcmp(key, "table_tiles")) return &g_tune.table_tiles;
-  return nullptr;
+// ---------------------------------------------------------------- per-launch profiling
+// [ref: GpuDevice::compute_pass insert_debug_marker(entry_point) gpu_device.rs:132; CmpQuery compute_query.rs:7-89 —
+//  a 2-slot timestamp query per pass + wait_for_results() logging "Time taken for compute pass"]
+agpu_status agpu_pipeline_enable_timing(agpu_pipeline* p, int32_t profile_bits) {
+  AGPU_REQUIRE(p && p->dev, AGPU_ERR_ARG, "null pipeline");
+  AGPU_REQUIRE(p->scope_depth == 0, AGPU_ERR_ARG, "not from inside a call");
+  uint32_t b = (uint32_t)profile_bits & (AGPU_PROF_ROCTX | AGPU_PROF_TIMING | AGPU_PROF_LOG);
+  if (b & AGPU_PROF_LOG) b |= AGPU_PROF_TIMING;
+  p->profile = b;
+  p->t_valid = false;
+  return AGPU_OK;
 }
 
+agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, const char** out_name) {
+  AGPU_REQUIRE(p && p->dev && out_ns, AGPU_ERR_ARG, "null argument");
+  AGPU_HIP(hipSetDevice(p->dev->ordinal));
+  AGPU_REQUIRE(p->t_valid, AGPU_ERR_ARG, "no timed launch yet (agpu_pipeline_enable_timing / AGPU_PROFILE=2)");
+  AGPU_HIP(hipEventSynchronize(p->t1));
+  float ms = 0.0f;
+  AGPU_HIP(hipEventElapsedTime(&ms, p->t0, p->t1));
+  *out_ns = (uint64_t)((double)ms * 1e6 + 0.5);
+  if (out_name) *out_name = p->last_name;
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- tuning
 agpu_status agpu_set_tuning(const char* key, int64_t value) {
-  int64_t* s = tune_slot(key);
-  AGPU_REQUIRE(s, AGPU_ERR_ARG, "unknown tuning key");
-  *s = value;
+  if (key && !strcmp(key, "mem_pool")) {
+    g_mem_pool.store(value, std::memory_order_relaxed);
+    return AGPU_OK;
+  }
+  const int i = tune_index(key);
+  AGPU_REQUIRE(i >= 0, AGPU_ERR_ARG, "unknown tuning key");
+  g_tune_default[i].store(value, std::memory_order_relaxed);
   return AGPU_OK;
 }
 
 agpu_status agpu_get_tuning(const char* key, int64_t* out_value) {
-  int64_t* s = tune_slot(key);
-  AGPU_REQUIRE(s && out_value, AGPU_ERR_ARG, "unknown tuning key");
-  *out_value = *s;
+  AGPU_REQUIRE(out_value, AGPU_ERR_ARG, "null out_value");
+  if (key && !strcmp(key, "mem_pool")) {
+    *out_value = g_mem_pool.load(std::memory_order_relaxed);
+    return AGPU_OK;
+  }
+  const int i = tune_index(key);
+  AGPU_REQUIRE(i >= 0, AGPU_ERR_ARG, "unknown tuning key");
+  *out_value = g_tune_default[i].load(std::memory_order_relaxed);
+  return AGPU_OK;
+}
+
+agpu_status agpu_pipeline_set_tuning(agpu_pipeline* p, const char* key, int64_t value) {
+  AGPU_REQUIRE(p, AGPU_ERR_ARG, "null pipeline");
+  const int i = tune_index(key);
+  AGPU_REQUIRE(i >= 0, AGPU_ERR_ARG, "unknown tuning key");
+  reinterpret_cast<int64_t*>(&p->tune)[i] = value;
+  return AGPU_OK;
+}
+
+agpu_status agpu_pipeline_get_tuning(agpu_pipeline* p, const char* key, int64_t* out_value) {
+  AGPU_REQUIRE(p && out_value, AGPU_ERR_ARG, "null argument");
+  const int i = tune_index(key);
+  AGPU_REQUIRE(i >= 0, AGPU_ERR_ARG, "unknown tuning key");
+  *out_value = reinterpret_cast<const int64_t*>(&p->tune)[i];
   return AGPU_OK;
 }
 
 }  // extern "C"
 
-agpu_status agpu_scratch(agpu_pipeline* p, size_t bytes, void** out) {
-  if (p->scratch_bytes < bytes) {
-    AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "scratch growth during graph capture; run the op once before capturing");
-    if (p->scratch) {
-      AGPU_HIP(hipStreamSynchronize(p->stream));
-      AGPU_HIP(hipFree(p->scratch));
-      p->scratch = nullptr;
-      p->scratch_bytes = 0;
-    }
-    size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
-    AGPU_HIP(hipMalloc(&p->scratch, want));
-    p->scratch_bytes = want;
+// ---------------------------------------------------------------- call scope (AGPU_BIND)
+agpu_status agpu_scope_enter(agpu_pipeline* p, const char* name) {
+  if (!p || !p->dev) {
+    agpu_set_error("%s: null pipeline", name);
+    return AGPU_ERR_ARG;
   }
-  *out = p->scratch;
+  AGPU_HIP(hipSetDevice(p->dev->ordinal));
+  agpu_device* dev = p->dev;
+  if (p->scope_depth == 0 && !p->capturing && p->seen_gen != dev->finish_gen.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> lock(dev->mu);
+    for (agpu_stream_slot* s : dev->slots) {
+      if (s == p->slot || !s->finish_ev || s->finish_gen <= p->seen_gen || ref_done_locked(s->finish_ev)) continue;
+      AGPU_HIP(hipStreamWaitEvent(p->stream, s->finish_ev->ev, 0));
+    }
+    p->seen_gen = dev->finish_gen.load(std::memory_order_relaxed);
+  }
+  if (p->profile && !p->capturing) {
+    if (p->profile & AGPU_PROF_ROCTX) roctxRangePushA(name);
+    if ((p->profile & AGPU_PROF_TIMING) && p->scope_depth == 0) {
+      if (!p->t0) {
+        AGPU_HIP(hipEventCreate(&p->t0));
+        AGPU_HIP(hipEventCreate(&p->t1));
+      }
+      p->t_valid = false;
+      p->last_name = name;
+      AGPU_HIP(hipEventRecord(p->t0, p->stream));
+    }
+  }
+  if (p->scope_depth++ == 0) p->slot->enq.fetch_add(1, std::memory_order_release);  // odd: call in progress
+  return AGPU_OK;
+}
+
+void agpu_scope_exit(agpu_pipeline* p) {
+  p->scope_depth--;
+  if (p->scope_depth == 0) p->slot->enq.fetch_add(1, std::memory_order_release);  // even: everything it enqueued is counted
+  if (p->profile && !p->capturing) {
+    if ((p->profile & AGPU_PROF_TIMING) && p->scope_depth == 0 && p->t0) {
+      if (hipEventRecord(p->t1, p->stream) == hipSuccess) p->t_valid = true;
+      if (p->t_valid && (p->profile & AGPU_PROF_LOG) && hipEventSynchronize(p->t1) == hipSuccess) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p->t0, p->t1) == hipSuccess)
+          fprintf(stderr, "[arrow_gpu] Time taken for compute pass %s: %.0f ns\n", p->last_name, (double)ms * 1e6);
+      }
+    }
+    if (p->profile & AGPU_PROF_ROCTX) roctxRangePop();
+  }
+}
+
+// Name the innermost open range after the reference's entry point (agpu_launch_by_name).
+void agpu_scope_label(agpu_pipeline* p, const char* label) {
+  if (p->profile & AGPU_PROF_ROCTX) roctxMarkA(label);
+  if (p->scope_depth == 1) p->last_name = label;
+}
+
+agpu_status agpu_scratch(agpu_pipeline* p, size_t bytes, void** out) {
+  agpu_stream_slot* s = p->slot;
+  if (!s->scratch || s->scratch->bytes < bytes) {
+    AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "scratch growth during graph capture; run the op once before capturing");
+    const size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+    void* ptr = nullptr;
+    AGPU_HIP(hipMalloc(&ptr, want));
+    agpu_scratch_block* old = s->scratch;
+    if (old) AGPU_HIP(hipStreamSynchronize(p->stream));  // queued reductions still read the old block
+    std::lock_guard<std::mutex> lock(p->dev->mu);
+    s->scratch = new agpu_scratch_block{ptr, want, 1};
+    if (old) scratch_release_locked(old);  // stays alive if a captured graph references it
+  }
+  *out = s->scratch->ptr;
   return AGPU_OK;
 }

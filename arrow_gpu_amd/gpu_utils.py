@@ -93,8 +93,14 @@ class GpuDevice:
 
     def clone_buffer(self, buf: DeviceBuffer, pipeline=None) -> DeviceBuffer:
         """[ref: clone_buffer gpu_device.rs:212-222]"""
-        p = pipeline or self._default_pipeline()
-        return p.clone_buffer(buf)
+        if pipeline is not None:
+            return pipeline.clone_buffer(buf)
+        # immediate form = record + submit, like the reference's queue.submit inside GpuDevice::clone_buffer: `finish`
+        # publishes the copy so pipelines that consume the clone are ordered behind it (and this one behind its producer)
+        p = self._default_pipeline()
+        out = p.clone_buffer(buf)
+        p.finish()
+        return out
 
     def sync(self) -> None:
         capi.call("agpu_device_sync", self._handle)
@@ -253,6 +259,24 @@ class ArrowComputePipeline:
         h = self._bitmap_handle if bitmap else self._handle
         capi.call("agpu_copy", h, C.c_void_p(dst.ptr + dst_off), C.c_void_p(src.ptr + src_off), size)
         self.keep(src, dst)
+
+    def set_tuning(self, key: str, value: int) -> None:
+        """Launch tuning of THIS pipeline only (include/arrow_gpu.h: agpu_pipeline_set_tuning)."""
+        capi.call("agpu_pipeline_set_tuning", self._h, key.encode(), int(value))
+
+    def wait_pipeline(self, other: "ArrowComputePipeline") -> None:
+        """Order this pipeline's later work behind everything `other` has enqueued so far (no host wait)."""
+        capi.call("agpu_pipeline_wait_pipeline", self._handle, other._handle)
+
+    def enable_timing(self, bits: int = 2) -> None:
+        """[ref: CmpQuery compute_query.rs:7-52] 1 = roctx ranges, 2 = event pair per launch, 4 = wait + log each launch."""
+        capi.call("agpu_pipeline_enable_timing", self._h, int(bits))
+
+    def last_kernel_ns(self):
+        """(nanoseconds, name) of the last timed launch; blocks on it.  [ref: CmpQuery::wait_for_results :54-75]"""
+        ns, name = C.c_uint64(), C.c_char_p()
+        capi.call("agpu_pipeline_last_kernel_ns", self._h, C.byref(ns), C.byref(name))
+        return ns.value, (name.value or b"").decode()
 
     def stream(self) -> int:
         s = C.c_void_p()

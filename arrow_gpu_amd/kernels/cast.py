@@ -19,7 +19,9 @@ CAST_TABLE = {
     Int16ArrayGPU: (Int32ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU, Float32ArrayGPU),
     UInt8ArrayGPU: (UInt16ArrayGPU, UInt32ArrayGPU, Int8ArrayGPU, Int16ArrayGPU, Int32ArrayGPU, Float32ArrayGPU),
     UInt16ArrayGPU: (UInt32ArrayGPU, Int16ArrayGPU, Int32ArrayGPU, Float32ArrayGPU),
-    Float32ArrayGPU: (UInt8ArrayGPU,),
+    # f32 → u8 is the reference's only narrowing cast [cast/src/f32_cast.rs:8-31]; the other five are REFERENCE-ABSENT
+    # (north_star "i8/i16/u8/u16 <-> f32"), defined by analogy with cast_u8.wgsl — see include/arrow_gpu.h agpu_cast
+    Float32ArrayGPU: (UInt8ArrayGPU, Int8ArrayGPU, Int16ArrayGPU, UInt16ArrayGPU, Int32ArrayGPU, UInt32ArrayGPU),
     BooleanArrayGPU: (Float32ArrayGPU,),
 }
 BITCAST_TABLE = {UInt32ArrayGPU: (Float32ArrayGPU,)}

@@ -11,7 +11,10 @@ spans (16-byte vector path, no split validity words).
 """
 from __future__ import annotations
 
+import ctypes as C
 from dataclasses import dataclass
+
+from . import _capi as capi
 
 ROW_ALIGN = 512
 
@@ -66,3 +69,97 @@ def final_reduce(sum_t=None, min_t=None, max_t=None, count_t=None, group=None):
     if count_t is not None:
         dist.all_reduce(count_t, op=dist.ReduceOp.SUM, group=group)
     return sum_t, min_t, max_t, count_t
+
+
+class Communicator:
+    """RCCL communicator of the C ABI (include/arrow_gpu.h "multi-GPU"): one rank per GPU, used ONLY for the final
+    reduce of whole-column statistics.  Nothing like it exists in the reference (single device + queue,
+    crates/array/src/gpu_utils/gpu_device.rs:29-33).
+
+    `reduce` = shard-local kernel + all-gather of one 16-byte record per rank + rank-ordered combine on every rank, so
+    the result is identical on all ranks and, for f32 Sum over shards of 256^k rows, bit-identical to the reference's
+    whole-column tree.  Rendezvous: rank 0 makes the 128-byte id (`Communicator.unique_id()`), the launcher ships it —
+    `from_torch` uses an initialised torch.distributed group (gloo or nccl) for that one broadcast, `from_file` a path
+    on a shared filesystem; a C++ host passes it between its per-GPU threads directly."""
+
+    def __init__(self, device, rank: int, world: int, unique_id: bytes):
+        if len(unique_id) != capi.COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        self.device, self.rank, self.world = device, rank, world
+        h = C.c_void_p()
+        idbuf = C.create_string_buffer(unique_id, capi.COMM_ID_BYTES)
+        capi.call("agpu_comm_init_rank", device._handle, idbuf, rank, world, C.byref(h))
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(capi.COMM_ID_BYTES)
+        capi.call("agpu_comm_get_unique_id", buf)
+        return buf.raw
+
+    @classmethod
+    def single(cls, device) -> "Communicator":
+        """World of one rank (no launcher needed): the same RCCL code path a multi-GPU run takes."""
+        return cls(device, 0, 1, cls.unique_id())
+
+    @classmethod
+    def from_torch(cls, device, group=None) -> "Communicator":
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(device, rank, world, box[0])
+
+    @classmethod
+    def from_file(cls, device, rank: int, world: int, path: str, timeout_s: float = 60.0) -> "Communicator":
+        import os
+        import time
+
+        if rank == 0:
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as f:
+                f.write(cls.unique_id())
+            os.replace(tmp, path)
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"no communicator id at {path}")
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            return cls(device, rank, world, f.read())
+
+    # -- collectives (asynchronous on the pipeline's stream; results are 1-element device buffers)
+    def reduce(self, pipeline, op: int, dtype: int, values, validity, n_local: int, out) -> None:
+        capi.call("agpu_comm_reduce", self._h, pipeline._handle, op, dtype, _ptr(values), _ptr(validity), n_local, _ptr(out))
+
+    def reduce_sum_f64(self, pipeline, values, validity, n_local: int, out) -> None:
+        capi.call("agpu_comm_reduce_sum_f64", self._h, pipeline._handle, _ptr(values), _ptr(validity), n_local, _ptr(out))
+
+    def final_reduce(self, pipeline, op: int, dtype: int, partial, n_local: int, out, f64: bool = False) -> None:
+        capi.call("agpu_comm_final_reduce", self._h, pipeline._handle, op, dtype, 1 if f64 else 0, _ptr(partial), n_local, _ptr(out))
+
+    def all_reduce(self, pipeline, op: int, ctype: int, buf, count: int) -> None:
+        capi.call("agpu_comm_all_reduce", self._h, pipeline._handle, op, ctype, _ptr(buf), count)
+
+    def barrier(self, pipeline) -> None:
+        capi.call("agpu_comm_barrier", self._h, pipeline._handle)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            capi.lib().agpu_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    return C.c_void_p(x.ptr)

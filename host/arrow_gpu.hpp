@@ -56,7 +56,8 @@ class ArrowComputePipeline;
 class GpuDevice : public std::enable_shared_from_this<GpuDevice> {
  public:
   agpu_device* raw = nullptr;
-  agpu_pipeline* io = nullptr;  // uploads / read-backs
+  agpu_pipeline* io = nullptr;  // uploads / read-backs / immediate clones; a pipeline serves one thread at a time:
+  std::mutex io_mu;             // … so the device-level helpers below take this lock
   static DevicePtr create(int ordinal = 0) {  // GpuDevice::new() [gpu_device.rs:46-85]
     auto d = std::shared_ptr<GpuDevice>(new GpuDevice());
     check(agpu_device_create(ordinal, &d->raw), "agpu_device_create");
@@ -77,18 +78,27 @@ class GpuDevice : public std::enable_shared_from_this<GpuDevice> {
   template <typename N>
   BufferPtr create_gpu_buffer_with_data(const N* data, size_t count) {  // [gpu_device.rs:171-181]
     auto b = create_empty_buffer(count * sizeof(N));
-    if (count) check(agpu_upload(io, b->ptr, data, count * sizeof(N)), "agpu_upload");
+    if (count) {
+      std::lock_guard<std::mutex> lock(io_mu);
+      check(agpu_upload(io, b->ptr, data, count * sizeof(N)), "agpu_upload");
+    }
     return b;
   }
   std::vector<uint8_t> retrive_data(const BufferPtr& b, uint64_t nbytes) {  // the only blocking call [gpu_device.rs:232-265]
     std::vector<uint8_t> out(nbytes);
     check(agpu_device_sync(raw), "agpu_device_sync");
-    if (nbytes) check(agpu_download(io, out.data(), b->ptr, nbytes), "agpu_download");
+    if (nbytes) {
+      std::lock_guard<std::mutex> lock(io_mu);
+      check(agpu_download(io, out.data(), b->ptr, nbytes), "agpu_download");
+    }
     return out;
   }
   BufferPtr clone_buffer(const BufferPtr& b) {  // [gpu_device.rs:212-222]
     auto out = create_empty_buffer(b->bytes);
+    std::lock_guard<std::mutex> lock(io_mu);
     if (b->bytes) check(agpu_copy(io, out->ptr, b->ptr, b->bytes), "agpu_copy");
+    // record + submit, like the reference's queue.submit: `finish` publishes the copy to every other pipeline
+    check(agpu_pipeline_finish(io), "agpu_pipeline_finish");
     return out;
   }
 

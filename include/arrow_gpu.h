@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define AGPU_ABI_VERSION 1
+#define AGPU_ABI_VERSION 2
 
 typedef int32_t agpu_status;
 enum {
@@ -99,7 +99,9 @@ typedef enum {
   AGPU_UN_SIN = 9,   /* for u8/i8/u16/i16 inputs: fused cast+sin, output f32 */
   AGPU_UN_COS = 10,  /* idem */
   AGPU_UN_ACOS = 11, /* f32 only */
-  AGPU_UN_SINH = 12  /* for small ints: fused, output f32 */
+  AGPU_UN_SINH = 12, /* for small ints: fused, output f32 */
+  AGPU_UN_POPCOUNT = 13 /* integer types: set bits per element [ref: crates/logical/compute_shaders/u32/countbitones.wgsl:9-15
+                           `countob`, the first half of BooleanArrayGPU::all(), crates/logical/src/boolean.rs:120-146] */
 } agpu_unary_op;
 
 /* [ref: crates/compare/src/lib.rs:17-21 entry points "gt","gteq","lt","lteq","eq"] */
@@ -133,12 +135,16 @@ agpu_status agpu_device_mem_info(agpu_device* dev, uint64_t* out_free, uint64_t*
 /* Resource pools.  The reference allocates an output buffer and (in its default, non-`_op` API) a command encoder per
  * operation [ref: impl_arithmetic_op! crates/arithmetic/src/lib.rs:11-50 — `ArrowComputePipeline::new` … `finish()`
  * around every op].  On ROCm a stream costs 4.3 ms to create and 2.6 ms to destroy and hipFree synchronises the device,
- * so idle streams and freed blocks >= 1 MiB are recycled (tuning key "mem_pool", default 1).  agpu_device_trim returns
- * the cached blocks to the driver (also done automatically when hipMalloc runs out of memory); cached bytes never
- * exceed half of the device memory. */
+ * so idle streams and freed blocks are recycled (tuning key "mem_pool", default 1): blocks > 512 KiB whole, in 2 MiB
+ * granules; smaller blocks (the reference's tests and examples live at 5–100 elements) from 2 MiB slabs carved into
+ * power-of-two size classes, 256 B … 512 KiB.  agpu_device_trim returns the cached blocks and fully free slabs to the
+ * driver (also done automatically when hipMalloc runs out of memory); cached large blocks never exceed half of the
+ * device memory. */
 agpu_status agpu_device_trim(agpu_device* dev);
 agpu_status agpu_device_pool_info(agpu_device* dev, uint64_t* out_cached_bytes, uint64_t* out_cached_blocks,
-                                  uint64_t* out_idle_streams);
+                                  uint64_t* out_idle_streams); /* the > 512 KiB cache and the idle streams */
+agpu_status agpu_device_small_pool_info(agpu_device* dev, uint64_t* out_slab_bytes, uint64_t* out_free_blocks,
+                                        uint64_t* out_live_blocks); /* the <= 512 KiB slab pool */
 
 /* ---------------------------------------------------------------- buffers (raw HBM pointers)
  * agpu_malloc          [ref: GpuDevice::create_empty_buffer gpu_device.rs:183-192] — zero_fill!=0 reproduces wgpu's
@@ -169,14 +175,25 @@ agpu_status agpu_download_async(agpu_pipeline* p, void* dst_pinned, const void* 
  * agpu_pipeline_wrap_stream adopts an existing hipStream_t (e.g. torch's current stream); it is not destroyed. */
 agpu_status agpu_pipeline_create(agpu_device* dev, agpu_pipeline** out_pipeline);
 agpu_status agpu_pipeline_wrap_stream(agpu_device* dev, void* hip_stream, agpu_pipeline** out_pipeline);
-agpu_status agpu_pipeline_finish(agpu_pipeline* p); /* submit point: work is already enqueued; does NOT wait */
+/* finish = the reference's submit point.  Work is already enqueued, so it does NOT wait — but it PUBLISHES the stream's
+ * position: every other pipeline of the device orders its next call behind it.  The reference has ONE queue, so whatever
+ * is submitted later runs after whatever was submitted earlier [ref: compute_pipeline.rs:259-263]; with one HIP stream
+ * per pipeline the same guarantee is: a pipeline may read what another pipeline produced once that pipeline has finished
+ * (or was destroyed — destroy publishes too).  Cost when nobody finished anything: one atomic load per call. */
+agpu_status agpu_pipeline_finish(agpu_pipeline* p);
 agpu_status agpu_pipeline_sync(agpu_pipeline* p);   /* host waits for everything enqueued so far */
 agpu_status agpu_pipeline_destroy(agpu_pipeline* p);
 agpu_status agpu_pipeline_device(agpu_pipeline* p, agpu_device** out_device);
 agpu_status agpu_pipeline_stream(agpu_pipeline* p, void** out_hip_stream);
+/* Explicit dependency for hosts that overlap pipelines on purpose (double-buffered staging): work enqueued on `p` after
+ * this call runs after everything enqueued on `other` so far.  Does not block the host, does not need a finish. */
+agpu_status agpu_pipeline_wait_pipeline(agpu_pipeline* p, agpu_pipeline* other);
 
 /* hipGraph capture of a launch-bound op chain (examples/simple.rs-style `*_op` chains).
- * begin → enqueue ops on p → end (returns a replayable graph) → agpu_graph_launch any number of times. */
+ * begin → enqueue ops on p → end (returns a replayable graph) → agpu_graph_launch any number of times.
+ * Reductions and popcounts use per-stream scratch whose POINTER is baked into the captured kernel nodes: run such an op
+ * once before capturing (scratch cannot grow during capture); the graph keeps that scratch block alive for its own
+ * lifetime, and must be replayed on the pipeline that captured it or while that pipeline is idle. */
 typedef struct agpu_graph agpu_graph;
 agpu_status agpu_pipeline_begin_capture(agpu_pipeline* p);
 agpu_status agpu_pipeline_end_capture(agpu_pipeline* p, agpu_graph** out_graph);
@@ -189,10 +206,26 @@ agpu_status agpu_event_record(agpu_event* e, agpu_pipeline* p);
 agpu_status agpu_event_elapsed_ms(agpu_event* start, agpu_event* stop, float* out_ms); /* syncs on `stop` */
 agpu_status agpu_event_destroy(agpu_event* e);
 
-/* Launch tuning (bench sweeps; defaults are the measured best).  key ∈ {"stream_grid","stream_unroll","stream_nt",
- * "cmp_variant","reduce_grid"}; unknown key → AGPU_ERR_ARG. */
+/* Per-launch profiling [ref: GpuDevice::compute_pass → insert_debug_marker(entry_point) gpu_device.rs:132; CmpQuery
+ * compute_query.rs:7-89 — timestamp pair per pass, wait_for_results() logs "Time taken for compute pass"].
+ * profile_bits: 1 = a roctx range named after the ABI call (and a roctx mark with the reference's shader/entry-point for
+ * agpu_launch_by_name*) around every launch — shows up in `rocprofv3 --marker-trace`; 2 = a HIP event pair around every
+ * launch, read back with agpu_pipeline_last_kernel_ns (blocks on the stop event; out_name = the call's name, static
+ * storage); 4 = additionally wait after every launch and log the reference's line to stderr.  The environment variable
+ * AGPU_PROFILE=<bits> sets the default for every new pipeline; 0 (default) costs nothing. */
+agpu_status agpu_pipeline_enable_timing(agpu_pipeline* p, int32_t profile_bits);
+agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, const char** out_name);
+
+/* Launch tuning (bench sweeps; defaults are the measured best).  key ∈ {"stream_grid","stream_bpc","stream_unroll",
+ * "stream_nt","cmp_variant","reduce_grid","table_tiles","gather_bucket","h2d_mode","h2d_threads"}; unknown key →
+ * AGPU_ERR_ARG.  Every pipeline carries its own copy: agpu_set_tuning changes the process default that pipelines
+ * created AFTERWARDS start from (atomic, any thread), agpu_pipeline_set_tuning changes one pipeline only — a sweep on one
+ * thread never changes the kernels another pipeline launches.  "mem_pool" (0/1, agpu_set_tuning only) switches the
+ * device-level block and stream pools. */
 agpu_status agpu_set_tuning(const char* key, int64_t value);
 agpu_status agpu_get_tuning(const char* key, int64_t* out_value);
+agpu_status agpu_pipeline_set_tuning(agpu_pipeline* p, const char* key, int64_t value);
+agpu_status agpu_pipeline_get_tuning(agpu_pipeline* p, const char* key, int64_t* out_value);
 
 /* ---------------------------------------------------------------- element-wise kernels
  * All take element counts `n` (rows).  in/out pointers must be aligned to the element size; 16-byte alignment
@@ -222,7 +255,11 @@ agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, con
 
 /* out[i] = (to)in[i].  Table = cast_dyn's [ref: crates/cast/src/lib.rs:135-161] plus identity-width sign
  * reinterprets (memcpy in the reference :69-86).  from=AGPU_BOOL,to=F32: `in` is a bitmap of n bits.
- * f32→u8: trunc toward 0, clamp to [0,2^32-1], then mod 256; NaN→0 [ref: crates/cast/compute_shaders/f32/cast_u8.wgsl]. */
+ * f32→u8: trunc toward 0, clamp to [0,2^32-1], then mod 256; NaN→0 [ref: crates/cast/compute_shaders/f32/cast_u8.wgsl].
+ * f32→i8 / i16 / u16 / i32 / u32 / date32: REFERENCE-ABSENT (the reference implements f32→u8 only; north_star asks for
+ * "i8/i16/u8/u16 <-> f32").  Defined by analogy with cast_u8.wgsl: WGSL's conversion to the 32-bit integer of the
+ * target's signedness (u32(x) / i32(x): truncate toward 0, clamp to that range, NaN → 0), then the low bits of the
+ * target width.  u32/i32 → f32 stay unsupported, as in the reference's table. */
 agpu_status agpu_cast(agpu_pipeline* p, agpu_dtype from, agpu_dtype to, const void* in, void* out, uint64_t n);
 
 /* out[i] = value (n elements of dtype); `value_bits` holds the scalar's little-endian bytes in its low bits.
@@ -336,6 +373,107 @@ agpu_status agpu_merge_bits(agpu_pipeline* p, const void* a, const void* b, cons
                             uint64_t n_bits);
 /* *out_max (device u32) = max(idx[0..n)) — lets a host wrapper reject out-of-range indices (HIP has no robust access) */
 agpu_status agpu_index_max(agpu_pipeline* p, const uint32_t* idx, uint64_t n, uint32_t* out_max_dev);
+
+/* ---------------------------------------------------------------- multi-GPU: chunk-sharded columns, RCCL final reduce
+ * Not in the reference (single device + single queue [ref: crates/array/src/gpu_utils/gpu_device.rs:29-33]); this is
+ * north_star config 5.  One host thread or process per GPU, each with its own agpu_device + pipeline + communicator
+ * rank; a column is sharded into contiguous row ranges (cut on multiples of 512 rows: whole bitmap words, 2 KiB-aligned
+ * f32 spans); every kernel above runs shard-local with no collective; only whole-column statistics finish over RCCL.
+ *   rank 0: agpu_comm_get_unique_id(id) → ship the 128 bytes to the other ranks (pipe / file / torch.distributed …)
+ *   all   : agpu_comm_init_rank(dev, id, rank, world, &comm)      — collective, blocks until all ranks arrived
+ *   all   : agpu_comm_reduce(comm, p, op, dtype, shard, validity, n_local, out_dev)   — collective, asynchronous on p
+ * agpu_comm_reduce = shard-local agpu_reduce + an all-gather of ONE 16-byte record per rank + a single-workgroup
+ * combine IN RANK ORDER on every rank (identical result everywhere, independent of RCCL's ring order):
+ *   SUM f32  : the shard sums are combined by the reference's own adjacent-pair tree (zero-padded to 256), so shards of
+ *              256^k rows reproduce the reference's whole-column tree bit for bit [ref: aggregate.wgsl:28-37];
+ *   SUM ints : wrapping; MIN/MAX: Arrow semantics (NaN ignored unless all NaN); empty shards contribute the identity.
+ * One statistic in flight per communicator (calls on one pipeline are stream-ordered, which is enough). */
+#define AGPU_COMM_ID_BYTES 128
+typedef struct agpu_comm agpu_comm;
+typedef enum { AGPU_COMM_F32 = 0, AGPU_COMM_F64 = 1, AGPU_COMM_I32 = 2, AGPU_COMM_U32 = 3, AGPU_COMM_I64 = 4, AGPU_COMM_U64 = 5 } agpu_comm_dtype;
+agpu_status agpu_comm_get_unique_id(void* out_id /* AGPU_COMM_ID_BYTES */);
+agpu_status agpu_comm_init_rank(agpu_device* dev, const void* unique_id, int32_t rank, int32_t world, agpu_comm** out_comm);
+agpu_status agpu_comm_destroy(agpu_comm* c);
+agpu_status agpu_comm_rank(agpu_comm* c, int32_t* out_rank, int32_t* out_world);
+agpu_status agpu_comm_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, const void* in,
+                             const void* validity, uint64_t n_local, void* out_dev);
+/* f32 column summed in f64 per shard, shard sums added in rank order in f64 (order-robust statistic for huge columns) */
+agpu_status agpu_comm_reduce_sum_f64(agpu_comm* c, agpu_pipeline* p, const float* in, const void* validity,
+                                     uint64_t n_local, double* out_dev);
+/* the same final reduce for a per-shard statistic the caller already holds on the device (1 element of dtype at
+ * partial_dev; kind_f64 != 0: an f64 sum) */
+agpu_status agpu_comm_final_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, int32_t kind_f64,
+                                   const void* partial_dev, uint64_t n_local, void* out_dev);
+/* plain in-place ncclAllReduce (null counts, row counts: integer statistics whose order cannot matter) */
+agpu_status agpu_comm_all_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, agpu_comm_dtype ctype, void* buf_dev,
+                                 uint64_t count);
+agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p); /* collective + host wait on p's stream */
+
+/* ---------------------------------------------------------------- Arrow C Data Interface
+ * The reference builds arrays from host Vecs and reads them back as Vecs
+ * [ref: PrimitiveArrayGpu::from_slice / from_optional_slice / raw_values / values,
+ *  crates/array/src/array/primitive_array_gpu.rs:22-104].  Here any producer of the Arrow C Data Interface (arrow-rs
+ * `FFI_ArrowArray`, Arrow C++, pyarrow `_export_to_c`) hands its buffers over as they are.  The two structs are the ones
+ * of the Arrow specification (https://arrow.apache.org/docs/format/CDataInterface.html), declared here so the header
+ * has no dependency. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+#define ARROW_FLAG_DICTIONARY_ORDERED 1
+#define ARROW_FLAG_NULLABLE 2
+#define ARROW_FLAG_MAP_KEYS_SORTED 4
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+/* A column resident in HBM: what PrimitiveArrayGpu<T> / BooleanArrayGPU hold
+ * [ref: primitive_array_gpu.rs:12-20 {data, gpu_device, len, null_buffer}; boolean_gpu.rs:15-22]. */
+typedef struct {
+  agpu_dtype dtype;
+  uint64_t length;
+  int64_t null_count;    /* -1 = not computed */
+  void* values;          /* device (agpu_malloc); for AGPU_BOOL a bitmap of `length` bits, word-aligned, padding 0 */
+  void* validity;        /* device bitmap (bit set = valid), word-aligned, padding 0 — or NULL: no nulls */
+  uint64_t values_bytes; /* allocation sizes */
+  uint64_t validity_bytes;
+} agpu_arrow_column;
+/* format ∈ {"c","C","s","S","i","I","f","b","tdD"} (i8,u8,i16,u16,i32,u32,f32,bool,date32); anything else →
+ * AGPU_ERR_UNSUPPORTED (the reference has no other array types [ref: crates/array/src/array/mod.rs:40-50]).
+ * `offset` (sliced arrays) is honoured: values are copied from `offset` on, bitmaps are re-aligned on the GPU
+ * (agpu_bitmap_copy_bits).  null_count == 0 or no validity buffer ⇒ out->validity = NULL.
+ * Host→HBM staging: arrays ≥ 1 MiB go through page-locked chunks filled by several host threads while earlier chunks
+ * are already on the link (tuning "h2d_mode"/"h2d_threads"); the device-side work is ordered on p's stream and the call
+ * returns as soon as the SOURCE has been read completely — the caller may release `array` immediately and keeps
+ * ownership of it (this call never calls array->release). */
+agpu_status agpu_import_arrow(agpu_pipeline* p, const struct ArrowArray* array, const struct ArrowSchema* schema,
+                              agpu_arrow_column* out_column);
+/* Device column → freshly allocated host buffers behind a released-by-consumer ArrowArray/ArrowSchema pair (both
+ * `release` callbacks free everything this call allocated).  Blocks until the data has arrived. */
+agpu_status agpu_export_arrow(agpu_pipeline* p, const agpu_arrow_column* column, struct ArrowArray* out_array,
+                              struct ArrowSchema* out_schema);
+agpu_status agpu_arrow_column_free(agpu_device* dev, agpu_arrow_column* column); /* agpu_free of both buffers */
+/* The staging engine on its own: copy `bytes` between pageable host memory and HBM through the same path
+ * (to_device != 0: host → device).  Returns when the host side is complete (H2D: source consumed; D2H: data arrived). */
+agpu_status agpu_staged_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, int32_t to_device);
 
 /* ---------------------------------------------------------------- reference entry-point names
  * Keeps the reference's kernel identity for a thin shim: shader_key = the WGSL file's path under crates/ without

@@ -22,7 +22,8 @@ _BUILD = os.path.join(_HERE, "_build")
 # enum mirrors of include/arrow_gpu.h
 BOOL, F32, U32, U16, U8, I32, I16, I8, DATE32 = range(9)
 OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_REM, OP_MIN, OP_MAX, OP_AND, OP_OR, OP_XOR, OP_SHL, OP_SHR, OP_POW = range(13)
-(UN_NEG, UN_ABS, UN_NOT, UN_SQRT, UN_CBRT, UN_EXP, UN_EXP2, UN_LOG, UN_LOG2, UN_SIN, UN_COS, UN_ACOS, UN_SINH) = range(13)
+(UN_NEG, UN_ABS, UN_NOT, UN_SQRT, UN_CBRT, UN_EXP, UN_EXP2, UN_LOG, UN_LOG2, UN_SIN, UN_COS, UN_ACOS, UN_SINH,
+ UN_POPCOUNT) = range(14)
 CMP_GT, CMP_GTEQ, CMP_LT, CMP_LTEQ, CMP_EQ = range(5)
 RED_SUM, RED_MIN, RED_MAX = range(3)
 
@@ -316,3 +317,28 @@ def checksum(arr) -> int:
     out = C.c_uint64(0)
     _chk(lib().orc_checksum(_p(a), C.c_uint64(a.nbytes), C.byref(out)), "checksum")
     return out.value
+
+
+def sharded_reduce(op, dtype, shards, validities=None):
+    """Spec of the multi-GPU final reduce (include/arrow_gpu.h agpu_comm_reduce; nothing in the reference): every shard
+    is reduced on its own (the reference's tree order for f32 Sum), then the per-shard results are combined IN RANK
+    ORDER — f32 Sum by one more adjacent-pair tree level over the shard sums [aggregate.wgsl:21-41, i.e. `reduce` of
+    the vector of shard sums], integer sums wrapping, min/max with Arrow semantics (NaN ignored unless all NaN); an
+    empty shard contributes the identity."""
+    npd = NP_DTYPE[dtype]
+    validities = validities or [None] * len(shards)
+    parts = [(reduce(op, dtype, s, v), len(s)) for s, v in zip(shards, validities)]
+    if op == RED_SUM:
+        vec = np.array([p for p, _ in parts], dtype=npd)
+        return reduce(RED_SUM, dtype, vec)
+    live = np.array([p for p, n in parts if n > 0], dtype=npd)
+    return reduce(op, dtype, live)
+
+
+def sharded_reduce_sum_f64(shards, validities=None) -> float:
+    validities = validities or [None] * len(shards)
+    acc = 0.0
+    for s, v in zip(shards, validities):
+        if len(s):
+            acc = acc + reduce_sum_f64(s, v)
+    return acc

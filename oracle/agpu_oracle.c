@@ -25,7 +25,7 @@
 /* enum values mirror include/arrow_gpu.h */
 enum { T_BOOL = 0, T_F32, T_U32, T_U16, T_U8, T_I32, T_I16, T_I8, T_DATE32 };
 enum { OP_ADD = 0, OP_SUB, OP_MUL, OP_DIV, OP_REM, OP_MIN, OP_MAX, OP_AND, OP_OR, OP_XOR, OP_SHL, OP_SHR, OP_POW };
-enum { UN_NEG = 0, UN_ABS, UN_NOT, UN_SQRT, UN_CBRT, UN_EXP, UN_EXP2, UN_LOG, UN_LOG2, UN_SIN, UN_COS, UN_ACOS, UN_SINH };
+enum { UN_NEG = 0, UN_ABS, UN_NOT, UN_SQRT, UN_CBRT, UN_EXP, UN_EXP2, UN_LOG, UN_LOG2, UN_SIN, UN_COS, UN_ACOS, UN_SINH, UN_POPCOUNT };
 enum { CMP_GT = 0, CMP_GTEQ, CMP_LT, CMP_LTEQ, CMP_EQ };
 enum { RED_SUM = 0, RED_MIN, RED_MAX };
 
@@ -114,6 +114,22 @@ static inline uint8_t f32_to_u8(float x) {
   else if (x >= 4294967296.0f) u = 0xFFFFFFFFu;
   else u = (uint32_t)x;
   return (uint8_t)(u % 256u);
+}
+/* f32 → i8 / i16 / u16 / i32 / u32: REFERENCE-ABSENT (the reference's table has f32 → u8 only,
+ * crates/cast/src/lib.rs:135-161; north_star asks for "i8/i16/u8/u16 <-> f32").  Defined by analogy with
+ * cast_u8.wgsl: the WGSL conversion to the 32-bit integer of the target's signedness — u32(x) / i32(x): truncate
+ * toward 0, clamp to that type's range, NaN -> 0 — then keep the low bits of the target width (for u8 that is the
+ * reference's `% 256`). */
+static inline uint32_t f32_to_u32_wgsl(float x) {
+  if (!(x > 0.0f)) return 0u;
+  if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+  return (uint32_t)x;
+}
+static inline int32_t f32_to_i32_wgsl(float x) {
+  if (x != x) return 0;
+  if (x >= 2147483648.0f) return INT32_MAX;
+  if (x <= -2147483648.0f) return INT32_MIN;
+  return (int32_t)x;
 }
 
 /* ------------------------------------------------------------------ binary / scalar element-wise
@@ -248,6 +264,8 @@ int orc_unary(int op, int dtype, const void* in, void* out, uint64_t n) {
         case UN_NOT: o[i] = (T)~x; break; /* logical/ * /not.wgsl */               \
         case UN_NEG: o[i] = (T)(0 - (UT)x); break;                                 \
         case UN_ABS: o[i] = (T)(x < 0 ? (T)(0 - (UT)x) : x); break; /* math/i32/unary.wgsl: abs(MIN)=MIN */ \
+        case UN_POPCOUNT: { UT u = (UT)x; int c = 0; while (u) { c += (int)(u & 1); u = (UT)(u >> 1); } /* logical/u32/countbitones.wgsl:9-15 countOneBits */ \
+                            o[i] = (T)c; break; }                                  \
         default: return ORC_UNSUPPORTED;                                           \
       }                                                                            \
     } return ORC_OK; }
@@ -292,6 +310,19 @@ int orc_cast(int from, int to, const void* in, void* out, uint64_t n) {
   }
   if (from == T_F32 && to == T_U8) {
     for (uint64_t i = 0; i < n; i++) ((uint8_t*)out)[i] = f32_to_u8(((const float*)in)[i]);
+    return ORC_OK;
+  }
+  if (from == T_F32 && to != T_F32 && to != T_BOOL && orc_dtype_size(to)) { /* reference-absent, see f32_to_*_wgsl */
+    const int is_signed = (to == T_I8 || to == T_I16 || to == T_I32 || to == T_DATE32);
+    for (uint64_t i = 0; i < n; i++) {
+      const float x = ((const float*)in)[i];
+      const uint32_t bits = is_signed ? (uint32_t)f32_to_i32_wgsl(x) : f32_to_u32_wgsl(x);
+      switch (orc_dtype_size(to)) {
+        case 1: ((uint8_t*)out)[i] = (uint8_t)bits; break;
+        case 2: ((uint16_t*)out)[i] = (uint16_t)bits; break;
+        default: ((uint32_t*)out)[i] = bits; break;
+      }
+    }
     return ORC_OK;
   }
   if (from == T_F32 || from == T_BOOL || to == T_BOOL) return ORC_UNSUPPORTED;

@@ -166,8 +166,14 @@ int main() {
     auto f = Float32ArrayGPU::from_slice({0.f, 1.f, -1.f, 5713.f, -5713.f, 255.f, 256.f}, device);
     CHECK(same(f.cast<UInt8ArrayGPU>().raw_values(), {(uint8_t)0, 1, 0, 81, 0, 255, 0}));
     bool threw = false;
-    try { (void)f.cast<Int32ArrayGPU>(); } catch (const ArrowErrorGPU& e) { threw = e.kind == ArrowErrorGPU::CastingNotSupported; }
-    CHECK(threw);
+    try { (void)UInt32ArrayGPU::from_slice({1u, 2u}, device).cast<Float32ArrayGPU>(); } catch (const ArrowErrorGPU& e) { threw = e.kind == ArrowErrorGPU::CastingNotSupported; }
+    CHECK(threw);  // u32 → f32 is not in the reference's table [cast/src/lib.rs:135-161]
+    // reference-absent narrowing casts (north_star "i8/i16/u8/u16 <-> f32"): WGSL i32(x)/u32(x), then the low bits
+    auto g = Float32ArrayGPU::from_slice({0.f, 1.9f, -1.9f, 300.f, -300.f, 70000.f, -70000.f, 3e9f, -3e9f}, device);
+    CHECK(same(g.cast<Int8ArrayGPU>().raw_values(), {(int8_t)0, 1, -1, 44, -44, 112, -112, -1, 0}));
+    CHECK(same(g.cast<Int16ArrayGPU>().raw_values(), {(int16_t)0, 1, -1, 300, -300, 4464, -4464, -1, 0}));
+    CHECK(same(g.cast<UInt16ArrayGPU>().raw_values(), {(uint16_t)0, 1, 0, 300, 0, 4464, 0, 24064, 0}));
+    CHECK(same(g.cast<Int32ArrayGPU>().raw_values(), {0, 1, -1, 300, -300, 70000, -70000, INT32_MAX, INT32_MIN}));
     auto bl = BooleanArrayGPU::from_slice({true, false, true, true, false, false, true, true, false}, device);
     CHECK(same(bl.cast_f32().raw_values(), {1.f, 0.f, 1.f, 1.f, 0.f, 0.f, 1.f, 1.f, 0.f}));
   }

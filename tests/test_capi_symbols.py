@@ -46,7 +46,7 @@ def test_misc_queries_work_without_gpu():
     from arrow_gpu_amd import _capi as capi
 
     lib = capi.lib()
-    assert lib.agpu_abi_version() == 1
+    assert lib.agpu_abi_version() == 2
     assert b"gfx950" in lib.agpu_build_info()
     assert lib.agpu_dtype_size(capi.F32) == 4 and lib.agpu_dtype_size(capi.I16) == 2 and lib.agpu_dtype_size(capi.BOOL) == 0
     assert lib.agpu_bitmap_bytes(0) == 0 and lib.agpu_bitmap_bytes(1) == 8 and lib.agpu_bitmap_bytes(65) == 16

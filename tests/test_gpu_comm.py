@@ -1,0 +1,111 @@
+"""GPU: the multi-GPU half of the C ABI (include/arrow_gpu.h "multi-GPU") rehearsed on ONE GPU: an RCCL communicator
+of world size 1 runs exactly the code a 2/4/8-GPU job runs (ncclCommInitRank, ncclAllGather of the 16-byte record,
+rank-ordered combine kernel, ncclAllReduce), checked against the oracle's sharded-reduce spec.  The world-size-2
+arithmetic of the combine (order, NaN rule, empty shards) is covered on CPU by tests/test_sharding_gloo.py against the
+same spec; an 8-GPU node is the driver's to launch."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from arrow_gpu_amd import _capi as capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+    from arrow_gpu_amd.sharding import Communicator
+
+    dev = GpuDevice(0)
+    p = ArrowComputePipeline(dev, "comm")
+    comm = Communicator.single(dev)
+    yield dev, p, comm
+    comm.close()
+
+
+def bits(x, npd):
+    return np.array([x], dtype=npd).view(np.uint32 if np.dtype(npd).itemsize == 4 else np.uint64)[0]
+
+
+CASES = [(capi.F32, O.F32, np.float32), (capi.I32, O.I32, np.int32), (capi.U32, O.U32, np.uint32)]
+
+
+@pytest.mark.parametrize("n", [0, 1, 255, 65536, 1_000_003, 16_777_216 + 5])
+def test_comm_reduce_world1_matches_the_sharded_spec(ctx, n):
+    dev, p, comm = ctx
+    out = dev.create_empty_buffer(16)
+    for dt, odt, npd in CASES:
+        host = (O.synth_f32(n, 9, 0, -1.0, 1.0) if dt == capi.F32 else O.synth_i32(n, 9, 0, 0).view(npd))
+        buf = dev.create_gpu_buffer_with_data(host) if n else dev.create_empty_buffer(16)
+        for op in (capi.RED_SUM, capi.RED_MIN, capi.RED_MAX):
+            comm.reduce(p, op, dt, buf, None, n, out)
+            got = dev.retrive_data(out, 4, pipeline=p).view(npd)[0]
+            exp = O.sharded_reduce(op, odt, [host])
+            assert bits(got, npd) == bits(exp, npd), (dt, op, n, got, exp)
+    if n:
+        host = O.synth_f32(n, 9, 0, -1.0, 1.0)
+        buf = dev.create_gpu_buffer_with_data(host)
+        comm.reduce_sum_f64(p, buf, None, n, out)
+        got = dev.retrive_data(out, 8, pipeline=p).view(np.float64)[0]
+        assert got == O.sharded_reduce_sum_f64([host])
+
+
+def test_comm_reduce_with_validity_and_nan(ctx):
+    dev, p, comm = ctx
+    n = 300_001
+    host = O.synth_f32(n, 3, 0, -5.0, 5.0)
+    host[::7] = np.nan
+    v = O.synth_bits(n, 4, 0, 0.7)
+    buf, dv, out = dev.create_gpu_buffer_with_data(host), dev.create_gpu_buffer_with_data(v), dev.create_empty_buffer(16)
+    for op in (capi.RED_MIN, capi.RED_MAX, capi.RED_SUM):
+        comm.reduce(p, op, capi.F32, buf, dv, n, out)
+        got = dev.retrive_data(out, 4, pipeline=p).view(np.float32)[0]
+        exp = O.sharded_reduce(op, O.F32, [host], [v])
+        assert bits(got, np.float32) == bits(exp, np.float32) or (np.isnan(got) and np.isnan(exp)), (op, got, exp)
+    allnan = np.full(1000, np.nan, np.float32)
+    b2 = dev.create_gpu_buffer_with_data(allnan)
+    comm.reduce(p, capi.RED_MIN, capi.F32, b2, None, 1000, out)
+    assert np.isnan(dev.retrive_data(out, 4, pipeline=p).view(np.float32)[0])
+
+
+def test_comm_final_reduce_all_reduce_and_barrier(ctx):
+    dev, p, comm = ctx
+    part = dev.create_gpu_buffer_with_data(np.array([12345], np.uint32))
+    out = dev.create_empty_buffer(16)
+    comm.final_reduce(p, capi.RED_SUM, capi.U32, part, 10, out)
+    assert dev.retrive_data(out, 4, pipeline=p).view(np.uint32)[0] == 12345
+    comm.final_reduce(p, capi.RED_MAX, capi.U32, part, 0, out)  # an empty shard contributes the identity
+    assert dev.retrive_data(out, 4, pipeline=p).view(np.uint32)[0] == 0
+    pf = dev.create_gpu_buffer_with_data(np.array([1.5], np.float64))
+    comm.final_reduce(p, capi.RED_SUM, capi.F32, pf, 3, out, f64=True)
+    assert dev.retrive_data(out, 8, pipeline=p).view(np.float64)[0] == 1.5
+    cnt = dev.create_gpu_buffer_with_data(np.array([7, 9], np.uint64))
+    comm.all_reduce(p, capi.RED_SUM, capi.COMM_U64, cnt, 2)
+    assert dev.retrive_data(cnt, 16, pipeline=p).view(np.uint64).tolist() == [7, 9]
+    comm.barrier(p)
+    r, w = C.c_int32(-1), C.c_int32(-1)
+    capi.call("agpu_comm_rank", comm._h, C.byref(r), C.byref(w))
+    assert (r.value, w.value) == (0, 1)
+
+
+def test_sharded_sum_of_256k_row_shards_is_the_reference_tree(ctx):
+    """Property the final reduce is built for: cut a column into shards of 256^k rows, reduce each with the reference's
+    tree, combine the shard sums with one more adjacent-pair level → bit-identical to the reference's tree over the
+    whole column.  Checked here with the GPU doing the per-shard part and the oracle the whole-column tree."""
+    dev, p, comm = ctx
+    k_rows = 65536
+    shards = 8
+    host = O.synth_f32(k_rows * shards, 21, 0, -1000.0, 1000.0)
+    whole = O.reduce(O.RED_SUM, O.F32, host)
+    parts = np.empty(shards, np.float32)
+    out = dev.create_empty_buffer(16)
+    buf = dev.create_gpu_buffer_with_data(host)
+    for s in range(shards):
+        capi.call("agpu_reduce", p._handle, capi.RED_SUM, capi.F32, C.c_void_p(buf.ptr + 4 * k_rows * s), None, k_rows, C.c_void_p(out.ptr))
+        parts[s] = dev.retrive_data(out, 4, pipeline=p).view(np.float32)[0]
+    combined = O.reduce(O.RED_SUM, O.F32, parts)  # what comm_finish_sum_f32_kernel does with the gathered records
+    assert bits(combined, np.float32) == bits(whole, np.float32)
+    assert bits(O.sharded_reduce(O.RED_SUM, O.F32, np.split(host, shards)), np.float32) == bits(whole, np.float32)

@@ -97,11 +97,11 @@ def test_i32_add_sum_linearity_minmax_partition_and_compare(ctx):
     # values are uniform on 0..1023 ⇒ P(eq) = 1/1024; a loose sanity band on the count
     assert abs(eq - N / 1024) < 5 * (N / 1024) ** 0.5 + 1000
     for variant in (0, 1):  # both compare kernels agree on the full column
-        capi.call("agpu_set_tuning", b"cmp_variant", variant)
+        capi.call("agpu_pipeline_set_tuning", h, b"cmp_variant", variant)
         try:
             assert popcount_of(capi.CMP_LTEQ, a, b) == lt + eq
         finally:
-            capi.call("agpu_set_tuning", b"cmp_variant", 0)
+            capi.call("agpu_pipeline_set_tuning", h, b"cmp_variant", 0)
 
 
 def test_eq_with_validity_fullsize_windows_and_bitmap_identities(ctx):

@@ -44,7 +44,7 @@ def test_unsupported_pairs_raise_like_the_reference_panics(ag):
     with pytest.raises(ag.OperationNotSupported):
         ag.sqrt_dyn(i)
     with pytest.raises(ag.CastingNotSupported):
-        ag.cast_dyn(f, ag.ArrowType.Int32Type)
+        ag.cast_dyn(ag.UInt32ArrayGPU.from_slice([1, 2], dev), ag.ArrowType.Float32Type)  # u32 → f32 is not in the table
     with pytest.raises(ag.CastingNotSupported):
         ag.Int32ArrayGPU.try_from(f)
     with pytest.raises(ag.OperationNotSupported):

@@ -163,7 +163,7 @@ def test_f32_power_exact_for_exponents_one_and_two(D):
 
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_unary_exact_ops(D, dtype):
-    ops = [capi.UN_NEG, capi.UN_ABS] + ([capi.UN_SQRT] if dtype == capi.F32 else [capi.UN_NOT])
+    ops = [capi.UN_NEG, capi.UN_ABS] + ([capi.UN_SQRT] if dtype == capi.F32 else [capi.UN_NOT, capi.UN_POPCOUNT])
     for n in SMALL_SIZES:
         a = rand_values(dtype, n, 9)
         da, out = D.up(a), D.empty(max(a.nbytes, 1))
@@ -204,7 +204,8 @@ def test_fused_small_int_trig_exhaustive(D, dtype, op):
 CASTS = [(capi.I8, t) for t in (capi.U8, capi.U16, capi.U32, capi.I16, capi.I32, capi.F32)] + \
         [(capi.I16, t) for t in (capi.I32, capi.U16, capi.U32, capi.F32)] + \
         [(capi.U8, t) for t in (capi.U16, capi.U32, capi.I8, capi.I16, capi.I32, capi.F32)] + \
-        [(capi.U16, t) for t in (capi.U32, capi.I16, capi.I32, capi.F32)] + [(capi.F32, capi.U8)]
+        [(capi.U16, t) for t in (capi.U32, capi.I16, capi.I32, capi.F32)] + [(capi.F32, capi.U8)] + \
+        [(capi.F32, t) for t in (capi.I8, capi.I16, capi.U16, capi.I32, capi.U32)]  # reference-absent (north_star "<->")
 
 
 @pytest.mark.parametrize("frm,to", CASTS)
@@ -213,6 +214,9 @@ def test_casts_exact(D, frm, to):
         a = rand_values(frm, n, 13)
         if frm == capi.F32 and n > 8:
             a[:8] = [0, 1, -1, 5713, -5713, 255, 256, 4.3e9]
+            if n > 24:  # range edges of every target, both signs, NaN / inf
+                a[8:24] = [127.9, 128, -128.9, -129, 32767.5, 32768, -32768.9, -32769, 65535.9, 65536, 2147483520, 2147483648,
+                           -2147483648, -2147483904, np.nan, -np.inf]
         out = D.empty(max(n * NP[to]().itemsize, 1))
         D.call("agpu_cast", frm, to, D.up(a).vp, out.vp, n)
         got = D.down(out, NP[to], n)
@@ -230,7 +234,7 @@ def test_cast_bool_to_f32_and_unsupported(D):
         D.call("agpu_cast", capi.BOOL, capi.F32, D.up(bits).vp, out.vp, n)
         assert bits_equal(D.down(out, np.float32, n), O.cast(O.BOOL, O.F32, bits, n))
     x = D.up(np.zeros(4, np.float32))
-    assert D.status("agpu_cast", capi.F32, capi.I32, x.vp, x.vp, 4) == capi.ERR_UNSUPPORTED
+    assert D.status("agpu_cast", capi.U32, capi.F32, x.vp, x.vp, 4) == capi.ERR_UNSUPPORTED  # not in the reference's table
     assert D.status("agpu_binary", capi.OP_DIV, capi.U8, x.vp, x.vp, x.vp, 4) == capi.ERR_UNSUPPORTED
     assert D.status("agpu_unary", capi.UN_SQRT, capi.I32, x.vp, x.vp, 4) == capi.ERR_UNSUPPORTED
     assert b"not supported" in capi.lib().agpu_last_error()
@@ -262,7 +266,7 @@ def test_broadcast(D, dtype):
 @pytest.mark.parametrize("dtype", ALL_DTYPES)
 @pytest.mark.parametrize("variant", [0, 1])
 def test_compare_all_ops(D, dtype, variant):
-    capi.call("agpu_set_tuning", b"cmp_variant", variant)
+    D.call("agpu_pipeline_set_tuning", b"cmp_variant", variant)
     try:
         for n in SIZES:
             a, b = rand_values(dtype, n, 31), rand_values(dtype, n, 32)
@@ -284,7 +288,7 @@ def test_compare_all_ops(D, dtype, variant):
             D.call("agpu_compare_validity", capi.CMP_EQ, dtype, da.vp, db.vp, None, dvb.vp, out.vp, outv.vp, n)
             assert bits_equal(D.down(outv, np.uint8, nb), vb[:nb])
     finally:
-        capi.call("agpu_set_tuning", b"cmp_variant", 0)
+        D.call("agpu_pipeline_set_tuning", b"cmp_variant", 0)
 
 
 def test_compare_f32_nan_inf_table(D):

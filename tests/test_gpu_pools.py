@@ -20,6 +20,12 @@ def pool_info(dev):
     return b.value, k.value, s.value
 
 
+def small_pool_info(dev):
+    b, f, l = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    capi.call("agpu_device_small_pool_info", dev._handle, C.byref(b), C.byref(f), C.byref(l))
+    return b.value, f.value, l.value
+
+
 def test_blocks_are_recycled_and_trim_releases_them(ag):
     import gc
 
@@ -34,9 +40,16 @@ def test_blocks_are_recycled_and_trim_releases_them(ag):
     assert blocks == 1 and cached == 64 << 20
     b = dev.create_empty_buffer((64 << 20) - 4096)  # rounds to the same 2 MiB granule count → same block
     assert b.ptr == ptr and pool_info(dev)[:2] == (0, 0)
-    small = dev.create_empty_buffer(4096)  # below 1 MiB: never pooled
-    del small
+    slab0, free0, live0 = small_pool_info(dev)
+    small = dev.create_empty_buffer(4096)  # below 1 MiB: a 4 KiB block of the slab pool, not the large-block cache
     assert pool_info(dev)[:2] == (0, 0)
+    slab1, free1, live1 = small_pool_info(dev)
+    assert live1 == live0 + 1 and slab1 >= max(slab0, 2 << 20)
+    del small
+    assert small_pool_info(dev)[2] == live0
+    again = [dev.create_empty_buffer(4000) for _ in range(3)]  # same size class; no hipMalloc, no hipFree
+    assert small_pool_info(dev)[0] == slab1 and len({b.ptr for b in again}) == 3
+    del again
     del b
     capi.call("agpu_device_trim", dev._handle)
     assert pool_info(dev)[:2] == (0, 0)

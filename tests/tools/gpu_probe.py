@@ -64,7 +64,7 @@ def main():
         nb = O.bitmap_bytes(n)
         dob, dov = dev.create_empty_buffer(max(nb, 16)), dev.create_empty_buffer(max(nb, 16))
         for variant in (0, 1):
-            capi.call("agpu_set_tuning", b"cmp_variant", variant)
+            capi.call("agpu_pipeline_set_tuning", p._handle, b"cmp_variant", variant)
             for op in (capi.CMP_EQ, capi.CMP_LT, capi.CMP_GT):
                 capi.call("agpu_memset", p._handle, vp(dob), 0xAA, max(nb, 16))
                 capi.call("agpu_compare_validity", p._handle, op, capi.I32, vp(dia), vp(dib), vp(dva), vp(dvb), vp(dob), vp(dov), n)
@@ -76,7 +76,7 @@ def main():
                 ok_all &= same
                 if not same:
                     print("MISMATCH compare variant", variant, "op", op, "n", n, flush=True)
-        capi.call("agpu_set_tuning", b"cmp_variant", 0)
+        capi.call("agpu_pipeline_set_tuning", p._handle, b"cmp_variant", 0)
         # f32 sum (reference order) + min/max
         dr = dev.create_empty_buffer(16)
         x = O.synth_f32(n, 7, 0, -1, 1)
@@ -170,13 +170,13 @@ def main():
     if args.sweep:
         grids = [0, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536]
     for g in grids:
-        capi.call("agpu_set_tuning", b"stream_grid", g)
+        capi.call("agpu_pipeline_set_tuning", p._handle, b"stream_grid", g)
         timeit(f"add_f32 grid={g}", add, 12 * n)
         for variant in (0, 1):
-            capi.call("agpu_set_tuning", b"cmp_variant", variant)
+            capi.call("agpu_pipeline_set_tuning", p._handle, b"cmp_variant", variant)
             timeit(f"eq_i32+validity v{variant} grid={g}", eqv, 8.5 * n)
-        capi.call("agpu_set_tuning", b"cmp_variant", 0)
-    capi.call("agpu_set_tuning", b"stream_grid", 0)
+        capi.call("agpu_pipeline_set_tuning", p._handle, b"cmp_variant", 0)
+    capi.call("agpu_pipeline_set_tuning", p._handle, b"stream_grid", 0)
     timeit("eq_i32 (no validity)", eq, 8.125 * n)
     timeit("add_scalar_f32", lambda: capi.call("agpu_scalar", p._handle, capi.OP_ADD, capi.F32, vp(A), vp(B), vp(Cc), n), 8 * n)
     timeit("sum_f32 (tree order)", lambda: capi.call("agpu_reduce", p._handle, capi.RED_SUM, capi.F32, vp(A), None, n, vp(R)), 4 * n)

@@ -30,8 +30,8 @@ cases = {"i32 eq": (8.125, lambda: capi.call("agpu_compare", h, capi.CMP_EQ, cap
          "u16 lt": (4.125, lambda: capi.call("agpu_compare", h, capi.CMP_LT, capi.U16, vp(A), vp(B), vp(OB), n))}
 for rep in range(2):
     for variant, u in ((0, 1), (1, 1), (1, 2), (1, 4)):
-        capi.call("agpu_set_tuning", b"cmp_variant", variant)
-        capi.call("agpu_set_tuning", b"stream_unroll", u)
+        capi.call("agpu_pipeline_set_tuning", h, b"cmp_variant", variant)
+        capi.call("agpu_pipeline_set_tuning", h, b"stream_unroll", u)
         for name, (bpr, f) in cases.items():
             f(); p.sync()
             ts = []

@@ -38,7 +38,7 @@ rows = []
 for rep in range(2):
     for k in (1, 2, 4, 8):
         for name, (bpr, tile_rows, f) in cases.items():
-            capi.call("agpu_set_tuning", b"stream_grid", 0 if k == 1 else max(1, n // tile_rows // k))
+            capi.call("agpu_pipeline_set_tuning", h, b"stream_grid", 0 if k == 1 else max(1, n // tile_rows // k))
             f(); p.sync()
             ts = []
             for _ in range(7):
@@ -47,6 +47,6 @@ for rep in range(2):
             ms = float(np.median(ts))
             rows.append({"kernel": name, "tiles_per_block": k, "rep": rep, "ms": round(ms, 4), "TBps": round(bpr * n / ms / 1e9, 3)})
             print(rows[-1], flush=True)
-capi.call("agpu_set_tuning", b"stream_grid", 0)
+capi.call("agpu_pipeline_set_tuning", h, b"stream_grid", 0)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(rows, open("gpurun_out/grid_div_sweep.json", "w"), indent=1)

@@ -30,7 +30,7 @@ cases = {"f32 min": (4, lambda: capi.call("agpu_reduce", h, capi.RED_MIN, capi.F
          "popcount": (0.125, lambda: capi.call("agpu_bitmap_popcount", h, vp(VA), n, vp(R)))}
 for rep in range(2):
     for g in (0, 256 * 8, 256 * 16, 256 * 32, 256 * 128, 256 * 256, 256 * 1024):
-        capi.call("agpu_set_tuning", b"reduce_grid", g)
+        capi.call("agpu_pipeline_set_tuning", h, b"reduce_grid", g)
         for name, (bpr, f) in cases.items():
             f(); p.sync()
             ts = []

@@ -28,7 +28,7 @@ cases = {"sin_u8": (5, lambda: capi.call("agpu_unary", h, capi.UN_SIN, capi.U8, 
 rows = []
 for rep in range(3):
     for k in (1, 2, 3, 4, 6, 8):
-        capi.call("agpu_set_tuning", b"table_tiles", k)
+        capi.call("agpu_pipeline_set_tuning", h, b"table_tiles", k)
         for name, (bpr, f) in cases.items():
             f(); p.sync()
             ts = []
