@@ -123,6 +123,7 @@ SIGNATURES = {
     "agpu_merge_bits": [_vp, _vp, _vp, _vp, _vp, _u64],
     "agpu_index_max": [_vp, _vp, _u64, _vp],
     "agpu_launch_by_name": [_vp, C.c_char_p, C.c_char_p, _pp, _i32, _vp, _u64],
+    "agpu_launch_by_name_sized": [_vp, C.c_char_p, C.c_char_p, _pp, C.POINTER(_u64), _i32, _vp, _u64, _u32],
     "agpu_synth_f32": [_vp, _vp, _u64, _u64, _u64, C.c_float, C.c_float],
     "agpu_synth_i32": [_vp, _vp, _u64, _u64, _u64, _u32],
     "agpu_synth_u8": [_vp, _vp, _u64, _u64, _u64],

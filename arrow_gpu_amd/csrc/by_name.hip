@@ -10,6 +10,19 @@
 
 agpu_status agpu_bitmap_andnot_internal(agpu_pipeline* p, const void* a, const void* b, void* out, uint64_t n_bits);
 
+#include <mutex>
+#include <set>
+
+// "<shader_key>::<entry_point>" with static lifetime (agpu_pipeline_last_kernel_ns hands the pointer out)
+static const char* intern_label(const char* shader_key, const char* entry_point) {
+  static std::mutex mu;
+  static std::set<std::string> names;
+  std::lock_guard<std::mutex> lock(mu);
+  return names.insert(std::string(shader_key) + "::" + entry_point).first->c_str();
+}
+
+agpu_status agpu_internal_sum_level(agpu_pipeline* p, agpu_dtype dtype, const void* in, uint64_t m, void* out, uint64_t groups);
+
 static bool dtype_of(const std::string& d, agpu_dtype* out) {
   if (d == "f32") *out = AGPU_F32;
   else if (d == "i32") *out = AGPU_I32;
@@ -62,6 +75,8 @@ static bool unary_of(const std::string& s, agpu_unary_op* out) {
 extern "C" agpu_status agpu_launch_by_name(agpu_pipeline* p, const char* shader_key, const char* entry_point,
                                            const void* const* inputs, int32_t n_inputs, void* out, uint64_t n) {
   AGPU_REQUIRE(p && shader_key && entry_point && (n_inputs == 0 || inputs), AGPU_ERR_ARG, "null argument");
+  AGPU_BIND_AS(p, "agpu_launch_by_name");
+  agpu_scope_label(p, intern_label(shader_key, entry_point));  // [ref: insert_debug_marker(entry_point) gpu_device.rs:132]
   const std::string key(shader_key), ep(entry_point);
   const size_t s1 = key.find('/'), s2 = key.rfind('/');
   AGPU_REQUIRE(s1 != std::string::npos && s2 != s1, AGPU_ERR_ARG, "shader_key must be <crate>/<dir>/<file>");
@@ -111,6 +126,9 @@ extern "C" agpu_status agpu_launch_by_name(agpu_pipeline* p, const char* shader_
     } else if (file == "any" && ep == "any") {
       NEED(1);  // n = bits
       return agpu_bitmap_any(p, IN(0), n, static_cast<uint32_t*>(out));
+    } else if (file == "countbitones" && ep == "countob") {
+      NEED(1);  // n = 32-bit words; out[i] = countOneBits(in[i])  [logical/u32/countbitones.wgsl:9-15]
+      return agpu_unary(p, AGPU_UN_POPCOUNT, dt, IN(0), out, n);
     }
   } else if (crate == "compare" && has_dt) {
     NEED(2);
@@ -181,4 +199,136 @@ extern "C" agpu_status agpu_launch_by_name(agpu_pipeline* p, const char* shader_
 #undef NEED
   agpu_set_error("no kernel for shader '%s' entry point '%s'", shader_key, entry_point);
   return AGPU_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------- the byte-sized form: the reference's literal call
+// apply_{unary,binary,scalar,ternary,broadcast}_function(buffers…, new_buffer_size, shader, entry_point, dispatch_size)
+// [ref: compute_pipeline.rs:24-256, gpu_device.rs:267-509; routines::apply_take_op take.rs:9-55, apply_put_op
+//  put.rs:9-56; cast::apply_boolean_unary_function boolean_cast.rs:8-55] carries NO element count: the WGSL runs
+// dispatch_size × 256 invocations and wgpu's robust buffer access drops whatever falls outside a binding.  The count is
+// therefore derived here the way the shader would see it — from the byte sizes of the bound buffers and the dispatch —
+// and every lane that is fully inside its bindings is processed, INCLUDING the padding lanes of sub-word columns
+// (buffers are multiples of 4 bytes; a 5-element u8 column is 2 words = 8 lanes), exactly like the WGSL does.  Lanes
+// whose inputs or output fall outside a binding are skipped (robust access leaves their value unspecified).
+namespace {
+struct Sized {
+  uint64_t inv;         // invocations = dispatch_size * 256
+  const uint64_t* ib;   // input byte sizes
+  int n_in;
+  uint64_t ob;          // output byte size
+  uint64_t W(int k) const { return k < n_in ? ib[k] / 4 : 0; }
+  uint64_t OW() const { return ob / 4; }
+};
+inline uint64_t min3(uint64_t a, uint64_t b, uint64_t c) { return a < b ? (a < c ? a : c) : (b < c ? b : c); }
+inline uint64_t min2(uint64_t a, uint64_t b) { return a < b ? a : b; }
+inline int lanes_of(agpu_dtype dt) {
+  const size_t w = agpu_dtype_size(dt);
+  return w ? (int)(4 / w) : 32;
+}
+}  // namespace
+
+extern "C" agpu_status agpu_launch_by_name_sized(agpu_pipeline* p, const char* shader_key, const char* entry_point,
+                                                 const void* const* inputs, const uint64_t* input_bytes, int32_t n_inputs,
+                                                 void* out, uint64_t out_bytes, uint32_t dispatch_size) {
+  AGPU_REQUIRE(p && shader_key && entry_point && (n_inputs == 0 || (inputs && input_bytes)), AGPU_ERR_ARG, "null argument");
+  AGPU_REQUIRE(n_inputs >= 0 && n_inputs <= 4, AGPU_ERR_ARG, "0..4 read bindings");
+  for (int k = 0; k < n_inputs; k++)
+    AGPU_REQUIRE(input_bytes[k] % 4 == 0, AGPU_ERR_SHAPE, "wgpu buffers are multiples of 4 bytes");
+  AGPU_REQUIRE(out_bytes % 4 == 0, AGPU_ERR_SHAPE, "wgpu buffers are multiples of 4 bytes");
+  AGPU_BIND_AS(p, "agpu_launch_by_name_sized");
+  const std::string key(shader_key), ep(entry_point);
+  const size_t s1 = key.find('/'), s2 = key.rfind('/');
+  AGPU_REQUIRE(s1 != std::string::npos && s2 != s1, AGPU_ERR_ARG, "shader_key must be <crate>/<dir>/<file>");
+  const std::string crate = key.substr(0, s1), dir = key.substr(s1 + 1, s2 - s1 - 1), file = key.substr(s2 + 1);
+  agpu_dtype dt = AGPU_U32;
+  const bool has_dt = dtype_of(dir, &dt);
+  const Sized z{(uint64_t)dispatch_size * 256, input_bytes, n_inputs, out_bytes};
+  const int L = has_dt ? lanes_of(dt) : 1;
+#define NEED(k) AGPU_REQUIRE(n_inputs >= (k), AGPU_ERR_ARG, "too few input bindings for this entry point")
+  uint64_t n = 0;
+  bool known = true;
+  if (crate == "arithmetic" && has_dt && file == "aggregate" && ep == "sum") {
+    // ONE level of the reference's tree per dispatch: workgroup g writes out[g] = tree sum of in[256g .. 256g+255],
+    // rows past arrayLength(&input) count as 0 [ref: aggregate.wgsl:21-41; the loop over levels is the caller's,
+    // aggregate_kernels.rs:26-43]
+    NEED(1);
+    agpu_scope_label(p, intern_label(shader_key, entry_point));
+    return agpu_internal_sum_level(p, dt, inputs[0], z.W(0), out, min2((uint64_t)dispatch_size, z.OW()));
+  } else if (crate == "arithmetic" && has_dt && file == "scalar") {
+    NEED(2);  // binding 1 is the 1-element operand
+    n = min3(z.inv, z.W(0), z.OW()) * (uint64_t)L;
+  } else if (crate == "array" && has_dt && file == "broadcast") {
+    NEED(1);
+    n = min2(z.inv, z.OW());
+  } else if (crate == "compare" && has_dt && file == "cmp") {
+    NEED(2);  // one invocation per input word (L lanes), one output word per 32 lanes
+    n = min2(min3(z.inv, z.W(0), z.W(1)) * (uint64_t)L, z.OW() * 32);
+  } else if (crate == "logical" && has_dt && file == "shift" && L > 1) {
+    NEED(2);  // one data word (L lanes) + L separate u32 shift amounts per invocation
+    n = min3(min2(z.inv, z.W(0)), z.OW(), z.W(1) / (uint64_t)L) * (uint64_t)L;
+  } else if (crate == "logical" && has_dt && file == "any") {
+    NEED(1);
+    n = min2(z.inv, z.W(0)) * 32;  // bits
+  } else if (crate == "cast" && has_dt && dt == AGPU_F32) {
+    NEED(1);  // cast_u8: one invocation per OUTPUT word, 4 f32 in
+    n = min2(min2(z.inv, z.OW()) * 4, z.W(0));
+  } else if (crate == "cast" && has_dt && dt == AGPU_BOOL) {
+    NEED(1);  // one invocation per output f32, guarded by arrayLength(&new_values)
+    n = min3(z.inv, z.OW(), z.W(0) * 32);
+  } else if ((crate == "cast" || crate == "trigonometry") && has_dt && L > 1) {
+    NEED(1);  // one invocation per input word → L outputs
+    agpu_dtype to = AGPU_F32;
+    if (crate == "cast") AGPU_REQUIRE(file.rfind("cast_", 0) == 0 && dtype_of(file.substr(5), &to), AGPU_ERR_UNSUPPORTED, "unknown cast shader");
+    n = min2(min2(z.inv, z.W(0)) * (uint64_t)L, out_bytes / agpu_dtype_size(to));
+  } else if (crate == "routines" && (dir == "32bit" || dir == "16bit" || dir == "8bit") && file == "merge") {
+    NEED(3);
+    const int ml = dir == "32bit" ? 1 : dir == "16bit" ? 2 : 4;
+    n = min2(min2(min3(z.inv, z.W(0), z.W(1)), z.OW()) * (uint64_t)ml, z.W(2) * 32);
+  } else if (crate == "routines" && dir == "32bit" && file == "take") {
+    NEED(2);  // values length comes with the binding: out-of-range indices read 0, like robust access
+    agpu_scope_label(p, intern_label(shader_key, entry_point));
+    return agpu_take(p, 4, inputs[0], z.W(0), static_cast<const uint32_t*>(inputs[1]), out, min3(z.inv, z.W(1), z.OW()));
+  } else if (crate == "routines" && dir == "32bit" && file == "put") {
+    NEED(3);  // inputs = {src, src_indexes, dst_indexes}, out = dst (binding 1, read_write)
+    agpu_scope_label(p, intern_label(shader_key, entry_point));
+    return agpu_put_bounded(p, 4, inputs[0], z.W(0), static_cast<const uint32_t*>(inputs[1]), out, z.OW(),
+                            static_cast<const uint32_t*>(inputs[2]), min3(z.inv, z.W(1), z.W(2)));
+  } else if (crate == "routines" && dir == "bool" && file == "take") {
+    NEED(2);  // one invocation per OUTPUT word of 32 gathered bits
+    agpu_scope_label(p, intern_label(shader_key, entry_point));
+    return agpu_take_bits(p, inputs[0], z.W(0) * 32, static_cast<const uint32_t*>(inputs[1]), out,
+                          min2(min2(z.inv, z.OW()) * 32, z.W(1)));
+  } else if (crate == "routines" && dir == "bool" && file == "put") {
+    NEED(3);  // one invocation per index pair
+    agpu_scope_label(p, intern_label(shader_key, entry_point));
+    return agpu_put_bits_bounded(p, inputs[0], z.W(0) * 32, static_cast<const uint32_t*>(inputs[1]), out, z.OW() * 32,
+                                 static_cast<const uint32_t*>(inputs[2]), min3(z.inv, z.W(1), z.W(2)));
+  } else if (crate == "routines" && ((dir == "bool" && file == "merge") || (dir == "u32" && file == "merge_null_buffer"))) {
+    NEED(2);  // whole 32-bit words of bits
+    uint64_t w = min3(z.inv, z.W(0), z.W(1));
+    if (file == "merge") {
+      NEED(3);
+      w = min2(w, z.W(2));
+    }
+    n = min2(w, z.OW()) * 32;
+  } else if (n_inputs >= 1 && (crate == "arithmetic" || crate == "logical" || crate == "compare" || crate == "math" || crate == "trigonometry") && has_dt) {
+    // the word-map shape: invocation i touches word i of every binding (array.wgsl, neg.wgsl, logical.wgsl, not.wgsl,
+    // 32-bit shift.wgsl, min_max.wgsl, floatunary/floatbinary.wgsl, i32 unary/binary.wgsl, f32 trigonometry.wgsl,
+    // countbitones.wgsl); sub-word min_max (u16) carries L lanes per word
+    uint64_t w = min3(z.inv, z.W(0), z.OW());
+    const bool two = file == "array" || file == "logical" || file == "shift" || file == "min_max" || file == "floatbinary" || file == "binary";
+    if (two) {
+      NEED(2);
+      w = min2(w, z.W(1));
+    }
+    n = w * (uint64_t)L;
+  } else {
+    known = false;
+  }
+#undef NEED
+  if (!known) {
+    agpu_set_error("no kernel for shader '%s' entry point '%s'", shader_key, entry_point);
+    return AGPU_ERR_UNSUPPORTED;
+  }
+  return agpu_launch_by_name(p, shader_key, entry_point, inputs, n_inputs, out, n);
 }

@@ -347,6 +347,44 @@ static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const 
   return AGPU_OK;
 }
 
+// ---------------------------------------------------------------- one level of the reference's tree (by_name.hip)
+// The reference's `sum` entry point reduces 256 rows per workgroup and is dispatched once per level by Sum::sum_op
+// [ref: aggregate.wgsl:21-41, aggregate_kernels.rs:26-43].  agpu_launch_by_name_sized keeps that call shape: workgroup g
+// writes out[g] = adjacent-pair tree over in[256g .. 256g+255], rows ≥ m count as 0.  (agpu_reduce runs the whole tree.)
+template <typename T>
+__global__ __launch_bounds__(AGPU_BLOCK) void sum_level_kernel(const T* in, uint64_t m, T* out, uint64_t groups) {
+  __shared__ T sh[AGPU_BLOCK];
+  const uint32_t tid = threadIdx.x;
+  for (uint64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const uint64_t i = g * 256 + tid;
+    sh[tid] = i < m ? in[i] : (T)0;
+    __syncthreads();
+    for (uint32_t s = 1; s < 256; s *= 2) {
+      const uint32_t idx = 2 * s * tid;
+      if (idx + s < 256) sh[idx] = (T)(sh[idx] + sh[idx + s]);  // u32/i32: wrapping; f32: rounds once per add
+      __syncthreads();
+    }
+    if (tid == 0) out[g] = sh[0];
+    __syncthreads();
+  }
+}
+
+agpu_status agpu_internal_sum_level(agpu_pipeline* p, agpu_dtype dtype, const void* in, uint64_t m, void* out, uint64_t groups) {
+  if (groups == 0) return AGPU_OK;
+  AGPU_REQUIRE(in && out, AGPU_ERR_ARG, "null pointer");
+  const int grid = (int)(groups < (1u << 20) ? groups : (1u << 20));
+  if (dtype == AGPU_F32)
+    hipLaunchKernelGGL((sum_level_kernel<float>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const float*>(in), m, static_cast<float*>(out), groups);
+  else if (dtype == AGPU_I32 || dtype == AGPU_U32 || dtype == AGPU_DATE32)
+    hipLaunchKernelGGL((sum_level_kernel<uint32_t>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(in), m, static_cast<uint32_t*>(out), groups);
+  else {
+    agpu_set_error("sum: 32-bit types only (like the reference's Sum32Bit)");
+    return AGPU_ERR_UNSUPPORTED;
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
 // ---------------------------------------------------------------- multi-GPU final reduce (comm.hip)
 // One 16-byte record per rank {statistic in the low 4 / 8 bytes, n_local}, gathered over RCCL, combined here IN RANK
 // ORDER by one workgroup on every rank — deterministic and identical everywhere, independent of RCCL's ring order.

@@ -484,6 +484,24 @@ agpu_status agpu_staged_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, si
  * [ref: GpuDevice::create_compute_pipeline(shader, entry_point) gpu_device.rs:145-168 — (shader, entry) is the cache key] */
 agpu_status agpu_launch_by_name(agpu_pipeline* p, const char* shader_key, const char* entry_point,
                                 const void* const* inputs, int32_t n_inputs, void* out, uint64_t n);
+/* The reference's LITERAL call: apply_{unary,binary,scalar,ternary,broadcast}_function(buffers…, new_buffer_size, shader,
+ * entry_point, dispatch_size) [ref: compute_pipeline.rs:24-66 (unary), 68-113 (binary), 115-165 (ternary), 167-213
+ * (scalar), 215-256 (broadcast); the immediate forms gpu_device.rs:267-509; routines::apply_take_op take.rs:9-55,
+ * apply_put_op put.rs:9-56; cast::apply_boolean_unary_function boolean_cast.rs:8-55] carries no element count — a
+ * shim that keeps every call site unchanged only has buffers with their BYTE sizes and the dispatch size.  This form
+ * takes exactly that: inputs[k] / input_bytes[k] = the read bindings in binding order (put: src, src_indexes,
+ * dst_indexes), out / out_bytes = the read_write binding (the buffer the shim allocated with new_buffer_size; put: dst),
+ * dispatch_size = workgroups of 256.  The element count is derived as the WGSL sees it: every lane that lies inside all
+ * of its bindings and inside dispatch_size × 256 invocations is processed — including the padding lanes of sub-word
+ * columns (a 5-element u8 column is 2 words = 8 lanes) — lanes outside are skipped (robust buffer access leaves them
+ * unspecified).  "sum" runs ONE 256-ary level per call, like the shader (the loop over levels stays in Sum::sum_op).
+ * All byte sizes are multiples of 4 (wgpu's COPY_BUFFER_ALIGNMENT); every buffer must come from agpu_malloc (blocks are
+ * padded to 16 bytes, which the word-granular bitmap kernels rely on).  All 148 live (shader, entry point) pairs of the
+ * reference are accepted (tests/golden/reference_entry_points.json, tests/test_gpu_by_name.py); the 5 dead ones — WGSL
+ * files no Rust source includes — return AGPU_ERR_UNSUPPORTED. */
+agpu_status agpu_launch_by_name_sized(agpu_pipeline* p, const char* shader_key, const char* entry_point,
+                                      const void* const* inputs, const uint64_t* input_bytes, int32_t n_inputs,
+                                      void* out, uint64_t out_bytes, uint32_t dispatch_size);
 
 /* ---------------------------------------------------------------- synthetic columns (bench / parity inputs)
  * Counter-based: element i of a column depends only on (seed, row0+i), so any shard of a column can be generated
