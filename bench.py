@@ -261,24 +261,59 @@ def main():
             capi.call("agpu_download", h, C.c_void_p(gv.ctypes.data), C.c_void_p(ov.ptr + start // 8), nbytes)
             windows.append({"row": row0 + start, "rows": cnt, "add": got, "eq_bits": gb, "eq_validity": gv})
 
-    # ---- config 5: per-shard sum/min/max + final reduce over RCCL (outside the timed region)
+    # ---- config 5: per-shard sum/min/max + final reduce over RCCL (outside the timed region).  Everything below goes
+    # through the C ABI's communicator (include/arrow_gpu.h "multi-GPU"): agpu_comm_reduce = the shard-local kernel
+    # (for SUM the reference-order tree, sum_tree_span_kernel) + an all-gather of one 16-byte record per rank + the
+    # rank-ordered combine.  The rendezvous id travels over the torch.distributed group when one exists; a plain
+    # `python bench.py` builds a world of one rank, so the RCCL path runs on every box.
     extra = {}
-    red = torch.zeros(1, dtype=torch.float64, device="cuda")
-    mn = torch.zeros(1, dtype=torch.float32, device="cuda")
-    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
-    rs, re_ = ev(), ev()
-    capi.call("agpu_event_record", rs, h)
-    capi.call("agpu_reduce_sum_f64", h, vp(fa), None, n, C.c_void_p(red.data_ptr()))
-    capi.call("agpu_reduce", h, capi.RED_MIN, capi.F32, vp(fa), None, n, C.c_void_p(mn.data_ptr()))
-    capi.call("agpu_reduce", h, capi.RED_MAX, capi.F32, vp(fa), None, n, C.c_void_p(mx.data_ptr()))
-    capi.call("agpu_event_record", re_, h)
+    comm = sharding.Communicator.from_torch(dev) if distributed else sharding.Communicator.single(dev)
+    stat_out = {k: dev.create_empty_buffer(16) for k in ("sum", "min", "max", "sum_f64")}
+    p.sync()
+    stats = {}
+    for name, launch in (
+            ("sum", lambda: capi.call("agpu_reduce", h, capi.RED_SUM, capi.F32, vp(fa), None, n, vp(stat_out["sum"]))),
+            ("min", lambda: capi.call("agpu_reduce", h, capi.RED_MIN, capi.F32, vp(fa), None, n, vp(stat_out["min"]))),
+            ("max", lambda: capi.call("agpu_reduce", h, capi.RED_MAX, capi.F32, vp(fa), None, n, vp(stat_out["max"]))),
+            ("sum_f64", lambda: capi.call("agpu_reduce_sum_f64", h, vp(fa), None, n, vp(stat_out["sum_f64"])))):
+        launch()  # warm (scratch allocation)
+        reps = 5
+        pairs = [(ev(), ev()) for _ in range(reps)]
+        for s_, e_ in pairs:  # the shard-local kernel alone, one event pair per launch
+            capi.call("agpu_event_record", s_, h)
+            launch()
+            capi.call("agpu_event_record", e_, h)
+        ms_k = mean_ms(pairs)
+        stats[name] = {"local_ms": round(ms_k, 4), "local_GBps": round(4.0 * n / ms_k / 1e6, 1),
+                       "frac_hbm_peak": round(4.0 * n / ms_k / 1e6 / HBM_PEAK_GBPS, 4)}
+    # the collective form: local kernel + RCCL all-gather + combine, timed end to end on the stream
+    cs, ce = ev(), ev()
+    comm.reduce(p, capi.RED_SUM, capi.F32, fa, None, n, stat_out["sum"])  # warm RCCL's first-call setup
+    p.sync()
+    capi.call("agpu_event_record", cs, h)
+    comm.reduce(p, capi.RED_SUM, capi.F32, fa, None, n, stat_out["sum"])
+    comm.reduce(p, capi.RED_MIN, capi.F32, fa, None, n, stat_out["min"])
+    comm.reduce(p, capi.RED_MAX, capi.F32, fa, None, n, stat_out["max"])
+    comm.reduce_sum_f64(p, fa, None, n, stat_out["sum_f64"])
+    capi.call("agpu_event_record", ce, h)
     p.sync()
     ms = C.c_float()
-    capi.call("agpu_event_elapsed_ms", rs, re_, C.byref(ms))
-    sharding.final_reduce(red, mn, mx)  # RCCL all_reduce of one element per statistic when world > 1
-    extra["reduce_sum_min_max"] = {"rows_total": n * world, "sum": float(red.item()), "min": float(mn.item()),
-                                   "max": float(mx.item()), "per_gpu_GBps": round(3 * 4.0 * n / ms.value / 1e6, 1),
-                                   "final_reduce": "RCCL all_reduce of 1 element per statistic" if distributed else "none (single process)"}
+    capi.call("agpu_event_elapsed_ms", cs, ce, C.byref(ms))
+    import numpy as _np
+
+    def scalar(buf, dt):
+        return dev.retrive_data(buf, _np.dtype(dt).itemsize, pipeline=p).view(dt)[0]
+
+    local_sum_ms = sum(stats[k]["local_ms"] for k in ("sum", "min", "max", "sum_f64"))
+    extra["reduce_sum_min_max"] = {
+        "rows_total": n * world, "sum_f32_reference_tree": float(scalar(stat_out["sum"], _np.float32)),
+        "min": float(scalar(stat_out["min"], _np.float32)), "max": float(scalar(stat_out["max"], _np.float32)),
+        "sum_f64": float(scalar(stat_out["sum_f64"], _np.float64)), "per_statistic": stats,
+        "four_statistics_with_final_reduce_ms": round(ms.value, 4),
+        "final_reduce_overhead_ms": round(ms.value - local_sum_ms, 4),
+        "final_reduce": f"C ABI agpu_comm_reduce: RCCL all-gather of one 16-byte record per rank (world {world}) + rank-ordered combine",
+    }
+    comm.close()
     extra["kernels"] = {"add_f32": {"ms": round(add_ms, 4), "GBps": round(add_gbps, 1), "frac_hbm_peak": round(add_gbps / HBM_PEAK_GBPS, 4)},
                         "eq_i32_validity": {"ms": round(eq_ms, 4), "GBps": round(eq_gbps, 1), "frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4)}}
 
@@ -301,6 +336,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "ew_kernel<float, OpAdd> (agpu_binary ADD f32)",
                          "achieved": round(add_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(add_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_source": ("profiles/hbm_traffic.json: HBM bytes per launch of this kernel from separate rocprofv3 "
+                                            "--pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/profile_bench.sh), "
+                                            "read side x2 per the guide's gfx950 correction; NOT measured inside this run")
+                         if traffic is not None else None,
                          "algorithmic_bytes_per_launch": ADD_BYTES_PER_ROW * n, "launch_ms": round(add_ms, 4)},
             "extra": extra,
         }

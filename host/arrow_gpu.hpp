@@ -10,6 +10,7 @@
 // Rust trait bounds become static_asserts (an op a type does not implement fails to compile, as in Rust); the *_dyn
 // functions throw ArrowErrorGPU where the reference panics.  Header-only; link with -larrow_gpu_hip.
 #pragma once
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -1052,5 +1053,75 @@ class FusedChain {
 #undef AGPU_CHAIN_CMP
 };
 template <typename T> FusedChain(const PrimitiveArrayGpu<T>&) -> FusedChain<T>;
+
+// ------------------------------------------------------------------ chunk-sharded columns (north_star config 5)
+// Not in the reference (one device, one queue: crates/array/src/gpu_utils/gpu_device.rs:29-33).  One host thread per
+// GPU, each with its own GpuDevice, pipeline and Communicator rank; a column is a contiguous row range per GPU (cut with
+// shard_rows on 512-row boundaries); every op of this header runs shard-local; only whole-column statistics finish over
+// RCCL — one 16-byte record per rank, combined in rank order on every rank (include/arrow_gpu.h "multi-GPU").
+struct Shard {
+  int rank, world;
+  uint64_t row0, rows;
+};
+inline Shard shard_rows(uint64_t total_rows, int world, int rank, uint64_t align = 512) {
+  const uint64_t chunks = (total_rows + align - 1) / align, per = chunks / (uint64_t)world, extra = chunks % (uint64_t)world;
+  const uint64_t r = (uint64_t)rank, first = r * per + (r < extra ? r : extra), cnt = per + (r < extra ? 1 : 0);
+  const uint64_t lo = first * align < total_rows ? first * align : total_rows;
+  const uint64_t hi = (first + cnt) * align < total_rows ? (first + cnt) * align : total_rows;
+  return Shard{rank, world, lo, hi - lo};
+}
+
+class Communicator {
+ public:
+  using Id = std::array<uint8_t, AGPU_COMM_ID_BYTES>;
+  agpu_comm* raw = nullptr;
+  int rank = 0, world = 1;
+  static Id unique_id() {  // rank 0 makes it; every rank passes the same bytes to the constructor
+    Id id{};
+    check(agpu_comm_get_unique_id(id.data()), "agpu_comm_get_unique_id");
+    return id;
+  }
+  Communicator(const DevicePtr& dev, const Id& id, int rank_, int world_) : rank(rank_), world(world_) {
+    check(agpu_comm_init_rank(dev->raw, id.data(), rank_, world_, &raw), "agpu_comm_init_rank");  // collective
+  }
+  Communicator(const Communicator&) = delete;
+  ~Communicator() {
+    if (raw) agpu_comm_destroy(raw);
+  }
+  void barrier(ArrowComputePipeline& p) { check(agpu_comm_barrier(raw, p.h()), "agpu_comm_barrier"); }
+};
+
+// Whole-column Sum / min / max of a sharded column → 1-element array holding the SAME value on every rank.
+// f32 Sum: each shard in the reference's tree order, shard sums combined by one more adjacent-pair level.
+template <typename T>
+PrimitiveArrayGpu<T> reduce_sharded_op(const PrimitiveArrayGpu<T>& shard, agpu_reduce_op op, Communicator& comm,
+                                       ArrowComputePipeline& p, bool use_validity = false) {
+  static_assert(is_one_of<T, float, int32_t, uint32_t>, "32-bit statistics: f32, i32, u32");
+  auto out = shard.gpu_device->create_empty_buffer(16);
+  const void* validity = use_validity && shard.null_buffer ? shard.null_buffer->bit_buffer->ptr : nullptr;
+  check(agpu_comm_reduce(comm.raw, p.h(), op, Prim<T>::dtype, shard.data->ptr, validity, shard.len, out->ptr), "agpu_comm_reduce");
+  p.keep.insert(p.keep.end(), {shard.data, out});
+  return PrimitiveArrayGpu<T>(out, shard.gpu_device, 1, std::nullopt);
+}
+template <typename T> PrimitiveArrayGpu<T> sum_sharded_op(const PrimitiveArrayGpu<T>& s, Communicator& c, ArrowComputePipeline& p) {
+  return reduce_sharded_op(s, AGPU_RED_SUM, c, p);
+}
+template <typename T> PrimitiveArrayGpu<T> min_sharded_op(const PrimitiveArrayGpu<T>& s, Communicator& c, ArrowComputePipeline& p) {
+  return reduce_sharded_op(s, AGPU_RED_MIN, c, p);
+}
+template <typename T> PrimitiveArrayGpu<T> max_sharded_op(const PrimitiveArrayGpu<T>& s, Communicator& c, ArrowComputePipeline& p) {
+  return reduce_sharded_op(s, AGPU_RED_MAX, c, p);
+}
+#define AGPU_SHARDED_DEFAULT(NAME)                                                                 \
+  template <typename T> PrimitiveArrayGpu<T> NAME(const PrimitiveArrayGpu<T>& s, Communicator& c) { \
+    ArrowComputePipeline p(s.gpu_device);                                                          \
+    auto out = NAME##_op(s, c, p);                                                                 \
+    p.finish();                                                                                    \
+    return out;                                                                                    \
+  }
+AGPU_SHARDED_DEFAULT(sum_sharded)
+AGPU_SHARDED_DEFAULT(min_sharded)
+AGPU_SHARDED_DEFAULT(max_sharded)
+#undef AGPU_SHARDED_DEFAULT
 
 }  // namespace arrow_gpu

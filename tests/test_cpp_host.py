@@ -67,3 +67,46 @@ def test_c_example_on_gpu():
     build_c()
     r = subprocess.run([C_EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "simple.c OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- config 5 through the C++ host alone: one thread per GPU, RCCL final reduce (examples/sharded_stats.cpp)
+S_SRC = os.path.join(ROOT, "examples", "sharded_stats.cpp")
+S_EXE = os.path.join(ROOT, "tests", "cpp", "build", "sharded_stats")
+
+
+def build_sharded():
+    os.makedirs(os.path.dirname(S_EXE), exist_ok=True)
+    deps = [S_SRC, os.path.join(ROOT, "host", "arrow_gpu.hpp"), os.path.join(ROOT, "include", "arrow_gpu.h")]
+    if os.path.exists(S_EXE) and all(os.path.getmtime(S_EXE) >= os.path.getmtime(d) for d in deps):
+        return
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-Wall", "-x", "c++", S_SRC, "-o", S_EXE, f"-L{LIBDIR}", "-larrow_gpu_hip",
+           "-Wl,-rpath," + LIBDIR, "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_sharded_stats_example_compiles():
+    build_sharded()
+
+
+@pytest.mark.gpu
+def test_sharded_stats_example_matches_the_sharded_spec():
+    import json
+
+    import numpy as np
+
+    import oracle as O
+
+    build_sharded()
+    rows = 1 << 24  # 256^3 rows per shard: the sharded f32 Sum equals the reference's whole-column tree bit for bit
+    r = subprocess.run([S_EXE, str(rows)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    world = line["world"]
+    assert line["identical_on_all_ranks"] is True and world >= 1
+    shards = [O.synth_f32(rows, 20250418, k * rows, -1.0, 1.0) for k in range(world)]
+    exp = O.sharded_reduce(O.RED_SUM, O.F32, shards)
+    assert np.float32(line["sum"]).view(np.uint32) == np.float32(exp).view(np.uint32), (line["sum"], exp)
+    assert np.float32(line["min"]) == min(s.min() for s in shards) and np.float32(line["max"]) == max(s.max() for s in shards)
+    if world == 1:
+        assert np.float32(exp).view(np.uint32) == np.float32(O.reduce(O.RED_SUM, O.F32, shards[0])).view(np.uint32)
