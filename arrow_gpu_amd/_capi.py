@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libarrow_gpu_hip.so")
+LIB_PATH = os.environ.get("AGPU_LIB") or os.path.join(_HERE, "lib", "libarrow_gpu_hip.so")  # AGPU_LIB: A/B builds in tools/probe
 
 # status codes
 OK, ERR_UNSUPPORTED, ERR_SHAPE, ERR_HIP, ERR_ARG, ERR_NO_DEVICE = range(6)

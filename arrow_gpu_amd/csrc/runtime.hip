@@ -30,11 +30,11 @@ void agpu_set_error(const char* fmt, ...) {
 static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
     /*stream_grid*/ {0}, /*stream_bpc*/ {0}, /*stream_unroll*/ {1}, /*stream_nt*/ {1}, /*cmp_variant*/ {0}, /*reduce_grid*/ {0},
     /*table_tiles*/ {4},  // profiles/r01_sweep_table_tiles.json: sin_u8 5.74 → 6.02, sin_u16 5.85 → 6.16 TB/s vs 1 tile per block
-    /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}};
+    /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}};
 static std::atomic<int64_t> g_mem_pool{1};  // 1 = recycle device blocks and idle streams (default), 0 = hipMalloc/hipFree every time
 static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "stream_bpc", "stream_unroll", "stream_nt",
                                                          "cmp_variant", "reduce_grid", "table_tiles", "gather_bucket",
-                                                         "h2d_mode", "h2d_threads"};
+                                                         "h2d_mode", "h2d_threads", "gather_region_bits"};
 
 agpu_tuning agpu_tuning_defaults() {
   agpu_tuning t;

@@ -181,6 +181,423 @@ __global__ __launch_bounds__(AGPU_BLOCK) void index_max_kernel(const uint32_t* i
   if ((threadIdx.x & (AGPU_WAVE - 1)) == 0 && m) atomicMax(out, m);
 }
 
+// ---------------------------------------------------------------- bucketed take / put (the locality lever)
+// A uniformly random 4-byte gather pulls one 128-byte line per row (131.5 B/row measured, profiles/r01_gather_sweep.json)
+// and a random 4-byte scatter one 32-byte partial-sector read-modify-write per row: both are bound by the NUMBER of
+// random HBM transactions (52 G rows/s take, 15 G rows/s put at 2^28 rows), not by bytes.  The bucketed form turns every
+// random access into an L2 hit by moving the indices to the data instead of the data to the indices:
+//   H  histogram of source buckets (bucket = index >> R, a 2^R-element region of at most 1 MiB) and, for put, of
+//      destination buckets — one streaming pass over the index column(s);
+//   P  partition: pairs (src index, destination) written to their source bucket's range (LDS ranks inside a 16 Ki-row
+//      tile, one global atomic per non-empty (tile, bucket));
+//   G  gather + re-partition: blocks walk the pair list IN BUCKET ORDER, each XCD a contiguous eighth of it, so at any
+//      moment an XCD's L2 serves one or two 1 MiB source regions; the fetched value is written with its destination to
+//      the DESTINATION bucket's range;
+//   F  final store: the same walk over destination buckets — every 4-byte store lands in a region the XCD's L2 is busy
+//      assembling, and leaves for HBM as full lines.
+// Streaming traffic ≈ 52 B/row instead of 132–160 B/row of random transactions.  Two 8 B/row temporaries come from
+// the pool.  Out-of-range indices keep the robust-access outcome: take reads 0, put drops the row, the sticky flag is set.
+#ifndef BKT_T
+#define BKT_T 1024     // threads per block
+#endif
+#define BKT_MAX (4 * BKT_T)  // keys per tile sort = buckets per side (every thread owns 4 counters of the scan)
+#define BKT_E 16       // rows per thread → 16 Ki-row tiles (128 KiB of LDS per workgroup)
+#define BKT_TILE (BKT_T * BKT_E)
+#define BKT_INVALID 0xFFFFFFFFu
+
+struct BktCtl {  // device-side control block
+  uint32_t hist_s[BKT_MAX + 1];  // +1: take's out-of-range rows (value 0 at the end)
+  uint32_t hist_d[BKT_MAX + 1];
+  uint32_t cur_s[BKT_MAX + 1];
+  uint32_t cur_d[BKT_MAX + 1];
+  uint32_t total;                // rows that reach the gather (take: n; put: rows with both indices in range)
+  uint32_t pad[3];
+};
+
+// take: di == nullptr (destination = the row number itself)
+__global__ __launch_bounds__(BKT_T) void bkt_hist_kernel(const uint32_t* si, const uint32_t* di, uint64_t n, uint64_t n_src,
+                                                        uint64_t n_dst, int rs, int rd, uint32_t bs, uint32_t bd,
+                                                        BktCtl* ctl, uint32_t* flags) {
+  __shared__ uint32_t ls[BKT_MAX + 1], ld[BKT_MAX + 1];
+  for (uint32_t b = threadIdx.x; b <= BKT_MAX; b += BKT_T) ls[b] = ld[b] = 0;
+  __syncthreads();
+  bool bad = false;
+  auto count = [&](uint32_t s, uint32_t d) {
+    if (di) {
+      if (s < n_src && d < n_dst) {
+        atomicAdd(&ls[s >> rs], 1u);
+        atomicAdd(&ld[d >> rd], 1u);
+      } else {
+        bad = true;
+      }
+    } else if (s < n_src) {
+      atomicAdd(&ls[s >> rs], 1u);
+    } else {
+      atomicAdd(&ls[bs], 1u);
+      bad = true;
+    }
+  };
+  const uint64_t tid = (uint64_t)blockIdx.x * BKT_T + threadIdx.x, stride = (uint64_t)gridDim.x * BKT_T;
+  const uint64_t npacks = n / 4;
+  for (uint64_t pk = tid; pk < npacks; pk += stride) {
+    const u32x4 s = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si) + pk);
+    u32x4 d = {0, 0, 0, 0};
+    if (di) d = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di) + pk);
+    count(s.x, d.x); count(s.y, d.y); count(s.z, d.z); count(s.w, d.w);
+  }
+  for (uint64_t i = npacks * 4 + tid; i < n; i += stride) count(si[i], di ? di[i] : 0u);
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T)
+    if (ls[b]) atomicAdd(&ctl->hist_s[b], ls[b]);
+  if (di)
+    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T)
+      if (ld[b]) atomicAdd(&ctl->hist_d[b], ld[b]);
+  if (bad) *reinterpret_cast<volatile uint32_t*>(flags) = AGPU_FLAG_INDEX_RANGE;
+}
+
+// exclusive scans → range start of every bucket; one workgroup
+__global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t bs, uint32_t bd, int rd, int is_put) {
+  __shared__ uint32_t sh[BKT_MAX + 2];
+  for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T) sh[b] = ctl->hist_s[b];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t b = 0; b <= bs; b++) {
+      const uint32_t c = sh[b];
+      sh[b] = acc;
+      acc += c;
+    }
+    ctl->total = acc;
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T) ctl->cur_s[b] = sh[b];
+  __syncthreads();
+  if (is_put) {
+    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) sh[b] = ctl->hist_d[b];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t acc = 0;
+      for (uint32_t b = 0; b < bd; b++) {
+        const uint32_t c = sh[b];
+        sh[b] = acc;
+        acc += c;
+      }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) ctl->cur_d[b] = sh[b];
+  } else {  // take: the destinations are 0..n-1, every destination bucket is full — its range is its own region
+    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) ctl->cur_d[b] = b << rd;
+  }
+}
+
+// Tile-local counting sort shared by P, G and F: every thread holds BKT_E rows {payload a, payload b, key}; rows with
+// key == BKT_INVALID are dropped.  The tile's pairs end up in LDS ordered by key (`sorted`), `lcnt[k]` holds the
+// EXCLUSIVE start of key k inside the tile and `*tile_rows` the number of kept rows — so the caller's copy-out loop lets
+// consecutive lanes write consecutive pairs: a bucket's rows leave as one contiguous run (a handful of memory requests
+// per wave store instead of 64).  Scattered 4–8-byte accesses retire at ≈100 G requests/s chip-wide even when every
+// one of them hits L2, which is what bounded the first version of these kernels (profiles/r02_gather_passes.json).
+struct BktRow {
+  uint32_t a, b, key;
+};
+__device__ __forceinline__ void bkt_tile_sort(BktRow (&row)[BKT_E], uint32_t nkeys, uint32_t* lcnt, u32x2* sorted,
+                                              uint32_t* wave_tot, uint32_t* tile_rows) {
+  // nkeys ≤ BKT_MAX = 4 · BKT_T: thread t owns counters 4t .. 4t+3
+  for (uint32_t k = threadIdx.x; k < BKT_MAX; k += BKT_T) lcnt[k] = 0;
+  __syncthreads();
+  uint32_t rank[BKT_E];
+#pragma unroll
+  for (int e = 0; e < BKT_E; e++) rank[e] = row[e].key != BKT_INVALID ? atomicAdd(&lcnt[row[e].key], 1u) : 0u;
+  __syncthreads();
+  // exclusive scan of the counters
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  uint32_t c[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    c[k] = lcnt[threadIdx.x * 4 + k];
+    sum += c[k];
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < AGPU_WAVE; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+    if (lane >= (uint32_t)off) incl += o;
+  }
+  if (lane == AGPU_WAVE - 1) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
+  uint32_t run = base + incl - sum;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    lcnt[threadIdx.x * 4 + k] = run;
+    run += c[k];
+  }
+  if (threadIdx.x == BKT_T - 1) *tile_rows = run;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < BKT_E; e++)
+    if (row[e].key != BKT_INVALID) {
+      u32x2 v = {row[e].a, row[e].b};
+      sorted[lcnt[row[e].key] + rank[e]] = v;
+    }
+  __syncthreads();
+  (void)nkeys;
+}
+
+// copy the sorted tile out: key k's rows go to out_pairs[gstart[k] ...], gstart reserved with ONE global atomic per
+// non-empty (tile, key).  On entry lcnt = exclusive starts; on exit lcnt[k] = gstart[k] − start[k] (wrapping).
+template <typename KeyOf>
+__device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, const u32x2* sorted, uint32_t tile_rows,
+                                             uint32_t* cursors, u32x2* out_pairs, KeyOf key_of) {
+  uint32_t st[4], cnt[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) st[k] = lcnt[threadIdx.x * 4 + k];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t kk = threadIdx.x * 4 + k;
+    const uint32_t nxt = k < 3 ? st[k + 1] : (kk + 1 < BKT_MAX ? lcnt[kk + 1] : tile_rows);
+    cnt[k] = nxt - st[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t kk = threadIdx.x * 4 + k;
+    if (kk < nkeys && cnt[k]) lcnt[kk] = atomicAdd(&cursors[kk], cnt[k]) - st[k];
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < tile_rows; j += BKT_T) {
+    const u32x2 v = sorted[j];
+    out_pairs[(uint64_t)(uint32_t)(lcnt[key_of(v)] + j)] = v;
+  }
+}
+
+#define BKT_LDS_DECL                                                   \
+  __shared__ u32x2 sorted[BKT_TILE];                                   \
+  __shared__ uint32_t lcnt[BKT_MAX];                                   \
+  __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];                     \
+  __shared__ uint32_t tile_rows
+
+// P: rows in natural order → pairs {source index, destination} in source-bucket order (take's out-of-range rows in the
+// extra bucket `bs`: they still produce an output, the value 0)
+__global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si, const uint32_t* di, uint64_t n,
+                                                             uint64_t n_src, uint64_t n_dst, int rs, uint32_t bs,
+                                                             BktCtl* ctl, u32x2* pairs) {
+  BKT_LDS_DECL;
+  const uint64_t base = (uint64_t)blockIdx.x * BKT_TILE;
+  BktRow row[BKT_E];
+#pragma unroll
+  for (int q = 0; q < BKT_E / 4; q++) {
+    const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+    uint32_t s[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
+    if (i0 + 4 <= n) {
+      const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
+      s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w;
+      if (di) {
+        const u32x4 u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + i0));
+        d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w;
+      }
+    } else {
+      for (int k = 0; k < 4; k++)
+        if (i0 + k < n) {
+          s[k] = si[i0 + k];
+          if (di) d[k] = di[i0 + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      BktRow& r = row[q * 4 + k];
+      const uint64_t i = i0 + k;
+      r.a = s[k];
+      r.b = di ? d[k] : (uint32_t)i;
+      if (i >= n) r.key = BKT_INVALID;
+      else if (di) r.key = (s[k] < n_src && d[k] < n_dst) ? (s[k] >> rs) : BKT_INVALID;
+      else r.key = s[k] < n_src ? (s[k] >> rs) : bs;
+    }
+  }
+  bkt_tile_sort(row, bs + 1, lcnt, sorted, wave_tot, &tile_rows);
+  const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
+  bkt_copy_out(bs + 1, lcnt, sorted, tile_rows, ctl->cur_s, pairs,
+               [=](const u32x2& v) { return v.x < n_src32 ? (v.x >> rs) : bs; });
+}
+
+// XCD-contiguous walk: workgroups are dealt round-robin to the 8 XCDs, so workgroup j takes tile (j % 8) · per + j / 8 —
+// each XCD streams one contiguous eighth of the bucket-ordered list and its L2 holds the one or two regions in flight
+__device__ __forceinline__ bool bkt_tile_of_block(uint32_t ntiles, uint64_t* tile) {
+  const uint32_t per = (ntiles + 7) / 8;
+  const uint64_t t = (uint64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  *tile = t;
+  return (blockIdx.x / 8) < per && t < ntiles;
+}
+
+__device__ __forceinline__ void bkt_load_tile(const u32x2* pairs_in, uint64_t base, uint64_t total, uint32_t (&pa)[BKT_E],
+                                              uint32_t (&pb)[BKT_E], bool (&live)[BKT_E]) {
+#pragma unroll
+  for (int q = 0; q < BKT_E / 2; q++) {
+    const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 2;
+    u32x4 t = {0, 0, 0, 0};
+    if (i0 + 2 <= total) t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pairs_in + i0));
+    else if (i0 < total) {
+      const u32x2 one = pairs_in[i0];
+      t.x = one.x; t.y = one.y;
+    }
+    pa[q * 2] = t.x; pb[q * 2] = t.y; live[q * 2] = i0 < total;
+    pa[q * 2 + 1] = t.z; pb[q * 2 + 1] = t.w; live[q * 2 + 1] = i0 + 1 < total;
+  }
+}
+
+// G: pairs in source-bucket order → {destination, value} in destination-bucket order
+template <int W>
+__global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf<W>::type* values, uint64_t n_src,
+                                                          const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles,
+                                                          int src_line_shift, BktCtl* ctl, u32x2* pairs_out) {
+  BKT_LDS_DECL;
+  uint64_t tile;
+  if (!bkt_tile_of_block(ntiles, &tile)) return;
+  const uint64_t total = ctl->total, base = tile * BKT_TILE;
+  if (base >= total) return;
+  uint32_t pa[BKT_E], pb[BKT_E];
+  bool live[BKT_E];
+  bkt_load_tile(pairs_in, base, total, pa, pb, live);
+  BktRow row[BKT_E];
+  // order the tile by SOURCE line first: the rows of a tile fall into one or two source regions at a density of a few
+  // rows per 128-byte line, and only neighbouring lanes of one load instruction are merged into one L2 request
+#pragma unroll
+  for (int e = 0; e < BKT_E; e++) {
+    row[e].a = pa[e];
+    row[e].b = pb[e];
+    row[e].key = live[e] ? ((pa[e] >> src_line_shift) & (BKT_MAX - 1)) : BKT_INVALID;
+  }
+  bkt_tile_sort(row, BKT_MAX, lcnt, sorted, wave_tot, &tile_rows);
+  const uint32_t rows_here = tile_rows;
+#pragma unroll
+  for (int e = 0; e < BKT_E; e++) {
+    const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
+    const bool ok = j < rows_here;
+    const u32x2 v = ok ? sorted[j] : u32x2{0u, 0u};
+    row[e].a = v.y;                                                     // destination
+    row[e].b = (ok && v.x < n_src) ? (uint32_t)values[v.x] : 0u;        // the L2-resident gather
+    row[e].key = ok ? (v.y >> rd) : BKT_INVALID;
+  }
+  __syncthreads();  // everyone has read `sorted` before the second sort overwrites it
+  bkt_tile_sort(row, bd, lcnt, sorted, wave_tot, &tile_rows);
+  bkt_copy_out(bd, lcnt, sorted, tile_rows, ctl->cur_d, pairs_out, [=](const u32x2& v) { return v.x >> rd; });
+}
+
+// F: {destination, value} in destination-bucket order → dst[destination] = value.  The tile is first ordered by
+// destination LINE (128 bytes) in LDS, so lanes that share a line sit next to each other and the store instruction's
+// coalescer merges them: the smaller the destination region, the more rows per line in one tile.
+template <int W>
+__global__ __launch_bounds__(BKT_T) void bkt_store_kernel(const u32x2* pairs, uint32_t ntiles, const BktCtl* ctl, int line_shift,
+                                                         typename ElemOf<W>::type* dst) {
+  typedef typename ElemOf<W>::type E;
+  BKT_LDS_DECL;
+  uint64_t tile;
+  if (!bkt_tile_of_block(ntiles, &tile)) return;
+  const uint64_t total = ctl->total, base = tile * BKT_TILE;
+  if (base >= total) return;
+  uint32_t pa[BKT_E], pb[BKT_E];
+  bool live[BKT_E];
+  bkt_load_tile(pairs, base, total, pa, pb, live);
+  BktRow row[BKT_E];
+#pragma unroll
+  for (int e = 0; e < BKT_E; e++) {
+    row[e].a = pa[e];
+    row[e].b = pb[e];
+    row[e].key = live[e] ? ((pa[e] >> line_shift) & (BKT_MAX - 1)) : BKT_INVALID;
+  }
+  bkt_tile_sort(row, BKT_MAX, lcnt, sorted, wave_tot, &tile_rows);
+  for (uint32_t j = threadIdx.x; j < tile_rows; j += BKT_T) {
+    const u32x2 v = sorted[j];
+    dst[v.x] = (E)v.y;
+  }
+}
+
+// region = 2^r elements = 512 KiB on both sides: an XCD has 32 tiles (2^19 rows) in flight, i.e. two or three regions,
+// beside the pair streams in its 4 MiB L2.  Measured at 2^28 rows (tools/probe/bucket_sweep.py --region-bits): 512 KiB
+// regions 4.8 / 5.5 ms (take / put), 1 MiB 5.2 / 5.8, 2 MiB 5.5 / 5.8, 4 MiB 5.8 / 6.4.  "gather_region_bits" overrides.
+static int bkt_region_bits(const agpu_pipeline* p, uint64_t n_elems, int width) {
+  int r = 17 + (width == 2 ? 1 : width == 1 ? 2 : 0);
+  if (p->tune.gather_region_bits > 0) r = (int)p->tune.gather_region_bits;
+  if (r < 10) r = 10;
+  while (((n_elems + ((uint64_t)1 << r) - 1) >> r) > BKT_MAX - 1) r++;
+  return r;
+}
+
+// di == nullptr: take (dst = out, n_dst = n).  Returns AGPU_ERR_UNSUPPORTED when the shape does not qualify.
+static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* si,
+                                   void* dst, uint64_t n_dst, const uint32_t* di, uint64_t n) {
+  if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || n_dst > 0xFFFFFFFFull || !aligned16(si) || (di && !aligned16(di)) ||
+      p->capturing)
+    return AGPU_ERR_UNSUPPORTED;
+  const int rs = bkt_region_bits(p, n_src, width), rd = bkt_region_bits(p, n_dst, width);
+  // F orders a tile by destination line: 128-byte lines, widened until a region's lines fit the BKT_MAX keys
+  int line_shift = width == 4 ? 5 : width == 2 ? 6 : 7;
+  while ((1 << (rd - line_shift)) > BKT_MAX) line_shift++;
+  int src_line_shift = width == 4 ? 5 : width == 2 ? 6 : 7;
+  while ((1 << (rs - src_line_shift)) > BKT_MAX) src_line_shift++;
+  const uint32_t bs = (uint32_t)((n_src + ((uint64_t)1 << rs) - 1) >> rs), bd = (uint32_t)((n_dst + ((uint64_t)1 << rd) - 1) >> rd);
+  agpu_device* dev = p->dev;
+  void *ctl_v = nullptr, *p1 = nullptr, *p2 = nullptr;
+  agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p1);
+  if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p2);
+  if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;  // no room for the 16 B/row of temporaries: the direct kernel needs none
+  if (st == AGPU_OK) {
+    BktCtl* ctl = static_cast<BktCtl*>(ctl_v);
+    const uint32_t ntiles = (uint32_t)((n + BKT_TILE - 1) / BKT_TILE);
+    const uint32_t nblk = (ntiles + 7) / 8 * 8;
+    hipError_t e = hipMemsetAsync(ctl, 0, sizeof(BktCtl), p->stream);
+    if (e != hipSuccess) {
+      agpu_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+      st = AGPU_ERR_HIP;
+    } else {
+      uint64_t hg = (uint64_t)dev->num_cus * 2;
+      if (hg > ntiles) hg = ntiles;
+      hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags);
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0);
+      hipLaunchKernelGGL(bkt_partition_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1));
+#define BKT_GF(W, E)                                                                                                         \
+  case W:                                                                                                                    \
+    hipLaunchKernelGGL((bkt_gather_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const E*>(src), n_src,     \
+                       static_cast<const u32x2*>(p1), rd, bd, ntiles, src_line_shift, ctl, static_cast<u32x2*>(p2));         \
+    hipLaunchKernelGGL((bkt_store_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p2), ntiles,  \
+                       ctl, line_shift, static_cast<E*>(dst));                                                               \
+    break;
+      switch (width) {
+        BKT_GF(4, uint32_t)
+        BKT_GF(2, uint16_t)
+        BKT_GF(1, uint8_t)
+        default: st = AGPU_ERR_UNSUPPORTED; break;
+      }
+#undef BKT_GF
+      if (st == AGPU_OK && hipGetLastError() != hipSuccess) {
+        agpu_set_error("bucketed take/put launch failed");
+        st = AGPU_ERR_HIP;
+      }
+    }
+  }
+  // the pool hands these blocks out again only after the stream has passed the kernels above (runtime.hip markers)
+  if (p2) (void)agpu_free(dev, p2);
+  if (p1) (void)agpu_free(dev, p1);
+  if (ctl_v) (void)agpu_free(dev, ctl_v);
+  return st;
+}
+
+// tuning "gather_bucket": 0 = auto, 1 = always direct, 2 = bucketed whenever the shape qualifies.
+// Auto, from one-process A/B sweeps on MI355X (tools/probe/bucket_sweep.py → profiles/r02_gather_sweep.json, uniformly
+// random 4-byte rows): PUT goes bucketed from 2^25 rows when neither side is sparser than 1 row in 16 elements —
+// 1.4–1.8× at 2^26 rows, 2.0–3.2× at 2^28 (15 → 49 G rows/s with both sides random over 1 GiB); below that the five
+// launches and the 16 B/row of temporaries cost more than the random transactions they save.  TAKE stays direct: a
+// random gather already runs at the 128-byte-line fetch roof (48–52 G rows/s) and the bucketed form, three scattered
+// passes of which the L2 accepts ≈100–200 G requests/s each, reaches 1.16× at best (2^28 rows from 2^28) and loses below.
+static bool want_bucketed(const agpu_pipeline* p, int width, uint64_t n, uint64_t n_src, uint64_t n_dst, bool is_put) {
+  const int64_t mode = p->tune.gather_bucket;
+  if (mode == 1) return false;
+  if (mode == 2) return n >= BKT_TILE;
+  (void)width;
+  return is_put && n >= ((uint64_t)1 << 25) && n_src / 16 <= n && n_dst / 16 <= n;
+}
+
 // nontemporal index / output streams: neutral for HBM-resident sources (A/B on one box: 638 vs 637 GB/s), +10 % when the
 // source fits in L2 (they stop evicting it)
 static constexpr bool swz_nt() { return true; }
@@ -196,6 +613,10 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   if (n_idx == 0) return AGPU_OK;
   AGPU_REQUIRE(values && idx && out, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
+  if ((width == 1 || width == 2 || width == 4) && n_values != UINT64_MAX && want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
+    const agpu_status bs = launch_bucketed(p, width, values, n_values, idx, out, n_idx, nullptr, n_idx);
+    if (bs != AGPU_ERR_UNSUPPORTED) return bs;
+  }
   const int vec_ok = aligned16(idx) && aligned16(out);
   const int grid = gs_grid(p, n_idx / (16 / (width > 0 ? width : 1)) + 1);
   switch (width) {
@@ -239,6 +660,11 @@ agpu_status agpu_put_bounded(agpu_pipeline* p, int32_t width, const void* src, u
   AGPU_BIND(p);
   if (n == 0) return AGPU_OK;
   AGPU_REQUIRE(src && src_idx && dst && dst_idx, AGPU_ERR_ARG, "null pointer");
+  if ((width == 1 || width == 2 || width == 4) && n_src != UINT64_MAX && n_dst != UINT64_MAX &&
+      want_bucketed(p, width, n, n_src, n_dst, true)) {
+    const agpu_status bs = launch_bucketed(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n);
+    if (bs != AGPU_ERR_UNSUPPORTED) return bs;
+  }
   const int vec_ok = aligned16(src_idx) && aligned16(dst_idx);
   const int grid = gs_grid(p, n / 4 + 1);
 #define AGPU_PUT_CASE(W, E)                                                                                              \

@@ -274,3 +274,120 @@ def test_columns_longer_than_2_pow_32_rows(ctx):
     ea, eb = O.synth_u8(tail, SEED, n - tail), O.synth_u8(tail, SEED + 1, n - tail)
     assert np.array_equal(download(dev, p, o, n - tail, tail), O.binary(O.OP_ADD, O.U8, ea, eb))
     assert np.array_equal(download(dev, p, wide, 4 * (n - tail), 4 * tail).view(np.float32), ea.astype(np.float32))
+
+
+def test_lt_gt_with_validity_fullsize_oracle_windows(ctx):
+    """BASELINE config 3 names eq / lt / gt: lt and gt → bitmap with the fused validity AND at 1e9 rows, 10 % nulls per
+    side, windows bit-exact against the oracle (eq is covered above)."""
+    dev, p = ctx
+    h = p._handle
+    nb = (N + 63) // 64 * 8
+    a, b = dev.create_empty_buffer(4 * N), dev.create_empty_buffer(4 * N)
+    va, vb, ob, ov = (dev.create_empty_buffer(nb) for _ in range(4))
+    cnt = dev.create_empty_buffer(16)
+    capi.call("agpu_synth_i32", h, vp(a), N, SEED + 2, 0, 1024)
+    capi.call("agpu_synth_i32", h, vp(b), N, SEED + 3, 0, 1024)
+    capi.call("agpu_synth_bits", h, vp(va), N, SEED + 4, 0, C.c_double(0.9))
+    capi.call("agpu_synth_bits", h, vp(vb), N, SEED + 5, 0, C.c_double(0.9))
+    counts = {}
+    for op, oop in ((capi.CMP_LT, O.CMP_LT), (capi.CMP_GT, O.CMP_GT)):
+        capi.call("agpu_compare_validity", h, op, capi.I32, vp(a), vp(b), vp(va), vp(vb), vp(ob), vp(ov), N)
+        capi.call("agpu_bitmap_popcount", h, vp(ob), N, vp(cnt))
+        counts[op] = scalar_u64(dev, p, cnt)
+        for start in windows(N):
+            wb = WINDOW // 8
+            ea, eb_ = O.synth_i32(WINDOW, SEED + 2, start, 1024), O.synth_i32(WINDOW, SEED + 3, start, 1024)
+            ev = O.bitmap_binary(O.OP_AND, O.synth_bits(WINDOW, SEED + 4, start, 0.9), O.synth_bits(WINDOW, SEED + 5, start, 0.9), WINDOW)
+            assert np.array_equal(download(dev, p, ob, start // 8, wb), O.compare(oop, O.I32, ea, eb_)[:wb]), (op, start)
+            assert np.array_equal(download(dev, p, ov, start // 8, wb), ev[:wb]), (op, start)
+    capi.call("agpu_compare", h, capi.CMP_EQ, capi.I32, vp(a), vp(b), vp(ob), N)
+    capi.call("agpu_bitmap_popcount", h, vp(ob), N, vp(cnt))
+    assert counts[capi.CMP_LT] + counts[capi.CMP_GT] + scalar_u64(dev, p, cnt) == N  # trichotomy over the whole column
+
+
+def test_sub_mul_div_with_both_validities_fullsize(ctx):
+    """f32 sub / mul / div through the HOST layer at 1e9 rows with a validity bitmap on both sides (10 % nulls each):
+    value windows bit-exact, output validity = AND of the inputs (windows + whole-column null count)."""
+    import arrow_gpu_amd as ag
+
+    dev, p = ctx
+    h = p._handle
+    nb = (N + 63) // 64 * 8
+    da, db = dev.create_empty_buffer(4 * N), dev.create_empty_buffer(4 * N)
+    va, vb = dev.create_empty_buffer(nb), dev.create_empty_buffer(nb)
+    capi.call("agpu_synth_f32", h, vp(da), N, SEED, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_f32", h, vp(db), N, SEED + 1, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_bits", h, vp(va), N, SEED + 4, 0, C.c_double(0.9))
+    capi.call("agpu_synth_bits", h, vp(vb), N, SEED + 5, 0, C.c_double(0.9))
+    p.finish()
+    a = ag.Float32ArrayGPU(da, dev, N, ag.NullBitBufferGpu(va, N, dev))
+    b = ag.Float32ArrayGPU(db, dev, N, ag.NullBitBufferGpu(vb, N, dev))
+    cnt = dev.create_empty_buffer(16)
+    for name, oop in (("sub", O.OP_SUB), ("mul", O.OP_MUL), ("div", O.OP_DIV)):
+        c = getattr(a, name)(b)
+        assert c.len == N and c.null_buffer is not None
+        for start in windows(N):
+            ea = O.synth_f32(WINDOW, SEED, start, -1000.0, 1000.0)
+            eb_ = O.synth_f32(WINDOW, SEED + 1, start, -1000.0, 1000.0)
+            got = download(dev, p, c.data, 4 * start, 4 * WINDOW).view(np.uint32)
+            assert np.array_equal(got, O.binary(oop, O.F32, ea, eb_).view(np.uint32)), (name, start)
+            ev = O.bitmap_binary(O.OP_AND, O.synth_bits(WINDOW, SEED + 4, start, 0.9), O.synth_bits(WINDOW, SEED + 5, start, 0.9), WINDOW)
+            assert np.array_equal(download(dev, p, c.null_buffer.bit_buffer, start // 8, WINDOW // 8), ev[: WINDOW // 8]), (name, start)
+        capi.call("agpu_bitmap_popcount", h, vp(c.null_buffer.bit_buffer), N, vp(cnt))
+        assert abs(scalar_u64(dev, p, cnt) / N - 0.81) < 1e-3
+        del c
+
+
+def test_cos_fullsize_u8_f32_and_cast_then_cos(ctx):
+    """BASELINE config 4 (cast u8→f32 then sin/cos): the cos half at 1e9 rows — fused cos_u8, cos f32 of the cast result
+    (bit-identical to the fused kernel) and f32 cos on a wide-range f32 column, oracle windows ≤ 1 ULP."""
+    dev, p = ctx
+    h = p._handle
+    u = dev.create_empty_buffer(N)
+    f, g = dev.create_empty_buffer(4 * N), dev.create_empty_buffer(4 * N)
+    cs1, cs2, mx = dev.create_empty_buffer(16), dev.create_empty_buffer(16), dev.create_empty_buffer(16)
+    capi.call("agpu_synth_u8", h, vp(u), N, SEED + 6, 0)
+    capi.call("agpu_unary", h, capi.UN_COS, capi.U8, vp(u), vp(g), N)          # fused cos_u8
+    capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u), vp(f), N)              # cast, then cos
+    capi.call("agpu_unary", h, capi.UN_COS, capi.F32, vp(f), vp(f), N)
+    capi.call("agpu_checksum", h, vp(g), 4 * N, vp(cs1))
+    capi.call("agpu_checksum", h, vp(f), 4 * N, vp(cs2))
+    assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
+    for start in windows(N):
+        got = download(dev, p, g, 4 * start, 4 * WINDOW).view(np.float32)
+        exp = O.unary(O.UN_COS, O.U8, O.synth_u8(WINDOW, SEED + 6, start))
+        assert np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64)).max() <= 1
+    capi.call("agpu_unary", h, capi.UN_ABS, capi.F32, vp(g), vp(f), N)
+    capi.call("agpu_reduce", h, capi.RED_MAX, capi.F32, vp(f), None, N, vp(mx))
+    assert dev.retrive_data(mx, 4, pipeline=p).view(np.float32)[0] <= 1.0
+    # f32 cos over [-1000, 1000): argument reduction is exercised, not just the table
+    capi.call("agpu_synth_f32", h, vp(f), N, SEED, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_unary", h, capi.UN_COS, capi.F32, vp(f), vp(g), N)
+    for start in windows(N):
+        got = download(dev, p, g, 4 * start, 4 * WINDOW).view(np.float32)
+        exp = O.unary(O.UN_COS, O.F32, O.synth_f32(WINDOW, SEED, start, -1000.0, 1000.0))
+        assert np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64)).max() <= 1
+
+
+def test_f32_to_small_int_casts_fullsize(ctx):
+    """The reference-absent narrowing casts (f32 → i8 / i16 / u16) at 1e9 rows: windows bit-exact vs the oracle and the
+    round trip i16 → f32 → i16 is the identity."""
+    dev, p = ctx
+    h = p._handle
+    f = dev.create_empty_buffer(4 * N)
+    o = dev.create_empty_buffer(2 * N)
+    capi.call("agpu_synth_f32", h, vp(f), N, SEED, 0, C.c_float(-70000.0), C.c_float(70000.0))
+    for to, oto, npd in ((capi.I8, O.I8, np.int8), (capi.I16, O.I16, np.int16), (capi.U16, O.U16, np.uint16)):
+        capi.call("agpu_cast", h, capi.F32, to, vp(f), vp(o), N)
+        w = np.dtype(npd).itemsize
+        for start in windows(N):
+            got = download(dev, p, o, w * start, w * WINDOW).view(npd)
+            exp = O.cast(O.F32, oto, O.synth_f32(WINDOW, SEED, start, -70000.0, 70000.0))
+            assert np.array_equal(got, exp), (to, start)
+    cs1, cs2 = dev.create_empty_buffer(16), dev.create_empty_buffer(16)
+    back = dev.create_empty_buffer(2 * N)
+    capi.call("agpu_cast", h, capi.I16, capi.F32, vp(o), vp(f), N)   # o holds u16 bits; reinterpret as i16
+    capi.call("agpu_cast", h, capi.F32, capi.I16, vp(f), vp(back), N)
+    capi.call("agpu_checksum", h, vp(o), 2 * N, vp(cs1))
+    capi.call("agpu_checksum", h, vp(back), 2 * N, vp(cs2))
+    assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
