@@ -141,6 +141,31 @@ _RESTYPES = {
 _NOT_STATUS = set(_RESTYPES)
 
 
+# ---- Arrow C Data Interface structs (include/arrow_gpu.h declares the same two, as the Arrow specification does)
+class ArrowSchemaStruct(C.Structure):
+    pass
+
+
+class ArrowArrayStruct(C.Structure):
+    pass
+
+
+ArrowSchemaStruct._fields_ = [
+    ("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64), ("n_children", C.c_int64),
+    ("children", C.POINTER(C.POINTER(ArrowSchemaStruct))), ("dictionary", C.POINTER(ArrowSchemaStruct)),
+    ("release", C.CFUNCTYPE(None, C.POINTER(ArrowSchemaStruct))), ("private_data", C.c_void_p)]
+ArrowArrayStruct._fields_ = [
+    ("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64), ("n_children", C.c_int64),
+    ("buffers", C.POINTER(C.c_void_p)), ("children", C.POINTER(C.POINTER(ArrowArrayStruct))),
+    ("dictionary", C.POINTER(ArrowArrayStruct)), ("release", C.CFUNCTYPE(None, C.POINTER(ArrowArrayStruct))),
+    ("private_data", C.c_void_p)]
+
+
+class ArrowColumnStruct(C.Structure):  # agpu_arrow_column
+    _fields_ = [("dtype", C.c_int32), ("length", C.c_uint64), ("null_count", C.c_int64), ("values", C.c_void_p),
+                ("validity", C.c_void_p), ("values_bytes", C.c_uint64), ("validity_bytes", C.c_uint64)]
+
+
 class ArrowErrorGPU(RuntimeError):
     """Mirror of `enum ArrowErrorGPU` (crates/array/src/lib.rs:11-14) plus device/runtime failures."""
 

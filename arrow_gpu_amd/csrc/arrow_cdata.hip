@@ -4,8 +4,11 @@
 // (wgpu create_buffer_init: a mapped-at-creation copy) and `raw_values` → `retrive_data` (copy to a MAP_READ buffer,
 // map, memcpy into a Vec) [ref: crates/array/src/array/primitive_array_gpu.rs:22-104, gpu_device.rs:171-181,232-265].
 // Here a producer's ArrowArray/ArrowSchema pair is consumed as it is: values from `offset` on, bitmaps re-aligned on
-// the GPU, and pageable memory crosses the link through page-locked chunks that several host threads fill while the
-// previous chunks are already in flight.
+// the GPU.  Host↔HBM movement has three selectable engines (pageable hipMemcpy — the default, at link rate on this
+// platform —, threaded page-locked staging, hipHostRegister in place); overlap of transfers with compute is the host
+// layer's job (two pipelines + agpu_pipeline_wait_pipeline: arrow_gpu_amd/interop.py map_chunks).
+#include <sys/mman.h>
+
 #include <thread>
 
 #include "common.hpp"
@@ -118,8 +121,13 @@ static agpu_status staged_copy_threads(agpu_pipeline* p, char* dev_ptr, char* ho
 
 static agpu_status staged_copy_impl(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device) {
   if (!bytes) return AGPU_OK;
+  // auto = mode 1: measured on the MI355X box (tools/probe/h2d_sweep.py → profiles/r02_h2d_sweep.json, 1 GiB, EPYC 9575F host):
+  // pageable hipMemcpy 56.3 / 56.1 GB/s (H2D / D2H) — the runtime already moves pageable memory at the rate of the link
+  // (page-locked reference: 57 GB/s) — hipHostRegister in place 57.6 / 57.0, the threaded staging below 45–46 at 2–32
+  // threads (29 with one).  The staging engine stays selectable (tuning "h2d_mode" = 2) for hosts whose runtime stages
+  // pageable copies slowly; it is not the default anywhere.
   int64_t mode = p->tune.h2d_mode;
-  if (mode <= 0 || mode > 3) mode = bytes >= ((size_t)1 << 20) ? 2 : 1;
+  if (mode <= 0 || mode > 3) mode = 1;
   if (mode == 2) return staged_copy_threads(p, static_cast<char*>(dev_ptr), static_cast<char*>(host_ptr), bytes, to_device);
   if (mode == 3) {
     hipError_t e = hipHostRegister(host_ptr, bytes, hipHostRegisterDefault);
@@ -204,6 +212,32 @@ static agpu_status import_bitmap(agpu_pipeline* p, const uint8_t* host_bits, uin
   *out_dev = out;
   *out_bytes = out_b;
   return AGPU_OK;
+}
+
+// Fresh host memory for an exported column.  A D2H copy into never-touched pages takes one page fault per 4 KiB inside
+// the copy (measured: 7 GB/s for a 1 GiB column against 56 GB/s into touched memory), so large buffers are 2 MiB-aligned,
+// offered to transparent huge pages and first-touched by a few threads in parallel before the DMA starts.
+static void* alloc_export_buffer(size_t bytes) {
+  const size_t big = (size_t)4 << 20;
+  const size_t align = bytes >= big ? ((size_t)2 << 20) : 64;
+  size_t padded = (bytes + align - 1) / align * align;
+  if (!padded) padded = align;
+  void* ptr = nullptr;
+  if (posix_memalign(&ptr, align, padded) != 0) return nullptr;
+  if (bytes >= big) {
+    (void)madvise(ptr, padded, MADV_HUGEPAGE);
+    const int T = 8;
+    const size_t per = (padded / T + 4095) & ~(size_t)4095;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+      th.emplace_back([=] {
+        char* b = static_cast<char*>(ptr);
+        const size_t lo = (size_t)t * per, hi = lo + per < padded ? lo + per : padded;
+        for (size_t off = lo; off < hi; off += 4096) b[off] = 0;
+      });
+    for (auto& x : th) x.join();
+  }
+  return ptr;
 }
 
 struct ExportPrivate {
@@ -297,9 +331,9 @@ agpu_status agpu_export_arrow(agpu_pipeline* p, const agpu_arrow_column* column,
   const size_t vbytes = column->dtype == AGPU_BOOL ? agpu_bitmap_bytes(n) : (size_t)n * agpu_dtype_size(column->dtype);
   const size_t nbytes = column->validity ? agpu_bitmap_bytes(n) : 0;
   ExportPrivate* pd = new ExportPrivate{nullptr, nullptr, {nullptr, nullptr}};
-  // 64-byte aligned, padded to 64 B as the Arrow spec recommends
-  if (posix_memalign(&pd->values, 64, ((vbytes + 63) / 64 * 64) ? (vbytes + 63) / 64 * 64 : 64) != 0) pd->values = nullptr;
-  if (nbytes && posix_memalign(&pd->validity, 64, (nbytes + 63) / 64 * 64) != 0) pd->validity = nullptr;
+  // 64-byte aligned and padded, as the Arrow specification recommends
+  pd->values = alloc_export_buffer(vbytes);
+  if (nbytes) pd->validity = alloc_export_buffer(nbytes);
   agpu_status st = (!pd->values || (nbytes && !pd->validity)) ? AGPU_ERR_ARG : AGPU_OK;
   if (st != AGPU_OK) agpu_set_error("host allocation of %zu bytes failed", vbytes + nbytes);
   if (st == AGPU_OK) st = staged_copy_impl(p, column->values, pd->values, vbytes, false);

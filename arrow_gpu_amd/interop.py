@@ -67,51 +67,44 @@ class PinnedStaging:
             self.ptr = None
 
 
-def _upload_raw(device: GpuDevice, pipeline: ArrowComputePipeline, address: int, nbytes: int, alloc_bytes: int) -> DeviceBuffer:
-    buf = device.create_empty_buffer(max(alloc_bytes, 16))
-    if nbytes:
-        capi.call("agpu_upload", pipeline._handle, C.c_void_p(buf.ptr), C.c_void_p(address), nbytes)
-    return buf
+def _release(c_struct):
+    if c_struct.release:
+        c_struct.release(C.byref(c_struct))
 
 
-def _import_bitmap(device, pipeline, pa_buffer, bit_offset: int, n_bits: int) -> DeviceBuffer:
-    """Arrow bitmap (byte-granular, arbitrary bit offset) → word-aligned device bitmap with zero padding."""
-    first_byte = bit_offset // 8
-    last_byte = (bit_offset + n_bits + 7) // 8
-    span = last_byte - first_byte
-    # stage the touched bytes at an 8-byte aligned device address, padded to whole words
-    staged = device.create_empty_buffer(bitmap_bytes(span * 8) + 8, zero_fill=True)
-    if span:
-        capi.call("agpu_upload", pipeline._handle, C.c_void_p(staged.ptr), C.c_void_p(pa_buffer.address + first_byte), span)
-    out = device.create_empty_buffer(max(bitmap_bytes(n_bits), 8))
-    capi.call("agpu_bitmap_copy_bits", pipeline._handle, C.c_void_p(staged.ptr), bit_offset % 8, C.c_void_p(out.ptr), n_bits)
-    pipeline.keep(staged, out)
-    return out
+def _class_of_dtype():
+    return {capi.F32: Float32ArrayGPU, capi.U32: UInt32ArrayGPU, capi.U16: UInt16ArrayGPU, capi.U8: UInt8ArrayGPU,
+            capi.I32: Int32ArrayGPU, capi.I16: Int16ArrayGPU, capi.I8: Int8ArrayGPU, capi.DATE32: Date32ArrayGPU,
+            capi.BOOL: BooleanArrayGPU}
 
 
 def from_arrow(obj, device: GpuDevice, pipeline: ArrowComputePipeline | None = None) -> ArrowArrayGPU:
-    """pyarrow.Array (or any `__arrow_c_array__` producer) → GPU array of the matching type.  Sliced arrays and
-    arrays with or without nulls are handled; a ChunkedArray must go through `from_arrow_chunked`."""
+    """pyarrow.Array (or any `__arrow_c_array__` producer) → GPU array of the matching type, through the C ABI's
+    Arrow C Data Interface entry point: the producer exports its `ArrowArray` / `ArrowSchema` pair, `agpu_import_arrow`
+    consumes the buffers as they are — values from `offset` on, bitmaps re-aligned on the GPU, arrays ≥ 1 MiB through
+    the threaded page-locked staging — and the pair is released.  A ChunkedArray goes through `from_arrow_chunked`."""
     pa = _pa()
     arr = obj if isinstance(obj, pa.Array) else pa.array(obj)
-    cls = _type_map().get(arr.type)
-    if cls is None:
+    if arr.type not in _type_map():
         raise capi.OperationNotSupported(f"Arrow type {arr.type} has no GPU array type (f32, u/i 8/16/32, date32, bool)")
     own = pipeline is None
     p = pipeline or ArrowComputePipeline(device, "from_arrow")
-    n, off = len(arr), arr.offset
-    validity_buf, data_buf = arr.buffers()[0], arr.buffers()[1]
+    c_arr, c_sch, col = capi.ArrowArrayStruct(), capi.ArrowSchemaStruct(), capi.ArrowColumnStruct()
+    arr._export_to_c(C.addressof(c_arr), C.addressof(c_sch))
+    try:
+        capi.call("agpu_import_arrow", p._handle, C.byref(c_arr), C.byref(c_sch), C.byref(col))
+    finally:
+        _release(c_arr)
+        _release(c_sch)
+    n = int(col.length)
+    data = DeviceBuffer(device, col.values, int(col.values_bytes))
     nulls = None
-    if arr.null_count and validity_buf is not None:
-        nulls = NullBitBufferGpu(_import_bitmap(device, p, validity_buf, off, n), n, device)
-    if cls is BooleanArrayGPU:
-        data = _import_bitmap(device, p, data_buf, off, n) if n else device.create_empty_buffer(8)
-        out = BooleanArrayGPU(data, device, n, nulls)
-    else:
-        w = cls.ITEM_SIZE
-        data = _upload_raw(device, p, data_buf.address + off * w if n else 0, n * w, n * w)
-        out = cls(data, device, n, nulls)
+    if col.validity:
+        nulls = NullBitBufferGpu(DeviceBuffer(device, col.validity, int(col.validity_bytes)), n, device)
+    cls = _type_map()[arr.type]  # date32 and i32 share storage: the Arrow type decides
+    out = cls(data, device, n, nulls)
     if own:
+        p.finish()
         p.sync()
     return out
 
@@ -124,23 +117,25 @@ def from_arrow_chunked(chunked, device: GpuDevice):
     return out
 
 
-def to_arrow(gpu_array: ArrowArrayGPU):
-    """GPU array → pyarrow.Array built from the downloaded buffers (validity bitmap passed through as is)."""
+def to_arrow(gpu_array: ArrowArrayGPU, pipeline: ArrowComputePipeline | None = None):
+    """GPU array → pyarrow.Array: `agpu_export_arrow` downloads values and validity into freshly allocated host buffers
+    behind an `ArrowArray` / `ArrowSchema` pair whose release callbacks free them; pyarrow imports (and later releases)
+    the pair — no element is touched in Python."""
     pa = _pa()
-    inv = {v: k for k, v in _type_map().items()}
-    typ = inv.get(type(gpu_array))
-    if typ is None:
-        raise capi.OperationNotSupported(f"{type(gpu_array).__name__} cannot be exported")
     dev = gpu_array.gpu_device
-    n = gpu_array.len
-    validity = None
+    codes = {v: k for k, v in _class_of_dtype().items()}
+    if type(gpu_array) not in codes:
+        raise capi.OperationNotSupported(f"{type(gpu_array).__name__} cannot be exported")
+    col = capi.ArrowColumnStruct()
+    col.dtype, col.length, col.null_count = codes[type(gpu_array)], gpu_array.len, -1
+    col.values, col.values_bytes = gpu_array.data.ptr, gpu_array.data.nbytes
     if gpu_array.null_buffer is not None:
-        validity = pa.py_buffer(dev.retrive_data(gpu_array.null_buffer.bit_buffer, (n + 7) // 8).tobytes())
-    if isinstance(gpu_array, BooleanArrayGPU):
-        data = pa.py_buffer(dev.retrive_data(gpu_array.data, (n + 7) // 8).tobytes())
-    else:
-        data = pa.py_buffer(dev.retrive_data(gpu_array.data, n * gpu_array.ITEM_SIZE).tobytes())
-    return pa.Array.from_buffers(typ, n, [validity, data])
+        col.validity, col.validity_bytes = gpu_array.null_buffer.bit_buffer.ptr, gpu_array.null_buffer.bit_buffer.nbytes
+    p = pipeline or ArrowComputePipeline(dev, "to_arrow")
+    dev.sync()  # other pipelines may still be writing the array (the reference's read-back polls the whole queue)
+    c_arr, c_sch = capi.ArrowArrayStruct(), capi.ArrowSchemaStruct()
+    capi.call("agpu_export_arrow", p._handle, C.byref(col), C.byref(c_arr), C.byref(c_sch))
+    return pa.Array._import_from_c(C.addressof(c_arr), C.addressof(c_sch))
 
 
 def _arrow_c_array(self, requested_schema=None):
@@ -152,3 +147,64 @@ for _cls in (PrimitiveArrayGpu, BooleanArrayGPU):
     _cls.__arrow_c_array__ = _arrow_c_array
     _cls.to_arrow = to_arrow
 ArrowArrayGPU.from_arrow = staticmethod(from_arrow)
+
+
+def map_chunks(device: GpuDevice, inputs, out: np.ndarray, chunk_rows: int, launch) -> dict:
+    """Host → HBM → host with everything overlapped (SURVEY §8f-1 "async H2D overlap"): the columns in `inputs` (numpy
+    arrays of equal length, pageable host memory) are cut into chunks of `chunk_rows`; an uploader thread stages chunk
+    k+1 into one of two device buffer sets while the compute pipeline runs `launch(pipeline, device_inputs, device_out,
+    rows)` on chunk k and streams its result back into `out`.  The upload and the compute + download run on different
+    pipelines (HIP streams) tied together by `wait_pipeline`; H2D and D2H use opposite directions of the link.  The
+    reference has no counterpart: it uploads whole Vecs before the first dispatch and reads back after the last
+    (primitive_array_gpu.rs:22-74).  Returns timing facts."""
+    import threading
+    import time
+
+    n = len(out)
+    assert all(len(a) == n for a in inputs)
+    up, comp = ArrowComputePipeline(device, "map_chunks.upload"), ArrowComputePipeline(device, "map_chunks.compute")
+    sets = []
+    for _ in range(2):
+        ins = [device.create_empty_buffer(chunk_rows * a.dtype.itemsize) for a in inputs]
+        sets.append((ins, device.create_empty_buffer(chunk_rows * out.dtype.itemsize)))
+    free = [threading.Semaphore(1), threading.Semaphore(1)]
+    ready = [threading.Semaphore(0), threading.Semaphore(0)]
+    nchunks = (n + chunk_rows - 1) // chunk_rows
+    errors = []
+
+    def uploader():
+        try:
+            for k in range(nchunks):
+                s = k % 2
+                free[s].acquire()
+                r0, rows = k * chunk_rows, min(chunk_rows, n - k * chunk_rows)
+                for a, buf in zip(inputs, sets[s][0]):
+                    src = a[r0:r0 + rows]
+                    capi.call("agpu_staged_copy", up._handle, C.c_void_p(buf.ptr), C.c_void_p(src.ctypes.data), src.nbytes, 1)
+                ready[s].release()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            for s in ready:
+                s.release()
+
+    t0 = time.perf_counter()
+    th = threading.Thread(target=uploader)
+    th.start()
+    for k in range(nchunks):
+        s = k % 2
+        ready[s].acquire()
+        if errors:
+            break
+        r0, rows = k * chunk_rows, min(chunk_rows, n - k * chunk_rows)
+        comp.wait_pipeline(up)  # the chunk's last DMA may still be in flight on the upload stream
+        launch(comp, sets[s][0], sets[s][1], rows)
+        dst = out[r0:r0 + rows]
+        capi.call("agpu_staged_copy", comp._handle, C.c_void_p(sets[s][1].ptr), C.c_void_p(dst.ctypes.data), dst.nbytes, 0)
+        free[s].release()  # the download has drained: the set may be refilled
+    th.join()
+    comp.sync()
+    dt = time.perf_counter() - t0
+    if errors:
+        raise errors[0]
+    moved = sum(a.nbytes for a in inputs) + out.nbytes
+    return {"seconds": dt, "chunks": nchunks, "host_bytes_moved": moved, "GBps_host_bytes": moved / dt / 1e9}

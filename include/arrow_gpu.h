@@ -460,10 +460,11 @@ typedef struct {
  * AGPU_ERR_UNSUPPORTED (the reference has no other array types [ref: crates/array/src/array/mod.rs:40-50]).
  * `offset` (sliced arrays) is honoured: values are copied from `offset` on, bitmaps are re-aligned on the GPU
  * (agpu_bitmap_copy_bits).  null_count == 0 or no validity buffer ⇒ out->validity = NULL.
- * Host→HBM staging: arrays ≥ 1 MiB go through page-locked chunks filled by several host threads while earlier chunks
- * are already on the link (tuning "h2d_mode"/"h2d_threads"); the device-side work is ordered on p's stream and the call
- * returns as soon as the SOURCE has been read completely — the caller may release `array` immediately and keeps
- * ownership of it (this call never calls array->release). */
+ * Host→HBM movement: tuning "h2d_mode" = 1 pageable hipMemcpy (default: 56 GB/s measured, the link's rate), 2 = page-locked
+ * 4 MiB chunks filled by "h2d_threads" host threads while earlier chunks are on the link (45 GB/s), 3 = hipHostRegister
+ * in place (57 GB/s).  The device-side work is ordered on p's stream and the call returns as soon as the SOURCE has been
+ * read completely — the caller may release `array` immediately and keeps ownership of it (this call never calls
+ * array->release). */
 agpu_status agpu_import_arrow(agpu_pipeline* p, const struct ArrowArray* array, const struct ArrowSchema* schema,
                               agpu_arrow_column* out_column);
 /* Device column → freshly allocated host buffers behind a released-by-consumer ArrowArray/ArrowSchema pair (both

@@ -110,3 +110,27 @@ def test_sharded_stats_example_matches_the_sharded_spec():
     assert np.float32(line["min"]) == min(s.min() for s in shards) and np.float32(line["max"]) == max(s.max() for s in shards)
     if world == 1:
         assert np.float32(exp).view(np.uint32) == np.float32(O.reduce(O.RED_SUM, O.F32, shards[0])).view(np.uint32)
+
+
+# ---- Arrow C Data Interface from plain C (examples/arrow_cdata.c)
+A_SRC = os.path.join(ROOT, "examples", "arrow_cdata.c")
+A_EXE = os.path.join(ROOT, "tests", "cpp", "build", "arrow_cdata")
+
+
+def build_arrow_c():
+    os.makedirs(os.path.dirname(A_EXE), exist_ok=True)
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", A_SRC, "-I" + os.path.join(ROOT, "include"),
+           f"-L{LIBDIR}", "-larrow_gpu_hip", "-Wl,-rpath," + LIBDIR, "-o", A_EXE]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_arrow_cdata_example_compiles_as_strict_c11():
+    build_arrow_c()
+
+
+@pytest.mark.gpu
+def test_arrow_cdata_example_on_gpu():
+    build_arrow_c()
+    r = subprocess.run([A_EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "arrow_cdata OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
