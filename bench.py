@@ -119,6 +119,32 @@ def cpu_baseline(sample_rows: int, gpu_windows=()):
                      f"single thread like arrow-rs's kernels",
            "all_cores": {"value": round(vall, 3), "cores": cores}, "cpu_model": model, "nproc": os.cpu_count(),
            "gpu_parity": parity}
+    # the reference's own criterion workloads, CPU side (same port library): f32 column + scalar at 10 Mi rows, u32 sum
+    # at 1 Mi / 10 Mi rows [crates/benchmarks/benches/compare_gpu_arrow.rs:18-43, compare_sum.rs:17-40]
+    try:
+        lib.base_sum_u32.restype = C.c_uint32
+        cnt = 10 * 1024 * 1024
+        col = np.arange(cnt, dtype=np.float32)
+        dst = np.empty(cnt, np.float32)
+        u = np.full(cnt, 2, np.uint32)
+
+        def best_ms(fn, k=7):
+            fn()
+            ts = []
+            for _ in range(k):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            return round(min(ts) * 1e3, 4)
+
+        res["reference_bench_workloads"] = {
+            "f32_add_scalar_10Mi_ms": best_ms(lambda: lib.base_add_scalar_f32(p(col), C.c_float(100.0), p(dst), C.c_uint64(cnt))),
+            "u32_sum_1Mi_ms": best_ms(lambda: lib.base_sum_u32(p(u), C.c_uint64(1024 * 1024))),
+            "u32_sum_10Mi_ms": best_ms(lambda: lib.base_sum_u32(p(u), C.c_uint64(cnt))),
+            "what": "CPU port, 1 thread, pre-allocated output, best of 7 (arrow-rs itself allocates the result each call)"}
+        assert dst[12345] == np.float32(12345.0) + np.float32(100.0) and lib.base_sum_u32(p(u), C.c_uint64(cnt)) == 2 * cnt
+    except Exception as e:  # noqa: BLE001 — context only
+        res["reference_bench_workloads"] = {"error": repr(e)}
     try:  # third-party sanity line: Arrow C++ through pyarrow on the same columns, same byte accounting
         import pyarrow as pa
         import pyarrow.compute as pc
@@ -317,6 +343,37 @@ def main():
     extra["kernels"] = {"add_f32": {"ms": round(add_ms, 4), "GBps": round(add_gbps, 1), "frac_hbm_peak": round(add_gbps / HBM_PEAK_GBPS, 4)},
                         "eq_i32_validity": {"ms": round(eq_ms, 4), "GBps": round(eq_gbps, 1), "frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4)}}
 
+    # ---- the reference's own criterion workloads on the GPU, through the HOST API exactly as its benches call it
+    # (add_dyn(column, 1-element column) at 10 Mi rows; UInt32ArrayGPU::broadcast(2, n).sum() at 1 Mi / 10 Mi rows)
+    # [crates/benchmarks/benches/compare_gpu_arrow.rs:18-43, compare_sum.rs:17-40].  Unlike criterion's loop — which
+    # returns after queue.submit and so times submission — every iteration here ends with a pipeline sync.
+    if rank == 0 and world == 1:
+        import numpy as _np2
+
+        import arrow_gpu_amd as ag
+
+        cnt = 10 * 1024 * 1024
+        col = ag.Float32ArrayGPU.from_slice(_np2.arange(cnt, dtype=_np2.float32), dev)
+        val = ag.Float32ArrayGPU.from_slice(_np2.array([100.0], _np2.float32), dev)
+
+        def best_ms(fn, k=15):
+            fn()
+            dev.sync()
+            ts = []
+            for _ in range(k):
+                t0 = time.perf_counter()
+                fn()
+                dev.sync()
+                ts.append(time.perf_counter() - t0)
+            return round(min(ts) * 1e3, 4)
+
+        w = {"f32_add_scalar_10Mi_ms": best_ms(lambda: ag.add_dyn(col, val))}
+        for label, rows_ in (("u32_sum_1Mi_ms", 1024 * 1024), ("u32_sum_10Mi_ms", cnt)):
+            u = ag.UInt32ArrayGPU.broadcast(2, rows_, dev)
+            w[label] = best_ms(lambda u=u: u.sum())
+            assert int(u.sum().raw_values()[0]) == 2 * rows_
+        w["what"] = "host API call + device sync per iteration (new pipeline + new output buffer per call, like the reference), best of 15"
+        extra["reference_bench_workloads_gpu"] = w
     if rank == 0:
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes

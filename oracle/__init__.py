@@ -34,7 +34,10 @@ NP_DTYPE = {
 
 
 def build(force: bool = False) -> str:
-    """Compile the oracle with gcc (oracle/Makefile). Returns the path of liboracle.so."""
+    """Compile the oracle with gcc (oracle/Makefile). Returns the path of liboracle.so.
+    ORACLE_LIB=<path> loads another build instead (the sanitizer job: oracle/Makefile `asan`)."""
+    if os.environ.get("ORACLE_LIB"):
+        return os.environ["ORACLE_LIB"]
     so = os.path.join(_BUILD, "liboracle.so")
     src = os.path.join(_HERE, "agpu_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

@@ -98,3 +98,20 @@ float base_sum_f32(const float* a, uint64_t n, int threads) {
   }
   return (float)total;
 }
+
+/* The reference's own criterion workloads (crates/benchmarks/benches/compare_gpu_arrow.rs:18-43: f32 column + scalar,
+ * 10 Mi rows, arrow::compute::kernels::numeric::add; compare_sum.rs:17-40: u32 sum, 1 Mi and 10 Mi rows,
+ * arrow::compute::kernels::aggregate::sum — wrapping, single pass). */
+void base_add_scalar_f32(const float* a, float s, float* out, uint64_t n) {
+  for (uint64_t i = 0; i < n; i++) out[i] = a[i] + s;
+}
+uint32_t base_sum_u32(const uint32_t* a, uint64_t n) {
+  uint32_t acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t i = 0;
+  for (; i + 8 <= n; i += 8)
+    for (int k = 0; k < 8; k++) acc[k] += a[i + k];
+  uint32_t t = 0;
+  for (int k = 0; k < 8; k++) t += acc[k];
+  for (; i < n; i++) t += a[i];
+  return t;
+}
