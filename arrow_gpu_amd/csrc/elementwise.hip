@@ -490,7 +490,7 @@ __device__ __forceinline__ float pow_small_exponent(float x, float y) {  // y âˆ
 }
 
 template <typename TabPtr>
-__device__ __forceinline__ float pow_f32_dev(TabPtr tab, float x, float y) {
+__device__ __forceinline__ float pow_f32_general(TabPtr tab, float x, float y) {  // any operands: specials, denormal x, huge |y|
   const uint64_t bits = __builtin_bit_cast(uint64_t, (double)x);
   const uint32_t hi = (uint32_t)(bits >> 32);
   const uint32_t j = (hi >> 13) & 127u;
@@ -505,7 +505,7 @@ __device__ __forceinline__ float pow_f32_dev(TabPtr tab, float x, float y) {
   q = __builtin_fmaf(uf, q, -0.25f);
   q = __builtin_fmaf(uf, q, 0x1.5555555555555p-2f);  // 1/3
   const double u2 = u * u;
-  const double l1p = fma(u2 * u, (double)q, fma(u2, -0.5, u));
+  const double l1p = fma(u2, fma(u, (double)q, -0.5), u);  // u âˆ’ uÂ²/2 + uÂ³Â·q, one f64 multiply less than the expanded form
   const double L = fma(l1p, 0x1.71547652b82fep+0, (double)e + T.lc);
   double w = (double)y * L;
   w = w < 2000.0 ? w : 2000.0;  // keeps k inside v_ldexp's range; NaN cannot occur here (specials handled below)
@@ -520,16 +520,71 @@ __device__ __forceinline__ float pow_f32_dev(TabPtr tab, float x, float y) {
   Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-5f);                              // 1/4!
   Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-3f);                              // 1/3!
   Q = __builtin_fmaf(tf, Q, 0.5f);
-  const double pw = fma(t * t, (double)Q, 1.0 + t);
+  const double pw = fma(t, fma(t, (double)Q, 1.0), 1.0);  // 1 + t + tÂ²Â·Q as two fmas
   float r = (float)ldexp(pw, (int)kd);
-  // specials, IEEE pow restricted to the reference's domain [math/src/f32.rs:209-271]: negative or NaN base â†’ NaN
+  // Specials, IEEE pow restricted to the reference's domain [math/src/f32.rs:209-271]: negative or NaN base â†’ NaN.
+  // The main path is already right for y == 0 and x == 1 with finite operands (w = 0 â‡’ 1) and for denormal x; the
+  // fix-ups sit behind a branch that a wave of ordinary positive finite operands skips â€” as selects they were 12 of
+  // the 62 VALU instructions per row of a kernel that is VALU-bound whenever the shader clock is not at its maximum.
   const float inf = __builtin_inff();
-  if (!(x > 0.0f && x < inf)) r = ((x != 0.0f) == (y > 0.0f)) ? inf : 0.0f;  // 0^y, inf^y
-  if (y == 0.0f || x == 1.0f) r = 1.0f;
-  if (x != x || y != y || x < 0.0f || (x == 0.0f && __builtin_signbit(x))) r = __builtin_nanf("");
+  const bool ordinary = x > 0.0f && x < inf && __builtin_fabsf(y) < inf;
+  if (!ordinary) {
+    if (!(x > 0.0f && x < inf)) r = ((x != 0.0f) == (y > 0.0f)) ? inf : 0.0f;  // 0^y, inf^y
+    if (y == 0.0f || x == 1.0f) r = 1.0f;
+    if (x != x || y != y || x < 0.0f || (x == 0.0f && __builtin_signbit(x))) r = __builtin_nanf("");
+  }
   return r;
 }
 
+// The hot path: x positive, normal and finite, |y| < 2^20 â€” everything a wave of ordinary data consists of.  Compared
+// with the general form it builds the f64 mantissa straight from the f32 bits (no v_cvt_f64_f32), needs no clamp on
+// yÂ·log2(x) (|w| < 2^28: v_ldexp_f64 saturates to 0 / inf by itself) and no special-case selects; the general form sits
+// behind a branch such waves never take.  Same table, same polynomials, same roundings: identical bits.
+__device__ __forceinline__ bool pow_ordinary(float x, float y) {  // x positive normal finite, |y| < 2^20
+  const uint32_t xb = __builtin_bit_cast(uint32_t, x), yb = __builtin_bit_cast(uint32_t, y);
+  return (xb - 0x00800000u) < 0x7f000000u && (yb & 0x7fffffffu) < 0x49800000u;
+}
+template <typename TabPtr>
+__device__ __forceinline__ float pow_f32_fast(TabPtr tab, float x, float y) {  // requires pow_ordinary(x, y)
+  const uint32_t xb = __builtin_bit_cast(uint32_t, x);
+  const uint32_t mant = xb & 0x007fffffu;
+  const uint32_t j = mant >> 16;
+  const bool big = j >= 53u;
+  const int e = (int)(xb >> 23) - 127 + (big ? 1 : 0);
+  const uint32_t mhi = (mant >> 3) | (big ? 0x3fe00000u : 0x3ff00000u);
+  const double m = __builtin_bit_cast(double, ((uint64_t)mhi << 32) | (uint64_t)(mant << 29));
+  const PowTab T = tab[j];
+  const double u = fma(m, T.rc, -1.0);
+  const float uf = (float)u;
+  float q = __builtin_fmaf(uf, -0x1.5555555555555p-3f, 0x1.999999999999ap-3f);  // âˆ’1/6, 1/5
+  q = __builtin_fmaf(uf, q, -0.25f);
+  q = __builtin_fmaf(uf, q, 0x1.5555555555555p-2f);  // 1/3
+  const double u2 = u * u;
+  const double l1p = fma(u2, fma(u, (double)q, -0.5), u);
+  const double L = fma(l1p, 0x1.71547652b82fep+0, (double)e + T.lc);
+  const double w = (double)y * L;
+  const double kd = rint(w);
+  const double t = (w - kd) * 0x1.62e42fefa39efp-1;
+  const float tf = (float)t;
+  float Q = __builtin_fmaf(tf, 0x1.71de3a556c734p-19f, 0x1.a01a01a01a01ap-16f);  // 1/9!, 1/8!
+  Q = __builtin_fmaf(tf, Q, 0x1.a01a01a01a01ap-13f);                             // 1/7!
+  Q = __builtin_fmaf(tf, Q, 0x1.6c16c16c16c17p-10f);                             // 1/6!
+  Q = __builtin_fmaf(tf, Q, 0x1.1111111111111p-7f);                              // 1/5!
+  Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-5f);                              // 1/4!
+  Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-3f);                              // 1/3!
+  Q = __builtin_fmaf(tf, Q, 0.5f);
+  const double pw = fma(t, fma(t, (double)Q, 1.0), 1.0);
+  return (float)ldexp(pw, (int)kd);
+}
+// per-element dispatch (tail rows, fused chains); the tile kernel below votes once per wave instead
+template <typename TabPtr>
+__device__ __forceinline__ float pow_f32_dev(TabPtr tab, float x, float y) {
+  return pow_ordinary(x, y) ? pow_f32_fast(tab, x, y) : pow_f32_general(tab, x, y);
+}
+
+#ifndef AGPU_POW_VOTE
+#define AGPU_POW_VOTE 1
+#endif
 #define AGPU_POW_U 2
 template <int MODE>
 __global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const float* b, float* out, uint64_t ntiles,
@@ -557,20 +612,42 @@ __global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const f
   __syncthreads();
   while (t < ntiles) {
     const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
+    // one vote per wave and tile: a wave whose 512 operand pairs are all ordinary (x positive normal, |y| < 2^20) takes
+    // the short path on a SCALAR branch â€” no exec masking, no selects; any other wave evaluates the general form
+    bool ok = true;
     static_for<U>([&](auto u) {
-      f32x4 r;
-      if constexpr (MODE == MODE_BINARY) {
-        r = f32x4{pow_f32_dev(tab, xa[u].x, xb[u].x), pow_f32_dev(tab, xa[u].y, xb[u].y),
-                  pow_f32_dev(tab, xa[u].z, xb[u].z), pow_f32_dev(tab, xa[u].w, xb[u].w)};
-      } else if (sv == 1.0f || sv == 2.0f) {
-        r = f32x4{pow_small_exponent(xa[u].x, sv), pow_small_exponent(xa[u].y, sv), pow_small_exponent(xa[u].z, sv),
-                  pow_small_exponent(xa[u].w, sv)};
-      } else {
-        r = f32x4{pow_f32_dev(tab, xa[u].x, sv), pow_f32_dev(tab, xa[u].y, sv), pow_f32_dev(tab, xa[u].z, sv),
-                  pow_f32_dev(tab, xa[u].w, sv)};
-      }
-      __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
+      if constexpr (MODE == MODE_BINARY)
+        ok = ok && pow_ordinary(xa[u].x, xb[u].x) && pow_ordinary(xa[u].y, xb[u].y) && pow_ordinary(xa[u].z, xb[u].z) &&
+             pow_ordinary(xa[u].w, xb[u].w);
+      else
+        ok = ok && pow_ordinary(xa[u].x, sv) && pow_ordinary(xa[u].y, sv) && pow_ordinary(xa[u].z, sv) && pow_ordinary(xa[u].w, sv);
     });
+    const bool small_exp = MODE == MODE_SCALAR && (sv == 1.0f || sv == 2.0f);
+    if (small_exp) {
+      static_for<U>([&](auto u) {
+        const f32x4 r = f32x4{pow_small_exponent(xa[u].x, sv), pow_small_exponent(xa[u].y, sv), pow_small_exponent(xa[u].z, sv),
+                              pow_small_exponent(xa[u].w, sv)};
+        __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
+      });
+    } else if (AGPU_POW_VOTE && __all(ok)) {
+      static_for<U>([&](auto u) {
+        f32x4 yb4;
+        if constexpr (MODE == MODE_BINARY) yb4 = xb[u];
+        else yb4 = f32x4{sv, sv, sv, sv};
+        const f32x4 r = f32x4{pow_f32_fast(tab, xa[u].x, yb4.x), pow_f32_fast(tab, xa[u].y, yb4.y), pow_f32_fast(tab, xa[u].z, yb4.z),
+                              pow_f32_fast(tab, xa[u].w, yb4.w)};
+        __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
+      });
+    } else {
+      static_for<U>([&](auto u) {
+        f32x4 yb4;
+        if constexpr (MODE == MODE_BINARY) yb4 = xb[u];
+        else yb4 = f32x4{sv, sv, sv, sv};
+        const f32x4 r = f32x4{pow_f32_general(tab, xa[u].x, yb4.x), pow_f32_general(tab, xa[u].y, yb4.y),
+                              pow_f32_general(tab, xa[u].z, yb4.z), pow_f32_general(tab, xa[u].w, yb4.w)};
+        __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
+      });
+    }
     t += gridDim.x;
     if (t < ntiles) load_tile(t);
   }
