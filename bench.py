@@ -73,21 +73,31 @@ def cpu_baseline(sample_rows: int, gpu_windows=()):
         so = os.path.join(build_dir, "libcpu_baseline.so")
     lib = C.CDLL(so)
     n = sample_rows
-    a = O.synth_f32(n, SEED, 0, -1000.0, 1000.0)
-    b = O.synth_f32(n, SEED + 1, 0, -1000.0, 1000.0)
-    out = np.empty(n, np.float32)
-    ia = O.synth_i32(n, SEED + 2, 0, 1024)
-    ib = O.synth_i32(n, SEED + 3, 0, 1024)
-    va = O.synth_bits(n, SEED + 4, 0, 0.9)
-    vb = O.synth_bits(n, SEED + 5, 0, 0.9)
-    ob = np.empty(O.bitmap_bytes(n), np.uint8)
-    ov = np.empty(O.bitmap_bytes(n), np.uint8)
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)
+    phys = max(1, usable // 2)  # SMT siblings share a core's load/store units: one thread per core
+    cores = min(phys, 64)  # measured on the pool's boxes: beyond 64 threads the container's CPU quota throttles the team
     p = lambda x: C.c_void_p(x.ctypes.data)  # noqa: E731
-    cores = min(os.cpu_count() or 1, 64)  # the all-core line is context only; >64 threads just adds fork/join noise
+
+    def placed(src):
+        """Copy of `src` whose pages were first touched by the all-core partition (NUMA-local slices on a 2-socket host)."""
+        dst = np.empty_like(src)
+        per64 = 64 * src.dtype.itemsize if src.dtype != np.uint8 else 8
+        lib.base_first_touch(p(dst), C.c_uint64(dst.nbytes), C.c_uint64(per64), cores)
+        dst[...] = src
+        return dst
+
+    # two copies of the sample: the plain one (first-touched by this thread: what a single-threaded arrow-rs kernel would
+    # read) for the 1-thread line, the placed one for the all-core line
+    plain = [O.synth_f32(n, SEED, 0, -1000.0, 1000.0), O.synth_f32(n, SEED + 1, 0, -1000.0, 1000.0), np.zeros(n, np.float32),
+             O.synth_i32(n, SEED + 2, 0, 1024), O.synth_i32(n, SEED + 3, 0, 1024), O.synth_bits(n, SEED + 4, 0, 0.9),
+             O.synth_bits(n, SEED + 5, 0, 0.9), np.zeros(O.bitmap_bytes(n), np.uint8), np.zeros(O.bitmap_bytes(n), np.uint8)]
+    spread = [placed(x) for x in plain]
+    a, b, out, ia, ib, va, vb, ob, ov = plain
 
     def one_pass(threads):
-        lib.base_add_f32(p(a), p(b), p(out), None, None, None, C.c_uint64(n), threads)
-        lib.base_eq_i32(p(ia), p(ib), p(ob), p(va), p(vb), p(ov), C.c_uint64(n), threads)
+        a_, b_, out_, ia_, ib_, va_, vb_, ob_, ov_ = plain if threads == 1 else spread
+        lib.base_add_f32(p(a_), p(b_), p(out_), None, None, None, C.c_uint64(n), threads)
+        lib.base_eq_i32(p(ia_), p(ib_), p(ob_), p(va_), p(vb_), p(ov_), C.c_uint64(n), threads)
 
     def rate(threads, budget_s):
         one_pass(threads)
@@ -117,7 +127,11 @@ def cpu_baseline(sample_rows: int, gpu_windows=()):
     res = {"value": round(v1, 3), "unit": "GB/s", "cores": 1, "kind": "port",
            "sample": f"{n} rows of the same synthetic columns (f32 add + i32 eq with validity), repeated passes, "
                      f"single thread like arrow-rs's kernels",
-           "all_cores": {"value": round(vall, 3), "cores": cores}, "cpu_model": model, "nproc": os.cpu_count(),
+           "all_cores": {"value": round(vall, 3), "cores": cores,
+                         "what": "OpenMP static row partition over copies of the columns that were first-touched by the same "
+                                 "partition (each thread's slice on its own NUMA node); capped at 64 threads — the container's "
+                                 "CPU quota throttles larger teams; DRAM-bound, a reported context line"},
+           "cpu_model": model, "nproc": os.cpu_count(), "cgroup_cpu_max": _cgroup_cpu_max(),
            "gpu_parity": parity}
     # the reference's own criterion workloads, CPU side (same port library): f32 column + scalar at 10 Mi rows, u32 sum
     # at 1 Mi / 10 Mi rows [crates/benchmarks/benches/compare_gpu_arrow.rs:18-43, compare_sum.rs:17-40]
@@ -166,7 +180,27 @@ def cpu_baseline(sample_rows: int, gpu_windows=()):
     return res
 
 
+def _cgroup_cpu_max():
+    """The container's CPU quota ("<quota_us> <period_us>" = quota/period CPUs' worth of time, or "max"): it, not nproc,
+    bounds what a thread team can use."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _claim_stdout():
+    """RCCL prints a version banner to the C-level stdout when a communicator comes up; the contract is ONE JSON line
+    on stdout.  Point fd 1 at stderr for the whole run and hand back the real stdout for the final line."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
+    real_stdout = _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -407,7 +441,12 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        try:
+            C.CDLL(None).fflush(None)  # whatever C libraries buffered for "stdout" goes to stderr now, not after the line
+        except Exception:  # noqa: BLE001
+            pass
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

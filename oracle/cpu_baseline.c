@@ -115,3 +115,24 @@ uint32_t base_sum_u32(const uint32_t* a, uint64_t n) {
   for (; i < n; i++) t += a[i];
   return t;
 }
+
+/* First-touch a buffer with the SAME static row partition the kernels above use, so that on a multi-socket host every
+ * thread's slice of every column lives on its own NUMA node (bench.py's all-core line; pages are placed where they are
+ * first written).  gran = bytes per row-granule of the partition (64 rows of the column's element size). */
+void base_first_touch(void* ptr, uint64_t bytes, uint64_t bytes_per_64_rows, int threads) {
+  if (threads < 1) threads = 1;
+  const uint64_t n64 = (bytes + bytes_per_64_rows - 1) / bytes_per_64_rows;  /* 64-row granules */
+#pragma omp parallel num_threads(threads)
+  {
+#ifdef _OPENMP
+    int t = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+    int t = 0, nt = 1;
+#endif
+    uint64_t lo, hi;
+    range_of(t, nt, n64 * 64, 64, &lo, &hi);
+    uint64_t b0 = lo / 64 * bytes_per_64_rows, b1 = hi / 64 * bytes_per_64_rows;
+    if (b1 > bytes) b1 = bytes;
+    for (uint64_t off = b0; off < b1; off += 4096) ((volatile char*)ptr)[off] = 0;
+  }
+}
