@@ -361,6 +361,45 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
       if (!null_buffer || BooleanBufferBuilder::is_set_in_slice(nulls.data(), i)) out[i] = raw[i];
     return out;
   }
+  // Arrow C Data Interface: any producer's ArrowArray / ArrowSchema pair → HBM, offsets and bit offsets of
+  // sliced arrays resolved on the way in; the pair stays the caller's to release.  The reference can only copy through
+  // host Vecs [primitive_array_gpu.rs:22-104].
+  static PrimitiveArrayGpu from_arrow_c(const struct ArrowArray* array, const struct ArrowSchema* schema, const DevicePtr& dev) {
+    ArrowComputePipeline p(dev);
+    agpu_arrow_column col;
+    check(agpu_import_arrow(p.h(), array, schema, &col), "agpu_import_arrow");
+    auto take = [&](void* ptr, uint64_t bytes) {
+      auto b = std::make_shared<Buffer>();
+      b->ptr = ptr;
+      b->bytes = bytes;
+      b->dev = dev;
+      return b;
+    };
+    BufferPtr values = take(col.values, col.values_bytes);
+    std::optional<NullBitBufferGpu> nulls;
+    if (col.validity) nulls = NullBitBufferGpu{take(col.validity, col.validity_bytes), (size_t)col.length, dev};
+    const bool same = col.dtype == DTYPE || (col.dtype == AGPU_I32 && DTYPE == AGPU_DATE32) || (col.dtype == AGPU_DATE32 && DTYPE == AGPU_I32);
+    if (!same) throw ArrowErrorGPU(ArrowErrorGPU::CastingNotSupported, "Arrow format does not match this array type");
+    p.finish();
+    p.sync();
+    return PrimitiveArrayGpu(values, dev, (size_t)col.length, nulls);
+  }
+  // → host buffers behind an ArrowArray / ArrowSchema pair whose release callbacks free them (the consumer calls release)
+  void to_arrow_c(struct ArrowArray* out_array, struct ArrowSchema* out_schema) const {
+    ArrowComputePipeline p(gpu_device);
+    agpu_arrow_column col{};
+    col.dtype = DTYPE;
+    col.length = len;
+    col.null_count = null_buffer ? -1 : 0;
+    col.values = data->ptr;
+    col.values_bytes = data->bytes;
+    if (null_buffer) {
+      col.validity = null_buffer->bit_buffer->ptr;
+      col.validity_bytes = null_buffer->bit_buffer->bytes;
+    }
+    check(agpu_device_sync(gpu_device->raw), "agpu_device_sync");  // other pipelines may still be writing this array
+    check(agpu_export_arrow(p.h(), &col, out_array, out_schema), "agpu_export_arrow");
+  }
   PrimitiveArrayGpu clone_array() const {
     ArrowComputePipeline p(gpu_device);
     auto out = PrimitiveArrayGpu(p.clone_buffer(data), gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));

@@ -216,6 +216,39 @@ int main() {
     auto s = BooleanBufferBuilder::new_set_with_capacity(10);
     CHECK(s.data[0] == 0xFF && s.data[1] == 0b00000011);
   }
+  {  // Arrow C Data Interface through the C++ host: a hand-built sliced f32 array with a validity bitmap, there and back
+    float vals[10] = {0.f, 1.5f, 2.5f, 3.5f, 4.5f, 5.5f, 6.5f, 7.5f, 8.5f, 9.5f};
+    uint8_t bits[8] = {0b11011011, 0b00000010, 0, 0, 0, 0, 0, 0};  // rows 2, 5, 8 null
+    const void* bufs[2] = {bits, vals};
+    struct ArrowArray in {};
+    in.length = 7;
+    in.offset = 2;  // rows 2..8 of the parent: its nulls at 2, 5, 8 land on positions 0, 3, 6
+    in.null_count = 3;
+    in.n_buffers = 2;
+    in.buffers = bufs;
+    in.release = [](struct ArrowArray* a) { a->release = nullptr; };
+    struct ArrowSchema sch {};
+    sch.format = "f";
+    sch.name = "x";
+    sch.release = [](struct ArrowSchema* x) { x->release = nullptr; };
+    auto g = Float32ArrayGPU::from_arrow_c(&in, &sch, device);
+    CHECK(same(g.values(), {N, Opt<float>(3.5f), 4.5f, N, 6.5f, 7.5f, N}));
+    auto doubled = g.add(g);
+    struct ArrowArray out {};
+    struct ArrowSchema osch {};
+    doubled.to_arrow_c(&out, &osch);
+    CHECK(std::string(osch.format) == "f" && out.length == 7 && out.offset == 0 && out.n_buffers == 2);
+    const float* ov = (const float*)out.buffers[1];
+    const uint8_t* ob = (const uint8_t*)out.buffers[0];
+    CHECK(ov[1] == 7.0f && ov[2] == 9.0f && ov[4] == 13.0f && ov[5] == 15.0f);
+    CHECK((ob[0] & 0x7f) == 0b0110110);
+    out.release(&out);
+    osch.release(&osch);
+    CHECK(out.release == nullptr && osch.release == nullptr);
+    bool threw = false;
+    try { (void)Int32ArrayGPU::from_arrow_c(&in, &sch, device); } catch (const ArrowErrorGPU&) { threw = true; }
+    CHECK(threw);  // an "f" column is not an Int32ArrayGPU
+  }
   if (failures) {
     std::printf("%d check(s) failed\n", failures);
     return 1;

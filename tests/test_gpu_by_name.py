@@ -325,3 +325,81 @@ def test_dead_entry_points_and_bad_arguments_are_rejected(ctx):
     capi.check(lib.agpu_launch_by_name_sized(p._handle, b"arithmetic/i32/array", b"add_i32", ptrs2, sizes2, 2, C.c_void_p(out.ptr), 4 * n, 1), "add")
     got = dev.retrive_data(out, 4 * n, pipeline=p).view(np.int32)
     assert np.array_equal(got[:256], 2 * np.arange(256)) and not got[256:].any()
+
+
+# ---------------------------------------------------------------------------------------------- robust-access fuzz
+def _lanes_model(family, W, OW, out_bytes, inv):
+    """Independent restatement of the rule in include/arrow_gpu.h: a lane is processed iff it lies inside
+    dispatch × 256 invocations AND inside every binding.  W = words per input binding, OW = output words."""
+    if family == "ew_f32":      # invocation i ↔ word i of a, b, out
+        return min(inv, W[0], W[1], OW)
+    if family == "scalar_u16":  # word i of a and out (2 lanes); binding 1 is the operand
+        return 2 * min(inv, W[0], OW)
+    if family == "cmp_u8":      # invocation ↔ input word (4 lanes); 32 lanes per output word
+        return min(4 * min(inv, W[0], W[1]), 32 * OW)
+    if family == "cast_u8_f32":  # invocation ↔ input word → 4 f32
+        return min(4 * min(inv, W[0]), out_bytes // 4)
+    if family == "cast_f32_u8":  # invocation ↔ OUTPUT word ← 4 f32
+        return min(4 * min(inv, OW), W[0])
+    if family == "cast_bool_f32":
+        return min(inv, OW, 32 * W[0])
+    raise AssertionError(family)
+
+
+@pytest.mark.gpu
+def test_sized_seam_with_arbitrary_sizes_never_touches_lanes_outside_a_binding(ctx):
+    """Random byte sizes and dispatch sizes (mismatched on purpose): the lanes the rule selects equal the oracle, every
+    byte of the output past them keeps the zero the reference's allocator put there."""
+    dev, p = ctx
+    rng = np.random.default_rng(20250418)
+    lib = capi.lib()
+    for trial in range(120):
+        family = ["ew_f32", "scalar_u16", "cmp_u8", "cast_u8_f32", "cast_f32_u8", "cast_bool_f32"][trial % 6]
+        W = [int(rng.integers(1, 700)), int(rng.integers(1, 700))]
+        OW = int(rng.integers(1, 2800 if family in ("cast_u8_f32",) else 700))
+        disp = int(rng.integers(1, 4))
+        inv = disp * 256
+        if family == "ew_f32":
+            key, ep = b"arithmetic/f32/array", b"mul_f32"
+            a, b = rng.standard_normal(W[0]).astype(np.float32), rng.standard_normal(W[1]).astype(np.float32)
+            ins, n = [a, b], None
+            def expect(n): return O.binary(O.OP_MUL, O.F32, a[:n], b[:n]).view(np.uint8)  # noqa: E704
+        elif family == "scalar_u16":
+            key, ep = b"arithmetic/u16/scalar", b"u16_add"
+            a = rng.integers(0, 65536, 2 * W[0]).astype(np.uint16)
+            s = np.array([7, 0], np.uint16)
+            ins = [a, s]
+            def expect(n): return O.scalar(O.OP_ADD, O.U16, a[:n], s[:1]).view(np.uint8)  # noqa: E704
+        elif family == "cmp_u8":
+            key, ep = b"compare/u8/cmp", b"lteq"
+            a, b = rng.integers(0, 4, 4 * W[0]).astype(np.uint8), rng.integers(0, 4, 4 * W[1]).astype(np.uint8)
+            ins = [a, b]
+            def expect(n): return O.compare(O.CMP_LTEQ, O.U8, a[:n], b[:n])[: (n + 7) // 8]  # noqa: E704
+        elif family == "cast_u8_f32":
+            key, ep = b"cast/u8/cast_f32", b"cast_f32"
+            a = rng.integers(0, 256, 4 * W[0]).astype(np.uint8)
+            ins = [a]
+            def expect(n): return O.cast(O.U8, O.F32, a[:n]).view(np.uint8)  # noqa: E704
+        elif family == "cast_f32_u8":
+            key, ep = b"cast/f32/cast_u8", b"cast_u8"
+            a = (rng.random(W[0]) * 600 - 100).astype(np.float32)
+            ins = [a]
+            def expect(n): return O.cast(O.F32, O.U8, a[:n])  # noqa: E704
+        else:
+            key, ep = b"cast/boolean/cast_f32", b"cast_f32"
+            a = rng.integers(0, 256, 4 * W[0]).astype(np.uint8)
+            ins = [a]
+            def expect(n): return O.cast(O.BOOL, O.F32, a, n).view(np.uint8)  # noqa: E704
+        n = _lanes_model(family, W, OW, 4 * OW, inv)
+        bufs = [dev.create_gpu_buffer_with_data(x) for x in ins]
+        out = dev.create_empty_buffer(4 * OW, zero_fill=True)
+        ptrs = (C.c_void_p * len(bufs))(*[b_.ptr for b_ in bufs])
+        sizes = (C.c_uint64 * len(bufs))(*[x.nbytes if x is not ins[-1] or family != "scalar_u16" else 4 for x in ins])
+        capi.check(lib.agpu_launch_by_name_sized(p._handle, key, ep, ptrs, sizes, len(bufs), C.c_void_p(out.ptr), 4 * OW, disp), ep.decode())
+        got = dev.retrive_data(out, 4 * OW, pipeline=p)
+        exp = np.ascontiguousarray(expect(n)).view(np.uint8).ravel()
+        if family == "cmp_u8":  # bits past n inside the last byte are zero too
+            assert got[: len(exp)].tobytes() == exp.tobytes(), (family, W, OW, disp, n)
+        else:
+            assert got[: len(exp)].tobytes() == exp.tobytes(), (family, W, OW, disp, n)
+        assert not got[len(exp):].any(), (family, W, OW, disp, n)
