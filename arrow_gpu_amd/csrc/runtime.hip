@@ -30,11 +30,11 @@ void agpu_set_error(const char* fmt, ...) {
 static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
     /*stream_grid*/ {0}, /*stream_bpc*/ {0}, /*stream_unroll*/ {1}, /*stream_nt*/ {1}, /*cmp_variant*/ {0}, /*reduce_grid*/ {0},
     /*table_tiles*/ {4},  // profiles/r01_sweep_table_tiles.json: sin_u8 5.74 → 6.02, sin_u16 5.85 → 6.16 TB/s vs 1 tile per block
-    /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}};
+    /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}, /*gather_offsets*/ {0}};
 static std::atomic<int64_t> g_mem_pool{1};  // 1 = recycle device blocks and idle streams (default), 0 = hipMalloc/hipFree every time
 static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "stream_bpc", "stream_unroll", "stream_nt",
                                                          "cmp_variant", "reduce_grid", "table_tiles", "gather_bucket",
-                                                         "h2d_mode", "h2d_threads", "gather_region_bits"};
+                                                         "h2d_mode", "h2d_threads", "gather_region_bits", "gather_offsets"};
 
 agpu_tuning agpu_tuning_defaults() {
   agpu_tuning t;
@@ -976,6 +976,7 @@ agpu_status agpu_scope_enter(agpu_pipeline* p, const char* name) {
   }
   AGPU_HIP(hipSetDevice(p->dev->ordinal));
   agpu_device* dev = p->dev;
+#ifndef AGPU_TEST_NO_ORDERING
   if (p->scope_depth == 0 && !p->capturing && p->seen_gen != dev->finish_gen.load(std::memory_order_acquire)) {
     std::lock_guard<std::mutex> lock(dev->mu);
     for (agpu_stream_slot* s : dev->slots) {
@@ -984,6 +985,7 @@ agpu_status agpu_scope_enter(agpu_pipeline* p, const char* name) {
     }
     p->seen_gen = dev->finish_gen.load(std::memory_order_relaxed);
   }
+#endif  // AGPU_TEST_NO_ORDERING: tools/probe builds a variant without the wait to prove the ordering tests can fail
   if (p->profile && !p->capturing) {
     if (p->profile & AGPU_PROF_ROCTX) roctxRangePushA(name);
     if ((p->profile & AGPU_PROF_TIMING) && p->scope_depth == 0) {

@@ -205,22 +205,31 @@ __global__ __launch_bounds__(AGPU_BLOCK) void index_max_kernel(const uint32_t* i
 #define BKT_TILE (BKT_T * BKT_E)
 #define BKT_INVALID 0xFFFFFFFFu
 
+// A region's range cursor takes one global atomic per (tile, region); with all cursors in one 16 KiB array every tile's
+// 2048 atomics land in a handful of L2 channels and the reservation phase was 57 % of the partition kernel's tile time
+// (tools/probe/bkt_phases.py: 35 600 of 62 500 cycles).  One cursor per 128-byte line spreads them over the channels.
+#define BKT_CUR_STRIDE 32
 struct BktCtl {  // device-side control block
   uint32_t hist_s[BKT_MAX + 1];  // +1: take's out-of-range rows (value 0 at the end)
   uint32_t hist_d[BKT_MAX + 1];
-  uint32_t cur_s[BKT_MAX + 1];
-  uint32_t cur_d[BKT_MAX + 1];
+  uint32_t cur_s[(BKT_MAX + 1) * BKT_CUR_STRIDE];
+  uint32_t cur_d[(BKT_MAX + 1) * BKT_CUR_STRIDE];
+  uint32_t base_s[BKT_MAX + 1];  // first pair of every source region (exclusive scan of hist_s)
   uint32_t total;                // rows that reach the gather (take: n; put: rows with both indices in range)
   uint32_t pad[3];
 };
 
-// take: di == nullptr (destination = the row number itself)
+// H.  take: di == nullptr (destination = the row number itself).  Source side: the count of every (tile, region) pair
+// goes to `counts` (u16, row stride nbp) — the partition pass gets its range starts from a column scan over these
+// instead of reserving them with global atomics: one reservation per (tile, region) is n/8 device-scope atomics per
+// pass, and the chip retires ≈ 26 G of them per second (2^28 rows: 33.5 M atomics = 1.3 ms, 57 % of the pass —
+// tools/probe/bkt_phases.py).  Destination side (put): region totals only, accumulated in LDS across the block's tiles.
 __global__ __launch_bounds__(BKT_T) void bkt_hist_kernel(const uint32_t* si, const uint32_t* di, uint64_t n, uint64_t n_src,
                                                         uint64_t n_dst, int rs, int rd, uint32_t bs, uint32_t bd,
-                                                        BktCtl* ctl, uint32_t* flags) {
+                                                        BktCtl* ctl, uint32_t* flags, uint16_t* counts, uint32_t nbp,
+                                                        uint32_t ntiles) {
   __shared__ uint32_t ls[BKT_MAX + 1], ld[BKT_MAX + 1];
-  for (uint32_t b = threadIdx.x; b <= BKT_MAX; b += BKT_T) ls[b] = ld[b] = 0;
-  __syncthreads();
+  for (uint32_t b = threadIdx.x; b <= BKT_MAX; b += BKT_T) ld[b] = 0;
   bool bad = false;
   auto count = [&](uint32_t s, uint32_t d) {
     if (di) {
@@ -237,26 +246,81 @@ __global__ __launch_bounds__(BKT_T) void bkt_hist_kernel(const uint32_t* si, con
       bad = true;
     }
   };
-  const uint64_t tid = (uint64_t)blockIdx.x * BKT_T + threadIdx.x, stride = (uint64_t)gridDim.x * BKT_T;
-  const uint64_t npacks = n / 4;
-  for (uint64_t pk = tid; pk < npacks; pk += stride) {
-    const u32x4 s = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si) + pk);
-    u32x4 d = {0, 0, 0, 0};
-    if (di) d = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di) + pk);
-    count(s.x, d.x); count(s.y, d.y); count(s.z, d.z); count(s.w, d.w);
-  }
-  for (uint64_t i = npacks * 4 + tid; i < n; i += stride) count(si[i], di ? di[i] : 0u);
+  for (uint32_t b = threadIdx.x; b <= BKT_MAX; b += BKT_T) ls[b] = 0;
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T)
-    if (ls[b]) atomicAdd(&ctl->hist_s[b], ls[b]);
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (counts) {
+      for (uint32_t b = threadIdx.x; b < nbp; b += BKT_T) ls[b] = 0;
+      __syncthreads();
+    }
+    const uint64_t base = (uint64_t)tile * BKT_TILE;
+#pragma unroll
+    for (int q = 0; q < BKT_E / 4; q++) {
+      const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+      if (i0 + 4 <= n) {
+        const u32x4 sv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
+        u32x4 dv = {0, 0, 0, 0};
+        if (di) dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + i0));
+        count(sv.x, dv.x); count(sv.y, dv.y); count(sv.z, dv.z); count(sv.w, dv.w);
+      } else {
+        for (int k = 0; k < 4; k++)
+          if (i0 + k < n) count(si[i0 + k], di ? di[i0 + k] : 0u);
+      }
+    }
+    if (counts) {
+      __syncthreads();
+      for (uint32_t b = threadIdx.x; b < nbp; b += BKT_T) counts[(uint64_t)tile * nbp + b] = (uint16_t)ls[b];
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (!counts)  // region totals straight from the block's LDS histogram (one atomic per region and block)
+    for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T)
+      if (ls[b]) atomicAdd(&ctl->hist_s[b], ls[b]);
   if (di)
     for (uint32_t b = threadIdx.x; b < bd; b += BKT_T)
       if (ld[b]) atomicAdd(&ctl->hist_d[b], ld[b]);
   if (bad) *reinterpret_cast<volatile uint32_t*>(flags) = AGPU_FLAG_INDEX_RANGE;
 }
 
+// Column scan of the (tile × region) count matrix in three small kernels (the matrix is 2 B per 8 rows of input):
+// chunk sums over BKT_CHUNK tiles → per-region exclusive scan over chunks (+ region totals) → [bkt_scan_kernel turns the
+// totals into region bases] → per-tile range starts.
+#define BKT_CHUNK 128
+__global__ __launch_bounds__(256) void bkt_colsum_kernel(const uint16_t* counts, uint32_t nbp, uint32_t ntiles, uint32_t* csum) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if (b >= nbp) return;
+  const uint32_t t0 = c * BKT_CHUNK, t1 = t0 + BKT_CHUNK < ntiles ? t0 + BKT_CHUNK : ntiles;
+  uint32_t acc = 0;
+  for (uint32_t t = t0; t < t1; t++) acc += counts[(uint64_t)t * nbp + b];
+  csum[(uint64_t)c * nbp + b] = acc;
+}
+__global__ __launch_bounds__(256) void bkt_colscan_kernel(uint32_t* csum, uint32_t nbp, uint32_t nchunks, BktCtl* ctl) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nbp) return;
+  uint32_t run = 0;
+  for (uint32_t c = 0; c < nchunks; c++) {
+    const uint32_t v = csum[(uint64_t)c * nbp + b];
+    csum[(uint64_t)c * nbp + b] = run;
+    run += v;
+  }
+  if (b <= BKT_MAX) ctl->hist_s[b] = run;
+}
+__global__ __launch_bounds__(256) void bkt_offsets_kernel(const uint16_t* counts, const uint32_t* csum, uint32_t nbp,
+                                                         uint32_t ntiles, const BktCtl* ctl, uint32_t* offsets) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+  if (b >= nbp) return;
+  const uint32_t t0 = c * BKT_CHUNK, t1 = t0 + BKT_CHUNK < ntiles ? t0 + BKT_CHUNK : ntiles;
+  uint32_t run = (b <= BKT_MAX ? ctl->base_s[b] : 0u) + csum[(uint64_t)c * nbp + b];
+  for (uint32_t t = t0; t < t1; t++) {
+    offsets[(uint64_t)t * nbp + b] = run;
+    run += counts[(uint64_t)t * nbp + b];
+  }
+}
+
 // exclusive scans → range start of every bucket; one workgroup
-__global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t bs, uint32_t bd, int rd, int is_put) {
+__global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t bs, uint32_t bd, int rd, int is_put,
+                                                        uint32_t stride_s, uint32_t stride_d) {
   __shared__ uint32_t sh[BKT_MAX + 2];
   for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T) sh[b] = ctl->hist_s[b];
   __syncthreads();
@@ -270,7 +334,10 @@ __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t b
     ctl->total = acc;
   }
   __syncthreads();
-  for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T) ctl->cur_s[b] = sh[b];
+  for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T) {
+    ctl->base_s[b] = sh[b];
+    ctl->cur_s[b * stride_s] = sh[b];
+  }
   __syncthreads();
   if (is_put) {
     for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) sh[b] = ctl->hist_d[b];
@@ -284,9 +351,9 @@ __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t b
       }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) ctl->cur_d[b] = sh[b];
+    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) ctl->cur_d[b * stride_d] = sh[b];
   } else {  // take: the destinations are 0..n-1, every destination bucket is full — its range is its own region
-    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) ctl->cur_d[b] = b << rd;
+    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) ctl->cur_d[b * stride_d] = b << rd;
   }
 }
 
@@ -299,15 +366,27 @@ __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t b
 struct BktRow {
   uint32_t a, b, key;
 };
+#ifdef BKT_PROFILE
+// tools/probe: per-phase cycle stamps of workgroup 0's thread 0 (s_memtime), dumped through a global debug buffer
+__device__ unsigned long long g_bkt_stamps[4][16];
+#define BKT_STAMP(k, i)                                                         \
+  do {                                                                          \
+    if (blockIdx.x == 64 && threadIdx.x == 0) g_bkt_stamps[k][i] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define BKT_STAMP(k, i) do {} while (0)
+#endif
 __device__ __forceinline__ void bkt_tile_sort(BktRow (&row)[BKT_E], uint32_t nkeys, uint32_t* lcnt, u32x2* sorted,
-                                              uint32_t* wave_tot, uint32_t* tile_rows) {
+                                              uint32_t* wave_tot, uint32_t* tile_rows, int kid = 3) {
   // nkeys ≤ BKT_MAX = 4 · BKT_T: thread t owns counters 4t .. 4t+3
+  BKT_STAMP(kid, 1);  // rows are in registers (loads waited for by the first use below)
   for (uint32_t k = threadIdx.x; k < BKT_MAX; k += BKT_T) lcnt[k] = 0;
   __syncthreads();
   uint32_t rank[BKT_E];
 #pragma unroll
   for (int e = 0; e < BKT_E; e++) rank[e] = row[e].key != BKT_INVALID ? atomicAdd(&lcnt[row[e].key], 1u) : 0u;
   __syncthreads();
+  BKT_STAMP(kid, 2);  // ranks done
   // exclusive scan of the counters
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   uint32_t c[4], sum = 0;
@@ -334,6 +413,7 @@ __device__ __forceinline__ void bkt_tile_sort(BktRow (&row)[BKT_E], uint32_t nke
   }
   if (threadIdx.x == BKT_T - 1) *tile_rows = run;
   __syncthreads();
+  BKT_STAMP(kid, 3);  // scan done
 #pragma unroll
   for (int e = 0; e < BKT_E; e++)
     if (row[e].key != BKT_INVALID) {
@@ -341,6 +421,7 @@ __device__ __forceinline__ void bkt_tile_sort(BktRow (&row)[BKT_E], uint32_t nke
       sorted[lcnt[row[e].key] + rank[e]] = v;
     }
   __syncthreads();
+  BKT_STAMP(kid, 4);  // LDS scatter done
   (void)nkeys;
 }
 
@@ -348,7 +429,8 @@ __device__ __forceinline__ void bkt_tile_sort(BktRow (&row)[BKT_E], uint32_t nke
 // non-empty (tile, key).  On entry lcnt = exclusive starts; on exit lcnt[k] = gstart[k] − start[k] (wrapping).
 template <typename KeyOf>
 __device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, const u32x2* sorted, uint32_t tile_rows,
-                                             uint32_t* cursors, u32x2* out_pairs, KeyOf key_of) {
+                                             uint32_t* cursors, uint32_t cur_stride, u32x2* out_pairs, KeyOf key_of,
+                                             int kid = 3, const uint32_t* tile_starts = nullptr) {
   uint32_t st[4], cnt[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) st[k] = lcnt[threadIdx.x * 4 + k];
@@ -359,16 +441,31 @@ __device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, con
     cnt[k] = nxt - st[k];
   }
   __syncthreads();
+  // all four reservations are issued before any result is consumed: four dependent round trips to the memory-side
+  // atomic unit per thread were most of this phase
+  uint32_t g[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const uint32_t kk = threadIdx.x * 4 + k;
-    if (kk < nkeys && cnt[k]) lcnt[kk] = atomicAdd(&cursors[kk], cnt[k]) - st[k];
+#ifdef BKT_FAKE_RESERVE  // tools/probe only: what would the pass cost without the reservation atomics? (results are wrong)
+    g[k] = (uint32_t)(blockIdx.x % 8192u) * BKT_TILE;
+#else
+    if (tile_starts) g[k] = kk < nkeys ? tile_starts[kk] : 0u;  // deterministic: the column scan of H's counts
+    else g[k] = (kk < nkeys && cnt[k]) ? __hip_atomic_fetch_add(&cursors[kk * cur_stride], cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#endif
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t kk = threadIdx.x * 4 + k;
+    if (kk < nkeys && cnt[k]) lcnt[kk] = g[k] - st[k];
   }
   __syncthreads();
+  BKT_STAMP(kid, 5);  // ranges reserved
   for (uint32_t j = threadIdx.x; j < tile_rows; j += BKT_T) {
     const u32x2 v = sorted[j];
     out_pairs[(uint64_t)(uint32_t)(lcnt[key_of(v)] + j)] = v;
   }
+  BKT_STAMP(kid, 6);  // stores issued
 }
 
 #define BKT_LDS_DECL                                                   \
@@ -381,8 +478,10 @@ __device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, con
 // extra bucket `bs`: they still produce an output, the value 0)
 __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si, const uint32_t* di, uint64_t n,
                                                              uint64_t n_src, uint64_t n_dst, int rs, uint32_t bs,
-                                                             BktCtl* ctl, u32x2* pairs) {
+                                                             BktCtl* ctl, u32x2* pairs, const uint32_t* offsets, uint32_t nbp,
+                                                             uint32_t cur_stride) {
   BKT_LDS_DECL;
+  BKT_STAMP(0, 0);
   const uint64_t base = (uint64_t)blockIdx.x * BKT_TILE;
   BktRow row[BKT_E];
 #pragma unroll
@@ -414,10 +513,11 @@ __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si
       else r.key = s[k] < n_src ? (s[k] >> rs) : bs;
     }
   }
-  bkt_tile_sort(row, bs + 1, lcnt, sorted, wave_tot, &tile_rows);
+  bkt_tile_sort(row, bs + 1, lcnt, sorted, wave_tot, &tile_rows, 0);
   const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
-  bkt_copy_out(bs + 1, lcnt, sorted, tile_rows, ctl->cur_s, pairs,
-               [=](const u32x2& v) { return v.x < n_src32 ? (v.x >> rs) : bs; });
+  bkt_copy_out(bs + 1, lcnt, sorted, tile_rows, ctl->cur_s, cur_stride, pairs,
+               [=](const u32x2& v) { return v.x < n_src32 ? (v.x >> rs) : bs; }, 0,
+               offsets ? offsets + (uint64_t)blockIdx.x * nbp : nullptr);
 }
 
 // XCD-contiguous walk: workgroups are dealt round-robin to the 8 XCDs, so workgroup j takes tile (j % 8) · per + j / 8 —
@@ -449,7 +549,7 @@ __device__ __forceinline__ void bkt_load_tile(const u32x2* pairs_in, uint64_t ba
 template <int W>
 __global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf<W>::type* values, uint64_t n_src,
                                                           const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles,
-                                                          int src_line_shift, BktCtl* ctl, u32x2* pairs_out) {
+                                                          int src_line_shift, BktCtl* ctl, u32x2* pairs_out, uint32_t cur_stride) {
   BKT_LDS_DECL;
   uint64_t tile;
   if (!bkt_tile_of_block(ntiles, &tile)) return;
@@ -479,8 +579,9 @@ __global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf
     row[e].key = ok ? (v.y >> rd) : BKT_INVALID;
   }
   __syncthreads();  // everyone has read `sorted` before the second sort overwrites it
-  bkt_tile_sort(row, bd, lcnt, sorted, wave_tot, &tile_rows);
-  bkt_copy_out(bd, lcnt, sorted, tile_rows, ctl->cur_d, pairs_out, [=](const u32x2& v) { return v.x >> rd; });
+  BKT_STAMP(1, 0);  // gathers issued
+  bkt_tile_sort(row, bd, lcnt, sorted, wave_tot, &tile_rows, 1);
+  bkt_copy_out(bd, lcnt, sorted, tile_rows, ctl->cur_d, cur_stride, pairs_out, [=](const u32x2& v) { return v.x >> rd; }, 1);
 }
 
 // F: {destination, value} in destination-bucket order → dst[destination] = value.  The tile is first ordered by
@@ -505,11 +606,13 @@ __global__ __launch_bounds__(BKT_T) void bkt_store_kernel(const u32x2* pairs, ui
     row[e].b = pb[e];
     row[e].key = live[e] ? ((pa[e] >> line_shift) & (BKT_MAX - 1)) : BKT_INVALID;
   }
-  bkt_tile_sort(row, BKT_MAX, lcnt, sorted, wave_tot, &tile_rows);
+  BKT_STAMP(2, 0);
+  bkt_tile_sort(row, BKT_MAX, lcnt, sorted, wave_tot, &tile_rows, 2);
   for (uint32_t j = threadIdx.x; j < tile_rows; j += BKT_T) {
     const u32x2 v = sorted[j];
     dst[v.x] = (E)v.y;
   }
+  BKT_STAMP(2, 6);
 }
 
 // region = 2^r elements = 512 KiB on both sides: an XCD has 32 tiles (2^19 rows) in flight, i.e. two or three regions,
@@ -537,14 +640,26 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   while ((1 << (rs - src_line_shift)) > BKT_MAX) src_line_shift++;
   const uint32_t bs = (uint32_t)((n_src + ((uint64_t)1 << rs) - 1) >> rs), bd = (uint32_t)((n_dst + ((uint64_t)1 << rd) - 1) >> rd);
   agpu_device* dev = p->dev;
-  void *ctl_v = nullptr, *p1 = nullptr, *p2 = nullptr;
+  void *ctl_v = nullptr, *p1 = nullptr, *p2 = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr;
+  const uint32_t ntiles = (uint32_t)((n + BKT_TILE - 1) / BKT_TILE);
+  const uint32_t nbp = (bs + 1 + 3) & ~3u;  // padded row stride of the (tile × region) matrices
+  const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
+  // "gather_offsets" = 2: the partition pass takes its range starts from a column scan of per-tile counts instead of
+  // reserving them with atomics.  Measured (same box, 2^26–2^28 rows): never faster — the pass is bound by its 64-byte
+  // runs of pairs landing all over a 2 GiB array (12 B written per 8 B row by PMC), not by the 33 M atomics — so the
+  // atomic form is the default and the deterministic form stays for hosts that need a reproducible pair order.
+  const bool det = p->tune.gather_offsets == 2;
   agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p1);
   if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p2);
+  if (det) {
+    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 2, 0, &cnt_v);
+    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 4, 0, &off_v);
+    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)nchunks * nbp * 4, 0, &csum_v);
+  }
   if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;  // no room for the 16 B/row of temporaries: the direct kernel needs none
   if (st == AGPU_OK) {
     BktCtl* ctl = static_cast<BktCtl*>(ctl_v);
-    const uint32_t ntiles = (uint32_t)((n + BKT_TILE - 1) / BKT_TILE);
     const uint32_t nblk = (ntiles + 7) / 8 * 8;
     hipError_t e = hipMemsetAsync(ctl, 0, sizeof(BktCtl), p->stream);
     if (e != hipSuccess) {
@@ -553,13 +668,26 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
     } else {
       uint64_t hg = (uint64_t)dev->num_cus * 2;
       if (hg > ntiles) hg = ntiles;
-      hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags);
-      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0);
-      hipLaunchKernelGGL(bkt_partition_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1));
+      uint16_t* counts = static_cast<uint16_t*>(cnt_v);
+      uint32_t* offsets = static_cast<uint32_t*>(off_v);
+      uint32_t* csum = static_cast<uint32_t*>(csum_v);
+      const dim3 cgrid((nbp + 255) / 256, nchunks);
+      hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags, counts, nbp, ntiles);
+      if (det) {
+        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
+        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl);
+      }
+      // one cursor per 128-byte line while the regions are few (the atomics spread over the L2 channels: −10…15 % per
+      // call at ≤ 1024 regions, same-box A/B), packed cursors beyond (a 256 KiB cursor array costs more than it spreads)
+      const uint32_t stride_s = bs + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 1;
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0, stride_s, stride_d);
+      if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl, offsets);
+      hipLaunchKernelGGL(bkt_partition_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),
+                         det ? offsets : static_cast<uint32_t*>(nullptr), nbp, stride_s);
 #define BKT_GF(W, E)                                                                                                         \
   case W:                                                                                                                    \
     hipLaunchKernelGGL((bkt_gather_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const E*>(src), n_src,     \
-                       static_cast<const u32x2*>(p1), rd, bd, ntiles, src_line_shift, ctl, static_cast<u32x2*>(p2));         \
+                       static_cast<const u32x2*>(p1), rd, bd, ntiles, src_line_shift, ctl, static_cast<u32x2*>(p2), stride_d); \
     hipLaunchKernelGGL((bkt_store_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p2), ntiles,  \
                        ctl, line_shift, static_cast<E*>(dst));                                                               \
     break;
@@ -577,6 +705,9 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
     }
   }
   // the pool hands these blocks out again only after the stream has passed the kernels above (runtime.hip markers)
+  if (csum_v) (void)agpu_free(dev, csum_v);
+  if (off_v) (void)agpu_free(dev, off_v);
+  if (cnt_v) (void)agpu_free(dev, cnt_v);
   if (p2) (void)agpu_free(dev, p2);
   if (p1) (void)agpu_free(dev, p1);
   if (ctl_v) (void)agpu_free(dev, ctl_v);
@@ -586,16 +717,19 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
 // tuning "gather_bucket": 0 = auto, 1 = always direct, 2 = bucketed whenever the shape qualifies.
 // Auto, from one-process A/B sweeps on MI355X (tools/probe/bucket_sweep.py → profiles/r02_gather_sweep.json, uniformly
 // random 4-byte rows): PUT goes bucketed from 2^25 rows when neither side is sparser than 1 row in 16 elements —
-// 1.4–1.8× at 2^26 rows, 2.0–3.2× at 2^28 (15 → 49 G rows/s with both sides random over 1 GiB); below that the five
-// launches and the 16 B/row of temporaries cost more than the random transactions they save.  TAKE stays direct: a
-// random gather already runs at the 128-byte-line fetch roof (48–52 G rows/s) and the bucketed form, three scattered
-// passes of which the L2 accepts ≈100–200 G requests/s each, reaches 1.16× at best (2^28 rows from 2^28) and loses below.
+// 1.6–2.4× at 2^26 rows, 2.4–3.3× at 2^28 (15 → 49 G rows/s with both sides random over 1 GiB); below that the
+// launches and the 16 B/row of temporaries cost more than the random transactions they save.  TAKE goes bucketed from
+// 2^26 rows when the source is at least 64 MiB (smaller sources sit in L2 / MALL and the direct gather is faster) and
+// not sparser than 1 row in 16 elements: 1.15–1.3× — a random gather already runs at the 128-byte-line fetch roof
+// (48–52 G rows/s), and the bucketed passes move 54 B/row instead of 135 but are bound by their LDS counting sorts and
+// by 64-byte runs of pairs landing all over a 2 GiB array, not by HBM bytes.
 static bool want_bucketed(const agpu_pipeline* p, int width, uint64_t n, uint64_t n_src, uint64_t n_dst, bool is_put) {
   const int64_t mode = p->tune.gather_bucket;
   if (mode == 1) return false;
   if (mode == 2) return n >= BKT_TILE;
-  (void)width;
-  return is_put && n >= ((uint64_t)1 << 25) && n_src / 16 <= n && n_dst / 16 <= n;
+  if (n_src / 16 > n || n_dst / 16 > n) return false;
+  if (is_put) return n >= ((uint64_t)1 << 25);
+  return n >= ((uint64_t)1 << 26) && n_src * (uint64_t)width >= ((uint64_t)64 << 20);
 }
 
 // nontemporal index / output streams: neutral for HBM-resident sources (A/B on one box: 638 vs 637 GB/s), +10 % when the
@@ -604,6 +738,12 @@ static constexpr bool swz_nt() { return true; }
 static int gs_grid(const agpu_pipeline* p, uint64_t items) {
   return stream_grid_for(p, (items + AGPU_BLOCK - 1) / AGPU_BLOCK);
 }
+
+#ifdef BKT_PROFILE
+extern "C" int agpu_debug_bkt_stamps(unsigned long long* out64) {  // 4 x 16 stamps
+  return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_bkt_stamps), sizeof(unsigned long long) * 64, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" {
 

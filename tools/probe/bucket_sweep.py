@@ -42,6 +42,8 @@ quick = "--quick" in sys.argv
 for a in sys.argv:
     if a.startswith("--region-bits="):
         p.set_tuning("gather_region_bits", int(a.split("=")[1]))
+    if a.startswith("--offsets="):
+        p.set_tuning("gather_offsets", int(a.split("=")[1]))
 modes = (("bucketed", 2),) if "--only-bucketed" in sys.argv else (("direct", 1), ("bucketed", 2))
 rows = []
 shapes = [(1 << 26, 1 << 22), (1 << 26, 1 << 26), (1 << 28, 1 << 24), (1 << 28, 1 << 26), (1 << 28, 1 << 28)]
