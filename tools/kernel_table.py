@@ -110,8 +110,9 @@ def main():
     m = min(n, 1 << 28)
     IDX = dev.create_empty_buffer(4 * m)
     capi.call("agpu_synth_i32", h, vp(IDX), m, 9, 0, m)  # uniform random indices in [0, m)
-    t("take f32, random idx (2^28 rows)", 12 * m / n, lambda: capi.call("agpu_take", h, 4, vp(A), m, vp(IDX), vp(O), m),
-      note="bytes/row quoted per 1e9-row column; rate = 12 B × 2^28 rows ÷ time")
+    p.set_tuning("gather_bucket", 1)
+    t("take f32, random idx, direct (2^28 rows)", 12 * m / n, lambda: capi.call("agpu_take", h, 4, vp(A), m, vp(IDX), vp(O), m),
+      note="tuning gather_bucket=1; bytes/row quoted per 1e9-row column; rate = 12 B × 2^28 rows ÷ time")
     IDX2 = dev.create_empty_buffer(4 * m)
     capi.call("agpu_synth_i32", h, vp(IDX2), m, 10, 0, m)
 
@@ -121,9 +122,9 @@ def main():
         rows[-1]["G_rows_per_s"] = round(m / rows[-1]["ms"] / 1e6, 1)
 
     fix(12)
-    p.set_tuning("gather_bucket", 2)
-    t("take f32, random idx, BUCKETED (2^28 rows)", 12 * m / n, lambda: capi.call("agpu_take", h, 4, vp(A), m, vp(IDX), vp(O), m),
-      note="tuning gather_bucket=2; not the default for take")
+    p.set_tuning("gather_bucket", 0)
+    t("take f32, random idx, default = bucketed (2^28 rows)", 12 * m / n, lambda: capi.call("agpu_take", h, 4, vp(A), m, vp(IDX), vp(O), m),
+      note="auto policy picks the bucketed form at this size")
     fix(12)
     p.set_tuning("gather_bucket", 1)
     t("put f32, random src and dst idx, direct (2^28 rows)", 16 * m / n,
