@@ -90,6 +90,7 @@ SIGNATURES = {
     "agpu_comm_reduce": [_vp, _vp, _i32, _i32, _vp, _vp, _u64, _vp],
     "agpu_comm_reduce_sum_f64": [_vp, _vp, _vp, _vp, _u64, _vp],
     "agpu_comm_final_reduce": [_vp, _vp, _i32, _i32, _i32, _vp, _u64, _vp],
+    "agpu_reduce_combine": [_vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "agpu_comm_all_reduce": [_vp, _vp, _i32, _i32, _vp, _u64],
     "agpu_comm_barrier": [_vp, _vp],
     "agpu_import_arrow": [_vp, _vp, _vp, _vp],

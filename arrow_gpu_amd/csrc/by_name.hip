@@ -236,6 +236,7 @@ extern "C" agpu_status agpu_launch_by_name_sized(agpu_pipeline* p, const char* s
     AGPU_REQUIRE(input_bytes[k] % 4 == 0, AGPU_ERR_SHAPE, "wgpu buffers are multiples of 4 bytes");
   AGPU_REQUIRE(out_bytes % 4 == 0, AGPU_ERR_SHAPE, "wgpu buffers are multiples of 4 bytes");
   AGPU_BIND_AS(p, "agpu_launch_by_name_sized");
+  agpu_scope_label(p, intern_label(shader_key, entry_point));  // [ref: insert_debug_marker(entry_point) gpu_device.rs:132]
   const std::string key(shader_key), ep(entry_point);
   const size_t s1 = key.find('/'), s2 = key.rfind('/');
   AGPU_REQUIRE(s1 != std::string::npos && s2 != s1, AGPU_ERR_ARG, "shader_key must be <crate>/<dir>/<file>");
@@ -252,7 +253,6 @@ extern "C" agpu_status agpu_launch_by_name_sized(agpu_pipeline* p, const char* s
     // rows past arrayLength(&input) count as 0 [ref: aggregate.wgsl:21-41; the loop over levels is the caller's,
     // aggregate_kernels.rs:26-43]
     NEED(1);
-    agpu_scope_label(p, intern_label(shader_key, entry_point));
     return agpu_internal_sum_level(p, dt, inputs[0], z.W(0), out, min2((uint64_t)dispatch_size, z.OW()));
   } else if (crate == "arithmetic" && has_dt && file == "scalar") {
     NEED(2);  // binding 1 is the 1-element operand
@@ -286,21 +286,17 @@ extern "C" agpu_status agpu_launch_by_name_sized(agpu_pipeline* p, const char* s
     n = min2(min2(min3(z.inv, z.W(0), z.W(1)), z.OW()) * (uint64_t)ml, z.W(2) * 32);
   } else if (crate == "routines" && dir == "32bit" && file == "take") {
     NEED(2);  // values length comes with the binding: out-of-range indices read 0, like robust access
-    agpu_scope_label(p, intern_label(shader_key, entry_point));
     return agpu_take(p, 4, inputs[0], z.W(0), static_cast<const uint32_t*>(inputs[1]), out, min3(z.inv, z.W(1), z.OW()));
   } else if (crate == "routines" && dir == "32bit" && file == "put") {
     NEED(3);  // inputs = {src, src_indexes, dst_indexes}, out = dst (binding 1, read_write)
-    agpu_scope_label(p, intern_label(shader_key, entry_point));
     return agpu_put_bounded(p, 4, inputs[0], z.W(0), static_cast<const uint32_t*>(inputs[1]), out, z.OW(),
                             static_cast<const uint32_t*>(inputs[2]), min3(z.inv, z.W(1), z.W(2)));
   } else if (crate == "routines" && dir == "bool" && file == "take") {
     NEED(2);  // one invocation per OUTPUT word of 32 gathered bits
-    agpu_scope_label(p, intern_label(shader_key, entry_point));
     return agpu_take_bits(p, inputs[0], z.W(0) * 32, static_cast<const uint32_t*>(inputs[1]), out,
                           min2(min2(z.inv, z.OW()) * 32, z.W(1)));
   } else if (crate == "routines" && dir == "bool" && file == "put") {
     NEED(3);  // one invocation per index pair
-    agpu_scope_label(p, intern_label(shader_key, entry_point));
     return agpu_put_bits_bounded(p, inputs[0], z.W(0) * 32, static_cast<const uint32_t*>(inputs[1]), out, z.OW() * 32,
                                  static_cast<const uint32_t*>(inputs[2]), min3(z.inv, z.W(1), z.W(2)));
   } else if (crate == "routines" && ((dir == "bool" && file == "merge") || (dir == "u32" && file == "merge_null_buffer"))) {

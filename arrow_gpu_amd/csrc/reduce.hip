@@ -535,6 +535,17 @@ agpu_status agpu_reduce(agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, c
   return AGPU_ERR_UNSUPPORTED;
 }
 
+agpu_status agpu_reduce_combine(agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, int32_t kind_f64,
+                                const void* records_dev, int32_t world, void* out_dev) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(records_dev && out_dev, AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(world >= 1 && world <= 256, AGPU_ERR_ARG, "1..256 records");
+  AGPU_REQUIRE((int)op >= 0 && (int)op <= 2, AGPU_ERR_ARG, "bad reduce op");
+  AGPU_REQUIRE(!kind_f64 || op == AGPU_RED_SUM, AGPU_ERR_UNSUPPORTED, "f64 partials are sums only");
+  if (dtype == AGPU_DATE32) dtype = AGPU_I32;
+  return agpu_internal_comm_finish(p, kind_f64 ? 3 : (int)op, dtype, records_dev, world, out_dev);
+}
+
 agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* validity, uint64_t n, double* out_dev) {
   AGPU_BIND(p);
   AGPU_REQUIRE(out_dev && (n == 0 || in), AGPU_ERR_ARG, "null pointer");

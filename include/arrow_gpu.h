@@ -404,6 +404,11 @@ agpu_status agpu_comm_reduce_sum_f64(agpu_comm* c, agpu_pipeline* p, const float
  * partial_dev; kind_f64 != 0: an f64 sum) */
 agpu_status agpu_comm_final_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, int32_t kind_f64,
                                    const void* partial_dev, uint64_t n_local, void* out_dev);
+/* The combine step on its own, for hosts that move the records by other means (MPI, a file, another collective):
+ * records_dev = `world` 16-byte records {statistic in the low 4 bytes (8 for an f64 sum), u64 n_local} in RANK ORDER on
+ * this device → out_dev (1 element).  Exactly what agpu_comm_reduce runs after its all-gather; no communicator needed. */
+agpu_status agpu_reduce_combine(agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, int32_t kind_f64,
+                                const void* records_dev, int32_t world, void* out_dev);
 /* plain in-place ncclAllReduce (null counts, row counts: integer statistics whose order cannot matter) */
 agpu_status agpu_comm_all_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, agpu_comm_dtype ctype, void* buf_dev,
                                  uint64_t count);

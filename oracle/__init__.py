@@ -345,3 +345,12 @@ def sharded_reduce_sum_f64(shards, validities=None) -> float:
         if len(s):
             acc = acc + reduce_sum_f64(s, v)
     return acc
+
+
+def combine_records(op, dtype, records):
+    """The rank-ordered combine of the multi-GPU final reduce on the gathered records [(statistic, n_local), …] — what
+    comm_finish_*_kernel (arrow_gpu_amd/csrc/reduce.hip) does after the all-gather.  Same rule as sharded_reduce."""
+    npd = NP_DTYPE[dtype]
+    if op == RED_SUM:
+        return reduce(RED_SUM, dtype, np.array([v for v, _ in records], dtype=npd))
+    return reduce(op, dtype, np.array([v for v, n in records if n > 0], dtype=npd))

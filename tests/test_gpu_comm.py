@@ -109,3 +109,43 @@ def test_sharded_sum_of_256k_row_shards_is_the_reference_tree(ctx):
     combined = O.reduce(O.RED_SUM, O.F32, parts)  # what comm_finish_sum_f32_kernel does with the gathered records
     assert bits(combined, np.float32) == bits(whole, np.float32)
     assert bits(O.sharded_reduce(O.RED_SUM, O.F32, np.split(host, shards)), np.float32) == bits(whole, np.float32)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8, 255, 256])
+def test_combine_of_many_ranks_records_matches_the_spec(ctx, world):
+    """The rank-ordered combine kernels with world > 1 — the step a 1-GPU box cannot reach through RCCL — fed with
+    hand-made records (NaN shards, empty shards, wrapping integer sums) and checked against oracle.combine_records."""
+    dev, p, _ = ctx
+    rng = np.random.default_rng(world)
+    out = dev.create_empty_buffer(16)
+    for dt, odt, npd in CASES:
+        if npd is np.float32:
+            vals = (rng.standard_normal(world) * 1e3).astype(np.float32)
+            vals[rng.random(world) < 0.2] = np.nan
+        else:
+            vals = rng.integers(np.iinfo(npd).min, int(np.iinfo(npd).max) + 1, world, dtype=np.int64).astype(npd)
+        n_local = rng.integers(0, 3, world).astype(np.uint64)  # a third of the shards are empty
+        for op in (capi.RED_SUM, capi.RED_MIN, capi.RED_MAX):
+            v = vals.copy()
+            if op == capi.RED_SUM:
+                v[n_local == 0] = 0  # an empty shard's local sum is 0
+                if npd is np.float32:
+                    v = np.nan_to_num(v, nan=1.5)
+            rec = np.zeros((world, 2), np.uint64)
+            rec[:, 0] = v.view(np.uint32).astype(np.uint64)
+            rec[:, 1] = n_local
+            drec = dev.create_gpu_buffer_with_data(rec)
+            capi.call("agpu_reduce_combine", p._handle, op, dt, 0, C.c_void_p(drec.ptr), world, C.c_void_p(out.ptr))
+            got = dev.retrive_data(out, 4, pipeline=p).view(npd)[0]
+            exp = O.combine_records(op, odt, [(v[r], int(n_local[r])) for r in range(world)])
+            assert bits(got, npd) == bits(exp, npd) or (npd is np.float32 and np.isnan(got) and np.isnan(exp)), (dt, op, got, exp)
+    sums = rng.standard_normal(world)
+    rec = np.zeros((world, 2), np.uint64)
+    rec[:, 0] = sums.view(np.uint64)
+    rec[:, 1] = 1
+    drec = dev.create_gpu_buffer_with_data(rec)
+    capi.call("agpu_reduce_combine", p._handle, capi.RED_SUM, capi.F32, 1, C.c_void_p(drec.ptr), world, C.c_void_p(out.ptr))
+    acc = 0.0
+    for x in sums:
+        acc = acc + float(x)
+    assert dev.retrive_data(out, 8, pipeline=p).view(np.float64)[0] == acc

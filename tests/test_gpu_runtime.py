@@ -193,6 +193,9 @@ def test_per_launch_timing(ag):
     capi.call("agpu_launch_by_name", p._handle, names[0], names[1], ins, 2, vp(out), n)
     ns2, name2 = p.last_kernel_ns()
     assert name2 == "arithmetic/f32/array::add_f32" and ns2 > 0
+    sizes = (C.c_uint64 * 2)(4 * n, 4 * n)
+    capi.call("agpu_launch_by_name_sized", p._handle, b"compare/f32/min_max", b"max_", ins, sizes, 2, vp(out), 4 * n, (n + 255) // 256)
+    assert p.last_kernel_ns()[1] == "compare/f32/min_max::max_"
     p.enable_timing(0)
     capi.call("agpu_binary", p._handle, capi.OP_ADD, capi.F32, vp(a), vp(b), vp(out), n)
     p.sync()

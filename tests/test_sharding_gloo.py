@@ -86,3 +86,60 @@ def test_final_reduce_single_process_is_identity():
     s = torch.tensor([1.5], dtype=torch.float64)
     out = sharding.final_reduce(s, None, None, None)
     assert out[0] is s and s.item() == 1.5
+
+
+# ---- the C ABI's protocol (agpu_comm_reduce: all-gather of one {statistic, n_local} record per rank, rank-ordered combine)
+# played by two gloo processes with the oracle as the shard-local kernel: every rank must arrive at the spec's value.
+def _record_worker(rank, world, port, shard_rows_list, case, q):
+    import torch.distributed as dist
+
+    import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        row0 = sum(shard_rows_list[:rank])
+        x = O.synth_f32(shard_rows_list[rank], 20250418, row0, -1000.0, 1000.0)
+        if case == "nan" and len(x):
+            x[:] = np.nan if rank == 0 else x
+        out = {}
+        for op in (O.RED_SUM, O.RED_MIN, O.RED_MAX):
+            mine = (float(O.reduce(op, O.F32, x)), len(x))
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            out[op] = float(O.combine_records(op, O.F32, gathered))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows,case", [([65536, 65536], "plain"), ([1000, 0], "empty"), ([4096, 4096], "nan"), ([70_001, 33], "plain")])
+def test_record_gather_protocol_world2_matches_the_sharded_spec(rows, case):
+    import torch.multiprocessing as mp
+
+    import oracle as O
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_record_worker, args=(r, 2, port, rows, case, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=120) for _ in range(2))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    shards, row0 = [], 0
+    for r, n in enumerate(rows):
+        x = O.synth_f32(n, 20250418, row0, -1000.0, 1000.0)
+        if case == "nan" and r == 0:
+            x[:] = np.nan
+        shards.append(x)
+        row0 += n
+    for op in (O.RED_SUM, O.RED_MIN, O.RED_MAX):
+        exp = float(O.sharded_reduce(op, O.F32, shards))
+        for rank in (0, 1):
+            got = res[rank][op]
+            assert (np.isnan(got) and np.isnan(exp)) or np.float32(got).view(np.uint32) == np.float32(exp).view(np.uint32), (op, rank, got, exp)
+    if rows == [65536, 65536]:  # shards of 256^2 rows: the sharded Sum IS the reference's whole-column tree
+        whole = np.concatenate(shards)
+        assert np.float32(res[0][O.RED_SUM]).view(np.uint32) == np.float32(O.reduce(O.RED_SUM, O.F32, whole)).view(np.uint32)
