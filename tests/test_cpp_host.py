@@ -134,3 +134,34 @@ def test_arrow_cdata_example_on_gpu():
     build_arrow_c()
     r = subprocess.run([A_EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "arrow_cdata OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ---- overlapped ingest / compute / egress from a compiled host (examples/overlap_pipeline.cpp)
+O_SRC = os.path.join(ROOT, "examples", "overlap_pipeline.cpp")
+O_EXE = os.path.join(ROOT, "tests", "cpp", "build", "overlap_pipeline")
+
+
+def build_overlap():
+    os.makedirs(os.path.dirname(O_EXE), exist_ok=True)
+    if os.path.exists(O_EXE) and os.path.getmtime(O_EXE) >= max(os.path.getmtime(O_SRC), os.path.getmtime(os.path.join(ROOT, "include", "arrow_gpu.h"))):
+        return
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-Wall", "-x", "c++", O_SRC, "-o", O_EXE, f"-L{LIBDIR}", "-larrow_gpu_hip",
+           "-Wl,-rpath," + LIBDIR, "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_overlap_pipeline_example_compiles():
+    build_overlap()
+
+
+@pytest.mark.gpu
+def test_overlap_pipeline_example_on_gpu():
+    import json
+
+    build_overlap()
+    r = subprocess.run([O_EXE, str(50_000_003), str(1 << 22)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ok"] is True and line["rows"] == 50_000_003
+    print(r.stdout.strip())
