@@ -181,6 +181,7 @@ def test_per_launch_timing(ag):
     a, b, out = (dev.create_empty_buffer(4 * n) for _ in range(3))
     capi.call("agpu_synth_f32", p._handle, vp(a), n, 1, 0, C.c_float(-1), C.c_float(1))
     capi.call("agpu_synth_f32", p._handle, vp(b), n, 2, 0, C.c_float(-1), C.c_float(1))
+    p.enable_timing(0)  # whatever AGPU_PROFILE set for new pipelines: start from "off"
     assert capi.lib().agpu_pipeline_last_kernel_ns(p._handle, C.byref(C.c_uint64()), None) == capi.ERR_ARG  # nothing timed yet
     p.enable_timing(3)  # roctx ranges + event pair
     capi.call("agpu_binary", p._handle, capi.OP_ADD, capi.F32, vp(a), vp(b), vp(out), n)
