@@ -233,7 +233,15 @@ __device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
 // + 2/11 z⁴ evaluated in f32 (it weighs < 1 % of the result), the division as an f32 reciprocal + one f64 Newton step,
 // the rest in f64, ONE rounding to f32.  (The f32 library logf measures 2 ULP on gfx950; the f64 library log is
 // VALU-bound at 37 % of HBM — tests/tools/math_ulp.py, profiles/r01_kernel_table.json.)
-__device__ __forceinline__ float log_f32_dev(float x) {
+// 128-entry table shared by log and pow: interval j of the mantissa [1 + j/128, 1 + (j+1)/128) → rc ≈ 1/centre (the
+// mantissa is halved into [0.707, 1) from j = 53 on) and lc = −log2(rc); built once per device (pow_build_kernel), staged
+// in LDS by the tile kernels, reachable from every other code path (tails, fused chains) through g_pow_tab.
+struct alignas(16) PowTab {
+  double rc, lc;
+};
+__device__ const PowTab* g_pow_tab = nullptr;
+
+__device__ __forceinline__ float log_f32_general(float x) {  // any operand: 0, negatives, NaN, inf, denormals
   if (!(x > 0.0f) || !(x < __builtin_inff())) {  // 0, negatives, NaN, +inf
     if (x == 0.0f) return -__builtin_inff();
     if (x < 0.0f || x != x) return __builtin_nanf("");
@@ -257,6 +265,35 @@ __device__ __forceinline__ float log_f32_dev(float x) {
   pf = __builtin_fmaf(zf, pf, 0.6666667f);
   const double t = fma(s * z, (double)pf, s + s);
   return (float)fma((double)e, 0x1.62e42fefa39efp-1, t);
+}
+
+// Positive normal finite x — what a wave of ordinary data consists of: ln x = (e + lc_j)·ln2 + log1p(u), u = m·rc_j − 1
+// (|u| < 2^-7, exact in f64), log1p(u) = u − u²/2 + u³·q(u) with the cubic q in f32 — the table form of pow's logarithm:
+// no division, no frexp, 11 f64-class instructions instead of 21 (the atanh form above is VALU-bound at 8 B/row:
+// 45 VALU instructions per row, 0.76 of the HBM roof).  ≤ 1 ULP like the general form (log2 to 2^-33 relative).
+__device__ __forceinline__ bool log_ordinary(float x) {
+  return (__builtin_bit_cast(uint32_t, x) - 0x00800000u) < 0x7f000000u;
+}
+template <typename TabPtr>
+__device__ __forceinline__ float log_f32_fast(TabPtr tab, float x) {
+  const uint32_t xb = __builtin_bit_cast(uint32_t, x);
+  const uint32_t mant = xb & 0x007fffffu;
+  const uint32_t j = mant >> 16;
+  const bool big = j >= 53u;
+  const int e = (int)(xb >> 23) - 127 + (big ? 1 : 0);
+  const uint32_t mhi = (mant >> 3) | (big ? 0x3fe00000u : 0x3ff00000u);
+  const double m = __builtin_bit_cast(double, ((uint64_t)mhi << 32) | (uint64_t)(mant << 29));
+  const PowTab T = tab[j];
+  const double u = fma(m, T.rc, -1.0);
+  const float uf = (float)u;
+  float q = __builtin_fmaf(uf, -0x1.5555555555555p-3f, 0x1.999999999999ap-3f);  // −1/6, 1/5
+  q = __builtin_fmaf(uf, q, -0.25f);
+  q = __builtin_fmaf(uf, q, 0x1.5555555555555p-2f);  // 1/3
+  const double l1p = fma(u * u, fma(u, (double)q, -0.5), u);
+  return (float)fma((double)e + T.lc, 0x1.62e42fefa39efp-1, l1p);
+}
+__device__ __forceinline__ float log_f32_dev(float x) {
+  return log_ordinary(x) ? log_f32_fast(g_pow_tab, x) : log_f32_general(x);
 }
 
 // sinh: a = |x| = k·ln2 + r (|r| ≤ ln2/2); cosh r = C and sinh r = S from the even / odd Taylor halves (inner terms in
@@ -469,9 +506,6 @@ static agpu_status launch_shift(agpu_pipeline* p, bool left, const void* a, cons
 // v_ldexp_f64 by k (handles overflow / underflow / denormal results) and ONE rounding to f32.
 // Validated against f64 pow over 6 × 4 M samples (generic, full exponent range, x → 1 with huge y, denormal x,
 // |y| ≤ 60) in tools/probe/pow_emul.py and on the device in tests/test_gpu_parity.py.
-struct alignas(16) PowTab {
-  double rc, lc;
-};
 __global__ void pow_build_kernel(PowTab* tab) {
   const int j = threadIdx.x;  // interval j of the f64 mantissa: [1 + j/128, 1 + (j+1)/128)
   if (j >= 128) return;
@@ -679,6 +713,70 @@ static agpu_status launch_pow_f32(agpu_pipeline* p, const void* a, const void* b
   if (done < n) {
     const int grid = stream_grid_for(p, (n - done + AGPU_BLOCK - 1) / AGPU_BLOCK);
     hipLaunchKernelGGL((pow_tail_kernel<MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po, done, n, tab);
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+// f32 log: the same tile shape as pow_kernel (256-thread workgroups, the 2 KiB table staged in LDS once per workgroup,
+// 2 packs per lane in flight, one vote per wave and tile between the table form and the general form).
+__global__ __launch_bounds__(AGPU_BLOCK) void log_kernel(const float* a, float* out, uint64_t ntiles, const PowTab* gtab) {
+  constexpr int U = AGPU_POW_U;
+  constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;
+  __shared__ PowTab tab[128];
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out);
+  uint64_t t = blockIdx.x;
+  f32x4 xa[U];
+  auto load_tile = [&](uint64_t tile) {
+    static_for<U>([&](auto u) { xa[u] = __builtin_nontemporal_load(a4 + tile * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
+  };
+  if (t < ntiles) load_tile(t);
+  if (threadIdx.x < 128) reinterpret_cast<u32x4*>(tab)[threadIdx.x] = reinterpret_cast<const u32x4*>(gtab)[threadIdx.x];
+  __syncthreads();
+  while (t < ntiles) {
+    const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
+    bool ok = true;
+    static_for<U>([&](auto u) { ok = ok && log_ordinary(xa[u].x) && log_ordinary(xa[u].y) && log_ordinary(xa[u].z) && log_ordinary(xa[u].w); });
+    if (__all(ok)) {
+      static_for<U>([&](auto u) {
+        const f32x4 r = f32x4{log_f32_fast(tab, xa[u].x), log_f32_fast(tab, xa[u].y), log_f32_fast(tab, xa[u].z), log_f32_fast(tab, xa[u].w)};
+        __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
+      });
+    } else {  // per element: the table form where it applies (same bits as above), the general form elsewhere
+      static_for<U>([&](auto u) {
+        const f32x4 r = f32x4{log_ordinary(xa[u].x) ? log_f32_fast(tab, xa[u].x) : log_f32_general(xa[u].x),
+                              log_ordinary(xa[u].y) ? log_f32_fast(tab, xa[u].y) : log_f32_general(xa[u].y),
+                              log_ordinary(xa[u].z) ? log_f32_fast(tab, xa[u].z) : log_f32_general(xa[u].z),
+                              log_ordinary(xa[u].w) ? log_f32_fast(tab, xa[u].w) : log_f32_general(xa[u].w)};
+        __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
+      });
+    }
+    t += gridDim.x;
+    if (t < ntiles) load_tile(t);
+  }
+}
+__global__ __launch_bounds__(AGPU_BLOCK) void log_tail_kernel(const float* a, float* out, uint64_t first, uint64_t n) {
+  for (uint64_t i = first + (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_BLOCK)
+    out[i] = log_f32_dev(a[i]);
+}
+static agpu_status launch_log_f32(agpu_pipeline* p, const void* a, void* out, uint64_t n) {
+  if (n == 0) return AGPU_OK;
+  const float* pa = static_cast<const float*>(a);
+  float* po = static_cast<float*>(out);
+  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_BLOCK * AGPU_POW_U * 4;
+  uint64_t done = 0;
+  if (aligned16(a) && aligned16(out)) {
+    const uint64_t ntiles = n / TILE_ROWS;
+    if (ntiles) {
+      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p))), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
+                         static_cast<const PowTab*>(p->dev->pow_table));
+      done = ntiles * TILE_ROWS;
+    }
+  }
+  if (done < n) {
+    const int grid = stream_grid_for(p, (n - done + AGPU_BLOCK - 1) / AGPU_BLOCK);
+    hipLaunchKernelGGL(log_tail_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, po, done, n);
   }
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
@@ -989,6 +1087,8 @@ agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table) {
   hipLaunchKernelGGL(pow_build_kernel, dim3(1), dim3(128), 0, nullptr, static_cast<PowTab*>(pow_table));
   AGPU_HIP(hipGetLastError());
   AGPU_HIP(hipStreamSynchronize(nullptr));
+  const PowTab* tp = static_cast<const PowTab*>(pow_table);  // this device's copy of the module gets this device's table
+  AGPU_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pow_tab), &tp, sizeof(tp), 0, hipMemcpyHostToDevice));
   return AGPU_OK;
 }
 
@@ -1520,7 +1620,7 @@ agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, con
         case AGPU_UN_CBRT: UN_F32(UnCbrt);
         case AGPU_UN_EXP: UN_F32(UnExp);
         case AGPU_UN_EXP2: UN_F32(UnExp2);
-        case AGPU_UN_LOG: UN_F32(UnLog);
+        case AGPU_UN_LOG: return launch_log_f32(p, in, out, n);
         case AGPU_UN_LOG2: UN_F32(UnLog2);
         case AGPU_UN_SIN: UN_F32(UnSin);
         case AGPU_UN_COS: UN_F32(UnCos);

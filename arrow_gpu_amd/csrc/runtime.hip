@@ -175,13 +175,30 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
     agpu_set_error("device %d is %s; this library is built for gfx950 only", ordinal, d->props.gcnArchName);
     return AGPU_ERR_NO_DEVICE;
   }
-  hipError_t me = hipMalloc(&d->trig16_table, AGPU_TABLE_BYTES);
-  d->pow_table = me == hipSuccess ? static_cast<char*>(d->trig16_table) + 512 * 16 : nullptr;
-  agpu_status ts = me == hipSuccess ? agpu_internal_build_tables(d->trig16_table, d->pow_table) : AGPU_ERR_HIP;
-  if (ts != AGPU_OK) {
-    if (me != hipSuccess) agpu_set_error("hipMalloc of the function tables failed: %s", hipGetErrorString(me));
-    if (d->trig16_table) (void)hipFree(d->trig16_table);
-    return ts;
+  // Function tables (10 KiB): ONE copy per physical device for the life of the process — every agpu_device created on
+  // the ordinal shares it, and the device-side pointer elementwise.hip keeps (g_pow_tab, read by tails and fused chains)
+  // never dangles when one of several handles on the same GPU is destroyed.
+  {
+    static std::mutex tab_mu;
+    static void* tab_of[64] = {nullptr};
+    std::lock_guard<std::mutex> lock(tab_mu);
+    const int slot = ordinal < 64 ? ordinal : 63;
+    if (!tab_of[slot]) {
+      void* t = nullptr;
+      hipError_t me = hipMalloc(&t, AGPU_TABLE_BYTES);
+      if (me != hipSuccess) {
+        agpu_set_error("hipMalloc of the function tables failed: %s", hipGetErrorString(me));
+        return AGPU_ERR_HIP;
+      }
+      agpu_status ts = agpu_internal_build_tables(t, static_cast<char*>(t) + 512 * 16);
+      if (ts != AGPU_OK) {
+        (void)hipFree(t);
+        return ts;
+      }
+      tab_of[slot] = t;
+    }
+    d->trig16_table = tab_of[slot];
+    d->pow_table = static_cast<char*>(d->trig16_table) + 512 * 16;
   }
   d->cache_cap = d->props.totalGlobalMem / 2;  // cached (idle) blocks never hold more than half of HBM
   *out_device = d.release();
@@ -283,7 +300,6 @@ agpu_status agpu_device_destroy(agpu_device* dev) {
     dev->flag_slabs.clear();
   }
   agpu_internal_free_staging(dev);
-  if (dev->trig16_table) (void)hipFree(dev->trig16_table);
   delete dev;
   return AGPU_OK;
 }
