@@ -229,10 +229,6 @@ __device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
   return (float)v;
 }
 
-// log: x = m·2^e with m ∈ [√½, √2), s = (m−1)/(m+1), log m = 2s + s·z·P(z), z = s² (|s| ≤ 0.172), P = 2/3 + 2/5 z + …
-// + 2/11 z⁴ evaluated in f32 (it weighs < 1 % of the result), the division as an f32 reciprocal + one f64 Newton step,
-// the rest in f64, ONE rounding to f32.  (The f32 library logf measures 2 ULP on gfx950; the f64 library log is
-// VALU-bound at 37 % of HBM — tests/tools/math_ulp.py, profiles/r01_kernel_table.json.)
 // 128-entry table shared by log and pow: interval j of the mantissa [1 + j/128, 1 + (j+1)/128) → rc ≈ 1/centre (the
 // mantissa is halved into [0.707, 1) from j = 53 on) and lc = −log2(rc); built once per device (pow_build_kernel), staged
 // in LDS by the tile kernels, reachable from every other code path (tails, fused chains) through g_pow_tab.
@@ -241,6 +237,11 @@ struct alignas(16) PowTab {
 };
 __device__ const PowTab* g_pow_tab = nullptr;
 
+// log, general form (specials and denormals; also the form every operand took in round 1): x = m·2^e with
+// m ∈ [√½, √2), s = (m−1)/(m+1), log m = 2s + s·z·P(z), z = s² (|s| ≤ 0.172), P = 2/3 + 2/5 z + … + 2/11 z⁴ evaluated in
+// f32 (it weighs < 1 % of the result), the division as an f32 reciprocal + one f64 Newton step, the rest in f64, ONE
+// rounding to f32.  (The f32 library logf measures 2 ULP on gfx950; the f64 library log is VALU-bound at 37 % of HBM —
+// tests/tools/math_ulp.py, profiles/r01_kernel_table.json.)
 __device__ __forceinline__ float log_f32_general(float x) {  // any operand: 0, negatives, NaN, inf, denormals
   if (!(x > 0.0f) || !(x < __builtin_inff())) {  // 0, negatives, NaN, +inf
     if (x == 0.0f) return -__builtin_inff();
