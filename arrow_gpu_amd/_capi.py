@@ -97,6 +97,19 @@ SIGNATURES = {
     "agpu_export_arrow": [_vp, _vp, _vp, _vp],
     "agpu_arrow_column_free": [_vp, _vp],
     "agpu_staged_copy": [_vp, _vp, _vp, _sz, _i32],
+    "agpu_ipc_open": [_vp, _u64, _pp],
+    "agpu_ipc_close": [_vp],
+    "agpu_ipc_num_fields": [_vp, C.POINTER(_i32)],
+    "agpu_ipc_field_info": [_vp, _i32, _vp],
+    "agpu_ipc_num_batches": [_vp, C.POINTER(C.c_int64)],
+    "agpu_ipc_batch_rows": [_vp, C.c_int64, C.POINTER(C.c_int64)],
+    "agpu_ipc_column_view": [_vp, C.c_int64, _i32, _vp, _vp],
+    "agpu_ipc_read_column": [_vp, C.c_int64, _i32, _vp, _vp],
+    "agpu_ipc_writer_create": [_vp, _i32, _i32, _i32, _pp],
+    "agpu_ipc_writer_write_batch": [_vp, _vp],
+    "agpu_ipc_writer_write_device_batch": [_vp, _vp, _vp],
+    "agpu_ipc_writer_finish": [_vp, _pp, C.POINTER(_u64)],
+    "agpu_ipc_writer_destroy": [_vp],
     "agpu_binary": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
     "agpu_scalar": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
     "agpu_unary": [_vp, _i32, _i32, _vp, _vp, _u64],
@@ -137,6 +150,8 @@ _RESTYPES = {
     "agpu_build_info": C.c_char_p,
     "agpu_dtype_size": _sz,
     "agpu_bitmap_bytes": _sz,
+    "agpu_ipc_close": None,
+    "agpu_ipc_writer_destroy": None,
 }
 # functions whose int result is NOT an agpu_status
 _NOT_STATUS = set(_RESTYPES)
@@ -165,6 +180,10 @@ ArrowArrayStruct._fields_ = [
 class ArrowColumnStruct(C.Structure):  # agpu_arrow_column
     _fields_ = [("dtype", C.c_int32), ("length", C.c_uint64), ("null_count", C.c_int64), ("values", C.c_void_p),
                 ("validity", C.c_void_p), ("values_bytes", C.c_uint64), ("validity_bytes", C.c_uint64)]
+
+
+class IpcFieldStruct(C.Structure):  # agpu_ipc_field
+    _fields_ = [("name", C.c_char_p), ("format", C.c_char_p), ("dtype", C.c_int32), ("nullable", C.c_int32)]
 
 
 class ArrowErrorGPU(RuntimeError):

@@ -46,14 +46,35 @@ struct VecOf {
   typedef T type __attribute__((ext_vector_type(N)));
 };
 
+// 8-bit elements are the exception on the LOAD side: legalising a <16 x i8> load LLVM re-creates it as <4 x i32> and
+// drops !nontemporal (every u8 / i8 kernel ran 7 % below the same bytes read as i32 — tools/probe/subword_vs_word.py),
+// while a load that is dword-typed from the start — and stays so past InstCombine — keeps the bit; the bytes are re-typed
+// in registers.
 template <bool NT, typename T, int N>
 __device__ __forceinline__ PackN<T, N> load_pack(const T* p) {
-  typedef typename VecOf<T, N>::type V;
-  const V r = ld_vec<NT>(reinterpret_cast<const V*>(p));
-  PackN<T, N> out;
+  if constexpr (NT && sizeof(T) == 1 && (N % 4) == 0) {
+    typedef typename VecOf<uint32_t, N / 4>::type W;
+    const W r0 = __builtin_nontemporal_load(reinterpret_cast<const W*>(p));
+    struct Words {
+      uint32_t w[N / 4];
+    } r;
 #pragma unroll
-  for (int k = 0; k < N; k++) out.v[k] = r[k];
-  return out;
+    for (int k = 0; k < N / 4; k++) {
+      uint32_t x = r0[k];
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass of this translation unit has no "v" registers
+      asm volatile("" : "+v"(x));  // opaque to InstCombine: load + bitcast would be merged back into the <N x i8> load
+#endif
+      r.w[k] = x;
+    }
+    return __builtin_bit_cast(PackN<T, N>, r);
+  } else {
+    typedef typename VecOf<T, N>::type V;
+    const V r = ld_vec<NT>(reinterpret_cast<const V*>(p));
+    PackN<T, N> out;
+#pragma unroll
+    for (int k = 0; k < N; k++) out.v[k] = r[k];
+    return out;
+  }
 }
 template <bool NT, typename T, int N>
 __device__ __forceinline__ void store_pack(T* p, const PackN<T, N>& v) {
@@ -901,36 +922,39 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel_unaligned(const TI* in,
 }
 
 // Widening (u8→f32, i8→i32, u8→u16, u16→f32 …): with cvt_kernel the narrow side moves 4–8 B per lane (256–512-byte
-// wave loads).  Here every lane loads a full 16-byte vector (the wave takes one contiguous 1 KiB chunk), the chunk is
-// transposed through 1 KiB of LDS (one ds_write_b128 per lane, conflict-free ds_read_b32/b64 back), and each of the
-// R = sizeof(TO)/sizeof(TI) stores of the wave is a fully coalesced 1 KiB row.  One wave per block, no barrier needed
-// beyond the single-wave __syncthreads.  Measured on cast u8→f32 at 1e9 rows: 5.4 → 6.4 TB/s
-// (tools/probe/cast_probe.hip, profiles/r01_sweep_cast.json).
+// wave loads).  Here every lane loads a full 16-byte vector (the wave takes one contiguous 1 KiB chunk) and the chunk is
+// transposed INSIDE the wave so that each of the R = sizeof(TO)/sizeof(TI) stores is a fully coalesced 1 KiB row: store
+// j, lane l needs the PIECE = 16/R input bytes at chunk offset (64 j + l)·PIECE, which sit in lane (64 j + l)/R at piece
+// l mod R — four ds_bpermute_b32 (one per dword of the source vector; the LDS crossbar, no LDS memory, no barrier) and
+// a select.  One wave per block.  Measured on cast u8→f32 at 1e9 rows, same process (tools/probe/cast_sweep.py,
+// profiles/r02_sweep_cast.json): 4-byte loads 5.4–5.9 TB/s, transposition through 1 KiB of LDS 5.9, this form 6.36.
 template <typename TI, typename TO, typename Conv>
 __global__ __launch_bounds__(AGPU_WAVE) void cvt_wide_kernel(const TI* in, TO* out, uint64_t nchunks) {
   constexpr int R = sizeof(TO) / sizeof(TI);   // 2 or 4 stores per load
   constexpr int NO = 16 / sizeof(TO);          // output elements per lane per store
-  constexpr int PIECE = 16 / R;                // input bytes feeding one store of one lane: 4 or 8
-  __shared__ __attribute__((aligned(16))) uint8_t lds[AGPU_WAVE * 16];
   const uint32_t lane = threadIdx.x;
   for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
-    __syncthreads();  // previous iteration's reads are done
-    *reinterpret_cast<u32x4*>(lds + lane * 16) = v;
-    __syncthreads();
     static_for<R>([&](auto j) {
-      const uint32_t g = (uint32_t)j * AGPU_WAVE + lane;  // slot of this lane's store inside the chunk
+      const int src = (int)(((uint32_t)j * (AGPU_WAVE / R) + lane / R) * 4);  // byte address of the source lane
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.x);
+      const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.y);
+      const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.z);
+      const uint32_t w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.w);
       PackN<TI, NO> x;
-      if constexpr (PIECE == 4) {
-        const uint32_t w = *reinterpret_cast<const uint32_t*>(lds + g * 4);
+      if constexpr (R == 4) {
+        const uint32_t sel = lane & 3u;
+        const uint32_t w = sel == 0 ? w0 : sel == 1 ? w1 : sel == 2 ? w2 : w3;
         x = __builtin_bit_cast(PackN<TI, NO>, w);
       } else {
-        const u32x2 w = *reinterpret_cast<const u32x2*>(lds + g * 8);
+        const bool hi = (lane & 1u) != 0;
+        const u32x2 w = {hi ? w2 : w0, hi ? w3 : w1};
         x = __builtin_bit_cast(PackN<TI, NO>, w);
       }
       PackN<TO, NO> r;
 #pragma unroll
       for (int k = 0; k < NO; k++) r.v[k] = Conv::ap(x.v[k]);
+      const uint32_t g = (uint32_t)j * AGPU_WAVE + lane;  // slot of this lane's store inside the chunk
       store_pack<(AGPU_STREAM_NT & 2) != 0, TO, NO>(out + (c * (uint64_t)(AGPU_WAVE * R) + g) * NO, r);
     });
   }
@@ -1017,25 +1041,37 @@ struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders
 
 // 8-bit sources (sin_u8 / cos_i8 / sinh_u8 …): only 256 distinct inputs exist, so evaluating the function per row
 // makes a 5 B/row stream VALU-bound (3.5 TB/s measured).  Each 256-thread block builds the 256-entry result table in
-// LDS once (one evaluation per thread, the SAME device function as the f32 kernel ⇒ identical bits), then streams a
-// 4096-row tile: one 4-byte load (4 rows) and one nontemporal 16-byte store per lane per step, 4 LDS reads per store.
+// LDS once (one evaluation per thread, the SAME device function as the f32 kernel ⇒ identical bits), then streams
+// 4096-row tiles: every wave takes one contiguous 1 KiB chunk with 16-byte loads and transposes it inside the wave
+// (cvt_wide_kernel's ds_bpermute shape) so that each of its 4 nontemporal stores is a coalesced 1 KiB row; 4 LDS reads
+// per store.  The next tile's load is issued before the current tile's lookups.
 template <typename TI, typename F>
 __global__ __launch_bounds__(AGPU_BLOCK) void lut8_kernel(const TI* in, float* out, uint64_t ntiles) {
-  constexpr int U = 4;
-  constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;  // packs of 4 rows
+  constexpr uint32_t WAVES = AGPU_BLOCK / AGPU_WAVE;
   __shared__ float lut[256];
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  const u32x4* in16 = reinterpret_cast<const u32x4*>(in);
+  f32x4* out4 = reinterpret_cast<f32x4*>(out);
+  uint64_t t = blockIdx.x;
+  u32x4 v = {0, 0, 0, 0};
+  if (t < ntiles) v = __builtin_nontemporal_load(in16 + (t * WAVES + wave) * AGPU_WAVE + lane);
   lut[threadIdx.x] = F::ap((float)(TI)(uint8_t)threadIdx.x, 0.0f);  // indexed by the raw byte
   __syncthreads();
-  const uint32_t* in32 = reinterpret_cast<const uint32_t*>(in);
-  f32x4* out4 = reinterpret_cast<f32x4*>(out);
-  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
-    uint32_t w[U];
-    static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in32 + p0 + (uint64_t)u * AGPU_BLOCK); });
-    static_for<U>([&](auto u) {
-      const uint32_t x = w[u];
+  while (t < ntiles) {
+    const uint64_t c = t * WAVES + wave;
+    const u32x4 cur = v;
+    t += gridDim.x;
+    if (t < ntiles) v = __builtin_nontemporal_load(in16 + (t * WAVES + wave) * AGPU_WAVE + lane);
+    static_for<4>([&](auto j) {
+      const int src = (int)(((uint32_t)j * 16u + (lane >> 2)) * 4u);
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.x);
+      const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.y);
+      const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.z);
+      const uint32_t w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.w);
+      const uint32_t sel = lane & 3u;
+      const uint32_t x = sel == 0 ? w0 : sel == 1 ? w1 : sel == 2 ? w2 : w3;
       f32x4 r = {lut[x & 255u], lut[(x >> 8) & 255u], lut[(x >> 16) & 255u], lut[x >> 24]};
-      __builtin_nontemporal_store(r, out4 + p0 + (uint64_t)u * AGPU_BLOCK);
+      __builtin_nontemporal_store(r, out4 + c * (AGPU_WAVE * 4) + (uint32_t)j * AGPU_WAVE + lane);
     });
   }
 }
@@ -1048,7 +1084,7 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
   const TI* pi = static_cast<const TI*>(in);
   float* po = static_cast<float*>(out);
   uint64_t done = 0;
-  if (aligned_to(in, 4) && aligned16(out)) {
+  if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
       const int grid = stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p));
@@ -1108,18 +1144,21 @@ __device__ __forceinline__ float trig16_eval(TabPtr tab, uint32_t raw16) {
   return (float)r;
 }
 
+// 4096-row tiles per 256-thread block: every wave takes two contiguous 1 KiB chunks (512 rows each) with 16-byte loads and
+// transposes each inside the wave (ds_bpermute, as cvt_wide_kernel) so that both stores of a chunk are coalesced 1 KiB rows.
 template <typename TI, int WANT_COS>
 __global__ __launch_bounds__(AGPU_BLOCK) void trig16_kernel(const TI* in, float* out, uint64_t ntiles,
                                                            const SinCos64* gtab) {
-  constexpr int U = 4;
-  constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;  // packs of 4 rows (8 bytes in, 16 bytes out)
+  constexpr int U = 2;  // chunks per wave per tile
+  constexpr uint32_t WAVES = AGPU_BLOCK / AGPU_WAVE;
   __shared__ SinCos64 tab[512];
-  const u32x2* in2 = reinterpret_cast<const u32x2*>(in);
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  const u32x4* in16 = reinterpret_cast<const u32x4*>(in);
   f32x4* out4 = reinterpret_cast<f32x4*>(out);
   uint64_t t = blockIdx.x;
-  u32x2 w[U];
+  u32x4 w[U];
   if (t < ntiles)  // the first tile's loads go out before the table copy so the two latencies overlap
-    static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in2 + t * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
+    static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in16 + ((t * WAVES + wave) * U + (uint32_t)u) * AGPU_WAVE + lane); });
   {
     const u32x4* g = reinterpret_cast<const u32x4*>(gtab);
     u32x4* l = reinterpret_cast<u32x4*>(tab);
@@ -1128,16 +1167,26 @@ __global__ __launch_bounds__(AGPU_BLOCK) void trig16_kernel(const TI* in, float*
   }
   __syncthreads();
   while (t < ntiles) {
-    const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
-    static_for<U>([&](auto u) {
-      const u32x2 x = w[u];
-      f32x4 r = {trig16_eval<TI, WANT_COS>(tab, x.x & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, x.x >> 16),
-                 trig16_eval<TI, WANT_COS>(tab, x.y & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, x.y >> 16)};
-      __builtin_nontemporal_store(r, out4 + p0 + (uint64_t)u * AGPU_BLOCK);
-    });
+    const uint64_t c0 = (t * WAVES + wave) * U;
+    u32x4 cur[U];
+    static_for<U>([&](auto u) { cur[u] = w[u]; });
     t += gridDim.x;
     if (t < ntiles)
-      static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in2 + t * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
+      static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in16 + ((t * WAVES + wave) * U + (uint32_t)u) * AGPU_WAVE + lane); });
+    static_for<U>([&](auto u) {
+      static_for<2>([&](auto j) {
+        const int src = (int)(((uint32_t)j * 32u + (lane >> 1)) * 4u);
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur[u].x);
+        const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur[u].y);
+        const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur[u].z);
+        const uint32_t w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur[u].w);
+        const bool hi = (lane & 1u) != 0;
+        const uint32_t x = hi ? w2 : w0, y = hi ? w3 : w1;
+        f32x4 r = {trig16_eval<TI, WANT_COS>(tab, x & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, x >> 16),
+                   trig16_eval<TI, WANT_COS>(tab, y & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, y >> 16)};
+        __builtin_nontemporal_store(r, out4 + (c0 + (uint32_t)u) * (AGPU_WAVE * 2) + (uint32_t)j * AGPU_WAVE + lane);
+      });
+    });
   }
 }
 // rows [first, n), one per lane, same arithmetic straight from the global table (tails and unaligned columns)
@@ -1157,7 +1206,7 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
   float* po = static_cast<float*>(out);
   const SinCos64* tab = static_cast<const SinCos64*>(p->dev->trig16_table);
   uint64_t done = 0;
-  if (aligned_to(in, 8) && aligned16(out)) {
+  if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
       hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS>), dim3(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p))), dim3(AGPU_BLOCK), 0, p->stream, pi,

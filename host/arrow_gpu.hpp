@@ -1163,4 +1163,181 @@ AGPU_SHARDED_DEFAULT(min_sharded)
 AGPU_SHARDED_DEFAULT(max_sharded)
 #undef AGPU_SHARDED_DEFAULT
 
+// ------------------------------------------------------------------ Arrow IPC files / streams (include/arrow_gpu.h "Arrow IPC")
+// Not in the reference (arrays exist only as host Vecs [primitive_array_gpu.rs:22-104]).  The reader borrows the bytes
+// (map_file(): the whole file memory-mapped, so a column goes page cache → HBM without a host copy in between).
+struct IpcField {
+  std::string name, format;
+  int dtype;  // agpu_dtype or -1: no GPU array type (the column is skipped)
+  bool nullable;
+};
+namespace detail {
+inline ArrowArrayGPU array_of_column(const agpu_arrow_column& col, const DevicePtr& dev) {
+  auto take = [&](void* ptr, uint64_t bytes) {
+    auto b = std::make_shared<Buffer>();
+    b->ptr = ptr;
+    b->bytes = bytes;
+    b->dev = dev;
+    return b;
+  };
+  BufferPtr values = take(col.values, col.values_bytes);
+  std::optional<NullBitBufferGpu> nulls;
+  if (col.validity) nulls = NullBitBufferGpu{take(col.validity, col.validity_bytes), (size_t)col.length, dev};
+  const size_t n = (size_t)col.length;
+  switch (col.dtype) {
+    case AGPU_F32: return Float32ArrayGPU(values, dev, n, nulls);
+    case AGPU_U32: return UInt32ArrayGPU(values, dev, n, nulls);
+    case AGPU_U16: return UInt16ArrayGPU(values, dev, n, nulls);
+    case AGPU_U8: return UInt8ArrayGPU(values, dev, n, nulls);
+    case AGPU_I32: return Int32ArrayGPU(values, dev, n, nulls);
+    case AGPU_I16: return Int16ArrayGPU(values, dev, n, nulls);
+    case AGPU_I8: return Int8ArrayGPU(values, dev, n, nulls);
+    case AGPU_DATE32: return Date32ArrayGPU(values, dev, n, nulls);
+    case AGPU_BOOL: return BooleanArrayGPU(values, dev, n, nulls);
+  }
+  throw ArrowErrorGPU(ArrowErrorGPU::CastingNotSupported, "unknown dtype in agpu_arrow_column");
+}
+inline agpu_arrow_column column_of_array(const ArrowArrayGPU& a) {
+  return std::visit(
+      [](const auto& x) {
+        using A = std::decay_t<decltype(x)>;
+        agpu_arrow_column col{};
+        if constexpr (std::is_same_v<A, BooleanArrayGPU>) col.dtype = AGPU_BOOL;
+        else col.dtype = A::DTYPE;
+        col.length = x.len;
+        col.null_count = x.null_buffer ? -1 : 0;
+        col.values = x.data->ptr;
+        col.values_bytes = x.data->bytes;
+        if (x.null_buffer) {
+          col.validity = x.null_buffer->bit_buffer->ptr;
+          col.validity_bytes = x.null_buffer->bit_buffer->bytes;
+        }
+        return col;
+      },
+      a);
+}
+}  // namespace detail
+
+class IpcReader {
+ public:
+  IpcReader(const void* data, size_t bytes) { open(data, bytes); }  // borrowed: keep `data` alive
+  static std::unique_ptr<IpcReader> map_file(const std::string& path);
+  IpcReader(const IpcReader&) = delete;
+  ~IpcReader();
+  const std::vector<IpcField>& fields() const { return fields_; }
+  int64_t num_batches() const {
+    int64_t n = 0;
+    check(agpu_ipc_num_batches(raw_, &n), "agpu_ipc_num_batches");
+    return n;
+  }
+  int64_t batch_rows(int64_t batch) const {
+    int64_t n = 0;
+    check(agpu_ipc_batch_rows(raw_, batch, &n), "agpu_ipc_batch_rows");
+    return n;
+  }
+  int column_index(const std::string& name) const {
+    for (size_t i = 0; i < fields_.size(); i++)
+      if (fields_[i].name == name) return (int)i;
+    throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "no column named " + name);
+  }
+  ArrowArrayGPU read_column_op(int64_t batch, int column, ArrowComputePipeline& p) const {
+    agpu_arrow_column col;
+    check(agpu_ipc_read_column(raw_, batch, column, p.h(), &col), "agpu_ipc_read_column");
+    return detail::array_of_column(col, p.device);
+  }
+  ArrowArrayGPU read_column(int64_t batch, int column, const DevicePtr& dev) const {
+    ArrowComputePipeline p(dev);
+    auto out = read_column_op(batch, column, p);
+    p.finish();
+    p.sync();  // the upload has read the source; the caller may unmap it
+    return out;
+  }
+
+ private:
+  IpcReader() = default;
+  void open(const void* data, size_t bytes) {
+    check(agpu_ipc_open(data, bytes, &raw_), "agpu_ipc_open");
+    int32_t n = 0;
+    check(agpu_ipc_num_fields(raw_, &n), "agpu_ipc_num_fields");
+    for (int32_t i = 0; i < n; i++) {
+      agpu_ipc_field f;
+      check(agpu_ipc_field_info(raw_, i, &f), "agpu_ipc_field_info");
+      fields_.push_back(IpcField{f.name ? f.name : "", f.format ? f.format : "", f.dtype, f.nullable != 0});
+    }
+  }
+  agpu_ipc_reader* raw_ = nullptr;
+  std::vector<IpcField> fields_;
+  void* map_ = nullptr;
+  size_t map_bytes_ = 0;
+};
+
+class IpcWriter {
+ public:
+  // fd ≥ 0: bytes go to that descriptor as produced; fd < 0: in memory, finish() returns them
+  IpcWriter(const std::vector<IpcField>& fields, bool file_format, int fd = -1) : n_fields_(fields.size()) {
+    std::vector<agpu_ipc_field> f(fields.size());
+    for (size_t i = 0; i < fields.size(); i++) f[i] = agpu_ipc_field{fields[i].name.c_str(), nullptr, fields[i].dtype, fields[i].nullable ? 1 : 0};
+    check(agpu_ipc_writer_create(f.data(), (int32_t)f.size(), file_format ? 1 : 0, fd, &raw_), "agpu_ipc_writer_create");
+  }
+  IpcWriter(const IpcWriter&) = delete;
+  ~IpcWriter() {
+    if (raw_) agpu_ipc_writer_destroy(raw_);
+  }
+  void write_batch_op(const std::vector<ArrowArrayGPU>& columns, ArrowComputePipeline& p) {
+    if (columns.size() != n_fields_) throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "one column per schema field");
+    std::vector<agpu_arrow_column> cols;
+    for (auto& c : columns) cols.push_back(detail::column_of_array(c));
+    check(agpu_device_sync(p.device->raw), "agpu_device_sync");  // other pipelines may still be writing the columns
+    check(agpu_ipc_writer_write_device_batch(raw_, p.h(), cols.data()), "agpu_ipc_writer_write_device_batch");
+  }
+  void write_batch(const std::vector<ArrowArrayGPU>& columns) {
+    if (columns.empty()) throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "write_batch needs a column");
+    ArrowComputePipeline p(get_gpu_device(columns[0]));
+    write_batch_op(columns, p);
+    p.finish();
+  }
+  std::vector<uint8_t> finish(uint64_t* total_bytes = nullptr) {
+    const void* data = nullptr;
+    uint64_t n = 0;
+    check(agpu_ipc_writer_finish(raw_, &data, &n), "agpu_ipc_writer_finish");
+    if (total_bytes) *total_bytes = n;
+    std::vector<uint8_t> out;
+    if (data) out.assign(static_cast<const uint8_t*>(data), static_cast<const uint8_t*>(data) + n);
+    return out;
+  }
+
+ private:
+  agpu_ipc_writer* raw_ = nullptr;
+  size_t n_fields_;
+};
+
+}  // namespace arrow_gpu
+
+// map_file needs POSIX mmap; kept at the end so the rest of the header stays free of system headers
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+namespace arrow_gpu {
+inline std::unique_ptr<IpcReader> IpcReader::map_file(const std::string& path) {
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "cannot open " + path);
+  struct stat st;
+  if (::fstat(fd, &st) != 0 || st.st_size <= 0) {
+    ::close(fd);
+    throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "cannot stat / empty file: " + path);
+  }
+  void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+  ::close(fd);
+  if (m == MAP_FAILED) throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "mmap failed: " + path);
+  std::unique_ptr<IpcReader> r(new IpcReader());
+  r->map_ = m;
+  r->map_bytes_ = (size_t)st.st_size;
+  r->open(m, r->map_bytes_);  // on failure the destructor unmaps
+  return r;
+}
+inline IpcReader::~IpcReader() {
+  if (raw_) agpu_ipc_close(raw_);
+  if (map_) ::munmap(map_, map_bytes_);
+}
 }  // namespace arrow_gpu

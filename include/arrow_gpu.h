@@ -481,6 +481,51 @@ agpu_status agpu_arrow_column_free(agpu_device* dev, agpu_arrow_column* column);
  * (to_device != 0: host → device).  Returns when the host side is complete (H2D: source consumed; D2H: data arrived). */
 agpu_status agpu_staged_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, int32_t to_device);
 
+/* ---------------------------------------------------------------- Arrow IPC: streaming format and file format
+ * Not in the reference (arrays exist only as host Vecs or wgpu buffers [ref: primitive_array_gpu.rs:22-104]); files and
+ * sockets carry Arrow IPC (arrow-rs `arrow::ipc`, pyarrow `pa.ipc`), so columns can come from and go to that format
+ * without a host-side Arrow library.  The reader BORROWS `data` (mmap the file: bytes go page cache → HBM with no copy in
+ * between) — keep it mapped until agpu_ipc_close.  Uncompressed little-endian V4/V5 metadata; columns of the nine GPU array
+ * types are readable, columns of any other type (utf8, int64, nested, dictionary …) are skipped correctly and report
+ * AGPU_ERR_UNSUPPORTED when asked for; compressed bodies → AGPU_ERR_UNSUPPORTED; malformed or truncated input →
+ * AGPU_ERR_SHAPE (every metadata access is bounds-checked).  Host-only calls (open … column_view, writer_create,
+ * write_batch, finish) need no GPU. */
+typedef struct agpu_ipc_reader agpu_ipc_reader;
+typedef struct agpu_ipc_writer agpu_ipc_writer;
+typedef struct {
+  const char* name;   /* reader: owned by the reader */
+  const char* format; /* Arrow C Data Interface format string ("f", "i", "b", "tdD", "u" …); "" when there is none; ignored by the writer */
+  int32_t dtype;      /* agpu_dtype, or -1: no GPU array type */
+  int32_t nullable;
+} agpu_ipc_field;
+agpu_status agpu_ipc_open(const void* data, uint64_t bytes, agpu_ipc_reader** out_reader);
+void agpu_ipc_close(agpu_ipc_reader* r);
+agpu_status agpu_ipc_num_fields(const agpu_ipc_reader* r, int32_t* out_n);
+agpu_status agpu_ipc_field_info(const agpu_ipc_reader* r, int32_t i, agpu_ipc_field* out);
+agpu_status agpu_ipc_num_batches(const agpu_ipc_reader* r, int64_t* out_n);
+agpu_status agpu_ipc_batch_rows(const agpu_ipc_reader* r, int64_t batch, int64_t* out_rows);
+/* column `column` of record batch `batch` as an ArrowArray / ArrowSchema pair whose buffers POINT INTO `data` (the
+ * release callbacks free only the two small structs' private parts) */
+agpu_status agpu_ipc_column_view(const agpu_ipc_reader* r, int64_t batch, int32_t column, struct ArrowArray* out_array,
+                                 struct ArrowSchema* out_schema);
+/* = agpu_ipc_column_view + agpu_import_arrow: the column in HBM, ordered on p's stream */
+agpu_status agpu_ipc_read_column(const agpu_ipc_reader* r, int64_t batch, int32_t column, agpu_pipeline* p,
+                                 agpu_arrow_column* out_column);
+/* Writer: fd ≥ 0 → bytes are written to that descriptor as they are produced (the caller opens and closes it);
+ * fd < 0 → bytes accumulate in memory and agpu_ipc_writer_finish hands out the buffer (valid until destroy).
+ * file_format != 0 → "ARROW1" file with footer; else the streaming format.  Body buffers are padded to 64 bytes. */
+agpu_status agpu_ipc_writer_create(const agpu_ipc_field* fields, int32_t n_fields, int32_t file_format, int32_t fd,
+                                   agpu_ipc_writer** out_writer);
+/* one record batch from host arrays (one ArrowArray per field, in schema order; `offset` honoured, bitmaps re-packed,
+ * null counts recomputed) */
+agpu_status agpu_ipc_writer_write_batch(agpu_ipc_writer* w, const struct ArrowArray* const* columns);
+/* one record batch from device columns (one agpu_arrow_column per field): HBM → sink; null_count −1 is counted on the GPU */
+agpu_status agpu_ipc_writer_write_device_batch(agpu_ipc_writer* w, agpu_pipeline* p, const agpu_arrow_column* columns);
+/* end-of-stream marker (+ footer for the file format).  out_data = the in-memory buffer (NULL for an fd sink); out_bytes =
+ * total bytes produced */
+agpu_status agpu_ipc_writer_finish(agpu_ipc_writer* w, const void** out_data, uint64_t* out_bytes);
+void agpu_ipc_writer_destroy(agpu_ipc_writer* w);
+
 /* ---------------------------------------------------------------- reference entry-point names
  * Keeps the reference's kernel identity for a thin shim: shader_key = the WGSL file's path under crates/ without
  * "compute_shaders/" and ".wgsl" (e.g. "arithmetic/f32/array", "compare/i32/cmp", "logical/u32/logical"),

@@ -165,3 +165,75 @@ def test_overlap_pipeline_example_on_gpu():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["ok"] is True and line["rows"] == 50_000_003
     print(r.stdout.strip())
+
+
+# ---- Arrow IPC file → HBM → kernels → Arrow IPC file from the C++ host (examples/ipc_roundtrip.cpp)
+I_SRC = os.path.join(ROOT, "examples", "ipc_roundtrip.cpp")
+I_EXE = os.path.join(ROOT, "tests", "cpp", "build", "ipc_roundtrip")
+
+
+def build_ipc():
+    os.makedirs(os.path.dirname(I_EXE), exist_ok=True)
+    deps = [I_SRC, os.path.join(ROOT, "host", "arrow_gpu.hpp"), os.path.join(ROOT, "include", "arrow_gpu.h")]
+    if os.path.exists(I_EXE) and all(os.path.getmtime(I_EXE) >= os.path.getmtime(d) for d in deps):
+        return
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-Wall", "-x", "c++", I_SRC, "-o", I_EXE, f"-L{LIBDIR}", "-larrow_gpu_hip",
+           "-Wl,-rpath," + LIBDIR]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def _ipc_input(path, n, batch_rows):
+    import numpy as np
+    import pyarrow as pa
+
+    rng = np.random.default_rng(n)
+    a, b = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    k, m = rng.integers(0, 3, n).astype(np.int32), rng.integers(0, 3, n).astype(np.int32)
+    ma, mb = rng.random(n) < 0.15, rng.random(n) < 0.15
+    t = pa.table({"a": pa.array(a, mask=ma), "note": pa.array([f"r{i % 10}" for i in range(n)]), "b": pa.array(b, mask=mb),
+                  "k": pa.array(k, mask=mb), "wide": pa.array(np.arange(n, dtype=np.int64)), "m": pa.array(m)})
+    with pa.OSFile(str(path), "wb") as f, pa.ipc.new_file(f, t.schema) as w:
+        for rb in t.to_batches(max_chunksize=batch_rows):
+            w.write_batch(rb)
+    return a, b, k, m, ma, mb
+
+
+def test_ipc_example_reads_the_schema_without_a_gpu(tmp_path):
+    import json
+
+    pytest.importorskip("pyarrow")
+    build_ipc()
+    _ipc_input(tmp_path / "in.arrow", 1000, 300)
+    r = subprocess.run([I_EXE, "--schema", str(tmp_path / "in.arrow")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    info = json.loads(r.stdout)
+    assert [(f["name"], f["format"], f["dtype"]) for f in info["fields"]] == [
+        ("a", "f", 1), ("note", "u", -1), ("b", "f", 1), ("k", "i", 5), ("wide", "l", -1), ("m", "i", 5)]
+    assert info["batch_rows"] == [300, 300, 300, 100]
+
+
+@pytest.mark.gpu
+def test_ipc_example_on_gpu(tmp_path):
+    import json
+
+    import numpy as np
+
+    import oracle as O
+
+    pa = pytest.importorskip("pyarrow")
+    build_ipc()
+    n = 1_000_003
+    a, b, k, m, ma, mb = _ipc_input(tmp_path / "in.arrow", n, 250_000)
+    r = subprocess.run([I_EXE, str(tmp_path / "in.arrow"), str(tmp_path / "out.arrow")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["ok"] is True and line["rows"] == n and line["batches"] == 5
+    got = pa.ipc.open_file(pa.memory_map(str(tmp_path / "out.arrow"))).read_all()
+    got.validate(full=True)
+    s, e = got.column("sum").combine_chunks(), got.column("eq").combine_chunks()
+    vs, ve = ~(ma | mb), ~mb
+    assert np.array_equal(np.asarray(s.is_valid()), vs) and np.array_equal(np.asarray(e.is_valid()), ve)
+    exp = O.binary(O.OP_ADD, O.F32, a, b)
+    assert np.array_equal(s.fill_null(0).to_numpy(zero_copy_only=False).view(np.uint32)[vs], exp.view(np.uint32)[vs])
+    assert np.array_equal(np.asarray(e.fill_null(False))[ve], (k == m)[ve])

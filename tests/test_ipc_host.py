@@ -1,0 +1,231 @@
+"""CPU: the C ABI's Arrow IPC reader / writer (csrc/arrow_ipc.hip) against pyarrow's — host-only calls,
+no GPU.  pyarrow writes → our reader must see the same schema, rows, values and validity (streaming and file format,
+several record batches, unsupported column types in between); our writer → pyarrow must read back equal tables (sliced
+inputs, nulls, all nine array types); truncated and corrupted input must be refused, never crash."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pa = pytest.importorskip("pyarrow")
+
+from arrow_gpu_amd import _capi as capi  # noqa: E402
+from arrow_gpu_amd.ipc import IpcReader, IpcWriter  # noqa: E402
+
+TYPES = [("f", pa.float32(), capi.F32), ("i", pa.int32(), capi.I32), ("I", pa.uint32(), capi.U32), ("s", pa.int16(), capi.I16),
+         ("S", pa.uint16(), capi.U16), ("c", pa.int8(), capi.I8), ("C", pa.uint8(), capi.U8), ("b", pa.bool_(), capi.BOOL),
+         ("tdD", pa.date32(), capi.DATE32)]
+
+
+def make_array(rng, typ, n, null_frac):
+    if typ == pa.bool_():
+        vals = rng.random(n) < 0.5
+    elif typ == pa.float32():
+        vals = rng.standard_normal(n).astype(np.float32)
+    elif typ == pa.date32():
+        vals = rng.integers(-10000, 30000, n).astype(np.int32)
+    else:
+        info = np.iinfo(typ.to_pandas_dtype())
+        vals = rng.integers(info.min, int(info.max) + 1, n).astype(typ.to_pandas_dtype())
+    mask = rng.random(n) < null_frac if null_frac else None
+    return pa.array(vals, type=typ, mask=mask)
+
+
+def make_table(rng, n, null_frac=0.2, with_unsupported=True):
+    cols, names = [], []
+    for k, (fmt, typ, _) in enumerate(TYPES):
+        cols.append(make_array(rng, typ, n, null_frac if k % 3 != 2 else 0.0))
+        names.append(f"col_{fmt}")
+        if with_unsupported and k == 1:
+            cols.append(pa.array([None if i % 7 == 0 else "s" * (i % 5) for i in range(n)], type=pa.utf8()))
+            names.append("text")
+        if with_unsupported and k == 3:
+            cols.append(pa.array([[i, i + 1] if i % 3 else None for i in range(n)], type=pa.list_(pa.int32())))
+            names.append("lists")
+            cols.append(pa.array(rng.integers(0, 1 << 40, n), type=pa.int64()))
+            names.append("wide")
+        if with_unsupported and k == 5:
+            cols.append(pa.array([{"x": i, "y": float(i)} for i in range(n)], type=pa.struct([("x", pa.int32()), ("y", pa.float64())])))
+            names.append("rec")
+            cols.append(pa.array(["a", "b", "a", None] * (n // 4) + ["a"] * (n % 4)).dictionary_encode())
+            names.append("dict")
+    return pa.table(cols, names=names)
+
+
+def serialise(table, file_format, batch_rows):
+    sink = pa.BufferOutputStream()
+    w = (pa.ipc.new_file if file_format else pa.ipc.new_stream)(sink, table.schema)
+    for b in table.to_batches(max_chunksize=batch_rows):
+        w.write_batch(b)
+    w.close()
+    return sink.getvalue().to_pybytes()
+
+
+def unpack_bits(bits, n):
+    return np.unpackbits(np.asarray(bits), bitorder="little")[:n].astype(bool)
+
+
+@pytest.mark.parametrize("file_format", [False, True])
+@pytest.mark.parametrize("n,batch_rows", [(1000, 1000), (1003, 257), (0, 10), (5, 1)])
+def test_reader_sees_what_pyarrow_wrote(file_format, n, batch_rows):
+    rng = np.random.default_rng(n + batch_rows)
+    table = make_table(rng, n)
+    data = serialise(table, file_format, batch_rows)
+    batches = table.to_batches(max_chunksize=batch_rows)
+    with IpcReader(data) as r:
+        assert [f.name for f in r.fields] == table.schema.names
+        by_name = {f.name: f for f in r.fields}
+        for fmt, _, code in TYPES:
+            assert by_name[f"col_{fmt}"].dtype == code and by_name[f"col_{fmt}"].format == fmt
+        for name in ("text", "lists", "wide", "rec", "dict"):
+            assert by_name[name].dtype == -1
+        assert by_name["text"].format == "u" and by_name["wide"].format == "l"
+        assert r.num_batches == len(batches)
+        for bi, batch in enumerate(batches):
+            assert r.batch_rows(bi) == batch.num_rows
+            for ci, f in enumerate(r.fields):
+                if f.dtype < 0:
+                    with pytest.raises(capi.OperationNotSupported):
+                        r.column_view(bi, ci)
+                    continue
+                values, validity, length, nulls = r.column_view(bi, ci)
+                col = batch.column(ci)
+                assert length == len(col) and nulls == col.null_count
+                valid = np.ones(length, bool) if validity is None else unpack_bits(validity, length)
+                assert (validity is None) == (col.null_count == 0)
+                exp_valid = np.asarray(col.is_valid())
+                assert np.array_equal(valid, exp_valid)
+                if f.dtype == capi.BOOL:
+                    got = unpack_bits(values, length)
+                    exp = np.asarray(col.fill_null(False))
+                else:
+                    got = np.asarray(values)
+                    storage = col.cast(pa.int32()) if col.type == pa.date32() else col
+                    exp = storage.fill_null(0).to_numpy(zero_copy_only=False).astype(got.dtype)
+                assert np.array_equal(got[exp_valid], exp[exp_valid])
+
+
+def host_write(table_batches, schema, file_format, sink=None):
+    codes = {t: c for _, t, c in TYPES}
+    w = IpcWriter([(f.name, codes[f.type], f.nullable) for f in schema], sink, file_format)
+    for b in table_batches:
+        w.write_host_batch(b.columns)
+    return w.finish()
+
+
+@pytest.mark.parametrize("file_format", [False, True])
+@pytest.mark.parametrize("n,batch_rows,offset", [(1000, 1000, 0), (1003, 257, 0), (0, 10, 0), (777, 100, 13), (64, 64, 8), (9, 3, 1)])
+def test_pyarrow_reads_what_the_writer_wrote(file_format, n, batch_rows, offset):
+    rng = np.random.default_rng(7 * n + batch_rows + offset)
+    table = make_table(rng, n + offset, with_unsupported=False).slice(offset)  # offset != 0: sliced arrays, bit offsets in the bitmaps
+    batches = table.to_batches(max_chunksize=batch_rows)
+    data = host_write(batches, table.schema, file_format)
+    rd = (pa.ipc.open_file if file_format else pa.ipc.open_stream)(pa.BufferReader(data))
+    got = rd.read_all()
+    assert got.schema.names == table.schema.names
+    assert [f.type for f in got.schema] == [f.type for f in table.schema]
+    assert got.num_rows == table.num_rows
+    if file_format:
+        assert rd.num_record_batches == len(batches)
+    for name in table.schema.names:
+        a, b = got.column(name).combine_chunks(), table.column(name).combine_chunks()
+        assert a.null_count == b.null_count
+        assert a.equals(b), name
+    got.validate(full=True)
+    # and our own reader agrees with pyarrow's about the bytes we wrote
+    with IpcReader(data) as r:
+        assert r.num_batches == len(batches) and [f.name for f in r.fields] == table.schema.names
+        assert sum(r.batch_rows(i) for i in range(r.num_batches)) == table.num_rows
+
+
+def test_writer_to_a_file_descriptor_and_mmap_reader(tmp_path):
+    rng = np.random.default_rng(5)
+    table = make_table(rng, 5000, with_unsupported=False)
+    path = tmp_path / "cols.arrow"
+    assert host_write(table.to_batches(max_chunksize=1200), table.schema, True, sink=str(path)) is None
+    with pa.memory_map(str(path)) as src:
+        assert pa.ipc.open_file(src).read_all().equals(table)
+    with IpcReader(str(path)) as r:  # memory-mapped
+        assert r.num_batches == 5
+        values, validity, length, nulls = r.column_view(4, r.column_index("col_f"))
+        exp = table.column("col_f").chunk(0)[4800:]
+        assert length == 200 and nulls == exp.null_count
+        ok = np.asarray(exp.is_valid())
+        assert np.array_equal(np.asarray(values)[ok], exp.fill_null(0).to_numpy(zero_copy_only=False)[ok])
+
+
+def test_no_nulls_means_no_validity_buffer():
+    t = pa.table({"a": pa.array([1, 2, 3], pa.int32()), "b": pa.array([True, None, False])})
+    data = host_write(t.to_batches(), t.schema, False)
+    with IpcReader(data) as r:
+        _, validity, _, nulls = r.column_view(0, 0)
+        assert validity is None and nulls == 0
+        _, validity, _, nulls = r.column_view(0, 1)
+        assert nulls == 1 and unpack_bits(validity, 3).tolist() == [True, False, True]
+
+
+def test_compressed_and_mismatched_input_is_refused():
+    t = pa.table({"a": pa.array(np.arange(1000, dtype=np.int32))})
+    sink = pa.BufferOutputStream()
+    try:
+        opts = pa.ipc.IpcWriteOptions(compression="lz4")
+    except Exception:
+        pytest.skip("pyarrow built without lz4")
+    with pa.ipc.new_stream(sink, t.schema, options=opts) as w:
+        w.write_table(t)
+    with IpcReader(sink.getvalue().to_pybytes()) as r:
+        assert r.fields[0].dtype == capi.I32 and r.num_batches == 1
+        with pytest.raises(capi.OperationNotSupported):
+            r.column_view(0, 0)
+    w = IpcWriter([("a", capi.I32, True), ("b", capi.F32, True)])
+    with pytest.raises(capi.ArrowErrorGPU):  # columns of different length
+        w.write_host_batch([pa.array([1, 2, 3], pa.int32()), pa.array([1.0], pa.float32())])
+    with pytest.raises(capi.OperationNotSupported):
+        IpcWriter([("a", 99, True)])
+    with pytest.raises(capi.ArrowErrorGPU):
+        IpcReader(b"definitely not arrow")
+    with pytest.raises(capi.ArrowErrorGPU):
+        IpcReader(b"ARROW1\0\0" + b"\0" * 40)
+
+
+@pytest.mark.parametrize("file_format", [False, True])
+def test_truncated_and_corrupted_input_never_crashes(file_format):
+    rng = np.random.default_rng(11)
+    table = make_table(rng, 300)
+    data = serialise(table, file_format, 100)
+    opened = refused = 0
+    for cut in list(range(0, 600, 7)) + list(range(600, len(data), 211)):
+        try:
+            with IpcReader(data[:cut] if cut else b"\0") as r:
+                for b in range(r.num_batches):
+                    for c, f in enumerate(r.fields):
+                        if f.dtype >= 0:
+                            r.column_view(b, c)
+            opened += 1
+        except capi.ArrowErrorGPU:
+            refused += 1
+    assert refused > 0
+    if not file_format:  # the end-of-stream marker is optional: a stream that simply stops after a message is complete
+        with IpcReader(data[:-8]) as r:
+            assert r.num_batches == 3
+    # byte flips inside the metadata of the schema and the first record batch
+    base = bytearray(data)
+    for trial in range(400):
+        buf = bytearray(base)
+        for _ in range(int(rng.integers(1, 4))):
+            pos = int(rng.integers(0, min(len(buf), 2500))) if not file_format or trial % 2 else int(rng.integers(max(0, len(buf) - 1500), len(buf)))
+            buf[pos] = int(rng.integers(0, 256))
+        try:
+            with IpcReader(bytes(buf)) as r:
+                for b in range(r.num_batches):
+                    r.batch_rows(b)
+                    for c, f in enumerate(r.fields):
+                        if f.dtype >= 0:
+                            try:
+                                values, validity, n, _ = r.column_view(b, c)
+                                if len(values):
+                                    int(np.asarray(values).view(np.uint8)[-1])  # touch the last byte: must be inside the source
+                            except capi.ArrowErrorGPU:
+                                pass
+        except capi.ArrowErrorGPU:
+            pass

@@ -50,6 +50,47 @@ __global__ __launch_bounds__(BLOCK) void cast_v1(const u32x4* in, f32x4* out, ui
   }
 }
 
+// variant 2: the product's shape (cvt_wide_kernel): 16 B per lane in, transposed through 1 KiB of LDS, 4 coalesced stores
+template <int U>
+__global__ __launch_bounds__(64) void cast_v2(const u32x4* in, f32x4* out, uint64_t nchunks) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[U][64 * 16];
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t c0 = (uint64_t)blockIdx.x * U; c0 < nchunks; c0 += (uint64_t)gridDim.x * U) {
+    u32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) v[u] = __builtin_nontemporal_load(in + (c0 + u) * 64 + lane);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; u++) *reinterpret_cast<u32x4*>(lds[u] + lane * 16) = v[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t g = j * 64 + lane;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(lds[u] + g * 4);
+        __builtin_nontemporal_store(cvt4(w), out + (c0 + u) * 256 + g);
+      }
+  }
+}
+// variant 3: as 2 but plain (temporal) stores
+__global__ __launch_bounds__(64) void cast_v3(const u32x4* in, f32x4* out, uint64_t nchunks) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds[64 * 16];
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const u32x4 v = __builtin_nontemporal_load(in + c * 64 + lane);
+    __syncthreads();
+    *reinterpret_cast<u32x4*>(lds + lane * 16) = v;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t g = j * 64 + lane;
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(lds + g * 4);
+      out[c * 256 + g] = cvt4(w);
+    }
+  }
+}
+
 extern "C" int probe_cast(const void* in, void* out, uint64_t n, int variant, int block, int u, void* stream) {
   hipStream_t s = (hipStream_t)stream;
 #define GO0(B, U_)                                                                                         \
@@ -61,6 +102,16 @@ extern "C" int probe_cast(const void* in, void* out, uint64_t n, int variant, in
   {                                                                                                        \
     uint64_t nt = n / 1024 / ((uint64_t)(B / 64) * U_);                                                    \
     hipLaunchKernelGGL((cast_v1<B, U_>), dim3((unsigned)nt), dim3(B), 0, s, (const u32x4*)in, (f32x4*)out, nt); \
+  }
+  if (variant == 2 || variant == 3) {
+    const uint64_t nchunks = n / 1024;
+    const unsigned grid = block > 0 ? (unsigned)block : (unsigned)(nchunks / (uint64_t)(u > 0 ? u : 1));  // block = grid cap here
+    if (variant == 3) hipLaunchKernelGGL(cast_v3, dim3(grid), dim3(64), 0, s, (const u32x4*)in, (f32x4*)out, nchunks);
+    else if (u == 1) hipLaunchKernelGGL(cast_v2<1>, dim3(grid), dim3(64), 0, s, (const u32x4*)in, (f32x4*)out, nchunks);
+    else if (u == 2) hipLaunchKernelGGL(cast_v2<2>, dim3(grid), dim3(64), 0, s, (const u32x4*)in, (f32x4*)out, nchunks);
+    else if (u == 4) hipLaunchKernelGGL(cast_v2<4>, dim3(grid), dim3(64), 0, s, (const u32x4*)in, (f32x4*)out, nchunks);
+    else return 1;
+    return (int)hipGetLastError();
   }
   if (variant == 0) {
     if (block == 64 && u == 1) GO0(64, 1) else if (block == 64 && u == 4) GO0(64, 4) else if (block == 256 && u == 1) GO0(256, 1)
