@@ -327,53 +327,56 @@ def main():
     # rank-ordered combine.  The rendezvous id travels over the torch.distributed group when one exists; a plain
     # `python bench.py` builds a world of one rank, so the RCCL path runs on every box.
     extra = {}
-    comm = sharding.Communicator.from_torch(dev) if distributed else sharding.Communicator.single(dev)
-    stat_out = {k: dev.create_empty_buffer(16) for k in ("sum", "min", "max", "sum_f64")}
-    p.sync()
-    stats = {}
-    for name, launch in (
-            ("sum", lambda: capi.call("agpu_reduce", h, capi.RED_SUM, capi.F32, vp(fa), None, n, vp(stat_out["sum"]))),
-            ("min", lambda: capi.call("agpu_reduce", h, capi.RED_MIN, capi.F32, vp(fa), None, n, vp(stat_out["min"]))),
-            ("max", lambda: capi.call("agpu_reduce", h, capi.RED_MAX, capi.F32, vp(fa), None, n, vp(stat_out["max"]))),
-            ("sum_f64", lambda: capi.call("agpu_reduce_sum_f64", h, vp(fa), None, n, vp(stat_out["sum_f64"])))):
-        launch()  # warm (scratch allocation)
-        reps = 5
-        pairs = [(ev(), ev()) for _ in range(reps)]
-        for s_, e_ in pairs:  # the shard-local kernel alone, one event pair per launch
-            capi.call("agpu_event_record", s_, h)
-            launch()
-            capi.call("agpu_event_record", e_, h)
-        ms_k = mean_ms(pairs)
-        stats[name] = {"local_ms": round(ms_k, 4), "local_GBps": round(4.0 * n / ms_k / 1e6, 1),
-                       "frac_hbm_peak": round(4.0 * n / ms_k / 1e6 / HBM_PEAK_GBPS, 4)}
-    # the collective form: local kernel + RCCL all-gather + combine, timed end to end on the stream
-    cs, ce = ev(), ev()
-    comm.reduce(p, capi.RED_SUM, capi.F32, fa, None, n, stat_out["sum"])  # warm RCCL's first-call setup
-    p.sync()
-    capi.call("agpu_event_record", cs, h)
-    comm.reduce(p, capi.RED_SUM, capi.F32, fa, None, n, stat_out["sum"])
-    comm.reduce(p, capi.RED_MIN, capi.F32, fa, None, n, stat_out["min"])
-    comm.reduce(p, capi.RED_MAX, capi.F32, fa, None, n, stat_out["max"])
-    comm.reduce_sum_f64(p, fa, None, n, stat_out["sum_f64"])
-    capi.call("agpu_event_record", ce, h)
-    p.sync()
-    ms = C.c_float()
-    capi.call("agpu_event_elapsed_ms", cs, ce, C.byref(ms))
-    import numpy as _np
+    try:  # the headline line must come out even if this leg cannot run (it is reported, not part of `value`)
+        comm = sharding.Communicator.from_torch(dev) if distributed else sharding.Communicator.single(dev)
+        stat_out = {k: dev.create_empty_buffer(16) for k in ("sum", "min", "max", "sum_f64")}
+        p.sync()
+        stats = {}
+        for name, launch in (
+                ("sum", lambda: capi.call("agpu_reduce", h, capi.RED_SUM, capi.F32, vp(fa), None, n, vp(stat_out["sum"]))),
+                ("min", lambda: capi.call("agpu_reduce", h, capi.RED_MIN, capi.F32, vp(fa), None, n, vp(stat_out["min"]))),
+                ("max", lambda: capi.call("agpu_reduce", h, capi.RED_MAX, capi.F32, vp(fa), None, n, vp(stat_out["max"]))),
+                ("sum_f64", lambda: capi.call("agpu_reduce_sum_f64", h, vp(fa), None, n, vp(stat_out["sum_f64"])))):
+            launch()  # warm (scratch allocation)
+            reps = 5
+            pairs = [(ev(), ev()) for _ in range(reps)]
+            for s_, e_ in pairs:  # the shard-local kernel alone, one event pair per launch
+                capi.call("agpu_event_record", s_, h)
+                launch()
+                capi.call("agpu_event_record", e_, h)
+            ms_k = mean_ms(pairs)
+            stats[name] = {"local_ms": round(ms_k, 4), "local_GBps": round(4.0 * n / ms_k / 1e6, 1),
+                           "frac_hbm_peak": round(4.0 * n / ms_k / 1e6 / HBM_PEAK_GBPS, 4)}
+        # the collective form: local kernel + RCCL all-gather + combine, timed end to end on the stream
+        cs, ce = ev(), ev()
+        comm.reduce(p, capi.RED_SUM, capi.F32, fa, None, n, stat_out["sum"])  # warm RCCL's first-call setup
+        p.sync()
+        capi.call("agpu_event_record", cs, h)
+        comm.reduce(p, capi.RED_SUM, capi.F32, fa, None, n, stat_out["sum"])
+        comm.reduce(p, capi.RED_MIN, capi.F32, fa, None, n, stat_out["min"])
+        comm.reduce(p, capi.RED_MAX, capi.F32, fa, None, n, stat_out["max"])
+        comm.reduce_sum_f64(p, fa, None, n, stat_out["sum_f64"])
+        capi.call("agpu_event_record", ce, h)
+        p.sync()
+        ms = C.c_float()
+        capi.call("agpu_event_elapsed_ms", cs, ce, C.byref(ms))
+        import numpy as _np
 
-    def scalar(buf, dt):
-        return dev.retrive_data(buf, _np.dtype(dt).itemsize, pipeline=p).view(dt)[0]
+        def scalar(buf, dt):
+            return dev.retrive_data(buf, _np.dtype(dt).itemsize, pipeline=p).view(dt)[0]
 
-    local_sum_ms = sum(stats[k]["local_ms"] for k in ("sum", "min", "max", "sum_f64"))
-    extra["reduce_sum_min_max"] = {
-        "rows_total": n * world, "sum_f32_reference_tree": float(scalar(stat_out["sum"], _np.float32)),
-        "min": float(scalar(stat_out["min"], _np.float32)), "max": float(scalar(stat_out["max"], _np.float32)),
-        "sum_f64": float(scalar(stat_out["sum_f64"], _np.float64)), "per_statistic": stats,
-        "four_statistics_with_final_reduce_ms": round(ms.value, 4),
-        "final_reduce_overhead_ms": round(ms.value - local_sum_ms, 4),
-        "final_reduce": f"C ABI agpu_comm_reduce: RCCL all-gather of one 16-byte record per rank (world {world}) + rank-ordered combine",
-    }
-    comm.close()
+        local_sum_ms = sum(stats[k]["local_ms"] for k in ("sum", "min", "max", "sum_f64"))
+        extra["reduce_sum_min_max"] = {
+            "rows_total": n * world, "sum_f32_reference_tree": float(scalar(stat_out["sum"], _np.float32)),
+            "min": float(scalar(stat_out["min"], _np.float32)), "max": float(scalar(stat_out["max"], _np.float32)),
+            "sum_f64": float(scalar(stat_out["sum_f64"], _np.float64)), "per_statistic": stats,
+            "four_statistics_with_final_reduce_ms": round(ms.value, 4),
+            "final_reduce_overhead_ms": round(ms.value - local_sum_ms, 4),
+            "final_reduce": f"C ABI agpu_comm_reduce: RCCL all-gather of one 16-byte record per rank (world {world}) + rank-ordered combine",
+        }
+        comm.close()
+    except Exception as e:  # noqa: BLE001
+        extra["reduce_sum_min_max"] = {"error": f"{type(e).__name__}: {e}"}
     extra["kernels"] = {"add_f32": {"ms": round(add_ms, 4), "GBps": round(add_gbps, 1), "frac_hbm_peak": round(add_gbps / HBM_PEAK_GBPS, 4)},
                         "eq_i32_validity": {"ms": round(eq_ms, 4), "GBps": round(eq_gbps, 1), "frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4)}}
 
