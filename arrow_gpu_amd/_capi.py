@@ -97,6 +97,7 @@ SIGNATURES = {
     "agpu_export_arrow": [_vp, _vp, _vp, _vp],
     "agpu_arrow_column_free": [_vp, _vp],
     "agpu_staged_copy": [_vp, _vp, _vp, _sz, _i32],
+    "agpu_malloc_table": [_vp, _i32, C.POINTER(_u64), _i32, _pp],
     "agpu_ipc_open": [_vp, _u64, _pp],
     "agpu_ipc_close": [_vp],
     "agpu_ipc_num_fields": [_vp, C.POINTER(_i32)],

@@ -97,6 +97,11 @@ struct agpu_device {
   std::vector<agpu_stream_slot*> idle;              // owned streams without a live pipeline
   std::atomic<uint64_t> finish_gen{0};              // bumped by every published finish (cross-pipeline ordering)
   std::unordered_map<void*, size_t> block_size;     // live pooled blocks handed out by agpu_malloc (large and small)
+  struct TableGroup {  // agpu_malloc_table: several columns carved out of one block, freed column by column
+    void* base;
+    uint32_t live;
+  };
+  std::unordered_map<void*, TableGroup*> table_member;  // column pointer → its group
   std::multimap<size_t, CachedBlock> cache;         // size → freed blocks ≥ 1 MiB
   size_t cached_bytes = 0, cache_cap = 0;
   static constexpr int kSmallClasses = 12;          // 256 B … 512 KiB, powers of two

@@ -12,10 +12,14 @@
 //   rows 4l..4l+3 of a 256-row block : one 16-byte load per lane, (x0+x1)+(x2+x3) in registers      (levels 1-2)
 //   64 lanes                         : shift-down shuffle adds, offsets 1,2,4..32                     (levels 3-8)
 //   64 consecutive blocks per wave   : block sums parked in lanes 0..63, same 6 shuffle steps          (levels 9-14)
-//   4 waves per workgroup            : (w0+w1)+(w2+w3) through LDS                                     (levels 15-16)
-// so one workgroup retires an aligned 65,536-row span = exactly two of the reference's 256-ary levels, and a tiny
-// single-workgroup kernel finishes the remaining levels over the per-span partials with the reference's own LDS
-// tree.  HBM-bound: 4 B/row, every byte read once.
+// One WAVE (a one-wave block: no LDS, no barrier) retires an aligned 16,384-row quarter span and writes one partial.  A
+// second, tiny launch — one wave per 256 spans — adds the four quarters of every span, (q0+q1)+(q2+q3) (levels 15-16,
+// which completes the reference's second 256-ary level), and runs the third 256-ary level over the span sums in
+// registers + 6 shuffle steps; whatever is left (≤ 256 values up to 4.3e9 rows) goes through a single-workgroup copy of
+// the reference's own LDS tree.  HBM-bound: 4 B/row, every byte read once.  (tools/probe/sum_probe.py, 1e9 rows, one
+// process: a 256-thread block per span 0.838 of the HBM roof, one wave per quarter span 0.861 — the access pattern's
+// ceiling, 0.858 with the cross-lane work removed; and the old finish — ONE workgroup walking 15 259 span sums through
+// 60 serial LDS trees — cost another 41 µs of a 0.64 ms launch.)
 #include <type_traits>
 
 #include "common.hpp"
@@ -61,19 +65,53 @@ __device__ __forceinline__ float load4_tree(const float* in, const uint8_t* vali
   return (x0 + x1) + (x2 + x3);
 }
 
+// Reduce EIGHT 256-row blocks at once ("transpose-reduce"): at butterfly step k the two registers of a pair are
+// merged so that lanes with bit k clear keep the even block and lanes with bit k set keep the odd one.  Every add
+// still pairs lane l with lane l^2^k in the order 1, 2, 4, … — the reference's adjacent-pair tree (f32 addition is
+// commutative, so which side is "left" does not change the bits) — but 8 blocks cost 10 shuffles instead of 48.
+// In: s[u] = this lane's 4-row partial of block u.  Out (every lane): the sum of block (lane & 7).
+__device__ __forceinline__ float transpose_reduce8(const float (&s)[8], uint32_t lane) {
+  float t4[4], t2[2];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const bool odd = lane & 1;
+    const float keep = odd ? s[2 * j + 1] : s[2 * j];
+    const float send = odd ? s[2 * j] : s[2 * j + 1];
+    t4[j] = keep + __shfl_xor(send, 1);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const bool odd = lane & 2;
+    const float keep = odd ? t4[2 * j + 1] : t4[2 * j];
+    const float send = odd ? t4[2 * j] : t4[2 * j + 1];
+    t2[j] = keep + __shfl_xor(send, 2);
+  }
+  float v;
+  {
+    const bool odd = lane & 4;
+    const float keep = odd ? t2[1] : t2[0];
+    const float send = odd ? t2[0] : t2[1];
+    v = keep + __shfl_xor(send, 4);
+  }
+  v = v + __shfl_xor(v, 8);
+  v = v + __shfl_xor(v, 16);
+  v = v + __shfl_xor(v, 32);
+  return v;
+}
+
+// One wave, one aligned 16,384-row quarter span (64 blocks of 256 rows) → its tree sum in lane 0.
+// GUARD: quarters that cross the end of the column and columns that are only 4-byte aligned — same tree, guarded scalar loads.
 template <bool GUARD, bool HASV>
-__device__ __forceinline__ float span_tree_sum(const float* in, const uint8_t* validity, uint64_t span_base, uint64_t n,
-                                               float* lds) {
+__device__ __forceinline__ float quarter_tree_sum(const float* in, const uint8_t* validity, uint64_t wave_base, uint64_t n) {
   constexpr int UNR = 8;
-  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
-  const uint64_t wave_base = span_base + (uint64_t)wave * WAVE_ROWS;
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
   float acc = 0.0f;  // lane j ends up holding the sum of this wave's j-th 256-row block
   for (int j0 = 0; j0 < AGPU_WAVE; j0 += UNR) {
     float s[UNR];
     if constexpr (HASV && !GUARD) {
       // validity of the 8 blocks of this step = 2048 bits = one 4-byte load per lane (256 contiguous bytes per wave);
       // lane l's nibble for block u sits in the word lane 8u + l/8 holds — one cross-lane read instead of a byte load per
-      // block and lane (measured neutral at 1e9 rows, 0.70 ms either way: kept because it removes 7 of 8 memory instructions)
+      // block and lane
       const uint32_t vword = reinterpret_cast<const uint32_t*>(validity)[(wave_base + (uint64_t)j0 * 256) / 32 + lane];
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
@@ -88,58 +126,49 @@ __device__ __forceinline__ float span_tree_sum(const float* in, const uint8_t* v
       for (int u = 0; u < UNR; u++)
         s[u] = load4_tree<GUARD, HASV>(in, validity, wave_base + (uint64_t)(j0 + u) * 256 + lane * 4, n);
     }
-    // Reduce EIGHT 256-row blocks at once ("transpose-reduce"): at butterfly step k the two registers of a pair are
-    // merged so that lanes with bit k clear keep the even block and lanes with bit k set keep the odd one.  Every add
-    // still pairs lane l with lane l^2^k in the order 1, 2, 4, … — the reference's adjacent-pair tree (f32 addition is
-    // commutative, so which side is "left" does not change the bits) — but 8 blocks cost 10 shuffles instead of 48.
-    float t4[4], t2[2];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const bool odd = lane & 1;
-      const float keep = odd ? s[2 * j + 1] : s[2 * j];
-      const float send = odd ? s[2 * j] : s[2 * j + 1];
-      t4[j] = keep + __shfl_xor(send, 1);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const bool odd = lane & 2;
-      const float keep = odd ? t4[2 * j + 1] : t4[2 * j];
-      const float send = odd ? t4[2 * j] : t4[2 * j + 1];
-      t2[j] = keep + __shfl_xor(send, 2);
-    }
-    float v;
-    {
-      const bool odd = lane & 4;
-      const float keep = odd ? t2[1] : t2[0];
-      const float send = odd ? t2[0] : t2[1];
-      v = keep + __shfl_xor(send, 4);
-    }
-    v = v + __shfl_xor(v, 8);
-    v = v + __shfl_xor(v, 16);
-    v = v + __shfl_xor(v, 32);
+    const float v = transpose_reduce8(s, lane);
     // every lane now holds the sum of block j0 + (lane & 7); park it in lane j0 + (lane & 7)
     if ((lane >> 3) == (uint32_t)(j0 >> 3)) acc = v;
   }
-  const float wsum = wave_tree_sum(acc);
-  __syncthreads();
-  if (lane == 0) lds[wave] = wsum;
-  __syncthreads();
-  return (lds[0] + lds[1]) + (lds[2] + lds[3]);
+  return wave_tree_sum(acc);
 }
 
+// first launch: quarters[q] for q < 4 * nspans (quarters that lie entirely beyond the column come out +0.0: the
+// reference's zero padding of the last workgroup)
 template <bool HASV>
-__global__ __launch_bounds__(AGPU_BLOCK) void sum_tree_span_kernel(const float* in, const uint8_t* validity, uint64_t n,
-                                                                  float* partials, int vec_ok) {
-  __shared__ float lds[AGPU_BLOCK / AGPU_WAVE];
-  const uint64_t nspans = (n + SPAN_ROWS - 1) / SPAN_ROWS;
-  for (uint64_t sp = blockIdx.x; sp < nspans; sp += gridDim.x) {
-    const uint64_t base = sp * SPAN_ROWS;
+__global__ __launch_bounds__(AGPU_WAVE) void sum_tree_quarter_kernel(const float* in, const uint8_t* validity, uint64_t n,
+                                                                    float* quarters, uint64_t nquarters, int vec_ok) {
+  for (uint64_t q = blockIdx.x; q < nquarters; q += gridDim.x) {
+    const uint64_t base = q * WAVE_ROWS;
     float r;
-    // vec_ok == 0: the column is only 4-byte aligned (a slice, an odd shard offset) — same spans, same tree, scalar loads
-    if (vec_ok && base + SPAN_ROWS <= n) r = span_tree_sum<false, HASV>(in, validity, base, n, lds);
-    else r = span_tree_sum<true, HASV>(in, validity, base, n, lds);
-    if (threadIdx.x == 0) partials[sp] = r;
+    if (vec_ok && base + WAVE_ROWS <= n) r = quarter_tree_sum<false, HASV>(in, validity, base, n);
+    else r = quarter_tree_sum<true, HASV>(in, validity, base, n);
+    if (threadIdx.x == 0) quarters[q] = r;
   }
+}
+
+// second launch: one wave per 256 spans.  Lane l owns spans 256 g + 4 l … + 3: sixteen consecutive quarter sums (four
+// 16-byte loads) → four span sums (q0+q1)+(q2+q3) → (s0+s1)+(s2+s3) → 6 shuffle steps = the reference's third 256-ary
+// level over zero-padded span sums.  A column of ONE span has no third level: its span sum is the result.
+__global__ __launch_bounds__(AGPU_WAVE) void sum_tree_combine_kernel(const float* quarters, uint64_t nspans, float* out) {
+  const uint32_t lane = threadIdx.x;
+  const uint64_t sp0 = ((uint64_t)blockIdx.x * AGPU_WAVE + lane) * 4;
+  float s[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (sp0 + (uint64_t)k < nspans) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(quarters + (sp0 + (uint64_t)k) * 4);
+      s[k] = (w.x + w.y) + (w.z + w.w);
+    } else {
+      s[k] = 0.0f;
+    }
+  }
+  if (nspans == 1) {
+    if (lane == 0) out[0] = s[0];
+    return;
+  }
+  const float t = wave_tree_sum((s[0] + s[1]) + (s[2] + s[3]));
+  if (lane == 0) out[blockIdx.x] = t;
 }
 
 // remaining 256-ary levels over m values, exactly the reference's workgroup tree (aggregate.wgsl:21-41); one workgroup
@@ -333,15 +362,17 @@ static agpu_status launch_reduce(agpu_pipeline* p, const void* in, const void* v
 
 static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const uint8_t* validity, uint64_t n,
                                        float* out) {
-  const uint64_t nspans = (n + SPAN_ROWS - 1) / SPAN_ROWS;
-  // scratch: partials[nspans] + two ping-pong buffers for the finishing levels
-  const size_t level_cap = (size_t)((nspans + 255) / 256 + 1);
-  const size_t floats = (size_t)nspans + 2 * level_cap + 8;
+  const uint64_t nspans = (n + SPAN_ROWS - 1) / SPAN_ROWS, nquarters = nspans * 4;
+  const uint64_t ngroups = (nspans + 255) / 256;  // values left after the combine launch
+  // scratch: quarters[4 nspans] + groups[ngroups] + two ping-pong buffers for the finishing levels
+  const size_t level_cap = (size_t)((ngroups + 255) / 256 + 1);
+  const size_t floats = (size_t)nquarters + 4 + (size_t)ngroups + 4 + 2 * level_cap + 8;
   void* scratch = nullptr;
   agpu_status st = agpu_scratch(p, floats * sizeof(float), &scratch);
   if (st != AGPU_OK) return st;
-  float* partials = static_cast<float*>(scratch);
-  float* buf0 = partials + nspans + 4;
+  float* quarters = static_cast<float*>(scratch);
+  float* groups = quarters + nquarters + 4;
+  float* buf0 = groups + ngroups + 4;
   float* buf1 = buf0 + level_cap;
   if (n <= 256) {
     // one plain reference level straight from the input (a single 256-row workgroup)
@@ -349,16 +380,22 @@ static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const 
     AGPU_LAUNCH_CHECK();
     return AGPU_OK;
   }
-  const int grid = reduce_grid_for(p, nspans, 64);
+  const int grid = reduce_grid_for(p, nquarters, 1 << 16);  // one-wave blocks: as many as there are quarters (sum_probe.py)
   const int vec_ok = (aligned16(in) && (!validity || aligned_to(validity, 4))) ? 1 : 0;
   if (validity)
-    hipLaunchKernelGGL((sum_tree_span_kernel<true>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, in, validity, n, partials, vec_ok);
+    hipLaunchKernelGGL((sum_tree_quarter_kernel<true>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, in, validity, n, quarters, nquarters, vec_ok);
   else
-    hipLaunchKernelGGL((sum_tree_span_kernel<false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, in, validity, n, partials, vec_ok);
+    hipLaunchKernelGGL((sum_tree_quarter_kernel<false>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, in, validity, n, quarters, nquarters, vec_ok);
   AGPU_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sum_tree_finish_kernel, dim3(1), dim3(AGPU_BLOCK), 0, p->stream, (const float*)partials,
-                     (const uint8_t*)nullptr, buf0, buf1, nspans, out, 0);
+  // ≤ 256 spans (16.7 M rows): the combine launch produces the result itself
+  hipLaunchKernelGGL(sum_tree_combine_kernel, dim3((unsigned)ngroups), dim3(AGPU_WAVE), 0, p->stream, (const float*)quarters, nspans,
+                     ngroups == 1 ? out : groups);
   AGPU_LAUNCH_CHECK();
+  if (ngroups > 1) {
+    hipLaunchKernelGGL(sum_tree_finish_kernel, dim3(1), dim3(AGPU_BLOCK), 0, p->stream, (const float*)groups,
+                       (const uint8_t*)nullptr, buf0, buf1, ngroups, out, 0);
+    AGPU_LAUNCH_CHECK();
+  }
   return AGPU_OK;
 }
 

@@ -69,6 +69,16 @@ class GpuDevice:
         capi.call("agpu_malloc", self._handle, size, 1 if zero_fill else 0, C.byref(ptr))
         return DeviceBuffer(self, ptr.value or 0, size)
 
+    def create_table_buffers(self, sizes, zero_fill: bool = False) -> list:
+        """The buffers of one table in ONE device block, placed for the HBM channel hash (`agpu_malloc_table`): columns a
+        kernel reads together should not sit in the same hash class.  Each returned DeviceBuffer is an
+        ordinary buffer and is freed on its own; the block goes back to the pool with the last of them."""
+        n = len(sizes)
+        arr = (C.c_uint64 * n)(*[int(x) for x in sizes])
+        ptrs = (C.c_void_p * n)()
+        capi.call("agpu_malloc_table", self._handle, n, arr, 1 if zero_fill else 0, ptrs)
+        return [DeviceBuffer(self, ptrs[k] or 0, int(sizes[k])) for k in range(n)]
+
     def create_gpu_buffer_with_data(self, data: np.ndarray) -> DeviceBuffer:
         """[ref: create_gpu_buffer_with_data gpu_device.rs:171-181]"""
         data = np.ascontiguousarray(data)

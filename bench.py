@@ -243,9 +243,11 @@ def main():
     vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
     nb = (n + 63) // 64 * 8
 
-    fa, fb, fo = (dev.create_empty_buffer(4 * n) for _ in range(3))
-    ia, ib = dev.create_empty_buffer(4 * n), dev.create_empty_buffer(4 * n)
-    va, vb, ob, ov = (dev.create_empty_buffer(nb) for _ in range(4))
+    # two tables (the f32 columns of the add; the i32 columns and the bitmaps of the compare), each out of one block placed for
+    # the HBM channel hash (agpu_malloc_table): element i of the columns a kernel reads together falls into
+    # different hash classes — adjacent columns of a table differ in the strongest hash bit
+    fa, fb, fo = dev.create_table_buffers([4 * n] * 3)
+    ia, ib, va, vb, ob, ov = dev.create_table_buffers([4 * n] * 2 + [nb] * 4)
     capi.call("agpu_synth_f32", h, vp(fa), n, SEED, row0, C.c_float(-1000.0), C.c_float(1000.0))
     capi.call("agpu_synth_f32", h, vp(fb), n, SEED + 1, row0, C.c_float(-1000.0), C.c_float(1000.0))
     capi.call("agpu_synth_i32", h, vp(ia), n, SEED + 2, row0, 1024)

@@ -76,6 +76,20 @@ class GpuDevice : public std::enable_shared_from_this<GpuDevice> {
     b->dev = shared_from_this();
     return b;
   }
+  // the buffers of one table in ONE block, placed for the HBM channel hash (agpu_malloc_table); each is freed on its own
+  std::vector<BufferPtr> create_table_buffers(const std::vector<uint64_t>& sizes) {
+    std::vector<void*> ptrs(sizes.size(), nullptr);
+    check(agpu_malloc_table(raw, (int32_t)sizes.size(), sizes.data(), 0, ptrs.data()), "agpu_malloc_table");
+    std::vector<BufferPtr> out;
+    for (size_t k = 0; k < sizes.size(); k++) {
+      auto b = std::make_shared<Buffer>();
+      b->ptr = ptrs[k];
+      b->bytes = sizes[k];
+      b->dev = shared_from_this();
+      out.push_back(b);
+    }
+    return out;
+  }
   template <typename N>
   BufferPtr create_gpu_buffer_with_data(const N* data, size_t count) {  // [gpu_device.rs:171-181]
     auto b = create_empty_buffer(count * sizeof(N));

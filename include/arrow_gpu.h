@@ -155,6 +155,14 @@ agpu_status agpu_device_small_pool_info(agpu_device* dev, uint64_t* out_slab_byt
  *                      copy_buffer_to_buffer} compute_pipeline.rs:275-299] — ordered on the pipeline's stream. */
 agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void** out_ptr);
 agpu_status agpu_free(agpu_device* dev, void* ptr);
+/* The buffers of one table (the columns a kernel will read together) in ONE block, placed for the HBM channel hash:
+ * 2 MiB-aligned allocations put element i of every column into the same hash class whenever their distance has no hash
+ * bit set, and two read streams in the same class cost a compare 10 % of its bandwidth (0.78 → 0.85–0.89 of the roof;
+ * f32 add 1.5 %: DESIGN.md §3, tools/probe/hash_bits.py).  Columns of 1 GiB and more start a multiple of 512 MiB apart
+ * plus 0 / 8 / 4 / 12 KiB by column index; smaller ones a multiple of 2 MiB plus the same colours.  Every out_ptrs[k] is
+ * an ordinary buffer: free each with agpu_free (any order); the block returns to the pool with the last one.
+ * Not in the reference (wgpu places buffers). */
+agpu_status agpu_malloc_table(agpu_device* dev, int32_t n_columns, const uint64_t* bytes, int32_t zero_fill, void** out_ptrs);
 agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, size_t bytes);
 agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev, size_t bytes);
 agpu_status agpu_copy(agpu_pipeline* p, void* dst_dev, const void* src_dev, size_t bytes);

@@ -144,3 +144,47 @@ def test_pools_under_concurrent_threads(ag):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_table_buffers_come_from_one_block_with_hash_colours_and_free_independently():
+    """agpu_malloc_table: columns ≥ 1 GiB a multiple of 512 MiB apart + 0 / 8 / 4 / 12 KiB by index; usable and freeable
+    one by one in any order; the block returns to the pool with the last column"""
+    import ctypes as C
+
+    import numpy as np
+
+    from arrow_gpu_amd import _capi as capi
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+
+    dev = GpuDevice(0)
+    capi.call("agpu_device_trim", dev._handle)
+    cached0, blocks0 = C.c_uint64(), C.c_uint64()
+    capi.call("agpu_device_pool_info", dev._handle, C.byref(cached0), C.byref(blocks0), None)
+    big, small = (1 << 30) + 12345, 5_000_000
+    bufs = dev.create_table_buffers([big, big, small, big, small])
+    base = bufs[0].ptr
+    offs = [b.ptr - base for b in bufs]
+    # big columns (index 0, 1, 3) first, 1.5 GiB strides (1 GiB + 12345 B + colour room → three 512 MiB units), colours 0 / 8 / 4 KiB;
+    # the small ones (index 2, 4) behind them on 2 MiB units (5 MB → three), colours 0 / 8 KiB
+    unit, gran = 512 << 20, 2 << 20
+    assert offs == [0, 3 * unit + 8192, 9 * unit, 6 * unit + 4096, 9 * unit + 3 * gran + 8192]
+    p = ArrowComputePipeline(dev, "table")
+    rng = np.random.default_rng(0)
+    n = 1_000_000
+    a, b = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    capi.call("agpu_upload", p._handle, C.c_void_p(bufs[0].ptr), C.c_void_p(a.ctypes.data), a.nbytes)
+    capi.call("agpu_upload", p._handle, C.c_void_p(bufs[1].ptr), C.c_void_p(b.ctypes.data), b.nbytes)
+    capi.call("agpu_binary", p._handle, capi.OP_ADD, capi.F32, C.c_void_p(bufs[0].ptr), C.c_void_p(bufs[1].ptr), C.c_void_p(bufs[2].ptr), n)
+    got = dev.retrive_data(bufs[2], 4 * n, pipeline=p).view(np.float32)
+    assert np.array_equal(got, a + b)
+    for k in (3, 0, 4, 1):  # any order; the block stays live while one column does
+        bufs[k] = None
+    cached, blocks = C.c_uint64(), C.c_uint64()
+    capi.call("agpu_device_pool_info", dev._handle, C.byref(cached), C.byref(blocks), None)
+    assert blocks.value == blocks0.value
+    got = dev.retrive_data(bufs[2], 4 * n, pipeline=p).view(np.float32)
+    assert np.array_equal(got, a + b)
+    bufs[2] = None
+    capi.call("agpu_device_pool_info", dev._handle, C.byref(cached), C.byref(blocks), None)
+    assert blocks.value == blocks0.value + 1 and cached.value >= 3 * big  # the whole block is back in the pool's cache
+    capi.call("agpu_device_trim", dev._handle)

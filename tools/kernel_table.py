@@ -30,8 +30,8 @@ def main():
     h = p._handle
     vp = lambda b, off=0: C.c_void_p(b.ptr + off)  # noqa: E731
     nb = (n + 63) // 64 * 8
-    A, B, O = (dev.create_empty_buffer(4 * n) for _ in range(3))
-    VA, VB, OB, OV, M = (dev.create_empty_buffer(nb) for _ in range(5))
+    # one table: the buffers come out of one block, placed for the HBM channel hash (agpu_malloc_table)
+    A, B, O, VA, VB, OB, OV, M = dev.create_table_buffers([4 * n] * 3 + [nb] * 5)
     R = dev.create_empty_buffer(64)
     S = dev.create_gpu_buffer_with_data(np.array([3.0], np.float32))
     SI = dev.create_gpu_buffer_with_data(np.array([3], np.int32))
