@@ -960,6 +960,48 @@ __global__ __launch_bounds__(AGPU_WAVE) void cvt_wide_kernel(const TI* in, TO* o
   }
 }
 
+// Narrowing (f32→u8 / i8 / i16 / u16): the mirror image.  With cvt_kernel the narrow side STORES 4–8 B per lane (256–512-byte
+// wave stores).  Here the wave takes R = sizeof(TI)/sizeof(TO) contiguous 1 KiB chunks with coalesced 16-byte loads, every
+// loaded vector becomes one 16/R-byte piece, and the 64·R pieces are transposed inside the wave (ds_bpermute: piece
+// q = R·l' + k of output lane l' was produced by load q / 64 in lane q mod 64) so that each lane stores 16 contiguous bytes:
+// ONE coalesced 1 KiB store per wave.  cast f32→u8 at 1e9 rows, same process (tools/probe/narrow_sweep.py,
+// profiles/r02_sweep_narrow.json): 4-byte stores 0.77–0.79 of the HBM roof in every block shape, this form 0.83.
+template <typename TI, typename TO, typename Conv>
+__global__ __launch_bounds__(AGPU_WAVE) void cvt_narrow_kernel(const TI* in, TO* out, uint64_t nchunks) {
+  constexpr int R = sizeof(TI) / sizeof(TO);  // 2 or 4 loads per store
+  constexpr int NI = 16 / sizeof(TI);         // elements per loaded vector = elements per piece
+  constexpr int PD = 4 / R;                   // dwords per piece: 1 (R = 4) or 2 (R = 2)
+  struct Piece {
+    uint32_t d[PD];
+  };
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    Piece w[R];
+    static_for<R>([&](auto j) {
+      const PackN<TI, NI> x = load_pack<(AGPU_STREAM_NT & 1) != 0, TI, NI>(in + ((c * R + (uint32_t)j) * AGPU_WAVE + lane) * NI);
+      PackN<TO, NI> r;
+#pragma unroll
+      for (int k = 0; k < NI; k++) r.v[k] = Conv::ap(x.v[k]);
+      w[j] = __builtin_bit_cast(Piece, r);
+    });
+    const uint32_t jsel = lane / (AGPU_WAVE / R);
+    u32x4 outv;
+    static_for<R>([&](auto k) {
+      const int src = (int)((R * (lane % (AGPU_WAVE / R)) + (uint32_t)k) * 4u);
+      static_for<PD>([&](auto d) {
+        uint32_t got[R];
+        static_for<R>([&](auto j) { got[j] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)w[j].d[d]); });
+        uint32_t pick = got[0];
+        static_for<R>([&](auto j) {
+          if ((uint32_t)j == jsel) pick = got[j];
+        });
+        outv[(int)k * PD + (int)d] = pick;
+      });
+    });
+    __builtin_nontemporal_store(outv, reinterpret_cast<u32x4*>(out) + c * AGPU_WAVE + lane);
+  }
+}
+
 template <typename TI, typename TO, typename Conv>
 static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
   if (n == 0) return AGPU_OK;
@@ -973,6 +1015,21 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
       if (nchunks) {
         const int grid = stream_grid_for(p, nchunks);
         hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, pi, po, nchunks);
+      }
+      if (nchunks * chunk_rows < n)
+        hipLaunchKernelGGL((cvt_tail_kernel<TI, TO, Conv>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pi, po,
+                           nchunks * chunk_rows, n);
+      AGPU_LAUNCH_CHECK();
+      return AGPU_OK;
+    }
+  }
+  if constexpr (sizeof(TI) == 2 * sizeof(TO) || sizeof(TI) == 4 * sizeof(TO)) {
+    if (aligned16(in) && aligned16(out)) {
+      constexpr uint64_t chunk_rows = (uint64_t)AGPU_WAVE * 16 / sizeof(TO);  // rows behind one 1 KiB wave store
+      const uint64_t nchunks = n / chunk_rows;
+      if (nchunks) {
+        const int grid = stream_grid_for(p, nchunks);
+        hipLaunchKernelGGL((cvt_narrow_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, pi, po, nchunks);
       }
       if (nchunks * chunk_rows < n)
         hipLaunchKernelGGL((cvt_tail_kernel<TI, TO, Conv>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pi, po,
