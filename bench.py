@@ -325,7 +325,7 @@ def main():
 
     # ---- config 5: per-shard sum/min/max + final reduce over RCCL (outside the timed region).  Everything below goes
     # through the C ABI's communicator (include/arrow_gpu.h "multi-GPU"): agpu_comm_reduce = the shard-local kernel
-    # (for SUM the reference-order tree, sum_tree_span_kernel) + an all-gather of one 16-byte record per rank + the
+    # (for SUM the reference-order tree, sum_tree_quarter_kernel + sum_tree_combine_kernel) + an all-gather of one 16-byte record per rank + the
     # rank-ordered combine.  The rendezvous id travels over the torch.distributed group when one exists; a plain
     # `python bench.py` builds a world of one rank, so the RCCL path runs on every box.
     extra = {}

@@ -91,6 +91,30 @@ __global__ __launch_bounds__(64) void cast_v3(const u32x4* in, f32x4* out, uint6
   }
 }
 
+// variant 4: as 1, but the transposition costs 4 ds_permute (push) instead of 16 ds_bpermute: in round d every lane s pushes
+// its dword (d + s/16) & 3 to lane 4 (s % 16) + ((d + s/16) & 3) — a permutation of the 64 lanes — so lane l receives, in
+// round d, the dword of store j = ((l & 3) - d) & 3; two 4-way selects per lane replace the other 12 crossbar trips
+__global__ __launch_bounds__(64) void cast_v4(const u32x4* in, f32x4* out, uint64_t nchunks) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t sj = lane >> 4, st = lane & 15, e = lane & 3;
+  for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const u32x4 v = __builtin_nontemporal_load(in + c * 64 + lane);
+    uint32_t r[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const uint32_t k = (d + sj) & 3;
+      const uint32_t val = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+      r[d] = (uint32_t)__builtin_amdgcn_ds_permute((int)((4 * st + k) * 4), (int)val);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t d = (e - j) & 3;
+      const uint32_t w = d == 0 ? r[0] : d == 1 ? r[1] : d == 2 ? r[2] : r[3];
+      __builtin_nontemporal_store(cvt4(w), out + c * 256 + j * 64 + lane);
+    }
+  }
+}
+
 extern "C" int probe_cast(const void* in, void* out, uint64_t n, int variant, int block, int u, void* stream) {
   hipStream_t s = (hipStream_t)stream;
 #define GO0(B, U_)                                                                                         \
@@ -102,6 +126,11 @@ extern "C" int probe_cast(const void* in, void* out, uint64_t n, int variant, in
   {                                                                                                        \
     uint64_t nt = n / 1024 / ((uint64_t)(B / 64) * U_);                                                    \
     hipLaunchKernelGGL((cast_v1<B, U_>), dim3((unsigned)nt), dim3(B), 0, s, (const u32x4*)in, (f32x4*)out, nt); \
+  }
+  if (variant == 4) {
+    const uint64_t nchunks = n / 1024;
+    hipLaunchKernelGGL(cast_v4, dim3((unsigned)nchunks), dim3(64), 0, s, (const u32x4*)in, (f32x4*)out, nchunks);
+    return (int)hipGetLastError();
   }
   if (variant == 2 || variant == 3) {
     const uint64_t nchunks = n / 1024;
