@@ -119,6 +119,42 @@ static agpu_status staged_copy_threads(agpu_pipeline* p, char* dev_ptr, char* ho
   return AGPU_OK;
 }
 
+// Small and medium transfers (≤ AGPU_BOUNCE_MAX_BYTES = 16 MiB) never hand the caller's pageable pointer to the runtime: the bytes go
+// through two of the device's page-locked slots, CPU memcpy on one while the DMA runs on the other.  A pageable
+// hipMemcpy makes the runtime pin the caller's pages for the duration (a KFD userptr mapping); with the C heap (numpy,
+// std::vector — brk memory that glibc keeps extending and trimming) that ended, about once in thirty runs of the GPU test
+// suite, in "Memory access fault by GPU … on address <a page of the brk heap>" raised from the runtime's event thread
+// (native backtrace via tools/probe/abort_bt.c): nothing of ours dereferences host memory, and the fault is fatal to
+// the process.  Big transfers keep the direct path — their buffers are separate mappings that live until the call
+// returns — and the measured 56 GB/s.
+agpu_status agpu_internal_bounce_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device) {
+  agpu_device* dev = p->dev;
+  char* d = static_cast<char*>(dev_ptr);
+  char* h = static_cast<char*>(host_ptr);
+  std::lock_guard<std::mutex> lock(dev->stage_mu);
+  agpu_status st = stage_reserve_locked(dev, 2);
+  if (st != AGPU_OK) return st;
+  const size_t nchunks = (bytes + AGPU_STAGE_CHUNK - 1) / AGPU_STAGE_CHUNK;
+  auto len_of = [&](size_t c) { return bytes - c * AGPU_STAGE_CHUNK < AGPU_STAGE_CHUNK ? bytes - c * AGPU_STAGE_CHUNK : AGPU_STAGE_CHUNK; };
+  for (size_t c = 0; c < nchunks; c++) {
+    agpu_device::StageSlot& s = dev->stage[c & 1];
+    if (s.used) AGPU_HIP(hipEventSynchronize(s.ev));  // the DMA that last touched this slot
+    if (to_device) {
+      memcpy(s.host, h + c * AGPU_STAGE_CHUNK, len_of(c));
+      AGPU_HIP(hipMemcpyAsync(d + c * AGPU_STAGE_CHUNK, s.host, len_of(c), hipMemcpyHostToDevice, p->stream));
+    } else {
+      if (c >= 2) memcpy(h + (c - 2) * AGPU_STAGE_CHUNK, s.host, AGPU_STAGE_CHUNK);  // what the slot still holds
+      AGPU_HIP(hipMemcpyAsync(s.host, d + c * AGPU_STAGE_CHUNK, len_of(c), hipMemcpyDeviceToHost, p->stream));
+    }
+    AGPU_HIP(hipEventRecord(s.ev, p->stream));
+    s.used = true;
+  }
+  AGPU_HIP(hipStreamSynchronize(p->stream));
+  if (!to_device)
+    for (size_t c = nchunks >= 2 ? nchunks - 2 : 0; c < nchunks; c++) memcpy(h + c * AGPU_STAGE_CHUNK, dev->stage[c & 1].host, len_of(c));
+  return AGPU_OK;
+}
+
 static agpu_status staged_copy_impl(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device) {
   if (!bytes) return AGPU_OK;
   // auto = mode 1: measured on the MI355X box (tools/probe/h2d_sweep.py → profiles/r02_h2d_sweep.json, 1 GiB, EPYC 9575F host):
@@ -128,6 +164,7 @@ static agpu_status staged_copy_impl(agpu_pipeline* p, void* dev_ptr, void* host_
   // pageable copies slowly; it is not the default anywhere.
   int64_t mode = p->tune.h2d_mode;
   if (mode <= 0 || mode > 3) mode = 1;
+  if (mode == 1 && bytes <= AGPU_BOUNCE_MAX_BYTES) return agpu_internal_bounce_copy(p, dev_ptr, host_ptr, bytes, to_device);
   if (mode == 2) return staged_copy_threads(p, static_cast<char*>(dev_ptr), static_cast<char*>(host_ptr), bytes, to_device);
   if (mode == 3) {
     hipError_t e = hipHostRegister(host_ptr, bytes, hipHostRegisterDefault);

@@ -129,6 +129,9 @@ struct agpu_device {
 };
 #define AGPU_STAGE_CHUNK ((size_t)4 << 20)
 void agpu_internal_free_staging(agpu_device* dev);  // arrow_cdata.hip
+#define AGPU_BOUNCE_MAX_BYTES ((size_t)16 << 20)
+struct agpu_pipeline;
+agpu_status agpu_internal_bounce_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device);  // arrow_cdata.hip
 #define AGPU_TABLE_BYTES (512 * 16 + 128 * 16)
 agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table);  // elementwise.hip; synchronous
 

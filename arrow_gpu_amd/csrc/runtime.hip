@@ -590,7 +590,9 @@ agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, s
   AGPU_BIND(p);
   if (!bytes) return AGPU_OK;
   AGPU_REQUIRE(dst_dev && src_host, AGPU_ERR_ARG, "null pointer");
-  // pageable source: hipMemcpyAsync stages synchronously w.r.t. the host buffer, ordered on the stream
+  // small and medium sources go through the library's own page-locked slots (arrow_cdata.hip: why); big ones straight
+  // from the caller's pageable memory, ordered on the stream
+  if (bytes <= AGPU_BOUNCE_MAX_BYTES && !p->capturing) return agpu_internal_bounce_copy(p, dst_dev, const_cast<void*>(src_host), bytes, true);
   AGPU_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, p->stream));
   AGPU_HIP(hipStreamSynchronize(p->stream));
   return AGPU_OK;
@@ -603,6 +605,7 @@ agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev,
     return AGPU_OK;
   }
   AGPU_REQUIRE(dst_host && src_dev, AGPU_ERR_ARG, "null pointer");
+  if (bytes <= AGPU_BOUNCE_MAX_BYTES && !p->capturing) return agpu_internal_bounce_copy(p, const_cast<void*>(src_dev), dst_host, bytes, false);
   AGPU_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));
   AGPU_HIP(hipStreamSynchronize(p->stream));
   return AGPU_OK;
