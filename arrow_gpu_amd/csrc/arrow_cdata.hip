@@ -46,6 +46,14 @@ static agpu_status stage_reserve_locked(agpu_device* dev, size_t slots) {
 }
 
 void agpu_internal_free_staging(agpu_device* dev) {
+  for (int d = 0; d < 2; d++) {
+    std::lock_guard<std::mutex> block(dev->bounce_mu[d]);
+    if (dev->bounce[d].host) {
+      (void)hipEventDestroy(dev->bounce[d].ev);
+      (void)hipHostFree(dev->bounce[d].host);
+      dev->bounce[d].host = nullptr;
+    }
+  }
   std::lock_guard<std::mutex> lock(dev->stage_mu);
   for (auto& s : dev->stage) {
     (void)hipEventSynchronize(s.ev);
@@ -119,8 +127,8 @@ static agpu_status staged_copy_threads(agpu_pipeline* p, char* dev_ptr, char* ho
   return AGPU_OK;
 }
 
-// Small and medium transfers (≤ AGPU_BOUNCE_MAX_BYTES = 16 MiB) never hand the caller's pageable pointer to the runtime: the bytes go
-// through two of the device's page-locked slots, CPU memcpy on one while the DMA runs on the other.  A pageable
+// Small and medium transfers (≤ AGPU_BOUNCE_MAX_BYTES = 4 MiB) never hand the caller's pageable pointer to the runtime: the bytes go
+// through a page-locked slot of the device (one per direction).  A pageable
 // hipMemcpy makes the runtime pin the caller's pages for the duration (a KFD userptr mapping); with the C heap (numpy,
 // std::vector — brk memory that glibc keeps extending and trimming) that ended, about once in thirty runs of the GPU test
 // suite, in "Memory access fault by GPU … on address <a page of the brk heap>" raised from the runtime's event thread
@@ -129,29 +137,28 @@ static agpu_status staged_copy_threads(agpu_pipeline* p, char* dev_ptr, char* ho
 // returns — and the measured 56 GB/s.
 agpu_status agpu_internal_bounce_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device) {
   agpu_device* dev = p->dev;
-  char* d = static_cast<char*>(dev_ptr);
-  char* h = static_cast<char*>(host_ptr);
-  std::lock_guard<std::mutex> lock(dev->stage_mu);
-  agpu_status st = stage_reserve_locked(dev, 2);
-  if (st != AGPU_OK) return st;
-  const size_t nchunks = (bytes + AGPU_STAGE_CHUNK - 1) / AGPU_STAGE_CHUNK;
-  auto len_of = [&](size_t c) { return bytes - c * AGPU_STAGE_CHUNK < AGPU_STAGE_CHUNK ? bytes - c * AGPU_STAGE_CHUNK : AGPU_STAGE_CHUNK; };
-  for (size_t c = 0; c < nchunks; c++) {
-    agpu_device::StageSlot& s = dev->stage[c & 1];
-    if (s.used) AGPU_HIP(hipEventSynchronize(s.ev));  // the DMA that last touched this slot
-    if (to_device) {
-      memcpy(s.host, h + c * AGPU_STAGE_CHUNK, len_of(c));
-      AGPU_HIP(hipMemcpyAsync(d + c * AGPU_STAGE_CHUNK, s.host, len_of(c), hipMemcpyHostToDevice, p->stream));
-    } else {
-      if (c >= 2) memcpy(h + (c - 2) * AGPU_STAGE_CHUNK, s.host, AGPU_STAGE_CHUNK);  // what the slot still holds
-      AGPU_HIP(hipMemcpyAsync(s.host, d + c * AGPU_STAGE_CHUNK, len_of(c), hipMemcpyDeviceToHost, p->stream));
+  const int dir = to_device ? 0 : 1;
+  std::lock_guard<std::mutex> lock(dev->bounce_mu[dir]);
+  agpu_device::StageSlot& s = dev->bounce[dir];
+  if (!s.host) {
+    AGPU_HIP(hipHostMalloc(&s.host, AGPU_BOUNCE_MAX_BYTES, hipHostMallocDefault));
+    hipError_t e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      (void)hipHostFree(s.host);
+      s.host = nullptr;
+      agpu_set_error("hipEventCreate failed: %s", hipGetErrorString(e));
+      return AGPU_ERR_HIP;
     }
-    AGPU_HIP(hipEventRecord(s.ev, p->stream));
-    s.used = true;
   }
-  AGPU_HIP(hipStreamSynchronize(p->stream));
-  if (!to_device)
-    for (size_t c = nchunks >= 2 ? nchunks - 2 : 0; c < nchunks; c++) memcpy(h + c * AGPU_STAGE_CHUNK, dev->stage[c & 1].host, len_of(c));
+  if (to_device) {
+    memcpy(s.host, host_ptr, bytes);
+    AGPU_HIP(hipMemcpyAsync(dev_ptr, s.host, bytes, hipMemcpyHostToDevice, p->stream));
+    AGPU_HIP(hipStreamSynchronize(p->stream));  // the slot is free again and, as before, the data is in place on return
+  } else {
+    AGPU_HIP(hipMemcpyAsync(s.host, dev_ptr, bytes, hipMemcpyDeviceToHost, p->stream));
+    AGPU_HIP(hipStreamSynchronize(p->stream));
+    memcpy(host_ptr, s.host, bytes);
+  }
   return AGPU_OK;
 }
 

@@ -126,10 +126,14 @@ struct agpu_device {
   };
   std::mutex stage_mu;
   std::vector<StageSlot> stage;
+  // bounce slots of the small-transfer path (agpu_internal_bounce_copy): one per direction so an upload and a download
+  // from two host threads do not serialise
+  std::mutex bounce_mu[2];
+  StageSlot bounce[2] = {{nullptr, nullptr, false}, {nullptr, nullptr, false}};
 };
 #define AGPU_STAGE_CHUNK ((size_t)4 << 20)
 void agpu_internal_free_staging(agpu_device* dev);  // arrow_cdata.hip
-#define AGPU_BOUNCE_MAX_BYTES ((size_t)16 << 20)
+#define AGPU_BOUNCE_MAX_BYTES ((size_t)4 << 20)  // = one stage slot
 struct agpu_pipeline;
 agpu_status agpu_internal_bounce_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device);  // arrow_cdata.hip
 #define AGPU_TABLE_BYTES (512 * 16 + 128 * 16)
