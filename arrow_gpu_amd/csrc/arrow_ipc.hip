@@ -458,6 +458,7 @@ static agpu_status column_buffers(const agpu_ipc_reader* r, int64_t batch, int32
   const size_t nat = nodes.first + 16 * (size_t)fi.first_node;
   const int64_t len = mb.i64(nat), nulls = mb.i64(nat + 8);
   AGPU_REQUIRE(len >= 0 && nulls >= 0 && nulls <= len, AGPU_ERR_SHAPE, "bad FieldNode");
+  AGPU_REQUIRE((uint64_t)len <= (uint64_t)bi.body_len * 8, AGPU_ERR_SHAPE, "FieldNode.length exceeds what the body can hold");  // also keeps len × width from overflowing
   const size_t bat = bufs.first + 16 * (size_t)fi.first_buffer;
   const int64_t voff = mb.i64(bat), vlen = mb.i64(bat + 8), doff = mb.i64(bat + 16), dlen = mb.i64(bat + 24);
   AGPU_REQUIRE(voff >= 0 && vlen >= 0 && doff >= 0 && dlen >= 0, AGPU_ERR_SHAPE, "negative buffer offset / length");

@@ -182,6 +182,20 @@ def test_compressed_and_mismatched_input_is_refused():
         w.write_host_batch([pa.array([1, 2, 3], pa.int32()), pa.array([1.0], pa.float32())])
     with pytest.raises(capi.OperationNotSupported):
         IpcWriter([("a", 99, True)])
+    # a FieldNode length far beyond the body (len × 4 would wrap around 2^64) must be refused, not believed
+    small = pa.table({"a": pa.array(np.arange(7, dtype=np.int32))})
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, small.schema) as w2:
+        w2.write_table(small)
+    raw = bytearray(sink.getvalue().to_pybytes())
+    seven = (7).to_bytes(8, "little")
+    hits = [i for i in range(len(raw) - 8) if raw[i:i + 8] == seven]
+    assert hits
+    for i in hits:  # RecordBatch.length and FieldNode.length both hold 7
+        raw[i:i + 8] = (1 << 62).to_bytes(8, "little")
+    with IpcReader(bytes(raw)) as r:
+        with pytest.raises(capi.ArrowErrorGPU):
+            r.column_view(0, 0)
     with pytest.raises(capi.ArrowErrorGPU):
         IpcReader(b"definitely not arrow")
     with pytest.raises(capi.ArrowErrorGPU):
