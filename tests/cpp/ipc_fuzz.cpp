@@ -1,0 +1,96 @@
+// Sanitizer harness for the Arrow IPC reader (arrow_gpu_amd/csrc/arrow_ipc.hip, host-only entry points): built with
+// -fsanitize=address,undefined by tests/test_sanitizers.py.  Reads an IPC stream / file from argv[1], then opens, walks and
+// touches every readable column of (a) the pristine bytes, (b) every truncation on a coarse grid, (c) N random byte flips —
+// each mutation on a heap copy of EXACTLY the mutated length, so that any read past the end is an ASan report.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/arrow_gpu.h"
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() {
+  rng_state ^= rng_state << 13;
+  rng_state ^= rng_state >> 7;
+  rng_state ^= rng_state << 17;
+  return rng_state;
+}
+
+static uint64_t walk(const uint8_t* data, size_t n, int* opened) {
+  agpu_ipc_reader* r = nullptr;
+  uint64_t sum = 0;
+  if (agpu_ipc_open(data, n, &r) != AGPU_OK) return 0;
+  (*opened)++;
+  int32_t nf = 0;
+  int64_t nbat = 0;
+  agpu_ipc_num_fields(r, &nf);
+  agpu_ipc_num_batches(r, &nbat);
+  for (int32_t i = 0; i < nf; i++) {
+    agpu_ipc_field f;
+    if (agpu_ipc_field_info(r, i, &f) == AGPU_OK) sum += strlen(f.name) + strlen(f.format);
+  }
+  for (int64_t b = 0; b < nbat; b++) {
+    int64_t rows = 0;
+    agpu_ipc_batch_rows(r, b, &rows);
+    for (int32_t c = 0; c < nf; c++) {
+      struct ArrowArray a;
+      struct ArrowSchema s;
+      if (agpu_ipc_column_view(r, b, c, &a, &s) != AGPU_OK) continue;
+      agpu_ipc_field f;
+      agpu_ipc_field_info(r, c, &f);
+      const size_t w = f.dtype == AGPU_BOOL ? 0 : agpu_dtype_size((agpu_dtype)f.dtype);
+      const size_t vbytes = w ? (size_t)a.length * w : (size_t)((a.length + 7) / 8);
+      const uint8_t* values = static_cast<const uint8_t*>(a.buffers[1]);
+      const uint8_t* validity = static_cast<const uint8_t*>(a.buffers[0]);
+      for (size_t k = 0; k < vbytes; k++) sum += values[k];  // every byte the view claims must be inside `data`
+      if (validity)
+        for (size_t k = 0; k < (size_t)((a.length + 7) / 8); k++) sum += validity[k];
+      a.release(&a);
+      s.release(&s);
+    }
+  }
+  agpu_ipc_close(r);
+  return sum;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  std::vector<uint8_t> src;
+  uint8_t buf[65536];
+  size_t k;
+  while ((k = fread(buf, 1, sizeof(buf), f)) > 0) src.insert(src.end(), buf, buf + k);
+  fclose(f);
+  const int flips = argc > 2 ? atoi(argv[2]) : 2000;
+  int opened = 0, cases = 0;
+  uint64_t sum = 0;
+  auto run = [&](const std::vector<uint8_t>& bytes) {  // exact-size heap copy: ASan guards both ends
+    uint8_t* p = static_cast<uint8_t*>(malloc(bytes.size() ? bytes.size() : 1));
+    if (!bytes.empty()) memcpy(p, bytes.data(), bytes.size());
+    sum += walk(p, bytes.size(), &opened);
+    free(p);
+    cases++;
+  };
+  run(src);
+  if (!opened) {
+    fprintf(stderr, "the pristine input did not open\n");
+    return 1;
+  }
+  for (size_t cut = 0; cut < src.size(); cut += (cut < 4096 ? 1 : 509)) run(std::vector<uint8_t>(src.begin(), src.begin() + (long)cut));
+  for (int i = 0; i < flips; i++) {
+    std::vector<uint8_t> m = src;
+    const int nflip = 1 + (int)(rnd() % 4);
+    for (int j = 0; j < nflip; j++) {
+      // metadata lives at the head (schema, first batches) and — for files — at the tail (footer): bias towards both
+      const uint64_t span = m.size() < 6000 ? m.size() : 6000;
+      const size_t pos = (rnd() & 1) ? (size_t)(rnd() % span) : m.size() - 1 - (size_t)(rnd() % span);
+      m[pos] = (uint8_t)rnd();
+    }
+    run(m);
+  }
+  printf("ipc_fuzz OK: %d cases, %d opened, checksum %llu\n", cases, opened, (unsigned long long)sum);
+  return 0;
+}

@@ -61,3 +61,34 @@ def test_c_examples_compile_with_sanitizers():
             env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
             r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
             assert r.returncode == 2, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+def test_ipc_reader_under_asan_ubsan_with_truncated_and_corrupted_input(tmp_path):
+    """The Arrow IPC reader (csrc/arrow_ipc.hip, host-only entry points) compiled with ASan + UBSan into
+    tests/cpp/ipc_fuzz.cpp: every truncation on a grid and 2 × 1500 random byte flips of a pyarrow-written stream and
+    file, each on a heap copy of exactly the mutated length, every byte a column view claims is read."""
+    pytest.importorskip("pyarrow")
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_ipc_host import make_table, serialise
+
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "ipc_fuzz_asan")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    libdir = os.path.join(ROOT, "arrow_gpu_amd", "lib")
+    srcs = [os.path.join(ROOT, "arrow_gpu_amd", "csrc", "arrow_ipc.hip"), os.path.join(ROOT, "tests", "cpp", "ipc_fuzz.cpp")]
+    deps = srcs + [os.path.join(ROOT, "arrow_gpu_amd", "csrc", "common.hpp"), os.path.join(ROOT, "include", "arrow_gpu.h")]
+    if not (os.path.exists(exe) and all(os.path.getmtime(exe) >= os.path.getmtime(d) for d in deps)):
+        cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-g", "--offload-host-only", "-fsanitize=address,undefined",
+               "-fno-sanitize-recover=undefined", "-x", "hip", srcs[0], "-x", "c++", srcs[1], "-o", exe, f"-L{libdir}",
+               "-larrow_gpu_hip", "-Wl,-rpath," + libdir]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+    table = make_table(np.random.default_rng(1), 300)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    for file_format in (False, True):
+        path = tmp_path / ("f.arrow" if file_format else "s.arrow")
+        path.write_bytes(serialise(table, file_format, 100))
+        r = subprocess.run([exe, str(path), "1500"], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "ipc_fuzz OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+        assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
