@@ -24,459 +24,7 @@
 
 #include "common.hpp"
 
-namespace {
-
-// ---------------------------------------------------------------- Flatbuffers, reading (every access bounds-checked)
-struct FbBuf {
-  const uint8_t* p;
-  size_t n;
-  bool has(size_t pos, size_t len) const { return pos <= n && len <= n - pos; }
-  uint16_t u16(size_t pos) const { uint16_t v; memcpy(&v, p + pos, 2); return v; }
-  uint32_t u32(size_t pos) const { uint32_t v; memcpy(&v, p + pos, 4); return v; }
-  int32_t i32(size_t pos) const { int32_t v; memcpy(&v, p + pos, 4); return v; }
-  int64_t i64(size_t pos) const { int64_t v; memcpy(&v, p + pos, 8); return v; }
-};
-struct FbTable {
-  const FbBuf* b = nullptr;
-  size_t pos = 0, vt = 0;
-  uint16_t vt_size = 0, tab_size = 0;
-  bool ok = false;
-};
-struct FbVec {
-  const FbBuf* b = nullptr;
-  size_t first = 0;  // position of element 0
-  uint32_t len = 0;
-  bool ok = false;
-};
-static FbTable fb_table_at(const FbBuf& b, size_t pos) {
-  FbTable t;
-  t.b = &b;
-  if (!b.has(pos, 4)) return t;
-  const int64_t vt = (int64_t)pos - (int64_t)b.i32(pos);
-  if (vt < 0 || !b.has((size_t)vt, 4)) return t;
-  t.pos = pos;
-  t.vt = (size_t)vt;
-  t.vt_size = b.u16(t.vt);
-  t.tab_size = b.u16(t.vt + 2);
-  if (t.vt_size < 4 || (t.vt_size & 1) || !b.has(t.vt, t.vt_size) || t.tab_size < 4 || !b.has(pos, t.tab_size)) return t;
-  t.ok = true;
-  return t;
-}
-static FbTable fb_root(const FbBuf& b) {
-  if (!b.has(0, 4)) return FbTable{};
-  return fb_table_at(b, b.u32(0));
-}
-// position of field `id` inside the table, or 0 when absent (default value applies)
-static size_t fb_field(const FbTable& t, int id, size_t size) {
-  const size_t slot = 4 + 2 * (size_t)id;
-  if (!t.ok || slot + 2 > t.vt_size) return 0;
-  const uint16_t o = t.b->u16(t.vt + slot);
-  if (!o || (size_t)o + size > t.tab_size) return 0;
-  return t.pos + o;
-}
-static int64_t fb_i64(const FbTable& t, int id, int64_t dflt) { const size_t f = fb_field(t, id, 8); return f ? t.b->i64(f) : dflt; }
-static int32_t fb_i32(const FbTable& t, int id, int32_t dflt) { const size_t f = fb_field(t, id, 4); return f ? t.b->i32(f) : dflt; }
-static int16_t fb_i16(const FbTable& t, int id, int16_t dflt) { const size_t f = fb_field(t, id, 2); return f ? (int16_t)t.b->u16(f) : dflt; }
-static uint8_t fb_u8(const FbTable& t, int id, uint8_t dflt) { const size_t f = fb_field(t, id, 1); return f ? t.b->p[f] : dflt; }
-static bool fb_present(const FbTable& t, int id) { return fb_field(t, id, 4) != 0; }
-static FbTable fb_sub(const FbTable& t, int id) {
-  const size_t f = fb_field(t, id, 4);
-  if (!f) return FbTable{};
-  const uint64_t target = (uint64_t)f + t.b->u32(f);
-  if (target > t.b->n) return FbTable{};
-  return fb_table_at(*t.b, (size_t)target);
-}
-static FbVec fb_vec(const FbTable& t, int id, size_t elem) {
-  FbVec v;
-  v.b = t.b;
-  const size_t f = fb_field(t, id, 4);
-  if (!f) return v;
-  const uint64_t target = (uint64_t)f + t.b->u32(f);
-  if (target > t.b->n || !t.b->has((size_t)target, 4)) return v;
-  v.len = t.b->u32((size_t)target);
-  v.first = (size_t)target + 4;
-  if ((uint64_t)v.len * elem > t.b->n || !t.b->has(v.first, (size_t)v.len * elem)) return v;
-  v.ok = true;
-  return v;
-}
-static FbTable fb_vec_table(const FbVec& v, uint32_t i) {
-  const size_t at = v.first + 4 * (size_t)i;
-  const uint64_t target = (uint64_t)at + v.b->u32(at);
-  if (target > v.b->n) return FbTable{};
-  return fb_table_at(*v.b, (size_t)target);
-}
-static bool fb_string(const FbTable& t, int id, std::string* out) {
-  const FbVec v = fb_vec(t, id, 1);
-  if (!v.ok) return false;
-  out->assign(reinterpret_cast<const char*>(v.b->p + v.first), v.len);
-  return true;
-}
-
-// ---------------------------------------------------------------- Flatbuffers, writing (front to back)
-struct FbOut {
-  std::vector<uint8_t> b;
-  void pad_to(size_t align, size_t bias = 0) {  // make (size + bias) a multiple of align
-    while ((b.size() + bias) % align) b.push_back(0);
-  }
-  void raw(const void* v, size_t n) { const uint8_t* s = static_cast<const uint8_t*>(v); b.insert(b.end(), s, s + n); }
-  void u16(uint16_t v) { raw(&v, 2); }
-  void u32(uint32_t v) { raw(&v, 4); }
-  void i64(int64_t v) { raw(&v, 8); }
-  void patch32(size_t at, uint32_t v) { memcpy(b.data() + at, &v, 4); }
-  void link(size_t ref_at) { patch32(ref_at, (uint32_t)(b.size() - ref_at)); }  // uoffset: from the field to the target that starts HERE
-};
-struct FbField {
-  int id;
-  int size;      // 1, 2, 4 or 8
-  uint64_t val;  // scalar value; ignored for references
-  bool ref;      // a uoffset to be linked later
-  size_t at;     // out: absolute position of the field
-};
-// vtable + table; the table starts 8-byte aligned.  Returns the table's position; fields[i].at = where each value sits.
-static size_t fb_write_table(FbOut& o, std::vector<FbField>& fields) {
-  int slots = 0;
-  for (auto& f : fields) slots = f.id + 1 > slots ? f.id + 1 : slots;
-  const size_t vt_size = 4 + 2 * (size_t)slots;
-  o.pad_to(8, vt_size);  // the table follows the vtable immediately and must sit on an 8-byte boundary
-  const size_t vt = o.b.size();
-  std::vector<uint16_t> off((size_t)slots, 0);
-  size_t cur = 4;  // after the soffset
-  for (int size : {8, 4, 2, 1})
-    for (auto& f : fields)
-      if (f.size == size) {
-        cur = (cur + (size_t)size - 1) / (size_t)size * (size_t)size;
-        off[(size_t)f.id] = (uint16_t)cur;
-        cur += (size_t)size;
-      }
-  const size_t tab_size = (cur + 3) / 4 * 4;
-  o.u16((uint16_t)vt_size);
-  o.u16((uint16_t)tab_size);
-  for (uint16_t x : off) o.u16(x);
-  const size_t tab = o.b.size();
-  o.b.resize(tab + tab_size, 0);
-  const int32_t so = (int32_t)(tab - vt);
-  memcpy(o.b.data() + tab, &so, 4);
-  for (auto& f : fields) {
-    f.at = tab + off[(size_t)f.id];
-    if (!f.ref) memcpy(o.b.data() + f.at, &f.val, (size_t)f.size);  // little-endian host
-  }
-  return tab;
-}
-static void fb_write_string(FbOut& o, size_t ref_at, const std::string& s) {
-  o.pad_to(4);
-  o.link(ref_at);
-  o.u32((uint32_t)s.size());
-  o.raw(s.data(), s.size());
-  o.b.push_back(0);
-}
-
-// ---------------------------------------------------------------- Arrow metadata constants (format/Schema.fbs, Message.fbs)
-enum : uint8_t {
-  T_NONE = 0, T_Null = 1, T_Int = 2, T_FloatingPoint = 3, T_Binary = 4, T_Utf8 = 5, T_Bool = 6, T_Decimal = 7, T_Date = 8,
-  T_Time = 9, T_Timestamp = 10, T_Interval = 11, T_List = 12, T_Struct = 13, T_Union = 14, T_FixedSizeBinary = 15,
-  T_FixedSizeList = 16, T_Map = 17, T_Duration = 18, T_LargeBinary = 19, T_LargeUtf8 = 20, T_LargeList = 21,
-  T_RunEndEncoded = 22, T_BinaryView = 23, T_Utf8View = 24, T_ListView = 25, T_LargeListView = 26
-};
-enum : uint8_t { H_NONE = 0, H_Schema = 1, H_DictionaryBatch = 2, H_RecordBatch = 3 };
-constexpr int16_t kV4 = 3, kV5 = 4;
-constexpr uint32_t kContinuation = 0xFFFFFFFFu;
-
-struct FieldInfo {
-  std::string name, format;
-  int32_t dtype = -1;  // agpu_dtype or -1
-  bool nullable = true;
-  int64_t n_nodes = 0, n_buffers = 0;         // of the whole subtree; -1: layout unknown (view types)
-  int64_t first_node = -1, first_buffer = -1; // in a record batch's flattened lists; -1: not locatable
-};
-struct BatchInfo {
-  size_t meta_pos, meta_len;  // the Message flatbuffer
-  size_t body_pos, body_len;
-  int64_t rows;
-};
-
-// nodes / buffers one field contributes to a record batch (depth first); false = unknown layout
-static bool field_layout(const FbTable& field, int16_t version, int64_t* nodes, int64_t* buffers, int depth) {
-  if (!field.ok || depth > 64) return false;
-  const uint8_t tt = fb_u8(field, 2, T_NONE);
-  int64_t own = 0;
-  bool with_children = false;
-  if (fb_sub(field, 4).ok) {  // dictionary-encoded: the batch carries the indices (an Int column); children live in the dictionary
-    *nodes += 1;
-    *buffers += 2;
-    return true;
-  }
-  switch (tt) {
-    case T_Null: own = 0; break;
-    case T_Int: case T_FloatingPoint: case T_Bool: case T_Decimal: case T_Date: case T_Time: case T_Timestamp:
-    case T_Interval: case T_Duration: case T_FixedSizeBinary: own = 2; break;
-    case T_Binary: case T_Utf8: case T_LargeBinary: case T_LargeUtf8: own = 3; break;
-    case T_List: case T_LargeList: case T_Map: own = 2; with_children = true; break;
-    case T_ListView: case T_LargeListView: own = 3; with_children = true; break;
-    case T_Struct: case T_FixedSizeList: own = 1; with_children = true; break;
-    case T_RunEndEncoded: own = 0; with_children = true; break;
-    case T_Union: {
-      const FbTable u = fb_sub(field, 3);
-      const int16_t mode = u.ok ? fb_i16(u, 0, 0) : 0;  // Sparse = 0, Dense = 1
-      own = (mode == 1 ? 2 : 1) + (version < kV5 ? 1 : 0);
-      with_children = true;
-      break;
-    }
-    default: return false;  // view types (variadic buffers) and anything newer than this reader
-  }
-  *nodes += 1;
-  *buffers += own;
-  if (with_children) {
-    const FbVec ch = fb_vec(field, 5, 4);
-    if (ch.ok)
-      for (uint32_t i = 0; i < ch.len; i++)
-        if (!field_layout(fb_vec_table(ch, i), version, nodes, buffers, depth + 1)) return false;
-  }
-  return true;
-}
-
-static void classify_type(const FbTable& field, FieldInfo* fi) {
-  const uint8_t tt = fb_u8(field, 2, T_NONE);
-  const FbTable ty = fb_sub(field, 3);
-  fi->dtype = -1;
-  fi->format = "";
-  if (fb_sub(field, 4).ok) return;  // dictionary-encoded
-  switch (tt) {
-    case T_Int: {
-      const int32_t bits = ty.ok ? fb_i32(ty, 0, 0) : 0;
-      const bool sg = ty.ok && fb_u8(ty, 1, 0) != 0;
-      if (bits == 8) { fi->dtype = sg ? AGPU_I8 : AGPU_U8; fi->format = sg ? "c" : "C"; }
-      else if (bits == 16) { fi->dtype = sg ? AGPU_I16 : AGPU_U16; fi->format = sg ? "s" : "S"; }
-      else if (bits == 32) { fi->dtype = sg ? AGPU_I32 : AGPU_U32; fi->format = sg ? "i" : "I"; }
-      else if (bits == 64) fi->format = sg ? "l" : "L";
-      break;
-    }
-    case T_FloatingPoint: {
-      const int16_t prec = ty.ok ? fb_i16(ty, 0, 0) : 0;  // HALF, SINGLE, DOUBLE
-      if (prec == 1) { fi->dtype = AGPU_F32; fi->format = "f"; }
-      else fi->format = prec == 0 ? "e" : "g";
-      break;
-    }
-    case T_Bool: fi->dtype = AGPU_BOOL; fi->format = "b"; break;
-    case T_Date: {
-      const int16_t unit = ty.ok ? fb_i16(ty, 0, 1) : 1;  // DAY = 0, MILLISECOND = 1 (the schema's default)
-      if (unit == 0) { fi->dtype = AGPU_DATE32; fi->format = "tdD"; }
-      else fi->format = "tdm";
-      break;
-    }
-    case T_Utf8: fi->format = "u"; break;
-    case T_Binary: fi->format = "z"; break;
-    case T_LargeUtf8: fi->format = "U"; break;
-    case T_LargeBinary: fi->format = "Z"; break;
-    case T_Null: fi->format = "n"; break;
-    default: break;
-  }
-}
-
-static size_t bitmap_span_bytes(uint64_t n_bits) { return (size_t)((n_bits + 7) / 8); }
-
-}  // namespace
-
-struct agpu_ipc_reader {
-  FbBuf data{nullptr, 0};
-  bool is_file = false;
-  int16_t version = kV5;
-  std::vector<FieldInfo> fields;
-  std::vector<BatchInfo> batches;
-};
-
-namespace {
-
-static agpu_status parse_schema(agpu_ipc_reader* r, const FbTable& schema) {
-  AGPU_REQUIRE(schema.ok, AGPU_ERR_SHAPE, "malformed Schema table");
-  if (fb_i16(schema, 0, 0) != 0) {
-    agpu_set_error("agpu_ipc_open: big-endian IPC data is not supported");
-    return AGPU_ERR_UNSUPPORTED;
-  }
-  const FbVec fv = fb_vec(schema, 1, 4);
-  AGPU_REQUIRE(fv.ok || !fb_present(schema, 1), AGPU_ERR_SHAPE, "malformed Schema.fields");
-  int64_t node = 0, buf = 0;
-  bool locatable = true;
-  for (uint32_t i = 0; fv.ok && i < fv.len; i++) {
-    const FbTable f = fb_vec_table(fv, i);
-    AGPU_REQUIRE(f.ok, AGPU_ERR_SHAPE, "malformed Field table");
-    FieldInfo fi;
-    (void)fb_string(f, 0, &fi.name);
-    fi.nullable = fb_u8(f, 1, 0) != 0;
-    classify_type(f, &fi);
-    int64_t nn = 0, nb = 0;
-    const bool known = field_layout(f, r->version, &nn, &nb, 0);
-    fi.n_nodes = known ? nn : -1;
-    fi.n_buffers = known ? nb : -1;
-    if (locatable) {
-      fi.first_node = node;
-      fi.first_buffer = buf;
-    }
-    if (!known) {
-      fi.dtype = -1;
-      locatable = false;  // the columns after a variadic-layout column cannot be located from the schema alone
-    }
-    node += nn;
-    buf += nb;
-    r->fields.push_back(std::move(fi));
-  }
-  return AGPU_OK;
-}
-
-// one encapsulated message at `pos`; *next = position after its body
-static agpu_status parse_message(agpu_ipc_reader* r, size_t pos, bool* end, bool* have_schema, size_t* next) {
-  const FbBuf& d = r->data;
-  *end = false;
-  if (!d.has(pos, 4)) {
-    *end = true;  // a stream may simply stop (the end-of-stream marker is optional)
-    return AGPU_OK;
-  }
-  uint32_t size = d.u32(pos);
-  pos += 4;
-  if (size == kContinuation) {
-    AGPU_REQUIRE(d.has(pos, 4), AGPU_ERR_SHAPE, "truncated message prefix");
-    size = d.u32(pos);
-    pos += 4;
-  }  // else: the pre-0.15 framing, the length alone
-  if (size == 0) {
-    *end = true;
-    return AGPU_OK;
-  }
-  AGPU_REQUIRE(d.has(pos, size), AGPU_ERR_SHAPE, "truncated message metadata");
-  FbBuf* mb = new FbBuf{d.p + pos, size};  // tables keep a pointer to their buffer: give it a stable home for this call
-  std::unique_ptr<FbBuf> hold(mb);
-  const FbTable msg = fb_root(*mb);
-  AGPU_REQUIRE(msg.ok, AGPU_ERR_SHAPE, "malformed Message flatbuffer");
-  const int16_t version = fb_i16(msg, 0, 0);
-  const uint8_t htype = fb_u8(msg, 1, H_NONE);
-  const int64_t body_len = fb_i64(msg, 3, 0);
-  AGPU_REQUIRE(body_len >= 0 && d.has(pos + size, (size_t)body_len), AGPU_ERR_SHAPE, "truncated message body");
-  const size_t body_pos = pos + size;
-  *next = body_pos + (size_t)body_len;
-  if (htype == H_Schema) {
-    AGPU_REQUIRE(!*have_schema, AGPU_ERR_SHAPE, "second Schema message");
-    if (version < kV4) {
-      agpu_set_error("agpu_ipc_open: metadata version %d predates V4", (int)version);
-      return AGPU_ERR_UNSUPPORTED;
-    }
-    r->version = version;
-    agpu_status st = parse_schema(r, fb_sub(msg, 2));
-    if (st != AGPU_OK) return st;
-    *have_schema = true;
-  } else if (htype == H_RecordBatch) {
-    AGPU_REQUIRE(*have_schema, AGPU_ERR_SHAPE, "RecordBatch before Schema");
-    const FbTable rb = fb_sub(msg, 2);
-    AGPU_REQUIRE(rb.ok, AGPU_ERR_SHAPE, "malformed RecordBatch table");
-    BatchInfo bi{pos, size, body_pos, (size_t)body_len, fb_i64(rb, 0, 0)};
-    AGPU_REQUIRE(bi.rows >= 0, AGPU_ERR_SHAPE, "negative RecordBatch.length");
-    r->batches.push_back(bi);
-  }  // DictionaryBatch / Tensor / SparseTensor: skipped (dictionary columns are reported as unsupported per column)
-  return AGPU_OK;
-}
-
-static agpu_status parse_stream(agpu_ipc_reader* r, size_t pos) {
-  bool have_schema = false, end = false;
-  while (!end) {
-    size_t next = pos;
-    agpu_status st = parse_message(r, pos, &end, &have_schema, &next);
-    if (st != AGPU_OK) return st;
-    pos = next;
-  }
-  AGPU_REQUIRE(have_schema, AGPU_ERR_SHAPE, "no Schema message");
-  return AGPU_OK;
-}
-
-// File format: the Footer lists every record batch as a Block {offset, metaDataLength, bodyLength}
-static agpu_status parse_file(agpu_ipc_reader* r) {
-  const FbBuf& d = r->data;
-  AGPU_REQUIRE(d.n >= 8 + 4 + 6 && !memcmp(d.p + d.n - 6, "ARROW1", 6), AGPU_ERR_SHAPE, "file does not end with the ARROW1 magic");
-  const int32_t fsize = d.i32(d.n - 10);
-  AGPU_REQUIRE(fsize > 0 && (size_t)fsize <= d.n - 18, AGPU_ERR_SHAPE, "bad footer size");
-  FbBuf fb{d.p + d.n - 10 - (size_t)fsize, (size_t)fsize};
-  const FbTable footer = fb_root(fb);
-  AGPU_REQUIRE(footer.ok, AGPU_ERR_SHAPE, "malformed Footer flatbuffer");
-  r->version = fb_i16(footer, 0, 0);
-  if (r->version < kV4) {
-    agpu_set_error("agpu_ipc_open: metadata version %d predates V4", (int)r->version);
-    return AGPU_ERR_UNSUPPORTED;
-  }
-  agpu_status st = parse_schema(r, fb_sub(footer, 1));
-  if (st != AGPU_OK) return st;
-  const FbVec blocks = fb_vec(footer, 3, 24);
-  AGPU_REQUIRE(blocks.ok || !fb_present(footer, 3), AGPU_ERR_SHAPE, "malformed Footer.recordBatches");
-  for (uint32_t i = 0; blocks.ok && i < blocks.len; i++) {
-    const size_t at = blocks.first + 24 * (size_t)i;
-    const int64_t off = fb.i64(at);
-    AGPU_REQUIRE(off >= 8 && (uint64_t)off < d.n, AGPU_ERR_SHAPE, "record batch block outside the file");
-    bool have_schema = true, end = false;
-    size_t next = 0;
-    const size_t before = r->batches.size();
-    st = parse_message(r, (size_t)off, &end, &have_schema, &next);
-    if (st != AGPU_OK) return st;
-    AGPU_REQUIRE(!end && r->batches.size() == before + 1, AGPU_ERR_SHAPE, "footer block does not point at a RecordBatch");
-  }
-  return AGPU_OK;
-}
-
-struct ViewPrivate {
-  const void* buffers[2];
-  std::string format, name;
-};
-static void release_view_array(struct ArrowArray* a) {
-  if (!a || !a->release) return;
-  delete static_cast<ViewPrivate*>(a->private_data);
-  a->release = nullptr;
-}
-static void release_view_schema(struct ArrowSchema* s) {
-  if (!s || !s->release) return;
-  delete static_cast<ViewPrivate*>(s->private_data);
-  s->release = nullptr;
-}
-
-static agpu_status column_buffers(const agpu_ipc_reader* r, int64_t batch, int32_t column, const FieldInfo** out_fi,
-                                  int64_t* rows, int64_t* null_count, const uint8_t** validity, const uint8_t** values) {
-  AGPU_REQUIRE(r, AGPU_ERR_ARG, "null reader");
-  AGPU_REQUIRE(batch >= 0 && (size_t)batch < r->batches.size(), AGPU_ERR_ARG, "batch index out of range");
-  AGPU_REQUIRE(column >= 0 && (size_t)column < r->fields.size(), AGPU_ERR_ARG, "column index out of range");
-  const FieldInfo& fi = r->fields[(size_t)column];
-  if (fi.dtype < 0 || fi.first_node < 0) {
-    agpu_set_error("agpu_ipc: column %d ('%s', format '%s') has no GPU array type (i8 u8 i16 u16 i32 u32 f32 bool date32)",
-                   (int)column, fi.name.c_str(), fi.format.c_str());
-    return AGPU_ERR_UNSUPPORTED;
-  }
-  const BatchInfo& bi = r->batches[(size_t)batch];
-  FbBuf mb{r->data.p + bi.meta_pos, bi.meta_len};
-  const FbTable rb = fb_sub(fb_root(mb), 2);
-  AGPU_REQUIRE(rb.ok, AGPU_ERR_SHAPE, "malformed RecordBatch table");
-  if (fb_present(rb, 3)) {
-    agpu_set_error("agpu_ipc: compressed record batch bodies (LZ4 / ZSTD) are not supported");
-    return AGPU_ERR_UNSUPPORTED;
-  }
-  const FbVec nodes = fb_vec(rb, 1, 16), bufs = fb_vec(rb, 2, 16);
-  AGPU_REQUIRE(nodes.ok && bufs.ok, AGPU_ERR_SHAPE, "malformed RecordBatch nodes / buffers");
-  AGPU_REQUIRE((uint64_t)fi.first_node < nodes.len && (uint64_t)fi.first_buffer + 2 <= bufs.len, AGPU_ERR_SHAPE,
-               "RecordBatch has fewer nodes / buffers than the schema requires");
-  const size_t nat = nodes.first + 16 * (size_t)fi.first_node;
-  const int64_t len = mb.i64(nat), nulls = mb.i64(nat + 8);
-  AGPU_REQUIRE(len >= 0 && nulls >= 0 && nulls <= len, AGPU_ERR_SHAPE, "bad FieldNode");
-  AGPU_REQUIRE((uint64_t)len <= (uint64_t)bi.body_len * 8, AGPU_ERR_SHAPE, "FieldNode.length exceeds what the body can hold");  // also keeps len × width from overflowing
-  const size_t bat = bufs.first + 16 * (size_t)fi.first_buffer;
-  const int64_t voff = mb.i64(bat), vlen = mb.i64(bat + 8), doff = mb.i64(bat + 16), dlen = mb.i64(bat + 24);
-  AGPU_REQUIRE(voff >= 0 && vlen >= 0 && doff >= 0 && dlen >= 0, AGPU_ERR_SHAPE, "negative buffer offset / length");
-  AGPU_REQUIRE((uint64_t)voff <= bi.body_len && (uint64_t)vlen <= bi.body_len - (uint64_t)voff && (uint64_t)doff <= bi.body_len &&
-                   (uint64_t)dlen <= bi.body_len - (uint64_t)doff,
-               AGPU_ERR_SHAPE, "buffer outside the message body");
-  const size_t need = fi.dtype == AGPU_BOOL ? bitmap_span_bytes((uint64_t)len) : (size_t)len * agpu_dtype_size((agpu_dtype)fi.dtype);
-  AGPU_REQUIRE((uint64_t)dlen >= need, AGPU_ERR_SHAPE, "values buffer shorter than the column");
-  AGPU_REQUIRE(nulls == 0 || (uint64_t)vlen >= bitmap_span_bytes((uint64_t)len), AGPU_ERR_SHAPE, "validity buffer shorter than the column");
-  *out_fi = &fi;
-  *rows = len;
-  *null_count = nulls;
-  *validity = (nulls > 0 && vlen > 0) ? r->data.p + bi.body_pos + (size_t)voff : nullptr;
-  *values = r->data.p + bi.body_pos + (size_t)doff;
-  return AGPU_OK;
-}
-
-}  // namespace
+#include "arrow_ipc_reader.inc"
 
 // ================================================================ writer
 struct agpu_ipc_writer {
@@ -706,81 +254,6 @@ static void build_batch_message(FbOut& o, int64_t rows, const std::vector<int64_
 }  // namespace
 
 extern "C" {
-
-agpu_status agpu_ipc_open(const void* data, uint64_t bytes, agpu_ipc_reader** out_reader) {
-  AGPU_REQUIRE(data && out_reader, AGPU_ERR_ARG, "null argument");
-  *out_reader = nullptr;
-  std::unique_ptr<agpu_ipc_reader> r(new agpu_ipc_reader);
-  r->data = FbBuf{static_cast<const uint8_t*>(data), (size_t)bytes};
-  agpu_status st;
-  if (bytes >= 8 && !memcmp(data, "ARROW1\0\0", 8)) {
-    r->is_file = true;
-    st = parse_file(r.get());
-  } else {
-    st = parse_stream(r.get(), 0);
-  }
-  if (st != AGPU_OK) return st;
-  *out_reader = r.release();
-  return AGPU_OK;
-}
-
-void agpu_ipc_close(agpu_ipc_reader* r) { delete r; }
-
-agpu_status agpu_ipc_num_fields(const agpu_ipc_reader* r, int32_t* out_n) {
-  AGPU_REQUIRE(r && out_n, AGPU_ERR_ARG, "null argument");
-  *out_n = (int32_t)r->fields.size();
-  return AGPU_OK;
-}
-
-agpu_status agpu_ipc_field_info(const agpu_ipc_reader* r, int32_t i, agpu_ipc_field* out) {
-  AGPU_REQUIRE(r && out, AGPU_ERR_ARG, "null argument");
-  AGPU_REQUIRE(i >= 0 && (size_t)i < r->fields.size(), AGPU_ERR_ARG, "field index out of range");
-  const FieldInfo& fi = r->fields[(size_t)i];
-  out->name = fi.name.c_str();
-  out->format = fi.format.c_str();
-  out->dtype = fi.dtype;
-  out->nullable = fi.nullable ? 1 : 0;
-  return AGPU_OK;
-}
-
-agpu_status agpu_ipc_num_batches(const agpu_ipc_reader* r, int64_t* out_n) {
-  AGPU_REQUIRE(r && out_n, AGPU_ERR_ARG, "null argument");
-  *out_n = (int64_t)r->batches.size();
-  return AGPU_OK;
-}
-
-agpu_status agpu_ipc_batch_rows(const agpu_ipc_reader* r, int64_t batch, int64_t* out_rows) {
-  AGPU_REQUIRE(r && out_rows, AGPU_ERR_ARG, "null argument");
-  AGPU_REQUIRE(batch >= 0 && (size_t)batch < r->batches.size(), AGPU_ERR_ARG, "batch index out of range");
-  *out_rows = r->batches[(size_t)batch].rows;
-  return AGPU_OK;
-}
-
-agpu_status agpu_ipc_column_view(const agpu_ipc_reader* r, int64_t batch, int32_t column, struct ArrowArray* out_array,
-                                 struct ArrowSchema* out_schema) {
-  AGPU_REQUIRE(out_array && out_schema, AGPU_ERR_ARG, "null argument");
-  const FieldInfo* fi = nullptr;
-  int64_t rows = 0, nulls = 0;
-  const uint8_t *validity = nullptr, *values = nullptr;
-  agpu_status st = column_buffers(r, batch, column, &fi, &rows, &nulls, &validity, &values);
-  if (st != AGPU_OK) return st;
-  ViewPrivate* ap = new ViewPrivate{{validity, values}, fi->format, fi->name};
-  ViewPrivate* sp = new ViewPrivate{{nullptr, nullptr}, fi->format, fi->name};
-  memset(out_array, 0, sizeof(*out_array));
-  out_array->length = rows;
-  out_array->null_count = nulls;
-  out_array->n_buffers = 2;
-  out_array->buffers = ap->buffers;
-  out_array->release = release_view_array;
-  out_array->private_data = ap;
-  memset(out_schema, 0, sizeof(*out_schema));
-  out_schema->format = sp->format.c_str();
-  out_schema->name = sp->name.c_str();
-  out_schema->flags = fi->nullable ? ARROW_FLAG_NULLABLE : 0;
-  out_schema->release = release_view_schema;
-  out_schema->private_data = sp;
-  return AGPU_OK;
-}
 
 agpu_status agpu_ipc_read_column(const agpu_ipc_reader* r, int64_t batch, int32_t column, agpu_pipeline* p,
                                  agpu_arrow_column* out_column) {

@@ -644,10 +644,34 @@ agpu_status agpu_download_async(agpu_pipeline* p, void* dst_pinned, const void* 
   return AGPU_OK;
 }
 
+// clone_buffer / clone_array [ref: gpu_device.rs:212-230, compute_pipeline.rs:275-299].  hipMemcpyAsync D2D runs the
+// runtime's blit kernel: 4.6 TB/s of traffic on a 4 GB column (0.58 of the roof, tools/kernel_table.py "context" row)
+// where a plain stream of nontemporal 16-byte loads and stores in one-wave blocks — the element-wise kernels' shape —
+// moves the same bytes at 6.7.  Big, 16-byte-aligned, non-overlapping copies take that kernel; everything else (small
+// copies: the launch dominates either way) stays with the runtime.
+__global__ __launch_bounds__(AGPU_WAVE) void copy_kernel(const u32x4* src, u32x4* dst, uint64_t nvec) {
+  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_WAVE + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x * AGPU_WAVE)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 agpu_status agpu_copy(agpu_pipeline* p, void* dst_dev, const void* src_dev, size_t bytes) {
   AGPU_BIND(p);
   if (!bytes) return AGPU_OK;
   AGPU_REQUIRE(dst_dev && src_dev, AGPU_ERR_ARG, "null pointer");
+  const uintptr_t d = reinterpret_cast<uintptr_t>(dst_dev), s = reinterpret_cast<uintptr_t>(src_dev);
+  const bool disjoint = d + bytes <= s || s + bytes <= d;
+  if (bytes >= ((size_t)1 << 20) && ((d | s) & 15u) == 0 && disjoint) {
+    const uint64_t nvec = bytes / 16;
+    const uint64_t blocks = (nvec + AGPU_WAVE - 1) / AGPU_WAVE;
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)(blocks < 0x3FFFFFFFull ? blocks : 0x3FFFFFFFull)), dim3(AGPU_WAVE), 0, p->stream,
+                       static_cast<const u32x4*>(src_dev), static_cast<u32x4*>(dst_dev), nvec);
+    AGPU_LAUNCH_CHECK();
+    const size_t done = (size_t)nvec * 16;
+    if (done < bytes)
+      AGPU_HIP(hipMemcpyAsync(static_cast<char*>(dst_dev) + done, static_cast<const char*>(src_dev) + done, bytes - done,
+                              hipMemcpyDeviceToDevice, p->stream));
+    return AGPU_OK;
+  }
   AGPU_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, p->stream));
   return AGPU_OK;
 }

@@ -1,5 +1,5 @@
-// Sanitizer harness for the Arrow IPC reader (arrow_gpu_amd/csrc/arrow_ipc.hip, host-only entry points): built with
-// -fsanitize=address,undefined by tests/test_sanitizers.py.  Reads an IPC stream / file from argv[1], then opens, walks and
+// Sanitizer harness for the Arrow IPC reader: arrow_gpu_amd/csrc/arrow_ipc_reader.inc (plain C++, no HIP) is compiled INTO
+// this program by g++ with -fsanitize=address,undefined (tests/test_sanitizers.py) — a CPU build, like the oracle's.  Reads an IPC stream / file from argv[1], then opens, walks and
 // touches every readable column of (a) the pristine bytes, (b) every truncation on a coarse grid, (c) N random byte flips —
 // each mutation on a heap copy of EXACTLY the mutated length, so that any read past the end is an ASan report.
 #include <cstdint>
@@ -8,7 +8,28 @@
 #include <cstring>
 #include <vector>
 
+#include <cstdarg>
+#include <memory>
+#include <string>
+
 #include "../../include/arrow_gpu.h"
+
+// what csrc/common.hpp gives the library build
+static char g_fuzz_err[512];
+static void agpu_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_fuzz_err, sizeof(g_fuzz_err), fmt, ap);
+  va_end(ap);
+}
+#define AGPU_REQUIRE(cond, code, msg)          \
+  do {                                         \
+    if (!(cond)) {                             \
+      agpu_set_error("%s: %s", __func__, msg); \
+      return code;                             \
+    }                                          \
+  } while (0)
+#include "../../arrow_gpu_amd/csrc/arrow_ipc_reader.inc"
 
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd() {

@@ -136,7 +136,7 @@ def main():
     fix(16)
     t("take_bits, random idx (2^28 rows)", 4.25 * m / n, lambda: capi.call("agpu_take_bits", h, vp(VA), m, vp(IDX), vp(OB), m))
     fix(4.25)
-    t("hipMemcpy D2D 4 GB (context)", 8, lambda: capi.call("agpu_copy", h, vp(O), vp(A), 4 * n))
+    t("clone_buffer (agpu_copy, 4 GB)", 8, lambda: capi.call("agpu_copy", h, vp(O), vp(A), 4 * n))
 
     # the reference's own criterion shapes, kernel time only (its benches: crates/benchmarks/benches/compare_gpu_arrow.rs
     # :18-43 f32 column + scalar at 10 Mi rows; compare_sum.rs:17-40 u32 sum at 1 Mi / 10 Mi rows).  The host-API and
