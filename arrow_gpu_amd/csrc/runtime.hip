@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <memory>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 #define AGPU_SMALL_MAX ((size_t)512 << 10)      // largest size class of the slab pool
@@ -294,6 +296,13 @@ agpu_status agpu_device_destroy(agpu_device* dev) {
     dev->flag_retired.clear();
     for (auto& kv : dev->slabs) (void)hipFree(kv.second.base);  // blocks the caller leaked
     dev->slabs.clear();
+    {  // table groups whose columns the caller leaked (the blocks themselves are the caller's leak, like any other)
+      std::vector<agpu_device::TableGroup*> groups;
+      for (auto& kv : dev->table_member)
+        if (std::find(groups.begin(), groups.end(), kv.second) == groups.end()) groups.push_back(kv.second);
+      for (agpu_device::TableGroup* g : groups) delete g;
+      dev->table_member.clear();
+    }
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     dev->event_pool.clear();
     for (void* f : dev->flag_slabs) (void)hipHostFree(f);
