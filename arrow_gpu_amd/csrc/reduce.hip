@@ -333,8 +333,9 @@ __global__ __launch_bounds__(AGPU_BLOCK) void reduce_finish_kernel(const typenam
 }
 
 // blocks_per_cu: 16 for the partial reductions (read-only grid-stride loops with 4 packs per lane in flight: 6.47 / 6.65 /
-// 6.70 TB/s for min / f64 sum / i32 sum vs 6.31 / 6.45 / 6.58 at 64 per CU), 64 for the span-per-block tree sum (6.18 vs
-// 5.96–6.07 at 8–32 per CU) — tools/probe/reduce_sweep.py, one process, same buffer.
+// 6.70 TB/s for min / f64 sum / i32 sum vs 6.31 / 6.45 / 6.58 at 64 per CU — tools/probe/reduce_sweep.py, one process,
+// same buffer).  The tree sum launches one one-wave block per quarter span (sum_probe.py); giving the order-free
+// reductions that shape too was tried and is no faster on a box in the fast state (0.84–0.86 either way).
 static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks, int blocks_per_cu) {
   int64_t g = p->tune.reduce_grid > 0 ? p->tune.reduce_grid : (int64_t)p->dev->num_cus * blocks_per_cu;
   if ((uint64_t)g > work_blocks) g = (int64_t)work_blocks;
