@@ -391,3 +391,37 @@ def test_f32_to_small_int_casts_fullsize(ctx):
     capi.call("agpu_checksum", h, vp(o), 2 * N, vp(cs1))
     capi.call("agpu_checksum", h, vp(back), 2 * N, vp(cs2))
     assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
+
+
+def test_f32_tree_sum_fullsize_is_the_reference_tree_of_its_aligned_chunks(ctx):
+    """f32 Sum at 1e9 rows in the reference's order [aggregate.wgsl:21-41]: the tree is perfect over aligned 256^k-row
+    blocks, so the whole-column result must equal the reference's 256-ary tree over the sums of the aligned
+    16 777 216-row chunks (the 4th level: 60 values, zero-padded) — each chunk summed by its own launch, three of them
+    checked bit for bit against the oracle's literal tree; the same with a validity bitmap."""
+    dev, p = ctx
+    h = p._handle
+    a = dev.create_empty_buffer(4 * N)
+    v = dev.create_empty_buffer((N + 63) // 64 * 8)
+    out = dev.create_empty_buffer(16)
+    capi.call("agpu_synth_f32", h, vp(a), N, SEED + 7, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_bits", h, vp(v), N, SEED + 8, 0, C.c_double(0.9))
+    chunk = 1 << 24
+    nchunks = (N + chunk - 1) // chunk
+    for validity in (None, v):
+        capi.call("agpu_reduce", h, capi.RED_SUM, capi.F32, vp(a), vp(validity) if validity is not None else None, N, vp(out))
+        whole = scalar_u32(dev, p, out)
+        parts = np.zeros(nchunks, np.float32)
+        for k in range(nchunks):
+            rows = min(chunk, N - k * chunk)
+            capi.call("agpu_reduce", h, capi.RED_SUM, capi.F32, vp(a, 4 * k * chunk), vp(validity, k * chunk // 8) if validity is not None else None,
+                      rows, vp(out))
+            parts[k] = dev.retrive_data(out, 4, pipeline=p).view(np.float32)[0]
+        assert np.float32(O.reduce(O.RED_SUM, O.F32, parts)).view(np.uint32) == whole
+        for k in (0, nchunks // 2, nchunks - 1):  # includes the ragged last chunk
+            rows = min(chunk, N - k * chunk)
+            vals = O.synth_f32(rows, SEED + 7, k * chunk, -1000.0, 1000.0)
+            if validity is not None:
+                bits = O.synth_bits(rows, SEED + 8, k * chunk, 0.9)
+                keep = np.unpackbits(bits, bitorder="little")[:rows].astype(bool)
+                vals = np.where(keep, vals, np.float32(0.0))
+            assert np.float32(O.reduce(O.RED_SUM, O.F32, vals)).view(np.uint32) == parts[k].view(np.uint32), k
