@@ -96,6 +96,8 @@ SIGNATURES = {
     "agpu_import_arrow": [_vp, _vp, _vp, _vp],
     "agpu_export_arrow": [_vp, _vp, _vp, _vp],
     "agpu_arrow_column_free": [_vp, _vp],
+    "agpu_import_arrow_table": [_vp, _i32, _vp, _vp, _vp],
+    "agpu_ipc_read_batch": [_vp, C.c_int64, C.POINTER(_i32), _i32, _vp, _vp],
     "agpu_staged_copy": [_vp, _vp, _vp, _sz, _i32],
     "agpu_malloc_table": [_vp, _i32, C.POINTER(_u64), _i32, _pp],
     "agpu_ipc_open": [_vp, _u64, _pp],

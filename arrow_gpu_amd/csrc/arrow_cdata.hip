@@ -224,33 +224,39 @@ static const char* format_of_dtype(agpu_dtype t) {
   return nullptr;
 }
 
-// Arrow bitmap (byte-granular, arbitrary bit offset) → word-aligned device bitmap, padding bits 0
-static agpu_status import_bitmap(agpu_pipeline* p, const uint8_t* host_bits, uint64_t bit_offset, uint64_t n_bits,
-                                 void** out_dev, uint64_t* out_bytes) {
+// Arrow bitmap (byte-granular, arbitrary bit offset) → word-aligned device bitmap `out` of `out_b` bytes, padding bits 0
+static agpu_status import_bitmap_into(agpu_pipeline* p, const uint8_t* host_bits, uint64_t bit_offset, uint64_t n_bits, void* out,
+                                      size_t out_b) {
   agpu_device* dev = p->dev;
-  const size_t out_b = agpu_bitmap_bytes(n_bits) ? agpu_bitmap_bytes(n_bits) : 8;
-  void* out = nullptr;
-  agpu_status st = agpu_malloc(dev, out_b, 0, &out);
-  if (st != AGPU_OK) return st;
-  if (n_bits) {
-    const uint64_t first = bit_offset / 8, last = (bit_offset + n_bits + 7) / 8, span = last - first;
-    if ((bit_offset & 7) == 0) {  // byte-aligned slice: the bytes are the bitmap; only the padding needs clearing
-      AGPU_HIP(hipMemsetAsync(static_cast<char*>(out) + (out_b - 8), 0, 8, p->stream));
-      st = staged_copy_impl(p, out, const_cast<uint8_t*>(host_bits + first), span, true);
-      if (st == AGPU_OK && (n_bits & 7)) st = agpu_bitmap_copy_bits(p, out, 0, out, n_bits);  // mask the tail bits
-    } else {
-      void* tmp = nullptr;
-      st = agpu_malloc(dev, agpu_bitmap_bytes(span * 8) + 8, 0, &tmp);
-      if (st == AGPU_OK) {
-        AGPU_HIP(hipMemsetAsync(static_cast<char*>(tmp) + agpu_bitmap_bytes(span * 8) - 8, 0, 16, p->stream));
-        st = staged_copy_impl(p, tmp, const_cast<uint8_t*>(host_bits + first), span, true);
-        if (st == AGPU_OK) st = agpu_bitmap_copy_bits(p, tmp, bit_offset & 7, out, n_bits);
-        (void)agpu_free(dev, tmp);  // recycled only after the stream has passed the kernel above (runtime.hip markers)
-      }
+  if (!n_bits) return AGPU_OK;
+  agpu_status st = AGPU_OK;
+  const uint64_t first = bit_offset / 8, last = (bit_offset + n_bits + 7) / 8, span = last - first;
+  if ((bit_offset & 7) == 0) {  // byte-aligned slice: the bytes are the bitmap; only the padding needs clearing
+    AGPU_HIP(hipMemsetAsync(static_cast<char*>(out) + (out_b - 8), 0, 8, p->stream));
+    st = staged_copy_impl(p, out, const_cast<uint8_t*>(host_bits + first), span, true);
+    if (st == AGPU_OK && (n_bits & 7)) st = agpu_bitmap_copy_bits(p, out, 0, out, n_bits);  // mask the tail bits
+  } else {
+    void* tmp = nullptr;
+    st = agpu_malloc(dev, agpu_bitmap_bytes(span * 8) + 8, 0, &tmp);
+    if (st == AGPU_OK) {
+      AGPU_HIP(hipMemsetAsync(static_cast<char*>(tmp) + agpu_bitmap_bytes(span * 8) - 8, 0, 16, p->stream));
+      st = staged_copy_impl(p, tmp, const_cast<uint8_t*>(host_bits + first), span, true);
+      if (st == AGPU_OK) st = agpu_bitmap_copy_bits(p, tmp, bit_offset & 7, out, n_bits);
+      (void)agpu_free(dev, tmp);  // recycled only after the stream has passed the kernel above (runtime.hip markers)
     }
   }
+  return st;
+}
+static size_t import_bitmap_bytes(uint64_t n_bits) { return agpu_bitmap_bytes(n_bits) ? agpu_bitmap_bytes(n_bits) : 8; }
+static agpu_status import_bitmap(agpu_pipeline* p, const uint8_t* host_bits, uint64_t bit_offset, uint64_t n_bits,
+                                 void** out_dev, uint64_t* out_bytes) {
+  const size_t out_b = import_bitmap_bytes(n_bits);
+  void* out = nullptr;
+  agpu_status st = agpu_malloc(p->dev, out_b, 0, &out);
+  if (st != AGPU_OK) return st;
+  st = import_bitmap_into(p, host_bits, bit_offset, n_bits, out, out_b);
   if (st != AGPU_OK) {
-    (void)agpu_free(dev, out);
+    (void)agpu_free(p->dev, out);
     return st;
   }
   *out_dev = out;
@@ -360,6 +366,68 @@ agpu_status agpu_import_arrow(agpu_pipeline* p, const struct ArrowArray* array, 
     return st;
   }
   *out_column = col;
+  return AGPU_OK;
+}
+
+// The columns of one record batch → ONE device block placed for the HBM channel hash (agpu_malloc_table): value buffers
+// first (in column order), validity bitmaps behind them.
+agpu_status agpu_import_arrow_table(agpu_pipeline* p, int32_t n_columns, const struct ArrowArray* const* arrays,
+                                    const struct ArrowSchema* const* schemas, agpu_arrow_column* out_columns) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(n_columns > 0 && arrays && schemas && out_columns, AGPU_ERR_ARG, "bad argument");
+  AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "not during graph capture");
+  std::vector<agpu_arrow_column> cols((size_t)n_columns);
+  std::vector<uint64_t> sizes;
+  std::vector<int> has_v((size_t)n_columns, 0);
+  for (int32_t k = 0; k < n_columns; k++) {
+    const struct ArrowArray* a = arrays[k];
+    const struct ArrowSchema* sc = schemas[k];
+    AGPU_REQUIRE(a && sc && a->release && sc->release, AGPU_ERR_ARG, "null / released ArrowArray / ArrowSchema");
+    agpu_dtype dt;
+    if (!dtype_of_format(sc->format, &dt)) {
+      agpu_set_error("Arrow format '%s' has no GPU array type (c C s S i I f b tdD)", sc->format ? sc->format : "(null)");
+      return AGPU_ERR_UNSUPPORTED;
+    }
+    AGPU_REQUIRE(!a->dictionary && a->n_children == 0, AGPU_ERR_UNSUPPORTED, "nested / dictionary arrays are not supported");
+    AGPU_REQUIRE(a->n_buffers == 2 && a->buffers && a->length >= 0 && a->offset >= 0, AGPU_ERR_SHAPE, "a primitive array has exactly 2 buffers");
+    AGPU_REQUIRE(a->length == 0 || a->buffers[1], AGPU_ERR_SHAPE, "null data buffer");
+    agpu_arrow_column& c = cols[(size_t)k];
+    memset(&c, 0, sizeof(c));
+    c.dtype = dt;
+    c.length = (uint64_t)a->length;
+    has_v[(size_t)k] = (a->buffers[0] && a->null_count != 0 && a->length) ? 1 : 0;
+    c.null_count = has_v[(size_t)k] ? a->null_count : 0;
+    c.values_bytes = dt == AGPU_BOOL ? import_bitmap_bytes(c.length) : (c.length * agpu_dtype_size(dt) ? c.length * agpu_dtype_size(dt) : 16);
+    c.validity_bytes = has_v[(size_t)k] ? import_bitmap_bytes(c.length) : 0;
+    sizes.push_back(c.values_bytes);
+  }
+  for (int32_t k = 0; k < n_columns; k++)
+    if (has_v[(size_t)k]) sizes.push_back(cols[(size_t)k].validity_bytes);
+  std::vector<void*> ptrs(sizes.size(), nullptr);
+  agpu_status st = agpu_malloc_table(p->dev, (int32_t)sizes.size(), sizes.data(), 0, ptrs.data());
+  if (st != AGPU_OK) return st;
+  size_t nv = (size_t)n_columns;
+  for (int32_t k = 0; k < n_columns; k++) {
+    cols[(size_t)k].values = ptrs[(size_t)k];
+    if (has_v[(size_t)k]) cols[(size_t)k].validity = ptrs[nv++];
+  }
+  for (int32_t k = 0; k < n_columns && st == AGPU_OK; k++) {
+    const struct ArrowArray* a = arrays[k];
+    agpu_arrow_column& c = cols[(size_t)k];
+    const uint64_t n = c.length, off = (uint64_t)a->offset;
+    if (has_v[(size_t)k]) st = import_bitmap_into(p, static_cast<const uint8_t*>(a->buffers[0]), off, n, c.validity, c.validity_bytes);
+    if (st != AGPU_OK) break;
+    if (c.dtype == AGPU_BOOL) st = import_bitmap_into(p, static_cast<const uint8_t*>(a->buffers[1]), off, n, c.values, c.values_bytes);
+    else if (n) {
+      const size_t w = agpu_dtype_size(c.dtype);
+      st = staged_copy_impl(p, c.values, const_cast<uint8_t*>(static_cast<const uint8_t*>(a->buffers[1]) + off * w), n * w, true);
+    }
+  }
+  if (st != AGPU_OK) {
+    for (void* q : ptrs) (void)agpu_free(p->dev, q);
+    return st;
+  }
+  for (int32_t k = 0; k < n_columns; k++) out_columns[k] = cols[(size_t)k];
   return AGPU_OK;
 }
 

@@ -268,6 +268,29 @@ agpu_status agpu_ipc_read_column(const agpu_ipc_reader* r, int64_t batch, int32_
   return st;
 }
 
+agpu_status agpu_ipc_read_batch(const agpu_ipc_reader* r, int64_t batch, const int32_t* columns, int32_t n_columns,
+                                agpu_pipeline* p, agpu_arrow_column* out_columns) {
+  AGPU_REQUIRE(p && columns && out_columns && n_columns > 0, AGPU_ERR_ARG, "bad argument");
+  std::vector<struct ArrowArray> arrays((size_t)n_columns);
+  std::vector<struct ArrowSchema> schemas((size_t)n_columns);
+  std::vector<const struct ArrowArray*> ap((size_t)n_columns);
+  std::vector<const struct ArrowSchema*> sp((size_t)n_columns);
+  agpu_status st = AGPU_OK;
+  int32_t made = 0;
+  for (; made < n_columns && st == AGPU_OK; made++) {
+    st = agpu_ipc_column_view(r, batch, columns[made], &arrays[(size_t)made], &schemas[(size_t)made]);
+    if (st != AGPU_OK) break;
+    ap[(size_t)made] = &arrays[(size_t)made];
+    sp[(size_t)made] = &schemas[(size_t)made];
+  }
+  if (st == AGPU_OK) st = agpu_import_arrow_table(p, n_columns, ap.data(), sp.data(), out_columns);
+  for (int32_t k = 0; k < made; k++) {
+    arrays[(size_t)k].release(&arrays[(size_t)k]);
+    schemas[(size_t)k].release(&schemas[(size_t)k]);
+  }
+  return st;
+}
+
 // ---------------------------------------------------------------- writer
 agpu_status agpu_ipc_writer_create(const agpu_ipc_field* fields, int32_t n_fields, int32_t file_format, int32_t fd,
                                    agpu_ipc_writer** out_writer) {

@@ -109,6 +109,41 @@ def from_arrow(obj, device: GpuDevice, pipeline: ArrowComputePipeline | None = N
     return out
 
 
+def from_arrow_batch(batch, device: GpuDevice, pipeline: ArrowComputePipeline | None = None) -> dict:
+    """pyarrow.RecordBatch (or {name: pyarrow.Array}) → {name: GPU array}, the device buffers of all columns out of ONE block
+    placed for the HBM channel hash (`agpu_import_arrow_table`): columns of a batch are what kernels read together."""
+    pa = _pa()
+    items = list(zip(batch.schema.names, batch.columns)) if isinstance(batch, pa.RecordBatch) else list(batch.items())
+    for name, arr in items:
+        if arr.type not in _type_map():
+            raise capi.OperationNotSupported(f"column {name!r}: Arrow type {arr.type} has no GPU array type")
+    n = len(items)
+    own = pipeline is None
+    p = pipeline or ArrowComputePipeline(device, "from_arrow_batch")
+    c_arrs, c_schs = [capi.ArrowArrayStruct() for _ in items], [capi.ArrowSchemaStruct() for _ in items]
+    ap, sp = (C.c_void_p * n)(), (C.c_void_p * n)()
+    cols = (capi.ArrowColumnStruct * n)()
+    try:
+        for k, (_, arr) in enumerate(items):
+            arr._export_to_c(C.addressof(c_arrs[k]), C.addressof(c_schs[k]))
+            ap[k], sp[k] = C.addressof(c_arrs[k]), C.addressof(c_schs[k])
+        capi.call("agpu_import_arrow_table", p._handle, n, ap, sp, cols)
+    finally:
+        for x in c_arrs + c_schs:
+            _release(x)
+    out = {}
+    for k, (name, arr) in enumerate(items):
+        col = cols[k]
+        ln = int(col.length)
+        data = DeviceBuffer(device, col.values, int(col.values_bytes))
+        nulls = NullBitBufferGpu(DeviceBuffer(device, col.validity, int(col.validity_bytes)), ln, device) if col.validity else None
+        out[name] = _type_map()[arr.type](data, device, ln, nulls)
+    if own:
+        p.finish()
+        p.sync()
+    return out
+
+
 def from_arrow_chunked(chunked, device: GpuDevice):
     """pyarrow.ChunkedArray → list of GPU arrays, one per chunk (chunks stay separate: that is the sharding unit)."""
     p = ArrowComputePipeline(device, "from_arrow_chunked")

@@ -119,13 +119,27 @@ class IpcReader:
         return out
 
     def read_batch(self, batch: int, device: GpuDevice, columns=None) -> dict:
-        """{name: GPU array} for the readable columns of one record batch (or the named / indexed `columns`)."""
+        """{name: GPU array} for the readable columns of one record batch (or the named / indexed `columns`).  The batch's
+        device buffers come out of ONE block placed for the HBM channel hash (`agpu_ipc_read_batch` →
+        `agpu_malloc_table`): columns of a batch are what kernels read together."""
         p = ArrowComputePipeline(device, "ipc.read_batch")
         if columns is None:
             idx = [i for i, f in enumerate(self.fields) if f.dtype >= 0]
         else:
             idx = [c if isinstance(c, int) else self.column_index(c) for c in columns]
-        out = {self.fields[i].name: self.read_column(batch, i, device, p) for i in idx}
+        if not idx:
+            return {}
+        cols = (capi.ArrowColumnStruct * len(idx))()
+        capi.call("agpu_ipc_read_batch", self._handle, batch, (C.c_int32 * len(idx))(*idx), len(idx), p._handle, cols)
+        out = {}
+        for k, i in enumerate(idx):
+            col = cols[k]
+            n = int(col.length)
+            data = DeviceBuffer(device, col.values, int(col.values_bytes))
+            nulls = None
+            if col.validity:
+                nulls = NullBitBufferGpu(DeviceBuffer(device, col.validity, int(col.validity_bytes)), n, device)
+            out[self.fields[i].name] = _classes()[self.fields[i].dtype](data, device, n, nulls)
         p.finish()
         p.sync()
         return out

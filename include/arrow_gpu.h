@@ -480,6 +480,12 @@ typedef struct {
  * array->release). */
 agpu_status agpu_import_arrow(agpu_pipeline* p, const struct ArrowArray* array, const struct ArrowSchema* schema,
                               agpu_arrow_column* out_column);
+/* The columns of one record batch at once: like n calls of agpu_import_arrow, but all device buffers come out of ONE
+ * block laid out by agpu_malloc_table (value buffers in column order, validity bitmaps behind them), so kernels that read
+ * several of the columns together find them in different HBM hash classes.  Each out_columns[k] is freed as usual
+ * (agpu_arrow_column_free / agpu_free of its two pointers, any order). */
+agpu_status agpu_import_arrow_table(agpu_pipeline* p, int32_t n_columns, const struct ArrowArray* const* arrays,
+                                    const struct ArrowSchema* const* schemas, agpu_arrow_column* out_columns);
 /* Device column → freshly allocated host buffers behind a released-by-consumer ArrowArray/ArrowSchema pair (both
  * `release` callbacks free everything this call allocated).  Blocks until the data has arrived. */
 agpu_status agpu_export_arrow(agpu_pipeline* p, const agpu_arrow_column* column, struct ArrowArray* out_array,
@@ -519,6 +525,9 @@ agpu_status agpu_ipc_column_view(const agpu_ipc_reader* r, int64_t batch, int32_
 /* = agpu_ipc_column_view + agpu_import_arrow: the column in HBM, ordered on p's stream */
 agpu_status agpu_ipc_read_column(const agpu_ipc_reader* r, int64_t batch, int32_t column, agpu_pipeline* p,
                                  agpu_arrow_column* out_column);
+/* several columns of one record batch → one table-placed block (agpu_import_arrow_table) */
+agpu_status agpu_ipc_read_batch(const agpu_ipc_reader* r, int64_t batch, const int32_t* columns, int32_t n_columns,
+                                agpu_pipeline* p, agpu_arrow_column* out_columns);
 /* Writer: fd ≥ 0 → bytes are written to that descriptor as they are produced (the caller opens and closes it);
  * fd < 0 → bytes accumulate in memory and agpu_ipc_writer_finish hands out the buffer (valid until destroy).
  * file_format != 0 → "ARROW1" file with footer; else the streaming format.  Body buffers are padded to 64 bytes. */

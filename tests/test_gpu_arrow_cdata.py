@@ -97,3 +97,31 @@ def test_map_chunks_overlapped_pipeline(ag):
     info = ag.interop.map_chunks(dev, [a, b], out, 1 << 22, launch)
     assert np.array_equal(out, a + b)
     print(f"map_chunks f32 add from and to pageable host memory: {info['GBps_host_bytes']:.1f} GB/s of host bytes, {info['chunks']} chunks")
+
+
+def test_record_batch_imports_into_one_table_block(ag):
+    """from_arrow_batch: every column's buffers out of ONE device block (agpu_import_arrow_table), values bit for bit,
+    sliced inputs and nulls included; the columns stay ordinary arrays (kernels, to_arrow, independent lifetime)."""
+    import pyarrow.compute as pc
+
+    dev = ag.GPU_DEVICE()
+    n = 300_007
+    cols = {"f": make(pa.float32(), n + 5, 1, 0.1).slice(5), "g": make(pa.float32(), n + 5, 2, 0.0).slice(5),
+            "i": make(pa.int32(), n + 13, 3, 0.2).slice(13), "b": make(pa.bool_(), n + 3, 4, 0.3).slice(3),
+            "u": make(pa.uint8(), n, 5, 0.0), "d": make(pa.date32(), n, 6, 0.05)}
+    got = ag.from_arrow_batch(pa.record_batch(list(cols.values()), names=list(cols)), dev)
+    assert list(got) == list(cols)
+    ptrs = []
+    for name, arr in cols.items():
+        g = got[name]
+        assert g.len == n and (g.null_buffer is not None) == (arr.null_count > 0)
+        assert ag.to_arrow(g).equals(arr), name
+        ptrs.append(g.data.ptr)
+        if g.null_buffer is not None:
+            ptrs.append(g.null_buffer.bit_buffer.ptr)
+    assert max(ptrs) - min(ptrs) < 64 << 20  # one block: 2 MiB strides + colours for these sizes
+    assert len({q % (1 << 21) for q in ptrs[:4]}) > 1  # coloured starts, not all on 2 MiB boundaries
+    s = got["f"].add(got["g"])
+    assert ag.to_arrow(s).equals(pc.add(cols["f"], cols["g"]))
+    del got["f"], got["b"]  # columns die independently; the rest stays valid
+    assert ag.to_arrow(got["i"]).equals(cols["i"])
