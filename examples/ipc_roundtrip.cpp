@@ -56,10 +56,11 @@ int main(int argc, char** argv) {
       IpcWriter w({IpcField{"sum", "", AGPU_F32, true}, IpcField{"eq", "", AGPU_BOOL, true}}, /*file_format=*/true, fd);
       for (int64_t b = 0; b < r->num_batches(); b++) {
         ArrowComputePipeline p(dev);
-        auto a = try_from<Float32ArrayGPU>(r->read_column_op(b, ca, p));
-        auto bb = try_from<Float32ArrayGPU>(r->read_column_op(b, cb, p));
-        auto k = try_from<Int32ArrayGPU>(r->read_column_op(b, ck, p));
-        auto m = try_from<Int32ArrayGPU>(r->read_column_op(b, cm, p));
+        auto cols = r->read_batch_op(b, {ca, cb, ck, cm}, p);  // one block, placed for the HBM channel hash
+        auto a = try_from<Float32ArrayGPU>(cols[0]);
+        auto bb = try_from<Float32ArrayGPU>(cols[1]);
+        auto k = try_from<Int32ArrayGPU>(cols[2]);
+        auto m = try_from<Int32ArrayGPU>(cols[3]);
         auto sum = a.add_op(bb, p);
         auto eq = k.eq_op(m, p);
         p.finish();

@@ -1259,6 +1259,14 @@ class IpcReader {
     check(agpu_ipc_read_column(raw_, batch, column, p.h(), &col), "agpu_ipc_read_column");
     return detail::array_of_column(col, p.device);
   }
+  // several columns of one record batch, their device buffers out of ONE block placed for the HBM channel hash
+  std::vector<ArrowArrayGPU> read_batch_op(int64_t batch, const std::vector<int32_t>& columns, ArrowComputePipeline& p) const {
+    std::vector<agpu_arrow_column> cols(columns.size());
+    check(agpu_ipc_read_batch(raw_, batch, columns.data(), (int32_t)columns.size(), p.h(), cols.data()), "agpu_ipc_read_batch");
+    std::vector<ArrowArrayGPU> out;
+    for (auto& c : cols) out.push_back(detail::array_of_column(c, p.device));
+    return out;
+  }
   ArrowArrayGPU read_column(int64_t batch, int column, const DevicePtr& dev) const {
     ArrowComputePipeline p(dev);
     auto out = read_column_op(batch, column, p);
