@@ -608,3 +608,39 @@ def test_two_pipelines_from_two_threads(D):
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+@pytest.mark.parametrize("frm,to", [(capi.U8, capi.F32), (capi.I8, capi.I32), (capi.U8, capi.U16), (capi.I16, capi.F32), (capi.U16, capi.U32),
+                                    (capi.F32, capi.U8), (capi.F32, capi.I8), (capi.F32, capi.I16), (capi.F32, capi.U16)])
+def test_width_changing_casts_on_slices_and_chunk_boundaries(D, frm, to):
+    """The wave-transposed cast kernels (cvt_wide_kernel / cvt_narrow_kernel: 16-byte accesses on BOTH sides) take only
+    16-byte-aligned columns and whole 512/1024-row chunks; slices that start at any element and sizes around the chunk
+    boundaries must go through the tail / element-granular paths with the same bits."""
+    wi, wo = NP[frm]().itemsize, NP[to]().itemsize
+    base = rand_values(frm, 70_000, 5)
+    if frm == capi.F32:
+        with np.errstate(invalid="ignore"):
+            base = (base % np.float32(70000.0)).astype(np.float32)  # both signs, beyond every target's range; NaN / inf stay NaN
+    src = D.up(base)
+    for first in (0, 1, 3, 4, 16 // wi, 17):
+        for n in (0, 1, 511, 512, 513, 1023, 1024, 1025, 2047, 2048 + 7, 65_536 - first):
+            for out_shift in (0, wo):  # output pointer 16-byte aligned or shifted by one element
+                out = D.empty(n * wo + 64)
+                D.call("agpu_cast", frm, to, C.c_void_p(src.buf.ptr + first * wi), C.c_void_p(out.buf.ptr + out_shift), n)
+                got = D.down(out, np.uint8, n * wo + 64)[out_shift:out_shift + n * wo].view(NP[to]) if n else np.empty(0, NP[to])
+                assert bits_equal(got, O.cast(frm, to, base[first:first + n])), (first, n, out_shift)
+
+
+@pytest.mark.parametrize("dtype", [capi.U8, capi.I8, capi.U16, capi.I16])
+@pytest.mark.parametrize("op", [capi.UN_SIN, capi.UN_COS])
+def test_fused_small_int_trig_on_slices(D, dtype, op):
+    """lut8_kernel / trig16_kernel in the wave-transposed form: 16-byte loads, so slices that start at any element and
+    ragged sizes take the tail kernels — identical bits."""
+    w = NP[dtype]().itemsize
+    base = rand_values(dtype, 40_000, 9)
+    src = D.up(base)
+    for first in (0, 1, 2, 8 // w, 16 // w, 5):
+        for n in (1, 4095, 4096, 4097, 8192 + 3, 30_000):
+            out = D.empty(4 * n + 16)
+            D.call("agpu_unary", op, dtype, C.c_void_p(src.buf.ptr + first * w), out.vp, n)
+            assert max_ulp(D.down(out, np.float32, n), O.unary(op, dtype, base[first:first + n])) <= G.MAX_ULP, (first, n)
