@@ -2,7 +2,8 @@
 
 SURVEY §8f-1 names "Arrow C Data Interface / IPC import-export" as the step either side of the hot path; the reference
 itself only has `from_slice` / `raw_values` over host Vecs (crates/array/src/array/primitive_array_gpu.rs:22-104).
-No pyarrow is needed here: the metadata (Flatbuffers) is parsed and produced by the library.  A file is memory-mapped,
+No pyarrow is needed here: the metadata (Flatbuffers) is parsed and produced by the library, LZ4-compressed bodies
+(Feather V2's default) are decompressed by it.  A file is memory-mapped,
 so a column travels page cache → HBM without an intermediate host copy; columns of types the GPU has no array for
 (utf8, int64, nested …) are skipped and listed with `dtype == -1`.
 """
@@ -75,7 +76,8 @@ class IpcReader:
 
     def column_view(self, batch: int, column: int):
         """Host view of one column: (values, validity, length, null_count) — numpy views INTO the source bytes (values
-        typed by the column's dtype; Boolean data and validity as uint8 bitmaps, LSB first; validity None without nulls)."""
+        typed by the column's dtype; Boolean data and validity as uint8 bitmaps, LSB first; validity None without nulls).
+        Columns of an LZ4-compressed batch are decompressed by the library and come back as copies."""
         c_arr, c_sch = capi.ArrowArrayStruct(), capi.ArrowSchemaStruct()
         capi.call("agpu_ipc_column_view", self._handle, batch, column, C.byref(c_arr), C.byref(c_sch))
         try:
@@ -87,9 +89,10 @@ class IpcReader:
 
             def view(addr, nbytes, dtype):
                 off = addr - base
-                if off < 0 or off + nbytes > self._view.nbytes:  # cannot happen: the library bounds-checks every buffer
-                    raise capi.ArrowErrorGPU("ShapeError", "column buffer outside the IPC source")
-                return self._view[off:off + nbytes].view(dtype)
+                if 0 <= off and off + nbytes <= self._view.nbytes:
+                    return self._view[off:off + nbytes].view(dtype)
+                # a compressed (LZ4) batch: the library decompressed into memory the ArrowArray owns — copy before release
+                return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(addr)).copy().view(dtype) if nbytes else np.empty(0, dtype)
 
             if dt == capi.BOOL:
                 values = view(c_arr.buffers[1], (n + 7) // 8, np.uint8)

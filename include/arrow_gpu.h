@@ -499,9 +499,10 @@ agpu_status agpu_staged_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, si
  * Not in the reference (arrays exist only as host Vecs or wgpu buffers [ref: primitive_array_gpu.rs:22-104]); files and
  * sockets carry Arrow IPC (arrow-rs `arrow::ipc`, pyarrow `pa.ipc`), so columns can come from and go to that format
  * without a host-side Arrow library.  The reader BORROWS `data` (mmap the file: bytes go page cache → HBM with no copy in
- * between) — keep it mapped until agpu_ipc_close.  Uncompressed little-endian V4/V5 metadata; columns of the nine GPU array
+ * between) — keep it mapped until agpu_ipc_close.  Little-endian V4/V5 metadata; bodies uncompressed or LZ4_FRAME-compressed
+ * (Feather V2's default: decoded by the library, the view then owns the decompressed bytes); columns of the nine GPU array
  * types are readable, columns of any other type (utf8, int64, nested, dictionary …) are skipped correctly and report
- * AGPU_ERR_UNSUPPORTED when asked for; compressed bodies → AGPU_ERR_UNSUPPORTED; malformed or truncated input →
+ * AGPU_ERR_UNSUPPORTED when asked for; ZSTD-compressed bodies → AGPU_ERR_UNSUPPORTED; malformed or truncated input →
  * AGPU_ERR_SHAPE (every metadata access is bounds-checked).  Host-only calls (open … column_view, writer_create,
  * write_batch, finish) need no GPU. */
 typedef struct agpu_ipc_reader agpu_ipc_reader;

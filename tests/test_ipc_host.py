@@ -164,18 +164,83 @@ def test_no_nulls_means_no_validity_buffer():
         assert nulls == 1 and unpack_bits(validity, 3).tolist() == [True, False, True]
 
 
-def test_compressed_and_mismatched_input_is_refused():
-    t = pa.table({"a": pa.array(np.arange(1000, dtype=np.int32))})
-    sink = pa.BufferOutputStream()
+@pytest.mark.parametrize("file_format", [False, True])
+def test_lz4_compressed_batches_are_decompressed(file_format):
+    """BodyCompression LZ4_FRAME (pyarrow's `compression="lz4"`, Feather V2's default): every buffer carries its
+    uncompressed length and an LZ4 frame; the reader decodes the frames itself."""
+    rng = np.random.default_rng(21)
+    n = 50_000
+    cols = {
+        "runs": pa.array(np.repeat(np.arange(n // 100, dtype=np.int32), 100)),                 # long matches, linked blocks
+        "noise": pa.array(rng.standard_normal(n).astype(np.float32), mask=rng.random(n) < 0.1),   # incompressible: stored blocks / −1 prefix
+        "small": pa.array(rng.integers(0, 3, n).astype(np.uint8)),
+        "flags": pa.array(rng.random(n) < 0.02),
+        "text": pa.array(["x" * (i % 7) for i in range(n)]),                                      # skipped, still compressed
+        "dates": pa.array(np.arange(n, dtype=np.int32) // 30, type=pa.date32(), mask=np.arange(n) % 11 == 0),
+    }
+    table = pa.table(cols)
     try:
         opts = pa.ipc.IpcWriteOptions(compression="lz4")
     except Exception:
         pytest.skip("pyarrow built without lz4")
+    sink = pa.BufferOutputStream()
+    with (pa.ipc.new_file if file_format else pa.ipc.new_stream)(sink, table.schema, options=opts) as w:
+        for b in table.to_batches(max_chunksize=20_000):
+            w.write_batch(b)
+    data = sink.getvalue().to_pybytes()
+    assert len(data) < table.nbytes  # it really is compressed
+    batches = table.to_batches(max_chunksize=20_000)
+    with IpcReader(data) as r:
+        assert r.num_batches == len(batches)
+        for bi, batch in enumerate(batches):
+            for ci, f in enumerate(r.fields):
+                if f.dtype < 0:
+                    continue
+                values, validity, length, nulls = r.column_view(bi, ci)
+                col = batch.column(ci)
+                assert length == len(col) and nulls == col.null_count
+                ok = np.asarray(col.is_valid())
+                if validity is not None:
+                    assert np.array_equal(unpack_bits(validity, length), ok)
+                if f.dtype == capi.BOOL:
+                    got, exp = unpack_bits(values, length), np.asarray(col.fill_null(False))
+                else:
+                    storage = col.cast(pa.int32()) if col.type == pa.date32() else col
+                    got, exp = np.asarray(values), storage.fill_null(0).to_numpy(zero_copy_only=False)
+                assert np.array_equal(got[ok], exp[ok]), (bi, f.name)
+
+
+def test_feather_v2_file_with_default_compression(tmp_path):
+    import pyarrow.feather as feather
+
+    rng = np.random.default_rng(4)
+    t = pa.table({"a": pa.array(rng.integers(0, 50, 100_000).astype(np.int32)), "b": pa.array(rng.random(100_000).astype(np.float32))})
+    path = tmp_path / "t.feather"
+    import warnings
+
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", FutureWarning)  # pyarrow ≥ 24 deprecates the feather module; the FORMAT is the IPC file format
+            feather.write_feather(t, str(path))  # compression="lz4" by default when available
+    except Exception:
+        pytest.skip("feather / lz4 not available")
+    with IpcReader(str(path)) as r:
+        got = {f.name: np.concatenate([np.asarray(r.column_view(b, i)[0]) for b in range(r.num_batches)]) for i, f in enumerate(r.fields)}
+    assert np.array_equal(got["a"], t.column("a").to_numpy()) and np.array_equal(got["b"], t.column("b").to_numpy())
+
+
+def test_compressed_and_mismatched_input_is_refused():
+    t = pa.table({"a": pa.array(np.arange(1000, dtype=np.int32))})
+    sink = pa.BufferOutputStream()
+    try:
+        opts = pa.ipc.IpcWriteOptions(compression="zstd")
+    except Exception:
+        pytest.skip("pyarrow built without zstd")
     with pa.ipc.new_stream(sink, t.schema, options=opts) as w:
         w.write_table(t)
     with IpcReader(sink.getvalue().to_pybytes()) as r:
         assert r.fields[0].dtype == capi.I32 and r.num_batches == 1
-        with pytest.raises(capi.OperationNotSupported):
+        with pytest.raises(capi.OperationNotSupported):  # ZSTD: not decoded here
             r.column_view(0, 0)
     w = IpcWriter([("a", capi.I32, True), ("b", capi.F32, True)])
     with pytest.raises(capi.ArrowErrorGPU):  # columns of different length
