@@ -264,44 +264,99 @@ static agpu_status import_bitmap(agpu_pipeline* p, const uint8_t* host_bits, uin
   return AGPU_OK;
 }
 
-// Fresh host memory for an exported column.  A D2H copy into never-touched pages takes one page fault per 4 KiB inside
-// the copy (measured: 7 GB/s for a 1 GiB column against 56 GB/s into touched memory), so large buffers are 2 MiB-aligned,
-// offered to transparent huge pages and first-touched by a few threads in parallel before the DMA starts.
+// Host memory for an exported column.  A D2H copy into never-touched pages takes one page fault per 4 KiB inside the
+// copy (measured: 7 GB/s for a 1 GiB column against 56 GB/s into touched memory), so large buffers are 2 MiB-aligned,
+// offered to transparent huge pages and first-touched by a few threads in parallel before the DMA starts (12 GB/s end to
+// end) — and when the consumer releases an exported array its big buffers go to a small process-wide cache instead of
+// back to the OS, so the NEXT export of a similar size lands in pages that are already there (the link's rate).  The
+// cache holds at most AGPU_EXPORT_CACHE_BYTES (4 GiB; environment AGPU_EXPORT_CACHE_MB overrides, 0 disables).
+struct ExportCache {
+  std::mutex mu;
+  std::vector<std::pair<void*, size_t>> blocks;  // {pointer, padded size}
+  size_t bytes = 0;
+  size_t cap = (size_t)4 << 30;
+  ExportCache() {
+    if (const char* e = getenv("AGPU_EXPORT_CACHE_MB")) cap = (size_t)strtoull(e, nullptr, 10) << 20;
+  }
+};
+static ExportCache& export_cache() {  // never destroyed: consumers may release exported arrays while the process exits
+  static ExportCache* c = new ExportCache;
+  return *c;
+}
+static const size_t kExportBig = (size_t)4 << 20;
+static size_t export_padded(size_t bytes) {
+  const size_t align = bytes >= kExportBig ? ((size_t)2 << 20) : 64;
+  const size_t padded = (bytes + align - 1) / align * align;
+  return padded ? padded : align;
+}
 static void* alloc_export_buffer(size_t bytes) {
-  const size_t big = (size_t)4 << 20;
-  const size_t align = bytes >= big ? ((size_t)2 << 20) : 64;
-  size_t padded = (bytes + align - 1) / align * align;
-  if (!padded) padded = align;
+  const size_t padded = export_padded(bytes);
+  if (bytes >= kExportBig) {
+    ExportCache& c = export_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    for (size_t i = 0; i < c.blocks.size(); i++)
+      if (c.blocks[i].second >= padded && c.blocks[i].second <= padded + padded / 4) {  // touched already: no faults in the copy
+        void* ptr = c.blocks[i].first;
+        c.bytes -= c.blocks[i].second;
+        c.blocks[i] = c.blocks.back();
+        c.blocks.pop_back();
+        return ptr;
+      }
+  }
+  const size_t align = bytes >= kExportBig ? ((size_t)2 << 20) : 64;
   void* ptr = nullptr;
   if (posix_memalign(&ptr, align, padded) != 0) return nullptr;
-  if (bytes >= big) {
+  if (bytes >= kExportBig) {
     (void)madvise(ptr, padded, MADV_HUGEPAGE);
     const int T = 8;
     const size_t per = (padded / T + 4095) & ~(size_t)4095;
     std::vector<std::thread> th;
-    for (int t = 0; t < T; t++)
-      th.emplace_back([=] {
-        char* b = static_cast<char*>(ptr);
-        const size_t lo = (size_t)t * per, hi = lo + per < padded ? lo + per : padded;
-        for (size_t off = lo; off < hi; off += 4096) b[off] = 0;
-      });
+    auto touch = [=](int t) {
+      char* b = static_cast<char*>(ptr);
+      const size_t lo = (size_t)t * per, hi = lo + per < padded ? lo + per : padded;
+      for (size_t off = lo; off < hi; off += 4096) b[off] = 0;
+    };
+    for (int t = 0; t < T; t++) {
+      try {
+        th.emplace_back(touch, t);
+      } catch (...) {  // no thread to be had: touch this slice here
+        touch(t);
+      }
+    }
     for (auto& x : th) x.join();
   }
   return ptr;
+}
+// `bytes` = what the buffer was allocated for (its padded size is recomputed: cached blocks may be up to 25 % bigger,
+// which only means the cache's accounting is conservative)
+static void free_export_buffer(void* ptr, size_t bytes) {
+  if (!ptr) return;
+  if (bytes >= kExportBig) {
+    ExportCache& c = export_cache();
+    const size_t padded = export_padded(bytes);
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (c.bytes + padded <= c.cap) {
+      c.blocks.emplace_back(ptr, padded);
+      c.bytes += padded;
+      return;
+    }
+  }
+  free(ptr);
 }
 
 struct ExportPrivate {
   void* values;
   void* validity;
   const void* buffers[2];
+  size_t values_bytes, validity_bytes;
 };
 
 static void release_exported_array(struct ArrowArray* a) {
   if (!a || !a->release) return;
   ExportPrivate* pd = static_cast<ExportPrivate*>(a->private_data);
   if (pd) {
-    free(pd->values);
-    free(pd->validity);
+    free_export_buffer(pd->values, pd->values_bytes);
+    free_export_buffer(pd->validity, pd->validity_bytes);
     delete pd;
   }
   a->release = nullptr;
@@ -442,7 +497,7 @@ agpu_status agpu_export_arrow(agpu_pipeline* p, const agpu_arrow_column* column,
   AGPU_REQUIRE(n == 0 || column->values, AGPU_ERR_ARG, "null values");
   const size_t vbytes = column->dtype == AGPU_BOOL ? agpu_bitmap_bytes(n) : (size_t)n * agpu_dtype_size(column->dtype);
   const size_t nbytes = column->validity ? agpu_bitmap_bytes(n) : 0;
-  ExportPrivate* pd = new ExportPrivate{nullptr, nullptr, {nullptr, nullptr}};
+  ExportPrivate* pd = new ExportPrivate{nullptr, nullptr, {nullptr, nullptr}, vbytes, nbytes};
   // 64-byte aligned and padded, as the Arrow specification recommends
   pd->values = alloc_export_buffer(vbytes);
   if (nbytes) pd->validity = alloc_export_buffer(nbytes);
@@ -458,8 +513,8 @@ agpu_status agpu_export_arrow(agpu_pipeline* p, const agpu_arrow_column* column,
     }
   }
   if (st != AGPU_OK) {
-    free(pd->values);
-    free(pd->validity);
+    free_export_buffer(pd->values, vbytes);
+    free_export_buffer(pd->validity, nbytes);
     delete pd;
     return st;
   }
