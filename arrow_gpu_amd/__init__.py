@@ -16,4 +16,4 @@ from .gpu_utils import ArrowComputePipeline, CmpQuery, DeviceBuffer, GpuDevice  
 from .gpu_utils import gpu_device as GPU_DEVICE  # noqa: F401
 from .kernels import *  # noqa: F401,F403
 from . import interop, ipc, sharding  # noqa: F401,E402
-from .interop import PinnedStaging, from_arrow, from_arrow_batch, from_arrow_chunked, to_arrow  # noqa: F401,E402
+from .interop import PinnedStaging, from_arrow, from_arrow_batch, from_arrow_chunked, from_arrow_reader, to_arrow  # noqa: F401,E402

@@ -97,6 +97,7 @@ SIGNATURES = {
     "agpu_export_arrow": [_vp, _vp, _vp, _vp],
     "agpu_arrow_column_free": [_vp, _vp],
     "agpu_import_arrow_table": [_vp, _i32, _vp, _vp, _vp],
+    "agpu_import_arrow_stream_next": [_vp, _vp, C.POINTER(_i32), _i32, _vp, C.POINTER(C.c_int64)],
     "agpu_ipc_read_batch": [_vp, C.c_int64, C.POINTER(_i32), _i32, _vp, _vp],
     "agpu_staged_copy": [_vp, _vp, _vp, _sz, _i32],
     "agpu_malloc_table": [_vp, _i32, C.POINTER(_u64), _i32, _pp],
@@ -178,6 +179,11 @@ ArrowArrayStruct._fields_ = [
     ("buffers", C.POINTER(C.c_void_p)), ("children", C.POINTER(C.POINTER(ArrowArrayStruct))),
     ("dictionary", C.POINTER(ArrowArrayStruct)), ("release", C.CFUNCTYPE(None, C.POINTER(ArrowArrayStruct))),
     ("private_data", C.c_void_p)]
+
+
+class ArrowArrayStreamStruct(C.Structure):  # struct ArrowArrayStream: five pointers
+    _fields_ = [("get_schema", C.c_void_p), ("get_next", C.c_void_p), ("get_last_error", C.c_void_p),
+                ("release", C.CFUNCTYPE(None, C.c_void_p)), ("private_data", C.c_void_p)]
 
 
 class ArrowColumnStruct(C.Structure):  # agpu_arrow_column

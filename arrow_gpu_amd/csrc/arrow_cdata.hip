@@ -486,6 +486,50 @@ agpu_status agpu_import_arrow_table(agpu_pipeline* p, int32_t n_columns, const s
   return AGPU_OK;
 }
 
+agpu_status agpu_import_arrow_stream_next(agpu_pipeline* p, struct ArrowArrayStream* stream, const int32_t* columns,
+                                          int32_t n_columns, agpu_arrow_column* out_columns, int64_t* out_rows) {
+  AGPU_REQUIRE(p && stream && stream->release && columns && out_columns && out_rows && n_columns > 0, AGPU_ERR_ARG, "bad argument");
+  *out_rows = -1;
+  struct ArrowSchema schema;
+  struct ArrowArray batch;
+  memset(&schema, 0, sizeof(schema));
+  memset(&batch, 0, sizeof(batch));
+  if (stream->get_schema(stream, &schema) != 0 || !schema.release) {
+    const char* why = stream->get_last_error ? stream->get_last_error(stream) : nullptr;
+    agpu_set_error("ArrowArrayStream.get_schema failed: %s", why ? why : "(no message)");
+    return AGPU_ERR_ARG;
+  }
+  agpu_status st = AGPU_OK;
+  if (stream->get_next(stream, &batch) != 0) {
+    const char* why = stream->get_last_error ? stream->get_last_error(stream) : nullptr;
+    agpu_set_error("ArrowArrayStream.get_next failed: %s", why ? why : "(no message)");
+    st = AGPU_ERR_ARG;
+  } else if (batch.release) {  // a released (all-zero) array marks the end of the stream
+    // a record batch travels as a struct array: children = the columns, schema.children = their schemas
+    if (!schema.format || strcmp(schema.format, "+s") != 0 || batch.n_children != schema.n_children || batch.offset != 0) {
+      agpu_set_error("agpu_import_arrow_stream_next: the stream's items are not plain struct arrays (format '%s')", schema.format ? schema.format : "(null)");
+      st = AGPU_ERR_UNSUPPORTED;
+    } else {
+      std::vector<const struct ArrowArray*> ap((size_t)n_columns);
+      std::vector<const struct ArrowSchema*> sp((size_t)n_columns);
+      for (int32_t k = 0; k < n_columns && st == AGPU_OK; k++) {
+        if (columns[k] < 0 || columns[k] >= batch.n_children) {
+          agpu_set_error("agpu_import_arrow_stream_next: column index %d out of range", (int)columns[k]);
+          st = AGPU_ERR_ARG;
+        } else {
+          ap[(size_t)k] = batch.children[columns[k]];
+          sp[(size_t)k] = schema.children[columns[k]];
+        }
+      }
+      if (st == AGPU_OK) st = agpu_import_arrow_table(p, n_columns, ap.data(), sp.data(), out_columns);
+      if (st == AGPU_OK) *out_rows = batch.length;
+    }
+    batch.release(&batch);
+  }
+  schema.release(&schema);
+  return st;
+}
+
 agpu_status agpu_export_arrow(agpu_pipeline* p, const agpu_arrow_column* column, struct ArrowArray* out_array,
                               struct ArrowSchema* out_schema) {
   AGPU_BIND(p);

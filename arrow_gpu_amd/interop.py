@@ -144,6 +144,42 @@ def from_arrow_batch(batch, device: GpuDevice, pipeline: ArrowComputePipeline | 
     return out
 
 
+def from_arrow_reader(reader, device: GpuDevice, columns=None):
+    """pyarrow.RecordBatchReader (or anything with `_export_to_c` for the Arrow C STREAM interface) → generator of
+    {name: GPU array} per record batch, pulled through `agpu_import_arrow_stream_next`: the stream is consumed by the
+    library batch by batch, each batch's buffers in one table-placed device block."""
+    names = list(reader.schema.names)
+    tm = _type_map()
+    if columns is None:
+        idx = [i for i, f in enumerate(reader.schema) if f.type in tm]
+    else:
+        idx = [c if isinstance(c, int) else names.index(c) for c in columns]
+    types = [reader.schema.field(i).type for i in idx]
+    stream = capi.ArrowArrayStreamStruct()
+    reader._export_to_c(C.addressof(stream))
+    p = ArrowComputePipeline(device, "from_arrow_reader")
+    try:
+        while True:
+            cols = (capi.ArrowColumnStruct * len(idx))()
+            rows = C.c_int64()
+            capi.call("agpu_import_arrow_stream_next", p._handle, C.byref(stream), (C.c_int32 * len(idx))(*idx), len(idx), cols, C.byref(rows))
+            if rows.value < 0:
+                break
+            out = {}
+            for k, i in enumerate(idx):
+                col = cols[k]
+                ln = int(col.length)
+                data = DeviceBuffer(device, col.values, int(col.values_bytes))
+                nulls = NullBitBufferGpu(DeviceBuffer(device, col.validity, int(col.validity_bytes)), ln, device) if col.validity else None
+                out[names[i]] = tm[types[k]](data, device, ln, nulls)
+            p.finish()
+            p.sync()
+            yield out
+    finally:
+        if stream.release:
+            stream.release(C.addressof(stream))
+
+
 def from_arrow_chunked(chunked, device: GpuDevice):
     """pyarrow.ChunkedArray → list of GPU arrays, one per chunk (chunks stay separate: that is the sharding unit)."""
     p = ArrowComputePipeline(device, "from_arrow_chunked")

@@ -458,6 +458,16 @@ struct ArrowArray {
   void* private_data;
 };
 #endif
+#ifndef ARROW_C_STREAM_INTERFACE
+#define ARROW_C_STREAM_INTERFACE
+struct ArrowArrayStream {
+  int (*get_schema)(struct ArrowArrayStream*, struct ArrowSchema* out);
+  int (*get_next)(struct ArrowArrayStream*, struct ArrowArray* out);
+  const char* (*get_last_error)(struct ArrowArrayStream*);
+  void (*release)(struct ArrowArrayStream*);
+  void* private_data;
+};
+#endif
 /* A column resident in HBM: what PrimitiveArrayGpu<T> / BooleanArrayGPU hold
  * [ref: primitive_array_gpu.rs:12-20 {data, gpu_device, len, null_buffer}; boolean_gpu.rs:15-22]. */
 typedef struct {
@@ -486,6 +496,13 @@ agpu_status agpu_import_arrow(agpu_pipeline* p, const struct ArrowArray* array, 
  * (agpu_arrow_column_free / agpu_free of its two pointers, any order). */
 agpu_status agpu_import_arrow_table(agpu_pipeline* p, int32_t n_columns, const struct ArrowArray* const* arrays,
                                     const struct ArrowSchema* const* schemas, agpu_arrow_column* out_columns);
+/* Arrow C Stream Interface (arrow-rs FFI_ArrowArrayStream, pyarrow RecordBatchReader._export_to_c): pull the NEXT record
+ * batch of `stream` and import the columns listed in `columns` (indices into the stream's schema; all must have a GPU
+ * array type) as one table-placed block (agpu_import_arrow_table).  *out_rows = the batch's row count, or −1 with
+ * nothing imported when the stream has ended.  The stream stays the caller's (this call never releases it); the batch
+ * pulled from it is released before returning. */
+agpu_status agpu_import_arrow_stream_next(agpu_pipeline* p, struct ArrowArrayStream* stream, const int32_t* columns,
+                                          int32_t n_columns, agpu_arrow_column* out_columns, int64_t* out_rows);
 /* Device column → freshly allocated host buffers behind a released-by-consumer ArrowArray/ArrowSchema pair (both
  * `release` callbacks free everything this call allocated).  Blocks until the data has arrived. */
 agpu_status agpu_export_arrow(agpu_pipeline* p, const agpu_arrow_column* column, struct ArrowArray* out_array,

@@ -125,3 +125,23 @@ def test_record_batch_imports_into_one_table_block(ag):
     assert ag.to_arrow(s).equals(pc.add(cols["f"], cols["g"]))
     del got["f"], got["b"]  # columns die independently; the rest stays valid
     assert ag.to_arrow(got["i"]).equals(cols["i"])
+
+
+def test_record_batch_reader_through_the_c_stream_interface(ag):
+    """Arrow C STREAM interface: the library pulls batch after batch from a pyarrow RecordBatchReader"""
+    dev = ag.GPU_DEVICE()
+    n = 250_003
+    t = pa.table({"a": make(pa.float32(), n, 1, 0.1), "s": pa.array(["q"] * n), "b": make(pa.int16(), n, 2, 0.0),
+                  "c": make(pa.bool_(), n, 3, 0.25)})
+    batches = t.to_batches(max_chunksize=60_000)
+    reader = pa.RecordBatchReader.from_batches(t.schema, batches)
+    seen = 0
+    for bi, cols in enumerate(ag.from_arrow_reader(reader, dev)):
+        assert list(cols) == ["a", "b", "c"]  # the utf8 column has no GPU array type and is left out
+        for name, g in cols.items():
+            assert ag.to_arrow(g).equals(batches[bi].column(t.schema.names.index(name))), (bi, name)
+        seen += 1
+    assert seen == len(batches)
+    reader = pa.RecordBatchReader.from_batches(t.schema, batches)
+    only_b = list(ag.from_arrow_reader(reader, dev, columns=["b"]))
+    assert len(only_b) == len(batches) and all(list(c) == ["b"] for c in only_b)
