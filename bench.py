@@ -428,6 +428,7 @@ def main():
             "vs_baseline": None, "dtype": "f32+i32", "data": "synthetic",
             "config": {"workload": "f32 add (1e9 rows, no nulls) + i32 eq -> bitmap with fused validity AND (1e9 rows, 10% nulls/side)",
                        "rows_per_gpu": n, "sharding": f"chunk-sharded x{world}, no data-path collective",
+                       "layout": "columns allocated as two tables placed for the HBM channel hash (agpu_malloc_table, DESIGN.md §3)",
                        "frac_hbm_peak_per_gpu": round(value / world / HBM_PEAK_GBPS, 4)},
             "roofline": {"bound": "hbm", "kernel": "ew_kernel<float, OpAdd> (agpu_binary ADD f32)",
                          "achieved": round(add_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
