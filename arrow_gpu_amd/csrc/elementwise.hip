@@ -1313,6 +1313,12 @@ __global__ __launch_bounds__(AGPU_BLOCK) void fill_kernel(uint8_t* out, uint32_t
     if (i < bytes) out[i] = (uint8_t)(pattern >> ((i & 3) * 8));
   }
 }
+agpu_status agpu_internal_fill_bytes(agpu_pipeline* p, void* out, uint32_t pattern, uint64_t bytes) {  // agpu_memset's big fills
+  const int grid = stream_grid_for(p, (bytes / 16 + AGPU_BLOCK - 1) / AGPU_BLOCK);
+  hipLaunchKernelGGL(fill_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<uint8_t*>(out), pattern, bytes);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
 // scalar read from a 1-element device buffer (the reference binds it as a storage buffer)
 template <typename E>
 __global__ __launch_bounds__(AGPU_BLOCK) void fill_from_device_kernel(uint8_t* out, const E* scalar, uint64_t bytes) {

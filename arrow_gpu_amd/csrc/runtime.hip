@@ -685,10 +685,14 @@ agpu_status agpu_copy(agpu_pipeline* p, void* dst_dev, const void* src_dev, size
   return AGPU_OK;
 }
 
+// the same for fills: hipMemsetAsync 6.3 TB/s on 4 GB, the broadcast kernel (elementwise.hip fill_kernel) 6.9
+// (tools/probe/memset_check.py; a one-wave-block variant with nontemporal stores measured no better than the runtime)
 agpu_status agpu_memset(agpu_pipeline* p, void* dst_dev, int32_t byte_value, size_t bytes) {
   AGPU_BIND(p);
   if (!bytes) return AGPU_OK;
   AGPU_REQUIRE(dst_dev, AGPU_ERR_ARG, "null pointer");
+  if (bytes >= ((size_t)1 << 20) && (reinterpret_cast<uintptr_t>(dst_dev) & 15u) == 0)
+    return agpu_internal_fill_bytes(p, dst_dev, ((uint32_t)byte_value & 255u) * 0x01010101u, bytes);
   AGPU_HIP(hipMemsetAsync(dst_dev, byte_value, bytes, p->stream));
   return AGPU_OK;
 }

@@ -21,7 +21,7 @@ def t(label, f):
 prod = lambda: capi.call("agpu_cast", p._handle, capi.U8, capi.F32, C.c_void_p(A.ptr), C.c_void_p(O.ptr), n)
 t("PRODUCT cast u8->f32", prod)
 t("PRODUCT cast u8->f32 into the probe's output buffer", lambda: capi.call("agpu_cast", p._handle, capi.U8, capi.F32, C.c_void_p(A.ptr), C.c_void_p(O2.ptr), n))
-for v, b, u in ((4, 0, 1), (1, 64, 1), (4, 0, 1), (1, 64, 1), (2, 0, 1)):  # v2/v3: `block` = grid cap (0 = one block per chunk group)
+for v, b, u in ((5, 0, 1), (1, 64, 1), (5, 0, 1), (1, 64, 1), (4, 0, 1)):  # v2/v3: `block` = grid cap (0 = one block per chunk group)
     def f(v=v, b=b, u=u):
         rc = lib.probe_cast(C.c_void_p(A.ptr), C.c_void_p(O2.ptr), n, v, b, u, C.c_void_p(p.stream())); assert rc == 0, rc
     t(f"probe v{v} grid{b} u{u}", f)
