@@ -50,6 +50,39 @@ def all_shards(total_rows: int, world: int, align: int = ROW_ALIGN):
     return [shard_rows(total_rows, world, r, align) for r in range(world)]
 
 
+def shard_batches(batch_rows, world: int, rank: int):
+    """Record batches of an Arrow IPC file are the natural shard unit (each is self-contained, with whole bitmap words):
+    rank r gets a CONTIGUOUS run of batches, so that rank order = row order — what the rank-ordered final reduce
+    (`Communicator.reduce`) assumes.  Runs are cut where the cumulative row count crosses r/world of the total, so the
+    ranks' row counts differ by at most one batch.  Returns range(first, last)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank {rank} for world {world}")
+    total = sum(batch_rows)
+    cuts, acc, b = [0], 0, 0
+    for r in range(1, world):
+        target = total * r / world
+        while b < len(batch_rows) and acc + batch_rows[b] / 2 <= target:
+            acc += batch_rows[b]
+            b += 1
+        cuts.append(b)
+    cuts.append(len(batch_rows))
+    return range(cuts[rank], cuts[rank + 1])
+
+
+def read_ipc_shard(source, device, rank: int, world: int, columns=None) -> dict:
+    """This rank's share of an Arrow IPC file / stream: {column: [GPU array per record batch]} for the contiguous run of
+    batches `shard_batches` assigns to `rank` (every rank maps the same file; only its own batches are uploaded)."""
+    from .ipc import IpcReader
+
+    out: dict = {}
+    with IpcReader(source) as r:
+        rows = [r.batch_rows(b) for b in range(r.num_batches)]
+        for b in shard_batches(rows, world, rank):
+            for name, arr in r.read_batch(b, device, columns).items():
+                out.setdefault(name, []).append(arr)
+    return out
+
+
 def final_reduce(sum_t=None, min_t=None, max_t=None, count_t=None, group=None):
     """In-place final reduce of per-shard partials held in 1-element tensors (any device / backend).
 

@@ -142,3 +142,41 @@ def test_lz4_compressed_file_to_device(dev, tmp_path):
     for name, chunks in cols.items():
         got = pa.chunked_array([c.to_arrow() for c in chunks])
         assert got.equals(t.column(name)), name
+
+
+def test_ipc_file_read_as_rank_shards_and_combined(dev, tmp_path):
+    """sharding.read_ipc_shard: two 'ranks' (same process, same GPU — RCCL cannot put two ranks on one device) each read
+    their contiguous run of record batches; per-rank statistics combined by the rank-ordered combine (agpu_reduce_combine,
+    what agpu_comm_reduce runs after its all-gather) must equal the oracle's sharded result"""
+    import ctypes as C
+
+    import oracle as O
+    from arrow_gpu_amd import _capi as capi
+    from arrow_gpu_amd import sharding
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline
+
+    n, per_batch = 1_000_000, 65_536
+    x = O.synth_f32(n, 5, 0, -1.0, 1.0)
+    path = tmp_path / "col.arrow"
+    with pa.OSFile(str(path), "wb") as f, pa.ipc.new_file(f, pa.schema([("x", pa.float32())])) as w:
+        for s in range(0, n, per_batch):
+            w.write_batch(pa.record_batch([pa.array(x[s:s + per_batch])], names=["x"]))
+    p = ArrowComputePipeline(dev, "shards")
+    world = 2
+    parts = [sharding.read_ipc_shard(str(path), dev, r, world)["x"] for r in range(world)]
+    assert sum(len(pt) for pt in parts) == (n + per_batch - 1) // per_batch
+    # one statistic per (rank, batch) record, in row order: the combine takes any number of records
+    stats = {op: [] for op in (capi.RED_SUM, capi.RED_MIN, capi.RED_MAX)}
+    chunks = [a for pt in parts for a in pt]
+    out = dev.create_empty_buffer(16)
+    for op in stats:
+        recs = np.zeros(len(chunks) * 2, np.uint64)
+        for k, a in enumerate(chunks):
+            capi.call("agpu_reduce", p._handle, op, capi.F32, C.c_void_p(a.data.ptr), None, a.len, C.c_void_p(out.ptr))
+            recs[2 * k] = int(dev.retrive_data(out, 4, pipeline=p).view(np.uint32)[0])
+            recs[2 * k + 1] = a.len
+        d = dev.create_gpu_buffer_with_data(recs)
+        capi.call("agpu_reduce_combine", p._handle, op, capi.F32, 0, C.c_void_p(d.ptr), len(chunks), C.c_void_p(out.ptr))
+        got = dev.retrive_data(out, 4, pipeline=p).view(np.float32)[0]
+        exp = O.sharded_reduce(op, O.F32, [x[s:s + per_batch] for s in range(0, n, per_batch)])
+        assert np.float32(got).view(np.uint32) == np.float32(exp).view(np.uint32), op

@@ -143,3 +143,21 @@ def test_record_gather_protocol_world2_matches_the_sharded_spec(rows, case):
     if rows == [65536, 65536]:  # shards of 256^2 rows: the sharded Sum IS the reference's whole-column tree
         whole = np.concatenate(shards)
         assert np.float32(res[0][O.RED_SUM]).view(np.uint32) == np.float32(O.reduce(O.RED_SUM, O.F32, whole)).view(np.uint32)
+
+
+def test_record_batches_are_sharded_as_contiguous_runs_in_rank_order():
+    """sharding.shard_batches: every batch goes to exactly one rank, runs are contiguous and ordered, row counts are balanced
+    to within one batch — for equal, ragged and degenerate batch lists"""
+    from arrow_gpu_amd.sharding import shard_batches
+
+    import numpy as np
+
+    rng = np.random.default_rng(2)
+    for rows in ([1000] * 16, [5, 5, 5], [7], [], list(rng.integers(1, 100_000, 37)), [0, 0, 10, 0, 10, 10, 0]):
+        rows = [int(x) for x in rows]
+        for world in (1, 2, 3, 8):
+            runs = [shard_batches(rows, world, r) for r in range(world)]
+            assert [b for run in runs for b in run] == list(range(len(rows)))  # a partition, in order
+            per_rank = [sum(rows[b] for b in run) for run in runs]
+            if rows and sum(rows):
+                assert max(per_rank) - sum(rows) / world <= max(rows)
