@@ -20,6 +20,7 @@
 #include <cerrno>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
 
 #include "common.hpp"
@@ -268,7 +269,7 @@ agpu_status agpu_ipc_read_column(const agpu_ipc_reader* r, int64_t batch, int32_
   return st;
 }
 
-agpu_status agpu_ipc_read_batch(const agpu_ipc_reader* r, int64_t batch, const int32_t* columns, int32_t n_columns,
+static agpu_status agpu_ipc_read_batch_impl(const agpu_ipc_reader* r, int64_t batch, const int32_t* columns, int32_t n_columns,
                                 agpu_pipeline* p, agpu_arrow_column* out_columns) {
   AGPU_REQUIRE(p && columns && out_columns && n_columns > 0, AGPU_ERR_ARG, "bad argument");
   std::vector<struct ArrowArray> arrays((size_t)n_columns);
@@ -292,7 +293,7 @@ agpu_status agpu_ipc_read_batch(const agpu_ipc_reader* r, int64_t batch, const i
 }
 
 // ---------------------------------------------------------------- writer
-agpu_status agpu_ipc_writer_create(const agpu_ipc_field* fields, int32_t n_fields, int32_t file_format, int32_t fd,
+static agpu_status agpu_ipc_writer_create_impl(const agpu_ipc_field* fields, int32_t n_fields, int32_t file_format, int32_t fd,
                                    agpu_ipc_writer** out_writer) {
   AGPU_REQUIRE(out_writer && (fields || n_fields == 0) && n_fields >= 0, AGPU_ERR_ARG, "bad argument");
   *out_writer = nullptr;
@@ -329,7 +330,7 @@ static agpu_status writer_ready(agpu_ipc_writer* w) {
   return AGPU_OK;
 }
 
-agpu_status agpu_ipc_writer_write_batch(agpu_ipc_writer* w, const struct ArrowArray* const* columns) {
+static agpu_status agpu_ipc_writer_write_batch_impl(agpu_ipc_writer* w, const struct ArrowArray* const* columns) {
   agpu_status st = writer_ready(w);
   if (st != AGPU_OK) return st;
   const size_t ncol = w->fields.size();
@@ -398,7 +399,7 @@ agpu_status agpu_ipc_writer_write_batch(agpu_ipc_writer* w, const struct ArrowAr
   return AGPU_OK;
 }
 
-agpu_status agpu_ipc_writer_write_device_batch(agpu_ipc_writer* w, agpu_pipeline* p, const agpu_arrow_column* columns) {
+static agpu_status agpu_ipc_writer_write_device_batch_impl(agpu_ipc_writer* w, agpu_pipeline* p, const agpu_arrow_column* columns) {
   agpu_status st = writer_ready(w);
   if (st != AGPU_OK) return st;
   AGPU_REQUIRE(p, AGPU_ERR_ARG, "null pipeline");
@@ -474,7 +475,7 @@ agpu_status agpu_ipc_writer_write_device_batch(agpu_ipc_writer* w, agpu_pipeline
   return AGPU_OK;
 }
 
-agpu_status agpu_ipc_writer_finish(agpu_ipc_writer* w, const void** out_data, uint64_t* out_bytes) {
+static agpu_status agpu_ipc_writer_finish_impl(agpu_ipc_writer* w, const void** out_data, uint64_t* out_bytes) {
   agpu_status st = writer_ready(w);
   if (st != AGPU_OK) return st;
   const uint32_t eos[2] = {kContinuation, 0};
@@ -512,6 +513,53 @@ agpu_status agpu_ipc_writer_finish(agpu_ipc_writer* w, const void** out_data, ui
   if (out_data) *out_data = w->fd < 0 ? w->mem.data() : nullptr;
   if (out_bytes) *out_bytes = w->pos;
   return AGPU_OK;
+}
+
+agpu_status agpu_ipc_read_batch(const agpu_ipc_reader* r, int64_t batch, const int32_t* columns, int32_t n_columns,
+                                agpu_pipeline* p, agpu_arrow_column* out_columns) {
+  try {  // these allocate (metadata, in-memory sink): an allocation failure must not unwind through the C ABI
+    return agpu_ipc_read_batch_impl(r, batch, columns, n_columns, p, out_columns);
+  } catch (const std::bad_alloc&) {
+    agpu_set_error("agpu_ipc_read_batch: out of host memory");
+    return AGPU_ERR_ARG;
+  }
+}
+
+agpu_status agpu_ipc_writer_create(const agpu_ipc_field* fields, int32_t n_fields, int32_t file_format, int32_t fd,
+                                   agpu_ipc_writer** out_writer) {
+  try {  // these allocate (metadata, in-memory sink): an allocation failure must not unwind through the C ABI
+    return agpu_ipc_writer_create_impl(fields, n_fields, file_format, fd, out_writer);
+  } catch (const std::bad_alloc&) {
+    agpu_set_error("agpu_ipc_writer_create: out of host memory");
+    return AGPU_ERR_ARG;
+  }
+}
+
+agpu_status agpu_ipc_writer_write_batch(agpu_ipc_writer* w, const struct ArrowArray* const* columns) {
+  try {  // these allocate (metadata, in-memory sink): an allocation failure must not unwind through the C ABI
+    return agpu_ipc_writer_write_batch_impl(w, columns);
+  } catch (const std::bad_alloc&) {
+    agpu_set_error("agpu_ipc_writer_write_batch: out of host memory");
+    return AGPU_ERR_ARG;
+  }
+}
+
+agpu_status agpu_ipc_writer_write_device_batch(agpu_ipc_writer* w, agpu_pipeline* p, const agpu_arrow_column* columns) {
+  try {  // these allocate (metadata, in-memory sink): an allocation failure must not unwind through the C ABI
+    return agpu_ipc_writer_write_device_batch_impl(w, p, columns);
+  } catch (const std::bad_alloc&) {
+    agpu_set_error("agpu_ipc_writer_write_device_batch: out of host memory");
+    return AGPU_ERR_ARG;
+  }
+}
+
+agpu_status agpu_ipc_writer_finish(agpu_ipc_writer* w, const void** out_data, uint64_t* out_bytes) {
+  try {  // these allocate (metadata, in-memory sink): an allocation failure must not unwind through the C ABI
+    return agpu_ipc_writer_finish_impl(w, out_data, out_bytes);
+  } catch (const std::bad_alloc&) {
+    agpu_set_error("agpu_ipc_writer_finish: out of host memory");
+    return AGPU_ERR_ARG;
+  }
 }
 
 void agpu_ipc_writer_destroy(agpu_ipc_writer* w) {
