@@ -110,6 +110,7 @@ SIGNATURES = {
     "agpu_ipc_column_view": [_vp, C.c_int64, _i32, _vp, _vp],
     "agpu_ipc_read_column": [_vp, C.c_int64, _i32, _vp, _vp],
     "agpu_ipc_writer_create": [_vp, _i32, _i32, _i32, _pp],
+    "agpu_ipc_writer_set_compression": [_vp, _i32],
     "agpu_ipc_writer_write_batch": [_vp, _vp],
     "agpu_ipc_writer_write_device_batch": [_vp, _vp, _vp],
     "agpu_ipc_writer_finish": [_vp, _pp, C.POINTER(_u64)],

@@ -38,6 +38,7 @@ struct agpu_ipc_writer {
   std::vector<Block> blocks;
   bool finished = false;
   bool failed = false;
+  int codec = 0;               // 0: bodies as they are; 1: every buffer as an LZ4 frame (BodyCompression LZ4_FRAME / BUFFER)
   void* pin[2] = {nullptr, nullptr};  // page-locked bounce slots of the descriptor sink (device batches only)
   hipEvent_t pin_ev[2] = {nullptr, nullptr};
   int pin_device = -1;
@@ -219,14 +220,21 @@ static size_t pad64(size_t n) { return (n + 63) / 64 * 64; }
 
 // RecordBatch metadata for `rows` rows with the given (validity_bytes, values_bytes, null_count) per column
 static void build_batch_message(FbOut& o, int64_t rows, const std::vector<int64_t>& null_counts,
-                                const std::vector<size_t>& vbytes, const std::vector<size_t>& dbytes, int64_t* body_len) {
+                                const std::vector<size_t>& vbytes, const std::vector<size_t>& dbytes, int64_t* body_len,
+                                bool lz4 = false) {
   o.u32(0);
   std::vector<FbField> mf = {{0, 2, (uint64_t)kV5, false, 0}, {1, 1, H_RecordBatch, false, 0}, {2, 4, 0, true, 0}, {3, 8, 0, false, 0}};
   const size_t msg = fb_write_table(o, mf);
   o.patch32(0, (uint32_t)msg);
   std::vector<FbField> rf = {{0, 8, (uint64_t)rows, false, 0}, {1, 4, 0, true, 0}, {2, 4, 0, true, 0}};
+  if (lz4) rf.push_back({3, 4, 0, true, 0});  // compression: BodyCompression
   const size_t rb = fb_write_table(o, rf);
   o.patch32(mf[2].at, (uint32_t)(rb - mf[2].at));
+  if (lz4) {  // {codec: LZ4_FRAME = 0, method: BUFFER = 0}, written out although both are the defaults
+    std::vector<FbField> cf = {{0, 1, 0, false, 0}, {1, 1, 0, false, 0}};
+    const size_t ct = fb_write_table(o, cf);
+    o.patch32(rf[3].at, (uint32_t)(ct - rf[3].at));
+  }
   const size_t ncol = null_counts.size();
   // nodes: vector of 16-byte structs, elements 8-byte aligned (so the length word sits at 4 mod 8)
   o.pad_to(8, 4);
@@ -250,6 +258,52 @@ static void build_batch_message(FbOut& o, int64_t rows, const std::vector<int64_
   }
   *body_len = off;
   memcpy(o.b.data() + mf[3].at, &off, 8);
+}
+
+// One record batch whose buffers are all in host memory, every buffer as {int64 uncompressed length, LZ4 frame} — or
+// {−1, the bytes} where the frame would not be smaller (the format's escape for incompressible buffers).
+struct HostPiece {
+  const uint8_t* p;
+  size_t n;
+};
+static agpu_status emit_batch_lz4(agpu_ipc_writer* w, int64_t rows, const std::vector<int64_t>& nulls, const std::vector<HostPiece>& validity,
+                                 const std::vector<HostPiece>& values) {
+  const size_t ncol = nulls.size();
+  std::vector<std::vector<uint8_t>> enc(2 * ncol);
+  std::vector<size_t> vbytes(ncol), dbytes(ncol);
+  for (size_t c = 0; c < ncol; c++)
+    for (int k = 0; k < 2; k++) {
+      const HostPiece& src = k == 0 ? validity[c] : values[c];
+      std::vector<uint8_t>& out = enc[2 * c + (size_t)k];
+      if (src.n) {
+        int64_t ulen = (int64_t)src.n;
+        out.resize(8);
+        lz4_frame_encode(src.p, src.n, &out);
+        if (out.size() - 8 >= src.n) {
+          ulen = -1;
+          out.resize(8);
+          out.insert(out.end(), src.p, src.p + src.n);
+        }
+        memcpy(out.data(), &ulen, 8);
+      }
+      (k == 0 ? vbytes[c] : dbytes[c]) = out.size();
+    }
+  FbOut o;
+  int64_t body_len = 0;
+  build_batch_message(o, rows, nulls, vbytes, dbytes, &body_len, true);
+  const int64_t block_off = (int64_t)w->pos;
+  int32_t meta_len = 0;
+  agpu_status st = emit_message(w, o, &meta_len);
+  for (size_t k = 0; k < enc.size() && st == AGPU_OK; k++) {
+    st = sink_write(w, enc[k].data(), enc[k].size());
+    if (st == AGPU_OK) st = sink_zeros(w, pad64(enc[k].size()) - enc[k].size());
+  }
+  if (st != AGPU_OK) {
+    w->failed = true;
+    return st;
+  }
+  w->blocks.push_back({block_off, meta_len, body_len});
+  return AGPU_OK;
 }
 
 }  // namespace
@@ -369,6 +423,22 @@ static agpu_status agpu_ipc_writer_write_batch_impl(agpu_ipc_writer* w, const st
       }
     }
   }
+  if (w->codec == 1) {
+    std::vector<HostPiece> pv(ncol), pd(ncol);
+    std::vector<std::vector<uint8_t>> bpacked(ncol);
+    for (size_t c = 0; c < ncol; c++) {
+      pv[c] = HostPiece{vpacked[c].data(), vbytes[c]};
+      const int32_t dt = w->fields[c].dtype;
+      if (dt == AGPU_BOOL) {
+        bpacked[c].resize(dbytes[c]);
+        copy_bits_host(hc[c].values, hc[c].offset, (uint64_t)rows, bpacked[c].data());
+        pd[c] = HostPiece{bpacked[c].data(), dbytes[c]};
+      } else {
+        pd[c] = HostPiece{dbytes[c] ? hc[c].values + hc[c].offset * agpu_dtype_size((agpu_dtype)dt) : nullptr, dbytes[c]};
+      }
+    }
+    return emit_batch_lz4(w, rows, nulls, pv, pd);
+  }
   FbOut o;
   int64_t body_len = 0;
   build_batch_message(o, rows, nulls, vbytes, dbytes, &body_len);
@@ -437,6 +507,21 @@ static agpu_status agpu_ipc_writer_write_device_batch_impl(agpu_ipc_writer* w, a
     dbytes[c] = col.dtype == AGPU_BOOL ? bitmap_span_bytes((uint64_t)rows) : (size_t)rows * agpu_dtype_size(col.dtype);
   }
   if (cnt_dev) (void)agpu_free(p->dev, cnt_dev);
+  if (w->codec == 1) {  // compression runs on the host: HBM → host buffers → LZ4 frames → sink
+    std::vector<std::vector<uint8_t>> hv(ncol), hd(ncol);
+    std::vector<HostPiece> pv(ncol), pd(ncol);
+    for (size_t c = 0; c < ncol; c++) {
+      hv[c].resize(vbytes[c]);
+      hd[c].resize(dbytes[c]);
+      if (vbytes[c]) st = agpu_staged_copy(p, const_cast<void*>(columns[c].validity), hv[c].data(), vbytes[c], 0);
+      if (st == AGPU_OK && dbytes[c]) st = agpu_staged_copy(p, const_cast<void*>(columns[c].values), hd[c].data(), dbytes[c], 0);
+      if (st != AGPU_OK) return st;
+      if (vbytes[c] && (rows & 7)) hv[c][vbytes[c] - 1] &= (uint8_t)((1u << (rows & 7)) - 1u);
+      pv[c] = HostPiece{hv[c].data(), vbytes[c]};
+      pd[c] = HostPiece{hd[c].data(), dbytes[c]};
+    }
+    return emit_batch_lz4(w, rows, nulls, pv, pd);
+  }
   FbOut o;
   int64_t body_len = 0;
   build_batch_message(o, rows, nulls, vbytes, dbytes, &body_len);
@@ -560,6 +645,17 @@ agpu_status agpu_ipc_writer_finish(agpu_ipc_writer* w, const void** out_data, ui
     agpu_set_error("agpu_ipc_writer_finish: out of host memory");
     return AGPU_ERR_ARG;
   }
+}
+
+agpu_status agpu_ipc_writer_set_compression(agpu_ipc_writer* w, int32_t codec) {
+  AGPU_REQUIRE(w, AGPU_ERR_ARG, "null writer");
+  AGPU_REQUIRE(w->blocks.empty() && !w->finished, AGPU_ERR_ARG, "set the compression before the first record batch");
+  if (codec != 0 && codec != 1) {
+    agpu_set_error("agpu_ipc_writer_set_compression: codec %d (0 = none, 1 = LZ4 frame; ZSTD is not implemented)", (int)codec);
+    return AGPU_ERR_UNSUPPORTED;
+  }
+  w->codec = codec;
+  return AGPU_OK;
 }
 
 void agpu_ipc_writer_destroy(agpu_ipc_writer* w) {

@@ -187,7 +187,9 @@ class IpcWriter:
     """Writer of the streaming format (default) or the file format.  `sink`: None → in memory (`finish()` returns bytes),
     a path → that file, an int → an open descriptor.  `fields` = [(name, dtype code or GPU array class, nullable)]."""
 
-    def __init__(self, fields, sink=None, file_format: bool = False):
+    def __init__(self, fields, sink=None, file_format: bool = False, compression: str | None = None):
+        if compression not in (None, "lz4"):
+            raise capi.OperationNotSupported(f"compression {compression!r}: only 'lz4' (LZ4 frame, Feather V2's default) is implemented")
         codes = {v: k for k, v in _classes().items()}
         self._names = []
         arr = (capi.IpcFieldStruct * max(1, len(fields)))()
@@ -209,6 +211,8 @@ class IpcWriter:
         self._handle = C.c_void_p()
         try:
             capi.call("agpu_ipc_writer_create", arr, len(fields), 1 if file_format else 0, fd, C.byref(self._handle))
+            if compression == "lz4":
+                capi.call("agpu_ipc_writer_set_compression", self._handle, 1)
         except Exception:
             if self._own_fd is not None:
                 os.close(self._own_fd)
@@ -278,14 +282,15 @@ def read_ipc(source, device: GpuDevice, columns=None) -> dict:
         return r.read_all(device, columns)
 
 
-def write_ipc(columns: dict, sink=None, file_format: bool = False):
-    """{name: GPU array | [GPU arrays, one per record batch]} → Arrow IPC (bytes when `sink` is None)."""
+def write_ipc(columns: dict, sink=None, file_format: bool = False, compression: str | None = None):
+    """{name: GPU array | [GPU arrays, one per record batch]} → Arrow IPC (bytes when `sink` is None); compression="lz4"
+    writes every buffer as an LZ4 frame (what Feather V2 defaults to)."""
     names = list(columns)
     chunks = [v if isinstance(v, (list, tuple)) else [v] for v in columns.values()]
     nb = len(chunks[0]) if chunks else 0
     assert all(len(c) == nb for c in chunks), "every column needs the same number of record batches"
     fields = [(n, type(c[0]), True) for n, c in zip(names, chunks)]
-    w = IpcWriter(fields, sink, file_format)
+    w = IpcWriter(fields, sink, file_format, compression)
     for b in range(nb):
         w.write_batch([c[b] for c in chunks])
     return w.finish()

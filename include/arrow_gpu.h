@@ -551,6 +551,9 @@ agpu_status agpu_ipc_read_batch(const agpu_ipc_reader* r, int64_t batch, const i
  * file_format != 0 → "ARROW1" file with footer; else the streaming format.  Body buffers are padded to 64 bytes. */
 agpu_status agpu_ipc_writer_create(const agpu_ipc_field* fields, int32_t n_fields, int32_t file_format, int32_t fd,
                                    agpu_ipc_writer** out_writer);
+/* codec 0: bodies as they are (default); 1: every buffer of every later batch as an LZ4 frame (BodyCompression LZ4_FRAME,
+ * what Feather V2 defaults to; incompressible buffers are stored).  Compression runs on the host, one thread. */
+agpu_status agpu_ipc_writer_set_compression(agpu_ipc_writer* w, int32_t codec);
 /* one record batch from host arrays (one ArrowArray per field, in schema order; `offset` honoured, bitmaps re-packed,
  * null counts recomputed) */
 agpu_status agpu_ipc_writer_write_batch(agpu_ipc_writer* w, const struct ArrowArray* const* columns);

@@ -112,6 +112,29 @@ int main(int argc, char** argv) {
     }
     run(m);
   }
-  printf("ipc_fuzz OK: %d cases, %d opened, checksum %llu\n", cases, opened, (unsigned long long)sum);
+  // the LZ4 frame codec on its own: encode → decode must give the bytes back (runs, noise, tiny and multi-block inputs),
+  // and decoding a truncated / flipped frame must fail or stay inside its buffers
+  int codec_cases = 0;
+  for (int t = 0; t < 120; t++) {
+    size_t n = t < 30 ? (size_t)t : (size_t)(rnd() % 200000);
+    if (t == 119) n = ((size_t)4 << 20) + 12345;
+    std::vector<uint8_t> a(n), c, d;
+    for (size_t i = 0; i < n; i++) a[i] = (t & 3) == 0 ? (uint8_t)rnd() : (t & 3) == 1 ? (uint8_t)(i / 100) : (t & 3) == 2 ? (uint8_t)((i % 7) * 3) : (uint8_t)(rnd() % 3);
+    lz4_frame_encode(a.data(), n, &c);
+    if (!lz4_frame_decode(c.data(), c.size(), n, &d) || d != a) {
+      fprintf(stderr, "LZ4 round trip failed at case %d (n = %zu)\n", t, n);
+      return 1;
+    }
+    for (int k = 0; k < 8 && !c.empty(); k++) {
+      std::vector<uint8_t> m(c.begin(), c.begin() + (long)(rnd() % (c.size() + 1)));
+      if (!m.empty() && (k & 1)) m[rnd() % m.size()] = (uint8_t)rnd();
+      uint8_t* q = static_cast<uint8_t*>(malloc(m.size() ? m.size() : 1));
+      if (!m.empty()) memcpy(q, m.data(), m.size());
+      (void)lz4_frame_decode(q, m.size(), n, &d);
+      free(q);
+    }
+    codec_cases++;
+  }
+  printf("ipc_fuzz OK: %d cases, %d opened, %d codec round trips, checksum %llu\n", cases, opened, codec_cases, (unsigned long long)sum);
   return 0;
 }

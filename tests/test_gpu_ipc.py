@@ -180,3 +180,21 @@ def test_ipc_file_read_as_rank_shards_and_combined(dev, tmp_path):
         got = dev.retrive_data(out, 4, pipeline=p).view(np.float32)[0]
         exp = O.sharded_reduce(op, O.F32, [x[s:s + per_batch] for s in range(0, n, per_batch)])
         assert np.float32(got).view(np.uint32) == np.float32(exp).view(np.uint32), op
+
+
+def test_device_columns_to_lz4_compressed_file(dev, tmp_path):
+    """write_ipc(compression="lz4") from HBM: download, LZ4 frames, pyarrow reads the table back"""
+    import arrow_gpu_amd as ag
+    from arrow_gpu_amd.ipc import write_ipc
+
+    n = 300_000
+    rng = np.random.default_rng(12)
+    t = pa.table({"k": pa.array(np.repeat(np.arange(n // 100, dtype=np.int32), 100), mask=np.arange(n) % 9 == 0),
+                  "x": pa.array(rng.standard_normal(n).astype(np.float32)), "b": pa.array(rng.random(n) < 0.1)})
+    cols = {name: ag.from_arrow(t.column(name).chunk(0), dev) for name in t.schema.names}
+    path = tmp_path / "out.feather"
+    assert write_ipc(cols, str(path), file_format=True, compression="lz4") is None
+    assert path.stat().st_size < 0.6 * t.nbytes
+    back = pa.ipc.open_file(pa.memory_map(str(path))).read_all()
+    back.validate(full=True)
+    assert back.equals(t)

@@ -308,3 +308,38 @@ def test_truncated_and_corrupted_input_never_crashes(file_format):
                                 pass
         except capi.ArrowErrorGPU:
             pass
+
+
+@pytest.mark.parametrize("file_format", [False, True])
+def test_lz4_compressing_writer_is_read_by_pyarrow_and_by_us(file_format):
+    """agpu_ipc_writer_set_compression(1): every buffer {uncompressed length, LZ4 frame} (or {-1, bytes} when a frame would
+    not be smaller); pyarrow's reader (liblz4, which verifies the frame header checksum) must return the source table"""
+    rng = np.random.default_rng(31)
+    n = 120_000
+    t = pa.table({
+        "runs": pa.array(np.repeat(np.arange(n // 200, dtype=np.int32), 200), mask=np.arange(n) % 17 == 0),
+        "noise": pa.array(rng.standard_normal(n).astype(np.float32)),
+        "small": pa.array(rng.integers(0, 4, n).astype(np.uint8), mask=rng.random(n) < 0.3),
+        "flags": pa.array(rng.random(n) < 0.01),
+        "days": pa.array((np.arange(n) // 1000).astype(np.int32), type=pa.date32()),
+    })
+    codes = {tp: c for _, tp, c in TYPES}
+    w = IpcWriter([(f.name, codes[f.type], True) for f in t.schema], None, file_format, compression="lz4")
+    batches = t.slice(3).to_batches(max_chunksize=50_000)  # sliced inputs too
+    for b in batches:
+        w.write_host_batch(b.columns)
+    data = w.finish()
+    assert len(data) < 0.7 * t.nbytes
+    got = (pa.ipc.open_file if file_format else pa.ipc.open_stream)(pa.BufferReader(data)).read_all()
+    got.validate(full=True)
+    assert got.equals(t.slice(3))
+    with IpcReader(data) as r:
+        assert r.num_batches == len(batches)
+        for bi, b in enumerate(batches):
+            v, _, ln, nulls = r.column_view(bi, 0)
+            col = b.column(0)
+            ok = np.asarray(col.is_valid())
+            assert ln == len(col) and nulls == col.null_count
+            assert np.array_equal(np.asarray(v)[ok], col.fill_null(0).to_numpy(zero_copy_only=False)[ok])
+    with pytest.raises(capi.OperationNotSupported):
+        IpcWriter([("a", capi.I32, True)], compression="zstd")
