@@ -310,9 +310,102 @@ static agpu_status emit_batch_lz4(agpu_ipc_writer* w, int64_t rows, const std::v
 
 extern "C" {
 
+// A dictionary-encoded column is decoded ON THE GPU: only the indices (1, 2 or 4 bytes per row) and the dictionary cross
+// the link; indices widen to u32 (agpu_cast), null slots — whose indices are unspecified — become index 0 (agpu_merge
+// against a zero column), and agpu_take gathers from the dictionary (small: it lives in L2).  An index beyond the
+// dictionary in a VALID slot surfaces like any bad take index: AGPU_ERR_SHAPE at the pipeline's next sync.
+static void release_noop_array(struct ArrowArray*) {}
+static void release_noop_schema(struct ArrowSchema*) {}
+static agpu_status read_dict_column_device(const agpu_ipc_reader* r, int64_t batch, int32_t column, agpu_pipeline* p,
+                                           agpu_arrow_column* out_column) {
+  const FieldInfo& fi = r->fields[(size_t)column];
+  const BatchInfo& bi = r->batches[(size_t)batch];
+  std::vector<uint8_t> idx_owned[2], dict_values;
+  const uint8_t *iv = nullptr, *ix = nullptr;
+  int64_t rows = 0, nulls = 0;
+  agpu_status st = dict_parts(r, bi, fi, (int)column, &rows, &nulls, &iv, &ix, idx_owned, &dict_values);
+  if (st != AGPU_OK) return st;
+  const uint64_t n = (uint64_t)rows;
+  const size_t w = agpu_dtype_size((agpu_dtype)fi.dtype), iw = agpu_dtype_size((agpu_dtype)fi.index_dtype);
+  const uint64_t dict_len = dict_values.size() / w;
+  agpu_device* dev = p->dev;
+  // 1. the indices as an ordinary primitive column (validity re-aligned and masked by the import)
+  static const char* const fmt_of[] = {nullptr, nullptr, "I", "S", "C", "i", "s", "c", nullptr};  // by agpu_dtype: U32 U16 U8 I32 I16 I8
+  const void* bufs[2] = {nulls > 0 ? iv : nullptr, ix};
+  struct ArrowArray a;
+  struct ArrowSchema sc;
+  memset(&a, 0, sizeof(a));
+  memset(&sc, 0, sizeof(sc));
+  a.length = rows;
+  a.null_count = nulls;
+  a.n_buffers = 2;
+  a.buffers = bufs;
+  a.release = release_noop_array;
+  sc.format = fmt_of[fi.index_dtype];
+  sc.name = "";
+  sc.release = release_noop_schema;
+  agpu_arrow_column idx;
+  st = agpu_import_arrow(p, &a, &sc, &idx);
+  if (st != AGPU_OK) return st;
+  void *idx32 = nullptr, *zeros = nullptr, *merged = nullptr, *dict_dev = nullptr, *vals = nullptr;
+  const size_t n4 = n * 4 ? n * 4 : 16, nvb = n * w ? n * w : 16;
+  const uint32_t* take_idx = static_cast<const uint32_t*>(idx.values);
+  if (st == AGPU_OK && iw < 4) {  // 2. widen to u32
+    st = agpu_malloc(dev, n4, 0, &idx32);
+    if (st == AGPU_OK && n) st = agpu_cast(p, (agpu_dtype)fi.index_dtype, AGPU_U32, idx.values, idx32, n);
+    take_idx = static_cast<const uint32_t*>(idx32);
+  }
+  if (st == AGPU_OK && idx.validity && n) {  // 3. null slots → index 0
+    st = agpu_malloc(dev, n4, 0, &zeros);
+    if (st == AGPU_OK) st = agpu_memset(p, zeros, 0, n4);
+    if (st == AGPU_OK) st = agpu_malloc(dev, n4, 0, &merged);
+    if (st == AGPU_OK) st = agpu_merge(p, 4, take_idx, zeros, idx.validity, merged, n);
+    take_idx = static_cast<const uint32_t*>(merged);
+  }
+  if (st == AGPU_OK) st = agpu_malloc(dev, nvb, 0, &vals);
+  if (st == AGPU_OK && n) {
+    if (dict_len == 0) {  // an all-null column over an empty dictionary
+      st = agpu_memset(p, vals, 0, nvb);
+    } else {  // 4. the dictionary and the gather
+      st = agpu_malloc(dev, dict_values.size(), 0, &dict_dev);
+      if (st == AGPU_OK) st = agpu_upload(p, dict_dev, dict_values.data(), dict_values.size());
+      if (st == AGPU_OK) st = agpu_take(p, (int32_t)w, dict_dev, dict_len, take_idx, vals, n);
+    }
+  }
+  // temporaries: the pool hands them out again only after the stream has passed the kernels above
+  if (dict_dev) (void)agpu_free(dev, dict_dev);
+  if (merged) (void)agpu_free(dev, merged);
+  if (zeros) (void)agpu_free(dev, zeros);
+  if (idx32) (void)agpu_free(dev, idx32);
+  (void)agpu_free(dev, idx.values);
+  if (st != AGPU_OK) {
+    if (vals) (void)agpu_free(dev, vals);
+    if (idx.validity) (void)agpu_free(dev, idx.validity);
+    return st;
+  }
+  memset(out_column, 0, sizeof(*out_column));
+  out_column->dtype = (agpu_dtype)fi.dtype;
+  out_column->length = n;
+  out_column->null_count = idx.validity ? nulls : 0;
+  out_column->values = vals;
+  out_column->values_bytes = nvb;
+  out_column->validity = idx.validity;
+  out_column->validity_bytes = idx.validity_bytes;
+  return AGPU_OK;
+}
+
 agpu_status agpu_ipc_read_column(const agpu_ipc_reader* r, int64_t batch, int32_t column, agpu_pipeline* p,
                                  agpu_arrow_column* out_column) {
   AGPU_REQUIRE(p && out_column, AGPU_ERR_ARG, "null argument");
+  if (r && batch >= 0 && (size_t)batch < r->batches.size() && column >= 0 && (size_t)column < r->fields.size() &&
+      r->fields[(size_t)column].dict && r->fields[(size_t)column].first_node >= 0) {
+    try {
+      return read_dict_column_device(r, batch, column, p, out_column);
+    } catch (const std::bad_alloc&) {
+      agpu_set_error("agpu_ipc_read_column: out of host memory");
+      return AGPU_ERR_ARG;
+    }
+  }
   struct ArrowArray a;
   struct ArrowSchema s;
   agpu_status st = agpu_ipc_column_view(r, batch, column, &a, &s);

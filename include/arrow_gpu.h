@@ -518,7 +518,9 @@ agpu_status agpu_staged_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, si
  * without a host-side Arrow library.  The reader BORROWS `data` (mmap the file: bytes go page cache → HBM with no copy in
  * between) — keep it mapped until agpu_ipc_close.  Little-endian V4/V5 metadata; bodies uncompressed or LZ4_FRAME-compressed
  * (Feather V2's default: decoded by the library, the view then owns the decompressed bytes); columns of the nine GPU array
- * types are readable, columns of any other type (utf8, int64, nested, dictionary …) are skipped correctly and report
+ * types are readable — also when dictionary-encoded (indices int8 / 16 / 32, dictionaries without nulls; deltas and
+ * replacements followed): agpu_ipc_column_view decodes on the host, agpu_ipc_read_column on the GPU (indices + dictionary
+ * cross the link, agpu_take gathers) —; columns of any other type (utf8, int64, nested, string dictionaries …) are skipped correctly and report
  * AGPU_ERR_UNSUPPORTED when asked for; ZSTD-compressed bodies → AGPU_ERR_UNSUPPORTED; malformed or truncated input →
  * AGPU_ERR_SHAPE (every metadata access is bounds-checked).  Host-only calls (open … column_view, writer_create,
  * write_batch, finish) need no GPU. */

@@ -343,3 +343,63 @@ def test_lz4_compressing_writer_is_read_by_pyarrow_and_by_us(file_format):
             assert np.array_equal(np.asarray(v)[ok], col.fill_null(0).to_numpy(zero_copy_only=False)[ok])
     with pytest.raises(capi.OperationNotSupported):
         IpcWriter([("a", capi.I32, True)], compression="zstd")
+
+
+@pytest.mark.parametrize("file_format", [False, True])
+@pytest.mark.parametrize("compression", [None, "lz4"])
+def test_dictionary_encoded_numeric_columns_are_decoded(file_format, compression):
+    """Dictionary-encoded columns whose VALUES have a GPU array type (f32 / i32 / u16 … with int8 / int16 / int32 indices)
+    read as their decoded values; string dictionaries stay unsupported; nulls travel in the index validity"""
+    rng = np.random.default_rng(5)
+    n = 40_000
+    f = pa.array(rng.choice(np.array([0.5, -1.25, 3.0, 1e10, -0.0], np.float32), n), mask=rng.random(n) < 0.15).dictionary_encode()
+    i = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 300, n).astype(np.int16)), pa.array(np.arange(1000, 1300, dtype=np.int32)))
+    u = pa.DictionaryArray.from_arrays(pa.array(rng.integers(0, 7, n).astype(np.int8), mask=rng.random(n) < 0.5),
+                                       pa.array(np.arange(7, dtype=np.uint16) * 1000))
+    s_ = pa.array(rng.choice(["a", "bb", "ccc"], n)).dictionary_encode()
+    plain = pa.array(rng.integers(0, 100, n).astype(np.int32))
+    t = pa.table({"f": f, "i": i, "s": s_, "u": u, "plain": plain})
+    sink = pa.BufferOutputStream()
+    opts = pa.ipc.IpcWriteOptions(compression=compression) if compression else pa.ipc.IpcWriteOptions()
+    with (pa.ipc.new_file if file_format else pa.ipc.new_stream)(sink, t.schema, options=opts) as w:
+        for b in t.to_batches(max_chunksize=15_000):
+            w.write_batch(b)
+    data = sink.getvalue().to_pybytes()
+    batches = t.to_batches(max_chunksize=15_000)
+    with IpcReader(data) as r:
+        by = {fl.name: fl for fl in r.fields}
+        assert (by["f"].dtype, by["i"].dtype, by["u"].dtype, by["plain"].dtype, by["s"].dtype) == (capi.F32, capi.I32, capi.U16, capi.I32, -1)
+        assert r.num_batches == len(batches)
+        for bi, batch in enumerate(batches):
+            for name in ("f", "i", "u", "plain"):
+                ci = r.column_index(name)
+                values, validity, length, nulls = r.column_view(bi, ci)
+                col = batch.column(ci)
+                dense = col.dictionary_decode() if pa.types.is_dictionary(col.type) else col
+                ok = np.asarray(dense.is_valid())
+                assert length == len(col) and nulls == col.null_count
+                if validity is not None:
+                    assert np.array_equal(unpack_bits(validity, length), ok)
+                exp = dense.fill_null(0).to_numpy(zero_copy_only=False)
+                assert np.array_equal(np.asarray(values)[ok].view(np.uint8), exp[ok].view(np.uint8)), (bi, name)
+            with pytest.raises(capi.OperationNotSupported):
+                r.column_view(bi, r.column_index("s"))
+
+
+def test_dictionary_deltas_and_replacements_in_a_stream():
+    """A stream may replace a dictionary between record batches or extend it with a delta batch; every record batch is
+    decoded with the dictionary in force where it stands"""
+    vals = [np.array([10, 20, 30], np.int32), np.array([10, 20, 30, 40, 50], np.int32), np.array([7, 8], np.int32)]  # extend, then replace
+    idx = [np.array([0, 2, 1, 1], np.int8), np.array([4, 0, 3, 3, 2], np.int8), np.array([1, 1, 0], np.int8)]
+    typ = pa.dictionary(pa.int8(), pa.int32())
+    batches = [pa.record_batch([pa.DictionaryArray.from_arrays(pa.array(i), pa.array(v))], schema=pa.schema([("d", typ)])) for i, v in zip(idx, vals)]
+    sink = pa.BufferOutputStream()
+    with pa.ipc.new_stream(sink, batches[0].schema, options=pa.ipc.IpcWriteOptions(emit_dictionary_deltas=True)) as w:
+        for b in batches:
+            w.write_batch(b)
+    with IpcReader(sink.getvalue().to_pybytes()) as r:
+        assert r.num_batches == 3 and r.fields[0].dtype == capi.I32
+        for k in range(3):
+            values, validity, length, nulls = r.column_view(k, 0)
+            assert validity is None and nulls == 0
+            assert np.array_equal(np.asarray(values), vals[k][idx[k]])

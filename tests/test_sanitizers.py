@@ -97,6 +97,15 @@ def test_ipc_reader_under_asan_ubsan_with_truncated_and_corrupted_input(tmp_path
         cases.append(("lz4.arrow", sink.getvalue().to_pybytes()))
     except Exception:
         pass
+    try:  # dictionary-encoded numeric columns: the index / dictionary decode sees the same mutations
+        rngd = np.random.default_rng(3)
+        dt = pa.table({"d": pa.DictionaryArray.from_arrays(pa.array(rngd.integers(0, 50, 400).astype(np.int16), mask=rngd.random(400) < 0.2),
+                                                             pa.array(np.arange(50, dtype=np.float32) * 1.5)),
+                       "p": pa.array(np.arange(400, dtype=np.int32))})
+        cases.append(("dict.arrow", serialise(dt, True, 150)))
+        cases.append(("dict_stream.arrow", serialise(dt, False, 150)))
+    except Exception:
+        pass
     for name, blob in cases:
         path = tmp_path / name
         path.write_bytes(blob)
