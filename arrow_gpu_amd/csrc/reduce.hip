@@ -247,9 +247,19 @@ template <bool MAX> struct RedMinMaxF32 {  // Arrow min_max: NaN skipped unless 
     if (x != x) return MinMaxF32{MAX ? -__builtin_inff() : __builtin_inff(), 2u};
     return MinMaxF32{x, 1u};
   }
+  // neither operand is ever NaN here (load() maps NaN to the identity), so the hardware's v_min_f32 / v_max_f32 — which
+  // order −0 below +0 — give Arrow's result in one instruction instead of two compares, a sign test and two selects
+  // (the reduction reads 4 B/row: at 3 rows per clock and CU those ten operations were half of the VALU budget)
+  // (written as the instruction itself: through fminf / fmaxf LLVM adds a canonicalising v_max_f32 x, x per operand)
   __device__ static float pick(float a, float b) {
-    if (a == b) return MAX ? (__builtin_signbit(a) ? b : a) : (__builtin_signbit(a) ? a : b);
-    return MAX ? (a > b ? a : b) : (a < b ? a : b);
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    if constexpr (MAX) asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return MAX ? __builtin_fmaxf(a, b) : __builtin_fminf(a, b);
+#endif
   }
   __device__ static Acc combine(Acc a, Acc b) { return MinMaxF32{pick(a.r, b.r), a.flags | b.flags}; }
   __device__ static Out finish(Acc a) {

@@ -644,3 +644,18 @@ def test_fused_small_int_trig_on_slices(D, dtype, op):
             out = D.empty(4 * n + 16)
             D.call("agpu_unary", op, dtype, C.c_void_p(src.buf.ptr + first * w), out.vp, n)
             assert max_ulp(D.down(out, np.float32, n), O.unary(op, dtype, base[first:first + n])) <= G.MAX_ULP, (first, n)
+
+
+def test_f32_min_max_reduction_orders_signed_zeros_and_ignores_nan(D):
+    """RedMinMaxF32 uses v_min_f32 / v_max_f32 directly: -0 < +0 in both directions and positions, NaN skipped unless all
+    NaN, +-inf ordered — bit-exact against the oracle"""
+    cases = [[0.0, -0.0], [-0.0, 0.0], [0.0] * 300 + [-0.0], [-0.0] * 300 + [0.0], [np.nan, -0.0, 0.0, np.nan], [np.nan] * 5,
+             [np.inf, -np.inf, np.nan, 0.0], [1e-45, -1e-45, 0.0, -0.0], [-0.0] * 70_000 + [0.0] + [-0.0] * 70_000]
+    for vals in cases:
+        x = np.array(vals, np.float32)
+        for op in (capi.RED_MIN, capi.RED_MAX):
+            out = D.empty(16)
+            D.call("agpu_reduce", op, capi.F32, D.up(x).vp, None, len(x), out.vp)
+            got = D.down(out, np.float32, 1)
+            exp = np.float32(O.reduce(op, O.F32, x))
+            assert got.view(np.uint32)[0] == exp.view(np.uint32) or (np.isnan(got[0]) and np.isnan(exp)), (vals[:4], op)
