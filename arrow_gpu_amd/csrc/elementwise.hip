@@ -290,29 +290,43 @@ __device__ __forceinline__ float log_f32_general(float x) {  // any operand: 0, 
 }
 
 // Positive normal finite x â€” what a wave of ordinary data consists of: ln x = (e + lc_j)Â·ln2 + log1p(u), u = mÂ·rc_j âˆ’ 1
-// (|u| < 2^-7, exact in f64), log1p(u) = u âˆ’ uÂ²/2 + uÂ³Â·q(u) with the cubic q in f32 â€” the table form of pow's logarithm:
+// (|u| < 2^-7, exact in f64), log1p(u) = u âˆ’ uÂ²/2 + uÂ³Â·q(u) with the quadratic q in f32 â€” the table form of pow's logarithm:
 // no division, no frexp, 11 f64-class instructions instead of 21 (the atanh form above is VALU-bound at 8 B/row:
 // 45 VALU instructions per row, 0.76 of the HBM roof).  â‰¤ 1 ULP like the general form (log2 to 2^-33 relative).
 __device__ __forceinline__ bool log_ordinary(float x) {
-  return (__builtin_bit_cast(uint32_t, x) - 0x00800000u) < 0x7f000000u;
+  return __builtin_amdgcn_classf(x, 0x100);  // +normal: one v_cmp_class_f32
+}
+// x = 2^e Â· m for a positive normal x, m âˆˆ [0.707, 1.414) as an f64 and j = the table interval of its mantissa.  Adding
+// (128 âˆ’ 53) << 16 carries into the exponent field exactly when j â‰¥ 53 (m â‰¥ 1.414 â†’ halved), so e, the "big" bit and
+// the exponent to strip from x all come out of ONE sum: 3 integer instructions + 2 conversions, where building the
+// f64 mantissa word by word took a compare, a select (a VCC round trip) and 6 more.
+struct MantSplit {
+  double m;
+  int e;
+  uint32_t j;
+};
+__device__ __forceinline__ MantSplit split_normal_f32(float x) {
+  const uint32_t xb = __builtin_bit_cast(uint32_t, x);
+  const uint32_t s = xb + (0x004b0000u - 0x3f800000u);
+  MantSplit r;
+  r.e = (int32_t)s >> 23;
+  r.m = (double)__builtin_bit_cast(float, xb - (s & 0xff800000u));
+  r.j = (xb >> 16) & 127u;
+  return r;
+}
+// log1p(u) âˆ’ u + uÂ²/2 = uÂ³Â·q(u) on |u| â‰¤ 2^-7: q as the degree-2 minimax polynomial (error 2^-39.6 relative to u;
+// tools/probe/poly_fit.py), evaluated in f32 â€” it weighs < 2^-15 of the sum
+__device__ __forceinline__ float log1p_q(float uf) {
+  float q = __builtin_fmaf(uf, 0x1.999f5p-3f, -0x1.0002p-2f);
+  return __builtin_fmaf(uf, q, 0x1.555556p-2f);
 }
 template <typename TabPtr>
 __device__ __forceinline__ float log_f32_fast(TabPtr tab, float x) {
-  const uint32_t xb = __builtin_bit_cast(uint32_t, x);
-  const uint32_t mant = xb & 0x007fffffu;
-  const uint32_t j = mant >> 16;
-  const bool big = j >= 53u;
-  const int e = (int)(xb >> 23) - 127 + (big ? 1 : 0);
-  const uint32_t mhi = (mant >> 3) | (big ? 0x3fe00000u : 0x3ff00000u);
-  const double m = __builtin_bit_cast(double, ((uint64_t)mhi << 32) | (uint64_t)(mant << 29));
-  const PowTab T = tab[j];
-  const double u = fma(m, T.rc, -1.0);
-  const float uf = (float)u;
-  float q = __builtin_fmaf(uf, -0x1.5555555555555p-3f, 0x1.999999999999ap-3f);  // âˆ’1/6, 1/5
-  q = __builtin_fmaf(uf, q, -0.25f);
-  q = __builtin_fmaf(uf, q, 0x1.5555555555555p-2f);  // 1/3
-  const double l1p = fma(u * u, fma(u, (double)q, -0.5), u);
-  return (float)fma((double)e + T.lc, 0x1.62e42fefa39efp-1, l1p);
+  const MantSplit sp = split_normal_f32(x);
+  const PowTab T = tab[sp.j];
+  const double u = fma(sp.m, T.rc, -1.0);
+  const double l1p = fma(u * u, fma(u, (double)log1p_q((float)u), -0.5), u);
+  return (float)fma((double)sp.e + T.lc, 0x1.62e42fefa39efp-1, l1p);
 }
 __device__ __forceinline__ float log_f32_dev(float x) {
   return log_ordinary(x) ? log_f32_fast(g_pow_tab, x) : log_f32_general(x);
@@ -522,9 +536,9 @@ static agpu_status launch_shift(agpu_pipeline* p, bool left, const void* a, cons
 // accuracy: f32 arithmetic cannot carry it, the f64 library pow runs at a quarter of the stream and the f32 library
 // powf (compensated f32) at 40 %.  Here: x = 2^e Â· m with m âˆˆ [0.707, 1.414); a 128-entry f64 table (LDS) gives
 // rc â‰ˆ 1/c and lc = âˆ’log2 rc for the centre c of m's interval, so u = mÂ·rc âˆ’ 1 is EXACT-ish (one fma) with |u| â‰¤ 2â»â· and
-//   log2 x = (e + lc) + log2e Â· (u âˆ’ uÂ²/2 + uÂ³Â·q(u)),   q = 1/3 âˆ’ u/4 + uÂ²/5 âˆ’ uÂ³/6 in f32 (weighs < 2â»Â¹âµ of the sum).
+//   log2 x = (e + lc) + log2e Â· (u âˆ’ uÂ²/2 + uÂ³Â·q(u)),   q â‰ˆ 1/3 âˆ’ u/4 + uÂ²/5 (minimax) in f32 (weighs < 2â»Â¹âµ of the sum).
 // The intervals touching 1 use rc = 1, lc = 0 exactly, so log2 x keeps its RELATIVE accuracy as x â†’ 1 (where y may be
-// 1e9).  Then w = yÂ·log2 x = k + r, 2^r = 1 + t + tÂ²Â·Q(t) with t = rÂ·ln2 and Q (1/2 â€¦ 1/9!) in f32 (weighs < 4 %),
+// 1e9).  Then w = yÂ·log2 x = k + r, 2^r = 1 + t + tÂ²Â·Q(t) with t = rÂ·ln2 and Q (degree-5 minimax of (e^t âˆ’ 1 âˆ’ t)/tÂ²) in f32 (weighs < 7 %),
 // v_ldexp_f64 by k (handles overflow / underflow / denormal results) and ONE rounding to f32.
 // Validated against f64 pow over 6 Ã— 4 M samples (generic, full exponent range, x â†’ 1 with huge y, denormal x,
 // |y| â‰¤ 60) in tools/probe/pow_emul.py and on the device in tests/test_gpu_parity.py.
@@ -545,6 +559,15 @@ __device__ __forceinline__ float pow_small_exponent(float x, float y) {  // y âˆ
   return y == 1.0f ? x : x * x;
 }
 
+// (e^t âˆ’ 1 âˆ’ t)/tÂ² on |t| â‰¤ ln2/2 as the degree-5 minimax polynomial (error 2^-32.5 of e^t; tools/probe/poly_fit.py), in f32:
+// tÂ²Â·Q weighs < 7 % of the result
+__device__ __forceinline__ float exp_q(float tf) {
+  float Q = __builtin_fmaf(tf, 0x1.a17e0cp-13f, 0x1.6d4328p-10f);
+  Q = __builtin_fmaf(tf, Q, 0x1.1110acp-7f);
+  Q = __builtin_fmaf(tf, Q, 0x1.5554eap-5f);
+  Q = __builtin_fmaf(tf, Q, 0x1.555556p-3f);
+  return __builtin_fmaf(tf, Q, 0.5f);
+}
 template <typename TabPtr>
 __device__ __forceinline__ float pow_f32_general(TabPtr tab, float x, float y) {  // any operands: specials, denormal x, huge |y|
   const uint64_t bits = __builtin_bit_cast(uint64_t, (double)x);
@@ -556,27 +579,15 @@ __device__ __forceinline__ float pow_f32_general(TabPtr tab, float x, float y) {
   const double m = __builtin_bit_cast(double, ((uint64_t)mhi << 32) | (uint64_t)(uint32_t)bits);
   const PowTab T = tab[j];
   const double u = fma(m, T.rc, -1.0);
-  const float uf = (float)u;
-  float q = __builtin_fmaf(uf, -0x1.5555555555555p-3f, 0x1.999999999999ap-3f);  // âˆ’1/6, 1/5
-  q = __builtin_fmaf(uf, q, -0.25f);
-  q = __builtin_fmaf(uf, q, 0x1.5555555555555p-2f);  // 1/3
   const double u2 = u * u;
-  const double l1p = fma(u2, fma(u, (double)q, -0.5), u);  // u âˆ’ uÂ²/2 + uÂ³Â·q, one f64 multiply less than the expanded form
+  const double l1p = fma(u2, fma(u, (double)log1p_q((float)u), -0.5), u);  // u âˆ’ uÂ²/2 + uÂ³Â·q, one f64 multiply less than the expanded form
   const double L = fma(l1p, 0x1.71547652b82fep+0, (double)e + T.lc);
   double w = (double)y * L;
   w = w < 2000.0 ? w : 2000.0;  // keeps k inside v_ldexp's range; NaN cannot occur here (specials handled below)
   w = w > -2000.0 ? w : -2000.0;
   const double kd = rint(w);
   const double t = (w - kd) * 0x1.62e42fefa39efp-1;
-  const float tf = (float)t;
-  float Q = __builtin_fmaf(tf, 0x1.71de3a556c734p-19f, 0x1.a01a01a01a01ap-16f);  // 1/9!, 1/8!
-  Q = __builtin_fmaf(tf, Q, 0x1.a01a01a01a01ap-13f);                             // 1/7!
-  Q = __builtin_fmaf(tf, Q, 0x1.6c16c16c16c17p-10f);                             // 1/6!
-  Q = __builtin_fmaf(tf, Q, 0x1.1111111111111p-7f);                              // 1/5!
-  Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-5f);                              // 1/4!
-  Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-3f);                              // 1/3!
-  Q = __builtin_fmaf(tf, Q, 0.5f);
-  const double pw = fma(t, fma(t, (double)Q, 1.0), 1.0);  // 1 + t + tÂ²Â·Q as two fmas
+  const double pw = fma(t, fma(t, (double)exp_q((float)t), 1.0), 1.0);  // 1 + t + tÂ²Â·Q as two fmas
   float r = (float)ldexp(pw, (int)kd);
   // Specials, IEEE pow restricted to the reference's domain [math/src/f32.rs:209-271]: negative or NaN base â†’ NaN.
   // The main path is already right for y == 0 and x == 1 with finite operands (w = 0 â‡’ 1) and for denormal x; the
@@ -597,39 +608,19 @@ __device__ __forceinline__ float pow_f32_general(TabPtr tab, float x, float y) {
 // yÂ·log2(x) (|w| < 2^28: v_ldexp_f64 saturates to 0 / inf by itself) and no special-case selects; the general form sits
 // behind a branch such waves never take.  Same table, same polynomials, same roundings: identical bits.
 __device__ __forceinline__ bool pow_ordinary(float x, float y) {  // x positive normal finite, |y| < 2^20
-  const uint32_t xb = __builtin_bit_cast(uint32_t, x), yb = __builtin_bit_cast(uint32_t, y);
-  return (xb - 0x00800000u) < 0x7f000000u && (yb & 0x7fffffffu) < 0x49800000u;
+  return __builtin_amdgcn_classf(x, 0x100) && __builtin_fabsf(y) < 0x1p20f;  // v_cmp_class_f32 + v_cmp_lt_f32 |y| (false for NaN)
 }
 template <typename TabPtr>
 __device__ __forceinline__ float pow_f32_fast(TabPtr tab, float x, float y) {  // requires pow_ordinary(x, y)
-  const uint32_t xb = __builtin_bit_cast(uint32_t, x);
-  const uint32_t mant = xb & 0x007fffffu;
-  const uint32_t j = mant >> 16;
-  const bool big = j >= 53u;
-  const int e = (int)(xb >> 23) - 127 + (big ? 1 : 0);
-  const uint32_t mhi = (mant >> 3) | (big ? 0x3fe00000u : 0x3ff00000u);
-  const double m = __builtin_bit_cast(double, ((uint64_t)mhi << 32) | (uint64_t)(mant << 29));
-  const PowTab T = tab[j];
-  const double u = fma(m, T.rc, -1.0);
-  const float uf = (float)u;
-  float q = __builtin_fmaf(uf, -0x1.5555555555555p-3f, 0x1.999999999999ap-3f);  // âˆ’1/6, 1/5
-  q = __builtin_fmaf(uf, q, -0.25f);
-  q = __builtin_fmaf(uf, q, 0x1.5555555555555p-2f);  // 1/3
-  const double u2 = u * u;
-  const double l1p = fma(u2, fma(u, (double)q, -0.5), u);
-  const double L = fma(l1p, 0x1.71547652b82fep+0, (double)e + T.lc);
+  const MantSplit sp = split_normal_f32(x);
+  const PowTab T = tab[sp.j];
+  const double u = fma(sp.m, T.rc, -1.0);
+  const double l1p = fma(u * u, fma(u, (double)log1p_q((float)u), -0.5), u);
+  const double L = fma(l1p, 0x1.71547652b82fep+0, (double)sp.e + T.lc);
   const double w = (double)y * L;
   const double kd = rint(w);
   const double t = (w - kd) * 0x1.62e42fefa39efp-1;
-  const float tf = (float)t;
-  float Q = __builtin_fmaf(tf, 0x1.71de3a556c734p-19f, 0x1.a01a01a01a01ap-16f);  // 1/9!, 1/8!
-  Q = __builtin_fmaf(tf, Q, 0x1.a01a01a01a01ap-13f);                             // 1/7!
-  Q = __builtin_fmaf(tf, Q, 0x1.6c16c16c16c17p-10f);                             // 1/6!
-  Q = __builtin_fmaf(tf, Q, 0x1.1111111111111p-7f);                              // 1/5!
-  Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-5f);                              // 1/4!
-  Q = __builtin_fmaf(tf, Q, 0x1.5555555555555p-3f);                              // 1/3!
-  Q = __builtin_fmaf(tf, Q, 0.5f);
-  const double pw = fma(t, fma(t, (double)Q, 1.0), 1.0);
+  const double pw = fma(t, fma(t, (double)exp_q((float)t), 1.0), 1.0);
   return (float)ldexp(pw, (int)kd);
 }
 // per-element dispatch (tail rows, fused chains); the tile kernel below votes once per wave instead
@@ -641,7 +632,12 @@ __device__ __forceinline__ float pow_f32_dev(TabPtr tab, float x, float y) {
 #ifndef AGPU_POW_VOTE
 #define AGPU_POW_VOTE 1
 #endif
-#define AGPU_POW_U 2
+// Tile shape of the two LDS-table kernels (pow, log), swept on one box at 1e9 rows (tools/probe/pow_shape.py,
+// profiles/r02_pow_shape.txt): ONE pack per lane and ONE tile per block â€” pow 0.68 â†’ 0.81 of the HBM roof, log 0.70 â†’ 0.78.
+// The arithmetic was never the bound (the same kernel with the stores disabled and the loads skipped: 1.05 ms; with
+// the arithmetic replaced by an add: the full 2.15 ms): a block that loops over tiles, or carries 8 rows per lane,
+// spends its waves in long compute phases with nothing in flight, and the one-tile form hands that to the dispatcher.
+#define AGPU_POW_U 1
 template <int MODE>
 __global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const float* b, float* out, uint64_t ntiles,
                                                         const PowTab* gtab) {
@@ -741,7 +737,7 @@ static agpu_status launch_pow_f32(agpu_pipeline* p, const void* a, const void* b
 }
 
 // f32 log: the same tile shape as pow_kernel (256-thread workgroups, the 2 KiB table staged in LDS once per workgroup,
-// 2 packs per lane in flight, one vote per wave and tile between the table form and the general form).
+// one pack per lane, one vote per wave and tile between the table form and the general form).
 __global__ __launch_bounds__(AGPU_BLOCK) void log_kernel(const float* a, float* out, uint64_t ntiles, const PowTab* gtab) {
   constexpr int U = AGPU_POW_U;
   constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;

@@ -31,7 +31,8 @@ void agpu_set_error(const char* fmt, ...) {
 // Plain atomics: agpu_set_tuning may be called from any thread; a pipeline snapshots them when it is created.
 static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
     /*stream_grid*/ {0}, /*stream_bpc*/ {0}, /*stream_unroll*/ {1}, /*stream_nt*/ {1}, /*cmp_variant*/ {0}, /*reduce_grid*/ {0},
-    /*table_tiles*/ {4},  // profiles/r01_sweep_table_tiles.json: sin_u8 5.74 → 6.02, sin_u16 5.85 → 6.16 TB/s vs 1 tile per block
+    /*table_tiles*/ {1},  // round 1's kernels liked 4 (profiles/r01_sweep_table_tiles.json); the wave-transposed lut8 / trig16 and
+                          // pow / log are all best at ONE tile per block (profiles/r02_pow_shape.txt: pow 0.69 → 0.75 at U = 2, sin_u8 0.70 → 0.73)
     /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}, /*gather_offsets*/ {0}};
 static std::atomic<int64_t> g_mem_pool{1};  // 1 = recycle device blocks and idle streams (default), 0 = hipMalloc/hipFree every time
 static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "stream_bpc", "stream_unroll", "stream_nt",

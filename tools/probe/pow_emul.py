@@ -24,7 +24,7 @@ def powm(x,y):
     u=m*RC[j]-1.0   # fma exact-ish; emulate: m*RC has rounding. use higher precision
     u=(m.astype(np.longdouble)*RC[j].astype(np.longdouble)-1).astype(D)
     uf=u.astype(F)
-    q3=uf*F(-1/6)+F(1/5); q3=uf*q3+F(-0.25); q3=uf*q3+F(1/3)
+    q3=uf*F(float.fromhex('0x1.999f5p-3'))+F(float.fromhex('-0x1.0002p-2')); q3=uf*q3+F(float.fromhex('0x1.555556p-2'))  # log1p_q
     u2=u*u
     t=u2*(-0.5)+u
     l1p=(u2*u)*q3.astype(D)+t
@@ -32,9 +32,9 @@ def powm(x,y):
     w=np.clip(yd*L,-2000,2000)
     kd=np.rint(w); r=w-kd
     tt=r*LN2; z=tt*tt; tf=tt.astype(F)
-    q=F(1/362880)
-    for c in (1/40320,1/5040,1/720,1/120,1/24,1/6,0.5):
-        q=tf*q+F(c)
+    q=F(float.fromhex('0x1.a17e0cp-13'))  # exp_q: degree-5 minimax (tools/probe/poly_fit.py)
+    for c in ('0x1.6d4328p-10','0x1.1110acp-7','0x1.5554eap-5','0x1.555556p-3','0x1p-1'):
+        q=tf*q+F(float.fromhex(c))
     p=z*q.astype(D)+(1.0+tt)
     with np.errstate(over='ignore',under='ignore'):
         res=np.ldexp(p,kd.astype(np.int64)).astype(F)
