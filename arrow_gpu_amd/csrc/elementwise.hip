@@ -382,11 +382,11 @@ struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { ret
 // sweep in profiles/r01_sweep_add_eq_1e9_b.json (6.7 TB/s vs 6.4 at 256 threads, ≤5.9 persistent).
 #define AGPU_EW_BLOCK 64
 
-template <typename T, typename Op, int MODE, int U, int NT>
-__global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_kernel(const T* a, const T* b, T* out, uint64_t ntiles) {
+template <typename T, typename Op, int MODE, int U, int NT, int BLK = AGPU_EW_BLOCK>
+__global__ __launch_bounds__(BLK) void ew_kernel(const T* a, const T* b, T* out, uint64_t ntiles) {
   constexpr int N = 16 / sizeof(T);
   constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0, XCD = (NT & 4) != 0;
-  constexpr uint64_t tile = (uint64_t)AGPU_EW_BLOCK * U;
+  constexpr uint64_t tile = (uint64_t)BLK * U;
   T sv = T();
   if constexpr (MODE == MODE_SCALAR) sv = b[0];
 
@@ -399,14 +399,14 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_kernel(const T* a, const T* 
     const uint64_t p0 = t * tile + threadIdx.x;
     PackN<T, N> va[U], vb[U];
     static_for<U>([&](auto u) {
-      va[u] = load_pack<NTL, T, N>(a + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N);
-      if constexpr (MODE == MODE_BINARY) vb[u] = load_pack<NTL, T, N>(b + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N);
+      va[u] = load_pack<NTL, T, N>(a + (p0 + (uint64_t)u * BLK) * N);
+      if constexpr (MODE == MODE_BINARY) vb[u] = load_pack<NTL, T, N>(b + (p0 + (uint64_t)u * BLK) * N);
     });
     static_for<U>([&](auto u) {
       PackN<T, N> r;
 #pragma unroll
       for (int k = 0; k < N; k++) r.v[k] = Op::ap(va[u].v[k], MODE == MODE_BINARY ? vb[u].v[k] : sv);
-      store_pack<NTS, T, N>(out + (p0 + (uint64_t)u * AGPU_EW_BLOCK) * N, r);
+      store_pack<NTS, T, N>(out + (p0 + (uint64_t)u * BLK) * N, r);
     });
   }
 }
@@ -443,6 +443,9 @@ template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };
+// Threads per block: one wave for everything.  (The LDS-table kernels pow / log run best at 256 threads × 1 pack, but
+// sin / cos / sinh lose 4–10 % in that shape and 5 % at 64 × 1: tools/probe/heavy_shape.py, profiles/r02_heavy_shape.txt.)
+template <typename Op> struct EwBlock { static constexpr int value = AGPU_EW_BLOCK; };
 
 template <typename T, typename Op, int MODE>
 static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, void* out, uint64_t n) {
@@ -457,7 +460,8 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
     // dependent f64 chains better with 2–4 independent rows of work per lane (A/B on one box at 1e9 rows: sin/cos/log
     // 5.9 → 6.25 TB/s at U = 2, sinh 5.95 → 6.44 at U = 4, while add_scalar/neg/exp LOSE 10 % at U = 2)
     constexpr int U = EwUnroll<Op>::value;
-    constexpr uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * U * N;
+    constexpr int BLK = EwBlock<Op>::value;
+    constexpr uint64_t tile_rows = (uint64_t)BLK * U * N;
     const uint64_t ntiles = n / tile_rows;
     if (ntiles) {
       const int grid = stream_grid_for(p, ntiles);
@@ -469,10 +473,10 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
       const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(out) |
                              (MODE == MODE_BINARY ? reinterpret_cast<uintptr_t>(b) : 0);
       if ((bits & 127u) == 0)
-        hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, AGPU_STREAM_NT>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pa, pb,
+        hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, AGPU_STREAM_NT, BLK>), dim3(grid), dim3(BLK), 0, p->stream, pa, pb,
                            po, ntiles);
       else
-        hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, 4>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pa, pb, po, ntiles);
+        hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, 4, BLK>), dim3(grid), dim3(BLK), 0, p->stream, pa, pb, po, ntiles);
     }
     if (ntiles * tile_rows < n)
       hipLaunchKernelGGL((ew_tail_kernel<T, Op, MODE>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
@@ -761,12 +765,14 @@ __global__ __launch_bounds__(AGPU_BLOCK) void log_kernel(const float* a, float* 
         const f32x4 r = f32x4{log_f32_fast(tab, xa[u].x), log_f32_fast(tab, xa[u].y), log_f32_fast(tab, xa[u].z), log_f32_fast(tab, xa[u].w)};
         __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
       });
-    } else {  // per element: the table form where it applies (same bits as above), the general form elsewhere
+    } else {  // the table form for every lane (same bits as above; harmless on any bit pattern), then the general form
+              // over the lanes it does not apply to — negatives, NaN, 0 and inf leave that on its first branch
       static_for<U>([&](auto u) {
-        const f32x4 r = f32x4{log_ordinary(xa[u].x) ? log_f32_fast(tab, xa[u].x) : log_f32_general(xa[u].x),
-                              log_ordinary(xa[u].y) ? log_f32_fast(tab, xa[u].y) : log_f32_general(xa[u].y),
-                              log_ordinary(xa[u].z) ? log_f32_fast(tab, xa[u].z) : log_f32_general(xa[u].z),
-                              log_ordinary(xa[u].w) ? log_f32_fast(tab, xa[u].w) : log_f32_general(xa[u].w)};
+        f32x4 r = f32x4{log_f32_fast(tab, xa[u].x), log_f32_fast(tab, xa[u].y), log_f32_fast(tab, xa[u].z), log_f32_fast(tab, xa[u].w)};
+        if (!log_ordinary(xa[u].x)) r.x = log_f32_general(xa[u].x);
+        if (!log_ordinary(xa[u].y)) r.y = log_f32_general(xa[u].y);
+        if (!log_ordinary(xa[u].z)) r.z = log_f32_general(xa[u].z);
+        if (!log_ordinary(xa[u].w)) r.w = log_f32_general(xa[u].w);
         __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
       });
     }

@@ -31,12 +31,16 @@ def main():
     vp = lambda b, off=0: C.c_void_p(b.ptr + off)  # noqa: E731
     nb = (n + 63) // 64 * 8
     # one table: the buffers come out of one block, placed for the HBM channel hash (agpu_malloc_table)
-    A, B, O, VA, VB, OB, OV, M = dev.create_table_buffers([4 * n] * 3 + [nb] * 5)
+    # (two tables, like bench.py: the value columns of the arithmetic rows, and the compare rows' columns with their bitmaps)
+    A, B, O, M = dev.create_table_buffers([4 * n] * 3 + [nb])
+    IA, IB, VA, VB, OB, OV = dev.create_table_buffers([4 * n] * 2 + [nb] * 4)
     R = dev.create_empty_buffer(64)
     S = dev.create_gpu_buffer_with_data(np.array([3.0], np.float32))
     SI = dev.create_gpu_buffer_with_data(np.array([3], np.int32))
     capi.call("agpu_synth_f32", h, vp(A), n, 1, 0, C.c_float(-1000), C.c_float(1000))
     capi.call("agpu_synth_f32", h, vp(B), n, 2, 0, C.c_float(-1000), C.c_float(1000))
+    capi.call("agpu_copy", h, vp(IA), vp(A), 4 * n)
+    capi.call("agpu_copy", h, vp(IB), vp(B), 4 * n)
     for buf, seed in ((VA, 3), (VB, 4), (M, 5)):
         capi.call("agpu_synth_bits", h, vp(buf), n, seed, 0, C.c_double(0.9 if buf is not M else 0.5))
     p.sync()
@@ -78,9 +82,9 @@ def main():
     t("f32 power", 12, lambda: capi.call("agpu_binary", h, capi.OP_POW, F32, vp(A), vp(B), vp(O), n))
     for name, op in (("eq", capi.CMP_EQ), ("lt", capi.CMP_LT), ("gt", capi.CMP_GT)):
         t(f"i32 {name} → bitmap + validity AND (fused)", 8.5,
-          lambda op=op: capi.call("agpu_compare_validity", h, op, I32, vp(A), vp(B), vp(VA), vp(VB), vp(OB), vp(OV), n))
-    t("i32 eq → bitmap (no validity)", 8.125, lambda: capi.call("agpu_compare", h, capi.CMP_EQ, I32, vp(A), vp(B), vp(OB), n))
-    t("f32 lt → bitmap", 8.125, lambda: capi.call("agpu_compare", h, capi.CMP_LT, F32, vp(A), vp(B), vp(OB), n))
+          lambda op=op: capi.call("agpu_compare_validity", h, op, I32, vp(IA), vp(IB), vp(VA), vp(VB), vp(OB), vp(OV), n))
+    t("i32 eq → bitmap (no validity)", 8.125, lambda: capi.call("agpu_compare", h, capi.CMP_EQ, I32, vp(IA), vp(IB), vp(OB), n))
+    t("f32 lt → bitmap", 8.125, lambda: capi.call("agpu_compare", h, capi.CMP_LT, F32, vp(IA), vp(IB), vp(OB), n))
     t("u8 eq → bitmap (vector variant)", 2.125, lambda: capi.call("agpu_compare", h, capi.CMP_EQ, U8, vp(A), vp(B), vp(OB), n))
     LAT = "launch-latency-bound: 125 MB per bitmap, the whole launch lasts 20–60 us"
     t("validity AND (bitmap)", 0.375, lambda: capi.call("agpu_bitmap_binary", h, capi.OP_AND, vp(VA), vp(VB), vp(OV), n), note=LAT)
