@@ -369,6 +369,50 @@ def test_cos_fullsize_u8_f32_and_cast_then_cos(ctx):
         assert np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64)).max() <= 1
 
 
+def test_pow_log_fullsize_windows_and_slice_consistency(ctx):
+    """The two LDS-table kernels at 1e9 rows: f32 pow (array ∘ array) and log against oracle windows (≤ 1 ULP, NaN for NaN),
+    log over a column that is half negative (mixed waves: table form + general form in one wave), and the whole column's
+    result bit-identical to the same column processed as two slices split at a row that is no tile boundary."""
+    dev, p = ctx
+    h = p._handle
+    x, y, o, o2 = (dev.create_empty_buffer(4 * N) for _ in range(4))
+    cs1, cs2 = dev.create_empty_buffer(16), dev.create_empty_buffer(16)
+    capi.call("agpu_synth_f32", h, vp(x), N, SEED + 11, 0, C.c_float(0.001), C.c_float(1000.0))
+    capi.call("agpu_synth_f32", h, vp(y), N, SEED + 12, 0, C.c_float(-8.0), C.c_float(8.0))
+
+    def ulps(got, exp):
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        ok = ~np.isnan(exp)
+        return int(np.abs(got.view(np.int32).astype(np.int64)[ok] - exp.view(np.int32).astype(np.int64)[ok]).max())
+
+    capi.call("agpu_binary", h, capi.OP_POW, capi.F32, vp(x), vp(y), vp(o), N)
+    for start in windows(N):
+        got = download(dev, p, o, 4 * start, 4 * WINDOW).view(np.float32)
+        exp = O.binary(O.OP_POW, O.F32, O.synth_f32(WINDOW, SEED + 11, start, 0.001, 1000.0), O.synth_f32(WINDOW, SEED + 12, start, -8.0, 8.0))
+        assert ulps(got, exp) <= 1
+    split = (N // 3) // 4 * 4 + 4 * 37          # 16-byte aligned, not a multiple of the 1024-row tile
+    capi.call("agpu_binary", h, capi.OP_POW, capi.F32, vp(x), vp(y), vp(o2), split)
+    capi.call("agpu_binary", h, capi.OP_POW, capi.F32, vp(x, 4 * split), vp(y, 4 * split), vp(o2, 4 * split), N - split)
+    capi.call("agpu_checksum", h, vp(o), 4 * N, vp(cs1))
+    capi.call("agpu_checksum", h, vp(o2), 4 * N, vp(cs2))
+    assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
+
+    capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(x), vp(o), N)
+    for start in windows(N):
+        got = download(dev, p, o, 4 * start, 4 * WINDOW).view(np.float32)
+        assert ulps(got, O.unary(O.UN_LOG, O.F32, O.synth_f32(WINDOW, SEED + 11, start, 0.001, 1000.0))) <= 1
+    capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(y), vp(o), N)   # half the rows negative → NaN
+    for start in windows(N):
+        got = download(dev, p, o, 4 * start, 4 * WINDOW).view(np.float32)
+        exp = O.unary(O.UN_LOG, O.F32, O.synth_f32(WINDOW, SEED + 12, start, -8.0, 8.0))
+        assert ulps(got, exp) <= 1 and np.isnan(exp).any() and not np.isnan(exp).all()
+    capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(y), vp(o2), split)
+    capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(y, 4 * split), vp(o2, 4 * split), N - split)
+    capi.call("agpu_checksum", h, vp(o), 4 * N, vp(cs1))
+    capi.call("agpu_checksum", h, vp(o2), 4 * N, vp(cs2))
+    assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2)
+
+
 def test_f32_to_small_int_casts_fullsize(ctx):
     """The reference-absent narrowing casts (f32 → i8 / i16 / u16) at 1e9 rows: windows bit-exact vs the oracle and the
     round trip i16 → f32 → i16 is the identity."""
