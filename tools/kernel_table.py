@@ -39,7 +39,7 @@ def main():
     SI = dev.create_gpu_buffer_with_data(np.array([3], np.int32))
     capi.call("agpu_synth_f32", h, vp(A), n, 1, 0, C.c_float(-1000), C.c_float(1000))
     capi.call("agpu_synth_f32", h, vp(B), n, 2, 0, C.c_float(-1000), C.c_float(1000))
-    capi.call("agpu_copy", h, vp(IA), vp(A), 4 * n)
+    capi.call("agpu_unary", h, capi.UN_ABS, capi.F32, vp(A), vp(IA), n)  # |a|: the compare rows do not care, log wants a positive column
     capi.call("agpu_copy", h, vp(IB), vp(B), 4 * n)
     for buf, seed in ((VA, 3), (VB, 4), (M, 5)):
         capi.call("agpu_synth_bits", h, vp(buf), n, seed, 0, C.c_double(0.9 if buf is not M else 0.5))
@@ -78,7 +78,10 @@ def main():
     t("f32 rem_scalar", 8, lambda: capi.call("agpu_scalar", h, capi.OP_REM, F32, vp(A), vp(S), vp(O), n))
     for name, op in (("neg", capi.UN_NEG), ("abs", capi.UN_ABS), ("sqrt", capi.UN_SQRT), ("sin", capi.UN_SIN), ("cos", capi.UN_COS),
                      ("exp", capi.UN_EXP), ("log", capi.UN_LOG), ("sinh", capi.UN_SINH), ("cbrt", capi.UN_CBRT), ("acos", capi.UN_ACOS)):
-        t(f"f32 {name}", 8, lambda op=op: capi.call("agpu_unary", h, op, F32, vp(A), vp(O), n))
+        t(f"f32 {name}", 8, lambda op=op: capi.call("agpu_unary", h, op, F32, vp(IA if name == "log" else A), vp(O), n),
+          note="positive column" if name == "log" else "")
+    t("f32 log, half the column negative (NaN rows)", 8, lambda: capi.call("agpu_unary", h, capi.UN_LOG, F32, vp(A), vp(O), n),
+      note="mixed waves: table form for every lane + general form over the rest")
     t("f32 power", 12, lambda: capi.call("agpu_binary", h, capi.OP_POW, F32, vp(A), vp(B), vp(O), n))
     for name, op in (("eq", capi.CMP_EQ), ("lt", capi.CMP_LT), ("gt", capi.CMP_GT)):
         t(f"i32 {name} → bitmap + validity AND (fused)", 8.5,

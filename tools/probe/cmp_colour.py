@@ -19,6 +19,7 @@ q = CmpQuery(dev)
 h = p._handle
 G, K = 1 << 30, 1 << 10
 n = 1_000_000_000
+pre = dev.create_table_buffers([4 * n] * 3) if "--quick" in sys.argv else None  # what bench.py allocates before its compare table
 big = dev.create_empty_buffer(14 * G)
 base = big.ptr
 capi.call("agpu_synth_i32", h, C.c_void_p(base), 3 * G, 1, 0, 1024)
@@ -37,7 +38,8 @@ def t(f, reps=10):
 
 
 rows = []
-for variant, unroll in ((0, 1), (1, 1), (1, 2), (1, 4)):
+QUICK = "--quick" in sys.argv  # the default variant only: is the best colour the same in every process / on every box?
+for variant, unroll in (((0, 1),) if QUICK else ((0, 1), (1, 1), (1, 2), (1, 4))):
     for k1 in (0, 1, 2, 3, 4, 8, 16, 64, 0):
         p.set_tuning("cmp_variant", variant)
         p.set_tuning("stream_unroll", unroll)
@@ -47,4 +49,5 @@ for variant, unroll in ((0, 1), (1, 1), (1, 2), (1, 4)):
         rows.append(r)
         print(json.dumps(r), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump({"what": __doc__, "rows": rows}, open(os.path.join(ROOT, "gpurun_out", "cmp_colour.json"), "w"), indent=1)
+if not QUICK:
+    json.dump({"what": __doc__, "rows": rows}, open(os.path.join(ROOT, "gpurun_out", "cmp_colour.json"), "w"), indent=1)
