@@ -1281,16 +1281,18 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
   return AGPU_OK;
 }
 
-// bool bitmap → f32 [cast/compute_shaders/boolean/cast_f32.wgsl:9-20]: lane expands 4 bits into one nontemporal
-// 16-byte store, 4 stores per lane per one-wave block (a pure store stream: with one store per block the launch is
-// bound by block dispatch, ≈4.7 G blocks/s, not by HBM)
-#define AGPU_B2F_U 4
-__global__ __launch_bounds__(AGPU_EW_BLOCK) void bool_to_f32_kernel(const uint32_t* bits, float* out, uint64_t n) {
+// bool bitmap → f32 [cast/compute_shaders/boolean/cast_f32.wgsl:9-20]: a lane expands 4 bits into ONE nontemporal
+// 16-byte store; 256-thread blocks, one store per lane.  A store stream is sensitive to its shape like nothing else
+// (tools/probe/store_probe.hip, profiles/r02_store_probe.txt, write-only / with this kernel's bitmap load in front):
+// 256 × 1 store 0.85 / 0.85 of the roof, one wave × 4 stores 0.81 / 0.76 (the round-2 shape), 256 × 4 0.74, one wave × 1
+// 0.60 (block dispatch), and 256 × 1 with a PLAIN store behind the load 0.57.
+#define AGPU_B2F_U 1
+__global__ __launch_bounds__(AGPU_BLOCK) void bool_to_f32_kernel(const uint32_t* bits, float* out, uint64_t n) {
   const uint64_t npacks = n / 4;
-  constexpr uint64_t TILE = (uint64_t)AGPU_EW_BLOCK * AGPU_B2F_U;
+  constexpr uint64_t TILE = (uint64_t)AGPU_BLOCK * AGPU_B2F_U;
   for (uint64_t t = blockIdx.x; t * TILE < npacks; t += gridDim.x) {
     static_for<AGPU_B2F_U>([&](auto u) {
-      const uint64_t pk = t * TILE + (uint64_t)u * AGPU_EW_BLOCK + threadIdx.x;
+      const uint64_t pk = t * TILE + (uint64_t)u * AGPU_BLOCK + threadIdx.x;
       if (pk < npacks) {
         const uint32_t w = bits[pk >> 3] >> ((pk & 7) * 4);
         f32x4 r = {(w & 1) ? 1.0f : 0.0f, (w & 2) ? 1.0f : 0.0f, (w & 4) ? 1.0f : 0.0f, (w & 8) ? 1.0f : 0.0f};
@@ -1775,8 +1777,8 @@ agpu_status agpu_cast(agpu_pipeline* p, agpu_dtype from, agpu_dtype to, const vo
   if (from == AGPU_BOOL && to == AGPU_F32) {
     if (n == 0) return AGPU_OK;
     AGPU_REQUIRE(aligned_to(in, 4) && aligned16(out), AGPU_ERR_SHAPE, "bool→f32 needs 4-byte aligned bits and 16-byte aligned output");
-    const int grid = stream_grid_for(p, (n / 4 + AGPU_EW_BLOCK * AGPU_B2F_U - 1) / (AGPU_EW_BLOCK * AGPU_B2F_U));
-    hipLaunchKernelGGL(bool_to_f32_kernel, dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream,
+    const int grid = stream_grid_for(p, (n / 4 + AGPU_BLOCK * AGPU_B2F_U - 1) / (AGPU_BLOCK * AGPU_B2F_U));
+    hipLaunchKernelGGL(bool_to_f32_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
                        static_cast<const uint32_t*>(in), static_cast<float*>(out), n);
     AGPU_LAUNCH_CHECK();
     return AGPU_OK;
