@@ -445,7 +445,10 @@ template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };
 // Threads per block: one wave for everything.  (The LDS-table kernels pow / log run best at 256 threads × 1 pack, but
 // sin / cos / sinh lose 4–10 % in that shape and 5 % at 64 × 1: tools/probe/heavy_shape.py, profiles/r02_heavy_shape.txt.)
-template <typename Op> struct EwBlock { static constexpr int value = AGPU_EW_BLOCK; };
+#ifndef AGPU_EW_DEFAULT_BLK
+#define AGPU_EW_DEFAULT_BLK AGPU_EW_BLOCK
+#endif
+template <typename Op> struct EwBlock { static constexpr int value = AGPU_EW_DEFAULT_BLK; };
 
 template <typename T, typename Op, int MODE>
 static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, void* out, uint64_t n) {

@@ -34,6 +34,18 @@ __global__ __launch_bounds__(BLOCK) void store_kernel(const uint32_t* bits, f32x
       const uint32_t w = bits[pk];  // the same 4 rows per pack through a cached load
       r = f32x4{(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24)};
     }
+    if constexpr (LOAD == 4) {  // 16 lanes of the wave load 16 bytes each (the wave's 256 rows), 4 ds_bpermute spread the dwords
+      typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+      const uint32_t lane = threadIdx.x & 63u;
+      u32x4_ v = {0, 0, 0, 0};
+      if (lane < 16) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_*>(bits) + (pk >> 6) * 16 + lane);
+      const int src = (int)((lane >> 2) * 4);
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.x), w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.y);
+      const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.z), w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.w);
+      const uint32_t sel = lane & 3u;
+      const uint32_t w = sel == 0 ? w0 : sel == 1 ? w1 : sel == 2 ? w2 : w3;
+      r = f32x4{(float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24)};
+    }
     if constexpr (NT) __builtin_nontemporal_store(r, out + pk);
     else out[pk] = r;
   }
@@ -76,6 +88,7 @@ int main() {
     RUN(256, 1, false, 0) RUN(256, 1, true, 0) RUN(64, 1, true, 0) RUN(64, 4, true, 0) RUN(64, 4, false, 0) RUN(256, 4, true, 0)
     RUN(64, 4, true, 1) RUN(64, 4, false, 1) RUN(256, 1, true, 1) RUN(256, 1, false, 1) RUN(64, 1, true, 1) RUN(64, 2, true, 1) RUN(128, 2, true, 1)
     RUN(64, 4, true, 2) RUN(256, 1, true, 2) RUN(256, 1, false, 2) RUN(64, 1, true, 2) RUN(64, 2, true, 2)
+    RUN(256, 1, true, 4) RUN(128, 1, true, 4) RUN(64, 1, true, 4) RUN(256, 2, true, 4) RUN(64, 4, true, 4)
     RUN(256, 1, true, 3) RUN(128, 1, true, 3) RUN(128, 2, true, 3) RUN(64, 4, true, 3) RUN(256, 2, true, 3)
   }
   for (const Row& r : rows) printf("%-46s %.4f ms  %.3f of 8 TB/s (4 B/row written)\n", r.name, r.ms, 4.0 * n / r.ms / 8e9);
