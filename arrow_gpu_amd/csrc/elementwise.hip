@@ -1740,7 +1740,7 @@ agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, con
         case AGPU_UN_CBRT: UN_F32(UnCbrt);
         case AGPU_UN_EXP: UN_F32(UnExp);
         case AGPU_UN_EXP2: UN_F32(UnExp2);
-        case AGPU_UN_LOG: return launch_log_f32(p, in, out, n);
+        case AGPU_UN_LOG: return launch_log_f32(p, in, out, n);  // (through ew_kernel with the table in global memory: 0.63 against 0.80)
         case AGPU_UN_LOG2: UN_F32(UnLog2);
         case AGPU_UN_SIN: UN_F32(UnSin);
         case AGPU_UN_COS: UN_F32(UnCos);
