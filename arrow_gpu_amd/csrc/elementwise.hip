@@ -226,14 +226,16 @@ struct UnPopc {  // countOneBits per element [logical/compute_shaders/u32/countb
 __device__ __attribute__((noinline)) float sincos_f32_slow(float x, int want_cos) {
   return (float)(want_cos ? cos((double)x) : sin((double)x));
 }
-__device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
-  if (!(fabsf(x) < 1.0e6f)) return sincos_f32_slow(x, want_cos);
+// k = round(x · 2/π) by the 1.5·2^52 trick: ONE fma rounds the exact product to an integer (no double rounding), the low
+// word of the sum IS k (no v_cvt_i32_f64), and kd = s − M is +0.0 for every |x| < π/4, so r = x exactly there, −0.0
+// included (round 1 paid a 64-bit compare and two selects for that): 6 instructions → 2.
+__device__ __forceinline__ float sincos_f32_fast(float x, int want_cos) {  // meaningful for |x| < 1e6, harmless elsewhere
   const double xd = (double)x;
-  const double kd = rint(xd * 0x1.45f306dc9c883p-1);  // x · 2/π
-  const int k = (int)kd;
+  const double sh = fma(xd, 0x1.45f306dc9c883p-1, 0x1.8p52);  // x · 2/π + 1.5 · 2^52
+  const double kd = sh - 0x1.8p52;
+  const int k = (int)(uint32_t)__builtin_bit_cast(uint64_t, sh);
   double r = fma(kd, -0x1.921fb54400000p+0, xd);
   r = fma(kd, -0x1.0b4611a626331p-34, r);
-  r = (kd == 0.0) ? xd : r;  // keeps sin(−0.0) = −0.0
   const float zf = (float)r * (float)r;
   float ps = __builtin_fmaf(zf, (float)-0x1.aa12ed611087fp-26, (float)0x1.71d97b66aa967p-19);
   ps = __builtin_fmaf(zf, ps, (float)-0x1.a019fd5d6492ep-13);
@@ -242,12 +244,17 @@ __device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
   pc = __builtin_fmaf(zf, pc, (float)-0x1.6c16ba7ffec5ep-10);
   pc = __builtin_fmaf(zf, pc, (float)0x1.55555550fad1cp-5);
   const double z = r * r;
-  const double s = fma(r * z, fma(z, (double)ps, -0x1.555555555510cp-3), r);
+  const double s = r * fma(z, fma(z, (double)ps, -0x1.555555555510cp-3), 1.0);  // r·(1 + …), not r + r·z·…: sin(−0.0) = −0.0
   const double c = fma(z, fma(z, (double)pc, -0x1.fffffffffe3f1p-2), 1.0);
   const int q = k + want_cos;  // cos(x) = sin(x + π/2)
   double v = (q & 1) ? c : s;
   v = (q & 2) ? -v : v;
   return (float)v;
+}
+__device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
+  float res = sincos_f32_fast(x, want_cos);  // unconditionally: the rare slow path then merges ONE register, not the whole state
+  if (!(fabsf(x) < 1.0e6f)) res = sincos_f32_slow(x, want_cos);
+  return res;
 }
 
 // 128-entry table shared by log and pow: interval j of the mantissa [1 + j/128, 1 + (j+1)/128) → rc ≈ 1/centre (the
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void ew_kernel_unaligned(const T* a, co
 }
 
 template <typename Op> struct EwUnroll { static constexpr int value = AGPU_STREAM_U; };
-template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };
+template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };  // re-checked after the round-2 trimming: 1 → −5 %, 3 → −5 %
 template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };
