@@ -348,8 +348,9 @@ __device__ __forceinline__ float sinh_f32_dev(float x) {
   float a = fabsf(x);
   a = (a < 128.0f) ? a : 128.0f;
   const double ad = (double)a;
-  const double kd = rint(ad * 0x1.71547652b82fep+0);  // a · log2 e
-  const int k = (int)kd;
+  const double sh = fma(ad, 0x1.71547652b82fep+0, 0x1.8p52);  // a · log2 e + 1.5 · 2^52: rounds to the integer k, whose
+  const double kd = sh - 0x1.8p52;                            // value is also the low word of the sum (cf. sincos_f32_fast)
+  const int k = (int)(uint32_t)__builtin_bit_cast(uint64_t, sh);
   const double r = fma(kd, -0x1.62e42fefa39efp-1, ad);
   const float rf = (float)r, zf = rf * rf;
   float qs = __builtin_fmaf(zf, 0x1.71de3a556c734p-19f, 0x1.a01a01a01a01ap-13f);  // 1/9!, 1/7!
