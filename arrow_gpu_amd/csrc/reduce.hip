@@ -344,8 +344,9 @@ __global__ __launch_bounds__(AGPU_BLOCK) void reduce_finish_kernel(const typenam
 
 // blocks_per_cu: 16 for the partial reductions (read-only grid-stride loops with 4 packs per lane in flight: 6.47 / 6.65 /
 // 6.70 TB/s for min / f64 sum / i32 sum vs 6.31 / 6.45 / 6.58 at 64 per CU — tools/probe/reduce_sweep.py, one process,
-// same buffer).  The tree sum launches one one-wave block per quarter span (sum_probe.py); giving the order-free
-// reductions that shape too was tried and is no faster on a box in the fast state (0.84–0.86 either way).
+// same buffer).  The tree sum launches one one-wave block per quarter span (sum_probe.py); the order-free reductions
+// of columns without validity take that shape too (reduce_wave_kernel: min / max 0.826 → 0.840, f64 sum 0.830 → 0.847 in
+// bench.py's 1e9-row shard) and keep this grid for everything else.
 static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks, int blocks_per_cu) {
   int64_t g = p->tune.reduce_grid > 0 ? p->tune.reduce_grid : (int64_t)p->dev->num_cus * blocks_per_cu;
   if ((uint64_t)g > work_blocks) g = (int64_t)work_blocks;
@@ -353,10 +354,77 @@ static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks, int blo
   return (int)g;
 }
 
+// Order-free reductions of a column WITHOUT validity in the tree sum's launch shape: one one-wave block per 16 384-row
+// chunk (64 KiB, eight 16-byte loads per lane in flight), its result to partials[chunk]; a small second level folds the
+// partials.  The grid-stride form above stays for columns with validity, unaligned columns and the < 1-chunk tail.
+#define AGPU_REDUCE_WAVE 1
+constexpr uint64_t RED_CHUNK_ROWS = 16384;
+template <typename T, typename Red>
+__global__ __launch_bounds__(AGPU_WAVE) void reduce_wave_kernel(const T* in, typename Red::Acc* partials, uint64_t nchunks) {
+  typedef typename Red::Acc A;
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+    const u32x4* base = reinterpret_cast<const u32x4*>(in + c * RED_CHUNK_ROWS) + lane;
+    A a0 = Red::identity(), a1 = Red::identity(), a2 = Red::identity(), a3 = Red::identity();
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+      u32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(base + (j0 + u) * AGPU_WAVE);
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t e0 = v[u].x, e1 = v[u].y, e2 = v[u].z, e3 = v[u].w;
+        a0 = Red::combine(a0, Red::load(word_as<T>(e0)));
+        a1 = Red::combine(a1, Red::load(word_as<T>(e1)));
+        a2 = Red::combine(a2, Red::load(word_as<T>(e2)));
+        a3 = Red::combine(a3, Red::load(word_as<T>(e3)));
+      }
+    }
+    A acc = Red::combine(Red::combine(a0, a1), Red::combine(a2, a3));
+#pragma unroll
+    for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) acc = Red::combine(acc, shfl_down_acc(acc, off));
+    if (lane == 0) partials[c] = acc;
+  }
+}
+template <typename Red>
+__global__ __launch_bounds__(AGPU_BLOCK) void reduce_fold_kernel(const typename Red::Acc* partials, uint64_t m,
+                                                                typename Red::Acc* out) {  // out[blockIdx.x]
+  typedef typename Red::Acc A;
+  __shared__ A lds[AGPU_BLOCK / AGPU_WAVE];
+  A acc = Red::identity();
+  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < m; i += (uint64_t)gridDim.x * AGPU_BLOCK)
+    acc = Red::combine(acc, partials[i]);
+  const A r = block_reduce<Red, A>(acc, lds);
+  if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+
 template <typename T, typename Red>
 static agpu_status launch_reduce(agpu_pipeline* p, const void* in, const void* validity, uint64_t n, void* out) {
   typedef typename Red::Acc A;
   constexpr int U = 4;
+  if (AGPU_REDUCE_WAVE && !validity && aligned16(in) && n >= 64 * RED_CHUNK_ROWS && p->tune.reduce_grid <= 0) {
+    const uint64_t nchunks = n / RED_CHUNK_ROWS, tail = n - nchunks * RED_CHUNK_ROWS;
+    const uint64_t m = nchunks + (tail ? 1 : 0);
+    const unsigned fold = (unsigned)((m + 4095) / 4096 < 256 ? (m + 4095) / 4096 : 256);
+    void* scratch = nullptr;
+    agpu_status st = agpu_scratch(p, sizeof(A) * (size_t)(m + fold), &scratch);
+    if (st != AGPU_OK) return st;
+    A* partials = static_cast<A*>(scratch);
+    const uint64_t g = nchunks < 0x3FFFFFFFull ? nchunks : 0x3FFFFFFFull;
+    hipLaunchKernelGGL((reduce_wave_kernel<T, Red>), dim3((unsigned)g), dim3(AGPU_WAVE), 0, p->stream, static_cast<const T*>(in),
+                       partials, nchunks);
+    AGPU_LAUNCH_CHECK();
+    if (tail) {
+      hipLaunchKernelGGL((reduce_partial_kernel<T, Red, U>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream,
+                         static_cast<const T*>(in) + nchunks * RED_CHUNK_ROWS, (const uint8_t*)nullptr, tail, partials + nchunks, 1);
+      AGPU_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((reduce_fold_kernel<Red>), dim3(fold), dim3(AGPU_BLOCK), 0, p->stream, (const A*)partials, m, partials + m);
+    AGPU_LAUNCH_CHECK();
+    hipLaunchKernelGGL((reduce_finish_kernel<Red>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, (const A*)(partials + m), (uint32_t)fold,
+                       static_cast<typename Red::Out*>(out));
+    AGPU_LAUNCH_CHECK();
+    return AGPU_OK;
+  }
   const int grid = reduce_grid_for(p, (n / 4 + (uint64_t)AGPU_BLOCK * U - 1) / ((uint64_t)AGPU_BLOCK * U), 16);
   void* scratch = nullptr;
   agpu_status st = agpu_scratch(p, sizeof(A) * (size_t)grid, &scratch);
