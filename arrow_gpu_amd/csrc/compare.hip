@@ -16,6 +16,17 @@
 #include <type_traits>
 
 #include "common.hpp"
+// The result bitmaps are 1/64 of a compare's traffic, and where the driver backed THEIR allocation decides 5–7 % of the
+// launch (0.81 ↔ 0.87 for eq + validity with identical inputs and layout; any offset inside one allocation behaves the
+// same: tools/probe/placement_lottery.py, out_offset.py).  Nontemporal stores for them halve the penalty of an
+// unlucky allocation (compare words: 0.813 → 0.834 / 0.870 → 0.875; with the validity words too: 0.848 / 0.886 —
+// alternations of bench.py on one box).
+#ifndef AGPU_CMP_OUT_NT
+#define AGPU_CMP_OUT_NT 1
+#endif
+#ifndef AGPU_CMP_OUTV_NT
+#define AGPU_CMP_OUTV_NT 1
+#endif
 
 template <int OP, typename T>
 __device__ __forceinline__ bool cmp_pred(T x, T y) {
@@ -53,9 +64,13 @@ __device__ __forceinline__ void validity_block(const uint64_t* va, const uint64_
   const uint64_t w = vblk * CMP_VBLOCK_WORDS + 2 * threadIdx.x;
   if (vec16 && w + 2 <= n_words) {
     const cmp_u64x2 ones = {~0ull, ~0ull};
-    const cmp_u64x2 x = va ? *reinterpret_cast<const cmp_u64x2*>(va + w) : ones;
+    const cmp_u64x2 x = va ? *reinterpret_cast<const cmp_u64x2*>(va + w) : ones;  // (nontemporal loads here: −0.4 %)
     const cmp_u64x2 y = vb ? *reinterpret_cast<const cmp_u64x2*>(vb + w) : ones;
+#if AGPU_CMP_OUTV_NT
+    __builtin_nontemporal_store(x & y, reinterpret_cast<cmp_u64x2*>(outv + w));
+#else
     *reinterpret_cast<cmp_u64x2*>(outv + w) = x & y;
+#endif
   } else {
     if (w < n_words) outv[w] = validity_word(va, vb, w);
     if (w + 1 < n_words) outv[w + 1] = validity_word(va, vb, w + 1);
@@ -97,7 +112,11 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, cons
       const uint64_t m = __ballot(cmp_pred<OP, T>(xa[r], xb[r]));
       if (lane == (uint32_t)r) word = m;
     }
+#if AGPU_CMP_OUT_NT
+    if (lane < R) __builtin_nontemporal_store(word, out + w0 + lane);
+#else
     if (lane < R) out[w0 + lane] = word;
+#endif
   }
 }
 
@@ -144,7 +163,11 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T
       for (int s = 1; s < G; s <<= 1) v |= (uint32_t)__shfl_xor((int)v, s);
       if (lane % G == 0) {
         const uint64_t w = pk / G;
+#if AGPU_CMP_OUT_NT
+        __builtin_nontemporal_store(v, out + w);
+#else
         out[w] = v;
+#endif
       }
     }
   }
