@@ -1110,14 +1110,17 @@ struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders
 };
 
 // 8-bit sources (sin_u8 / cos_i8 / sinh_u8 …): only 256 distinct inputs exist, so evaluating the function per row
-// makes a 5 B/row stream VALU-bound (3.5 TB/s measured).  Each 256-thread block builds the 256-entry result table in
-// LDS once (one evaluation per thread, the SAME device function as the f32 kernel ⇒ identical bits), then streams
-// 4096-row tiles: every wave takes one contiguous 1 KiB chunk with 16-byte loads and transposes it inside the wave
+// makes a 5 B/row stream VALU-bound (3.5 TB/s measured).  Each block builds the 256-entry result table in
+// LDS once (the SAME device function as the f32 kernel ⇒ identical bits), then streams
+// its tiles (16 rows per lane): every wave takes one contiguous 1 KiB chunk with 16-byte loads and transposes it inside the wave
 // (cvt_wide_kernel's ds_bpermute shape) so that each of its 4 nontemporal stores is a coalesced 1 KiB row; 4 LDS reads
 // per store.  The next tile's load is issued before the current tile's lookups.
+// 128 threads (each builds two table entries): 0.78 of the roof against 0.75–0.77 at 256 and 0.78 at 64 (three
+// alternations on one box) — four stores per lane want small blocks (tools/probe/store_probe.hip)
+#define AGPU_LUT8_BLOCK 128
 template <typename TI, typename F>
-__global__ __launch_bounds__(AGPU_BLOCK) void lut8_kernel(const TI* in, float* out, uint64_t ntiles) {
-  constexpr uint32_t WAVES = AGPU_BLOCK / AGPU_WAVE;
+__global__ __launch_bounds__(AGPU_LUT8_BLOCK) void lut8_kernel(const TI* in, float* out, uint64_t ntiles) {
+  constexpr uint32_t WAVES = AGPU_LUT8_BLOCK / AGPU_WAVE;
   __shared__ float lut[256];
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   const u32x4* in16 = reinterpret_cast<const u32x4*>(in);
@@ -1125,7 +1128,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void lut8_kernel(const TI* in, float* o
   uint64_t t = blockIdx.x;
   u32x4 v = {0, 0, 0, 0};
   if (t < ntiles) v = __builtin_nontemporal_load(in16 + (t * WAVES + wave) * AGPU_WAVE + lane);
-  lut[threadIdx.x] = F::ap((float)(TI)(uint8_t)threadIdx.x, 0.0f);  // indexed by the raw byte
+  for (uint32_t e = threadIdx.x; e < 256; e += AGPU_LUT8_BLOCK) lut[e] = F::ap((float)(TI)(uint8_t)e, 0.0f);  // indexed by the raw byte
   __syncthreads();
   while (t < ntiles) {
     const uint64_t c = t * WAVES + wave;
@@ -1150,7 +1153,7 @@ template <typename TI, typename F>
 static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
   static_assert(sizeof(TI) == 1, "8-bit sources only");
   if (n == 0) return AGPU_OK;
-  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_BLOCK * 4 * 4;
+  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_LUT8_BLOCK * 4 * 4;
   const TI* pi = static_cast<const TI*>(in);
   float* po = static_cast<float*>(out);
   uint64_t done = 0;
@@ -1158,7 +1161,7 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
       const int grid = stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p));
-      hipLaunchKernelGGL((lut8_kernel<TI, F>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, ntiles);
+      hipLaunchKernelGGL((lut8_kernel<TI, F>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, po, ntiles);
       done = ntiles * TILE_ROWS;
     }
     if (done < n)
@@ -1216,10 +1219,13 @@ __device__ __forceinline__ float trig16_eval(TabPtr tab, uint32_t raw16) {
 
 // 4096-row tiles per 256-thread block: every wave takes two contiguous 1 KiB chunks (512 rows each) with 16-byte loads and
 // transposes each inside the wave (ds_bpermute, as cvt_wide_kernel) so that both stores of a chunk are coalesced 1 KiB rows.
+// one chunk per wave and tile: two stores per lane (two chunks, i.e. four stores: 0.72 → 0.75 of the roof; a store stream
+// likes few stores per lane, tools/probe/store_probe.hip)
+#define AGPU_TRIG16_U 1
 template <typename TI, int WANT_COS>
 __global__ __launch_bounds__(AGPU_BLOCK) void trig16_kernel(const TI* in, float* out, uint64_t ntiles,
                                                            const SinCos64* gtab) {
-  constexpr int U = 2;  // chunks per wave per tile
+  constexpr int U = AGPU_TRIG16_U;  // chunks per wave per tile
   constexpr uint32_t WAVES = AGPU_BLOCK / AGPU_WAVE;
   __shared__ SinCos64 tab[512];
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
@@ -1271,7 +1277,7 @@ template <typename TI, int WANT_COS>
 static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
   static_assert(sizeof(TI) == 2, "16-bit sources only");
   if (n == 0) return AGPU_OK;
-  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_BLOCK * 4 * 4;
+  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_BLOCK * 8 * AGPU_TRIG16_U;
   const TI* pi = static_cast<const TI*>(in);
   float* po = static_cast<float*>(out);
   const SinCos64* tab = static_cast<const SinCos64*>(p->dev->trig16_table);
