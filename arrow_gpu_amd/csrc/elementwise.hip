@@ -941,12 +941,17 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel_unaligned(const TI* in,
 // l mod R — four ds_bpermute_b32 (one per dword of the source vector; the LDS crossbar, no LDS memory, no barrier) and
 // a select.  One wave per block.  Measured on cast u8→f32 at 1e9 rows, same process (tools/probe/cast_sweep.py,
 // profiles/r02_sweep_cast.json): 4-byte loads 5.4–5.9 TB/s, transposition through 1 KiB of LDS 5.9, this form 6.36.
+// threads per block: one wave (u8→f32 0.787, i16→f32 0.785); 128: 0.77 / 0.79; 256: 0.70 / 0.76 (tools/probe/cast_shape.py)
+#ifndef AGPU_CVTW_BLOCK
+#define AGPU_CVTW_BLOCK 64
+#endif
 template <typename TI, typename TO, typename Conv>
-__global__ __launch_bounds__(AGPU_WAVE) void cvt_wide_kernel(const TI* in, TO* out, uint64_t nchunks) {
+__global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in, TO* out, uint64_t nchunks) {
   constexpr int R = sizeof(TO) / sizeof(TI);   // 2 or 4 stores per load
   constexpr int NO = 16 / sizeof(TO);          // output elements per lane per store
-  const uint32_t lane = threadIdx.x;
-  for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+  constexpr uint32_t WAVES = AGPU_CVTW_BLOCK / AGPU_WAVE;
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
+  for (uint64_t c = (uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE; c < nchunks; c += (uint64_t)gridDim.x * WAVES) {
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
     static_for<R>([&](auto j) {
       const int src = (int)(((uint32_t)j * (AGPU_WAVE / R) + lane / R) * 4);  // byte address of the source lane
@@ -1026,8 +1031,8 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
       constexpr uint64_t chunk_rows = (uint64_t)AGPU_WAVE * 16 / sizeof(TI);
       const uint64_t nchunks = n / chunk_rows;
       if (nchunks) {
-        const int grid = stream_grid_for(p, nchunks);
-        hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, pi, po, nchunks);
+        const int grid = stream_grid_for(p, (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE));
+        hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, po, nchunks);
       }
       if (nchunks * chunk_rows < n)
         hipLaunchKernelGGL((cvt_tail_kernel<TI, TO, Conv>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pi, po,
