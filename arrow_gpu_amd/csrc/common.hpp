@@ -274,6 +274,25 @@ __device__ __forceinline__ void st_vec(V* p, V v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
+// 16-byte streaming store with the sc1 bit beside nt — a cache policy the compiler cannot be asked for (it knows plain and
+// nontemporal).  tools/probe/cache_policy.hip tries all eight sc0 / sc1 / nt combinations on both sides of an f32 add (loads:
+// nt is what matters, the scope bits change nothing; stores: "sc1 nt" +0.7 %); in the product it is worth +2 % to the
+// 8 B/row kernels (unary / scalar: 0.831 → 0.848) and +3 % to the ×2 widening casts (i16 → f32 0.785 → 0.81), nothing to
+// the binary kernels, and it COSTS the 8-bit kernels and the ×4 widening casts 1–2 % — so it is opt-in per call site.
+template <typename V>
+__device__ __forceinline__ void st_vec_sc1(V* p, V v) {
+  static_assert(sizeof(V) == 16, "16-byte vectors only");
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef uint32_t st_u32x4 __attribute__((ext_vector_type(4)));
+  const st_u32x4 w = __builtin_bit_cast(st_u32x4, v);
+  // s_nop: a store of more than 8 bytes reads its data registers over several cycles and the next VALU instruction may
+  // overwrite them — the compiler pads its OWN stores for this hazard but cannot see through inline asm (found the hard
+  // way: sinh_i16 came out with two of four components clobbered in lanes 12–15 of every 16)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" : : "v"(p), "v"(w) : "memory");
+#else
+  *p = v;
+#endif
+}
 
 // Compile-time unrolled `for (u = 0; u < U; u++) f(u)`.  NOT a `#pragma unroll` loop on purpose: with U == 1 LICM sees a
 // single-trip loop whose store address is loop-invariant, promotes the store out of it and the re-created store loses

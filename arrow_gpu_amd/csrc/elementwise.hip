@@ -76,13 +76,17 @@ __device__ __forceinline__ PackN<T, N> load_pack(const T* p) {
     return out;
   }
 }
-template <bool NT, typename T, int N>
+#ifndef AGPU_USE_SC1
+#define AGPU_USE_SC1 1
+#endif
+template <bool NT, typename T, int N, bool SC1 = false>
 __device__ __forceinline__ void store_pack(T* p, const PackN<T, N>& v) {
   typedef typename VecOf<T, N>::type V;
   V r;
 #pragma unroll
   for (int k = 0; k < N; k++) r[k] = v.v[k];
-  st_vec<NT>(reinterpret_cast<V*>(p), r);
+  if constexpr (SC1 && NT && sizeof(V) == 16 && AGPU_USE_SC1) st_vec_sc1(reinterpret_cast<V*>(p), r);
+  else st_vec<NT>(reinterpret_cast<V*>(p), r);
 }
 
 // ---------------------------------------------------------------- scalar semantics (mirrors oracle/agpu_oracle.c)
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(BLK) void ew_kernel(const T* a, const T* b, T* out,
       PackN<T, N> r;
 #pragma unroll
       for (int k = 0; k < N; k++) r.v[k] = Op::ap(va[u].v[k], MODE == MODE_BINARY ? vb[u].v[k] : sv);
-      store_pack<NTS, T, N>(out + (p0 + (uint64_t)u * BLK) * N, r);
+      store_pack<NTS, T, N, (MODE != MODE_BINARY && sizeof(T) == 4)>(out + (p0 + (uint64_t)u * BLK) * N, r);  // sc1: common.hpp st_vec_sc1
     });
   }
 }
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in,
 #pragma unroll
       for (int k = 0; k < NO; k++) r.v[k] = Conv::ap(x.v[k]);
       const uint32_t g = (uint32_t)j * AGPU_WAVE + lane;  // slot of this lane's store inside the chunk
-      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, NO>(out + (c * (uint64_t)(AGPU_WAVE * R) + g) * NO, r);
+      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, NO, (R == 2)>(out + (c * (uint64_t)(AGPU_WAVE * R) + g) * NO, r);  // sc1 for ×2 only
     });
   }
 }
