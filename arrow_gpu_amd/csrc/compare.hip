@@ -79,8 +79,9 @@ __device__ __forceinline__ void validity_block(const uint64_t* va, const uint64_
 
 // ---------------------------------------------------------------- variant 0: ballot
 // R = rounds per wave tile (R output u64 words per wave).  R = 4 with 256-thread blocks (1024 rows per block) measured
-// best at 1e9 rows (6.07 TB/s vs 5.89 at R = 16: profiles/r01_sweep_add_eq_1e9_b.json).  Full tiles only; the
-// remainder is a separate tiny launch of cmp_word_kernel.
+// best at 1e9 rows (6.07 TB/s vs 5.89 at R = 16: profiles/r01_sweep_add_eq_1e9_b.json; re-checked in round 2 with the
+// nontemporal result stores, lucky / unlucky allocation: R = 4 0.89 / 0.85, R = 8 0.875 / 0.80, R = 2 0.73 / 0.685).  Full
+// tiles only; the remainder is a separate tiny launch of cmp_word_kernel.
 #define CMP_R 4
 template <typename T, int OP, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, const T* b, const uint64_t* va,
