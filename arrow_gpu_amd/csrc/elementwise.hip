@@ -821,6 +821,73 @@ static agpu_status launch_log_f32(agpu_pipeline* p, const void* a, void* out, ui
   return AGPU_OK;
 }
 
+// ---------------------------------------------------------------- self-test of the f32 functions (agpu_selftest_unary_f32)
+// Every f32 bit pattern in [first, first + count) through the product's functor and through the f64 device library
+// rounded once to f32; the largest distance in ULPs (monotone integer order, ±0 equal, NaN only against NaN) and a bit
+// pattern that attains it.  2^32 patterns take seconds on the GPU — the CPU oracle covers 2^24 samples per test.
+template <typename F, int REF>
+__global__ __launch_bounds__(AGPU_BLOCK) void selftest_unary_kernel(uint64_t first, uint64_t count, unsigned long long* worst) {
+  unsigned long long w = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < count; i += (uint64_t)gridDim.x * AGPU_BLOCK) {
+    const uint32_t bits = (uint32_t)(first + i);
+    const float x = __builtin_bit_cast(float, bits);
+    const float got = F::ap(x, 0.0f);
+    const double xd = (double)x;
+    double rd;
+    if constexpr (REF == AGPU_UN_SIN) rd = sin(xd);
+    else if constexpr (REF == AGPU_UN_COS) rd = cos(xd);
+    else if constexpr (REF == AGPU_UN_LOG) rd = log(xd);
+    else if constexpr (REF == AGPU_UN_LOG2) rd = log2(xd);
+    else if constexpr (REF == AGPU_UN_EXP) rd = exp(xd);
+    else if constexpr (REF == AGPU_UN_EXP2) rd = exp2(xd);
+    else if constexpr (REF == AGPU_UN_SINH) rd = sinh(xd);
+    else if constexpr (REF == AGPU_UN_CBRT) rd = cbrt(xd);
+    else if constexpr (REF == AGPU_UN_ACOS) rd = acos(xd);
+    else rd = sqrt(xd);
+    const float ref = (float)rd;
+    uint32_t d;
+    if (got != got || ref != ref) d = (got != got && ref != ref) ? 0u : 0xFFFFFFFFu;
+    else {
+      const int32_t gb = __builtin_bit_cast(int32_t, got), rb = __builtin_bit_cast(int32_t, ref);
+      const int64_t go = gb < 0 ? -(int64_t)(gb & 0x7fffffff) : gb, ro = rb < 0 ? -(int64_t)(rb & 0x7fffffff) : rb;
+      const int64_t dd = go > ro ? go - ro : ro - go;
+      d = dd > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)dd;
+    }
+    const unsigned long long key = ((unsigned long long)d << 32) | bits;
+    if (key > w && d > 0) w = key;
+  }
+  if (w) atomicMax(worst, w);
+}
+agpu_status agpu_selftest_unary_f32(agpu_pipeline* p, agpu_unary_op op, uint64_t first_bits, uint64_t count, uint32_t* out_max_ulp,
+                                    uint32_t* out_worst_bits) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(out_max_ulp && first_bits + count <= (1ull << 32), AGPU_ERR_ARG, "bad range");
+  void* scratch = nullptr;
+  agpu_status st = agpu_scratch(p, 8, &scratch);
+  if (st != AGPU_OK) return st;
+  unsigned long long* worst = static_cast<unsigned long long*>(scratch);
+  AGPU_HIP(hipMemsetAsync(worst, 0, 8, p->stream));
+  const int grid = (int)std::min<uint64_t>((count + AGPU_BLOCK - 1) / AGPU_BLOCK, (uint64_t)p->dev->num_cus * 32);
+#define ST_CASE(OPV, FUNCTOR)                                                                                                     \
+  case OPV:                                                                                                                       \
+    if (count) hipLaunchKernelGGL((selftest_unary_kernel<FUNCTOR, OPV>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, first_bits, count, worst); \
+    break;
+  switch (op) {
+    ST_CASE(AGPU_UN_SIN, UnSin) ST_CASE(AGPU_UN_COS, UnCos) ST_CASE(AGPU_UN_LOG, UnLog) ST_CASE(AGPU_UN_LOG2, UnLog2)
+    ST_CASE(AGPU_UN_EXP, UnExp) ST_CASE(AGPU_UN_EXP2, UnExp2) ST_CASE(AGPU_UN_SINH, UnSinh) ST_CASE(AGPU_UN_CBRT, UnCbrt)
+    ST_CASE(AGPU_UN_ACOS, UnAcos) ST_CASE(AGPU_UN_SQRT, UnSqrt)
+    default: agpu_set_error("no f64 reference for unary op %d", (int)op); return AGPU_ERR_UNSUPPORTED;
+  }
+#undef ST_CASE
+  AGPU_LAUNCH_CHECK();
+  unsigned long long host = 0;
+  AGPU_HIP(hipMemcpyAsync(&host, worst, 8, hipMemcpyDeviceToHost, p->stream));
+  AGPU_HIP(hipStreamSynchronize(p->stream));
+  *out_max_ulp = (uint32_t)(host >> 32);
+  if (out_worst_bits) *out_worst_bits = (uint32_t)host;
+  return AGPU_OK;
+}
+
 // ---------------------------------------------------------------- dispatch: op × dtype
 template <typename T, int MODE>
 static agpu_status dispatch_int_op(agpu_pipeline* p, agpu_binary_op op, const void* a, const void* b, void* out,

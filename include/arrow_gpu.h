@@ -260,6 +260,14 @@ agpu_status agpu_scalar(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, c
  *  logical/src/lib.rs:135-158, apply_unary_function_op! crates/math/src/lib.rs:138-193 and
  *  crates/trigonometry/src/lib.rs:85-137]. */
 agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, const void* in, void* out, uint64_t n);
+/* Self-test of an f32 function over a RANGE OF BIT PATTERNS: every pattern in [first_bits, first_bits + count) (count
+ * up to 2^32 = all of f32) goes through the kernel's own arithmetic and through the f64 device library rounded once to
+ * f32; *out_max_ulp is the largest distance in ULPs (±0 equal, NaN only against NaN, 0xFFFFFFFF if one side is NaN),
+ * *out_worst_bits (optional) a pattern that attains it.  ops: SQRT CBRT EXP EXP2 LOG LOG2 SIN COS ACOS SINH.  Blocking.
+ * Not in the reference, whose tests pin these functions to 0.01 absolute on a handful of points
+ * [ref: crates/trigonometry/src/f32_kernel.rs:62-132, crates/math/src/f32.rs:84-271]. */
+agpu_status agpu_selftest_unary_f32(agpu_pipeline* p, agpu_unary_op op, uint64_t first_bits, uint64_t count,
+                                    uint32_t* out_max_ulp, uint32_t* out_worst_bits);
 
 /* out[i] = (to)in[i].  Table = cast_dyn's [ref: crates/cast/src/lib.rs:135-161] plus identity-width sign
  * reinterprets (memcpy in the reference :69-86).  from=AGPU_BOOL,to=F32: `in` is a bitmap of n bits.

@@ -191,6 +191,20 @@ def test_f32_transcendentals_within_ulp(D, op, name, lo, hi):
         assert np.signbit(got[1]) and not np.signbit(got[0]) and got[1] == 0.0
 
 
+@pytest.mark.parametrize("op,name", [(capi.UN_SIN, "sin"), (capi.UN_COS, "cos"), (capi.UN_LOG, "log"), (capi.UN_SINH, "sinh"),
+                                     (capi.UN_EXP, "exp"), (capi.UN_SQRT, "sqrt"), (capi.UN_CBRT, "cbrt"), (capi.UN_ACOS, "acos"),
+                                     (capi.UN_EXP2, "exp2"), (capi.UN_LOG2, "log2")])
+def test_f32_functions_exhaustive_over_all_bit_patterns(D, op, name):
+    """ALL 2^32 f32 bit patterns (every NaN payload, denormal and huge argument included) through the kernel's own
+    arithmetic against the f64 device library rounded once (agpu_selftest_unary_f32): ≤ MAX_ULP everywhere.  The CPU
+    oracle (f64 libm) pins the same functions on 2^22–2^24 samples in test_f32_transcendentals_within_ulp."""
+    import ctypes as C
+    mx, worst = C.c_uint32(0), C.c_uint32(0)
+    D.call("agpu_selftest_unary_f32", op, 0, 1 << 32, C.byref(mx), C.byref(worst))
+    x = np.array([worst.value], np.uint32).view(np.float32)[0]
+    assert mx.value <= G.MAX_ULP, f"{name}: {mx.value} ULP at bits {worst.value:#010x} (x = {x!r})"
+
+
 @pytest.mark.parametrize("dtype", [capi.U8, capi.I8, capi.U16, capi.I16])
 @pytest.mark.parametrize("op", [capi.UN_SIN, capi.UN_COS, capi.UN_SINH])
 def test_fused_small_int_trig_exhaustive(D, dtype, op):
