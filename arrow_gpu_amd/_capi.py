@@ -119,6 +119,7 @@ SIGNATURES = {
     "agpu_scalar": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
     "agpu_unary": [_vp, _i32, _i32, _vp, _vp, _u64],
     "agpu_selftest_unary_f32": [_vp, _i32, _u64, _u64, _vp, _vp],
+    "agpu_selftest_pow_f32": [_vp, _u64, _u64, _i32, _vp, _vp, _vp],
     "agpu_cast": [_vp, _i32, _i32, _vp, _vp, _u64],
     "agpu_broadcast": [_vp, _i32, _u32, _vp, _u64],
     "agpu_broadcast_from_device": [_vp, _i32, _vp, _vp, _u64],

@@ -888,6 +888,72 @@ agpu_status agpu_selftest_unary_f32(agpu_pipeline* p, agpu_unary_op op, uint64_t
   return AGPU_OK;
 }
 
+// pow has 2^64 operand pairs: `count` pseudo-random ones instead (counter-based, reproducible from `seed`).
+//   domain 0: x any positive f32 bit pattern (denormals, inf and NaN included), |y| < 2^8 with a random exponent
+//   domain 1: x within 2^13 ULPs of 1.0, |y| up to 2^30 — where log2 x needs its relative accuracy
+//   domain 2: x ∈ [2^-3, 2^3), |y| < 2^7 — results across the whole exponent range incl. overflow / underflow
+__device__ __forceinline__ uint32_t selftest_mix(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
+__global__ __launch_bounds__(AGPU_BLOCK) void selftest_pow_kernel(uint64_t seed, uint64_t count, int domain, const PowTab* tab,
+                                                                 unsigned long long* worst_d, unsigned long long* worst_xy) {
+  unsigned long long wd = 0, wxy = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < count; i += (uint64_t)gridDim.x * AGPU_BLOCK) {
+    const uint32_t r0 = selftest_mix(seed + 2 * i + 0x9e3779b97f4a7c15ull), r1 = selftest_mix(seed + 2 * i + 1);
+    uint32_t xb, yb;
+    if (domain == 0) {
+      xb = r0 & 0x7fffffffu;
+      yb = (r1 & 0x807fffffu) | ((100u + (r1 >> 23) % 35u) << 23);  // exponent 2^-27 … 2^7
+    } else if (domain == 1) {
+      xb = 0x3f800000u + (r0 & 0x3fffu) - 0x2000u;
+      yb = (r1 & 0x807fffffu) | ((127u + (r1 >> 23) % 31u) << 23);  // 1 … 2^30
+    } else {
+      xb = (r0 & 0x007fffffu) | ((124u + (r0 >> 23) % 6u) << 23);
+      yb = (r1 & 0x807fffffu) | ((118u + (r1 >> 23) % 16u) << 23);  // 2^-9 … 2^6
+    }
+    const float x = __builtin_bit_cast(float, xb), y = __builtin_bit_cast(float, yb);
+    const float got = pow_f32_dev(tab, x, y);
+    const float ref = (float)pow((double)x, (double)y);
+    uint32_t d;
+    if (got != got || ref != ref) d = (got != got && ref != ref) ? 0u : 0xFFFFFFFFu;
+    else {
+      const int32_t gb = __builtin_bit_cast(int32_t, got), rb = __builtin_bit_cast(int32_t, ref);
+      const int64_t go = gb < 0 ? -(int64_t)(gb & 0x7fffffff) : gb, ro = rb < 0 ? -(int64_t)(rb & 0x7fffffff) : rb;
+      const int64_t dd = go > ro ? go - ro : ro - go;
+      d = dd > 0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)dd;
+    }
+    if (d > wd) {
+      wd = d;
+      wxy = ((unsigned long long)xb << 32) | yb;
+    }
+  }
+  if (wd && atomicMax(worst_d, wd) < wd) atomicExch(worst_xy, wxy);  // (the pair is "a" worst one: good enough for a report)
+}
+agpu_status agpu_selftest_pow_f32(agpu_pipeline* p, uint64_t seed, uint64_t count, int32_t domain, uint32_t* out_max_ulp,
+                                  uint32_t* out_worst_x_bits, uint32_t* out_worst_y_bits) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(out_max_ulp && domain >= 0 && domain <= 2, AGPU_ERR_ARG, "bad argument");
+  void* scratch = nullptr;
+  agpu_status st = agpu_scratch(p, 16, &scratch);
+  if (st != AGPU_OK) return st;
+  unsigned long long* w = static_cast<unsigned long long*>(scratch);
+  AGPU_HIP(hipMemsetAsync(w, 0, 16, p->stream));
+  const int grid = (int)std::min<uint64_t>((count + AGPU_BLOCK - 1) / AGPU_BLOCK, (uint64_t)p->dev->num_cus * 32);
+  if (count)
+    hipLaunchKernelGGL(selftest_pow_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, seed, count, (int)domain,
+                       static_cast<const PowTab*>(p->dev->pow_table), w, w + 1);
+  AGPU_LAUNCH_CHECK();
+  unsigned long long host[2] = {0, 0};
+  AGPU_HIP(hipMemcpyAsync(host, w, 16, hipMemcpyDeviceToHost, p->stream));
+  AGPU_HIP(hipStreamSynchronize(p->stream));
+  *out_max_ulp = (uint32_t)host[0];
+  if (out_worst_x_bits) *out_worst_x_bits = (uint32_t)(host[1] >> 32);
+  if (out_worst_y_bits) *out_worst_y_bits = (uint32_t)host[1];
+  return AGPU_OK;
+}
+
 // ---------------------------------------------------------------- dispatch: op × dtype
 template <typename T, int MODE>
 static agpu_status dispatch_int_op(agpu_pipeline* p, agpu_binary_op op, const void* a, const void* b, void* out,

@@ -268,6 +268,11 @@ agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, con
  * [ref: crates/trigonometry/src/f32_kernel.rs:62-132, crates/math/src/f32.rs:84-271]. */
 agpu_status agpu_selftest_unary_f32(agpu_pipeline* p, agpu_unary_op op, uint64_t first_bits, uint64_t count,
                                     uint32_t* out_max_ulp, uint32_t* out_worst_bits);
+/* The same for f32 pow over `count` reproducible pseudo-random operand pairs (2^64 pairs cannot be enumerated):
+ * domain 0 = x any positive bit pattern (denormals, inf, NaN), |y| < 2^8; 1 = x within 2^13 ULPs of 1, |y| up to 2^30;
+ * 2 = x in [2^-3, 2^3), |y| < 2^7 (results across overflow / underflow).  2^32 pairs take about a second. */
+agpu_status agpu_selftest_pow_f32(agpu_pipeline* p, uint64_t seed, uint64_t count, int32_t domain, uint32_t* out_max_ulp,
+                                  uint32_t* out_worst_x_bits, uint32_t* out_worst_y_bits);
 
 /* out[i] = (to)in[i].  Table = cast_dyn's [ref: crates/cast/src/lib.rs:135-161] plus identity-width sign
  * reinterprets (memcpy in the reference :69-86).  from=AGPU_BOOL,to=F32: `in` is a bitmap of n bits.

@@ -205,6 +205,17 @@ def test_f32_functions_exhaustive_over_all_bit_patterns(D, op, name):
     assert mx.value <= G.MAX_ULP, f"{name}: {mx.value} ULP at bits {worst.value:#010x} (x = {x!r})"
 
 
+@pytest.mark.parametrize("domain", [0, 1, 2])
+def test_f32_power_device_selftest_2_pow_32_pairs(D, domain):
+    """2^32 pseudo-random operand pairs per domain (any positive x incl. denormals / inf / NaN; x → 1 with |y| up to 2^30;
+    results across overflow / underflow) against the f64 device library rounded once: ≤ MAX_ULP."""
+    import ctypes as C
+    mx, wx, wy = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    D.call("agpu_selftest_pow_f32", 20250418 + domain, 1 << 32, domain, C.byref(mx), C.byref(wx), C.byref(wy))
+    xy = np.array([wx.value, wy.value], np.uint32).view(np.float32)
+    assert mx.value <= G.MAX_ULP, f"pow domain {domain}: {mx.value} ULP at x = {xy[0]!r}, y = {xy[1]!r}"
+
+
 @pytest.mark.parametrize("dtype", [capi.U8, capi.I8, capi.U16, capi.I16])
 @pytest.mark.parametrize("op", [capi.UN_SIN, capi.UN_COS, capi.UN_SINH])
 def test_fused_small_int_trig_exhaustive(D, dtype, op):
