@@ -85,6 +85,8 @@ SIGNATURES = {
     "agpu_pipeline_last_kernel_ns": [_vp, C.POINTER(_u64), C.POINTER(C.c_char_p)],
     "agpu_comm_get_unique_id": [_vp],
     "agpu_comm_init_rank": [_vp, _vp, _i32, _i32, _pp],
+    "agpu_comm_init_rank_timeout": [_vp, _vp, _i32, _i32, _i64, _pp],
+    "agpu_comm_runtime_info": [C.c_char_p, _sz],
     "agpu_comm_destroy": [_vp],
     "agpu_comm_rank": [_vp, C.POINTER(_i32), C.POINTER(_i32)],
     "agpu_comm_reduce": [_vp, _vp, _i32, _i32, _vp, _vp, _u64, _vp],

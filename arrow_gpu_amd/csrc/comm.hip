@@ -15,7 +15,13 @@
 // not promise; (iii) empty shards must contribute the identity.  The message is 16 B per rank: pure latency, the
 // xGMI link rate is irrelevant, one collective per statistic.  agpu_comm_all_reduce is the plain ncclAllReduce for
 // integer counts (null counts, row counts) where the order cannot matter.
+#include <dlfcn.h>
 #include <rccl/rccl.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <thread>
 
 #include "common.hpp"
 
@@ -28,7 +34,23 @@ struct agpu_comm {
   char* send;      // device: one 16-byte record
   char* recv;      // device: world records
   int32_t* token;  // device: barrier word
+  // One record in flight: every collective here writes send / recv asynchronously on the CALLER's stream.  Calls from one
+  // pipeline are stream-ordered; a call from ANOTHER pipeline is ordered behind the previous call with this event, so two
+  // pipelines sharing a communicator never race on the record (and RCCL sees its collectives in one order).  `mu` covers
+  // the host side (two host threads).
+  std::mutex mu;
+  hipEvent_t last_done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool used = false;
 };
+
+// AGPU_COMM_TIMEOUT_MS: how long a collective rendezvous (communicator init, barrier) may wait for the other ranks
+// before the call gives up with AGPU_ERR_HIP.  Default 120 s; 0 = wait for ever (RCCL's own behaviour).
+static int64_t comm_timeout_ms() {
+  const char* e = getenv("AGPU_COMM_TIMEOUT_MS");
+  if (e && *e) return strtoll(e, nullptr, 10);
+  return 120000;
+}
 
 // reduce.hip: combine `world` gathered records in rank order → out_dev (1 element); kind: 0..2 = agpu_reduce_op on
 // `dtype`, 3 = f64 sum
@@ -55,7 +77,23 @@ agpu_status agpu_comm_get_unique_id(void* out_id) {
   return AGPU_OK;
 }
 
-agpu_status agpu_comm_init_rank(agpu_device* dev, const void* unique_id, int32_t rank, int32_t world, agpu_comm** out_comm) {
+// ncclCommInitRank blocks until all `world` ranks have called it — for ever when one never arrives (a worker that died
+// before reaching it, a launcher that started fewer ranks).  The blocking call therefore runs on a helper thread and the
+// caller waits for it with a deadline.  On a timeout the helper is still inside RCCL and cannot be cancelled: it is
+// detached, the call reports AGPU_ERR_HIP, and the PROCESS should exit (a fresh process is the only clean retry; the
+// communicator of a rank that did arrive is useless without its peers anyway).  The collectives themselves stay on the
+// plain blocking-communicator path.
+struct comm_init_job {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+  ncclResult_t result = ncclSuccess;
+  hipError_t hip = hipSuccess;
+  ncclComm_t comm = nullptr;
+};
+
+agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id, int32_t rank, int32_t world,
+                                        int64_t timeout_ms, agpu_comm** out_comm) {
   AGPU_REQUIRE(dev && unique_id && out_comm, AGPU_ERR_ARG, "null argument");
   AGPU_REQUIRE(world >= 1 && world <= 256 && rank >= 0 && rank < world, AGPU_ERR_ARG, "bad rank / world (1..256 ranks)");
   *out_comm = nullptr;
@@ -63,7 +101,39 @@ agpu_status agpu_comm_init_rank(agpu_device* dev, const void* unique_id, int32_t
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof(id));
   ncclComm_t comm = nullptr;
-  AGPU_NCCL(ncclCommInitRank(&comm, world, id, rank));  // blocks until all `world` ranks have called it
+  if (timeout_ms <= 0) {
+    AGPU_NCCL(ncclCommInitRank(&comm, world, id, rank));
+  } else {
+    auto job = std::make_shared<comm_init_job>();
+    const int ordinal = dev->ordinal;
+    std::thread([job, id, rank, world, ordinal]() {
+      ncclComm_t c = nullptr;
+      hipError_t he = hipSetDevice(ordinal);
+      ncclResult_t r = he == hipSuccess ? ncclCommInitRank(&c, world, id, rank) : ncclUnhandledCudaError;
+      std::lock_guard<std::mutex> lk(job->mu);
+      job->comm = c;
+      job->result = r;
+      job->hip = he;
+      job->done = true;
+      job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->mu);
+    if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return job->done; })) {
+      agpu_set_error("agpu_comm_init_rank: rank %d of %d gave up after %lld ms waiting for the other ranks "
+                     "(ncclCommInitRank is still pending on a helper thread: exit this process)",
+                     (int)rank, (int)world, (long long)timeout_ms);
+      return AGPU_ERR_HIP;
+    }
+    if (job->hip != hipSuccess) {
+      agpu_set_error("hipSetDevice(%d) failed on the init thread: %s", ordinal, hipGetErrorString(job->hip));
+      return AGPU_ERR_HIP;
+    }
+    if (job->result != ncclSuccess) {
+      agpu_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(job->result));
+      return AGPU_ERR_HIP;
+    }
+    comm = job->comm;
+  }
   char* mem = nullptr;
   hipError_t e = hipMalloc(&mem, 16 + 16 * (size_t)world + 16);
   if (e != hipSuccess) {
@@ -81,7 +151,27 @@ agpu_status agpu_comm_init_rank(agpu_device* dev, const void* unique_id, int32_t
   c->send = mem;
   c->recv = mem + 16;
   c->token = reinterpret_cast<int32_t*>(mem + 16 + 16 * (size_t)world);
+  if (hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming) != hipSuccess) c->last_done = nullptr;
   *out_comm = c;
+  return AGPU_OK;
+}
+
+agpu_status agpu_comm_init_rank(agpu_device* dev, const void* unique_id, int32_t rank, int32_t world, agpu_comm** out_comm) {
+  return agpu_comm_init_rank_timeout(dev, unique_id, rank, world, comm_timeout_ms(), out_comm);
+}
+
+// Which shared objects the collectives and the HIP runtime of THIS process come from (dladdr of one symbol of each): a
+// process that imported torch first runs on torch's bundled librccl / libamdhip64, one that did not on /opt/rocm's — the
+// bench prints this so a multi-GPU record says which runtime it measured.
+agpu_status agpu_comm_runtime_info(char* out, size_t out_cap) {
+  AGPU_REQUIRE(out && out_cap > 0, AGPU_ERR_ARG, "null out");
+  Dl_info a{}, b{};
+  const char* rccl = dladdr(reinterpret_cast<void*>(&ncclGetUniqueId), &a) && a.dli_fname ? a.dli_fname : "?";
+  const char* hip = dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &b) && b.dli_fname ? b.dli_fname : "?";
+  int v = 0, hv = 0;
+  (void)ncclGetVersion(&v);
+  (void)hipRuntimeGetVersion(&hv);
+  snprintf(out, out_cap, "rccl %d (built against %d) from %s; hip runtime %d from %s", v, (int)NCCL_VERSION_CODE, rccl, hv, hip);
   return AGPU_OK;
 }
 
@@ -91,6 +181,7 @@ agpu_status agpu_comm_destroy(agpu_comm* c) {
   (void)hipDeviceSynchronize();
   (void)ncclCommDestroy(c->comm);
   (void)hipFree(c->send);
+  if (c->last_done) (void)hipEventDestroy(c->last_done);
   delete c;
   return AGPU_OK;
 }
@@ -109,11 +200,29 @@ static agpu_status comm_check(agpu_comm* c, agpu_pipeline* p) {
   return AGPU_OK;
 }
 
+// Holds the communicator for one collective call: orders p's stream behind the previous call when that ran on another
+// stream, and leaves the "done" event behind on the way out.
+struct comm_use {
+  agpu_comm* c;
+  agpu_pipeline* p;
+  std::unique_lock<std::mutex> lk;
+  comm_use(agpu_comm* c_, agpu_pipeline* p_) : c(c_), p(p_), lk(c_->mu) {
+    if (c->used && c->last_done && c->last_stream != p->stream) (void)hipStreamWaitEvent(p->stream, c->last_done, 0);
+  }
+  ~comm_use() {
+    if (c->last_done && hipEventRecord(c->last_done, p->stream) == hipSuccess) {
+      c->last_stream = p->stream;
+      c->used = true;
+    }
+  }
+};
+
 agpu_status agpu_comm_all_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, agpu_comm_dtype ctype, void* buf_dev,
                                  uint64_t count) {
   AGPU_BIND(p);
   agpu_status st = comm_check(c, p);
   if (st != AGPU_OK) return st;
+  comm_use use(c, p);
   AGPU_REQUIRE(buf_dev || count == 0, AGPU_ERR_ARG, "null buffer");
   ncclDataType_t dt;
   switch (ctype) {
@@ -148,6 +257,7 @@ agpu_status agpu_comm_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, 
   AGPU_BIND(p);
   agpu_status st = comm_check(c, p);
   if (st != AGPU_OK) return st;
+  comm_use use(c, p);
   AGPU_REQUIRE(out_dev, AGPU_ERR_ARG, "null out_dev");
   AGPU_REQUIRE((int)op >= 0 && (int)op <= 2, AGPU_ERR_ARG, "bad reduce op");
   st = agpu_internal_comm_pack(p, c->send, n_local);
@@ -162,6 +272,7 @@ agpu_status agpu_comm_reduce_sum_f64(agpu_comm* c, agpu_pipeline* p, const float
   AGPU_BIND(p);
   agpu_status st = comm_check(c, p);
   if (st != AGPU_OK) return st;
+  comm_use use(c, p);
   AGPU_REQUIRE(out_dev, AGPU_ERR_ARG, "null out_dev");
   st = agpu_internal_comm_pack(p, c->send, n_local);
   if (st != AGPU_OK) return st;
@@ -177,6 +288,7 @@ agpu_status agpu_comm_final_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_o
   AGPU_BIND(p);
   agpu_status st = comm_check(c, p);
   if (st != AGPU_OK) return st;
+  comm_use use(c, p);
   AGPU_REQUIRE(partial_dev && out_dev, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE((int)op >= 0 && (int)op <= 2, AGPU_ERR_ARG, "bad reduce op");
   AGPU_REQUIRE(!kind_f64 || op == AGPU_RED_SUM, AGPU_ERR_UNSUPPORTED, "f64 partials are sums only");
@@ -193,9 +305,30 @@ agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p) {
   AGPU_BIND(p);
   agpu_status st = comm_check(c, p);
   if (st != AGPU_OK) return st;
+  comm_use use(c, p);
   AGPU_NCCL(ncclAllReduce(c->token, c->token, 1, ncclInt32, ncclMax, c->comm, p->stream));
-  AGPU_HIP(hipStreamSynchronize(p->stream));
-  return AGPU_OK;
+  const int64_t limit = comm_timeout_ms();
+  if (limit <= 0) {
+    AGPU_HIP(hipStreamSynchronize(p->stream));
+    return AGPU_OK;
+  }
+  // a peer that died never joins the all-reduce and the stream would never drain: poll with a deadline instead
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 0;; spin++) {
+    hipError_t q = hipStreamQuery(p->stream);
+    if (q == hipSuccess) return AGPU_OK;
+    if (q != hipErrorNotReady) {
+      agpu_set_error("agpu_comm_barrier: %s", hipGetErrorString(q));
+      return AGPU_ERR_HIP;
+    }
+    if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spin & 255) == 255 &&
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > limit) {
+      agpu_set_error("agpu_comm_barrier: rank %d of %d waited %lld ms for the other ranks (AGPU_COMM_TIMEOUT_MS): exit this process",
+                     c->rank, c->world, (long long)limit);
+      return AGPU_ERR_HIP;
+    }
+  }
 }
 
 }  // extern "C"

@@ -3,8 +3,9 @@
 Not in the reference (it is single-device, single-queue: SURVEY §5); this is north_star's multi-GPU rule:
 one process per GPU, every rank owns ONE contiguous row range of the column, element-wise / compare / cast / bitmap
 kernels need no communication (outputs stay sharded), and only sum / min / max / popcount finish with a collective of
-ONE element per statistic over `torch.distributed` (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
-CPU tests).  The message is 4–8 bytes, so the collective is latency-bound and independent of the xGMI link rate.
+ONE 16-byte record per statistic over the C ABI's RCCL communicator (`Communicator`: rendezvous over a file with a
+deadline, over torch.distributed when the caller already has a group, or in-process between threads).  The message is
+tiny, so the collective is latency-bound and independent of the xGMI link rate.
 
 Shard boundaries fall on multiples of 512 rows so every rank owns whole 64-bit bitmap words and 2 KiB-aligned f32
 spans (16-byte vector path, no split validity words).
@@ -83,6 +84,134 @@ def read_ipc_shard(source, device, rank: int, world: int, columns=None) -> dict:
     return out
 
 
+def ranks_from_env(env=None):
+    """(rank, world, local_rank) from the launcher's environment — torch.distributed.run's names first, then Open MPI's
+    and Slurm's; (0, 1, 0) when none is set."""
+    import os
+
+    e = os.environ if env is None else env
+    for r, w, l in (("RANK", "WORLD_SIZE", "LOCAL_RANK"), ("OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_RANK"),
+                    ("SLURM_PROCID", "SLURM_NTASKS", "SLURM_LOCALID")):
+        if r in e and w in e:
+            rank, world = int(e[r]), int(e[w])
+            if world < 1 or not (0 <= rank < world):
+                raise ValueError(f"bad {r}={rank} / {w}={world}")
+            return rank, world, int(e.get(l, rank))
+    return 0, 1, 0
+
+
+def rendezvous_path_from_env(env=None) -> str:
+    """A path that is the same for all ranks of ONE launch and different for every other launch on the machine:
+    AGPU_RENDEZVOUS_FILE if set, else <tmp>/agpu_rdzv_<MASTER_PORT>_<run id>_<parent pid>_<parent start time> — all workers
+    of a single-node launch are children of the same launcher process."""
+    import os
+    import tempfile
+
+    e = os.environ if env is None else env
+    if e.get("AGPU_RENDEZVOUS_FILE"):
+        return e["AGPU_RENDEZVOUS_FILE"]
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open(f"/proc/{ppid}/stat") as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time in clock ticks since boot
+    except (OSError, IndexError):
+        pass
+    tag = "_".join(str(x) for x in (e.get("MASTER_PORT", "0"), e.get("TORCHELASTIC_RUN_ID", "none"),
+                                    e.get("TORCHELASTIC_RESTART_COUNT", "0"), ppid, start))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    return os.path.join(base, "agpu_rdzv_" + tag)
+
+
+def file_rendezvous(path: str, rank: int, world: int, make_payload=None, timeout_s: float = 60.0, payload_bytes: int = capi.COMM_ID_BYTES) -> bytes:
+    """Ship `payload_bytes` bytes from rank 0 to every rank through the filesystem, with a deadline and proof against files
+    left behind by an earlier run at the same path:
+      every rank r  writes  <path>.ready.<r> = a fresh 16-byte nonce                         (atomically: tmp + rename)
+      rank 0        waits for all `world` ready files, writes <path>.id = payload ‖ nonce_0 ‖ … ‖ nonce_{world-1}, and keeps
+                    re-reading the ready files — a nonce that changes (it had picked up an older run's file before this
+                    launch's rank replaced it) re-issues the id — until every rank has acknowledged
+      rank r        waits for an id file that carries ITS nonce at position r (a stale file cannot), writes
+                    <path>.ack.<r> = its nonce, and returns the payload.
+    A rank that never arrives makes the others raise TimeoutError after `timeout_s` instead of blocking in RCCL.
+    `make_payload` is called on rank 0 only, once."""
+    import os
+    import time
+
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank {rank} for world {world}")
+    nonce = os.urandom(16)
+
+    def put(name, data):
+        tmp = f"{name}.tmp.{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, name)
+
+    def get(name, size):
+        try:
+            with open(name, "rb") as f:
+                data = f.read()
+            return data if len(data) == size else None
+        except OSError:
+            return None
+
+    deadline = time.monotonic() + timeout_s
+    # acks and ids of an older run at this path: an ack can only be fresh AFTER rank 0 has issued an id, so rank 0 may
+    # safely clear them all before it starts
+    for stale in ([f"{path}.id"] + [f"{path}.ack.{r}" for r in range(world)] if rank == 0 else [f"{path}.ack.{rank}"]):
+        try:
+            os.unlink(stale)
+        except OSError:
+            pass
+    put(f"{path}.ready.{rank}", nonce)
+    id_size = payload_bytes + 16 * world
+    if rank != 0:
+        while True:
+            data = get(f"{path}.id", id_size)
+            if data is not None and data[payload_bytes + 16 * rank: payload_bytes + 16 * (rank + 1)] == nonce:
+                put(f"{path}.ack.{rank}", nonce)
+                return data[:payload_bytes]
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rendezvous at {path}: rank {rank} saw no id from rank 0 within {timeout_s} s")
+            time.sleep(0.005)
+    payload, issued = None, None
+    while True:
+        nonces = [get(f"{path}.ready.{r}", 16) for r in range(world)]
+        nonces[0] = nonce
+        if all(x is not None for x in nonces):
+            if payload is None:
+                payload = make_payload()
+                if len(payload) != payload_bytes:
+                    raise ValueError("payload size")
+            if nonces != issued:
+                put(f"{path}.id", payload + b"".join(nonces))
+                issued = nonces
+            if all(get(f"{path}.ack.{r}", 16) == issued[r] for r in range(1, world)):
+                return payload
+        if time.monotonic() > deadline:
+            missing = [r for r in range(world) if nonces[r] is None] or \
+                      [r for r in range(1, world) if get(f"{path}.ack.{r}", 16) != (issued or nonces)[r]]
+            raise TimeoutError(f"rendezvous at {path}: ranks {missing} of {world} never arrived within {timeout_s} s")
+        time.sleep(0.005)
+
+
+def file_rendezvous_cleanup(path: str, rank: int, wait_s: float = 5.0) -> None:
+    """Remove this rank's files.  Rank 0 returns from `file_rendezvous` only after every ack, so it may delete the id at
+    once; the others keep their ack until the id has gone (rank 0 may not have read the ack yet), for at most `wait_s`."""
+    import os
+    import time
+
+    if rank != 0:
+        t0 = time.monotonic()
+        while os.path.exists(f"{path}.id") and time.monotonic() - t0 < wait_s:
+            time.sleep(0.002)
+    for name in ([f"{path}.ready.{rank}", f"{path}.ack.{rank}"] + ([f"{path}.id"] if rank == 0 else [])):
+        try:
+            os.unlink(name)
+        except OSError:
+            pass
+
+
 def final_reduce(sum_t=None, min_t=None, max_t=None, count_t=None, group=None):
     """In-place final reduce of per-shard partials held in 1-element tensors (any device / backend).
 
@@ -115,14 +244,27 @@ class Communicator:
     `from_torch` uses an initialised torch.distributed group (gloo or nccl) for that one broadcast, `from_file` a path
     on a shared filesystem; a C++ host passes it between its per-GPU threads directly."""
 
-    def __init__(self, device, rank: int, world: int, unique_id: bytes):
+    def __init__(self, device, rank: int, world: int, unique_id: bytes, timeout_s: float | None = None):
+        """Collective: returns once all `world` ranks have arrived.  timeout_s: None = the library default
+        (AGPU_COMM_TIMEOUT_MS, 120 s), 0 = wait for ever; on a timeout ArrowErrorGPU is raised and the process should
+        exit (the pending RCCL rendezvous cannot be cancelled)."""
         if len(unique_id) != capi.COMM_ID_BYTES:
             raise ValueError("unique id must be 128 bytes")
         self.device, self.rank, self.world = device, rank, world
         h = C.c_void_p()
         idbuf = C.create_string_buffer(unique_id, capi.COMM_ID_BYTES)
-        capi.call("agpu_comm_init_rank", device._handle, idbuf, rank, world, C.byref(h))
+        if timeout_s is None:
+            capi.call("agpu_comm_init_rank", device._handle, idbuf, rank, world, C.byref(h))
+        else:
+            capi.call("agpu_comm_init_rank_timeout", device._handle, idbuf, rank, world, int(timeout_s * 1000), C.byref(h))
         self._h = h
+
+    @staticmethod
+    def runtime_info() -> str:
+        """Which librccl / libamdhip64 this process runs on (path + version)."""
+        buf = C.create_string_buffer(1024)
+        capi.call("agpu_comm_runtime_info", buf, len(buf))
+        return buf.value.decode()
 
     @staticmethod
     def unique_id() -> bytes:
@@ -146,21 +288,21 @@ class Communicator:
 
     @classmethod
     def from_file(cls, device, rank: int, world: int, path: str, timeout_s: float = 60.0) -> "Communicator":
-        import os
-        import time
+        """Torch-free rendezvous over a path every rank can see (one node: /tmp or /dev/shm).  See `file_rendezvous`."""
+        uid = file_rendezvous(path, rank, world, cls.unique_id if rank == 0 else None, timeout_s)
+        comm = cls(device, rank, world, uid, timeout_s=timeout_s)
+        file_rendezvous_cleanup(path, rank)
+        return comm
 
-        if rank == 0:
-            tmp = path + ".tmp"
-            with open(tmp, "wb") as f:
-                f.write(cls.unique_id())
-            os.replace(tmp, path)
-        t0 = time.time()
-        while not os.path.exists(path):
-            if time.time() - t0 > timeout_s:
-                raise TimeoutError(f"no communicator id at {path}")
-            time.sleep(0.01)
-        with open(path, "rb") as f:
-            return cls(device, rank, world, f.read())
+    @classmethod
+    def from_env(cls, device, timeout_s: float = 120.0) -> "Communicator":
+        """One rank per process as a launcher (torch.distributed.run, mpirun, srun, a shell loop) sets it up: RANK /
+        WORLD_SIZE (or OMPI_COMM_WORLD_RANK / _SIZE, SLURM_PROCID / SLURM_NTASKS) from the environment, the id through
+        `file_rendezvous` at `rendezvous_path_from_env()`.  Nothing of torch is imported."""
+        rank, world, _ = ranks_from_env()
+        if world == 1:
+            return cls.single(device)
+        return cls.from_file(device, rank, world, rendezvous_path_from_env(), timeout_s)
 
     # -- collectives (asynchronous on the pipeline's stream; results are 1-element device buffers)
     def reduce(self, pipeline, op: int, dtype: int, values, validity, n_local: int, out) -> None:

@@ -9,10 +9,16 @@ A "step" = one pass of the hot path over one batch of synthetic 1-billion-row co
 ranks per second.  Inputs are generated on the device (counter-based hash, include/arrow_gpu.h agpu_synth_*), outputs
 are pre-allocated; nothing but the two kernel launches per step is inside the timed region.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): every rank owns its own 1e9-row shard of a
-N×1e9-row column (row0 = rank·1e9) — chunk-sharded, no data-path collective, "scaling": "weak".  RCCL (torch
-"nccl" backend) is used only for the barrier/timing reduction and, after the timed region, for the final reduce of the
-per-shard sum/min/max (config 5), reported under "extra".
+N > 1 (launched by torch.distributed.run, one process per GPU): the workers do NOT import torch — rank / world /
+local rank come from the launcher's environment, the RCCL id travels through a file rendezvous with a deadline
+(arrow_gpu_amd/sharding.py), barriers and the timing reduction go through the C ABI's communicator (agpu_comm_*), so
+the whole process runs on ONE HIP + RCCL runtime (the one libarrow_gpu_hip.so links, printed in extra.runtime).
+  --scaling weak   (default) every rank owns its own 1e9-row shard of an N×1e9-row column (row0 = rank·1e9)
+  --scaling strong the 1e9-row column is cut into N contiguous shards (sharding.shard_rows: 125 M rows per GPU at N = 8)
+Chunk-sharded, no data-path collective.  A weak run also times a short strong-scaling leg on the resident shards
+(extra.strong_scaling), so that one launch per N yields both curves.  RCCL is used only for the barrier / timing
+reduction and, after the timed region, for the final reduce of the per-shard sum/min/max (config 5), under "extra".
+A rank that fails (or never arrives) makes every rank exit non-zero within the rendezvous deadline instead of hanging.
 
 Also printed in the same JSON line:
   roofline     — the dominant kernel (f32 add), algorithmic bytes per launch ÷ its mean duration measured with HIP
@@ -42,7 +48,69 @@ ADD_BYTES_PER_ROW = 12.0
 EQ_BYTES_PER_ROW = 8.5  # 8 data + 0.125 result bits + 0.375 validity in/out
 
 
-def cpu_baseline(sample_rows: int, gpu_windows=()):
+def _ulp_distance(x, y):
+    """ULPs between two f32 arrays (±0 equal, NaN only against NaN)."""
+    import numpy as np
+
+    def key(v):
+        b = v.view(np.int32).astype(np.int64)
+        return np.where(b < 0, -(b & 0x7FFFFFFF), b)
+
+    d = np.abs(key(x) - key(y))
+    nan = np.isnan(x) | np.isnan(y)
+    d[nan] = np.where(np.isnan(x[nan]) & np.isnan(y[nan]), 0, 1 << 40)
+    return int(d.max()) if d.size else 0
+
+
+def check_config_windows(cfg_windows):
+    """Oracle check of one 65 536-row window per extra.configs kernel (same synthetic columns, re-generated on the CPU).
+    Returns {name: "bit-exact" | "<= 1 ULP" | "MISMATCH…"}.  Only called from the cpu_baseline leg."""
+    import numpy as np
+
+    import oracle as O
+
+    out = {}
+    for name, w in cfg_windows.items():
+        cnt, r0, got = w["rows"], w["row"], w["got"]
+        fa = lambda: O.synth_f32(cnt, SEED, r0, -1000.0, 1000.0)  # noqa: E731
+        fb = lambda: O.synth_f32(cnt, SEED + 1, r0, -1000.0, 1000.0)  # noqa: E731
+        ia = lambda: O.synth_i32(cnt, SEED + 2, r0, 1024)  # noqa: E731
+        ib = lambda: O.synth_i32(cnt, SEED + 3, r0, 1024)  # noqa: E731
+        u8 = lambda: O.synth_u8(cnt, SEED + 6, r0)  # noqa: E731
+        ulp = None
+        if name in ("sub_f32", "mul_f32", "div_f32"):
+            exp = O.binary({"sub_f32": O.OP_SUB, "mul_f32": O.OP_MUL, "div_f32": O.OP_DIV}[name], O.F32, fa(), fb())
+        elif name == "add_scalar_f32":
+            exp = O.scalar(O.OP_ADD, O.F32, fa(), np.array([100.0], np.float32))
+        elif name in ("lt_i32_validity", "gt_i32_validity"):
+            bits = O.compare(O.CMP_LT if name.startswith("lt") else O.CMP_GT, O.I32, ia(), ib())
+            vd = O.bitmap_binary(O.OP_AND, O.synth_bits(cnt, SEED + 4, r0, 0.9), O.synth_bits(cnt, SEED + 5, r0, 0.9), cnt)
+            exp = np.concatenate([bits[: cnt // 8], vd[: cnt // 8]])
+        elif name == "eq_i32_unfused":
+            exp = O.compare(O.CMP_EQ, O.I32, ia(), ib())[: cnt // 8]
+        elif name == "validity_and":
+            exp = O.bitmap_binary(O.OP_AND, O.synth_bits(cnt, SEED + 4, r0, 0.9), O.synth_bits(cnt, SEED + 5, r0, 0.9), cnt)[: cnt // 8]
+        elif name == "cast_u8_f32":
+            exp = O.cast(O.U8, O.F32, u8())
+        elif name in ("sin_f32", "cos_f32"):
+            exp = O.unary(O.UN_SIN if name == "sin_f32" else O.UN_COS, O.F32, O.cast(O.U8, O.F32, u8()))
+            ulp = 1
+        elif name in ("sin_u8", "cos_u8"):
+            exp = O.unary(O.UN_SIN if name == "sin_u8" else O.UN_COS, O.U8, u8())
+            ulp = 1
+        else:
+            out[name] = "unchecked"
+            continue
+        if ulp is None:
+            ok = np.array_equal(np.asarray(got).view(np.uint8), np.asarray(exp).view(np.uint8)[: np.asarray(got).nbytes])
+            out[name] = "bit-exact" if ok else "MISMATCH"
+        else:
+            d = _ulp_distance(np.asarray(got, np.float32), np.asarray(exp, np.float32))
+            out[name] = f"<= {ulp} ULP vs f64 libm rounded once (max {d})" if d <= ulp else f"MISMATCH (max {d} ULP)"
+    return out
+
+
+def cpu_baseline(sample_rows: int, gpu_windows=(), cfg_windows=None):
     """The CPU leg: time the CPU port on a bounded sample of the same workload, and use the oracle as the CHECKER of
     windows of the GPU outputs the timed steps produced.  Test/bench infrastructure only (oracle/)."""
     import numpy as np
@@ -133,6 +201,11 @@ def cpu_baseline(sample_rows: int, gpu_windows=()):
                                  "CPU quota throttles larger teams; DRAM-bound, a reported context line"},
            "cpu_model": model, "nproc": os.cpu_count(), "cgroup_cpu_max": _cgroup_cpu_max(),
            "gpu_parity": parity}
+    if cfg_windows:
+        try:
+            res["configs_parity"] = check_config_windows(cfg_windows)
+        except Exception as e:  # noqa: BLE001 — reported, the headline stands
+            res["configs_parity"] = {"error": repr(e)}
     # the reference's own criterion workloads, CPU side (same port library): f32 column + scalar at 10 Mi rows, u32 sum
     # at 1 Mi / 10 Mi rows [crates/benchmarks/benches/compare_gpu_arrow.rs:18-43, compare_sum.rs:17-40]
     try:
@@ -205,41 +278,43 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=ROWS, help="rows per GPU shard (default 1e9 = the BASELINE config)")
+    ap.add_argument("--rows", type=int, default=ROWS, help="rows per GPU shard (weak) / rows in total (strong); default 1e9 = the BASELINE config")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank owns --rows rows; strong: --rows rows in total, cut into one contiguous shard per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip extra.configs / extra.layout_pool / extra.strong_scaling")
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
+    ap.add_argument("--rendezvous-timeout", type=float, default=120.0)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    # launched by torch.distributed.run (RANK set) → join the RCCL process group even at world size 1, so the exact
-    # code path the 2/4/8-GPU runs take (init, barrier, all_reduce) is exercised on a single-GPU box too
-    distributed = "RANK" in os.environ and "MASTER_PORT" in os.environ
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
+    # NOTHING of torch is imported by a worker: the process runs on the HIP + RCCL that libarrow_gpu_hip.so links
+    # (/opt/rocm), not on torch's bundled copies — one runtime.
     from arrow_gpu_amd import _capi as capi
+    from arrow_gpu_amd import sharding
     from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
 
-    from arrow_gpu_amd import sharding
-
-    # weak scaling: the column has world × rows rows, this rank owns one contiguous chunk of it
-    shard = sharding.shard_rows(args.rows * world, world, rank)
-    n, row0 = shard.rows, shard.row0
-    dev = GpuDevice(local_rank)
+    rank, world, local_rank = sharding.ranks_from_env()
+    if world != args.gpus and rank == 0:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                             "--master-port P bench.py --gpus N ...")
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; using {world}", file=sys.stderr)
+    dev = GpuDevice(local_rank)  # ArrowErrorGPU(NoDevice) without an MI355X: the HIP path has no CPU fallback
     p = ArrowComputePipeline(dev, "bench")
     h = p._handle
+    # the same communicator code path at every world size (world 1 = a one-rank RCCL communicator): init, barrier,
+    # all-reduce are exercised on a single-GPU box too
+    comm = sharding.Communicator.from_env(dev, timeout_s=args.rendezvous_timeout)
+    runtime = sharding.Communicator.runtime_info()
+    if rank == 0:
+        print(f"bench.py: world {world}, {runtime}", file=sys.stderr)
+
+    if args.scaling == "weak":  # the column has world × rows rows, this rank owns one contiguous chunk of it
+        shard = sharding.shard_rows(args.rows * world, world, rank)
+    else:  # the column has `rows` rows in total
+        shard = sharding.shard_rows(args.rows, world, rank)
+    n, row0 = shard.rows, shard.row0
+    total_rows = args.rows * world if args.scaling == "weak" else args.rows
     vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
     nb = (n + 63) // 64 * 8
 
@@ -248,12 +323,16 @@ def main():
     # different hash classes — adjacent columns of a table differ in the strongest hash bit
     fa, fb, fo = dev.create_table_buffers([4 * n] * 3)
     ia, ib, va, vb, ob, ov = dev.create_table_buffers([4 * n] * 2 + [nb] * 4)
-    capi.call("agpu_synth_f32", h, vp(fa), n, SEED, row0, C.c_float(-1000.0), C.c_float(1000.0))
-    capi.call("agpu_synth_f32", h, vp(fb), n, SEED + 1, row0, C.c_float(-1000.0), C.c_float(1000.0))
-    capi.call("agpu_synth_i32", h, vp(ia), n, SEED + 2, row0, 1024)
-    capi.call("agpu_synth_i32", h, vp(ib), n, SEED + 3, row0, 1024)
-    capi.call("agpu_synth_bits", h, vp(va), n, SEED + 4, row0, C.c_double(0.9))
-    capi.call("agpu_synth_bits", h, vp(vb), n, SEED + 5, row0, C.c_double(0.9))
+
+    def synth_inputs(fa, fb, ia, ib, va, vb):
+        capi.call("agpu_synth_f32", h, vp(fa), n, SEED, row0, C.c_float(-1000.0), C.c_float(1000.0))
+        capi.call("agpu_synth_f32", h, vp(fb), n, SEED + 1, row0, C.c_float(-1000.0), C.c_float(1000.0))
+        capi.call("agpu_synth_i32", h, vp(ia), n, SEED + 2, row0, 1024)
+        capi.call("agpu_synth_i32", h, vp(ib), n, SEED + 3, row0, 1024)
+        capi.call("agpu_synth_bits", h, vp(va), n, SEED + 4, row0, C.c_double(0.9))
+        capi.call("agpu_synth_bits", h, vp(vb), n, SEED + 5, row0, C.c_double(0.9))
+
+    synth_inputs(fa, fb, ia, ib, va, vb)
     p.sync()
 
     def ev():
@@ -261,56 +340,82 @@ def main():
         capi.call("agpu_event_create", dev._handle, C.byref(e))
         return e
 
-    add_ev = [(ev(), ev()) for _ in range(args.steps)]
-    eq_ev = [(ev(), ev()) for _ in range(args.steps)]
-
-    def step(i=None):
-        if i is not None:
-            capi.call("agpu_event_record", add_ev[i][0], h)
-        capi.call("agpu_binary", h, capi.OP_ADD, capi.F32, vp(fa), vp(fb), vp(fo), n)
-        if i is not None:
-            capi.call("agpu_event_record", add_ev[i][1], h)
-            capi.call("agpu_event_record", eq_ev[i][0], h)
-        capi.call("agpu_compare_validity", h, capi.CMP_EQ, capi.I32, vp(ia), vp(ib), vp(va), vp(vb), vp(ob), vp(ov), n)
-        if i is not None:
-            capi.call("agpu_event_record", eq_ev[i][1], h)
-
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def ms_between(s, e):
+        ms = C.c_float()
+        capi.call("agpu_event_elapsed_ms", s, e, C.byref(ms))
+        return ms.value
 
     def mean_ms(pairs):
-        tot = 0.0
-        for s, e in pairs:
-            ms = C.c_float()
-            capi.call("agpu_event_elapsed_ms", s, e, C.byref(ms))
-            tot += ms.value
-        return tot / max(len(pairs), 1)
+        return sum(ms_between(s, e) for s, e in pairs) / max(len(pairs), 1)
 
-    add_ms, eq_ms = mean_ms(add_ev), mean_ms(eq_ev)
-    step_bytes = (ADD_BYTES_PER_ROW + EQ_BYTES_PER_ROW) * n
-    value = step_bytes * args.steps * world / elapsed / 1e9
+    def make_step(bufs, rows):
+        fa_, fb_, fo_, ia_, ib_, va_, vb_, ob_, ov_ = bufs
+
+        def step(evs=None):
+            if evs is not None:
+                capi.call("agpu_event_record", evs[0][0], h)
+            capi.call("agpu_binary", h, capi.OP_ADD, capi.F32, vp(fa_), vp(fb_), vp(fo_), rows)
+            if evs is not None:
+                capi.call("agpu_event_record", evs[0][1], h)
+                capi.call("agpu_event_record", evs[1][0], h)
+            capi.call("agpu_compare_validity", h, capi.CMP_EQ, capi.I32, vp(ia_), vp(ib_), vp(va_), vp(vb_), vp(ob_), vp(ov_), rows)
+            if evs is not None:
+                capi.call("agpu_event_record", evs[1][1], h)
+        return step
+
+    def barrier():
+        comm.barrier(p)  # RCCL all-reduce of one word + host wait on the stream (with a deadline)
+        dev.sync()
+
+    stat_buf = dev.create_empty_buffer(64)
+
+    def across_ranks(values, op):
+        """MIN / MAX / SUM of a few f64 over the ranks through the C ABI's communicator (identity at world 1)."""
+        import numpy as np
+
+        arr = np.array(values, np.float64)
+        capi.call("agpu_upload", h, vp(stat_buf), C.c_void_p(arr.ctypes.data), arr.nbytes)
+        comm.all_reduce(p, op, capi.COMM_F64, stat_buf, len(values))
+        out = np.empty_like(arr)
+        capi.call("agpu_download", h, C.c_void_p(out.ctypes.data), vp(stat_buf), arr.nbytes)
+        return [float(x) for x in out]
+
+    def timed_run(step, steps, warmup):
+        """The contract's timed region: warm-up, barrier + device sync, EXACTLY `steps` steps, barrier + device sync; MAX over
+        ranks.  Also the per-kernel HIP-event means of this rank and their min / max over ranks (a straggler shows up here)."""
+        add_ev = [(ev(), ev()) for _ in range(steps)]
+        eq_ev = [(ev(), ev()) for _ in range(steps)]
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step((add_ev[i], eq_ev[i]))
+        barrier()
+        mine = time.perf_counter() - t0
+        add_ms, eq_ms = mean_ms(add_ev), mean_ms(eq_ev)
+        for pair in add_ev + eq_ev:
+            for e in pair:
+                capi.lib().agpu_event_destroy(e)
+        lo = across_ranks([mine, add_ms, eq_ms], capi.RED_MIN)
+        hi = across_ranks([mine, add_ms, eq_ms], capi.RED_MAX)
+        per_rank = {"elapsed_s": {"min": round(lo[0], 6), "max": round(hi[0], 6)},
+                    "add_ms": {"min": round(lo[1], 4), "max": round(hi[1], 4)},
+                    "eq_ms": {"min": round(lo[2], 4), "max": round(hi[2], 4)}}
+        return hi[0], add_ms, eq_ms, per_rank
+
+    main_bufs = (fa, fb, fo, ia, ib, va, vb, ob, ov)
+    elapsed, add_ms, eq_ms, per_rank = timed_run(make_step(main_bufs, n), args.steps, args.warmup)
+    step_bytes_per_row = ADD_BYTES_PER_ROW + EQ_BYTES_PER_ROW
+    value = step_bytes_per_row * total_rows * args.steps / elapsed / 1e9
     add_gbps = ADD_BYTES_PER_ROW * n / add_ms / 1e6
     eq_gbps = EQ_BYTES_PER_ROW * n / eq_ms / 1e6
 
     # ---- windows of the benchmarked 1e9-row outputs, downloaded for the CPU-baseline leg to check against the oracle
     # (the oracle is only ever touched inside cpu_baseline(); the product path above never sees it)
     windows = []
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if want_cpu:
         import numpy as np
 
         w = 1 << 16
@@ -323,14 +428,30 @@ def main():
             capi.call("agpu_download", h, C.c_void_p(gv.ctypes.data), C.c_void_p(ov.ptr + start // 8), nbytes)
             windows.append({"row": row0 + start, "rows": cnt, "add": got, "eq_bits": gb, "eq_validity": gv})
 
+    extra = {"runtime": runtime, "per_rank": per_rank}
+
+    # ---- strong-scaling leg of a weak run: the same step over this rank's share of a `rows`-row column (shard_rows cuts
+    # it: 125 M rows per GPU at world 8), on the leading rows of the resident shards; same barrier-bracketed timing.
+    # One launch per N then yields both curves.  At world 1 strong == weak, nothing to add.
+    if world > 1 and args.scaling == "weak" and not args.no_extra_configs:
+        try:
+            ns = sharding.shard_rows(args.rows, world, rank).rows
+            el_s, add_s, eq_s, pr_s = timed_run(make_step(main_bufs, ns), args.steps, args.warmup)
+            extra["strong_scaling"] = {
+                "scaling": "strong", "rows_total": args.rows, "rows_per_gpu": ns, "steps": args.steps,
+                "value_GBps": round(step_bytes_per_row * args.rows * args.steps / el_s / 1e9, 2),
+                "ms_per_step": round(el_s / args.steps * 1e3, 4), "rank0_add_ms": round(add_s, 4), "rank0_eq_ms": round(eq_s, 4),
+                "per_rank": pr_s,
+                "what": "the 1e9-row column cut into `world` contiguous shards (sharding.shard_rows); same step, same "
+                        "barrier-bracketed region, MAX over ranks; run on the leading rows of the weak run's resident shards"}
+        except Exception as e:  # noqa: BLE001
+            extra["strong_scaling"] = {"error": f"{type(e).__name__}: {e}"}
+
     # ---- config 5: per-shard sum/min/max + final reduce over RCCL (outside the timed region).  Everything below goes
     # through the C ABI's communicator (include/arrow_gpu.h "multi-GPU"): agpu_comm_reduce = the shard-local kernel
-    # (for SUM the reference-order tree, sum_tree_quarter_kernel + sum_tree_combine_kernel) + an all-gather of one 16-byte record per rank + the
-    # rank-ordered combine.  The rendezvous id travels over the torch.distributed group when one exists; a plain
-    # `python bench.py` builds a world of one rank, so the RCCL path runs on every box.
-    extra = {}
+    # (for SUM the reference-order tree, sum_tree_quarter_kernel + sum_tree_combine_kernel) + an all-gather of one 16-byte
+    # record per rank + the rank-ordered combine.
     try:  # the headline line must come out even if this leg cannot run (it is reported, not part of `value`)
-        comm = sharding.Communicator.from_torch(dev) if distributed else sharding.Communicator.single(dev)
         stat_out = {k: dev.create_empty_buffer(16) for k in ("sum", "min", "max", "sum_f64")}
         p.sync()
         stats = {}
@@ -352,7 +473,7 @@ def main():
         # the collective form: local kernel + RCCL all-gather + combine, timed end to end on the stream
         cs, ce = ev(), ev()
         comm.reduce(p, capi.RED_SUM, capi.F32, fa, None, n, stat_out["sum"])  # warm RCCL's first-call setup
-        p.sync()
+        barrier()
         capi.call("agpu_event_record", cs, h)
         comm.reduce(p, capi.RED_SUM, capi.F32, fa, None, n, stat_out["sum"])
         comm.reduce(p, capi.RED_MIN, capi.F32, fa, None, n, stat_out["min"])
@@ -360,27 +481,120 @@ def main():
         comm.reduce_sum_f64(p, fa, None, n, stat_out["sum_f64"])
         capi.call("agpu_event_record", ce, h)
         p.sync()
-        ms = C.c_float()
-        capi.call("agpu_event_elapsed_ms", cs, ce, C.byref(ms))
+        four_ms = ms_between(cs, ce)
         import numpy as _np
 
         def scalar(buf, dt):
             return dev.retrive_data(buf, _np.dtype(dt).itemsize, pipeline=p).view(dt)[0]
 
         local_sum_ms = sum(stats[k]["local_ms"] for k in ("sum", "min", "max", "sum_f64"))
+        four_max = across_ranks([four_ms], capi.RED_MAX)[0]
         extra["reduce_sum_min_max"] = {
-            "rows_total": n * world, "sum_f32_reference_tree": float(scalar(stat_out["sum"], _np.float32)),
+            "rows_total": total_rows, "sum_f32_reference_tree": float(scalar(stat_out["sum"], _np.float32)),
             "min": float(scalar(stat_out["min"], _np.float32)), "max": float(scalar(stat_out["max"], _np.float32)),
             "sum_f64": float(scalar(stat_out["sum_f64"], _np.float64)), "per_statistic": stats,
-            "four_statistics_with_final_reduce_ms": round(ms.value, 4),
-            "final_reduce_overhead_ms": round(ms.value - local_sum_ms, 4),
+            "four_statistics_with_final_reduce_ms": round(four_ms, 4),
+            "four_statistics_with_final_reduce_ms_max_over_ranks": round(four_max, 4),
+            "aggregate_GBps": round(4 * 4.0 * total_rows / four_max / 1e6, 1),
+            "final_reduce_overhead_ms": round(four_ms - local_sum_ms, 4),
             "final_reduce": f"C ABI agpu_comm_reduce: RCCL all-gather of one 16-byte record per rank (world {world}) + rank-ordered combine",
         }
-        comm.close()
     except Exception as e:  # noqa: BLE001
         extra["reduce_sum_min_max"] = {"error": f"{type(e).__name__}: {e}"}
     extra["kernels"] = {"add_f32": {"ms": round(add_ms, 4), "GBps": round(add_gbps, 1), "frac_hbm_peak": round(add_gbps / HBM_PEAK_GBPS, 4)},
                         "eq_i32_validity": {"ms": round(eq_ms, 4), "GBps": round(eq_gbps, 1), "frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4)}}
+
+    # ---- every other kernel BASELINE.json's configs 2–4 name, at the same 1e9 rows: median of 9 HIP-event timings after
+    # 2 untimed launches, algorithmic bytes per row, fraction of the 8 TB/s roof; one 65 536-row window each goes to the
+    # cpu_baseline leg for the oracle.  Reported beside the headline; not part of `value`.
+    cfg_windows = {}
+    if rank == 0 and world == 1 and not args.no_extra_configs:
+        try:
+            import numpy as np
+
+            u8, = dev.create_table_buffers([n])
+            sc = dev.create_gpu_buffer_with_data(np.array([100.0], np.float32))
+            capi.call("agpu_synth_u8", h, vp(u8), n, SEED + 6, row0)
+            ov2 = dev.create_empty_buffer(nb)
+            wrow = (n // 2) // 64 * 64
+            wcnt = min(1 << 16, n - wrow)
+
+            def grab(buf, itemsize_bits, dtype, count):
+                nbytes = count * itemsize_bits // 8
+                got = np.empty(nbytes, np.uint8)
+                capi.call("agpu_download", h, C.c_void_p(got.ctypes.data), C.c_void_p(buf.ptr + wrow * itemsize_bits // 8), nbytes)
+                return got.view(dtype)
+
+            def timed(launch, reps=9):
+                launch(), launch()
+                pairs = [(ev(), ev()) for _ in range(reps)]
+                for s_, e_ in pairs:
+                    capi.call("agpu_event_record", s_, h)
+                    launch()
+                    capi.call("agpu_event_record", e_, h)
+                ts = sorted(ms_between(s_, e_) for s_, e_ in pairs)
+                for pr in pairs:
+                    for e in pr:
+                        capi.lib().agpu_event_destroy(e)
+                return ts[len(ts) // 2]
+
+            cfgs = {}
+
+            def record(name, config, bpr, launch, window):
+                ms = timed(launch)
+                gbps = bpr * n / ms / 1e6
+                cfgs[name] = {"config": config, "alg_bytes_per_row": bpr, "ms": round(ms, 4), "GBps": round(gbps, 1),
+                              "frac_hbm_peak": round(gbps / HBM_PEAK_GBPS, 4)}
+                if want_cpu:
+                    cfg_windows[name] = {"row": row0 + wrow, "rows": wcnt, "got": window()}
+
+            for nm, op in (("sub_f32", capi.OP_SUB), ("mul_f32", capi.OP_MUL), ("div_f32", capi.OP_DIV)):
+                record(nm, 2, 12.0, lambda op=op: capi.call("agpu_binary", h, op, capi.F32, vp(fa), vp(fb), vp(fo), n),
+                       lambda: grab(fo, 32, np.float32, wcnt))
+            record("add_scalar_f32", 2, 8.0, lambda: capi.call("agpu_scalar", h, capi.OP_ADD, capi.F32, vp(fa), vp(sc), vp(fo), n),
+                   lambda: grab(fo, 32, np.float32, wcnt))
+            for nm, op in (("lt_i32_validity", capi.CMP_LT), ("gt_i32_validity", capi.CMP_GT)):
+                record(nm, 3, 8.5, lambda op=op: capi.call("agpu_compare_validity", h, op, capi.I32, vp(ia), vp(ib), vp(va), vp(vb), vp(ob), vp(ov), n),
+                       lambda: np.concatenate([grab(ob, 1, np.uint8, wcnt), grab(ov, 1, np.uint8, wcnt)]))
+            record("eq_i32_unfused", 3, 8.125, lambda: capi.call("agpu_compare", h, capi.CMP_EQ, capi.I32, vp(ia), vp(ib), vp(ob), n),
+                   lambda: grab(ob, 1, np.uint8, wcnt))
+            record("validity_and", 3, 0.375, lambda: capi.call("agpu_bitmap_binary", h, capi.OP_AND, vp(va), vp(vb), vp(ov2), n),
+                   lambda: grab(ov2, 1, np.uint8, wcnt))
+            record("cast_u8_f32", 4, 5.0, lambda: capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u8), vp(fo), n),
+                   lambda: grab(fo, 32, np.float32, wcnt))
+            # fo now holds f32(u8 column): the input of the stand-alone sin / cos; results go to the add's output table slot
+            # of the second input (fb is re-generated below)
+            for nm, op in (("sin_f32", capi.UN_SIN), ("cos_f32", capi.UN_COS)):
+                record(nm, 4, 8.0, lambda op=op: capi.call("agpu_unary", h, op, capi.F32, vp(fo), vp(fb), n),
+                       lambda: grab(fb, 32, np.float32, wcnt))
+            for nm, op in (("sin_u8", capi.UN_SIN), ("cos_u8", capi.UN_COS)):
+                record(nm, 4, 5.0, lambda op=op: capi.call("agpu_unary", h, op, capi.U8, vp(u8), vp(fb), n),
+                       lambda: grab(fb, 32, np.float32, wcnt))
+            capi.call("agpu_synth_f32", h, vp(fb), n, SEED + 1, row0, C.c_float(-1000.0), C.c_float(1000.0))
+            cfgs["what"] = ("BASELINE.json configs 2-4 beyond the headline pair, same rows, table-placed buffers: median of 9 HIP-event "
+                            "timings after 2 untimed launches; parity of one 65536-row window each in cpu_baseline.configs_parity")
+            extra["configs"] = cfgs
+            del u8, ov2, sc
+        except Exception as e:  # noqa: BLE001
+            extra["configs"] = {"error": f"{type(e).__name__}: {e}"}
+        # ---- the headline step with nine ORDINARY agpu_malloc blocks (what a caller of the host API gets) instead of the
+        # two placed tables
+        try:
+            sizes = [4 * n] * 3 + [4 * n] * 2 + [nb] * 4
+            pool = [dev.create_empty_buffer(sz) for sz in sizes]
+            pfa, pfb, pfo, pia, pib, pva, pvb, pob, pov = pool
+            synth_inputs(pfa, pfb, pia, pib, pva, pvb)
+            p.sync()
+            el_p, add_p, eq_p, _ = timed_run(make_step(tuple(pool), n), min(args.steps, 10), 2)
+            extra["layout_pool"] = {
+                "value_GBps": round(step_bytes_per_row * n * min(args.steps, 10) / el_p / 1e9, 2),
+                "add_ms": round(add_p, 4), "add_frac_hbm_peak": round(ADD_BYTES_PER_ROW * n / add_p / 1e6 / HBM_PEAK_GBPS, 4),
+                "eq_ms": round(eq_p, 4), "eq_frac_hbm_peak": round(EQ_BYTES_PER_ROW * n / eq_p / 1e6 / HBM_PEAK_GBPS, 4),
+                "what": "the same step over nine ordinary agpu_malloc blocks (the allocator's own placement, DESIGN.md §3) — "
+                        "what an a.add(b) / a.eq(b) caller of the host API gets"}
+            del pool, pfa, pfb, pfo, pia, pib, pva, pvb, pob, pov
+        except Exception as e:  # noqa: BLE001
+            extra["layout_pool"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- the reference's own criterion workloads on the GPU, through the HOST API exactly as its benches call it
     # (add_dyn(column, 1-element column) at 10 Mi rows; UInt32ArrayGPU::broadcast(2, n).sum() at 1 Mi / 10 Mi rows)
@@ -421,13 +635,16 @@ def main():
                 traffic = json.load(open(tpath)).get("add_f32_bytes_per_launch")
             except Exception:
                 traffic = None
+        shard_txt = (f"chunk-sharded x{world}: every rank owns its own {args.rows}-row shard of a {total_rows}-row column"
+                     if args.scaling == "weak" else
+                     f"chunk-sharded x{world}: one {total_rows}-row column cut into {world} contiguous shards (sharding.shard_rows)")
         line = {
             "metric": "GB/s on 1B-row f32 add + i32 eq (algorithmic bytes, inputs resident in HBM)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32+i32", "data": "synthetic",
             "config": {"workload": "f32 add (1e9 rows, no nulls) + i32 eq -> bitmap with fused validity AND (1e9 rows, 10% nulls/side)",
-                       "rows_per_gpu": n, "sharding": f"chunk-sharded x{world}, no data-path collective",
+                       "rows_per_gpu": n, "rows_total": total_rows, "sharding": shard_txt + ", no data-path collective",
                        "layout": "columns allocated as two tables placed for the HBM channel hash (agpu_malloc_table, DESIGN.md §3)",
                        "frac_hbm_peak_per_gpu": round(value / world / HBM_PEAK_GBPS, 4)},
             "roofline": {"bound": "hbm", "kernel": "ew_kernel<float, OpAdd> (agpu_binary ADD f32)",
@@ -440,9 +657,9 @@ def main():
                          "algorithmic_bytes_per_launch": ADD_BYTES_PER_ROW * n, "launch_ms": round(add_ms, 4)},
             "extra": extra,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if want_cpu:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, windows)
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, windows, cfg_windows)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         else:
@@ -453,10 +670,18 @@ def main():
             pass
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    barrier()  # nobody tears its communicator down while rank 0 still measures the CPU leg… (world 1 only) / prints
+    comm.close()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:  # noqa: BLE001 — a failed rank must END (a pending RCCL rendezvous thread would keep the process alive)
+        import traceback
+
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

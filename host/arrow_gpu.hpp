@@ -1134,8 +1134,16 @@ class Communicator {
     check(agpu_comm_get_unique_id(id.data()), "agpu_comm_get_unique_id");
     return id;
   }
-  Communicator(const DevicePtr& dev, const Id& id, int rank_, int world_) : rank(rank_), world(world_) {
-    check(agpu_comm_init_rank(dev->raw, id.data(), rank_, world_, &raw), "agpu_comm_init_rank");  // collective
+  // collective: returns once all `world` ranks have arrived; timeout_ms < 0 = the library default (AGPU_COMM_TIMEOUT_MS,
+  // 120 s), 0 = wait for ever.  A timeout throws; the process should then exit (the pending rendezvous cannot be cancelled)
+  Communicator(const DevicePtr& dev, const Id& id, int rank_, int world_, int64_t timeout_ms = -1) : rank(rank_), world(world_) {
+    if (timeout_ms < 0) check(agpu_comm_init_rank(dev->raw, id.data(), rank_, world_, &raw), "agpu_comm_init_rank");
+    else check(agpu_comm_init_rank_timeout(dev->raw, id.data(), rank_, world_, timeout_ms, &raw), "agpu_comm_init_rank_timeout");
+  }
+  static std::string runtime_info() {
+    char buf[1024];
+    check(agpu_comm_runtime_info(buf, sizeof buf), "agpu_comm_runtime_info");
+    return buf;
   }
   Communicator(const Communicator&) = delete;
   ~Communicator() {

@@ -401,19 +401,30 @@ agpu_status agpu_index_max(agpu_pipeline* p, const uint32_t* idx, uint64_t n, ui
  * rank; a column is sharded into contiguous row ranges (cut on multiples of 512 rows: whole bitmap words, 2 KiB-aligned
  * f32 spans); every kernel above runs shard-local with no collective; only whole-column statistics finish over RCCL.
  *   rank 0: agpu_comm_get_unique_id(id) → ship the 128 bytes to the other ranks (pipe / file / torch.distributed …)
- *   all   : agpu_comm_init_rank(dev, id, rank, world, &comm)      — collective, blocks until all ranks arrived
+ *   all   : agpu_comm_init_rank(dev, id, rank, world, &comm)      — collective, waits until all ranks arrived — at most
+ *           AGPU_COMM_TIMEOUT_MS (default 120 000; 0 = for ever), then AGPU_ERR_HIP instead of hanging: exit the process
  *   all   : agpu_comm_reduce(comm, p, op, dtype, shard, validity, n_local, out_dev)   — collective, asynchronous on p
  * agpu_comm_reduce = shard-local agpu_reduce + an all-gather of ONE 16-byte record per rank + a single-workgroup
  * combine IN RANK ORDER on every rank (identical result everywhere, independent of RCCL's ring order):
  *   SUM f32  : the shard sums are combined by the reference's own adjacent-pair tree (zero-padded to 256), so shards of
  *              256^k rows reproduce the reference's whole-column tree bit for bit [ref: aggregate.wgsl:28-37];
  *   SUM ints : wrapping; MIN/MAX: Arrow semantics (NaN ignored unless all NaN); empty shards contribute the identity.
- * One statistic in flight per communicator (calls on one pipeline are stream-ordered, which is enough). */
+ * One statistic in flight per communicator: calls on one pipeline are stream-ordered, a call made on ANOTHER pipeline is
+ * ordered behind the previous one by an event (the record buffers are shared), and a mutex serialises host threads —
+ * every rank must still issue its collectives in the same order, as with any RCCL communicator. */
 #define AGPU_COMM_ID_BYTES 128
 typedef struct agpu_comm agpu_comm;
 typedef enum { AGPU_COMM_F32 = 0, AGPU_COMM_F64 = 1, AGPU_COMM_I32 = 2, AGPU_COMM_U32 = 3, AGPU_COMM_I64 = 4, AGPU_COMM_U64 = 5 } agpu_comm_dtype;
 agpu_status agpu_comm_get_unique_id(void* out_id /* AGPU_COMM_ID_BYTES */);
 agpu_status agpu_comm_init_rank(agpu_device* dev, const void* unique_id, int32_t rank, int32_t world, agpu_comm** out_comm);
+/* the same with an explicit deadline (timeout_ms <= 0: wait for ever).  On a timeout ncclCommInitRank is still pending on a
+ * helper thread that cannot be cancelled — report, and exit the process (a fresh process is the only clean retry). */
+agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id, int32_t rank, int32_t world,
+                                        int64_t timeout_ms, agpu_comm** out_comm);
+/* "rccl <version> (built against <version>) from <path of the loaded librccl>; hip runtime <version> from <path of the
+ * loaded libamdhip64>" — a process that imported torch first runs on torch's bundled copies, any other on /opt/rocm's;
+ * multi-GPU records print it so that they say which runtime they measured. */
+agpu_status agpu_comm_runtime_info(char* out, size_t out_cap);
 agpu_status agpu_comm_destroy(agpu_comm* c);
 agpu_status agpu_comm_rank(agpu_comm* c, int32_t* out_rank, int32_t* out_world);
 agpu_status agpu_comm_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, const void* in,
@@ -433,7 +444,8 @@ agpu_status agpu_reduce_combine(agpu_pipeline* p, agpu_reduce_op op, agpu_dtype 
 /* plain in-place ncclAllReduce (null counts, row counts: integer statistics whose order cannot matter) */
 agpu_status agpu_comm_all_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, agpu_comm_dtype ctype, void* buf_dev,
                                  uint64_t count);
-agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p); /* collective + host wait on p's stream */
+/* collective + host wait on p's stream; gives up with AGPU_ERR_HIP after AGPU_COMM_TIMEOUT_MS when a peer never joins */
+agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p);
 
 /* ---------------------------------------------------------------- Arrow C Data Interface
  * The reference builds arrays from host Vecs and reads them back as Vecs

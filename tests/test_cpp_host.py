@@ -103,13 +103,26 @@ def test_sharded_stats_example_matches_the_sharded_spec():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     world = line["world"]
-    assert line["identical_on_all_ranks"] is True and world >= 1
-    shards = [O.synth_f32(rows, 20250418, k * rows, -1.0, 1.0) for k in range(world)]
+    assert line["identical_on_all_ranks"] is True and world >= 1 and line["scaling"] == "weak"
+    assert line["value_GBps"] > 0 and line["add_ms"]["min"] > 0 and line["eq_ms"]["max"] >= line["eq_ms"]["min"] > 0
+    assert "librccl" in line["runtime"]
+    shards = [O.synth_f32(rows, 20250418, k * rows, -1000.0, 1000.0) for k in range(world)]
     exp = O.sharded_reduce(O.RED_SUM, O.F32, shards)
     assert np.float32(line["sum"]).view(np.uint32) == np.float32(exp).view(np.uint32), (line["sum"], exp)
     assert np.float32(line["min"]) == min(s.min() for s in shards) and np.float32(line["max"]) == max(s.max() for s in shards)
     if world == 1:
         assert np.float32(exp).view(np.uint32) == np.float32(O.reduce(O.RED_SUM, O.F32, shards[0])).view(np.uint32)
+    # strong mode: the same column cut into `world` shards (ragged total: the last shard is short)
+    total = 3_000_001
+    r = subprocess.run([S_EXE, str(total), str(world), "strong", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["rows_total"] == total and line["steps"] == 3
+    whole = O.synth_f32(total, 20250418, 0, -1000.0, 1000.0)
+    cuts = [(s.row0, s.row0 + s.rows) for s in __import__("arrow_gpu_amd.sharding", fromlist=["x"]).all_shards(total, world)]
+    exp = O.sharded_reduce(O.RED_SUM, O.F32, [whole[a:b] for a, b in cuts])
+    assert np.float32(line["sum"]).view(np.uint32) == np.float32(exp).view(np.uint32)
+    assert np.float32(line["min"]) == whole.min() and np.float32(line["max"]) == whole.max()
 
 
 # ---- Arrow C Data Interface from plain C (examples/arrow_cdata.c)

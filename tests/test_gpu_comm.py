@@ -149,3 +149,81 @@ def test_combine_of_many_ranks_records_matches_the_spec(ctx, world):
     for x in sums:
         acc = acc + float(x)
     assert dev.retrive_data(out, 8, pipeline=p).view(np.float64)[0] == acc
+
+
+# ---- round 3: first-contact proofing of the multi-rank path
+_TIMEOUT_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+from arrow_gpu_amd._capi import ArrowErrorGPU
+from arrow_gpu_amd.gpu_utils import GpuDevice
+from arrow_gpu_amd.sharding import Communicator
+dev = GpuDevice(0)
+t0 = time.monotonic()
+try:
+    Communicator(dev, 0, 2, Communicator.unique_id(), timeout_s=3.0)   # rank 1 of 2 never arrives
+except ArrowErrorGPU as e:
+    dt = time.monotonic() - t0
+    sys.stdout.write("TIMEOUT %.2f %s\n" % (dt, e))
+    sys.stdout.flush()
+    os._exit(0 if 2.5 < dt < 20 else 3)   # the pending RCCL rendezvous thread cannot be joined: end the process
+os._exit(4)
+"""
+
+
+def test_comm_init_gives_up_when_a_rank_never_arrives():
+    """agpu_comm_init_rank_timeout: rank 0 of a world of 2 alone → AGPU_ERR_HIP after the deadline, not a hang (a fresh
+    process: the pending ncclCommInitRank stays behind on its helper thread)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _TIMEOUT_WORKER.format(root=root)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "TIMEOUT" in r.stdout and "gave up after 3000 ms" in r.stdout
+
+
+def test_comm_shared_by_two_pipelines_is_ordered(ctx):
+    """the record buffers of a communicator are shared: a call made on ANOTHER pipeline is ordered behind the previous one
+    (two streams raced on c->send / c->recv)"""
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline
+
+    dev, p, comm = ctx
+    q = ArrowComputePipeline(dev, "comm-2")
+    n = 40_000_003
+    a, b = O.synth_f32(n, 21, 0, -1.0, 1.0), O.synth_f32(n, 22, 0, -1.0, 1.0)
+    da, db = dev.create_gpu_buffer_with_data(a), dev.create_gpu_buffer_with_data(b)
+    dev.sync()
+    outs = [dev.create_empty_buffer(16) for _ in range(8)]
+    for k in range(4):  # alternate streams without any host sync in between
+        comm.reduce(p, capi.RED_SUM, capi.F32, da, None, n, outs[2 * k])
+        comm.reduce(q, capi.RED_MAX, capi.F32, db, None, n, outs[2 * k + 1])
+    p.sync(), q.sync()
+    es, em = O.sharded_reduce(O.RED_SUM, O.F32, [a]), O.sharded_reduce(O.RED_MAX, O.F32, [b])
+    for k in range(4):
+        assert bits(dev.retrive_data(outs[2 * k], 4).view(np.float32)[0], np.float32) == bits(es, np.float32)
+        assert bits(dev.retrive_data(outs[2 * k + 1], 4).view(np.float32)[0], np.float32) == bits(em, np.float32)
+
+
+def test_comm_from_env_and_runtime_info(monkeypatch, tmp_path):
+    """the bench worker's way in: ranks from the environment, id over the file rendezvous — at world 1 here; and the
+    process reports which librccl / libamdhip64 it runs on (one runtime: no torch in this process's product path)"""
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+    from arrow_gpu_amd.sharding import Communicator
+
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.setenv(k, {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}[k])
+    dev = GpuDevice(0)
+    p = ArrowComputePipeline(dev, "env")
+    comm = Communicator.from_env(dev)
+    assert (comm.rank, comm.world) == (0, 1)
+    comm.barrier(p)
+    comm.close()
+    # the file path itself, world 1 (rank 0 is also the only reader)
+    comm = Communicator.from_file(dev, 0, 1, str(tmp_path / "id"), timeout_s=10.0)
+    comm.barrier(p)
+    comm.close()
+    assert list(tmp_path.iterdir()) == []
+    info = Communicator.runtime_info()
+    assert "rccl" in info and "librccl" in info and "libamdhip64" in info
