@@ -8,6 +8,7 @@
 // platform —, threaded page-locked staging, hipHostRegister in place); overlap of transfers with compute is the host
 // layer's job (two pipelines + agpu_pipeline_wait_pipeline: arrow_gpu_amd/interop.py map_chunks).
 #include <sys/mman.h>
+#include <unistd.h>
 
 #include <thread>
 
@@ -162,6 +163,63 @@ agpu_status agpu_internal_bounce_copy(agpu_pipeline* p, void* dev_ptr, void* hos
   return AGPU_OK;
 }
 
+// Does [ptr, ptr + bytes) touch the C heap proper — the brk segment, "[heap]" in /proc/self/maps?  glibc's dynamic mmap
+// threshold lets malloc serve blocks of up to 32 MiB from there once bigger ones have been freed, and that is the one kind
+// of host memory whose pages come and go under a running process (the heap top is trimmed and re-extended): a pageable
+// hipMemcpy — or hipHostRegister — pins such pages through a KFD userptr mapping, and that is what the GPU memory faults
+// of round 2 pointed at.  mmap'ed blocks (numpy arrays ≥ 128 KiB by default, Arrow buffers, files) are
+// separate mappings that live until the caller frees them.  The heap's start never moves; its end is sbrk(0).
+static bool host_range_in_brk_heap(const void* ptr, size_t bytes) {
+  static std::atomic<uintptr_t> heap_start{0};
+  uintptr_t start = heap_start.load(std::memory_order_relaxed);
+  if (!start) {
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (f) {
+      char line[512];
+      while (fgets(line, sizeof line, f))
+        if (strstr(line, "[heap]")) {
+          unsigned long long a = 0;
+          if (sscanf(line, "%llx-", &a) == 1) start = (uintptr_t)a;
+          break;
+        }
+      fclose(f);
+    }
+    if (!start) return false;  // no heap segment yet: nothing can live in it
+    heap_start.store(start, std::memory_order_relaxed);
+  }
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes, brk_now = reinterpret_cast<uintptr_t>(sbrk(0));
+  return lo < brk_now && hi > start;
+}
+
+// One host↔HBM copy of a caller's (possibly pageable) range that is COMPLETE on return, never handing heap pages to the
+// runtime: ≤ 4 MiB through the bounce slot, brk-heap ranges of any size through the page-locked chunk engine (mode 2's),
+// everything else — separate mappings — straight to the runtime at the link's rate.  agpu_upload / agpu_download and the
+// default staged copy all end here.
+agpu_status agpu_internal_host_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device) {
+  if (!bytes) return AGPU_OK;
+  // AGPU_HOST_COPY_DIRECT=1: hand every range to the runtime as it is — ONLY for tools/probe/heap_copy_stress.py --direct, the
+  // reproducer of the round-2 memory fault
+  static const bool direct = [] { const char* e = getenv("AGPU_HOST_COPY_DIRECT"); return e && *e && *e != '0'; }();
+  if (!p->capturing && !direct) {
+    if (bytes <= AGPU_BOUNCE_MAX_BYTES) return agpu_internal_bounce_copy(p, dev_ptr, host_ptr, bytes, to_device);
+    if (host_range_in_brk_heap(host_ptr, bytes)) {
+      agpu_status st = staged_copy_threads(p, static_cast<char*>(dev_ptr), static_cast<char*>(host_ptr), bytes, to_device);
+      if (st != AGPU_OK) return st;
+      AGPU_HIP(hipStreamSynchronize(p->stream));
+      return AGPU_OK;
+    }
+  }
+  if (to_device) AGPU_HIP(hipMemcpyAsync(dev_ptr, host_ptr, bytes, hipMemcpyHostToDevice, p->stream));
+  else AGPU_HIP(hipMemcpyAsync(host_ptr, dev_ptr, bytes, hipMemcpyDeviceToHost, p->stream));
+  AGPU_HIP(hipStreamSynchronize(p->stream));
+  return AGPU_OK;
+}
+// test hook (tests/test_gpu_host_copies.py): which path a host range would take — 0 bounce, 1 chunk engine (brk heap), 2 direct
+extern "C" int32_t agpu_internal_host_copy_path(const void* host_ptr, size_t bytes) {
+  if (bytes <= AGPU_BOUNCE_MAX_BYTES) return 0;
+  return host_range_in_brk_heap(host_ptr, bytes) ? 1 : 2;
+}
+
 static agpu_status staged_copy_impl(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device) {
   if (!bytes) return AGPU_OK;
   // auto = mode 1: measured on the MI355X box (tools/probe/h2d_sweep.py → profiles/r02_h2d_sweep.json, 1 GiB, EPYC 9575F host):
@@ -171,7 +229,8 @@ static agpu_status staged_copy_impl(agpu_pipeline* p, void* dev_ptr, void* host_
   // pageable copies slowly; it is not the default anywhere.
   int64_t mode = p->tune.h2d_mode;
   if (mode <= 0 || mode > 3) mode = 1;
-  if (mode == 1 && bytes <= AGPU_BOUNCE_MAX_BYTES) return agpu_internal_bounce_copy(p, dev_ptr, host_ptr, bytes, to_device);
+  if (mode == 1) return agpu_internal_host_copy(p, dev_ptr, host_ptr, bytes, to_device);
+  if (mode == 3 && host_range_in_brk_heap(host_ptr, bytes)) mode = 2;  // registering heap pages in place is the same userptr pin
   if (mode == 2) return staged_copy_threads(p, static_cast<char*>(dev_ptr), static_cast<char*>(host_ptr), bytes, to_device);
   if (mode == 3) {
     hipError_t e = hipHostRegister(host_ptr, bytes, hipHostRegisterDefault);

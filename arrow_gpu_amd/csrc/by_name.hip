@@ -279,6 +279,7 @@ extern "C" agpu_status agpu_launch_by_name_sized(agpu_pipeline* p, const char* s
     NEED(1);  // one invocation per input word → L outputs
     agpu_dtype to = AGPU_F32;
     if (crate == "cast") AGPU_REQUIRE(file.rfind("cast_", 0) == 0 && dtype_of(file.substr(5), &to), AGPU_ERR_UNSUPPORTED, "unknown cast shader");
+    AGPU_REQUIRE(agpu_dtype_size(to) != 0, AGPU_ERR_UNSUPPORTED, "no sub-word cast to a bit-packed type");  // "cast/u8/cast_bool"
     n = min2(min2(z.inv, z.W(0)) * (uint64_t)L, out_bytes / agpu_dtype_size(to));
   } else if (crate == "routines" && (dir == "32bit" || dir == "16bit" || dir == "8bit") && file == "merge") {
     NEED(3);

@@ -136,6 +136,7 @@ void agpu_internal_free_staging(agpu_device* dev);  // arrow_cdata.hip
 #define AGPU_BOUNCE_MAX_BYTES ((size_t)4 << 20)  // = one stage slot
 struct agpu_pipeline;
 agpu_status agpu_internal_bounce_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device);  // arrow_cdata.hip
+agpu_status agpu_internal_host_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device);    // arrow_cdata.hip: complete on return
 #define AGPU_TABLE_BYTES (512 * 16 + 128 * 16)
 agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table);  // elementwise.hip; synchronous
 agpu_status agpu_internal_fill_bytes(struct agpu_pipeline* p, void* out, uint32_t pattern, uint64_t bytes);  // elementwise.hip: fill_kernel, out 16-byte aligned

@@ -566,18 +566,28 @@ agpu_status agpu_free(agpu_device* dev, void* ptr) {
 //    column index: any two of four consecutive columns differ in the first or the second hash bit, adjacent ones in the first.
 #define AGPU_TABLE_BIG_COLUMN ((size_t)1 << 30)
 #define AGPU_TABLE_BIG_STRIDE ((size_t)512 << 20)
+#define AGPU_TABLE_PLACED_MIN ((size_t)32 << 20)
 agpu_status agpu_malloc_table(agpu_device* dev, int32_t n_columns, const uint64_t* bytes, int32_t zero_fill, void** out_ptrs) {
   AGPU_REQUIRE(dev && bytes && out_ptrs && n_columns > 0, AGPU_ERR_ARG, "bad argument");
   static const size_t colour[4] = {0, 8192, 4096, 12288};
   std::vector<size_t> off((size_t)n_columns);
   size_t total = 0;
-  for (int pass = 0; pass < 2; pass++) {  // big columns first (so they stay 512 MiB multiples apart), the small ones behind them
+  // three passes: big columns first (so they stay 512 MiB multiples apart), medium ones behind them on 2 MiB granules with
+  // the same colours, and SMALL ones (< 32 MiB: validity bitmaps of modest batches, the columns of a 64 Ki-row record batch)
+  // packed back to back at 256-byte alignment — placement buys nothing below tens of megabytes, and a 2 MiB granule per
+  // 8 KiB bitmap made a file of many small batches cost 256× its size in HBM
+  for (int pass = 0; pass < 3; pass++) {
     int pos = 0;
     for (int32_t k = 0; k < n_columns; k++) {
       const size_t b = bytes[k] ? (size_t)bytes[k] : 16;
-      const bool big = b >= AGPU_TABLE_BIG_COLUMN;
-      if (big != (pass == 0)) continue;
-      const size_t gran = big ? AGPU_TABLE_BIG_STRIDE : AGPU_POOL_GRANULE;
+      const int cls = b >= AGPU_TABLE_BIG_COLUMN ? 0 : b >= AGPU_TABLE_PLACED_MIN ? 1 : 2;
+      if (cls != pass) continue;
+      if (cls == 2) {
+        off[(size_t)k] = total;
+        total += (b + 255) / 256 * 256;
+        continue;
+      }
+      const size_t gran = cls == 0 ? AGPU_TABLE_BIG_STRIDE : AGPU_POOL_GRANULE;
       off[(size_t)k] = total + colour[pos++ & 3];
       total += (b + 16384 + gran - 1) / gran * gran;  // 16 KiB: room for the colour
     }
@@ -600,12 +610,9 @@ agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, s
   AGPU_BIND(p);
   if (!bytes) return AGPU_OK;
   AGPU_REQUIRE(dst_dev && src_host, AGPU_ERR_ARG, "null pointer");
-  // small and medium sources go through the library's own page-locked slots (arrow_cdata.hip: why); big ones straight
-  // from the caller's pageable memory, ordered on the stream
-  if (bytes <= AGPU_BOUNCE_MAX_BYTES && !p->capturing) return agpu_internal_bounce_copy(p, dst_dev, const_cast<void*>(src_host), bytes, true);
-  AGPU_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, p->stream));
-  AGPU_HIP(hipStreamSynchronize(p->stream));
-  return AGPU_OK;
+  // small and medium sources, and anything that lives in the brk heap, go through the library's own page-locked slots
+  // (arrow_cdata.hip agpu_internal_host_copy: why); big separate mappings straight from the caller's pageable memory
+  return agpu_internal_host_copy(p, dst_dev, const_cast<void*>(src_host), bytes, true);
 }
 
 agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev, size_t bytes) {
@@ -615,10 +622,7 @@ agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev,
     return AGPU_OK;
   }
   AGPU_REQUIRE(dst_host && src_dev, AGPU_ERR_ARG, "null pointer");
-  if (bytes <= AGPU_BOUNCE_MAX_BYTES && !p->capturing) return agpu_internal_bounce_copy(p, const_cast<void*>(src_dev), dst_host, bytes, false);
-  AGPU_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));
-  AGPU_HIP(hipStreamSynchronize(p->stream));
-  return AGPU_OK;
+  return agpu_internal_host_copy(p, const_cast<void*>(src_dev), dst_host, bytes, false);
 }
 
 agpu_status agpu_host_alloc(agpu_device* dev, size_t bytes, void** out_host_ptr) {

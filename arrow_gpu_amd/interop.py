@@ -243,11 +243,15 @@ def map_chunks(device: GpuDevice, inputs, out: np.ndarray, chunk_rows: int, laun
     nchunks = (n + chunk_rows - 1) // chunk_rows
     errors = []
 
+    stop = threading.Event()
+
     def uploader():
         try:
             for k in range(nchunks):
                 s = k % 2
                 free[s].acquire()
+                if stop.is_set():  # the consumer failed: it released both `free` slots to get us out of the acquire above
+                    return
                 r0, rows = k * chunk_rows, min(chunk_rows, n - k * chunk_rows)
                 for a, buf in zip(inputs, sets[s][0]):
                     src = a[r0:r0 + rows]
@@ -259,21 +263,37 @@ def map_chunks(device: GpuDevice, inputs, out: np.ndarray, chunk_rows: int, laun
                 s.release()
 
     t0 = time.perf_counter()
-    th = threading.Thread(target=uploader)
+    th = threading.Thread(target=uploader, daemon=True)
     th.start()
-    for k in range(nchunks):
-        s = k % 2
-        ready[s].acquire()
-        if errors:
-            break
-        r0, rows = k * chunk_rows, min(chunk_rows, n - k * chunk_rows)
-        comp.wait_pipeline(up)  # the chunk's last DMA may still be in flight on the upload stream
-        launch(comp, sets[s][0], sets[s][1], rows)
-        dst = out[r0:r0 + rows]
-        capi.call("agpu_staged_copy", comp._handle, C.c_void_p(sets[s][1].ptr), C.c_void_p(dst.ctypes.data), dst.nbytes, 0)
-        free[s].release()  # the download has drained: the set may be refilled
-    th.join()
-    comp.sync()
+    failed = True
+    try:
+        for k in range(nchunks):
+            s = k % 2
+            ready[s].acquire()
+            if errors:
+                break
+            r0, rows = k * chunk_rows, min(chunk_rows, n - k * chunk_rows)
+            comp.wait_pipeline(up)  # the chunk's last DMA may still be in flight on the upload stream
+            launch(comp, sets[s][0], sets[s][1], rows)
+            dst = out[r0:r0 + rows]
+            capi.call("agpu_staged_copy", comp._handle, C.c_void_p(sets[s][1].ptr), C.c_void_p(dst.ctypes.data), dst.nbytes, 0)
+            free[s].release()  # the download has drained: the set may be refilled
+        failed = False
+    finally:
+        # whatever happened above (launch() raised, a copy failed, the uploader reported an error): the uploader must not
+        # stay parked in free[s].acquire() — a non-daemon thread blocked there kept the interpreter from exiting
+        stop.set()
+        for sem in free:
+            sem.release()
+        th.join()
+        if failed:  # the device buffer sets are about to be dropped: nothing may still be reading them
+            try:
+                comp.sync()
+                up.sync()
+            except Exception:  # noqa: BLE001 — the original exception is the one to report
+                pass
+        else:
+            comp.sync()
     dt = time.perf_counter() - t0
     if errors:
         raise errors[0]

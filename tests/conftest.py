@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: timing expectations (tests/test_zz_gpu_perf.py): run after the parity files, "
+                                       "reported instead of asserted unless AGPU_PERF_STRICT=1")
 
 
 @pytest.fixture(scope="session")

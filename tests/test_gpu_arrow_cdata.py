@@ -99,6 +99,32 @@ def test_map_chunks_overlapped_pipeline(ag):
     print(f"map_chunks f32 add from and to pageable host memory: {info['GBps_host_bytes']:.1f} GB/s of host bytes, {info['chunks']} chunks")
 
 
+def test_map_chunks_ends_its_uploader_when_the_consumer_fails(ag):
+    """launch() raising mid-way must not leave the uploader thread parked on its semaphore (the interpreter could
+    not exit)"""
+    import threading
+
+    dev = ag.GPU_DEVICE()
+    n = 8_000_000
+    a = np.ones(n, np.float32)
+    out = np.empty(n, np.float32)
+    calls = []
+
+    def launch(p, ins, o, rows):
+        calls.append(rows)
+        if len(calls) == 2:
+            raise RuntimeError("consumer failed")
+        capi.call("agpu_copy", p._handle, C.c_void_p(o.ptr), C.c_void_p(ins[0].ptr), 4 * rows)
+
+    before = threading.active_count()
+    with pytest.raises(RuntimeError, match="consumer failed"):
+        ag.interop.map_chunks(dev, [a], out, 1 << 20, launch)
+    assert threading.active_count() == before
+    info = ag.interop.map_chunks(dev, [a], out, 1 << 20, lambda p, ins, o, rows: capi.call(
+        "agpu_copy", p._handle, C.c_void_p(o.ptr), C.c_void_p(ins[0].ptr), 4 * rows))
+    assert info["chunks"] == 8 and np.array_equal(out, a)
+
+
 def test_record_batch_imports_into_one_table_block(ag):
     """from_arrow_batch: every column's buffers out of ONE device block (agpu_import_arrow_table), values bit for bit,
     sliced inputs and nulls included; the columns stay ordinary arrays (kernels, to_arrow, independent lifetime)."""

@@ -315,6 +315,9 @@ def test_dead_entry_points_and_bad_arguments_are_rejected(ctx):
         assert lib.agpu_launch_by_name_sized(p._handle, r["shader_key"].encode(), r["entry_point"].encode(), ptrs, sizes, 2,
                                              C.c_void_p(buf.ptr), 64, 1) == capi.ERR_UNSUPPORTED
     assert lib.agpu_launch_by_name_sized(p._handle, b"arithmetic/f32/array", b"add_f32", ptrs, sizes, 1, C.c_void_p(buf.ptr), 64, 1) == capi.ERR_ARG
+    # a caller-supplied key that names a bit-packed cast target must be refused, not divide by its element size of 0
+    for key in (b"cast/u8/cast_bool", b"cast/i16/cast_boolean", b"cast/u16/cast_bool"):
+        assert lib.agpu_launch_by_name_sized(p._handle, key, b"cast_bool", ptrs, sizes, 1, C.c_void_p(buf.ptr), 64, 1) == capi.ERR_UNSUPPORTED
     bad = (C.c_uint64 * 2)(63, 64)
     assert lib.agpu_launch_by_name_sized(p._handle, b"arithmetic/f32/array", b"add_f32", ptrs, bad, 2, C.c_void_p(buf.ptr), 64, 1) == capi.ERR_SHAPE
     # the dispatch bounds the work like the shader's invocation count: 1 workgroup = 256 words

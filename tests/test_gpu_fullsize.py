@@ -469,46 +469,3 @@ def test_f32_tree_sum_fullsize_is_the_reference_tree_of_its_aligned_chunks(ctx):
                 keep = np.unpackbits(bits, bitorder="little")[:rows].astype(bool)
                 vals = np.where(keep, vals, np.float32(0.0))
             assert np.float32(O.reduce(O.RED_SUM, O.F32, vals)).view(np.uint32) == parts[k].view(np.uint32), k
-
-
-def test_north_star_bandwidth_targets_at_one_gpu(ctx):
-    """BASELINE.json north_star: >= 70 % of the 8 TB/s HBM3E peak on the 1e9-row f32 add and on i32 eq -> bitmap with
-    validity at one GPU.  Median of 7 HIP-event timings after 3 warm-ups, columns allocated as tables (what bench.py does);
-    every run of this round measured 0.78-0.85 / 0.78-0.87, so 0.70 leaves room for a throttled box."""
-    dev, p = ctx
-    h = p._handle
-    nb = (N + 63) // 64 * 8
-    fa, fb, fo = dev.create_table_buffers([4 * N] * 3)
-    ia, ib, va, vb, ob, ov = dev.create_table_buffers([4 * N] * 2 + [nb] * 4)
-    capi.call("agpu_synth_f32", h, vp(fa), N, SEED, 0, C.c_float(-1000.0), C.c_float(1000.0))
-    capi.call("agpu_synth_f32", h, vp(fb), N, SEED + 1, 0, C.c_float(-1000.0), C.c_float(1000.0))
-    capi.call("agpu_synth_i32", h, vp(ia), N, SEED + 2, 0, 1024)
-    capi.call("agpu_synth_i32", h, vp(ib), N, SEED + 3, 0, 1024)
-    capi.call("agpu_synth_bits", h, vp(va), N, SEED + 4, 0, C.c_double(0.9))
-    capi.call("agpu_synth_bits", h, vp(vb), N, SEED + 5, 0, C.c_double(0.9))
-    p.sync()
-
-    def ev():
-        e = C.c_void_p()
-        capi.call("agpu_event_create", dev._handle, C.byref(e))
-        return e
-
-    def median_ms(launch):
-        for _ in range(3):
-            launch()
-        ts = []
-        for _ in range(7):
-            s, e = ev(), ev()
-            capi.call("agpu_event_record", s, h)
-            launch()
-            capi.call("agpu_event_record", e, h)
-            ms = C.c_float()
-            capi.call("agpu_event_elapsed_ms", s, e, C.byref(ms))
-            ts.append(ms.value)
-        return float(np.median(ts))
-
-    add_ms = median_ms(lambda: capi.call("agpu_binary", h, capi.OP_ADD, capi.F32, vp(fa), vp(fb), vp(fo), N))
-    eq_ms = median_ms(lambda: capi.call("agpu_compare_validity", h, capi.CMP_EQ, capi.I32, vp(ia), vp(ib), vp(va), vp(vb), vp(ob), vp(ov), N))
-    add_frac, eq_frac = 12.0 * N / add_ms / 1e6 / 8000.0, 8.5 * N / eq_ms / 1e6 / 8000.0
-    print(f"\nf32 add {add_ms:.4f} ms = {add_frac:.3f} of 8 TB/s; i32 eq + validity {eq_ms:.4f} ms = {eq_frac:.3f}")
-    assert add_frac >= 0.70 and eq_frac >= 0.70

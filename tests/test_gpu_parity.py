@@ -686,3 +686,30 @@ def test_f32_min_max_reduction_orders_signed_zeros_and_ignores_nan(D):
             got = D.down(out, np.float32, 1)
             exp = np.float32(O.reduce(op, O.F32, x))
             assert got.view(np.uint32)[0] == exp.view(np.uint32) or (np.isnan(got[0]) and np.isnan(exp)), (vals[:4], op)
+
+
+def test_config_1_literal_i32_add_1Mi_rows(ag):
+    """BASELINE.json configs[0] as SURVEY §8(d) writes it: Int32ArrayGPU of 1 048 576 rows, a[i] = i, b[i] = 1_000_000 − i
+    (mod 2^32), no nulls, through `add` AND `add_dyn`, bit-exact against numpy's wrapping int32 add
+    [ref: crates/arithmetic/src/i32.rs:103-110 impl_arithmetic_array_op!(Int32ArrayGPU, add_i32);
+    arithmetic_kernels.rs:77-120 add_dyn].  (The reference runs it on wgpu's fallback adapter; here there is ONE backend,
+    the HIP path — no CPU path exists in the product.)"""
+    dev = ag.GPU_DEVICE()
+    n = 1_048_576
+    i = np.arange(n, dtype=np.int64)
+    a_np = i.astype(np.int32)
+    b_np = ((1_000_000 - i) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    want = (a_np.astype(np.int64) + b_np.astype(np.int64)).astype(np.uint64).astype(np.uint32).view(np.int32)  # wrap-add
+    assert (want == 1_000_000).all()
+    a, b = ag.Int32ArrayGPU.from_slice(a_np, dev), ag.Int32ArrayGPU.from_slice(b_np, dev)
+    got = a.add(b)
+    assert isinstance(got, ag.Int32ArrayGPU) and len(got) == n and got.null_buffer is None
+    assert np.array_equal(got.raw_values(), want)
+    dyn = ag.add_dyn(a, b)
+    assert np.array_equal(ag.Int32ArrayGPU.try_from(dyn).raw_values(), want)
+    assert np.array_equal(got.raw_values(), O.binary(O.OP_ADD, O.I32, a_np, b_np))  # and the oracle agrees with numpy
+    # the same columns with a wrap in them: i + (2^31 − 1 − i + 5) overflows for every row
+    c_np = ((0x7FFFFFFF - i + 5) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    want2 = (a_np.view(np.uint32) + c_np.view(np.uint32)).view(np.int32)
+    assert (want2 < 0).all()
+    assert np.array_equal(a.add(ag.Int32ArrayGPU.from_slice(c_np, dev)).raw_values(), want2)

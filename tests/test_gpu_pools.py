@@ -165,9 +165,9 @@ def test_table_buffers_come_from_one_block_with_hash_colours_and_free_independen
     base = bufs[0].ptr
     offs = [b.ptr - base for b in bufs]
     # big columns (index 0, 1, 3) first, 1.5 GiB strides (1 GiB + 12345 B + colour room → three 512 MiB units), colours 0 / 8 / 4 KiB;
-    # the small ones (index 2, 4) behind them on 2 MiB units (5 MB → three), colours 0 / 8 KiB
-    unit, gran = 512 << 20, 2 << 20
-    assert offs == [0, 3 * unit + 8192, 9 * unit, 6 * unit + 4096, 9 * unit + 3 * gran + 8192]
+    # the small ones (index 2, 4: < 32 MiB) packed back to back behind them at 256-byte alignment, no colour
+    unit = 512 << 20
+    assert offs == [0, 3 * unit + 8192, 9 * unit, 6 * unit + 4096, 9 * unit + (small + 255) // 256 * 256]
     p = ArrowComputePipeline(dev, "table")
     rng = np.random.default_rng(0)
     n = 1_000_000
@@ -187,4 +187,20 @@ def test_table_buffers_come_from_one_block_with_hash_colours_and_free_independen
     bufs[2] = None
     capi.call("agpu_device_pool_info", dev._handle, C.byref(cached), C.byref(blocks), None)
     assert blocks.value == blocks0.value + 1 and cached.value >= 3 * big  # the whole block is back in the pool's cache
+    capi.call("agpu_device_trim", dev._handle)
+    # medium columns (32 MiB … 1 GiB) keep 2 MiB granules and the colours; a record batch of small columns and bitmaps costs
+    # about its own size — not a 2 MiB granule per 8 KiB bitmap
+    med, gran = 100_000_000, 2 << 20
+    bufs = dev.create_table_buffers([med, 8192, med, 262144, 8192])
+    offs = [b.ptr - bufs[0].ptr for b in bufs]
+    step = (med + 16384 + gran - 1) // gran * gran
+    assert offs == [0, 2 * step, step + 8192, 2 * step + 8192, 2 * step + 8192 + 262144]
+    del bufs
+    free0 = dev.mem_info()[0]
+    tables = [dev.create_table_buffers([262144, 262144, 8192, 8192]) for _ in range(2000)]  # 2 000 batches of 64 Ki rows
+    used = free0 - dev.mem_info()[0]
+    assert used < 3 * 2000 * (2 * 262144 + 2 * 8192), used  # was 4 × 2 MiB per batch = 16 GiB
+    ptrs = sorted(b.ptr for t in tables for b in t)
+    assert all(q - p_ >= 8192 for p_, q in zip(ptrs, ptrs[1:]))  # no overlap
+    del tables
     capi.call("agpu_device_trim", dev._handle)

@@ -106,6 +106,12 @@ def test_ipc_reader_under_asan_ubsan_with_truncated_and_corrupted_input(tmp_path
         cases.append(("dict_stream.arrow", serialise(dt, False, 150)))
     except Exception:
         pass
+    # a hand-written schema whose struct Fields share ONE child table per level (k^depth walk) — byte flips alone
+    # never reach that shape
+    from test_ipc_host import shared_child_schema_stream
+
+    cases.append(("shared_child.arrow", shared_child_schema_stream(10, 4)))
+    cases.append(("shared_child_deep.arrow", shared_child_schema_stream(80, 4)))
     for name, blob in cases:
         path = tmp_path / name
         path.write_bytes(blob)

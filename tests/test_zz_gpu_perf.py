@@ -1,0 +1,184 @@
+"""GPU: TIMING expectations, kept apart from the parity suite.
+
+The file sorts after every parity file, so under `pytest -x` a slow box can no longer hide parity results behind a red
+timing line; and a missed expectation is REPORTED — a pytest warning plus a record in gpurun_out/perf_report.json — not
+asserted, unless AGPU_PERF_STRICT=1 (tools/profile_*.sh set it on boxes whose numbers are about to be committed).  Every
+result a timing run produces is still checked bit for bit.  Marker: `perf` (and `gpu`)."""
+import ctypes as C
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+import oracle as O
+from arrow_gpu_amd import _capi as capi
+
+pytestmark = [pytest.mark.gpu, pytest.mark.perf]
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 1_000_000_000
+SEED = 20250418
+_REPORT = []
+
+
+def expect(ok: bool, what: str, **facts):
+    _REPORT.append({"what": what, "met": bool(ok), **facts})
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "perf_report.json"), "w") as f:
+            json.dump(_REPORT, f, indent=1)
+    except OSError:
+        pass
+    print(f"\n[perf] {'met' if ok else 'MISSED'}: {what} {facts}")
+    if not ok:
+        if os.environ.get("AGPU_PERF_STRICT", "0") not in ("", "0"):
+            raise AssertionError(f"perf expectation missed: {what} {facts}")
+        warnings.warn(f"perf expectation missed (reported, not asserted): {what} {facts}")
+
+
+def bits(a):
+    return np.ascontiguousarray(a).tobytes()
+
+
+def vp(buf, off=0):
+    return C.c_void_p(buf.ptr + off)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+
+    dev = GpuDevice(0)
+    p = ArrowComputePipeline(dev, "perf")
+    return dev, p
+
+
+def test_north_star_bandwidth_targets_at_one_gpu(ctx):
+    """BASELINE.json north_star: >= 70 % of the 8 TB/s HBM3E peak on the 1e9-row f32 add and on i32 eq -> bitmap with
+    validity at one GPU.  Median of 7 HIP-event timings after 3 warm-ups, columns allocated as tables (what bench.py does);
+    rounds 1-2 measured 0.78-0.85 / 0.78-0.89 on every box."""
+    dev, p = ctx
+    h = p._handle
+    nb = (N + 63) // 64 * 8
+    fa, fb, fo = dev.create_table_buffers([4 * N] * 3)
+    ia, ib, va, vb, ob, ov = dev.create_table_buffers([4 * N] * 2 + [nb] * 4)
+    capi.call("agpu_synth_f32", h, vp(fa), N, SEED, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_f32", h, vp(fb), N, SEED + 1, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_i32", h, vp(ia), N, SEED + 2, 0, 1024)
+    capi.call("agpu_synth_i32", h, vp(ib), N, SEED + 3, 0, 1024)
+    capi.call("agpu_synth_bits", h, vp(va), N, SEED + 4, 0, C.c_double(0.9))
+    capi.call("agpu_synth_bits", h, vp(vb), N, SEED + 5, 0, C.c_double(0.9))
+    p.sync()
+
+    def ev():
+        e = C.c_void_p()
+        capi.call("agpu_event_create", dev._handle, C.byref(e))
+        return e
+
+    def median_ms(launch):
+        for _ in range(3):
+            launch()
+        ts = []
+        for _ in range(7):
+            s, e = ev(), ev()
+            capi.call("agpu_event_record", s, h)
+            launch()
+            capi.call("agpu_event_record", e, h)
+            ms = C.c_float()
+            capi.call("agpu_event_elapsed_ms", s, e, C.byref(ms))
+            ts.append(ms.value)
+        return float(np.median(ts))
+
+    add_ms = median_ms(lambda: capi.call("agpu_binary", h, capi.OP_ADD, capi.F32, vp(fa), vp(fb), vp(fo), N))
+    eq_ms = median_ms(lambda: capi.call("agpu_compare_validity", h, capi.CMP_EQ, capi.I32, vp(ia), vp(ib), vp(va), vp(vb), vp(ob), vp(ov), N))
+    add_frac, eq_frac = 12.0 * N / add_ms / 1e6 / 8000.0, 8.5 * N / eq_ms / 1e6 / 8000.0
+    # parity of what was just timed: one window of each output against the oracle (hard assert)
+    r0, cnt = (N // 2) // 64 * 64, 1 << 16
+    got = np.empty(cnt, np.float32)
+    capi.call("agpu_download", h, C.c_void_p(got.ctypes.data), vp(fo, 4 * r0), 4 * cnt)
+    exp = O.binary(O.OP_ADD, O.F32, O.synth_f32(cnt, SEED, r0, -1000.0, 1000.0), O.synth_f32(cnt, SEED + 1, r0, -1000.0, 1000.0))
+    assert bits(got) == bits(exp)
+    gb = np.empty(cnt // 8, np.uint8)
+    capi.call("agpu_download", h, C.c_void_p(gb.ctypes.data), vp(ob, r0 // 8), cnt // 8)
+    assert bits(gb) == bits(O.compare(O.CMP_EQ, O.I32, O.synth_i32(cnt, SEED + 2, r0, 1024), O.synth_i32(cnt, SEED + 3, r0, 1024))[: cnt // 8])
+    expect(add_frac >= 0.70 and eq_frac >= 0.70, "north_star: >= 0.70 of HBM peak on 1e9-row f32 add and i32 eq + validity",
+           add_ms=round(add_ms, 4), add_frac=round(add_frac, 4), eq_ms=round(eq_ms, 4), eq_frac=round(eq_frac, 4))
+
+
+class _Step(C.Structure):
+    _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+
+def _median(p, q, f):
+    f()
+    p.sync()
+    ts = []
+    for _ in range(5):
+        q.begin(p)
+        f()
+        q.end(p)
+        ts.append(q.wait_for_results())
+    return float(np.median(ts))
+
+
+def test_fusion_cuts_time(ag):
+    """(a + s) * s over 2^28 rows: two kernels move 16 B/row, the fused one 8 B/row — same bits, less time."""
+    dev = ag.GPU_DEVICE()
+    n = 1 << 28
+    p = ag.ArrowComputePipeline(dev, "fuse-timing")
+    q = ag.CmpQuery(dev)
+    a = dev.create_empty_buffer(4 * n)
+    t, out = dev.create_empty_buffer(4 * n), dev.create_empty_buffer(4 * n)
+    s = dev.create_gpu_buffer_with_data(np.array([20.0], np.float32))
+    capi.call("agpu_synth_f32", p._handle, C.c_void_p(a.ptr), n, 1, 0, C.c_float(-1), C.c_float(1))
+    steps = (_Step * 2)()
+    steps[0].op, steps[0].kind, steps[0].operand = capi.OP_ADD, 1, s.ptr
+    steps[1].op, steps[1].kind, steps[1].operand = capi.OP_MUL, 1, s.ptr
+
+    def unfused():
+        capi.call("agpu_scalar", p._handle, capi.OP_ADD, capi.F32, C.c_void_p(a.ptr), C.c_void_p(s.ptr), C.c_void_p(t.ptr), n)
+        capi.call("agpu_scalar", p._handle, capi.OP_MUL, capi.F32, C.c_void_p(t.ptr), C.c_void_p(s.ptr), C.c_void_p(out.ptr), n)
+
+    def fused():
+        capi.call("agpu_fused_chain", p._handle, capi.F32, C.c_void_p(a.ptr), C.cast(steps, C.c_void_p), 2, C.c_void_p(out.ptr), n)
+
+    unfused()
+    ref = dev.retrive_data(out, 1 << 20, pipeline=p).copy()
+    t_unfused = _median(p, q, unfused)
+    fused()
+    got = dev.retrive_data(out, 1 << 20, pipeline=p)
+    assert bits(got) == bits(ref)
+    t_fused = _median(p, q, fused)
+    expect(t_fused < 0.7 * t_unfused, "fused (a + s) * s at 2^28 rows takes < 0.7 of the two-kernel form",
+           unfused_ms=round(t_unfused, 4), fused_ms=round(t_fused, 4), fused_TBps=round(8 * n / t_fused / 1e9, 3))
+
+
+def test_fused_predicate_cuts_time(ag):
+    """(a * b + c) > d at 2^28 rows: 16 B/row + 1 bit instead of 12 + 12 + 8.125 B/row — same bitmap, less time."""
+    dev = ag.GPU_DEVICE()
+    n = 1 << 28
+    p = ag.ArrowComputePipeline(dev, "pred-timing")
+    q = ag.CmpQuery(dev)
+    a, b, c, d, t1, t2 = (dev.create_empty_buffer(4 * n) for _ in range(6))
+    ob1, ob2 = dev.create_empty_buffer(n // 8), dev.create_empty_buffer(n // 8)
+    for buf, seed in ((a, 1), (b, 2), (c, 3), (d, 4)):
+        capi.call("agpu_synth_f32", p._handle, C.c_void_p(buf.ptr), n, seed, 0, C.c_float(-1), C.c_float(1))
+    steps = (_Step * 2)()
+    steps[0].op, steps[0].kind, steps[0].operand = capi.OP_MUL, 2, b.ptr
+    steps[1].op, steps[1].kind, steps[1].operand = capi.OP_ADD, 2, c.ptr
+
+    def unfused():
+        capi.call("agpu_binary", p._handle, capi.OP_MUL, capi.F32, vp(a), vp(b), vp(t1), n)
+        capi.call("agpu_binary", p._handle, capi.OP_ADD, capi.F32, vp(t1), vp(c), vp(t2), n)
+        capi.call("agpu_compare", p._handle, capi.CMP_GT, capi.F32, vp(t2), vp(d), vp(ob1), n)
+
+    def fused():
+        capi.call("agpu_fused_chain_compare", p._handle, capi.F32, vp(a), C.cast(steps, C.c_void_p), 2, capi.CMP_GT, 2, vp(d),
+                  vp(ob2), n)
+
+    t_unfused, t_fused = _median(p, q, unfused), _median(p, q, fused)
+    assert bits(dev.retrive_data(ob1, n // 8, pipeline=p)) == bits(dev.retrive_data(ob2, n // 8, pipeline=p))
+    expect(t_fused < 0.62 * t_unfused, "fused predicate (a*b+c)>d at 2^28 rows takes < 0.62 of the three-kernel form",
+           unfused_ms=round(t_unfused, 4), fused_ms=round(t_fused, 4), fused_TBps=round(16.125 * n / t_fused / 1e9, 3))
