@@ -87,6 +87,8 @@ SIGNATURES = {
     "agpu_comm_init_rank": [_vp, _vp, _i32, _i32, _pp],
     "agpu_comm_init_rank_timeout": [_vp, _vp, _i32, _i32, _i64, _pp],
     "agpu_comm_runtime_info": [C.c_char_p, _sz],
+    "agpu_shader_key_for_source": [C.c_char_p, _sz, C.c_char_p, _sz],
+    "agpu_shader_key_for_hash": [_u64, _u64, C.c_char_p, _sz],
     "agpu_comm_destroy": [_vp],
     "agpu_comm_rank": [_vp, C.POINTER(_i32), C.POINTER(_i32)],
     "agpu_comm_reduce": [_vp, _vp, _i32, _i32, _vp, _vp, _u64, _vp],

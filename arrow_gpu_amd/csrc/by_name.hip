@@ -72,9 +72,89 @@ static bool unary_of(const std::string& s, agpu_unary_op* out) {
   return true;
 }
 
+// ---------------------------------------------------------------- the reference's shader argument is the TEXT
+// Every op crate holds `const X_SHADER: &str = include_str!("…wgsl")` or `concat!(include_str!("…/utils.wgsl"),
+// include_str!("…wgsl"))` and hands that text to apply_*_function; (text, entry point) is the pipeline-cache key
+// [ref: crates/arithmetic/src/f32.rs:10-15, crates/compare/src/u8.rs:3-12, gpu_device.rs:145-168].  So that a shim can pass
+// those constants through UNCHANGED, the `shader_key` argument of the by-name entry points accepts either the path key or
+// the text itself: a text is recognised by its 64-bit FNV-1a hash + byte length in a table generated from the reference's
+// 76 constants (71 distinct texts) by tools/extract_entry_points.py — hashes are data, no WGSL is shipped.  Two files of
+// the reference are byte-identical (compare/u32/min_max.wgsl = compare/i32/min_max.wgsl, both over array<i32>: its u32
+// min / max compare as signed); such a text resolves to the program it IS — the i32 kernel.
+namespace {
+struct ShaderHash {
+  uint64_t hash;
+  uint32_t bytes;
+  const char* key;
+};
+const ShaderHash kShaderHashes[] = {
+#include "shader_hashes.inc"
+};
+uint64_t fnv1a64(const char* s, size_t n) {
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (size_t i = 0; i < n; i++) h = (h ^ (uint8_t)s[i]) * 0x100000001B3ull;
+  return h;
+}
+const char* key_of_hash(uint64_t h, uint64_t n) {
+  for (const ShaderHash& e : kShaderHashes)
+    if (e.hash == h && e.bytes == n) return e.key;
+  return nullptr;
+}
+// a path key is short and has no white space; anything else is taken for shader text
+bool looks_like_key(const char* s, size_t n) {
+  if (n == 0 || n > 96) return false;
+  int slashes = 0;
+  for (size_t i = 0; i < n; i++) {
+    const unsigned char c = (unsigned char)s[i];
+    if (c <= ' ' || c == '@' || c == '{' || c == ';') return false;
+    slashes += c == '/';
+  }
+  return slashes == 2;
+}
+// → the path key to dispatch on (static storage or the caller's own string), or nullptr with the error set
+const char* resolve_shader(const char* shader) {
+  const size_t n = strlen(shader);
+  if (shader[0] == '#') {  // "#<16 hex digits of the FNV-1a 64>:<byte length>": a text named by its hash (a shim may hash its constants once)
+    unsigned long long h = 0, len = 0;
+    if (sscanf(shader + 1, "%16llx:%llu", &h, &len) == 2) {
+      const char* key = key_of_hash(h, len);
+      if (!key) agpu_set_error("no shader constant of the reference has FNV-1a %016llx / %llu bytes", h, len);
+      return key;
+    }
+    agpu_set_error("malformed shader hash reference '%.40s' (want #<16 hex>:<bytes>)", shader);
+    return nullptr;
+  }
+  if (looks_like_key(shader, n)) return shader;
+  const char* key = key_of_hash(fnv1a64(shader, n), n);
+  if (!key) agpu_set_error("shader text of %zu bytes is none of the reference's %zu shader constants (FNV-1a %016llx)", n,
+                           sizeof(kShaderHashes) / sizeof(kShaderHashes[0]), (unsigned long long)fnv1a64(shader, n));
+  return key;
+}
+}  // namespace
+
+extern "C" agpu_status agpu_shader_key_for_hash(uint64_t fnv1a64_of_text, uint64_t text_bytes, char* out_key, size_t out_cap) {
+  AGPU_REQUIRE(out_key && out_cap > 0, AGPU_ERR_ARG, "null out_key");
+  const char* key = key_of_hash(fnv1a64_of_text, text_bytes);
+  if (!key) {
+    agpu_set_error("no shader constant of the reference has FNV-1a %016llx / %llu bytes", (unsigned long long)fnv1a64_of_text,
+                   (unsigned long long)text_bytes);
+    return AGPU_ERR_UNSUPPORTED;
+  }
+  AGPU_REQUIRE(strlen(key) < out_cap, AGPU_ERR_ARG, "out_key too small (64 bytes suffice)");
+  strcpy(out_key, key);
+  return AGPU_OK;
+}
+
+extern "C" agpu_status agpu_shader_key_for_source(const char* wgsl, size_t len, char* out_key, size_t out_cap) {
+  AGPU_REQUIRE(wgsl, AGPU_ERR_ARG, "null shader text");
+  return agpu_shader_key_for_hash(fnv1a64(wgsl, len), len, out_key, out_cap);
+}
+
 extern "C" agpu_status agpu_launch_by_name(agpu_pipeline* p, const char* shader_key, const char* entry_point,
                                            const void* const* inputs, int32_t n_inputs, void* out, uint64_t n) {
   AGPU_REQUIRE(p && shader_key && entry_point && (n_inputs == 0 || inputs), AGPU_ERR_ARG, "null argument");
+  shader_key = resolve_shader(shader_key);  // the path key, or the reference's shader TEXT
+  if (!shader_key) return AGPU_ERR_UNSUPPORTED;
   AGPU_BIND_AS(p, "agpu_launch_by_name");
   agpu_scope_label(p, intern_label(shader_key, entry_point));  // [ref: insert_debug_marker(entry_point) gpu_device.rs:132]
   const std::string key(shader_key), ep(entry_point);
@@ -232,6 +312,8 @@ extern "C" agpu_status agpu_launch_by_name_sized(agpu_pipeline* p, const char* s
                                                  void* out, uint64_t out_bytes, uint32_t dispatch_size) {
   AGPU_REQUIRE(p && shader_key && entry_point && (n_inputs == 0 || (inputs && input_bytes)), AGPU_ERR_ARG, "null argument");
   AGPU_REQUIRE(n_inputs >= 0 && n_inputs <= 4, AGPU_ERR_ARG, "0..4 read bindings");
+  shader_key = resolve_shader(shader_key);  // the path key, or the reference's shader TEXT (its literal argument)
+  if (!shader_key) return AGPU_ERR_UNSUPPORTED;
   for (int k = 0; k < n_inputs; k++)
     AGPU_REQUIRE(input_bytes[k] % 4 == 0, AGPU_ERR_SHAPE, "wgpu buffers are multiples of 4 bytes");
   AGPU_REQUIRE(out_bytes % 4 == 0, AGPU_ERR_SHAPE, "wgpu buffers are multiples of 4 bytes");

@@ -104,7 +104,7 @@ struct agpu_device {
   std::unordered_map<void*, TableGroup*> table_member;  // column pointer → its group
   std::multimap<size_t, CachedBlock> cache;         // size → freed blocks ≥ 1 MiB
   size_t cached_bytes = 0, cache_cap = 0;
-  static constexpr int kSmallClasses = 12;          // 256 B … 512 KiB, powers of two
+  static constexpr int kSmallClasses = 13;          // 256 B … 1 MiB, powers of two
   std::deque<CachedBlock> small_free[kSmallClasses];
   std::map<uintptr_t, Slab> slabs;                  // base address → slab
   size_t slab_bytes = 0;

@@ -11,7 +11,7 @@
 
 #include "common.hpp"
 
-#define AGPU_SMALL_MAX ((size_t)512 << 10)      // largest size class of the slab pool
+#define AGPU_SMALL_MAX ((size_t)1 << 20)        // largest size class of the slab pool (two blocks per slab)
 #define AGPU_POOL_MIN_BYTES (AGPU_SMALL_MAX + 1) // larger blocks: size-keyed cache of whole hipMalloc'ed blocks (2 MiB granules)
 #define AGPU_POOL_GRANULE ((size_t)2 << 20)
 #define AGPU_SMALL_MIN ((size_t)256)            // smallest size class of the slab pool
@@ -387,7 +387,7 @@ static agpu_status wait_pending(agpu_device* dev, std::vector<agpu_event_ref*>& 
   return AGPU_OK;
 }
 
-static int small_class(size_t padded) {  // 256 B → 0 … 512 KiB → 11
+static int small_class(size_t padded) {  // 256 B → 0 … 512 KiB → 11, 1 MiB → 12
   int c = 0;
   while (((size_t)AGPU_SMALL_MIN << c) < padded) c++;
   return c;

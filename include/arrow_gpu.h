@@ -135,16 +135,16 @@ agpu_status agpu_device_mem_info(agpu_device* dev, uint64_t* out_free, uint64_t*
 /* Resource pools.  The reference allocates an output buffer and (in its default, non-`_op` API) a command encoder per
  * operation [ref: impl_arithmetic_op! crates/arithmetic/src/lib.rs:11-50 — `ArrowComputePipeline::new` … `finish()`
  * around every op].  On ROCm a stream costs 4.3 ms to create and 2.6 ms to destroy and hipFree synchronises the device,
- * so idle streams and freed blocks are recycled (tuning key "mem_pool", default 1): blocks > 512 KiB whole, in 2 MiB
+ * so idle streams and freed blocks are recycled (tuning key "mem_pool", default 1): blocks > 1 MiB whole, in 2 MiB
  * granules; smaller blocks (the reference's tests and examples live at 5–100 elements) from 2 MiB slabs carved into
- * power-of-two size classes, 256 B … 512 KiB.  agpu_device_trim returns the cached blocks and fully free slabs to the
+ * power-of-two size classes, 256 B … 1 MiB.  agpu_device_trim returns the cached blocks and fully free slabs to the
  * driver (also done automatically when hipMalloc runs out of memory); cached large blocks never exceed half of the
  * device memory. */
 agpu_status agpu_device_trim(agpu_device* dev);
 agpu_status agpu_device_pool_info(agpu_device* dev, uint64_t* out_cached_bytes, uint64_t* out_cached_blocks,
-                                  uint64_t* out_idle_streams); /* the > 512 KiB cache and the idle streams */
+                                  uint64_t* out_idle_streams); /* the > 1 MiB cache and the idle streams */
 agpu_status agpu_device_small_pool_info(agpu_device* dev, uint64_t* out_slab_bytes, uint64_t* out_free_blocks,
-                                        uint64_t* out_live_blocks); /* the <= 512 KiB slab pool */
+                                        uint64_t* out_live_blocks); /* the <= 1 MiB slab pool */
 
 /* ---------------------------------------------------------------- buffers (raw HBM pointers)
  * agpu_malloc          [ref: GpuDevice::create_empty_buffer gpu_device.rs:183-192] — zero_fill!=0 reproduces wgpu's
@@ -592,14 +592,28 @@ agpu_status agpu_ipc_writer_finish(agpu_ipc_writer* w, const void** out_data, ui
 void agpu_ipc_writer_destroy(agpu_ipc_writer* w);
 
 /* ---------------------------------------------------------------- reference entry-point names
- * Keeps the reference's kernel identity for a thin shim: shader_key = the WGSL file's path under crates/ without
- * "compute_shaders/" and ".wgsl" (e.g. "arithmetic/f32/array", "compare/i32/cmp", "logical/u32/logical"),
+ * Keeps the reference's kernel identity for a thin shim.  `shader_key` is EITHER
+ *   - the reference's own argument: the WGSL TEXT of one of its shader constants, NUL-terminated, exactly as the op crates
+ *     build them — `include_str!("…/f32/array.wgsl")` or `concat!(include_str!("…/u8/utils.wgsl"), include_str!("…/u8/cmp.wgsl"))`
+ *     [ref: crates/arithmetic/src/f32.rs:10-15, crates/compare/src/u8.rs:3-12; (text, entry point) is the pipeline-cache
+ *     key, gpu_device.rs:145-168].  The text is recognised by its 64-bit FNV-1a hash + length in a table of the reference's
+ *     76 constants (csrc/shader_hashes.inc, generated by tools/extract_entry_points.py: hashes only, no WGSL is shipped); an
+ *     unknown text → AGPU_ERR_UNSUPPORTED.  One text exists under two names: compare/u32/min_max.wgsl is byte-identical to
+ *     compare/i32/min_max.wgsl (array<i32>: the reference's u32 min / max compare as SIGNED) and resolves to the i32 kernel
+ *     — the program the text is; the typed agpu_binary(MIN / MAX, AGPU_U32) compares unsigned;
+ *   - or such a text named by its hash, "#<16 hex digits of FNV-1a 64>:<byte length>" (a shim may hash each constant once);
+ *   - or the path key: the WGSL file's path under crates/ without "compute_shaders/" and ".wgsl" (e.g.
+ *     "arithmetic/f32/array", "compare/i32/cmp", "logical/u32/logical").
  * entry_point = the @compute fn name ("add_f32", "eq", "bitwise_and", ...).  inputs[] are the read bindings in
  * binding order (for `put`: src, src_indexes, dst_indexes); out is the read_write binding; n = number of OUTPUT
  * elements the dispatch covers (bits for Boolean/bitmap kernels, index count for take/put, INPUT rows for "sum").
  * [ref: GpuDevice::create_compute_pipeline(shader, entry_point) gpu_device.rs:145-168 — (shader, entry) is the cache key] */
 agpu_status agpu_launch_by_name(agpu_pipeline* p, const char* shader_key, const char* entry_point,
                                 const void* const* inputs, int32_t n_inputs, void* out, uint64_t n);
+/* The lookup on its own (host only, no GPU): path key of a shader text / of its (FNV-1a 64, byte length); out_cap ≥ 64.
+ * A shim may resolve each `const *_SHADER` once and cache the key. */
+agpu_status agpu_shader_key_for_source(const char* wgsl, size_t len, char* out_key, size_t out_cap);
+agpu_status agpu_shader_key_for_hash(uint64_t fnv1a64_of_text, uint64_t text_bytes, char* out_key, size_t out_cap);
 /* The reference's LITERAL call: apply_{unary,binary,scalar,ternary,broadcast}_function(buffers…, new_buffer_size, shader,
  * entry_point, dispatch_size) [ref: compute_pipeline.rs:24-66 (unary), 68-113 (binary), 115-165 (ternary), 167-213
  * (scalar), 215-256 (broadcast); the immediate forms gpu_device.rs:267-509; routines::apply_take_op take.rs:9-55,

@@ -274,6 +274,53 @@ def test_every_live_entry_point_has_a_plan():
         assert len(plan(r).inputs) == len(r["bindings"]) - 1, (r["shader_key"], r["entry_point"])
 
 
+# ---------------------------------------------------------------------------------------------- the shader argument is the TEXT
+SHADERS = json.load(open(os.path.join(HERE, "golden", "reference_shader_hashes.json")))["constants"]
+
+
+def fnv1a64(data: bytes) -> int:
+    h = 0xCBF29CE484222325
+    for b in data:
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def test_fixture_lists_the_reference_shader_constants():
+    """76 `const *_SHADER` in the op crates (every include_str! of the reference sits in one), 71 distinct texts; together
+    they cover exactly the 72 live WGSL files"""
+    assert len(SHADERS) == 76 and len({(c["fnv1a64"], c["bytes"]) for c in SHADERS}) == 71
+    assert {c["shader_key"] for c in SHADERS} == {r["shader_key"] for r in LIVE}
+    twins = [(c["const"], c["shader_key"], c["resolves_to"]) for c in SHADERS if c["shader_key"] != c["resolves_to"]]
+    assert twins == [("U32_MIN_MAX_SHADER", "compare/u32/min_max", "compare/i32/min_max")]  # byte-identical files
+
+
+def test_every_shader_constant_resolves_by_hash():
+    """host only (no GPU): (FNV-1a 64, length) of every constant's text → the path key of its kernel file"""
+    lib = capi.lib()
+    out = C.create_string_buffer(64)
+    for c in SHADERS:
+        capi.check(lib.agpu_shader_key_for_hash(int(c["fnv1a64"], 16), c["bytes"], out, 64), c["const"])
+        assert out.value.decode() == c["resolves_to"], c
+    assert lib.agpu_shader_key_for_hash(0x1234, 10, out, 64) == capi.ERR_UNSUPPORTED
+    assert lib.agpu_shader_key_for_source(b"fn main() {}", 12, out, 64) == capi.ERR_UNSUPPORTED
+    assert lib.agpu_shader_key_for_hash(int(SHADERS[0]["fnv1a64"], 16), SHADERS[0]["bytes"], out, 4) == capi.ERR_ARG
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/crates"), reason="the reference's WGSL exists only in the build container")
+def test_the_reference_texts_themselves_resolve():
+    """build container only: the TEXT of every shader constant, assembled the way rustc evaluates include_str! / concat!,
+    handed to agpu_shader_key_for_source — the reference's literal `shader` argument
+    [ref: crates/arithmetic/src/f32.rs:10-15, crates/compare/src/u8.rs:3-12, gpu_device.rs:145-168]"""
+    lib = capi.lib()
+    out = C.create_string_buffer(64)
+    for c in SHADERS:
+        text = b"".join(open(os.path.join("/root/reference", f), "rb").read() for f in c["includes"])
+        assert len(text) == c["bytes"] and f"{fnv1a64(text):016x}" == c["fnv1a64"], c["const"]
+        capi.check(lib.agpu_shader_key_for_source(text, len(text), out, 64), c["const"])
+        assert out.value.decode() == c["resolves_to"]
+        assert b"\0" not in text  # travels as a C string through agpu_launch_by_name*
+
+
 # ---------------------------------------------------------------------------------------------- GPU
 @pytest.fixture(scope="module")
 def ctx():
@@ -283,14 +330,14 @@ def ctx():
     return dev, ArrowComputePipeline(dev, "by_name")
 
 
-def launch(dev, p, r, pl):
+def launch(dev, p, r, pl, shader=None):
     bufs = [dev.create_gpu_buffer_with_data(b) for b in pl.inputs]
     out = dev.create_empty_buffer(max(pl.out_bytes, 4), zero_fill=True)  # the reference's outputs are zero-filled
     if pl.out_init is not None:
         capi.call("agpu_upload", p._handle, C.c_void_p(out.ptr), C.c_void_p(pl.out_init.ctypes.data), len(pl.out_init))
     ptrs = (C.c_void_p * len(bufs))(*[b.ptr for b in bufs])
     sizes = (C.c_uint64 * len(bufs))(*[len(b) for b in pl.inputs])
-    st = capi.lib().agpu_launch_by_name_sized(p._handle, r["shader_key"].encode(), r["entry_point"].encode(), ptrs, sizes,
+    st = capi.lib().agpu_launch_by_name_sized(p._handle, (shader or r["shader_key"]).encode(), r["entry_point"].encode(), ptrs, sizes,
                                               len(bufs), C.c_void_p(out.ptr), pl.out_bytes, pl.dispatch)
     capi.check(st, f'{r["shader_key"]}::{r["entry_point"]}')
     return dev.retrive_data(out, pl.out_bytes, pipeline=p)
@@ -303,6 +350,34 @@ def test_entry_point_through_the_sized_seam(ctx, r):
     for n in (1003, 5):  # ragged; 5 is the size of most of the reference's own tests
         pl = plan(r, n)
         pl.check(launch(dev, p, r, pl))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", SHADERS, ids=[f'{c["rust"].split(":")[0].replace("crates/", "")}::{c["const"]}' for c in SHADERS])
+def test_shader_constant_named_by_its_text_reaches_the_same_kernels(ctx, c):
+    """the `shader` argument as the reference passes it — the TEXT, here named by (FNV-1a 64, length) because WGSL never
+    travels to the GPU box — for every one of the 76 constants: every live entry point of the file it resolves to runs
+    through the sized seam and matches the oracle, exactly as with the path key"""
+    dev, p = ctx
+    ref = f'#{c["fnv1a64"]}:{c["bytes"]}'
+    eps = [r for r in LIVE if r["shader_key"] == c["resolves_to"]]
+    assert eps
+    for r in eps:
+        pl = plan(r, 1003)
+        pl.check(launch(dev, p, r, pl, shader=ref))
+
+
+@pytest.mark.gpu
+def test_unknown_shader_text_is_refused(ctx):
+    dev, p = ctx
+    buf = dev.create_empty_buffer(64, zero_fill=True)
+    ptrs, sizes = (C.c_void_p * 2)(buf.ptr, buf.ptr), (C.c_uint64 * 2)(64, 64)
+    lib = capi.lib()
+    wgsl = b"@group(0) @binding(0) var<storage, read> a: array<f32>;\n@compute @workgroup_size(256) fn add_f32() {}\n"
+    for shader in (wgsl, b"#0123456789abcdef:12", b"#zz", b"no/such"):
+        assert lib.agpu_launch_by_name_sized(p._handle, shader, b"add_f32", ptrs, sizes, 2, C.c_void_p(buf.ptr), 64, 1) in (
+            capi.ERR_UNSUPPORTED, capi.ERR_ARG), shader
+    assert lib.agpu_launch_by_name(p._handle, wgsl, b"add_f32", ptrs, 2, C.c_void_p(buf.ptr), 16) == capi.ERR_UNSUPPORTED
 
 
 @pytest.mark.gpu
