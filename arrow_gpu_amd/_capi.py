@@ -51,6 +51,7 @@ SIGNATURES = {
     "agpu_device_pool_info": [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)],
     "agpu_device_small_pool_info": [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)],
     "agpu_malloc": [_vp, _sz, _i32, _pp],
+    "agpu_malloc_like": [_vp, _sz, _i32, _pp, _i32, _pp],
     "agpu_free": [_vp, _vp],
     "agpu_upload": [_vp, _vp, _vp, _sz],
     "agpu_download": [_vp, _vp, _vp, _sz],
@@ -87,6 +88,9 @@ SIGNATURES = {
     "agpu_comm_init_rank": [_vp, _vp, _i32, _i32, _pp],
     "agpu_comm_init_rank_timeout": [_vp, _vp, _i32, _i32, _i64, _pp],
     "agpu_comm_runtime_info": [C.c_char_p, _sz],
+    "agpu_compare_validity_count": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp],
+    "agpu_bitmap_binary_count": [_vp, _i32, _vp, _vp, _vp, _u64, _vp],
+    "agpu_bitmap_merge_validity_count": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp],
     "agpu_shader_key_for_source": [C.c_char_p, _sz, C.c_char_p, _sz],
     "agpu_shader_key_for_hash": [_u64, _u64, C.c_char_p, _sz],
     "agpu_comm_destroy": [_vp],

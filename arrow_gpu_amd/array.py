@@ -98,10 +98,33 @@ def _upload_bitmap(device: GpuDevice, data: np.ndarray, n_bits: int) -> DeviceBu
 class NullBitBufferGpu:
     """Validity bitmap in HBM.  [ref: crates/array/src/array/null_bit_buffer.rs:92-243]"""
 
-    def __init__(self, bit_buffer: DeviceBuffer, len_: int, gpu_device: GpuDevice):
+    def __init__(self, bit_buffer: DeviceBuffer, len_: int, gpu_device: GpuDevice, count_buf: Optional[DeviceBuffer] = None,
+                 count_is_set_bits: bool = False):
         self.bit_buffer = bit_buffer
         self.len = len_
         self.gpu_device = gpu_device
+        # the kernel that produced this bitmap may have left its count behind as a by-product (a device u64: the null count,
+        # or the number of set bits): `null_count()` then costs one 8-byte read-back instead of a pass over the bitmap
+        self._count_buf = count_buf
+        self._count_is_set_bits = count_is_set_bits
+        self._null_count: Optional[int] = None
+
+    def null_count_known(self) -> bool:
+        """True when `null_count()` needs no pass over the bitmap (already read, or left behind by the producing kernel)."""
+        return self._null_count is not None or self._count_buf is not None
+
+    def null_count(self) -> int:
+        """Number of null slots (unset bits among the first `len`).  Blocking.  The reference has no such accessor: its
+        only bit count is countob + Sum over a Boolean array [ref: crates/logical/src/boolean.rs:120-146]."""
+        if self._null_count is None:
+            if self._count_buf is None:
+                self._count_buf = self.gpu_device.create_empty_buffer(8)
+                self._count_is_set_bits = True
+                p = self.gpu_device._default_pipeline()
+                capi.call("agpu_bitmap_popcount", p._handle, C.c_void_p(self.bit_buffer.ptr), self.len, C.c_void_p(self._count_buf.ptr))
+            v = int(self.gpu_device.retrive_data(self._count_buf, 8).view(np.uint64)[0])
+            self._null_count = self.len - v if self._count_is_set_bits else v
+        return self._null_count
 
     @classmethod
     def new(cls, gpu_device: GpuDevice, builder: BooleanBufferBuilder) -> Optional["NullBitBufferGpu"]:
@@ -145,10 +168,11 @@ class NullBitBufferGpu:
         assert left.len == right.len, "validity bitmaps of different length"
         assert left.gpu_device is right.gpu_device
         out = left.gpu_device.create_empty_buffer(left.bit_buffer.nbytes)
-        capi.call("agpu_bitmap_binary", pipeline._bitmap_handle, capi.OP_AND, C.c_void_p(left.bit_buffer.ptr),
-                  C.c_void_p(right.bit_buffer.ptr), C.c_void_p(out.ptr), left.len)
-        pipeline.keep(left.bit_buffer, right.bit_buffer, out)
-        return NullBitBufferGpu(out, left.len, left.gpu_device)
+        cnt = left.gpu_device.create_empty_buffer(8)  # set bits of the result, counted by the waves that store it
+        capi.call("agpu_bitmap_binary_count", pipeline._bitmap_handle, capi.OP_AND, C.c_void_p(left.bit_buffer.ptr),
+                  C.c_void_p(right.bit_buffer.ptr), C.c_void_p(out.ptr), left.len, C.c_void_p(cnt.ptr))
+        pipeline.keep(left.bit_buffer, right.bit_buffer, out, cnt)
+        return NullBitBufferGpu(out, left.len, left.gpu_device, cnt, True)
 
     @staticmethod
     def merge_null_bit_buffer(left, right):

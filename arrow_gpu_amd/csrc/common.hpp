@@ -102,6 +102,20 @@ struct agpu_device {
     uint32_t live;
   };
   std::unordered_map<void*, TableGroup*> table_member;  // column pointer → its group
+  // Placed arenas (runtime.hip "pool placement"): pool blocks of ≥ 1 GiB are carved out of big hipMalloc'ed arenas at
+  // multiples of 512 MiB plus a rotating colour, so that the separate outputs / inputs of ordinary agpu_malloc callers
+  // get the layout agpu_malloc_table gives the columns of one table.
+  struct Arena {
+    char* base;
+    std::vector<uint8_t> used;  // one flag per 512 MiB unit
+    uint32_t live;              // units in use
+  };
+  struct ArenaBlock {
+    uint32_t arena, first, units;
+  };
+  std::vector<Arena> arenas;
+  std::unordered_map<void*, ArenaBlock> arena_block;  // pointer handed out (base + unit offset + colour) → its units
+  uint32_t arena_colour = 0;                           // rotates 0 / 8 / 4 / 12 KiB over successive carvings
   std::multimap<size_t, CachedBlock> cache;         // size → freed blocks ≥ 1 MiB
   size_t cached_bytes = 0, cache_cap = 0;
   static constexpr int kSmallClasses = 13;          // 256 B … 1 MiB, powers of two

@@ -59,21 +59,49 @@ __device__ __forceinline__ uint64_t validity_word(const uint64_t* va, const uint
 // the stand-alone bitmap kernel uses, and overlaps with the first compare tiles.
 typedef uint64_t cmp_u64x2 __attribute__((ext_vector_type(2)));
 #define CMP_VBLOCK_WORDS (2 * AGPU_BLOCK)  // u64 words of each bitmap per validity block
+// vcount != nullptr: the NULL COUNT as a by-product — the block adds v_bcnt of the words it stores (wave shuffles, four
+// words through LDS) and leaves one u32 at vcount[vblk]; bitmap.hip's count_fold_kernel sums them (no atomics, no second
+// pass over the bitmap)
 __device__ __forceinline__ void validity_block(const uint64_t* va, const uint64_t* vb, uint64_t* outv, uint64_t vblk,
-                                               uint64_t n_words, bool vec16) {
+                                               uint64_t n_words, bool vec16, uint32_t* vcount) {
   const uint64_t w = vblk * CMP_VBLOCK_WORDS + 2 * threadIdx.x;
+  uint32_t cnt = 0;
   if (vec16 && w + 2 <= n_words) {
     const cmp_u64x2 ones = {~0ull, ~0ull};
     const cmp_u64x2 x = va ? *reinterpret_cast<const cmp_u64x2*>(va + w) : ones;  // (nontemporal loads here: −0.4 %)
     const cmp_u64x2 y = vb ? *reinterpret_cast<const cmp_u64x2*>(vb + w) : ones;
+    const cmp_u64x2 r = x & y;
 #if AGPU_CMP_OUTV_NT
-    __builtin_nontemporal_store(x & y, reinterpret_cast<cmp_u64x2*>(outv + w));
+    __builtin_nontemporal_store(r, reinterpret_cast<cmp_u64x2*>(outv + w));
 #else
-    *reinterpret_cast<cmp_u64x2*>(outv + w) = x & y;
+    *reinterpret_cast<cmp_u64x2*>(outv + w) = r;
 #endif
+    cnt = (uint32_t)__popcll(r.x) + (uint32_t)__popcll(r.y);
   } else {
-    if (w < n_words) outv[w] = validity_word(va, vb, w);
-    if (w + 1 < n_words) outv[w + 1] = validity_word(va, vb, w + 1);
+    if (w < n_words) {
+      const uint64_t r = validity_word(va, vb, w);
+      outv[w] = r;
+      cnt = (uint32_t)__popcll(r);
+    }
+    if (w + 1 < n_words) {
+      const uint64_t r = validity_word(va, vb, w + 1);
+      outv[w + 1] = r;
+      cnt += (uint32_t)__popcll(r);
+    }
+  }
+  if (vcount) {  // uniform across the block: every lane takes part in the shuffles and the barrier
+    __shared__ uint32_t wcnt[AGPU_BLOCK / AGPU_WAVE];
+#pragma unroll
+    for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) cnt += (uint32_t)__shfl_down((int)cnt, off);
+    __syncthreads();  // a grid-stride block may come through here twice: the previous round's reads of wcnt are over
+    if ((threadIdx.x & (AGPU_WAVE - 1)) == 0) wcnt[threadIdx.x / AGPU_WAVE] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t s = 0;
+#pragma unroll
+      for (int k = 0; k < AGPU_BLOCK / AGPU_WAVE; k++) s += wcnt[k];
+      vcount[vblk] = s;
+    }
   }
 }
 
@@ -86,7 +114,7 @@ __device__ __forceinline__ void validity_block(const uint64_t* va, const uint64_
 template <typename T, int OP, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, const T* b, const uint64_t* va,
                                                                const uint64_t* vb, uint64_t* out, uint64_t* outv,
-                                                               uint64_t ntiles, uint64_t nvb, int vec16) {
+                                                               uint64_t ntiles, uint64_t nvb, int vec16, uint32_t* vcount) {
   constexpr int R = CMP_R;
   constexpr uint64_t WAVE_TILE = (uint64_t)AGPU_WAVE * R;
   constexpr uint64_t TILE = WAVE_TILE * (AGPU_BLOCK / AGPU_WAVE);
@@ -95,7 +123,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_ballot_kernel(const T* a, cons
 
   for (uint64_t v = blockIdx.x; v < nvb + ntiles; v += gridDim.x) {
     if (v < nvb) {  // validity words of the tiled rows: [0, ntiles * TILE / 64); interleaving these blocks with the
-      validity_block(va, vb, outv, v, ntiles * (TILE / 64), vec16 != 0);  // tiles (every 33rd) measured 3 % slower
+      validity_block(va, vb, outv, v, ntiles * (TILE / 64), vec16 != 0, vcount);  // tiles (every 33rd) measured 3 % slower
       continue;
     }
     const uint64_t t = v - nvb;
@@ -130,7 +158,7 @@ struct CmpPack {
 template <typename T, int OP, int U, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T* b, const uint32_t* va,
                                                             const uint32_t* vb, uint32_t* out, uint32_t* outv,
-                                                            uint64_t ntiles, uint64_t nvb, int vec16) {
+                                                            uint64_t ntiles, uint64_t nvb, int vec16, uint32_t* vcount) {
   constexpr int N = 16 / sizeof(T);  // rows per lane per vector: 4, 8 or 16
   constexpr int G = 32 / N;          // lanes per 32-bit output word: 8, 4 or 2
   constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;
@@ -139,7 +167,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_vec_kernel(const T* a, const T
   for (uint64_t vid = blockIdx.x; vid < nvb + ntiles; vid += gridDim.x) {
     if (vid < nvb) {  // validity words of the tiled rows: [0, ntiles * TILE_PACKS * N / 64)
       validity_block(reinterpret_cast<const uint64_t*>(va), reinterpret_cast<const uint64_t*>(vb),
-                     reinterpret_cast<uint64_t*>(outv), vid, ntiles * (TILE_PACKS * N / 64), vec16 != 0);
+                     reinterpret_cast<uint64_t*>(outv), vid, ntiles * (TILE_PACKS * N / 64), vec16 != 0, vcount);
       continue;
     }
     const uint64_t t = vid - nvb;
@@ -190,24 +218,33 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cmp_word_kernel(const T* a, const 
 
 template <typename T, int OP, int U>
 static uint64_t launch_cmp_vec(agpu_pipeline* p, const T* pa, const T* pb, const void* va, const void* vb, void* out,
-                               void* outv, uint64_t n, bool nt, int vec16) {
+                               void* outv, uint64_t n, bool nt, int vec16, uint32_t* vcount, uint64_t* n_vcount) {
   constexpr int N = 16 / sizeof(T);
   constexpr uint64_t TILE = (uint64_t)AGPU_BLOCK * U * N;
   const uint64_t ntiles = n / TILE;
   if (ntiles) {
     const uint64_t nvb = outv ? (ntiles * (TILE / 64) + CMP_VBLOCK_WORDS - 1) / CMP_VBLOCK_WORDS : 0;
+    *n_vcount = nvb;
     const int grid = stream_grid_for(p, ntiles + nvb);
     auto k = nt ? cmp_vec_kernel<T, OP, U, true> : cmp_vec_kernel<T, OP, U, false>;
     hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, static_cast<const uint32_t*>(va),
                        static_cast<const uint32_t*>(vb), static_cast<uint32_t*>(out), static_cast<uint32_t*>(outv), ntiles,
-                       nvb, vec16);
+                       nvb, vec16, vcount);
   }
   return ntiles * TILE;
 }
 
+agpu_status agpu_internal_count_fold(agpu_pipeline* p, const uint32_t* partials, uint64_t m, const void* bits,
+                                     uint64_t tail_first_word, uint64_t n_bits, bool sub_padding, bool complement, uint64_t* out_dev);  // bitmap.hip
+
+// vblocks_for: validity blocks a tiled launch over `rows` rows will run (the by-product count needs its scratch up front)
+static uint64_t vcount_slots_for(uint64_t rows) {
+  return (rows / 64 + CMP_VBLOCK_WORDS - 1) / CMP_VBLOCK_WORDS + 4;
+}
+
 template <typename T, int OP>
 static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, const void* va, const void* vb,
-                              void* out, void* outv, uint64_t n) {
+                              void* out, void* outv, uint64_t n, uint64_t* out_null_count) {
   const T* pa = static_cast<const T*>(a);
   const T* pb = static_cast<const T*>(b);
   const bool use_ballot = sizeof(T) == 4 && p->tune.cmp_variant == 0;
@@ -218,23 +255,32 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
   uint64_t* outv64 = static_cast<uint64_t*>(outv);
   uint64_t done_rows = 0;  // rows covered by the tiled kernel (a multiple of 64)
   const int vec16 = (!va || aligned16(va)) && (!vb || aligned16(vb)) && (!outv || aligned16(outv));
+  uint32_t* vcount = nullptr;  // per-wave set-bit counts of the validity words the tiled kernel stores
+  uint64_t n_vcount = 0;
+  if (out_null_count && outv) {
+    void* scratch = nullptr;
+    agpu_status st = agpu_scratch(p, vcount_slots_for(n) * sizeof(uint32_t), &scratch);
+    if (st != AGPU_OK) return st;
+    vcount = static_cast<uint32_t*>(scratch);
+  }
   if (use_ballot) {
     constexpr uint64_t TILE = (uint64_t)AGPU_WAVE * CMP_R * (AGPU_BLOCK / AGPU_WAVE);
     const uint64_t ntiles = n / TILE;
     if (ntiles) {
       const uint64_t nvb = outv ? (ntiles * (TILE / 64) + CMP_VBLOCK_WORDS - 1) / CMP_VBLOCK_WORDS : 0;
+      n_vcount = nvb;
       const int grid = stream_grid_for(p, ntiles + nvb);
       auto k = nt ? cmp_ballot_kernel<T, OP, true> : cmp_ballot_kernel<T, OP, false>;
       hipLaunchKernelGGL(k, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, va64, vb64, out64, outv64, ntiles, nvb,
-                         vec16);
+                         vec16, vcount);
     }
     done_rows = ntiles * TILE;
   } else if (aligned16(a) && aligned16(b)) {
     // packs per lane and array in flight: 1 by default; "stream_unroll" = 2 / 4 for sweeps
     const int u = p->tune.stream_unroll == 2 || p->tune.stream_unroll == 4 ? (int)p->tune.stream_unroll : 1;
-    if (u == 4) done_rows = launch_cmp_vec<T, OP, 4>(p, pa, pb, va, vb, out, outv, n, nt, vec16);
-    else if (u == 2) done_rows = launch_cmp_vec<T, OP, 2>(p, pa, pb, va, vb, out, outv, n, nt, vec16);
-    else done_rows = launch_cmp_vec<T, OP, 1>(p, pa, pb, va, vb, out, outv, n, nt, vec16);
+    if (u == 4) done_rows = launch_cmp_vec<T, OP, 4>(p, pa, pb, va, vb, out, outv, n, nt, vec16, vcount, &n_vcount);
+    else if (u == 2) done_rows = launch_cmp_vec<T, OP, 2>(p, pa, pb, va, vb, out, outv, n, nt, vec16, vcount, &n_vcount);
+    else done_rows = launch_cmp_vec<T, OP, 1>(p, pa, pb, va, vb, out, outv, n, nt, vec16, vcount, &n_vcount);
   }
   if (done_rows < n) {
     const uint64_t first_word = done_rows / 64, nwords = (n + 63) / 64;
@@ -243,18 +289,27 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
                        outv64, first_word, n);
   }
   AGPU_LAUNCH_CHECK();
+  if (out_null_count) {
+    if (!outv) {  // (None, None) → None: no nulls
+      AGPU_HIP(hipMemsetAsync(out_null_count, 0, sizeof(uint64_t), p->stream));
+      return AGPU_OK;
+    }
+    // the stream-grid may be smaller than the work (tuning): the kernels are grid-stride over VIRTUAL block ids, so the
+    // slots [0, n_vcount) are all written either way; words ≥ done_rows / 64 came from the tail kernel and are the fold's
+    return agpu_internal_count_fold(p, vcount, n_vcount, outv, done_rows / 64, n, false, true, out_null_count);
+  }
   return AGPU_OK;
 }
 
 template <typename T>
 static agpu_status dispatch_cmp_op(agpu_pipeline* p, agpu_cmp_op op, const void* a, const void* b, const void* va,
-                                   const void* vb, void* out, void* outv, uint64_t n) {
+                                   const void* vb, void* out, void* outv, uint64_t n, uint64_t* nc) {
   switch (op) {
-    case AGPU_CMP_GT: return launch_cmp<T, AGPU_CMP_GT>(p, a, b, va, vb, out, outv, n);
-    case AGPU_CMP_GTEQ: return launch_cmp<T, AGPU_CMP_GTEQ>(p, a, b, va, vb, out, outv, n);
-    case AGPU_CMP_LT: return launch_cmp<T, AGPU_CMP_LT>(p, a, b, va, vb, out, outv, n);
-    case AGPU_CMP_LTEQ: return launch_cmp<T, AGPU_CMP_LTEQ>(p, a, b, va, vb, out, outv, n);
-    case AGPU_CMP_EQ: return launch_cmp<T, AGPU_CMP_EQ>(p, a, b, va, vb, out, outv, n);
+    case AGPU_CMP_GT: return launch_cmp<T, AGPU_CMP_GT>(p, a, b, va, vb, out, outv, n, nc);
+    case AGPU_CMP_GTEQ: return launch_cmp<T, AGPU_CMP_GTEQ>(p, a, b, va, vb, out, outv, n, nc);
+    case AGPU_CMP_LT: return launch_cmp<T, AGPU_CMP_LT>(p, a, b, va, vb, out, outv, n, nc);
+    case AGPU_CMP_LTEQ: return launch_cmp<T, AGPU_CMP_LTEQ>(p, a, b, va, vb, out, outv, n, nc);
+    case AGPU_CMP_EQ: return launch_cmp<T, AGPU_CMP_EQ>(p, a, b, va, vb, out, outv, n, nc);
     default: break;
   }
   agpu_set_error("bad compare op %d", (int)op);
@@ -262,9 +317,12 @@ static agpu_status dispatch_cmp_op(agpu_pipeline* p, agpu_cmp_op op, const void*
 }
 
 static agpu_status compare_impl(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
-                                const void* va, const void* vb, void* out, void* outv, uint64_t n) {
+                                const void* va, const void* vb, void* out, void* outv, uint64_t n, uint64_t* nc = nullptr) {
   AGPU_BIND_AS(p, outv ? "agpu_compare_validity" : "agpu_compare");
-  if (n == 0) return AGPU_OK;
+  if (n == 0) {
+    if (nc) AGPU_HIP(hipMemsetAsync(nc, 0, sizeof(uint64_t), p->stream));
+    return AGPU_OK;
+  }
   AGPU_REQUIRE(a && b && out, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(aligned_to(out, 8) && (!outv || aligned_to(outv, 8)) && (!va || aligned_to(va, 8)) &&
                    (!vb || aligned_to(vb, 8)),
@@ -272,13 +330,13 @@ static agpu_status compare_impl(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dty
   if (!va && !vb) outv = nullptr;  // (None, None) → None [null_bit_buffer.rs:211]
   AGPU_REQUIRE(!(va || vb) || outv, AGPU_ERR_ARG, "out_validity required when an input validity is given");
   switch (dtype) {
-    case AGPU_F32: return dispatch_cmp_op<float>(p, op, a, b, va, vb, out, outv, n);
-    case AGPU_I32: case AGPU_DATE32: return dispatch_cmp_op<int32_t>(p, op, a, b, va, vb, out, outv, n);
-    case AGPU_U32: return dispatch_cmp_op<uint32_t>(p, op, a, b, va, vb, out, outv, n);
-    case AGPU_I16: return dispatch_cmp_op<int16_t>(p, op, a, b, va, vb, out, outv, n);
-    case AGPU_U16: return dispatch_cmp_op<uint16_t>(p, op, a, b, va, vb, out, outv, n);
-    case AGPU_I8: return dispatch_cmp_op<int8_t>(p, op, a, b, va, vb, out, outv, n);
-    case AGPU_U8: return dispatch_cmp_op<uint8_t>(p, op, a, b, va, vb, out, outv, n);
+    case AGPU_F32: return dispatch_cmp_op<float>(p, op, a, b, va, vb, out, outv, n, nc);
+    case AGPU_I32: case AGPU_DATE32: return dispatch_cmp_op<int32_t>(p, op, a, b, va, vb, out, outv, n, nc);
+    case AGPU_U32: return dispatch_cmp_op<uint32_t>(p, op, a, b, va, vb, out, outv, n, nc);
+    case AGPU_I16: return dispatch_cmp_op<int16_t>(p, op, a, b, va, vb, out, outv, n, nc);
+    case AGPU_U16: return dispatch_cmp_op<uint16_t>(p, op, a, b, va, vb, out, outv, n, nc);
+    case AGPU_I8: return dispatch_cmp_op<int8_t>(p, op, a, b, va, vb, out, outv, n, nc);
+    case AGPU_U8: return dispatch_cmp_op<uint8_t>(p, op, a, b, va, vb, out, outv, n, nc);
     default: break;
   }
   agpu_set_error("dtype %d not supported for compare", (int)dtype);
@@ -295,6 +353,12 @@ agpu_status agpu_compare(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, con
 agpu_status agpu_compare_validity(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
                                   const void* va, const void* vb, void* out_bits, void* out_validity, uint64_t n) {
   return compare_impl(p, op, dtype, a, b, va, vb, out_bits, out_validity, n);
+}
+
+agpu_status agpu_compare_validity_count(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
+                                        const void* va, const void* vb, void* out_bits, void* out_validity, uint64_t n,
+                                        uint64_t* out_null_count_dev) {
+  return compare_impl(p, op, dtype, a, b, va, vb, out_bits, out_validity, n, out_null_count_dev);
 }
 
 }  // extern "C"

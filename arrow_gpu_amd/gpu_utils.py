@@ -63,10 +63,17 @@ class GpuDevice:
         return p
 
     # -- buffers
-    def create_empty_buffer(self, size: int, zero_fill: bool = False) -> DeviceBuffer:
-        """[ref: create_empty_buffer gpu_device.rs:183-192] — wgpu zero-fills; kernels here overwrite every byte."""
+    def create_empty_buffer(self, size: int, zero_fill: bool = False, like=()) -> DeviceBuffer:
+        """[ref: create_empty_buffer gpu_device.rs:183-192] — wgpu zero-fills; kernels here overwrite every byte.
+        `like`: the buffers this one will be read / written together with (an op's inputs, for its output): big blocks are
+        then placed against them for the HBM channel hash (agpu_malloc_like)."""
         ptr = C.c_void_p()
-        capi.call("agpu_malloc", self._handle, size, 1 if zero_fill else 0, C.byref(ptr))
+        like = [b for b in like if b is not None] if size >= (1 << 30) else ()
+        if like:
+            arr = (C.c_void_p * len(like))(*[b.ptr for b in like])
+            capi.call("agpu_malloc_like", self._handle, size, 1 if zero_fill else 0, arr, len(like), C.byref(ptr))
+        else:
+            capi.call("agpu_malloc", self._handle, size, 1 if zero_fill else 0, C.byref(ptr))
         return DeviceBuffer(self, ptr.value or 0, size)
 
     def create_table_buffers(self, sizes, zero_fill: bool = False) -> list:

@@ -202,8 +202,12 @@ def to_arrow(gpu_array: ArrowArrayGPU, pipeline: ArrowComputePipeline | None = N
     col.values, col.values_bytes = gpu_array.data.ptr, gpu_array.data.nbytes
     if gpu_array.null_buffer is not None:
         col.validity, col.validity_bytes = gpu_array.null_buffer.bit_buffer.ptr, gpu_array.null_buffer.bit_buffer.nbytes
+    else:
+        col.null_count = 0
     p = pipeline or ArrowComputePipeline(dev, "to_arrow")
     dev.sync()  # other pipelines may still be writing the array (the reference's read-back polls the whole queue)
+    if gpu_array.null_buffer is not None and gpu_array.null_buffer.null_count_known():
+        col.null_count = gpu_array.null_buffer.null_count()  # left behind by the kernel that made the bitmap: an 8-byte read, no pass
     c_arr, c_sch = capi.ArrowArrayStruct(), capi.ArrowSchemaStruct()
     capi.call("agpu_export_arrow", p._handle, C.byref(col), C.byref(c_arr), C.byref(c_sch))
     return pa.Array._import_from_c(C.addressof(c_arr), C.addressof(c_sch))

@@ -75,7 +75,7 @@ def _finish_record(node, result):
 
 def binary_values(pipeline, op: int, dtype: int, a, b, out_cls, n: int):
     dev = a.gpu_device
-    out = dev.create_empty_buffer(max(n * out_cls.ITEM_SIZE, 1))
+    out = dev.create_empty_buffer(max(n * out_cls.ITEM_SIZE, 1), like=(a.data, b.data))
     capi.call("agpu_binary", pipeline._handle, op, dtype, vp(a.data), vp(b.data), vp(out), n)
     pipeline.keep(a.data, b.data, out)
     return out
@@ -89,7 +89,7 @@ def array_op(op: int, out_cls=None):
         cls = out_cls or type(self)
         node = None
         if _recordable(pipeline, _KIND_ARRAY, op, self.DTYPE, cls is type(self) and value.ITEM_SIZE == self.ITEM_SIZE):
-            out = self.gpu_device.create_empty_buffer(max(self.len * cls.ITEM_SIZE, 1))
+            out = self.gpu_device.create_empty_buffer(max(self.len * cls.ITEM_SIZE, 1), like=(self.data, value.data))
             node = pipeline.record_elementwise(_KIND_ARRAY, op, self.DTYPE, self.data, value.data, out, self.len)
         else:
             out = binary_values(pipeline, op, self.DTYPE, self, value, cls, self.len)
@@ -104,7 +104,7 @@ def scalar_op(op: int):
 
     def fn(self, value, pipeline: ArrowComputePipeline):
         dev = self.gpu_device
-        out = dev.create_empty_buffer(max(self.len * self.ITEM_SIZE, 1))
+        out = dev.create_empty_buffer(max(self.len * self.ITEM_SIZE, 1), like=(self.data,))
         node = None
         if _recordable(pipeline, _KIND_SCALAR, op, self.DTYPE, value.ITEM_SIZE == self.ITEM_SIZE):
             node = pipeline.record_elementwise(_KIND_SCALAR, op, self.DTYPE, self.data, value.data, out, self.len)
@@ -123,7 +123,7 @@ def unary_op(op: int, out_cls=None):
     def fn(self, pipeline: ArrowComputePipeline):
         dev = self.gpu_device
         cls = out_cls or type(self)
-        out = dev.create_empty_buffer(max(self.len * cls.ITEM_SIZE, 1))
+        out = dev.create_empty_buffer(max(self.len * cls.ITEM_SIZE, 1), like=(self.data,))
         node = None
         if _recordable(pipeline, _KIND_UNARY, op, self.DTYPE, cls is type(self)):
             node = pipeline.record_elementwise(_KIND_UNARY, op, self.DTYPE, self.data, None, out, self.len)

@@ -35,10 +35,11 @@ def _cmp_op(op: int):
             capi.call("agpu_compare", pipeline._handle, op, self.DTYPE, vp(self.data), vp(operand.data), vp(out), n)
         else:
             outv = dev.create_empty_buffer(max(bitmap_bytes(n), 8))
-            capi.call("agpu_compare_validity", pipeline._handle, op, self.DTYPE, vp(self.data), vp(operand.data),
-                      vp(va.bit_buffer) if va else None, vp(vb.bit_buffer) if vb else None, vp(out), vp(outv), n)
-            nulls = NullBitBufferGpu(outv, n, dev)
-            pipeline.keep(va.bit_buffer if va else None, vb.bit_buffer if vb else None, outv)
+            cnt = dev.create_empty_buffer(8)  # the result's null count, a by-product of the validity blocks of the launch
+            capi.call("agpu_compare_validity_count", pipeline._handle, op, self.DTYPE, vp(self.data), vp(operand.data),
+                      vp(va.bit_buffer) if va else None, vp(vb.bit_buffer) if vb else None, vp(out), vp(outv), n, vp(cnt))
+            nulls = NullBitBufferGpu(outv, n, dev, cnt, False)
+            pipeline.keep(va.bit_buffer if va else None, vb.bit_buffer if vb else None, outv, cnt)
         pipeline.keep(self.data, operand.data, out)
         return BooleanArrayGPU(out, dev, n, nulls)
 

@@ -69,9 +69,17 @@ class GpuDevice : public std::enable_shared_from_this<GpuDevice> {
     if (io) agpu_pipeline_destroy(io);
     if (raw) agpu_device_destroy(raw);
   }
-  BufferPtr create_empty_buffer(uint64_t size) {  // [gpu_device.rs:183-192]
+  // `like`: the buffers this one will be read / written together with (an op's inputs, for its output) — big blocks are
+  // then placed against them for the HBM channel hash (agpu_malloc_like, include/arrow_gpu.h "Pool placement")
+  BufferPtr create_empty_buffer(uint64_t size, std::initializer_list<const Buffer*> like = {}) {  // [gpu_device.rs:183-192]
     auto b = std::make_shared<Buffer>();
-    check(agpu_malloc(raw, size ? size : 1, 0, &b->ptr), "agpu_malloc");
+    const void* nb[4];
+    int n = 0;
+    if (size >= (1ull << 30))
+      for (const Buffer* x : like)
+        if (x && x->ptr && n < 4) nb[n++] = x->ptr;
+    if (n) check(agpu_malloc_like(raw, size, 0, nb, n, &b->ptr), "agpu_malloc_like");
+    else check(agpu_malloc(raw, size ? size : 1, 0, &b->ptr), "agpu_malloc");
     b->bytes = size;
     b->dev = shared_from_this();
     return b;
@@ -272,6 +280,26 @@ struct NullBitBufferGpu {  // [null_bit_buffer.rs:92-243]
   BufferPtr bit_buffer;
   size_t len = 0;
   DevicePtr gpu_device;
+  // the kernel that produced the bitmap may have left a count behind (device u64; count_is_set_bits: set bits, else nulls):
+  // null_count() is then an 8-byte read-back instead of a pass over the bitmap
+  BufferPtr count_buf;
+  bool count_is_set_bits = false;
+  bool null_count_known() const { return (bool)count_buf; }
+  uint64_t null_count() const {  // blocking; no reference counterpart (countob + Sum, boolean.rs:120-146, is its only bit count)
+    BufferPtr c = count_buf;
+    bool set_bits = count_is_set_bits;
+    if (!c) {
+      c = gpu_device->create_empty_buffer(8);
+      set_bits = true;
+      std::lock_guard<std::mutex> lk(gpu_device->io_mu);
+      check(agpu_bitmap_popcount(gpu_device->io, bit_buffer->ptr, len, static_cast<uint64_t*>(c->ptr)), "agpu_bitmap_popcount");
+    }
+    check(agpu_device_sync(gpu_device->raw), "agpu_device_sync");
+    const auto raw = gpu_device->retrive_data(c, 8);
+    uint64_t v = 0;
+    std::memcpy(&v, raw.data(), 8);
+    return set_bits ? (uint64_t)len - v : v;
+  }
   static std::optional<NullBitBufferGpu> make(const DevicePtr& dev, const BooleanBufferBuilder& b) {
     if (!b.contains_nulls) return std::nullopt;
     return NullBitBufferGpu{upload_bitmap(dev, b.data, b.len), b.len, dev};
@@ -292,9 +320,11 @@ struct NullBitBufferGpu {  // [null_bit_buffer.rs:92-243]
     if (!l && !r) return std::nullopt;
     if (!l || !r) return clone_null_bit_buffer_op(l ? l : r, p);
     auto out = l->gpu_device->create_empty_buffer(l->bit_buffer->bytes);
-    check(agpu_bitmap_binary(p.raw, AGPU_OP_AND, l->bit_buffer->ptr, r->bit_buffer->ptr, out->ptr, l->len), "bitmap and");
-    p.keep.insert(p.keep.end(), {l->bit_buffer, r->bit_buffer, out});
-    return NullBitBufferGpu{out, l->len, l->gpu_device};
+    auto cnt = l->gpu_device->create_empty_buffer(8);  // set bits of the result, counted by the waves that store it
+    check(agpu_bitmap_binary_count(p.raw, AGPU_OP_AND, l->bit_buffer->ptr, r->bit_buffer->ptr, out->ptr, l->len,
+                                   static_cast<uint64_t*>(cnt->ptr)), "bitmap and");
+    p.keep.insert(p.keep.end(), {l->bit_buffer, r->bit_buffer, out, cnt});
+    return NullBitBufferGpu{out, l->len, l->gpu_device, cnt, true};
   }
   static std::optional<NullBitBufferGpu> merge_null_bit_buffer(const std::optional<NullBitBufferGpu>& l,
                                                                 const std::optional<NullBitBufferGpu>& r) {
@@ -412,6 +442,7 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
       col.validity_bytes = null_buffer->bit_buffer->bytes;
     }
     check(agpu_device_sync(gpu_device->raw), "agpu_device_sync");  // other pipelines may still be writing this array
+    if (null_buffer && null_buffer->null_count_known()) col.null_count = (int64_t)null_buffer->null_count();  // 8-byte read, no pass
     check(agpu_export_arrow(p.h(), &col, out_array, out_schema), "agpu_export_arrow");
   }
   PrimitiveArrayGpu clone_array() const {
@@ -442,7 +473,7 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
   template <typename Rhs>
   PrimitiveArrayGpu binary_op_(agpu_binary_op op, const PrimitiveArrayGpu<Rhs>& v, ArrowComputePipeline& p) const {
     if (len != v.len) throw ArrowErrorGPU(ArrowErrorGPU::Runtime, "binary op: arrays of different length");
-    auto out = gpu_device->create_empty_buffer(len * sizeof(Native));
+    auto out = gpu_device->create_empty_buffer(len * sizeof(Native), {data.get(), v.data.get()});
     if (p.fuse && sizeof(typename Prim<Rhs>::Native) == sizeof(Native) && ArrowComputePipeline::recordable(AGPU_CHAIN_ARRAY, op, DTYPE)) {
       p.record(AGPU_CHAIN_ARRAY, op, DTYPE, data, v.data, out, len);
     } else {
@@ -453,7 +484,7 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
   }
   template <typename Rhs>
   PrimitiveArrayGpu scalar_op_(agpu_binary_op op, const PrimitiveArrayGpu<Rhs>& v, ArrowComputePipeline& p) const {
-    auto out = gpu_device->create_empty_buffer(len * sizeof(Native));
+    auto out = gpu_device->create_empty_buffer(len * sizeof(Native), {data.get()});
     if (p.fuse && sizeof(typename Prim<Rhs>::Native) == sizeof(Native) && ArrowComputePipeline::recordable(AGPU_CHAIN_SCALAR, op, DTYPE)) {
       p.record(AGPU_CHAIN_SCALAR, op, DTYPE, data, v.data, out, len);
     } else {
@@ -464,7 +495,7 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
   }
   template <typename Out = T>
   PrimitiveArrayGpu<Out> unary_op_(agpu_unary_op op, ArrowComputePipeline& p) const {
-    auto out = gpu_device->create_empty_buffer(len * sizeof(typename Prim<Out>::Native));
+    auto out = gpu_device->create_empty_buffer(len * sizeof(typename Prim<Out>::Native), {data.get()});
     if (p.fuse && std::is_same_v<Out, T> && ArrowComputePipeline::recordable(AGPU_CHAIN_UNARY, op, DTYPE)) {
       p.record(AGPU_CHAIN_UNARY, op, DTYPE, data, nullptr, out, len);
     } else {
@@ -778,11 +809,14 @@ BooleanArrayGPU PrimitiveArrayGpu<T>::compare_op_(agpu_cmp_op op, const Primitiv
     check(agpu_compare(p.h(), op, DTYPE, data->ptr, v.data->ptr, out->ptr, len), "agpu_compare");
   } else {  // fused validity AND (the reference: a second, separately submitted dispatch)
     auto outv = gpu_device->create_empty_buffer(nb);
-    check(agpu_compare_validity(p.h(), op, DTYPE, data->ptr, v.data->ptr,
-                                null_buffer ? null_buffer->bit_buffer->ptr : nullptr,
-                                v.null_buffer ? v.null_buffer->bit_buffer->ptr : nullptr, out->ptr, outv->ptr, len),
-          "agpu_compare_validity");
-    nulls = NullBitBufferGpu{outv, len, gpu_device};
+    auto cnt = gpu_device->create_empty_buffer(8);  // the result's null count: a by-product of the launch's validity blocks
+    check(agpu_compare_validity_count(p.h(), op, DTYPE, data->ptr, v.data->ptr,
+                                      null_buffer ? null_buffer->bit_buffer->ptr : nullptr,
+                                      v.null_buffer ? v.null_buffer->bit_buffer->ptr : nullptr, out->ptr, outv->ptr, len,
+                                      static_cast<uint64_t*>(cnt->ptr)),
+          "agpu_compare_validity_count");
+    nulls = NullBitBufferGpu{outv, len, gpu_device, cnt, false};
+    p.keep.push_back(cnt);
     if (null_buffer) p.keep.push_back(null_buffer->bit_buffer);
     if (v.null_buffer) p.keep.push_back(v.null_buffer->bit_buffer);
     p.keep.push_back(outv);

@@ -155,6 +155,16 @@ agpu_status agpu_device_small_pool_info(agpu_device* dev, uint64_t* out_slab_byt
  *                      copy_buffer_to_buffer} compute_pipeline.rs:275-299] — ordered on the pipeline's stream. */
 agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void** out_ptr);
 agpu_status agpu_free(agpu_device* dev, void* ptr);
+/* Pool placement.  Blocks of ≥ 1 GiB are carved out of arenas (one hipMalloc of up to 32 GiB each) at multiples of 512 MiB
+ * plus a colour of 0 / 8 / 4 / 12 KiB, so that the buffers an ordinary caller allocates one by one relate to each other the
+ * way the columns of an agpu_malloc_table do (the HBM channel hash) — agpu_malloc rotates the colour over
+ * successive allocations; agpu_malloc_like picks, for a buffer that will be used TOGETHER with `neighbours` (the output of
+ * an op and its inputs: what every `*_op` of the reference's API allocates, [ref: apply_binary_function
+ * compute_pipeline.rs:68-113 `create_empty_buffer(new_buffer_size)`]), the arena the neighbours live in and the colour that
+ * differs from theirs in the strongest hash bit.  Smaller blocks and neighbours outside any arena: plain agpu_malloc.
+ * Sizes round up to 512 MiB; tuning "pool_arena" = 0 switches the arenas off. */
+agpu_status agpu_malloc_like(agpu_device* dev, size_t bytes, int32_t zero_fill, const void* const* neighbours,
+                             int32_t n_neighbours, void** out_ptr);
 /* The buffers of one table (the columns a kernel will read together) in ONE block, placed for the HBM channel hash:
  * 2 MiB-aligned allocations put element i of every column into the same hash class whenever their distance has no hash
  * bit set, and two read streams in the same class cost a compare 10 % of its bandwidth (0.78 → 0.85–0.89 of the roof;
@@ -328,6 +338,14 @@ agpu_status agpu_compare(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, con
  * va / vb may each be NULL (= all valid): both NULL → out_validity untouched (may be NULL); one NULL → copy. */
 agpu_status agpu_compare_validity(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
                                   const void* va, const void* vb, void* out_bits, void* out_validity, uint64_t n);
+/* The same, with the NULL COUNT of the result as a by-product: *out_null_count_dev (device u64) = n − popcount of the first n
+ * bits of out_validity (0 when both va and vb are NULL).  The waves that store the validity words add v_bcnt of what they
+ * store (one u32 per wave in stream scratch, no atomics) and one small block folds them — no second pass over the bitmap.
+ * The reference needs that pass [ref: crates/logical/src/boolean.rs:120-146 countob + Sum]; Arrow consumers want the
+ * count with every array (ArrowArray.null_count).  out_null_count_dev may be NULL (= agpu_compare_validity). */
+agpu_status agpu_compare_validity_count(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype dtype, const void* a, const void* b,
+                                        const void* va, const void* vb, void* out_bits, void* out_validity, uint64_t n,
+                                        uint64_t* out_null_count_dev);
 
 /* ---------------------------------------------------------------- bitmaps (Boolean data and validity)
  * op ∈ {AND, OR, XOR} word-wise over n_bits.  This is NullBitBufferGpu::merge_null_bit_buffer's kernel
@@ -335,10 +353,16 @@ agpu_status agpu_compare_validity(agpu_pipeline* p, agpu_cmp_op op, agpu_dtype d
  * and BooleanArrayGPU's Logical impl [ref: crates/logical/src/boolean.rs:18-75]. Padding bits: op applied as-is. */
 agpu_status agpu_bitmap_binary(agpu_pipeline* p, agpu_binary_op op, const void* a, const void* b, void* out,
                                uint64_t n_bits);
+/* The same with the number of SET bits among the first n_bits of `out` as a by-product (*out_set_count_dev, device u64; padding
+ * bits are not counted whatever they hold): for a validity AND that is the valid count, n_bits − it the null count
+ * [ref: NullBitBufferGpu::merge_null_bit_buffer_op null_bit_buffer.rs:206-243; countob + Sum boolean.rs:120-146]. */
+agpu_status agpu_bitmap_binary_count(agpu_pipeline* p, agpu_binary_op op, const void* a, const void* b, void* out,
+                                     uint64_t n_bits, uint64_t* out_set_count_dev);
 /* out = ~in on every whole word covering n_bits (padding flipped too, like the reference) [ref: u32/not.wgsl:9-13] */
 agpu_status agpu_bitmap_not(agpu_pipeline* p, const void* in, void* out, uint64_t n_bits);
 /* *out_count (device u64) = number of set bits among the first n_bits.  Null counts, `all()`
- * [ref: crates/logical/src/boolean.rs:120-146 countob + Sum] */
+ * [ref: crates/logical/src/boolean.rs:120-146 countob + Sum].  One-wave blocks over 16 KiB chunks + one folding block (no
+ * atomics, no memset); bitmaps that were just produced by agpu_compare_validity_count / agpu_bitmap_*_count need no call. */
 agpu_status agpu_bitmap_popcount(agpu_pipeline* p, const void* bits, uint64_t n_bits, uint64_t* out_count_dev);
 /* *out_any (device u32) = 1 if any of the first n_bits is set else 0 [ref: boolean.rs:106-118, u32/any.wgsl] */
 agpu_status agpu_bitmap_any(agpu_pipeline* p, const void* bits, uint64_t n_bits, uint32_t* out_any_dev);
@@ -350,6 +374,8 @@ agpu_status agpu_bitmap_copy_bits(agpu_pipeline* p, const void* src, uint64_t sr
  * [ref: merge_null_buffers_op crates/routines/src/merge.rs:17-86, u32/merge_null_buffer.wgsl] */
 agpu_status agpu_bitmap_merge_validity(agpu_pipeline* p, const void* va, const void* vb, const void* mask,
                                        const void* vmask, void* out, uint64_t n_bits);
+agpu_status agpu_bitmap_merge_validity_count(agpu_pipeline* p, const void* va, const void* vb, const void* mask,
+                                             const void* vmask, void* out, uint64_t n_bits, uint64_t* out_set_count_dev);
 
 /* ---------------------------------------------------------------- reductions
  * out_dev → 1 element: SUM f32→f32, i32→i32 (wrapping), u32→u32 (wrapping); MIN/MAX → same dtype.

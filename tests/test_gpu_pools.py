@@ -205,3 +205,59 @@ def test_table_buffers_come_from_one_block_with_hash_colours_and_free_independen
     assert all(q - p_ >= 8192 for p_, q in zip(ptrs, ptrs[1:]))  # no overlap
     del tables
     capi.call("agpu_device_trim", dev._handle)
+
+
+def test_big_pool_blocks_come_out_of_placed_arenas():
+    """pool placement (runtime.hip): agpu_malloc blocks of ≥ 1 GiB are carved out of one arena at multiples of 512 MiB plus a
+    rotating colour of 0 / 8 / 4 / 12 KiB — the layout agpu_malloc_table gives one table, for buffers allocated one by one;
+    agpu_malloc_like places an op's output against its inputs; blocks never overlap; trim gives the arena back"""
+    import ctypes as C
+
+    import numpy as np
+
+    from arrow_gpu_amd import _capi as capi
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+
+    dev = GpuDevice(0)
+    p = ArrowComputePipeline(dev, "arena")
+    capi.call("agpu_device_trim", dev._handle)
+    free0 = dev.mem_info()[0]
+    unit, big = 512 << 20, (1 << 30) + 4096
+    bufs = [dev.create_empty_buffer(big) for _ in range(5)]
+    base = min(b.ptr for b in bufs) & ~0x3FFF
+    offs = [b.ptr - base for b in bufs]
+    assert [o % unit for o in offs] == [0, 8192, 4096, 12288, 0]            # the rotating colour
+    assert sorted(o // unit for o in offs) == [0, 3, 6, 9, 12]              # (1 GiB + 4 KiB + colour room) → three units each
+    assert free0 - dev.mem_info()[0] >= 15 * unit                           # one arena holds them all
+    # every block is usable to its last byte without touching its neighbours
+    pat = [np.full(1 << 16, 17 * (k + 1), np.uint8) for k in range(5)]
+    for k, b in enumerate(bufs):
+        capi.call("agpu_memset", p._handle, C.c_void_p(b.ptr), 17 * (k + 1), big)
+    for k, b in enumerate(bufs):
+        for off in (0, big - (1 << 16)):
+            got = np.empty(1 << 16, np.uint8)
+            capi.call("agpu_download", p._handle, C.c_void_p(got.ctypes.data), C.c_void_p(b.ptr + off), 1 << 16)
+            assert np.array_equal(got, pat[k]), (k, off)
+    # an output placed against its inputs: colours 0 (bufs[0]) and 4 KiB (bufs[2]) → bit 13 must differ from both
+    out = dev.create_empty_buffer(big, like=(bufs[0], bufs[2]))
+    assert (out.ptr - base) % unit in (8192, 12288)
+    out2 = dev.create_empty_buffer(big, like=(bufs[1],))                    # neighbour at 8 KiB → 0 or 4 KiB
+    assert (out2.ptr - base) % unit in (0, 4096)
+    # a freed block is reused (from the cache) and re-coloured for its new neighbours
+    units_out = (out.ptr - base) // unit
+    del out
+    again = dev.create_empty_buffer(big, like=(bufs[1], bufs[3]))           # neighbours at 8 and 12 KiB → 0 or 4 KiB
+    assert (again.ptr - base) // unit == units_out and (again.ptr - base) % unit in (0, 4096)
+    del bufs, out2, again, b  # (`b`: the loop variable above still names the last block)
+    p.sync()
+    capi.call("agpu_device_trim", dev._handle)
+    assert dev.mem_info()[0] >= free0 - (64 << 20)                          # the arena went back to the driver
+    # switched off: one hipMalloc per block, as before
+    capi.call("agpu_set_tuning", b"pool_arena", 0)
+    try:
+        a, b = dev.create_empty_buffer(big), dev.create_empty_buffer(big)
+        assert free0 - dev.mem_info()[0] < 3 * (1 << 30)
+        del a, b
+    finally:
+        capi.call("agpu_set_tuning", b"pool_arena", 1)
+        capi.call("agpu_device_trim", dev._handle)

@@ -93,6 +93,12 @@ def main():
     t("validity AND (bitmap)", 0.375, lambda: capi.call("agpu_bitmap_binary", h, capi.OP_AND, vp(VA), vp(VB), vp(OV), n), note=LAT)
     t("bitmap not", 0.25, lambda: capi.call("agpu_bitmap_not", h, vp(VA), vp(OV), n), note=LAT)
     t("popcount (null count)", 0.125, lambda: capi.call("agpu_bitmap_popcount", h, vp(VA), n, vp(R)), note=LAT)
+    R2 = dev.create_empty_buffer(64)
+    t("validity AND + set-bit count by-product", 0.375,
+      lambda: capi.call("agpu_bitmap_binary_count", h, capi.OP_AND, vp(VA), vp(VB), vp(OV), n, vp(R2)), note=LAT + "; count = per-wave v_bcnt + one folding block")
+    t("i32 eq → bitmap + validity AND + null count by-product", 8.5,
+      lambda: capi.call("agpu_compare_validity_count", h, capi.CMP_EQ, I32, vp(IA), vp(IB), vp(VA), vp(VB), vp(OB), vp(OV), n, vp(R2)),
+      note="the validity blocks of the launch count what they store; + one folding block")
     t("merge validity (fused 4-input)", 0.625, lambda: capi.call("agpu_bitmap_merge_validity", h, vp(VA), vp(VB), vp(M), vp(VA), vp(OV), n), note=LAT)
     t("u32 popcount per element (countob)", 8, lambda: capi.call("agpu_unary", h, capi.UN_POPCOUNT, capi.U32, vp(A), vp(O), n))
     t("cast u8→f32", 5, lambda: capi.call("agpu_cast", h, U8, F32, vp(B), vp(O), n))
