@@ -322,16 +322,42 @@ __global__ __launch_bounds__(256) void bkt_offsets_kernel(const uint16_t* counts
 __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t bs, uint32_t bd, int rd, int is_put,
                                                         uint32_t stride_s, uint32_t stride_d) {
   __shared__ uint32_t sh[BKT_MAX + 2];
-  for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T) sh[b] = ctl->hist_s[b];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t acc = 0;
-    for (uint32_t b = 0; b <= bs; b++) {
-      const uint32_t c = sh[b];
-      sh[b] = acc;
-      acc += c;
+  __shared__ uint32_t wtot[BKT_T / AGPU_WAVE];
+  {  // exclusive scan of hist_s[0 .. bs]: thread t owns entries 4t .. 4t+3, the last entry (bs == BKT_MAX) is thread 0's extra
+     // (a thread-0 loop over 2049 entries was 30 µs of a 3.5 ms take)
+    uint32_t c[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t b = threadIdx.x * 4 + k;
+      c[k] = b <= bs && b < BKT_MAX ? ctl->hist_s[b] : 0u;
+      sum += c[k];
     }
-    ctl->total = acc;
+    const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < AGPU_WAVE; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= (uint32_t)off) incl += o;
+    }
+    if (lane == AGPU_WAVE - 1) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wave; w++) pre += wtot[w];
+    uint32_t run = pre + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t b = threadIdx.x * 4 + k;
+      if (b <= bs && b < BKT_MAX) sh[b] = run;
+      run += c[k];
+    }
+    if (threadIdx.x == BKT_T - 1) {
+      uint32_t acc = run;  // Σ of entries 0 .. BKT_MAX−1
+      if (bs == BKT_MAX) {
+        sh[BKT_MAX] = acc;
+        acc += ctl->hist_s[BKT_MAX];
+      }
+      ctl->total = acc;
+    }
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T) {
@@ -474,15 +500,28 @@ __device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, con
   __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];                     \
   __shared__ uint32_t tile_rows
 
+// XCD-contiguous walk: workgroups are dealt round-robin to the 8 XCDs, so workgroup j takes tile (j % 8) · per + j / 8 —
+// each XCD streams one contiguous eighth of the bucket-ordered list and its L2 holds the one or two regions in flight
+__device__ __forceinline__ bool bkt_tile_of_block(uint32_t ntiles, uint64_t* tile) {
+  const uint32_t per = (ntiles + 7) / 8;
+  const uint64_t t = (uint64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  *tile = t;
+  return (blockIdx.x / 8) < per && t < ntiles;
+}
+
 // P: rows in natural order → pairs {source index, destination} in source-bucket order (take's out-of-range rows in the
 // extra bucket `bs`: they still produce an output, the value 0)
 __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si, const uint32_t* di, uint64_t n,
                                                              uint64_t n_src, uint64_t n_dst, int rs, uint32_t bs,
                                                              BktCtl* ctl, u32x2* pairs, const uint32_t* offsets, uint32_t nbp,
-                                                             uint32_t cur_stride) {
+                                                             uint32_t cur_stride, uint32_t ntiles) {
   BKT_LDS_DECL;
   BKT_STAMP(0, 0);
-  const uint64_t base = (uint64_t)blockIdx.x * BKT_TILE;
+  // XCD-contiguous tiles (round 3): with range starts from the column scan, the runs of tiles t and t + 1 are neighbours in
+  // every region's range — one XCD handles both a few dispatches apart and their 64-byte halves meet in its L2
+  uint64_t tile64;
+  if (!bkt_tile_of_block(ntiles, &tile64)) return;
+  const uint64_t base = tile64 * BKT_TILE;
   BktRow row[BKT_E];
 #pragma unroll
   for (int q = 0; q < BKT_E / 4; q++) {
@@ -517,16 +556,7 @@ __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si
   const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
   bkt_copy_out(bs + 1, lcnt, sorted, tile_rows, ctl->cur_s, cur_stride, pairs,
                [=](const u32x2& v) { return v.x < n_src32 ? (v.x >> rs) : bs; }, 0,
-               offsets ? offsets + (uint64_t)blockIdx.x * nbp : nullptr);
-}
-
-// XCD-contiguous walk: workgroups are dealt round-robin to the 8 XCDs, so workgroup j takes tile (j % 8) · per + j / 8 —
-// each XCD streams one contiguous eighth of the bucket-ordered list and its L2 holds the one or two regions in flight
-__device__ __forceinline__ bool bkt_tile_of_block(uint32_t ntiles, uint64_t* tile) {
-  const uint32_t per = (ntiles + 7) / 8;
-  const uint64_t t = (uint64_t)(blockIdx.x % 8) * per + blockIdx.x / 8;
-  *tile = t;
-  return (blockIdx.x / 8) < per && t < ntiles;
+               offsets ? offsets + tile64 * nbp : nullptr);
 }
 
 __device__ __forceinline__ void bkt_load_tile(const u32x2* pairs_in, uint64_t base, uint64_t total, uint32_t (&pa)[BKT_E],
@@ -644,11 +674,13 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   const uint32_t ntiles = (uint32_t)((n + BKT_TILE - 1) / BKT_TILE);
   const uint32_t nbp = (bs + 1 + 3) & ~3u;  // padded row stride of the (tile × region) matrices
   const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
-  // "gather_offsets" = 2: the partition pass takes its range starts from a column scan of per-tile counts instead of
-  // reserving them with atomics.  Measured (same box, 2^26–2^28 rows): never faster — the pass is bound by its 64-byte
-  // runs of pairs landing all over a 2 GiB array (12 B written per 8 B row by PMC), not by the 33 M atomics — so the
-  // atomic form is the default and the deterministic form stays for hosts that need a reproducible pair order.
-  const bool det = p->tune.gather_offsets == 2;
+  // Range starts of the partition pass: from a column scan of per-tile counts (default since round 3; "gather_offsets" = 1
+  // brings the global-atomic reservations back).  Under round-robin tiles the scan form was never faster — the pass is
+  // bound by its 64-byte runs landing all over a 2 GiB array, not by the 33 M atomics — but with XCD-CONTIGUOUS tiles the
+  // deterministic layout puts the runs of tiles t and t + 1 side by side in every region's range, the two halves of a line
+  // meet in one L2, and the pass gains what the atomics could never give: put 5.42 → 5.07 ms, pair-pipeline take 4.90 → 4.36
+  // at 2^28 rows (tools/probe/put_offsets_ab.py, one process, alternating).
+  const bool det = p->tune.gather_offsets != 1;
   agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p1);
   if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p2);
@@ -682,8 +714,8 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       const uint32_t stride_s = bs + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 1;
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0, stride_s, stride_d);
       if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl, offsets);
-      hipLaunchKernelGGL(bkt_partition_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),
-                         det ? offsets : static_cast<uint32_t*>(nullptr), nbp, stride_s);
+      hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),
+                         det ? offsets : static_cast<uint32_t*>(nullptr), nbp, stride_s, ntiles);
 #define BKT_GF(W, E)                                                                                                         \
   case W:                                                                                                                    \
     hipLaunchKernelGGL((bkt_gather_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const E*>(src), n_src,     \
@@ -714,22 +746,491 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   return st;
 }
 
-// tuning "gather_bucket": 0 = auto, 1 = always direct, 2 = bucketed whenever the shape qualifies.
-// Auto, from one-process A/B sweeps on MI355X (tools/probe/bucket_sweep.py → profiles/r02_gather_sweep.json, uniformly
-// random 4-byte rows): PUT goes bucketed from 2^25 rows when neither side is sparser than 1 row in 16 elements —
-// 1.6–2.4× at 2^26 rows, 2.4–3.3× at 2^28 (15 → 49 G rows/s with both sides random over 1 GiB); below that the
-// launches and the 16 B/row of temporaries cost more than the random transactions they save.  TAKE goes bucketed from
-// 2^26 rows when the source is at least 64 MiB (smaller sources sit in L2 / MALL and the direct gather is faster) and
-// not sparser than 1 row in 16 elements: 1.15–1.3× — a random gather already runs at the 128-byte-line fetch roof
-// (48–52 G rows/s), and the bucketed passes move 54 B/row instead of 135 but are bound by their LDS counting sorts and
-// by 64-byte runs of pairs landing all over a 2 GiB array, not by HBM bytes.
+// ---------------------------------------------------------------- take, round 3: the "merge-back" pipeline (4-byte values)
+// The bucketed take above moves PAIRS {source index, destination} through two partitions (by source region, then by
+// destination region): 54 B/row of HBM traffic, three tile sorts, 64-byte runs of 8-byte pairs.  But a take's destination is
+// the row NUMBER: nothing has to travel with the index if the way back is remembered instead —
+//   H2  counts[t][b] (u16) = rows of tile t (32 Ki rows) that fall into source region b (512 KiB)            4 B/row read
+//       column scan of the matrix (bkt_colsum / colscan / offsets, shared with the deterministic partition) → slot of
+//       every (tile, region) run: offs[t][b].  No reservation atomics anywhere.
+//   P2  the tile's source indices, counting-sorted by region in LDS, leave as runs of 4-byte entries        4 r + 4 w (runs)
+//       srcs[offs[t][b] + rank]; every row's rank inside its run goes to rank16[i] (natural order)         + 2 w
+//   G2  16 Ki-slot tiles of srcs, in region order (each XCD a contiguous eighth: its L2 holds the regions in flight):
+//       ordered by source line in LDS, gathered, put BACK into slot order in LDS, stored as vals[slot]     4 r + ~5 gather + 4 w
+//   F2  tile t again: key from idx[i], slot = offs[t][key] + rank16[i]; the tile's runs are read from vals as contiguous
+//       pieces into LDS and every row picks its value: out[i] in natural order, one coalesced store        4 + 2 + 4 (runs) r, 4 w
+// ≈ 41 B/row, three LDS passes instead of five, entries half the size so a 32 Ki-row tile fits (the runs keep their
+// 64 bytes), and nothing is nondeterministic but the ranks, which are recorded.  Out-of-range indices: their own bucket,
+// value 0, sticky flag (as above).  Other widths, and put (whose destinations are data), keep the pair pipeline.
+#define TK2_E 32
+#define TK2_TILE (BKT_T * TK2_E)  // 32 Ki rows: P2 / F2 tiles
+#define TK2_GE 16
+#define TK2_GTILE (BKT_T * TK2_GE)  // 16 Ki slots: G2 tiles
+#define TK2_REL_BITS 18             // a G2 tile takes the sorted path when its sources span < 2^18 elements (two regions)
+#define TK2_POS_BITS 14
+#define TK2_GKEY_SHIFT 7                              // G2 orders a tile by groups of 128 source elements (four lines)
+#define TK2_GKEYS (1 << (TK2_REL_BITS - TK2_GKEY_SHIFT))  // 2048 keys: two counters per thread
+
+// exclusive scan of lcnt[0 .. 4·BKT_T) in place (thread t owns counters 4t .. 4t+3); returns the grand total via *total
+__device__ __forceinline__ void tk2_scan4(uint32_t* lcnt, uint32_t* wave_tot, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  uint32_t c[4], sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    c[k] = lcnt[threadIdx.x * 4 + k];
+    sum += c[k];
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < AGPU_WAVE; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+    if (lane >= (uint32_t)off) incl += o;
+  }
+  if (lane == AGPU_WAVE - 1) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; w++) base += wave_tot[w];
+  uint32_t run = base + incl - sum;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    lcnt[threadIdx.x * 4 + k] = run;
+    run += c[k];
+  }
+  if (threadIdx.x == BKT_T - 1) *total = run;
+  __syncthreads();
+}
+
+// H2: counts[t][b] for 32 Ki-row tiles; sets the sticky flag for out-of-range indices
+__global__ __launch_bounds__(BKT_T) void tk2_hist_kernel(const uint32_t* si, uint64_t n, uint64_t n_src, int rs, uint32_t bs,
+                                                        uint32_t* flags, uint16_t* counts, uint32_t nbp, uint32_t ntiles) {
+  __shared__ uint32_t ls[BKT_MAX];
+  bool bad = false;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (uint32_t b = threadIdx.x; b < nbp; b += BKT_T) ls[b] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)tile * TK2_TILE;
+#pragma unroll
+    for (int q = 0; q < TK2_E / 4; q++) {
+      const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+      uint32_t s[4];
+      int live = 0;
+      if (i0 + 4 <= n) {
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
+        s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w;
+        live = 4;
+      } else {
+        for (int k = 0; k < 4; k++)
+          if (i0 + k < n) {
+            s[k] = si[i0 + k];
+            live = k + 1;
+          }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (k < live) {
+          const bool ok = s[k] < n_src;
+          bad |= !ok;
+          atomicAdd(&ls[ok ? (s[k] >> rs) : bs], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbp; b += BKT_T) counts[(uint64_t)tile * nbp + b] = (uint16_t)ls[b];
+    __syncthreads();
+  }
+  if (bad) *reinterpret_cast<volatile uint32_t*>(flags) = AGPU_FLAG_INDEX_RANGE;
+}
+
+// P2: one 32 Ki-row tile per workgroup
+__global__ __launch_bounds__(BKT_T) void tk2_partition_kernel(const uint32_t* si, uint64_t n, uint64_t n_src, int rs, uint32_t bs,
+                                                             const uint32_t* offsets, uint32_t nbp, uint32_t ntiles, uint32_t* srcs,
+                                                             uint16_t* rank16) {
+  __shared__ uint32_t sorted[TK2_TILE];
+  __shared__ uint32_t lcnt[BKT_MAX];
+  __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
+  __shared__ uint32_t tile_rows;
+  // XCD-contiguous walk: the runs of tiles t and t + 1 are NEIGHBOURS in every region's range (64 bytes each, the slots
+  // come from a column scan) — handled by the same XCD a few dispatches apart, the two halves of a 128-byte line meet in
+  // that XCD's L2 and leave as one full line (round-robin tiles put them into two different L2s)
+  uint64_t tile64;
+  if (!bkt_tile_of_block(ntiles, &tile64)) return;
+  const uint32_t tile = (uint32_t)tile64;
+  const uint64_t base = (uint64_t)tile * TK2_TILE;
+  const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
+  uint32_t s[TK2_E];
+#pragma unroll
+  for (int q = 0; q < TK2_E / 4; q++) {
+    const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+    u32x4 t = {0, 0, 0, 0};
+    if (i0 + 4 <= n) t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
+    else {
+      if (i0 < n) t.x = si[i0];
+      if (i0 + 1 < n) t.y = si[i0 + 1];
+      if (i0 + 2 < n) t.z = si[i0 + 2];
+    }
+    s[q * 4] = t.x; s[q * 4 + 1] = t.y; s[q * 4 + 2] = t.z; s[q * 4 + 3] = t.w;
+  }
+  for (uint32_t k = threadIdx.x; k < BKT_MAX; k += BKT_T) lcnt[k] = 0;
+  __syncthreads();
+  uint16_t rank[TK2_E];
+#pragma unroll
+  for (int e = 0; e < TK2_E; e++) {
+    const uint64_t i = base + ((uint64_t)(e / 4) * BKT_T + threadIdx.x) * 4 + (e & 3);
+    rank[e] = 0;
+    if (i < n) rank[e] = (uint16_t)atomicAdd(&lcnt[s[e] < n_src32 ? (s[e] >> rs) : bs], 1u);
+  }
+  // the ranks leave at once (natural order, 8 bytes per lane and quad): F2 finds every row's slot with them
+#pragma unroll
+  for (int q = 0; q < TK2_E / 4; q++) {
+    const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+    if (i0 + 4 <= n) {
+      const u32x2 pk = {(uint32_t)rank[q * 4] | ((uint32_t)rank[q * 4 + 1] << 16), (uint32_t)rank[q * 4 + 2] | ((uint32_t)rank[q * 4 + 3] << 16)};
+      __builtin_nontemporal_store(pk, reinterpret_cast<u32x2*>(rank16 + i0));
+    } else {
+      for (int k = 0; k < 4; k++)
+        if (i0 + k < n) rank16[i0 + k] = rank[q * 4 + k];
+    }
+  }
+  __syncthreads();
+  tk2_scan4(lcnt, wave_tot, &tile_rows);  // lcnt[k] = exclusive start of key k inside the tile
+#pragma unroll
+  for (int e = 0; e < TK2_E; e++) {
+    const uint64_t i = base + ((uint64_t)(e / 4) * BKT_T + threadIdx.x) * 4 + (e & 3);
+    if (i < n) sorted[lcnt[s[e] < n_src32 ? (s[e] >> rs) : bs] + rank[e]] = s[e];
+  }
+  __syncthreads();
+  // lcnt[k] := global slot of the run's first entry − its start inside the tile, so that slot(j) = lcnt[key(j)] + j
+  {
+    uint32_t st[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) st[k] = lcnt[threadIdx.x * 4 + k];
+    const uint32_t* orow = offsets + (uint64_t)tile * nbp;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t kk = threadIdx.x * 4 + k;
+      if (kk <= bs) lcnt[kk] = orow[kk] - st[k];
+    }
+  }
+  __syncthreads();
+  const uint32_t rows_here = tile_rows;
+  for (uint32_t j = threadIdx.x; j < rows_here; j += BKT_T) {
+    const uint32_t v = sorted[j];
+    srcs[(uint32_t)(lcnt[v < n_src32 ? (v >> rs) : bs] + j)] = v;
+  }
+}
+
+// G2: vals[slot] = values[srcs[slot]] (0 when out of range), 16 Ki slots per workgroup, XCD-contiguous walk
+template <int WPE>
+__global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* values, uint64_t n_src, const uint32_t* srcs, uint64_t total,
+                                                          uint32_t ntiles, uint32_t* vals) {
+  // 64 KiB + 8 KiB of LDS: TWO workgroups per CU, so that one's loads and gathers run under the other's LDS phases (with a
+  // separate 64 KiB array for the way back into slot order the kernel held one workgroup per CU: 1.20 ms → see DESIGN §4)
+  __shared__ uint32_t sorted[TK2_GTILE];
+  __shared__ uint32_t lcnt[TK2_GKEYS];
+  __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
+  __shared__ uint32_t tile_rows;
+  __shared__ uint32_t red[2 * (BKT_T / AGPU_WAVE)];
+  uint64_t tile;
+  if (!bkt_tile_of_block(ntiles, &tile)) return;
+  const uint64_t base = tile * TK2_GTILE;
+  if (base >= total) return;
+  uint32_t s[TK2_GE];
+  bool live[TK2_GE];
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+  for (int q = 0; q < TK2_GE / 4; q++) {
+    const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+    u32x4 t = {0, 0, 0, 0};
+    if (i0 + 4 <= total) t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(srcs + i0));
+    else {
+      if (i0 < total) t.x = srcs[i0];
+      if (i0 + 1 < total) t.y = srcs[i0 + 1];
+      if (i0 + 2 < total) t.z = srcs[i0 + 2];
+    }
+    s[q * 4] = t.x; s[q * 4 + 1] = t.y; s[q * 4 + 2] = t.z; s[q * 4 + 3] = t.w;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      live[q * 4 + k] = i0 + k < total;
+      if (live[q * 4 + k]) {
+        mn = s[q * 4 + k] < mn ? s[q * 4 + k] : mn;
+        mx = s[q * 4 + k] > mx ? s[q * 4 + k] : mx;
+      }
+    }
+  }
+  // the tile's source span decides the path (uniform over the block)
+#pragma unroll
+  for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) {
+    const uint32_t a = (uint32_t)__shfl_down((int)mn, off), b = (uint32_t)__shfl_down((int)mx, off);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  if (lane == 0) {
+    red[wave] = mn;
+    red[BKT_T / AGPU_WAVE + wave] = mx;
+  }
+  for (uint32_t k = threadIdx.x; k < TK2_GKEYS; k += BKT_T) lcnt[k] = 0;
+  __syncthreads();
+  mn = red[0];
+  mx = red[BKT_T / AGPU_WAVE];
+  for (int w = 1; w < BKT_T / AGPU_WAVE; w++) {
+    mn = red[w] < mn ? red[w] : mn;
+    mx = red[BKT_T / AGPU_WAVE + w] > mx ? red[BKT_T / AGPU_WAVE + w] : mx;
+  }
+  const uint32_t origin = mn & ~((1u << TK2_GKEY_SHIFT) - 1u);
+  const bool fast = mx < n_src && (mx - origin) < (1u << TK2_REL_BITS);
+  if (!fast) {  // a tile of out-of-range rows, or one that straddles many small regions: row by row, slots keep their place
+#pragma unroll
+    for (int e = 0; e < TK2_GE; e++) {
+      const uint64_t i = base + ((uint64_t)(e / 4) * BKT_T + threadIdx.x) * 4 + (e & 3);
+      if (live[e]) vals[i] = s[e] < n_src ? values[s[e]] : 0u;
+    }
+    return;
+  }
+  // order the tile by source LINE GROUP (128 elements): neighbouring lanes of the gather share a request
+  uint32_t rank[TK2_GE];
+#pragma unroll
+  for (int e = 0; e < TK2_GE; e++) rank[e] = live[e] ? atomicAdd(&lcnt[(s[e] - origin) >> TK2_GKEY_SHIFT], 1u) : 0u;
+  __syncthreads();
+  {  // exclusive scan of the 2048 counters: thread t owns 2t, 2t+1
+    const uint32_t c0 = lcnt[threadIdx.x * 2], c1 = lcnt[threadIdx.x * 2 + 1];
+    uint32_t incl = c0 + c1;
+#pragma unroll
+    for (int off = 1; off < AGPU_WAVE; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= (uint32_t)off) incl += o;
+    }
+    if (lane == AGPU_WAVE - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wave; w++) pre += wave_tot[w];
+    const uint32_t run = pre + incl - (c0 + c1);
+    lcnt[threadIdx.x * 2] = run;
+    lcnt[threadIdx.x * 2 + 1] = run + c0;
+    if (threadIdx.x == BKT_T - 1) tile_rows = run + c0 + c1;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < TK2_GE; e++)
+    if (live[e]) {
+      const uint32_t rel = s[e] - origin;
+      const uint32_t pos = ((uint32_t)(e / 4) * BKT_T + threadIdx.x) * 4 + (uint32_t)(e & 3);  // the slot inside the tile
+      sorted[lcnt[rel >> TK2_GKEY_SHIFT] + rank[e]] = (rel << TK2_POS_BITS) | pos;
+    }
+  __syncthreads();
+  const uint32_t rows_here = tile_rows;
+  uint32_t val[TK2_GE], pos_of[TK2_GE];
+#pragma unroll
+  for (int e = 0; e < TK2_GE; e++) {
+    const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
+    pos_of[e] = 0xFFFFFFFFu;
+    val[e] = 0;
+    if (j < rows_here) {
+      const uint32_t ent = sorted[j];
+      pos_of[e] = ent & ((1u << TK2_POS_BITS) - 1u);
+      val[e] = values[origin + (ent >> TK2_POS_BITS)];  // the L2-resident gather
+    }
+  }
+  __syncthreads();  // every entry has been read: the same array takes the values, back in slot order
+#pragma unroll
+  for (int e = 0; e < TK2_GE; e++)
+    if (pos_of[e] != 0xFFFFFFFFu) sorted[pos_of[e]] = val[e];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < TK2_GE / 4; q++) {
+    const uint32_t l0 = ((uint32_t)q * BKT_T + threadIdx.x) * 4;
+    const uint64_t i0 = base + l0;
+    if (i0 + 4 <= total) {
+      const u32x4 v = {sorted[l0], sorted[l0 + 1], sorted[l0 + 2], sorted[l0 + 3]};
+      *reinterpret_cast<u32x4*>(vals + i0) = v;
+    } else {
+      for (int k = 0; k < 4; k++)
+        if (i0 + k < total) vals[i0 + k] = sorted[l0 + k];
+    }
+  }
+}
+
+// F2: out[i] = vals[offs[t][key(i)] + rank16[i]] — the tile's runs come into LDS as contiguous pieces, rows pick from there
+__global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, uint64_t n, uint64_t n_src, int rs, uint32_t bs,
+                                                         const uint16_t* counts, const uint32_t* offsets, uint32_t nbp,
+                                                         uint32_t ntiles, const uint16_t* rank16, const uint32_t* vals, uint32_t* out) {
+  __shared__ uint32_t A[TK2_TILE];
+  __shared__ uint32_t lcnt[BKT_MAX];
+  __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
+  __shared__ uint32_t tile_rows;
+  uint64_t tile64;  // XCD-contiguous, like P2: the 64-byte runs of neighbouring tiles share their lines in one L2
+  if (!bkt_tile_of_block(ntiles, &tile64)) return;
+  const uint32_t tile = (uint32_t)tile64;
+  const uint64_t base = (uint64_t)tile * TK2_TILE;
+  const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
+  // start[k] (exclusive scan of the tile's counts) and the runs' global slots
+  const uint16_t* crow = counts + (uint64_t)tile * nbp;
+  const uint32_t* orow = offsets + (uint64_t)tile * nbp;
+  uint32_t goff[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t kk = threadIdx.x * 4 + k;
+    lcnt[kk] = kk <= bs ? (uint32_t)crow[kk] : 0u;
+    goff[k] = kk <= bs ? orow[kk] : 0u;
+  }
+  uint32_t s[TK2_E];
+  uint16_t rank[TK2_E];
+#pragma unroll
+  for (int q = 0; q < TK2_E / 4; q++) {
+    const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+    u32x4 t = {0, 0, 0, 0};
+    u32x2 r = {0, 0};
+    if (i0 + 4 <= n) {
+      t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
+      r = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(rank16 + i0));
+    } else {
+      uint32_t tt[4] = {0, 0, 0, 0}, rr[4] = {0, 0, 0, 0};
+      for (int k = 0; k < 4; k++)
+        if (i0 + k < n) {
+          tt[k] = si[i0 + k];
+          rr[k] = rank16[i0 + k];
+        }
+      t = u32x4{tt[0], tt[1], tt[2], tt[3]};
+      r = u32x2{rr[0] | (rr[1] << 16), rr[2] | (rr[3] << 16)};
+    }
+    s[q * 4] = t.x; s[q * 4 + 1] = t.y; s[q * 4 + 2] = t.z; s[q * 4 + 3] = t.w;
+    rank[q * 4] = (uint16_t)r.x; rank[q * 4 + 1] = (uint16_t)(r.x >> 16); rank[q * 4 + 2] = (uint16_t)r.y; rank[q * 4 + 3] = (uint16_t)(r.y >> 16);
+  }
+  __syncthreads();
+  tk2_scan4(lcnt, wave_tot, &tile_rows);  // lcnt[k] = start of run k inside the tile
+  // every row names its global slot at its local slot; then the slots are filled with the values, coalesced per run
+  // (LDS budget: A 128 KiB + 16 KiB + 8 KiB — the starts fit 16 bits, their 32-bit array is reused for the deltas)
+  __shared__ uint16_t start16[BKT_MAX];
+  uint32_t st[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) st[k] = lcnt[threadIdx.x * 4 + k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    start16[threadIdx.x * 4 + k] = (uint16_t)st[k];
+    lcnt[threadIdx.x * 4 + k] = goff[k] - st[k];  // global slot of run k − its local start
+  }
+  __syncthreads();
+  const uint32_t rows_here = tile_rows;
+  uint32_t sl[TK2_E];
+#pragma unroll
+  for (int e = 0; e < TK2_E; e++) {
+    const uint64_t i = base + ((uint64_t)(e / 4) * BKT_T + threadIdx.x) * 4 + (e & 3);
+    sl[e] = 0;
+    if (i < n) {
+      const uint32_t key = s[e] < n_src32 ? (s[e] >> rs) : bs;
+      sl[e] = (uint32_t)start16[key] + rank[e];
+      A[sl[e]] = lcnt[key] + sl[e];
+    }
+  }
+  __syncthreads();
+  {  // all 32 slot numbers first, then 32 loads in flight, then the values back into the slots
+    uint32_t g[TK2_E];
+#pragma unroll
+    for (int e = 0; e < TK2_E; e++) {
+      const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
+      g[e] = j < rows_here ? A[j] : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < TK2_E; e++) {
+      const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
+      if (j < rows_here) g[e] = __builtin_nontemporal_load(vals + g[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < TK2_E; e++) {
+      const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
+      if (j < rows_here) A[j] = g[e];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < TK2_E / 4; q++) {
+    const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+    if (i0 + 4 <= n) {
+      const u32x4 v = {A[sl[q * 4]], A[sl[q * 4 + 1]], A[sl[q * 4 + 2]], A[sl[q * 4 + 3]]};
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + i0));
+    } else {
+      for (int k = 0; k < 4; k++)
+        if (i0 + k < n) out[i0 + k] = A[sl[q * 4 + k]];
+    }
+  }
+}
+
+// take of 4-byte values through the merge-back pipeline; AGPU_ERR_UNSUPPORTED when the shape does not qualify
+static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* values, uint64_t n_src, const uint32_t* si, uint32_t* out,
+                                         uint64_t n) {
+  if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || !aligned16(si) || !aligned16(out) || p->capturing) return AGPU_ERR_UNSUPPORTED;
+  const int rs = bkt_region_bits(p, n_src, 4);
+  const uint32_t bs = (uint32_t)((n_src + ((uint64_t)1 << rs) - 1) >> rs);
+  if (bs + 1 > BKT_MAX) return AGPU_ERR_UNSUPPORTED;
+  agpu_device* dev = p->dev;
+  const uint32_t ntiles = (uint32_t)((n + TK2_TILE - 1) / TK2_TILE);
+  const uint32_t gtiles = (uint32_t)((n + TK2_GTILE - 1) / TK2_GTILE);
+  const uint32_t nbp = (bs + 1 + 3) & ~3u;
+  const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
+  void *ctl_v = nullptr, *srcs_v = nullptr, *vals_v = nullptr, *rank_v = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr;
+  agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, 4 * n + 16, 0, &srcs_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, 4 * n + 16, 0, &vals_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, 2 * n + 16, 0, &rank_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 2, 0, &cnt_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 4, 0, &off_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)nchunks * nbp * 4, 0, &csum_v);
+  if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;  // no room for the temporaries: the direct kernel needs none
+  if (st == AGPU_OK) {
+    BktCtl* ctl = static_cast<BktCtl*>(ctl_v);
+    uint16_t* counts = static_cast<uint16_t*>(cnt_v);
+    uint32_t* offsets = static_cast<uint32_t*>(off_v);
+    uint32_t* csum = static_cast<uint32_t*>(csum_v);
+    hipError_t e = hipMemsetAsync(ctl, 0, sizeof(BktCtl), p->stream);
+    if (e != hipSuccess) {
+      agpu_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+      st = AGPU_ERR_HIP;
+    } else {
+      const dim3 cgrid((nbp + 255) / 256, nchunks);
+      hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, p->flags, counts, nbp, ntiles);
+      hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
+      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl);
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 0, 0, 1u, 1u);
+      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl, offsets);
+      hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, offsets, nbp,
+                         ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v));
+      static const int g_wpe = [] { const char* e = getenv("AGPU_TK2_G_WPE"); return e && *e == '4' ? 4 : 8; }();  // A/B probe only
+      if (g_wpe == 8)
+        hipLaunchKernelGGL((tk2_gather_kernel<8>), dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, values, n_src,
+                           static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint32_t*>(vals_v));
+      else
+        hipLaunchKernelGGL((tk2_gather_kernel<4>), dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, values, n_src,
+                           static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint32_t*>(vals_v));
+      hipLaunchKernelGGL(tk2_merge_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp,
+                         ntiles, static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(vals_v), out);
+      if (hipGetLastError() != hipSuccess) {
+        agpu_set_error("merge-back take launch failed");
+        st = AGPU_ERR_HIP;
+      }
+    }
+  }
+  for (void* q : {csum_v, off_v, cnt_v, rank_v, vals_v, srcs_v, ctl_v})
+    if (q) (void)agpu_free(dev, q);
+  return st;
+}
+
+// tuning "gather_bucket": 0 = auto, 1 = always direct, 2 = bucketed whenever the shape qualifies (4-byte take: the
+// merge-back pipeline), 3 = like 2 but 4-byte takes keep the pair pipeline (A/B).
+// Auto, from one-process A/B sweeps on MI355X (tools/probe/bucket_sweep.py --crossover3 → profiles/r03_gather_crossover.json,
+// r03_gather_sweep.json; uniformly random 4-byte rows): TAKE goes bucketed from 2^25 rows when the source is at least
+// 16 MiB and not sparser than 1 row in 8 elements — merge-back 1.2–1.5× at 2^25 rows, 1.3–1.7× at 2^26, 1.8–2.1× at 2^28
+// (48 → 90–113 G rows/s); at 2^24 rows it wins only 1.1–1.2× and loses against a sparse source, below that the six launches
+// cost more than the random transactions they save.  PUT goes bucketed from 2^24 rows when neither side is sparser than
+// 1 row in 8 elements: 1.25–1.35× at 2^24, 1.5–1.75× at 2^25, 1.6–2.4× at 2^26, 2.4–3.5× at 2^28 (15 → 53 G rows/s with both
+// sides random over 1 GiB).
 static bool want_bucketed(const agpu_pipeline* p, int width, uint64_t n, uint64_t n_src, uint64_t n_dst, bool is_put) {
   const int64_t mode = p->tune.gather_bucket;
   if (mode == 1) return false;
-  if (mode == 2) return n >= BKT_TILE;
-  if (n_src / 16 > n || n_dst / 16 > n) return false;
-  if (is_put) return n >= ((uint64_t)1 << 25);
-  return n >= ((uint64_t)1 << 26) && n_src * (uint64_t)width >= ((uint64_t)64 << 20);
+  if (mode == 2 || mode == 3) return n >= BKT_TILE;
+  if (n_src / 8 > n || n_dst / 8 > n) return false;
+  if (is_put) return n >= ((uint64_t)1 << 24);
+  return n >= ((uint64_t)1 << 25) && n_src * (uint64_t)width >= ((uint64_t)16 << 20);
 }
 
 // nontemporal index / output streams: neutral for HBM-resident sources (A/B on one box: 638 vs 637 GB/s), +10 % when the
@@ -754,6 +1255,10 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   AGPU_REQUIRE(values && idx && out, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
   if ((width == 1 || width == 2 || width == 4) && n_values != UINT64_MAX && want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
+    if (width == 4 && p->tune.gather_bucket != 3 && n_idx >= TK2_TILE) {  // "gather_bucket" = 3: the pair pipeline, for A/B
+      const agpu_status ms = launch_take_mergeback(p, static_cast<const uint32_t*>(values), n_values, idx, static_cast<uint32_t*>(out), n_idx);
+      if (ms != AGPU_ERR_UNSUPPORTED) return ms;
+    }
     const agpu_status bs = launch_bucketed(p, width, values, n_values, idx, out, n_idx, nullptr, n_idx);
     if (bs != AGPU_ERR_UNSUPPORTED) return bs;
   }

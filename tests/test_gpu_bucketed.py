@@ -49,6 +49,83 @@ def test_bucketed_take_equals_oracle(ctx, width, n, n_values, dist):
     assert np.array_equal(got, O.take(width, values, idx))
 
 
+# ---- round 3: 4-byte takes go through the merge-back pipeline (tk2_*: 32 Ki-row tiles, ranks recorded, runs merged back);
+# gather_bucket = 3 keeps the pair pipeline.  Both against the oracle, around the new tile sizes, with the G2 slow path
+# (tiles whose sources span more than two regions), a whole tile of out-of-range rows, and one-region sources.
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("n,n_values,dist", [(32767, 70_000, "uniform"), (32768, 1 << 20, "uniform"), (32769, 9, "uniform"),
+                                             (65_537, 1 << 22, "uniform"), (40_000, 300_000_007, "uniform"),
+                                             (1_000_003, 40_000_003, "uniform"), (3 * 32768 + 5, 1 << 24, "oob_tile"),
+                                             (500_000, 1 << 23, "skew"), (1 << 20, 1 << 21, "sorted"), (2_500_000, 1 << 20, "dups")])
+def test_take_u32_pipelines_equal_the_oracle(ctx, mode, n, n_values, dist):
+    dev, p = ctx
+    p.set_tuning("gather_bucket", mode)
+    try:
+        rng = np.random.default_rng(n * 7 + mode)
+        values = rng.integers(1, 1 << 32, n_values, dtype=np.uint64).astype(np.uint32)
+        idx = rng.integers(0, n_values, n).astype(np.uint32)
+        expect_flag = False
+        if dist == "skew":
+            idx = np.where(rng.random(n) < 0.9, rng.integers(1000, 1064, n), idx).astype(np.uint32)
+        elif dist == "sorted":
+            idx = np.sort(idx)
+        elif dist == "dups":
+            idx = (idx // 4096 * 4096).astype(np.uint32)  # 4096 rows per distinct source
+        elif dist == "oob_tile":  # the middle tile is out of range from its first to its last row
+            idx[32768:65536] = rng.integers(n_values, 1 << 32, 32768, dtype=np.uint64).astype(np.uint32)
+            expect_flag = True
+        dv, di = dev.create_gpu_buffer_with_data(values), dev.create_gpu_buffer_with_data(idx)
+        out = dev.create_empty_buffer(4 * n + 16)
+        capi.call("agpu_memset", p._handle, vp(out), 0xEE, 4 * n + 16)
+        capi.call("agpu_take", p._handle, 4, vp(dv), n_values, vp(di), vp(out), n)
+        if expect_flag:
+            import arrow_gpu_amd as ag
+
+            with pytest.raises(ag.ArrowErrorGPU):
+                p.sync()
+        else:
+            p.sync()
+        got = dev.retrive_data(out, 4 * n + 16, pipeline=p)
+        exp = np.where(idx < n_values, values[np.minimum(idx, n_values - 1)], 0).astype(np.uint32)
+        assert np.array_equal(got[: 4 * n].view(np.uint32), exp)
+        assert (got[4 * n:] == 0xEE).all()  # nothing past the end
+        if not expect_flag:
+            assert np.array_equal(exp, O.take(4, values, idx))
+    finally:
+        p.set_tuning("gather_bucket", 2)
+
+
+def test_take_u32_at_2_28_rows_merge_back_equals_direct(ctx):
+    """full size: 2^28 uniformly random rows over a 1 GiB source — merge-back, pair pipeline and direct kernel agree (checksums
+    of the outputs) and a window matches the oracle"""
+    dev, p = ctx
+    n = 1 << 28
+    h = p._handle
+    values, idx = dev.create_empty_buffer(4 * n), dev.create_empty_buffer(4 * n)
+    capi.call("agpu_synth_i32", h, vp(values), n, 11, 0, 0)
+    capi.call("agpu_synth_i32", h, vp(idx), n, 12, 0, n)
+    sums = {}
+    outs = {}
+    for mode in (1, 2, 3):
+        p.set_tuning("gather_bucket", mode)
+        outs[mode] = dev.create_empty_buffer(4 * n)
+        capi.call("agpu_take", h, 4, vp(values), n, vp(idx), vp(outs[mode]), n)
+        cs = dev.create_empty_buffer(8)
+        capi.call("agpu_checksum", h, vp(outs[mode]), 4 * n, vp(cs))
+        sums[mode] = int(dev.retrive_data(cs, 8, pipeline=p).view(np.uint64)[0])
+    p.set_tuning("gather_bucket", 2)
+    assert sums[1] == sums[2] == sums[3], sums
+    w = 1 << 16
+    vi = O.synth_i32(n, 11, 0, 0) if False else None  # (the whole column is too slow for the scalar oracle: a window of rows)
+    ix = O.synth_i32(w, 12, (n // 2), n).view(np.uint32)
+    got = np.empty(w, np.uint32)
+    capi.call("agpu_download", h, C.c_void_p(got.ctypes.data), C.c_void_p(outs[2].ptr + 4 * (n // 2)), 4 * w)
+    # values[j] = synth_i32 at row j: regenerate just the rows the window's indices name
+    exp = np.array([O.synth_i32(1, 11, int(j), 0)[0] for j in ix[:2048]], np.int32).view(np.uint32)
+    assert np.array_equal(got[:2048], exp)
+    del vi
+
+
 def test_bucketed_take_out_of_range_reads_zero_and_flags(ctx):
     import arrow_gpu_amd as ag
 

@@ -11,7 +11,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-round_ = sys.argv[1] if len(sys.argv) > 1 else "r02"
+round_ = sys.argv[1] if len(sys.argv) > 1 else "r03"
 base = os.path.join(ROOT, "gpurun_out", f"gather_{round_}")
 N, LAUNCHES = 1 << 28, 3
 SKIP = ("synth_", "__amd_rocclr", "trig16_build", "pow_build")
@@ -39,9 +39,10 @@ def durations(variant):
 
 
 out = {"rows": N, "launches_per_pass": LAUNCHES, "index_distribution": "uniform random over 2^28, 4-byte values",
+       "variants_explained": "take_bucketed = merge-back pipeline (tk2_* kernels), take_pairs = pair pipeline (bkt_* kernels, gather_bucket = 3), put_bucketed = pair pipeline with range starts from the column scan",
        "note": "per-row figures = totals of the pass / (launches x rows); read bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950), write bytes = WRITE_SIZE KiB x 1024",
        "variants": {}}
-for v in ("take_direct", "take_bucketed", "put_direct", "put_bucketed"):
+for v in ("take_direct", "take_bucketed", "take_pairs", "put_direct", "put_bucketed"):
     fetch, write, dur = counters("fetch", v, "FETCH_SIZE"), counters("write", v, "WRITE_SIZE"), durations(v)
     kernels = {}
     for k in sorted(set(fetch) | set(write) | set(dur)):

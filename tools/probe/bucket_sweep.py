@@ -51,6 +51,8 @@ if quick:
     shapes = [(1 << 26, 1 << 26), (1 << 28, 1 << 28)]
 if "--crossover" in sys.argv:
     shapes = [(n, nv) for n in (1 << 18, 1 << 20, 1 << 22, 1 << 24) for nv in (1 << 20, 1 << 24, 1 << 28)]
+if "--crossover3" in sys.argv:  # round 3: where does the merge-back take start to win?
+    shapes = [(n, nv) for n in (1 << 21, 1 << 22, 1 << 23, 1 << 24, 1 << 25, 1 << 26) for nv in (1 << 22, 1 << 24, 1 << 26, 1 << 28)]
 for n, nv in shapes:
     values, out = dev.create_empty_buffer(4 * nv), dev.create_empty_buffer(4 * n)
     idx, idx2 = dev.create_empty_buffer(4 * n), dev.create_empty_buffer(4 * n)

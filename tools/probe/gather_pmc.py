@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One variant of take / put at 2^28 uniformly random rows, a few launches, for rocprofv3 --pmc passes
-(tools/profile_gather.sh).  Usage: gather_pmc.py {take,put}_{direct,bucketed} [log2_rows]"""
+(tools/profile_gather.sh).  Usage: gather_pmc.py {take,put}_{direct,bucketed} | take_pairs [log2_rows]
+take_bucketed = the merge-back pipeline (round 3), take_pairs = the pair pipeline (tuning gather_bucket = 3)."""
 import ctypes as C
 import os
 import sys
@@ -20,7 +21,7 @@ values, out, idx, idx2 = (dev.create_empty_buffer(4 * n) for _ in range(4))
 capi.call("agpu_synth_i32", h, vp(values), n, 1, 0, 0)
 capi.call("agpu_synth_i32", h, vp(idx), n, 2, 0, n)
 capi.call("agpu_synth_i32", h, vp(idx2), n, 3, 0, n)
-p.set_tuning("gather_bucket", 2 if variant.endswith("bucketed") else 1)
+p.set_tuning("gather_bucket", 3 if variant.endswith("pairs") else 2 if variant.endswith("bucketed") else 1)
 for _ in range(3):
     if variant.startswith("take"):
         capi.call("agpu_take", h, 4, vp(values), n, vp(idx), vp(out), n)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""take / put at 2^28 uniformly random rows: direct, pair pipeline (gather_bucket = 3) and — for take — the merge-back pipeline
+(gather_bucket = 2), HIP-event medians in one process on the same buffers.  Run under `rocprofv3 --kernel-trace --stats` for the
+per-pass times (tools/profile_gather.sh)."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from arrow_gpu_amd import _capi as capi  # noqa: E402
+from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, CmpQuery, GpuDevice  # noqa: E402
+
+dev = GpuDevice(0)
+p = ArrowComputePipeline(dev, "take")
+q = CmpQuery(dev)
+h = p._handle
+vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 28
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+values, out, idx, idx2 = (dev.create_empty_buffer(4 * n) for _ in range(4))
+capi.call("agpu_synth_i32", h, vp(values), n, 1, 0, 0)
+capi.call("agpu_synth_i32", h, vp(idx), n, 2, 0, n)
+capi.call("agpu_synth_i32", h, vp(idx2), n, 3, 0, n)
+p.sync()
+
+
+def med(f):
+    f(), f()
+    p.sync()
+    ts = []
+    for _ in range(iters):
+        q.begin(p)
+        f()
+        q.end(p)
+        ts.append(q.wait_for_results())
+    return float(np.median(ts))
+
+
+res = {"rows": n}
+for label, mode in (("take_direct", 1), ("take_pairs", 3), ("take_mergeback", 2)):
+    p.set_tuning("gather_bucket", mode)
+    ms = med(lambda: capi.call("agpu_take", h, 4, vp(values), n, vp(idx), vp(out), n))
+    res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
+    print(label, res[label], flush=True)
+for label, mode in (("put_direct", 1), ("put_pairs", 2)):
+    p.set_tuning("gather_bucket", mode)
+    ms = med(lambda: capi.call("agpu_put_bounded", h, 4, vp(values), n, vp(idx), vp(out), n, vp(idx2), n))
+    res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
+    print(label, res[label], flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r03_take_passes.json"), "w"), indent=1)
