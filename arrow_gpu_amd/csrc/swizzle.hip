@@ -922,9 +922,12 @@ __global__ __launch_bounds__(BKT_T) void tk2_partition_kernel(const uint32_t* si
 // G2: vals[slot] = values[srcs[slot]] (0 when out of range), 16 Ki slots per workgroup, XCD-contiguous walk
 template <int WPE>
 __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* values, uint64_t n_src, const uint32_t* srcs, uint64_t total,
-                                                          uint32_t ntiles, uint32_t* vals) {
-  // 64 KiB + 8 KiB of LDS: TWO workgroups per CU, so that one's loads and gathers run under the other's LDS phases (with a
-  // separate 64 KiB array for the way back into slot order the kernel held one workgroup per CU: 1.20 ms → see DESIGN §4)
+                                                               uint32_t ntiles, uint32_t* vals) {
+  // 64 KiB + 8 KiB of LDS and ≤ 64 VGPRs: TWO workgroups per CU, so that one's loads and gathers run under the other's LDS
+  // phases.  To stay inside 64 registers the tile's sources are loaded twice (the second time from L2) instead of being
+  // kept across the ranking, ranks are packed two to a register, and only the 16 sorted entries live across the barrier
+  // that turns the entry array into the value array (a first version with everything kept spilled 18–32 VGPRs: 4.5 B/row of
+  // scratch traffic by PMC).
   __shared__ uint32_t sorted[TK2_GTILE];
   __shared__ uint32_t lcnt[TK2_GKEYS];
   __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
@@ -934,42 +937,43 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
   if (!bkt_tile_of_block(ntiles, &tile)) return;
   const uint64_t base = tile * TK2_GTILE;
   if (base >= total) return;
-  uint32_t s[TK2_GE];
-  bool live[TK2_GE];
-  uint32_t mn = 0xFFFFFFFFu, mx = 0;
-#pragma unroll
-  for (int q = 0; q < TK2_GE / 4; q++) {
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  auto load4 = [&](int q) -> u32x4 {
     const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
     u32x4 t = {0, 0, 0, 0};
-    if (i0 + 4 <= total) t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(srcs + i0));
+    if (i0 + 4 <= total) t = *reinterpret_cast<const u32x4*>(srcs + i0);
     else {
       if (i0 < total) t.x = srcs[i0];
       if (i0 + 1 < total) t.y = srcs[i0 + 1];
       if (i0 + 2 < total) t.z = srcs[i0 + 2];
     }
-    s[q * 4] = t.x; s[q * 4 + 1] = t.y; s[q * 4 + 2] = t.z; s[q * 4 + 3] = t.w;
+    return t;
+  };
+  auto live_at = [&](int q, int k) { return base + ((uint64_t)q * BKT_T + threadIdx.x) * 4 + (uint64_t)k < total; };
+  // pass 1: the tile's source span decides the path (uniform over the block)
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  for (uint32_t k = threadIdx.x; k < TK2_GKEYS; k += BKT_T) lcnt[k] = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      live[q * 4 + k] = i0 + k < total;
-      if (live[q * 4 + k]) {
-        mn = s[q * 4 + k] < mn ? s[q * 4 + k] : mn;
-        mx = s[q * 4 + k] > mx ? s[q * 4 + k] : mx;
+  for (int q = 0; q < TK2_GE / 4; q++) {
+    const u32x4 t = load4(q);
+    const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (live_at(q, k)) {
+        mn = sv[k] < mn ? sv[k] : mn;
+        mx = sv[k] > mx ? sv[k] : mx;
       }
-    }
   }
-  // the tile's source span decides the path (uniform over the block)
 #pragma unroll
   for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) {
-    const uint32_t a = (uint32_t)__shfl_down((int)mn, off), b = (uint32_t)__shfl_down((int)mx, off);
+    const uint32_t a = (uint32_t)__shfl_down((int)mn, off), b2 = (uint32_t)__shfl_down((int)mx, off);
     mn = a < mn ? a : mn;
-    mx = b > mx ? b : mx;
+    mx = b2 > mx ? b2 : mx;
   }
-  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   if (lane == 0) {
     red[wave] = mn;
     red[BKT_T / AGPU_WAVE + wave] = mx;
   }
-  for (uint32_t k = threadIdx.x; k < TK2_GKEYS; k += BKT_T) lcnt[k] = 0;
   __syncthreads();
   mn = red[0];
   mx = red[BKT_T / AGPU_WAVE];
@@ -981,16 +985,28 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
   const bool fast = mx < n_src && (mx - origin) < (1u << TK2_REL_BITS);
   if (!fast) {  // a tile of out-of-range rows, or one that straddles many small regions: row by row, slots keep their place
 #pragma unroll
-    for (int e = 0; e < TK2_GE; e++) {
-      const uint64_t i = base + ((uint64_t)(e / 4) * BKT_T + threadIdx.x) * 4 + (e & 3);
-      if (live[e]) vals[i] = s[e] < n_src ? values[s[e]] : 0u;
+    for (int q = 0; q < TK2_GE / 4; q++) {
+      const u32x4 t = load4(q);
+      const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (live_at(q, k)) vals[base + ((uint64_t)q * BKT_T + threadIdx.x) * 4 + (uint64_t)k] = sv[k] < n_src ? values[sv[k]] : 0u;
     }
     return;
   }
-  // order the tile by source LINE GROUP (128 elements): neighbouring lanes of the gather share a request
-  uint32_t rank[TK2_GE];
+  // pass 2 (sources from L2): rank every row inside its source LINE GROUP (128 elements): neighbouring lanes of the gather
+  // will share a request.  Ranks < 2^14: two to a register.
+  uint32_t rank2[TK2_GE / 2];
 #pragma unroll
-  for (int e = 0; e < TK2_GE; e++) rank[e] = live[e] ? atomicAdd(&lcnt[(s[e] - origin) >> TK2_GKEY_SHIFT], 1u) : 0u;
+  for (int q = 0; q < TK2_GE / 4; q++) {
+    const u32x4 t = load4(q);
+    const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
+    uint32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = live_at(q, k) ? atomicAdd(&lcnt[(sv[k] - origin) >> TK2_GKEY_SHIFT], 1u) : 0u;
+    rank2[q * 2] = r[0] | (r[1] << 16);
+    rank2[q * 2 + 1] = r[2] | (r[3] << 16);
+  }
   __syncthreads();
   {  // exclusive scan of the 2048 counters: thread t owns 2t, 2t+1
     const uint32_t c0 = lcnt[threadIdx.x * 2], c1 = lcnt[threadIdx.x * 2 + 1];
@@ -1010,31 +1026,43 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
     if (threadIdx.x == BKT_T - 1) tile_rows = run + c0 + c1;
     __syncthreads();
   }
+  // pass 3 (sources from L2 again): entries {source − origin, slot inside the tile} into line-group order
 #pragma unroll
-  for (int e = 0; e < TK2_GE; e++)
-    if (live[e]) {
-      const uint32_t rel = s[e] - origin;
-      const uint32_t pos = ((uint32_t)(e / 4) * BKT_T + threadIdx.x) * 4 + (uint32_t)(e & 3);  // the slot inside the tile
-      sorted[lcnt[rel >> TK2_GKEY_SHIFT] + rank[e]] = (rel << TK2_POS_BITS) | pos;
-    }
+  for (int q = 0; q < TK2_GE / 4; q++) {
+    const u32x4 t = load4(q);
+    const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (live_at(q, k)) {
+        const uint32_t rel = sv[k] - origin;
+        const uint32_t pos = ((uint32_t)q * BKT_T + threadIdx.x) * 4 + (uint32_t)k;
+        const uint32_t rk = (rank2[q * 2 + (k >> 1)] >> ((k & 1) * 16)) & 0xFFFFu;
+        sorted[lcnt[rel >> TK2_GKEY_SHIFT] + rk] = (rel << TK2_POS_BITS) | pos;
+      }
+  }
   __syncthreads();
   const uint32_t rows_here = tile_rows;
-  uint32_t val[TK2_GE], pos_of[TK2_GE];
+  uint32_t ent[TK2_GE];
 #pragma unroll
   for (int e = 0; e < TK2_GE; e++) {
     const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
-    pos_of[e] = 0xFFFFFFFFu;
-    val[e] = 0;
-    if (j < rows_here) {
-      const uint32_t ent = sorted[j];
-      pos_of[e] = ent & ((1u << TK2_POS_BITS) - 1u);
-      val[e] = values[origin + (ent >> TK2_POS_BITS)];  // the L2-resident gather
-    }
+    ent[e] = j < rows_here ? sorted[j] : 0u;
   }
   __syncthreads();  // every entry has been read: the same array takes the values, back in slot order
 #pragma unroll
-  for (int e = 0; e < TK2_GE; e++)
-    if (pos_of[e] != 0xFFFFFFFFu) sorted[pos_of[e]] = val[e];
+  for (int h0 = 0; h0 < TK2_GE; h0 += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+      v[e] = j < rows_here ? values[origin + (ent[h0 + e] >> TK2_POS_BITS)] : 0u;  // the L2-resident gather
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+      if (j < rows_here) sorted[ent[h0 + e] & ((1u << TK2_POS_BITS) - 1u)] = v[e];
+    }
+  }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < TK2_GE / 4; q++) {
