@@ -78,6 +78,9 @@ struct agpu_device {
   void* trig16_table = nullptr;
   // 2 KiB of f64 {1/c, −log2(1/c)} pairs for f32 pow (elementwise.hip: pow_f32_dev); same allocation, + 8 KiB
   void* pow_table = nullptr;
+  // 6 KiB behind it: f32 results of sin / cos / sinh for every u8 and every i8 value, by the SAME device functions as the f32
+  // kernels (identical bits), built once per device — a block copies its 1 KiB instead of evaluating 256 functions
+  void* lut8_tables = nullptr;
 
   // ---- resource pools (runtime.hip).  Measured on MI355X / ROCm 7: hipStreamCreate 4.3 ms + hipStreamDestroy 2.6 ms,
   // hipFree 0.2 ms (implicit device sync), hipMalloc of a 4 GB block 0.2–60 ms — against 0.19 ms for the kernel of a
@@ -151,7 +154,9 @@ void agpu_internal_free_staging(agpu_device* dev);  // arrow_cdata.hip
 struct agpu_pipeline;
 agpu_status agpu_internal_bounce_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device);  // arrow_cdata.hip
 agpu_status agpu_internal_host_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device);    // arrow_cdata.hip: complete on return
-#define AGPU_TABLE_BYTES (512 * 16 + 128 * 16)
+// + 6 result tables of 256 f32 for the fused 8-bit kernels (elementwise.hip lut8_kernel): {u8, i8} × {sin, cos, sinh}
+#define AGPU_LUT8_TABLES 6
+#define AGPU_TABLE_BYTES (512 * 16 + 128 * 16 + AGPU_LUT8_TABLES * 256 * 4)
 agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table);  // elementwise.hip; synchronous
 agpu_status agpu_internal_fill_bytes(struct agpu_pipeline* p, void* out, uint32_t pattern, uint64_t bytes);  // elementwise.hip: fill_kernel, out 16-byte aligned
 

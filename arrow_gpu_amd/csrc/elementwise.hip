@@ -1259,9 +1259,41 @@ struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders
 // per store.  The next tile's load is issued before the current tile's lookups.
 // 128 threads (each builds two table entries): 0.78 of the roof against 0.75–0.77 at 256 and 0.78 at 64 (three
 // alternations on one box) — four stores per lane want small blocks (tools/probe/store_probe.hip)
+// Round 3: the table is no longer EVALUATED per block (256 function calls per 2048-row tile were two thirds of the block's
+// instructions: sin_u8 ran at 0.745 of the roof where the plain u8 → f32 cast ran at 0.79 on the same buffers) — it is built
+// once per device by lut8_build_kernel with the same device functions (agpu_device::lut8_tables) and a block copies its 1 KiB.
 #define AGPU_LUT8_BLOCK 128
 template <typename TI, typename F>
-__global__ __launch_bounds__(AGPU_LUT8_BLOCK) void lut8_kernel(const TI* in, float* out, uint64_t ntiles) {
+__global__ void lut8_build_kernel(float* tab) {
+  const uint32_t e = threadIdx.x;
+  if (e < 256) tab[e] = F::ap((float)(TI)(uint8_t)e, 0.0f);  // indexed by the raw byte
+}
+template <typename TI, typename F> struct Lut8Slot;
+#define AGPU_LUT8_SLOT(TI, F, K) \
+  template <> struct Lut8Slot<TI, F> { static constexpr int value = K; };
+AGPU_LUT8_SLOT(uint8_t, UnSin, 0)
+AGPU_LUT8_SLOT(uint8_t, UnCos, 1)
+AGPU_LUT8_SLOT(uint8_t, UnSinh, 2)
+AGPU_LUT8_SLOT(int8_t, UnSin, 3)
+AGPU_LUT8_SLOT(int8_t, UnCos, 4)
+AGPU_LUT8_SLOT(int8_t, UnSinh, 5)
+#undef AGPU_LUT8_SLOT
+agpu_status agpu_internal_build_lut8(void* tables) {
+  float* t = static_cast<float*>(tables);
+#define AGPU_LUT8_BUILD(TI, F) hipLaunchKernelGGL((lut8_build_kernel<TI, F>), dim3(1), dim3(256), 0, nullptr, t + 256 * Lut8Slot<TI, F>::value)
+  AGPU_LUT8_BUILD(uint8_t, UnSin);
+  AGPU_LUT8_BUILD(uint8_t, UnCos);
+  AGPU_LUT8_BUILD(uint8_t, UnSinh);
+  AGPU_LUT8_BUILD(int8_t, UnSin);
+  AGPU_LUT8_BUILD(int8_t, UnCos);
+  AGPU_LUT8_BUILD(int8_t, UnSinh);
+#undef AGPU_LUT8_BUILD
+  AGPU_HIP(hipGetLastError());
+  AGPU_HIP(hipStreamSynchronize(nullptr));
+  return AGPU_OK;
+}
+template <typename TI>
+__global__ __launch_bounds__(AGPU_LUT8_BLOCK) void lut8_kernel(const TI* in, float* out, uint64_t ntiles, const float* gtab) {
   constexpr uint32_t WAVES = AGPU_LUT8_BLOCK / AGPU_WAVE;
   __shared__ float lut[256];
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
@@ -1270,7 +1302,7 @@ __global__ __launch_bounds__(AGPU_LUT8_BLOCK) void lut8_kernel(const TI* in, flo
   uint64_t t = blockIdx.x;
   u32x4 v = {0, 0, 0, 0};
   if (t < ntiles) v = __builtin_nontemporal_load(in16 + (t * WAVES + wave) * AGPU_WAVE + lane);
-  for (uint32_t e = threadIdx.x; e < 256; e += AGPU_LUT8_BLOCK) lut[e] = F::ap((float)(TI)(uint8_t)e, 0.0f);  // indexed by the raw byte
+  if (threadIdx.x < 64) reinterpret_cast<f32x4*>(lut)[threadIdx.x] = reinterpret_cast<const f32x4*>(gtab)[threadIdx.x];  // 1 KiB from L2
   __syncthreads();
   while (t < ntiles) {
     const uint64_t c = t * WAVES + wave;
@@ -1303,7 +1335,8 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
       const int grid = stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p));
-      hipLaunchKernelGGL((lut8_kernel<TI, F>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, po, ntiles);
+      hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, po, ntiles,
+                         static_cast<const float*>(p->dev->lut8_tables) + 256 * Lut8Slot<TI, F>::value);
       done = ntiles * TILE_ROWS;
     }
     if (done < n)
@@ -1334,7 +1367,12 @@ __global__ void trig16_build_kernel(SinCos64* tab) {
   tab[i].s = sin(a);
   tab[i].c = cos(a);
 }
+agpu_status agpu_internal_build_lut8(void* tables);
 agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table) {
+  {  // the 8-bit result tables live right behind the pow table (common.hpp AGPU_TABLE_BYTES)
+    const agpu_status ls = agpu_internal_build_lut8(static_cast<char*>(pow_table) + 128 * 16);
+    if (ls != AGPU_OK) return ls;
+  }
   hipLaunchKernelGGL(trig16_build_kernel, dim3(2), dim3(256), 0, nullptr, static_cast<SinCos64*>(trig16_table));
   hipLaunchKernelGGL(pow_build_kernel, dim3(1), dim3(128), 0, nullptr, static_cast<PowTab*>(pow_table));
   AGPU_HIP(hipGetLastError());
@@ -1364,11 +1402,14 @@ __device__ __forceinline__ float trig16_eval(TabPtr tab, uint32_t raw16) {
 // one chunk per wave and tile: two stores per lane (two chunks, i.e. four stores: 0.72 → 0.75 of the roof; a store stream
 // likes few stores per lane, tools/probe/store_probe.hip)
 #define AGPU_TRIG16_U 1
-template <typename TI, int WANT_COS>
-__global__ __launch_bounds__(AGPU_BLOCK) void trig16_kernel(const TI* in, float* out, uint64_t ntiles,
-                                                           const SinCos64* gtab) {
+#ifndef AGPU_TRIG16_BLOCK
+#define AGPU_TRIG16_BLOCK 512  // 256: 0.71 of the roof, 512: 0.73–0.74, 1024: 0.72–0.73 (tools/probe/narrow_tunings.py, AGPU_TRIG16_BLOCK env for the A/B)
+#endif
+template <typename TI, int WANT_COS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trig16_kernel(const TI* in, float* out, uint64_t ntiles,
+                                                      const SinCos64* gtab) {
   constexpr int U = AGPU_TRIG16_U;  // chunks per wave per tile
-  constexpr uint32_t WAVES = AGPU_BLOCK / AGPU_WAVE;
+  constexpr uint32_t WAVES = BLOCK / AGPU_WAVE;
   __shared__ SinCos64 tab[512];
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   const u32x4* in16 = reinterpret_cast<const u32x4*>(in);
@@ -1380,8 +1421,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void trig16_kernel(const TI* in, float*
   {
     const u32x4* g = reinterpret_cast<const u32x4*>(gtab);
     u32x4* l = reinterpret_cast<u32x4*>(tab);
-    l[threadIdx.x] = g[threadIdx.x];
-    l[threadIdx.x + AGPU_BLOCK] = g[threadIdx.x + AGPU_BLOCK];
+    for (uint32_t k = threadIdx.x; k < 512; k += BLOCK) l[k] = g[k];
   }
   __syncthreads();
   while (t < ntiles) {
@@ -1419,7 +1459,10 @@ template <typename TI, int WANT_COS>
 static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
   static_assert(sizeof(TI) == 2, "16-bit sources only");
   if (n == 0) return AGPU_OK;
-  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_BLOCK * 8 * AGPU_TRIG16_U;
+  // the 8 KiB table is copied into LDS by every block: with 256-thread blocks (2048-row tiles) that is 4 B/row of L2 → LDS
+  // traffic beside the 6 B/row of the stream; bigger blocks keep the two stores per lane and pay the copy once per 4096 / 8192 rows
+  static const int blk = [] { const char* e = getenv("AGPU_TRIG16_BLOCK"); const int v = e ? atoi(e) : 0; return v == 256 || v == 512 || v == 1024 ? v : AGPU_TRIG16_BLOCK; }();
+  const uint64_t TILE_ROWS = (uint64_t)blk * 8 * AGPU_TRIG16_U;
   const TI* pi = static_cast<const TI*>(in);
   float* po = static_cast<float*>(out);
   const SinCos64* tab = static_cast<const SinCos64*>(p->dev->trig16_table);
@@ -1427,8 +1470,10 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
   if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS>), dim3(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p))), dim3(AGPU_BLOCK), 0, p->stream, pi,
-                         po, ntiles, tab);
+      const dim3 grid(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p)));
+      if (blk == 1024) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 1024>), grid, dim3(1024), 0, p->stream, pi, po, ntiles, tab);
+      else if (blk == 512) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 512>), grid, dim3(512), 0, p->stream, pi, po, ntiles, tab);
+      else hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 256>), grid, dim3(256), 0, p->stream, pi, po, ntiles, tab);
       done = ntiles * TILE_ROWS;
     }
   }

@@ -203,6 +203,7 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
     }
     d->trig16_table = tab_of[slot];
     d->pow_table = static_cast<char*>(d->trig16_table) + 512 * 16;
+    d->lut8_tables = static_cast<char*>(d->pow_table) + 128 * 16;
   }
   d->cache_cap = d->props.totalGlobalMem / 2;  // cached (idle) blocks never hold more than half of HBM
   *out_device = d.release();

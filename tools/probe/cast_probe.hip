@@ -134,6 +134,64 @@ __global__ __launch_bounds__(64) void cast_v5(const u32x4* in, f32x4* out, uint6
   }
 }
 
+
+// variant 6 (round 3): LOAD-WAVE / STORE-WAVE split through LDS — the idea DESIGN listed as untried.  A block of (1 + SW) waves:
+// wave 0 only LOADS (K chunks of 1 KiB = K 16-byte loads per lane per round, a K KiB read burst) into one half of a double
+// buffer in LDS; waves 1..SW only STORE: wave w converts chunks w-1, w-1+SW, … of the round and writes each as four coalesced
+// 1 KiB rows (the dword of store j, lane l sits at LDS word j*64 + l of the chunk: conflict-free reads, no crossbar trips).
+// Persistent over the grid; one barrier per round.
+template <int SW, int K>
+__global__ __launch_bounds__(64 * (1 + SW)) void cast_v6(const u32x4* in, f32x4* out, uint64_t nrounds) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2][K * 256];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t r = blockIdx.x;
+  if (wave == 0 && r < nrounds) {
+#pragma unroll
+    for (int k = 0; k < K; k++) *reinterpret_cast<u32x4*>(&lds[0][k * 256 + lane * 4]) = __builtin_nontemporal_load(in + (r * K + k) * 64 + lane);
+  }
+  __syncthreads();
+  int buf = 0;
+  while (r < nrounds) {
+    const uint64_t nxt = r + gridDim.x;
+    if (wave == 0) {
+      if (nxt < nrounds) {
+#pragma unroll
+        for (int k = 0; k < K; k++) *reinterpret_cast<u32x4*>(&lds[buf ^ 1][k * 256 + lane * 4]) = __builtin_nontemporal_load(in + (nxt * K + k) * 64 + lane);
+      }
+    } else {
+      for (int k = (int)wave - 1; k < K; k += SW) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t w = lds[buf][k * 256 + j * 64 + lane];
+          __builtin_nontemporal_store(cvt4(w), out + (r * K + k) * 256 + j * 64 + lane);
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+    r = nxt;
+  }
+}
+
+// variant 7: no dedicated waves, but the READS of a 256-thread block go out as one burst first: every wave loads its chunk, all
+// four chunks meet in LDS, then every wave stores its own chunk's four rows from LDS (conflict-free) — cvt_wide's shape with the
+// transposition done by LDS memory instead of the crossbar, one block-wide barrier per tile
+__global__ __launch_bounds__(256) void cast_v7(const u32x4* in, f32x4* out, uint64_t ntiles) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 256];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const u32x4 v = __builtin_nontemporal_load(in + (t * 4 + wave) * 64 + lane);
+    __syncthreads();
+    *reinterpret_cast<u32x4*>(&lds[wave * 256 + lane * 4]) = v;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t w = lds[wave * 256 + j * 64 + lane];
+      __builtin_nontemporal_store(cvt4(w), out + (t * 4 + wave) * 256 + j * 64 + lane);
+    }
+  }
+}
+
 extern "C" int probe_cast(const void* in, void* out, uint64_t n, int variant, int block, int u, void* stream) {
   hipStream_t s = (hipStream_t)stream;
 #define GO0(B, U_)                                                                                         \
@@ -145,6 +203,20 @@ extern "C" int probe_cast(const void* in, void* out, uint64_t n, int variant, in
   {                                                                                                        \
     uint64_t nt = n / 1024 / ((uint64_t)(B / 64) * U_);                                                    \
     hipLaunchKernelGGL((cast_v1<B, U_>), dim3((unsigned)nt), dim3(B), 0, s, (const u32x4*)in, (f32x4*)out, nt); \
+  }
+  if (variant == 6) {  // block = store waves (1, 2 or 4), u = chunks per round (4 or 8); grid = persistent (8 blocks per CU)
+    const int sw = block, k = u;
+    const uint64_t nrounds = n / 1024 / (uint64_t)k;
+    const unsigned grid = (unsigned)(nrounds < 2048 ? nrounds : 2048);
+#define GO6(SW, K) hipLaunchKernelGGL((cast_v6<SW, K>), dim3(grid), dim3(64 * (1 + SW)), 0, s, (const u32x4*)in, (f32x4*)out, nrounds)
+    if (sw == 1 && k == 4) GO6(1, 4); else if (sw == 2 && k == 4) GO6(2, 4); else if (sw == 4 && k == 4) GO6(4, 4);
+    else if (sw == 2 && k == 8) GO6(2, 8); else if (sw == 4 && k == 8) GO6(4, 8); else if (sw == 4 && k == 16) GO6(4, 16); else return 1;
+    return (int)hipGetLastError();
+  }
+  if (variant == 7) {
+    const uint64_t ntiles = n / 4096;
+    hipLaunchKernelGGL(cast_v7, dim3((unsigned)ntiles), dim3(256), 0, s, (const u32x4*)in, (f32x4*)out, ntiles);
+    return (int)hipGetLastError();
   }
   if (variant == 5) {
     const uint64_t nchunks = n / 1024;
