@@ -544,6 +544,11 @@ static bool all_done_locked(const std::vector<agpu_event_ref*>& v) {
 
 static agpu_status malloc_impl(agpu_device* dev, size_t bytes, int32_t zero_fill, const void* const* neighbours, int n_neighbours,
                                void** out_ptr);
+// agpu_malloc_table lays its columns out itself inside ONE fresh hipMalloc block: keep that block out of the arenas (a table
+// carved from an arena ran its compare at 0.80–0.83 of the roof where the same layout in its own block runs 0.85–0.89:
+// tools/r03_ab.sh, three boxes — inside a 32 GiB arena the physical placement of a 9 GiB span is not what a fresh 9 GiB
+// allocation gets)
+static thread_local bool t_no_arena = false;
 agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void** out_ptr) {
   return malloc_impl(dev, bytes, zero_fill, nullptr, 0, out_ptr);
 }
@@ -568,7 +573,7 @@ static agpu_status malloc_impl(agpu_device* dev, size_t bytes, int32_t zero_fill
   std::vector<agpu_event_ref*> pending;
   bool sync_all = false;
   if (large) {
-    const bool placed = padded >= AGPU_ARENA_MIN_BLOCK && g_pool_arena.load(std::memory_order_relaxed) != 0;
+    const bool placed = padded >= AGPU_ARENA_MIN_BLOCK && g_pool_arena.load(std::memory_order_relaxed) != 0 && !t_no_arena;
     padded = placed ? arena_padded(padded) : (padded + AGPU_POOL_GRANULE - 1) / AGPU_POOL_GRANULE * AGPU_POOL_GRANULE;
     std::lock_guard<std::mutex> lock(dev->mu);
     auto it = dev->cache.lower_bound(padded);
@@ -760,7 +765,9 @@ agpu_status agpu_malloc_table(agpu_device* dev, int32_t n_columns, const uint64_
     }
   }
   void* base = nullptr;
+  t_no_arena = true;
   agpu_status st = agpu_malloc(dev, total, zero_fill, &base);
+  t_no_arena = false;
   if (st != AGPU_OK) return st;
   agpu_device::TableGroup* g = new agpu_device::TableGroup{base, (uint32_t)n_columns};
   {

@@ -285,6 +285,8 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true", help="skip extra.configs / extra.layout_pool / extra.strong_scaling")
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
     ap.add_argument("--rendezvous-timeout", type=float, default=120.0)
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="agpu_set_tuning before anything is allocated (A/B runs, e.g. --tune pool_arena=0); recorded in config.tuning")
     args = ap.parse_args()
 
     # NOTHING of torch is imported by a worker: the process runs on the HIP + RCCL that libarrow_gpu_hip.so links
@@ -293,6 +295,9 @@ def main():
     from arrow_gpu_amd import sharding
     from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
 
+    for kv in args.tune:
+        k, v = kv.split("=", 1)
+        capi.call("agpu_set_tuning", k.encode(), int(v))
     rank, world, local_rank = sharding.ranks_from_env()
     if world != args.gpus and rank == 0:
         if world == 1 and args.gpus > 1:
@@ -646,7 +651,8 @@ def main():
             "config": {"workload": "f32 add (1e9 rows, no nulls) + i32 eq -> bitmap with fused validity AND (1e9 rows, 10% nulls/side)",
                        "rows_per_gpu": n, "rows_total": total_rows, "sharding": shard_txt + ", no data-path collective",
                        "layout": "columns allocated as two tables placed for the HBM channel hash (agpu_malloc_table, DESIGN.md §3)",
-                       "frac_hbm_peak_per_gpu": round(value / world / HBM_PEAK_GBPS, 4)},
+                       "frac_hbm_peak_per_gpu": round(value / world / HBM_PEAK_GBPS, 4),
+                       **({"tuning": args.tune} if args.tune else {})},
             "roofline": {"bound": "hbm", "kernel": "ew_kernel<float, OpAdd> (agpu_binary ADD f32)",
                          "achieved": round(add_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(add_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
