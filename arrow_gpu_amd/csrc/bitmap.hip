@@ -90,12 +90,12 @@ agpu_status agpu_internal_count_fold(agpu_pipeline* p, const uint32_t* partials,
 }
 
 // inputs a,b,c,d may be null (treated as all-ones) when NULLABLE; COUNT: partials[blockIdx.x] = set bits this block stored
-template <int OP, bool NULLABLE, bool COUNT = false>
-__global__ __launch_bounds__(AGPU_BLOCK) void bitmap_kernel(const uint64_t* a, const uint64_t* b, const uint64_t* c,
-                                                           const uint64_t* d, uint64_t* out, uint64_t n_words,
-                                                           int vec_ok, uint32_t* partials = nullptr) {
-  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+template <int OP, bool NULLABLE, bool COUNT = false, int BLK = AGPU_BLOCK>
+__global__ __launch_bounds__(BLK) void bitmap_kernel(const uint64_t* a, const uint64_t* b, const uint64_t* c,
+                                                    const uint64_t* d, uint64_t* out, uint64_t n_words,
+                                                    int vec_ok, uint32_t* partials = nullptr) {
+  const uint64_t tid = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * BLK;
   const uint64_t n_pairs = vec_ok ? n_words / 2 : 0;
   const u64x2 ones = {~0ull, ~0ull};
   uint32_t cnt = 0;
@@ -119,14 +119,14 @@ __global__ __launch_bounds__(AGPU_BLOCK) void bitmap_kernel(const uint64_t* a, c
     if constexpr (COUNT) cnt += (uint32_t)__popcll(r);
   }
   if constexpr (COUNT) {  // every lane reaches this point: no divergence around the shuffles / the barrier
-    __shared__ uint32_t wcnt[AGPU_BLOCK / AGPU_WAVE];
+    __shared__ uint32_t wcnt[BLK / AGPU_WAVE];
     cnt = wave_sum_u32(cnt);
     if ((threadIdx.x & (AGPU_WAVE - 1)) == 0) wcnt[threadIdx.x / AGPU_WAVE] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t s = 0;
 #pragma unroll
-      for (int k = 0; k < AGPU_BLOCK / AGPU_WAVE; k++) s += wcnt[k];
+      for (int k = 0; k < BLK / AGPU_WAVE; k++) s += wcnt[k];
       partials[blockIdx.x] = s;
     }
   }
@@ -162,6 +162,15 @@ static agpu_status launch_bitmap(agpu_pipeline* p, const void* a, const void* b,
     AGPU_LAUNCH_CHECK();
     // the kernel counted every bit of every word it stored: take the padding bits of the last word out again
     return agpu_internal_count_fold(p, static_cast<const uint32_t*>(scratch), m, out, n_words, n_bits, true, false, out_count_dev);
+  }
+  static const int blk = [] { const char* e = getenv("AGPU_BITMAP_BLOCK"); return e && atoi(e) == 64 ? 64 : AGPU_BLOCK; }();  // A/B probe
+  if (blk == 64) {
+    const int g64 = stream_grid_for(p, (n_words / 2 + 63) / 64);
+    hipLaunchKernelGGL((bitmap_kernel<OP, NULLABLE, false, 64>), dim3(g64), dim3(64), 0, p->stream,
+                       static_cast<const uint64_t*>(a), static_cast<const uint64_t*>(b), static_cast<const uint64_t*>(c),
+                       static_cast<const uint64_t*>(d), static_cast<uint64_t*>(out), n_words, vec_ok, (uint32_t*)nullptr);
+    AGPU_LAUNCH_CHECK();
+    return AGPU_OK;
   }
   hipLaunchKernelGGL((bitmap_kernel<OP, NULLABLE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
                      static_cast<const uint64_t*>(a), static_cast<const uint64_t*>(b), static_cast<const uint64_t*>(c),
