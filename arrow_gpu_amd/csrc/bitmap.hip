@@ -163,7 +163,11 @@ static agpu_status launch_bitmap(agpu_pipeline* p, const void* a, const void* b,
     // the kernel counted every bit of every word it stored: take the padding bits of the last word out again
     return agpu_internal_count_fold(p, static_cast<const uint32_t*>(scratch), m, out, n_words, n_bits, true, false, out_count_dev);
   }
-  static const int blk = [] { const char* e = getenv("AGPU_BITMAP_BLOCK"); return e && atoi(e) == 64 ? 64 : AGPU_BLOCK; }();  // A/B probe
+  // two- to four-input ops in one-wave blocks (the element-wise kernels' shape), `not` in 256-thread blocks: at 125 MB per bitmap,
+  // alternating runs of tools/kernel_table.py on one box — AND 0.725–0.740 → 0.749–0.755 of the roof, merge validity 0.885–0.905 →
+  // 0.915–0.936, not 0.834–0.841 → 0.818–0.833 (AGPU_BITMAP_BLOCK = 64 / 256 forces one shape for the A/B)
+  static const int forced = [] { const char* e = getenv("AGPU_BITMAP_BLOCK"); return e ? atoi(e) : 0; }();
+  const int blk = forced == 64 || forced == 256 ? forced : (OP == BM_NOT ? 256 : 64);
   if (blk == 64) {
     const int g64 = stream_grid_for(p, (n_words / 2 + 63) / 64);
     hipLaunchKernelGGL((bitmap_kernel<OP, NULLABLE, false, 64>), dim3(g64), dim3(64), 0, p->stream,

@@ -438,7 +438,7 @@ def main():
     # ---- strong-scaling leg of a weak run: the same step over this rank's share of a `rows`-row column (shard_rows cuts
     # it: 125 M rows per GPU at world 8), on the leading rows of the resident shards; same barrier-bracketed timing.
     # One launch per N then yields both curves.  At world 1 strong == weak, nothing to add.
-    if world > 1 and args.scaling == "weak" and not args.no_extra_configs:
+    if (world > 1 or os.environ.get("AGPU_BENCH_STRONG_LEG")) and args.scaling == "weak" and not args.no_extra_configs:  # (env: world-1 rehearsal of this leg)
         try:
             ns = sharding.shard_rows(args.rows, world, rank).rows
             el_s, add_s, eq_s, pr_s = timed_run(make_step(main_bufs, ns), args.steps, args.warmup)
