@@ -88,6 +88,7 @@ SIGNATURES = {
     "agpu_comm_init_rank": [_vp, _vp, _i32, _i32, _pp],
     "agpu_comm_init_rank_timeout": [_vp, _vp, _i32, _i32, _i64, _pp],
     "agpu_comm_runtime_info": [C.c_char_p, _sz],
+    "agpu_take_validity": [_vp, _i32, _vp, _u64, _vp, _vp, _vp, _vp, _u64],
     "agpu_compare_validity_count": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp],
     "agpu_bitmap_binary_count": [_vp, _i32, _vp, _vp, _vp, _u64, _vp],
     "agpu_bitmap_merge_validity_count": [_vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp],

@@ -920,9 +920,14 @@ __global__ __launch_bounds__(BKT_T) void tk2_partition_kernel(const uint32_t* si
 }
 
 // G2: vals[slot] = values[srcs[slot]] (0 when out of range), 16 Ki slots per workgroup, XCD-contiguous walk
-template <int WPE>
+// BITS: the source column's VALIDITY bit travels with the value (take of an array with nulls [ref: crates/routines/src/take.rs
+// :9-55 values + bool.rs:33-46 validity]): the bit of row idx sits in the 16 KiB of bitmap that belong to the tile's 512 KiB
+// region — after the line-group sort neighbouring lanes read the same 16 bytes of it — and leaves as vbits_slot, one bit per
+// slot in slot order (256 u64 words per tile).
+template <int WPE, bool BITS>
 __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* values, uint64_t n_src, const uint32_t* srcs, uint64_t total,
-                                                               uint32_t ntiles, uint32_t* vals) {
+                                                               uint32_t ntiles, uint32_t* vals, const uint32_t* vbits_src,
+                                                               uint64_t* vbits_slot) {
   // 64 KiB + 8 KiB of LDS and ≤ 64 VGPRs: TWO workgroups per CU, so that one's loads and gathers run under the other's LDS
   // phases.  To stay inside 64 registers the tile's sources are loaded twice (the second time from L2) instead of being
   // kept across the ranking, ranks are packed two to a register, and only the 16 sorted entries live across the barrier
@@ -933,11 +938,20 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
   __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
   __shared__ uint32_t tile_rows;
   __shared__ uint32_t red[2 * (BKT_T / AGPU_WAVE)];
+  __shared__ uint32_t bitl[BITS ? TK2_GTILE / 32 : 1];  // the tile's validity bits by slot
   uint64_t tile;
   if (!bkt_tile_of_block(ntiles, &tile)) return;
   const uint64_t base = tile * TK2_GTILE;
   if (base >= total) return;
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  if constexpr (BITS)
+    if (threadIdx.x < TK2_GTILE / 32) bitl[threadIdx.x] = 0;
+  auto store_bits = [&]() {  // after a barrier: slot-ordered validity words of this tile
+    if constexpr (BITS) {
+      if (threadIdx.x < TK2_GTILE / 64 && base + (uint64_t)threadIdx.x * 64 < total)
+        vbits_slot[base / 64 + threadIdx.x] = (uint64_t)bitl[threadIdx.x * 2] | ((uint64_t)bitl[threadIdx.x * 2 + 1] << 32);
+    }
+  };
   auto load4 = [&](int q) -> u32x4 {
     const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
     u32x4 t = {0, 0, 0, 0};
@@ -990,7 +1004,18 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
       const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        if (live_at(q, k)) vals[base + ((uint64_t)q * BKT_T + threadIdx.x) * 4 + (uint64_t)k] = sv[k] < n_src ? values[sv[k]] : 0u;
+        if (live_at(q, k)) {
+          const bool ok = sv[k] < n_src;
+          vals[base + ((uint64_t)q * BKT_T + threadIdx.x) * 4 + (uint64_t)k] = ok ? values[sv[k]] : 0u;
+          if constexpr (BITS) {
+            const uint32_t pos = ((uint32_t)q * BKT_T + threadIdx.x) * 4 + (uint32_t)k;
+            if (ok && ((vbits_src[sv[k] >> 5] >> (sv[k] & 31)) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
+          }
+        }
+    }
+    if constexpr (BITS) {
+      __syncthreads();
+      store_bits();
     }
     return;
   }
@@ -1062,8 +1087,23 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
       const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
       if (j < rows_here) sorted[ent[h0 + e] & ((1u << TK2_POS_BITS) - 1u)] = v[e];
     }
+    if constexpr (BITS) {  // the validity bits of the same eight sources: 16 bytes of bitmap per line group, shared by neighbours
+      uint32_t w[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+        w[e] = j < rows_here ? vbits_src[(origin + (ent[h0 + e] >> TK2_POS_BITS)) >> 5] : 0u;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+        const uint32_t src = origin + (ent[h0 + e] >> TK2_POS_BITS), pos = ent[h0 + e] & ((1u << TK2_POS_BITS) - 1u);
+        if (j < rows_here && ((w[e] >> (src & 31)) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
+      }
+    }
   }
   __syncthreads();
+  store_bits();
 #pragma unroll
   for (int q = 0; q < TK2_GE / 4; q++) {
     const uint32_t l0 = ((uint32_t)q * BKT_T + threadIdx.x) * 4;
@@ -1079,16 +1119,20 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
 }
 
 // F2: out[i] = vals[offs[t][key(i)] + rank16[i]] — the tile's runs come into LDS as contiguous pieces, rows pick from there
+template <bool BITS>
 __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, uint64_t n, uint64_t n_src, int rs, uint32_t bs,
                                                          const uint16_t* counts, const uint32_t* offsets, uint32_t nbp,
-                                                         uint32_t ntiles, const uint16_t* rank16, const uint32_t* vals, uint32_t* out) {
+                                                         uint32_t ntiles, const uint16_t* rank16, const uint32_t* vals, uint32_t* out,
+                                                         const uint32_t* vbits_slot, uint64_t* out_validity) {
   __shared__ uint32_t A[TK2_TILE];
+  __shared__ uint32_t bl[BITS ? TK2_TILE / 32 : 1];  // the validity bits of the tile's slots (BITS)
   __shared__ uint32_t lcnt[BKT_MAX];
   __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
   __shared__ uint32_t tile_rows;
   uint64_t tile64;  // XCD-contiguous, like P2: the 64-byte runs of neighbouring tiles share their lines in one L2
   if (!bkt_tile_of_block(ntiles, &tile64)) return;
   const uint32_t tile = (uint32_t)tile64;
+  if constexpr (BITS) bl[threadIdx.x] = 0;  // TK2_TILE / 32 == BKT_T words
   const uint64_t base = (uint64_t)tile * TK2_TILE;
   const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
   // start[k] (exclusive scan of the tile's counts) and the runs' global slots
@@ -1159,6 +1203,13 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
       const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
       g[e] = j < rows_here ? A[j] : 0u;
     }
+    if constexpr (BITS) {  // the slot's validity bit: one word per 32 slots, a run's 16 slots share it
+#pragma unroll
+      for (int e = 0; e < TK2_E; e++) {
+        const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
+        if (j < rows_here && ((vbits_slot[g[e] >> 5] >> (g[e] & 31)) & 1u)) atomicOr(&bl[j >> 5], 1u << (j & 31));
+      }
+    }
 #pragma unroll
     for (int e = 0; e < TK2_E; e++) {
       const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
@@ -1181,12 +1232,23 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
       for (int k = 0; k < 4; k++)
         if (i0 + k < n) out[i0 + k] = A[sl[q * 4 + k]];
     }
+    if constexpr (BITS) {  // 16 neighbouring lanes hold the 64 rows of one output validity word (rows past n: 0)
+      uint64_t nib = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (i0 + k < n && ((bl[sl[q * 4 + k] >> 5] >> (sl[q * 4 + k] & 31)) & 1u)) nib |= 1ull << k;
+      uint64_t word = nib << (4 * (threadIdx.x & 15));
+#pragma unroll
+      for (int sft = 1; sft < 16; sft <<= 1) word |= __shfl_xor(word, sft);
+      if ((threadIdx.x & 15) == 0 && i0 < n) out_validity[i0 / 64] = word;
+    }
   }
 }
 
 // take of 4-byte values through the merge-back pipeline; AGPU_ERR_UNSUPPORTED when the shape does not qualify
+// vbits_src != nullptr: the source's validity bitmap is gathered with the values into out_validity (agpu_take_validity)
 static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* values, uint64_t n_src, const uint32_t* si, uint32_t* out,
-                                         uint64_t n) {
+                                         uint64_t n, const uint32_t* vbits_src = nullptr, uint64_t* out_validity = nullptr) {
   if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || !aligned16(si) || !aligned16(out) || p->capturing) return AGPU_ERR_UNSUPPORTED;
   const int rs = bkt_region_bits(p, n_src, 4);
   const uint32_t bs = (uint32_t)((n_src + ((uint64_t)1 << rs) - 1) >> rs);
@@ -1197,7 +1259,9 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* value
   const uint32_t nbp = (bs + 1 + 3) & ~3u;
   const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
   void *ctl_v = nullptr, *srcs_v = nullptr, *vals_v = nullptr, *rank_v = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr;
+  void* vslot_v = nullptr;
   agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
+  if (st == AGPU_OK && vbits_src) st = agpu_malloc(dev, ((size_t)gtiles * TK2_GTILE) / 8 + 16, 0, &vslot_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 4 * n + 16, 0, &srcs_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 4 * n + 16, 0, &vals_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 2 * n + 16, 0, &rank_v);
@@ -1223,22 +1287,28 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* value
       hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl, offsets);
       hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, offsets, nbp,
                          ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v));
-      static const int g_wpe = [] { const char* e = getenv("AGPU_TK2_G_WPE"); return e && *e == '4' ? 4 : 8; }();  // A/B probe only
-      if (g_wpe == 8)
-        hipLaunchKernelGGL((tk2_gather_kernel<8>), dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, values, n_src,
-                           static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint32_t*>(vals_v));
-      else
-        hipLaunchKernelGGL((tk2_gather_kernel<4>), dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, values, n_src,
-                           static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint32_t*>(vals_v));
-      hipLaunchKernelGGL(tk2_merge_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp,
-                         ntiles, static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(vals_v), out);
+      const dim3 ggrid((gtiles + 7) / 8 * 8), fgrid((ntiles + 7) / 8 * 8);
+      uint64_t* vslot = static_cast<uint64_t*>(vslot_v);
+      if (vbits_src) {
+        hipLaunchKernelGGL((tk2_gather_kernel<8, true>), ggrid, dim3(BKT_T), 0, p->stream, values, n_src, static_cast<const uint32_t*>(srcs_v),
+                           n, gtiles, static_cast<uint32_t*>(vals_v), vbits_src, vslot);
+        hipLaunchKernelGGL((tk2_merge_kernel<true>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles,
+                           static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(vals_v), out,
+                           reinterpret_cast<const uint32_t*>(vslot), out_validity);
+      } else {
+        hipLaunchKernelGGL((tk2_gather_kernel<8, false>), ggrid, dim3(BKT_T), 0, p->stream, values, n_src, static_cast<const uint32_t*>(srcs_v),
+                           n, gtiles, static_cast<uint32_t*>(vals_v), static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr));
+        hipLaunchKernelGGL((tk2_merge_kernel<false>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles,
+                           static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(vals_v), out,
+                           static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr));
+      }
       if (hipGetLastError() != hipSuccess) {
         agpu_set_error("merge-back take launch failed");
         st = AGPU_ERR_HIP;
       }
     }
   }
-  for (void* q : {csum_v, off_v, cnt_v, rank_v, vals_v, srcs_v, ctl_v})
+  for (void* q : {vslot_v, csum_v, off_v, cnt_v, rank_v, vals_v, srcs_v, ctl_v})
     if (q) (void)agpu_free(dev, q);
   return st;
 }
@@ -1311,6 +1381,28 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   }
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
+}
+
+agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const void* validity,
+                               const uint32_t* idx, void* out, void* out_validity, uint64_t n_idx) {
+  if (!validity) return agpu_take(p, width, values, n_values, idx, out, n_idx);
+  AGPU_REQUIRE(out_validity, AGPU_ERR_ARG, "out_validity required when the source has a validity bitmap");
+  {
+    AGPU_BIND(p);
+    if (n_idx == 0) return AGPU_OK;
+    AGPU_REQUIRE(values && idx && out, AGPU_ERR_ARG, "null pointer");
+    AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
+    AGPU_REQUIRE(aligned_to(validity, 4) && aligned_to(out_validity, 8), AGPU_ERR_SHAPE, "bitmap alignment");
+    if (width == 4 && n_values != UINT64_MAX && p->tune.gather_bucket != 3 && n_idx >= TK2_TILE &&
+        want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
+      const agpu_status ms = launch_take_mergeback(p, static_cast<const uint32_t*>(values), n_values, idx, static_cast<uint32_t*>(out), n_idx,
+                                                   static_cast<const uint32_t*>(validity), static_cast<uint64_t*>(out_validity));
+      if (ms != AGPU_ERR_UNSUPPORTED) return ms;
+    }
+  }
+  const agpu_status st = agpu_take(p, width, values, n_values, idx, out, n_idx);
+  if (st != AGPU_OK) return st;
+  return agpu_take_bits(p, validity, n_values, idx, out_validity, n_idx);
 }
 
 agpu_status agpu_take_bits(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits,

@@ -62,10 +62,17 @@ def _merge_op(self: PrimitiveArrayGpu, other, mask: BooleanArrayGPU, pipeline: A
 def _take_op(self: PrimitiveArrayGpu, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipeline):
     dev = self.gpu_device
     out = dev.create_empty_buffer(max(indexes.len * self.ITEM_SIZE, 1))
-    capi.call("agpu_take", pipeline._handle, self.ITEM_SIZE, vp(self.data), self.len, vp(indexes.data), vp(out), indexes.len)
-    pipeline.keep(self.data, indexes.data, out)
-    nulls = take_null_buffer(self.null_buffer, indexes, pipeline)
-    return type(self)(out, dev, indexes.len, nulls)
+    if self.null_buffer is None:
+        capi.call("agpu_take", pipeline._handle, self.ITEM_SIZE, vp(self.data), self.len, vp(indexes.data), vp(out), indexes.len)
+        pipeline.keep(self.data, indexes.data, out)
+        return type(self)(out, dev, indexes.len, None)
+    # values and validity in ONE call: at bucketed sizes the validity bit travels with the value (agpu_take_validity) instead
+    # of a second random pass over the index column [ref: take.rs:9-55 + bool.rs:33-46, two dispatches]
+    outv = dev.create_empty_buffer(max(bitmap_bytes(indexes.len), 8))
+    capi.call("agpu_take_validity", pipeline._handle, self.ITEM_SIZE, vp(self.data), self.len, vp(self.null_buffer.bit_buffer),
+              vp(indexes.data), vp(out), vp(outv), indexes.len)
+    pipeline.keep(self.data, self.null_buffer.bit_buffer, indexes.data, out, outv)
+    return type(self)(out, dev, indexes.len, NullBitBufferGpu(outv, indexes.len, dev))
 
 
 def _all_valid(dev, n: int, pipeline: ArrowComputePipeline) -> NullBitBufferGpu:

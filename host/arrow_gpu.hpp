@@ -855,9 +855,18 @@ inline std::optional<NullBitBufferGpu> take_null_buffer(const std::optional<Null
 template <typename T>
 PrimitiveArrayGpu<T> PrimitiveArrayGpu<T>::take_op(const UInt32ArrayGPU& indexes, ArrowComputePipeline& p) const {
   auto out = gpu_device->create_empty_buffer(indexes.len * sizeof(Native));
-  check(agpu_take(p.h(), (int)sizeof(Native), data->ptr, len, (const uint32_t*)indexes.data->ptr, out->ptr, indexes.len), "agpu_take");
-  p.keep.insert(p.keep.end(), {data, indexes.data, out});
-  return PrimitiveArrayGpu(out, gpu_device, indexes.len, take_null_buffer(null_buffer, indexes, p));
+  if (!null_buffer) {
+    check(agpu_take(p.h(), (int)sizeof(Native), data->ptr, len, (const uint32_t*)indexes.data->ptr, out->ptr, indexes.len), "agpu_take");
+    p.keep.insert(p.keep.end(), {data, indexes.data, out});
+    return PrimitiveArrayGpu(out, gpu_device, indexes.len, std::nullopt);
+  }
+  // values and validity in ONE call (the reference: two dispatches, take.rs:9-55 + bool.rs:33-46): at bucketed sizes the
+  // validity bit travels with the value
+  auto outv = gpu_device->create_empty_buffer(bitmap_bytes(indexes.len) ? bitmap_bytes(indexes.len) : 8);
+  check(agpu_take_validity(p.h(), (int)sizeof(Native), data->ptr, len, null_buffer->bit_buffer->ptr, (const uint32_t*)indexes.data->ptr,
+                           out->ptr, outv->ptr, indexes.len), "agpu_take_validity");
+  p.keep.insert(p.keep.end(), {data, null_buffer->bit_buffer, indexes.data, out, outv});
+  return PrimitiveArrayGpu(out, gpu_device, indexes.len, NullBitBufferGpu{outv, indexes.len, gpu_device});
 }
 // validity of merge: ((v1 & m) | (v2 & ~m)) & v_mask in one kernel [crates/routines/src/merge.rs:17-86]
 inline std::optional<NullBitBufferGpu> merge_null_buffers_op(const std::optional<NullBitBufferGpu>& a,

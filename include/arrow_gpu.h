@@ -397,6 +397,14 @@ agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* v
  * [ref: apply_take_op crates/routines/src/take.rs:9-55, 32bit/take.wgsl:13-17] */
 agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const uint32_t* idx,
                       void* out, uint64_t n_idx);
+/* take of an array WITH NULLS in one call: out[i] = values[idx[i]] and out_validity bit i = validity bit idx[i] (n_values
+ * bits; out_validity: agpu_bitmap_bytes(n_idx) bytes, padding bits 0) [ref: Swizzle::take_op crates/routines/src/lib.rs:122-143
+ * = apply_take_op (take.rs:9-55) for the values + take_null_buffer (bool.rs:33-46) for the validity: two dispatches].  For
+ * 4-byte values at bucketed sizes the bit travels with the value through the merge-back pipeline (one extra word load per
+ * gather, the 16 KiB of bitmap behind a 512 KiB region are L2-resident) instead of a second random pass over the index
+ * column; otherwise = agpu_take + agpu_take_bits.  validity == NULL: plain agpu_take, out_validity untouched. */
+agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const void* validity,
+                               const uint32_t* idx, void* out, void* out_validity, uint64_t n_idx);
 /* out bit i = bits[idx[i]]  [ref: crates/routines/src/bool.rs:15-46, bool/take.wgsl:13-33] — data and validity */
 agpu_status agpu_take_bits(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits,
                            uint64_t n_idx);

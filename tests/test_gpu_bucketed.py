@@ -186,3 +186,75 @@ def test_bucketed_put_drops_out_of_range_rows(ctx):
     exp = dst.copy()
     exp[di[ok]] = src[si[ok]]
     assert np.array_equal(got, exp)
+
+
+# ---- round 3: take of an array WITH NULLS — agpu_take_validity: the validity bit travels with the value
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("n,n_values,dist", [(5, 9, "uniform"), (32767, 70_000, "uniform"), (32768, 1 << 20, "uniform"), (65_537, 1 << 22, "uniform"),
+                                             (40_000, 300_000_007, "uniform"), (1_000_003, 40_000_003, "uniform"),
+                                             (3 * 32768 + 5, 1 << 24, "oob_tile"), (500_000, 1 << 23, "skew"), (2_500_000, 1 << 20, "dups")])
+def test_take_validity_equals_take_plus_take_bits(ctx, mode, n, n_values, dist):
+    """direct (mode 1: agpu_take + agpu_take_bits) and merge-back (mode 2: one pipeline) against the oracle's take and take_bits"""
+    dev, p = ctx
+    p.set_tuning("gather_bucket", mode)
+    try:
+        rng = np.random.default_rng(n * 11 + mode)
+        values = rng.integers(1, 1 << 32, n_values, dtype=np.uint64).astype(np.uint32)
+        vbits = np.packbits(rng.random((n_values + 63) // 64 * 64) < 0.8, bitorder="little")  # whole words; padding random (never addressed)
+        idx = rng.integers(0, n_values, n).astype(np.uint32)
+        expect_flag = False
+        if dist == "skew":
+            idx = np.where(rng.random(n) < 0.9, rng.integers(1000, 1064, n), idx).astype(np.uint32)
+        elif dist == "dups":
+            idx = (idx // 4096 * 4096).astype(np.uint32)
+        elif dist == "oob_tile":
+            idx[32768:65536] = rng.integers(n_values, 1 << 32, 32768, dtype=np.uint64).astype(np.uint32)
+            expect_flag = True
+        dv, dvb, di = dev.create_gpu_buffer_with_data(values), dev.create_gpu_buffer_with_data(vbits), dev.create_gpu_buffer_with_data(idx)
+        nb = O.bitmap_bytes(n)
+        out, outv = dev.create_empty_buffer(4 * n + 16), dev.create_empty_buffer(nb + 16)
+        capi.call("agpu_memset", p._handle, vp(out), 0xEE, 4 * n + 16)
+        capi.call("agpu_memset", p._handle, vp(outv), 0xEE, nb + 16)
+        capi.call("agpu_take_validity", p._handle, 4, vp(dv), n_values, vp(dvb), vp(di), vp(out), vp(outv), n)
+        if expect_flag:
+            import arrow_gpu_amd as ag
+
+            with pytest.raises(ag.ArrowErrorGPU):
+                p.sync()
+        else:
+            p.sync()
+        got = dev.retrive_data(out, 4 * n + 16, pipeline=p)
+        gotv = dev.retrive_data(outv, nb + 16, pipeline=p)
+        ok = idx < n_values
+        exp = np.where(ok, values[np.minimum(idx, n_values - 1)], 0).astype(np.uint32)
+        src_bits = np.unpackbits(vbits, bitorder="little")
+        exp_bits = np.where(ok, src_bits[np.minimum(idx, n_values - 1)], 0).astype(np.uint8)
+        assert np.array_equal(got[: 4 * n].view(np.uint32), exp)
+        assert (got[4 * n:] == 0xEE).all()
+        got_bits = np.unpackbits(gotv[:nb], bitorder="little")
+        assert np.array_equal(got_bits[:n], exp_bits)
+        assert not got_bits[n:].any()            # padding bits 0
+        assert (gotv[nb:] == 0xEE).all()         # nothing past the bitmap
+        if not expect_flag:
+            assert np.array_equal(np.unpackbits(O.take_bits(vbits, n_values, idx), bitorder="little")[:n], exp_bits)
+    finally:
+        p.set_tuning("gather_bucket", 2)
+
+
+def test_host_take_of_an_array_with_nulls_uses_the_fused_call(ctx):
+    import arrow_gpu_amd as ag
+
+    dev, p = ctx
+    rng = np.random.default_rng(5)
+    n_values, n = 200_000, 150_000
+    vals = [None if rng.random() < 0.3 else float(v) for v in rng.standard_normal(n_values).astype(np.float32)]
+    a = ag.Float32ArrayGPU.from_optional_slice(vals, dev)
+    idx_np = rng.integers(0, n_values, n).astype(np.uint32)
+    idx = ag.UInt32ArrayGPU.from_slice(idx_np, dev)
+    for mode in (1, 2):
+        p.set_tuning("gather_bucket", mode)
+        got = a.take_op(idx, p)
+        p.finish()
+        p.sync()
+        assert got.values() == [vals[i] for i in idx_np]
+    p.set_tuning("gather_bucket", 2)

@@ -143,6 +143,16 @@ def main():
     t("take f32, random idx, pair pipeline (2^28 rows)", 12 * m / n, lambda: capi.call("agpu_take", h, 4, vp(A), m, vp(IDX), vp(O), m),
       note="tuning gather_bucket=3: round 2's form, now with range starts from the column scan and XCD-contiguous partition tiles")
     fix(12)
+    OV = dev.create_empty_buffer(m // 8 + 64)
+    p.set_tuning("gather_bucket", 0)
+    t("take f32 WITH validity, random idx, default = one merge-back pipeline (2^28 rows)", 12.25 * m / n,
+      lambda: capi.call("agpu_take_validity", h, 4, vp(A), m, vp(VA), vp(IDX), vp(O), vp(OV), m),
+      note="agpu_take_validity: the validity bit travels with the value (the reference: take + bool take, two dispatches)")
+    fix(12.25)
+    p.set_tuning("gather_bucket", 1)
+    t("take f32 WITH validity, direct = take + take_bits (2^28 rows)", 12.25 * m / n,
+      lambda: capi.call("agpu_take_validity", h, 4, vp(A), m, vp(VA), vp(IDX), vp(O), vp(OV), m), note="tuning gather_bucket=1")
+    fix(12.25)
     p.set_tuning("gather_bucket", 1)
     t("put f32, random src and dst idx, direct (2^28 rows)", 16 * m / n,
       lambda: capi.call("agpu_put_bounded", h, 4, vp(A), m, vp(IDX), vp(O), m, vp(IDX2), m), note="tuning gather_bucket=1")

@@ -27,11 +27,11 @@ for v, b, u in ((5, 0, 1), (1, 64, 1), (5, 0, 1), (1, 64, 1), (4, 0, 1)):  # v2/
     t(f"probe v{v} grid{b} u{u}", f)
 # round 3: the load-wave / store-wave split through LDS (v6: block = store waves, u = chunks per round) and the LDS-transposed
 # 256-thread tile (v7), alternated with the product kernel on the same buffers
-for v, b, u in ((6, 4, 4), (6, 2, 4), (6, 1, 4), (6, 4, 8), (6, 2, 8), (6, 4, 16), (7, 0, 1), (1, 64, 1), (6, 4, 8), (7, 0, 1)):
+for v, b, u in ((8, 256, 1), (8, 128, 1), (1, 64, 1), (8, 256, 1), (8, 128, 1), (6, 4, 4), (6, 2, 4), (6, 1, 4), (6, 4, 8), (6, 2, 8), (6, 4, 16), (7, 0, 1), (1, 64, 1), (6, 4, 8), (7, 0, 1)):
     def f(v=v, b=b, u=u):
         rc = lib.probe_cast(C.c_void_p(A.ptr), C.c_void_p(O2.ptr), n, v, b, u, C.c_void_p(p.stream())); assert rc == 0, rc
     t(f"probe v{v} {'store-waves' if v == 6 else 'block'}{b} u{u}", f)
-    if v in (6, 7):
+    if v in (6, 7, 8):
         cs1, cs2 = dev.create_empty_buffer(16), dev.create_empty_buffer(16)
         prod()
         capi.call("agpu_checksum", p._handle, C.c_void_p(O.ptr), 4 * n, C.c_void_p(cs1.ptr)); capi.call("agpu_checksum", p._handle, C.c_void_p(O2.ptr), 4 * n, C.c_void_p(cs2.ptr))

@@ -46,6 +46,17 @@ for label, mode in (("take_direct", 1), ("take_pairs", 3), ("take_mergeback", 2)
     ms = med(lambda: capi.call("agpu_take", h, 4, vp(values), n, vp(idx), vp(out), n))
     res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
     print(label, res[label], flush=True)
+vb, ov = dev.create_empty_buffer(n // 8 + 64), dev.create_empty_buffer(n // 8 + 64)
+capi.call("agpu_synth_bits", h, vp(vb), n, 7, 0, C.c_double(0.9))
+for label, mode in (("take_with_validity_direct (agpu_take + agpu_take_bits)", 1), ("take_with_validity_mergeback (one pipeline)", 2)):
+    p.set_tuning("gather_bucket", mode)
+    ms = med(lambda: capi.call("agpu_take_validity", h, 4, vp(values), n, vp(vb), vp(idx), vp(out), vp(ov), n))
+    res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
+    print(label, res[label], flush=True)
+p.set_tuning("gather_bucket", 1)
+ms = med(lambda: capi.call("agpu_take_bits", h, vp(vb), n, vp(idx), vp(ov), n))
+res["take_bits_alone"] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
+print("take_bits_alone", res["take_bits_alone"], flush=True)
 for label, mode in (("put_direct", 1), ("put_pairs", 2)):
     p.set_tuning("gather_bucket", mode)
     ms = med(lambda: capi.call("agpu_put_bounded", h, 4, vp(values), n, vp(idx), vp(out), n, vp(idx2), n))
