@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
   uint64_t tile64;  // XCD-contiguous, like P2: the 64-byte runs of neighbouring tiles share their lines in one L2
   if (!bkt_tile_of_block(ntiles, &tile64)) return;
   const uint32_t tile = (uint32_t)tile64;
-  if constexpr (BITS) bl[threadIdx.x] = 0;  // TK2_TILE / 32 == BKT_T words
+  // (bl needs no zeroing: every word of it is written whole by a ballot below)
   const uint64_t base = (uint64_t)tile * TK2_TILE;
   const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
   // start[k] (exclusive scan of the tile's counts) and the runs' global slots
@@ -1203,11 +1203,17 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
       const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
       g[e] = j < rows_here ? A[j] : 0u;
     }
-    if constexpr (BITS) {  // the slot's validity bit: one word per 32 slots, a run's 16 slots share it
+    if constexpr (BITS) {  // the slot's validity bit: one word per 32 slots, a run's 16 slots share it.  A wave's lanes hold 64
+                           // CONSECUTIVE local slots: its ballot is two whole words of bl — no LDS atomics (32 lanes ORing
+                           // into one word serialise)
 #pragma unroll
       for (int e = 0; e < TK2_E; e++) {
         const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
-        if (j < rows_here && ((vbits_slot[g[e] >> 5] >> (g[e] & 31)) & 1u)) atomicOr(&bl[j >> 5], 1u << (j & 31));
+        const bool bit = j < rows_here && ((vbits_slot[g[e] >> 5] >> (g[e] & 31)) & 1u);
+        const uint64_t m = __ballot(bit);
+        const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
+        if (lane == 0) bl[j >> 5] = (uint32_t)m;
+        if (lane == 32) bl[j >> 5] = (uint32_t)(m >> 32);
       }
     }
 #pragma unroll

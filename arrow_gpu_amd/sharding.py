@@ -101,15 +101,23 @@ def ranks_from_env(env=None):
 
 
 def rendezvous_path_from_env(env=None) -> str:
-    """A path that is the same for all ranks of ONE launch and different for every other launch on the machine:
-    AGPU_RENDEZVOUS_FILE if set, else <tmp>/agpu_rdzv_<MASTER_PORT>_<run id>_<parent pid>_<parent start time> — all workers
-    of a single-node launch are children of the same launcher process."""
+    """A path that is the same for all ranks of ONE launch: AGPU_RENDEZVOUS_FILE if set; under torch.distributed.run (or anything
+    else that exports MASTER_PORT) <tmp>/agpu_rdzv_<MASTER_ADDR>_<MASTER_PORT>_<run id>_<restart count> — two launches cannot hold
+    one port at a time, and files an EARLIER launch left at the same path are harmless (`file_rendezvous` only accepts an id that
+    carries this process's fresh nonce), so nothing about the process tree is assumed (wrapper scripts between launcher and worker
+    are fine); without MASTER_PORT (mpirun, srun) the parent's pid and start time tell launches apart — there the workers must be
+    siblings."""
     import os
     import tempfile
 
     e = os.environ if env is None else env
     if e.get("AGPU_RENDEZVOUS_FILE"):
         return e["AGPU_RENDEZVOUS_FILE"]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    if e.get("MASTER_PORT"):
+        tag = "_".join(str(x).replace("/", "-") for x in (e.get("MASTER_ADDR", "local"), e["MASTER_PORT"], e.get("TORCHELASTIC_RUN_ID", "none"),
+                                                          e.get("TORCHELASTIC_RESTART_COUNT", "0")))
+        return os.path.join(base, "agpu_rdzv_" + tag)
     ppid = os.getppid()
     start = "0"
     try:
@@ -117,10 +125,7 @@ def rendezvous_path_from_env(env=None) -> str:
             start = f.read().rsplit(")", 1)[1].split()[19]  # field 22: start time in clock ticks since boot
     except (OSError, IndexError):
         pass
-    tag = "_".join(str(x) for x in (e.get("MASTER_PORT", "0"), e.get("TORCHELASTIC_RUN_ID", "none"),
-                                    e.get("TORCHELASTIC_RESTART_COUNT", "0"), ppid, start))
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-    return os.path.join(base, "agpu_rdzv_" + tag)
+    return os.path.join(base, f"agpu_rdzv_ppid{ppid}_{start}")
 
 
 def file_rendezvous(path: str, rank: int, world: int, make_payload=None, timeout_s: float = 60.0, payload_bytes: int = capi.COMM_ID_BYTES) -> bytes:

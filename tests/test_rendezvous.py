@@ -69,18 +69,26 @@ def test_a_rank_that_never_arrives_is_a_timeout_not_a_hang(tmp_path):
     assert time.monotonic() - t0 < 30
 
 
-def test_default_path_is_shared_by_siblings_and_unique_per_launch():
-    # all workers of one launch are children of one launcher → same path; another port / run id → another path
+def test_default_path_is_shared_by_the_ranks_of_a_launch():
+    # under torchrun (MASTER_PORT exported): the path depends on address / port / run id / restart count only — wrapper
+    # processes between launcher and worker do not matter; another port or run id → another path
     procs = [_spawn(r, 2, {}) for r in range(2)]
     outs = [p.communicate(timeout=60) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     paths = {o[0].split()[4] for o in outs}
-    assert len(paths) == 1 and str(os.getpid()) in paths.pop()
+    assert len(paths) == 1 and "29999" in paths.pop()
     a = sharding.rendezvous_path_from_env({"MASTER_PORT": "1"})
     b = sharding.rendezvous_path_from_env({"MASTER_PORT": "2"})
     c = sharding.rendezvous_path_from_env({"MASTER_PORT": "1", "TORCHELASTIC_RUN_ID": "x"})
     assert len({a, b, c}) == 3
     assert sharding.rendezvous_path_from_env({"AGPU_RENDEZVOUS_FILE": "/x/y"}) == "/x/y"
+    # no MASTER_PORT (mpirun / srun): siblings of one launcher share the parent's pid + start time
+    assert f"ppid{os.getppid()}_" in sharding.rendezvous_path_from_env({"OMPI_COMM_WORLD_RANK": "0"})
+    # a second launch on the same port right after the first (files possibly left behind) still works: nonces
+    for _ in range(2):
+        procs = [_spawn(r, 2, {"DELAY": str(0.2 * r)}) for r in range(2)]
+        outs = [p.communicate(timeout=60) for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
 
 
 def test_ranks_from_env_knows_the_common_launchers():
