@@ -22,7 +22,10 @@ A rank that fails (or never arrives) makes every rank exit non-zero within the r
 
 Also printed in the same JSON line:
   roofline     — the dominant kernel (f32 add), algorithmic bytes per launch ÷ its mean duration measured with HIP
-                 events on the launch stream over the timed region, against 8 TB/s HBM3E.
+                 events on the launch stream over the timed region, against 8 TB/s HBM3E; `traffic` = HBM bytes per launch
+                 MEASURED in this run (N = 1): two child `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE) over a
+                 short run of the same workload after the timed region (≈ 6 s; falls back to profiles/hbm_traffic.json
+                 and says so when rocprofv3 is not usable).
   cpu_baseline — the CPU port (oracle/cpu_baseline.c, arrow-rs-style single pass) timed on this box's host cores on
                  a bounded sample (rank 0, N=1 only), a pyarrow (Arrow C++) sanity line, and `gpu_parity`: windows of
                  the benchmarked GPU outputs checked bit-exact against the oracle.  This leg is the only place the
@@ -253,6 +256,48 @@ def cpu_baseline(sample_rows: int, gpu_windows=(), cfg_windows=None):
     return res
 
 
+def measure_traffic_live(timeout_s: float = 90.0):
+    """HBM bytes per launch of the dominant kernel (f32 add), MEASURED for this run: two child processes — rocprofv3 --pmc
+    FETCH_SIZE, then --pmc WRITE_SIZE (separate passes, never combined with tracing) — over a short bench.py of the same
+    workload, collected and corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes (KiB units; the gfx950 read side
+    counts 128-byte requests at 64 bytes: × 2).  Children, not exec: this process has initialised the GPU.  Returns
+    (bytes_per_launch | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    per = {}
+    t0 = time.time()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="agpu_pmc_", dir="/tmp")
+        try:
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra-configs", "--no-traffic"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}: {r.stderr[-200:]}"
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    k = row.get("Kernel_Name", "")
+                    if row.get("Counter_Name") == counter and "ew_kernel<float, OpAdd, 1" in k:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no {counter} rows for the add kernel"
+            per[counter] = sorted(vals)[len(vals) // 2]
+        except Exception as e:  # noqa: BLE001 — the line falls back to the stored figure
+            return None, f"{type(e).__name__}: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = per["FETCH_SIZE"] * 1024 * 2 + per["WRITE_SIZE"] * 1024
+    return total, (f"measured in this run: median per launch over two child rocprofv3 passes of the same workload (--pmc FETCH_SIZE, then --pmc "
+                   f"WRITE_SIZE; KiB x 1024, read side x 2 per the guide's gfx950 correction), {time.time() - t0:.0f} s")
+
+
 def _cgroup_cpu_max():
     """The container's CPU quota ("<quota_us> <period_us>" = quota/period CPUs' worth of time, or "max"): it, not nproc,
     bounds what a thread team can use."""
@@ -285,6 +330,7 @@ def main():
     ap.add_argument("--no-extra-configs", action="store_true", help="skip extra.configs / extra.layout_pool / extra.strong_scaling")
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 26)
     ap.add_argument("--rendezvous-timeout", type=float, default=120.0)
+    ap.add_argument("--no-traffic", action="store_true", help="do not measure roofline.traffic with child rocprofv3 --pmc passes (use profiles/hbm_traffic.json)")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="agpu_set_tuning before anything is allocated (A/B runs, e.g. --tune pool_arena=0); recorded in config.tuning")
     args = ap.parse_args()
@@ -633,11 +679,19 @@ def main():
         w["what"] = "host API call + device sync per iteration (new pipeline + new output buffer per call, like the reference), best of 15"
         extra["reference_bench_workloads_gpu"] = w
     if rank == 0:
-        traffic = None
+        traffic, traffic_source = None, None
+        if world == 1 and n == ROWS and not args.no_traffic and not args.no_extra_configs:
+            p.sync()
+            traffic, traffic_source = measure_traffic_live()
+            if traffic is None:
+                print(f"bench.py: live traffic measurement unavailable ({traffic_source}); using profiles/hbm_traffic.json", file=sys.stderr)
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
-        if os.path.exists(tpath) and n == ROWS:
+        if traffic is None and os.path.exists(tpath) and n == ROWS:
             try:
                 traffic = json.load(open(tpath)).get("add_f32_bytes_per_launch")
+                traffic_source = ("profiles/hbm_traffic.json: HBM bytes per launch of this kernel from separate rocprofv3 --pmc FETCH_SIZE / "
+                                  "WRITE_SIZE passes over this same command (tools/profile_bench.sh), read side x2 per the guide's gfx950 "
+                                  "correction; NOT measured inside this run")
             except Exception:
                 traffic = None
         shard_txt = (f"chunk-sharded x{world}: every rank owns its own {args.rows}-row shard of a {total_rows}-row column"
@@ -656,10 +710,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "ew_kernel<float, OpAdd> (agpu_binary ADD f32)",
                          "achieved": round(add_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(add_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "traffic_source": ("profiles/hbm_traffic.json: HBM bytes per launch of this kernel from separate rocprofv3 "
-                                            "--pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/profile_bench.sh), "
-                                            "read side x2 per the guide's gfx950 correction; NOT measured inside this run")
-                         if traffic is not None else None,
+                         "traffic_source": traffic_source if traffic is not None else None,
                          "algorithmic_bytes_per_launch": ADD_BYTES_PER_ROW * n, "launch_ms": round(add_ms, 4)},
             "extra": extra,
         }

@@ -12,11 +12,11 @@ export TMPDIR=/tmp
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_trace_$ROUND" -- python3 "$REPO/bench.py" --steps "$STEPS" --warmup 2 --no-cpu-baseline > "$OUT/prof_trace_$ROUND.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_trace_$ROUND" -- python3 "$REPO/bench.py" --steps "$STEPS" --warmup 2 --no-cpu-baseline --no-traffic > "$OUT/prof_trace_$ROUND.log" 2>&1
 echo "trace rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch_$ROUND" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/prof_fetch_$ROUND.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_fetch_$ROUND" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-traffic > "$OUT/prof_fetch_$ROUND.log" 2>&1
 echo "fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write_$ROUND" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/prof_write_$ROUND.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_write_$ROUND" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-traffic > "$OUT/prof_write_$ROUND.log" 2>&1
 echo "write rc=$?"
 cd "$REPO"
 python3 tools/pmc_traffic.py "$ROUND" || true
