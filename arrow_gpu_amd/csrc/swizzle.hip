@@ -1119,12 +1119,14 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
 }
 
 // F2: out[i] = vals[offs[t][key(i)] + rank16[i]] — the tile's runs come into LDS as contiguous pieces, rows pick from there
-template <bool BITS>
+// MODE 0: values; 1: values + the source validity bits (agpu_take_validity); 2: bits only (Boolean take: no value array at all)
+template <int MODE>
 __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, uint64_t n, uint64_t n_src, int rs, uint32_t bs,
                                                          const uint16_t* counts, const uint32_t* offsets, uint32_t nbp,
                                                          uint32_t ntiles, const uint16_t* rank16, const uint32_t* vals, uint32_t* out,
                                                          const uint32_t* vbits_slot, uint64_t* out_validity) {
   __shared__ uint32_t A[TK2_TILE];
+  constexpr bool BITS = MODE >= 1, VALUES = MODE <= 1;
   __shared__ uint32_t bl[BITS ? TK2_TILE / 32 : 1];  // the validity bits of the tile's slots (BITS)
   __shared__ uint32_t lcnt[BKT_MAX];
   __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
@@ -1216,27 +1218,31 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
         if (lane == 32) bl[j >> 5] = (uint32_t)(m >> 32);
       }
     }
+    if constexpr (VALUES) {
 #pragma unroll
-    for (int e = 0; e < TK2_E; e++) {
-      const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
-      if (j < rows_here) g[e] = __builtin_nontemporal_load(vals + g[e]);
-    }
+      for (int e = 0; e < TK2_E; e++) {
+        const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
+        if (j < rows_here) g[e] = __builtin_nontemporal_load(vals + g[e]);
+      }
 #pragma unroll
-    for (int e = 0; e < TK2_E; e++) {
-      const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
-      if (j < rows_here) A[j] = g[e];
+      for (int e = 0; e < TK2_E; e++) {
+        const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
+        if (j < rows_here) A[j] = g[e];
+      }
     }
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < TK2_E / 4; q++) {
     const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
-    if (i0 + 4 <= n) {
-      const u32x4 v = {A[sl[q * 4]], A[sl[q * 4 + 1]], A[sl[q * 4 + 2]], A[sl[q * 4 + 3]]};
-      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + i0));
-    } else {
-      for (int k = 0; k < 4; k++)
-        if (i0 + k < n) out[i0 + k] = A[sl[q * 4 + k]];
+    if constexpr (VALUES) {
+      if (i0 + 4 <= n) {
+        const u32x4 v = {A[sl[q * 4]], A[sl[q * 4 + 1]], A[sl[q * 4 + 2]], A[sl[q * 4 + 3]]};
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + i0));
+      } else {
+        for (int k = 0; k < 4; k++)
+          if (i0 + k < n) out[i0 + k] = A[sl[q * 4 + k]];
+      }
     }
     if constexpr (BITS) {  // 16 neighbouring lanes hold the 64 rows of one output validity word (rows past n: 0)
       uint64_t nib = 0;
@@ -1252,6 +1258,209 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
 }
 
 // take of 4-byte values through the merge-back pipeline; AGPU_ERR_UNSUPPORTED when the shape does not qualify
+// G2 for BITS as the data (Boolean take: out bit i = bits[idx[i]] [ref: crates/routines/src/bool.rs:15-46, bool/take.wgsl]): the
+// "elements" are the bitmap's 32-bit words, regions are 2^rsw words (16 KiB of bitmap by default), the slot entries are
+// {word − origin : 13 bits, bit position : 5, slot : 14}, ordered by source LINE (32 words); every gathered bit goes straight to
+// the tile's slot-ordered bit array — there is no value array at all — and leaves as vbits_slot like above.
+#define TK2B_REL_BITS 13
+__global__ __launch_bounds__(BKT_T, 8) void tk2_gather_bits_kernel(const uint32_t* bits, uint64_t n_bits, const uint32_t* srcs, uint64_t total,
+                                                                  uint32_t ntiles, uint64_t* vbits_slot) {
+  __shared__ uint32_t sorted[TK2_GTILE];
+  __shared__ uint32_t lcnt[1 << (TK2B_REL_BITS - 5)];  // 256 line keys
+  __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
+  __shared__ uint32_t tile_rows;
+  __shared__ uint32_t red[2 * (BKT_T / AGPU_WAVE)];
+  __shared__ uint32_t bitl[TK2_GTILE / 32];
+  constexpr uint32_t NKEYS = 1u << (TK2B_REL_BITS - 5);
+  uint64_t tile;
+  if (!bkt_tile_of_block(ntiles, &tile)) return;
+  const uint64_t base = tile * TK2_GTILE;
+  if (base >= total) return;
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  if (threadIdx.x < TK2_GTILE / 32) bitl[threadIdx.x] = 0;
+  if (threadIdx.x < NKEYS) lcnt[threadIdx.x] = 0;
+  auto load4 = [&](int q) -> u32x4 {
+    const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+    u32x4 t = {0, 0, 0, 0};
+    if (i0 + 4 <= total) t = *reinterpret_cast<const u32x4*>(srcs + i0);
+    else {
+      if (i0 < total) t.x = srcs[i0];
+      if (i0 + 1 < total) t.y = srcs[i0 + 1];
+      if (i0 + 2 < total) t.z = srcs[i0 + 2];
+    }
+    return t;
+  };
+  auto live_at = [&](int q, int k) { return base + ((uint64_t)q * BKT_T + threadIdx.x) * 4 + (uint64_t)k < total; };
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+#pragma unroll
+  for (int q = 0; q < TK2_GE / 4; q++) {
+    const u32x4 t = load4(q);
+    const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (live_at(q, k)) {
+        mn = sv[k] < mn ? sv[k] : mn;
+        mx = sv[k] > mx ? sv[k] : mx;
+      }
+  }
+#pragma unroll
+  for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) {
+    const uint32_t a = (uint32_t)__shfl_down((int)mn, off), b2 = (uint32_t)__shfl_down((int)mx, off);
+    mn = a < mn ? a : mn;
+    mx = b2 > mx ? b2 : mx;
+  }
+  if (lane == 0) {
+    red[wave] = mn;
+    red[BKT_T / AGPU_WAVE + wave] = mx;
+  }
+  __syncthreads();
+  mn = red[0];
+  mx = red[BKT_T / AGPU_WAVE];
+  for (int w = 1; w < BKT_T / AGPU_WAVE; w++) {
+    mn = red[w] < mn ? red[w] : mn;
+    mx = red[BKT_T / AGPU_WAVE + w] > mx ? red[BKT_T / AGPU_WAVE + w] : mx;
+  }
+  const uint32_t origin = (mn >> 5) & ~31u;  // in WORDS, line-aligned
+  const bool fast = mx < n_bits && ((mx >> 5) - origin) < (1u << TK2B_REL_BITS);
+  auto store_bits = [&]() {
+    if (threadIdx.x < TK2_GTILE / 64 && base + (uint64_t)threadIdx.x * 64 < total)
+      vbits_slot[base / 64 + threadIdx.x] = (uint64_t)bitl[threadIdx.x * 2] | ((uint64_t)bitl[threadIdx.x * 2 + 1] << 32);
+  };
+  if (!fast) {  // out-of-range rows (bit 0) or a tile that spans many regions: row by row
+#pragma unroll
+    for (int q = 0; q < TK2_GE / 4; q++) {
+      const u32x4 t = load4(q);
+      const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (live_at(q, k) && sv[k] < n_bits && ((bits[sv[k] >> 5] >> (sv[k] & 31)) & 1u)) {
+          const uint32_t pos = ((uint32_t)q * BKT_T + threadIdx.x) * 4 + (uint32_t)k;
+          atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
+        }
+    }
+    __syncthreads();
+    store_bits();
+    return;
+  }
+  uint32_t rank2[TK2_GE / 2];
+#pragma unroll
+  for (int q = 0; q < TK2_GE / 4; q++) {
+    const u32x4 t = load4(q);
+    const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
+    uint32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = live_at(q, k) ? atomicAdd(&lcnt[((sv[k] >> 5) - origin) >> 5], 1u) : 0u;
+    rank2[q * 2] = r[0] | (r[1] << 16);
+    rank2[q * 2 + 1] = r[2] | (r[3] << 16);
+  }
+  __syncthreads();
+  {  // exclusive scan of the 256 line counters by the first four waves' worth of threads (one counter each)
+    uint32_t c = threadIdx.x < NKEYS ? lcnt[threadIdx.x] : 0u, incl = c;
+#pragma unroll
+    for (int off = 1; off < AGPU_WAVE; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= (uint32_t)off) incl += o;
+    }
+    if (lane == AGPU_WAVE - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wave; w++) pre += wave_tot[w];
+    if (threadIdx.x < NKEYS) lcnt[threadIdx.x] = pre + incl - c;
+    if (threadIdx.x == NKEYS - 1) tile_rows = pre + incl;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < TK2_GE / 4; q++) {
+    const u32x4 t = load4(q);
+    const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (live_at(q, k)) {
+        const uint32_t rel = (sv[k] >> 5) - origin;
+        const uint32_t pos = ((uint32_t)q * BKT_T + threadIdx.x) * 4 + (uint32_t)k;
+        const uint32_t rk = (rank2[q * 2 + (k >> 1)] >> ((k & 1) * 16)) & 0xFFFFu;
+        sorted[lcnt[rel >> 5] + rk] = (rel << 19) | ((sv[k] & 31u) << TK2_POS_BITS) | pos;
+      }
+  }
+  __syncthreads();
+  const uint32_t rows_here = tile_rows;
+#pragma unroll
+  for (int h0 = 0; h0 < TK2_GE; h0 += 8) {
+    uint32_t ent[8], w[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+      ent[e] = j < rows_here ? sorted[j] : 0u;
+      w[e] = j < rows_here ? bits[origin + (ent[e] >> 19)] : 0u;  // the L2-resident gather: neighbours share the line
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+      const uint32_t pos = ent[e] & ((1u << TK2_POS_BITS) - 1u);
+      if (j < rows_here && ((w[e] >> ((ent[e] >> TK2_POS_BITS) & 31u)) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
+    }
+  }
+  __syncthreads();
+  store_bits();
+}
+
+// Boolean take through the merge-back pipeline; AGPU_ERR_UNSUPPORTED when the shape does not qualify
+static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* bits, uint64_t n_bits, const uint32_t* si, uint64_t* out_bits,
+                                              uint64_t n) {
+  if (n >= 0xFFFF0000ull || n_bits > 0xFFFFFFFFull || !aligned16(si) || p->capturing) return AGPU_ERR_UNSUPPORTED;
+  const uint64_t n_words = (n_bits + 31) / 32;
+  int rsw = 12;  // 2^12 words = 16 KiB of bitmap per region: two regions span < 2^13 words (the entry's 13 bits)
+  if (((n_words + ((uint64_t)1 << rsw) - 1) >> rsw) > BKT_MAX - 1) return AGPU_ERR_UNSUPPORTED;  // > 2^29 bits: the direct kernel
+  const int rs = rsw + 5;  // H2 / P2 / F2 key an index by (idx >> rs): idx is a BIT number here
+  const uint32_t bs = (uint32_t)((n_words + ((uint64_t)1 << rsw) - 1) >> rsw);
+  agpu_device* dev = p->dev;
+  const uint32_t ntiles = (uint32_t)((n + TK2_TILE - 1) / TK2_TILE);
+  const uint32_t gtiles = (uint32_t)((n + TK2_GTILE - 1) / TK2_GTILE);
+  const uint32_t nbp = (bs + 1 + 3) & ~3u;
+  const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
+  void *ctl_v = nullptr, *srcs_v = nullptr, *rank_v = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr, *vslot_v = nullptr;
+  agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, 4 * n + 16, 0, &srcs_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, 2 * n + 16, 0, &rank_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, ((size_t)gtiles * TK2_GTILE) / 8 + 16, 0, &vslot_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 2, 0, &cnt_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 4, 0, &off_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)nchunks * nbp * 4, 0, &csum_v);
+  if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;
+  if (st == AGPU_OK) {
+    BktCtl* ctl = static_cast<BktCtl*>(ctl_v);
+    uint16_t* counts = static_cast<uint16_t*>(cnt_v);
+    uint32_t* offsets = static_cast<uint32_t*>(off_v);
+    uint32_t* csum = static_cast<uint32_t*>(csum_v);
+    hipError_t e = hipMemsetAsync(ctl, 0, sizeof(BktCtl), p->stream);
+    if (e != hipSuccess) {
+      agpu_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
+      st = AGPU_ERR_HIP;
+    } else {
+      const dim3 cgrid((nbp + 255) / 256, nchunks);
+      hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, p->flags, counts, nbp, ntiles);
+      hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
+      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl);
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 0, 0, 1u, 1u);
+      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl, offsets);
+      hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, offsets, nbp,
+                         ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v));
+      hipLaunchKernelGGL(tk2_gather_bits_kernel, dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, bits, n_bits,
+                         static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint64_t*>(vslot_v));
+      hipLaunchKernelGGL((tk2_merge_kernel<2>), dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, counts, offsets,
+                         nbp, ntiles, static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(nullptr),
+                         static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(vslot_v), out_bits);
+      if (hipGetLastError() != hipSuccess) {
+        agpu_set_error("merge-back take_bits launch failed");
+        st = AGPU_ERR_HIP;
+      }
+    }
+  }
+  for (void* q : {csum_v, off_v, cnt_v, vslot_v, rank_v, srcs_v, ctl_v})
+    if (q) (void)agpu_free(dev, q);
+  return st;
+}
+
 // vbits_src != nullptr: the source's validity bitmap is gathered with the values into out_validity (agpu_take_validity)
 static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* values, uint64_t n_src, const uint32_t* si, uint32_t* out,
                                          uint64_t n, const uint32_t* vbits_src = nullptr, uint64_t* out_validity = nullptr) {
@@ -1298,13 +1507,13 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* value
       if (vbits_src) {
         hipLaunchKernelGGL((tk2_gather_kernel<8, true>), ggrid, dim3(BKT_T), 0, p->stream, values, n_src, static_cast<const uint32_t*>(srcs_v),
                            n, gtiles, static_cast<uint32_t*>(vals_v), vbits_src, vslot);
-        hipLaunchKernelGGL((tk2_merge_kernel<true>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles,
+        hipLaunchKernelGGL((tk2_merge_kernel<1>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles,
                            static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(vals_v), out,
                            reinterpret_cast<const uint32_t*>(vslot), out_validity);
       } else {
         hipLaunchKernelGGL((tk2_gather_kernel<8, false>), ggrid, dim3(BKT_T), 0, p->stream, values, n_src, static_cast<const uint32_t*>(srcs_v),
                            n, gtiles, static_cast<uint32_t*>(vals_v), static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr));
-        hipLaunchKernelGGL((tk2_merge_kernel<false>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles,
+        hipLaunchKernelGGL((tk2_merge_kernel<0>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles,
                            static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(vals_v), out,
                            static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr));
       }
@@ -1418,6 +1627,12 @@ agpu_status agpu_take_bits(agpu_pipeline* p, const void* bits, uint64_t n_bits, 
   AGPU_REQUIRE(bits && idx && out_bits, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(n_bits > 0, AGPU_ERR_SHAPE, "take from an empty bitmap");
   AGPU_REQUIRE(aligned_to(bits, 4) && aligned_to(out_bits, 8), AGPU_ERR_SHAPE, "bitmap alignment");
+  if (n_bits != UINT64_MAX && n_idx >= TK2_TILE && p->tune.gather_bucket != 1 && p->tune.gather_bucket != 3 &&
+      (p->tune.gather_bucket == 2 || (n_idx >= ((uint64_t)1 << 25) && n_bits >= ((uint64_t)1 << 27) && n_bits / 8 <= n_idx))) {
+    // round 3: the merge-back pipeline with the bitmap's words as the elements (auto: ≥ 2^25 rows from a bitmap of ≥ 16 MiB)
+    const agpu_status ms = launch_take_bits_mergeback(p, static_cast<const uint32_t*>(bits), n_bits, idx, static_cast<uint64_t*>(out_bits), n_idx);
+    if (ms != AGPU_ERR_UNSUPPORTED) return ms;
+  }
   const uint64_t nwords = (n_idx + 63) / 64;
   const int grid = stream_grid_for(p, (nwords + 3) / 4);
   hipLaunchKernelGGL(take_bits_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(bits),

@@ -258,3 +258,75 @@ def test_host_take_of_an_array_with_nulls_uses_the_fused_call(ctx):
         p.sync()
         assert got.values() == [vals[i] for i in idx_np]
     p.set_tuning("gather_bucket", 2)
+
+
+# ---- round 3: Boolean take (agpu_take_bits) through the merge-back pipeline — the bitmap's words are the elements
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("n,n_bits,dist", [(32768, 9, "uniform"), (32769, 70_001, "uniform"), (65_537, 1 << 22, "uniform"), (40_000, 300_000_007, "uniform"),
+                                           (1_000_003, 40_000_003, "uniform"), (3 * 32768 + 5, 1 << 24, "oob_tile"), (500_000, 1 << 23, "skew"),
+                                           (2_500_000, 1 << 20, "dups"), (2_000_000, (1 << 29) - 3, "uniform"), (100_000, (1 << 29) + 77, "uniform")])
+def test_take_bits_pipelines_equal_the_oracle(ctx, mode, n, n_bits, dist):
+    """[ref: crates/routines/src/bool.rs:15-46 + bool/take.wgsl] direct (mode 1) and merge-back (mode 2; > 2^29 bits falls back to the
+    direct kernel by itself) against oracle.take_bits; out-of-range rows read 0 and raise the sticky flag"""
+    dev, p = ctx
+    p.set_tuning("gather_bucket", mode)
+    try:
+        rng = np.random.default_rng(n * 13 + mode)
+        bits = rng.integers(0, 256, (n_bits + 63) // 64 * 8, dtype=np.uint8)  # padding bits random: never addressed
+        idx = rng.integers(0, n_bits, n).astype(np.uint32)
+        expect_flag = False
+        if dist == "skew":
+            idx = np.where(rng.random(n) < 0.9, rng.integers(1000, 1064, n), idx).astype(np.uint32)
+        elif dist == "dups":
+            idx = (idx // 4096 * 4096).astype(np.uint32)
+        elif dist == "oob_tile":
+            idx[32768:65536] = rng.integers(n_bits, 1 << 32, 32768, dtype=np.uint64).astype(np.uint32)
+            expect_flag = True
+        db, di = dev.create_gpu_buffer_with_data(bits), dev.create_gpu_buffer_with_data(idx)
+        nb = O.bitmap_bytes(n)
+        outb = dev.create_empty_buffer(nb + 16)
+        capi.call("agpu_memset", p._handle, vp(outb), 0xEE, nb + 16)
+        capi.call("agpu_take_bits", p._handle, vp(db), n_bits, vp(di), vp(outb), n)
+        if expect_flag:
+            import arrow_gpu_amd as ag
+
+            with pytest.raises(ag.ArrowErrorGPU):
+                p.sync()
+        else:
+            p.sync()
+        got = dev.retrive_data(outb, nb + 16, pipeline=p)
+        ok = idx < n_bits
+        src = np.unpackbits(bits, bitorder="little")
+        exp = np.where(ok, src[np.minimum(idx, n_bits - 1)], 0).astype(np.uint8)
+        got_bits = np.unpackbits(got[:nb], bitorder="little")
+        assert np.array_equal(got_bits[:n], exp)
+        assert not got_bits[n:].any()
+        assert (got[nb:] == 0xEE).all()
+        if not expect_flag:
+            assert np.array_equal(np.unpackbits(O.take_bits(bits, n_bits, idx), bitorder="little")[:n], exp)
+    finally:
+        p.set_tuning("gather_bucket", 2)
+
+
+def test_take_bits_at_2_28_rows_merge_back_equals_direct(ctx):
+    """the size the auto policy serves: both forms give the same bitmap (and the same popcount as the host's gather)"""
+    dev, p = ctx
+    n = n_bits = 1 << 28
+    rng = np.random.default_rng(77)
+    bits = rng.integers(0, 256, n_bits // 8, dtype=np.uint8)
+    idx = rng.integers(0, n_bits, n, dtype=np.uint32)
+    db, di = dev.create_gpu_buffer_with_data(bits), dev.create_gpu_buffer_with_data(idx)
+    outs = {}
+    try:
+        for mode in (1, 0):  # 0 = auto: the merge-back form at this size
+            p.set_tuning("gather_bucket", mode)
+            ob = dev.create_empty_buffer(n // 8)
+            capi.call("agpu_take_bits", p._handle, vp(db), n_bits, vp(di), vp(ob), n)
+            p.sync()
+            outs[mode] = dev.retrive_data(ob, n // 8, pipeline=p)
+    finally:
+        p.set_tuning("gather_bucket", 2)
+    assert np.array_equal(outs[0], outs[1])
+    sample = slice(12_345_678, 12_345_678 + 1_000_000)
+    src = np.unpackbits(bits, bitorder="little")
+    assert np.array_equal(np.unpackbits(outs[0], bitorder="little")[sample], src[idx[sample]])

@@ -161,8 +161,14 @@ def main():
     t("put f32, random src and dst idx, default = bucketed (2^28 rows)", 16 * m / n,
       lambda: capi.call("agpu_put_bounded", h, 4, vp(A), m, vp(IDX), vp(O), m, vp(IDX2), m), note="auto policy picks the bucketed form at this size")
     fix(16)
-    t("take_bits, random idx (2^28 rows)", 4.25 * m / n, lambda: capi.call("agpu_take_bits", h, vp(VA), m, vp(IDX), vp(OB), m))
+    t("take_bits (Boolean take), random idx, default = merge-back pipeline (2^28 rows)", 4.25 * m / n,
+      lambda: capi.call("agpu_take_bits", h, vp(VA), m, vp(IDX), vp(OB), m), note="round 3: the bitmap's words are the pipeline's elements")
     fix(4.25)
+    p.set_tuning("gather_bucket", 1)
+    t("take_bits (Boolean take), random idx, direct (2^28 rows)", 4.25 * m / n,
+      lambda: capi.call("agpu_take_bits", h, vp(VA), m, vp(IDX), vp(OB), m), note="tuning gather_bucket=1")
+    fix(4.25)
+    p.set_tuning("gather_bucket", 0)
     t("clone_buffer (agpu_copy, 4 GB)", 8, lambda: capi.call("agpu_copy", h, vp(O), vp(A), 4 * n))
 
     # the reference's own criterion shapes, kernel time only (its benches: crates/benchmarks/benches/compare_gpu_arrow.rs

@@ -53,10 +53,27 @@ for label, mode in (("take_with_validity_direct (agpu_take + agpu_take_bits)", 1
     ms = med(lambda: capi.call("agpu_take_validity", h, 4, vp(values), n, vp(vb), vp(idx), vp(out), vp(ov), n))
     res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
     print(label, res[label], flush=True)
-p.set_tuning("gather_bucket", 1)
-ms = med(lambda: capi.call("agpu_take_bits", h, vp(vb), n, vp(idx), vp(ov), n))
-res["take_bits_alone"] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
-print("take_bits_alone", res["take_bits_alone"], flush=True)
+for label, mode in (("take_bits_alone", 1), ("take_bits_mergeback", 2)):  # Boolean take: the bitmap's words are the elements
+    p.set_tuning("gather_bucket", mode)
+    ms = med(lambda: capi.call("agpu_take_bits", h, vp(vb), n, vp(idx), vp(ov), n))
+    res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
+    print(label, res[label], flush=True)
+if os.environ.get("TAKE_BITS_SWEEP"):  # where the merge-back form starts to win for bits: rows x bitmap size
+    sweep = {}
+    for lg_n in (22, 24, 25, 26, 27, 28):
+        for lg_b in (24, 26, 27, 28):
+            if lg_b > 28 or lg_n > 28:
+                continue
+            capi.call("agpu_synth_i32", h, vp(idx2), 1 << lg_n, 5, 0, 1 << lg_b)
+            row = {}
+            for label, mode in (("direct", 1), ("mergeback", 2)):
+                p.set_tuning("gather_bucket", mode)
+                row[label] = round(med(lambda: capi.call("agpu_take_bits", h, vp(vb), 1 << lg_b, vp(idx2), vp(ov), 1 << lg_n)), 4)
+            sweep[f"rows 2^{lg_n}, bits 2^{lg_b}"] = row
+            print(lg_n, lg_b, row, flush=True)
+    res["take_bits_sweep_ms"] = sweep
+    capi.call("agpu_synth_i32", h, vp(idx2), n, 3, 0, n)
+    p.sync()
 for label, mode in (("put_direct", 1), ("put_pairs", 2)):
     p.set_tuning("gather_bucket", mode)
     ms = med(lambda: capi.call("agpu_put_bounded", h, 4, vp(values), n, vp(idx), vp(out), n, vp(idx2), n))
