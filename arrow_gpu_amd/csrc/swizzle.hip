@@ -201,7 +201,12 @@ __global__ __launch_bounds__(AGPU_BLOCK) void index_max_kernel(const uint32_t* i
 #define BKT_T 1024     // threads per block
 #endif
 #define BKT_MAX (4 * BKT_T)  // keys per tile sort = buckets per side (every thread owns 4 counters of the scan)
+#ifndef BKT_E
 #define BKT_E 16       // rows per thread → 16 Ki-row tiles (128 KiB of LDS per workgroup)
+#endif
+#ifndef BKT_RD_EXTRA
+#define BKT_RD_EXTRA 0  // tools/probe/put_variants.sh: destination regions 2^BKT_RD_EXTRA times the source regions
+#endif
 #define BKT_TILE (BKT_T * BKT_E)
 #define BKT_INVALID 0xFFFFFFFFu
 
@@ -662,7 +667,7 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || n_dst > 0xFFFFFFFFull || !aligned16(si) || (di && !aligned16(di)) ||
       p->capturing)
     return AGPU_ERR_UNSUPPORTED;
-  const int rs = bkt_region_bits(p, n_src, width), rd = bkt_region_bits(p, n_dst, width);
+  const int rs = bkt_region_bits(p, n_src, width), rd = bkt_region_bits(p, n_dst, width) + (di ? BKT_RD_EXTRA : 0);
   // F orders a tile by destination line: 128-byte lines, widened until a region's lines fit the BKT_MAX keys
   int line_shift = width == 4 ? 5 : width == 2 ? 6 : 7;
   while ((1 << (rd - line_shift)) > BKT_MAX) line_shift++;

@@ -43,6 +43,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Multi-process GPU work on hosts whose driver only offers dmabuf IPC needs this BEFORE the HSA runtime starts (RCCL's
+# hipIpcGetMemHandle fails with "invalid argument" otherwise); the launcher normally exports it — only a default here.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROWS = 1_000_000_000
 SEED = 20250418

@@ -32,6 +32,7 @@ struct RankResult {
 };
 
 int main(int argc, char** argv) {
+  setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);  // dmabuf-only hosts: must be in place before the first HIP call (a default, not an override)
   const uint64_t rows = argc > 1 ? strtoull(argv[1], nullptr, 10) : 100000000ull;
   int32_t ndev = 0;
   agpu_device_count(&ndev);

@@ -41,19 +41,20 @@ def med(f):
 
 
 res = {"rows": n}
-for label, mode in (("take_direct", 1), ("take_pairs", 3), ("take_mergeback", 2)):
+PUT_ONLY = bool(os.environ.get("PUT_ONLY"))  # tools/probe/put_variants.sh: only the pair-pipeline rows
+for label, mode in ((("take_pairs", 3),) if PUT_ONLY else (("take_direct", 1), ("take_pairs", 3), ("take_mergeback", 2))):
     p.set_tuning("gather_bucket", mode)
     ms = med(lambda: capi.call("agpu_take", h, 4, vp(values), n, vp(idx), vp(out), n))
     res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
     print(label, res[label], flush=True)
 vb, ov = dev.create_empty_buffer(n // 8 + 64), dev.create_empty_buffer(n // 8 + 64)
 capi.call("agpu_synth_bits", h, vp(vb), n, 7, 0, C.c_double(0.9))
-for label, mode in (("take_with_validity_direct (agpu_take + agpu_take_bits)", 1), ("take_with_validity_mergeback (one pipeline)", 2)):
+for label, mode in (() if PUT_ONLY else (("take_with_validity_direct (agpu_take + agpu_take_bits)", 1), ("take_with_validity_mergeback (one pipeline)", 2))):
     p.set_tuning("gather_bucket", mode)
     ms = med(lambda: capi.call("agpu_take_validity", h, 4, vp(values), n, vp(vb), vp(idx), vp(out), vp(ov), n))
     res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
     print(label, res[label], flush=True)
-for label, mode in (("take_bits_alone", 1), ("take_bits_mergeback", 2)):  # Boolean take: the bitmap's words are the elements
+for label, mode in (() if PUT_ONLY else (("take_bits_alone", 1), ("take_bits_mergeback", 2))):  # Boolean take: the bitmap's words are the elements
     p.set_tuning("gather_bucket", mode)
     ms = med(lambda: capi.call("agpu_take_bits", h, vp(vb), n, vp(idx), vp(ov), n))
     res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
@@ -74,10 +75,11 @@ if os.environ.get("TAKE_BITS_SWEEP"):  # where the merge-back form starts to win
     res["take_bits_sweep_ms"] = sweep
     capi.call("agpu_synth_i32", h, vp(idx2), n, 3, 0, n)
     p.sync()
-for label, mode in (("put_direct", 1), ("put_pairs", 2)):
+for label, mode in ((("put_pairs", 2),) if PUT_ONLY else (("put_direct", 1), ("put_pairs", 2))):
     p.set_tuning("gather_bucket", mode)
     ms = med(lambda: capi.call("agpu_put_bounded", h, 4, vp(values), n, vp(idx), vp(out), n, vp(idx2), n))
     res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
     print(label, res[label], flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r03_take_passes.json"), "w"), indent=1)
+if not PUT_ONLY:
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r03_take_passes.json"), "w"), indent=1)
