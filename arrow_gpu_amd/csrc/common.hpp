@@ -34,7 +34,7 @@ struct agpu_tuning {
   int64_t h2d_mode;       // host↔device staging of agpu_import/export_arrow: 0 = auto, 1 = pageable hipMemcpy, 2 = threaded pinned staging, 3 = hipHostRegister in place
   int64_t h2d_threads;    // staging threads for mode 2 (0 = auto)
   int64_t gather_region_bits;  // bucketed take/put: log2(elements) of a source region (0 = auto: 512 KiB regions)
-  int64_t gather_offsets;      // bucketed partition pass: 0 = auto, 1 = ranges reserved with global atomics, 2 = from the column scan of per-tile counts
+  int64_t gather_offsets;      // bucketed pair pipeline: 0 = auto (= 3), 1 = ranges reserved with global atomics, 2 = from column scans of per-tile counts (P and G), 3 = scan for P, atomics for G
 };
 #define AGPU_TUNE_KEYS 12
 agpu_tuning agpu_tuning_defaults();  // snapshot of the process-wide defaults (atomics, runtime.hip)

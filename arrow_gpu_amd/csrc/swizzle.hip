@@ -220,6 +220,7 @@ struct BktCtl {  // device-side control block
   uint32_t cur_s[(BKT_MAX + 1) * BKT_CUR_STRIDE];
   uint32_t cur_d[(BKT_MAX + 1) * BKT_CUR_STRIDE];
   uint32_t base_s[BKT_MAX + 1];  // first pair of every source region (exclusive scan of hist_s)
+  uint32_t base_d[BKT_MAX + 1];  // first pair of every destination region in G's output
   uint32_t total;                // rows that reach the gather (take: n; put: rows with both indices in range)
   uint32_t pad[3];
 };
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void bkt_colsum_kernel(const uint16_t* counts,
   for (uint32_t t = t0; t < t1; t++) acc += counts[(uint64_t)t * nbp + b];
   csum[(uint64_t)c * nbp + b] = acc;
 }
-__global__ __launch_bounds__(256) void bkt_colscan_kernel(uint32_t* csum, uint32_t nbp, uint32_t nchunks, BktCtl* ctl) {
+__global__ __launch_bounds__(256) void bkt_colscan_kernel(uint32_t* csum, uint32_t nbp, uint32_t nchunks, uint32_t* totals) {
   const uint32_t b = blockIdx.x * 256 + threadIdx.x;
   if (b >= nbp) return;
   uint32_t run = 0;
@@ -309,14 +310,14 @@ __global__ __launch_bounds__(256) void bkt_colscan_kernel(uint32_t* csum, uint32
     csum[(uint64_t)c * nbp + b] = run;
     run += v;
   }
-  if (b <= BKT_MAX) ctl->hist_s[b] = run;
+  if (totals && b <= BKT_MAX) totals[b] = run;
 }
 __global__ __launch_bounds__(256) void bkt_offsets_kernel(const uint16_t* counts, const uint32_t* csum, uint32_t nbp,
-                                                         uint32_t ntiles, const BktCtl* ctl, uint32_t* offsets) {
+                                                         uint32_t ntiles, const uint32_t* base, uint32_t* offsets) {
   const uint32_t b = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
   if (b >= nbp) return;
   const uint32_t t0 = c * BKT_CHUNK, t1 = t0 + BKT_CHUNK < ntiles ? t0 + BKT_CHUNK : ntiles;
-  uint32_t run = (b <= BKT_MAX ? ctl->base_s[b] : 0u) + csum[(uint64_t)c * nbp + b];
+  uint32_t run = (b <= BKT_MAX ? base[b] : 0u) + csum[(uint64_t)c * nbp + b];
   for (uint32_t t = t0; t < t1; t++) {
     offsets[(uint64_t)t * nbp + b] = run;
     run += counts[(uint64_t)t * nbp + b];
@@ -370,21 +371,40 @@ __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t b
     ctl->cur_s[b * stride_s] = sh[b];
   }
   __syncthreads();
-  if (is_put) {
-    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) sh[b] = ctl->hist_d[b];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t acc = 0;
-      for (uint32_t b = 0; b < bd; b++) {
-        const uint32_t c = sh[b];
-        sh[b] = acc;
-        acc += c;
-      }
+  if (is_put) {  // the same scan over hist_d[0 .. bd-1] (bd ≤ BKT_MAX)
+    uint32_t c[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t b = threadIdx.x * 4 + k;
+      c[k] = b < bd ? ctl->hist_d[b] : 0u;
+      sum += c[k];
     }
+    const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < AGPU_WAVE; off <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+      if (lane >= (uint32_t)off) incl += o;
+    }
+    if (lane == AGPU_WAVE - 1) wtot[wave] = incl;
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) ctl->cur_d[b * stride_d] = sh[b];
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wave; w++) pre += wtot[w];
+    uint32_t run = pre + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t b = threadIdx.x * 4 + k;
+      if (b < bd) {
+        ctl->cur_d[b * stride_d] = run;
+        ctl->base_d[b] = run;
+      }
+      run += c[k];
+    }
   } else {  // take: the destinations are 0..n-1, every destination bucket is full — its range is its own region
-    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) ctl->cur_d[b * stride_d] = b << rd;
+    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) {
+      ctl->cur_d[b * stride_d] = b << rd;
+      ctl->base_d[b] = b << rd;
+    }
   }
 }
 
@@ -580,11 +600,43 @@ __device__ __forceinline__ void bkt_load_tile(const u32x2* pairs_in, uint64_t ba
   }
 }
 
+// C (round 3): counts2[k][d] = pairs of G's tile k (the same tiles, the same XCD-contiguous walk) whose destination falls
+// into region d.  With a column scan over these, G gets the start of every (tile, destination region) run instead of
+// reserving it with a device-scope atomic: the reservations were 35 000 of G's 75 000 cycles per tile
+// (tools/probe/bkt_phases.py: n/8 atomics per pass at ≈ 26 G/s, nothing to overlap them with at one workgroup per CU), and
+// runs placed by a scan are tile-adjacent, so their 64-byte halves merge in the XCD's L2 like P's do.  8 B/row read.
+__global__ __launch_bounds__(BKT_T) void bkt_count_dst_kernel(const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles, const BktCtl* ctl,
+                                                             uint16_t* counts2, uint32_t nbp2) {
+  __shared__ uint32_t ld[BKT_MAX];
+  uint64_t tile;
+  if (!bkt_tile_of_block(ntiles, &tile)) return;
+  const uint64_t total = ctl->total, base = tile * BKT_TILE;
+  for (uint32_t b = threadIdx.x; b < nbp2; b += BKT_T) ld[b] = 0;
+  __syncthreads();
+  if (base < total) {
+#pragma unroll
+    for (int q = 0; q < BKT_E / 2; q++) {
+      const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 2;
+      if (i0 + 2 <= total) {
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pairs_in + i0));
+        atomicAdd(&ld[t.y >> rd], 1u);
+        atomicAdd(&ld[t.w >> rd], 1u);
+      } else if (i0 < total) {
+        atomicAdd(&ld[pairs_in[i0].y >> rd], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < nbp2; b += BKT_T) counts2[tile * nbp2 + b] = (uint16_t)ld[b];
+  (void)bd;
+}
+
 // G: pairs in source-bucket order → {destination, value} in destination-bucket order
 template <int W>
 __global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf<W>::type* values, uint64_t n_src,
                                                           const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles,
-                                                          int src_line_shift, BktCtl* ctl, u32x2* pairs_out, uint32_t cur_stride) {
+                                                          int src_line_shift, BktCtl* ctl, u32x2* pairs_out, uint32_t cur_stride,
+                                                          const uint32_t* offsets2, uint32_t nbp2) {
   BKT_LDS_DECL;
   uint64_t tile;
   if (!bkt_tile_of_block(ntiles, &tile)) return;
@@ -616,7 +668,8 @@ __global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf
   __syncthreads();  // everyone has read `sorted` before the second sort overwrites it
   BKT_STAMP(1, 0);  // gathers issued
   bkt_tile_sort(row, bd, lcnt, sorted, wave_tot, &tile_rows, 1);
-  bkt_copy_out(bd, lcnt, sorted, tile_rows, ctl->cur_d, cur_stride, pairs_out, [=](const u32x2& v) { return v.x >> rd; }, 1);
+  bkt_copy_out(bd, lcnt, sorted, tile_rows, ctl->cur_d, cur_stride, pairs_out, [=](const u32x2& v) { return v.x >> rd; }, 1,
+               offsets2 ? offsets2 + tile * nbp2 : nullptr);
 }
 
 // F: {destination, value} in destination-bucket order → dst[destination] = value.  The tile is first ordered by
@@ -678,6 +731,8 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   void *ctl_v = nullptr, *p1 = nullptr, *p2 = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr;
   const uint32_t ntiles = (uint32_t)((n + BKT_TILE - 1) / BKT_TILE);
   const uint32_t nbp = (bs + 1 + 3) & ~3u;  // padded row stride of the (tile × region) matrices
+  const uint32_t nbp2 = (bd + 3) & ~3u;      // … of G's (tile × destination region) matrices: the same blocks, used after P is through
+  const uint32_t nbpm = nbp > nbp2 ? nbp : nbp2;
   const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
   // Range starts of the partition pass: from a column scan of per-tile counts (default since round 3; "gather_offsets" = 1
   // brings the global-atomic reservations back).  Under round-robin tiles the scan form was never faster — the pass is
@@ -690,10 +745,16 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p1);
   if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p2);
   if (det) {
-    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 2, 0, &cnt_v);
-    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 4, 0, &off_v);
-    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)nchunks * nbp * 4, 0, &csum_v);
+    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbpm * 2, 0, &cnt_v);
+    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbpm * 4, 0, &off_v);
+    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)nchunks * nbpm * 4, 0, &csum_v);
   }
+  // G's range starts: reserved with atomics (default), or — "gather_offsets" = 2 — from a count pass over P's output + the same
+  // column scan.  Measured at 2^28 rows (tools/probe/put_offsets_ab.py under rocprofv3): G 2.10 → 1.77 ms, but the count pass costs
+  // 0.52 ms and its scans 0.11: put 5.05 → 5.00 ms, pair-pipeline take 4.42 → 5.1.  The per-tile stamps had promised more (35 000 of
+  // G's 75 000 cycles in the reservation phase) — at one workgroup per CU a tile's phases add up, but chip-wide the atomic unit's
+  // 1.3 ms overlap with the other CUs' sorts; what is left of G is its own chain of phases (load → sort → gather → sort → store).
+  const bool det2 = det && p->tune.gather_offsets == 2;
   if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;  // no room for the 16 B/row of temporaries: the direct kernel needs none
   if (st == AGPU_OK) {
     BktCtl* ctl = static_cast<BktCtl*>(ctl_v);
@@ -712,19 +773,27 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags, counts, nbp, ntiles);
       if (det) {
         hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
-        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl);
+        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s);
       }
       // one cursor per 128-byte line while the regions are few (the atomics spread over the L2 channels: −10…15 % per
       // call at ≤ 1024 regions, same-box A/B), packed cursors beyond (a 256 KiB cursor array costs more than it spreads)
       const uint32_t stride_s = bs + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 1;
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0, stride_s, stride_d);
-      if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl, offsets);
+      if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets);
       hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),
                          det ? offsets : static_cast<uint32_t*>(nullptr), nbp, stride_s, ntiles);
+      if (det2) {  // C + the column scan again, over the blocks P has just finished with
+        const dim3 cgrid2((nbp2 + 255) / 256, nchunks);
+        hipLaunchKernelGGL(bkt_count_dst_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), rd, bd, ntiles, ctl, counts, nbp2);
+        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid2, dim3(256), 0, p->stream, counts, nbp2, ntiles, csum);
+        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp2 + 255) / 256), dim3(256), 0, p->stream, csum, nbp2, nchunks, static_cast<uint32_t*>(nullptr));
+        hipLaunchKernelGGL(bkt_offsets_kernel, cgrid2, dim3(256), 0, p->stream, counts, csum, nbp2, ntiles, ctl->base_d, offsets);
+      }
 #define BKT_GF(W, E)                                                                                                         \
   case W:                                                                                                                    \
     hipLaunchKernelGGL((bkt_gather_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const E*>(src), n_src,     \
-                       static_cast<const u32x2*>(p1), rd, bd, ntiles, src_line_shift, ctl, static_cast<u32x2*>(p2), stride_d); \
+                       static_cast<const u32x2*>(p1), rd, bd, ntiles, src_line_shift, ctl, static_cast<u32x2*>(p2), stride_d, \
+                       det2 ? offsets : static_cast<const uint32_t*>(nullptr), nbp2);                                          \
     hipLaunchKernelGGL((bkt_store_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p2), ntiles,  \
                        ctl, line_shift, static_cast<E*>(dst));                                                               \
     break;
@@ -1445,9 +1514,9 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
       const dim3 cgrid((nbp + 255) / 256, nchunks);
       hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, p->flags, counts, nbp, ntiles);
       hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
-      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl);
+      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s);
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 0, 0, 1u, 1u);
-      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl, offsets);
+      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets);
       hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, offsets, nbp,
                          ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v));
       hipLaunchKernelGGL(tk2_gather_bits_kernel, dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, bits, n_bits,
@@ -1502,9 +1571,9 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* value
       const dim3 cgrid((nbp + 255) / 256, nchunks);
       hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, p->flags, counts, nbp, ntiles);
       hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
-      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl);
+      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s);
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 0, 0, 1u, 1u);
-      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl, offsets);
+      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets);
       hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, offsets, nbp,
                          ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v));
       const dim3 ggrid((gtiles + 7) / 8 * 8), fgrid((ntiles + 7) / 8 * 8);

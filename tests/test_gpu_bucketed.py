@@ -330,3 +330,42 @@ def test_take_bits_at_2_28_rows_merge_back_equals_direct(ctx):
     sample = slice(12_345_678, 12_345_678 + 1_000_000)
     src = np.unpackbits(bits, bitorder="little")
     assert np.array_equal(np.unpackbits(outs[0], bitorder="little")[sample], src[idx[sample]])
+
+
+# ---- the pair pipeline's range starts: by atomics (1), from column scans for P and G (2), scan for P + atomics for G (3 = default)
+@pytest.mark.parametrize("offsets", [1, 2, 3])
+@pytest.mark.parametrize("width", [4, 1])
+def test_pair_pipeline_range_start_variants(ctx, offsets, width):
+    dev, p = ctx
+    p.set_tuning("gather_offsets", offsets)
+    try:
+        rng = np.random.default_rng(offsets * 7 + width)
+        n, n_src, n_dst = 3 * 16384 + 77, 2_000_003, (1 << 21) + 9
+        src = rng.integers(0, 1 << (8 * width), n_src, dtype=np.uint64).astype(NPW[width])
+        dst = rng.integers(0, 1 << (8 * width), n_dst, dtype=np.uint64).astype(NPW[width])
+        si = rng.integers(0, n_src, n).astype(np.uint32)
+        di = rng.permutation(n_dst)[:n].astype(np.uint32)
+        si[5::997] = n_src + 1  # dropped rows: the tiles behind P are ragged
+        ok = si < n_src
+        ds, dd = dev.create_gpu_buffer_with_data(src), dev.create_gpu_buffer_with_data(dst)
+        dsi, ddi = dev.create_gpu_buffer_with_data(si), dev.create_gpu_buffer_with_data(di)
+        capi.call("agpu_put_bounded", p._handle, width, vp(ds), n_src, vp(dsi), vp(dd), n_dst, vp(ddi), n)
+        import arrow_gpu_amd as ag
+
+        with pytest.raises(ag.ArrowErrorGPU):
+            p.sync()
+        got = dev.retrive_data(dd, n_dst * width, pipeline=p).view(NPW[width])
+        exp = dst.copy()
+        exp[di[ok]] = src[si[ok]]
+        assert np.array_equal(got, exp)
+        # the pair-pipeline take (mode 3 for 4-byte values, the only bucketed form for 1-byte ones)
+        p.set_tuning("gather_bucket", 3 if width == 4 else 2)
+        out = dev.create_empty_buffer(n * width + 16)
+        capi.call("agpu_take", p._handle, width, vp(ds), n_src, vp(dsi), vp(out), n)
+        with pytest.raises(ag.ArrowErrorGPU):
+            p.sync()
+        got = dev.retrive_data(out, n * width, pipeline=p).view(NPW[width])
+        assert np.array_equal(got, np.where(ok, src[np.minimum(si, n_src - 1)], 0).astype(NPW[width]))
+    finally:
+        p.set_tuning("gather_offsets", 0)
+        p.set_tuning("gather_bucket", 2)

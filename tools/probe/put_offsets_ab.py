@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """put at 2^28 random rows, pair pipeline: range starts by global atomics (gather_offsets = 1) vs from the column scan of
-per-tile counts (= 2), both with XCD-contiguous partition tiles.  One process, same buffers."""
+per-tile counts for P only (= 3) and for P and G (= 2: G's starts from a count pass over P's output; measured a wash, not the default), all with
+XCD-contiguous tiles.  One process, same buffers."""
 import ctypes as C
 import os
 import sys
@@ -24,7 +25,7 @@ capi.call("agpu_synth_i32", h, vp(idx), n, 2, 0, n)
 capi.call("agpu_synth_i32", h, vp(idx2), n, 3, 0, n)
 p.sync()
 p.set_tuning("gather_bucket", 2)
-for off in (1, 2, 1, 2):
+for off in [int(x) for x in os.environ.get("AB_MODES", "1,3,2,1,3,2").split(",")]:
     p.set_tuning("gather_offsets", off)
     for what in ("put", "take_pairs"):
         if what == "take_pairs":
