@@ -320,6 +320,30 @@ def _claim_stdout():
     return real
 
 
+def _self_launch(n: int, real_stdout) -> int:
+    """`python bench.py --gpus N` without torchrun: N children, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set like torchrun sets
+    them (the rendezvous path is derived from MASTER_PORT + this pid, sharding.rendezvous_path_from_env)."""
+    import socket
+
+    with socket.socket() as sk:  # a free port only names the rendezvous: nothing listens on it
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TORCHELASTIC_RUN_ID=f"bench_self_{os.getpid()}")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0]
+    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    if any(rcs):
+        print(f"bench.py: worker exit codes {rcs}", file=sys.stderr)
+        return 1
+    real_stdout.write(out.decode())
+    real_stdout.flush()
+    return 0
+
+
 def main():
     real_stdout = _claim_stdout()
     ap = argparse.ArgumentParser()
@@ -337,6 +361,10 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="agpu_set_tuning before anything is allocated (A/B runs, e.g. --tune pool_arena=0); recorded in config.tuning")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "OMPI_COMM_WORLD_RANK" not in os.environ and "SLURM_PROCID" not in os.environ:
+        # started plainly with --gpus N (no launcher): be our own launcher.  This process has not touched the GPU and never will:
+        # it starts one worker per GPU as CHILD processes (never an exec) with the launcher's environment and relays rank 0's line.
+        sys.exit(_self_launch(args.gpus, real_stdout))
 
     # NOTHING of torch is imported by a worker: the process runs on the HIP + RCCL that libarrow_gpu_hip.so links
     # (/opt/rocm), not on torch's bundled copies — one runtime.

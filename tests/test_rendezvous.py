@@ -108,3 +108,19 @@ def test_bench_worker_never_imports_torch():
     assert not stmt.search(open(os.path.join(ROOT, "bench.py")).read())
     for name in ("_capi.py", "gpu_utils.py", "array.py"):
         assert not stmt.search(open(os.path.join(ROOT, "arrow_gpu_amd", name)).read())
+
+
+def test_bench_started_plainly_with_gpus_n_launches_its_own_workers():
+    """`python bench.py --gpus 2` without a launcher: the parent starts one child per GPU (torchrun's environment) and never
+    touches a device itself.  Without a GPU both children fail at device creation and the parent reports it — no hang, no line."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "OMPI_COMM_WORLD_RANK", "SLURM_PROCID")}
+    env["HIP_VISIBLE_DEVICES"] = "-1"  # also on a GPU box: this test is about the plumbing
+    env["ROCR_VISIBLE_DEVICES"] = "-1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--rendezvous-timeout", "5"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1
+    assert r.stdout.strip() == ""
+    assert "worker exit codes [1, 1]" in r.stderr and "NoDevice" in r.stderr
