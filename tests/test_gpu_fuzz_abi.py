@@ -32,6 +32,8 @@ def _dev():
 def D(_dev):
     yield _dev
     _dev.release()
+    _dev.p.set_tuning("gather_bucket", 0)
+    _dev.p.set_tuning("gather_offsets", 0)
 
 
 def pick_n(rng):
@@ -59,7 +61,11 @@ def test_random_abi_calls_match_the_oracle(D, seed):
     rng = np.random.default_rng(5000 + seed)
     for it in range(12):
         fam = ("binary", "scalar", "unary", "compare", "compare_validity", "cast", "bitmap", "reduce", "take", "merge",
-               "chain", "shift", "put", "take_bits")[rng.integers(14)]
+               "chain", "shift", "put", "take_bits", "take_validity")[rng.integers(15)]
+        # take / put: the direct kernels (auto at these sizes), the forced pipelines (2: merge-back take, pair-pipeline put;
+        # 3: pair-pipeline take) and all three range-start variants — small, ragged, mis-aligned inputs through every form
+        D.p.set_tuning("gather_bucket", int((0, 2, 3)[rng.integers(3)]))
+        D.p.set_tuning("gather_offsets", int(rng.integers(0, 4)))
         n = pick_n(rng)
         dtype = ALL_DTYPES[rng.integers(len(ALL_DTYPES))]
         w = NP[dtype]().itemsize
@@ -157,6 +163,18 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             D.call("agpu_put_bounded", w, D.up(a, off(rng, w)).vp, n, D.up(si, off(rng, 4)).vp, ddst.vp, n_dst,
                    D.up(di, off(rng, 4)).vp, k)
             assert bits_equal(D.down(ddst, NP[dtype], n_dst), O.put(w, a, si, dst, di)), what
+            assert D.status("agpu_pipeline_sync") == capi.OK
+        elif fam == "take_validity":
+            if n == 0:
+                continue
+            k = pick_n(rng)
+            idx = rng.integers(0, n, k).astype(np.uint32)
+            vb = O.synth_bits(n, seed, it + 9, 0.6)
+            out = D.empty(max(k * w, 1), offset_bytes=off(rng, w))
+            outv = D.empty(O.bitmap_bytes(k) + 8)
+            D.call("agpu_take_validity", w, D.up(a, off(rng, w)).vp, n, D.up(vb).vp, D.up(idx, off(rng, 4)).vp, out.vp, outv.vp, k)
+            assert bits_equal(D.down(out, NP[dtype], k), O.take(w, a, idx)), what
+            assert bits_equal(D.down(outv, np.uint8, O.bitmap_bytes(k)), O.take_bits(vb, n, idx)), what
             assert D.status("agpu_pipeline_sync") == capi.OK
         elif fam == "take_bits":
             if n == 0:
