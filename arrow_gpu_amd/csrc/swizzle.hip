@@ -1148,28 +1148,31 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
     ent[e] = j < rows_here ? sorted[j] : 0u;
   }
   __syncthreads();  // every entry has been read: the same array takes the values, back in slot order
+#ifndef TK2_GGRP
+#define TK2_GGRP 8  // gathers in flight per lane (16: 58 VGPRs, measured no faster — tools/probe/put_variants.sh)
+#endif
 #pragma unroll
-  for (int h0 = 0; h0 < TK2_GE; h0 += 8) {
-    uint32_t v[8];
+  for (int h0 = 0; h0 < TK2_GE; h0 += TK2_GGRP) {
+    uint32_t v[TK2_GGRP];
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
+    for (int e = 0; e < TK2_GGRP; e++) {
       const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
       v[e] = j < rows_here ? values[origin + (ent[h0 + e] >> TK2_POS_BITS)] : 0u;  // the L2-resident gather
     }
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
+    for (int e = 0; e < TK2_GGRP; e++) {
       const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
       if (j < rows_here) sorted[ent[h0 + e] & ((1u << TK2_POS_BITS) - 1u)] = v[e];
     }
     if constexpr (BITS) {  // the validity bits of the same eight sources: 16 bytes of bitmap per line group, shared by neighbours
-      uint32_t w[8];
+      uint32_t w[TK2_GGRP];
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
+      for (int e = 0; e < TK2_GGRP; e++) {
         const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
         w[e] = j < rows_here ? vbits_src[(origin + (ent[h0 + e] >> TK2_POS_BITS)) >> 5] : 0u;
       }
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
+      for (int e = 0; e < TK2_GGRP; e++) {
         const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
         const uint32_t src = origin + (ent[h0 + e] >> TK2_POS_BITS), pos = ent[h0 + e] & ((1u << TK2_POS_BITS) - 1u);
         if (j < rows_here && ((w[e] >> (src & 31)) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
