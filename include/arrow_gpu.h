@@ -417,7 +417,10 @@ agpu_status agpu_put_bounded(agpu_pipeline* p, int32_t width, const void* src, u
                              void* dst, uint64_t n_dst, const uint32_t* dst_idx, uint64_t n);
 agpu_status agpu_put(agpu_pipeline* p, int32_t width, const void* src, const uint32_t* src_idx, void* dst,
                      const uint32_t* dst_idx, uint64_t n);
-/* bit scatter (atomic and/or) [ref: crates/routines/src/bool.rs:48-128, bool/put.wgsl:17-34] */
+/* bit scatter: dst bit dst_idx[i] = src bit src_idx[i] [ref: crates/routines/src/bool.rs:48-128, bool/put.wgsl:17-34 — an
+ * atomic and / or per row there].  The bounded form runs bucketed by destination region from 2^24 rows (the bits are gathered
+ * by the Boolean take's pipeline, partitioned by 32 KiB bitmap regions and applied in LDS: no global atomics, 2.8x the direct
+ * kernel at 2^28 rows); below that, with unknown lengths, or under tuning gather_bucket = 1: one atomic per row. */
 agpu_status agpu_put_bits_bounded(agpu_pipeline* p, const void* src_bits, uint64_t n_src_bits, const uint32_t* src_idx,
                                   void* dst_bits, uint64_t n_dst_bits, const uint32_t* dst_idx, uint64_t n);
 agpu_status agpu_put_bits(agpu_pipeline* p, const void* src_bits, const uint32_t* src_idx, void* dst_bits,

@@ -369,3 +369,78 @@ def test_pair_pipeline_range_start_variants(ctx, offsets, width):
     finally:
         p.set_tuning("gather_offsets", 0)
         p.set_tuning("gather_bucket", 2)
+
+
+# ---- round 3: Boolean put (agpu_put_bits_bounded) bucketed by destination region — LDS-resident regions, no global atomics
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("n,n_src,n_dst,dist", [(5, 9, 77, "uniform"), (32768, 70_001, 40_000, "uniform"), (100_003, 1 << 20, (1 << 21) + 5, "uniform"),
+                                                (1_000_003, 40_000_003, 3_000_017, "uniform"), (300_000, 1 << 22, (1 << 18) * 5 + 3, "oob"),
+                                                (500_000, 1 << 23, 1 << 24, "skew"), (200_000, 1 << 20, 1_200_000_007, "uniform")])
+def test_put_bits_pipelines_equal_the_oracle(ctx, mode, n, n_src, n_dst, dist):
+    """[ref: crates/routines/src/bool.rs put + bool/put.wgsl] direct (mode 1: one atomic per row) and bucketed (mode 2) against
+    oracle.put_bits with distinct destinations; rows with either index out of range are dropped and raise the sticky flag"""
+    import arrow_gpu_amd as ag
+
+    dev, p = ctx
+    p.set_tuning("gather_bucket", mode)
+    try:
+        rng = np.random.default_rng(n * 17 + mode)
+        src = rng.integers(0, 256, (n_src + 63) // 64 * 8, dtype=np.uint8)
+        dst = rng.integers(0, 256, (n_dst + 63) // 64 * 8, dtype=np.uint8)
+        si = rng.integers(0, n_src, n).astype(np.uint32)
+        if n_dst > 100_000_000:  # distinct destinations without a 1.2 G-entry permutation
+            di = np.unique(rng.integers(0, n_dst, 2 * n).astype(np.uint32))[:n]
+            rng.shuffle(di)
+            assert len(di) == n
+        else:
+            di = rng.permutation(n_dst)[:n].astype(np.uint32)
+        if dist == "skew":  # most rows land in one destination region
+            di = np.where(rng.random(n) < 0.9, rng.permutation(1 << 18)[:n] if n <= (1 << 18) else di, di).astype(np.uint32)
+            di = np.unique(di)
+            rng.shuffle(di)
+            si = si[: len(di)]
+        ok = np.ones(len(di), bool)
+        if dist == "oob":
+            si[::101] = n_src + 5
+            di[::103] = n_dst
+            ok = (si < n_src) & (di < n_dst)
+        k = len(di)
+        ds, dd = dev.create_gpu_buffer_with_data(src), dev.create_gpu_buffer_with_data(np.concatenate([dst, np.full(16, 0xEE, np.uint8)]))
+        dsi, ddi = dev.create_gpu_buffer_with_data(si), dev.create_gpu_buffer_with_data(di)
+        capi.call("agpu_put_bits_bounded", p._handle, vp(ds), n_src, vp(dsi), vp(dd), n_dst, vp(ddi), k)
+        if dist == "oob":
+            with pytest.raises(ag.ArrowErrorGPU):
+                p.sync()
+        else:
+            p.sync()
+        got = dev.retrive_data(dd, len(dst) + 16, pipeline=p)
+        exp = O.put_bits(src, si[ok], dst, di[ok])
+        assert np.array_equal(got[: len(dst)], exp)
+        assert (got[len(dst):] == 0xEE).all()
+    finally:
+        p.set_tuning("gather_bucket", 2)
+
+
+def test_put_bits_at_2_27_rows_bucketed_equals_direct(ctx):
+    dev, p = ctx
+    n, n_src, n_dst = 1 << 27, 1 << 28, 1 << 28
+    rng = np.random.default_rng(99)
+    src = rng.integers(0, 256, n_src // 8, dtype=np.uint8)
+    dst = rng.integers(0, 256, n_dst // 8, dtype=np.uint8)
+    si = rng.integers(0, n_src, n, dtype=np.uint32)
+    di = rng.permutation(n_dst).astype(np.uint32)[:n]
+    ds, dsi, ddi = dev.create_gpu_buffer_with_data(src), dev.create_gpu_buffer_with_data(si), dev.create_gpu_buffer_with_data(di)
+    outs = {}
+    try:
+        for mode in (1, 0):  # 0 = auto: bucketed at this size
+            p.set_tuning("gather_bucket", mode)
+            dd = dev.create_gpu_buffer_with_data(dst)
+            capi.call("agpu_put_bits_bounded", p._handle, vp(ds), n_src, vp(dsi), vp(dd), n_dst, vp(ddi), n)
+            p.sync()
+            outs[mode] = dev.retrive_data(dd, n_dst // 8, pipeline=p)
+    finally:
+        p.set_tuning("gather_bucket", 2)
+    assert np.array_equal(outs[0], outs[1])
+    sb, db = np.unpackbits(src, bitorder="little"), np.unpackbits(dst, bitorder="little")
+    db[di] = sb[si]
+    assert np.array_equal(outs[0], np.packbits(db, bitorder="little"))

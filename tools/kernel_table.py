@@ -169,6 +169,15 @@ def main():
       lambda: capi.call("agpu_take_bits", h, vp(VA), m, vp(IDX), vp(OB), m), note="tuning gather_bucket=1")
     fix(4.25)
     p.set_tuning("gather_bucket", 0)
+    t("put_bits (Boolean put), random src and dst idx, default = bucketed by destination region (2^28 rows)", 8.25 * m / n,
+      lambda: capi.call("agpu_put_bits_bounded", h, vp(VA), m, vp(IDX), vp(OB), m, vp(IDX2), m),
+      note="round 3: Boolean take emitting entries + partition by 32 KiB bitmap regions + LDS apply; no global atomics")
+    fix(8.25)
+    p.set_tuning("gather_bucket", 1)
+    t("put_bits (Boolean put), random src and dst idx, direct (2^28 rows)", 8.25 * m / n,
+      lambda: capi.call("agpu_put_bits_bounded", h, vp(VA), m, vp(IDX), vp(OB), m, vp(IDX2), m), note="tuning gather_bucket=1: one device-scope atomic per row")
+    fix(8.25)
+    p.set_tuning("gather_bucket", 0)
     t("clone_buffer (agpu_copy, 4 GB)", 8, lambda: capi.call("agpu_copy", h, vp(O), vp(A), 4 * n))
 
     # the reference's own criterion shapes, kernel time only (its benches: crates/benchmarks/benches/compare_gpu_arrow.rs
