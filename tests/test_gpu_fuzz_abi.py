@@ -61,7 +61,7 @@ def test_random_abi_calls_match_the_oracle(D, seed):
     rng = np.random.default_rng(5000 + seed)
     for it in range(12):
         fam = ("binary", "scalar", "unary", "compare", "compare_validity", "cast", "bitmap", "reduce", "take", "merge",
-               "chain", "shift", "put", "take_bits", "take_validity")[rng.integers(15)]
+               "chain", "shift", "put", "take_bits", "take_validity", "put_bits")[rng.integers(16)]
         # take / put: the direct kernels (auto at these sizes), the forced pipelines (2: merge-back take, pair-pipeline put;
         # 3: pair-pipeline take) and all three range-start variants — small, ragged, mis-aligned inputs through every form
         D.p.set_tuning("gather_bucket", int((0, 2, 3)[rng.integers(3)]))
@@ -163,6 +163,18 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             D.call("agpu_put_bounded", w, D.up(a, off(rng, w)).vp, n, D.up(si, off(rng, 4)).vp, ddst.vp, n_dst,
                    D.up(di, off(rng, 4)).vp, k)
             assert bits_equal(D.down(ddst, NP[dtype], n_dst), O.put(w, a, si, dst, di)), what
+            assert D.status("agpu_pipeline_sync") == capi.OK
+        elif fam == "put_bits":
+            if n == 0:
+                continue
+            n_dst = n + int(rng.integers(0, 100))
+            k = min(pick_n(rng), n_dst)
+            src_b, dst_b = O.synth_bits(n, seed, it + 11, 0.5), O.synth_bits(n_dst, seed, it + 12, 0.5)
+            si = rng.integers(0, n, k).astype(np.uint32)
+            di = rng.permutation(n_dst)[:k].astype(np.uint32)  # unique destinations
+            ddst = D.up(dst_b)
+            D.call("agpu_put_bits_bounded", D.up(src_b).vp, n, D.up(si, off(rng, 4)).vp, ddst.vp, n_dst, D.up(di, off(rng, 4)).vp, k)
+            assert bits_equal(D.down(ddst, np.uint8, O.bitmap_bytes(n_dst)), O.put_bits(src_b, si, dst_b, di)), what
             assert D.status("agpu_pipeline_sync") == capi.OK
         elif fam == "take_validity":
             if n == 0:
