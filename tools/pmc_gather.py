@@ -39,10 +39,10 @@ def durations(variant):
 
 
 out = {"rows": N, "launches_per_pass": LAUNCHES, "index_distribution": "uniform random over 2^28, 4-byte values",
-       "variants_explained": "take_bucketed = merge-back pipeline (tk2_* kernels), take_pairs = pair pipeline (bkt_* kernels, gather_bucket = 3), put_bucketed = pair pipeline with range starts from the column scan",
+       "variants_explained": "take_bucketed = merge-back pipeline (tk2_* kernels), take_pairs = pair pipeline (bkt_* kernels, gather_bucket = 3), put_bucketed = pair pipeline with range starts from the column scan, takebits_* = Boolean take (bucketed: the merge-back pipeline over the bitmap's words), putbits_* = Boolean put (bucketed: entries by destination region, applied in LDS)",
        "note": "per-row figures = totals of the pass / (launches x rows); read bytes = FETCH_SIZE KiB x 1024 x 2 (gfx950), write bytes = WRITE_SIZE KiB x 1024",
        "variants": {}}
-for v in ("take_direct", "take_bucketed", "take_pairs", "put_direct", "put_bucketed"):
+for v in ("take_direct", "take_bucketed", "take_pairs", "put_direct", "put_bucketed", "takebits_direct", "takebits_bucketed", "putbits_direct", "putbits_bucketed"):
     fetch, write, dur = counters("fetch", v, "FETCH_SIZE"), counters("write", v, "WRITE_SIZE"), durations(v)
     kernels = {}
     for k in sorted(set(fetch) | set(write) | set(dur)):

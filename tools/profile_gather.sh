@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/gather_$ROUND
 mkdir -p "$OUT"
 cd /tmp
-for v in take_direct take_bucketed take_pairs put_direct put_bucketed; do
+for v in take_direct take_bucketed take_pairs put_direct put_bucketed takebits_direct takebits_bucketed putbits_direct putbits_bucketed; do
   timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$v" -o t -- python3 "$REPO/tools/probe/gather_pmc.py" $v > "$OUT/trace_$v.log" 2>&1
   echo "$v trace rc=$?"
   timeout 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch_$v" -o t -- python3 "$REPO/tools/probe/gather_pmc.py" $v > "$OUT/fetch_$v.log" 2>&1
