@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 round_ = sys.argv[1] if len(sys.argv) > 1 else "r03"
 base = os.path.join(ROOT, "gpurun_out", f"gather_{round_}")
 N, LAUNCHES = 1 << 28, 3
-SKIP = ("synth_", "__amd_rocclr", "trig16_build", "pow_build")
+SKIP = ("synth_", "__amd_rocclr", "trig16_build", "pow_build", "lut8_build")
 
 
 def short(name):
