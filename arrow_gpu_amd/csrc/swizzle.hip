@@ -835,7 +835,8 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
 //       pieces into LDS and every row picks its value: out[i] in natural order, one coalesced store        4 + 2 + 4 (runs) r, 4 w
 // ≈ 41 B/row, three LDS passes instead of five, entries half the size so a 32 Ki-row tile fits (the runs keep their
 // 64 bytes), and nothing is nondeterministic but the ranks, which are recorded.  Out-of-range indices: their own bucket,
-// value 0, sticky flag (as above).  Other widths, and put (whose destinations are data), keep the pair pipeline.
+// value 0, sticky flag (as above).  1- / 2-byte values: the same kernels (template parameter W).  put (whose destinations are data)
+// keeps the pair pipeline.
 #define TK2_E 32
 #define TK2_TILE (BKT_T * TK2_E)  // 32 Ki rows: P2 / F2 tiles
 #define TK2_GE 16
@@ -1000,10 +1001,13 @@ __global__ __launch_bounds__(BKT_T) void tk2_partition_kernel(const uint32_t* si
 // :9-55 values + bool.rs:33-46 validity]): the bit of row idx sits in the 16 KiB of bitmap that belong to the tile's 512 KiB
 // region — after the line-group sort neighbouring lanes read the same 16 bytes of it — and leaves as vbits_slot, one bit per
 // slot in slot order (256 u64 words per tile).
-template <int WPE, bool BITS>
-__global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* values, uint64_t n_src, const uint32_t* srcs, uint64_t total,
-                                                               uint32_t ntiles, uint32_t* vals, const uint32_t* vbits_src,
-                                                               uint64_t* vbits_slot) {
+// W = the value width in bytes (4, 2, 1): regions, entries and the LDS arrays are in ELEMENTS either way; only the gather, the
+// slow path and the last store see the type.
+template <int WPE, bool BITS, int W = 4>
+__global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename ElemOf<W>::type* values, uint64_t n_src, const uint32_t* srcs,
+                                                               uint64_t total, uint32_t ntiles, typename ElemOf<W>::type* vals,
+                                                               const uint32_t* vbits_src, uint64_t* vbits_slot) {
+  typedef typename ElemOf<W>::type E;
   // 64 KiB + 8 KiB of LDS and ≤ 64 VGPRs: TWO workgroups per CU, so that one's loads and gathers run under the other's LDS
   // phases.  To stay inside 64 registers the tile's sources are loaded twice (the second time from L2) instead of being
   // kept across the ranking, ranks are packed two to a register, and only the 16 sorted entries live across the barrier
@@ -1082,7 +1086,7 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
       for (int k = 0; k < 4; k++)
         if (live_at(q, k)) {
           const bool ok = sv[k] < n_src;
-          vals[base + ((uint64_t)q * BKT_T + threadIdx.x) * 4 + (uint64_t)k] = ok ? values[sv[k]] : 0u;
+          vals[base + ((uint64_t)q * BKT_T + threadIdx.x) * 4 + (uint64_t)k] = ok ? values[sv[k]] : (E)0;
           if constexpr (BITS) {
             const uint32_t pos = ((uint32_t)q * BKT_T + threadIdx.x) * 4 + (uint32_t)k;
             if (ok && ((vbits_src[sv[k] >> 5] >> (sv[k] & 31)) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
@@ -1159,7 +1163,7 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
 #pragma unroll
     for (int e = 0; e < TK2_GGRP; e++) {
       const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
-      v[e] = j < rows_here ? values[origin + (ent[h0 + e] >> TK2_POS_BITS)] : 0u;  // the L2-resident gather
+      v[e] = j < rows_here ? (uint32_t)values[origin + (ent[h0 + e] >> TK2_POS_BITS)] : 0u;  // the L2-resident gather
     }
 #pragma unroll
     for (int e = 0; e < TK2_GGRP; e++) {
@@ -1188,11 +1192,18 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
     const uint32_t l0 = ((uint32_t)q * BKT_T + threadIdx.x) * 4;
     const uint64_t i0 = base + l0;
     if (i0 + 4 <= total) {
-      const u32x4 v = {sorted[l0], sorted[l0 + 1], sorted[l0 + 2], sorted[l0 + 3]};
-      *reinterpret_cast<u32x4*>(vals + i0) = v;
+      if constexpr (W == 4) {
+        const u32x4 v = {sorted[l0], sorted[l0 + 1], sorted[l0 + 2], sorted[l0 + 3]};
+        *reinterpret_cast<u32x4*>(vals + i0) = v;
+      } else if constexpr (W == 2) {
+        const u32x2 v = {sorted[l0] | (sorted[l0 + 1] << 16), sorted[l0 + 2] | (sorted[l0 + 3] << 16)};
+        *reinterpret_cast<u32x2*>(vals + i0) = v;
+      } else {
+        *reinterpret_cast<uint32_t*>(vals + i0) = sorted[l0] | (sorted[l0 + 1] << 8) | (sorted[l0 + 2] << 16) | (sorted[l0 + 3] << 24);
+      }
     } else {
       for (int k = 0; k < 4; k++)
-        if (i0 + k < total) vals[i0 + k] = sorted[l0 + k];
+        if (i0 + k < total) vals[i0 + k] = (E)sorted[l0 + k];
     }
   }
 }
@@ -1200,12 +1211,14 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const uint32_t* 
 // F2: out[i] = vals[offs[t][key(i)] + rank16[i]] — the tile's runs come into LDS as contiguous pieces, rows pick from there
 // MODE 0: values; 1: values + the source validity bits (agpu_take_validity); 2: bits only (Boolean take: no value array at all);
 // 3: bits only, leaving as the Boolean put's entries ent[i] = dst_idx[i] * 2 + bit (0xFFFFFFFF for a row with either index out of range)
-template <int MODE>
+template <int MODE, int W = 4>
 __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, uint64_t n, uint64_t n_src, int rs, uint32_t bs,
                                                          const uint16_t* counts, const uint32_t* offsets, uint32_t nbp,
-                                                         uint32_t ntiles, const uint16_t* rank16, const uint32_t* vals, uint32_t* out,
-                                                         const uint32_t* vbits_slot, uint64_t* out_validity, const uint32_t* di = nullptr,
-                                                         uint64_t n_dst = 0) {
+                                                         uint32_t ntiles, const uint16_t* rank16, const typename ElemOf<W>::type* vals,
+                                                         typename ElemOf<W>::type* out, const uint32_t* vbits_slot, uint64_t* out_validity,
+                                                         const uint32_t* di = nullptr, uint64_t n_dst = 0) {
+  typedef typename ElemOf<W>::type E;
+  static_assert(MODE < 3 || W == 4, "the entry array is 4 bytes wide");
   __shared__ uint32_t A[TK2_TILE];
   constexpr bool BITS = MODE >= 1, VALUES = MODE <= 1, ENT = MODE == 3;
   __shared__ uint32_t bl[BITS ? TK2_TILE / 32 : 1];  // the validity bits of the tile's slots (BITS)
@@ -1304,7 +1317,7 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
 #pragma unroll
       for (int e = 0; e < TK2_E; e++) {
         const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
-        if (j < rows_here) g[e] = __builtin_nontemporal_load(vals + g[e]);
+        if (j < rows_here) g[e] = (uint32_t)__builtin_nontemporal_load(vals + g[e]);
       }
 #pragma unroll
       for (int e = 0; e < TK2_E; e++) {
@@ -1319,11 +1332,13 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
     const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
     if constexpr (VALUES) {
       if (i0 + 4 <= n) {
-        const u32x4 v = {A[sl[q * 4]], A[sl[q * 4 + 1]], A[sl[q * 4 + 2]], A[sl[q * 4 + 3]]};
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(out + i0));
+        const uint32_t a0 = A[sl[q * 4]], a1 = A[sl[q * 4 + 1]], a2 = A[sl[q * 4 + 2]], a3 = A[sl[q * 4 + 3]];
+        if constexpr (W == 4) __builtin_nontemporal_store(u32x4{a0, a1, a2, a3}, reinterpret_cast<u32x4*>(out + i0));
+        else if constexpr (W == 2) __builtin_nontemporal_store(u32x2{a0 | (a1 << 16), a2 | (a3 << 16)}, reinterpret_cast<u32x2*>(out + i0));
+        else __builtin_nontemporal_store(a0 | (a1 << 8) | (a2 << 16) | (a3 << 24), reinterpret_cast<uint32_t*>(out + i0));
       } else {
         for (int k = 0; k < 4; k++)
-          if (i0 + k < n) out[i0 + k] = A[sl[q * 4 + k]];
+          if (i0 + k < n) out[i0 + k] = (E)A[sl[q * 4 + k]];
       }
     }
     if constexpr (ENT) {  // entries of the Boolean put in natural order (out = the entry array)
@@ -1567,9 +1582,10 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
 }
 
 // vbits_src != nullptr: the source's validity bitmap is gathered with the values into out_validity (agpu_take_validity)
-static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* values, uint64_t n_src, const uint32_t* si, uint32_t* out,
+static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void* values, uint64_t n_src, const uint32_t* si, void* out,
                                          uint64_t n, const uint32_t* vbits_src = nullptr, uint64_t* out_validity = nullptr) {
   if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || !aligned16(si) || !aligned16(out) || p->capturing) return AGPU_ERR_UNSUPPORTED;
+  if (width != 4 && width != 2 && width != 1) return AGPU_ERR_UNSUPPORTED;
   const int rs = bkt_region_bits(p, n_src, 4);
   const uint32_t bs = (uint32_t)((n_src + ((uint64_t)1 << rs) - 1) >> rs);
   if (bs + 1 > BKT_MAX) return AGPU_ERR_UNSUPPORTED;
@@ -1583,7 +1599,7 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* value
   agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
   if (st == AGPU_OK && vbits_src) st = agpu_malloc(dev, ((size_t)gtiles * TK2_GTILE) / 8 + 16, 0, &vslot_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 4 * n + 16, 0, &srcs_v);
-  if (st == AGPU_OK) st = agpu_malloc(dev, 4 * n + 16, 0, &vals_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)width * n + 16, 0, &vals_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 2 * n + 16, 0, &rank_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 2, 0, &cnt_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 4, 0, &off_v);
@@ -1609,19 +1625,30 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, const uint32_t* value
                          ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v));
       const dim3 ggrid((gtiles + 7) / 8 * 8), fgrid((ntiles + 7) / 8 * 8);
       uint64_t* vslot = static_cast<uint64_t*>(vslot_v);
-      if (vbits_src) {
-        hipLaunchKernelGGL((tk2_gather_kernel<8, true>), ggrid, dim3(BKT_T), 0, p->stream, values, n_src, static_cast<const uint32_t*>(srcs_v),
-                           n, gtiles, static_cast<uint32_t*>(vals_v), vbits_src, vslot);
-        hipLaunchKernelGGL((tk2_merge_kernel<1>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles,
-                           static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(vals_v), out,
-                           reinterpret_cast<const uint32_t*>(vslot), out_validity);
-      } else {
-        hipLaunchKernelGGL((tk2_gather_kernel<8, false>), ggrid, dim3(BKT_T), 0, p->stream, values, n_src, static_cast<const uint32_t*>(srcs_v),
-                           n, gtiles, static_cast<uint32_t*>(vals_v), static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr));
-        hipLaunchKernelGGL((tk2_merge_kernel<0>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles,
-                           static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(vals_v), out,
-                           static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr));
+#define TK2_GF(WW, E)                                                                                                                    \
+  case WW:                                                                                                                               \
+    if (vbits_src) {                                                                                                                     \
+      hipLaunchKernelGGL((tk2_gather_kernel<8, true, WW>), ggrid, dim3(BKT_T), 0, p->stream, static_cast<const E*>(values), n_src,        \
+                         static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), vbits_src, vslot);                    \
+      hipLaunchKernelGGL((tk2_merge_kernel<1, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \
+                         static_cast<const uint16_t*>(rank_v), static_cast<const E*>(vals_v), static_cast<E*>(out),                      \
+                         reinterpret_cast<const uint32_t*>(vslot), out_validity, static_cast<const uint32_t*>(nullptr), (uint64_t)0);    \
+    } else {                                                                                                                             \
+      hipLaunchKernelGGL((tk2_gather_kernel<8, false, WW>), ggrid, dim3(BKT_T), 0, p->stream, static_cast<const E*>(values), n_src,       \
+                         static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), static_cast<const uint32_t*>(nullptr), \
+                         static_cast<uint64_t*>(nullptr));                                                                               \
+      hipLaunchKernelGGL((tk2_merge_kernel<0, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \
+                         static_cast<const uint16_t*>(rank_v), static_cast<const E*>(vals_v), static_cast<E*>(out),                      \
+                         static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr), static_cast<const uint32_t*>(nullptr),  \
+                         (uint64_t)0);                                                                                                   \
+    }                                                                                                                                    \
+    break;
+      switch (width) {
+        TK2_GF(4, uint32_t)
+        TK2_GF(2, uint16_t)
+        TK2_GF(1, uint8_t)
       }
+#undef TK2_GF
       if (hipGetLastError() != hipSuccess) {
         agpu_set_error("merge-back take launch failed");
         st = AGPU_ERR_HIP;
@@ -1673,8 +1700,8 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   AGPU_REQUIRE(values && idx && out, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
   if ((width == 1 || width == 2 || width == 4) && n_values != UINT64_MAX && want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
-    if (width == 4 && p->tune.gather_bucket != 3 && n_idx >= TK2_TILE) {  // "gather_bucket" = 3: the pair pipeline, for A/B
-      const agpu_status ms = launch_take_mergeback(p, static_cast<const uint32_t*>(values), n_values, idx, static_cast<uint32_t*>(out), n_idx);
+    if (p->tune.gather_bucket != 3 && n_idx >= TK2_TILE) {  // "gather_bucket" = 3: the pair pipeline, for A/B
+      const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx);
       if (ms != AGPU_ERR_UNSUPPORTED) return ms;
     }
     const agpu_status bs = launch_bucketed(p, width, values, n_values, idx, out, n_idx, nullptr, n_idx);
@@ -1713,9 +1740,9 @@ agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* valu
     AGPU_REQUIRE(values && idx && out, AGPU_ERR_ARG, "null pointer");
     AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
     AGPU_REQUIRE(aligned_to(validity, 4) && aligned_to(out_validity, 8), AGPU_ERR_SHAPE, "bitmap alignment");
-    if (width == 4 && n_values != UINT64_MAX && p->tune.gather_bucket != 3 && n_idx >= TK2_TILE &&
+    if ((width == 4 || width == 2 || width == 1) && n_values != UINT64_MAX && p->tune.gather_bucket != 3 && n_idx >= TK2_TILE &&
         want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
-      const agpu_status ms = launch_take_mergeback(p, static_cast<const uint32_t*>(values), n_values, idx, static_cast<uint32_t*>(out), n_idx,
+      const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx,
                                                    static_cast<const uint32_t*>(validity), static_cast<uint64_t*>(out_validity));
       if (ms != AGPU_ERR_UNSUPPORTED) return ms;
     }

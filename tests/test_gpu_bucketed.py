@@ -444,3 +444,57 @@ def test_put_bits_at_2_27_rows_bucketed_equals_direct(ctx):
     sb, db = np.unpackbits(src, bitorder="little"), np.unpackbits(dst, bitorder="little")
     db[di] = sb[si]
     assert np.array_equal(outs[0], np.packbits(db, bitorder="little"))
+
+
+# ---- round 3: 1- and 2-byte takes through the merge-back pipeline too (with and without the source's validity)
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("width", [1, 2])
+@pytest.mark.parametrize("n,n_values,dist", [(32768, 9, "uniform"), (32769, 70_001, "uniform"), (300_001, 3_000_017, "uniform"), (40_000, 300_000_007, "uniform"),
+                                             (3 * 32768 + 5, 1 << 24, "oob_tile"), (500_000, 1 << 23, "skew"), (1_000_003, 1 << 20, "dups")])
+def test_narrow_takes_through_both_pipelines(ctx, mode, width, n, n_values, dist):
+    import arrow_gpu_amd as ag
+
+    dev, p = ctx
+    p.set_tuning("gather_bucket", mode)
+    try:
+        rng = np.random.default_rng(n * 19 + mode + width)
+        values = rng.integers(0, 1 << (8 * width), n_values, dtype=np.uint64).astype(NPW[width])
+        vbits = np.packbits(rng.random((n_values + 63) // 64 * 64) < 0.7, bitorder="little")
+        idx = rng.integers(0, n_values, n).astype(np.uint32)
+        expect_flag = False
+        if dist == "skew":
+            idx = np.where(rng.random(n) < 0.9, rng.integers(1000, 1064, n), idx).astype(np.uint32)
+        elif dist == "dups":
+            idx = (idx // 4096 * 4096).astype(np.uint32)
+        elif dist == "oob_tile":
+            idx[32768:65536] = rng.integers(n_values, 1 << 32, 32768, dtype=np.uint64).astype(np.uint32)
+            expect_flag = True
+        dv, dvb, di = dev.create_gpu_buffer_with_data(values), dev.create_gpu_buffer_with_data(vbits), dev.create_gpu_buffer_with_data(idx)
+        nb = O.bitmap_bytes(n)
+        ok = idx < n_values
+        exp = np.where(ok, values[np.minimum(idx, n_values - 1)], 0).astype(NPW[width])
+        exp_bits = np.where(ok, np.unpackbits(vbits, bitorder="little")[np.minimum(idx, n_values - 1)], 0).astype(np.uint8)
+        for with_validity in (False, True):
+            out, outv = dev.create_empty_buffer(width * n + 16), dev.create_empty_buffer(nb + 16)
+            capi.call("agpu_memset", p._handle, vp(out), 0xEE, width * n + 16)
+            capi.call("agpu_memset", p._handle, vp(outv), 0xEE, nb + 16)
+            if with_validity:
+                capi.call("agpu_take_validity", p._handle, width, vp(dv), n_values, vp(dvb), vp(di), vp(out), vp(outv), n)
+            else:
+                capi.call("agpu_take", p._handle, width, vp(dv), n_values, vp(di), vp(out), n)
+            if expect_flag:
+                with pytest.raises(ag.ArrowErrorGPU):
+                    p.sync()
+            else:
+                p.sync()
+            got = dev.retrive_data(out, width * n + 16, pipeline=p)
+            assert np.array_equal(got[: width * n].view(NPW[width]), exp)
+            assert (got[width * n:] == 0xEE).all()
+            if with_validity:
+                gotv = dev.retrive_data(outv, nb + 16, pipeline=p)
+                gb = np.unpackbits(gotv[:nb], bitorder="little")
+                assert np.array_equal(gb[:n], exp_bits) and not gb[n:].any() and (gotv[nb:] == 0xEE).all()
+        if not expect_flag:
+            assert np.array_equal(O.take(width, values, idx), exp)
+    finally:
+        p.set_tuning("gather_bucket", 2)

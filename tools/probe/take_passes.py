@@ -47,6 +47,12 @@ for label, mode in ((("take_pairs", 3),) if PUT_ONLY else (("take_direct", 1), (
     ms = med(lambda: capi.call("agpu_take", h, 4, vp(values), n, vp(idx), vp(out), n))
     res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
     print(label, res[label], flush=True)
+for w in (() if PUT_ONLY else (1, 2)):  # narrow values: the same pipelines over the first n bytes / halfwords of the buffers
+    for label, mode in ((f"take_u{8 * w}_direct", 1), (f"take_u{8 * w}_pairs", 3), (f"take_u{8 * w}_mergeback", 2)):
+        p.set_tuning("gather_bucket", mode)
+        ms = med(lambda: capi.call("agpu_take", h, w, vp(values), n, vp(idx), vp(out), n))
+        res[label] = {"ms": round(ms, 4), "G_rows_per_s": round(n / ms / 1e6, 1)}
+        print(label, res[label], flush=True)
 vb, ov = dev.create_empty_buffer(n // 8 + 64), dev.create_empty_buffer(n // 8 + 64)
 capi.call("agpu_synth_bits", h, vp(vb), n, 7, 0, C.c_double(0.9))
 for label, mode in (() if PUT_ONLY else (("take_with_validity_direct (agpu_take + agpu_take_bits)", 1), ("take_with_validity_mergeback (one pipeline)", 2))):
