@@ -1948,7 +1948,8 @@ agpu_status agpu_put_bits_bounded(agpu_pipeline* p, const void* src_bits, uint64
   AGPU_REQUIRE(src_bits && src_idx && dst_bits && dst_idx, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(aligned_to(src_bits, 4) && aligned_to(dst_bits, 4), AGPU_ERR_SHAPE, "bitmap alignment");
   if (n_src_bits != UINT64_MAX && n_dst_bits != UINT64_MAX && n_src_bits > 0 && n_dst_bits > 0 && p->tune.gather_bucket != 1 &&
-      (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 3 || n >= ((uint64_t)1 << 24))) {
+      (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 3 || (n >= ((uint64_t)1 << 24) && n_dst_bits >= ((uint64_t)1 << 22)))) {
+    // (a destination of fewer than 16 regions leaves the apply pass with too few workgroups: the direct kernel keeps those)
     // round 3: bucketed by destination region, no global atomics (auto from 2^24 rows: 0.67 → 0.46 ms there, 10.4 → 3.6 at 2^28)
     const agpu_status bs = launch_put_bits_bucketed(p, static_cast<const uint32_t*>(src_bits), n_src_bits, src_idx, static_cast<uint32_t*>(dst_bits),
                                                     n_dst_bits, dst_idx, n);
