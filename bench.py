@@ -381,6 +381,10 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
                              "--master-port P bench.py --gpus N ...")
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; using {world}", file=sys.stderr)
+    if os.environ.get("AGPU_BENCH_DEVICE_OVERRIDE") is not None:
+        # rehearsal on a 1-GPU box only (tools/r03_bootstrap_rehearsal.sh): every rank names the same GPU, so RCCL's bootstrap between
+        # the processes runs for real and its init then refuses the duplicate device — a clean failure, never a measurement
+        local_rank = int(os.environ["AGPU_BENCH_DEVICE_OVERRIDE"])
     dev = GpuDevice(local_rank)  # ArrowErrorGPU(NoDevice) without an MI355X: the HIP path has no CPU fallback
     p = ArrowComputePipeline(dev, "bench")
     h = p._handle
