@@ -205,6 +205,24 @@ def test_f32_functions_exhaustive_over_all_bit_patterns(D, op, name):
     assert mx.value <= G.MAX_ULP, f"{name}: {mx.value} ULP at bits {worst.value:#010x} (x = {x!r})"
 
 
+def test_f32_trig_exhaustive_against_the_cpu_oracle():
+    """ALL 2^32 bit patterns through agpu_unary against the CPU ORACLE (f64 libm rounded once) — not the device's own f64 library:
+    tests/tools/exhaustive_vs_oracle.py in a fresh process (its oracle workers are forked before that process touches the GPU).
+    sin and cos (BASELINE config 4) by default, ≈ 25 s; AGPU_EXHAUSTIVE=1: all ten functions (profiles/r03_exhaustive_vs_oracle.json)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = [] if os.environ.get("AGPU_EXHAUSTIVE") == "1" else ["sin", "cos"]
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "exhaustive_vs_oracle.py")] + names, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.load(open(os.path.join(root, "gpurun_out", "r03_exhaustive_vs_oracle.json")))["functions"]
+    for name in names or res:
+        assert res[name]["max_ulp"] <= G.MAX_ULP and res[name]["zeros_with_the_other_sign"] == 0, (name, res[name])
+
+
 @pytest.mark.parametrize("domain", [0, 1, 2])
 def test_f32_power_device_selftest_2_pow_32_pairs(D, domain):
     """2^32 pseudo-random operand pairs per domain (any positive x incl. denormals / inf / NaN; x → 1 with |y| up to 2^30;
