@@ -25,7 +25,8 @@ from arrow_gpu_amd import _capi as capi  # noqa: E402
 OPS = {"sin": capi.UN_SIN, "cos": capi.UN_COS, "sinh": capi.UN_SINH, "acos": capi.UN_ACOS, "exp": capi.UN_EXP, "exp2": capi.UN_EXP2,
        "log": capi.UN_LOG, "log2": capi.UN_LOG2, "sqrt": capi.UN_SQRT, "cbrt": capi.UN_CBRT}
 CHUNK = 1 << 28
-_X = _GOT = None  # inherited by the forked workers
+PAIRS = 1 << 26    # pow: pairs per launch
+_X = _GOT = _Y = None  # inherited by the forked workers
 
 
 def _ordered(v):
@@ -36,7 +37,7 @@ def _ordered(v):
 def _check(args):
     op, lo, hi = args
     x, got = _X[lo:hi], _GOT[lo:hi]
-    exp = O.unary(op, O.F32, x)
+    exp = O.binary(O.OP_POW, O.F32, x, _Y[lo:hi]) if op == "pow" else O.unary(op, O.F32, x)
     nan_e, nan_g = np.isnan(exp), np.isnan(got)
     if not np.array_equal(nan_e, nan_g):
         k = int(np.flatnonzero(nan_e != nan_g)[0])
@@ -50,25 +51,75 @@ def _check(args):
 
 
 def main():
-    global _X, _GOT
+    global _X, _GOT, _Y
     from multiprocessing import shared_memory
 
-    names = sys.argv[1:] or list(OPS)
+    names = sys.argv[1:] or list(OPS) + ["pow"]
     workers = int(os.environ.get("AGPU_ORACLE_WORKERS", "16"))
     # the two chunk buffers are shared memory and the workers are forked BEFORE this process touches the GPU: no child ever
     # carries HIP state
     shm_x, shm_g = shared_memory.SharedMemory(create=True, size=4 * CHUNK), shared_memory.SharedMemory(create=True, size=4 * CHUNK)
     _X = np.ndarray(CHUNK, np.float32, buffer=shm_x.buf)
     _GOT = np.ndarray(CHUNK, np.float32, buffer=shm_g.buf)
+    shm_y = shared_memory.SharedMemory(create=True, size=4 * PAIRS)
+    _Y = np.ndarray(PAIRS, np.float32, buffer=shm_y.buf)
     pool = mp.get_context("fork").Pool(workers)
     try:
         return _run(names, workers, pool)
     finally:
         pool.terminate()
-        _X = _GOT = None
-        for m in (shm_x, shm_g):
+        _X = _GOT = _Y = None
+        for m in (shm_x, shm_g, shm_y):
             m.close()
             m.unlink()
+
+
+def _pow(p, pool, workers, din, dout, dev, vp):
+    """pow(x, y) is binary — no exhaustive sweep: 16 launches of 2^26 pseudo-random pairs (2^30 pairs) over four domains against the
+    oracle's f64 pow rounded once."""
+    dy = dev.create_empty_buffer(4 * PAIRS)
+    rng = np.random.default_rng(20250418)
+    t0 = time.time()
+    out = {}
+    for dom in ("any finite or infinite positive base (denormals included), |y| = 2^[-8, 8]", "base -> 1 (1 +- 2^[-24, -1]), |y| = 2^[0, 30]",
+                "results across overflow / underflow (y log2 x in [-160, 140])", "negative bases: integer and non-integer exponents"):
+        worst, worst_xy, differing, zero_sign = 0, (0, 0), 0, 0
+        for rep in range(4):
+            n = PAIRS
+            if dom.startswith("any"):
+                x = rng.integers(0, 0x7F800001, n, dtype=np.uint32).view(np.float32)
+                y = (2.0 ** rng.uniform(-8, 8, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+            elif dom.startswith("base"):
+                x = (1.0 + 2.0 ** rng.uniform(-24, -1, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+                y = (2.0 ** rng.uniform(0, 30, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+            elif dom.startswith("results"):
+                lx = rng.uniform(-126, 127, n)
+                lx = np.where(np.abs(lx) < 1e-3, 1.0, lx)
+                x = (2.0 ** lx).astype(np.float32)
+                y = (rng.uniform(-160, 140, n) / lx).astype(np.float32)
+            else:
+                x = (-(2.0 ** rng.uniform(-20, 20, n))).astype(np.float32)
+                y = np.where(rng.random(n) < 0.7, rng.integers(-40, 41, n).astype(np.float64), rng.uniform(-4, 4, n)).astype(np.float32)
+            _X[:n], _Y[:n] = x, y
+            capi.call("agpu_upload", p._handle, vp(din), C.c_void_p(_X.ctypes.data), 4 * n)
+            capi.call("agpu_upload", p._handle, vp(dy), C.c_void_p(_Y.ctypes.data), 4 * n)
+            capi.call("agpu_binary", p._handle, capi.OP_POW, capi.F32, vp(din), vp(dy), vp(dout), n)
+            capi.call("agpu_download", p._handle, C.c_void_p(_GOT.ctypes.data), vp(dout), 4 * n)
+            p.sync()
+            step = n // (workers * 4)
+            for r in pool.imap_unordered(_check, [("pow", lo, lo + step) for lo in range(0, n, step)]):
+                differing += r[2]
+                zero_sign += r[3] if len(r) > 3 else 0
+                if r[0] > worst:
+                    worst = r[0]
+                    k = int(np.flatnonzero(_X[:n].view(np.uint32) == r[1])[0])
+                    worst_xy = (float(_X[k]), float(_Y[k]))
+        out[dom] = {"pairs": 4 * PAIRS, "max_ulp": worst if worst < (1 << 31) else "NaN mismatch", "worst_x_y": [repr(worst_xy[0]), repr(worst_xy[1])],
+                    "pairs_not_bit_identical": differing, "zeros_with_the_other_sign": zero_sign}
+    out["seconds"] = round(time.time() - t0, 1)
+    out["max_ulp"] = max((d["max_ulp"] if isinstance(d["max_ulp"], int) else 1 << 31) for d in out.values() if isinstance(d, dict))
+    out["zeros_with_the_other_sign"] = sum(d["zeros_with_the_other_sign"] for d in out.values() if isinstance(d, dict))
+    return out
 
 
 def _run(names, workers, pool):
@@ -80,6 +131,10 @@ def _run(names, workers, pool):
     vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
     res = {"what": "all 2^32 f32 bit patterns: agpu_unary on the device vs the CPU oracle (f64 libm rounded once to f32)", "functions": {}}
     for name in names:
+        if name == "pow":
+            res["functions"]["pow"] = _pow(p, pool, workers, din, dout, dev, vp)
+            print("pow", res["functions"]["pow"], flush=True)
+            continue
         op = OPS[name]
         t0 = time.time()
         worst, worst_bits, differing, zero_sign = 0, 0, 0, 0
