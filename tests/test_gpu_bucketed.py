@@ -498,3 +498,56 @@ def test_narrow_takes_through_both_pipelines(ctx, mode, width, n, n_values, dist
             assert np.array_equal(O.take(width, values, idx), exp)
     finally:
         p.set_tuning("gather_bucket", 2)
+
+
+def test_bucketed_pipelines_from_several_threads(ctx):
+    """four host threads, each with its own pipeline, run the forced pipelines (take, take with validity, Boolean take / put, put) over
+    their own columns at the same time: the temporaries come from one pool and go back to it mid-stream — results stay the oracle's"""
+    import threading
+
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline
+
+    dev, _ = ctx
+    errors = []
+
+    def worker(tid):
+        try:
+            p = ArrowComputePipeline(dev, f"bucketed-{tid}")
+            p.set_tuning("gather_bucket", 2)
+            rng = np.random.default_rng(100 + tid)
+            n, n_src, n_dst = 200_003 + 4096 * tid, 1 << 21, (1 << 21) + 12345
+            values = rng.integers(0, 1 << 32, n_src, dtype=np.uint64).astype(np.uint32)
+            vbits = np.packbits(rng.random((n_src + 63) // 64 * 64) < 0.5, bitorder="little")
+            dst = rng.integers(0, 1 << 32, n_dst, dtype=np.uint64).astype(np.uint32)
+            dbits = np.packbits(rng.random((n_dst + 63) // 64 * 64) < 0.5, bitorder="little")
+            si = rng.integers(0, n_src, n).astype(np.uint32)
+            di = rng.permutation(n_dst)[:n].astype(np.uint32)
+            dv, dvb, dsi, ddi = (dev.create_gpu_buffer_with_data(x) for x in (values, vbits, si, di))
+            nb = O.bitmap_bytes(n)
+            exp_take, exp_tbits = values[si], O.take_bits(vbits, n_src, si)
+            exp_put = dst.copy()
+            exp_put[di] = values[si]
+            exp_pbits = O.put_bits(vbits, si, dbits, di)
+            for _ in range(5):
+                out, outv = dev.create_empty_buffer(4 * n + 16), dev.create_empty_buffer(nb + 16)
+                capi.call("agpu_take_validity", p._handle, 4, vp(dv), n_src, vp(dvb), vp(dsi), vp(out), vp(outv), n)
+                ob = dev.create_empty_buffer(nb + 16)
+                capi.call("agpu_take_bits", p._handle, vp(dvb), n_src, vp(dsi), vp(ob), n)
+                dd, ddb = dev.create_gpu_buffer_with_data(dst), dev.create_gpu_buffer_with_data(dbits)
+                capi.call("agpu_put_bounded", p._handle, 4, vp(dv), n_src, vp(dsi), vp(dd), n_dst, vp(ddi), n)
+                capi.call("agpu_put_bits_bounded", p._handle, vp(dvb), n_src, vp(dsi), vp(ddb), n_dst, vp(ddi), n)
+                p.sync()
+                assert np.array_equal(dev.retrive_data(out, 4 * n, pipeline=p).view(np.uint32), exp_take)
+                assert np.array_equal(dev.retrive_data(outv, nb, pipeline=p), exp_tbits)
+                assert np.array_equal(dev.retrive_data(ob, nb, pipeline=p), exp_tbits)
+                assert np.array_equal(dev.retrive_data(dd, 4 * n_dst, pipeline=p).view(np.uint32), exp_put)
+                assert np.array_equal(dev.retrive_data(ddb, len(dbits), pipeline=p), exp_pbits)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
