@@ -375,7 +375,8 @@ def test_pair_pipeline_range_start_variants(ctx, offsets, width):
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("n,n_src,n_dst,dist", [(5, 9, 77, "uniform"), (32768, 70_001, 40_000, "uniform"), (100_003, 1 << 20, (1 << 21) + 5, "uniform"),
                                                 (1_000_003, 40_000_003, 3_000_017, "uniform"), (300_000, 1 << 22, (1 << 18) * 5 + 3, "oob"),
-                                                (500_000, 1 << 23, 1 << 24, "skew"), (200_000, 1 << 20, 1_200_000_007, "uniform")])
+                                                (500_000, 1 << 23, 1 << 24, "skew"), (200_000, 1 << 20, 1_200_000_007, "uniform"),
+                                                (150_000, 1 << 20, 2_147_000_001, "uniform")])  # 64 KiB and 128 KiB regions in LDS
 def test_put_bits_pipelines_equal_the_oracle(ctx, mode, n, n_src, n_dst, dist):
     """[ref: crates/routines/src/bool.rs put + bool/put.wgsl] direct (mode 1: one atomic per row) and bucketed (mode 2) against
     oracle.put_bits with distinct destinations; rows with either index out of range are dropped and raise the sticky flag"""
