@@ -34,8 +34,9 @@ __device__ __forceinline__ V swz_ld(const V* p, bool nt) { return nt ? __builtin
 template <int W, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void take_kernel(const typename ElemOf<W>::type* values, uint64_t n_values,
                                                          const uint32_t* idx, typename ElemOf<W>::type* out, uint64_t n,
-                                                         int vec_ok, uint32_t* flags) {
+                                                         int vec_ok, uint32_t* flags, const uint32_t* only_if = nullptr) {
   typedef typename ElemOf<W>::type E;
+  if (only_if && !*only_if) return;  // launched behind a pipeline whose locality probe decides which of the two does the work
   constexpr int N = 16 / W;  // output elements per lane (one 16-byte store)
   const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(AGPU_BLOCK) void take_kernel(const typename ElemOf<
 
 // out bit i = bits[idx[i]]: lane handles one index per round, ballot = 64 output bits
 __global__ __launch_bounds__(AGPU_BLOCK) void take_bits_kernel(const uint32_t* bits, uint64_t n_bits, const uint32_t* idx,
-                                                              uint64_t* out, uint64_t n, uint32_t* flags) {
+                                                              uint64_t* out, uint64_t n, uint32_t* flags, const uint32_t* only_if = nullptr) {
+  if (only_if && !*only_if) return;
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
   const uint64_t wave_id = ((uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x) / AGPU_WAVE;
   const uint64_t n_waves = (uint64_t)gridDim.x * (AGPU_BLOCK / AGPU_WAVE);
@@ -222,8 +224,69 @@ struct BktCtl {  // device-side control block
   uint32_t base_s[BKT_MAX + 1];  // first pair of every source region (exclusive scan of hist_s)
   uint32_t base_d[BKT_MAX + 1];  // first pair of every destination region in G's output
   uint32_t total;                // rows that reach the gather (take: n; put: rows with both indices in range)
-  uint32_t pad[3];
+  uint32_t use_direct;           // set by idx_locality_kernel: the index columns are local — the pipeline's kernels return at once and
+                                 // the direct kernel launched behind them does the work (no host round trip)
+  uint32_t loc_distinct[2], loc_rows[2], loc_done;
+  uint32_t pad[2];
 };
+#define BKT_GATE(g)                         \
+  do {                                      \
+    if ((g) && (g)->use_direct) return;     \
+  } while (0)
+
+// Locality probe (round 3): the pipelines below win against RANDOM indices — against sorted, sequential, clustered or
+// few-valued ones the direct kernels run at streaming speed (take of 2^27 sorted rows: 0.36 ms direct, 2.0 ms through the
+// pipeline; tools/probe/take_distributions.py), and sorted indices are what a take after a filter gets.  LOC_BLOCKS windows of
+// LOC_ROWS consecutive rows, spread over the column, each count the DISTINCT lines (2^line_shift elements) their rows touch (an
+// LDS hash set); the last block to finish sums up: fewer than one distinct line per two rows ⇒ ctl->use_direct = 1.  The decision
+// stays on the device — the pipeline's kernels are launched either way and return at once when it is set, the direct kernel
+// behind them returns at once when it is not: ≈ 60 µs of empty launches in the worst case, no host round trip, `take_op` still
+// never blocks.  A put probes both of its index columns and goes direct only when both are local.
+#define LOC_BLOCKS 128
+#define LOC_ROWS 2048
+#define LOC_SLOTS 4096
+__global__ __launch_bounds__(256) void idx_locality_kernel(const uint32_t* idx0, const uint32_t* idx1, uint64_t n, int shift0, int shift1, BktCtl* ctl) {
+  __shared__ uint32_t tab[LOC_SLOTS];
+  __shared__ uint32_t cnt;
+  const int which = blockIdx.x >= LOC_BLOCKS ? 1 : 0;
+  const uint32_t* idx = which ? idx1 : idx0;
+  const int shift = which ? shift1 : shift0;
+  const uint32_t b = blockIdx.x % LOC_BLOCKS;
+  for (uint32_t k = threadIdx.x; k < LOC_SLOTS; k += 256) tab[k] = 0xFFFFFFFFu;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const uint64_t start = n > LOC_ROWS ? (uint64_t)b * (n - LOC_ROWS) / (LOC_BLOCKS - 1) : 0;
+  const uint32_t rows = (uint32_t)(n - start < LOC_ROWS ? n - start : LOC_ROWS);
+  uint32_t mine = 0;
+  for (uint32_t j = threadIdx.x; j < rows; j += 256) {
+    const uint32_t key = idx[start + j] >> shift;  // < 2^27: never the empty marker
+    uint32_t h = (key * 2654435761u) >> 20;
+    for (;;) {
+      const uint32_t old = atomicCAS(&tab[h], 0xFFFFFFFFu, key);
+      if (old == 0xFFFFFFFFu) {
+        mine++;
+        break;
+      }
+      if (old == key) break;
+      h = (h + 1) & (LOC_SLOTS - 1);
+    }
+  }
+  if (mine) atomicAdd(&cnt, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&ctl->loc_distinct[which], cnt);
+    atomicAdd(&ctl->loc_rows[which], rows);
+    __threadfence();
+    if (atomicAdd(&ctl->loc_done, 1u) == gridDim.x - 1) {  // the last block: every total above is visible
+      bool local = true;
+      for (int w = 0; w < (idx1 ? 2 : 1); w++) {
+        const uint32_t d = atomicAdd(&ctl->loc_distinct[w], 0u), r = atomicAdd(&ctl->loc_rows[w], 0u);
+        local = local && (uint64_t)d * 2 < r;
+      }
+      ctl->use_direct = local ? 1u : 0u;
+    }
+  }
+}
 
 // H.  take: di == nullptr (destination = the row number itself).  Source side: the count of every (tile, region) pair
 // goes to `counts` (u16, row stride nbp) — the partition pass gets its range starts from a column scan over these
@@ -293,7 +356,8 @@ __global__ __launch_bounds__(BKT_T) void bkt_hist_kernel(const uint32_t* si, con
 // chunk sums over BKT_CHUNK tiles → per-region exclusive scan over chunks (+ region totals) → [bkt_scan_kernel turns the
 // totals into region bases] → per-tile range starts.
 #define BKT_CHUNK 128
-__global__ __launch_bounds__(256) void bkt_colsum_kernel(const uint16_t* counts, uint32_t nbp, uint32_t ntiles, uint32_t* csum) {
+__global__ __launch_bounds__(256) void bkt_colsum_kernel(const uint16_t* counts, uint32_t nbp, uint32_t ntiles, uint32_t* csum, const BktCtl* gate = nullptr) {
+  BKT_GATE(gate);
   const uint32_t b = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
   if (b >= nbp) return;
   const uint32_t t0 = c * BKT_CHUNK, t1 = t0 + BKT_CHUNK < ntiles ? t0 + BKT_CHUNK : ntiles;
@@ -301,7 +365,8 @@ __global__ __launch_bounds__(256) void bkt_colsum_kernel(const uint16_t* counts,
   for (uint32_t t = t0; t < t1; t++) acc += counts[(uint64_t)t * nbp + b];
   csum[(uint64_t)c * nbp + b] = acc;
 }
-__global__ __launch_bounds__(256) void bkt_colscan_kernel(uint32_t* csum, uint32_t nbp, uint32_t nchunks, uint32_t* totals) {
+__global__ __launch_bounds__(256) void bkt_colscan_kernel(uint32_t* csum, uint32_t nbp, uint32_t nchunks, uint32_t* totals, const BktCtl* gate = nullptr) {
+  BKT_GATE(gate);
   const uint32_t b = blockIdx.x * 256 + threadIdx.x;
   if (b >= nbp) return;
   uint32_t run = 0;
@@ -313,7 +378,8 @@ __global__ __launch_bounds__(256) void bkt_colscan_kernel(uint32_t* csum, uint32
   if (totals && b <= BKT_MAX) totals[b] = run;
 }
 __global__ __launch_bounds__(256) void bkt_offsets_kernel(const uint16_t* counts, const uint32_t* csum, uint32_t nbp,
-                                                         uint32_t ntiles, const uint32_t* base, uint32_t* offsets) {
+                                                         uint32_t ntiles, const uint32_t* base, uint32_t* offsets, const BktCtl* gate = nullptr) {
+  BKT_GATE(gate);
   const uint32_t b = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
   if (b >= nbp) return;
   const uint32_t t0 = c * BKT_CHUNK, t1 = t0 + BKT_CHUNK < ntiles ? t0 + BKT_CHUNK : ntiles;
@@ -327,6 +393,7 @@ __global__ __launch_bounds__(256) void bkt_offsets_kernel(const uint16_t* counts
 // exclusive scans → range start of every bucket; one workgroup
 __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t bs, uint32_t bd, int rd, int is_put,
                                                         uint32_t stride_s, uint32_t stride_d) {
+  if (ctl->use_direct) return;
   __shared__ uint32_t sh[BKT_MAX + 2];
   __shared__ uint32_t wtot[BKT_T / AGPU_WAVE];
   {  // exclusive scan of hist_s[0 .. bs]: thread t owns entries 4t .. 4t+3, the last entry (bs == BKT_MAX) is thread 0's extra
@@ -837,6 +904,10 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
 // 64 bytes), and nothing is nondeterministic but the ranks, which are recorded.  Out-of-range indices: their own bucket,
 // value 0, sticky flag (as above).  1- / 2-byte values: the same kernels (template parameter W).  put (whose destinations are data)
 // keeps the pair pipeline.
+static agpu_status launch_take_direct(agpu_pipeline* p, int width, const void* values, uint64_t n_values, const uint32_t* idx, void* out,
+                                      uint64_t n_idx, const uint32_t* only_if);
+static agpu_status launch_take_bits_direct(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits, uint64_t n_idx,
+                                           const uint32_t* only_if);
 #define TK2_E 32
 #define TK2_TILE (BKT_T * TK2_E)  // 32 Ki rows: P2 / F2 tiles
 #define TK2_GE 16
@@ -877,7 +948,8 @@ __device__ __forceinline__ void tk2_scan4(uint32_t* lcnt, uint32_t* wave_tot, ui
 
 // H2: counts[t][b] for 32 Ki-row tiles; sets the sticky flag for out-of-range indices
 __global__ __launch_bounds__(BKT_T) void tk2_hist_kernel(const uint32_t* si, uint64_t n, uint64_t n_src, int rs, uint32_t bs,
-                                                        uint32_t* flags, uint16_t* counts, uint32_t nbp, uint32_t ntiles) {
+                                                        uint32_t* flags, uint16_t* counts, uint32_t nbp, uint32_t ntiles, const BktCtl* gate = nullptr) {
+  BKT_GATE(gate);
   __shared__ uint32_t ls[BKT_MAX];
   bool bad = false;
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -918,7 +990,8 @@ __global__ __launch_bounds__(BKT_T) void tk2_hist_kernel(const uint32_t* si, uin
 // P2: one 32 Ki-row tile per workgroup
 __global__ __launch_bounds__(BKT_T) void tk2_partition_kernel(const uint32_t* si, uint64_t n, uint64_t n_src, int rs, uint32_t bs,
                                                              const uint32_t* offsets, uint32_t nbp, uint32_t ntiles, uint32_t* srcs,
-                                                             uint16_t* rank16) {
+                                                             uint16_t* rank16, const BktCtl* gate = nullptr) {
+  BKT_GATE(gate);
   __shared__ uint32_t sorted[TK2_TILE];
   __shared__ uint32_t lcnt[BKT_MAX];
   __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
@@ -1006,7 +1079,8 @@ __global__ __launch_bounds__(BKT_T) void tk2_partition_kernel(const uint32_t* si
 template <int WPE, bool BITS, int W = 4>
 __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename ElemOf<W>::type* values, uint64_t n_src, const uint32_t* srcs,
                                                                uint64_t total, uint32_t ntiles, typename ElemOf<W>::type* vals,
-                                                               const uint32_t* vbits_src, uint64_t* vbits_slot) {
+                                                               const uint32_t* vbits_src, uint64_t* vbits_slot, const BktCtl* gate = nullptr) {
+  BKT_GATE(gate);
   typedef typename ElemOf<W>::type E;
   // 64 KiB + 8 KiB of LDS and ≤ 64 VGPRs: TWO workgroups per CU, so that one's loads and gathers run under the other's LDS
   // phases.  To stay inside 64 registers the tile's sources are loaded twice (the second time from L2) instead of being
@@ -1216,7 +1290,8 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
                                                          const uint16_t* counts, const uint32_t* offsets, uint32_t nbp,
                                                          uint32_t ntiles, const uint16_t* rank16, const typename ElemOf<W>::type* vals,
                                                          typename ElemOf<W>::type* out, const uint32_t* vbits_slot, uint64_t* out_validity,
-                                                         const uint32_t* di = nullptr, uint64_t n_dst = 0) {
+                                                         const uint32_t* di = nullptr, uint64_t n_dst = 0, const BktCtl* gate = nullptr) {
+  BKT_GATE(gate);
   typedef typename ElemOf<W>::type E;
   static_assert(MODE < 3 || W == 4, "the entry array is 4 bytes wide");
   __shared__ uint32_t A[TK2_TILE];
@@ -1410,7 +1485,8 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
 // the tile's slot-ordered bit array — there is no value array at all — and leaves as vbits_slot like above.
 #define TK2B_REL_BITS 13
 __global__ __launch_bounds__(BKT_T, 8) void tk2_gather_bits_kernel(const uint32_t* bits, uint64_t n_bits, const uint32_t* srcs, uint64_t total,
-                                                                  uint32_t ntiles, uint64_t* vbits_slot) {
+                                                                  uint32_t ntiles, uint64_t* vbits_slot, const BktCtl* gate = nullptr) {
+  BKT_GATE(gate);
   __shared__ uint32_t sorted[TK2_GTILE];
   __shared__ uint32_t lcnt[1 << (TK2B_REL_BITS - 5)];  // 256 line keys
   __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
@@ -1553,7 +1629,7 @@ __global__ __launch_bounds__(BKT_T, 8) void tk2_gather_bits_kernel(const uint32_
 // Boolean take through the merge-back pipeline; AGPU_ERR_UNSUPPORTED when the shape does not qualify
 // ent_out != nullptr (the Boolean put): the gathered bits leave as entries dst_idx[i] * 2 + bit instead of a bitmap
 static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* bits, uint64_t n_bits, const uint32_t* si, uint64_t* out_bits,
-                                              uint64_t n, const uint32_t* di = nullptr, uint64_t n_dst = 0, uint32_t* ent_out = nullptr) {
+                                              uint64_t n, const uint32_t* di = nullptr, uint64_t n_dst = 0, uint32_t* ent_out = nullptr, bool adaptive = false) {
   if (n >= 0xFFFF0000ull || n_bits > 0xFFFFFFFFull || !aligned16(si) || p->capturing) return AGPU_ERR_UNSUPPORTED;
   const uint64_t n_words = (n_bits + 31) / 32;
   int rsw = 12;  // 2^12 words = 16 KiB of bitmap per region: two regions span < 2^13 words (the entry's 13 bits)
@@ -1585,15 +1661,18 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
       st = AGPU_ERR_HIP;
     } else {
       const dim3 cgrid((nbp + 255) / 256, nchunks);
-      hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, p->flags, counts, nbp, ntiles);
-      hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
-      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s);
+      const BktCtl* gate = adaptive ? ctl : nullptr;  // see launch_take_mergeback
+      if (adaptive)
+        hipLaunchKernelGGL(idx_locality_kernel, dim3(LOC_BLOCKS), dim3(256), 0, p->stream, si, static_cast<const uint32_t*>(nullptr), n, 10, 0, ctl);
+      hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, p->flags, counts, nbp, ntiles, gate);
+      hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum, gate);
+      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s, gate);
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 0, 0, 1u, 1u);
-      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets);
+      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets, gate);
       hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, offsets, nbp,
-                         ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v));
+                         ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v), gate);
       hipLaunchKernelGGL(tk2_gather_bits_kernel, dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, bits, n_bits,
-                         static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint64_t*>(vslot_v));
+                         static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint64_t*>(vslot_v), gate);
       if (ent_out)
         hipLaunchKernelGGL((tk2_merge_kernel<3>), dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, counts, offsets,
                            nbp, ntiles, static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(nullptr), ent_out,
@@ -1602,7 +1681,8 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
         hipLaunchKernelGGL((tk2_merge_kernel<2>), dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, counts, offsets,
                            nbp, ntiles, static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(nullptr),
                            static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(vslot_v), out_bits, static_cast<const uint32_t*>(nullptr),
-                           (uint64_t)0);
+                           (uint64_t)0, gate);
+      if (adaptive && !ent_out) (void)launch_take_bits_direct(p, bits, n_bits, si, out_bits, n, &ctl->use_direct);
       if (hipGetLastError() != hipSuccess) {
         agpu_set_error("merge-back take_bits launch failed");
         st = AGPU_ERR_HIP;
@@ -1616,7 +1696,7 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
 
 // vbits_src != nullptr: the source's validity bitmap is gathered with the values into out_validity (agpu_take_validity)
 static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void* values, uint64_t n_src, const uint32_t* si, void* out,
-                                         uint64_t n, const uint32_t* vbits_src = nullptr, uint64_t* out_validity = nullptr) {
+                                         uint64_t n, const uint32_t* vbits_src = nullptr, uint64_t* out_validity = nullptr, bool adaptive = false) {
   if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || !aligned16(si) || !aligned16(out) || p->capturing) return AGPU_ERR_UNSUPPORTED;
   if (width != 4 && width != 2 && width != 1) return AGPU_ERR_UNSUPPORTED;
   const int rs = bkt_region_bits(p, n_src, 4);
@@ -1649,31 +1729,37 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
       st = AGPU_ERR_HIP;
     } else {
       const dim3 cgrid((nbp + 255) / 256, nchunks);
-      hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, p->flags, counts, nbp, ntiles);
-      hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
-      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s);
+      // adaptive (the auto policy): the locality probe decides on the device whether these kernels or the direct one behind them run
+      const BktCtl* gate = adaptive ? ctl : nullptr;
+      if (adaptive)
+        hipLaunchKernelGGL(idx_locality_kernel, dim3(LOC_BLOCKS), dim3(256), 0, p->stream, si, static_cast<const uint32_t*>(nullptr), n,
+                           width == 4 ? 5 : width == 2 ? 6 : 7, 0, ctl);
+      hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, p->flags, counts, nbp, ntiles, gate);
+      hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum, gate);
+      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s, gate);
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 0, 0, 1u, 1u);
-      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets);
+      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets, gate);
       hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, offsets, nbp,
-                         ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v));
+                         ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v), gate);
       const dim3 ggrid((gtiles + 7) / 8 * 8), fgrid((ntiles + 7) / 8 * 8);
       uint64_t* vslot = static_cast<uint64_t*>(vslot_v);
 #define TK2_GF(WW, E)                                                                                                                    \
   case WW:                                                                                                                               \
     if (vbits_src) {                                                                                                                     \
       hipLaunchKernelGGL((tk2_gather_kernel<8, true, WW>), ggrid, dim3(BKT_T), 0, p->stream, static_cast<const E*>(values), n_src,        \
-                         static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), vbits_src, vslot);                    \
+                         static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), vbits_src, vslot, gate);              \
       hipLaunchKernelGGL((tk2_merge_kernel<1, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \
                          static_cast<const uint16_t*>(rank_v), static_cast<const E*>(vals_v), static_cast<E*>(out),                      \
-                         reinterpret_cast<const uint32_t*>(vslot), out_validity, static_cast<const uint32_t*>(nullptr), (uint64_t)0);    \
+                         reinterpret_cast<const uint32_t*>(vslot), out_validity, static_cast<const uint32_t*>(nullptr), (uint64_t)0,     \
+                         gate);                                                                                                          \
     } else {                                                                                                                             \
       hipLaunchKernelGGL((tk2_gather_kernel<8, false, WW>), ggrid, dim3(BKT_T), 0, p->stream, static_cast<const E*>(values), n_src,       \
                          static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), static_cast<const uint32_t*>(nullptr), \
-                         static_cast<uint64_t*>(nullptr));                                                                               \
+                         static_cast<uint64_t*>(nullptr), gate);                                                                         \
       hipLaunchKernelGGL((tk2_merge_kernel<0, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \
                          static_cast<const uint16_t*>(rank_v), static_cast<const E*>(vals_v), static_cast<E*>(out),                      \
                          static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr), static_cast<const uint32_t*>(nullptr),  \
-                         (uint64_t)0);                                                                                                   \
+                         (uint64_t)0, gate);                                                                                             \
     }                                                                                                                                    \
     break;
       switch (width) {
@@ -1682,6 +1768,10 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
         TK2_GF(1, uint8_t)
       }
 #undef TK2_GF
+      if (adaptive) {  // … and the direct form, which returns at once unless the probe chose it
+        (void)launch_take_direct(p, width, values, n_src, si, out, n, &ctl->use_direct);
+        if (vbits_src) (void)launch_take_bits_direct(p, vbits_src, n_src, si, out_validity, n, &ctl->use_direct);
+      }
       if (hipGetLastError() != hipSuccess) {
         agpu_set_error("merge-back take launch failed");
         st = AGPU_ERR_HIP;
@@ -1718,6 +1808,47 @@ static int gs_grid(const agpu_pipeline* p, uint64_t items) {
   return stream_grid_for(p, (items + AGPU_BLOCK - 1) / AGPU_BLOCK);
 }
 
+// the direct gather; only_if != nullptr: launched behind a pipeline, does the work only when the locality probe said so
+static agpu_status launch_take_direct(agpu_pipeline* p, int width, const void* values, uint64_t n_values, const uint32_t* idx, void* out,
+                                      uint64_t n_idx, const uint32_t* only_if) {
+  const int vec_ok = aligned16(idx) && aligned16(out);
+  int grid = gs_grid(p, n_idx / (16 / (width > 0 ? width : 1)) + 1);
+  // behind a pipeline: a grid-stride launch of 128 blocks per CU — when the probe chose the pipeline, the blocks that return at once
+  // are few (131 072 empty blocks cost 50 µs at 2^27 rows), when it chose this kernel the grid still covers the chip many times
+  // (32 per CU: 0.36 → 0.50 ms on sorted indices)
+  if (only_if && grid > p->dev->num_cus * 128) grid = p->dev->num_cus * 128;
+  switch (width) {
+    case 4:
+      hipLaunchKernelGGL((swz_nt() ? take_kernel<4, true> : take_kernel<4, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(values),
+                         n_values, idx, static_cast<uint32_t*>(out), n_idx, vec_ok, p->flags, only_if);
+      break;
+    case 2:
+      hipLaunchKernelGGL((swz_nt() ? take_kernel<2, true> : take_kernel<2, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(values),
+                         n_values, idx, static_cast<uint16_t*>(out), n_idx, vec_ok, p->flags, only_if);
+      break;
+    case 1:
+      hipLaunchKernelGGL((swz_nt() ? take_kernel<1, true> : take_kernel<1, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(values),
+                         n_values, idx, static_cast<uint8_t*>(out), n_idx, vec_ok, p->flags, only_if);
+      break;
+    default:
+      agpu_set_error("take: width %d not supported (1, 2, 4)", width);
+      return AGPU_ERR_UNSUPPORTED;
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+static agpu_status launch_take_bits_direct(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits, uint64_t n_idx,
+                                           const uint32_t* only_if) {
+  const uint64_t nwords = (n_idx + 63) / 64;
+  int grid = stream_grid_for(p, (nwords + 3) / 4);
+  if (only_if && grid > p->dev->num_cus * 32) grid = p->dev->num_cus * 32;  // see launch_take_direct
+  hipLaunchKernelGGL(take_bits_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(bits), n_bits, idx,
+                     static_cast<uint64_t*>(out_bits), n_idx, p->flags, only_if);
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
+
 #ifdef BKT_PROFILE
 extern "C" int agpu_debug_bkt_stamps(unsigned long long* out64) {  // 4 x 16 stamps
   return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_bkt_stamps), sizeof(unsigned long long) * 64, 0, hipMemcpyDeviceToHost);
@@ -1734,33 +1865,13 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
   if ((width == 1 || width == 2 || width == 4) && n_values != UINT64_MAX && want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
     if (p->tune.gather_bucket != 3 && n_idx >= TK2_TILE) {  // "gather_bucket" = 3: the pair pipeline, for A/B
-      const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx);
+      const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx, nullptr, nullptr, p->tune.gather_bucket == 0);
       if (ms != AGPU_ERR_UNSUPPORTED) return ms;
     }
     const agpu_status bs = launch_bucketed(p, width, values, n_values, idx, out, n_idx, nullptr, n_idx);
     if (bs != AGPU_ERR_UNSUPPORTED) return bs;
   }
-  const int vec_ok = aligned16(idx) && aligned16(out);
-  const int grid = gs_grid(p, n_idx / (16 / (width > 0 ? width : 1)) + 1);
-  switch (width) {
-    case 4:
-      hipLaunchKernelGGL((swz_nt() ? take_kernel<4, true> : take_kernel<4, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(values),
-                         n_values, idx, static_cast<uint32_t*>(out), n_idx, vec_ok, p->flags);
-      break;
-    case 2:
-      hipLaunchKernelGGL((swz_nt() ? take_kernel<2, true> : take_kernel<2, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint16_t*>(values),
-                         n_values, idx, static_cast<uint16_t*>(out), n_idx, vec_ok, p->flags);
-      break;
-    case 1:
-      hipLaunchKernelGGL((swz_nt() ? take_kernel<1, true> : take_kernel<1, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint8_t*>(values),
-                         n_values, idx, static_cast<uint8_t*>(out), n_idx, vec_ok, p->flags);
-      break;
-    default:
-      agpu_set_error("take: width %d not supported (1, 2, 4)", width);
-      return AGPU_ERR_UNSUPPORTED;
-  }
-  AGPU_LAUNCH_CHECK();
-  return AGPU_OK;
+  return launch_take_direct(p, width, values, n_values, idx, out, n_idx, nullptr);
 }
 
 agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const void* validity,
@@ -1776,7 +1887,8 @@ agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* valu
     if ((width == 4 || width == 2 || width == 1) && n_values != UINT64_MAX && p->tune.gather_bucket != 3 && n_idx >= TK2_TILE &&
         want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
       const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx,
-                                                   static_cast<const uint32_t*>(validity), static_cast<uint64_t*>(out_validity));
+                                                   static_cast<const uint32_t*>(validity), static_cast<uint64_t*>(out_validity),
+                                                   p->tune.gather_bucket == 0);
       if (ms != AGPU_ERR_UNSUPPORTED) return ms;
     }
   }
@@ -1793,15 +1905,11 @@ static agpu_status take_bits_impl(agpu_pipeline* p, const void* bits, uint64_t n
   if (n_bits != UINT64_MAX && n_idx >= TK2_TILE && p->tune.gather_bucket != 1 && p->tune.gather_bucket != 3 &&
       (p->tune.gather_bucket == 2 || (n_idx >= ((uint64_t)1 << 25) && n_bits >= ((uint64_t)1 << 27) && n_bits / 8 <= n_idx))) {
     // round 3: the merge-back pipeline with the bitmap's words as the elements (auto: ≥ 2^25 rows from a bitmap of ≥ 16 MiB)
-    const agpu_status ms = launch_take_bits_mergeback(p, static_cast<const uint32_t*>(bits), n_bits, idx, static_cast<uint64_t*>(out_bits), n_idx);
+    const agpu_status ms = launch_take_bits_mergeback(p, static_cast<const uint32_t*>(bits), n_bits, idx, static_cast<uint64_t*>(out_bits), n_idx,
+                                                      nullptr, 0, nullptr, p->tune.gather_bucket == 0);
     if (ms != AGPU_ERR_UNSUPPORTED) return ms;
   }
-  const uint64_t nwords = (n_idx + 63) / 64;
-  const int grid = stream_grid_for(p, (nwords + 3) / 4);
-  hipLaunchKernelGGL(take_bits_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, static_cast<const uint32_t*>(bits),
-                     n_bits, idx, static_cast<uint64_t*>(out_bits), n_idx, p->flags);
-  AGPU_LAUNCH_CHECK();
-  return AGPU_OK;
+  return launch_take_bits_direct(p, bits, n_bits, idx, out_bits, n_idx, nullptr);
 }
 
 agpu_status agpu_take_bits(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits,

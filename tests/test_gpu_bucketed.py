@@ -552,3 +552,40 @@ def test_bucketed_pipelines_from_several_threads(ctx):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+# ---- round 3: the auto policy decides on the DEVICE (locality probe) between the pipeline and the direct kernel
+@pytest.mark.parametrize("dist", ["uniform", "sorted", "hot_window", "half_sorted_half_random"])
+def test_auto_policy_is_right_either_way(ctx, dist):
+    """2^25 rows under the auto policy: whichever form the probe picks (random indices → the pipeline's kernels run and the direct
+    kernel behind them returns at once; sorted / clustered → the other way round), values, validity and Boolean takes equal numpy's"""
+    dev, p = ctx
+    n, n_src = 1 << 25, 1 << 27
+    rng = np.random.default_rng(31)
+    values = rng.integers(0, 1 << 32, n_src, dtype=np.uint64).astype(np.uint32)
+    vbits = rng.integers(0, 256, n_src // 8, dtype=np.uint8)
+    if dist == "uniform":
+        idx = rng.integers(0, n_src, n, dtype=np.uint32)
+    elif dist == "sorted":
+        idx = np.sort(rng.integers(0, n_src, n, dtype=np.uint32))
+    elif dist == "hot_window":
+        idx = np.where(rng.random(n) < 0.9, rng.integers(5000, 5064, n), rng.integers(0, n_src, n)).astype(np.uint32)
+    else:
+        idx = np.concatenate([np.sort(rng.integers(0, n_src, n // 2, dtype=np.uint32)), rng.integers(0, n_src, n // 2, dtype=np.uint32)])
+    dv, dvb, di = dev.create_gpu_buffer_with_data(values), dev.create_gpu_buffer_with_data(vbits), dev.create_gpu_buffer_with_data(idx)
+    src_bits = np.unpackbits(vbits, bitorder="little")
+    exp, exp_bits = values[idx], np.packbits(src_bits[idx], bitorder="little")
+    try:
+        p.set_tuning("gather_bucket", 0)
+        out, outv, ob = dev.create_empty_buffer(4 * n), dev.create_empty_buffer(n // 8), dev.create_empty_buffer(n // 8)
+        capi.call("agpu_take_validity", p._handle, 4, vp(dv), n_src, vp(dvb), vp(di), vp(out), vp(outv), n)
+        capi.call("agpu_take_bits", p._handle, vp(dvb), n_src, vp(di), vp(ob), n)
+        out2 = dev.create_empty_buffer(4 * n)
+        capi.call("agpu_take", p._handle, 4, vp(dv), n_src, vp(di), vp(out2), n)
+        p.sync()
+        assert np.array_equal(dev.retrive_data(out, 4 * n, pipeline=p).view(np.uint32), exp)
+        assert np.array_equal(dev.retrive_data(out2, 4 * n, pipeline=p).view(np.uint32), exp)
+        assert np.array_equal(dev.retrive_data(outv, n // 8, pipeline=p), exp_bits)
+        assert np.array_equal(dev.retrive_data(ob, n // 8, pipeline=p), exp_bits)
+    finally:
+        p.set_tuning("gather_bucket", 2)
