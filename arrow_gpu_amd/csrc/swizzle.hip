@@ -98,7 +98,8 @@ template <int W, bool NT>
 __global__ __launch_bounds__(AGPU_BLOCK) void put_kernel(const typename ElemOf<W>::type* src, uint64_t n_src,
                                                         const uint32_t* src_idx, typename ElemOf<W>::type* dst,
                                                         uint64_t n_dst, const uint32_t* dst_idx, uint64_t n, int vec_ok,
-                                                        uint32_t* flags) {
+                                                        uint32_t* flags, const uint32_t* only_if) {
+  if (only_if && !*only_if) return;  // behind the bucketed pipeline: see take_kernel
   const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
   const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
   const uint64_t npacks = vec_ok ? n / 4 : 0;
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(BKT_T) void bkt_hist_kernel(const uint32_t* si, con
                                                         uint64_t n_dst, int rs, int rd, uint32_t bs, uint32_t bd,
                                                         BktCtl* ctl, uint32_t* flags, uint16_t* counts, uint32_t nbp,
                                                         uint32_t ntiles) {
+  if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
   __shared__ uint32_t ls[BKT_MAX + 1], ld[BKT_MAX + 1];
   for (uint32_t b = threadIdx.x; b <= BKT_MAX; b += BKT_T) ld[b] = 0;
   bool bad = false;
@@ -607,6 +609,7 @@ __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si
                                                              uint64_t n_src, uint64_t n_dst, int rs, uint32_t bs,
                                                              BktCtl* ctl, u32x2* pairs, const uint32_t* offsets, uint32_t nbp,
                                                              uint32_t cur_stride, uint32_t ntiles) {
+  if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
   BKT_LDS_DECL;
   BKT_STAMP(0, 0);
   // XCD-contiguous tiles (round 3): with range starts from the column scan, the runs of tiles t and t + 1 are neighbours in
@@ -674,6 +677,7 @@ __device__ __forceinline__ void bkt_load_tile(const u32x2* pairs_in, uint64_t ba
 // runs placed by a scan are tile-adjacent, so their 64-byte halves merge in the XCD's L2 like P's do.  8 B/row read.
 __global__ __launch_bounds__(BKT_T) void bkt_count_dst_kernel(const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles, const BktCtl* ctl,
                                                              uint16_t* counts2, uint32_t nbp2) {
+  if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
   __shared__ uint32_t ld[BKT_MAX];
   uint64_t tile;
   if (!bkt_tile_of_block(ntiles, &tile)) return;
@@ -704,6 +708,7 @@ __global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf
                                                           const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles,
                                                           int src_line_shift, BktCtl* ctl, u32x2* pairs_out, uint32_t cur_stride,
                                                           const uint32_t* offsets2, uint32_t nbp2) {
+  if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
   BKT_LDS_DECL;
   uint64_t tile;
   if (!bkt_tile_of_block(ntiles, &tile)) return;
@@ -745,6 +750,7 @@ __global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf
 template <int W>
 __global__ __launch_bounds__(BKT_T) void bkt_store_kernel(const u32x2* pairs, uint32_t ntiles, const BktCtl* ctl, int line_shift,
                                                          typename ElemOf<W>::type* dst) {
+  if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
   typedef typename ElemOf<W>::type E;
   BKT_LDS_DECL;
   uint64_t tile;
@@ -781,9 +787,11 @@ static int bkt_region_bits(const agpu_pipeline* p, uint64_t n_elems, int width) 
   return r;
 }
 
+static agpu_status launch_put_direct(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* src_idx, void* dst,
+                                     uint64_t n_dst, const uint32_t* dst_idx, uint64_t n, const uint32_t* only_if);
 // di == nullptr: take (dst = out, n_dst = n).  Returns AGPU_ERR_UNSUPPORTED when the shape does not qualify.
 static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* si,
-                                   void* dst, uint64_t n_dst, const uint32_t* di, uint64_t n) {
+                                   void* dst, uint64_t n_dst, const uint32_t* di, uint64_t n, bool adaptive = false) {
   if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || n_dst > 0xFFFFFFFFull || !aligned16(si) || (di && !aligned16(di)) ||
       p->capturing)
     return AGPU_ERR_UNSUPPORTED;
@@ -837,24 +845,33 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       uint32_t* offsets = static_cast<uint32_t*>(off_v);
       uint32_t* csum = static_cast<uint32_t*>(csum_v);
       const dim3 cgrid((nbp + 255) / 256, nchunks);
+      // adaptive (put under the auto policy): BOTH index columns local ⇒ the direct scatter launched behind the pipeline does the work
+      // (tools/probe/put_distributions.py: sorted → sorted 2.1 ms bucketed, 1.2 direct; sequential → sequential 1.8 vs 0.23; with either
+      // side random the pipeline wins)
+      adaptive = adaptive && di;
+      const BktCtl* gate = adaptive ? ctl : nullptr;
+      if (adaptive) {
+        const int sh = width == 4 ? 5 : width == 2 ? 6 : 7;
+        hipLaunchKernelGGL(idx_locality_kernel, dim3(2 * LOC_BLOCKS), dim3(256), 0, p->stream, si, di, n, sh, sh, ctl);
+      }
       hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags, counts, nbp, ntiles);
       if (det) {
-        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
-        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s);
+        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum, gate);
+        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s, gate);
       }
       // one cursor per 128-byte line while the regions are few (the atomics spread over the L2 channels: −10…15 % per
       // call at ≤ 1024 regions, same-box A/B), packed cursors beyond (a 256 KiB cursor array costs more than it spreads)
       const uint32_t stride_s = bs + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 1;
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0, stride_s, stride_d);
-      if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets);
+      if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets, gate);
       hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),
                          det ? offsets : static_cast<uint32_t*>(nullptr), nbp, stride_s, ntiles);
       if (det2) {  // C + the column scan again, over the blocks P has just finished with
         const dim3 cgrid2((nbp2 + 255) / 256, nchunks);
         hipLaunchKernelGGL(bkt_count_dst_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), rd, bd, ntiles, ctl, counts, nbp2);
-        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid2, dim3(256), 0, p->stream, counts, nbp2, ntiles, csum);
-        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp2 + 255) / 256), dim3(256), 0, p->stream, csum, nbp2, nchunks, static_cast<uint32_t*>(nullptr));
-        hipLaunchKernelGGL(bkt_offsets_kernel, cgrid2, dim3(256), 0, p->stream, counts, csum, nbp2, ntiles, ctl->base_d, offsets);
+        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid2, dim3(256), 0, p->stream, counts, nbp2, ntiles, csum, gate);
+        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp2 + 255) / 256), dim3(256), 0, p->stream, csum, nbp2, nchunks, static_cast<uint32_t*>(nullptr), gate);
+        hipLaunchKernelGGL(bkt_offsets_kernel, cgrid2, dim3(256), 0, p->stream, counts, csum, nbp2, ntiles, ctl->base_d, offsets, gate);
       }
 #define BKT_GF(W, E)                                                                                                         \
   case W:                                                                                                                    \
@@ -871,6 +888,7 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
         default: st = AGPU_ERR_UNSUPPORTED; break;
       }
 #undef BKT_GF
+      if (st == AGPU_OK && adaptive) (void)launch_put_direct(p, width, src, n_src, si, dst, n_dst, di, n, &ctl->use_direct);
       if (st == AGPU_OK && hipGetLastError() != hipSuccess) {
         agpu_set_error("bucketed take/put launch failed");
         st = AGPU_ERR_HIP;
@@ -908,6 +926,28 @@ static agpu_status launch_take_direct(agpu_pipeline* p, int width, const void* v
                                       uint64_t n_idx, const uint32_t* only_if);
 static agpu_status launch_take_bits_direct(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits, uint64_t n_idx,
                                            const uint32_t* only_if);
+// E of the Boolean put (see "Boolean put" below): entries from natural-order bits
+__global__ __launch_bounds__(256) void pb_entries_kernel(const uint32_t* si, const uint32_t* di, const uint32_t* tbits, uint64_t n, uint64_t n_src,
+                                                        uint64_t n_dst, uint32_t* ent, const uint32_t* only_if) {
+  if (only_if && !*only_if) return;
+  const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  const uint32_t tb = tbits[i0 >> 5] >> (i0 & 31);  // the four rows' bits (i0 is a multiple of 4)
+  if (i0 + 4 <= n) {
+    const u32x4 s = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
+    const u32x4 d = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + i0));
+    u32x4 e;
+    e.x = (s.x < n_src && d.x < n_dst) ? (d.x << 1) | (tb & 1u) : 0xFFFFFFFFu;
+    e.y = (s.y < n_src && d.y < n_dst) ? (d.y << 1) | ((tb >> 1) & 1u) : 0xFFFFFFFFu;
+    e.z = (s.z < n_src && d.z < n_dst) ? (d.z << 1) | ((tb >> 2) & 1u) : 0xFFFFFFFFu;
+    e.w = (s.w < n_src && d.w < n_dst) ? (d.w << 1) | ((tb >> 3) & 1u) : 0xFFFFFFFFu;
+    __builtin_nontemporal_store(e, reinterpret_cast<u32x4*>(ent + i0));
+  } else {
+    for (int k = 0; k < 4; k++)
+      if (i0 + k < n) ent[i0 + k] = (si[i0 + k] < n_src && di[i0 + k] < n_dst) ? (di[i0 + k] << 1) | ((tb >> k) & 1u) : 0xFFFFFFFFu;
+  }
+}
+
 #define TK2_E 32
 #define TK2_TILE (BKT_T * TK2_E)  // 32 Ki rows: P2 / F2 tiles
 #define TK2_GE 16
@@ -1629,7 +1669,8 @@ __global__ __launch_bounds__(BKT_T, 8) void tk2_gather_bits_kernel(const uint32_
 // Boolean take through the merge-back pipeline; AGPU_ERR_UNSUPPORTED when the shape does not qualify
 // ent_out != nullptr (the Boolean put): the gathered bits leave as entries dst_idx[i] * 2 + bit instead of a bitmap
 static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* bits, uint64_t n_bits, const uint32_t* si, uint64_t* out_bits,
-                                              uint64_t n, const uint32_t* di = nullptr, uint64_t n_dst = 0, uint32_t* ent_out = nullptr, bool adaptive = false) {
+                                              uint64_t n, const uint32_t* di = nullptr, uint64_t n_dst = 0, uint32_t* ent_out = nullptr, bool adaptive = false,
+                                              void* tbits_tmp = nullptr) {
   if (n >= 0xFFFF0000ull || n_bits > 0xFFFFFFFFull || !aligned16(si) || p->capturing) return AGPU_ERR_UNSUPPORTED;
   const uint64_t n_words = (n_bits + 31) / 32;
   int rsw = 12;  // 2^12 words = 16 KiB of bitmap per region: two regions span < 2^13 words (the entry's 13 bits)
@@ -1676,13 +1717,18 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
       if (ent_out)
         hipLaunchKernelGGL((tk2_merge_kernel<3>), dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, counts, offsets,
                            nbp, ntiles, static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(nullptr), ent_out,
-                           static_cast<const uint32_t*>(vslot_v), static_cast<uint64_t*>(nullptr), di, n_dst);
+                           static_cast<const uint32_t*>(vslot_v), static_cast<uint64_t*>(nullptr), di, n_dst, gate);
       else
         hipLaunchKernelGGL((tk2_merge_kernel<2>), dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, counts, offsets,
                            nbp, ntiles, static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(nullptr),
                            static_cast<uint32_t*>(nullptr), static_cast<const uint32_t*>(vslot_v), out_bits, static_cast<const uint32_t*>(nullptr),
                            (uint64_t)0, gate);
       if (adaptive && !ent_out) (void)launch_take_bits_direct(p, bits, n_bits, si, out_bits, n, &ctl->use_direct);
+      if (adaptive && ent_out) {  // the Boolean put's entries the direct way: bits in natural order, then one pass that builds the entries
+        (void)launch_take_bits_direct(p, bits, n_bits, si, tbits_tmp, n, &ctl->use_direct);
+        hipLaunchKernelGGL(pb_entries_kernel, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, p->stream, si, di, static_cast<const uint32_t*>(tbits_tmp), n,
+                           n_bits, n_dst, ent_out, &ctl->use_direct);
+      }
       if (hipGetLastError() != hipSuccess) {
         agpu_set_error("merge-back take_bits launch failed");
         st = AGPU_ERR_HIP;
@@ -1837,6 +1883,30 @@ static agpu_status launch_take_direct(agpu_pipeline* p, int width, const void* v
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
 }
+static agpu_status launch_put_direct(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* src_idx, void* dst,
+                                     uint64_t n_dst, const uint32_t* dst_idx, uint64_t n, const uint32_t* only_if) {
+  const int vec_ok = aligned16(src_idx) && aligned16(dst_idx);
+  int grid = gs_grid(p, n / 4 + 1);
+  if (only_if && grid > p->dev->num_cus * 128) grid = p->dev->num_cus * 128;  // see launch_take_direct
+#define AGPU_PUT_CASE(W, E)                                                                                              \
+  case W:                                                                                                                \
+    hipLaunchKernelGGL((swz_nt() ? put_kernel<W, true> : put_kernel<W, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, \
+                       static_cast<const E*>(src), n_src, src_idx, static_cast<E*>(dst), n_dst, dst_idx, n, vec_ok,     \
+                       p->flags, only_if);                                                                               \
+    break;
+  switch (width) {
+    AGPU_PUT_CASE(4, uint32_t)
+    AGPU_PUT_CASE(2, uint16_t)
+    AGPU_PUT_CASE(1, uint8_t)
+    default:
+      agpu_set_error("put: width %d not supported (1, 2, 4)", width);
+      return AGPU_ERR_UNSUPPORTED;
+  }
+#undef AGPU_PUT_CASE
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
 static agpu_status launch_take_bits_direct(agpu_pipeline* p, const void* bits, uint64_t n_bits, const uint32_t* idx, void* out_bits, uint64_t n_idx,
                                            const uint32_t* only_if) {
   const uint64_t nwords = (n_idx + 63) / 64;
@@ -1928,26 +1998,6 @@ agpu_status agpu_take_bits(agpu_pipeline* p, const void* bits, uint64_t n_bits, 
 //   S   one workgroup per destination region: its 2^r bits (32 KiB for r = 18) live in LDS, the region's entries are applied
 //       with LDS atomics, the words go back — no global atomic anywhere.
 // Duplicate destinations: unspecified winner, like the direct kernel.
-__global__ __launch_bounds__(256) void pb_entries_kernel(const uint32_t* si, const uint32_t* di, const uint32_t* tbits, uint64_t n, uint64_t n_src,
-                                                        uint64_t n_dst, uint32_t* ent) {
-  const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i0 >= n) return;
-  const uint32_t tb = tbits[i0 >> 5] >> (i0 & 31);  // the four rows' bits (i0 is a multiple of 4)
-  if (i0 + 4 <= n) {
-    const u32x4 s = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
-    const u32x4 d = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + i0));
-    u32x4 e;
-    e.x = (s.x < n_src && d.x < n_dst) ? (d.x << 1) | (tb & 1u) : 0xFFFFFFFFu;
-    e.y = (s.y < n_src && d.y < n_dst) ? (d.y << 1) | ((tb >> 1) & 1u) : 0xFFFFFFFFu;
-    e.z = (s.z < n_src && d.z < n_dst) ? (d.z << 1) | ((tb >> 2) & 1u) : 0xFFFFFFFFu;
-    e.w = (s.w < n_src && d.w < n_dst) ? (d.w << 1) | ((tb >> 3) & 1u) : 0xFFFFFFFFu;
-    __builtin_nontemporal_store(e, reinterpret_cast<u32x4*>(ent + i0));
-  } else {
-    for (int k = 0; k < 4; k++)
-      if (i0 + k < n) ent[i0 + k] = (si[i0 + k] < n_src && di[i0 + k] < n_dst) ? (di[i0 + k] << 1) | ((tb >> k) & 1u) : 0xFFFFFFFFu;
-  }
-}
-
 __global__ __launch_bounds__(BKT_T) void pb_apply_kernel(const uint32_t* ents, const BktCtl* ctl, int r, uint32_t* dst, uint64_t n_dst) {
   extern __shared__ uint32_t pb_words[];
   const uint32_t b = blockIdx.x;
@@ -1998,13 +2048,15 @@ static agpu_status launch_put_bits_bucketed(agpu_pipeline* p, const uint32_t* sr
   if (st == AGPU_OK && n >= TK2_TILE &&
       (p->tune.gather_bucket == 2 || (n >= ((uint64_t)1 << 25) && n_src >= ((uint64_t)1 << 27) && n_src / 8 <= n))) {
     // T + E in one: the Boolean take's merge pass emits the entries itself (no natural-order bitmap in between)
-    const agpu_status ms = launch_take_bits_mergeback(p, src_bits, n_src, si, nullptr, n, di, n_dst, static_cast<uint32_t*>(ent_v));
+    const bool adaptive = p->tune.gather_bucket == 0;  // local source indices: the merge-back kernels return, the direct gather + E run
+    if (adaptive && agpu_malloc(dev, (n + 63) / 64 * 8 + 16, 0, &tb_v) != AGPU_OK) tb_v = nullptr;
+    const agpu_status ms = launch_take_bits_mergeback(p, src_bits, n_src, si, nullptr, n, di, n_dst, static_cast<uint32_t*>(ent_v), adaptive && tb_v, tb_v);
     if (ms == AGPU_OK) have_entries = true;
     else if (ms != AGPU_ERR_UNSUPPORTED) st = ms;
   }
   if (st == AGPU_OK && !have_entries) {
     // T: out-of-range source indices read 0 here and raise the flag; E drops those rows
-    st = agpu_malloc(dev, (n + 63) / 64 * 8 + 16, 0, &tb_v);
+    if (!tb_v) st = agpu_malloc(dev, (n + 63) / 64 * 8 + 16, 0, &tb_v);
     if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;
     else st = take_bits_impl(p, src_bits, n_src, si, tb_v, n);
   }
@@ -2024,7 +2076,7 @@ static agpu_status launch_put_bits_bucketed(agpu_pipeline* p, const uint32_t* sr
       if (hg > ntiles) hg = ntiles;
       if (!have_entries)
         hipLaunchKernelGGL(pb_entries_kernel, dim3((uint32_t)((n + 1023) / 1024)), dim3(256), 0, p->stream, si, di, static_cast<const uint32_t*>(tb_v), n,
-                           n_src, n_dst, ent);
+                           n_src, n_dst, ent, static_cast<const uint32_t*>(nullptr));
       hipLaunchKernelGGL(tk2_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, ent, n, n_ent, rs, bs, p->flags, counts, nbp, ntiles);
       hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
       hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s);
@@ -2053,28 +2105,10 @@ agpu_status agpu_put_bounded(agpu_pipeline* p, int32_t width, const void* src, u
   AGPU_REQUIRE(src && src_idx && dst && dst_idx, AGPU_ERR_ARG, "null pointer");
   if ((width == 1 || width == 2 || width == 4) && n_src != UINT64_MAX && n_dst != UINT64_MAX &&
       want_bucketed(p, width, n, n_src, n_dst, true)) {
-    const agpu_status bs = launch_bucketed(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n);
+    const agpu_status bs = launch_bucketed(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n, p->tune.gather_bucket == 0);
     if (bs != AGPU_ERR_UNSUPPORTED) return bs;
   }
-  const int vec_ok = aligned16(src_idx) && aligned16(dst_idx);
-  const int grid = gs_grid(p, n / 4 + 1);
-#define AGPU_PUT_CASE(W, E)                                                                                              \
-  case W:                                                                                                                \
-    hipLaunchKernelGGL((swz_nt() ? put_kernel<W, true> : put_kernel<W, false>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, \
-                       static_cast<const E*>(src), n_src, src_idx, static_cast<E*>(dst), n_dst, dst_idx, n, vec_ok,     \
-                       p->flags);                                                                                        \
-    break;
-  switch (width) {
-    AGPU_PUT_CASE(4, uint32_t)
-    AGPU_PUT_CASE(2, uint16_t)
-    AGPU_PUT_CASE(1, uint8_t)
-    default:
-      agpu_set_error("put: width %d not supported (1, 2, 4)", width);
-      return AGPU_ERR_UNSUPPORTED;
-  }
-#undef AGPU_PUT_CASE
-  AGPU_LAUNCH_CHECK();
-  return AGPU_OK;
+  return launch_put_direct(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n, nullptr);
 }
 
 agpu_status agpu_put(agpu_pipeline* p, int32_t width, const void* src, const uint32_t* src_idx, void* dst,
