@@ -589,3 +589,34 @@ def test_auto_policy_is_right_either_way(ctx, dist):
         assert np.array_equal(dev.retrive_data(ob, n // 8, pipeline=p), exp_bits)
     finally:
         p.set_tuning("gather_bucket", 2)
+
+
+@pytest.mark.parametrize("src_dist,dst_dist", [("uniform", "uniform"), ("sorted", "sorted"), ("sequential", "sequential"), ("sorted", "uniform")])
+def test_put_auto_policy_is_right_either_way(ctx, src_dist, dst_dist):
+    """2^24 rows under the auto policy (put probes both index columns, the Boolean put its source side): whichever kernels the device-side
+    decision lets run, values and bits equal numpy's (distinct destinations)"""
+    dev, p = ctx
+    n, n_src, n_dst = 1 << 24, 1 << 26, 1 << 26
+    rng = np.random.default_rng(47)
+    src = rng.integers(0, 1 << 32, n_src, dtype=np.uint64).astype(np.uint32)
+    dst = rng.integers(0, 1 << 32, n_dst, dtype=np.uint64).astype(np.uint32)
+    sbits, dbits = rng.integers(0, 256, n_src // 8, dtype=np.uint8), rng.integers(0, 256, n_dst // 8, dtype=np.uint8)
+    si = {"uniform": lambda: rng.integers(0, n_src, n, dtype=np.uint32), "sorted": lambda: np.sort(rng.integers(0, n_src, n, dtype=np.uint32)),
+          "sequential": lambda: np.arange(n, dtype=np.uint32)}[src_dist]()
+    perm = rng.permutation(n_dst).astype(np.uint32)[:n]
+    di = {"uniform": lambda: perm, "sorted": lambda: np.sort(perm), "sequential": lambda: np.arange(n, dtype=np.uint32) + 12345}[dst_dist]()
+    ds, dsb, dsi, ddi = (dev.create_gpu_buffer_with_data(x) for x in (src, sbits, si, di))
+    dd, ddb = dev.create_gpu_buffer_with_data(dst), dev.create_gpu_buffer_with_data(dbits)
+    try:
+        p.set_tuning("gather_bucket", 0)
+        capi.call("agpu_put_bounded", p._handle, 4, vp(ds), n_src, vp(dsi), vp(dd), n_dst, vp(ddi), n)
+        capi.call("agpu_put_bits_bounded", p._handle, vp(dsb), n_src, vp(dsi), vp(ddb), n_dst, vp(ddi), n)
+        p.sync()
+    finally:
+        p.set_tuning("gather_bucket", 2)
+    exp = dst.copy()
+    exp[di] = src[si]
+    assert np.array_equal(dev.retrive_data(dd, 4 * n_dst, pipeline=p).view(np.uint32), exp)
+    eb = np.unpackbits(dbits, bitorder="little")
+    eb[di] = np.unpackbits(sbits, bitorder="little")[si]
+    assert np.array_equal(dev.retrive_data(ddb, n_dst // 8, pipeline=p), np.packbits(eb, bitorder="little"))
