@@ -1116,38 +1116,40 @@ __global__ __launch_bounds__(BKT_T) void tk2_partition_kernel(const uint32_t* si
 // slot in slot order (256 u64 words per tile).
 // W = the value width in bytes (4, 2, 1): regions, entries and the LDS arrays are in ELEMENTS either way; only the gather, the
 // slow path and the last store see the type.
-template <int WPE, bool BITS, int W = 4>
-__global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename ElemOf<W>::type* values, uint64_t n_src, const uint32_t* srcs,
+template <int WPE, bool BITS, int W = 4, int T = BKT_T>
+__global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemOf<W>::type* values, uint64_t n_src, const uint32_t* srcs,
                                                                uint64_t total, uint32_t ntiles, typename ElemOf<W>::type* vals,
                                                                const uint32_t* vbits_src, uint64_t* vbits_slot, const BktCtl* gate = nullptr) {
   BKT_GATE(gate);
   typedef typename ElemOf<W>::type E;
+  constexpr int GT = TK2_GE * T;  // slots per tile (T = 1024: 16 Ki; the 512-thread variant: 8 Ki, four workgroups per CU)
+  constexpr int KPT = TK2_GKEYS / T;  // line-group counters per thread in the scan
   // 64 KiB + 8 KiB of LDS and ≤ 64 VGPRs: TWO workgroups per CU, so that one's loads and gathers run under the other's LDS
   // phases.  To stay inside 64 registers the tile's sources are loaded twice (the second time from L2) instead of being
   // kept across the ranking, ranks are packed two to a register, and only the 16 sorted entries live across the barrier
   // that turns the entry array into the value array (a first version with everything kept spilled 18–32 VGPRs: 4.5 B/row of
   // scratch traffic by PMC).
-  __shared__ uint32_t sorted[TK2_GTILE];
+  __shared__ uint32_t sorted[GT];
   __shared__ uint32_t lcnt[TK2_GKEYS];
-  __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
+  __shared__ uint32_t wave_tot[T / AGPU_WAVE];
   __shared__ uint32_t tile_rows;
-  __shared__ uint32_t red[2 * (BKT_T / AGPU_WAVE)];
-  __shared__ uint32_t bitl[BITS ? TK2_GTILE / 32 : 1];  // the tile's validity bits by slot
+  __shared__ uint32_t red[2 * (T / AGPU_WAVE)];
+  __shared__ uint32_t bitl[BITS ? GT / 32 : 1];  // the tile's validity bits by slot
   uint64_t tile;
   if (!bkt_tile_of_block(ntiles, &tile)) return;
-  const uint64_t base = tile * TK2_GTILE;
+  const uint64_t base = tile * GT;
   if (base >= total) return;
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   if constexpr (BITS)
-    if (threadIdx.x < TK2_GTILE / 32) bitl[threadIdx.x] = 0;
+    if (threadIdx.x < GT / 32) bitl[threadIdx.x] = 0;
   auto store_bits = [&]() {  // after a barrier: slot-ordered validity words of this tile
     if constexpr (BITS) {
-      if (threadIdx.x < TK2_GTILE / 64 && base + (uint64_t)threadIdx.x * 64 < total)
+      if (threadIdx.x < GT / 64 && base + (uint64_t)threadIdx.x * 64 < total)
         vbits_slot[base / 64 + threadIdx.x] = (uint64_t)bitl[threadIdx.x * 2] | ((uint64_t)bitl[threadIdx.x * 2 + 1] << 32);
     }
   };
   auto load4 = [&](int q) -> u32x4 {
-    const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
+    const uint64_t i0 = base + ((uint64_t)q * T + threadIdx.x) * 4;
     u32x4 t = {0, 0, 0, 0};
     if (i0 + 4 <= total) t = *reinterpret_cast<const u32x4*>(srcs + i0);
     else {
@@ -1157,10 +1159,10 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename E
     }
     return t;
   };
-  auto live_at = [&](int q, int k) { return base + ((uint64_t)q * BKT_T + threadIdx.x) * 4 + (uint64_t)k < total; };
+  auto live_at = [&](int q, int k) { return base + ((uint64_t)q * T + threadIdx.x) * 4 + (uint64_t)k < total; };
   // pass 1: the tile's source span decides the path (uniform over the block)
   uint32_t mn = 0xFFFFFFFFu, mx = 0;
-  for (uint32_t k = threadIdx.x; k < TK2_GKEYS; k += BKT_T) lcnt[k] = 0;
+  for (uint32_t k = threadIdx.x; k < TK2_GKEYS; k += T) lcnt[k] = 0;
 #pragma unroll
   for (int q = 0; q < TK2_GE / 4; q++) {
     const u32x4 t = load4(q);
@@ -1180,14 +1182,14 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename E
   }
   if (lane == 0) {
     red[wave] = mn;
-    red[BKT_T / AGPU_WAVE + wave] = mx;
+    red[T / AGPU_WAVE + wave] = mx;
   }
   __syncthreads();
   mn = red[0];
-  mx = red[BKT_T / AGPU_WAVE];
-  for (int w = 1; w < BKT_T / AGPU_WAVE; w++) {
+  mx = red[T / AGPU_WAVE];
+  for (int w = 1; w < T / AGPU_WAVE; w++) {
     mn = red[w] < mn ? red[w] : mn;
-    mx = red[BKT_T / AGPU_WAVE + w] > mx ? red[BKT_T / AGPU_WAVE + w] : mx;
+    mx = red[T / AGPU_WAVE + w] > mx ? red[T / AGPU_WAVE + w] : mx;
   }
   const uint32_t origin = mn & ~((1u << TK2_GKEY_SHIFT) - 1u);
   const bool fast = mx < n_src && (mx - origin) < (1u << TK2_REL_BITS);
@@ -1200,9 +1202,9 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename E
       for (int k = 0; k < 4; k++)
         if (live_at(q, k)) {
           const bool ok = sv[k] < n_src;
-          vals[base + ((uint64_t)q * BKT_T + threadIdx.x) * 4 + (uint64_t)k] = ok ? values[sv[k]] : (E)0;
+          vals[base + ((uint64_t)q * T + threadIdx.x) * 4 + (uint64_t)k] = ok ? values[sv[k]] : (E)0;
           if constexpr (BITS) {
-            const uint32_t pos = ((uint32_t)q * BKT_T + threadIdx.x) * 4 + (uint32_t)k;
+            const uint32_t pos = ((uint32_t)q * T + threadIdx.x) * 4 + (uint32_t)k;
             if (ok && ((vbits_src[sv[k] >> 5] >> (sv[k] & 31)) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
           }
         }
@@ -1227,9 +1229,14 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename E
     rank2[q * 2 + 1] = r[2] | (r[3] << 16);
   }
   __syncthreads();
-  {  // exclusive scan of the 2048 counters: thread t owns 2t, 2t+1
-    const uint32_t c0 = lcnt[threadIdx.x * 2], c1 = lcnt[threadIdx.x * 2 + 1];
-    uint32_t incl = c0 + c1;
+  {  // exclusive scan of the 2048 counters: thread t owns KPT consecutive ones
+    uint32_t c[KPT], sum = 0;
+#pragma unroll
+    for (int k = 0; k < KPT; k++) {
+      c[k] = lcnt[threadIdx.x * KPT + k];
+      sum += c[k];
+    }
+    uint32_t incl = sum;
 #pragma unroll
     for (int off = 1; off < AGPU_WAVE; off <<= 1) {
       const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
@@ -1239,10 +1246,13 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename E
     __syncthreads();
     uint32_t pre = 0;
     for (uint32_t w = 0; w < wave; w++) pre += wave_tot[w];
-    const uint32_t run = pre + incl - (c0 + c1);
-    lcnt[threadIdx.x * 2] = run;
-    lcnt[threadIdx.x * 2 + 1] = run + c0;
-    if (threadIdx.x == BKT_T - 1) tile_rows = run + c0 + c1;
+    uint32_t run = pre + incl - sum;
+#pragma unroll
+    for (int k = 0; k < KPT; k++) {
+      lcnt[threadIdx.x * KPT + k] = run;
+      run += c[k];
+    }
+    if (threadIdx.x == T - 1) tile_rows = run;
     __syncthreads();
   }
   // pass 3 (sources from L2 again): entries {source − origin, slot inside the tile} into line-group order
@@ -1254,7 +1264,7 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename E
     for (int k = 0; k < 4; k++)
       if (live_at(q, k)) {
         const uint32_t rel = sv[k] - origin;
-        const uint32_t pos = ((uint32_t)q * BKT_T + threadIdx.x) * 4 + (uint32_t)k;
+        const uint32_t pos = ((uint32_t)q * T + threadIdx.x) * 4 + (uint32_t)k;
         const uint32_t rk = (rank2[q * 2 + (k >> 1)] >> ((k & 1) * 16)) & 0xFFFFu;
         sorted[lcnt[rel >> TK2_GKEY_SHIFT] + rk] = (rel << TK2_POS_BITS) | pos;
       }
@@ -1264,7 +1274,7 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename E
   uint32_t ent[TK2_GE];
 #pragma unroll
   for (int e = 0; e < TK2_GE; e++) {
-    const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
+    const uint32_t j = (uint32_t)e * T + threadIdx.x;
     ent[e] = j < rows_here ? sorted[j] : 0u;
   }
   __syncthreads();  // every entry has been read: the same array takes the values, back in slot order
@@ -1276,24 +1286,24 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename E
     uint32_t v[TK2_GGRP];
 #pragma unroll
     for (int e = 0; e < TK2_GGRP; e++) {
-      const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+      const uint32_t j = (uint32_t)(h0 + e) * T + threadIdx.x;
       v[e] = j < rows_here ? (uint32_t)values[origin + (ent[h0 + e] >> TK2_POS_BITS)] : 0u;  // the L2-resident gather
     }
 #pragma unroll
     for (int e = 0; e < TK2_GGRP; e++) {
-      const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+      const uint32_t j = (uint32_t)(h0 + e) * T + threadIdx.x;
       if (j < rows_here) sorted[ent[h0 + e] & ((1u << TK2_POS_BITS) - 1u)] = v[e];
     }
     if constexpr (BITS) {  // the validity bits of the same eight sources: 16 bytes of bitmap per line group, shared by neighbours
       uint32_t w[TK2_GGRP];
 #pragma unroll
       for (int e = 0; e < TK2_GGRP; e++) {
-        const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+        const uint32_t j = (uint32_t)(h0 + e) * T + threadIdx.x;
         w[e] = j < rows_here ? vbits_src[(origin + (ent[h0 + e] >> TK2_POS_BITS)) >> 5] : 0u;
       }
 #pragma unroll
       for (int e = 0; e < TK2_GGRP; e++) {
-        const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
+        const uint32_t j = (uint32_t)(h0 + e) * T + threadIdx.x;
         const uint32_t src = origin + (ent[h0 + e] >> TK2_POS_BITS), pos = ent[h0 + e] & ((1u << TK2_POS_BITS) - 1u);
         if (j < rows_here && ((w[e] >> (src & 31)) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
       }
@@ -1303,7 +1313,7 @@ __global__ __launch_bounds__(BKT_T, WPE) void tk2_gather_kernel(const typename E
   store_bits();
 #pragma unroll
   for (int q = 0; q < TK2_GE / 4; q++) {
-    const uint32_t l0 = ((uint32_t)q * BKT_T + threadIdx.x) * 4;
+    const uint32_t l0 = ((uint32_t)q * T + threadIdx.x) * 4;
     const uint64_t i0 = base + l0;
     if (i0 + 4 <= total) {
       if constexpr (W == 4) {
@@ -1741,6 +1751,9 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
 }
 
 // vbits_src != nullptr: the source's validity bitmap is gathered with the values into out_validity (agpu_take_validity)
+#ifndef TK2_GTHREADS
+#define TK2_GTHREADS BKT_T  // threads of a G2 workgroup (tile = 16 slots per thread): 1024 → two workgroups per CU; 512 → four (A/B, tools/probe)
+#endif
 static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void* values, uint64_t n_src, const uint32_t* si, void* out,
                                          uint64_t n, const uint32_t* vbits_src = nullptr, uint64_t* out_validity = nullptr, bool adaptive = false) {
   if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || !aligned16(si) || !aligned16(out) || p->capturing) return AGPU_ERR_UNSUPPORTED;
@@ -1750,13 +1763,13 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
   if (bs + 1 > BKT_MAX) return AGPU_ERR_UNSUPPORTED;
   agpu_device* dev = p->dev;
   const uint32_t ntiles = (uint32_t)((n + TK2_TILE - 1) / TK2_TILE);
-  const uint32_t gtiles = (uint32_t)((n + TK2_GTILE - 1) / TK2_GTILE);
+  const uint32_t gtiles = (uint32_t)((n + TK2_GE * TK2_GTHREADS - 1) / (TK2_GE * TK2_GTHREADS));
   const uint32_t nbp = (bs + 1 + 3) & ~3u;
   const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
   void *ctl_v = nullptr, *srcs_v = nullptr, *vals_v = nullptr, *rank_v = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr;
   void* vslot_v = nullptr;
   agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
-  if (st == AGPU_OK && vbits_src) st = agpu_malloc(dev, ((size_t)gtiles * TK2_GTILE) / 8 + 16, 0, &vslot_v);
+  if (st == AGPU_OK && vbits_src) st = agpu_malloc(dev, ((size_t)gtiles * TK2_GE * TK2_GTHREADS) / 8 + 16, 0, &vslot_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 4 * n + 16, 0, &srcs_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)width * n + 16, 0, &vals_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 2 * n + 16, 0, &rank_v);
@@ -1792,14 +1805,14 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
 #define TK2_GF(WW, E)                                                                                                                    \
   case WW:                                                                                                                               \
     if (vbits_src) {                                                                                                                     \
-      hipLaunchKernelGGL((tk2_gather_kernel<8, true, WW>), ggrid, dim3(BKT_T), 0, p->stream, static_cast<const E*>(values), n_src,        \
+      hipLaunchKernelGGL((tk2_gather_kernel<8, true, WW, TK2_GTHREADS>), ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src,        \
                          static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), vbits_src, vslot, gate);              \
       hipLaunchKernelGGL((tk2_merge_kernel<1, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \
                          static_cast<const uint16_t*>(rank_v), static_cast<const E*>(vals_v), static_cast<E*>(out),                      \
                          reinterpret_cast<const uint32_t*>(vslot), out_validity, static_cast<const uint32_t*>(nullptr), (uint64_t)0,     \
                          gate);                                                                                                          \
     } else {                                                                                                                             \
-      hipLaunchKernelGGL((tk2_gather_kernel<8, false, WW>), ggrid, dim3(BKT_T), 0, p->stream, static_cast<const E*>(values), n_src,       \
+      hipLaunchKernelGGL((tk2_gather_kernel<8, false, WW, TK2_GTHREADS>), ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src,       \
                          static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), static_cast<const uint32_t*>(nullptr), \
                          static_cast<uint64_t*>(nullptr), gate);                                                                         \
       hipLaunchKernelGGL((tk2_merge_kernel<0, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \
