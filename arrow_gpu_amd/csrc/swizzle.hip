@@ -1854,7 +1854,7 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
 static bool want_bucketed(const agpu_pipeline* p, int width, uint64_t n, uint64_t n_src, uint64_t n_dst, bool is_put) {
   const int64_t mode = p->tune.gather_bucket;
   if (mode == 1) return false;
-  if (mode == 2 || mode == 3) return n >= BKT_TILE;
+  if (mode == 2 || mode == 3 || mode == 4) return n >= BKT_TILE;  // 4: like 2, but with the device-side probe (tests: both outcomes at small sizes)
   if (n_src / 8 > n || n_dst / 8 > n) return false;
   if (is_put) return n >= ((uint64_t)1 << 24);
   return n >= ((uint64_t)1 << 25) && n_src * (uint64_t)width >= ((uint64_t)16 << 20);
@@ -1948,7 +1948,7 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
   if ((width == 1 || width == 2 || width == 4) && n_values != UINT64_MAX && want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
     if (p->tune.gather_bucket != 3 && n_idx >= TK2_TILE) {  // "gather_bucket" = 3: the pair pipeline, for A/B
-      const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx, nullptr, nullptr, p->tune.gather_bucket == 0);
+      const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx, nullptr, nullptr, p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4);
       if (ms != AGPU_ERR_UNSUPPORTED) return ms;
     }
     const agpu_status bs = launch_bucketed(p, width, values, n_values, idx, out, n_idx, nullptr, n_idx);
@@ -1971,7 +1971,7 @@ agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* valu
         want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
       const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx,
                                                    static_cast<const uint32_t*>(validity), static_cast<uint64_t*>(out_validity),
-                                                   p->tune.gather_bucket == 0);
+                                                   p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4);
       if (ms != AGPU_ERR_UNSUPPORTED) return ms;
     }
   }
@@ -1986,10 +1986,11 @@ static agpu_status take_bits_impl(agpu_pipeline* p, const void* bits, uint64_t n
   AGPU_REQUIRE(n_bits > 0, AGPU_ERR_SHAPE, "take from an empty bitmap");
   AGPU_REQUIRE(aligned_to(bits, 4) && aligned_to(out_bits, 8), AGPU_ERR_SHAPE, "bitmap alignment");
   if (n_bits != UINT64_MAX && n_idx >= TK2_TILE && p->tune.gather_bucket != 1 && p->tune.gather_bucket != 3 &&
-      (p->tune.gather_bucket == 2 || (n_idx >= ((uint64_t)1 << 25) && n_bits >= ((uint64_t)1 << 27) && n_bits / 8 <= n_idx))) {
+      (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 4 ||
+       (n_idx >= ((uint64_t)1 << 25) && n_bits >= ((uint64_t)1 << 27) && n_bits / 8 <= n_idx))) {
     // round 3: the merge-back pipeline with the bitmap's words as the elements (auto: ≥ 2^25 rows from a bitmap of ≥ 16 MiB)
     const agpu_status ms = launch_take_bits_mergeback(p, static_cast<const uint32_t*>(bits), n_bits, idx, static_cast<uint64_t*>(out_bits), n_idx,
-                                                      nullptr, 0, nullptr, p->tune.gather_bucket == 0);
+                                                      nullptr, 0, nullptr, p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4);
     if (ms != AGPU_ERR_UNSUPPORTED) return ms;
   }
   return launch_take_bits_direct(p, bits, n_bits, idx, out_bits, n_idx, nullptr);
@@ -2059,9 +2060,9 @@ static agpu_status launch_put_bits_bucketed(agpu_pipeline* p, const uint32_t* sr
   if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;
   bool have_entries = false;
   if (st == AGPU_OK && n >= TK2_TILE &&
-      (p->tune.gather_bucket == 2 || (n >= ((uint64_t)1 << 25) && n_src >= ((uint64_t)1 << 27) && n_src / 8 <= n))) {
+      (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 4 || (n >= ((uint64_t)1 << 25) && n_src >= ((uint64_t)1 << 27) && n_src / 8 <= n))) {
     // T + E in one: the Boolean take's merge pass emits the entries itself (no natural-order bitmap in between)
-    const bool adaptive = p->tune.gather_bucket == 0;  // local source indices: the merge-back kernels return, the direct gather + E run
+    const bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;  // local source indices: the merge-back kernels return, the direct gather + E run
     if (adaptive && agpu_malloc(dev, (n + 63) / 64 * 8 + 16, 0, &tb_v) != AGPU_OK) tb_v = nullptr;
     const agpu_status ms = launch_take_bits_mergeback(p, src_bits, n_src, si, nullptr, n, di, n_dst, static_cast<uint32_t*>(ent_v), adaptive && tb_v, tb_v);
     if (ms == AGPU_OK) have_entries = true;
@@ -2118,7 +2119,7 @@ agpu_status agpu_put_bounded(agpu_pipeline* p, int32_t width, const void* src, u
   AGPU_REQUIRE(src && src_idx && dst && dst_idx, AGPU_ERR_ARG, "null pointer");
   if ((width == 1 || width == 2 || width == 4) && n_src != UINT64_MAX && n_dst != UINT64_MAX &&
       want_bucketed(p, width, n, n_src, n_dst, true)) {
-    const agpu_status bs = launch_bucketed(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n, p->tune.gather_bucket == 0);
+    const agpu_status bs = launch_bucketed(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n, p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4);
     if (bs != AGPU_ERR_UNSUPPORTED) return bs;
   }
   return launch_put_direct(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n, nullptr);
@@ -2136,7 +2137,8 @@ agpu_status agpu_put_bits_bounded(agpu_pipeline* p, const void* src_bits, uint64
   AGPU_REQUIRE(src_bits && src_idx && dst_bits && dst_idx, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(aligned_to(src_bits, 4) && aligned_to(dst_bits, 4), AGPU_ERR_SHAPE, "bitmap alignment");
   if (n_src_bits != UINT64_MAX && n_dst_bits != UINT64_MAX && n_src_bits > 0 && n_dst_bits > 0 && p->tune.gather_bucket != 1 &&
-      (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 3 || (n >= ((uint64_t)1 << 24) && n_dst_bits >= ((uint64_t)1 << 22)))) {
+      (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 3 || p->tune.gather_bucket == 4 ||
+       (n >= ((uint64_t)1 << 24) && n_dst_bits >= ((uint64_t)1 << 22)))) {
     // (a destination of fewer than 16 regions leaves the apply pass with too few workgroups: the direct kernel keeps those)
     // round 3: bucketed by destination region, no global atomics (auto from 2^24 rows: 0.67 → 0.46 ms there, 10.4 → 3.6 at 2^28)
     const agpu_status bs = launch_put_bits_bucketed(p, static_cast<const uint32_t*>(src_bits), n_src_bits, src_idx, static_cast<uint32_t*>(dst_bits),

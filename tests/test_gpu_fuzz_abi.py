@@ -64,7 +64,7 @@ def test_random_abi_calls_match_the_oracle(D, seed):
                "chain", "shift", "put", "take_bits", "take_validity", "put_bits")[rng.integers(16)]
         # take / put: the direct kernels (auto at these sizes), the forced pipelines (2: merge-back take, pair-pipeline put;
         # 3: pair-pipeline take) and all three range-start variants — small, ragged, mis-aligned inputs through every form
-        D.p.set_tuning("gather_bucket", int((0, 2, 3)[rng.integers(3)]))
+        D.p.set_tuning("gather_bucket", int((0, 2, 3, 4, 4)[rng.integers(5)]))  # 4: pipelines + the device-side probe at any size
         D.p.set_tuning("gather_offsets", int(rng.integers(0, 4)))
         n = pick_n(rng)
         dtype = ALL_DTYPES[rng.integers(len(ALL_DTYPES))]
@@ -133,6 +133,8 @@ def test_random_abi_calls_match_the_oracle(D, seed):
                 continue
             k = pick_n(rng)
             idx = rng.integers(0, n, k).astype(np.uint32)
+            if rng.random() < 0.4:
+                idx = np.sort(idx)  # local indices: the probe's other outcome
             out = D.empty(max(k * w, 1), offset_bytes=off(rng, w))
             D.call("agpu_take", w, D.up(a, off(rng, w)).vp, n, D.up(idx, off(rng, 4)).vp, out.vp, k)
             assert bits_equal(D.down(out, NP[dtype], k), O.take(w, a, idx)), what
@@ -159,6 +161,8 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             dst = rand_values(dtype, n_dst, seed * 19 + it)
             si = rng.integers(0, n, k).astype(np.uint32)
             di = rng.permutation(n_dst)[:k].astype(np.uint32)  # unique destinations
+            if rng.random() < 0.4:
+                si, di = np.sort(si), np.sort(di)
             ddst = D.up(dst, off(rng, w))
             D.call("agpu_put_bounded", w, D.up(a, off(rng, w)).vp, n, D.up(si, off(rng, 4)).vp, ddst.vp, n_dst,
                    D.up(di, off(rng, 4)).vp, k)
@@ -172,6 +176,8 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             src_b, dst_b = O.synth_bits(n, seed, it + 11, 0.5), O.synth_bits(n_dst, seed, it + 12, 0.5)
             si = rng.integers(0, n, k).astype(np.uint32)
             di = rng.permutation(n_dst)[:k].astype(np.uint32)  # unique destinations
+            if rng.random() < 0.4:
+                si, di = np.sort(si), np.sort(di)
             ddst = D.up(dst_b)
             D.call("agpu_put_bits_bounded", D.up(src_b).vp, n, D.up(si, off(rng, 4)).vp, ddst.vp, n_dst, D.up(di, off(rng, 4)).vp, k)
             assert bits_equal(D.down(ddst, np.uint8, O.bitmap_bytes(n_dst)), O.put_bits(src_b, si, dst_b, di)), what
@@ -181,6 +187,8 @@ def test_random_abi_calls_match_the_oracle(D, seed):
                 continue
             k = pick_n(rng)
             idx = rng.integers(0, n, k).astype(np.uint32)
+            if rng.random() < 0.4:
+                idx = np.sort(idx)
             vb = O.synth_bits(n, seed, it + 9, 0.6)
             out = D.empty(max(k * w, 1), offset_bytes=off(rng, w))
             outv = D.empty(O.bitmap_bytes(k) + 8)
@@ -194,6 +202,8 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             bits_in = O.synth_bits(n, seed, it + 7, 0.5)
             k = pick_n(rng)
             idx = rng.integers(0, n, k).astype(np.uint32)
+            if rng.random() < 0.4:
+                idx = np.sort(idx)
             outb = D.empty(O.bitmap_bytes(k) + 8)
             D.call("agpu_take_bits", D.up(bits_in).vp, n, D.up(idx, off(rng, 4)).vp, outb.vp, k)
             assert bits_equal(D.down(outb, np.uint8, O.bitmap_bytes(k)), O.take_bits(bits_in, n, idx)), what
