@@ -189,7 +189,7 @@ def test_bucketed_put_drops_out_of_range_rows(ctx):
 
 
 # ---- round 3: take of an array WITH NULLS — agpu_take_validity: the validity bit travels with the value
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 4])
 @pytest.mark.parametrize("n,n_values,dist", [(5, 9, "uniform"), (32767, 70_000, "uniform"), (32768, 1 << 20, "uniform"), (65_537, 1 << 22, "uniform"),
                                              (40_000, 300_000_007, "uniform"), (1_000_003, 40_000_003, "uniform"),
                                              (3 * 32768 + 5, 1 << 24, "oob_tile"), (500_000, 1 << 23, "skew"), (2_500_000, 1 << 20, "dups")])
@@ -261,7 +261,7 @@ def test_host_take_of_an_array_with_nulls_uses_the_fused_call(ctx):
 
 
 # ---- round 3: Boolean take (agpu_take_bits) through the merge-back pipeline — the bitmap's words are the elements
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 4])
 @pytest.mark.parametrize("n,n_bits,dist", [(32768, 9, "uniform"), (32769, 70_001, "uniform"), (65_537, 1 << 22, "uniform"), (40_000, 300_000_007, "uniform"),
                                            (1_000_003, 40_000_003, "uniform"), (3 * 32768 + 5, 1 << 24, "oob_tile"), (500_000, 1 << 23, "skew"),
                                            (2_500_000, 1 << 20, "dups"), (2_000_000, (1 << 29) - 3, "uniform"), (100_000, (1 << 29) + 77, "uniform")])
@@ -372,7 +372,7 @@ def test_pair_pipeline_range_start_variants(ctx, offsets, width):
 
 
 # ---- round 3: Boolean put (agpu_put_bits_bounded) bucketed by destination region — LDS-resident regions, no global atomics
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 4])
 @pytest.mark.parametrize("n,n_src,n_dst,dist", [(5, 9, 77, "uniform"), (32768, 70_001, 40_000, "uniform"), (100_003, 1 << 20, (1 << 21) + 5, "uniform"),
                                                 (1_000_003, 40_000_003, 3_000_017, "uniform"), (300_000, 1 << 22, (1 << 18) * 5 + 3, "oob"),
                                                 (500_000, 1 << 23, 1 << 24, "skew"), (200_000, 1 << 20, 1_200_000_007, "uniform"),
