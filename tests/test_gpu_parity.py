@@ -626,6 +626,35 @@ def test_graph_capture_replays_an_op_chain(D):
     capi.call("agpu_graph_destroy", g)
 
 
+def test_graph_capture_of_takes_and_puts_uses_the_direct_kernels(D):
+    """the bucketed pipelines allocate temporaries and (under the auto policy) decide on the device: neither belongs in a captured
+    graph — while a pipeline is capturing, take / put / their Boolean forms enqueue the direct kernels, whatever the tuning says"""
+    n, n_src, n_dst = 100_000, 250_000, 300_000
+    rng = np.random.default_rng(8)
+    vals, dst = rand_values(capi.U32, n_src, 1), rand_values(capi.U32, n_dst, 2)
+    bits = O.synth_bits(n_src, 3, 0, 0.5)
+    idx = rng.integers(0, n_src, n).astype(np.uint32)
+    di = rng.permutation(n_dst)[:n].astype(np.uint32)
+    dv, db, dix, ddi = D.up(vals), D.up(bits), D.up(idx), D.up(di)
+    out, outb, ddst = D.empty(4 * n), D.empty(O.bitmap_bytes(n) + 8), D.up(dst)
+    for mode in (2, 4, 0):
+        D.p.set_tuning("gather_bucket", mode)
+        g = C.c_void_p()
+        D.call("agpu_pipeline_begin_capture")
+        D.call("agpu_take", 4, dv.vp, n_src, dix.vp, out.vp, n)
+        D.call("agpu_take_bits", db.vp, n_src, dix.vp, outb.vp, n)
+        D.call("agpu_put_bounded", 4, dv.vp, n_src, dix.vp, ddst.vp, n_dst, ddi.vp, n)
+        D.call("agpu_pipeline_end_capture", C.byref(g))
+        for _ in range(2):
+            capi.call("agpu_memset", D.h, out.vp, 0, 4 * n)
+            capi.call("agpu_graph_launch", g, D.h)
+            assert bits_equal(D.down(out, np.uint32, n), O.take(4, vals, idx))
+            assert bits_equal(D.down(outb, np.uint8, O.bitmap_bytes(n)), O.take_bits(bits, n_src, idx))
+            assert bits_equal(D.down(ddst, np.uint32, n_dst), O.put(4, vals, idx, dst, di))
+        capi.call("agpu_graph_destroy", g)
+    D.p.set_tuning("gather_bucket", 0)
+
+
 def test_two_pipelines_from_two_threads(D):
     import threading
 
