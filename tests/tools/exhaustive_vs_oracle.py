@@ -52,26 +52,24 @@ def _check(args):
 
 def main():
     global _X, _GOT, _Y
-    from multiprocessing import shared_memory
+    import mmap
 
     names = sys.argv[1:] or list(OPS) + ["pow"]
     workers = int(os.environ.get("AGPU_ORACLE_WORKERS", "16"))
     # the two chunk buffers are shared memory and the workers are forked BEFORE this process touches the GPU: no child ever
     # carries HIP state
-    shm_x, shm_g = shared_memory.SharedMemory(create=True, size=4 * CHUNK), shared_memory.SharedMemory(create=True, size=4 * CHUNK)
-    _X = np.ndarray(CHUNK, np.float32, buffer=shm_x.buf)
-    _GOT = np.ndarray(CHUNK, np.float32, buffer=shm_g.buf)
-    shm_y = shared_memory.SharedMemory(create=True, size=4 * PAIRS)
-    _Y = np.ndarray(PAIRS, np.float32, buffer=shm_y.buf)
+    # (anonymous shared mappings: inherited by fork, nothing under /dev/shm to size or to clean up)
+    shm_x, shm_g, shm_y = mmap.mmap(-1, 4 * CHUNK), mmap.mmap(-1, 4 * CHUNK), mmap.mmap(-1, 4 * PAIRS)
+    _X = np.frombuffer(shm_x, np.float32)
+    _GOT = np.frombuffer(shm_g, np.float32)
+    _Y = np.frombuffer(shm_y, np.float32)
     pool = mp.get_context("fork").Pool(workers)
     try:
         return _run(names, workers, pool)
     finally:
         pool.terminate()
+        pool.join()
         _X = _GOT = _Y = None
-        for m in (shm_x, shm_g, shm_y):
-            m.close()
-            m.unlink()
 
 
 def _pow(p, pool, workers, din, dout, dev, vp):
