@@ -228,7 +228,8 @@ struct BktCtl {  // device-side control block
   uint32_t use_direct;           // set by idx_locality_kernel: the index columns are local — the pipeline's kernels return at once and
                                  // the direct kernel launched behind them does the work (no host round trip)
   uint32_t loc_distinct[2], loc_rows[2], loc_done;
-  uint32_t pad[2];
+  uint32_t run_direct;           // 1: the direct kernel behind the pipelines does the work (take: = use_direct; put: both columns local)
+  uint32_t pad[1];
 };
 #define BKT_GATE(g)                         \
   do {                                      \
@@ -246,7 +247,10 @@ struct BktCtl {  // device-side control block
 #define LOC_BLOCKS 128
 #define LOC_ROWS 2048
 #define LOC_SLOTS 4096
-__global__ __launch_bounds__(256) void idx_locality_kernel(const uint32_t* idx0, const uint32_t* idx1, uint64_t n, int shift0, int shift1, BktCtl* ctl) {
+// ctl_lr != nullptr (put): the control block of the destination-only pipeline, which runs when the SOURCE column is local and the
+// destination column is not (a scatter of a contiguous or sorted selection: the source side needs no partition at all)
+__global__ __launch_bounds__(256) void idx_locality_kernel(const uint32_t* idx0, const uint32_t* idx1, uint64_t n, int shift0, int shift1, BktCtl* ctl,
+                                                          BktCtl* ctl_lr = nullptr, BktCtl* ctl_rl = nullptr) {
   __shared__ uint32_t tab[LOC_SLOTS];
   __shared__ uint32_t cnt;
   const int which = blockIdx.x >= LOC_BLOCKS ? 1 : 0;
@@ -279,12 +283,19 @@ __global__ __launch_bounds__(256) void idx_locality_kernel(const uint32_t* idx0,
     atomicAdd(&ctl->loc_rows[which], rows);
     __threadfence();
     if (atomicAdd(&ctl->loc_done, 1u) == gridDim.x - 1) {  // the last block: every total above is visible
-      bool local = true;
+      bool loc[2] = {true, true};
       for (int w = 0; w < (idx1 ? 2 : 1); w++) {
         const uint32_t d = atomicAdd(&ctl->loc_distinct[w], 0u), r = atomicAdd(&ctl->loc_rows[w], 0u);
-        local = local && (uint64_t)d * 2 < r;
+        loc[w] = (uint64_t)d * 2 < r;
       }
-      ctl->use_direct = local ? 1u : 0u;
+      const bool direct = loc[0] && loc[1];
+      ctl->run_direct = direct ? 1u : 0u;
+      // put, four ways: both local → direct; source local only → the destination-only pipeline (ctl_lr); destination local only → the
+      // take's merge-back pipeline storing through the destination column (ctl_rl); neither → the full pair pipeline (ctl)
+      const bool lr = ctl_lr && loc[0] && !loc[1], rl = ctl_rl && !loc[0] && loc[1];
+      if (ctl_lr) ctl_lr->use_direct = lr ? 0u : 1u;
+      if (ctl_rl) ctl_rl->use_direct = rl ? 0u : 1u;
+      ctl->use_direct = (direct || lr || rl) ? 1u : 0u;
     }
   }
 }
@@ -608,7 +619,7 @@ __device__ __forceinline__ bool bkt_tile_of_block(uint32_t ntiles, uint64_t* til
 __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si, const uint32_t* di, uint64_t n,
                                                              uint64_t n_src, uint64_t n_dst, int rs, uint32_t bs,
                                                              BktCtl* ctl, u32x2* pairs, const uint32_t* offsets, uint32_t nbp,
-                                                             uint32_t cur_stride, uint32_t ntiles) {
+                                                             uint32_t cur_stride, uint32_t ntiles, const void* gvals = nullptr, int gw = 0) {
   if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
   BKT_LDS_DECL;
   BKT_STAMP(0, 0);
@@ -645,6 +656,11 @@ __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si
       if (i >= n) r.key = BKT_INVALID;
       else if (di) r.key = (s[k] < n_src && d[k] < n_dst) ? (s[k] >> rs) : BKT_INVALID;
       else r.key = s[k] < n_src ? (s[k] >> rs) : bs;
+      if (gvals && r.key != BKT_INVALID) {  // the destination-only pipeline of a put: `si` is the DESTINATION column here, `di` the (local)
+                                            // source column — the pair carries the value itself, fetched with a near-streaming gather
+        r.b = gw == 4 ? static_cast<const uint32_t*>(gvals)[d[k]] : gw == 2 ? (uint32_t)static_cast<const uint16_t*>(gvals)[d[k]]
+                                                                          : (uint32_t)static_cast<const uint8_t*>(gvals)[d[k]];
+      }
     }
   }
   bkt_tile_sort(row, bs + 1, lcnt, sorted, wave_tot, &tile_rows, 0);
@@ -790,6 +806,13 @@ static int bkt_region_bits(const agpu_pipeline* p, uint64_t n_elems, int width) 
 static agpu_status launch_put_direct(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* src_idx, void* dst,
                                      uint64_t n_dst, const uint32_t* dst_idx, uint64_t n, const uint32_t* only_if);
 // di == nullptr: take (dst = out, n_dst = n).  Returns AGPU_ERR_UNSUPPORTED when the shape does not qualify.
+static agpu_status launch_put_through_take(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* si, void* dst, uint64_t n,
+                                           const uint32_t* di, uint64_t n_dst, const BktCtl* gate);
+// the rare case in which the destination-local variant of a put could not be enqueued after the probe was told about it: whatever
+// the probe gave to that variant goes to the direct kernel
+__global__ void bkt_flag_or_kernel(const BktCtl* rl, BktCtl* main) {
+  if (!rl->use_direct) main->run_direct = 1u;
+}
 static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* si,
                                    void* dst, uint64_t n_dst, const uint32_t* di, uint64_t n, bool adaptive = false) {
   if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || n_dst > 0xFFFFFFFFull || !aligned16(si) || (di && !aligned16(di)) ||
@@ -803,11 +826,12 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   while ((1 << (rs - src_line_shift)) > BKT_MAX) src_line_shift++;
   const uint32_t bs = (uint32_t)((n_src + ((uint64_t)1 << rs) - 1) >> rs), bd = (uint32_t)((n_dst + ((uint64_t)1 << rd) - 1) >> rd);
   agpu_device* dev = p->dev;
-  void *ctl_v = nullptr, *p1 = nullptr, *p2 = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr;
+  void *ctl_v = nullptr, *p1 = nullptr, *p2 = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr, *ctlb_v = nullptr, *ctlc_v = nullptr;
   const uint32_t ntiles = (uint32_t)((n + BKT_TILE - 1) / BKT_TILE);
   const uint32_t nbp = (bs + 1 + 3) & ~3u;  // padded row stride of the (tile × region) matrices
   const uint32_t nbp2 = (bd + 3) & ~3u;      // … of G's (tile × destination region) matrices: the same blocks, used after P is through
-  const uint32_t nbpm = nbp > nbp2 ? nbp : nbp2;
+  const uint32_t nbpB = (bd + 1 + 3) & ~3u;  // … of the destination-only pipeline's (tile × destination region) matrix
+  const uint32_t nbpm = (nbp > nbp2 ? nbp : nbp2) > nbpB ? (nbp > nbp2 ? nbp : nbp2) : nbpB;
   const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
   // Range starts of the partition pass: from a column scan of per-tile counts (default since round 3; "gather_offsets" = 1
   // brings the global-atomic reservations back).  Under round-robin tiles the scan form was never faster — the pass is
@@ -830,11 +854,24 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   // G's 75 000 cycles in the reservation phase) — at one workgroup per CU a tile's phases add up, but chip-wide the atomic unit's
   // 1.3 ms overlap with the other CUs' sorts; what is left of G is its own chain of phases (load → sort → gather → sort → store).
   const bool det2 = det && p->tune.gather_offsets == 2;
+  // put under the auto policy, three ways (idx_locality_kernel): both columns local → the direct scatter; SOURCE local only (the scatter
+  // of a contiguous or sorted selection) → the destination-only pipeline below: the values are fetched by a near-streaming gather inside
+  // the partition pass, pairs {destination, value} are partitioned by destination region once and stored by F — no source-side
+  // partition, no G; otherwise the full pipeline.  All three are enqueued over the same temporaries, two return at once.
+  // (from 2^26 rows: every variant costs a handful of empty launches when it stands down — ≈ 0.1 ms for both, too much for a 0.4 ms put)
+  const bool lr = adaptive && di && det && n >= ((uint64_t)1 << 26);
+  if (lr && st == AGPU_OK) st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctlb_v);
+  // … and DESTINATION local only (a gather into a contiguous or sorted selection): the take's merge-back pipeline with its merge pass
+  // storing through the destination column — no pairs at all
+  const bool rl = lr && n >= (uint64_t)BKT_T * 32;  // one tile of the merge-back pipeline (TK2_TILE, defined below)
+  if (rl && st == AGPU_OK) st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctlc_v);
   if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;  // no room for the 16 B/row of temporaries: the direct kernel needs none
   if (st == AGPU_OK) {
     BktCtl* ctl = static_cast<BktCtl*>(ctl_v);
     const uint32_t nblk = (ntiles + 7) / 8 * 8;
     hipError_t e = hipMemsetAsync(ctl, 0, sizeof(BktCtl), p->stream);
+    if (e == hipSuccess && lr) e = hipMemsetAsync(ctlb_v, 0, sizeof(BktCtl), p->stream);
+    if (e == hipSuccess && rl) e = hipMemsetAsync(ctlc_v, 0, sizeof(BktCtl), p->stream);
     if (e != hipSuccess) {
       agpu_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
       st = AGPU_ERR_HIP;
@@ -852,7 +889,7 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       const BktCtl* gate = adaptive ? ctl : nullptr;
       if (adaptive) {
         const int sh = width == 4 ? 5 : width == 2 ? 6 : 7;
-        hipLaunchKernelGGL(idx_locality_kernel, dim3(2 * LOC_BLOCKS), dim3(256), 0, p->stream, si, di, n, sh, sh, ctl);
+        hipLaunchKernelGGL(idx_locality_kernel, dim3(2 * LOC_BLOCKS), dim3(256), 0, p->stream, si, di, n, sh, sh, ctl, static_cast<BktCtl*>(ctlb_v), static_cast<BktCtl*>(ctlc_v));
       }
       hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags, counts, nbp, ntiles);
       if (det) {
@@ -888,7 +925,32 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
         default: st = AGPU_ERR_UNSUPPORTED; break;
       }
 #undef BKT_GF
-      if (st == AGPU_OK && adaptive) (void)launch_put_direct(p, width, src, n_src, si, dst, n_dst, di, n, &ctl->use_direct);
+      if (st == AGPU_OK && lr) {  // the destination-only pipeline: H, P and F with the two index columns in each other's roles
+        BktCtl* cb = static_cast<BktCtl*>(ctlb_v);
+        const dim3 cgridB((nbpB + 255) / 256, nchunks);
+        const uint32_t stride_b = bd + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_b2 = bs <= 1024 ? BKT_CUR_STRIDE : 1;
+        hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, rs, bd, bs, cb, p->flags, counts, nbpB, ntiles);
+        hipLaunchKernelGGL(bkt_colsum_kernel, cgridB, dim3(256), 0, p->stream, counts, nbpB, ntiles, csum, cb);
+        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbpB + 255) / 256), dim3(256), 0, p->stream, csum, nbpB, nchunks, cb->hist_s, cb);
+        hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, cb, bd, bs, rs, 1, stride_b, stride_b2);
+        hipLaunchKernelGGL(bkt_offsets_kernel, cgridB, dim3(256), 0, p->stream, counts, csum, nbpB, ntiles, cb->base_s, offsets, cb);
+        hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, bd, cb, static_cast<u32x2*>(p1), offsets, nbpB,
+                           stride_b, ntiles, src, width);
+        switch (width) {
+          case 4: hipLaunchKernelGGL((bkt_store_kernel<4>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), ntiles, cb, line_shift, static_cast<uint32_t*>(dst)); break;
+          case 2: hipLaunchKernelGGL((bkt_store_kernel<2>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), ntiles, cb, line_shift, static_cast<uint16_t*>(dst)); break;
+          default: hipLaunchKernelGGL((bkt_store_kernel<1>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), ntiles, cb, line_shift, static_cast<uint8_t*>(dst)); break;
+        }
+      }
+      if (st == AGPU_OK && rl) {
+        const agpu_status rs_ = launch_put_through_take(p, width, src, n_src, si, dst, n, di, n_dst, static_cast<const BktCtl*>(ctlc_v));
+        if (rs_ != AGPU_OK && rs_ != AGPU_ERR_UNSUPPORTED) st = rs_;
+        else if (rs_ == AGPU_ERR_UNSUPPORTED) {  // this variant cannot run: hand its case back to the full pipeline… which has already been
+                                                 // told to stand down by the probe — so let the direct kernel take it instead
+          hipLaunchKernelGGL(bkt_flag_or_kernel, dim3(1), dim3(1), 0, p->stream, static_cast<const BktCtl*>(ctlc_v), ctl);
+        }
+      }
+      if (st == AGPU_OK && adaptive) (void)launch_put_direct(p, width, src, n_src, si, dst, n_dst, di, n, &ctl->run_direct);
       if (st == AGPU_OK && hipGetLastError() != hipSuccess) {
         agpu_set_error("bucketed take/put launch failed");
         st = AGPU_ERR_HIP;
@@ -902,6 +964,8 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   if (p2) (void)agpu_free(dev, p2);
   if (p1) (void)agpu_free(dev, p1);
   if (ctl_v) (void)agpu_free(dev, ctl_v);
+  if (ctlb_v) (void)agpu_free(dev, ctlb_v);
+  if (ctlc_v) (void)agpu_free(dev, ctlc_v);
   return st;
 }
 
@@ -1334,18 +1398,21 @@ __global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemO
 
 // F2: out[i] = vals[offs[t][key(i)] + rank16[i]] — the tile's runs come into LDS as contiguous pieces, rows pick from there
 // MODE 0: values; 1: values + the source validity bits (agpu_take_validity); 2: bits only (Boolean take: no value array at all);
-// 3: bits only, leaving as the Boolean put's entries ent[i] = dst_idx[i] * 2 + bit (0xFFFFFFFF for a row with either index out of range)
+// 3: bits only, leaving as the Boolean put's entries ent[i] = dst_idx[i] * 2 + bit (0xFFFFFFFF for a row with either index out of range);
+// 4: a PUT whose destination column is local: out = the destination array, row i's value goes to out[dst_idx[i]] (rows with either index out
+//    of range are dropped and raise the sticky flag) — the source side is this pipeline's random gather, the destination side needs none
 template <int MODE, int W = 4>
 __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, uint64_t n, uint64_t n_src, int rs, uint32_t bs,
                                                          const uint16_t* counts, const uint32_t* offsets, uint32_t nbp,
                                                          uint32_t ntiles, const uint16_t* rank16, const typename ElemOf<W>::type* vals,
                                                          typename ElemOf<W>::type* out, const uint32_t* vbits_slot, uint64_t* out_validity,
-                                                         const uint32_t* di = nullptr, uint64_t n_dst = 0, const BktCtl* gate = nullptr) {
+                                                         const uint32_t* di = nullptr, uint64_t n_dst = 0, const BktCtl* gate = nullptr,
+                                                         uint32_t* flags = nullptr) {
   BKT_GATE(gate);
   typedef typename ElemOf<W>::type E;
-  static_assert(MODE < 3 || W == 4, "the entry array is 4 bytes wide");
+  static_assert(MODE != 3 || W == 4, "the entry array is 4 bytes wide");
   __shared__ uint32_t A[TK2_TILE];
-  constexpr bool BITS = MODE >= 1, VALUES = MODE <= 1, ENT = MODE == 3;
+  constexpr bool PUT = MODE == 4, BITS = MODE >= 1 && MODE <= 3, VALUES = MODE <= 1 || PUT, ENT = MODE == 3;
   __shared__ uint32_t bl[BITS ? TK2_TILE / 32 : 1];  // the validity bits of the tile's slots (BITS)
   __shared__ uint32_t lcnt[BKT_MAX];
   __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
@@ -1414,7 +1481,7 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
       const uint32_t key = s[e] < n_src32 ? (s[e] >> rs) : bs;
       sl[e] = (uint32_t)start16[key] + rank[e];
       A[sl[e]] = lcnt[key] + sl[e];
-      if constexpr (ENT) sl[e] |= s[e] < n_src32 ? 0u : 0x80000000u;  // the row's source index is out of range: its entry is dropped
+      if constexpr (ENT || PUT) sl[e] |= s[e] < n_src32 ? 0u : 0x80000000u;  // the row's source index is out of range: it is dropped
     }
   }
   __syncthreads();
@@ -1488,7 +1555,22 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
 #pragma unroll
   for (int q = 0; q < TK2_E / 4; q++) {
     const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
-    if constexpr (VALUES) {
+    if constexpr (PUT) {
+      u32x4 d = {0, 0, 0, 0};
+      if (i0 + 4 <= n) d = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + i0));
+      else
+        for (int k = 0; k < 4; k++)
+          if (i0 + k < n) d[k] = di[i0 + k];
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (i0 + k < n) {
+          const uint32_t slk = sl[q * 4 + k];
+          if (!(slk >> 31) && d[k] < n_dst) out[d[k]] = (E)A[slk];
+          else bad = true;
+        }
+      if (bad) *reinterpret_cast<volatile uint32_t*>(flags) = AGPU_FLAG_INDEX_RANGE;
+    } else if constexpr (VALUES) {
       if (i0 + 4 <= n) {
         const uint32_t a0 = A[sl[q * 4]], a1 = A[sl[q * 4 + 1]], a2 = A[sl[q * 4 + 2]], a3 = A[sl[q * 4 + 3]];
         if constexpr (W == 4) __builtin_nontemporal_store(u32x4{a0, a1, a2, a3}, reinterpret_cast<u32x4*>(out + i0));
@@ -1755,8 +1837,12 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
 #define TK2_GTHREADS BKT_T  // threads of a G2 workgroup (tile = 16 slots per thread): 1024 → two workgroups per CU; 512 → four (A/B, tools/probe)
 #endif
 static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void* values, uint64_t n_src, const uint32_t* si, void* out,
-                                         uint64_t n, const uint32_t* vbits_src = nullptr, uint64_t* out_validity = nullptr, bool adaptive = false) {
-  if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || !aligned16(si) || !aligned16(out) || p->capturing) return AGPU_ERR_UNSUPPORTED;
+                                         uint64_t n, const uint32_t* vbits_src = nullptr, uint64_t* out_validity = nullptr, bool adaptive = false,
+                                         const uint32_t* put_di = nullptr, uint64_t put_n_dst = 0, const BktCtl* ext_gate = nullptr) {
+  // put_di != nullptr: a PUT whose destination column is local — `out` is the destination array, the merge pass stores row i's value at
+  // out[put_di[i]]; ext_gate: the control block the put's locality probe wrote its decision for this pipeline to
+  if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || !aligned16(si) || (!put_di && !aligned16(out)) || (put_di && !aligned16(put_di)) || p->capturing)
+    return AGPU_ERR_UNSUPPORTED;
   if (width != 4 && width != 2 && width != 1) return AGPU_ERR_UNSUPPORTED;
   const int rs = bkt_region_bits(p, n_src, 4);
   const uint32_t bs = (uint32_t)((n_src + ((uint64_t)1 << rs) - 1) >> rs);
@@ -1789,7 +1875,7 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
     } else {
       const dim3 cgrid((nbp + 255) / 256, nchunks);
       // adaptive (the auto policy): the locality probe decides on the device whether these kernels or the direct one behind them run
-      const BktCtl* gate = adaptive ? ctl : nullptr;
+      const BktCtl* gate = ext_gate ? ext_gate : adaptive ? ctl : nullptr;
       if (adaptive)
         hipLaunchKernelGGL(idx_locality_kernel, dim3(LOC_BLOCKS), dim3(256), 0, p->stream, si, static_cast<const uint32_t*>(nullptr), n,
                            width == 4 ? 5 : width == 2 ? 6 : 7, 0, ctl);
@@ -1811,6 +1897,13 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
                          static_cast<const uint16_t*>(rank_v), static_cast<const E*>(vals_v), static_cast<E*>(out),                      \
                          reinterpret_cast<const uint32_t*>(vslot), out_validity, static_cast<const uint32_t*>(nullptr), (uint64_t)0,     \
                          gate);                                                                                                          \
+    } else if (put_di) {                                                                                                                 \
+      hipLaunchKernelGGL((tk2_gather_kernel<8, false, WW, TK2_GTHREADS>), ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src, \
+                         static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), static_cast<const uint32_t*>(nullptr), \
+                         static_cast<uint64_t*>(nullptr), gate);                                                                         \
+      hipLaunchKernelGGL((tk2_merge_kernel<4, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \
+                         static_cast<const uint16_t*>(rank_v), static_cast<const E*>(vals_v), static_cast<E*>(out),                      \
+                         static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr), put_di, put_n_dst, gate, p->flags);     \
     } else {                                                                                                                             \
       hipLaunchKernelGGL((tk2_gather_kernel<8, false, WW, TK2_GTHREADS>), ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src,       \
                          static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), static_cast<const uint32_t*>(nullptr), \
@@ -1840,6 +1933,11 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
   for (void* q : {vslot_v, csum_v, off_v, cnt_v, rank_v, vals_v, srcs_v, ctl_v})
     if (q) (void)agpu_free(dev, q);
   return st;
+}
+
+static agpu_status launch_put_through_take(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* si, void* dst, uint64_t n,
+                                           const uint32_t* di, uint64_t n_dst, const BktCtl* gate) {
+  return launch_take_mergeback(p, width, src, n_src, si, dst, n, nullptr, nullptr, false, di, n_dst, gate);
 }
 
 // tuning "gather_bucket": 0 = auto, 1 = always direct, 2 = bucketed whenever the shape qualifies (4-byte take: the
