@@ -859,7 +859,7 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   // the partition pass, pairs {destination, value} are partitioned by destination region once and stored by F — no source-side
   // partition, no G; otherwise the full pipeline.  All three are enqueued over the same temporaries, two return at once.
   // (from 2^26 rows: every variant costs a handful of empty launches when it stands down — ≈ 0.1 ms for both, too much for a 0.4 ms put)
-  const bool lr = adaptive && di && det && n >= ((uint64_t)1 << 26);
+  const bool lr = adaptive && di && det && (n >= ((uint64_t)1 << 26) || p->tune.gather_bucket == 4);  // (4: tests, any size)
   if (lr && st == AGPU_OK) st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctlb_v);
   // … and DESTINATION local only (a gather into a contiguous or sorted selection): the take's merge-back pipeline with its merge pass
   // storing through the destination column — no pairs at all

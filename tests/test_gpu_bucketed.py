@@ -620,3 +620,36 @@ def test_put_auto_policy_is_right_either_way(ctx, src_dist, dst_dist):
     eb = np.unpackbits(dbits, bitorder="little")
     eb[di] = np.unpackbits(sbits, bitorder="little")[si]
     assert np.array_equal(dev.retrive_data(ddb, n_dst // 8, pipeline=p), np.packbits(eb, bitorder="little"))
+
+
+@pytest.mark.parametrize("corner", ["source_local", "destination_local"])
+def test_put_with_one_local_column_at_2_26_rows(ctx, corner):
+    """the two extra forms of a put under the auto policy (from 2^26 rows): source column local → the destination-only pipeline;
+    destination column local → the take's merge-back pipeline storing through the destination column.  Distinct destinations."""
+    dev, p = ctx
+    n, n_src, n_dst = 1 << 26, 1 << 27, 1 << 27
+    rng = np.random.default_rng(53)
+    src = rng.integers(0, 1 << 32, n_src, dtype=np.uint64).astype(np.uint32)
+    dst = rng.integers(0, 1 << 32, n_dst, dtype=np.uint64).astype(np.uint32)
+    i = np.arange(n, dtype=np.uint64)
+    if corner == "source_local":
+        si = (i + 777).astype(np.uint32)
+        di = ((i * 0x9E3779B1) % n_dst).astype(np.uint32)  # an odd multiplier: a bijection on 2^27 — distinct, and no two neighbours share a line
+    else:
+        si = rng.integers(0, n_src, n, dtype=np.uint32)
+        di = (i * 2 + (i & 1)).astype(np.uint32)
+    si[::1_000_003] = n_src + 9  # a few rows with a source index out of range: dropped, sticky flag
+    ok = si < n_src
+    ds, dd, dsi, ddi = (dev.create_gpu_buffer_with_data(x) for x in (src, dst, si, di))
+    import arrow_gpu_amd as ag
+
+    try:
+        p.set_tuning("gather_bucket", 0)
+        capi.call("agpu_put_bounded", p._handle, 4, vp(ds), n_src, vp(dsi), vp(dd), n_dst, vp(ddi), n)
+        with pytest.raises(ag.ArrowErrorGPU):
+            p.sync()
+    finally:
+        p.set_tuning("gather_bucket", 2)
+    exp = dst.copy()
+    exp[di[ok]] = src[si[ok]]
+    assert np.array_equal(dev.retrive_data(dd, 4 * n_dst, pipeline=p).view(np.uint32), exp)

@@ -161,8 +161,13 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             dst = rand_values(dtype, n_dst, seed * 19 + it)
             si = rng.integers(0, n, k).astype(np.uint32)
             di = rng.permutation(n_dst)[:k].astype(np.uint32)  # unique destinations
-            if rng.random() < 0.4:
+            r = rng.random()  # local columns: both, the source only, the destination only — the put's four device-side forms
+            if r < 0.2:
                 si, di = np.sort(si), np.sort(di)
+            elif r < 0.4:
+                si = np.sort(si)
+            elif r < 0.6:
+                di = np.sort(di)
             ddst = D.up(dst, off(rng, w))
             D.call("agpu_put_bounded", w, D.up(a, off(rng, w)).vp, n, D.up(si, off(rng, 4)).vp, ddst.vp, n_dst,
                    D.up(di, off(rng, 4)).vp, k)
