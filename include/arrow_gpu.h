@@ -397,11 +397,13 @@ agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* v
  * which the next agpu_pipeline_sync reports once as AGPU_ERR_SHAPE.  No pre-pass over the indices, no readback.
  * take: out[i] = values[idx[i]], i < n_idx.
  * [ref: apply_take_op crates/routines/src/take.rs:9-55, 32bit/take.wgsl:13-17]
- * Large takes / puts (from 2^24 - 2^25 rows) are enqueued in TWO forms: a bucketed pipeline that moves the indices to the data
+ * Large takes / puts (from 2^24 - 2^25 rows) are enqueued in SEVERAL forms: a bucketed pipeline that moves the indices to the data
  * (random indices: 1.8 - 3.5x the direct kernels) and the direct kernel behind it.  A locality probe over the index column(s)
- * decides ON THE DEVICE which of the two does the work — sorted, sequential, clustered or few-valued indices (a take after a
- * filter) stream through the direct kernel, random ones go through the pipeline; the other form returns at once.  The call never
- * blocks.  Tuning "gather_bucket" = 1 / 2 forces direct / pipelined (no probe), 3 = the round-2 pair pipeline for takes. */
+ * decides ON THE DEVICE which form does the work — sorted, sequential, clustered or few-valued indices (a take after a filter)
+ * stream through the direct kernel, random ones go through the pipeline; the other forms return at once.  A put of 2^26 rows or
+ * more has two forms in between: source column local (the scatter of a contiguous or sorted selection) -> a destination-only
+ * pipeline, destination column local (the gather into one) -> the take's pipeline storing through the destination column.  The
+ * call never blocks.  Tuning "gather_bucket" = 1 / 2 forces direct / pipelined (no probe), 3 = the round-2 pair pipeline for takes. */
 agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const uint32_t* idx,
                       void* out, uint64_t n_idx);
 /* take of an array WITH NULLS in one call: out[i] = values[idx[i]] and out_validity bit i = validity bit idx[i] (n_values
