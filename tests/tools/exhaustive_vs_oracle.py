@@ -24,6 +24,8 @@ from arrow_gpu_amd import _capi as capi  # noqa: E402
 
 OPS = {"sin": capi.UN_SIN, "cos": capi.UN_COS, "sinh": capi.UN_SINH, "acos": capi.UN_ACOS, "exp": capi.UN_EXP, "exp2": capi.UN_EXP2,
        "log": capi.UN_LOG, "log2": capi.UN_LOG2, "sqrt": capi.UN_SQRT, "cbrt": capi.UN_CBRT}
+CASTS = {"cast_f32_u8": capi.U8, "cast_f32_i8": capi.I8, "cast_f32_u16": capi.U16, "cast_f32_i16": capi.I16, "cast_f32_u32": capi.U32,
+         "cast_f32_i32": capi.I32}  # every f32 bit pattern through agpu_cast against the oracle's cast: bit-exact or not
 CHUNK = 1 << 28
 PAIRS = 1 << 26    # pow: pairs per launch
 _X = _GOT = _Y = None  # inherited by the forked workers
@@ -32,6 +34,16 @@ _X = _GOT = _Y = None  # inherited by the forked workers
 def _ordered(v):
     b = v.view(np.int32).astype(np.int64)
     return np.where(b < 0, np.int64(-(2 ** 31)) - b, b)
+
+
+def _check_cast(args):
+    to, lo, hi = args
+    x = _X[lo:hi]
+    exp = O.cast(O.F32, to, x)
+    got = _GOT.view(np.uint8)[lo * exp.itemsize:hi * exp.itemsize].view(exp.dtype)
+    bad = got != exp
+    k = int(bad.argmax()) if bad.any() else 0
+    return int(bad.sum()), int(x.view(np.uint32)[k])
 
 
 def _check(args):
@@ -54,7 +66,7 @@ def main():
     global _X, _GOT, _Y
     import mmap
 
-    names = sys.argv[1:] or list(OPS) + ["pow"]
+    names = sys.argv[1:] or list(OPS) + ["pow"] + list(CASTS)
     workers = int(os.environ.get("AGPU_ORACLE_WORKERS", "16"))
     # the two chunk buffers are shared memory and the workers are forked BEFORE this process touches the GPU: no child ever
     # carries HIP state
@@ -129,6 +141,24 @@ def _run(names, workers, pool):
     vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
     res = {"what": "all 2^32 f32 bit patterns: agpu_unary on the device vs the CPU oracle (f64 libm rounded once to f32)", "functions": {}}
     for name in names:
+        if name in CASTS:
+            to, t0, mism, first_bad = CASTS[name], time.time(), 0, None
+            width = {capi.U8: 1, capi.I8: 1, capi.U16: 2, capi.I16: 2}.get(to, 4)
+            for c in range(16):
+                _X.view(np.uint32)[:] = np.arange(c * CHUNK, (c + 1) * CHUNK, dtype=np.uint32)
+                capi.call("agpu_upload", p._handle, vp(din), C.c_void_p(_X.ctypes.data), 4 * CHUNK)
+                capi.call("agpu_cast", p._handle, capi.F32, to, vp(din), vp(dout), CHUNK)
+                capi.call("agpu_download", p._handle, C.c_void_p(_GOT.ctypes.data), vp(dout), width * CHUNK)
+                p.sync()
+                step = CHUNK // (workers * 4)
+                for r in pool.imap_unordered(_check_cast, [(to, lo, lo + step) for lo in range(0, CHUNK, step)]):
+                    mism += r[0]
+                    if r[0] and first_bad is None:
+                        first_bad = r[1]
+            res["functions"][name] = {"patterns_not_bit_identical": mism, "first_mismatch_bits": None if first_bad is None else f"{first_bad:#010x}",
+                                      "max_ulp": 0 if mism == 0 else 1 << 30, "zeros_with_the_other_sign": 0, "seconds": round(time.time() - t0, 1)}
+            print(name, res["functions"][name], flush=True)
+            continue
         if name == "pow":
             res["functions"]["pow"] = _pow(p, pool, workers, din, dout, dev, vp)
             print("pow", res["functions"]["pow"], flush=True)
