@@ -89,6 +89,34 @@ def test_shifts(D, dtype):
             assert bits_equal(D.down(out, NP[dtype], n), O.binary(op, dtype, a, s)), (op, n)
 
 
+@pytest.mark.parametrize("dtype", [capi.U8, capi.I8])
+def test_every_operand_pair_of_the_8_bit_types(D, dtype):
+    """all 65 536 (a, b) pairs of an 8-bit type through every binary op, both shifts (amounts 0 … 255 reach past the width and past 32),
+    every compare and the scalar form — the whole input space of those kernels, bit-exact against the oracle"""
+    info = np.iinfo(NP[dtype])
+    vals = np.arange(info.min, info.max + 1, dtype=np.int64).astype(NP[dtype])
+    a, b = np.repeat(vals, 256), np.tile(vals, 256)
+    n = len(a)
+    da, db, out = D.up(a), D.up(b), D.empty(n)
+    for op in SMALL_BIN:
+        D.call("agpu_binary", op, dtype, da.vp, db.vp, out.vp, n)
+        assert bits_equal(D.down(out, NP[dtype], n), O.binary(op, dtype, a, b)), op
+    amounts = np.tile(np.arange(256, dtype=np.uint32), 256)
+    dam = D.up(amounts)
+    for op in (capi.OP_SHL, capi.OP_SHR):
+        D.call("agpu_binary", op, dtype, da.vp, dam.vp, out.vp, n)
+        assert bits_equal(D.down(out, NP[dtype], n), O.binary(op, dtype, a, amounts)), op
+    outb = D.empty(O.bitmap_bytes(n) + 8)
+    for op in range(5):
+        D.call("agpu_compare", op, dtype, da.vp, db.vp, outb.vp, n)
+        assert bits_equal(D.down(outb, np.uint8, O.bitmap_bytes(n)), O.compare(op, dtype, a, b)), op
+    for sv in (vals[0], vals[-1], vals[len(vals) // 2], vals[3]):
+        sarr = np.array([sv], NP[dtype])
+        for op in SMALL_BIN:
+            D.call("agpu_scalar", op, dtype, da.vp, D.up(sarr).vp, out.vp, n)
+            assert bits_equal(D.down(out, NP[dtype], n), O.scalar(op, dtype, a, sarr)), (op, sv)
+
+
 def test_int32_power(D):
     n = 5003
     rng = np.random.default_rng(3)
