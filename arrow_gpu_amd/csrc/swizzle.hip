@@ -1940,9 +1940,11 @@ static agpu_status launch_put_through_take(agpu_pipeline* p, int width, const vo
   return launch_take_mergeback(p, width, src, n_src, si, dst, n, nullptr, nullptr, false, di, n_dst, gate);
 }
 
-// tuning "gather_bucket": 0 = auto, 1 = always direct, 2 = bucketed whenever the shape qualifies (4-byte take: the
-// merge-back pipeline), 3 = like 2 but 4-byte takes keep the pair pipeline (A/B).
-// Auto, from one-process A/B sweeps on MI355X (tools/probe/bucket_sweep.py --crossover3 → profiles/r03_gather_crossover.json,
+// tuning "gather_bucket": 0 = auto, 1 = always direct, 2 = bucketed whenever the shape qualifies (take: the merge-back
+// pipeline), 3 = like 2 but takes keep the pair pipeline (A/B), 4 = like 2 plus the device-side locality probe (tests).
+// Auto is two decisions: THIS one, on the host, by size and sparsity — is a pipeline worth enqueuing at all? — and the probe's,
+// on the device, by what the index columns look like (idx_locality_kernel) — which of the enqueued forms does the work.
+// The size thresholds, from one-process A/B sweeps on MI355X (tools/probe/bucket_sweep.py --crossover3 → profiles/r03_gather_crossover.json,
 // r03_gather_sweep.json; uniformly random 4-byte rows): TAKE goes bucketed from 2^25 rows when the source is at least
 // 16 MiB and not sparser than 1 row in 8 elements — merge-back 1.2–1.5× at 2^25 rows, 1.3–1.7× at 2^26, 1.8–2.1× at 2^28
 // (48 → 90–113 G rows/s); at 2^24 rows it wins only 1.1–1.2× and loses against a sparse source, below that the six launches
