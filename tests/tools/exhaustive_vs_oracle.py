@@ -26,6 +26,9 @@ OPS = {"sin": capi.UN_SIN, "cos": capi.UN_COS, "sinh": capi.UN_SINH, "acos": cap
        "log": capi.UN_LOG, "log2": capi.UN_LOG2, "sqrt": capi.UN_SQRT, "cbrt": capi.UN_CBRT}
 CASTS = {"cast_f32_u8": capi.U8, "cast_f32_i8": capi.I8, "cast_f32_u16": capi.U16, "cast_f32_i16": capi.I16, "cast_f32_u32": capi.U32,
          "cast_f32_i32": capi.I32}  # every f32 bit pattern through agpu_cast against the oracle's cast: bit-exact or not
+BIN16 = {f"{tn}_{on}": (t, o) for tn, t in (("u16", capi.U16), ("i16", capi.I16))
+         for on, o in (("add", capi.OP_ADD), ("sub", capi.OP_SUB), ("mul", capi.OP_MUL), ("min", capi.OP_MIN), ("max", capi.OP_MAX),
+                       ("and", capi.OP_AND), ("or", capi.OP_OR), ("xor", capi.OP_XOR))}  # every operand PAIR of a 16-bit type: 2^32 pairs
 CHUNK = 1 << 28
 PAIRS = 1 << 26    # pow: pairs per launch
 _X = _GOT = _Y = None  # inherited by the forked workers
@@ -34,6 +37,18 @@ _X = _GOT = _Y = None  # inherited by the forked workers
 def _ordered(v):
     b = v.view(np.int32).astype(np.int64)
     return np.where(b < 0, np.int64(-(2 ** 31)) - b, b)
+
+
+def _check_bin16(args):
+    (t, o), lo, hi = args
+    ab = _X.view(np.uint16)[2 * lo:2 * hi].reshape(-1, 2)  # pair j of the chunk = (a, b) = (high half, low half) of the pair's number
+    dt = np.uint16 if t == capi.U16 else np.int16
+    a, b = np.ascontiguousarray(ab[:, 1]).view(dt), np.ascontiguousarray(ab[:, 0]).view(dt)
+    exp = O.binary(o, t, a, b)
+    got = _GOT.view(np.uint16)[lo:hi].view(dt)
+    bad = got != exp
+    k = int(bad.argmax()) if bad.any() else 0
+    return int(bad.sum()), int(_X.view(np.uint32)[lo + k])
 
 
 def _check_cast(args):
@@ -66,7 +81,9 @@ def main():
     global _X, _GOT, _Y
     import mmap
 
-    names = sys.argv[1:] or list(OPS) + ["pow"] + list(CASTS)
+    names = sys.argv[1:] or list(OPS) + ["pow"] + list(CASTS)  # (the 16-bit pair sweeps, ≈ 15 s each, only by name: "u16_add" …, or "bin16" for all)
+    if "bin16" in names:
+        names = [x for x in names if x != "bin16"] + list(BIN16)
     workers = int(os.environ.get("AGPU_ORACLE_WORKERS", "16"))
     # the two chunk buffers are shared memory and the workers are forked BEFORE this process touches the GPU: no child ever
     # carries HIP state
@@ -158,6 +175,29 @@ def _run(names, workers, pool):
             res["functions"][name] = {"patterns_not_bit_identical": mism, "first_mismatch_bits": None if first_bad is None else f"{first_bad:#010x}",
                                       "max_ulp": 0 if mism == 0 else 1 << 30, "zeros_with_the_other_sign": 0, "seconds": round(time.time() - t0, 1)}
             print(name, res["functions"][name], flush=True)
+            continue
+        if name in BIN16:
+            t, o = BIN16[name]
+            t0, mism, first_bad = time.time(), 0, None
+            da, db = dev.create_empty_buffer(2 * CHUNK), dev.create_empty_buffer(2 * CHUNK)
+            for c in range(16):
+                pair = np.arange(c * CHUNK, (c + 1) * CHUNK, dtype=np.uint32)
+                _X.view(np.uint32)[:] = pair
+                a16, b16 = (pair >> 16).astype(np.uint16), (pair & 0xFFFF).astype(np.uint16)
+                capi.call("agpu_upload", p._handle, vp(da), C.c_void_p(a16.ctypes.data), 2 * CHUNK)
+                capi.call("agpu_upload", p._handle, vp(db), C.c_void_p(b16.ctypes.data), 2 * CHUNK)
+                capi.call("agpu_binary", p._handle, o, t, vp(da), vp(db), vp(dout), CHUNK)
+                capi.call("agpu_download", p._handle, C.c_void_p(_GOT.ctypes.data), vp(dout), 2 * CHUNK)
+                p.sync()
+                step = CHUNK // (workers * 4)
+                for r in pool.imap_unordered(_check_bin16, [((t, o), lo, lo + step) for lo in range(0, CHUNK, step)]):
+                    mism += r[0]
+                    if r[0] and first_bad is None:
+                        first_bad = r[1]
+            res["functions"][name] = {"pairs": 1 << 32, "pairs_not_bit_identical": mism, "first_mismatch_pair": None if first_bad is None else f"{first_bad:#010x}",
+                                      "max_ulp": 0 if mism == 0 else 1 << 30, "zeros_with_the_other_sign": 0, "seconds": round(time.time() - t0, 1)}
+            print(name, res["functions"][name], flush=True)
+            del da, db
             continue
         if name == "pow":
             res["functions"]["pow"] = _pow(p, pool, workers, din, dout, dev, vp)
