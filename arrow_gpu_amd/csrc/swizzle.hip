@@ -250,7 +250,8 @@ struct BktCtl {  // device-side control block
 // ctl_lr != nullptr (put): the control block of the destination-only pipeline, which runs when the SOURCE column is local and the
 // destination column is not (a scatter of a contiguous or sorted selection: the source side needs no partition at all)
 __global__ __launch_bounds__(256) void idx_locality_kernel(const uint32_t* idx0, const uint32_t* idx1, uint64_t n, int shift0, int shift1, BktCtl* ctl,
-                                                          BktCtl* ctl_lr = nullptr, BktCtl* ctl_rl = nullptr) {
+                                                          BktCtl* ctl_lr = nullptr, BktCtl* ctl_rl = nullptr, uint32_t* host_word = nullptr,
+                                                          uint32_t tag = 0) {
   __shared__ uint32_t tab[LOC_SLOTS];
   __shared__ uint32_t cnt;
   const int which = blockIdx.x >= LOC_BLOCKS ? 1 : 0;
@@ -290,6 +291,9 @@ __global__ __launch_bounds__(256) void idx_locality_kernel(const uint32_t* idx0,
       }
       const bool direct = loc[0] && loc[1];
       ctl->run_direct = direct ? 1u : 0u;
+      // the same answer for the HOST, should it be listening (probe_decide): {tag : 28, valid : 1, -, column 1 local, column 0 local}
+      if (host_word)
+        __hip_atomic_store(host_word, (tag << 4) | 8u | (loc[1] ? 2u : 0u) | (loc[0] ? 1u : 0u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       // put, four ways: both local → direct; source local only → the destination-only pipeline (ctl_lr); destination local only → the
       // take's merge-back pipeline storing through the destination column (ctl_rl); neither → the full pair pipeline (ctl)
       const bool lr = ctl_lr && loc[0] && !loc[1], rl = ctl_rl && !loc[0] && loc[1];
@@ -805,6 +809,40 @@ static int bkt_region_bits(const agpu_pipeline* p, uint64_t n_elems, int width) 
 
 static agpu_status launch_put_direct(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* src_idx, void* dst,
                                      uint64_t n_dst, const uint32_t* dst_idx, uint64_t n, const uint32_t* only_if);
+// The probe's answer on the HOST, when it is there in time: the probe is launched by itself, the host polls a pinned word (the
+// pipeline's error-word slot, second word) for at most 150 µs.  On an idle stream — every default-API call has a pipeline of its own —
+// the answer arrives in ≈ 25 µs and ONLY the chosen form is enqueued: no empty launches at all.  On a busy stream the wait times out
+// (−1) and the caller enqueues all forms gated by the device-side copy of the same decision, as before.  Returns bit 0: column 0 local,
+// bit 1: column 1 local.
+#include <atomic>
+#include <chrono>
+static std::atomic<uint32_t> g_probe_tag{1};
+static int probe_decide(agpu_pipeline* p, const uint32_t* idx0, const uint32_t* idx1, uint64_t n, int shift0, int shift1) {
+  if (!p->flags || p->capturing) return -1;
+  void* ctl_v = nullptr;
+  if (agpu_malloc(p->dev, sizeof(BktCtl), 0, &ctl_v) != AGPU_OK) return -1;
+  int result = -1;
+  if (hipMemsetAsync(ctl_v, 0, sizeof(BktCtl), p->stream) == hipSuccess) {
+    const uint32_t tag = g_probe_tag.fetch_add(1, std::memory_order_relaxed) & 0x0FFFFFFFu;
+    volatile uint32_t* w = p->flags + 1;
+    hipLaunchKernelGGL(idx_locality_kernel, dim3(idx1 ? 2 * LOC_BLOCKS : LOC_BLOCKS), dim3(256), 0, p->stream, idx0, idx1, n, shift0, shift1,
+                       static_cast<BktCtl*>(ctl_v), static_cast<BktCtl*>(nullptr), static_cast<BktCtl*>(nullptr), const_cast<uint32_t*>(w), tag);
+    if (hipGetLastError() == hipSuccess) {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        const uint32_t v = *w;
+        if ((v >> 4) == tag && (v & 8u)) {
+          result = (int)(v & 3u);
+          break;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(150)) break;
+      }
+    }
+  }
+  (void)agpu_free(p->dev, ctl_v);
+  return result;
+}
+
 // di == nullptr: take (dst = out, n_dst = n).  Returns AGPU_ERR_UNSUPPORTED when the shape does not qualify.
 static agpu_status launch_put_through_take(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* si, void* dst, uint64_t n,
                                            const uint32_t* di, uint64_t n_dst, const BktCtl* gate);
@@ -966,6 +1004,62 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   if (ctl_v) (void)agpu_free(dev, ctl_v);
   if (ctlb_v) (void)agpu_free(dev, ctlb_v);
   if (ctlc_v) (void)agpu_free(dev, ctlc_v);
+  return st;
+}
+
+// The destination-only pipeline of a put by itself (the host already knows the source column is local — probe_decide): the same
+// kernels as inside launch_bucketed, nothing gated, only its own temporaries.
+static agpu_status launch_put_dst_only(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* si, void* dst, uint64_t n_dst,
+                                       const uint32_t* di, uint64_t n) {
+  if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || n_dst > 0xFFFFFFFFull || !aligned16(si) || !aligned16(di) || p->capturing) return AGPU_ERR_UNSUPPORTED;
+  const int rs = bkt_region_bits(p, n_src, width), rd = bkt_region_bits(p, n_dst, width);
+  int line_shift = width == 4 ? 5 : width == 2 ? 6 : 7;
+  while ((1 << (rd - line_shift)) > BKT_MAX) line_shift++;
+  const uint32_t bs = (uint32_t)((n_src + ((uint64_t)1 << rs) - 1) >> rs), bd = (uint32_t)((n_dst + ((uint64_t)1 << rd) - 1) >> rd);
+  agpu_device* dev = p->dev;
+  const uint32_t ntiles = (uint32_t)((n + BKT_TILE - 1) / BKT_TILE), nbpB = (bd + 1 + 3) & ~3u, nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
+  void *ctl_v = nullptr, *p1 = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr;
+  agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p1);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbpB * 2, 0, &cnt_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbpB * 4, 0, &off_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)nchunks * nbpB * 4, 0, &csum_v);
+  if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;
+  if (st == AGPU_OK) {
+    BktCtl* cb = static_cast<BktCtl*>(ctl_v);
+    uint16_t* counts = static_cast<uint16_t*>(cnt_v);
+    uint32_t* offsets = static_cast<uint32_t*>(off_v);
+    uint32_t* csum = static_cast<uint32_t*>(csum_v);
+    if (hipMemsetAsync(cb, 0, sizeof(BktCtl), p->stream) != hipSuccess) {
+      agpu_set_error("hipMemsetAsync failed");
+      st = AGPU_ERR_HIP;
+    } else {
+      const uint32_t nblk = (ntiles + 7) / 8 * 8;
+      uint64_t hg = (uint64_t)dev->num_cus * 2;
+      if (hg > ntiles) hg = ntiles;
+      const dim3 cgridB((nbpB + 255) / 256, nchunks);
+      const uint32_t stride_b = bd + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_b2 = bs <= 1024 ? BKT_CUR_STRIDE : 1;
+      hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, rs, bd, bs, cb, p->flags, counts, nbpB, ntiles);
+      hipLaunchKernelGGL(bkt_colsum_kernel, cgridB, dim3(256), 0, p->stream, counts, nbpB, ntiles, csum, static_cast<const BktCtl*>(nullptr));
+      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbpB + 255) / 256), dim3(256), 0, p->stream, csum, nbpB, nchunks, cb->hist_s, static_cast<const BktCtl*>(nullptr));
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, cb, bd, bs, rs, 1, stride_b, stride_b2);
+      hipLaunchKernelGGL(bkt_offsets_kernel, cgridB, dim3(256), 0, p->stream, counts, csum, nbpB, ntiles, cb->base_s, offsets, static_cast<const BktCtl*>(nullptr));
+      hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, bd, cb, static_cast<u32x2*>(p1), offsets, nbpB, stride_b,
+                         ntiles, src, width);
+      switch (width) {
+        case 4: hipLaunchKernelGGL((bkt_store_kernel<4>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), ntiles, cb, line_shift, static_cast<uint32_t*>(dst)); break;
+        case 2: hipLaunchKernelGGL((bkt_store_kernel<2>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), ntiles, cb, line_shift, static_cast<uint16_t*>(dst)); break;
+        case 1: hipLaunchKernelGGL((bkt_store_kernel<1>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), ntiles, cb, line_shift, static_cast<uint8_t*>(dst)); break;
+        default: st = AGPU_ERR_UNSUPPORTED; break;
+      }
+      if (st == AGPU_OK && hipGetLastError() != hipSuccess) {
+        agpu_set_error("destination-only put launch failed");
+        st = AGPU_ERR_HIP;
+      }
+    }
+  }
+  for (void* q : {csum_v, off_v, cnt_v, p1, ctl_v})
+    if (q) (void)agpu_free(dev, q);
   return st;
 }
 
@@ -2048,7 +2142,13 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
   if ((width == 1 || width == 2 || width == 4) && n_values != UINT64_MAX && want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
     if (p->tune.gather_bucket != 3 && n_idx >= TK2_TILE) {  // "gather_bucket" = 3: the pair pipeline, for A/B
-      const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx, nullptr, nullptr, p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4);
+      bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;
+      if (p->tune.gather_bucket == 0) {  // the probe's answer on the host, if it comes in time: only the chosen form is enqueued
+        const int d = probe_decide(p, idx, nullptr, n_idx, width == 4 ? 5 : width == 2 ? 6 : 7, 0);
+        if (d >= 0 && (d & 1)) return launch_take_direct(p, width, values, n_values, idx, out, n_idx, nullptr);
+        if (d >= 0) adaptive = false;
+      }
+      const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx, nullptr, nullptr, adaptive);
       if (ms != AGPU_ERR_UNSUPPORTED) return ms;
     }
     const agpu_status bs = launch_bucketed(p, width, values, n_values, idx, out, n_idx, nullptr, n_idx);
@@ -2069,9 +2169,20 @@ agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* valu
     AGPU_REQUIRE(aligned_to(validity, 4) && aligned_to(out_validity, 8), AGPU_ERR_SHAPE, "bitmap alignment");
     if ((width == 4 || width == 2 || width == 1) && n_values != UINT64_MAX && p->tune.gather_bucket != 3 && n_idx >= TK2_TILE &&
         want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
+      bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;
+      bool go_direct = false;
+      if (p->tune.gather_bucket == 0) {
+        const int d = probe_decide(p, idx, nullptr, n_idx, width == 4 ? 5 : width == 2 ? 6 : 7, 0);
+        if (d >= 0 && (d & 1)) go_direct = true;
+        else if (d >= 0) adaptive = false;
+      }
+      if (go_direct) {
+        const agpu_status st1 = launch_take_direct(p, width, values, n_values, idx, out, n_idx, nullptr);
+        if (st1 != AGPU_OK) return st1;
+        return launch_take_bits_direct(p, validity, n_values, idx, out_validity, n_idx, nullptr);
+      }
       const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx,
-                                                   static_cast<const uint32_t*>(validity), static_cast<uint64_t*>(out_validity),
-                                                   p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4);
+                                                   static_cast<const uint32_t*>(validity), static_cast<uint64_t*>(out_validity), adaptive);
       if (ms != AGPU_ERR_UNSUPPORTED) return ms;
     }
   }
@@ -2089,8 +2200,14 @@ static agpu_status take_bits_impl(agpu_pipeline* p, const void* bits, uint64_t n
       (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 4 ||
        (n_idx >= ((uint64_t)1 << 25) && n_bits >= ((uint64_t)1 << 27) && n_bits / 8 <= n_idx))) {
     // round 3: the merge-back pipeline with the bitmap's words as the elements (auto: ≥ 2^25 rows from a bitmap of ≥ 16 MiB)
+    bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;
+    if (p->tune.gather_bucket == 0) {
+      const int d = probe_decide(p, idx, nullptr, n_idx, 10, 0);
+      if (d >= 0 && (d & 1)) return launch_take_bits_direct(p, bits, n_bits, idx, out_bits, n_idx, nullptr);
+      if (d >= 0) adaptive = false;
+    }
     const agpu_status ms = launch_take_bits_mergeback(p, static_cast<const uint32_t*>(bits), n_bits, idx, static_cast<uint64_t*>(out_bits), n_idx,
-                                                      nullptr, 0, nullptr, p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4);
+                                                      nullptr, 0, nullptr, adaptive);
     if (ms != AGPU_ERR_UNSUPPORTED) return ms;
   }
   return launch_take_bits_direct(p, bits, n_bits, idx, out_bits, n_idx, nullptr);
@@ -2158,21 +2275,30 @@ static agpu_status launch_put_bits_bucketed(agpu_pipeline* p, const uint32_t* sr
   if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbp * 4, 0, &off_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)nchunks * nbp * 4, 0, &csum_v);
   if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;
-  bool have_entries = false;
+  bool have_entries = false, src_local_known = false;
   if (st == AGPU_OK && n >= TK2_TILE &&
       (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 4 || (n >= ((uint64_t)1 << 25) && n_src >= ((uint64_t)1 << 27) && n_src / 8 <= n))) {
     // T + E in one: the Boolean take's merge pass emits the entries itself (no natural-order bitmap in between)
-    const bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;  // local source indices: the merge-back kernels return, the direct gather + E run
+    bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;  // local source indices: the merge-back kernels return, the direct gather + E run
+    if (p->tune.gather_bucket == 0) {
+      const int d = probe_decide(p, si, nullptr, n, 10, 0);
+      if (d >= 0) {
+        adaptive = false;
+        src_local_known = (d & 1) != 0;
+      }
+    }
     if (adaptive && agpu_malloc(dev, (n + 63) / 64 * 8 + 16, 0, &tb_v) != AGPU_OK) tb_v = nullptr;
-    const agpu_status ms = launch_take_bits_mergeback(p, src_bits, n_src, si, nullptr, n, di, n_dst, static_cast<uint32_t*>(ent_v), adaptive && tb_v, tb_v);
-    if (ms == AGPU_OK) have_entries = true;
-    else if (ms != AGPU_ERR_UNSUPPORTED) st = ms;
+    if (!src_local_known) {  // (known local: straight to the direct bit gather + E below)
+      const agpu_status ms = launch_take_bits_mergeback(p, src_bits, n_src, si, nullptr, n, di, n_dst, static_cast<uint32_t*>(ent_v), adaptive && tb_v, tb_v);
+      if (ms == AGPU_OK) have_entries = true;
+      else if (ms != AGPU_ERR_UNSUPPORTED) st = ms;
+    }
   }
   if (st == AGPU_OK && !have_entries) {
     // T: out-of-range source indices read 0 here and raise the flag; E drops those rows
     if (!tb_v) st = agpu_malloc(dev, (n + 63) / 64 * 8 + 16, 0, &tb_v);
     if (st != AGPU_OK) st = AGPU_ERR_UNSUPPORTED;
-    else st = take_bits_impl(p, src_bits, n_src, si, tb_v, n);
+    else st = src_local_known ? launch_take_bits_direct(p, src_bits, n_src, si, tb_v, n, nullptr) : take_bits_impl(p, src_bits, n_src, si, tb_v, n);
   }
   if (st == AGPU_OK) {
     BktCtl* ctl = static_cast<BktCtl*>(ctl_v);
@@ -2219,7 +2345,22 @@ agpu_status agpu_put_bounded(agpu_pipeline* p, int32_t width, const void* src, u
   AGPU_REQUIRE(src && src_idx && dst && dst_idx, AGPU_ERR_ARG, "null pointer");
   if ((width == 1 || width == 2 || width == 4) && n_src != UINT64_MAX && n_dst != UINT64_MAX &&
       want_bucketed(p, width, n, n_src, n_dst, true)) {
-    const agpu_status bs = launch_bucketed(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n, p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4);
+    bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;
+    if (p->tune.gather_bucket == 0) {  // the probe's answer on the host, if it comes in time: ONE form is enqueued, nothing gated
+      const int sh = width == 4 ? 5 : width == 2 ? 6 : 7;
+      const int d = probe_decide(p, src_idx, dst_idx, n, sh, sh);
+      if (d == 3) return launch_put_direct(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n, nullptr);
+      if (d == 1) {  // source local, destination random
+        const agpu_status ls = launch_put_dst_only(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n);
+        if (ls != AGPU_ERR_UNSUPPORTED) return ls;
+      }
+      if (d == 2 && n >= TK2_TILE) {  // source random, destination local
+        const agpu_status ls = launch_put_through_take(p, width, src, n_src, src_idx, dst, n, dst_idx, n_dst, nullptr);
+        if (ls != AGPU_ERR_UNSUPPORTED) return ls;
+      }
+      if (d >= 0) adaptive = false;  // both random (or a form that could not run): the full pipeline, nothing gated
+    }
+    const agpu_status bs = launch_bucketed(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n, adaptive);
     if (bs != AGPU_ERR_UNSUPPORTED) return bs;
   }
   return launch_put_direct(p, width, src, n_src, src_idx, dst, n_dst, dst_idx, n, nullptr);

@@ -403,7 +403,8 @@ agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* v
  * stream through the direct kernel, random ones go through the pipeline; the other forms return at once.  A put of 2^26 rows or
  * more has two forms in between: source column local (the scatter of a contiguous or sorted selection) -> a destination-only
  * pipeline, destination column local (the gather into one) -> the take's pipeline storing through the destination column.  The
- * call never blocks.  Tuning "gather_bucket" = 1 / 2 forces direct / pipelined (no probe), 3 = the round-2 pair pipeline for takes. */
+ * host waits at most 150 us for the probe's answer (an idle stream delivers it in ~25 us) and then enqueues only the chosen form;
+ * without the answer every form is enqueued, gated on the device.  The call never blocks beyond that.  Tuning "gather_bucket" = 1 / 2 forces direct / pipelined (no probe), 3 = the round-2 pair pipeline for takes. */
 agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const uint32_t* idx,
                       void* out, uint64_t n_idx);
 /* take of an array WITH NULLS in one call: out[i] = values[idx[i]] and out_validity bit i = validity bit idx[i] (n_values
