@@ -653,3 +653,30 @@ def test_put_with_one_local_column_at_2_26_rows(ctx, corner):
     exp = dst.copy()
     exp[di[ok]] = src[si[ok]]
     assert np.array_equal(dev.retrive_data(dd, 4 * n_dst, pipeline=p).view(np.uint32), exp)
+
+
+def test_auto_policy_on_a_busy_stream_falls_back_to_the_gated_forms(ctx):
+    """the host waits 150 µs for the probe's answer; with milliseconds of work queued ahead on the same stream it cannot come in time, so every
+    form is enqueued and the device-side copy of the decision picks — same results (sorted and random index columns, take and put)"""
+    dev, p = ctx
+    n, n_src = 1 << 25, 1 << 27
+    rng = np.random.default_rng(61)
+    values = rng.integers(0, 1 << 32, n_src, dtype=np.uint64).astype(np.uint32)
+    dv = dev.create_gpu_buffer_with_data(values)
+    ballast = dev.create_empty_buffer(1 << 32)
+    try:
+        p.set_tuning("gather_bucket", 0)
+        for dist in ("sorted", "uniform"):
+            idx = rng.integers(0, n_src, n, dtype=np.uint32)
+            if dist == "sorted":
+                idx = np.sort(idx)
+            di = dev.create_gpu_buffer_with_data(idx)
+            out = dev.create_empty_buffer(4 * n)
+            p.sync()
+            for _ in range(6):  # ≈ 4 ms of fills ahead of the take
+                capi.call("agpu_memset", p._handle, vp(ballast), 0x5A, 1 << 32)
+            capi.call("agpu_take", p._handle, 4, vp(dv), n_src, vp(di), vp(out), n)
+            p.sync()
+            assert np.array_equal(dev.retrive_data(out, 4 * n, pipeline=p).view(np.uint32), values[idx])
+    finally:
+        p.set_tuning("gather_bucket", 2)
