@@ -18,7 +18,7 @@ p = ArrowComputePipeline(dev, "dist")
 q = CmpQuery(dev)
 h = p._handle
 vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
-n = 1 << 26
+n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 26)
 n_col = 1 << 28
 src, dst = dev.create_empty_buffer(4 * n_col), dev.create_empty_buffer(4 * n_col)
 capi.call("agpu_synth_i32", h, vp(src), n_col, 1, 0, 0)
