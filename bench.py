@@ -77,6 +77,18 @@ def check_config_windows(cfg_windows):
 
     out = {}
     for name, w in cfg_windows.items():
+        if name.startswith("swz_"):  # take-shaped results: row j of the window holds the value / bit at idx[j]
+            m, w0, rows = w["m"], w["w0"], w["rows"]
+            idx = O.synth_i32(rows, SEED + 8, w0, m).view(np.uint32)
+            ok = True
+            if "got" in w:
+                exp = np.array([O.synth_i32(1, SEED + 7, int(i), 0)[0] for i in idx], np.int32).view(np.uint32)
+                ok &= bool(np.array_equal(np.asarray(w["got"]).view(np.uint32), exp))
+            if "bits" in w:
+                eb = np.array([O.synth_bits(1, SEED + 10, int(i), 0.5)[0] & 1 for i in idx], np.uint8)
+                ok &= bool(np.array_equal(np.unpackbits(np.asarray(w["bits"]), bitorder="little")[:rows], eb))
+            out[name] = "bit-exact" if ok else "MISMATCH"
+            continue
         cnt, r0, got = w["rows"], w["row"], w["got"]
         fa = lambda: O.synth_f32(cnt, SEED, r0, -1000.0, 1000.0)  # noqa: E731
         fb = lambda: O.synth_f32(cnt, SEED + 1, r0, -1000.0, 1000.0)  # noqa: E731
@@ -681,6 +693,74 @@ def main():
             del pool, pfa, pfb, pfo, pia, pib, pva, pvb, pob, pov
         except Exception as e:  # noqa: BLE001
             extra["layout_pool"] = {"error": f"{type(e).__name__}: {e}"}
+
+    # ---- north_star's "take / put … scatter-gather in crates/routines": 2^28 rows, uniformly random indices unless said otherwise, through
+    # the auto policy (a locality probe over the index columns picks the form); G rows/s, median of 5 HIP-event timings.  One 4096-row
+    # window of the well-defined results goes to the cpu_baseline leg for the oracle.  Reported beside the headline; not part of `value`.
+    if rank == 0 and world == 1 and not args.no_extra_configs and n >= (1 << 28):
+        try:
+            import numpy as np
+
+            m = 1 << 28
+            V, I1, I2, SEQ, OUT = (dev.create_empty_buffer(4 * m) for _ in range(5))
+            VB, OB = dev.create_empty_buffer(m // 8 + 64), dev.create_empty_buffer(m // 8 + 64)
+            capi.call("agpu_synth_i32", h, vp(V), m, SEED + 7, 0, 0)
+            capi.call("agpu_synth_i32", h, vp(I1), m, SEED + 8, 0, m)
+            capi.call("agpu_synth_i32", h, vp(I2), m, SEED + 9, 0, m)
+            capi.call("agpu_synth_bits", h, vp(VB), m, SEED + 10, 0, C.c_double(0.5))
+            seq = np.arange(m, dtype=np.uint32)
+            capi.call("agpu_upload", h, vp(SEQ), C.c_void_p(seq.ctypes.data), 4 * m)
+            p.sync()
+            del seq
+            w0, wn = (m // 3) // 64 * 64, 4096
+
+            def med5(launch):
+                launch()
+                pairs = [(ev(), ev()) for _ in range(5)]
+                for s_, e_ in pairs:
+                    capi.call("agpu_event_record", s_, h)
+                    launch()
+                    capi.call("agpu_event_record", e_, h)
+                ts = sorted(ms_between(s_, e_) for s_, e_ in pairs)
+                for pr in pairs:
+                    for e in pr:
+                        capi.lib().agpu_event_destroy(e)
+                return ts[2]
+
+            def win(buf, nbytes, off):
+                got = np.empty(nbytes, np.uint8)
+                capi.call("agpu_download", h, C.c_void_p(got.ctypes.data), C.c_void_p(buf.ptr + off), nbytes)
+                return got
+
+            swz = {}
+
+            def rec(name, launch, what, window=None):
+                ms = med5(launch)
+                swz[name] = {"ms": round(ms, 4), "G_rows_per_s": round(m / ms / 1e6, 1), "what": what}
+                if want_cpu and window is not None:
+                    cfg_windows["swz_" + name] = dict(window(), w0=w0, rows=wn, m=m)
+
+            rec("take_f32_random", lambda: capi.call("agpu_take", h, 4, vp(V), m, vp(I1), vp(OUT), m), "out[i] = values[idx[i]], idx uniformly random",
+                lambda: {"kind": "take", "got": win(OUT, 4 * wn, 4 * w0).view(np.uint32)})
+            rec("take_f32_random_with_validity", lambda: capi.call("agpu_take_validity", h, 4, vp(V), m, vp(VB), vp(I1), vp(OUT), vp(OB), m),
+                "values and validity bits in one pipeline", lambda: {"kind": "take_validity", "got": win(OUT, 4 * wn, 4 * w0).view(np.uint32), "bits": win(OB, wn // 8, w0 // 8)})
+            rec("take_bits_random", lambda: capi.call("agpu_take_bits", h, vp(VB), m, vp(I1), vp(OB), m), "Boolean take", lambda: {"kind": "take_bits", "bits": win(OB, wn // 8, w0 // 8)})
+            rec("take_f32_sequential", lambda: capi.call("agpu_take", h, 4, vp(V), m, vp(SEQ), vp(OUT), m), "local indices: the probe keeps the streaming direct kernel")
+            rec("put_f32_random_to_sequential", lambda: capi.call("agpu_put_bounded", h, 4, vp(V), m, vp(I1), vp(OUT), m, vp(SEQ), m),
+                "dst[dst_idx[i]] = src[src_idx[i]]: random source, local destination (the gather into a contiguous selection)",
+                lambda: {"kind": "take", "got": win(OUT, 4 * wn, 4 * w0).view(np.uint32)})
+            rec("put_f32_sequential_to_random", lambda: capi.call("agpu_put_bounded", h, 4, vp(V), m, vp(SEQ), vp(OUT), m, vp(I2), m),
+                "local source, random destination (the scatter of a contiguous selection; duplicate destinations: unspecified winner)")
+            rec("put_f32_random_to_random", lambda: capi.call("agpu_put_bounded", h, 4, vp(V), m, vp(I1), vp(OUT), m, vp(I2), m), "both index columns random")
+            rec("put_bits_random_to_random", lambda: capi.call("agpu_put_bits_bounded", h, vp(VB), m, vp(I1), vp(OB), m, vp(I2), m), "Boolean put, both index columns random")
+            p.set_tuning("gather_bucket", 1)
+            rec("take_f32_random_direct_kernel", lambda: capi.call("agpu_take", h, 4, vp(V), m, vp(I1), vp(OUT), m), "tuning gather_bucket = 1: one 128-byte line fetched per row")
+            p.set_tuning("gather_bucket", 0)
+            swz["rows"] = m
+            extra["swizzle"] = swz
+            del V, I1, I2, SEQ, OUT, VB, OB
+        except Exception as e:  # noqa: BLE001
+            extra["swizzle"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- the reference's own criterion workloads on the GPU, through the HOST API exactly as its benches call it
     # (add_dyn(column, 1-element column) at 10 Mi rows; UInt32ArrayGPU::broadcast(2, n).sum() at 1 Mi / 10 Mi rows)
