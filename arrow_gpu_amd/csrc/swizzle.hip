@@ -1709,24 +1709,28 @@ __global__ __launch_bounds__(BKT_T) void tk2_merge_kernel(const uint32_t* si, ui
 // "elements" are the bitmap's 32-bit words, regions are 2^rsw words (16 KiB of bitmap by default), the slot entries are
 // {word − origin : 13 bits, bit position : 5, slot : 14}, ordered by source LINE (32 words); every gathered bit goes straight to
 // the tile's slot-ordered bit array — there is no value array at all — and leaves as vbits_slot like above.
-#define TK2B_REL_BITS 13
+// WIDE (bitmaps over 2^29 bits — a 1e9-row column's — whose regions have to be larger than 2^12 words for ≤ 4095 of them): the entry
+// is {word − origin : 18 bits, slot : 14} like G2's, ordered by groups of four lines (2048 keys), and the BIT POSITION, which no longer
+// fits, is read back from the tile's (L2-resident) index entries.
+template <bool WIDE>
 __global__ __launch_bounds__(BKT_T, 8) void tk2_gather_bits_kernel(const uint32_t* bits, uint64_t n_bits, const uint32_t* srcs, uint64_t total,
                                                                   uint32_t ntiles, uint64_t* vbits_slot, const BktCtl* gate = nullptr) {
   BKT_GATE(gate);
   __shared__ uint32_t sorted[TK2_GTILE];
-  __shared__ uint32_t lcnt[1 << (TK2B_REL_BITS - 5)];  // 256 line keys
+  constexpr int TK2B_REL_BITS = WIDE ? 18 : 13, KS = WIDE ? 7 : 5;  // key = (word − origin) >> KS
+  __shared__ uint32_t lcnt[1 << (TK2B_REL_BITS - KS)];  // 256 line keys (2048 groups of four lines when WIDE)
   __shared__ uint32_t wave_tot[BKT_T / AGPU_WAVE];
   __shared__ uint32_t tile_rows;
   __shared__ uint32_t red[2 * (BKT_T / AGPU_WAVE)];
   __shared__ uint32_t bitl[TK2_GTILE / 32];
-  constexpr uint32_t NKEYS = 1u << (TK2B_REL_BITS - 5);
+  constexpr uint32_t NKEYS = 1u << (TK2B_REL_BITS - KS);
   uint64_t tile;
   if (!bkt_tile_of_block(ntiles, &tile)) return;
   const uint64_t base = tile * TK2_GTILE;
   if (base >= total) return;
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   if (threadIdx.x < TK2_GTILE / 32) bitl[threadIdx.x] = 0;
-  if (threadIdx.x < NKEYS) lcnt[threadIdx.x] = 0;
+  for (uint32_t kk = threadIdx.x; kk < NKEYS; kk += BKT_T) lcnt[kk] = 0;
   auto load4 = [&](int q) -> u32x4 {
     const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
     u32x4 t = {0, 0, 0, 0};
@@ -1797,13 +1801,20 @@ __global__ __launch_bounds__(BKT_T, 8) void tk2_gather_bits_kernel(const uint32_
     const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
     uint32_t r[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) r[k] = live_at(q, k) ? atomicAdd(&lcnt[((sv[k] >> 5) - origin) >> 5], 1u) : 0u;
+    for (int k = 0; k < 4; k++) r[k] = live_at(q, k) ? atomicAdd(&lcnt[((sv[k] >> 5) - origin) >> KS], 1u) : 0u;
     rank2[q * 2] = r[0] | (r[1] << 16);
     rank2[q * 2 + 1] = r[2] | (r[3] << 16);
   }
   __syncthreads();
-  {  // exclusive scan of the 256 line counters by the first four waves' worth of threads (one counter each)
-    uint32_t c = threadIdx.x < NKEYS ? lcnt[threadIdx.x] : 0u, incl = c;
+  {  // exclusive scan of the counters: 256 of them, one per thread of the first four waves — or 2048, two per thread
+    constexpr uint32_t KPT = NKEYS >= BKT_T ? NKEYS / BKT_T : 1;
+    uint32_t c[KPT], sum = 0;
+#pragma unroll
+    for (uint32_t kk = 0; kk < KPT; kk++) {
+      c[kk] = threadIdx.x * KPT + kk < NKEYS ? lcnt[threadIdx.x * KPT + kk] : 0u;
+      sum += c[kk];
+    }
+    uint32_t incl = sum;
 #pragma unroll
     for (int off = 1; off < AGPU_WAVE; off <<= 1) {
       const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
@@ -1813,8 +1824,13 @@ __global__ __launch_bounds__(BKT_T, 8) void tk2_gather_bits_kernel(const uint32_
     __syncthreads();
     uint32_t pre = 0;
     for (uint32_t w = 0; w < wave; w++) pre += wave_tot[w];
-    if (threadIdx.x < NKEYS) lcnt[threadIdx.x] = pre + incl - c;
-    if (threadIdx.x == NKEYS - 1) tile_rows = pre + incl;
+    uint32_t run = pre + incl - sum;
+#pragma unroll
+    for (uint32_t kk = 0; kk < KPT; kk++) {
+      if (threadIdx.x * KPT + kk < NKEYS) lcnt[threadIdx.x * KPT + kk] = run;
+      run += c[kk];
+    }
+    if (threadIdx.x == BKT_T - 1) tile_rows = run;
     __syncthreads();
   }
 #pragma unroll
@@ -1827,25 +1843,27 @@ __global__ __launch_bounds__(BKT_T, 8) void tk2_gather_bits_kernel(const uint32_
         const uint32_t rel = (sv[k] >> 5) - origin;
         const uint32_t pos = ((uint32_t)q * BKT_T + threadIdx.x) * 4 + (uint32_t)k;
         const uint32_t rk = (rank2[q * 2 + (k >> 1)] >> ((k & 1) * 16)) & 0xFFFFu;
-        sorted[lcnt[rel >> 5] + rk] = (rel << 19) | ((sv[k] & 31u) << TK2_POS_BITS) | pos;
+        sorted[lcnt[rel >> KS] + rk] = WIDE ? (rel << TK2_POS_BITS) | pos : (rel << 19) | ((sv[k] & 31u) << TK2_POS_BITS) | pos;
       }
   }
   __syncthreads();
   const uint32_t rows_here = tile_rows;
 #pragma unroll
   for (int h0 = 0; h0 < TK2_GE; h0 += 8) {
-    uint32_t ent[8], w[8];
+    uint32_t ent[8], w[8], bp[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
       ent[e] = j < rows_here ? sorted[j] : 0u;
-      w[e] = j < rows_here ? bits[origin + (ent[e] >> 19)] : 0u;  // the L2-resident gather: neighbours share the line
+      w[e] = j < rows_here ? bits[origin + (ent[e] >> (WIDE ? TK2_POS_BITS : 19))] : 0u;  // the L2-resident gather: neighbours share the line
+      if constexpr (WIDE) bp[e] = j < rows_here ? srcs[base + (ent[e] & ((1u << TK2_POS_BITS) - 1u))] & 31u : 0u;  // the bit position: from the index entry itself
+      else bp[e] = (ent[e] >> TK2_POS_BITS) & 31u;
     }
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const uint32_t j = (uint32_t)(h0 + e) * BKT_T + threadIdx.x;
       const uint32_t pos = ent[e] & ((1u << TK2_POS_BITS) - 1u);
-      if (j < rows_here && ((w[e] >> ((ent[e] >> TK2_POS_BITS) & 31u)) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
+      if (j < rows_here && ((w[e] >> bp[e]) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
     }
   }
   __syncthreads();
@@ -1859,8 +1877,10 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
                                               void* tbits_tmp = nullptr) {
   if (n >= 0xFFFF0000ull || n_bits > 0xFFFFFFFFull || !aligned16(si) || p->capturing) return AGPU_ERR_UNSUPPORTED;
   const uint64_t n_words = (n_bits + 31) / 32;
-  int rsw = 12;  // 2^12 words = 16 KiB of bitmap per region: two regions span < 2^13 words (the entry's 13 bits)
-  if (((n_words + ((uint64_t)1 << rsw) - 1) >> rsw) > BKT_MAX - 1) return AGPU_ERR_UNSUPPORTED;  // > 2^29 bits: the direct kernel
+  int rsw = 12;  // 2^12 words = 16 KiB of bitmap per region: two regions span < 2^13 words (the narrow entry's 13 bits)
+  while (((n_words + ((uint64_t)1 << rsw) - 1) >> rsw) > BKT_MAX - 1) rsw++;  // > 2^29 bits (a 1e9-row column's bitmap): larger regions and
+  const bool wide = rsw > 12;                                                    // the WIDE gather (18-bit entries: two regions of ≤ 2^17 words)
+  if (rsw > 17) return AGPU_ERR_UNSUPPORTED;
   const int rs = rsw + 5;  // H2 / P2 / F2 key an index by (idx >> rs): idx is a BIT number here
   const uint32_t bs = (uint32_t)((n_words + ((uint64_t)1 << rsw) - 1) >> rsw);
   agpu_device* dev = p->dev;
@@ -1898,8 +1918,12 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
       hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets, gate);
       hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, offsets, nbp,
                          ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v), gate);
-      hipLaunchKernelGGL(tk2_gather_bits_kernel, dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, bits, n_bits,
-                         static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint64_t*>(vslot_v), gate);
+      if (wide)
+        hipLaunchKernelGGL((tk2_gather_bits_kernel<true>), dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, bits, n_bits,
+                           static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint64_t*>(vslot_v), gate);
+      else
+        hipLaunchKernelGGL((tk2_gather_bits_kernel<false>), dim3((gtiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, bits, n_bits,
+                           static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<uint64_t*>(vslot_v), gate);
       if (ent_out)
         hipLaunchKernelGGL((tk2_merge_kernel<3>), dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, counts, offsets,
                            nbp, ntiles, static_cast<const uint16_t*>(rank_v), static_cast<const uint32_t*>(nullptr), ent_out,

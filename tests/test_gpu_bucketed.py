@@ -264,10 +264,11 @@ def test_host_take_of_an_array_with_nulls_uses_the_fused_call(ctx):
 @pytest.mark.parametrize("mode", [1, 2, 4])
 @pytest.mark.parametrize("n,n_bits,dist", [(32768, 9, "uniform"), (32769, 70_001, "uniform"), (65_537, 1 << 22, "uniform"), (40_000, 300_000_007, "uniform"),
                                            (1_000_003, 40_000_003, "uniform"), (3 * 32768 + 5, 1 << 24, "oob_tile"), (500_000, 1 << 23, "skew"),
-                                           (2_500_000, 1 << 20, "dups"), (2_000_000, (1 << 29) - 3, "uniform"), (100_000, (1 << 29) + 77, "uniform")])
+                                           (2_500_000, 1 << 20, "dups"), (2_000_000, (1 << 29) - 3, "uniform"), (100_000, (1 << 29) + 77, "uniform"),
+                                           (1_500_000, 1_000_000_007, "uniform"), (400_000, 3_000_000_011, "uniform"), (300_000, 1_000_000_007, "skew")])
 def test_take_bits_pipelines_equal_the_oracle(ctx, mode, n, n_bits, dist):
-    """[ref: crates/routines/src/bool.rs:15-46 + bool/take.wgsl] direct (mode 1) and merge-back (mode 2; > 2^29 bits falls back to the
-    direct kernel by itself) against oracle.take_bits; out-of-range rows read 0 and raise the sticky flag"""
+    """[ref: crates/routines/src/bool.rs:15-46 + bool/take.wgsl] direct (mode 1) and merge-back (mode 2; bitmaps over 2^29 bits — a 1e9-row
+    column's — through the WIDE gather with larger regions) against oracle.take_bits; out-of-range rows read 0 and raise the sticky flag"""
     dev, p = ctx
     p.set_tuning("gather_bucket", mode)
     try:
