@@ -12,7 +12,7 @@ from arrow_gpu_amd import _capi as capi  # noqa: E402
 from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice  # noqa: E402
 
 variant = sys.argv[1]
-n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 28)
+n = (int(float(sys.argv[2])) if len(sys.argv) > 2 and float(sys.argv[2]) > 64 else 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 28))  # log2 or a row count
 dev = GpuDevice(0)
 p = ArrowComputePipeline(dev, "pmc")
 h = p._handle

@@ -8,7 +8,7 @@ from arrow_gpu_amd import _capi as capi
 from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, CmpQuery, GpuDevice
 dev = GpuDevice(0); p = ArrowComputePipeline(dev, "lr"); q = CmpQuery(dev); h = p._handle
 vp = lambda b: C.c_void_p(b.ptr)
-n = 1 << 28
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1 << 28
 src, dst, si, di = (dev.create_empty_buffer(4*n) for _ in range(4))
 capi.call("agpu_synth_i32", h, vp(src), n, 1, 0, 0)
 capi.call("agpu_synth_i32", h, vp(di), n, 3, 0, n)
