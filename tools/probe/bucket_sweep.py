@@ -44,7 +44,7 @@ for a in sys.argv:
         p.set_tuning("gather_region_bits", int(a.split("=")[1]))
     if a.startswith("--offsets="):
         p.set_tuning("gather_offsets", int(a.split("=")[1]))
-modes = (("bucketed", 2),) if "--only-bucketed" in sys.argv else (("direct", 1), ("bucketed", 2))
+modes = (("bucketed", 2),) if "--only-bucketed" in sys.argv else (("direct", 1), ("bucketed", 2), ("auto", 0))  # auto: size thresholds + the probe
 rows = []
 shapes = [(1 << 26, 1 << 22), (1 << 26, 1 << 26), (1 << 28, 1 << 24), (1 << 28, 1 << 26), (1 << 28, 1 << 28)]
 if quick:
@@ -69,7 +69,7 @@ for n, nv in shapes:
         cs = dev.create_empty_buffer(16)
         capi.call("agpu_checksum", h, vp(out), 4 * n, vp(cs))
         rec[f"take_{name}_checksum"] = int(dev.retrive_data(cs, 8, pipeline=p).view(np.uint64)[0])
-    if len(modes) == 2:
+    if len(modes) >= 2:
         rec["take_same_result"] = rec["take_direct_checksum"] == rec["take_bucketed_checksum"]
         rec["take_speedup"] = round(rec["take_direct_ms"] / rec["take_bucketed_ms"], 2)
     # put: src = values (nv rows, random source index), dst = out (n rows, random destination index; duplicates have no
@@ -79,7 +79,7 @@ for n, nv in shapes:
         ms = timeit(lambda: capi.call("agpu_put_bounded", h, 4, vp(values), nv, vp(idx), vp(out), n, vp(idx2), n))
         rec[f"put_{name}_ms"] = round(ms, 3)
         rec[f"put_{name}_Grows_s"] = round(n / ms / 1e6, 1)
-    if len(modes) == 2:
+    if len(modes) >= 2:
         rec["put_speedup"] = round(rec["put_direct_ms"] / rec["put_bucketed_ms"], 2)
     print(json.dumps(rec), flush=True)
     rows.append(rec)
