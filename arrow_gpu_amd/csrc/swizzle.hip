@@ -1274,21 +1274,23 @@ __global__ __launch_bounds__(BKT_T) void tk2_partition_kernel(const uint32_t* si
 // slot in slot order (256 u64 words per tile).
 // W = the value width in bytes (4, 2, 1): regions, entries and the LDS arrays are in ELEMENTS either way; only the gather, the
 // slow path and the last store see the type.
-template <int WPE, bool BITS, int W = 4, int T = BKT_T>
+template <int WPE, bool BITS, int W = 4, int T = BKT_T, int GE = TK2_GE>
 __global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemOf<W>::type* values, uint64_t n_src, const uint32_t* srcs,
                                                                uint64_t total, uint32_t ntiles, typename ElemOf<W>::type* vals,
                                                                const uint32_t* vbits_src, uint64_t* vbits_slot, const BktCtl* gate = nullptr) {
   BKT_GATE(gate);
   typedef typename ElemOf<W>::type E;
-  constexpr int GT = TK2_GE * T;  // slots per tile (T = 1024: 16 Ki; the 512-thread variant: 8 Ki, four workgroups per CU)
-  constexpr int KPT = TK2_GKEYS / T;  // line-group counters per thread in the scan
+  // GE = slots per thread: 16 (16 Ki-slot tiles, 18-bit offsets: regions up to 2^17 elements) or 8 (8 Ki slots, 19-bit offsets: the
+  // 2^18 … 2^19-element regions a source of more than 2^29 elements needs to stay within 4095 of them)
+  constexpr int GT = GE * T, PB = GE == 16 ? 14 : 13, RB = 32 - PB, NK = 1 << (RB - TK2_GKEY_SHIFT);  // slots per tile (T = 1024: 16 Ki; the 512-thread variant: 8 Ki, four workgroups per CU)
+  constexpr int KPT = NK / T;  // line-group counters per thread in the scan
   // 64 KiB + 8 KiB of LDS and ≤ 64 VGPRs: TWO workgroups per CU, so that one's loads and gathers run under the other's LDS
   // phases.  To stay inside 64 registers the tile's sources are loaded twice (the second time from L2) instead of being
   // kept across the ranking, ranks are packed two to a register, and only the 16 sorted entries live across the barrier
   // that turns the entry array into the value array (a first version with everything kept spilled 18–32 VGPRs: 4.5 B/row of
   // scratch traffic by PMC).
   __shared__ uint32_t sorted[GT];
-  __shared__ uint32_t lcnt[TK2_GKEYS];
+  __shared__ uint32_t lcnt[NK];
   __shared__ uint32_t wave_tot[T / AGPU_WAVE];
   __shared__ uint32_t tile_rows;
   __shared__ uint32_t red[2 * (T / AGPU_WAVE)];
@@ -1320,9 +1322,9 @@ __global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemO
   auto live_at = [&](int q, int k) { return base + ((uint64_t)q * T + threadIdx.x) * 4 + (uint64_t)k < total; };
   // pass 1: the tile's source span decides the path (uniform over the block)
   uint32_t mn = 0xFFFFFFFFu, mx = 0;
-  for (uint32_t k = threadIdx.x; k < TK2_GKEYS; k += T) lcnt[k] = 0;
+  for (uint32_t k = threadIdx.x; k < NK; k += T) lcnt[k] = 0;
 #pragma unroll
-  for (int q = 0; q < TK2_GE / 4; q++) {
+  for (int q = 0; q < GE / 4; q++) {
     const u32x4 t = load4(q);
     const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -1350,10 +1352,10 @@ __global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemO
     mx = red[T / AGPU_WAVE + w] > mx ? red[T / AGPU_WAVE + w] : mx;
   }
   const uint32_t origin = mn & ~((1u << TK2_GKEY_SHIFT) - 1u);
-  const bool fast = mx < n_src && (mx - origin) < (1u << TK2_REL_BITS);
+  const bool fast = mx < n_src && (mx - origin) < (1u << RB);
   if (!fast) {  // a tile of out-of-range rows, or one that straddles many small regions: row by row, slots keep their place
 #pragma unroll
-    for (int q = 0; q < TK2_GE / 4; q++) {
+    for (int q = 0; q < GE / 4; q++) {
       const u32x4 t = load4(q);
       const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -1375,9 +1377,9 @@ __global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemO
   }
   // pass 2 (sources from L2): rank every row inside its source LINE GROUP (128 elements): neighbouring lanes of the gather
   // will share a request.  Ranks < 2^14: two to a register.
-  uint32_t rank2[TK2_GE / 2];
+  uint32_t rank2[GE / 2];
 #pragma unroll
-  for (int q = 0; q < TK2_GE / 4; q++) {
+  for (int q = 0; q < GE / 4; q++) {
     const u32x4 t = load4(q);
     const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
     uint32_t r[4];
@@ -1415,7 +1417,7 @@ __global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemO
   }
   // pass 3 (sources from L2 again): entries {source − origin, slot inside the tile} into line-group order
 #pragma unroll
-  for (int q = 0; q < TK2_GE / 4; q++) {
+  for (int q = 0; q < GE / 4; q++) {
     const u32x4 t = load4(q);
     const uint32_t sv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -1424,14 +1426,14 @@ __global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemO
         const uint32_t rel = sv[k] - origin;
         const uint32_t pos = ((uint32_t)q * T + threadIdx.x) * 4 + (uint32_t)k;
         const uint32_t rk = (rank2[q * 2 + (k >> 1)] >> ((k & 1) * 16)) & 0xFFFFu;
-        sorted[lcnt[rel >> TK2_GKEY_SHIFT] + rk] = (rel << TK2_POS_BITS) | pos;
+        sorted[lcnt[rel >> TK2_GKEY_SHIFT] + rk] = (rel << PB) | pos;
       }
   }
   __syncthreads();
   const uint32_t rows_here = tile_rows;
-  uint32_t ent[TK2_GE];
+  uint32_t ent[GE];
 #pragma unroll
-  for (int e = 0; e < TK2_GE; e++) {
+  for (int e = 0; e < GE; e++) {
     const uint32_t j = (uint32_t)e * T + threadIdx.x;
     ent[e] = j < rows_here ? sorted[j] : 0u;
   }
@@ -1440,29 +1442,29 @@ __global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemO
 #define TK2_GGRP 8  // gathers in flight per lane (16: 58 VGPRs, measured no faster — tools/probe/put_variants.sh)
 #endif
 #pragma unroll
-  for (int h0 = 0; h0 < TK2_GE; h0 += TK2_GGRP) {
+  for (int h0 = 0; h0 < GE; h0 += TK2_GGRP) {
     uint32_t v[TK2_GGRP];
 #pragma unroll
     for (int e = 0; e < TK2_GGRP; e++) {
       const uint32_t j = (uint32_t)(h0 + e) * T + threadIdx.x;
-      v[e] = j < rows_here ? (uint32_t)values[origin + (ent[h0 + e] >> TK2_POS_BITS)] : 0u;  // the L2-resident gather
+      v[e] = j < rows_here ? (uint32_t)values[origin + (ent[h0 + e] >> PB)] : 0u;  // the L2-resident gather
     }
 #pragma unroll
     for (int e = 0; e < TK2_GGRP; e++) {
       const uint32_t j = (uint32_t)(h0 + e) * T + threadIdx.x;
-      if (j < rows_here) sorted[ent[h0 + e] & ((1u << TK2_POS_BITS) - 1u)] = v[e];
+      if (j < rows_here) sorted[ent[h0 + e] & ((1u << PB) - 1u)] = v[e];
     }
     if constexpr (BITS) {  // the validity bits of the same eight sources: 16 bytes of bitmap per line group, shared by neighbours
       uint32_t w[TK2_GGRP];
 #pragma unroll
       for (int e = 0; e < TK2_GGRP; e++) {
         const uint32_t j = (uint32_t)(h0 + e) * T + threadIdx.x;
-        w[e] = j < rows_here ? vbits_src[(origin + (ent[h0 + e] >> TK2_POS_BITS)) >> 5] : 0u;
+        w[e] = j < rows_here ? vbits_src[(origin + (ent[h0 + e] >> PB)) >> 5] : 0u;
       }
 #pragma unroll
       for (int e = 0; e < TK2_GGRP; e++) {
         const uint32_t j = (uint32_t)(h0 + e) * T + threadIdx.x;
-        const uint32_t src = origin + (ent[h0 + e] >> TK2_POS_BITS), pos = ent[h0 + e] & ((1u << TK2_POS_BITS) - 1u);
+        const uint32_t src = origin + (ent[h0 + e] >> PB), pos = ent[h0 + e] & ((1u << PB) - 1u);
         if (j < rows_here && ((w[e] >> (src & 31)) & 1u)) atomicOr(&bitl[pos >> 5], 1u << (pos & 31));
       }
     }
@@ -1470,7 +1472,7 @@ __global__ __launch_bounds__(T, WPE) void tk2_gather_kernel(const typename ElemO
   __syncthreads();
   store_bits();
 #pragma unroll
-  for (int q = 0; q < TK2_GE / 4; q++) {
+  for (int q = 0; q < GE / 4; q++) {
     const uint32_t l0 = ((uint32_t)q * T + threadIdx.x) * 4;
     const uint64_t i0 = base + l0;
     if (i0 + 4 <= total) {
@@ -1954,6 +1956,11 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
 #ifndef TK2_GTHREADS
 #define TK2_GTHREADS BKT_T  // threads of a G2 workgroup (tile = 16 slots per thread): 1024 → two workgroups per CU; 512 → four (A/B, tools/probe)
 #endif
+#define TK2_GG(BITS_, WW, E, grid_, ...)                                                                                   \
+  do {                                                                                                                     \
+    if (ge == 8) hipLaunchKernelGGL((tk2_gather_kernel<8, BITS_, WW, TK2_GTHREADS, 8>), grid_, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((tk2_gather_kernel<8, BITS_, WW, TK2_GTHREADS, TK2_GE>), grid_, __VA_ARGS__);                 \
+  } while (0)
 static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void* values, uint64_t n_src, const uint32_t* si, void* out,
                                          uint64_t n, const uint32_t* vbits_src = nullptr, uint64_t* out_validity = nullptr, bool adaptive = false,
                                          const uint32_t* put_di = nullptr, uint64_t put_n_dst = 0, const BktCtl* ext_gate = nullptr) {
@@ -1967,13 +1974,17 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
   if (bs + 1 > BKT_MAX) return AGPU_ERR_UNSUPPORTED;
   agpu_device* dev = p->dev;
   const uint32_t ntiles = (uint32_t)((n + TK2_TILE - 1) / TK2_TILE);
-  const uint32_t gtiles = (uint32_t)((n + TK2_GE * TK2_GTHREADS - 1) / (TK2_GE * TK2_GTHREADS));
+  // regions of 2^19 elements (sources over 4095 · 2^18 ≈ 1.07e9 elements): the 8-slot gather, whose 19-bit offsets cover a region — with 16
+  // slots every tile would take the row-by-row path (2^30 rows: 63.6 → 75.7 G rows/s).  At 2^18-element regions (1e9 rows) the 16-slot gather
+  // stays: its straddling tiles (1 in 16) cost less than half the coalescing (80.6 against 75.6).
+  const int ge = rs >= 19 ? 8 : TK2_GE;
+  const uint32_t gtiles = (uint32_t)((n + (uint64_t)ge * TK2_GTHREADS - 1) / ((uint64_t)ge * TK2_GTHREADS));
   const uint32_t nbp = (bs + 1 + 3) & ~3u;
   const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
   void *ctl_v = nullptr, *srcs_v = nullptr, *vals_v = nullptr, *rank_v = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr;
   void* vslot_v = nullptr;
   agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
-  if (st == AGPU_OK && vbits_src) st = agpu_malloc(dev, ((size_t)gtiles * TK2_GE * TK2_GTHREADS) / 8 + 16, 0, &vslot_v);
+  if (st == AGPU_OK && vbits_src) st = agpu_malloc(dev, ((size_t)gtiles * ge * TK2_GTHREADS) / 8 + 16, 0, &vslot_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 4 * n + 16, 0, &srcs_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)width * n + 16, 0, &vals_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 2 * n + 16, 0, &rank_v);
@@ -2006,24 +2017,24 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
                          ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v), gate);
       const dim3 ggrid((gtiles + 7) / 8 * 8), fgrid((ntiles + 7) / 8 * 8);
       uint64_t* vslot = static_cast<uint64_t*>(vslot_v);
-#define TK2_GF(WW, E)                                                                                                                    \
+#define TK2_GF(WW, E) /* G2 with 16 or 8 slots per thread (TK2_GG) */                                                                                                                    \
   case WW:                                                                                                                               \
     if (vbits_src) {                                                                                                                     \
-      hipLaunchKernelGGL((tk2_gather_kernel<8, true, WW, TK2_GTHREADS>), ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src,        \
+      TK2_GG(true, WW, E, ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src,        \
                          static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), vbits_src, vslot, gate);              \
       hipLaunchKernelGGL((tk2_merge_kernel<1, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \
                          static_cast<const uint16_t*>(rank_v), static_cast<const E*>(vals_v), static_cast<E*>(out),                      \
                          reinterpret_cast<const uint32_t*>(vslot), out_validity, static_cast<const uint32_t*>(nullptr), (uint64_t)0,     \
                          gate);                                                                                                          \
     } else if (put_di) {                                                                                                                 \
-      hipLaunchKernelGGL((tk2_gather_kernel<8, false, WW, TK2_GTHREADS>), ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src, \
+      TK2_GG(false, WW, E, ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src, \
                          static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), static_cast<const uint32_t*>(nullptr), \
                          static_cast<uint64_t*>(nullptr), gate);                                                                         \
       hipLaunchKernelGGL((tk2_merge_kernel<4, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \
                          static_cast<const uint16_t*>(rank_v), static_cast<const E*>(vals_v), static_cast<E*>(out),                      \
                          static_cast<const uint32_t*>(nullptr), static_cast<uint64_t*>(nullptr), put_di, put_n_dst, gate, p->flags);     \
     } else {                                                                                                                             \
-      hipLaunchKernelGGL((tk2_gather_kernel<8, false, WW, TK2_GTHREADS>), ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src,       \
+      TK2_GG(false, WW, E, ggrid, dim3(TK2_GTHREADS), 0, p->stream, static_cast<const E*>(values), n_src,       \
                          static_cast<const uint32_t*>(srcs_v), n, gtiles, static_cast<E*>(vals_v), static_cast<const uint32_t*>(nullptr), \
                          static_cast<uint64_t*>(nullptr), gate);                                                                         \
       hipLaunchKernelGGL((tk2_merge_kernel<0, WW>), fgrid, dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, counts, offsets, nbp, ntiles, \

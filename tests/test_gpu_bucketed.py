@@ -452,7 +452,8 @@ def test_put_bits_at_2_27_rows_bucketed_equals_direct(ctx):
 @pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("width", [1, 2])
 @pytest.mark.parametrize("n,n_values,dist", [(32768, 9, "uniform"), (32769, 70_001, "uniform"), (300_001, 3_000_017, "uniform"), (40_000, 300_000_007, "uniform"),
-                                             (3 * 32768 + 5, 1 << 24, "oob_tile"), (500_000, 1 << 23, "skew"), (1_000_003, 1 << 20, "dups")])
+                                             (3 * 32768 + 5, 1 << 24, "oob_tile"), (500_000, 1 << 23, "skew"), (1_000_003, 1 << 20, "dups"),
+                                             (700_001, 600_000_007, "uniform"), (300_001, 1_200_000_011, "uniform")])  # > 4095 · 2^17 / 2^18 elements: 2^18- / 2^19-element regions (the 8-slot gather)
 def test_narrow_takes_through_both_pipelines(ctx, mode, width, n, n_values, dist):
     import arrow_gpu_amd as ag
 
