@@ -40,6 +40,8 @@ def med(f):
     return float(np.median(ts))
 
 
+if os.environ.get("TAKE_REGION_BITS"):  # A/B of the region size (tuning gather_region_bits)
+    p.set_tuning("gather_region_bits", int(os.environ["TAKE_REGION_BITS"]))
 res = {"rows": n}
 PUT_ONLY = bool(os.environ.get("PUT_ONLY"))  # tools/probe/put_variants.sh: only the pair-pipeline rows
 for label, mode in ((("take_pairs", 3),) if PUT_ONLY else (("take_direct", 1), ("take_pairs", 3), ("take_mergeback", 2))):
