@@ -14,6 +14,9 @@
 // 52 G × 128 B = 6.7 TB/s is the HBM roof; 4 / 8 / 16 gathers in flight per lane, one-wave blocks and nontemporal
 // gathers change nothing (nt: −7 %).  Sorted indices reach 245–720 G rows/s.  The index and output streams are
 // nontemporal so they do not evict a cache-resident source (4 MiB source: 165 → 183 G rows/s).  Bit gathers use the wave ballot exactly like the compare kernel.
+#include <atomic>
+#include <chrono>
+
 #include "common.hpp"
 
 template <int W> struct ElemOf;
@@ -814,8 +817,6 @@ static agpu_status launch_put_direct(agpu_pipeline* p, int width, const void* sr
 // the answer arrives in ≈ 25 µs and ONLY the chosen form is enqueued: no empty launches at all.  On a busy stream the wait times out
 // (−1) and the caller enqueues all forms gated by the device-side copy of the same decision, as before.  Returns bit 0: column 0 local,
 // bit 1: column 1 local.
-#include <atomic>
-#include <chrono>
 static std::atomic<uint32_t> g_probe_tag{1};
 static int probe_decide(agpu_pipeline* p, const uint32_t* idx0, const uint32_t* idx1, uint64_t n, int shift0, int shift1) {
   if (!p->flags || p->capturing) return -1;
