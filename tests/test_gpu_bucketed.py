@@ -457,6 +457,9 @@ def test_put_bits_at_2_27_rows_bucketed_equals_direct(ctx):
 def test_narrow_takes_through_both_pipelines(ctx, mode, width, n, n_values, dist):
     import arrow_gpu_amd as ag
 
+    if n_values > 500_000_000 and width != 1:
+        pytest.skip("the very large sources (2^18- / 2^19-element regions) with 1-byte values only: a gigabyte of host data per case")
+
     dev, p = ctx
     p.set_tuning("gather_bucket", mode)
     try:
