@@ -102,6 +102,10 @@ SIGNATURES = {
     "agpu_reduce_combine": [_vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "agpu_comm_all_reduce": [_vp, _vp, _i32, _i32, _vp, _u64],
     "agpu_comm_barrier": [_vp, _vp],
+    "agpu_comm_sync": [_vp, _vp],
+    "agpu_comm_size": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
+    "agpu_device_identity": [_vp, _vp],
+    "agpu_comm_peers": [_vp, _vp, _vp, _i32, C.POINTER(_i32)],
     "agpu_import_arrow": [_vp, _vp, _vp, _vp],
     "agpu_export_arrow": [_vp, _vp, _vp, _vp],
     "agpu_arrow_column_free": [_vp, _vp],

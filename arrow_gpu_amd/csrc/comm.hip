@@ -16,8 +16,10 @@
 // xGMI link rate is irrelevant, one collective per statistic.  agpu_comm_all_reduce is the plain ncclAllReduce for
 // integer counts (null counts, row counts) where the order cannot matter.
 #include <dlfcn.h>
+#include <unistd.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <memory>
@@ -50,6 +52,45 @@ static int64_t comm_timeout_ms() {
   const char* e = getenv("AGPU_COMM_TIMEOUT_MS");
   if (e && *e) return strtoll(e, nullptr, 10);
   return 120000;
+}
+
+// A collective whose peer never joined stays queued on its stream for ever: every later wait on that stream, every
+// hipDeviceSynchronize, hipFree and hipStreamDestroy of the device would block behind it.  The deadline-aware waits below
+// therefore POISON the device when they give up (agpu_device::poisoned): from then on every ABI call that could wait
+// returns AGPU_ERR_HIP at once, the destroy calls leak instead of synchronising (runtime.hip), and agpu_comm_destroy
+// aborts the communicator instead of draining it — so a host that unwinds through its destructors after the timeout
+// (C++ exceptions, Python __del__) ends instead of hanging.  The process is expected to exit.
+static void comm_poison(agpu_comm* c, const char* what, long long waited_ms) {
+  c->dev->poisoned.store(true, std::memory_order_release);
+  agpu_set_error("%s: rank %d of %d waited %lld ms for the other ranks (AGPU_COMM_TIMEOUT_MS); the device is poisoned — "
+                 "every further call fails fast, destroy calls leak: exit this process",
+                 what, c->rank, c->world, waited_ms);
+}
+
+// host wait for everything queued on p's stream, giving up after AGPU_COMM_TIMEOUT_MS (0 = wait for ever)
+static agpu_status comm_wait_stream(agpu_comm* c, agpu_pipeline* p, const char* what) {
+  const int64_t limit = comm_timeout_ms();
+  if (limit <= 0) {
+    AGPU_HIP(hipStreamSynchronize(p->stream));
+    return AGPU_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 0;; spin++) {
+    hipError_t q = hipStreamQuery(p->stream);
+    if (q == hipSuccess) return AGPU_OK;
+    if (q != hipErrorNotReady) {
+      agpu_set_error("%s: %s", what, hipGetErrorString(q));
+      return AGPU_ERR_HIP;
+    }
+    if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spin & 255) == 255) {
+      const long long waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (waited > limit) {
+        comm_poison(c, what, waited);
+        return AGPU_ERR_HIP;
+      }
+    }
+  }
 }
 
 // reduce.hip: combine `world` gathered records in rank order → out_dev (1 element); kind: 0..2 = agpu_reduce_op on
@@ -122,6 +163,7 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
       agpu_set_error("agpu_comm_init_rank: rank %d of %d gave up after %lld ms waiting for the other ranks "
                      "(ncclCommInitRank is still pending on a helper thread: exit this process)",
                      (int)rank, (int)world, (long long)timeout_ms);
+      dev->poisoned.store(true, std::memory_order_release);  // the helper may hold device work: nothing may wait for the device now
       return AGPU_ERR_HIP;
     }
     if (job->hip != hipSuccess) {
@@ -178,6 +220,22 @@ agpu_status agpu_comm_runtime_info(char* out, size_t out_cap) {
 agpu_status agpu_comm_destroy(agpu_comm* c) {
   if (!c) return AGPU_OK;
   (void)hipSetDevice(c->dev->ordinal);
+  if (c->dev->poisoned.load(std::memory_order_acquire)) {
+    // a collective is stuck on some stream: never wait for the device.  ncclCommAbort raises the abort flag the stuck
+    // kernel polls (so the stream may drain after all); it runs on a helper thread because it may itself wait, and is
+    // given two seconds.  The record buffers and the event leak — the process is about to exit.
+    auto done = std::make_shared<std::atomic<bool>>(false);
+    ncclComm_t comm = c->comm;
+    const int ordinal = c->dev->ordinal;
+    std::thread([done, comm, ordinal]() {
+      (void)hipSetDevice(ordinal);
+      (void)ncclCommAbort(comm);
+      done->store(true, std::memory_order_release);
+    }).detach();
+    for (int i = 0; i < 400 && !done->load(std::memory_order_acquire); i++) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    delete c;
+    return AGPU_OK;
+  }
   (void)hipDeviceSynchronize();
   (void)ncclCommDestroy(c->comm);
   (void)hipFree(c->send);
@@ -193,11 +251,63 @@ agpu_status agpu_comm_rank(agpu_comm* c, int32_t* out_rank, int32_t* out_world) 
   return AGPU_OK;
 }
 
+// what RCCL itself reports — not what the caller passed to init
+agpu_status agpu_comm_size(agpu_comm* c, int32_t* out_count, int32_t* out_user_rank, int32_t* out_device) {
+  AGPU_REQUIRE(c, AGPU_ERR_ARG, "null communicator");
+  int v = 0;
+  if (out_count) {
+    AGPU_NCCL(ncclCommCount(c->comm, &v));
+    *out_count = v;
+  }
+  if (out_user_rank) {
+    AGPU_NCCL(ncclCommUserRank(c->comm, &v));
+    *out_user_rank = v;
+  }
+  if (out_device) {
+    AGPU_NCCL(ncclCommCuDevice(c->comm, &v));
+    *out_device = v;
+  }
+  return AGPU_OK;
+}
+
+static uint64_t fnv1a64(const void* data, size_t n, uint64_t h = 1469598103934665603ull) {
+  const unsigned char* b = static_cast<const unsigned char*>(data);
+  for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  return h;
+}
+
+// this process's identity record (no communicator needed: also what a host that gathers by other means would ship)
+agpu_status agpu_device_identity(agpu_device* dev, agpu_comm_peer* out) {
+  AGPU_REQUIRE(dev && out, AGPU_ERR_ARG, "null argument");
+  memset(out, 0, sizeof(*out));
+  out->rank = -1;
+  out->world = -1;
+  out->nccl_device = -1;
+  out->device_ordinal = dev->ordinal;
+  out->pci_domain = dev->props.pciDomainID;
+  out->pci_bus = dev->props.pciBusID;
+  out->pci_device = dev->props.pciDeviceID;
+  out->pid = (int32_t)getpid();
+  char host[256] = {0};
+  (void)gethostname(host, sizeof(host) - 1);
+  uint64_t h = fnv1a64(host, strlen(host));
+  if (FILE* f = fopen("/proc/sys/kernel/random/boot_id", "r")) {  // two containers of one name on different machines differ here
+    char boot[64] = {0};
+    if (fgets(boot, sizeof(boot), f)) h = fnv1a64(boot, strlen(boot), h);
+    fclose(f);
+  }
+  out->host_hash = h;
+  static_assert(sizeof(out->uuid) == sizeof(dev->props.uuid.bytes), "uuid is 16 bytes");
+  memcpy(out->uuid, dev->props.uuid.bytes, sizeof(out->uuid));
+  snprintf(out->gcn_arch, sizeof(out->gcn_arch), "%s", dev->props.gcnArchName);
+  return AGPU_OK;
+}
+
 static agpu_status comm_check(agpu_comm* c, agpu_pipeline* p) {
   AGPU_REQUIRE(c, AGPU_ERR_ARG, "null communicator");
   AGPU_REQUIRE(c->dev == p->dev, AGPU_ERR_ARG, "communicator and pipeline belong to different devices");
   AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "collectives are not captured into graphs");
-  return AGPU_OK;
+  return AGPU_OK;  // (a poisoned device never gets here: AGPU_BIND refuses it)
 }
 
 // Holds the communicator for one collective call: orders p's stream behind the previous call when that ran on another
@@ -307,28 +417,71 @@ agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p) {
   if (st != AGPU_OK) return st;
   comm_use use(c, p);
   AGPU_NCCL(ncclAllReduce(c->token, c->token, 1, ncclInt32, ncclMax, c->comm, p->stream));
-  const int64_t limit = comm_timeout_ms();
-  if (limit <= 0) {
-    AGPU_HIP(hipStreamSynchronize(p->stream));
-    return AGPU_OK;
-  }
   // a peer that died never joins the all-reduce and the stream would never drain: poll with a deadline instead
-  const auto t0 = std::chrono::steady_clock::now();
-  for (uint32_t spin = 0;; spin++) {
-    hipError_t q = hipStreamQuery(p->stream);
-    if (q == hipSuccess) return AGPU_OK;
-    if (q != hipErrorNotReady) {
-      agpu_set_error("agpu_comm_barrier: %s", hipGetErrorString(q));
+  return comm_wait_stream(c, p, "agpu_comm_barrier");
+}
+
+// The host wait that belongs behind agpu_comm_reduce / _all_reduce / _final_reduce: like agpu_pipeline_sync, but it gives up
+// after AGPU_COMM_TIMEOUT_MS (and poisons the device) instead of blocking for ever behind a collective a dead peer never joins.
+agpu_status agpu_comm_sync(agpu_comm* c, agpu_pipeline* p) {
+  AGPU_BIND(p);
+  agpu_status st = comm_check(c, p);
+  if (st != AGPU_OK) return st;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return comm_wait_stream(c, p, "agpu_comm_sync");
+}
+
+// One identity record per rank, gathered THROUGH the communicator: proof of which devices joined it.  out_host[r] is rank
+// r's record (rank / world as RCCL reports them there); *out_distinct = the number of distinct (host, PCI address) pairs.
+agpu_status agpu_comm_peers(agpu_comm* c, agpu_pipeline* p, agpu_comm_peer* out_host, int32_t cap, int32_t* out_distinct) {
+  AGPU_BIND(p);
+  agpu_status st = comm_check(c, p);
+  if (st != AGPU_OK) return st;
+  AGPU_REQUIRE(out_host && cap >= c->world, AGPU_ERR_ARG, "out_host must hold one record per rank");
+  agpu_comm_peer mine;
+  st = agpu_device_identity(c->dev, &mine);
+  if (st != AGPU_OK) return st;
+  st = agpu_comm_size(c, &mine.world, &mine.rank, &mine.nccl_device);
+  if (st != AGPU_OK) return st;
+  const size_t rec = sizeof(agpu_comm_peer);
+  char* mem = nullptr;
+  AGPU_HIP(hipMalloc(&mem, rec * ((size_t)c->world + 1)));
+  {
+    comm_use use(c, p);
+    hipError_t e = hipMemcpyAsync(mem, &mine, rec, hipMemcpyHostToDevice, p->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->stream);  // `mine` is pageable stack memory: the copy must be over before it goes
+    if (e != hipSuccess) {
+      (void)hipFree(mem);
+      agpu_set_error("agpu_comm_peers: %s", hipGetErrorString(e));
       return AGPU_ERR_HIP;
     }
-    if (spin > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
-    if ((spin & 255) == 255 &&
-        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > limit) {
-      agpu_set_error("agpu_comm_barrier: rank %d of %d waited %lld ms for the other ranks (AGPU_COMM_TIMEOUT_MS): exit this process",
-                     c->rank, c->world, (long long)limit);
+    ncclResult_t r = ncclAllGather(mem, mem + rec, rec, ncclUint8, c->comm, p->stream);
+    if (r != ncclSuccess) {
+      (void)hipFree(mem);
+      agpu_set_error("ncclAllGather failed: %s", ncclGetErrorString(r));
       return AGPU_ERR_HIP;
     }
+    st = comm_wait_stream(c, p, "agpu_comm_peers");
+    if (st != AGPU_OK) return st;  // poisoned: `mem` leaks with everything else
   }
+  hipError_t e = hipMemcpy(out_host, mem + rec, rec * (size_t)c->world, hipMemcpyDeviceToHost);
+  (void)hipFree(mem);
+  if (e != hipSuccess) {
+    agpu_set_error("agpu_comm_peers: %s", hipGetErrorString(e));
+    return AGPU_ERR_HIP;
+  }
+  if (out_distinct) {
+    int32_t d = 0;
+    for (int i = 0; i < c->world; i++) {
+      bool seen = false;
+      for (int j = 0; j < i && !seen; j++)
+        seen = out_host[j].host_hash == out_host[i].host_hash && out_host[j].pci_domain == out_host[i].pci_domain &&
+               out_host[j].pci_bus == out_host[i].pci_bus && out_host[j].pci_device == out_host[i].pci_device;
+      d += seen ? 0 : 1;
+    }
+    *out_distinct = d;
+  }
+  return AGPU_OK;
 }
 
 }  // extern "C"

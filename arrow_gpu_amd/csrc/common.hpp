@@ -73,6 +73,9 @@ struct agpu_device {
   int ordinal;
   hipDeviceProp_t props;
   int num_cus;
+  // set when a deadline-aware collective wait gave up (comm.hip): a collective nobody will ever join is queued on some
+  // stream, so nothing may wait for the device any more — calls fail fast, destroy calls leak, the process should exit
+  std::atomic<bool> poisoned{false};
   // 8 KiB of f64 {sin, cos} pairs for the 16-bit fused trig kernels (elementwise.hip: trig16_kernel), built once at
   // device creation: [l] = sincos(l), [256 + h] = sincos(256·h), l, h ∈ 0..255
   void* trig16_table = nullptr;

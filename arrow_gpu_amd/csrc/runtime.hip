@@ -262,13 +262,16 @@ static uint32_t arena_pick_colour_locked(agpu_device* dev, uint32_t arena, const
   return best_c;
 }
 
-// a cached arena block is handed out again: its 16 KiB of colour room lets the colour be chosen afresh for the new use
-static void* arena_recolour_locked(agpu_device* dev, void* ptr, const void* const* neighbours, int n_neighbours) {
+// a cached arena block is handed out again: its 16 KiB of colour room lets the colour be chosen afresh for the new use.
+// Only a request that was arena-padded (`has_room`) reserved that room: any other one (a table's block, pool_arena = 0) may
+// need every byte of the units, so it gets the block at colour 0 — a pointer moved up by 4–12 KiB would let the request's
+// tail (and its zero fill) run into the next arena block.
+static void* arena_recolour_locked(agpu_device* dev, void* ptr, bool has_room, const void* const* neighbours, int n_neighbours) {
   auto it = dev->arena_block.find(ptr);
   if (it == dev->arena_block.end()) return ptr;
   const agpu_device::ArenaBlock blk = it->second;
   char* q = dev->arenas[blk.arena].base + (size_t)blk.first * AGPU_ARENA_UNIT +
-            kArenaColour[arena_pick_colour_locked(dev, blk.arena, neighbours, n_neighbours)];
+            (has_room ? kArenaColour[arena_pick_colour_locked(dev, blk.arena, neighbours, n_neighbours)] : 0);
   if (q != ptr) {
     dev->arena_block.erase(it);
     dev->arena_block[q] = blk;
@@ -384,8 +387,18 @@ static void device_trim_locked(agpu_device* dev) {
   }
 }
 
+static const char* kPoisonedMsg = "the device is poisoned: a collective timed out and is still queued (comm.hip) — exit this process";
+#define AGPU_NOT_POISONED(dev)                                          \
+  do {                                                                  \
+    if ((dev)->poisoned.load(std::memory_order_acquire)) {              \
+      agpu_set_error("%s", kPoisonedMsg);                               \
+      return AGPU_ERR_HIP;                                              \
+    }                                                                   \
+  } while (0)
+
 agpu_status agpu_device_trim(agpu_device* dev) {
   AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
+  AGPU_NOT_POISONED(dev);
   AGPU_HIP(hipSetDevice(dev->ordinal));
   std::lock_guard<std::mutex> lock(dev->mu);
   device_trim_locked(dev);
@@ -420,6 +433,8 @@ agpu_status agpu_device_small_pool_info(agpu_device* dev, uint64_t* out_slab_byt
 agpu_status agpu_device_destroy(agpu_device* dev) {
   if (!dev) return AGPU_OK;
   (void)hipSetDevice(dev->ordinal);
+  // a stuck collective blocks every hipFree / hipStreamDestroy: leak the lot, the process is on its way out
+  if (dev->poisoned.load(std::memory_order_acquire)) return AGPU_OK;
   {
     std::lock_guard<std::mutex> lock(dev->mu);
     device_trim_locked(dev);
@@ -459,6 +474,7 @@ agpu_status agpu_device_destroy(agpu_device* dev) {
 
 agpu_status agpu_device_sync(agpu_device* dev) {
   AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
+  AGPU_NOT_POISONED(dev);
   AGPU_HIP(hipSetDevice(dev->ordinal));
   AGPU_HIP(hipDeviceSynchronize());
   return AGPU_OK;
@@ -561,6 +577,7 @@ agpu_status agpu_malloc_like(agpu_device* dev, size_t bytes, int32_t zero_fill, 
 static agpu_status malloc_impl(agpu_device* dev, size_t bytes, int32_t zero_fill, const void* const* neighbours, int n_neighbours,
                                void** out_ptr) {
   AGPU_REQUIRE(dev && out_ptr, AGPU_ERR_ARG, "null argument");
+  AGPU_NOT_POISONED(dev);  // reusing a block may wait for a marker behind the stuck collective
   AGPU_HIP(hipSetDevice(dev->ordinal));
   // pad to 16 B so vector tails of sub-word columns and bitmap words are always addressable
   size_t padded = (bytes + 15) & ~(size_t)15;
@@ -578,7 +595,7 @@ static agpu_status malloc_impl(agpu_device* dev, size_t bytes, int32_t zero_fill
     std::lock_guard<std::mutex> lock(dev->mu);
     auto it = dev->cache.lower_bound(padded);
     if (it != dev->cache.end() && it->first <= padded + padded / 8) {  // accept up to 12.5 % slack
-      p = arena_recolour_locked(dev, it->second.ptr, neighbours, n_neighbours);
+      p = arena_recolour_locked(dev, it->second.ptr, placed, neighbours, n_neighbours);
       pending = std::move(it->second.pending);
       dev->cached_bytes -= it->first;
       dev->block_size[p] = it->first;
@@ -662,6 +679,7 @@ static agpu_status malloc_impl(agpu_device* dev, size_t bytes, int32_t zero_fill
 agpu_status agpu_free(agpu_device* dev, void* ptr) {
   AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
   if (!ptr) return AGPU_OK;
+  if (dev->poisoned.load(std::memory_order_acquire)) return AGPU_OK;  // hipFree would wait for the device: leak (host destructors run this)
   AGPU_HIP(hipSetDevice(dev->ordinal));
   {  // a column of an agpu_malloc_table group: the block goes back when its last column does
     void* group_base = nullptr;
@@ -1023,6 +1041,10 @@ agpu_status agpu_pipeline_destroy(agpu_pipeline* p) {
   if (!p) return AGPU_OK;
   agpu_device* dev = p->dev;
   (void)hipSetDevice(dev->ordinal);
+  if (dev->poisoned.load(std::memory_order_acquire)) {  // its stream may hold the stuck collective: no wait, no hipStreamDestroy
+    delete p;
+    return AGPU_OK;
+  }
   if (p->t0) (void)hipEventDestroy(p->t0);
   if (p->t1) (void)hipEventDestroy(p->t1);
   agpu_stream_slot* s = p->slot;
@@ -1275,6 +1297,7 @@ agpu_status agpu_scope_enter(agpu_pipeline* p, const char* name) {
     agpu_set_error("%s: null pipeline", name);
     return AGPU_ERR_ARG;
   }
+  AGPU_NOT_POISONED(p->dev);  // every pipeline call: uploads, downloads, syncs and launches alike would queue or wait behind it
   AGPU_HIP(hipSetDevice(p->dev->ordinal));
   agpu_device* dev = p->dev;
 #ifndef AGPU_TEST_NO_ORDERING

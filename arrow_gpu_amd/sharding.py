@@ -238,6 +238,48 @@ def final_reduce(sum_t=None, min_t=None, max_t=None, count_t=None, group=None):
     return sum_t, min_t, max_t, count_t
 
 
+class Peer(C.Structure):
+    """include/arrow_gpu.h `agpu_comm_peer`: one rank's identity as gathered through the communicator."""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("device_ordinal", C.c_int32), ("nccl_device", C.c_int32),
+                ("pci_domain", C.c_int32), ("pci_bus", C.c_int32), ("pci_device", C.c_int32), ("pid", C.c_int32),
+                ("host_hash", C.c_uint64), ("uuid", C.c_uint8 * 16), ("gcn_arch", C.c_char * 16)]
+
+    def as_dict(self) -> dict:
+        return {"rank": self.rank, "world": self.world, "device_ordinal": self.device_ordinal, "nccl_device": self.nccl_device,
+                "pci": f"{self.pci_domain:04x}:{self.pci_bus:02x}:{self.pci_device:02x}", "pid": self.pid,
+                "host": f"{self.host_hash:016x}", "uuid": bytes(self.uuid).hex(), "arch": self.gcn_arch.decode(errors="replace")}
+
+
+assert C.sizeof(Peer) == 72
+
+
+def world_proof(peers, expect_gpus: int) -> dict:
+    """What a multi-GPU record may claim, from the identity records the ranks exchanged THROUGH the communicator (`Communicator.peers`;
+    dicts as `Peer.as_dict` makes them, in rank order).  n_gpus = the number of ranks RCCL reports, and the record is only valid when
+    every rank reports that same count, the ranks are 0..n-1 in order, every rank drives a DIFFERENT physical GPU (host + PCI address,
+    uuid where the driver gives one) and the count is what `--gpus` asked for.  Returns {"ok", "rccl_ranks", "distinct_devices",
+    "devices", "errors"}; pure function — the same on every rank, so all ranks take the same exit."""
+    errors = []
+    n = len(peers)
+    counts = sorted({int(q["world"]) for q in peers})
+    if counts != [n]:
+        errors.append(f"ncclCommCount differs from the number of gathered records: counts {counts}, records {n}")
+    if [int(q["rank"]) for q in peers] != list(range(n)):
+        errors.append(f"ranks out of order: {[int(q['rank']) for q in peers]}")
+    phys = [(q["host"], q["pci"]) for q in peers]
+    distinct = len(set(phys))
+    if distinct != n:
+        dup = sorted({x for x in phys if phys.count(x) > 1})
+        errors.append(f"{n} ranks on {distinct} distinct devices: {dup} shared")
+    uu = [q["uuid"] for q in peers if q.get("uuid") and set(q["uuid"]) != {"0"}]
+    if len(uu) == n and len(set(uu)) != n:
+        errors.append("two ranks report the same device uuid")
+    if n != expect_gpus:
+        errors.append(f"--gpus {expect_gpus} but {n} ranks joined the communicator")
+    return {"ok": not errors, "rccl_ranks": n, "distinct_devices": distinct,
+            "devices": [f'{q["host"][:8]}/{q["pci"]}' for q in peers], "errors": errors}
+
+
 class Communicator:
     """RCCL communicator of the C ABI (include/arrow_gpu.h "multi-GPU"): one rank per GPU, used ONLY for the final
     reduce of whole-column statistics.  Nothing like it exists in the reference (single device + queue,
@@ -324,6 +366,25 @@ class Communicator:
 
     def barrier(self, pipeline) -> None:
         capi.call("agpu_comm_barrier", self._h, pipeline._handle)
+
+    def sync(self, pipeline) -> None:
+        """Host wait for the pipeline's stream WITH the collective deadline (AGPU_COMM_TIMEOUT_MS): the wait to use behind
+        `reduce` / `all_reduce` / `final_reduce` — a plain `pipeline.sync()` or a download would block for ever behind a
+        collective a dead peer never joins.  On a timeout the device is poisoned (see include/arrow_gpu.h): exit the process."""
+        capi.call("agpu_comm_sync", self._h, pipeline._handle)
+
+    def size(self) -> tuple:
+        """(ncclCommCount, ncclCommUserRank, ncclCommCuDevice): what RCCL reports, not what the launcher said."""
+        n, r, d = C.c_int32(), C.c_int32(), C.c_int32()
+        capi.call("agpu_comm_size", self._h, C.byref(n), C.byref(r), C.byref(d))
+        return n.value, r.value, d.value
+
+    def peers(self, pipeline) -> list:
+        """Collective: every rank's identity record (`Peer.as_dict`), gathered through the communicator, in rank order."""
+        arr = (Peer * self.world)()
+        distinct = C.c_int32()
+        capi.call("agpu_comm_peers", self._h, pipeline._handle, arr, self.world, C.byref(distinct))
+        return [q.as_dict() for q in arr]
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -392,7 +392,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
                              "--master-port P bench.py --gpus N ...")
-        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; using {world}", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks: the world check below will refuse the run", file=sys.stderr)
     if os.environ.get("AGPU_BENCH_DEVICE_OVERRIDE") is not None:
         # rehearsal on a 1-GPU box only (tools/r03_bootstrap_rehearsal.sh): every rank names the same GPU, so RCCL's bootstrap between
         # the processes runs for real and its init then refuses the duplicate device — a clean failure, never a measurement
@@ -404,8 +404,27 @@ def main():
     # all-reduce are exercised on a single-GPU box too
     comm = sharding.Communicator.from_env(dev, timeout_s=args.rendezvous_timeout)
     runtime = sharding.Communicator.runtime_info()
+    # ---- what the line may claim as n_gpus is what RCCL says, proven by one identity record per rank gathered THROUGH the
+    # communicator (rank, ncclCommCount, PCI address, uuid): the launcher's WORLD_SIZE is only the expectation it is checked
+    # against.  A world that is not N distinct devices in one communicator ends here, on every rank alike (the verdict is a
+    # pure function of the gathered records), with ONE JSON error line from rank 0 and a non-zero exit — never a number.
+    peers = comm.peers(p)
+    proof = sharding.world_proof(peers, args.gpus)
+    if comm.size()[0] != proof["rccl_ranks"]:
+        proof["ok"] = False
+        proof["errors"].append(f"ncclCommCount {comm.size()[0]} on rank {rank} vs {proof['rccl_ranks']} gathered records")
     if rank == 0:
-        print(f"bench.py: world {world}, {runtime}", file=sys.stderr)
+        print(f"bench.py: world {world} (RCCL reports {proof['rccl_ranks']} ranks on {proof['distinct_devices']} distinct devices), {runtime}", file=sys.stderr)
+    if not proof["ok"] and not os.environ.get("AGPU_BENCH_ALLOW_WORLD_MISMATCH"):
+        if rank == 0:
+            real_stdout.write(json.dumps({"error": "the communicator is not the world --gpus names", "n_gpus_requested": args.gpus,
+                                          "launcher_world": world, "rccl_ranks": proof["rccl_ranks"], "distinct_devices": proof["distinct_devices"],
+                                          "devices": proof["devices"], "details": proof["errors"]}) + "\n")
+            real_stdout.flush()
+        comm.barrier(p)
+        comm.close()
+        sys.exit(3)
+    world = proof["rccl_ranks"]  # from here on the world IS what RCCL reports
 
     if args.scaling == "weak":  # the column has world × rows rows, this rank owns one contiguous chunk of it
         shard = sharding.shard_rows(args.rows * world, world, rank)
@@ -474,9 +493,21 @@ def main():
         arr = np.array(values, np.float64)
         capi.call("agpu_upload", h, vp(stat_buf), C.c_void_p(arr.ctypes.data), arr.nbytes)
         comm.all_reduce(p, op, capi.COMM_F64, stat_buf, len(values))
+        comm.sync(p)  # the wait with the collective deadline: a download would block for ever behind a collective a dead peer never joins
         out = np.empty_like(arr)
         capi.call("agpu_download", h, C.c_void_p(out.ctypes.data), vp(stat_buf), arr.nbytes)
         return [float(x) for x in out]
+
+    def all_ranks_ok(ok: bool) -> bool:
+        """A leg that contains collectives runs inside try/except on every rank; if ONE rank failed, the ranks would issue different
+        collective sequences from here on (wrong numbers, or a hang).  So after such a leg the ranks agree on a failure word (MAX):
+        at world 1 this is the local flag; at world > 1 any failure is fatal for every rank — exit together, no line."""
+        bad = across_ranks([0.0 if ok else 1.0], capi.RED_MAX)[0] > 0.0
+        if bad and world > 1:
+            print(f"bench.py: rank {rank}: a rank failed inside a collective leg; all ranks exit", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(4)
+        return not bad
 
     def timed_run(step, steps, warmup):
         """The contract's timed region: warm-up, barrier + device sync, EXACTLY `steps` steps, barrier + device sync; MAX over
@@ -526,7 +557,10 @@ def main():
             capi.call("agpu_download", h, C.c_void_p(gv.ctypes.data), C.c_void_p(ov.ptr + start // 8), nbytes)
             windows.append({"row": row0 + start, "rows": cnt, "add": got, "eq_bits": gb, "eq_validity": gv})
 
-    extra = {"runtime": runtime, "per_rank": per_rank}
+    extra = {"runtime": runtime, "per_rank": per_rank, "rccl_ranks": proof["rccl_ranks"], "distinct_devices": proof["distinct_devices"],
+             "devices": peers, "launcher_world": int(os.environ.get("WORLD_SIZE", "1")),
+             "world_proof": "one identity record per rank all-gathered through the RCCL communicator (agpu_comm_peers): rank / ncclCommCount as "
+                            "RCCL reports them on that rank, PCI address, uuid, pid; n_gpus = ncclCommCount, checked against --gpus"}
 
     # ---- strong-scaling leg of a weak run: the same step over this rank's share of a `rows`-row column (shard_rows cuts
     # it: 125 M rows per GPU at world 8), on the leading rows of the resident shards; same barrier-bracketed timing.
@@ -542,14 +576,23 @@ def main():
                 "per_rank": pr_s,
                 "what": "the 1e9-row column cut into `world` contiguous shards (sharding.shard_rows); same step, same "
                         "barrier-bracketed region, MAX over ranks; run on the leading rows of the weak run's resident shards"}
+            leg_ok = True
         except Exception as e:  # noqa: BLE001
             extra["strong_scaling"] = {"error": f"{type(e).__name__}: {e}"}
+            leg_ok = False
+            if world > 1:  # the other ranks are inside (or past) collectives this rank never issued: nothing to agree on any more
+                import traceback
+
+                traceback.print_exc()
+                os._exit(4)
+        all_ranks_ok(leg_ok)
 
     # ---- config 5: per-shard sum/min/max + final reduce over RCCL (outside the timed region).  Everything below goes
     # through the C ABI's communicator (include/arrow_gpu.h "multi-GPU"): agpu_comm_reduce = the shard-local kernel
     # (for SUM the reference-order tree, sum_tree_quarter_kernel + sum_tree_combine_kernel) + an all-gather of one 16-byte
     # record per rank + the rank-ordered combine.
-    try:  # the headline line must come out even if this leg cannot run (it is reported, not part of `value`)
+    try:  # the headline line must come out even if this leg cannot run (it is reported, not part of `value`) — at world 1;
+        # at world > 1 a rank that fails in here has left the collective sequence: fatal for all (below)
         stat_out = {k: dev.create_empty_buffer(16) for k in ("sum", "min", "max", "sum_f64")}
         p.sync()
         stats = {}
@@ -578,7 +621,7 @@ def main():
         comm.reduce(p, capi.RED_MAX, capi.F32, fa, None, n, stat_out["max"])
         comm.reduce_sum_f64(p, fa, None, n, stat_out["sum_f64"])
         capi.call("agpu_event_record", ce, h)
-        p.sync()
+        comm.sync(p)
         four_ms = ms_between(cs, ce)
         import numpy as _np
 
@@ -599,6 +642,11 @@ def main():
         }
     except Exception as e:  # noqa: BLE001
         extra["reduce_sum_min_max"] = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1:
+            import traceback
+
+            traceback.print_exc()
+            os._exit(4)
     extra["kernels"] = {"add_f32": {"ms": round(add_ms, 4), "GBps": round(add_gbps, 1), "frac_hbm_peak": round(add_gbps / HBM_PEAK_GBPS, 4)},
                         "eq_i32_validity": {"ms": round(eq_ms, 4), "GBps": round(eq_gbps, 1), "frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4)}}
 

@@ -28,6 +28,7 @@ struct RankResult {
   float sum = 0, mn = 0, mx = 0;
   double stats_ms = 0, step_s = 0, add_ms = 0, eq_ms = 0;
   uint64_t rows = 0;
+  int rccl_ranks = 0, distinct_devices = 0;
   std::string error;
 };
 
@@ -56,6 +57,14 @@ int main(int argc, char** argv) {
       auto dev = GpuDevice::create(r);
       ArrowComputePipeline p(dev, "rank");
       Communicator comm(dev, id, r, world, 60000);  // collective: all threads arrive here, or give up after 60 s
+      {  // what the line may claim: RCCL's own rank count and one identity record per rank gathered through the communicator
+        auto pr = comm.peers(p);
+        out.rccl_ranks = comm.size();
+        out.distinct_devices = pr.second;
+        if (out.rccl_ranks != world || pr.second != world)
+          throw ArrowErrorGPU(ArrowErrorGPU::Runtime, "the communicator is not `world` distinct devices: ncclCommCount " +
+                                                          std::to_string(out.rccl_ranks) + ", distinct devices " + std::to_string(pr.second));
+      }
       const Shard sh = shard_rows(total, world, r);
       const uint64_t n = sh.rows, nb = agpu_bitmap_bytes(n);
       out.rows = n;
@@ -104,13 +113,13 @@ int main(int argc, char** argv) {
         buf->dev = dev;  // the Buffer frees f[0] (an ordinary member of the table block) when the array goes
         Float32ArrayGPU shard(buf, dev, n, std::nullopt);
         (void)sum_sharded_op(shard, comm, p);  // warm-up: scratch + RCCL's first call
-        p.sync();
+        comm.sync(p);
         comm.barrier(p);
         t0 = std::chrono::steady_clock::now();
         auto s = sum_sharded_op(shard, comm, p);
         auto lo = min_sharded_op(shard, comm, p);
         auto hi = max_sharded_op(shard, comm, p);
-        p.sync();
+        comm.sync(p);  // the wait with the collective deadline (p.sync() would block for ever behind a collective a dead peer never joins)
         comm.barrier(p);
         out.stats_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         out.sum = s.raw_values()[0];
@@ -147,11 +156,11 @@ int main(int argc, char** argv) {
     _Exit(1);
   }
   printf("{\"what\": \"C++ host, one thread per GPU: f32 add + i32 eq with validity (bench.py's step), then chunk-sharded f32 "
-         "sum/min/max with the RCCL final reduce\", \"world\": %d, \"scaling\": \"%s\", \"rows_total\": %llu, \"rows_rank0\": %llu, "
+         "sum/min/max with the RCCL final reduce\", \"world\": %d, \"rccl_ranks\": %d, \"distinct_devices\": %d, \"scaling\": \"%s\", \"rows_total\": %llu, \"rows_rank0\": %llu, "
          "\"steps\": %d, \"value_GBps\": %.2f, \"ms_per_step\": %.4f, \"add_ms\": {\"min\": %.4f, \"max\": %.4f}, "
          "\"eq_ms\": {\"min\": %.4f, \"max\": %.4f}, \"sum\": %.9g, \"min\": %.9g, \"max\": %.9g, \"ms_3_statistics\": %.4f, "
          "\"statistics_aggregate_GBps\": %.1f, \"identical_on_all_ranks\": true, \"runtime\": \"%s\"}\n",
-         world, strong ? "strong" : "weak", (unsigned long long)total, (unsigned long long)res[0].rows, steps,
+         world, res[0].rccl_ranks, res[0].distinct_devices, strong ? "strong" : "weak", (unsigned long long)total, (unsigned long long)res[0].rows, steps,
          20.5 * (double)total * steps / step_s / 1e9, step_s / steps * 1e3, add_lo, add_hi, eq_lo, eq_hi, res[0].sum, res[0].mn,
          res[0].mx, stats_ms, 3.0 * 4.0 * (double)total / stats_ms / 1e6, Communicator::runtime_info().c_str());
   return 0;

@@ -1193,6 +1193,23 @@ class Communicator {
     if (raw) agpu_comm_destroy(raw);
   }
   void barrier(ArrowComputePipeline& p) { check(agpu_comm_barrier(raw, p.h()), "agpu_comm_barrier"); }
+  // the host wait that belongs behind a collective (reduce_sharded_op, all-reduce): like p.sync() but with the collective deadline;
+  // a timeout throws, the device is poisoned (include/arrow_gpu.h) and every destructor on the way out returns without waiting
+  void sync(ArrowComputePipeline& p) { check(agpu_comm_sync(raw, p.h()), "agpu_comm_sync"); }
+  // what RCCL reports (ncclCommCount), not what the launcher said
+  int size() const {
+    int32_t n = 0;
+    check(agpu_comm_size(raw, &n, nullptr, nullptr), "agpu_comm_size");
+    return n;
+  }
+  // collective: one identity record per rank gathered through the communicator; .second = distinct (host, PCI address) pairs —
+  // equal to world exactly when every rank drives its own GPU
+  std::pair<std::vector<agpu_comm_peer>, int> peers(ArrowComputePipeline& p) {
+    std::vector<agpu_comm_peer> v((size_t)world);
+    int32_t distinct = 0;
+    check(agpu_comm_peers(raw, p.h(), v.data(), world, &distinct), "agpu_comm_peers");
+    return {std::move(v), distinct};
+  }
 };
 
 // Whole-column Sum / min / max of a sharded column → 1-element array holding the SAME value on every rank.

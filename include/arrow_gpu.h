@@ -495,6 +495,35 @@ agpu_status agpu_comm_all_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op 
                                  uint64_t count);
 /* collective + host wait on p's stream; gives up with AGPU_ERR_HIP after AGPU_COMM_TIMEOUT_MS when a peer never joins */
 agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p);
+/* The host wait that belongs behind agpu_comm_reduce / _all_reduce / _final_reduce (instead of agpu_pipeline_sync or a
+ * download, which would block for ever behind a collective a dead peer never joins): waits for p's stream, gives up after
+ * AGPU_COMM_TIMEOUT_MS.
+ * POISONING: when this wait, agpu_comm_barrier, agpu_comm_peers or agpu_comm_init_rank(_timeout) gives up, a collective
+ * nobody will join is still queued on the device.  The device is then marked poisoned: every pipeline call, agpu_malloc,
+ * agpu_device_sync / _trim return AGPU_ERR_HIP at once; agpu_free, agpu_pipeline_destroy and agpu_device_destroy return
+ * AGPU_OK without waiting (they leak); agpu_comm_destroy aborts the communicator (ncclCommAbort, bounded to 2 s) instead of
+ * draining it — so a host unwinding through its destructors ends instead of hanging.  Exit the process afterwards. */
+agpu_status agpu_comm_sync(agpu_comm* c, agpu_pipeline* p);
+/* What RCCL itself reports for this communicator — ncclCommCount, ncclCommUserRank, ncclCommCuDevice — as opposed to what
+ * the caller passed to init (agpu_comm_rank).  Any out pointer may be NULL. */
+agpu_status agpu_comm_size(agpu_comm* c, int32_t* out_count, int32_t* out_user_rank, int32_t* out_device);
+/* One identity record per rank, so that a multi-GPU record can PROVE which devices joined one communicator. */
+typedef struct agpu_comm_peer {
+  int32_t rank;           /* ncclCommUserRank on the rank the record came from (-1 from agpu_device_identity) */
+  int32_t world;          /* ncclCommCount as that rank sees it */
+  int32_t device_ordinal; /* HIP ordinal inside that rank's process (after HIP_VISIBLE_DEVICES) */
+  int32_t nccl_device;    /* ncclCommCuDevice */
+  int32_t pci_domain, pci_bus, pci_device; /* hipDeviceProp_t: the physical address of the GPU */
+  int32_t pid;
+  uint64_t host_hash;     /* FNV-1a 64 of hostname + kernel boot id: equal on one node */
+  uint8_t uuid[16];       /* hipDeviceProp_t.uuid */
+  char gcn_arch[16];      /* "gfx950…", truncated */
+} agpu_comm_peer;         /* 72 bytes */
+agpu_status agpu_device_identity(agpu_device* dev, agpu_comm_peer* out);
+/* collective: all-gather of the records THROUGH the communicator + host wait with the deadline.  out_host[r] = rank r's
+ * record (cap ≥ world); *out_distinct (may be NULL) = number of distinct (host_hash, PCI address) among them — equal to
+ * world exactly when every rank drives its own GPU. */
+agpu_status agpu_comm_peers(agpu_comm* c, agpu_pipeline* p, agpu_comm_peer* out_host, int32_t cap, int32_t* out_distinct);
 
 /* ---------------------------------------------------------------- Arrow C Data Interface
  * The reference builds arrays from host Vecs and reads them back as Vecs

@@ -227,3 +227,82 @@ def test_comm_from_env_and_runtime_info(monkeypatch, tmp_path):
     assert list(tmp_path.iterdir()) == []
     info = Communicator.runtime_info()
     assert "rccl" in info and "librccl" in info and "libamdhip64" in info
+
+
+# ---- round 4: a multi-GPU record that proves itself and a failed collective that cannot hang the host
+def test_comm_size_and_peers_report_what_rccl_sees(ctx):
+    """agpu_comm_size = ncclCommCount / UserRank / CuDevice; agpu_comm_peers gathers one identity record per rank THROUGH the
+    communicator — at world 1: this process, this GPU; `sharding.world_proof` turns the records into the n_gpus a line may claim"""
+    import os
+
+    from arrow_gpu_amd import sharding
+
+    dev, p, comm = ctx
+    n, r, d = comm.size()
+    assert (n, r) == (1, 0) and d == dev.ordinal
+    peers = comm.peers(p)
+    assert len(peers) == 1
+    me = peers[0]
+    assert me["rank"] == 0 and me["world"] == 1 and me["pid"] == os.getpid() and me["device_ordinal"] == dev.ordinal
+    assert me["arch"].startswith("gfx950") and len(me["uuid"]) == 32 and len(me["host"]) == 16
+    ident = sharding.Peer()
+    capi.call("agpu_device_identity", dev._handle, C.byref(ident))
+    same = ident.as_dict()
+    assert (same["pci"], same["uuid"], same["host"]) == (me["pci"], me["uuid"], me["host"]) and same["rank"] == -1
+    proof = sharding.world_proof(peers, 1)
+    assert proof["ok"] and proof["rccl_ranks"] == 1 and proof["distinct_devices"] == 1
+    assert not sharding.world_proof(peers, 8)["ok"]       # --gpus 8 on a one-rank communicator is refused
+    assert not sharding.world_proof(peers + peers, 2)["ok"]  # two records of ONE device are not two GPUs
+    # the deadline-aware wait behind a collective
+    out = dev.create_empty_buffer(16)
+    buf = dev.create_gpu_buffer_with_data(O.synth_f32(100_000, 1, 0, -1.0, 1.0))
+    comm.reduce(p, capi.RED_MAX, capi.F32, buf, None, 100_000, out)
+    comm.sync(p)
+    assert dev.retrive_data(out, 4, pipeline=p).view(np.float32)[0] == O.synth_f32(100_000, 1, 0, -1.0, 1.0).max()
+
+
+_POISON_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+from arrow_gpu_amd import _capi as capi
+from arrow_gpu_amd._capi import ArrowErrorGPU
+from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+from arrow_gpu_amd.sharding import Communicator
+dev = GpuDevice(0)
+p = ArrowComputePipeline(dev, "poison")
+buf = dev.create_gpu_buffer_with_data(np.arange(1000, dtype=np.float32))
+try:
+    Communicator(dev, 0, 2, Communicator.unique_id(), timeout_s=2.0)   # rank 1 of 2 never arrives → the device is poisoned
+    os._exit(10)
+except ArrowErrorGPU:
+    pass
+t0 = time.monotonic()
+fails = 0
+for call in (lambda: p.sync(), lambda: dev.sync(), lambda: dev.create_empty_buffer(1 << 20), lambda: dev.retrive_data(buf, 4000, pipeline=p)):
+    try:
+        call()
+    except ArrowErrorGPU as e:
+        fails += 1 if "poisoned" in str(e) else 0
+# destructors / destroy calls return instead of waiting for the device
+del buf
+capi.lib().agpu_pipeline_destroy(p._handle); p._handle = None
+capi.lib().agpu_device_destroy(dev._handle); dev._handle = None
+dt = time.monotonic() - t0
+sys.stdout.write("POISONED fails=%d dt=%.2f\n" % (fails, dt))
+sys.stdout.flush()
+os._exit(0 if fails == 4 and dt < 10 else 5)
+"""
+
+
+def test_a_timed_out_collective_poisons_the_device_and_nothing_hangs_afterwards():
+    """after a collective deadline every call fails fast and the destroy calls leak instead of synchronising, so a host
+    unwinding through destructors ends (a fresh process: the pending RCCL call stays behind on its helper thread)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _POISON_WORKER.format(root=root)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "POISONED fails=4" in r.stdout

@@ -261,3 +261,42 @@ def test_big_pool_blocks_come_out_of_placed_arenas():
     finally:
         capi.call("agpu_set_tuning", b"pool_arena", 1)
         capi.call("agpu_device_trim", dev._handle)
+
+
+def test_a_cached_arena_block_reused_for_a_table_keeps_to_its_units():
+    """a cache hit used to be re-coloured whatever the request was.  A table's block (agpu_malloc_table asks with
+    the arena switched off, so without the 16 KiB of colour room) whose total equals the cached arena block's size must get
+    the block at colour 0 — moved up by 4–12 KiB its zero fill and last column ran into the next arena block."""
+    import ctypes as C
+
+    import numpy as np
+
+    from arrow_gpu_amd import _capi as capi
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+
+    dev = GpuDevice(0)
+    p = ArrowComputePipeline(dev, "arena-table")
+    capi.call("agpu_device_trim", dev._handle)
+    unit, big = 512 << 20, (1 << 30) + 4096
+    for attempt in range(4):  # the rotating colour: every starting phase of it
+        blocks = [dev.create_empty_buffer(big) for _ in range(3)]             # units 0-2, 3-5, 6-8 of one arena
+        base = min(b.ptr for b in blocks) & ~0x3FFF
+        order = sorted(range(3), key=lambda k: blocks[k].ptr)
+        mid, last = blocks[order[1]], blocks[order[2]]
+        assert (last.ptr - base) // unit == 6 and (mid.ptr - base) // unit == 3
+        capi.call("agpu_memset", p._handle, C.c_void_p(last.ptr), 0xA5, 1 << 20)
+        p.sync()
+        mid_unit = mid.ptr & ~0x3FFF
+        blocks[order[1]] = None
+        del mid                                                                # → the size-keyed cache, 3 units
+        table = dev.create_table_buffers([3 * unit - 16384], zero_fill=True)   # total = 3 units exactly, no colour room
+        assert table[0].ptr == mid_unit, (attempt, hex(table[0].ptr), hex(mid_unit))  # reused, at colour 0
+        got = np.empty(1 << 20, np.uint8)
+        capi.call("agpu_download", p._handle, C.c_void_p(got.ctypes.data), C.c_void_p(last.ptr), 1 << 20)
+        assert (got == 0xA5).all(), attempt                                    # the neighbour is intact
+        capi.call("agpu_memset", p._handle, C.c_void_p(table[0].ptr), 0x11, 3 * unit - 16384)  # usable to its last byte
+        capi.call("agpu_download", p._handle, C.c_void_p(got.ctypes.data), C.c_void_p(last.ptr), 1 << 20)
+        assert (got == 0xA5).all(), attempt
+        del table, blocks, last
+        p.sync()
+        capi.call("agpu_device_trim", dev._handle)

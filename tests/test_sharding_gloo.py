@@ -161,3 +161,71 @@ def test_record_batches_are_sharded_as_contiguous_runs_in_rank_order():
             per_rank = [sum(rows[b] for b in run) for run in runs]
             if rows and sum(rows):
                 assert max(per_rank) - sum(rows) / world <= max(rows)
+
+
+# ---- the record that makes an N > 1 bench line self-proving: `sharding.world_proof` over the identity records
+# the ranks exchange through the communicator (`agpu_comm_peers` on the GPU; gloo's all_gather_object as the stand-in here)
+def _peer(rank, world, pci_bus, host="00c0ffee00c0ffee", uuid=None):
+    return {"rank": rank, "world": world, "device_ordinal": rank, "nccl_device": rank, "pci": f"0000:{pci_bus:02x}:00", "pid": 1000 + rank,
+            "host": host, "uuid": uuid if uuid is not None else f"{pci_bus:032x}", "arch": "gfx950"}
+
+
+def test_world_proof_accepts_n_distinct_devices_and_nothing_else():
+    from arrow_gpu_amd.sharding import world_proof
+
+    good = [_peer(r, 8, 0x10 + r) for r in range(8)]
+    pr = world_proof(good, 8)
+    assert pr["ok"] and pr["rccl_ranks"] == 8 and pr["distinct_devices"] == 8 and len(pr["devices"]) == 8 and not pr["errors"]
+    assert world_proof([_peer(0, 1, 5)], 1)["ok"]
+    # the launcher was asked for 8 but 4 ranks joined
+    pr = world_proof([_peer(r, 4, 0x10 + r) for r in range(4)], 8)
+    assert not pr["ok"] and pr["rccl_ranks"] == 4 and any("--gpus 8" in e for e in pr["errors"])
+    # two ranks on one physical GPU (same host + PCI address): 8 ranks, 7 devices
+    shared = [_peer(r, 8, 0x10 + (r if r != 7 else 0)) for r in range(8)]
+    pr = world_proof(shared, 8)
+    assert not pr["ok"] and pr["distinct_devices"] == 7 and any("distinct devices" in e for e in pr["errors"])
+    # the same PCI address on ANOTHER host is another device
+    two_nodes = [_peer(r, 2, 0x10, host=f"{r:016x}", uuid=f"{r + 1:032x}") for r in range(2)]
+    assert world_proof(two_nodes, 2)["ok"]
+    # a rank whose RCCL communicator has another size than the number of records (two communicators mixed up)
+    odd = [_peer(0, 2, 0x10), _peer(1, 3, 0x11)]
+    assert not world_proof(odd, 2)["ok"]
+    # ranks out of order / duplicated
+    assert not world_proof([_peer(1, 2, 0x10), _peer(0, 2, 0x11)], 2)["ok"]
+    assert not world_proof([_peer(0, 2, 0x10), _peer(0, 2, 0x11)], 2)["ok"]
+    # same uuid behind two PCI addresses (a partitioned GPU seen twice)
+    assert not world_proof([_peer(0, 2, 0x10, uuid="ab" * 16), _peer(1, 2, 0x11, uuid="ab" * 16)], 2)["ok"]
+    # drivers that report an all-zero uuid are not held against the run
+    assert world_proof([_peer(0, 2, 0x10, uuid="0" * 32), _peer(1, 2, 0x11, uuid="0" * 32)], 2)["ok"]
+
+
+def _proof_worker(rank, world, port, same_device, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = _peer(dist.get_rank(), dist.get_world_size(), 0x20 if same_device else 0x20 + rank)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        q.put((rank, sharding.world_proof(gathered, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("same_device", [False, True])
+def test_world_proof_world2_gloo_every_rank_reaches_the_same_verdict(same_device):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_proof_worker, args=(r, 2, port, same_device, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=120) for _ in range(2))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert res[0] == res[1]                       # a pure function of the gathered records: all ranks take the same exit
+    assert res[0]["ok"] == (not same_device) and res[0]["rccl_ranks"] == 2
+    assert res[0]["distinct_devices"] == (1 if same_device else 2)
