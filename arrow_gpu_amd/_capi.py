@@ -138,6 +138,7 @@ SIGNATURES = {
     "agpu_broadcast_from_device": [_vp, _i32, _vp, _vp, _u64],
     "agpu_fused_chain": [_vp, _i32, _vp, _vp, _i32, _vp, _u64],
     "agpu_fused_chain_compare": [_vp, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _u64],
+    "agpu_fused_cast_chain": [_vp, _i32, _vp, _vp, _i32, _vp, _u64],
     "agpu_compare": [_vp, _i32, _i32, _vp, _vp, _vp, _u64],
     "agpu_compare_validity": [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _u64],
     "agpu_bitmap_binary": [_vp, _i32, _vp, _vp, _vp, _u64],

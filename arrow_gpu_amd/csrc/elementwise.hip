@@ -1607,6 +1607,8 @@ __device__ __forceinline__ T chain_apply_unary(int op, T x) {
       case AGPU_UN_LOG2: return UnLog2::ap(x, x);
       case AGPU_UN_SIN: return UnSin::ap(x, x);
       case AGPU_UN_COS: return UnCos::ap(x, x);
+      case AGPU_UN_ACOS: return UnAcos::ap(x, x);
+      case AGPU_UN_SINH: return UnSinh::ap(x, x);
       default: return x;
     }
   } else {
@@ -1736,8 +1738,7 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_kernel(const T* in, T* ou
 
 // one row of the chain, element-granular (tails, unaligned columns)
 template <typename T>
-__device__ __forceinline__ T chain_eval_row(const T* in, uint64_t i, int n_steps, uint64_t code, const ChainPtrs& ptrs) {
-  T acc = in[i];
+__device__ __forceinline__ T chain_eval_from(T acc, uint64_t i, int n_steps, uint64_t code, const ChainPtrs& ptrs) {
   for (int s = 0; s < n_steps; s++) {
     const int op = chain_op(code, s), kind = chain_kind(code, s);
     if (kind == AGPU_CHAIN_UNARY) {
@@ -1751,6 +1752,10 @@ __device__ __forceinline__ T chain_eval_row(const T* in, uint64_t i, int n_steps
     }
   }
   return acc;
+}
+template <typename T>
+__device__ __forceinline__ T chain_eval_row(const T* in, uint64_t i, int n_steps, uint64_t code, const ChainPtrs& ptrs) {
+  return chain_eval_from<T>(in[i], i, n_steps, code, ptrs);
 }
 
 // compare tail: one 32-bit output word per thread, words [first_word, n_words); bits past n are written as 0
@@ -1840,6 +1845,121 @@ static agpu_status launch_chain(agpu_pipeline* p, const void* in, void* out, uin
   return AGPU_OK;
 }
 
+// ---------------------------------------------------------------- chains with a WIDENING CAST at the head (agpu_fused_cast_chain)
+// acc = (float)in[i] for an 8- / 16-bit integer column, then the f32 chain — `cast → sin`, `cast → mul_scalar → add_scalar` as the
+// reference's callers write them [ref: crates/trigonometry/src/u8_kernel.rs:34-38 fuses exactly cast + trig; examples/simple.rs:45-72
+// chains `*_op`s] — in ONE pass: the narrow column is read once (1–2 B/row), the f32 result written once, the 4 B/row intermediate
+// the unfused pair writes and re-reads never exists.  The shape is cvt_wide_kernel's: one wave per 1 KiB chunk of the narrow column,
+// 16-byte loads, the chunk transposed inside the wave (ds_bpermute) so that each of the R stores is a coalesced 1 KiB row; the chain
+// runs on the f32x4 pack in between, with exactly chain_kernel's functors (bit-identical to the unfused sequence).  ARRAY operands
+// are f32 columns read at the store position.
+template <typename TI, bool HEAVY, int NARR>
+__global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* in, float* out, uint64_t nchunks, int n_steps,
+                                                                     int n_arrs, uint64_t code, ChainPtrs ptrs, ChainPtrs arrs) {
+  constexpr int R = 4 / sizeof(TI);  // 4 (8-bit) or 2 (16-bit) stores per load
+  constexpr int NO = 4;
+  constexpr uint32_t WAVES = AGPU_CVTW_BLOCK / AGPU_WAVE;
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
+  uint32_t sc[AGPU_CHAIN_MAX_STEPS];
+  static_for<AGPU_CHAIN_MAX_STEPS>([&](auto s) { sc[s] = *(const __attribute__((address_space(4))) uint32_t*)(ptrs.p[s]); });
+  for (uint64_t c = (uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE; c < nchunks; c += (uint64_t)gridDim.x * WAVES) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
+    static_for<R>([&](auto j) {
+      const uint64_t at = (c * (uint64_t)(AGPU_WAVE * R) + (uint32_t)j * AGPU_WAVE + lane) * NO;  // first row of this lane's store
+      PackN<float, NO> ya[NARR > 0 ? NARR : 1];
+      static_for<NARR>([&](auto a) {
+        if (a < n_arrs) ya[a] = load_pack<true, float, NO>(static_cast<const float*>(arrs.p[a]) + at);
+      });
+      const int src = (int)(((uint32_t)j * (AGPU_WAVE / R) + lane / R) * 4);
+      const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.x);
+      const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.y);
+      const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.z);
+      const uint32_t w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.w);
+      PackN<TI, NO> x;
+      if constexpr (R == 4) {
+        const uint32_t sel = lane & 3u;
+        const uint32_t w = sel == 0 ? w0 : sel == 1 ? w1 : sel == 2 ? w2 : w3;
+        x = __builtin_bit_cast(PackN<TI, NO>, w);
+      } else {
+        const bool hi = (lane & 1u) != 0;
+        const u32x2 w = {hi ? w2 : w0, hi ? w3 : w1};
+        x = __builtin_bit_cast(PackN<TI, NO>, w);
+      }
+      PackN<float, NO> acc;
+#pragma unroll
+      for (int k = 0; k < NO; k++) acc.v[k] = (float)x.v[k];
+      int ai = 0;
+      for (int s = 0; s < n_steps; s++) {
+        const int op = chain_op(code, s), kind = chain_kind(code, s);
+        if (kind == AGPU_CHAIN_UNARY) {
+#pragma unroll
+          for (int k = 0; k < NO; k++) acc.v[k] = chain_apply_unary<float, HEAVY>(op, acc.v[k]);
+        } else {
+          PackN<float, NO> y;
+          if (kind == AGPU_CHAIN_ARRAY) {
+            y = ya[0];
+            static_for<NARR>([&](auto q) {
+              if (q == ai) y = ya[q];
+            });
+            ai++;
+          } else {
+            uint32_t w = 0;
+            static_for<AGPU_CHAIN_MAX_STEPS>([&](auto q) {
+              if (q == s) w = sc[q];
+            });
+            const float f = __builtin_bit_cast(float, w);
+#pragma unroll
+            for (int k = 0; k < NO; k++) y.v[k] = f;
+          }
+#pragma unroll
+          for (int k = 0; k < NO; k++) acc.v[k] = chain_apply_binary<float>(op, acc.v[k], y.v[k]);
+        }
+      }
+      store_pack<(AGPU_STREAM_NT & 2) != 0, float, NO, (R == 2)>(out + at, acc);
+    });
+  }
+}
+// rows [first, n), one per lane (tails, unaligned columns): the same arithmetic
+template <typename TI>
+__global__ __launch_bounds__(AGPU_EW_BLOCK) void cast_chain_tail_kernel(const TI* in, float* out, uint64_t first, uint64_t n,
+                                                                       int n_steps, uint64_t code, ChainPtrs ptrs) {
+  for (uint64_t i = first + (uint64_t)blockIdx.x * AGPU_EW_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_EW_BLOCK)
+    out[i] = chain_eval_from<float>((float)in[i], i, n_steps, code, ptrs);
+}
+
+template <typename TI>
+static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* out, uint64_t n, int n_steps, uint64_t code,
+                                     const ChainPtrs& ptrs, bool vec_ok, bool heavy) {
+  const TI* pi = static_cast<const TI*>(in);
+  constexpr uint64_t chunk_rows = (uint64_t)AGPU_WAVE * 16 / sizeof(TI);
+  const uint64_t nchunks = vec_ok ? n / chunk_rows : 0;
+  if (nchunks) {
+    ChainPtrs arrs{}, scal;
+    int n_arrs = 0;
+    for (int s = 0; s < AGPU_CHAIN_MAX_STEPS; s++) {
+      scal.p[s] = (s < n_steps && ptrs.p[s]) ? ptrs.p[s] : in;  // every slot readable: the kernel loads all eight
+      if (s < n_steps && chain_kind(code, s) == AGPU_CHAIN_ARRAY) arrs.p[n_arrs++] = ptrs.p[s];
+    }
+    const int slots = n_arrs == 0 ? 0 : n_arrs <= 2 ? 2 : 4;
+    const int grid = stream_grid_for(p, (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE));
+#define AGPU_CCHAIN_CASE(H, A)                                                                                              \
+  if (heavy == H && slots == A)                                                                                             \
+    hipLaunchKernelGGL((cast_chain_kernel<TI, H, A>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, out, nchunks, n_steps, \
+                       n_arrs, code, scal, arrs);
+    AGPU_CCHAIN_CASE(false, 0) AGPU_CCHAIN_CASE(false, 2) AGPU_CCHAIN_CASE(false, 4)
+    AGPU_CCHAIN_CASE(true, 0) AGPU_CCHAIN_CASE(true, 2) AGPU_CCHAIN_CASE(true, 4)
+#undef AGPU_CCHAIN_CASE
+  }
+  if (nchunks * chunk_rows < n) {
+    const uint64_t rest = n - nchunks * chunk_rows;
+    const int grid = stream_grid_for(p, (rest + AGPU_EW_BLOCK - 1) / AGPU_EW_BLOCK);
+    hipLaunchKernelGGL((cast_chain_tail_kernel<TI>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, out, nchunks * chunk_rows, n,
+                       n_steps, code, ptrs);
+  }
+  AGPU_LAUNCH_CHECK();
+  return AGPU_OK;
+}
+
 extern "C" {
 
 // cmp_op < 0: agpu_fused_chain.  cmp_op ≥ 0: agpu_fused_chain_compare — the compare's operand rides in step slot n_steps.
@@ -1872,7 +1992,7 @@ static agpu_status chain_dispatch(agpu_pipeline* p, agpu_dtype dtype, const void
     const bool is_f = dtype == AGPU_F32;
     if (steps[s].kind == AGPU_CHAIN_UNARY) {
       const int o = steps[s].op;
-      const bool ok = is_f ? (o == AGPU_UN_NEG || o == AGPU_UN_ABS || (o >= AGPU_UN_SQRT && o <= AGPU_UN_COS))
+      const bool ok = is_f ? (o == AGPU_UN_NEG || o == AGPU_UN_ABS || (o >= AGPU_UN_SQRT && o <= AGPU_UN_SINH))
                            : (o == AGPU_UN_NEG || o == AGPU_UN_ABS || o == AGPU_UN_NOT);
       AGPU_REQUIRE(ok, AGPU_ERR_UNSUPPORTED, "unary op not available in fused chains for this dtype");
       if (is_f && o >= AGPU_UN_CBRT) heavy = true;
@@ -1901,6 +2021,52 @@ agpu_status agpu_fused_chain_compare(agpu_pipeline* p, agpu_dtype dtype, const v
                                      int32_t n_steps, agpu_cmp_op cmp_op, int32_t operand_kind, const void* operand,
                                      void* out_bits, uint64_t n) {
   return chain_dispatch(p, dtype, in, steps, n_steps, out_bits, n, (int)cmp_op, operand_kind, operand);
+}
+
+agpu_status agpu_fused_cast_chain(agpu_pipeline* p, agpu_dtype from, const void* in, const agpu_chain_step* steps,
+                                  int32_t n_steps, float* out, uint64_t n) {
+  AGPU_REQUIRE(p, AGPU_ERR_ARG, "null pipeline");
+  AGPU_REQUIRE(from == AGPU_U8 || from == AGPU_I8 || from == AGPU_U16 || from == AGPU_I16, AGPU_ERR_UNSUPPORTED,
+               "fused cast chains start from u8 / i8 / u16 / i16 (the reference's casts to f32)");
+  AGPU_REQUIRE(n_steps >= 0 && n_steps <= AGPU_CHAIN_MAX_STEPS, AGPU_ERR_ARG, "0..8 steps per chain");
+  AGPU_REQUIRE(n == 0 || (in && out && (n_steps == 0 || steps)), AGPU_ERR_ARG, "null pointer");
+  if (n_steps == 0) return agpu_cast(p, from, AGPU_F32, in, out, n);
+  // cast → sin / cos / sinh of an 8-bit column IS the reference's fused kernel [trigonometry/src/u8_kernel.rs:34-38]: the 256-entry
+  // table is built with the f32 kernels' own device functions, so the lookup is bit-identical to the unfused pair
+  if (n_steps == 1 && steps[0].kind == AGPU_CHAIN_UNARY && (from == AGPU_U8 || from == AGPU_I8) &&
+      (steps[0].op == AGPU_UN_SIN || steps[0].op == AGPU_UN_COS || steps[0].op == AGPU_UN_SINH))
+    return agpu_unary(p, (agpu_unary_op)steps[0].op, from, in, out, n);
+  AGPU_BIND(p);
+  if (n == 0) return AGPU_OK;
+  ChainPtrs ptrs{};
+  uint64_t code = 0;
+  bool vec_ok = aligned16(in) && aligned16(out), heavy = false;
+  int n_arrays = 0;
+  for (int s = 0; s < n_steps; s++) {
+    code |= ((uint64_t)(steps[s].op & 15) | ((uint64_t)(steps[s].kind & 3) << 4)) << (6 * s);
+    ptrs.p[s] = steps[s].operand;
+    const int o = steps[s].op;
+    if (steps[s].kind == AGPU_CHAIN_UNARY) {
+      const bool ok = o == AGPU_UN_NEG || o == AGPU_UN_ABS || (o >= AGPU_UN_SQRT && o <= AGPU_UN_SINH);
+      AGPU_REQUIRE(ok, AGPU_ERR_UNSUPPORTED, "unary op not available in fused chains for f32");
+      if (o >= AGPU_UN_CBRT) heavy = true;
+    } else {
+      AGPU_REQUIRE(steps[s].kind == AGPU_CHAIN_SCALAR || steps[s].kind == AGPU_CHAIN_ARRAY, AGPU_ERR_ARG, "bad step kind");
+      AGPU_REQUIRE(steps[s].operand, AGPU_ERR_ARG, "null operand");
+      AGPU_REQUIRE(o >= AGPU_OP_ADD && o <= AGPU_OP_MAX, AGPU_ERR_UNSUPPORTED, "binary op not available in fused chains for f32");
+      if (steps[s].kind == AGPU_CHAIN_ARRAY) {
+        n_arrays++;
+        if (!aligned16(steps[s].operand)) vec_ok = false;
+      }
+    }
+  }
+  AGPU_REQUIRE(n_arrays <= 4, AGPU_ERR_UNSUPPORTED, "at most four array operands behind a cast head");
+  switch (from) {
+    case AGPU_U8: return launch_cast_chain<uint8_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, heavy);
+    case AGPU_I8: return launch_cast_chain<int8_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, heavy);
+    case AGPU_U16: return launch_cast_chain<uint16_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, heavy);
+    default: return launch_cast_chain<int16_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, heavy);
+  }
 }
 
 agpu_status agpu_binary(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, const void* a, const void* b, void* out,

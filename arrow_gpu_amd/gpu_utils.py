@@ -148,6 +148,7 @@ _FUSE_DEFAULT = os.environ.get("AGPU_FUSE", "0") not in ("", "0")
 _CHAIN_MAX = 8
 _UNARY, _SCALAR, _ARRAY = 0, 1, 2
 _CMP = 3  # recorded compare (array operand): may only END a chain; `op` is an agpu_cmp_op, `out` the result bitmap
+_CAST = 4  # recorded widening cast u8 / i8 / u16 / i16 → f32: may only START a chain; `op` is the SOURCE agpu_dtype, `dtype` F32
 
 
 class ArrowComputePipeline:
@@ -198,10 +199,19 @@ class ArrowComputePipeline:
         self.stats["recorded"] += 1
         return node
 
+    def record_cast(self, from_dtype: int, a: DeviceBuffer, out: DeviceBuffer, n: int) -> _LazyNode:
+        """A widening cast to f32 (u8 / i8 / u16 / i16 source): the head of a chain such as `cast → sin`."""
+        node = _LazyNode(_CAST, from_dtype, capi.F32, a, None, out, n, None)
+        self._pending.append(node)
+        self.stats["recorded"] += 1
+        return node
+
     def _launch_single(self, nd: _LazyNode) -> None:
         vp = lambda b: C.c_void_p(b.ptr)  # noqa: E731
         if nd.kind == _CMP:
             capi.call("agpu_compare", self._h, nd.op, nd.dtype, vp(nd.a), vp(nd.operand), vp(nd.out), nd.n)
+        elif nd.kind == _CAST:
+            capi.call("agpu_cast", self._h, nd.op, capi.F32, vp(nd.a), vp(nd.out), nd.n)
         elif nd.kind == _UNARY:
             capi.call("agpu_unary", self._h, nd.op, nd.dtype, vp(nd.a), vp(nd.out), nd.n)
         elif nd.kind == _SCALAR:
@@ -226,12 +236,24 @@ class ArrowComputePipeline:
                 # buffer, a later node reading it or a keep-alive entry all add one and keep it materialised.
                 dead = (last.out_ref is not None and last.out_ref() is None and sys.getrefcount(last.out) == 3)
                 if (nxt.a is last.out and nxt.operand is not last.out and nxt.n == last.n and nxt.dtype == last.dtype
+                        and nxt.kind != _CAST and not (chain[0].kind == _CAST and nxt.kind == _CMP)  # a cast only starts a chain; cast-headed chains store
                         and dead and not read_later(last.out, i + len(chain) + 1)):
                     chain.append(nxt)
                 else:
                     break
             if len(chain) == 1:
                 self._launch_single(chain[0])
+            elif chain[0].kind == _CAST:  # narrow column in, the f32 chain behind it, one launch (agpu_fused_cast_chain)
+                body = chain[1:]
+                steps = (_ChainStep * len(body))()
+                for k, nd in enumerate(body):
+                    steps[k].op, steps[k].kind = nd.op, nd.kind
+                    steps[k].operand = nd.operand.ptr if nd.operand is not None else None
+                capi.call("agpu_fused_cast_chain", self._h, chain[0].op, C.c_void_p(chain[0].a.ptr), C.cast(steps, C.c_void_p), len(body),
+                          C.c_void_p(chain[-1].out.ptr), chain[0].n)
+                self.stats["kernels"] += 1
+                self.stats["fused_chains"] += 1
+                self.stats["fused_ops"] += len(chain)
             else:
                 body = chain[:-1] if chain[-1].kind == _CMP else chain
                 steps = (_ChainStep * len(body))()

@@ -50,7 +50,7 @@ _FUSABLE_DTYPES = (capi.F32, capi.I32, capi.U32, capi.DATE32)
 _FUSABLE_BINARY_F32 = (capi.OP_ADD, capi.OP_SUB, capi.OP_MUL, capi.OP_DIV, capi.OP_REM, capi.OP_MIN, capi.OP_MAX)
 _FUSABLE_BINARY_INT = _FUSABLE_BINARY_F32 + (capi.OP_AND, capi.OP_OR, capi.OP_XOR)
 _FUSABLE_UNARY_F32 = (capi.UN_NEG, capi.UN_ABS, capi.UN_SQRT, capi.UN_CBRT, capi.UN_EXP, capi.UN_EXP2, capi.UN_LOG, capi.UN_LOG2,
-                      capi.UN_SIN, capi.UN_COS)
+                      capi.UN_SIN, capi.UN_COS, capi.UN_ACOS, capi.UN_SINH)
 _FUSABLE_UNARY_INT = (capi.UN_NEG, capi.UN_ABS, capi.UN_NOT)
 _KIND_UNARY, _KIND_SCALAR, _KIND_ARRAY = 0, 1, 2
 

@@ -11,7 +11,7 @@ from .._capi import CastingNotSupported
 from ..array import (ARRAY_OF_TYPE, ArrowArrayGPU, ArrowType, BooleanArrayGPU, Float32ArrayGPU, Int8ArrayGPU,
                      Int16ArrayGPU, Int32ArrayGPU, NullBitBufferGpu, UInt8ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU)
 from ..gpu_utils import ArrowComputePipeline
-from ._ops import vp
+from ._ops import _finish_record, vp
 
 # cast_dyn's table [crates/cast/src/lib.rs:135-161]
 CAST_TABLE = {
@@ -25,6 +25,7 @@ CAST_TABLE = {
     BooleanArrayGPU: (Float32ArrayGPU,),
 }
 BITCAST_TABLE = {UInt32ArrayGPU: (Float32ArrayGPU,)}
+_WIDENING_HEADS = (UInt8ArrayGPU, Int8ArrayGPU, UInt16ArrayGPU, Int16ArrayGPU)  # casts a fusing pipeline may record
 
 
 def _cast_op(self: ArrowArrayGPU, into, pipeline: ArrowComputePipeline):
@@ -32,10 +33,16 @@ def _cast_op(self: ArrowArrayGPU, into, pipeline: ArrowComputePipeline):
         raise CastingNotSupported(f"Casting not supported for type {self.get_dtype().name} {into.ARROW_TYPE.name}")
     dev = self.gpu_device
     out = dev.create_empty_buffer(max(self.len * into.ITEM_SIZE, 1))
-    capi.call("agpu_cast", pipeline._handle, self.DTYPE, into.DTYPE, vp(self.data), vp(out), self.len)
-    pipeline.keep(self.data, out)
+    node = None
+    if getattr(pipeline, "fuse", False) and into is Float32ArrayGPU and type(self) in _WIDENING_HEADS:
+        # a fusing pipeline records the widening cast: `cast_op → sin_op`, `cast_op → mul_scalar_op → …` become ONE launch at
+        # finish() (agpu_fused_cast_chain) when the caller dropped the f32 intermediate  [SURVEY §8f-2: "cast → sin"]
+        node = pipeline.record_cast(self.DTYPE, self.data, out, self.len)
+    else:
+        capi.call("agpu_cast", pipeline._handle, self.DTYPE, into.DTYPE, vp(self.data), vp(out), self.len)
+        pipeline.keep(self.data, out)
     nulls = NullBitBufferGpu.clone_null_bit_buffer_op(self.null_buffer, pipeline)
-    return into(out, dev, self.len, nulls)
+    return _finish_record(node, into(out, dev, self.len, nulls))
 
 
 def _cast(self, into):

@@ -10,6 +10,10 @@ The reference batches the dispatches of a chain into one command buffer (`exampl
 Each step applies the same scalar operation with the same rounding as the stand-alone kernel, so the result is
 bit-identical to `a.add_scalar(s).mul_scalar(s)`; validity follows the reference's rules step by step (clone for
 unary/scalar steps, AND with every array operand's validity).  f32 / i32 / u32 / Date32 columns, ≤ 8 steps.
+
+A u8 / i8 / u16 / i16 column may START a chain: the widening cast to f32 is its head (`agpu_fused_cast_chain`) and the steps are
+f32 steps — `ag.FusedChain(u8_col).sin().finish()` is the reference's fused `sin_u8` (trigonometry/src/u8_kernel.rs:34-38),
+`ag.FusedChain(u8_col).mul_scalar(s).add_scalar(o).finish()` reads 1 B/row and writes 4 instead of 5 + 8 + 8.
 """
 from __future__ import annotations
 
@@ -17,7 +21,8 @@ import ctypes as C
 
 from .. import _capi as capi
 from .._capi import ArrowErrorGPU, OperationNotSupported
-from ..array import Date32ArrayGPU, Float32ArrayGPU, Int32ArrayGPU, NullBitBufferGpu, UInt32ArrayGPU
+from ..array import (Date32ArrayGPU, Float32ArrayGPU, Int8ArrayGPU, Int16ArrayGPU, Int32ArrayGPU, NullBitBufferGpu, UInt8ArrayGPU,
+                     UInt16ArrayGPU, UInt32ArrayGPU)
 from ..gpu_utils import ArrowComputePipeline
 from ._ops import vp
 
@@ -34,15 +39,18 @@ _BINARY = {"add": capi.OP_ADD, "sub": capi.OP_SUB, "mul": capi.OP_MUL, "div": ca
            "bitwise_xor": capi.OP_XOR}
 _UNARY = {"neg": capi.UN_NEG, "abs": capi.UN_ABS, "bitwise_not": capi.UN_NOT, "sqrt": capi.UN_SQRT, "cbrt": capi.UN_CBRT,
           "exp": capi.UN_EXP, "exp2": capi.UN_EXP2, "log": capi.UN_LOG, "log2": capi.UN_LOG2, "sin": capi.UN_SIN,
-          "cos": capi.UN_COS}
+          "cos": capi.UN_COS, "acos": capi.UN_ACOS, "sinh": capi.UN_SINH}
 _TYPES = (Float32ArrayGPU, Int32ArrayGPU, UInt32ArrayGPU, Date32ArrayGPU)
+_CAST_HEADS = (UInt8ArrayGPU, Int8ArrayGPU, UInt16ArrayGPU, Int16ArrayGPU)  # the chain computes in f32 behind a widening cast
 
 
 class FusedChain:
     def __init__(self, array):
-        if type(array) not in _TYPES:
+        if type(array) not in _TYPES + _CAST_HEADS:
             raise OperationNotSupported(f"FusedChain not supported for type {array.get_dtype().name}")
         self.src = array
+        self.cast_head = type(array) in _CAST_HEADS
+        self.acc_cls = Float32ArrayGPU if self.cast_head else type(array)  # the type the steps compute in / the result type
         self.steps = []  # (op, kind, operand array or None)
 
     def _push(self, op, kind, operand):
@@ -52,9 +60,9 @@ class FusedChain:
         return self
 
     def _binary(self, name, other, force_scalar=False):
-        if type(other).NP_DTYPE != type(self.src).NP_DTYPE:
+        if type(other).NP_DTYPE != self.acc_cls.NP_DTYPE or (self.cast_head and name.startswith("bitwise")):
             raise OperationNotSupported(
-                f"Operation {name} not supported for type {self.src.get_dtype().name} {other.get_dtype().name}")
+                f"Operation {name} not supported for type {self.acc_cls.ARROW_TYPE.name} {other.get_dtype().name}")
         scalar = force_scalar or (other.len == 1 and self.src.len != 1)
         if not scalar and other.len != self.src.len:
             raise ArrowErrorGPU("ShapeError", f"{name}: arrays of different length", capi.ERR_SHAPE)
@@ -63,7 +71,7 @@ class FusedChain:
     def finish_op(self, pipeline: ArrowComputePipeline):
         a = self.src
         dev = a.gpu_device
-        out = dev.create_empty_buffer(max(a.len * a.ITEM_SIZE, 1))
+        out = dev.create_empty_buffer(max(a.len * self.acc_cls.ITEM_SIZE, 1))
         steps = (_Step * max(len(self.steps), 1))()
         nulls = a.null_buffer  # validity: AND with every ARRAY operand's bitmap; unary / scalar steps clone
         for i, (op, kind, operand) in enumerate(self.steps):
@@ -75,10 +83,14 @@ class FusedChain:
                 pipeline.keep(operand.data)
         if nulls is a.null_buffer:  # never merged: the output owns a copy, like every unary/scalar op
             nulls = NullBitBufferGpu.clone_null_bit_buffer_op(nulls, pipeline)
-        capi.call("agpu_fused_chain", pipeline._handle, a.DTYPE, vp(a.data), C.cast(steps, C.c_void_p), len(self.steps),
-                  vp(out), a.len)
+        if self.cast_head:
+            capi.call("agpu_fused_cast_chain", pipeline._handle, a.DTYPE, vp(a.data), C.cast(steps, C.c_void_p), len(self.steps),
+                      vp(out), a.len)
+        else:
+            capi.call("agpu_fused_chain", pipeline._handle, a.DTYPE, vp(a.data), C.cast(steps, C.c_void_p), len(self.steps),
+                      vp(out), a.len)
         pipeline.keep(a.data, out)
-        return type(a)(out, dev, a.len, nulls)
+        return self.acc_cls(out, dev, a.len, nulls)
 
     def finish(self):
         p = ArrowComputePipeline(self.src.get_gpu_device(), "fused_chain")
@@ -91,7 +103,7 @@ class FusedChain:
         from ..array import BooleanArrayGPU, bitmap_bytes
 
         a = self.src
-        if type(other).NP_DTYPE != type(a).NP_DTYPE:
+        if self.cast_head or type(other).NP_DTYPE != type(a).NP_DTYPE:  # (a cast-headed chain stores its result; compare it afterwards)
             raise OperationNotSupported(f"Operation {name} not supported for type {a.get_dtype().name} {other.get_dtype().name}")
         if len(self.steps) >= MAX_STEPS:
             raise ArrowErrorGPU("ShapeError", f"a fused chain holds at most {MAX_STEPS - 1} steps before a compare", capi.ERR_SHAPE)
@@ -143,9 +155,9 @@ def _make_scalar(name):
 
 def _make_unary(name):
     def method(self):
-        if name == "bitwise_not" and type(self.src) is Float32ArrayGPU:
+        if name == "bitwise_not" and self.acc_cls is Float32ArrayGPU:
             raise OperationNotSupported("Operation bitwise_not not supported for type Float32Type")
-        if name not in ("neg", "abs", "bitwise_not") and type(self.src) is not Float32ArrayGPU:
+        if name not in ("neg", "abs", "bitwise_not") and self.acc_cls is not Float32ArrayGPU:
             raise OperationNotSupported(f"Operation {name} not supported for type {self.src.get_dtype().name}")
         return self._push(_UNARY[name], UNARY, None)
 

@@ -309,7 +309,8 @@ agpu_status agpu_broadcast_from_device(agpu_pipeline* p, agpu_dtype dtype, const
  *     acc = in[i];  for each step: acc = op(acc, operand_i)   (operand = none | 1-element scalar buffer | array[n])
  * in ONE kernel: the column is read once and written once however long the chain is.  Every step applies exactly the
  * same scalar operation, in the same order and with the same rounding, as the stand-alone kernel, so the result is
- * bit-identical to running the ops one by one.  dtype ∈ {F32, I32, U32, DATE32}; all arrays have n rows.
+ * bit-identical to running the ops one by one.  dtype ∈ {F32, I32, U32, DATE32}; all arrays have n rows.  Unary steps: neg abs (all),
+ * not (integers), sqrt cbrt exp exp2 log log2 sin cos acos sinh (f32).
  * kind == AGPU_CHAIN_UNARY: `op` is an agpu_unary_op and `operand` is ignored; otherwise `op` is an agpu_binary_op. */
 typedef enum { AGPU_CHAIN_UNARY = 0, AGPU_CHAIN_SCALAR = 1, AGPU_CHAIN_ARRAY = 2 } agpu_chain_kind;
 typedef struct {
@@ -327,6 +328,17 @@ agpu_status agpu_fused_chain(agpu_pipeline* p, agpu_dtype dtype, const void* in,
 agpu_status agpu_fused_chain_compare(agpu_pipeline* p, agpu_dtype dtype, const void* in, const agpu_chain_step* steps,
                                      int32_t n_steps, agpu_cmp_op cmp_op, int32_t operand_kind, const void* operand,
                                      void* out_bits, uint64_t n);
+
+/* A chain with a WIDENING CAST at its head: acc = (float)in[i] for a u8 / i8 / u16 / i16 column, then the f32 chain, stored as
+ * f32 — `cast → sin`, `cast → mul_scalar → add_scalar` in ONE pass: the narrow column is read once (1–2 B/row) and the result
+ * written once; the 4 B/row intermediate of the unfused pair (written by the cast, re-read by the next op) never exists:
+ * cast u8→f32 then sin is 5 B/row instead of 13.  Bit-identical to agpu_cast(from → F32) followed by the steps one by one.
+ * Steps: f32 unary (neg abs sqrt cbrt exp exp2 log log2 sin cos acos sinh), f32 scalar / array (add sub mul div rem min max;
+ * ≤ 4 array operands, f32 columns of n rows).  n_steps == 0: the plain cast.  `cast → sin | cos | sinh` of an 8-bit column runs the
+ * reference's own fused kernels [ref: crates/trigonometry/src/u8_kernel.rs:34-38, i8_kernel.rs; the chain API of
+ * crates/arrow/examples/simple.rs:45-72]. */
+agpu_status agpu_fused_cast_chain(agpu_pipeline* p, agpu_dtype from, const void* in, const agpu_chain_step* steps,
+                                  int32_t n_steps, float* out, uint64_t n);
 
 /* ---------------------------------------------------------------- compare → bitmap
  * out_bits bit i = a[i] cmp b[i], LSB-first, agpu_bitmap_bytes(n) bytes written, padding bits 0.

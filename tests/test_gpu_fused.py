@@ -56,7 +56,11 @@ def test_int_chain_and_errors(ag):
     with pytest.raises(ag.OperationNotSupported):
         ag.FusedChain(a).sqrt()
     with pytest.raises(ag.OperationNotSupported):
-        ag.FusedChain(ag.UInt8ArrayGPU.from_slice([1], dev))
+        ag.FusedChain(ag.BooleanArrayGPU.from_slice([True], dev))
+    with pytest.raises(ag.OperationNotSupported):   # behind a cast head the chain is an f32 chain: no bitwise steps, f32 operands only
+        ag.FusedChain(ag.UInt8ArrayGPU.from_slice([1], dev)).bitwise_not()
+    with pytest.raises(ag.OperationNotSupported):
+        ag.FusedChain(ag.UInt8ArrayGPU.from_slice([1], dev)).add(ag.UInt8ArrayGPU.from_slice([1], dev))
     with pytest.raises(ag.OperationNotSupported):
         ag.FusedChain(a).add(ag.Float32ArrayGPU.from_slice([1.0] * n, dev))
     ch = ag.FusedChain(a)
@@ -188,3 +192,137 @@ def test_fusing_pipeline_ends_chains_in_compares(ag):
     assert bits(m.raw_values()) == bits(a.mul(b).add(c).gt(d).raw_values())
     assert bits(m2.raw_values()) == bits(a.sub(b).lteq(c).raw_values())
     assert bits(keep.raw_values()) == bits(a.sub(b).raw_values())
+
+
+# ---------------------------------------------------------------- round 4: a widening cast at the head of a chain (agpu_fused_cast_chain)
+# `cast → sin` is what SURVEY §8f-2 names; the reference fuses exactly cast + trig in its *_u8 kernels
+# [crates/trigonometry/src/u8_kernel.rs:34-38] and chains `*_op`s in examples/simple.rs:45-72.
+NARROW = {"u8": ("UInt8ArrayGPU", np.uint8), "i8": ("Int8ArrayGPU", np.int8), "u16": ("UInt16ArrayGPU", np.uint16), "i16": ("Int16ArrayGPU", np.int16)}
+
+
+def _narrow(ag, dev, kind, n, seed, nulls=False):
+    cls, npd = getattr(ag, NARROW[kind][0]), NARROW[kind][1]
+    info = np.iinfo(npd)
+    rng = np.random.default_rng(seed)
+    vals = rng.integers(info.min, int(info.max) + 1, n, dtype=np.int64).astype(npd)
+    if n >= 4:
+        vals[:4] = [info.min, info.max, 0, 1]
+    if not nulls:
+        return cls.from_slice(vals, dev)
+    return cls.from_optional_slice([None if rng.random() < 0.2 else int(v) for v in vals], dev)
+
+
+@pytest.mark.parametrize("kind", list(NARROW))
+@pytest.mark.parametrize("n", [0, 1, 5, 511, 512, 513, 1023, 1024, 1025, 4099, 1_000_003])
+def test_cast_headed_chain_bit_identical_to_cast_then_ops(ag, kind, n):
+    """FusedChain(narrow).steps…  ==  narrow.cast(f32).steps…  bit for bit, values and validity, every tail shape"""
+    dev = ag.GPU_DEVICE()
+    a = _narrow(ag, dev, kind, n, n + 7, nulls=n < 5000)
+    b, c = _rand(ag, dev, n, 2, nulls=0 < n < 5000), _rand(ag, dev, n, 3)
+    s, o = ag.Float32ArrayGPU.from_slice([0.0123], dev), ag.Float32ArrayGPU.from_slice([-3.5], dev)
+    F32 = ag.Float32ArrayGPU
+    cases = {
+        "plain cast": (lambda ch: ch, lambda x: x),
+        "sin": (lambda ch: ch.sin(), lambda x: x.sin()),
+        "cos": (lambda ch: ch.cos(), lambda x: x.cos()),
+        "sinh": (lambda ch: ch.sinh(), lambda x: x.sinh()),
+        "scale+offset": (lambda ch: ch.mul_scalar(s).add_scalar(o), lambda x: x.mul_scalar(s).add_scalar(o)),
+        "scalars+heavy": (lambda ch: ch.mul_scalar(s).sin().abs().sqrt().neg(), lambda x: x.mul_scalar(s).sin().abs().sqrt().neg()),
+        "arrays": (lambda ch: ch.mul(b).add(c).abs().sqrt(), lambda x: x.mul(b).add(c).abs().sqrt()),
+        "arrays+heavy": (lambda ch: ch.mul_scalar(s).add(b).cos().sub(c).max(b), lambda x: x.mul_scalar(s).add(b).cos().sub(c).max(b)),
+        "acos": (lambda ch: ch.mul_scalar(s).acos(), lambda x: x.mul_scalar(s).acos()),
+    }
+    for name, (fused_fn, eager_fn) in cases.items():
+        fused = fused_fn(ag.FusedChain(a)).finish()
+        eager = eager_fn(a.cast(F32))
+        assert type(fused) is F32 and fused.len == n
+        assert bits(fused.raw_values()) == bits(eager.raw_values()), (kind, n, name)
+        assert (fused.null_buffer is None) == (eager.null_buffer is None), (kind, n, name)
+        if fused.null_buffer is not None:
+            assert bits(fused.null_buffer.raw_values()) == bits(eager.null_buffer.raw_values()), (kind, n, name)
+
+
+@pytest.mark.parametrize("kind", list(NARROW))
+def test_cast_then_trig_equals_the_fused_narrow_kernels_and_the_oracle(ag, kind):
+    """every input value of the narrow type: cast → sin / cos / sinh through the chain == the unfused pair (bit for bit) and within
+    1 ULP of the oracle's sin_<kind> (f64 libm rounded once); for 8-bit sources also == the reference-shaped sin_u8 kernel"""
+    dev = ag.GPU_DEVICE()
+    cls, npd = getattr(ag, NARROW[kind][0]), NARROW[kind][1]
+    info = np.iinfo(npd)
+    vals = np.arange(info.min, int(info.max) + 1, dtype=np.int64).astype(npd)
+    a = cls.from_slice(vals, dev)
+    odt = {"u8": O.U8, "i8": O.I8, "u16": O.U16, "i16": O.I16}[kind]
+    for name, oun in (("sin", O.UN_SIN), ("cos", O.UN_COS), ("sinh", O.UN_SINH)):
+        fused = getattr(ag.FusedChain(a), name)().finish().raw_values()
+        pair = getattr(a.cast(ag.Float32ArrayGPU), name)().raw_values()
+        assert bits(fused) == bits(pair), (kind, name)
+        if kind in ("u8", "i8"):
+            assert bits(fused) == bits(getattr(a, name)().raw_values()), (kind, name)
+        if name != "sinh" or kind in ("u8", "i8"):  # sinh of a 16-bit value overflows to inf beyond |x| ≈ 89: compare where finite
+            exp = O.unary(oun, odt, vals)
+            fin = np.isfinite(exp) & np.isfinite(fused)
+            assert np.array_equal(np.isfinite(exp), np.isfinite(fused))
+            d = np.abs(fused[fin].view(np.int32).astype(np.int64) - exp[fin].view(np.int32).astype(np.int64))
+            assert d.max() <= 1, (kind, name, int(d.max()))
+
+
+def test_fusing_pipeline_collapses_cast_then_sin_into_one_launch(ag):
+    """BASELINE config 4 as it is worded — "cast u8→f32 then sin/cos" — written with the reference's `*_op` API on a fusing pipeline:
+    ONE launch at finish(), results identical to the eager pair"""
+    dev = ag.GPU_DEVICE()
+    n = 300_001
+    F32 = ag.Float32ArrayGPU
+    for kind in NARROW:
+        a = _narrow(ag, dev, kind, n, 5)
+        s = F32.from_slice([0.5], dev)
+        p = ag.ArrowComputePipeline(dev, "cast-sin", fuse=True)
+        r = a.cast_op(F32, p).sin_op(p)
+        assert p.stats["recorded"] == 2 and p.stats["kernels"] == 0
+        p.finish()
+        assert p.stats == {"recorded": 2, "kernels": 1, "fused_chains": 1, "fused_ops": 2}, kind
+        assert bits(r.raw_values()) == bits(a.cast(F32).sin().raw_values()), kind
+        # dyn entry points, a longer chain, a kept intermediate and a compare behind the chain
+        p = ag.ArrowComputePipeline(dev, "cast-chain", fuse=True)
+        x = ag.cos_op_dyn(ag.mul_scalar_op_dyn(ag.cast_op_dyn(a, ag.ArrowType.Float32Type, p), s, p), p)
+        kept = a.cast_op(F32, p)                       # the caller keeps the f32 column: materialised by a plain cast
+        y = kept.add_scalar_op(s, p).neg_op(p)
+        m = a.cast_op(F32, p).mul_scalar_op(s, p).gt_op(kept, p)   # cast-headed chains store; the compare runs on the stored column
+        p.finish()
+        assert p.stats["fused_chains"] >= 3, (kind, p.stats)
+        e = a.cast(F32)
+        assert bits(x.raw_values()) == bits(e.mul_scalar(s).cos().raw_values()), kind
+        assert bits(kept.raw_values()) == bits(e.raw_values()) and bits(y.raw_values()) == bits(e.add_scalar(s).neg().raw_values()), kind
+        assert bits(m.raw_values()) == bits(e.mul_scalar(s).gt(e).raw_values()), kind
+
+
+def test_fused_cast_chain_abi_edges(ag):
+    """the C entry point directly: mis-aligned pointers take the element-granular path, unsupported heads / ops are refused"""
+    dev = ag.GPU_DEVICE()
+    p = ag.ArrowComputePipeline(dev, "abi")
+    n = 70_001
+    vals = np.random.default_rng(1).integers(0, 65536, n + 8, dtype=np.int64).astype(np.uint16)
+    src = dev.create_gpu_buffer_with_data(vals)
+    sc = dev.create_gpu_buffer_with_data(np.array([1.5], np.float32))
+    out = dev.create_empty_buffer(4 * n + 64)
+
+    class Step(C.Structure):
+        _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+    steps = (Step * 2)()
+    steps[0].op, steps[0].kind, steps[0].operand = capi.OP_MUL, 1, sc.ptr
+    steps[1].op, steps[1].kind, steps[1].operand = capi.UN_SIN, 0, None
+    for in_off, out_off in ((0, 0), (2, 0), (0, 4), (6, 12)):
+        capi.call("agpu_fused_cast_chain", p._handle, capi.U16, C.c_void_p(src.ptr + in_off), C.cast(steps, C.c_void_p), 2,
+                  C.c_void_p(out.ptr + out_off), n)
+        got = dev.retrive_data(out, 4 * n + 64, pipeline=p)[out_off: out_off + 4 * n].view(np.float32)
+        x = ag.UInt16ArrayGPU.from_slice(vals[in_off // 2: in_off // 2 + n], dev)
+        exp = x.cast(ag.Float32ArrayGPU).mul_scalar(ag.Float32ArrayGPU.from_slice([1.5], dev)).sin().raw_values()
+        assert bits(got) == bits(exp), (in_off, out_off)
+    lib = capi.lib()
+    assert lib.agpu_fused_cast_chain(p._handle, capi.F32, C.c_void_p(src.ptr), C.cast(steps, C.c_void_p), 2, C.c_void_p(out.ptr), n) == capi.ERR_UNSUPPORTED
+    assert lib.agpu_fused_cast_chain(p._handle, capi.U32, C.c_void_p(src.ptr), C.cast(steps, C.c_void_p), 2, C.c_void_p(out.ptr), n) == capi.ERR_UNSUPPORTED
+    steps[1].op = capi.UN_NOT
+    assert lib.agpu_fused_cast_chain(p._handle, capi.U16, C.c_void_p(src.ptr), C.cast(steps, C.c_void_p), 2, C.c_void_p(out.ptr), n) == capi.ERR_UNSUPPORTED
+    steps[1].op, steps[0].op = capi.UN_SIN, capi.OP_AND
+    assert lib.agpu_fused_cast_chain(p._handle, capi.U16, C.c_void_p(src.ptr), C.cast(steps, C.c_void_p), 2, C.c_void_p(out.ptr), n) == capi.ERR_UNSUPPORTED
+    assert lib.agpu_fused_cast_chain(p._handle, capi.U16, C.c_void_p(src.ptr), C.cast(steps, C.c_void_p), 9, C.c_void_p(out.ptr), n) == capi.ERR_ARG
