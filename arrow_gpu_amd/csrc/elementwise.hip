@@ -23,7 +23,9 @@
 #include "common.hpp"
 
 // tiles per block for the kernels that stage a table in LDS (lut8, trig16, pow): tuning key "table_tiles"
-static inline uint64_t tab_k(const agpu_pipeline* p) { return p->tune.table_tiles > 0 ? (uint64_t)p->tune.table_tiles : 1; }
+// tiles per block of the kernels that stage a table in LDS; `dflt` = the kernel's measured best (tools/probe/prefetch_sweep.py,
+// profiles/r04_prefetch_sweep.json: lut8 0.74 → 0.82 at 2, trig16 0.75 → 0.82 at 4, log 0.79 → 0.82 at 2, pow see launch_pow_f32)
+static inline uint64_t tab_k(const agpu_pipeline* p, uint64_t dflt = 1) { return p->tune.table_tiles > 0 ? (uint64_t)p->tune.table_tiles : dflt; }
 
 #ifndef AGPU_STREAM_U
 #define AGPU_STREAM_U 1  // 16-byte vectors per lane per input array per tile (measured best: profiles/r01_sweep_add_f32_1e9.json)
@@ -233,6 +235,13 @@ __device__ __attribute__((noinline)) float sincos_f32_slow(float x, int want_cos
 // k = round(x · 2/π) by the 1.5·2^52 trick: ONE fma rounds the exact product to an integer (no double rounding), the low
 // word of the sum IS k (no v_cvt_i32_f64), and kd = s − M is +0.0 for every |x| < π/4, so r = x exactly there, −0.0
 // included (round 1 paid a 64-bit compare and two selects for that): 6 instructions → 2.
+// Round 4: ONE outer f64 evaluation per row instead of two.  Both inner polynomials still run — as ONE packed chain, the pair
+// {ps, pc} in three v_pk_fma_f32 — and the quadrant picks which of them, which second coefficient and which multiplier (r for
+// sin, 1.0 for cos) feed the single outer step  v = m · (1 + z·(k1 + z·p)).  The operands of every rounding are the ones the
+// two-chain form used (sin: r · fma(…), cos: 1.0 · fma(…) = fma(…)), so the bits are unchanged; the sign goes onto the f32
+// result.  Per row: 10 → 8 f64 operations, 5 → 4 conversions, 7 → 4 f32 operations, 3 → 5 selects: ≈ 49 → ≈ 38 f32-rate issue
+// slots (ISA counted with tools/probe: llvm -S of this file).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float sincos_f32_fast(float x, int want_cos) {  // meaningful for |x| < 1e6, harmless elsewhere
   const double xd = (double)x;
   const double sh = fma(xd, 0x1.45f306dc9c883p-1, 0x1.8p52);  // x · 2/π + 1.5 · 2^52
@@ -240,25 +249,44 @@ __device__ __forceinline__ float sincos_f32_fast(float x, int want_cos) {  // me
   const int k = (int)(uint32_t)__builtin_bit_cast(uint64_t, sh);
   double r = fma(kd, -0x1.921fb54400000p+0, xd);
   r = fma(kd, -0x1.0b4611a626331p-34, r);
-  const float zf = (float)r * (float)r;
-  float ps = __builtin_fmaf(zf, (float)-0x1.aa12ed611087fp-26, (float)0x1.71d97b66aa967p-19);
-  ps = __builtin_fmaf(zf, ps, (float)-0x1.a019fd5d6492ep-13);
-  ps = __builtin_fmaf(zf, ps, (float)0x1.1111110fba75dp-7);
-  float pc = __builtin_fmaf(zf, (float)-0x1.24635bc27779cp-22, (float)0x1.a0124c744e1f9p-16);
-  pc = __builtin_fmaf(zf, pc, (float)-0x1.6c16ba7ffec5ep-10);
-  pc = __builtin_fmaf(zf, pc, (float)0x1.55555550fad1cp-5);
-  const double z = r * r;
-  const double s = r * fma(z, fma(z, (double)ps, -0x1.555555555510cp-3), 1.0);  // r·(1 + …), not r + r·z·…: sin(−0.0) = −0.0
-  const double c = fma(z, fma(z, (double)pc, -0x1.fffffffffe3f1p-2), 1.0);
+  const float rf = (float)r;
+  const float zf = rf * rf;
+  const f32x2_t zz = {zf, zf};
+  f32x2_t pp = __builtin_elementwise_fma(zz, (f32x2_t){(float)-0x1.aa12ed611087fp-26, (float)-0x1.24635bc27779cp-22},
+                                         (f32x2_t){(float)0x1.71d97b66aa967p-19, (float)0x1.a0124c744e1f9p-16});
+  pp = __builtin_elementwise_fma(zz, pp, (f32x2_t){(float)-0x1.a019fd5d6492ep-13, (float)-0x1.6c16ba7ffec5ep-10});
+  pp = __builtin_elementwise_fma(zz, pp, (f32x2_t){(float)0x1.1111110fba75dp-7, (float)0x1.55555550fad1cp-5});  // {ps, pc}
   const int q = k + want_cos;  // cos(x) = sin(x + π/2)
-  double v = (q & 1) ? c : s;
-  v = (q & 2) ? -v : v;
-  return (float)v;
+  const bool use_cos = (q & 1) != 0;
+  const double z = r * r;
+  const double p = (double)(use_cos ? pp.y : pp.x);
+  const double k1 = use_cos ? -0x1.fffffffffe3f1p-2 : -0x1.555555555510cp-3;
+  const double m = use_cos ? 1.0 : r;  // sin r = r·(1 + …) (not r + r·z·…: sin(−0.0) = −0.0), cos r = 1 + …
+  const double v = m * fma(z, fma(z, p, k1), 1.0);
+  const uint32_t sign = ((uint32_t)q << 30) & 0x80000000u;  // quadrants 2, 3: negate
+  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)v) ^ sign);
 }
 __device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
   float res = sincos_f32_fast(x, want_cos);  // unconditionally: the rare slow path then merges ONE register, not the whole state
   if (!(fabsf(x) < 1.0e6f)) res = sincos_f32_slow(x, want_cos);
   return res;
+}
+// a 16-byte pack at a time (the tile kernel): the four fast paths run back to back — independent chains the scheduler can
+// interleave — and ONE branch per pack covers the |x| ≥ 1e6 / inf / NaN rows, where the per-row form broke the instruction
+// stream with a branch after every row
+template <int WANT_COS>
+__device__ __forceinline__ void sincos_f32_pack(const float (&x)[4], float (&res)[4]) {
+  bool slow = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    res[k] = sincos_f32_fast(x[k], WANT_COS);
+    slow |= !(fabsf(x[k]) < 1.0e6f);
+  }
+  if (slow) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (!(fabsf(x[k]) < 1.0e6f)) res[k] = sincos_f32_slow(x[k], WANT_COS);
+  }
 }
 
 // 128-entry table shared by log and pow: interval j of the mantissa [1 + j/128, 1 + (j+1)/128) → rc ≈ 1/centre (the
@@ -382,8 +410,17 @@ struct UnExp { __device__ static __forceinline__ float ap(float x, float) { retu
 struct UnExp2 { __device__ static __forceinline__ float ap(float x, float) { return exp2f(x); } };
 struct UnLog { __device__ static __forceinline__ float ap(float x, float) { return log_f32_dev(x); } };
 struct UnLog2 { __device__ static __forceinline__ float ap(float x, float) { return log2f(x); } };
-struct UnSin { __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 0); } };
-struct UnCos { __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 1); } };
+struct UnSin {
+  __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 0); }
+  __device__ static __forceinline__ void ap_pack(const float (&x)[4], float (&r)[4]) { sincos_f32_pack<0>(x, r); }
+};
+struct UnCos {
+  __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 1); }
+  __device__ static __forceinline__ void ap_pack(const float (&x)[4], float (&r)[4]) { sincos_f32_pack<1>(x, r); }
+};
+template <typename Op> struct EwPackOp { static constexpr bool value = false; };  // functors with a 4-row form for the f32 tile kernel
+template <> struct EwPackOp<UnSin> { static constexpr bool value = true; };
+template <> struct EwPackOp<UnCos> { static constexpr bool value = true; };
 struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { return acosf(x); } };
 struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return sinh_f32_dev(x); } };
 
@@ -416,12 +453,54 @@ __global__ __launch_bounds__(BLK) void ew_kernel(const T* a, const T* b, T* out,
     });
     static_for<U>([&](auto u) {
       PackN<T, N> r;
+      if constexpr (EwPackOp<Op>::value && MODE == MODE_UNARY && std::is_same<T, float>::value) {
+        Op::ap_pack(va[u].v, r.v);
+      } else {
 #pragma unroll
-      for (int k = 0; k < N; k++) r.v[k] = Op::ap(va[u].v[k], MODE == MODE_BINARY ? vb[u].v[k] : sv);
+        for (int k = 0; k < N; k++) r.v[k] = Op::ap(va[u].v[k], MODE == MODE_BINARY ? vb[u].v[k] : sv);
+      }
       store_pack<NTS, T, N, (MODE != MODE_BINARY && sizeof(T) == 4)>(out + (p0 + (uint64_t)u * BLK) * N, r);  // sc1: common.hpp st_vec_sc1
     });
   }
 }
+
+// The VALU-heavy f32 unary functors (sin / cos / sinh / log): a wave that evaluates 8–16 rows of f64 arithmetic has NOTHING in
+// flight while it does — with one tile per block the memory system sees each wave's bytes only between its launch and its
+// first instruction of arithmetic (sin / cos / sinh all sat at 0.775–0.78 of the roof whatever their instruction count: 36 → 30
+// VALU instructions per row changed nothing, profiles/r04_pmc_narrow.json: VALU 59 % busy).  Here a block walks `tiles per
+// block` tiles a grid apart and issues the NEXT tile's loads before it evaluates the current one, so the loads ride under the
+// arithmetic.  One tile per block degenerates to ew_kernel's shape.
+template <typename Op, int U, int NT>
+__global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_prefetch_kernel(const float* a, float* out, uint64_t ntiles) {
+  constexpr int N = 4;
+  constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0;
+  constexpr uint64_t tile = (uint64_t)AGPU_EW_BLOCK * U;
+  uint64_t t = blockIdx.x;
+  if (t >= ntiles) return;
+  PackN<float, N> cur[U];
+  static_for<U>([&](auto u) { cur[u] = load_pack<NTL, float, N>(a + (t * tile + threadIdx.x + (uint64_t)u * AGPU_EW_BLOCK) * N); });
+  for (;;) {
+    const uint64_t tn = t + gridDim.x;
+    const bool more = tn < ntiles;  // block-uniform
+    PackN<float, N> nxt[U];
+    if (more)
+      static_for<U>([&](auto u) { nxt[u] = load_pack<NTL, float, N>(a + (tn * tile + threadIdx.x + (uint64_t)u * AGPU_EW_BLOCK) * N); });
+    static_for<U>([&](auto u) {
+      PackN<float, N> r;
+      if constexpr (EwPackOp<Op>::value) {
+        Op::ap_pack(cur[u].v, r.v);
+      } else {
+#pragma unroll
+        for (int k = 0; k < N; k++) r.v[k] = Op::ap(cur[u].v[k], 0.0f);
+      }
+      store_pack<NTS, float, N, true>(out + (t * tile + threadIdx.x + (uint64_t)u * AGPU_EW_BLOCK) * N, r);
+    });
+    if (!more) break;
+    static_for<U>([&](auto u) { cur[u] = nxt[u]; });
+    t = tn;
+  }
+}
+template <typename Op> struct EwPrefetch { static constexpr bool value = false; static constexpr int tiles = 1; };
 
 // rows [first, n): whole packs while they last, then single elements.  One small block; also serves tiny arrays.
 template <typename T, typename Op, int MODE>
@@ -455,6 +534,11 @@ template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };  // re-c
 template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };
+// tiles per block, measured (tools/probe/prefetch_sweep.py → profiles/r04_prefetch_sweep.json, 1e9 rows): sin 0.785 → 0.817 at 3–6,
+// cos 0.794 → 0.82 at 2–4, sinh 0.79 → 0.81 at 2 (falls again from 4)
+template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 4; };
+template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 3; };
+template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 2; };
 // Threads per block: one wave for everything.  (The LDS-table kernels pow / log run best at 256 threads × 1 pack, but
 // sin / cos / sinh lose 4–10 % in that shape and 5 % at 64 × 1: tools/probe/heavy_shape.py, profiles/r02_heavy_shape.txt.)
 #ifndef AGPU_EW_DEFAULT_BLK
@@ -487,7 +571,17 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
       // round-robin + nontemporal shape (the XCD mapping costs them 1.4 %).
       const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(out) |
                              (MODE == MODE_BINARY ? reinterpret_cast<uintptr_t>(b) : 0);
-      if ((bits & 127u) == 0)
+      bool done = false;
+      if constexpr (EwPrefetch<Op>::value && MODE == MODE_UNARY && std::is_same<T, float>::value && BLK == AGPU_EW_BLOCK) {
+        const int64_t k = p->tune.heavy_tiles > 0 ? p->tune.heavy_tiles : EwPrefetch<Op>::tiles;
+        if (k > 1 && (bits & 127u) == 0 && p->tune.stream_grid == 0 && p->tune.stream_bpc == 0) {
+          const int g = stream_grid_for(p, (ntiles + (uint64_t)k - 1) / (uint64_t)k);
+          hipLaunchKernelGGL((ew_prefetch_kernel<Op, U, AGPU_STREAM_NT>), dim3(g), dim3(AGPU_EW_BLOCK), 0, p->stream, pa, po, ntiles);
+          done = true;
+        }
+      }
+      if (done) {
+      } else if ((bits & 127u) == 0)
         hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, AGPU_STREAM_NT, BLK>), dim3(grid), dim3(BLK), 0, p->stream, pa, pb,
                            po, ntiles);
       else
@@ -683,6 +777,15 @@ __global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const f
   __syncthreads();
   while (t < ntiles) {
     const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
+    // the next tile's loads go out BEFORE this tile is evaluated (table_tiles > 1): they ride under the arithmetic
+    const uint64_t tn = t + gridDim.x;
+    f32x4 na[U], nb[U];
+    if (tn < ntiles)
+      static_for<U>([&](auto u) {
+        const uint64_t pk = tn * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK;
+        na[u] = __builtin_nontemporal_load(a4 + pk);
+        if constexpr (MODE == MODE_BINARY) nb[u] = __builtin_nontemporal_load(b4 + pk);
+      });
     // one vote per wave and tile: a wave whose 512 operand pairs are all ordinary (x positive normal, |y| < 2^20) takes
     // the short path on a SCALAR branch — no exec masking, no selects; any other wave evaluates the general form
     bool ok = true;
@@ -719,8 +822,12 @@ __global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const f
         __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
       });
     }
-    t += gridDim.x;
-    if (t < ntiles) load_tile(t);
+    if (tn < ntiles)
+      static_for<U>([&](auto u) {
+        xa[u] = na[u];
+        if constexpr (MODE == MODE_BINARY) xb[u] = nb[u];
+      });
+    t = tn;
   }
 }
 template <int MODE>
@@ -742,7 +849,9 @@ static agpu_status launch_pow_f32(agpu_pipeline* p, const void* a, const void* b
   if (aligned16(a) && aligned16(out) && (MODE != MODE_BINARY || aligned16(b))) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p))), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
+      // tiles per block with the next tile prefetched (profiles/r04_prefetch_sweep.json): array ∘ array is best at 1 (0.807 → 0.80 at 2), array ∘ scalar 0.69 → 0.77 at 3
+      const uint64_t tk = tab_k(p, MODE == MODE_SCALAR ? 3 : 1);
+      hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, (ntiles + tk - 1) / tk)), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
                          ntiles, tab);
       done = ntiles * TILE_ROWS;
     }
@@ -773,6 +882,11 @@ __global__ __launch_bounds__(AGPU_BLOCK) void log_kernel(const float* a, float* 
   __syncthreads();
   while (t < ntiles) {
     const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
+    // the next tile's loads go out BEFORE this tile is evaluated (table_tiles > 1): they ride under the arithmetic
+    const uint64_t tn = t + gridDim.x;
+    f32x4 na[U];
+    if (tn < ntiles)
+      static_for<U>([&](auto u) { na[u] = __builtin_nontemporal_load(a4 + tn * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
     bool ok = true;
     static_for<U>([&](auto u) { ok = ok && log_ordinary(xa[u].x) && log_ordinary(xa[u].y) && log_ordinary(xa[u].z) && log_ordinary(xa[u].w); });
     if (__all(ok)) {
@@ -791,8 +905,8 @@ __global__ __launch_bounds__(AGPU_BLOCK) void log_kernel(const float* a, float* 
         __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
       });
     }
-    t += gridDim.x;
-    if (t < ntiles) load_tile(t);
+    if (tn < ntiles) static_for<U>([&](auto u) { xa[u] = na[u]; });
+    t = tn;
   }
 }
 __global__ __launch_bounds__(AGPU_BLOCK) void log_tail_kernel(const float* a, float* out, uint64_t first, uint64_t n) {
@@ -808,7 +922,7 @@ static agpu_status launch_log_f32(agpu_pipeline* p, const void* a, void* out, ui
   if (aligned16(a) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p))), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
+      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, (ntiles + tab_k(p, 2) - 1) / tab_k(p, 2))), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
                          static_cast<const PowTab*>(p->dev->pow_table));
       done = ntiles * TILE_ROWS;
     }
@@ -1082,14 +1196,22 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel_unaligned(const TI* in,
 #ifndef AGPU_CVTW_BLOCK
 #define AGPU_CVTW_BLOCK 64
 #endif
+
 template <typename TI, typename TO, typename Conv>
 __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in, TO* out, uint64_t nchunks) {
   constexpr int R = sizeof(TO) / sizeof(TI);   // 2 or 4 stores per load
   constexpr int NO = 16 / sizeof(TO);          // output elements per lane per store
   constexpr uint32_t WAVES = AGPU_CVTW_BLOCK / AGPU_WAVE;
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
-  for (uint64_t c = (uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE; c < nchunks; c += (uint64_t)gridDim.x * WAVES) {
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
+  uint64_t c = (uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE;
+  if (c >= nchunks) return;
+  // the next chunk's load is issued before the current chunk's four stores (tuning cast_tiles > 1: a wave walks several chunks)
+  u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
+  for (;;) {
+    const uint64_t cn = c + (uint64_t)gridDim.x * WAVES;
+    const bool more = cn < nchunks;
+    u32x4 vn = v;
+    if (more) vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + cn * AGPU_WAVE + lane);
     static_for<R>([&](auto j) {
       const int src = (int)(((uint32_t)j * (AGPU_WAVE / R) + lane / R) * 4);  // byte address of the source lane
       const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.x);
@@ -1112,6 +1234,9 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in,
       const uint32_t g = (uint32_t)j * AGPU_WAVE + lane;  // slot of this lane's store inside the chunk
       store_pack<(AGPU_STREAM_NT & 2) != 0, TO, NO, (R == 2)>(out + (c * (uint64_t)(AGPU_WAVE * R) + g) * NO, r);  // sc1 for ×2 only
     });
+    if (!more) break;
+    v = vn;
+    c = cn;
   }
 }
 
@@ -1168,7 +1293,10 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
       constexpr uint64_t chunk_rows = (uint64_t)AGPU_WAVE * 16 / sizeof(TI);
       const uint64_t nchunks = n / chunk_rows;
       if (nchunks) {
-        const int grid = stream_grid_for(p, (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE));
+        // chunks per wave (next chunk prefetched): ×4 widenings 0.79 → 0.835 at 2 (and down again beyond), ×2 0.815 → 0.824 at 4
+        const uint64_t k = (uint64_t)(p->tune.cast_tiles > 0 ? p->tune.cast_tiles : (sizeof(TO) == 4 * sizeof(TI) ? 2 : 4));
+        const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
+        const int grid = stream_grid_for(p, (blocks + k - 1) / k);
         hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, po, nchunks);
       }
       if (nchunks * chunk_rows < n)
@@ -1334,7 +1462,7 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
   if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      const int grid = stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p));
+      const int grid = stream_grid_for(p, (ntiles + tab_k(p, 2) - 1) / tab_k(p, 2));
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, po, ntiles,
                          static_cast<const float*>(p->dev->lut8_tables) + 256 * Lut8Slot<TI, F>::value);
       done = ntiles * TILE_ROWS;
@@ -1470,7 +1598,7 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
   if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      const dim3 grid(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p)));
+      const dim3 grid(stream_grid_for(p, (ntiles + tab_k(p, 4) - 1) / tab_k(p, 4)));
       if (blk == 1024) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 1024>), grid, dim3(1024), 0, p->stream, pi, po, ntiles, tab);
       else if (blk == 512) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 512>), grid, dim3(512), 0, p->stream, pi, po, ntiles, tab);
       else hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 256>), grid, dim3(256), 0, p->stream, pi, po, ntiles, tab);
@@ -1862,8 +1990,14 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
   uint32_t sc[AGPU_CHAIN_MAX_STEPS];
   static_for<AGPU_CHAIN_MAX_STEPS>([&](auto s) { sc[s] = *(const __attribute__((address_space(4))) uint32_t*)(ptrs.p[s]); });
-  for (uint64_t c = (uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE; c < nchunks; c += (uint64_t)gridDim.x * WAVES) {
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
+  uint64_t c = (uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE;
+  if (c >= nchunks) return;
+  u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
+  for (;;) {
+    const uint64_t cn = c + (uint64_t)gridDim.x * WAVES;
+    const bool more = cn < nchunks;
+    u32x4 vn = v;
+    if (more) vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + cn * AGPU_WAVE + lane);
     static_for<R>([&](auto j) {
       const uint64_t at = (c * (uint64_t)(AGPU_WAVE * R) + (uint32_t)j * AGPU_WAVE + lane) * NO;  // first row of this lane's store
       PackN<float, NO> ya[NARR > 0 ? NARR : 1];
@@ -1917,6 +2051,9 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
       }
       store_pack<(AGPU_STREAM_NT & 2) != 0, float, NO, (R == 2)>(out + at, acc);
     });
+    if (!more) break;
+    v = vn;
+    c = cn;
   }
 }
 // rows [first, n), one per lane (tails, unaligned columns): the same arithmetic
@@ -1927,10 +2064,43 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void cast_chain_tail_kernel(const TI
     out[i] = chain_eval_from<float>((float)in[i], i, n_steps, code, ptrs);
 }
 
+// An 8-bit source has 256 distinct values: a chain of unary / scalar steps behind the cast is a FUNCTION of the byte.  One 256-thread
+// block evaluates the chain once per byte value (the same functors, so the same bits as evaluating it per row) into a 1 KiB table in
+// the pipeline's scratch, and the rows stream through lut8_kernel — `cast → · 0.37 → sin` runs at the lookup kernel's 0.82 of the HBM
+// roof instead of the VALU-bound 0.43 of evaluating sin per row.
+template <typename TI>
+__global__ __launch_bounds__(256) void lut8_chain_build_kernel(float* tab, int n_steps, uint64_t code, ChainPtrs ptrs) {
+  const uint32_t e = threadIdx.x;  // indexed by the raw byte, like lut8_build_kernel
+  tab[e] = chain_eval_from<float>((float)(TI)(uint8_t)e, 0, n_steps, code, ptrs);
+}
+#define AGPU_LUT8_CHAIN_MIN_ROWS (1u << 16)
+
 template <typename TI>
 static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* out, uint64_t n, int n_steps, uint64_t code,
                                      const ChainPtrs& ptrs, bool vec_ok, bool heavy) {
   const TI* pi = static_cast<const TI*>(in);
+  if constexpr (sizeof(TI) == 1) {
+    bool arrays = false;
+    for (int s = 0; s < n_steps; s++) arrays = arrays || chain_kind(code, s) == AGPU_CHAIN_ARRAY;
+    constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_LUT8_BLOCK * 4 * 4;
+    if (!arrays && vec_ok && n >= AGPU_LUT8_CHAIN_MIN_ROWS) {
+      void* tab = nullptr;
+      const agpu_status st = agpu_scratch(p, 1024, &tab);
+      if (st != AGPU_OK) return st;
+      hipLaunchKernelGGL((lut8_chain_build_kernel<TI>), dim3(1), dim3(256), 0, p->stream, static_cast<float*>(tab), n_steps, code, ptrs);
+      const uint64_t ntiles = n / TILE_ROWS;
+      const int grid = stream_grid_for(p, (ntiles + tab_k(p, 2) - 1) / tab_k(p, 2));
+      hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, out, ntiles, static_cast<const float*>(tab));
+      if (ntiles * TILE_ROWS < n) {
+        const uint64_t rest = n - ntiles * TILE_ROWS;
+        const int g2 = stream_grid_for(p, (rest + AGPU_EW_BLOCK - 1) / AGPU_EW_BLOCK);
+        hipLaunchKernelGGL((cast_chain_tail_kernel<TI>), dim3(g2), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, out, ntiles * TILE_ROWS, n, n_steps,
+                           code, ptrs);
+      }
+      AGPU_LAUNCH_CHECK();
+      return AGPU_OK;
+    }
+  }
   constexpr uint64_t chunk_rows = (uint64_t)AGPU_WAVE * 16 / sizeof(TI);
   const uint64_t nchunks = vec_ok ? n / chunk_rows : 0;
   if (nchunks) {
@@ -1941,7 +2111,10 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
       if (s < n_steps && chain_kind(code, s) == AGPU_CHAIN_ARRAY) arrs.p[n_arrs++] = ptrs.p[s];
     }
     const int slots = n_arrs == 0 ? 0 : n_arrs <= 2 ? 2 : 4;
-    const int grid = stream_grid_for(p, (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE));
+    // light chains are best at one chunk per wave (0.80; 0.79 at 2), chains with a transcendental step gain from prefetching (0.53 → 0.60 at 8)
+    const uint64_t kt = (uint64_t)(p->tune.cast_tiles > 0 ? p->tune.cast_tiles : (heavy ? 8 : 1));
+    const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
+    const int grid = stream_grid_for(p, (blocks + kt - 1) / kt);
 #define AGPU_CCHAIN_CASE(H, A)                                                                                              \
   if (heavy == H && slots == A)                                                                                             \
     hipLaunchKernelGGL((cast_chain_kernel<TI, H, A>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, out, nchunks, n_steps, \

@@ -31,14 +31,16 @@ void agpu_set_error(const char* fmt, ...) {
 // Plain atomics: agpu_set_tuning may be called from any thread; a pipeline snapshots them when it is created.
 static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
     /*stream_grid*/ {0}, /*stream_bpc*/ {0}, /*stream_unroll*/ {1}, /*stream_nt*/ {1}, /*cmp_variant*/ {0}, /*reduce_grid*/ {0},
-    /*table_tiles*/ {1},  // round 1's kernels liked 4 (profiles/r01_sweep_table_tiles.json); the wave-transposed lut8 / trig16 and
-                          // pow / log are all best at ONE tile per block (profiles/r02_pow_shape.txt: pow 0.69 → 0.75 at U = 2, sin_u8 0.70 → 0.73)
-    /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}, /*gather_offsets*/ {0}};
+    /*table_tiles*/ {0},  // 0 = each kernel's measured best (elementwise.hip tab_k: lut8 2, trig16 4, pow / log 1 — profiles/r04_prefetch_sweep.json;
+                          // round 2 had found 1 best for all of them, before the 8-bit tables were built once per device)
+    /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}, /*gather_offsets*/ {0},
+    /*heavy_tiles*/ {0}, /*cast_tiles*/ {0}};
 static std::atomic<int64_t> g_mem_pool{1};  // 1 = recycle device blocks and idle streams (default), 0 = hipMalloc/hipFree every time
 static std::atomic<int64_t> g_pool_arena{1};  // 1 = pool blocks of ≥ 1 GiB come out of placed arenas (default), 0 = one hipMalloc each
 static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "stream_bpc", "stream_unroll", "stream_nt",
                                                          "cmp_variant", "reduce_grid", "table_tiles", "gather_bucket",
-                                                         "h2d_mode", "h2d_threads", "gather_region_bits", "gather_offsets"};
+                                                         "h2d_mode", "h2d_threads", "gather_region_bits", "gather_offsets",
+                                                         "heavy_tiles", "cast_tiles"};
 
 agpu_tuning agpu_tuning_defaults() {
   agpu_tuning t;

@@ -113,9 +113,11 @@ def check_config_windows(cfg_windows):
         elif name in ("sin_f32", "cos_f32"):
             exp = O.unary(O.UN_SIN if name == "sin_f32" else O.UN_COS, O.F32, O.cast(O.U8, O.F32, u8()))
             ulp = 1
-        elif name in ("sin_u8", "cos_u8"):
-            exp = O.unary(O.UN_SIN if name == "sin_u8" else O.UN_COS, O.U8, u8())
+        elif name in ("sin_u8", "cos_u8", "cast_u8_f32_then_sin_one_launch", "cast_u8_f32_then_cos_one_launch"):
+            exp = O.unary(O.UN_COS if "cos" in name else O.UN_SIN, O.U8, u8())
             ulp = 1
+        elif name == "fused_add_scalar_then_mul_scalar":
+            exp = O.scalar(O.OP_MUL, O.F32, O.scalar(O.OP_ADD, O.F32, fa(), np.array([100.0], np.float32)), np.array([0.37], np.float32))
         else:
             out[name] = "unchecked"
             continue
@@ -716,7 +718,96 @@ def main():
             for nm, op in (("sin_u8", capi.UN_SIN), ("cos_u8", capi.UN_COS)):
                 record(nm, 4, 5.0, lambda op=op: capi.call("agpu_unary", h, op, capi.U8, vp(u8), vp(fb), n),
                        lambda: grab(fb, 32, np.float32, wcnt))
+            # config 4 AS WORDED — "cast u8→f32 then sin/cos" — in ONE launch: what a fusing pipeline issues at finish() for
+            # `col.cast_op(F32, p).sin_op(p)` (agpu_fused_cast_chain; 5 B/row instead of the pair's 5 + 8)
+            class _Step(C.Structure):
+                _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+            def chain(*items):
+                arr = (_Step * max(len(items), 1))()
+                for k_, (op_, kind_, operand_) in enumerate(items):
+                    arr[k_].op, arr[k_].kind, arr[k_].operand = op_, kind_, (operand_.ptr if operand_ is not None else None)
+                return arr, len(items)
+
+            for nm, op in (("cast_u8_f32_then_sin_one_launch", capi.UN_SIN), ("cast_u8_f32_then_cos_one_launch", capi.UN_COS)):
+                st, ns_ = chain((op, 0, None))
+                record(nm, 4, 5.0, lambda st=st, ns_=ns_: capi.call("agpu_fused_cast_chain", h, capi.U8, vp(u8), C.cast(st, C.c_void_p), ns_, vp(fb), n),
+                       lambda: grab(fb, 32, np.float32, wcnt))
+            pair_ms = cfgs["cast_u8_f32"]["ms"] + cfgs["sin_f32"]["ms"]
+            cfgs["cast_u8_f32_then_sin_one_launch"]["unfused_pair_ms"] = round(pair_ms, 4)
+            cfgs["cast_u8_f32_then_sin_one_launch"]["what"] = ("agpu_fused_cast_chain(U8, [sin]): the launch a fusing pipeline issues at finish() for "
+                                                               "cast_op → sin_op; bit-identical to the two-launch pair (13 B/row)")
             capi.call("agpu_synth_f32", h, vp(fb), n, SEED + 1, row0, C.c_float(-1000.0), C.c_float(1000.0))
+
+            # ---- extra.fused: element-wise chains as ONE kernel against the same chain launch by launch, 1e9 rows
+            fused = {}
+            fd, = dev.create_table_buffers([4 * n])
+            sc2 = dev.create_gpu_buffer_with_data(np.array([0.37], np.float32))
+            cs_a, cs_b = dev.create_empty_buffer(16), dev.create_empty_buffer(16)
+            capi.call("agpu_synth_f32", h, vp(fd), n, SEED + 11, row0, C.c_float(-1000.0), C.c_float(1000.0))
+
+            def checksum_of(buf, nbytes, cs):
+                capi.call("agpu_checksum", h, vp(buf), nbytes, vp(cs))
+                return int(dev.retrive_data(cs, 8, pipeline=p).view(np.uint64)[0])
+
+            def fused_row(name, bpr_fused, bpr_unfused, run_fused, run_unfused, result, result_bytes, what):
+                ms_f, ms_u = timed(run_fused), timed(run_unfused)
+                run_unfused()
+                ref = checksum_of(result, result_bytes, cs_a)
+                capi.call("agpu_memset", h, vp(result), 0, min(result_bytes, 1 << 20))
+                run_fused()
+                same = checksum_of(result, result_bytes, cs_b) == ref
+                g = bpr_fused * n / ms_f / 1e6
+                fused[name] = {"fused_ms": round(ms_f, 4), "unfused_ms": round(ms_u, 4), "alg_bytes_per_row_fused": bpr_fused,
+                               "alg_bytes_per_row_unfused": bpr_unfused, "GBps": round(g, 1), "frac_hbm_peak": round(g / HBM_PEAK_GBPS, 4),
+                               "speedup": round(ms_u / ms_f, 3), "bit_identical_to_unfused": bool(same), "what": what}
+
+            st_am, n_am = chain((capi.OP_ADD, 1, sc), (capi.OP_MUL, 1, sc2))
+
+            def unf_am():
+                capi.call("agpu_scalar", h, capi.OP_ADD, capi.F32, vp(fa), vp(sc), vp(fo), n)
+                capi.call("agpu_scalar", h, capi.OP_MUL, capi.F32, vp(fo), vp(sc2), vp(fo), n)
+
+            fused_row("add_scalar_then_mul_scalar", 8.0, 16.0,
+                      lambda: capi.call("agpu_fused_chain", h, capi.F32, vp(fa), C.cast(st_am, C.c_void_p), n_am, vp(fo), n), unf_am, fo, 4 * n,
+                      "(a + s) * t [crates/arrow/examples/simple.rs:45-72]: agpu_fused_chain vs agpu_scalar twice")
+            if want_cpu:
+                cfg_windows["fused_add_scalar_then_mul_scalar"] = {"row": row0 + wrow, "rows": wcnt, "got": grab(fo, 32, np.float32, wcnt)}
+            st_p, n_p = chain((capi.OP_MUL, 2, fb), (capi.OP_ADD, 2, fd))
+            tmp, = dev.create_table_buffers([4 * n])
+
+            def unf_pred():
+                capi.call("agpu_binary", h, capi.OP_MUL, capi.F32, vp(fa), vp(fb), vp(tmp), n)
+                capi.call("agpu_binary", h, capi.OP_ADD, capi.F32, vp(tmp), vp(fd), vp(tmp), n)
+                capi.call("agpu_compare", h, capi.CMP_GT, capi.F32, vp(tmp), vp(fo), vp(ob), n)
+
+            fused_row("mul_add_gt_predicate", 16.125, 32.125,
+                      lambda: capi.call("agpu_fused_chain_compare", h, capi.F32, vp(fa), C.cast(st_p, C.c_void_p), n_p, capi.CMP_GT, 2, vp(fo), vp(ob), n),
+                      unf_pred, ob, nb, "(a * b + c) > d → bitmap: agpu_fused_chain_compare vs mul, add, compare")
+            del tmp
+            st_c, n_c = chain((capi.OP_MUL, 1, sc2), (capi.OP_ADD, 1, sc))
+
+            def unf_cast():
+                capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u8), vp(fo), n)
+                capi.call("agpu_scalar", h, capi.OP_MUL, capi.F32, vp(fo), vp(sc2), vp(fo), n)
+                capi.call("agpu_scalar", h, capi.OP_ADD, capi.F32, vp(fo), vp(sc), vp(fo), n)
+
+            fused_row("cast_u8_then_scale_offset", 5.0, 21.0,
+                      lambda: capi.call("agpu_fused_cast_chain", h, capi.U8, vp(u8), C.cast(st_c, C.c_void_p), n_c, vp(fo), n), unf_cast, fo, 4 * n,
+                      "f32(u8) * t + s: agpu_fused_cast_chain vs cast, mul_scalar, add_scalar")
+            st_s, n_s = chain((capi.UN_SIN, 0, None))
+
+            def unf_sin():
+                capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u8), vp(fo), n)
+                capi.call("agpu_unary", h, capi.UN_SIN, capi.F32, vp(fo), vp(fo), n)
+
+            fused_row("cast_u8_then_sin", 5.0, 13.0,
+                      lambda: capi.call("agpu_fused_cast_chain", h, capi.U8, vp(u8), C.cast(st_s, C.c_void_p), n_s, vp(fo), n), unf_sin, fo, 4 * n,
+                      "BASELINE config 4 as worded: cast u8→f32 then sin, one launch vs two")
+            fused["what"] = ("median of 9 HIP-event timings after 2 untimed launches, 1e9 rows; bit_identical_to_unfused = order-independent 64-bit "
+                             "checksums of the whole result column equal; parity windows of the fused results in cpu_baseline.configs_parity")
+            extra["fused"] = fused
+            del fd, sc2, cs_a, cs_b
             cfgs["what"] = ("BASELINE.json configs 2-4 beyond the headline pair, same rows, table-placed buffers: median of 9 HIP-event "
                             "timings after 2 untimed launches; parity of one 65536-row window each in cpu_baseline.configs_parity")
             extra["configs"] = cfgs

@@ -182,11 +182,17 @@ class ArrowComputePipeline {  // [compute_pipeline.rs:8-300]; one HIP stream, op
     const bool is_f = dtype == AGPU_F32;
     if (!(is_f || dtype == AGPU_I32 || dtype == AGPU_U32 || dtype == AGPU_DATE32)) return false;
     if (kind == AGPU_CHAIN_UNARY)
-      return op == AGPU_UN_NEG || op == AGPU_UN_ABS || (is_f ? (op >= AGPU_UN_SQRT && op <= AGPU_UN_COS) : op == AGPU_UN_NOT);
+      return op == AGPU_UN_NEG || op == AGPU_UN_ABS || (is_f ? (op >= AGPU_UN_SQRT && op <= AGPU_UN_SINH) : op == AGPU_UN_NOT);
     return (op >= AGPU_OP_ADD && op <= AGPU_OP_MAX) || (!is_f && op >= AGPU_OP_AND && op <= AGPU_OP_XOR);
   }
   void record(int kind, int op, agpu_dtype dtype, BufferPtr a, BufferPtr operand, BufferPtr out, size_t n) {
     pending_.push_back(Node{kind, op, dtype, std::move(a), std::move(operand), std::move(out), n});
+    stats.recorded++;
+  }
+  // a widening cast u8 / i8 / u16 / i16 → f32: may only START a chain (`cast → sin`); `op` carries the source dtype
+  static constexpr int kCastNode = 4;
+  void record_cast(agpu_dtype from, BufferPtr a, BufferPtr out, size_t n) {
+    pending_.push_back(Node{kCastNode, (int)from, AGPU_F32, std::move(a), nullptr, std::move(out), n});
     stats.recorded++;
   }
   void flush() {
@@ -202,17 +208,28 @@ class ArrowComputePipeline {  // [compute_pipeline.rs:8-300]; one HIP stream, op
         // dead intermediate: only `last.out` and `nxt.a` still reference the buffer (the caller dropped the array, no
         // later node reads it, nothing else keeps it alive)
         const bool dead = last.out.use_count() == 2;
-        if (nxt.a == last.out && nxt.operand != last.out && nxt.n == last.n && nxt.dtype == last.dtype && dead) len++;
+        if (nxt.a == last.out && nxt.operand != last.out && nxt.n == last.n && nxt.dtype == last.dtype && nxt.kind != kCastNode && dead) len++;
         else break;
       }
       if (len == 1) {
         const Node& nd = nodes[i];
-        if (nd.kind == AGPU_CHAIN_UNARY)
+        if (nd.kind == kCastNode)
+          check(agpu_cast(raw, (agpu_dtype)nd.op, AGPU_F32, nd.a->ptr, nd.out->ptr, nd.n), "agpu_cast");
+        else if (nd.kind == AGPU_CHAIN_UNARY)
           check(agpu_unary(raw, (agpu_unary_op)nd.op, nd.dtype, nd.a->ptr, nd.out->ptr, nd.n), "agpu_unary");
         else if (nd.kind == AGPU_CHAIN_SCALAR)
           check(agpu_scalar(raw, (agpu_binary_op)nd.op, nd.dtype, nd.a->ptr, nd.operand->ptr, nd.out->ptr, nd.n), "agpu_scalar");
         else
           check(agpu_binary(raw, (agpu_binary_op)nd.op, nd.dtype, nd.a->ptr, nd.operand->ptr, nd.out->ptr, nd.n), "agpu_binary");
+      } else if (nodes[i].kind == kCastNode) {  // narrow column in, the f32 chain behind it: one launch
+        std::vector<agpu_chain_step> steps(len - 1);
+        for (size_t k = 1; k < len; k++)
+          steps[k - 1] = agpu_chain_step{nodes[i + k].op, nodes[i + k].kind, nodes[i + k].operand ? nodes[i + k].operand->ptr : nullptr};
+        check(agpu_fused_cast_chain(raw, (agpu_dtype)nodes[i].op, nodes[i].a->ptr, steps.data(), (int32_t)(len - 1),
+                                    static_cast<float*>(nodes[i + len - 1].out->ptr), nodes[i].n),
+              "agpu_fused_cast_chain");
+        stats.fused_chains++;
+        stats.fused_ops += len;
       } else {
         std::vector<agpu_chain_step> steps(len);
         for (size_t k = 0; k < len; k++)
@@ -649,10 +666,14 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
   template <typename OutArray> OutArray cast_op(ArrowComputePipeline& p) const {
     using O = typename OutArray::ElemTag;
     auto out = gpu_device->create_empty_buffer(len * sizeof(typename Prim<O>::Native));
-    agpu_status s = agpu_cast(p.h(), DTYPE, Prim<O>::dtype, data->ptr, out->ptr, len);
-    if (s == AGPU_ERR_UNSUPPORTED) throw ArrowErrorGPU(ArrowErrorGPU::CastingNotSupported, agpu_last_error());
-    check(s, "agpu_cast");
-    p.keep.insert(p.keep.end(), {data, out});
+    if (p.fuse && std::is_same_v<O, float> && is_small_int<T>) {  // a fusing pipeline records the widening cast (the head of a chain)
+      p.record_cast(DTYPE, data, out, len);
+    } else {
+      agpu_status s = agpu_cast(p.h(), DTYPE, Prim<O>::dtype, data->ptr, out->ptr, len);
+      if (s == AGPU_ERR_UNSUPPORTED) throw ArrowErrorGPU(ArrowErrorGPU::CastingNotSupported, agpu_last_error());
+      check(s, "agpu_cast");
+      p.keep.insert(p.keep.end(), {data, out});
+    }
     return OutArray(out, gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
   }
   template <typename OutArray> OutArray cast() const {
@@ -1075,6 +1096,8 @@ class FusedChain {
   AGPU_CHAIN_FLOAT_UNARY(log2, AGPU_UN_LOG2)
   AGPU_CHAIN_FLOAT_UNARY(sin, AGPU_UN_SIN)
   AGPU_CHAIN_FLOAT_UNARY(cos, AGPU_UN_COS)
+  AGPU_CHAIN_FLOAT_UNARY(acos, AGPU_UN_ACOS)
+  AGPU_CHAIN_FLOAT_UNARY(sinh, AGPU_UN_SINH)
 #undef AGPU_CHAIN_FLOAT_UNARY
 
   Arr finish_op(ArrowComputePipeline& p) const {
@@ -1149,6 +1172,87 @@ class FusedChain {
 #undef AGPU_CHAIN_CMP
 };
 template <typename T> FusedChain(const PrimitiveArrayGpu<T>&) -> FusedChain<T>;
+
+// A chain with a WIDENING CAST at its head (agpu_fused_cast_chain): a u8 / i8 / u16 / i16 column in, f32 steps, an f32 column out —
+//   auto y = FusedCastChain(u8_col).sin().finish();                         // the reference's fused sin_u8 [trigonometry/src/u8_kernel.rs:34-38]
+//   auto z = FusedCastChain(u8_col).mul_scalar(scale).add_scalar(off).finish();  // 1 B/row in, 4 B/row out, nothing in between
+// bit-identical to col.cast<Float32ArrayGPU>() followed by the same ops one by one; validity as in FusedChain.
+template <typename T>
+class FusedCastChain {
+  static_assert(is_small_int<T>, "cast-headed chains start from u8 / i8 / u16 / i16 (the reference's casts to f32)");
+  using Src = PrimitiveArrayGpu<T>;
+  using Arr = PrimitiveArrayGpu<float>;
+  Src src_;
+  std::vector<agpu_chain_step> steps_;
+  std::vector<Arr> operands_;
+
+  FusedCastChain& push(int op, int kind, const Arr* operand) {
+    if (steps_.size() >= AGPU_CHAIN_MAX_STEPS) throw ArrowErrorGPU(ArrowErrorGPU::Runtime, "a fused chain holds at most 8 steps");
+    if (kind == AGPU_CHAIN_ARRAY && operand->len != src_.len)
+      throw ArrowErrorGPU(ArrowErrorGPU::Runtime, "fused chain: arrays of different length");
+    steps_.push_back(agpu_chain_step{op, kind, operand ? operand->data->ptr : nullptr});
+    if (operand) operands_.push_back(*operand);
+    return *this;
+  }
+
+ public:
+  explicit FusedCastChain(const Src& a) : src_(a) {}
+#define AGPU_CCHAIN_BIN(NAME, OP)                                                                                \
+  FusedCastChain& NAME(const Arr& v) { return push(OP, v.len == 1 && src_.len != 1 ? AGPU_CHAIN_SCALAR : AGPU_CHAIN_ARRAY, &v); } \
+  FusedCastChain& NAME##_scalar(const Arr& v) { return push(OP, AGPU_CHAIN_SCALAR, &v); }
+  AGPU_CCHAIN_BIN(add, AGPU_OP_ADD)
+  AGPU_CCHAIN_BIN(sub, AGPU_OP_SUB)
+  AGPU_CCHAIN_BIN(mul, AGPU_OP_MUL)
+  AGPU_CCHAIN_BIN(div, AGPU_OP_DIV)
+  AGPU_CCHAIN_BIN(rem, AGPU_OP_REM)
+  AGPU_CCHAIN_BIN(min, AGPU_OP_MIN)
+  AGPU_CCHAIN_BIN(max, AGPU_OP_MAX)
+#undef AGPU_CCHAIN_BIN
+#define AGPU_CCHAIN_UNARY(NAME, OP) \
+  FusedCastChain& NAME() { return push(OP, AGPU_CHAIN_UNARY, nullptr); }
+  AGPU_CCHAIN_UNARY(neg, AGPU_UN_NEG)
+  AGPU_CCHAIN_UNARY(abs, AGPU_UN_ABS)
+  AGPU_CCHAIN_UNARY(sqrt, AGPU_UN_SQRT)
+  AGPU_CCHAIN_UNARY(cbrt, AGPU_UN_CBRT)
+  AGPU_CCHAIN_UNARY(exp, AGPU_UN_EXP)
+  AGPU_CCHAIN_UNARY(exp2, AGPU_UN_EXP2)
+  AGPU_CCHAIN_UNARY(log, AGPU_UN_LOG)
+  AGPU_CCHAIN_UNARY(log2, AGPU_UN_LOG2)
+  AGPU_CCHAIN_UNARY(sin, AGPU_UN_SIN)
+  AGPU_CCHAIN_UNARY(cos, AGPU_UN_COS)
+  AGPU_CCHAIN_UNARY(acos, AGPU_UN_ACOS)
+  AGPU_CCHAIN_UNARY(sinh, AGPU_UN_SINH)
+#undef AGPU_CCHAIN_UNARY
+
+  Arr finish_op(ArrowComputePipeline& p) const {
+    auto out = src_.gpu_device->create_empty_buffer(src_.len * sizeof(float));
+    std::optional<NullBitBufferGpu> nulls = src_.null_buffer;
+    bool merged = false;
+    size_t k = 0;
+    for (const auto& st : steps_) {
+      if (st.kind == AGPU_CHAIN_UNARY) continue;
+      const Arr& operand = operands_[k++];
+      p.keep.push_back(operand.data);
+      if (st.kind == AGPU_CHAIN_ARRAY && operand.null_buffer) {
+        nulls = NullBitBufferGpu::merge_null_bit_buffer_op(nulls, operand.null_buffer, p);
+        merged = true;
+      }
+    }
+    if (!merged) nulls = NullBitBufferGpu::clone_null_bit_buffer_op(nulls, p);
+    check(agpu_fused_cast_chain(p.h(), Src::DTYPE, src_.data->ptr, steps_.data(), (int32_t)steps_.size(), static_cast<float*>(out->ptr),
+                                src_.len),
+          "agpu_fused_cast_chain");
+    p.keep.insert(p.keep.end(), {src_.data, out});
+    return Arr(out, src_.gpu_device, src_.len, nulls);
+  }
+  Arr finish() const {
+    ArrowComputePipeline p(src_.gpu_device);
+    auto out = finish_op(p);
+    p.finish();
+    return out;
+  }
+};
+template <typename T> FusedCastChain(const PrimitiveArrayGpu<T>&) -> FusedCastChain<T>;
 
 // ------------------------------------------------------------------ chunk-sharded columns (north_star config 5)
 // Not in the reference (one device, one queue: crates/array/src/gpu_utils/gpu_device.rs:29-33).  One host thread per

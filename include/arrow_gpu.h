@@ -236,7 +236,8 @@ agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, con
 
 /* Launch tuning (bench sweeps; defaults are the measured best).  key ∈ {"stream_grid","stream_bpc","stream_unroll",
  * "stream_nt","cmp_variant","reduce_grid","table_tiles","gather_bucket","gather_region_bits","gather_offsets","h2d_mode",
- * "h2d_threads"}; unknown key → AGPU_ERR_ARG.  gather_bucket: 0 = auto (size thresholds + the device-side locality probe), 1 = direct
+ * "h2d_threads","heavy_tiles","cast_tiles"}; unknown key → AGPU_ERR_ARG.  heavy_tiles / cast_tiles: tiles per block of the VALU-heavy f32
+ * unary kernels / chunks per wave of the widening casts, the next one's loads issued before the current one is evaluated (0 = the measured default).  gather_bucket: 0 = auto (size thresholds + the device-side locality probe), 1 = direct
  * kernels, 2 = bucketed pipelines whenever the shape qualifies, 3 = like 2 with the round-2 pair pipeline for takes, 4 = like 2 but with the probe (tests);
  * gather_offsets: range starts of the pair pipeline (1 = atomics, 2 = column scans for both passes, 3 = default).  Every pipeline carries its own copy: agpu_set_tuning changes the process default that pipelines
  * created AFTERWARDS start from (atomic, any thread), agpu_pipeline_set_tuning changes one pipeline only — a sweep on one

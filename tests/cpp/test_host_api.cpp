@@ -80,6 +80,35 @@ static void run_compute_pipeline_ops(const DevicePtr& device) {
     CHECK(k2.raw_values() == fr.raw_values());
     CHECK(k3.raw_values() == fr.neg().abs().sqrt().raw_values());
   }
+  // a widening cast at the head of a chain (agpu_fused_cast_chain): `cast → sin` — the reference's fused sin_u8
+  // [crates/trigonometry/src/u8_kernel.rs:34-38] — and `cast → scale → offset`, explicit and through a fusing pipeline
+  {
+    std::vector<Opt<uint8_t>> bytes;
+    for (int i = 0; i < 3000; i++) bytes.push_back(i % 7 == 3 ? Opt<uint8_t>(N) : Opt<uint8_t>((uint8_t)(i * 37)));
+    auto u = UInt8ArrayGPU::from_optional_slice(bytes, device);
+    auto w = Int16ArrayGPU::from_slice({-32768, -1, 0, 1, 255, 256, 32767}, device);
+    auto scale = Float32ArrayGPU::from_slice({0.5f}, device), off = Float32ArrayGPU::from_slice({-3.0f}, device);
+    auto e = u.cast<Float32ArrayGPU>();
+    CHECK(FusedCastChain(u).sin().finish().raw_values() == e.sin().raw_values());
+    CHECK(FusedCastChain(u).sin().finish().raw_values() == u.sin().raw_values());
+    CHECK(FusedCastChain(u).sin().finish().values() == e.sin().values());
+    CHECK(FusedCastChain(u).mul_scalar(scale).add_scalar(off).cos().finish().values() == e.mul_scalar(scale).add_scalar(off).cos().values());
+    CHECK(FusedCastChain(w).mul_scalar(scale).sinh().neg().finish().raw_values() ==
+          w.cast<Float32ArrayGPU>().mul_scalar(scale).sinh().neg().raw_values());
+    ArrowComputePipeline cp(device, "cast-sin", true);
+    auto r = u.cast_op<Float32ArrayGPU>(cp).sin_op(cp);
+    CHECK(cp.stats.recorded == 2 && cp.stats.kernels == 0);
+    cp.finish();
+    CHECK(cp.stats.kernels == 1 && cp.stats.fused_chains == 1 && cp.stats.fused_ops == 2);
+    CHECK(r.values() == e.sin().values());
+    ArrowComputePipeline kp(device, "cast-kept", true);
+    auto kept = w.cast_op<Float32ArrayGPU>(kp);                       // kept by the caller: a plain cast
+    auto q = w.cast_op<Float32ArrayGPU>(kp).mul_scalar_op(scale, kp).cos_op(kp);
+    kp.sync();
+    CHECK(kp.stats.kernels == 2 && kp.stats.fused_chains == 1 && kp.stats.fused_ops == 3);
+    CHECK(kept.raw_values() == w.cast<Float32ArrayGPU>().raw_values());
+    CHECK(q.raw_values() == w.cast<Float32ArrayGPU>().mul_scalar(scale).cos().raw_values());
+  }
   // chain ending in a compare: (x + y) > x  as one pass, same bits and validity as the three-kernel form
   auto fp = FusedChain(x).add(y).gt(x);
   auto up = x.add(y).gt(x);

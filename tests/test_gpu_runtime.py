@@ -168,9 +168,9 @@ def test_tuning_is_per_pipeline(ag):
         capi.call("agpu_pipeline_get_tuning", p3._handle, b"table_tiles", C.byref(v))
         assert v.value == 2
         capi.call("agpu_pipeline_get_tuning", p2._handle, b"table_tiles", C.byref(v))
-        assert v.value == 1
+        assert v.value == 0  # 0 = each kernel's measured best
     finally:
-        capi.call("agpu_set_tuning", b"table_tiles", 1)
+        capi.call("agpu_set_tuning", b"table_tiles", 0)
 
 
 # ------------------------------------------------------------------ profiling hooks [ref: compute_query.rs, gpu_device.rs:132]
