@@ -63,6 +63,14 @@ class Header:
                     members.append((k, int(v)))
             self.enums.append((m.group(2), members))
         body_wo = re.sub(r"typedef\s+enum\s*\{.*?\}\s*\w+\s*;", "", body, flags=re.S)
+        self.status_codes = []  # the anonymous enum of agpu_status values
+        for m in re.finditer(r"(?<!typedef\s)\benum\s*\{(.*?)\}\s*;", body_wo, flags=re.S):
+            for item in m.group(1).split(","):
+                item = item.strip()
+                if item:
+                    k, v = [x.strip() for x in item.split("=")]
+                    self.status_codes.append((k, int(v)))
+        body_wo = re.sub(r"(?<!typedef\s)\benum\s*\{.*?\}\s*;", "", body_wo, flags=re.S)
         for m in re.finditer(r"typedef\s+struct\s+(\w+)\s+(\w+)\s*;", body_wo):
             self.opaque.append(m.group(2))
         for m in re.finditer(r"typedef\s+(\w+)\s+(\w+)\s*;", body_wo):
@@ -175,7 +183,8 @@ def generate_ffi(h: Header) -> str:
     w("")
     for name, cty in h.aliases:
         w(f"pub type {name} = {SCALARS[cty]};")
-    w("// status codes (agpu_status): 0 = OK")
+    for k, v in h.status_codes:
+        w(f"pub const {k}: agpu_status = {v};")
     for name, members in h.enums:
         w(f"pub type {name} = i32;")
         for k, v in members:
