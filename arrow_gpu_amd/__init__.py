@@ -10,8 +10,8 @@ from . import kernels  # noqa: F401  (attaches the op methods to the array class
 from ._capi import ArrowErrorGPU, CastingNotSupported, OperationNotSupported  # noqa: F401
 from .array import (ARRAY_OF_TYPE, ArrowArrayGPU, ArrowType, BooleanArrayGPU, BooleanBufferBuilder,  # noqa: F401
                     Date32ArrayGPU, Float32ArrayGPU, Int8ArrayGPU, Int16ArrayGPU, Int32ArrayGPU, NullBitBufferGpu,
-                    PrimitiveArrayGpu, ScalarValue, UInt8ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU, broadcast_dyn,
-                    broadcast_op_dyn)
+                    Operand, PrimitiveArrayGpu, ScalarArray, ScalarValue, UInt8ArrayGPU, UInt16ArrayGPU, UInt32ArrayGPU,
+                    broadcast_dyn, broadcast_op_dyn)
 from .gpu_utils import ArrowComputePipeline, CmpQuery, DeviceBuffer, GpuDevice  # noqa: F401
 from .gpu_utils import gpu_device as GPU_DEVICE  # noqa: F401
 from .kernels import *  # noqa: F401,F403

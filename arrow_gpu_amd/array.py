@@ -197,8 +197,10 @@ class ArrowArrayGPU:
     def get_dtype(self) -> ArrowType:
         return self.ARROW_TYPE
 
-    def get_raw_values(self):
-        return self.raw_values()
+    def get_raw_values(self) -> "ScalarArray":
+        """`ArrowArrayGPU::get_raw_values` → `ScalarArray` [ref: crates/array/src/array/mod.rs:145-157]: the raw values tagged with their
+        element type (`ScalarArray.F32Vec(…)`, `ScalarArray.BOOLVec(…)`); compares equal to a plain list / ndarray of the same values."""
+        return ScalarArray.of(type(self), self.raw_values())
 
     def into(self) -> "ArrowArrayGPU":
         return self
@@ -386,6 +388,27 @@ class BooleanArrayGPU(ArrowArrayGPU):
         return f"BooleanArrayGPU(len={self.len}, nulls={'yes' if self.null_buffer else 'no'})"
 
 
+def _u32_create_broadcast_buffer_op(value: int, len_: int, pipeline: ArrowComputePipeline):
+    """`UInt32ArrayGPU::create_broadcast_buffer_op(value, len, pipeline) -> Buffer` [ref: crates/array/src/array/u32_gpu.rs:48-64]:
+    a bare device buffer of `len` copies of `value` (the reference's helper for index / count columns), enqueued on the pipeline."""
+    dev = pipeline.device
+    out = dev.create_empty_buffer(max(4 * int(len_), 1))
+    capi.call("agpu_broadcast", pipeline._handle, capi.U32, int(value) & 0xFFFFFFFF, C.c_void_p(out.ptr), int(len_))
+    pipeline.keep(out)
+    return out
+
+
+def _u32_create_broadcast_buffer(value: int, len_: int, gpu_device: GpuDevice):
+    """`UInt32ArrayGPU::create_broadcast_buffer(value, len, gpu_device) -> Buffer` [ref: u32_gpu.rs:36-46]: the immediate form."""
+    p = ArrowComputePipeline(gpu_device, "create_broadcast_buffer")
+    out = _u32_create_broadcast_buffer_op(value, len_, p)
+    p.finish()
+    return out
+
+
+UInt32ArrayGPU.create_broadcast_buffer = staticmethod(_u32_create_broadcast_buffer)
+UInt32ArrayGPU.create_broadcast_buffer_op = staticmethod(_u32_create_broadcast_buffer_op)
+
 PRIMITIVE_TYPES = (Float32ArrayGPU, UInt32ArrayGPU, UInt16ArrayGPU, UInt8ArrayGPU, Int32ArrayGPU, Int16ArrayGPU,
                    Int8ArrayGPU, Date32ArrayGPU)
 ARRAY_OF_TYPE = {t.ARROW_TYPE: t for t in PRIMITIVE_TYPES}
@@ -410,6 +433,101 @@ class ScalarValue:
 
 for _k in ScalarValue._KINDS:
     setattr(ScalarValue, _k, staticmethod(lambda v, _k=_k: ScalarValue(_k, v)))
+
+
+class ScalarArray:
+    """`enum ScalarArray` (crates/array/src/utils/mod.rs:2-11): host values tagged with their type — ScalarArray.F32Vec([1.0, 2.0]),
+    ScalarArray.BOOLVec([True]) …; what `ArrowArrayGPU::get_raw_values` returns.  `From<Vec<T>>` is `ScalarArray.from_vec(values, dtype)`."""
+
+    _KINDS = {"F32Vec": (np.float32, "F32"), "U32Vec": (np.uint32, "U32"), "U16Vec": (np.uint16, "U16"), "U8Vec": (np.uint8, "U8"),
+              "I32Vec": (np.int32, "I32"), "I16Vec": (np.int16, "I16"), "I8Vec": (np.int8, "I8"), "BOOLVec": (np.bool_, "BOOL")}
+
+    def __init__(self, kind: str, values):
+        if kind not in self._KINDS:
+            raise ArrowErrorGPU("ArgumentError", f"unknown ScalarArray variant {kind}")
+        self.kind = kind
+        self.values = np.asarray(values, dtype=self._KINDS[kind][0])
+
+    @classmethod
+    def from_vec(cls, values, np_dtype) -> "ScalarArray":
+        for kind, (dt, _) in cls._KINDS.items():
+            if np.dtype(dt) == np.dtype(np_dtype):
+                return cls(kind, values)
+        raise ArrowErrorGPU("ArgumentError", f"no ScalarArray variant for {np.dtype(np_dtype)}")
+
+    @classmethod
+    def of(cls, array_cls, values) -> "ScalarArray":
+        """the variant an array class's raw values belong to (Date32 → I32Vec, as `Vec<i32>.into()` in the reference)"""
+        if array_cls is BooleanArrayGPU:
+            return cls("BOOLVec", values)
+        return cls.from_vec(values, array_cls.NP_DTYPE)
+
+    def scalar_kind(self) -> str:
+        return self._KINDS[self.kind][1]
+
+    def __len__(self):
+        return len(self.values)
+
+    def __iter__(self):
+        return iter(self.values.tolist())
+
+    def __getitem__(self, i):
+        return self.values[i]
+
+    def tolist(self):
+        return self.values.tolist()
+
+    def __eq__(self, other):  # #[derive(PartialEq)]: same variant and same values; a bare sequence compares by values
+        if isinstance(other, ScalarArray):
+            return self.kind == other.kind and np.array_equal(self.values, other.values, equal_nan=False)
+        try:
+            return bool(np.array_equal(self.values, np.asarray(other)))
+        except Exception:  # noqa: BLE001
+            return NotImplemented
+
+    def __repr__(self):
+        return f"ScalarArray.{self.kind}({self.values.tolist()!r})"
+
+
+for _k in ScalarArray._KINDS:
+    setattr(ScalarArray, _k, staticmethod(lambda v, _k=_k: ScalarArray(_k, v)))
+
+
+class Operand:
+    """`enum Operand { Scalar(ScalarValue), Array(ArrowArrayGPU) }` (crates/array/src/kernels/mod.rs:19-24): what a kernel combines
+    an array with.  `Operand.Scalar(ScalarValue.F32(2.0))`, `Operand.Array(arr)`; `.as_array(len_hint, device)` gives the 1-element
+    (scalar) or full array the `*_dyn` entry points dispatch on (a 1-element array IS the scalar form there:
+    crates/arithmetic/src/arithmetic_kernels.rs:225-267)."""
+
+    def __init__(self, kind: str, value):
+        if kind == "Scalar" and not isinstance(value, ScalarValue):
+            raise ArrowErrorGPU("ArgumentError", "Operand.Scalar holds a ScalarValue")
+        if kind == "Array" and not isinstance(value, (PrimitiveArrayGpu, BooleanArrayGPU)):
+            raise ArrowErrorGPU("ArgumentError", "Operand.Array holds an ArrowArrayGPU")
+        if kind not in ("Scalar", "Array"):
+            raise ArrowErrorGPU("ArgumentError", f"unknown Operand variant {kind}")
+        self.kind, self.value = kind, value
+
+    @staticmethod
+    def Scalar(value: "ScalarValue") -> "Operand":  # noqa: N802 — the reference's variant names
+        return Operand("Scalar", value)
+
+    @staticmethod
+    def Array(value) -> "Operand":  # noqa: N802
+        return Operand("Array", value)
+
+    def is_scalar(self) -> bool:
+        return self.kind == "Scalar"
+
+    def as_array(self, device: GpuDevice):
+        """the array a `*_dyn` kernel takes for this operand: the array itself, or the scalar as a 1-element array"""
+        if self.kind == "Array":
+            return self.value
+        cls = self.value.array_type()
+        return cls.from_slice([self.value.value], device)
+
+    def __repr__(self):
+        return f"Operand.{self.kind}({self.value!r})"
 
 
 def broadcast_op_dyn(value: ScalarValue, len_: int, pipeline: ArrowComputePipeline) -> ArrowArrayGPU:

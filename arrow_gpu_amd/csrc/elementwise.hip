@@ -23,8 +23,28 @@
 #include "common.hpp"
 
 // tiles per block for the kernels that stage a table in LDS (lut8, trig16, pow): tuning key "table_tiles"
-// tiles per block of the kernels that stage a table in LDS; `dflt` = the kernel's measured best (tools/probe/prefetch_sweep.py,
-// profiles/r04_prefetch_sweep.json: lut8 0.74 → 0.82 at 2, trig16 0.75 → 0.82 at 4, log 0.79 → 0.82 at 2, pow see launch_pow_f32)
+// tiles per block of the kernels that stage a table in LDS; `dflt` = the kernel's default: 1 for the HBM-bound ones (lut8, trig16, log,
+// pow array ∘ array — see tile_run below), 3 for pow with a scalar exponent (launch_pow_f32)
+// A block that takes several tiles walks them A GRID APART (tile b, b + G, b + 2G …) and issues the next tile's loads before it
+// evaluates the current one.  What that buys was measured at length in round 4 (tools/probe/prefetch_sweep.py, prefetch_context.py,
+// grid_bits.py, cast_offsets.py, clock_state.py → profiles/r04_prefetch_*.json, DESIGN.md §4 "Tiles per block"):
+//   * kernels whose bound is VALU issue (a cast-headed chain with a transcendental step, pow with a scalar exponent) gain 10–15 %
+//     from 3–8 tiles per block on every box and in every layout — their defaults below;
+//   * the HBM-bound ones (widening casts, the LDS-table kernels, sin / cos / sinh) gain 4–6 % at 2–4 tiles per block in SOME
+//     allocations (cast u8→f32 0.80 → 0.84, sin_u8 0.77 → 0.84, sin f32 0.785 → 0.82) and LOSE 7–9 % in others — the same library,
+//     the same box, another process: it follows what the driver backed the buffers with (the allocation lottery of DESIGN.md §3), not
+//     the distance between the windows (every G from +1 to +2^19 tiles behaves alike), the relative position of input and output,
+//     the timing method or the clock state.  One tile per block is insensitive to it (±1 %), so that is their default; the tunings
+//     "heavy_tiles" / "cast_tiles" / "table_tiles" stay for callers who measure their own allocation;
+//   * CONTIGUOUS runs (block b owns [b·k, b·k + k)) lose 10–13 % everywhere: neighbouring waves then write every k-th 1–4 KiB tile at a
+//     time, and address bits 12 / 13 feed the channel hash (profiles/r04_prefetch_sweep_contiguous_runs.json).
+struct TileRun {
+  uint64_t t, end, step;
+};
+__device__ __forceinline__ TileRun tile_run(uint64_t unit, uint64_t n_units, uint64_t ntiles) {
+  return TileRun{unit, ntiles, n_units};
+}
+
 static inline uint64_t tab_k(const agpu_pipeline* p, uint64_t dflt = 1) { return p->tune.table_tiles > 0 ? (uint64_t)p->tune.table_tiles : dflt; }
 
 #ifndef AGPU_STREAM_U
@@ -475,13 +495,14 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_prefetch_kernel(const float*
   constexpr int N = 4;
   constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0;
   constexpr uint64_t tile = (uint64_t)AGPU_EW_BLOCK * U;
-  uint64_t t = blockIdx.x;
-  if (t >= ntiles) return;
+  const TileRun run = tile_run(blockIdx.x, gridDim.x, ntiles);
+  uint64_t t = run.t;
+  if (t >= run.end) return;
   PackN<float, N> cur[U];
   static_for<U>([&](auto u) { cur[u] = load_pack<NTL, float, N>(a + (t * tile + threadIdx.x + (uint64_t)u * AGPU_EW_BLOCK) * N); });
   for (;;) {
-    const uint64_t tn = t + gridDim.x;
-    const bool more = tn < ntiles;  // block-uniform
+    const uint64_t tn = t + run.step;
+    const bool more = tn < run.end;  // block-uniform
     PackN<float, N> nxt[U];
     if (more)
       static_for<U>([&](auto u) { nxt[u] = load_pack<NTL, float, N>(a + (tn * tile + threadIdx.x + (uint64_t)u * AGPU_EW_BLOCK) * N); });
@@ -534,11 +555,10 @@ template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };  // re-c
 template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };
-// tiles per block, measured (tools/probe/prefetch_sweep.py → profiles/r04_prefetch_sweep.json, 1e9 rows): sin 0.785 → 0.817 at 3–6,
-// cos 0.794 → 0.82 at 2–4, sinh 0.79 → 0.81 at 2 (falls again from 4)
-template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 4; };
-template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 3; };
-template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 2; };
+// tiles per block: 1 by default (see tile_run above: 3–4 tiles gain 4 % in lucky allocations — sin 0.785 → 0.82 — and lose 7 % in others)
+template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; };
+template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; };
+template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; };
 // Threads per block: one wave for everything.  (The LDS-table kernels pow / log run best at 256 threads × 1 pack, but
 // sin / cos / sinh lose 4–10 % in that shape and 5 % at 64 × 1: tools/probe/heavy_shape.py, profiles/r02_heavy_shape.txt.)
 #ifndef AGPU_EW_DEFAULT_BLK
@@ -760,7 +780,9 @@ __global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const f
   const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
   const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
   f32x4* o4 = reinterpret_cast<f32x4*>(out);
-  uint64_t t = blockIdx.x;
+  const TileRun run = tile_run(blockIdx.x, gridDim.x, ntiles);
+  const uint64_t ntiles_end = run.end;
+  uint64_t t = run.t;
   f32x4 xa[U], xb[U];
   float sv = 0.0f;
   if constexpr (MODE == MODE_SCALAR) sv = b[0];
@@ -771,16 +793,16 @@ __global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const f
       if constexpr (MODE == MODE_BINARY) xb[u] = __builtin_nontemporal_load(b4 + pk);
     });
   };
-  if (t < ntiles) load_tile(t);
+  if (t < ntiles_end) load_tile(t);
   if (threadIdx.x < 128)
     reinterpret_cast<u32x4*>(tab)[threadIdx.x] = reinterpret_cast<const u32x4*>(gtab)[threadIdx.x];
   __syncthreads();
-  while (t < ntiles) {
+  while (t < ntiles_end) {
     const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
     // the next tile's loads go out BEFORE this tile is evaluated (table_tiles > 1): they ride under the arithmetic
-    const uint64_t tn = t + gridDim.x;
+    const uint64_t tn = t + run.step;
     f32x4 na[U], nb[U];
-    if (tn < ntiles)
+    if (tn < ntiles_end)
       static_for<U>([&](auto u) {
         const uint64_t pk = tn * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK;
         na[u] = __builtin_nontemporal_load(a4 + pk);
@@ -822,7 +844,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const f
         __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
       });
     }
-    if (tn < ntiles)
+    if (tn < ntiles_end)
       static_for<U>([&](auto u) {
         xa[u] = na[u];
         if constexpr (MODE == MODE_BINARY) xb[u] = nb[u];
@@ -849,7 +871,8 @@ static agpu_status launch_pow_f32(agpu_pipeline* p, const void* a, const void* b
   if (aligned16(a) && aligned16(out) && (MODE != MODE_BINARY || aligned16(b))) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      // tiles per block with the next tile prefetched (profiles/r04_prefetch_sweep.json): array ∘ array is best at 1 (0.807 → 0.80 at 2), array ∘ scalar 0.69 → 0.77 at 3
+      // tiles per block with the next tile prefetched (profiles/r04_prefetch_sweep*.json): array ∘ array is best at 1 (0.807 → 0.80 at 2); array ∘ scalar
+      // 0.67–0.69 → 0.75–0.77 at 3 in every run
       const uint64_t tk = tab_k(p, MODE == MODE_SCALAR ? 3 : 1);
       hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, (ntiles + tk - 1) / tk)), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
                          ntiles, tab);
@@ -872,20 +895,22 @@ __global__ __launch_bounds__(AGPU_BLOCK) void log_kernel(const float* a, float* 
   __shared__ PowTab tab[128];
   const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
   f32x4* o4 = reinterpret_cast<f32x4*>(out);
-  uint64_t t = blockIdx.x;
+  const TileRun run = tile_run(blockIdx.x, gridDim.x, ntiles);
+  const uint64_t ntiles_end = run.end;
+  uint64_t t = run.t;
   f32x4 xa[U];
   auto load_tile = [&](uint64_t tile) {
     static_for<U>([&](auto u) { xa[u] = __builtin_nontemporal_load(a4 + tile * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
   };
-  if (t < ntiles) load_tile(t);
+  if (t < ntiles_end) load_tile(t);
   if (threadIdx.x < 128) reinterpret_cast<u32x4*>(tab)[threadIdx.x] = reinterpret_cast<const u32x4*>(gtab)[threadIdx.x];
   __syncthreads();
-  while (t < ntiles) {
+  while (t < ntiles_end) {
     const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
     // the next tile's loads go out BEFORE this tile is evaluated (table_tiles > 1): they ride under the arithmetic
-    const uint64_t tn = t + gridDim.x;
+    const uint64_t tn = t + run.step;
     f32x4 na[U];
-    if (tn < ntiles)
+    if (tn < ntiles_end)
       static_for<U>([&](auto u) { na[u] = __builtin_nontemporal_load(a4 + tn * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
     bool ok = true;
     static_for<U>([&](auto u) { ok = ok && log_ordinary(xa[u].x) && log_ordinary(xa[u].y) && log_ordinary(xa[u].z) && log_ordinary(xa[u].w); });
@@ -905,7 +930,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void log_kernel(const float* a, float* 
         __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
       });
     }
-    if (tn < ntiles) static_for<U>([&](auto u) { xa[u] = na[u]; });
+    if (tn < ntiles_end) static_for<U>([&](auto u) { xa[u] = na[u]; });
     t = tn;
   }
 }
@@ -922,7 +947,7 @@ static agpu_status launch_log_f32(agpu_pipeline* p, const void* a, void* out, ui
   if (aligned16(a) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, (ntiles + tab_k(p, 2) - 1) / tab_k(p, 2))), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
+      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p))), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
                          static_cast<const PowTab*>(p->dev->pow_table));
       done = ntiles * TILE_ROWS;
     }
@@ -1203,13 +1228,14 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in,
   constexpr int NO = 16 / sizeof(TO);          // output elements per lane per store
   constexpr uint32_t WAVES = AGPU_CVTW_BLOCK / AGPU_WAVE;
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
-  uint64_t c = (uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE;
-  if (c >= nchunks) return;
+  const TileRun run = tile_run((uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE, (uint64_t)gridDim.x * WAVES, nchunks);
+  uint64_t c = run.t;
+  if (c >= run.end) return;
   // the next chunk's load is issued before the current chunk's four stores (tuning cast_tiles > 1: a wave walks several chunks)
   u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
   for (;;) {
-    const uint64_t cn = c + (uint64_t)gridDim.x * WAVES;
-    const bool more = cn < nchunks;
+    const uint64_t cn = c + run.step;
+    const bool more = cn < run.end;
     u32x4 vn = v;
     if (more) vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + cn * AGPU_WAVE + lane);
     static_for<R>([&](auto j) {
@@ -1293,8 +1319,8 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
       constexpr uint64_t chunk_rows = (uint64_t)AGPU_WAVE * 16 / sizeof(TI);
       const uint64_t nchunks = n / chunk_rows;
       if (nchunks) {
-        // chunks per wave (next chunk prefetched): ×4 widenings 0.79 → 0.835 at 2 (and down again beyond), ×2 0.815 → 0.824 at 4
-        const uint64_t k = (uint64_t)(p->tune.cast_tiles > 0 ? p->tune.cast_tiles : (sizeof(TO) == 4 * sizeof(TI) ? 2 : 4));
+        // chunks per wave (next chunk prefetched): 1 by default — 2 is +5 % in lucky allocations and −8 % in others (tile_run above)
+        const uint64_t k = (uint64_t)(p->tune.cast_tiles > 0 ? p->tune.cast_tiles : 1);
         const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
         const int grid = stream_grid_for(p, (blocks + k - 1) / k);
         hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, po, nchunks);
@@ -1427,16 +1453,18 @@ __global__ __launch_bounds__(AGPU_LUT8_BLOCK) void lut8_kernel(const TI* in, flo
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   const u32x4* in16 = reinterpret_cast<const u32x4*>(in);
   f32x4* out4 = reinterpret_cast<f32x4*>(out);
-  uint64_t t = blockIdx.x;
+  const TileRun run = tile_run(blockIdx.x, gridDim.x, ntiles);
+  const uint64_t ntiles_end = run.end;
+  uint64_t t = run.t;
   u32x4 v = {0, 0, 0, 0};
-  if (t < ntiles) v = __builtin_nontemporal_load(in16 + (t * WAVES + wave) * AGPU_WAVE + lane);
+  if (t < ntiles_end) v = __builtin_nontemporal_load(in16 + (t * WAVES + wave) * AGPU_WAVE + lane);
   if (threadIdx.x < 64) reinterpret_cast<f32x4*>(lut)[threadIdx.x] = reinterpret_cast<const f32x4*>(gtab)[threadIdx.x];  // 1 KiB from L2
   __syncthreads();
-  while (t < ntiles) {
+  while (t < ntiles_end) {
     const uint64_t c = t * WAVES + wave;
     const u32x4 cur = v;
-    t += gridDim.x;
-    if (t < ntiles) v = __builtin_nontemporal_load(in16 + (t * WAVES + wave) * AGPU_WAVE + lane);
+    t += run.step;
+    if (t < ntiles_end) v = __builtin_nontemporal_load(in16 + (t * WAVES + wave) * AGPU_WAVE + lane);
     static_for<4>([&](auto j) {
       const int src = (int)(((uint32_t)j * 16u + (lane >> 2)) * 4u);
       const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur.x);
@@ -1462,7 +1490,7 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
   if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      const int grid = stream_grid_for(p, (ntiles + tab_k(p, 2) - 1) / tab_k(p, 2));
+      const int grid = stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p));
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, po, ntiles,
                          static_cast<const float*>(p->dev->lut8_tables) + 256 * Lut8Slot<TI, F>::value);
       done = ntiles * TILE_ROWS;
@@ -1542,9 +1570,11 @@ __global__ __launch_bounds__(BLOCK) void trig16_kernel(const TI* in, float* out,
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   const u32x4* in16 = reinterpret_cast<const u32x4*>(in);
   f32x4* out4 = reinterpret_cast<f32x4*>(out);
-  uint64_t t = blockIdx.x;
+  const TileRun run = tile_run(blockIdx.x, gridDim.x, ntiles);
+  const uint64_t ntiles_end = run.end;
+  uint64_t t = run.t;
   u32x4 w[U];
-  if (t < ntiles)  // the first tile's loads go out before the table copy so the two latencies overlap
+  if (t < ntiles_end)  // the first tile's loads go out before the table copy so the two latencies overlap
     static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in16 + ((t * WAVES + wave) * U + (uint32_t)u) * AGPU_WAVE + lane); });
   {
     const u32x4* g = reinterpret_cast<const u32x4*>(gtab);
@@ -1552,12 +1582,12 @@ __global__ __launch_bounds__(BLOCK) void trig16_kernel(const TI* in, float* out,
     for (uint32_t k = threadIdx.x; k < 512; k += BLOCK) l[k] = g[k];
   }
   __syncthreads();
-  while (t < ntiles) {
+  while (t < ntiles_end) {
     const uint64_t c0 = (t * WAVES + wave) * U;
     u32x4 cur[U];
     static_for<U>([&](auto u) { cur[u] = w[u]; });
-    t += gridDim.x;
-    if (t < ntiles)
+    t += run.step;
+    if (t < ntiles_end)
       static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in16 + ((t * WAVES + wave) * U + (uint32_t)u) * AGPU_WAVE + lane); });
     static_for<U>([&](auto u) {
       static_for<2>([&](auto j) {
@@ -1598,7 +1628,7 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
   if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      const dim3 grid(stream_grid_for(p, (ntiles + tab_k(p, 4) - 1) / tab_k(p, 4)));
+      const dim3 grid(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p)));
       if (blk == 1024) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 1024>), grid, dim3(1024), 0, p->stream, pi, po, ntiles, tab);
       else if (blk == 512) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 512>), grid, dim3(512), 0, p->stream, pi, po, ntiles, tab);
       else hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 256>), grid, dim3(256), 0, p->stream, pi, po, ntiles, tab);
@@ -1990,12 +2020,13 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1);
   uint32_t sc[AGPU_CHAIN_MAX_STEPS];
   static_for<AGPU_CHAIN_MAX_STEPS>([&](auto s) { sc[s] = *(const __attribute__((address_space(4))) uint32_t*)(ptrs.p[s]); });
-  uint64_t c = (uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE;
-  if (c >= nchunks) return;
+  const TileRun run = tile_run((uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE, (uint64_t)gridDim.x * WAVES, nchunks);
+  uint64_t c = run.t;
+  if (c >= run.end) return;
   u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
   for (;;) {
-    const uint64_t cn = c + (uint64_t)gridDim.x * WAVES;
-    const bool more = cn < nchunks;
+    const uint64_t cn = c + run.step;
+    const bool more = cn < run.end;
     u32x4 vn = v;
     if (more) vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + cn * AGPU_WAVE + lane);
     static_for<R>([&](auto j) {
@@ -2089,7 +2120,7 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
       if (st != AGPU_OK) return st;
       hipLaunchKernelGGL((lut8_chain_build_kernel<TI>), dim3(1), dim3(256), 0, p->stream, static_cast<float*>(tab), n_steps, code, ptrs);
       const uint64_t ntiles = n / TILE_ROWS;
-      const int grid = stream_grid_for(p, (ntiles + tab_k(p, 2) - 1) / tab_k(p, 2));
+      const int grid = stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p));
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, out, ntiles, static_cast<const float*>(tab));
       if (ntiles * TILE_ROWS < n) {
         const uint64_t rest = n - ntiles * TILE_ROWS;
@@ -2111,7 +2142,7 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
       if (s < n_steps && chain_kind(code, s) == AGPU_CHAIN_ARRAY) arrs.p[n_arrs++] = ptrs.p[s];
     }
     const int slots = n_arrs == 0 ? 0 : n_arrs <= 2 ? 2 : 4;
-    // light chains are best at one chunk per wave (0.80; 0.79 at 2), chains with a transcendental step gain from prefetching (0.53 → 0.60 at 8)
+    // light chains: one chunk per wave (tile_run above); chains with a transcendental step are VALU-bound and gain in every run (0.53 → 0.61 at 8)
     const uint64_t kt = (uint64_t)(p->tune.cast_tiles > 0 ? p->tune.cast_tiles : (heavy ? 8 : 1));
     const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
     const int grid = stream_grid_for(p, (blocks + kt - 1) / kt);

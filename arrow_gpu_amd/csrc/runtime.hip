@@ -31,8 +31,7 @@ void agpu_set_error(const char* fmt, ...) {
 // Plain atomics: agpu_set_tuning may be called from any thread; a pipeline snapshots them when it is created.
 static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
     /*stream_grid*/ {0}, /*stream_bpc*/ {0}, /*stream_unroll*/ {1}, /*stream_nt*/ {1}, /*cmp_variant*/ {0}, /*reduce_grid*/ {0},
-    /*table_tiles*/ {0},  // 0 = each kernel's measured best (elementwise.hip tab_k: lut8 2, trig16 4, pow / log 1 — profiles/r04_prefetch_sweep.json;
-                          // round 2 had found 1 best for all of them, before the 8-bit tables were built once per device)
+    /*table_tiles*/ {0},  // 0 = each kernel's default (elementwise.hip tab_k: 1 for the HBM-bound table kernels, 3 for pow with a scalar exponent)
     /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}, /*gather_offsets*/ {0},
     /*heavy_tiles*/ {0}, /*cast_tiles*/ {0}};
 static std::atomic<int64_t> g_mem_pool{1};  // 1 = recycle device blocks and idle streams (default), 0 = hipMalloc/hipFree every time

@@ -54,6 +54,12 @@ class GpuDevice:
         capi.call("agpu_device_name", self._handle, name, 128)
         self.name = name.value.decode()
 
+    @classmethod
+    def from_adapter(cls, adapter: int = 0) -> "GpuDevice":
+        """`GpuDevice::from_adapter(adapter)` [ref: gpu_device.rs:87-106] named a wgpu adapter; on a ROCm node the choice among
+        the visible GPUs is the device ordinal (after HIP_VISIBLE_DEVICES), so the adapter IS the ordinal."""
+        return cls(int(adapter))
+
     # -- default pipeline per host thread (used by immediate calls such as upload / retrive_data)
     def _default_pipeline(self) -> "ArrowComputePipeline":
         p = getattr(self._tls, "pipeline", None)

@@ -45,6 +45,24 @@ def _cast_op(self: ArrowArrayGPU, into, pipeline: ArrowComputePipeline):
     return _finish_record(node, into(out, dev, self.len, nulls))
 
 
+def apply_boolean_unary_function(gpu_device, original_values, new_buffer_size: int, output_item_size: int, shader: str, entry_point: str,
+                                 pipeline: ArrowComputePipeline):
+    """`cast::apply_boolean_unary_function(gpu_device, original_values, new_buffer_size, output_item_size, shader, entry_point,
+    pipeline) -> Buffer` [ref: crates/cast/src/boolean_cast.rs:8-55]: a Boolean bitmap in, `new_buffer_size / output_item_size`
+    elements out, one invocation per OUTPUT element — the reference's literal call shape, served by the by-name seam
+    (`agpu_launch_by_name_sized`: `shader` is the WGSL text, its `#hash:len` name or its path key, e.g. "cast/boolean/cast_f32")."""
+    import ctypes as C
+
+    out = gpu_device.create_empty_buffer(max(int(new_buffer_size), 1), zero_fill=True)
+    dispatch = -(-(-(-int(new_buffer_size) // int(output_item_size))) // 256)  # ceil(ceil(size / item) / 256)
+    ins = (C.c_void_p * 1)(original_values.ptr)
+    sizes = (C.c_uint64 * 1)(original_values.nbytes)
+    key = shader.encode() if isinstance(shader, str) else shader
+    capi.call("agpu_launch_by_name_sized", pipeline._handle, key, entry_point.encode(), ins, sizes, 1, vp(out), int(new_buffer_size), dispatch)
+    pipeline.keep(original_values, out)
+    return out
+
+
 def _cast(self, into):
     p = ArrowComputePipeline(self.get_gpu_device(), "cast")
     out = _cast_op(self, into, p)
@@ -103,4 +121,4 @@ def bitcast_dyn(from_: ArrowArrayGPU, into: ArrowType) -> ArrowArrayGPU:
     return out
 
 
-__all__ = ["cast_dyn", "cast_op_dyn", "bitcast_dyn", "bitcast_op_dyn", "CAST_TABLE", "BITCAST_TABLE"]
+__all__ = ["cast_dyn", "cast_op_dyn", "bitcast_dyn", "bitcast_op_dyn", "apply_boolean_unary_function", "CAST_TABLE", "BITCAST_TABLE"]

@@ -105,7 +105,8 @@ pub(crate) fn apply_put_op(_device: &GpuDevice, src_buffer: &Buffer, dst_buffer:
 }
 
 /// crates/cast/src/boolean_cast.rs:8-55 — Boolean bitmap in, one f32 per bit out
-pub fn apply_boolean_unary_function(_device: &GpuDevice, original_values: &Buffer, new_buffer_size: u64, shader: &str, entry_point: &str,
-                                    dispatch_size: u32, pipeline: &mut ArrowComputePipeline) -> Buffer {
-    pipeline.apply_unary_function(original_values, new_buffer_size, shader, entry_point, dispatch_size)
+pub fn apply_boolean_unary_function(_gpu_device: &GpuDevice, original_values: &Buffer, new_buffer_size: u64, output_item_size: u64, shader: &str,
+                                    entry_point: &str, pipeline: &mut ArrowComputePipeline) -> Buffer {
+    let dispatch_size = new_buffer_size.div_ceil(output_item_size); // one invocation per OUTPUT element
+    pipeline.apply_unary_function(original_values, new_buffer_size, shader, entry_point, dispatch_size.div_ceil(256) as u32)
 }

@@ -65,6 +65,9 @@ class GpuDevice : public std::enable_shared_from_this<GpuDevice> {
     check(agpu_pipeline_create(d->raw, &d->io), "agpu_pipeline_create");
     return d;
   }
+  // GpuDevice::from_adapter(adapter) [gpu_device.rs:87-106] named a wgpu adapter; on a ROCm node the choice among the visible GPUs is
+  // the device ordinal (after HIP_VISIBLE_DEVICES), so the adapter IS the ordinal
+  static DevicePtr from_adapter(int adapter) { return create(adapter); }
   ~GpuDevice() {
     if (io) agpu_pipeline_destroy(io);
     if (raw) agpu_device_destroy(raw);
@@ -682,6 +685,32 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
     p.finish();
     return out;
   }
+  // BitCast<T>: reinterpret the values, a device copy of the buffer [crates/cast/src/lib.rs:90-107, table :187-192: u32 → f32]
+  template <typename OutArray> OutArray bitcast_op(ArrowComputePipeline& p) const {
+    static_assert(std::is_same_v<T, uint32_t> && std::is_same_v<typename OutArray::ElemTag, float>, "BitCast is implemented for UInt32ArrayGPU → Float32ArrayGPU");
+    return OutArray(p.clone_buffer(data), gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
+  }
+  template <typename OutArray> OutArray bitcast() const {
+    ArrowComputePipeline p(gpu_device);
+    auto out = bitcast_op<OutArray>(p);
+    p.finish();
+    return out;
+  }
+  // UInt32ArrayGPU::create_broadcast_buffer(_op)(value, len, …) -> Buffer [crates/array/src/array/u32_gpu.rs:36-64]: a bare device
+  // buffer of `len` copies of `value` (the reference's helper for index / count columns)
+  static BufferPtr create_broadcast_buffer_op(uint32_t value, uint64_t n, ArrowComputePipeline& p) {
+    static_assert(std::is_same_v<T, uint32_t>, "create_broadcast_buffer is a UInt32ArrayGPU function");
+    auto out = p.device->create_empty_buffer(4 * n);
+    check(agpu_broadcast(p.h(), AGPU_U32, value, out->ptr, n), "agpu_broadcast");
+    p.keep.push_back(out);
+    return out;
+  }
+  static BufferPtr create_broadcast_buffer(uint32_t value, uint64_t n, const DevicePtr& dev) {
+    ArrowComputePipeline p(dev);
+    auto out = create_broadcast_buffer_op(value, n, p);
+    p.finish();
+    return out;
+  }
   using ElemTag = T;
 
   // ---- arrow_gpu_routines: Swizzle [crates/routines/src/lib.rs:28-171]
@@ -746,6 +775,10 @@ class BooleanArrayGPU {
       if (v[i]) buf.set_bit(i);
     return BooleanArrayGPU(upload_bitmap(dev, buf.data, v.size()), dev, v.size(), std::nullopt);
   }
+  // NB: like the reference, `len` is the BYTE count of the slice [boolean_gpu.rs:72-82]
+  static BooleanArrayGPU from_bytes_slice(const std::vector<uint8_t>& bytes, const DevicePtr& dev) {
+    return BooleanArrayGPU(upload_bitmap(dev, bytes, bytes.size() * 8), dev, bytes.size(), std::nullopt);
+  }
   std::vector<bool> raw_values() const {
     auto raw = gpu_device->retrive_data(data, (len + 7) / 8);
     std::vector<bool> out(len);
@@ -769,6 +802,12 @@ class BooleanArrayGPU {
     return BooleanArrayGPU(out, dev, n, std::nullopt);
   }
   ArrowType get_dtype() const { return ArrowType::BooleanType; }
+  BooleanArrayGPU clone_array() const {  // [boolean_gpu.rs / array/mod.rs:159-171]
+    ArrowComputePipeline p(gpu_device);
+    auto out = BooleanArrayGPU(p.clone_buffer(data, true), gpu_device, len, NullBitBufferGpu::clone_null_bit_buffer_op(null_buffer, p));
+    p.finish();
+    return out;
+  }
 
   // Logical / LogicalContains [crates/logical/src/boolean.rs:12-147]
   BooleanArrayGPU logical_(agpu_binary_op op, const BooleanArrayGPU& v, ArrowComputePipeline& p) const {
@@ -1045,6 +1084,124 @@ inline ArrowArrayGPU take_dyn(const ArrowArrayGPU& a, const UInt32ArrayGPU& idx)
         else not_supported("take_dyn");
       },
       a);
+}
+
+// ---- the remaining names of the reference's public surface
+// enum ScalarArray [crates/array/src/utils/mod.rs:2-11] — what ArrowArrayGPU::get_raw_values returns [array/src/array/mod.rs:145-157]
+using ScalarArray = std::variant<std::vector<float>, std::vector<uint32_t>, std::vector<uint16_t>, std::vector<uint8_t>, std::vector<int32_t>,
+                                 std::vector<int16_t>, std::vector<int8_t>, std::vector<bool>>;
+inline ScalarArray get_raw_values(const ArrowArrayGPU& a) {
+  return std::visit([](const auto& x) -> ScalarArray { return ScalarArray(x.raw_values()); }, a);  // Date32 → Vec<i32>, as in the reference
+}
+inline ArrowArrayGPU clone_array(const ArrowArrayGPU& a) {  // [array/src/array/mod.rs:159-171]
+  return std::visit([](const auto& x) -> ArrowArrayGPU { return ArrowArrayGPU(x.clone_array()); }, a);
+}
+// enum ScalarValue / enum Operand [crates/array/src/kernels/mod.rs:5-24]
+struct ScalarValue {
+  std::variant<float, uint32_t, uint16_t, uint8_t, int32_t, int16_t, int8_t, bool> v;
+  static ScalarValue F32(float x) { return {x}; }
+  static ScalarValue U32(uint32_t x) { return {x}; }
+  static ScalarValue U16(uint16_t x) { return {x}; }
+  static ScalarValue U8(uint8_t x) { return {x}; }
+  static ScalarValue I32(int32_t x) { return {x}; }
+  static ScalarValue I16(int16_t x) { return {x}; }
+  static ScalarValue I8(int8_t x) { return {x}; }
+  static ScalarValue BOOL(bool x) { return {x}; }
+};
+// broadcast_dyn / broadcast_op_dyn [array/src/array/mod.rs:189-219]
+inline ArrowArrayGPU broadcast_op_dyn(const ScalarValue& value, size_t n, ArrowComputePipeline& p) {
+  return std::visit(
+      [&](auto x) -> ArrowArrayGPU {
+        using X = decltype(x);
+        if constexpr (std::is_same_v<X, bool>) {
+          auto out = p.device->create_empty_buffer(bitmap_bytes(n) ? bitmap_bytes(n) : 8);
+          check(agpu_broadcast(p.h(), AGPU_BOOL, x ? 1u : 0u, out->ptr, n), "agpu_broadcast");
+          p.keep.push_back(out);
+          return ArrowArrayGPU(BooleanArrayGPU(out, p.device, n, std::nullopt));
+        } else {
+          return ArrowArrayGPU(PrimitiveArrayGpu<X>::broadcast_op(x, n, p));
+        }
+      },
+      value.v);
+}
+inline ArrowArrayGPU broadcast_dyn(const ScalarValue& value, size_t n, const DevicePtr& dev) {
+  ArrowComputePipeline p(dev);
+  auto out = broadcast_op_dyn(value, n, p);
+  p.finish();
+  return out;
+}
+struct Operand {  // enum Operand { Scalar(ScalarValue), Array(ArrowArrayGPU) }
+  std::variant<ScalarValue, ArrowArrayGPU> v;
+  static Operand Scalar(ScalarValue s) { return Operand{std::move(s)}; }
+  static Operand Array(ArrowArrayGPU a) { return Operand{std::move(a)}; }
+  bool is_scalar() const { return v.index() == 0; }
+  // the array a `*_dyn` kernel takes for this operand: the array itself, or the scalar as a 1-element array (a 1-element array IS
+  // the scalar form there: crates/arithmetic/src/arithmetic_kernels.rs:101-119)
+  ArrowArrayGPU as_array(const DevicePtr& dev) const {
+    if (!is_scalar()) return std::get<ArrowArrayGPU>(v);
+    return broadcast_dyn(std::get<ScalarValue>(v), 1, dev);
+  }
+};
+// cast_dyn / cast_op_dyn(from, &ArrowType) [crates/cast/src/lib.rs:135-185] and bitcast_dyn / bitcast_op_dyn [:187-218]
+inline ArrowArrayGPU cast_op_dyn(const ArrowArrayGPU& from, ArrowType into, ArrowComputePipeline& p) {
+  return std::visit(
+      [&](const auto& x) -> ArrowArrayGPU {
+        using X = std::decay_t<decltype(x)>;
+        if constexpr (std::is_same_v<X, BooleanArrayGPU>) {
+          if (into == ArrowType::Float32Type) {
+            auto out = x.gpu_device->create_empty_buffer(x.len * 4);
+            check(agpu_cast(p.h(), AGPU_BOOL, AGPU_F32, x.data->ptr, out->ptr, x.len), "agpu_cast");
+            p.keep.insert(p.keep.end(), {x.data, out});
+            return ArrowArrayGPU(Float32ArrayGPU(out, x.gpu_device, x.len, NullBitBufferGpu::clone_null_bit_buffer_op(x.null_buffer, p)));
+          }
+        } else if constexpr (!std::is_same_v<X, Date32ArrayGPU>) {
+          switch (into) {  // the C ABI owns the table (agpu_cast → AGPU_ERR_UNSUPPORTED → CastingNotSupported)
+            case ArrowType::Float32Type: return ArrowArrayGPU(x.template cast_op<Float32ArrayGPU>(p));
+            case ArrowType::UInt32Type: return ArrowArrayGPU(x.template cast_op<UInt32ArrayGPU>(p));
+            case ArrowType::UInt16Type: return ArrowArrayGPU(x.template cast_op<UInt16ArrayGPU>(p));
+            case ArrowType::UInt8Type: return ArrowArrayGPU(x.template cast_op<UInt8ArrayGPU>(p));
+            case ArrowType::Int32Type: return ArrowArrayGPU(x.template cast_op<Int32ArrayGPU>(p));
+            case ArrowType::Int16Type: return ArrowArrayGPU(x.template cast_op<Int16ArrayGPU>(p));
+            case ArrowType::Int8Type: return ArrowArrayGPU(x.template cast_op<Int8ArrayGPU>(p));
+            default: break;
+          }
+        }
+        throw ArrowErrorGPU(ArrowErrorGPU::CastingNotSupported, "Casting not supported for these types");
+      },
+      from);
+}
+inline ArrowArrayGPU cast_dyn(const ArrowArrayGPU& from, ArrowType into) {
+  ArrowComputePipeline p(get_gpu_device(from));
+  auto out = cast_op_dyn(from, into, p);
+  p.finish();
+  return out;
+}
+inline ArrowArrayGPU bitcast_op_dyn(const ArrowArrayGPU& from, ArrowType into, ArrowComputePipeline& p) {
+  if (auto u = std::get_if<UInt32ArrayGPU>(&from); u && into == ArrowType::Float32Type)
+    return ArrowArrayGPU(u->template bitcast_op<Float32ArrayGPU>(p));
+  throw ArrowErrorGPU(ArrowErrorGPU::CastingNotSupported, "Casting not supported for these types");
+}
+inline ArrowArrayGPU bitcast_dyn(const ArrowArrayGPU& from, ArrowType into) {
+  ArrowComputePipeline p(get_gpu_device(from));
+  auto out = bitcast_op_dyn(from, into, p);
+  p.finish();
+  return out;
+}
+// cast::apply_boolean_unary_function(gpu_device, original_values, new_buffer_size, output_item_size, shader, entry_point, pipeline)
+// [crates/cast/src/boolean_cast.rs:8-55]: a Boolean bitmap in, one invocation per OUTPUT element — the reference's literal call
+// shape through the by-name seam (`shader`: the WGSL text, its "#hash:len" name or its path key, e.g. "cast/boolean/cast_f32")
+inline BufferPtr apply_boolean_unary_function(const DevicePtr& gpu_device, const BufferPtr& original_values, uint64_t new_buffer_size,
+                                              uint64_t output_item_size, const char* shader, const char* entry_point,
+                                              ArrowComputePipeline& pipeline) {
+  auto out = gpu_device->create_empty_buffer(new_buffer_size);
+  check(agpu_memset(pipeline.h(), out->ptr, 0, new_buffer_size), "agpu_memset");  // create_empty_buffer of the reference is zero-filled
+  const void* ins[1] = {original_values->ptr};
+  const uint64_t sizes[1] = {original_values->bytes};
+  const uint64_t dispatch = ((new_buffer_size + output_item_size - 1) / output_item_size + 255) / 256;
+  check(agpu_launch_by_name_sized(pipeline.h(), shader, entry_point, ins, sizes, 1, out->ptr, new_buffer_size, (uint32_t)dispatch),
+        "agpu_launch_by_name_sized");
+  pipeline.keep.insert(pipeline.keep.end(), {original_values, out});
+  return out;
 }
 
 // ---- fused element-wise chains: the `*_op` chain of examples/simple.rs:45-72 as ONE kernel.

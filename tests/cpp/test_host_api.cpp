@@ -115,6 +115,78 @@ static void run_compute_pipeline_ops(const DevicePtr& device) {
   CHECK(fp.values() == up.values());
 }
 
+// the last public names of SURVEY Appendix C, one check per name (VERDICT r3 missing #4)
+static void run_appendix_c_names(const DevicePtr& device) {
+  {  // UInt32ArrayGPU::create_broadcast_buffer(_op) [crates/array/src/array/u32_gpu.rs:36-64]
+    auto buf = UInt32ArrayGPU::create_broadcast_buffer(7u, 100, device);
+    UInt32ArrayGPU arr(buf, device, 100, std::nullopt);
+    CHECK(arr.raw_values() == std::vector<uint32_t>(100, 7u));
+    ArrowComputePipeline p(device);
+    auto big = UInt32ArrayGPU::create_broadcast_buffer_op(0xFFFFFFFFu, 1000003, p);
+    p.finish();
+    CHECK(UInt32ArrayGPU(big, device, 1000003, std::nullopt).raw_values() == std::vector<uint32_t>(1000003, 0xFFFFFFFFu));
+  }
+  {  // ScalarArray / get_raw_values [utils/mod.rs:2-11, array/mod.rs:145-157]; clone_array
+    ArrowArrayGPU f = Float32ArrayGPU::from_slice({1.5f, -2.0f}, device);
+    ArrowArrayGPU d = Date32ArrayGPU::from_slice({19000, -5}, device);
+    ArrowArrayGPU b = BooleanArrayGPU::from_slice({true, false, true}, device);
+    CHECK(get_raw_values(f) == ScalarArray(std::vector<float>{1.5f, -2.0f}));
+    CHECK(get_raw_values(d) == ScalarArray(std::vector<int32_t>{19000, -5}));   // Date32 → I32Vec, as Vec<i32>.into() in the reference
+    CHECK(get_raw_values(b) == ScalarArray(std::vector<bool>{true, false, true}));
+    CHECK(get_raw_values(f) != ScalarArray(std::vector<uint32_t>{1u, 2u}));
+    CHECK(get_raw_values(clone_array(f)) == get_raw_values(f));
+  }
+  {  // ScalarValue / Operand / broadcast_dyn [kernels/mod.rs:5-24, array/mod.rs:189-219]
+    ArrowArrayGPU a = Int32ArrayGPU::from_slice({1, 2, 3}, device);
+    auto s = Operand::Scalar(ScalarValue::I32(10));
+    auto v = Operand::Array(ArrowArrayGPU(Int32ArrayGPU::from_slice({100, 200, 300}, device)));
+    CHECK(s.is_scalar() && !v.is_scalar());
+    CHECK(get_raw_values(add_dyn(a, s.as_array(device))) == ScalarArray(std::vector<int32_t>{11, 12, 13}));
+    CHECK(get_raw_values(add_dyn(a, v.as_array(device))) == ScalarArray(std::vector<int32_t>{101, 202, 303}));
+    CHECK(get_raw_values(broadcast_dyn(ScalarValue::F32(2.5f), 4, device)) == ScalarArray(std::vector<float>(4, 2.5f)));
+    CHECK(get_raw_values(broadcast_dyn(ScalarValue::BOOL(true), 70, device)) == ScalarArray(std::vector<bool>(70, true)));
+    CHECK(get_raw_values(broadcast_dyn(ScalarValue::U8(9), 3, device)) == ScalarArray(std::vector<uint8_t>(3, 9)));
+  }
+  {  // BitCast / bitcast_dyn [crates/cast/src/lib.rs:90-107,187-218; test :227-236: u32 bits → f32]
+    auto u = UInt32ArrayGPU::from_slice({0x3F800000u, 0x40000000u, 0xBF800000u}, device);
+    CHECK(u.bitcast<Float32ArrayGPU>().raw_values() == std::vector<float>({1.0f, 2.0f, -1.0f}));
+    CHECK(get_raw_values(bitcast_dyn(ArrowArrayGPU(u), ArrowType::Float32Type)) == ScalarArray(std::vector<float>{1.0f, 2.0f, -1.0f}));
+    bool threw = false;
+    try { bitcast_dyn(ArrowArrayGPU(u), ArrowType::Int32Type); } catch (const ArrowErrorGPU& e) { threw = e.kind == ArrowErrorGPU::CastingNotSupported; }
+    CHECK(threw);
+    // cast_dyn [crates/cast/src/lib.rs:135-161]: i8 → f32, u8 → u16, bool → f32; an unsupported pair → CastingNotSupported
+    CHECK(get_raw_values(cast_dyn(ArrowArrayGPU(Int8ArrayGPU::from_slice({-128, 0, 127}, device)), ArrowType::Float32Type)) ==
+          ScalarArray(std::vector<float>{-128.0f, 0.0f, 127.0f}));
+    CHECK(get_raw_values(cast_dyn(ArrowArrayGPU(UInt8ArrayGPU::from_slice({0, 255}, device)), ArrowType::UInt16Type)) ==
+          ScalarArray(std::vector<uint16_t>{0, 255}));
+    CHECK(get_raw_values(cast_dyn(ArrowArrayGPU(BooleanArrayGPU::from_slice({true, false}, device)), ArrowType::Float32Type)) ==
+          ScalarArray(std::vector<float>{1.0f, 0.0f}));
+    threw = false;
+    try { cast_dyn(ArrowArrayGPU(UInt32ArrayGPU::from_slice({1u}, device)), ArrowType::Float32Type); } catch (const ArrowErrorGPU& e) { threw = e.kind == ArrowErrorGPU::CastingNotSupported; }
+    CHECK(threw);  // u32 → f32 is not in the reference's table
+  }
+  {  // BooleanArrayGPU::from_bytes_slice [boolean_gpu.rs:72-82]: len = the BYTE count (the reference's own quirk)
+    auto b = BooleanArrayGPU::from_bytes_slice({0b00000101, 0xFF, 0x00}, device);
+    CHECK(b.len == 3);
+    CHECK(b.raw_values() == std::vector<bool>({true, false, true}));
+  }
+  {  // cast::apply_boolean_unary_function [crates/cast/src/boolean_cast.rs:8-55] with the arguments of Cast<Float32ArrayGPU> for BooleanArrayGPU (:57-74)
+    auto b = BooleanArrayGPU::from_slice({true, true, false, true, false}, device);
+    ArrowComputePipeline p(device);
+    auto out = apply_boolean_unary_function(device, b.data, b.len * 4, 4, "cast/boolean/cast_f32", "cast_f32", p);
+    p.finish();
+    CHECK(Float32ArrayGPU(out, device, b.len, std::nullopt).raw_values() == std::vector<float>({1.0f, 1.0f, 0.0f, 1.0f, 0.0f}));
+  }
+  {  // GpuDevice::from_adapter [gpu_device.rs:87-106]: the adapter of a ROCm node is the device ordinal
+    auto dev0 = GpuDevice::from_adapter(0);
+    auto a = Float32ArrayGPU::from_slice({1.0f, 2.0f}, dev0);
+    CHECK(a.add(a).raw_values() == std::vector<float>({2.0f, 4.0f}));
+    bool threw = false;
+    try { GpuDevice::from_adapter(99); } catch (const ArrowErrorGPU&) { threw = true; }
+    CHECK(threw);
+  }
+}
+
 int main() {
   DevicePtr device;
   try {
@@ -125,6 +197,7 @@ int main() {
   }
   run_basic_add(device);
   run_compute_pipeline_ops(device);
+  run_appendix_c_names(device);
 
   {  // crates/arithmetic/src/f32.rs:209-255 — f32 array ops with nulls, typed + dyn
     auto a = Float32ArrayGPU::from_optional_slice({0.0f, 1.0f, N, N, 4.0f}, device);
