@@ -171,8 +171,11 @@ agpu_status agpu_internal_bounce_copy(agpu_pipeline* p, void* dev_ptr, void* hos
 // separate mappings that live until the caller frees them.  The heap's start never moves; its end is sbrk(0).
 static bool host_range_in_brk_heap(const void* ptr, size_t bytes) {
   static std::atomic<uintptr_t> heap_start{0};
+  static std::atomic<uintptr_t> no_heap_at_brk{0};  // "no [heap] line" was established while sbrk(0) had this value: re-parse only when it moved
   uintptr_t start = heap_start.load(std::memory_order_relaxed);
+  const uintptr_t brk_now = reinterpret_cast<uintptr_t>(sbrk(0));
   if (!start) {
+    if (no_heap_at_brk.load(std::memory_order_relaxed) == brk_now) return false;
     FILE* f = fopen("/proc/self/maps", "r");
     if (f) {
       char line[512];
@@ -184,11 +187,47 @@ static bool host_range_in_brk_heap(const void* ptr, size_t bytes) {
         }
       fclose(f);
     }
-    if (!start) return false;  // no heap segment yet: nothing can live in it
+    if (!start) {  // no heap segment yet: nothing can live in it (remembered until the break moves)
+      no_heap_at_brk.store(brk_now, std::memory_order_relaxed);
+      return false;
+    }
     heap_start.store(start, std::memory_order_relaxed);
   }
-  const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes, brk_now = reinterpret_cast<uintptr_t>(sbrk(0));
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes;
   return lo < brk_now && hi > start;
+}
+
+// glibc serves malloc calls of NON-main threads out of mmap'ed thread arenas — 64 MiB-aligned "heaps" of at most 64 MiB
+// (HEAP_MAX_SIZE) that are trimmed and shrunk exactly like the brk heap, so their pages are the same hazard.  A block
+// inside one is necessarily smaller than 64 MiB; whatever is bigger is either the brk heap (checked above) or a mapping of its own.
+// For the sizes in between, the range is handed to the runtime directly only when it is PROVEN to be a mapping of its own: it
+// starts within a chunk header of its mapping's beginning (an mmapped malloc chunk: 16-byte header; numpy, Arrow buffers, mmap itself),
+// the mapping is not 64 MiB-aligned (an arena heap is) and the range ends inside it.  One pass over /proc/self/maps (tens of microseconds) per 4–64 MiB copy; anything unproven takes the staged path.
+#define AGPU_THREAD_ARENA_MAX ((size_t)64 << 20)
+static bool host_range_is_own_mapping(const void* ptr, size_t bytes) {
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes;
+  FILE* f = fopen("/proc/self/maps", "r");
+  if (!f) return false;
+  char line[512];
+  bool own = false;
+  while (fgets(line, sizeof line, f)) {
+    unsigned long long a = 0, b = 0;
+    if (sscanf(line, "%llx-%llx", &a, &b) != 2) continue;
+    if (lo >= a && lo < b) {
+      // "at the beginning" = within a malloc chunk header of it (an mmapped chunk's data starts 16 bytes in); a thread arena's first
+      // block lies ~2 KiB in, behind heap_info + malloc_state, and its mapping is 64 MiB-aligned — both tests exclude it.  Adjacent
+      // anonymous mappings merge into one line: a block that merged with a neighbour is simply "unproven" and takes the staged path.
+      own = (lo - a) <= 64 && hi <= b && (a & (AGPU_THREAD_ARENA_MAX - 1)) != 0 && !strstr(line, "[heap]");
+      break;
+    }
+  }
+  fclose(f);
+  return own;
+}
+static bool host_range_needs_staging(const void* ptr, size_t bytes) {
+  if (host_range_in_brk_heap(ptr, bytes)) return true;
+  if (bytes >= AGPU_THREAD_ARENA_MAX) return false;
+  return !host_range_is_own_mapping(ptr, bytes);
 }
 
 // One host↔HBM copy of a caller's (possibly pageable) range that is COMPLETE on return, never handing heap pages to the
@@ -202,7 +241,7 @@ agpu_status agpu_internal_host_copy(agpu_pipeline* p, void* dev_ptr, void* host_
   static const bool direct = [] { const char* e = getenv("AGPU_HOST_COPY_DIRECT"); return e && *e && *e != '0'; }();
   if (!p->capturing && !direct) {
     if (bytes <= AGPU_BOUNCE_MAX_BYTES) return agpu_internal_bounce_copy(p, dev_ptr, host_ptr, bytes, to_device);
-    if (host_range_in_brk_heap(host_ptr, bytes)) {
+    if (host_range_needs_staging(host_ptr, bytes)) {
       agpu_status st = staged_copy_threads(p, static_cast<char*>(dev_ptr), static_cast<char*>(host_ptr), bytes, to_device);
       if (st != AGPU_OK) return st;
       AGPU_HIP(hipStreamSynchronize(p->stream));
@@ -214,10 +253,10 @@ agpu_status agpu_internal_host_copy(agpu_pipeline* p, void* dev_ptr, void* host_
   AGPU_HIP(hipStreamSynchronize(p->stream));
   return AGPU_OK;
 }
-// test hook (tests/test_gpu_host_copies.py): which path a host range would take — 0 bounce, 1 chunk engine (brk heap), 2 direct
+// test hook (tests/test_gpu_host_copies.py): which path a host range would take — 0 bounce, 1 chunk engine (brk heap / a malloc arena / unproven), 2 direct
 extern "C" int32_t agpu_internal_host_copy_path(const void* host_ptr, size_t bytes) {
   if (bytes <= AGPU_BOUNCE_MAX_BYTES) return 0;
-  return host_range_in_brk_heap(host_ptr, bytes) ? 1 : 2;
+  return host_range_needs_staging(host_ptr, bytes) ? 1 : 2;
 }
 
 static agpu_status staged_copy_impl(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device) {
@@ -230,7 +269,7 @@ static agpu_status staged_copy_impl(agpu_pipeline* p, void* dev_ptr, void* host_
   int64_t mode = p->tune.h2d_mode;
   if (mode <= 0 || mode > 3) mode = 1;
   if (mode == 1) return agpu_internal_host_copy(p, dev_ptr, host_ptr, bytes, to_device);
-  if (mode == 3 && host_range_in_brk_heap(host_ptr, bytes)) mode = 2;  // registering heap pages in place is the same userptr pin
+  if (mode == 3 && host_range_needs_staging(host_ptr, bytes)) mode = 2;  // registering heap pages in place is the same userptr pin
   if (mode == 2) return staged_copy_threads(p, static_cast<char*>(dev_ptr), static_cast<char*>(host_ptr), bytes, to_device);
   if (mode == 3) {
     hipError_t e = hipHostRegister(host_ptr, bytes, hipHostRegisterDefault);

@@ -649,6 +649,12 @@ def main():
 
             traceback.print_exc()
             os._exit(4)
+    # which class of allocation the compare's table drew (DESIGN.md §3 "lucky / unlucky blocks": the same binary and layout runs the
+    # almost read-only compare at 0.81–0.85 or at 0.87–0.89 of the roof by what the driver backed the block with; the add does not care)
+    extra["layout"] = {"eq_frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4), "add_frac_hbm_peak": round(add_gbps / HBM_PEAK_GBPS, 4),
+                       "allocation_class": "lucky" if eq_gbps / HBM_PEAK_GBPS >= 0.865 else "unlucky",
+                       "what": "allocation lottery of the compare's table: >= 0.865 of the roof on eq + validity = the lucky class (DESIGN.md §3); "
+                               "extra.layout_pool has the same step over ordinary pool blocks"}
     extra["kernels"] = {"add_f32": {"ms": round(add_ms, 4), "GBps": round(add_gbps, 1), "frac_hbm_peak": round(add_gbps / HBM_PEAK_GBPS, 4)},
                         "eq_i32_validity": {"ms": round(eq_ms, 4), "GBps": round(eq_gbps, 1), "frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4)}}
 

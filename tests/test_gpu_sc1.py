@@ -33,21 +33,3 @@ def test_every_sc1_call_site_matches_the_oracle_and_the_build_without_it():
     assert without["lib"] == NOSC1 and without["bad"] == []
     diff = [k for k in with_sc1["sites"] if with_sc1["sites"][k] != without["sites"][k]]
     assert diff == [], diff[:10]
-
-
-def test_the_two_builds_differ_only_in_the_store_instruction():
-    """the default build carries the sc1 stores, the leg has none — so the comparison above compares what it says"""
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
-        pytest.skip("no llvm-objdump")
-
-    def count(lib):
-        tmp = subprocess.run(["bash", "-c", f"cd /tmp && rm -rf sc1x && mkdir sc1x && cd sc1x && "
-                              f"/opt/rocm/lib/llvm/bin/clang-offload-bundler --list --type=o --input={lib} >/dev/null 2>&1; "
-                              f"{objdump} -d --offloading {lib} 2>/dev/null | grep -c 'sc1 nt' || true"], capture_output=True, text=True)
-        return int((tmp.stdout.strip().splitlines() or ["0"])[-1])
-
-    a, b = count(os.path.join(ROOT, "arrow_gpu_amd", "lib", "libarrow_gpu_hip.so")), count(NOSC1)
-    if a == 0 and b == 0:
-        pytest.skip("this llvm-objdump cannot disassemble the embedded code objects")
-    assert a > 0 and b == 0, (a, b)
