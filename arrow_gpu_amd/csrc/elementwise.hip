@@ -262,6 +262,39 @@ __device__ __attribute__((noinline)) float sincos_f32_slow(float x, int want_cos
 // result.  Per row: 10 → 8 f64 operations, 5 → 4 conversions, 7 → 4 f32 operations, 3 → 5 selects: ≈ 49 → ≈ 38 f32-rate issue
 // slots (ISA counted with tools/probe: llvm -S of this file).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#ifndef AGPU_SINCOS_FORM
+#define AGPU_SINCOS_FORM 1  // 1 = one outer step (below); 0 = the two-chain form of rounds 1–3 (A/B: tools/probe/sincos_ab.sh)
+#endif
+#ifndef AGPU_SINCOS_PACK
+#define AGPU_SINCOS_PACK 0  // 1 = the tile kernel evaluates a 16-byte pack with ONE slow-path branch; 0 = a branch per row.  Same box, three
+                            // alternations (tools/probe/sincos_ab.sh, 1e9 rows, fraction of the HBM roof, sin / cos): two-chain form 0.761 / 0.801,
+                            // + pack 0.753 / 0.777, one-step form 0.773 / 0.793, + pack 0.752 / 0.785 — the kernel is bound by bytes in flight,
+                            // not by its 36 → 30 VALU instructions per row, and the pack form's longer straight-line phases cost 2 %
+#endif
+#if AGPU_SINCOS_FORM == 0
+__device__ __forceinline__ float sincos_f32_fast(float x, int want_cos) {
+  const double xd = (double)x;
+  const double sh = fma(xd, 0x1.45f306dc9c883p-1, 0x1.8p52);
+  const double kd = sh - 0x1.8p52;
+  const int k = (int)(uint32_t)__builtin_bit_cast(uint64_t, sh);
+  double r = fma(kd, -0x1.921fb54400000p+0, xd);
+  r = fma(kd, -0x1.0b4611a626331p-34, r);
+  const float zf = (float)r * (float)r;
+  float ps = __builtin_fmaf(zf, (float)-0x1.aa12ed611087fp-26, (float)0x1.71d97b66aa967p-19);
+  ps = __builtin_fmaf(zf, ps, (float)-0x1.a019fd5d6492ep-13);
+  ps = __builtin_fmaf(zf, ps, (float)0x1.1111110fba75dp-7);
+  float pc = __builtin_fmaf(zf, (float)-0x1.24635bc27779cp-22, (float)0x1.a0124c744e1f9p-16);
+  pc = __builtin_fmaf(zf, pc, (float)-0x1.6c16ba7ffec5ep-10);
+  pc = __builtin_fmaf(zf, pc, (float)0x1.55555550fad1cp-5);
+  const double z = r * r;
+  const double s = r * fma(z, fma(z, (double)ps, -0x1.555555555510cp-3), 1.0);
+  const double c = fma(z, fma(z, (double)pc, -0x1.fffffffffe3f1p-2), 1.0);
+  const int q = k + want_cos;
+  double v = (q & 1) ? c : s;
+  v = (q & 2) ? -v : v;
+  return (float)v;
+}
+#else
 __device__ __forceinline__ float sincos_f32_fast(float x, int want_cos) {  // meaningful for |x| < 1e6, harmless elsewhere
   const double xd = (double)x;
   const double sh = fma(xd, 0x1.45f306dc9c883p-1, 0x1.8p52);  // x · 2/π + 1.5 · 2^52
@@ -286,6 +319,7 @@ __device__ __forceinline__ float sincos_f32_fast(float x, int want_cos) {  // me
   const uint32_t sign = ((uint32_t)q << 30) & 0x80000000u;  // quadrants 2, 3: negate
   return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)v) ^ sign);
 }
+#endif
 __device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
   float res = sincos_f32_fast(x, want_cos);  // unconditionally: the rare slow path then merges ONE register, not the whole state
   if (!(fabsf(x) < 1.0e6f)) res = sincos_f32_slow(x, want_cos);
@@ -439,8 +473,8 @@ struct UnCos {
   __device__ static __forceinline__ void ap_pack(const float (&x)[4], float (&r)[4]) { sincos_f32_pack<1>(x, r); }
 };
 template <typename Op> struct EwPackOp { static constexpr bool value = false; };  // functors with a 4-row form for the f32 tile kernel
-template <> struct EwPackOp<UnSin> { static constexpr bool value = true; };
-template <> struct EwPackOp<UnCos> { static constexpr bool value = true; };
+template <> struct EwPackOp<UnSin> { static constexpr bool value = AGPU_SINCOS_PACK != 0; };
+template <> struct EwPackOp<UnCos> { static constexpr bool value = AGPU_SINCOS_PACK != 0; };
 struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { return acosf(x); } };
 struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return sinh_f32_dev(x); } };
 
