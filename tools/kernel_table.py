@@ -110,6 +110,28 @@ def main():
     t("cast f32→u16 (reference-absent)", 6, lambda: capi.call("agpu_cast", h, F32, capi.U16, vp(A), vp(O), n))
     t("fused sin_u8 (LDS table)", 5, lambda: capi.call("agpu_unary", h, capi.UN_SIN, U8, vp(B), vp(O), n))
     t("fused cos_i8 (LDS table)", 5, lambda: capi.call("agpu_unary", h, capi.UN_COS, capi.I8, vp(B), vp(O), n))
+
+    # round 4: chains with a widening cast at the head (agpu_fused_cast_chain) — what a fusing pipeline issues at finish() for cast_op → …
+    class _Step(C.Structure):
+        _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+    def _chain(*items):
+        arr = (_Step * len(items))()
+        for k_, (op_, kind_, operand_) in enumerate(items):
+            arr[k_].op, arr[k_].kind, arr[k_].operand = op_, kind_, (operand_.ptr if operand_ is not None else None)
+        return arr, len(items)
+
+    c_sin, n_sin = _chain((capi.UN_SIN, 0, None))
+    c_so, n_so = _chain((capi.OP_MUL, 1, S), (capi.OP_ADD, 1, S))
+    c_hv, n_hv = _chain((capi.OP_MUL, 1, S), (capi.UN_SIN, 0, None))
+    t("cast u8→f32 then sin, ONE launch (config 4 as worded)", 5, lambda: capi.call("agpu_fused_cast_chain", h, U8, vp(B), C.cast(c_sin, C.c_void_p), n_sin, vp(O), n),
+      note="the unfused pair moves 13 B/row in two launches")
+    t("cast u8→f32 · s + s, ONE launch", 5, lambda: capi.call("agpu_fused_cast_chain", h, U8, vp(B), C.cast(c_so, C.c_void_p), n_so, vp(O), n),
+      note="8-bit source: the chain is evaluated once per byte value into a 256-entry table")
+    t("cast u8→f32 · s then sin, ONE launch", 5, lambda: capi.call("agpu_fused_cast_chain", h, U8, vp(B), C.cast(c_hv, C.c_void_p), n_hv, vp(O), n),
+      note="same table route: a transcendental step costs nothing per row")
+    t("cast i16→f32 then sin, ONE launch", 6, lambda: capi.call("agpu_fused_cast_chain", h, capi.I16, vp(B), C.cast(c_sin, C.c_void_p), n_sin, vp(O), n),
+      note="16-bit source: sin evaluated per row (VALU-bound); bit-identical to the pair, which the table kernel sin_i16 is not")
     t("fused sin_u16", 6, lambda: capi.call("agpu_unary", h, capi.UN_SIN, capi.U16, vp(B), vp(O), n))
     t("broadcast f32", 4, lambda: capi.call("agpu_broadcast", h, F32, 0x40400000, vp(O), n))
     t("f32 sum (reference tree order)", 4, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, F32, vp(A), None, n, vp(R)))
