@@ -85,11 +85,25 @@ def main():
     with open(os.path.join(ROOT, "profiles", f"{round_}_pmc_summary.json"), "w") as fh:
         json.dump(summary, fh, indent=1)
     add = [v for k, v in summary.items() if "ew_kernel" in k and "OpAdd" in k and "float" in k]
-    cmpk = [v for k, v in summary.items() if "cmp_ballot_kernel" in k or "cmp_vec_kernel" in k]
+    # the bench step's second kernel: the i32 compare WITH the fused validity AND (template argument `true`); the un-fused and f32 compares of
+    # extra.configs / extra.fused are other instantiations
+    cmpk = [v for k, v in summary.items() if "cmp_ballot_kernel<int, 4, true>" in k] or \
+           [v for k, v in summary.items() if "cmp_ballot_kernel" in k or "cmp_vec_kernel" in k]
     out = {}
     if add and add[0]["hbm_bytes_per_launch"]:
         out["add_f32_bytes_per_launch"] = add[0]["hbm_bytes_per_launch"]
-    if cmpk and cmpk[0]["hbm_bytes_per_launch"]:
+    # fused launches only: the same instantiation also runs the un-fused compares of extra.configs (no validity pointers: 8.125 B/row,
+    # one bitmap written).  The two passes replay the same program, so launch i of one is launch i of the other: pair them and keep the
+    # launches that wrote TWO bitmaps.
+    fk = [k for k in fetch if "cmp_ballot_kernel<int, 4, true>" in k]
+    if fk and fk[0] in write and len(fetch[fk[0]]) == len(write[fk[0]]):
+        pairs = [(f_ * 2048 + w_ * 1024, w_ * 1024) for f_, w_ in zip(fetch[fk[0]], write[fk[0]])]
+        wmax = max(w_ for _, w_ in pairs)
+        fused = sorted(b_ for b_, w_ in pairs if w_ > 0.75 * wmax)
+        if fused:
+            out["eq_i32_bytes_per_launch"] = fused[len(fused) // 2]
+            out["eq_i32_fused_launches"] = len(fused)
+    elif cmpk and cmpk[0]["hbm_bytes_per_launch"]:
         out["eq_i32_bytes_per_launch"] = cmpk[0]["hbm_bytes_per_launch"]
     if out:
         out["source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, round {round_}; read side doubled (gfx950)"
