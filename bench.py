@@ -391,10 +391,9 @@ def main():
         capi.call("agpu_set_tuning", k.encode(), int(v))
     rank, world, local_rank = sharding.ranks_from_env()
     if world != args.gpus and rank == 0:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
-                             "--master-port P bench.py --gpus N ...")
-        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks: the world check below will refuse the run", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): the world check below will refuse the run "
+              f"(launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)",
+              file=sys.stderr)
     if os.environ.get("AGPU_BENCH_DEVICE_OVERRIDE") is not None:
         # rehearsal on a 1-GPU box only (tools/r03_bootstrap_rehearsal.sh): every rank names the same GPU, so RCCL's bootstrap between
         # the processes runs for real and its init then refuses the duplicate device — a clean failure, never a measurement
