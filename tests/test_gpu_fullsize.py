@@ -469,3 +469,51 @@ def test_f32_tree_sum_fullsize_is_the_reference_tree_of_its_aligned_chunks(ctx):
                 keep = np.unpackbits(bits, bitorder="little")[:rows].astype(bool)
                 vals = np.where(keep, vals, np.float32(0.0))
             assert np.float32(O.reduce(O.RED_SUM, O.F32, vals)).view(np.uint32) == parts[k].view(np.uint32), k
+
+
+def test_cast_headed_chains_fullsize_equal_the_unfused_sequence(ctx):
+    """BASELINE config 4 as worded — "cast u8→f32 then sin/cos" — at 1e9 rows in ONE launch (agpu_fused_cast_chain): the whole result column
+    checksum-equal to the two-launch pair, for the 8-bit table route (sin, cos, a scale + offset, a heavy chain) and the 16-bit per-row route;
+    windows against the oracle's sin_u8 (≤ 1 ULP)."""
+    dev, p = ctx
+    h = p._handle
+    u = dev.create_empty_buffer(2 * N)       # N bytes as u8, 2N bytes as i16
+    f, g = dev.create_empty_buffer(4 * N), dev.create_empty_buffer(4 * N)
+    sc = dev.create_gpu_buffer_with_data(np.array([0.37], np.float32))
+    cs1, cs2 = dev.create_empty_buffer(16), dev.create_empty_buffer(16)
+    capi.call("agpu_synth_u8", h, vp(u), 2 * N, SEED + 6, 0)
+
+    class Step(C.Structure):
+        _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+    def chain(*items):
+        arr = (Step * len(items))()
+        for k, (op, kind, operand) in enumerate(items):
+            arr[k].op, arr[k].kind, arr[k].operand = op, kind, (operand.ptr if operand is not None else None)
+        return arr, len(items)
+
+    def unfused(src_dt, steps):
+        capi.call("agpu_cast", h, src_dt, capi.F32, vp(u), vp(f), N)
+        for op, kind, operand in steps:
+            if kind == 0:
+                capi.call("agpu_unary", h, op, capi.F32, vp(f), vp(f), N)
+            else:
+                capi.call("agpu_scalar", h, op, capi.F32, vp(f), vp(operand), vp(f), N)
+
+    cases = [(capi.U8, [(capi.UN_SIN, 0, None)]), (capi.U8, [(capi.UN_COS, 0, None)]), (capi.U8, [(capi.OP_MUL, 1, sc), (capi.OP_ADD, 1, sc)]),
+             (capi.U8, [(capi.OP_MUL, 1, sc), (capi.UN_SIN, 0, None), (capi.UN_ABS, 0, None), (capi.UN_SQRT, 0, None)]),
+             (capi.I16, [(capi.UN_COS, 0, None)]), (capi.I16, [(capi.OP_MUL, 1, sc), (capi.UN_NEG, 0, None)])]
+    for src_dt, steps in cases:
+        st, ns = chain(*steps)
+        capi.call("agpu_memset", h, vp(g), 0, 1 << 20)
+        capi.call("agpu_fused_cast_chain", h, src_dt, vp(u), C.cast(st, C.c_void_p), ns, vp(g), N)
+        unfused(src_dt, steps)
+        capi.call("agpu_checksum", h, vp(g), 4 * N, vp(cs1))
+        capi.call("agpu_checksum", h, vp(f), 4 * N, vp(cs2))
+        assert scalar_u64(dev, p, cs1) == scalar_u64(dev, p, cs2), (src_dt, [s_[0] for s_ in steps])
+    st, ns = chain((capi.UN_SIN, 0, None))
+    capi.call("agpu_fused_cast_chain", h, capi.U8, vp(u), C.cast(st, C.c_void_p), ns, vp(g), N)
+    for start in windows(N):
+        got = download(dev, p, g, 4 * start, 4 * WINDOW).view(np.float32)
+        exp = O.unary(O.UN_SIN, O.U8, O.synth_u8(WINDOW, SEED + 6, start))
+        assert np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64)).max() <= 1, start
