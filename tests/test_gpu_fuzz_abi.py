@@ -34,6 +34,8 @@ def D(_dev):
     _dev.release()
     _dev.p.set_tuning("gather_bucket", 0)
     _dev.p.set_tuning("gather_offsets", 0)
+    for key in ("heavy_tiles", "cast_tiles", "table_tiles"):
+        _dev.p.set_tuning(key, 0)
 
 
 def pick_n(rng):
@@ -61,7 +63,10 @@ def test_random_abi_calls_match_the_oracle(D, seed):
     rng = np.random.default_rng(5000 + seed)
     for it in range(12):
         fam = ("binary", "scalar", "unary", "compare", "compare_validity", "cast", "bitmap", "reduce", "take", "merge",
-               "chain", "shift", "put", "take_bits", "take_validity", "put_bits")[rng.integers(16)]
+               "chain", "shift", "put", "take_bits", "take_validity", "put_bits", "cast_chain")[rng.integers(17)]
+        # tiles per block of the prefetching kernels (casts, cast-headed chains, table kernels): any value, same results
+        for key in ("heavy_tiles", "cast_tiles", "table_tiles"):
+            D.p.set_tuning(key, int(rng.integers(0, 9)) if rng.random() < 0.5 else 0)
         # take / put: the direct kernels (auto at these sizes), the forced pipelines (2: merge-back take, pair-pipeline put;
         # 3: pair-pipeline take) and all three range-start variants — small, ragged, mis-aligned inputs through every form
         D.p.set_tuning("gather_bucket", int((0, 2, 3, 4, 4)[rng.integers(5)]))  # 4: pipelines + the device-side probe at any size
@@ -212,6 +217,34 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             outb = D.empty(O.bitmap_bytes(k) + 8)
             D.call("agpu_take_bits", D.up(bits_in).vp, n, D.up(idx, off(rng, 4)).vp, outb.vp, k)
             assert bits_equal(D.down(outb, np.uint8, O.bitmap_bytes(k)), O.take_bits(bits_in, n, idx)), what
+        elif fam == "cast_chain":  # a widening cast at the head of 0–4 exact f32 steps, one launch (8-bit sources of ≥ 65 536 rows: the table route)
+            import ctypes as C
+
+            frm = (capi.U8, capi.I8, capi.U16, capi.I16)[rng.integers(4)]
+            wi = NP[frm]().itemsize
+            x = rand_values(frm, n, seed * 23 + it)
+            k = int(rng.integers(0, 5))
+
+            class CStep(C.Structure):
+                _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+            steps = (CStep * max(k, 1))()
+            exp = O.cast(frm, capi.F32, x)
+            for s in range(k):
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    op = (capi.UN_NEG, capi.UN_ABS, capi.UN_SQRT)[rng.integers(3)]
+                    steps[s].op, steps[s].kind, steps[s].operand = op, 0, None
+                    exp = O.unary(op, capi.F32, exp)
+                else:
+                    ops = [capi.OP_ADD, capi.OP_SUB, capi.OP_MUL, capi.OP_DIV, capi.OP_MIN, capi.OP_MAX]
+                    op = ops[rng.integers(len(ops))]
+                    y = rand_values(capi.F32, n if kind == 2 else 1, seed * 29 + it * 7 + s, special=kind == 2)
+                    steps[s].op, steps[s].kind, steps[s].operand = op, kind, D.up(y, off(rng, 4) if kind == 2 else 0).vp.value
+                    exp = O.binary(op, capi.F32, exp, y) if kind == 2 else O.scalar(op, capi.F32, exp, y)
+            out = D.empty(max(4 * n, 1), offset_bytes=off(rng, 4))
+            D.call("agpu_fused_cast_chain", frm, D.up(x, off(rng, wi)).vp, C.cast(steps, C.c_void_p), k, out.vp, n)
+            assert nan_aware_bits_equal(D.down(out, np.float32, n), exp), what
         else:  # chain of 2–5 exact steps on a 32-bit column, with or without a terminal compare
             import ctypes as C
 
