@@ -26,6 +26,11 @@ capi.call("agpu_synth_u8", h, vp(u8), n, 6, 0)
 capi.call("agpu_synth_u8", h, vp(u16), 2 * n, 7, 0)
 capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u8), vp(f), n)
 sc = dev.create_gpu_buffer_with_data(np.array([0.37], np.float32))
+want = os.environ.get("NARROW_ONLY", "")
+f2 = u8b = None
+if "add_f32" in want or "cast_f32_u8" in want:  # reference rows for the memory-side counters (tools/probe/pmc_memside.sh)
+    f2, u8b = dev.create_table_buffers([4 * n, n])
+    capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u8), vp(f2), n)
 p.sync()
 
 
@@ -56,6 +61,9 @@ rows = {
     "cast_u8_scale_offset_one_launch": (5.0, lambda: capi.call("agpu_fused_cast_chain", h, capi.U8, vp(u8), C.cast(st_so, C.c_void_p), n_so, vp(g), n)),
     "cast_u16_then_sin_one_launch": (6.0, lambda: capi.call("agpu_fused_cast_chain", h, capi.U16, vp(u16), C.cast(st_sin, C.c_void_p), n_sin, vp(g), n)),
     "cast_u8_scale_then_sin_one_launch": (5.0, lambda: capi.call("agpu_fused_cast_chain", h, capi.U8, vp(u8), C.cast(st_heavy, C.c_void_p), n_heavy, vp(g), n)),
+    "add_f32": (12.0, lambda: capi.call("agpu_binary", h, capi.OP_ADD, capi.F32, vp(f), vp(f2), vp(g), n)),
+    "fill_f32": (4.0, lambda: capi.call("agpu_broadcast", h, capi.F32, 0x3F000000, vp(g), n)),
+    "cast_f32_u8": (5.0, lambda: capi.call("agpu_cast", h, capi.F32, capi.U8, vp(f), vp(u8b), n)),
     "u8_eq": (2.125, lambda: capi.call("agpu_compare", h, capi.CMP_EQ, capi.U8, vp(u8), vp(u16), vp(g), n)),
 }
 only = os.environ.get("NARROW_ONLY")
