@@ -655,6 +655,44 @@ def test_graph_capture_replays_an_op_chain(D):
     capi.call("agpu_graph_destroy", g)
 
 
+def test_graph_capture_of_cast_headed_chains_rebuilds_the_table_on_replay(D):
+    """agpu_fused_cast_chain inside a captured graph: the 8-bit route's 256-entry table is built by a kernel of the SAME capture from the
+    scalar operands as they are at replay time (new source bytes and a new scalar between replays → new results); the 16-bit route
+    evaluates per row.  Scratch grows on the warm-up call, not during capture."""
+
+    class Step(C.Structure):
+        _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+
+    n = 3 * 65536 + 0
+    x8, x16 = rand_values(capi.U8, n, 1), rand_values(capi.I16, n, 2)
+    s = np.array([0.25], np.float32)
+    d8, d16, ds = D.up(x8), D.up(x16), D.up(s)
+    o8, o16 = D.empty(4 * n), D.empty(4 * n)
+    steps = (Step * 2)()
+    steps[0].op, steps[0].kind, steps[0].operand = capi.OP_MUL, 1, ds.vp.value
+    steps[1].op, steps[1].kind, steps[1].operand = capi.UN_SQRT, 0, None
+    D.call("agpu_fused_cast_chain", capi.U8, d8.vp, C.cast(steps, C.c_void_p), 2, o8.vp, n)  # warm-up: scratch for the table
+    g = C.c_void_p()
+    D.call("agpu_pipeline_begin_capture")
+    D.call("agpu_fused_cast_chain", capi.U8, d8.vp, C.cast(steps, C.c_void_p), 2, o8.vp, n)
+    D.call("agpu_fused_cast_chain", capi.I16, d16.vp, C.cast(steps, C.c_void_p), 2, o16.vp, n)
+    D.call("agpu_pipeline_end_capture", C.byref(g))
+    for rep in range(3):
+        if rep:  # new inputs in the same device buffers
+            x8, x16 = rand_values(capi.U8, n, 10 + rep), rand_values(capi.I16, n, 20 + rep)
+            s = np.array([0.25 + rep], np.float32)
+            for buf, arr in ((d8, x8), (d16, x16), (ds, s)):
+                capi.call("agpu_upload", D.h, buf.vp, arr.ctypes.data_as(C.c_void_p), arr.nbytes)
+        capi.call("agpu_memset", D.h, o8.vp, 0, 4 * n)
+        capi.call("agpu_memset", D.h, o16.vp, 0, 4 * n)
+        capi.call("agpu_graph_launch", g, D.h)
+        assert float(s[0]) == 0.25 + rep
+        for out, frm, x in ((o8, capi.U8, x8), (o16, capi.I16, x16)):
+            exp = O.unary(O.UN_SQRT, O.F32, O.scalar(O.OP_MUL, O.F32, O.cast(frm, O.F32, x), s))
+            assert nan_aware_bits_equal(D.down(out, np.float32, n), exp), (rep, frm)
+    capi.call("agpu_graph_destroy", g)
+
+
 def test_graph_capture_of_takes_and_puts_uses_the_direct_kernels(D):
     """the bucketed pipelines allocate temporaries and (under the auto policy) decide on the device: neither belongs in a captured
     graph — while a pipeline is capturing, take / put / their Boolean forms enqueue the direct kernels, whatever the tuning says"""
