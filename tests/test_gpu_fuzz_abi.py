@@ -58,7 +58,7 @@ def bin_ops(dtype):
     return INT32_BIN if NP[dtype]().itemsize == 4 else SMALL_BIN
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("AGPU_FUZZ_SEEDS", "40"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AGPU_FUZZ_BASE", "0")), int(os.environ.get("AGPU_FUZZ_BASE", "0")) + int(os.environ.get("AGPU_FUZZ_SEEDS", "40"))))  # soaks: AGPU_FUZZ_SEEDS = how many, AGPU_FUZZ_BASE = the first
 def test_random_abi_calls_match_the_oracle(D, seed):
     rng = np.random.default_rng(5000 + seed)
     for it in range(12):

@@ -76,7 +76,7 @@ def compare(got, exp, ulp, what):
 
 
 @pytest.mark.parametrize("fuse", [False, True])
-@pytest.mark.parametrize("seed", range(int(os.environ.get("AGPU_FUZZ_SEEDS", "30"))))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AGPU_FUZZ_BASE", "0")), int(os.environ.get("AGPU_FUZZ_BASE", "0")) + int(os.environ.get("AGPU_FUZZ_SEEDS", "30"))))  # soaks: AGPU_FUZZ_SEEDS = how many, AGPU_FUZZ_BASE = the first
 def test_random_dyn_programs_agree_with_the_model(ag, seed, fuse, monkeypatch):
     import arrow_gpu_amd.gpu_utils as gu
 
