@@ -937,7 +937,10 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       }
       // one cursor per 128-byte line while the regions are few (the atomics spread over the L2 channels: −10…15 % per
       // call at ≤ 1024 regions, same-box A/B), packed cursors beyond (a 256 KiB cursor array costs more than it spreads)
-      const uint32_t stride_s = bs + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 1;
+      // G's cursors (the one pass that still reserves with atomics): 32 bytes apart beyond 1024 regions (round 4, tools/probe/cur_stride_probe.py,
+      // fresh processes: put of 2^28 rows 5.01–5.05 ms packed, 4.92–4.95 at 8 / 16 / 32 words — reservations to one 128-byte line queue up
+      // behind each other; 8 words keep the array at 64–128 KiB)
+      const uint32_t stride_s = bs + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 8;
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0, stride_s, stride_d);
       if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets, gate);
       hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),
