@@ -410,6 +410,13 @@ __global__ __launch_bounds__(256) void bkt_offsets_kernel(const uint16_t* counts
   }
 }
 
+// Where cursor b of a pass lives.  Plain: word b · stride.  PAIRED (stride's top bit): cursors 2j and 2j + 1 share one aligned 8-byte
+// word at (stride & 0x7fffffff) · j — one 64-bit fetch-add reserves both ranges (round 4: G's reservations are bound by how many
+// atomics the chip retires, so two ranges per atomic; neither half can carry into the other: a cursor never exceeds the row count < 2^32)
+#define BKT_CUR_PAIRED 0x80000000u
+__host__ __device__ __forceinline__ uint32_t bkt_cur_index(uint32_t b, uint32_t stride) {
+  return (stride & BKT_CUR_PAIRED) ? (b >> 1) * (stride & ~BKT_CUR_PAIRED) + (b & 1u) : b * stride;
+}
 // exclusive scans → range start of every bucket; one workgroup
 __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t bs, uint32_t bd, int rd, int is_put,
                                                         uint32_t stride_s, uint32_t stride_d) {
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t b
   __syncthreads();
   for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T) {
     ctl->base_s[b] = sh[b];
-    ctl->cur_s[b * stride_s] = sh[b];
+    ctl->cur_s[bkt_cur_index(b, stride_s)] = sh[b];
   }
   __syncthreads();
   if (is_put) {  // the same scan over hist_d[0 .. bd-1] (bd ≤ BKT_MAX)
@@ -482,14 +489,14 @@ __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t b
     for (int k = 0; k < 4; k++) {
       const uint32_t b = threadIdx.x * 4 + k;
       if (b < bd) {
-        ctl->cur_d[b * stride_d] = run;
+        ctl->cur_d[bkt_cur_index(b, stride_d)] = run;
         ctl->base_d[b] = run;
       }
       run += c[k];
     }
   } else {  // take: the destinations are 0..n-1, every destination bucket is full — its range is its own region
     for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) {
-      ctl->cur_d[b * stride_d] = b << rd;
+      ctl->cur_d[bkt_cur_index(b, stride_d)] = b << rd;
       ctl->base_d[b] = b << rd;
     }
   }
@@ -504,6 +511,7 @@ __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t b
 struct BktRow {
   uint32_t a, b, key;
 };
+static_assert(offsetof(BktCtl, cur_d) % 8 == 0 && offsetof(BktCtl, cur_s) % 8 == 0 && BKT_CUR_STRIDE % 2 == 0, "paired cursors are 8-byte words");
 #ifdef BKT_PROFILE
 // tools/probe: per-phase cycle stamps of workgroup 0's thread 0 (s_memtime), dumped through a global debug buffer
 __device__ unsigned long long g_bkt_stamps[4][16];
@@ -582,6 +590,20 @@ __device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, con
   // all four reservations are issued before any result is consumed: four dependent round trips to the memory-side
   // atomic unit per thread were most of this phase
   uint32_t g[4];
+  if (!tile_starts && (cur_stride & BKT_CUR_PAIRED)) {  // two ranges per 64-bit atomic (keys 4t, 4t+1 | 4t+2, 4t+3)
+    const uint32_t S = cur_stride & ~BKT_CUR_PAIRED;
+    unsigned long long old[2] = {0ull, 0ull};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint32_t kk = threadIdx.x * 4 + 2 * q;
+      const uint32_t c0 = kk < nkeys ? cnt[2 * q] : 0u, c1 = kk + 1 < nkeys ? cnt[2 * q + 1] : 0u;
+      if (c0 | c1)
+        old[q] = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cursors + (size_t)(kk >> 1) * S), (unsigned long long)c0 | ((unsigned long long)c1 << 32),
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    g[0] = (uint32_t)old[0]; g[1] = (uint32_t)(old[0] >> 32);
+    g[2] = (uint32_t)old[1]; g[3] = (uint32_t)(old[1] >> 32);
+  } else
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const uint32_t kk = threadIdx.x * 4 + k;
@@ -589,7 +611,7 @@ __device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, con
     g[k] = (uint32_t)(blockIdx.x % 8192u) * BKT_TILE;
 #else
     if (tile_starts) g[k] = kk < nkeys ? tile_starts[kk] : 0u;  // deterministic: the column scan of H's counts
-    else g[k] = (kk < nkeys && cnt[k]) ? __hip_atomic_fetch_add(&cursors[kk * cur_stride], cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    else g[k] = (kk < nkeys && cnt[k]) ? __hip_atomic_fetch_add(&cursors[bkt_cur_index(kk, cur_stride)], cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #endif
   }
 #pragma unroll
@@ -940,7 +962,9 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       // G's cursors (the one pass that still reserves with atomics): 32 bytes apart beyond 1024 regions (round 4, tools/probe/cur_stride_probe.py,
       // fresh processes: put of 2^28 rows 5.01–5.05 ms packed, 4.92–4.95 at 8 / 16 / 32 words — reservations to one 128-byte line queue up
       // behind each other; 8 words keep the array at 64–128 KiB)
-      const uint32_t stride_s = bs + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 8;
+      const uint32_t stride_s = bs + 1 <= 1024 ? BKT_CUR_STRIDE : 1;
+      uint32_t stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 8;
+      if (p->tune.gather_offsets != 6) stride_d = (bd <= 1024 ? BKT_CUR_STRIDE : 16) | BKT_CUR_PAIRED;  // ("gather_offsets" = 6: one atomic per range, for A/B)
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0, stride_s, stride_d);
       if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets, gate);
       hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),

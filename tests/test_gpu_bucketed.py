@@ -333,8 +333,9 @@ def test_take_bits_at_2_28_rows_merge_back_equals_direct(ctx):
     assert np.array_equal(np.unpackbits(outs[0], bitorder="little")[sample], src[idx[sample]])
 
 
-# ---- the pair pipeline's range starts: by atomics (1), from column scans for P and G (2), scan for P + atomics for G (3 = default)
-@pytest.mark.parametrize("offsets", [1, 2, 3])
+# ---- the pair pipeline's range starts: by atomics (1), from column scans for P and G (2), scan for P + atomics for G (3 = default: two
+# ranges per 64-bit atomic since round 4; 6 = one 32-bit atomic per range)
+@pytest.mark.parametrize("offsets", [1, 2, 3, 6])
 @pytest.mark.parametrize("width", [4, 1])
 def test_pair_pipeline_range_start_variants(ctx, offsets, width):
     dev, p = ctx
