@@ -789,6 +789,237 @@ __global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf
                offsets2 ? offsets2 + tile * nbp2 : nullptr);
 }
 
+// G over 32 Ki-pair tiles (round 4): the same inputs and outputs as bkt_gather_kernel, twice its tile.  A 32 Ki-pair tile does not fit LDS as
+// 8-byte pairs; it does as ONE 4-byte array (128 KiB + 16 KiB of counters), 1024 threads holding 32 rows each:
+//   sort 1 (by source line)       the array receives the SOURCE INDEX only; every thread remembers where its rows went; the lane that
+//                                 finds an index at position j gathers the value and puts it back at j; the owner picks it up from there;
+//   sort 2 (by destination region) the values travel first (array → lane j keeps value j in a register), the destinations second;
+//                                 lane j then holds pair j of the sorted tile and stores it as one 8-byte word.
+// Ranks, positions and range deltas live in the one counter array, one after the other.  What the bigger tile buys: a (tile, region) run is
+// 16 pairs = one full 128-byte line instead of half of one, half as many range reservations per row, eight rows per source line and
+// gather instruction instead of four.  (The form was first built for 16 Ki-pair tiles at two workgroups per CU — 13 % SLOWER than
+// bkt_gather_kernel: docs/experiments.md R4.4, tools/probe/patches/.)  117–119 VGPRs, no scratch — see BK2_PIN.
+#define BK2_T 1024
+#define BK2_TILE 32768  // pairs per tile: twice P's and F's
+#define BK2_E (BK2_TILE / BK2_T)
+#define BK2_K (BKT_MAX / BK2_T)  // counters per thread in the scans
+#define BK2_PIN(x) asm volatile("" : "+v"(x))  // the value is materialised at this point of the program and nothing is known about it afterwards
+// exclusive scan of C[0 .. BKT_MAX) in place; `scratch` = BK2_T / 64 words nobody else uses right now; returns nothing (callers know the total)
+__device__ __forceinline__ void bk2_scan(uint32_t* C, uint32_t* scratch) {
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  uint32_t c[BK2_K], sum = 0;
+#pragma unroll
+  for (int k = 0; k < BK2_K; k += 4) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(&C[threadIdx.x * BK2_K + k]);
+    c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
+    sum += v.x + v.y + v.z + v.w;
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < AGPU_WAVE; off <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
+    if (lane >= (uint32_t)off) incl += o;
+  }
+  if (lane == AGPU_WAVE - 1) scratch[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - sum;
+  for (uint32_t w = 0; w < wave; w++) run += scratch[w];
+#pragma unroll
+  for (int k = 0; k < BK2_K; k += 4) {
+    u32x4 v;
+    v.x = run; run += c[k];
+    v.y = run; run += c[k + 1];
+    v.z = run; run += c[k + 2];
+    v.w = run; run += c[k + 3];
+    *reinterpret_cast<u32x4*>(&C[threadIdx.x * BK2_K + k]) = v;
+  }
+  __syncthreads();
+}
+
+// one tile; FULL: all BK2_TILE pairs are live (every tile but the list's last one) — no per-row predicates
+template <int W, bool FULL>
+__device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values, uint32_t n_src32, const u32x2* pairs_in, uint32_t rows, int rd,
+                                         uint32_t bd, int src_line_shift, uint32_t* cursors, uint32_t cur_stride, u32x2* pairs_out,
+                                         const uint32_t* tile_starts, uint32_t* A, uint32_t* C) {
+  uint32_t s[BK2_E], d[BK2_E], r[BK2_E / 2];  // r: two 14-bit ranks / positions per register (rows 2q and 2q + 1)
+  auto live = [&](int e) { return FULL || (((uint32_t)(e / 2) * BK2_T + threadIdx.x) * 2 + (uint32_t)(e % 2)) < rows; };
+  BKT_STAMP(1, 0);
+  for (uint32_t k = threadIdx.x; k < BKT_MAX; k += BK2_T) C[k] = 0;
+  // row e of this thread is pair (e / 2 · BK2_T + thread) · 2 + e % 2 of the tile
+#pragma unroll
+  for (int q = 0; q < BK2_E / 2; q++) {
+    const uint32_t l0 = ((uint32_t)q * BK2_T + threadIdx.x) * 2;
+    u32x4 t = {0, 0, 0, 0};
+    if (FULL || l0 + 2 <= rows) t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pairs_in + l0));
+    else if (l0 < rows) {
+      const u32x2 one = pairs_in[l0];
+      t.x = one.x; t.y = one.y;
+    }
+    s[q * 2] = t.x; d[q * 2] = t.y;
+    s[q * 2 + 1] = t.z; d[q * 2 + 1] = t.w;
+  }
+  __syncthreads();
+  // ---- sort 1: by source line
+  auto key1 = [&](uint32_t v) { return (v >> src_line_shift) & (uint32_t)(BKT_MAX - 1); };
+#pragma unroll
+  for (int q = 0; q < BK2_E / 2; q++) {
+    const uint32_t lo = live(2 * q) ? atomicAdd(&C[key1(s[2 * q])], 1u) : 0u;
+    const uint32_t hi = live(2 * q + 1) ? atomicAdd(&C[key1(s[2 * q + 1])], 1u) : 0u;
+    r[q] = lo | (hi << 16);
+    BK2_PIN(r[q]);  // the packed word exists HERE (two ranks per register; else the compiler keeps 32 results and 32 counter addresses alive
+                    // across the scan and spills the destinations)
+  }
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++) BK2_PIN(s[e]);
+  __syncthreads();
+  BKT_STAMP(1, 1);
+  bk2_scan(C, A);
+#pragma unroll
+  for (int q = 0; q < BK2_E / 2; q++) {
+    const uint32_t lo = (r[q] & 0xFFFFu) + C[key1(s[2 * q])], hi = (r[q] >> 16) + C[key1(s[2 * q + 1])];
+    r[q] = lo | (hi << 16);
+    BK2_PIN(r[q]);
+  }
+  __syncthreads();  // the scan's scratch words (A[0 .. 8)) have been read by everyone
+  BKT_STAMP(1, 2);
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++)
+    if (live(e)) A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu] = s[e];
+  __syncthreads();
+  BKT_STAMP(1, 3);
+  // the L2-resident gather, in line order; the value replaces the index at its place.  Eight rows per step: thirty-two 64-bit addresses
+  // at once would not fit beside the rows' destinations in 128 registers
+  for (uint32_t k = threadIdx.x; k < BKT_MAX; k += BK2_T) C[k] = 0;  // (everyone is past the position lookups: two barriers ago)
+#pragma unroll 1
+  for (uint32_t c = 0; c < BK2_E; c += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t j = (c + (uint32_t)u) * BK2_T + threadIdx.x;
+      v[u] = (FULL || j < rows) ? A[j] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = v[u] < n_src32 ? (uint32_t)values[v[u]] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const uint32_t j = (c + (uint32_t)u) * BK2_T + threadIdx.x;
+      if (FULL || j < rows) A[j] = v[u];
+    }
+  }
+  __syncthreads();
+  BKT_STAMP(1, 4);
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++)
+    if (live(e)) s[e] = A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu];  // the value of MY row e
+  // ---- sort 2: by destination region
+#pragma unroll
+  for (int q = 0; q < BK2_E / 2; q++) {
+    const uint32_t lo = live(2 * q) ? atomicAdd(&C[d[2 * q] >> rd], 1u) : 0u;
+    const uint32_t hi = live(2 * q + 1) ? atomicAdd(&C[d[2 * q + 1] >> rd], 1u) : 0u;
+    r[q] = lo | (hi << 16);
+    BK2_PIN(r[q]);
+  }
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++) BK2_PIN(d[e]);
+  __syncthreads();  // … which also ends the reads of A above: the scan may use its first words
+  BKT_STAMP(1, 5);
+  bk2_scan(C, A);
+  BKT_STAMP(1, 6);
+  // ranges of the tile's runs in the output: thread t owns keys BK2_K·t …; one reservation per non-empty (tile, region), all of them in
+  // flight while the tile is moved
+  uint32_t g[BK2_K];
+  {
+    static_assert(BK2_K == 4, "two paired reservations per thread");
+    uint32_t st[BK2_K], cnt[BK2_K];
+#pragma unroll
+    for (int k = 0; k < BK2_K; k++) st[k] = C[threadIdx.x * BK2_K + k];
+#pragma unroll
+    for (int k = 0; k < BK2_K; k++) {
+      const uint32_t kk = threadIdx.x * BK2_K + k;
+      const uint32_t nxt = k < BK2_K - 1 ? st[k + 1] : (kk + 1 < BKT_MAX ? C[kk + 1] : rows);
+      cnt[k] = kk < bd ? nxt - st[k] : 0u;
+    }
+    if (tile_starts) {
+#pragma unroll
+      for (int k = 0; k < BK2_K; k++) g[k] = threadIdx.x * BK2_K + k < bd ? tile_starts[threadIdx.x * BK2_K + k] - st[k] : 0u;
+    } else if (cur_stride & BKT_CUR_PAIRED) {  // two ranges per 64-bit atomic (bkt_copy_out)
+      const uint32_t S = cur_stride & ~BKT_CUR_PAIRED;
+      unsigned long long old[2] = {0ull, 0ull};
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const uint32_t kk = threadIdx.x * 4 + 2 * q;
+        if (cnt[2 * q] | cnt[2 * q + 1])
+          old[q] = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cursors + (size_t)(kk >> 1) * S),
+                                          (unsigned long long)cnt[2 * q] | ((unsigned long long)cnt[2 * q + 1] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      g[0] = (uint32_t)old[0] - st[0]; g[1] = (uint32_t)(old[0] >> 32) - st[1];
+      g[2] = (uint32_t)old[1] - st[2]; g[3] = (uint32_t)(old[1] >> 32) - st[3];
+    } else {
+#pragma unroll
+      for (int k = 0; k < BK2_K; k++) {
+        const uint32_t kk = threadIdx.x * BK2_K + k;
+        g[k] = cnt[k] ? __hip_atomic_fetch_add(&cursors[bkt_cur_index(kk, cur_stride)], cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - st[k] : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < BK2_E / 2; q++) {
+    const uint32_t lo = (r[q] & 0xFFFFu) + (live(2 * q) ? C[d[2 * q] >> rd] : 0u), hi = (r[q] >> 16) + (live(2 * q + 1) ? C[d[2 * q + 1] >> rd] : 0u);
+    r[q] = lo | (hi << 16);
+    BK2_PIN(r[q]);
+  }
+  __syncthreads();  // everyone has its positions and starts
+  BKT_STAMP(1, 7);
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++)
+    if (live(e)) A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu] = s[e];  // values first …
+#pragma unroll
+  for (int k = 0; k < BK2_K; k++) C[threadIdx.x * BK2_K + k] = g[k];  // the counters turn into deltas: range start − start inside the tile
+  __syncthreads();
+  BKT_STAMP(1, 8);
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++) s[e] = A[(uint32_t)e * BK2_T + threadIdx.x];  // … value j of the sorted tile stays with lane j
+  __syncthreads();
+  BKT_STAMP(1, 9);
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++)
+    if (live(e)) A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu] = d[e];  // … then the destinations
+  __syncthreads();
+  BKT_STAMP(1, 10);
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++) {
+    const uint32_t j = (uint32_t)e * BK2_T + threadIdx.x;
+    if (FULL || j < rows) {
+      const uint32_t dj = A[j];
+      const u32x2 v = {dj, s[e]};
+      pairs_out[(uint64_t)(uint32_t)(C[dj >> rd] + j)] = v;
+    }
+    if (e % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // (eight addresses at a time)
+  }
+  BKT_STAMP(1, 11);
+}
+
+template <int W>
+__global__ __launch_bounds__(BK2_T, 4) void bkt_gather2_kernel(const typename ElemOf<W>::type* values, uint64_t n_src,
+                                                              const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles,
+                                                              int src_line_shift, BktCtl* ctl, u32x2* pairs_out, uint32_t cur_stride,
+                                                              const uint32_t* offsets2, uint32_t nbp2) {
+  if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
+  static_assert(BK2_T * BK2_E == BK2_TILE && BK2_K % 4 == 0 && BK2_E % 2 == 0 && BK2_TILE <= 65536, "tile shape (positions travel as 16-bit halves)");
+  __shared__ __attribute__((aligned(16))) uint32_t A[BK2_TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t C[BKT_MAX];
+  uint64_t tile;
+  if (!bkt_tile_of_block(ntiles, &tile)) return;
+  const uint64_t total = ctl->total, base = tile * BK2_TILE;
+  if (base >= total) return;
+  const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
+  const uint32_t* ts = offsets2 ? offsets2 + tile * nbp2 : nullptr;
+  if (total - base >= BK2_TILE)  // every pair of P's output is a live row: only the list's last tile is ragged
+    bk2_tile<W, true>(values, n_src32, pairs_in + base, BK2_TILE, rd, bd, src_line_shift, ctl->cur_d, cur_stride, pairs_out, ts, A, C);
+  else
+    bk2_tile<W, false>(values, n_src32, pairs_in + base, (uint32_t)(total - base), rd, bd, src_line_shift, ctl->cur_d, cur_stride, pairs_out, ts, A, C);
+}
+
 // F: {destination, value} in destination-bucket order → dst[destination] = value.  The tile is first ordered by
 // destination LINE (128 bytes) in LDS, so lanes that share a line sit next to each other and the store instruction's
 // coalescer merges them: the smaller the destination region, the more rows per line in one tile.
@@ -915,6 +1146,10 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   // G's 75 000 cycles in the reservation phase) — at one workgroup per CU a tile's phases add up, but chip-wide the atomic unit's
   // 1.3 ms overlap with the other CUs' sorts; what is left of G is its own chain of phases (load → sort → gather → sort → store).
   const bool det2 = det && p->tune.gather_offsets == 2;
+  // G over 32 Ki-pair tiles through ONE 4-byte LDS array (bkt_gather2_kernel: put of 2^28 random rows 4.78 → 4.47 ms, one process, alternating)
+  // unless its ranges come from the count pass (whose tiles are P's) or "gather_offsets" = 4 asks for round 3's 16 Ki-pair G, for A/B
+  const bool g_one_wg = p->tune.gather_offsets == 4 || det2 || !di;  // (the pair-pipeline TAKE — sequential destinations — is faster on the old G: 4.42 vs 4.65 ms)
+  const uint32_t ntiles2 = (uint32_t)((n + BK2_TILE - 1) / BK2_TILE), nblk2 = (ntiles2 + 7) / 8 * 8;
   // put under the auto policy, three ways (idx_locality_kernel): both columns local → the direct scatter; SOURCE local only (the scatter
   // of a contiguous or sorted selection) → the destination-only pipeline below: the values are fetched by a near-streaming gather inside
   // the partition pass, pairs {destination, value} are partitioned by destination region once and stored by F — no source-side
@@ -978,9 +1213,14 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       }
 #define BKT_GF(W, E)                                                                                                         \
   case W:                                                                                                                    \
-    hipLaunchKernelGGL((bkt_gather_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const E*>(src), n_src,     \
-                       static_cast<const u32x2*>(p1), rd, bd, ntiles, src_line_shift, ctl, static_cast<u32x2*>(p2), stride_d, \
-                       det2 ? offsets : static_cast<const uint32_t*>(nullptr), nbp2);                                          \
+    if (g_one_wg)                                                                                                            \
+      hipLaunchKernelGGL((bkt_gather_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const E*>(src), n_src,   \
+                         static_cast<const u32x2*>(p1), rd, bd, ntiles, src_line_shift, ctl, static_cast<u32x2*>(p2), stride_d, \
+                         det2 ? offsets : static_cast<const uint32_t*>(nullptr), nbp2);                                        \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((bkt_gather2_kernel<W>), dim3(nblk2), dim3(BK2_T), 0, p->stream, static_cast<const E*>(src), n_src, \
+                         static_cast<const u32x2*>(p1), rd, bd, ntiles2, src_line_shift, ctl, static_cast<u32x2*>(p2), stride_d, \
+                         static_cast<const uint32_t*>(nullptr), nbp2);                                                         \
     hipLaunchKernelGGL((bkt_store_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p2), ntiles,  \
                        ctl, line_shift, static_cast<E*>(dst));                                                               \
     break;
