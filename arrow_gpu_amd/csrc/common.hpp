@@ -34,7 +34,7 @@ struct agpu_tuning {
   int64_t h2d_mode;       // host↔device staging of agpu_import/export_arrow: 0 = auto, 1 = pageable hipMemcpy, 2 = threaded pinned staging, 3 = hipHostRegister in place
   int64_t h2d_threads;    // staging threads for mode 2 (0 = auto)
   int64_t gather_region_bits;  // bucketed take/put: log2(elements) of a source region (0 = auto: 512 KiB regions)
-  int64_t gather_offsets;      // bucketed pair pipeline: 0 = auto (= 3), 1 = ranges reserved with global atomics, 2 = from column scans of per-tile counts (P and G), 3 = scan for P, atomics for G (two ranges per 64-bit atomic), 6 = the same with one 32-bit atomic per range
+  int64_t gather_offsets;      // bucketed pair pipeline: 0 = auto (= 3), 1 = ranges reserved with global atomics, 2 = from column scans of per-tile counts (P and G), 3 = scan for P, atomics for G (two ranges per 64-bit atomic), 6 = the same with one 32-bit atomic per range, 8 = 16 Ki-row partition tiles, 4 = round 3's partition and gather passes
   int64_t heavy_tiles;         // tiles per block of the VALU-heavy f32 unary kernels (sin / cos / sinh / log): the next tile's loads are issued before the current tile is evaluated (0 = auto)
   int64_t cast_tiles;          // chunks per wave of the widening casts and cast-headed chains, next chunk prefetched the same way (0 = auto)
 };

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void idx_locality_kernel(const uint32_t* idx0,
 __global__ __launch_bounds__(BKT_T) void bkt_hist_kernel(const uint32_t* si, const uint32_t* di, uint64_t n, uint64_t n_src,
                                                         uint64_t n_dst, int rs, int rd, uint32_t bs, uint32_t bd,
                                                         BktCtl* ctl, uint32_t* flags, uint16_t* counts, uint32_t nbp,
-                                                        uint32_t ntiles) {
+                                                        uint32_t ntiles, int tile_quads = BKT_E / 4) {  // tile = tile_quads · 4 · BKT_T rows
   if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
   __shared__ uint32_t ls[BKT_MAX + 1], ld[BKT_MAX + 1];
   for (uint32_t b = threadIdx.x; b <= BKT_MAX; b += BKT_T) ld[b] = 0;
@@ -342,9 +342,9 @@ __global__ __launch_bounds__(BKT_T) void bkt_hist_kernel(const uint32_t* si, con
       for (uint32_t b = threadIdx.x; b < nbp; b += BKT_T) ls[b] = 0;
       __syncthreads();
     }
-    const uint64_t base = (uint64_t)tile * BKT_TILE;
-#pragma unroll
-    for (int q = 0; q < BKT_E / 4; q++) {
+    const uint64_t base = (uint64_t)tile * ((uint64_t)tile_quads * 4 * BKT_T);
+#pragma unroll 4
+    for (int q = 0; q < tile_quads; q++) {
       const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
       if (i0 + 4 <= n) {
         const u32x4 sv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
@@ -888,7 +888,8 @@ __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values,
   __syncthreads();
   BKT_STAMP(1, 3);
   // the L2-resident gather, in line order; the value replaces the index at its place.  Eight rows per step: thirty-two 64-bit addresses
-  // at once would not fit beside the rows' destinations in 128 registers
+  // at once would not fit beside the rows' destinations in 128 registers (all 32 in flight through a scalar base + 32-bit offsets was
+  // built and measured: no faster — the phase is not waiting on the round trips)
   for (uint32_t k = threadIdx.x; k < BKT_MAX; k += BK2_T) C[k] = 0;  // (everyone is past the position lookups: two barriers ago)
 #pragma unroll 1
   for (uint32_t c = 0; c < BK2_E; c += 8) {
@@ -1018,6 +1019,97 @@ __global__ __launch_bounds__(BK2_T, 4) void bkt_gather2_kernel(const typename El
     bk2_tile<W, true>(values, n_src32, pairs_in + base, BK2_TILE, rd, bd, src_line_shift, ctl->cur_d, cur_stride, pairs_out, ts, A, C);
   else
     bk2_tile<W, false>(values, n_src32, pairs_in + base, (uint32_t)(total - base), rd, bd, src_line_shift, ctl->cur_d, cur_stride, pairs_out, ts, A, C);
+}
+
+// P over 32 Ki-row tiles (round 4; put only): rows in natural order → pairs {source index, destination} in source-region order, the tile
+// sent through the ONE 4-byte array like G's second sort (sources first, destinations second).  A (tile, region) run is 16 pairs — one
+// whole 128-byte line — where bkt_partition_kernel writes halves of lines and relies on the neighbouring tile's half meeting it in L2.
+// Range starts from the column scan of H's counts (H counts the same 32 Ki-row tiles).  Rows with either index out of range are dropped.
+template <bool FULL>
+__device__ __forceinline__ void bk2_partition_tile(const uint32_t* si, const uint32_t* di, uint32_t rows, uint32_t n_src32, uint32_t n_dst32, int rs,
+                                                   const uint32_t* tile_starts, uint32_t nbp, u32x2* pairs, uint32_t* A, uint32_t* C) {
+  uint32_t s[BK2_E], d[BK2_E], r[BK2_E / 2];
+  for (uint32_t k = threadIdx.x; k < BKT_MAX; k += BK2_T) C[k] = 0;
+  // row e of this thread is row (e / 4 · BK2_T + thread) · 4 + e % 4 of the tile
+#pragma unroll
+  for (int q = 0; q < BK2_E / 4; q++) {
+    const uint32_t l0 = ((uint32_t)q * BK2_T + threadIdx.x) * 4;
+    u32x4 a = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, b = a;  // (an index of 2^32 − 1 is out of range for every array)
+    if (FULL || l0 + 4 <= rows) {
+      a = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + l0));
+      b = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + l0));
+    } else {
+      if (l0 < rows) { a.x = si[l0]; b.x = di[l0]; }
+      if (l0 + 1 < rows) { a.y = si[l0 + 1]; b.y = di[l0 + 1]; }
+      if (l0 + 2 < rows) { a.z = si[l0 + 2]; b.z = di[l0 + 2]; }
+    }
+    s[q * 4] = a.x; s[q * 4 + 1] = a.y; s[q * 4 + 2] = a.z; s[q * 4 + 3] = a.w;
+    d[q * 4] = b.x; d[q * 4 + 1] = b.y; d[q * 4 + 2] = b.z; d[q * 4 + 3] = b.w;
+  }
+  auto kept = [&](int e) { return s[e] < n_src32 && d[e] < n_dst32; };
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < BK2_E / 2; q++) {
+    const uint32_t lo = kept(2 * q) ? atomicAdd(&C[s[2 * q] >> rs], 1u) : 0u;
+    const uint32_t hi = kept(2 * q + 1) ? atomicAdd(&C[s[2 * q + 1] >> rs], 1u) : 0u;
+    r[q] = lo | (hi << 16);
+    BK2_PIN(r[q]);
+  }
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++) BK2_PIN(s[e]);
+  __syncthreads();
+  uint32_t own_total = 0;  // rows kept in the tile = the last counter's start + its count: thread BK2_T − 1 has it after the scan
+  if (threadIdx.x == BK2_T - 1) own_total = C[BKT_MAX - 1];
+  bk2_scan(C, A);
+  if (threadIdx.x == BK2_T - 1) A[BK2_TILE - 1] = own_total + C[BKT_MAX - 1];  // (the scan's scratch is A[0 .. 16); nobody uses A's last word yet)
+#pragma unroll
+  for (int q = 0; q < BK2_E / 2; q++) {
+    const uint32_t lo = (r[q] & 0xFFFFu) + (kept(2 * q) ? C[s[2 * q] >> rs] : 0u), hi = (r[q] >> 16) + (kept(2 * q + 1) ? C[s[2 * q + 1] >> rs] : 0u);
+    r[q] = lo | (hi << 16);
+    BK2_PIN(r[q]);
+  }
+  // the counters turn into deltas: range start of (tile, region) − start inside the tile
+  uint32_t g[BK2_K];
+#pragma unroll
+  for (int k = 0; k < BK2_K; k++) g[k] = (threadIdx.x * BK2_K + k < nbp ? tile_starts[threadIdx.x * BK2_K + k] : 0u) - C[threadIdx.x * BK2_K + k];
+  __syncthreads();  // everyone has its positions (and the kept-row count is in place)
+  const uint32_t tile_rows = A[BK2_TILE - 1];
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++)
+    if (kept(e)) A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu] = s[e];  // sources first …
+#pragma unroll
+  for (int k = 0; k < BK2_K; k++) C[threadIdx.x * BK2_K + k] = g[k];
+  __syncthreads();
+  uint32_t sj[BK2_E];
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++) sj[e] = A[(uint32_t)e * BK2_T + threadIdx.x];  // … source j of the sorted tile stays with lane j
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++)
+    if (kept(e)) A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu] = d[e];  // … then the destinations
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < BK2_E; e++) {
+    const uint32_t j = (uint32_t)e * BK2_T + threadIdx.x;
+    if (j < tile_rows) {
+      const u32x2 v = {sj[e], A[j]};
+      pairs[(uint64_t)(uint32_t)(C[sj[e] >> rs] + j)] = v;
+    }
+    if (e % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // (eight addresses at a time)
+  }
+}
+__global__ __launch_bounds__(BK2_T, 4) void bkt_partition2_kernel(const uint32_t* si, const uint32_t* di, uint64_t n, uint64_t n_src, uint64_t n_dst, int rs,
+                                                                 const BktCtl* ctl, u32x2* pairs, const uint32_t* offsets, uint32_t nbp, uint32_t ntiles) {
+  if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
+  __shared__ __attribute__((aligned(16))) uint32_t A[BK2_TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t C[BKT_MAX];
+  uint64_t tile;
+  if (!bkt_tile_of_block(ntiles, &tile)) return;
+  const uint64_t base = tile * BK2_TILE;
+  const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src), n_dst32 = (uint32_t)(n_dst > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_dst);
+  if (n - base >= BK2_TILE) bk2_partition_tile<true>(si + base, di + base, BK2_TILE, n_src32, n_dst32, rs, offsets + tile * nbp, nbp, pairs, A, C);
+  else bk2_partition_tile<false>(si + base, di + base, (uint32_t)(n - base), n_src32, n_dst32, rs, offsets + tile * nbp, nbp, pairs, A, C);
 }
 
 // F: {destination, value} in destination-bucket order → dst[destination] = value.  The tile is first ordered by
@@ -1172,8 +1264,13 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       agpu_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
       st = AGPU_ERR_HIP;
     } else {
+      // P (and H with it) over 32 Ki-row tiles for a put whose range starts come from the column scan ("gather_offsets" = 4 / 8: round 3's
+      // 16 Ki-row P, for A/B)
+      const bool p_big = di && det && p->tune.gather_offsets != 4 && p->tune.gather_offsets != 8;
+      const uint32_t ntiles_p = p_big ? ntiles2 : ntiles, nchunks_p = (ntiles_p + BKT_CHUNK - 1) / BKT_CHUNK;
       uint64_t hg = (uint64_t)dev->num_cus * 2;
-      if (hg > ntiles) hg = ntiles;
+      if (hg > ntiles_p) hg = ntiles_p;
+      const dim3 cgrid_p((nbp + 255) / 256, nchunks_p);
       uint16_t* counts = static_cast<uint16_t*>(cnt_v);
       uint32_t* offsets = static_cast<uint32_t*>(off_v);
       uint32_t* csum = static_cast<uint32_t*>(csum_v);
@@ -1187,10 +1284,11 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
         const int sh = width == 4 ? 5 : width == 2 ? 6 : 7;
         hipLaunchKernelGGL(idx_locality_kernel, dim3(2 * LOC_BLOCKS), dim3(256), 0, p->stream, si, di, n, sh, sh, ctl, static_cast<BktCtl*>(ctlb_v), static_cast<BktCtl*>(ctlc_v));
       }
-      hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags, counts, nbp, ntiles);
+      hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags, counts, nbp, ntiles_p,
+                         p_big ? BK2_TILE / (4 * BKT_T) : BKT_E / 4);
       if (det) {
-        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum, gate);
-        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s, gate);
+        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid_p, dim3(256), 0, p->stream, counts, nbp, ntiles_p, csum, gate);
+        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks_p, ctl->hist_s, gate);
       }
       // one cursor per 128-byte line while the regions are few (the atomics spread over the L2 channels: −10…15 % per
       // call at ≤ 1024 regions, same-box A/B), packed cursors beyond (a 256 KiB cursor array costs more than it spreads)
@@ -1201,9 +1299,12 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       uint32_t stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 8;
       if (p->tune.gather_offsets != 6) stride_d = (bd <= 1024 ? BKT_CUR_STRIDE : 16) | BKT_CUR_PAIRED;  // ("gather_offsets" = 6: one atomic per range, for A/B)
       hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0, stride_s, stride_d);
-      if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets, gate);
-      hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),
-                         det ? offsets : static_cast<uint32_t*>(nullptr), nbp, stride_s, ntiles);
+      if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid_p, dim3(256), 0, p->stream, counts, csum, nbp, ntiles_p, ctl->base_s, offsets, gate);
+      if (p_big)
+        hipLaunchKernelGGL(bkt_partition2_kernel, dim3(nblk2), dim3(BK2_T), 0, p->stream, si, di, n, n_src, n_dst, rs, ctl, static_cast<u32x2*>(p1), offsets, nbp, ntiles2);
+      else
+        hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),
+                           det ? offsets : static_cast<uint32_t*>(nullptr), nbp, stride_s, ntiles);
       if (det2) {  // C + the column scan again, over the blocks P has just finished with
         const dim3 cgrid2((nbp2 + 255) / 256, nchunks);
         hipLaunchKernelGGL(bkt_count_dst_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), rd, bd, ntiles, ctl, counts, nbp2);

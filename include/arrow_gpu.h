@@ -239,7 +239,7 @@ agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, con
  * "h2d_threads","heavy_tiles","cast_tiles"}; unknown key → AGPU_ERR_ARG.  heavy_tiles / cast_tiles: tiles per block of the VALU-heavy f32
  * unary kernels / chunks per wave of the widening casts, the next one's loads issued before the current one is evaluated (0 = the measured default).  gather_bucket: 0 = auto (size thresholds + the device-side locality probe), 1 = direct
  * kernels, 2 = bucketed pipelines whenever the shape qualifies, 3 = like 2 with the round-2 pair pipeline for takes, 4 = like 2 but with the probe (tests);
- * gather_offsets: range starts of the pair pipeline (1 = atomics, 2 = column scans for both passes, 3 = default, 6 = default with one atomic per range).  Every pipeline carries its own copy: agpu_set_tuning changes the process default that pipelines
+ * gather_offsets: range starts of the pair pipeline (1 = atomics, 2 = column scans for both passes, 3 = default, 6 = default with one atomic per range, 8 / 4 = round 3's partition / partition + gather passes).  Every pipeline carries its own copy: agpu_set_tuning changes the process default that pipelines
  * created AFTERWARDS start from (atomic, any thread), agpu_pipeline_set_tuning changes one pipeline only — a sweep on one
  * thread never changes the kernels another pipeline launches.  "mem_pool" (0/1, agpu_set_tuning only) switches the
  * device-level block and stream pools, "pool_arena" (0/1, agpu_set_tuning only) the placed arenas behind blocks of >= 1 GiB. */

@@ -334,8 +334,9 @@ def test_take_bits_at_2_28_rows_merge_back_equals_direct(ctx):
 
 
 # ---- the pair pipeline's range starts: by atomics (1), from column scans for P and G (2), scan for P + atomics for G (3 = default: two
-# ranges per 64-bit atomic since round 4; 6 = one 32-bit atomic per range)
-@pytest.mark.parametrize("offsets", [1, 2, 3, 6])
+# ranges per 64-bit atomic and P / G over 32 Ki-row tiles since round 4; 6 = one 32-bit atomic per range; 8 = round 3's 16 Ki-row P under the new
+# G; 4 = round 3's P and G)
+@pytest.mark.parametrize("offsets", [1, 2, 3, 4, 6, 8])
 @pytest.mark.parametrize("width", [4, 1])
 def test_pair_pipeline_range_start_variants(ctx, offsets, width):
     dev, p = ctx

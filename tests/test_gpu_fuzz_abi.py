@@ -70,7 +70,7 @@ def test_random_abi_calls_match_the_oracle(D, seed):
         # take / put: the direct kernels (auto at these sizes), the forced pipelines (2: merge-back take, pair-pipeline put;
         # 3: pair-pipeline take) and all three range-start variants — small, ragged, mis-aligned inputs through every form
         D.p.set_tuning("gather_bucket", int((0, 2, 3, 4, 4)[rng.integers(5)]))  # 4: pipelines + the device-side probe at any size
-        D.p.set_tuning("gather_offsets", int((0, 1, 2, 3, 6)[rng.integers(5)]))
+        D.p.set_tuning("gather_offsets", int((0, 1, 2, 3, 4, 6, 8)[rng.integers(7)]))
         n = pick_n(rng)
         dtype = ALL_DTYPES[rng.integers(len(ALL_DTYPES))]
         w = NP[dtype]().itemsize

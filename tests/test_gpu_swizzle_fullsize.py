@@ -260,7 +260,7 @@ def test_put_all_four_corners_pinned_through_the_inverse_take(cols, width):
                 expect = taken
             else:  # src_idx = iota: the source column itself
                 expect = c.values
-            forms = [(0, 3), (2, 3), (1, 3)] + ([(2, 1), (2, 2), (2, 6)] if (src_kind, dst_kind) == ("random", "random") else [])
+            forms = [(0, 3), (2, 3), (1, 3)] + ([(2, 1), (2, 2), (2, 4), (2, 6)] if (src_kind, dst_kind) == ("random", "random") else [])
             for mode, offsets in forms:
                 c.p.set_tuning("gather_bucket", mode)
                 c.p.set_tuning("gather_offsets", offsets)
