@@ -1202,7 +1202,18 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || n_dst > 0xFFFFFFFFull || !aligned16(si) || (di && !aligned16(di)) ||
       p->capturing)
     return AGPU_ERR_UNSUPPORTED;
-  const int rs = bkt_region_bits(p, n_src, width), rd = bkt_region_bits(p, n_dst, width) + (di ? BKT_RD_EXTRA : 0);
+  // A put's SOURCE regions (round 4, tools/probe/put_tile_sweep.py with the region size forced, 2^25 … 2^28 rows): about a thousand of them is
+  // the optimum at every size — 32-pair runs out of P's 32 Ki-row tiles, a count matrix half the size — between 256 KiB and 1 MiB each
+  // (2^28 rows 4.41 → 4.34 ms, 2^26 1.11 → 1.09, 2^25 0.61 → 0.59; 2^27 rows have it already).  The destination regions keep their 512 KiB.
+  int rs = bkt_region_bits(p, n_src, width);
+  if (di && p->tune.gather_region_bits <= 0) {
+    const uint64_t bytes = n_src * (uint64_t)width;
+    int rb = 18;  // log2 of the region's bytes
+    while (rb < 20 && (bytes >> rb) > 1024) rb++;
+    rs = rb - (width == 4 ? 2 : width == 2 ? 1 : 0);
+    while (((n_src + ((uint64_t)1 << rs) - 1) >> rs) > BKT_MAX - 1) rs++;
+  }
+  const int rd = bkt_region_bits(p, n_dst, width) + (di ? BKT_RD_EXTRA : 0);
   // F orders a tile by destination line: 128-byte lines, widened until a region's lines fit the BKT_MAX keys
   int line_shift = width == 4 ? 5 : width == 2 ? 6 : 7;
   while ((1 << (rd - line_shift)) > BKT_MAX) line_shift++;
