@@ -903,6 +903,22 @@ def main():
             swz["rows"] = m
             extra["swizzle"] = swz
             del V, I1, I2, SEQ, OUT, VB, OB
+            # … and the two random forms at BASELINE's own row count (1e9 rows over 1e9-element arrays: 1 MiB regions, the take's 8-slot gather);
+            # parity at this size: tests/test_gpu_swizzle_fullsize.py
+            m = n
+            V, I1, I2, OUT = (dev.create_empty_buffer(4 * m) for _ in range(4))
+            capi.call("agpu_synth_i32", h, vp(V), m, SEED + 7, 0, 0)
+            capi.call("agpu_synth_i32", h, vp(I1), m, SEED + 8, 0, m)
+            capi.call("agpu_synth_i32", h, vp(I2), m, SEED + 9, 0, m)
+            p.sync()
+            big = {}
+            for name, launch in (("take_f32_random", lambda: capi.call("agpu_take", h, 4, vp(V), m, vp(I1), vp(OUT), m)),
+                                 ("put_f32_random_to_random", lambda: capi.call("agpu_put_bounded", h, 4, vp(V), m, vp(I1), vp(OUT), m, vp(I2), m))):
+                ms = med5(launch)
+                big[name] = {"ms": round(ms, 4), "G_rows_per_s": round(m / ms / 1e6, 1)}
+            big["rows"] = m
+            extra["swizzle_full_rows"] = big
+            del V, I1, I2, OUT
         except Exception as e:  # noqa: BLE001
             extra["swizzle"] = {"error": f"{type(e).__name__}: {e}"}
 
