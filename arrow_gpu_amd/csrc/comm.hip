@@ -44,6 +44,12 @@ struct agpu_comm {
   hipEvent_t last_done = nullptr;
   hipStream_t last_stream = nullptr;
   bool used = false;
+  char* peers = nullptr;  // device: world + 1 identity records (agpu_comm_peers), part of the one allocation behind `send`
+  // Collectives enqueued and not yet known to be over (a successful deadline wait on the stream of the last one clears it;
+  // every call is ordered behind the previous one, so that stream drains last).  A wait that gives up while this is zero
+  // was only behind ordinary work: it reports the timeout and leaves the device alone.
+  std::atomic<uint32_t> in_flight{0};
+  std::mutex peers_mu;  // one agpu_comm_peers at a time (they share `peers`); never taken together with a wait on `mu`
 };
 
 // AGPU_COMM_TIMEOUT_MS: how long a collective rendezvous (communicator init, barrier) may wait for the other ranks
@@ -67,17 +73,36 @@ static void comm_poison(agpu_comm* c, const char* what, long long waited_ms) {
                  what, c->rank, c->world, waited_ms);
 }
 
-// host wait for everything queued on p's stream, giving up after AGPU_COMM_TIMEOUT_MS (0 = wait for ever)
+// Host wait for everything queued on p's stream, giving up after AGPU_COMM_TIMEOUT_MS (0 = wait for ever).  Called WITHOUT
+// c->mu: other host threads may enqueue on the communicator while this one polls (the mutex only covers the bookkeeping).
 static agpu_status comm_wait_stream(agpu_comm* c, agpu_pipeline* p, const char* what) {
   const int64_t limit = comm_timeout_ms();
+  uint32_t seen;
+  bool last_here;
+  {
+    std::lock_guard<std::mutex> lk(c->mu);
+    seen = c->in_flight.load(std::memory_order_relaxed);
+    last_here = c->used && c->last_stream == p->stream;
+  }
+  // everything this communicator enqueued up to `seen` is over once the stream of its last call has drained
+  auto drained = [&]() {
+    if (!last_here || !seen) return;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const uint32_t now = c->in_flight.load(std::memory_order_relaxed);
+    c->in_flight.store(now >= seen ? now - seen : 0, std::memory_order_relaxed);
+  };
   if (limit <= 0) {
     AGPU_HIP(hipStreamSynchronize(p->stream));
+    drained();
     return AGPU_OK;
   }
   const auto t0 = std::chrono::steady_clock::now();
   for (uint32_t spin = 0;; spin++) {
     hipError_t q = hipStreamQuery(p->stream);
-    if (q == hipSuccess) return AGPU_OK;
+    if (q == hipSuccess) {
+      drained();
+      return AGPU_OK;
+    }
     if (q != hipErrorNotReady) {
       agpu_set_error("%s: %s", what, hipGetErrorString(q));
       return AGPU_ERR_HIP;
@@ -86,6 +111,11 @@ static agpu_status comm_wait_stream(agpu_comm* c, agpu_pipeline* p, const char* 
     if ((spin & 255) == 255) {
       const long long waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
       if (waited > limit) {
+        if (c->in_flight.load(std::memory_order_acquire) == 0) {  // no collective of this communicator anywhere: slow ordinary work
+          agpu_set_error("%s: the stream did not drain within %lld ms (AGPU_COMM_TIMEOUT_MS); no collective of this communicator is in "
+                         "flight, so the device is NOT poisoned — wait again or raise the limit", what, waited);
+          return AGPU_ERR_HIP;
+        }
         comm_poison(c, what, waited);
         return AGPU_ERR_HIP;
       }
@@ -177,13 +207,14 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
     comm = job->comm;
   }
   char* mem = nullptr;
-  hipError_t e = hipMalloc(&mem, 16 + 16 * (size_t)world + 16);
+  const size_t rec_bytes = 16 + 16 * (size_t)world + 16, peer_bytes = sizeof(agpu_comm_peer) * ((size_t)world + 1);
+  hipError_t e = hipMalloc(&mem, rec_bytes + peer_bytes);
   if (e != hipSuccess) {
     (void)ncclCommDestroy(comm);
     agpu_set_error("hipMalloc of the communicator records failed: %s", hipGetErrorString(e));
     return AGPU_ERR_HIP;
   }
-  (void)hipMemset(mem, 0, 16 + 16 * (size_t)world + 16);
+  (void)hipMemset(mem, 0, rec_bytes + peer_bytes);
   (void)hipStreamSynchronize(nullptr);
   agpu_comm* c = new agpu_comm();
   c->dev = dev;
@@ -193,6 +224,7 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
   c->send = mem;
   c->recv = mem + 16;
   c->token = reinterpret_cast<int32_t*>(mem + 16 + 16 * (size_t)world);
+  c->peers = mem + rec_bytes;  // 16-byte aligned: rec_bytes is a multiple of 16
   if (hipEventCreateWithFlags(&c->last_done, hipEventDisableTiming) != hipSuccess) c->last_done = nullptr;
   *out_comm = c;
   return AGPU_OK;
@@ -320,6 +352,7 @@ struct comm_use {
     if (c->used && c->last_done && c->last_stream != p->stream) (void)hipStreamWaitEvent(p->stream, c->last_done, 0);
   }
   ~comm_use() {
+    c->in_flight.fetch_add(1, std::memory_order_release);  // (a call that failed before it enqueued only makes a later timeout poison)
     if (c->last_done && hipEventRecord(c->last_done, p->stream) == hipSuccess) {
       c->last_stream = p->stream;
       c->used = true;
@@ -415,9 +448,12 @@ agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p) {
   AGPU_BIND(p);
   agpu_status st = comm_check(c, p);
   if (st != AGPU_OK) return st;
-  comm_use use(c, p);
-  AGPU_NCCL(ncclAllReduce(c->token, c->token, 1, ncclInt32, ncclMax, c->comm, p->stream));
-  // a peer that died never joins the all-reduce and the stream would never drain: poll with a deadline instead
+  {
+    comm_use use(c, p);
+    AGPU_NCCL(ncclAllReduce(c->token, c->token, 1, ncclInt32, ncclMax, c->comm, p->stream));
+  }
+  // a peer that died never joins the all-reduce and the stream would never drain: poll with a deadline instead (the
+  // communicator is not held meanwhile)
   return comm_wait_stream(c, p, "agpu_comm_barrier");
 }
 
@@ -427,8 +463,7 @@ agpu_status agpu_comm_sync(agpu_comm* c, agpu_pipeline* p) {
   AGPU_BIND(p);
   agpu_status st = comm_check(c, p);
   if (st != AGPU_OK) return st;
-  std::lock_guard<std::mutex> lk(c->mu);
-  return comm_wait_stream(c, p, "agpu_comm_sync");
+  return comm_wait_stream(c, p, "agpu_comm_sync");  // polls without c->mu: other threads keep using the communicator
 }
 
 // One identity record per rank, gathered THROUGH the communicator: proof of which devices joined it.  out_host[r] is rank
@@ -437,35 +472,35 @@ agpu_status agpu_comm_peers(agpu_comm* c, agpu_pipeline* p, agpu_comm_peer* out_
   AGPU_BIND(p);
   agpu_status st = comm_check(c, p);
   if (st != AGPU_OK) return st;
-  AGPU_REQUIRE(out_host && cap >= c->world, AGPU_ERR_ARG, "out_host must hold one record per rank");
+  AGPU_REQUIRE(out_host, AGPU_ERR_ARG, "null out_host");
   agpu_comm_peer mine;
   st = agpu_device_identity(c->dev, &mine);
   if (st != AGPU_OK) return st;
   st = agpu_comm_size(c, &mine.world, &mine.rank, &mine.nccl_device);
   if (st != AGPU_OK) return st;
+  // the gather moves ncclCommCount records: that, not the world the caller passed to init, is what must fit
+  AGPU_REQUIRE(mine.world == c->world, AGPU_ERR_SHAPE, "ncclCommCount differs from the world this communicator was created with");
+  AGPU_REQUIRE(cap >= mine.world, AGPU_ERR_ARG, "out_host must hold one record per rank (ncclCommCount)");
   const size_t rec = sizeof(agpu_comm_peer);
-  char* mem = nullptr;
-  AGPU_HIP(hipMalloc(&mem, rec * ((size_t)c->world + 1)));
+  std::lock_guard<std::mutex> one_at_a_time(c->peers_mu);
+  char* mem = c->peers;  // owned by the communicator: no allocation, no device-wide hipFree per call, nothing to leak on an error
   {
     comm_use use(c, p);
     hipError_t e = hipMemcpyAsync(mem, &mine, rec, hipMemcpyHostToDevice, p->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(p->stream);  // `mine` is pageable stack memory: the copy must be over before it goes
     if (e != hipSuccess) {
-      (void)hipFree(mem);
       agpu_set_error("agpu_comm_peers: %s", hipGetErrorString(e));
       return AGPU_ERR_HIP;
     }
     ncclResult_t r = ncclAllGather(mem, mem + rec, rec, ncclUint8, c->comm, p->stream);
     if (r != ncclSuccess) {
-      (void)hipFree(mem);
       agpu_set_error("ncclAllGather failed: %s", ncclGetErrorString(r));
       return AGPU_ERR_HIP;
     }
-    st = comm_wait_stream(c, p, "agpu_comm_peers");
-    if (st != AGPU_OK) return st;  // poisoned: `mem` leaks with everything else
   }
+  st = comm_wait_stream(c, p, "agpu_comm_peers");
+  if (st != AGPU_OK) return st;
   hipError_t e = hipMemcpy(out_host, mem + rec, rec * (size_t)c->world, hipMemcpyDeviceToHost);
-  (void)hipFree(mem);
   if (e != hipSuccess) {
     agpu_set_error("agpu_comm_peers: %s", hipGetErrorString(e));
     return AGPU_ERR_HIP;

@@ -2267,7 +2267,8 @@ agpu_status agpu_fused_cast_chain(agpu_pipeline* p, agpu_dtype from, const void*
   AGPU_REQUIRE(from == AGPU_U8 || from == AGPU_I8 || from == AGPU_U16 || from == AGPU_I16, AGPU_ERR_UNSUPPORTED,
                "fused cast chains start from u8 / i8 / u16 / i16 (the reference's casts to f32)");
   AGPU_REQUIRE(n_steps >= 0 && n_steps <= AGPU_CHAIN_MAX_STEPS, AGPU_ERR_ARG, "0..8 steps per chain");
-  AGPU_REQUIRE(n == 0 || (in && out && (n_steps == 0 || steps)), AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(n_steps == 0 || steps, AGPU_ERR_ARG, "null steps");  // read below before n is looked at
+  AGPU_REQUIRE(n == 0 || (in && out), AGPU_ERR_ARG, "null pointer");
   if (n_steps == 0) return agpu_cast(p, from, AGPU_F32, in, out, n);
   // cast → sin / cos / sinh of an 8-bit column IS the reference's fused kernel [trigonometry/src/u8_kernel.rs:34-38]: the 256-entry
   // table is built with the f32 kernels' own device functions, so the lookup is bit-identical to the unfused pair
@@ -2298,7 +2299,7 @@ agpu_status agpu_fused_cast_chain(agpu_pipeline* p, agpu_dtype from, const void*
       }
     }
   }
-  AGPU_REQUIRE(n_arrays <= 4, AGPU_ERR_UNSUPPORTED, "at most four array operands behind a cast head");
+  AGPU_REQUIRE(n_arrays <= AGPU_CAST_CHAIN_MAX_ARRAYS, AGPU_ERR_UNSUPPORTED, "at most four array operands behind a cast head");
   switch (from) {
     case AGPU_U8: return launch_cast_chain<uint8_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, heavy);
     case AGPU_I8: return launch_cast_chain<int8_t>(p, in, out, n, n_steps, code, ptrs, vec_ok, heavy);

@@ -152,6 +152,7 @@ class _ChainStep(C.Structure):
 
 _FUSE_DEFAULT = os.environ.get("AGPU_FUSE", "0") not in ("", "0")
 _CHAIN_MAX = 8
+_CAST_CHAIN_MAX_ARRAYS = 4  # AGPU_CAST_CHAIN_MAX_ARRAYS (include/arrow_gpu.h)
 _UNARY, _SCALAR, _ARRAY = 0, 1, 2
 _CMP = 3  # recorded compare (array operand): may only END a chain; `op` is an agpu_cmp_op, `out` the result bitmap
 _CAST = 4  # recorded widening cast u8 / i8 / u16 / i16 → f32: may only START a chain; `op` is the SOURCE agpu_dtype, `dtype` F32
@@ -232,6 +233,7 @@ class ArrowComputePipeline:
         def read_later(buf, start):
             return any(m.a is buf or m.operand is buf for m in nodes[start:])
 
+        first_error = None
         i = 0
         while i < len(nodes):
             chain = [nodes[i]]
@@ -241,15 +243,35 @@ class ArrowComputePipeline:
                 # three references remain (last.out, nxt.a, getrefcount's argument).  A bitcast view sharing the
                 # buffer, a later node reading it or a keep-alive entry all add one and keep it materialised.
                 dead = (last.out_ref is not None and last.out_ref() is None and sys.getrefcount(last.out) == 3)
+                # behind a cast head the kernel reads at most AGPU_CAST_CHAIN_MAX_ARRAYS array operands: the chain is cut
+                # in front of the next one (its intermediate is materialised and a plain chain starts there)
+                room = not (chain[0].kind == _CAST and nxt.kind == _ARRAY
+                            and sum(m.kind == _ARRAY for m in chain) >= _CAST_CHAIN_MAX_ARRAYS)
                 if (nxt.a is last.out and nxt.operand is not last.out and nxt.n == last.n and nxt.dtype == last.dtype
                         and nxt.kind != _CAST and not (chain[0].kind == _CAST and nxt.kind == _CMP)  # a cast only starts a chain; cast-headed chains store
-                        and dead and not read_later(last.out, i + len(chain) + 1)):
+                        and room and dead and not read_later(last.out, i + len(chain) + 1)):
                     chain.append(nxt)
                 else:
                     break
-            if len(chain) == 1:
-                self._launch_single(chain[0])
-            elif chain[0].kind == _CAST:  # narrow column in, the f32 chain behind it, one launch (agpu_fused_cast_chain)
+            # A failing launch must not take the rest of the recording with it: every op was "issued" by the caller, so the
+            # remaining chains still run and the first error is raised once the list is empty.
+            try:
+                self._launch_chain(chain)
+            except Exception as e:  # noqa: BLE001 — re-raised below
+                if first_error is None:
+                    first_error = e
+            for nd in chain:
+                self.keep(nd.a, nd.operand, nd.out)
+            i += len(chain)
+        if first_error is not None:
+            raise first_error
+
+    def _launch_chain(self, chain) -> None:
+        if len(chain) == 1:
+            self._launch_single(chain[0])
+            return
+        try:
+            if chain[0].kind == _CAST:  # narrow column in, the f32 chain behind it, one launch (agpu_fused_cast_chain)
                 body = chain[1:]
                 steps = (_ChainStep * len(body))()
                 for k, nd in enumerate(body):
@@ -257,9 +279,6 @@ class ArrowComputePipeline:
                     steps[k].operand = nd.operand.ptr if nd.operand is not None else None
                 capi.call("agpu_fused_cast_chain", self._h, chain[0].op, C.c_void_p(chain[0].a.ptr), C.cast(steps, C.c_void_p), len(body),
                           C.c_void_p(chain[-1].out.ptr), chain[0].n)
-                self.stats["kernels"] += 1
-                self.stats["fused_chains"] += 1
-                self.stats["fused_ops"] += len(chain)
             else:
                 body = chain[:-1] if chain[-1].kind == _CMP else chain
                 steps = (_ChainStep * len(body))()
@@ -274,12 +293,16 @@ class ArrowComputePipeline:
                 else:
                     capi.call("agpu_fused_chain", self._h, chain[0].dtype, C.c_void_p(chain[0].a.ptr), C.cast(steps, C.c_void_p),
                               len(chain), C.c_void_p(chain[-1].out.ptr), chain[0].n)
-                self.stats["kernels"] += 1
-                self.stats["fused_chains"] += 1
-                self.stats["fused_ops"] += len(chain)
+        except capi.ArrowErrorGPU as e:
+            if getattr(e, "status", None) != capi.ERR_UNSUPPORTED:
+                raise
+            # a chain shape the fused kernels do not take: the recorded ops one by one (every intermediate has its buffer)
             for nd in chain:
-                self.keep(nd.a, nd.operand, nd.out)
-            i += len(chain)
+                self._launch_single(nd)
+            return
+        self.stats["kernels"] += 1
+        self.stats["fused_chains"] += 1
+        self.stats["fused_ops"] += len(chain)
 
     def finish(self) -> None:
         """Submit; does NOT wait.  [ref: compute_pipeline.rs:259-273]"""

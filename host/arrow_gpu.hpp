@@ -13,6 +13,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -202,48 +203,34 @@ class ArrowComputePipeline {  // [compute_pipeline.rs:8-300]; one HIP stream, op
     if (pending_.empty()) return;
     std::vector<Node> nodes;
     nodes.swap(pending_);
+    std::exception_ptr first_error;
     size_t i = 0;
     while (i < nodes.size()) {
-      size_t len = 1;
+      size_t len = 1, arrays = 0;
       while (len < AGPU_CHAIN_MAX_STEPS && i + len < nodes.size()) {
         const Node& last = nodes[i + len - 1];
         const Node& nxt = nodes[i + len];
         // dead intermediate: only `last.out` and `nxt.a` still reference the buffer (the caller dropped the array, no
         // later node reads it, nothing else keeps it alive)
         const bool dead = last.out.use_count() == 2;
-        if (nxt.a == last.out && nxt.operand != last.out && nxt.n == last.n && nxt.dtype == last.dtype && nxt.kind != kCastNode && dead) len++;
-        else break;
+        // behind a cast head the kernel reads at most AGPU_CAST_CHAIN_MAX_ARRAYS array operands: the chain is cut in front of
+        // the next one (its intermediate is materialised, a plain chain starts there)
+        const bool room = !(nodes[i].kind == kCastNode && nxt.kind == AGPU_CHAIN_ARRAY && arrays >= AGPU_CAST_CHAIN_MAX_ARRAYS);
+        if (nxt.a == last.out && nxt.operand != last.out && nxt.n == last.n && nxt.dtype == last.dtype && nxt.kind != kCastNode && room &&
+            dead) {
+          if (nxt.kind == AGPU_CHAIN_ARRAY) arrays++;
+          len++;
+        } else {
+          break;
+        }
       }
-      if (len == 1) {
-        const Node& nd = nodes[i];
-        if (nd.kind == kCastNode)
-          check(agpu_cast(raw, (agpu_dtype)nd.op, AGPU_F32, nd.a->ptr, nd.out->ptr, nd.n), "agpu_cast");
-        else if (nd.kind == AGPU_CHAIN_UNARY)
-          check(agpu_unary(raw, (agpu_unary_op)nd.op, nd.dtype, nd.a->ptr, nd.out->ptr, nd.n), "agpu_unary");
-        else if (nd.kind == AGPU_CHAIN_SCALAR)
-          check(agpu_scalar(raw, (agpu_binary_op)nd.op, nd.dtype, nd.a->ptr, nd.operand->ptr, nd.out->ptr, nd.n), "agpu_scalar");
-        else
-          check(agpu_binary(raw, (agpu_binary_op)nd.op, nd.dtype, nd.a->ptr, nd.operand->ptr, nd.out->ptr, nd.n), "agpu_binary");
-      } else if (nodes[i].kind == kCastNode) {  // narrow column in, the f32 chain behind it: one launch
-        std::vector<agpu_chain_step> steps(len - 1);
-        for (size_t k = 1; k < len; k++)
-          steps[k - 1] = agpu_chain_step{nodes[i + k].op, nodes[i + k].kind, nodes[i + k].operand ? nodes[i + k].operand->ptr : nullptr};
-        check(agpu_fused_cast_chain(raw, (agpu_dtype)nodes[i].op, nodes[i].a->ptr, steps.data(), (int32_t)(len - 1),
-                                    static_cast<float*>(nodes[i + len - 1].out->ptr), nodes[i].n),
-              "agpu_fused_cast_chain");
-        stats.fused_chains++;
-        stats.fused_ops += len;
-      } else {
-        std::vector<agpu_chain_step> steps(len);
-        for (size_t k = 0; k < len; k++)
-          steps[k] = agpu_chain_step{nodes[i + k].op, nodes[i + k].kind, nodes[i + k].operand ? nodes[i + k].operand->ptr : nullptr};
-        check(agpu_fused_chain(raw, nodes[i].dtype, nodes[i].a->ptr, steps.data(), (int32_t)len, nodes[i + len - 1].out->ptr,
-                               nodes[i].n),
-              "agpu_fused_chain");
-        stats.fused_chains++;
-        stats.fused_ops += len;
+      // a failing launch does not take the rest of the recording with it: the caller issued every op, so the remaining
+      // chains still run and the first error is thrown once the list is empty
+      try {
+        launch_chain(nodes, i, len);
+      } catch (...) {
+        if (!first_error) first_error = std::current_exception();
       }
-      stats.kernels++;
       for (size_t k = 0; k < len; k++) {
         keep.push_back(nodes[i + k].a);
         if (nodes[i + k].operand) keep.push_back(nodes[i + k].operand);
@@ -251,9 +238,43 @@ class ArrowComputePipeline {  // [compute_pipeline.rs:8-300]; one HIP stream, op
       }
       i += len;
     }
+    if (first_error) std::rethrow_exception(first_error);
   }
 
  private:
+  struct Node;
+  void launch_single(const Node& nd) {
+    if (nd.kind == kCastNode)
+      check(agpu_cast(raw, (agpu_dtype)nd.op, AGPU_F32, nd.a->ptr, nd.out->ptr, nd.n), "agpu_cast");
+    else if (nd.kind == AGPU_CHAIN_UNARY)
+      check(agpu_unary(raw, (agpu_unary_op)nd.op, nd.dtype, nd.a->ptr, nd.out->ptr, nd.n), "agpu_unary");
+    else if (nd.kind == AGPU_CHAIN_SCALAR)
+      check(agpu_scalar(raw, (agpu_binary_op)nd.op, nd.dtype, nd.a->ptr, nd.operand->ptr, nd.out->ptr, nd.n), "agpu_scalar");
+    else
+      check(agpu_binary(raw, (agpu_binary_op)nd.op, nd.dtype, nd.a->ptr, nd.operand->ptr, nd.out->ptr, nd.n), "agpu_binary");
+    stats.kernels++;
+  }
+  void launch_chain(const std::vector<Node>& nodes, size_t i, size_t len) {
+    if (len == 1) return launch_single(nodes[i]);
+    const bool cast_head = nodes[i].kind == kCastNode;
+    const size_t first = cast_head ? 1 : 0;
+    std::vector<agpu_chain_step> steps(len - first);
+    for (size_t k = first; k < len; k++)
+      steps[k - first] = agpu_chain_step{nodes[i + k].op, nodes[i + k].kind, nodes[i + k].operand ? nodes[i + k].operand->ptr : nullptr};
+    const agpu_status st =
+        cast_head ? agpu_fused_cast_chain(raw, (agpu_dtype)nodes[i].op, nodes[i].a->ptr, steps.data(), (int32_t)steps.size(),
+                                          static_cast<float*>(nodes[i + len - 1].out->ptr), nodes[i].n)
+                  : agpu_fused_chain(raw, nodes[i].dtype, nodes[i].a->ptr, steps.data(), (int32_t)steps.size(), nodes[i + len - 1].out->ptr,
+                                     nodes[i].n);
+    if (st == AGPU_ERR_UNSUPPORTED) {  // a chain shape the fused kernels do not take: the recorded ops one by one
+      for (size_t k = 0; k < len; k++) launch_single(nodes[i + k]);
+      return;
+    }
+    check(st, cast_head ? "agpu_fused_cast_chain" : "agpu_fused_chain");
+    stats.kernels++;
+    stats.fused_chains++;
+    stats.fused_ops += len;
+  }
   struct Node {
     int kind, op;
     agpu_dtype dtype;

@@ -335,9 +335,11 @@ agpu_status agpu_fused_chain_compare(agpu_pipeline* p, agpu_dtype dtype, const v
  * written once; the 4 B/row intermediate of the unfused pair (written by the cast, re-read by the next op) never exists:
  * cast u8→f32 then sin is 5 B/row instead of 13.  Bit-identical to agpu_cast(from → F32) followed by the steps one by one.
  * Steps: f32 unary (neg abs sqrt cbrt exp exp2 log log2 sin cos acos sinh), f32 scalar / array (add sub mul div rem min max;
- * ≤ 4 array operands, f32 columns of n rows).  n_steps == 0: the plain cast.  `cast → sin | cos | sinh` of an 8-bit column runs the
+ * ≤ AGPU_CAST_CHAIN_MAX_ARRAYS array operands, f32 columns of n rows — more is AGPU_ERR_UNSUPPORTED, and a recording host must cut
+ * the chain there).  `steps` must not be NULL when n_steps > 0, whatever n is.  n_steps == 0: the plain cast.  `cast → sin | cos | sinh` of an 8-bit column runs the
  * reference's own fused kernels [ref: crates/trigonometry/src/u8_kernel.rs:34-38, i8_kernel.rs; the chain API of
  * crates/arrow/examples/simple.rs:45-72]. */
+#define AGPU_CAST_CHAIN_MAX_ARRAYS 4
 agpu_status agpu_fused_cast_chain(agpu_pipeline* p, agpu_dtype from, const void* in, const agpu_chain_step* steps,
                                   int32_t n_steps, float* out, uint64_t n);
 
@@ -510,7 +512,9 @@ agpu_status agpu_comm_all_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op 
 agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p);
 /* The host wait that belongs behind agpu_comm_reduce / _all_reduce / _final_reduce (instead of agpu_pipeline_sync or a
  * download, which would block for ever behind a collective a dead peer never joins): waits for p's stream, gives up after
- * AGPU_COMM_TIMEOUT_MS.
+ * AGPU_COMM_TIMEOUT_MS.  The communicator is NOT held while the host polls: other threads may keep enqueueing on it.
+ * A wait that gives up while no collective of this communicator is in flight (the stream was only behind long ordinary work)
+ * returns AGPU_ERR_HIP and leaves the device alone — wait again.
  * POISONING: when this wait, agpu_comm_barrier, agpu_comm_peers or agpu_comm_init_rank(_timeout) gives up, a collective
  * nobody will join is still queued on the device.  The device is then marked poisoned: every pipeline call, agpu_malloc,
  * agpu_device_sync / _trim return AGPU_ERR_HIP at once; agpu_free, agpu_pipeline_destroy and agpu_device_destroy return
@@ -534,7 +538,8 @@ typedef struct agpu_comm_peer {
 } agpu_comm_peer;         /* 72 bytes */
 agpu_status agpu_device_identity(agpu_device* dev, agpu_comm_peer* out);
 /* collective: all-gather of the records THROUGH the communicator + host wait with the deadline.  out_host[r] = rank r's
- * record (cap ≥ world); *out_distinct (may be NULL) = number of distinct (host_hash, PCI address) among them — equal to
+ * record (cap ≥ ncclCommCount, which must equal the world given to init: AGPU_ERR_SHAPE otherwise); the gather buffer belongs to
+ * the communicator (no allocation per call; concurrent callers take turns); *out_distinct (may be NULL) = number of distinct (host_hash, PCI address) among them — equal to
  * world exactly when every rank drives its own GPU. */
 agpu_status agpu_comm_peers(agpu_comm* c, agpu_pipeline* p, agpu_comm_peer* out_host, int32_t cap, int32_t* out_distinct);
 

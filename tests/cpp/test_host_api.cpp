@@ -108,6 +108,16 @@ static void run_compute_pipeline_ops(const DevicePtr& device) {
     CHECK(kp.stats.kernels == 2 && kp.stats.fused_chains == 1 && kp.stats.fused_ops == 3);
     CHECK(kept.raw_values() == w.cast<Float32ArrayGPU>().raw_values());
     CHECK(q.raw_values() == w.cast<Float32ArrayGPU>().mul_scalar(scale).cos().raw_values());
+    // more than AGPU_CAST_CHAIN_MAX_ARRAYS array operands behind a cast head — the fusing pipeline cuts the chain
+    // there instead of failing at finish()
+    std::vector<float> col(3000);
+    for (int i = 0; i < 3000; i++) col[i] = (float)(i % 17) - 8.0f;
+    auto c = Float32ArrayGPU::from_slice(col, device);
+    ArrowComputePipeline ap(device, "cast-arrays", true);
+    auto t = u.cast_op<Float32ArrayGPU>(ap).add_op(c, ap).mul_op(c, ap).sub_op(c, ap).add_op(c, ap).mul_op(c, ap).add_op(c, ap).neg_op(ap);
+    ap.sync();
+    CHECK(ap.stats.recorded == 8 && ap.stats.fused_chains == 2 && ap.stats.kernels == 2);
+    CHECK(t.raw_values() == e.add(c).mul(c).sub(c).add(c).mul(c).add(c).neg().raw_values());
   }
   // chain ending in a compare: (x + y) > x  as one pass, same bits and validity as the three-kernel form
   auto fp = FusedChain(x).add(y).gt(x);

@@ -295,6 +295,70 @@ def test_fusing_pipeline_collapses_cast_then_sin_into_one_launch(ag):
         assert bits(m.raw_values()) == bits(e.mul_scalar(s).gt(e).raw_values()), kind
 
 
+@pytest.mark.parametrize("n_arrays", [4, 5, 7])
+def test_fusing_pipeline_cuts_a_cast_headed_chain_at_four_array_operands(ag, n_arrays):
+    """agpu_fused_cast_chain takes at most AGPU_CAST_CHAIN_MAX_ARRAYS array operands; a fusing pipeline that recorded
+    `cast → 5..7 array ops` with dropped intermediates must cut the chain there (a plain chain continues), not raise at finish()"""
+    dev = ag.GPU_DEVICE()
+    n = 100_003
+    F32 = ag.Float32ArrayGPU
+    rng = np.random.default_rng(n_arrays)
+    a = ag.UInt8ArrayGPU.from_slice(rng.integers(0, 256, n, dtype=np.int64).astype(np.uint8), dev)
+    cols = [F32.from_slice(rng.uniform(-3, 3, n).astype(np.float32), dev) for _ in range(n_arrays)]
+    ops = ["add_op", "mul_op", "sub_op", "max_op", "min_op", "add_op", "mul_op"]
+    p = ag.ArrowComputePipeline(dev, "cast-arrays", fuse=True)
+    r = a.cast_op(F32, p)
+    for k in range(n_arrays):
+        r = getattr(r, ops[k])(cols[k], p)
+    tail = r.neg_op(p)
+    p.finish()
+    e = a.cast(F32)
+    for k in range(n_arrays):
+        e = getattr(e, ops[k][:-3])(cols[k])
+    assert bits(tail.raw_values()) == bits(e.neg().raw_values())
+    assert bits(r.raw_values()) == bits(e.raw_values())  # the kept column in front of the tail
+    # cast + 4 arrays in one launch; whatever follows is a second (plain) chain or a single kernel
+    assert p.stats["fused_chains"] >= 1 and p.stats["kernels"] <= 3, p.stats
+    # the C entry point itself still refuses five arrays — and a pipeline told to run such a chain falls back to single launches
+    class Step(C.Structure):
+        _fields_ = [("op", C.c_int32), ("kind", C.c_int32), ("operand", C.c_void_p)]
+    steps = (Step * 5)()
+    for k in range(5):
+        steps[k].op, steps[k].kind, steps[k].operand = capi.OP_ADD, 2, cols[k % n_arrays].data.ptr
+    out = dev.create_empty_buffer(4 * n)
+    q = ag.ArrowComputePipeline(dev, "abi")
+    assert capi.lib().agpu_fused_cast_chain(q._handle, capi.U8, C.c_void_p(a.data.ptr), C.cast(steps, C.c_void_p), 5, C.c_void_p(out.ptr), n) == capi.ERR_UNSUPPORTED
+    assert capi.lib().agpu_fused_cast_chain(q._handle, capi.U8, C.c_void_p(a.data.ptr), C.cast(steps, C.c_void_p), 4, C.c_void_p(out.ptr), n) == capi.OK
+    q.sync()
+
+
+def test_a_failing_chain_does_not_drop_the_rest_of_the_recording(ag, monkeypatch):
+    """when one launch raises inside the flush, the ops recorded behind it still run; the first error is raised at the end"""
+    dev = ag.GPU_DEVICE()
+    F32 = ag.Float32ArrayGPU
+    a = F32.from_slice([1.0, 2.0, 3.0, 4.0], dev)
+    s = F32.from_slice([2.0], dev)
+    p = ag.ArrowComputePipeline(dev, "partial", fuse=True)
+    bad = a.add_scalar_op(s, p)
+    good = a.mul_scalar_op(s, p)
+    real = p._launch_chain
+    calls = []
+
+    def flaky(chain):
+        calls.append(chain)
+        if len(calls) == 1:
+            raise capi.ArrowErrorGPU("Runtime", "injected", capi.ERR_HIP)
+        return real(chain)
+
+    monkeypatch.setattr(p, "_launch_chain", flaky)
+    with pytest.raises(capi.ArrowErrorGPU, match="injected"):
+        p.finish()
+    assert len(calls) == 2 and not p._pending
+    p.sync()
+    assert good.values() == [2.0, 4.0, 6.0, 8.0]
+    del bad
+
+
 def test_fused_cast_chain_abi_edges(ag):
     """the C entry point directly: mis-aligned pointers take the element-granular path, unsupported heads / ops are refused"""
     dev = ag.GPU_DEVICE()
@@ -326,3 +390,8 @@ def test_fused_cast_chain_abi_edges(ag):
     steps[1].op, steps[0].op = capi.UN_SIN, capi.OP_AND
     assert lib.agpu_fused_cast_chain(p._handle, capi.U16, C.c_void_p(src.ptr), C.cast(steps, C.c_void_p), 2, C.c_void_p(out.ptr), n) == capi.ERR_UNSUPPORTED
     assert lib.agpu_fused_cast_chain(p._handle, capi.U16, C.c_void_p(src.ptr), C.cast(steps, C.c_void_p), 9, C.c_void_p(out.ptr), n) == capi.ERR_ARG
+    # `steps` is read before n is looked at — NULL steps with n_steps > 0 is an argument error for every n, never a crash
+    for rows in (0, n):
+        for head in (capi.U8, capi.U16):
+            assert lib.agpu_fused_cast_chain(p._handle, head, C.c_void_p(src.ptr), None, 1, C.c_void_p(out.ptr), rows) == capi.ERR_ARG
+    assert lib.agpu_fused_cast_chain(p._handle, capi.U8, None, C.cast(steps, C.c_void_p), 2, None, 0) == capi.OK
