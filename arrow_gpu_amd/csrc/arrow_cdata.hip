@@ -21,10 +21,11 @@
 //         overlapped with the next memcpy), event per slot so a slot is refilled only after its DMA has finished.
 //         Chunks land in disjoint destinations, so their order on the stream does not matter.
 // mode 3: hipHostRegister the caller's range in place, one async DMA, unregister (no CPU copy; pays the pinning).
+static size_t stage_chunk_for(size_t bytes) { return bytes < ((size_t)64 << 20) ? ((size_t)1 << 20) : AGPU_STAGE_CHUNK; }
 static int stage_threads_for(const agpu_pipeline* p, size_t bytes) {
   int64_t t = p->tune.h2d_threads;
   if (t <= 0) t = 8;
-  const size_t chunks = (bytes + AGPU_STAGE_CHUNK - 1) / AGPU_STAGE_CHUNK;
+  const size_t chunks = (bytes + stage_chunk_for(bytes) - 1) / stage_chunk_for(bytes) / 2;  // at least two pieces per thread
   if ((size_t)t > chunks) t = (int64_t)chunks;
   if (t > 32) t = 32;
   if (t < 1) t = 1;
@@ -70,15 +71,18 @@ static agpu_status staged_copy_threads(agpu_pipeline* p, char* dev_ptr, char* ho
   std::lock_guard<std::mutex> lock(dev->stage_mu);  // the slots serve one transfer at a time
   agpu_status st = stage_reserve_locked(dev, (size_t)T * 2);
   if (st != AGPU_OK) return st;
-  const size_t nchunks = (bytes + AGPU_STAGE_CHUNK - 1) / AGPU_STAGE_CHUNK;
+  // pieces of a slot's size for big transfers; 1 MiB pieces below 64 MiB (malloc-arena ranges: every thread then has several pieces, so
+  // its DMA of one runs under its memcpy of the other instead of the two happening once, one after the other)
+  const size_t CH = stage_chunk_for(bytes);
+  const size_t nchunks = (bytes + CH - 1) / CH;
   std::vector<hipError_t> errs((size_t)T, hipSuccess);
   auto worker = [&](int t) {
     hipError_t e = hipSetDevice(dev->ordinal);
     int k = 0;
     for (size_t c = (size_t)t; c < nchunks && e == hipSuccess; c += (size_t)T, k ^= 1) {
       agpu_device::StageSlot& s = dev->stage[(size_t)t * 2 + (size_t)k];
-      const size_t off = c * AGPU_STAGE_CHUNK;
-      const size_t len = bytes - off < AGPU_STAGE_CHUNK ? bytes - off : AGPU_STAGE_CHUNK;
+      const size_t off = c * CH;
+      const size_t len = bytes - off < CH ? bytes - off : CH;
       if (to_device) {
         if (s.used) e = hipEventSynchronize(s.ev);  // the DMA that last read this slot
         if (e != hipSuccess) break;
@@ -95,9 +99,9 @@ static agpu_status staged_copy_threads(agpu_pipeline* p, char* dev_ptr, char* ho
         s.used = true;
         if (c >= (size_t)T) {  // previous chunk of this thread sits in the other slot
           agpu_device::StageSlot& o = dev->stage[(size_t)t * 2 + (size_t)(k ^ 1)];
-          const size_t poff = (c - (size_t)T) * AGPU_STAGE_CHUNK;
+          const size_t poff = (c - (size_t)T) * CH;
           if (e == hipSuccess) e = hipEventSynchronize(o.ev);
-          if (e == hipSuccess) memcpy(host_ptr + poff, o.host, AGPU_STAGE_CHUNK);
+          if (e == hipSuccess) memcpy(host_ptr + poff, o.host, CH);
         }
       }
     }
@@ -107,8 +111,8 @@ static agpu_status staged_copy_threads(agpu_pipeline* p, char* dev_ptr, char* ho
       if (last < nchunks) {
         const int lk = (int)(((last - (size_t)t) / (size_t)T) & 1);
         agpu_device::StageSlot& o = dev->stage[(size_t)t * 2 + (size_t)lk];
-        const size_t off = last * AGPU_STAGE_CHUNK;
-        const size_t len = bytes - off < AGPU_STAGE_CHUNK ? bytes - off : AGPU_STAGE_CHUNK;
+        const size_t off = last * CH;
+        const size_t len = bytes - off < CH ? bytes - off : CH;
         e = hipEventSynchronize(o.ev);
         if (e == hipSuccess) memcpy(host_ptr + off, o.host, len);
       }
@@ -199,35 +203,54 @@ static bool host_range_in_brk_heap(const void* ptr, size_t bytes) {
 
 // glibc serves malloc calls of NON-main threads out of mmap'ed thread arenas — 64 MiB-aligned "heaps" of at most 64 MiB
 // (HEAP_MAX_SIZE) that are trimmed and shrunk exactly like the brk heap, so their pages are the same hazard.  A block
-// inside one is necessarily smaller than 64 MiB; whatever is bigger is either the brk heap (checked above) or a mapping of its own.
-// For the sizes in between, the range is handed to the runtime directly only when it is PROVEN to be a mapping of its own: it
-// starts within a chunk header of its mapping's beginning (an mmapped malloc chunk: 16-byte header; numpy, Arrow buffers, mmap itself),
-// the mapping is not 64 MiB-aligned (an arena heap is) and the range ends inside it.  One pass over /proc/self/maps (tens of microseconds) per 4–64 MiB copy; anything unproven takes the staged path.
+// inside one is necessarily smaller than 64 MiB and never crosses a 64 MiB boundary; whatever is bigger is either the brk heap
+// (checked above) or a mapping of its own.
+// Round 4 sent every 4–64 MiB range to the staging engine unless it was PROVEN to be a mapping of its own (starts at its mapping's
+// beginning, mapping not 64 MiB-aligned).  Measured in round 5 (tools/probe/host_copy_routes.py → profiles/r05_host_copy_routes*.json):
+// that proof fails for nearly everything real — fresh numpy arrays (their mmapped chunk merges with a neighbouring mapping), numpy
+// views at an offset, every pyarrow pool (mimalloc / jemalloc carve buffers out of big regions), arrays built by pa.array — and the
+// staged path moves them at 14–40 GB/s where the runtime does 40–56.  So the test now asks the question itself: IS THE RANGE INSIDE A
+// GLIBC THREAD ARENA?  Such a heap starts at A = lo & ~(64 MiB − 1) with a `heap_info` header {mstate ar_ptr; heap_info* prev; size_t
+// size; size_t mprotect_size; …} (malloc/arena.c, unchanged in these fields from glibc 2.26 to 2.39): the first heap of an arena keeps
+// its malloc_state right behind the header (ar_ptr − A is 32 or 48), later heaps point back (prev is 64 MiB-aligned, ar_ptr lies a
+// header behind ANOTHER 64 MiB boundary); size ≤ mprotect_size ≤ 64 MiB, both page multiples.  A range is staged when the header at A
+// is readable (one pass over /proc/self/maps — the header is only dereferenced inside a readable mapping) and looks like that; any
+// other memory — numpy, Arrow pools, file mappings, mmap itself — goes to the runtime at the link's rate.  A false "arena" costs
+// bandwidth only; a false "not an arena" would need a glibc whose heap_info no longer starts with these four words.
 #define AGPU_THREAD_ARENA_MAX ((size_t)64 << 20)
-static bool host_range_is_own_mapping(const void* ptr, size_t bytes) {
-  const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes;
+static bool host_range_in_thread_arena(const void* ptr, size_t bytes) {
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes, mask = AGPU_THREAD_ARENA_MAX - 1;
+  if (((lo ^ (hi - 1)) & ~mask) != 0) return false;  // crosses a 64 MiB boundary: no single heap holds it
+  const uintptr_t A = lo & ~mask;
   FILE* f = fopen("/proc/self/maps", "r");
-  if (!f) return false;
+  if (!f) return true;  // cannot tell: the safe path
   char line[512];
-  bool own = false;
+  bool readable = false;
   while (fgets(line, sizeof line, f)) {
     unsigned long long a = 0, b = 0;
-    if (sscanf(line, "%llx-%llx", &a, &b) != 2) continue;
-    if (lo >= a && lo < b) {
-      // "at the beginning" = within a malloc chunk header of it (an mmapped chunk's data starts 16 bytes in); a thread arena's first
-      // block lies ~2 KiB in, behind heap_info + malloc_state, and its mapping is 64 MiB-aligned — both tests exclude it.  Adjacent
-      // anonymous mappings merge into one line: a block that merged with a neighbour is simply "unproven" and takes the staged path.
-      own = (lo - a) <= 64 && hi <= b && (a & (AGPU_THREAD_ARENA_MAX - 1)) != 0 && !strstr(line, "[heap]");
+    char perms[8] = {0};
+    if (sscanf(line, "%llx-%llx %7s", &a, &b, perms) != 3) continue;
+    if (A >= a && A + 64 <= b) {
+      readable = perms[0] == 'r';
       break;
     }
+    if (a > A) break;  // the file is sorted by address: A is not mapped
   }
   fclose(f);
-  return own;
+  if (!readable) return false;  // nothing (readable) at the would-be header: not a heap
+  uint64_t w[4];
+  memcpy(w, reinterpret_cast<const void*>(A), sizeof w);
+  const uint64_t ar_ptr = w[0], prev = w[1], size = w[2], mprot = w[3];
+  const uint64_t ar_off = ar_ptr & mask;
+  const bool header = ar_ptr != 0 && (ar_ptr & 7) == 0 && ar_off >= 16 && ar_off <= 256 &&
+                      (prev == 0 ? (ar_ptr & ~(uint64_t)mask) == A : ((prev & mask) == 0 && prev != A)) &&
+                      size >= 4096 && (size & 4095) == 0 && mprot >= size && (mprot & 4095) == 0 && mprot <= AGPU_THREAD_ARENA_MAX;
+  return header;
 }
 static bool host_range_needs_staging(const void* ptr, size_t bytes) {
   if (host_range_in_brk_heap(ptr, bytes)) return true;
   if (bytes >= AGPU_THREAD_ARENA_MAX) return false;
-  return !host_range_is_own_mapping(ptr, bytes);
+  return host_range_in_thread_arena(ptr, bytes);
 }
 
 // One host↔HBM copy of a caller's (possibly pageable) range that is COMPLETE on return, never handing heap pages to the

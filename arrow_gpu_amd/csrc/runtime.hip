@@ -34,6 +34,13 @@ static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
     /*table_tiles*/ {0},  // 0 = each kernel's default (elementwise.hip tab_k: 1 for the HBM-bound table kernels, 3 for pow with a scalar exponent)
     /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}, /*gather_offsets*/ {0},
     /*heavy_tiles*/ {0}, /*cast_tiles*/ {0}};
+// DEV SWITCH (tools/probe, docs/experiments.md R5): AGPU_DEVICE_MALLOC_FLAGS=<hipExtMallocWithFlags flags> makes every block the
+// pool, the arenas and the tables take from the driver a hipDeviceMallocContiguous (4) / Uncached (3) / Finegrained (1) one.
+// Unset or 0 = plain hipMalloc, which is what the product ships with.
+static hipError_t dev_malloc(void** out, size_t bytes) {
+  static const unsigned flags = [] { const char* e = getenv("AGPU_DEVICE_MALLOC_FLAGS"); return e && *e ? (unsigned)strtoul(e, nullptr, 0) : 0u; }();
+  return flags ? hipExtMallocWithFlags(out, bytes, flags) : hipMalloc(out, bytes);
+}
 static std::atomic<int64_t> g_mem_pool{1};  // 1 = recycle device blocks and idle streams (default), 0 = hipMalloc/hipFree every time
 static std::atomic<int64_t> g_pool_arena{1};  // 1 = pool blocks of ≥ 1 GiB come out of placed arenas (default), 0 = one hipMalloc each
 static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "stream_bpc", "stream_unroll", "stream_nt",
@@ -316,7 +323,7 @@ static void* arena_carve_locked(agpu_device* dev, uint32_t units, const void* co
   while (want > units && (size_t)want * AGPU_ARENA_UNIT > free_b / 2) want = want / 2 > units ? want / 2 : units;
   for (;;) {
     void* base = nullptr;
-    if (hipMalloc(&base, (size_t)want * AGPU_ARENA_UNIT) == hipSuccess) {
+    if (dev_malloc(&base, (size_t)want * AGPU_ARENA_UNIT) == hipSuccess) {
       uint32_t slot = 0;
       for (; slot < dev->arenas.size(); slot++)
         if (!dev->arenas[slot].base) break;
@@ -645,12 +652,12 @@ static agpu_status malloc_impl(agpu_device* dev, size_t bytes, int32_t zero_fill
     if (ws != AGPU_OK) return ws;
   }
   if (!p) {
-    hipError_t e = hipMalloc(&p, padded);
+    hipError_t e = dev_malloc(&p, padded);
     if (e == hipErrorOutOfMemory) {  // give the cached blocks back and retry once
       (void)hipGetLastError();
       std::lock_guard<std::mutex> lock(dev->mu);
       device_trim_locked(dev);
-      e = hipMalloc(&p, padded);
+      e = dev_malloc(&p, padded);
     }
     if (e != hipSuccess) {
       (void)hipGetLastError();
