@@ -21,11 +21,14 @@
 //         overlapped with the next memcpy), event per slot so a slot is refilled only after its DMA has finished.
 //         Chunks land in disjoint destinations, so their order on the stream does not matter.
 // mode 3: hipHostRegister the caller's range in place, one async DMA, unregister (no CPU copy; pays the pinning).
-static size_t stage_chunk_for(size_t bytes) { return bytes < ((size_t)64 << 20) ? ((size_t)1 << 20) : AGPU_STAGE_CHUNK; }
+// Pieces of a slot's size at every transfer size.  1 MiB pieces below 64 MiB (several per thread, so that a thread's DMA runs under its
+// memcpy) were measured in round 5 on thread-arena ranges and are WORSE: 8 / 32 MiB up 23 / 27 GB/s (4 MiB pieces: 23 / 36), down 6.4 / 6.5
+// (21 / 16) — every piece costs an event wait of ≈ 150 µs on the shared stream, which is what bounds the engine, not the copies.
+static size_t stage_chunk_for(size_t bytes) { (void)bytes; return AGPU_STAGE_CHUNK; }
 static int stage_threads_for(const agpu_pipeline* p, size_t bytes) {
   int64_t t = p->tune.h2d_threads;
   if (t <= 0) t = 8;
-  const size_t chunks = (bytes + stage_chunk_for(bytes) - 1) / stage_chunk_for(bytes) / 2;  // at least two pieces per thread
+  const size_t chunks = (bytes + stage_chunk_for(bytes) - 1) / stage_chunk_for(bytes);
   if ((size_t)t > chunks) t = (int64_t)chunks;
   if (t > 32) t = 32;
   if (t < 1) t = 1;
@@ -71,8 +74,6 @@ static agpu_status staged_copy_threads(agpu_pipeline* p, char* dev_ptr, char* ho
   std::lock_guard<std::mutex> lock(dev->stage_mu);  // the slots serve one transfer at a time
   agpu_status st = stage_reserve_locked(dev, (size_t)T * 2);
   if (st != AGPU_OK) return st;
-  // pieces of a slot's size for big transfers; 1 MiB pieces below 64 MiB (malloc-arena ranges: every thread then has several pieces, so
-  // its DMA of one runs under its memcpy of the other instead of the two happening once, one after the other)
   const size_t CH = stage_chunk_for(bytes);
   const size_t nchunks = (bytes + CH - 1) / CH;
   std::vector<hipError_t> errs((size_t)T, hipSuccess);

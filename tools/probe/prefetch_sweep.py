@@ -2,7 +2,8 @@
 """DEV TOOL (GPU box): tiles per block with the next tile's loads issued before the current one is evaluated —
 tuning heavy_tiles for sin / cos / sinh / log f32 (ew_prefetch_kernel), cast_tiles for the widening casts and the cast-headed
 chains (cvt_wide_kernel / cast_chain_kernel), table_tiles for the LDS-table kernels (lut8 / trig16).  1e9 rows, median of 7
-HIP-event timings, alternating K so that drift shows.     python tools/probe/prefetch_sweep.py [rows] > gpurun_out/r04_prefetch_sweep.json"""
+HIP-event timings, alternating K so that drift shows.  PREFETCH_KS=0,1,64,256,… sweeps other tile counts — large ones make the
+kernels PERSISTENT (grid = tiles / K: one moving front instead of K fronts a grid apart; round 5).     python tools/probe/prefetch_sweep.py [rows] > gpurun_out/r04_prefetch_sweep.json"""
 import ctypes as C
 import json
 import os
@@ -65,7 +66,7 @@ KERNELS = {
         "pow_f32_scalar": (8.0, lambda: capi.call("agpu_scalar", h, capi.OP_POW, capi.F32, vp(f), vp(sc), vp(g), n)),
     },
 }
-KS = [0, 1, 2, 3, 4, 6, 8, 0, 1, 2, 4]
+KS = [int(x) for x in os.environ.get("PREFETCH_KS", "0,1,2,3,4,6,8,0,1,2,4").split(",")]
 
 
 def median_ms(fn, reps=7):
