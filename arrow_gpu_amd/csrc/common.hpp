@@ -37,8 +37,9 @@ struct agpu_tuning {
   int64_t gather_offsets;      // bucketed pair pipeline: 0 = auto (= 3), 1 = ranges reserved with global atomics, 2 = from column scans of per-tile counts (P and G), 3 = scan for P, atomics for G (two ranges per 64-bit atomic), 6 = the same with one 32-bit atomic per range, 8 = 16 Ki-row partition tiles, 4 = round 3's partition and gather passes
   int64_t heavy_tiles;         // tiles per block of the VALU-heavy f32 unary kernels (sin / cos / sinh / log): the next tile's loads are issued before the current tile is evaluated (0 = auto)
   int64_t cast_tiles;          // chunks per wave of the widening casts and cast-headed chains, next chunk prefetched the same way (0 = auto)
+  int64_t tile_auto;           // 0 = the "auto" of heavy_tiles / cast_tiles / table_tiles is ADAPTIVE for big launches (one or two tiles per block, whichever the device measures faster on these buffers: runtime.hip agpu_tiles_pick); 1 = static defaults (one tile); > 1 = adaptive with this many bytes as the threshold instead of 256 MiB (tests)
 };
-#define AGPU_TUNE_KEYS 14
+#define AGPU_TUNE_KEYS 15
 agpu_tuning agpu_tuning_defaults();  // snapshot of the process-wide defaults (atomics, runtime.hip)
 bool agpu_mem_pool_enabled();        // process-wide "mem_pool" switch (device-level behaviour, not per pipeline)
 
@@ -152,7 +153,46 @@ struct agpu_device {
   // from two host threads do not serialise
   std::mutex bounce_mu[2];
   StageSlot bounce[2] = {{nullptr, nullptr, false}, {nullptr, nullptr, false}};
+  // ---- adaptive tiles per block (runtime.hip agpu_tiles_pick).  Guarded by tile_mu.
+  struct TileSlot {  // one timed launch
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    uint8_t variant = 0;  // 0 = one tile per block, 1 = two
+    bool pending = false;
+    double bytes = 0;
+  };
+  struct TileEntry {
+    bool live = false;
+    uint16_t family = 0;  // AGPU_TILE_FAMILY_* << 8 | the kernel inside the family (sin ≠ sinh: their answers differ)
+    uint8_t lg_bytes = 0;
+    uint64_t in_region = 0, out_region = 0;  // pointers >> 28: the answer follows what the driver backed the buffers with
+    uint8_t choice = 0;                      // 0 = still measuring, 1 / 2 = tiles per block
+    uint8_t current = 1;                     // what launches use while measuring (the last decision, one tile at first)
+    uint8_t n[2] = {0, 0}, issued[2] = {0, 0};
+    double best[2] = {0, 0};                 // fastest sample, ns per byte
+    uint32_t launches = 0;                   // since the last decision
+    uint64_t last_use = 0;
+    TileSlot slot[8];
+  };
+  static constexpr int kTileEntries = 32;
+  std::mutex tile_mu;
+  TileEntry tile_tab[kTileEntries];
+  uint64_t tile_clock = 0;
 };
+// Adaptive tiles per block (round 5).  The kernels that prefetch the next tile (ew_prefetch_kernel, cvt_wide_kernel, lut8_kernel, trig16_kernel,
+// log_kernel) run 3–7 % faster with TWO tiles per block in some processes and 5–9 % slower in others — it follows what the driver backed the
+// buffers with (docs/experiments.md R4.1, R5.4), which no address a process can see predicts.  So the device MEASURES: for a launch whose
+// tiles-per-block tuning is 0 (auto) and that moves ≥ AGPU_TILE_AUTO_MIN_BYTES, the first eight launches per (kernel, size class, input
+// region, output region) alternate one and two tiles with a HIP event pair around each; with four samples of both the faster form (two tiles
+// must win by 2.5 % on the fastest sample of each: single samples scatter by ±2 %) is used from then on and re-measured every 1024 launches.  Results never depend on the tile count (tests/test_gpu_tile_auto.py,
+// the ABI fuzz draws the tunings at random).  Off: tuning tile_auto = 1, or any explicit tile count.
+#define AGPU_TILE_AUTO_MIN_BYTES ((uint64_t)256 << 20)
+enum { AGPU_TILE_FAMILY_HEAVY = 1, AGPU_TILE_FAMILY_CAST = 2, AGPU_TILE_FAMILY_LUT8 = 3, AGPU_TILE_FAMILY_TRIG16 = 4, AGPU_TILE_FAMILY_LOG = 5 };
+struct agpu_pipeline;
+struct agpu_tile_sample {
+  int entry = -1, slot = -1;
+};
+uint64_t agpu_tiles_pick(agpu_pipeline* p, int family, int kernel, const void* in, const void* out, uint64_t bytes, agpu_tile_sample* sample);  // 1 or 2
+void agpu_tiles_done(agpu_pipeline* p, agpu_tile_sample* sample);
 #define AGPU_STAGE_CHUNK ((size_t)4 << 20)
 void agpu_internal_free_staging(agpu_device* dev);  // arrow_cdata.hip
 #define AGPU_BOUNCE_MAX_BYTES ((size_t)4 << 20)  // = one stage slot

@@ -555,7 +555,7 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_prefetch_kernel(const float*
     t = tn;
   }
 }
-template <typename Op> struct EwPrefetch { static constexpr bool value = false; static constexpr int tiles = 1; };
+template <typename Op> struct EwPrefetch { static constexpr bool value = false; static constexpr int tiles = 1; static constexpr int id = 0; };
 
 // rows [first, n): whole packs while they last, then single elements.  One small block; also serves tiny arrays.
 template <typename T, typename Op, int MODE>
@@ -590,9 +590,9 @@ template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };
 // tiles per block: 1 by default (see tile_run above: 3–4 tiles gain 4 % in lucky allocations — sin 0.785 → 0.82 — and lose 7 % in others)
-template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; };
-template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; };
-template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; };
+template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 1; };
+template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 2; };
+template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 3; };
 // Threads per block: one wave for everything.  (The LDS-table kernels pow / log run best at 256 threads × 1 pack, but
 // sin / cos / sinh lose 4–10 % in that shape and 5 % at 64 × 1: tools/probe/heavy_shape.py, profiles/r02_heavy_shape.txt.)
 #ifndef AGPU_EW_DEFAULT_BLK
@@ -626,9 +626,13 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
       const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(out) |
                              (MODE == MODE_BINARY ? reinterpret_cast<uintptr_t>(b) : 0);
       bool done = false;
+      agpu_tile_sample tile_sample;
       if constexpr (EwPrefetch<Op>::value && MODE == MODE_UNARY && std::is_same<T, float>::value && BLK == AGPU_EW_BLOCK) {
-        const int64_t k = p->tune.heavy_tiles > 0 ? p->tune.heavy_tiles : EwPrefetch<Op>::tiles;
-        if (k > 1 && (bits & 127u) == 0 && p->tune.stream_grid == 0 && p->tune.stream_bpc == 0) {
+        int64_t k = p->tune.heavy_tiles > 0 ? p->tune.heavy_tiles : EwPrefetch<Op>::tiles;
+        const bool shape_ok = (bits & 127u) == 0 && p->tune.stream_grid == 0 && p->tune.stream_bpc == 0;
+        // auto: one or two tiles per block, whichever this device measures faster on these buffers (common.hpp, adaptive tiles)
+        if (p->tune.heavy_tiles <= 0 && shape_ok) k = (int64_t)agpu_tiles_pick(p, AGPU_TILE_FAMILY_HEAVY, EwPrefetch<Op>::id, a, out, 2 * sizeof(T) * n, &tile_sample);
+        if (k > 1 && shape_ok) {
           const int g = stream_grid_for(p, (ntiles + (uint64_t)k - 1) / (uint64_t)k);
           hipLaunchKernelGGL((ew_prefetch_kernel<Op, U, AGPU_STREAM_NT>), dim3(g), dim3(AGPU_EW_BLOCK), 0, p->stream, pa, po, ntiles);
           done = true;
@@ -640,6 +644,7 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
                            po, ntiles);
       else
         hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, 4, BLK>), dim3(grid), dim3(BLK), 0, p->stream, pa, pb, po, ntiles);
+      agpu_tiles_done(p, &tile_sample);
     }
     if (ntiles * tile_rows < n)
       hipLaunchKernelGGL((ew_tail_kernel<T, Op, MODE>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
@@ -981,8 +986,11 @@ static agpu_status launch_log_f32(agpu_pipeline* p, const void* a, void* out, ui
   if (aligned16(a) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p))), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
+      agpu_tile_sample tile_sample;
+      const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LOG, 0, a, out, 8 * n, &tile_sample);
+      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, (ntiles + tk - 1) / tk)), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
                          static_cast<const PowTab*>(p->dev->pow_table));
+      agpu_tiles_done(p, &tile_sample);
       done = ntiles * TILE_ROWS;
     }
   }
@@ -1354,10 +1362,13 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
       const uint64_t nchunks = n / chunk_rows;
       if (nchunks) {
         // chunks per wave (next chunk prefetched): 1 by default — 2 is +5 % in lucky allocations and −8 % in others (tile_run above)
-        const uint64_t k = (uint64_t)(p->tune.cast_tiles > 0 ? p->tune.cast_tiles : 1);
+        agpu_tile_sample tile_sample;
+        const uint64_t k = p->tune.cast_tiles > 0 ? (uint64_t)p->tune.cast_tiles
+                                                  : agpu_tiles_pick(p, AGPU_TILE_FAMILY_CAST, (int)(sizeof(TI) * 16 + sizeof(TO)), in, out, (sizeof(TI) + sizeof(TO)) * n, &tile_sample);
         const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
         const int grid = stream_grid_for(p, (blocks + k - 1) / k);
         hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, po, nchunks);
+        agpu_tiles_done(p, &tile_sample);
       }
       if (nchunks * chunk_rows < n)
         hipLaunchKernelGGL((cvt_tail_kernel<TI, TO, Conv>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pi, po,
@@ -1524,9 +1535,12 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
   if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      const int grid = stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p));
+      agpu_tile_sample tile_sample;
+      const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
+      const int grid = stream_grid_for(p, (ntiles + tk - 1) / tk);
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, po, ntiles,
                          static_cast<const float*>(p->dev->lut8_tables) + 256 * Lut8Slot<TI, F>::value);
+      agpu_tiles_done(p, &tile_sample);
       done = ntiles * TILE_ROWS;
     }
     if (done < n)
@@ -1662,10 +1676,13 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
   if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      const dim3 grid(stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p)));
+      agpu_tile_sample tile_sample;
+      const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_TRIG16, 0, in, out, 6 * n, &tile_sample);
+      const dim3 grid(stream_grid_for(p, (ntiles + tk - 1) / tk));
       if (blk == 1024) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 1024>), grid, dim3(1024), 0, p->stream, pi, po, ntiles, tab);
       else if (blk == 512) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 512>), grid, dim3(512), 0, p->stream, pi, po, ntiles, tab);
       else hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 256>), grid, dim3(256), 0, p->stream, pi, po, ntiles, tab);
+      agpu_tiles_done(p, &tile_sample);
       done = ntiles * TILE_ROWS;
     }
   }
@@ -2154,8 +2171,11 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
       if (st != AGPU_OK) return st;
       hipLaunchKernelGGL((lut8_chain_build_kernel<TI>), dim3(1), dim3(256), 0, p->stream, static_cast<float*>(tab), n_steps, code, ptrs);
       const uint64_t ntiles = n / TILE_ROWS;
-      const int grid = stream_grid_for(p, (ntiles + tab_k(p) - 1) / tab_k(p));
+      agpu_tile_sample tile_sample;
+      const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
+      const int grid = stream_grid_for(p, (ntiles + tk - 1) / tk);
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, out, ntiles, static_cast<const float*>(tab));
+      agpu_tiles_done(p, &tile_sample);
       if (ntiles * TILE_ROWS < n) {
         const uint64_t rest = n - ntiles * TILE_ROWS;
         const int g2 = stream_grid_for(p, (rest + AGPU_EW_BLOCK - 1) / AGPU_EW_BLOCK);

@@ -34,7 +34,7 @@ def D(_dev):
     _dev.release()
     _dev.p.set_tuning("gather_bucket", 0)
     _dev.p.set_tuning("gather_offsets", 0)
-    for key in ("heavy_tiles", "cast_tiles", "table_tiles"):
+    for key in ("heavy_tiles", "cast_tiles", "table_tiles", "tile_auto"):
         _dev.p.set_tuning(key, 0)
 
 
@@ -67,6 +67,8 @@ def test_random_abi_calls_match_the_oracle(D, seed):
         # tiles per block of the prefetching kernels (casts, cast-headed chains, table kernels): any value, same results
         for key in ("heavy_tiles", "cast_tiles", "table_tiles"):
             D.p.set_tuning(key, int(rng.integers(0, 9)) if rng.random() < 0.5 else 0)
+        # the adaptive policy behind "auto" with a threshold small enough for the fuzz's sizes: whatever it samples or decides, same results
+        D.p.set_tuning("tile_auto", int((0, 1, 4096, 4096)[rng.integers(4)]))
         # take / put: the direct kernels (auto at these sizes), the forced pipelines (2: merge-back take, pair-pipeline put;
         # 3: pair-pipeline take) and all three range-start variants — small, ragged, mis-aligned inputs through every form
         D.p.set_tuning("gather_bucket", int((0, 2, 3, 4, 4)[rng.integers(5)]))  # 4: pipelines + the device-side probe at any size
