@@ -49,8 +49,11 @@ def main():
     def t(label, bytes_per_row, f, note=""):
         # 6 untimed launches first: the VALU-heavy kernels (pow above all) run their first 4–5 launches after a
         # memory-bound or idle phase at 1.3–1.5 GHz before the shader clock has ramped (tools/probe/pow_clock.py)
-        for _ in range(6):
+        # (10 since round 5, with a sync before the last: the adaptive tiles-per-block policy times eight of them and decides)
+        for _ in range(9):
             f()
+        p.sync()
+        f()
         p.sync()
         ts = []
         for _ in range(args.iters):
@@ -211,8 +214,11 @@ def main():
             ("ref bench: f32 add_scalar, 10 Mi rows", 10 << 20, 8, lambda: capi.call("agpu_scalar", h, capi.OP_ADD, F32, vp(A), vp(S), vp(O), 10 << 20)),
             ("ref bench: u32 sum, 1 Mi rows", 1 << 20, 4, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, capi.U32, vp(A), None, 1 << 20, vp(R))),
             ("ref bench: u32 sum, 10 Mi rows", 10 << 20, 4, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, capi.U32, vp(A), None, 10 << 20, vp(R)))):
-        for _ in range(6):
+        # (10 since round 5, with a sync before the last: the adaptive tiles-per-block policy times eight of them and decides)
+        for _ in range(9):
             f()
+        p.sync()
+        f()
         p.sync()
         ts = []
         for _ in range(15):
@@ -287,7 +293,7 @@ def main():
     os.makedirs(outdir, exist_ok=True)
     with open(os.path.join(outdir, f"kernel_table_{args.tag}.json"), "w") as f:
         json.dump({"rows": n, "device": dev.name, "kernels": rows, "reference_bench_shapes": ref_rows, "host_link": pcie,
-                   "small_n": small_n}, f, indent=1)
+                   "small_n": small_n, "tile_auto": dev.tile_auto_info()}, f, indent=1)
     print("\n| kernel | alg. B/row | ms @1e9 | GB/s | frac of 8 TB/s |\n|---|---|---|---|---|")
     for r in rows:
         print(f"| {r['kernel']} | {r['alg_B_per_row']:.4g} | {r['ms']} | {r['GBps']} | {r['frac_8TBs']} |")
