@@ -41,8 +41,31 @@
 struct TileRun {
   uint64_t t, end, step;
 };
+// EXPERIMENT (round 5, AGPU_TILE_NEAR=S): the k tiles of a unit S tiles apart inside a window of k·S tiles instead of a grid apart —
+// the blocks in flight then cover ONE contiguous stretch of the column, as with one tile per block, only permuted at S-tile granularity.
+__device__ uint32_t g_tile_near = 0;
+static uint32_t tile_near_host() {
+  static const uint32_t s = [] {
+    const char* e = getenv("AGPU_TILE_NEAR");
+    const uint32_t v = e && *e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+    if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_near), &v, sizeof v);
+    return v;
+  }();
+  return s;
+}
+// units a launch needs so that every tile is covered: whole groups of S units when the near walk is on
+static inline uint64_t tile_units(uint64_t tiles, uint64_t k) {
+  const uint64_t S = tile_near_host();
+  const uint64_t u = (tiles + k - 1) / k;
+  return (S && k > 1) ? (tiles + k * S - 1) / (k * S) * S : u;
+}
 __device__ __forceinline__ TileRun tile_run(uint64_t unit, uint64_t n_units, uint64_t ntiles) {
-  return TileRun{unit, ntiles, n_units};
+  const uint64_t S = g_tile_near;
+  if (S == 0 || n_units >= ntiles || n_units % S != 0) return TileRun{unit, ntiles, n_units};  // (a forced grid is not whole groups: the far walk)
+  const uint64_t k = (ntiles + n_units - 1) / n_units;  // (whole groups were launched: n_units = ceil(ntiles / (k·S))·S gives the same k back)
+  const uint64_t grp = unit / S, first = grp * k * S;
+  const uint64_t end = first + k * S < ntiles ? first + k * S : ntiles;
+  return TileRun{first + unit % S, end, S};
 }
 
 static inline uint64_t tab_k(const agpu_pipeline* p, uint64_t dflt = 1) { return p->tune.table_tiles > 0 ? (uint64_t)p->tune.table_tiles : dflt; }
@@ -633,7 +656,7 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
         // auto: one or two tiles per block, whichever this device measures faster on these buffers (common.hpp, adaptive tiles)
         if (p->tune.heavy_tiles <= 0 && shape_ok) k = (int64_t)agpu_tiles_pick(p, AGPU_TILE_FAMILY_HEAVY, EwPrefetch<Op>::id, a, out, 2 * sizeof(T) * n, &tile_sample);
         if (k > 1 && shape_ok) {
-          const int g = stream_grid_for(p, (ntiles + (uint64_t)k - 1) / (uint64_t)k);
+          const int g = stream_grid_for(p, tile_units(ntiles, (uint64_t)k));
           hipLaunchKernelGGL((ew_prefetch_kernel<Op, U, AGPU_STREAM_NT>), dim3(g), dim3(AGPU_EW_BLOCK), 0, p->stream, pa, po, ntiles);
           done = true;
         }
@@ -913,7 +936,7 @@ static agpu_status launch_pow_f32(agpu_pipeline* p, const void* a, const void* b
       // tiles per block with the next tile prefetched (profiles/r04_prefetch_sweep*.json): array ∘ array is best at 1 (0.807 → 0.80 at 2); array ∘ scalar
       // 0.67–0.69 → 0.75–0.77 at 3 in every run
       const uint64_t tk = tab_k(p, MODE == MODE_SCALAR ? 3 : 1);
-      hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, (ntiles + tk - 1) / tk)), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
+      hipLaunchKernelGGL((pow_kernel<MODE>), dim3(stream_grid_for(p, tile_units(ntiles, tk))), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
                          ntiles, tab);
       done = ntiles * TILE_ROWS;
     }
@@ -988,7 +1011,7 @@ static agpu_status launch_log_f32(agpu_pipeline* p, const void* a, void* out, ui
     if (ntiles) {
       agpu_tile_sample tile_sample;
       const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LOG, 0, a, out, 8 * n, &tile_sample);
-      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, (ntiles + tk - 1) / tk)), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
+      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, tile_units(ntiles, tk))), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
                          static_cast<const PowTab*>(p->dev->pow_table));
       agpu_tiles_done(p, &tile_sample);
       done = ntiles * TILE_ROWS;
@@ -1366,7 +1389,8 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
         const uint64_t k = p->tune.cast_tiles > 0 ? (uint64_t)p->tune.cast_tiles
                                                   : agpu_tiles_pick(p, AGPU_TILE_FAMILY_CAST, (int)(sizeof(TI) * 16 + sizeof(TO)), in, out, (sizeof(TI) + sizeof(TO)) * n, &tile_sample);
         const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
-        const int grid = stream_grid_for(p, (blocks + k - 1) / k);
+        const int grid = tile_near_host() && k > 1 ? (int)((tile_units(nchunks, k) + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE))
+                                                   : stream_grid_for(p, (blocks + k - 1) / k);
         hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, po, nchunks);
         agpu_tiles_done(p, &tile_sample);
       }
@@ -1537,7 +1561,7 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
     if (ntiles) {
       agpu_tile_sample tile_sample;
       const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
-      const int grid = stream_grid_for(p, (ntiles + tk - 1) / tk);
+      const int grid = stream_grid_for(p, tile_units(ntiles, tk));
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, po, ntiles,
                          static_cast<const float*>(p->dev->lut8_tables) + 256 * Lut8Slot<TI, F>::value);
       agpu_tiles_done(p, &tile_sample);
@@ -1678,7 +1702,7 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
     if (ntiles) {
       agpu_tile_sample tile_sample;
       const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_TRIG16, 0, in, out, 6 * n, &tile_sample);
-      const dim3 grid(stream_grid_for(p, (ntiles + tk - 1) / tk));
+      const dim3 grid(stream_grid_for(p, tile_units(ntiles, tk)));
       if (blk == 1024) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 1024>), grid, dim3(1024), 0, p->stream, pi, po, ntiles, tab);
       else if (blk == 512) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 512>), grid, dim3(512), 0, p->stream, pi, po, ntiles, tab);
       else hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 256>), grid, dim3(256), 0, p->stream, pi, po, ntiles, tab);
@@ -2173,7 +2197,7 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
       const uint64_t ntiles = n / TILE_ROWS;
       agpu_tile_sample tile_sample;
       const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
-      const int grid = stream_grid_for(p, (ntiles + tk - 1) / tk);
+      const int grid = stream_grid_for(p, tile_units(ntiles, tk));
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, out, ntiles, static_cast<const float*>(tab));
       agpu_tiles_done(p, &tile_sample);
       if (ntiles * TILE_ROWS < n) {
@@ -2199,7 +2223,8 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
     // light chains: one chunk per wave (tile_run above); chains with a transcendental step are VALU-bound and gain in every run (0.53 → 0.61 at 8)
     const uint64_t kt = (uint64_t)(p->tune.cast_tiles > 0 ? p->tune.cast_tiles : (heavy ? 8 : 1));
     const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
-    const int grid = stream_grid_for(p, (blocks + kt - 1) / kt);
+    const int grid = tile_near_host() && kt > 1 ? (int)((tile_units(nchunks, kt) + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE))
+                                                 : stream_grid_for(p, (blocks + kt - 1) / kt);
 #define AGPU_CCHAIN_CASE(H, A)                                                                                              \
   if (heavy == H && slots == A)                                                                                             \
     hipLaunchKernelGGL((cast_chain_kernel<TI, H, A>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, out, nchunks, n_steps, \
