@@ -38,8 +38,9 @@ struct agpu_tuning {
   int64_t heavy_tiles;         // tiles per block of the VALU-heavy f32 unary kernels (sin / cos / sinh / log): the next tile's loads are issued before the current tile is evaluated (0 = auto)
   int64_t cast_tiles;          // chunks per wave of the widening casts and cast-headed chains, next chunk prefetched the same way (0 = auto)
   int64_t tile_auto;           // 0 = the "auto" of heavy_tiles / cast_tiles / table_tiles is ADAPTIVE for big launches (one or two tiles per block, whichever the device measures faster on these buffers: runtime.hip agpu_tiles_pick); 1 = static defaults (one tile); > 1 = adaptive with this many bytes as the threshold instead of 256 MiB (tests)
+  int64_t wave_lds;            // unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the ×2 / ×4 widening casts and the 8-bit table kernels: 0 = each kernel's measured default (6800 B ≈ 24 waves per CU; u8 → 32-bit casts 10240 B ≈ 16), < 0 = no cap, > 0 = this many bytes
 };
-#define AGPU_TUNE_KEYS 15
+#define AGPU_TUNE_KEYS 16
 agpu_tuning agpu_tuning_defaults();  // snapshot of the process-wide defaults (atomics, runtime.hip)
 bool agpu_mem_pool_enabled();        // process-wide "mem_pool" switch (device-level behaviour, not per pipeline)
 
@@ -293,6 +294,19 @@ struct agpu_call_scope {
 agpu_status agpu_scratch(agpu_pipeline* p, size_t bytes, void** out);
 void agpu_scope_label(agpu_pipeline* p, const char* label);
 
+
+// Occupancy caps (round 5, docs/experiments.md R5.5).  The VALU-heavy sin / cos, the widening casts and the LDS-table kernels of the 8-bit
+// sources run 3–9 % FASTER with fewer waves per CU than the 32 their registers allow (sin 0.80 → 0.83 of the roof, cos 0.79 → 0.835, u16 → f32
+// 0.81 → 0.845, sin_u8 0.74 → 0.81 at ≈ 24 waves; u8 → f32 0.79 → 0.81 at ≈ 16; four boxes, every process), while everything light or already
+// LDS-bound loses (add −1.5 %, compare −11 %, log −20 %).  The cap is unused dynamic LDS requested at launch — bytes per WAVE of the block.
+static inline unsigned wave_lds_for(const agpu_pipeline* p, unsigned dflt_bytes_per_wave, unsigned waves_per_block) {
+  const int64_t t = p->tune.wave_lds;
+  const unsigned per_wave = t > 0 ? (unsigned)(t > 65536 ? 65536 : t) : t < 0 ? 0u : dflt_bytes_per_wave;
+  const uint64_t total = (uint64_t)per_wave * waves_per_block;
+  return (unsigned)(total > 65536 ? 65536 : total);  // the default dynamic-LDS limit of a launch
+}
+#define AGPU_WAVE_LDS_24 6800u
+#define AGPU_WAVE_LDS_16 10240u
 
 // Grid for a streaming kernel that owns `tiles` block-tiles.  Measured on MI355X at 1e9 rows (profiles/
 // r01_sweep_add_f32_1e9.json): ONE tile per block beats every persistent grid (6.54 vs ≤6.52 TB/s at 32768 blocks,

@@ -41,33 +41,11 @@
 struct TileRun {
   uint64_t t, end, step;
 };
-// EXPERIMENT (round 5, AGPU_TILE_NEAR=S): the k tiles of a unit S tiles apart inside a window of k·S tiles instead of a grid apart —
-// the blocks in flight then cover ONE contiguous stretch of the column, as with one tile per block, only permuted at S-tile granularity.
-__device__ uint32_t g_tile_near = 0;
-static uint32_t tile_near_host() {
-  static const uint32_t s = [] {
-    const char* e = getenv("AGPU_TILE_NEAR");
-    const uint32_t v = e && *e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
-    if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_near), &v, sizeof v);
-    return v;
-  }();
-  return s;
-}
-// units a launch needs so that every tile is covered: whole groups of S units when the near walk is on
-static inline uint64_t tile_units(uint64_t tiles, uint64_t k) {
-  const uint64_t S = tile_near_host();
-  const uint64_t u = (tiles + k - 1) / k;
-  return (S && k > 1) ? (tiles + k * S - 1) / (k * S) * S : u;
-}
 __device__ __forceinline__ TileRun tile_run(uint64_t unit, uint64_t n_units, uint64_t ntiles) {
-  const uint64_t S = g_tile_near;
-  if (S == 0 || n_units >= ntiles || n_units % S != 0) return TileRun{unit, ntiles, n_units};  // (a forced grid is not whole groups: the far walk)
-  const uint64_t k = (ntiles + n_units - 1) / n_units;  // (whole groups were launched: n_units = ceil(ntiles / (k·S))·S gives the same k back)
-  const uint64_t grp = unit / S, first = grp * k * S;
-  const uint64_t end = first + k * S < ntiles ? first + k * S : ntiles;
-  return TileRun{first + unit % S, end, S};
+  return TileRun{unit, ntiles, n_units};
 }
-
+// units a launch needs for `tiles` tiles at k tiles per unit
+static inline uint64_t tile_units(uint64_t tiles, uint64_t k) { return (tiles + k - 1) / k; }
 static inline uint64_t tab_k(const agpu_pipeline* p, uint64_t dflt = 1) { return p->tune.table_tiles > 0 ? (uint64_t)p->tune.table_tiles : dflt; }
 
 #ifndef AGPU_STREAM_U
@@ -579,6 +557,7 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_prefetch_kernel(const float*
   }
 }
 template <typename Op> struct EwPrefetch { static constexpr bool value = false; static constexpr int tiles = 1; static constexpr int id = 0; };
+template <typename Op> struct EwWaveLds { static constexpr unsigned value = 0; };  // occupancy cap (common.hpp wave_lds_for): bytes per wave
 
 // rows [first, n): whole packs while they last, then single elements.  One small block; also serves tiny arrays.
 template <typename T, typename Op, int MODE>
@@ -613,6 +592,8 @@ template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };
 // tiles per block: 1 by default (see tile_run above: 3–4 tiles gain 4 % in lucky allocations — sin 0.785 → 0.82 — and lose 7 % in others)
+template <> struct EwWaveLds<UnSin> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };
+template <> struct EwWaveLds<UnCos> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };
 template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 1; };
 template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 2; };
 template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 3; };
@@ -657,14 +638,14 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
         if (p->tune.heavy_tiles <= 0 && shape_ok) k = (int64_t)agpu_tiles_pick(p, AGPU_TILE_FAMILY_HEAVY, EwPrefetch<Op>::id, a, out, 2 * sizeof(T) * n, &tile_sample);
         if (k > 1 && shape_ok) {
           const int g = stream_grid_for(p, tile_units(ntiles, (uint64_t)k));
-          hipLaunchKernelGGL((ew_prefetch_kernel<Op, U, AGPU_STREAM_NT>), dim3(g), dim3(AGPU_EW_BLOCK), 0, p->stream, pa, po, ntiles);
+          hipLaunchKernelGGL((ew_prefetch_kernel<Op, U, AGPU_STREAM_NT>), dim3(g), dim3(AGPU_EW_BLOCK), wave_lds_for(p, EwWaveLds<Op>::value, 1), p->stream, pa, po, ntiles);
           done = true;
         }
       }
       if (done) {
       } else if ((bits & 127u) == 0)
-        hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, AGPU_STREAM_NT, BLK>), dim3(grid), dim3(BLK), 0, p->stream, pa, pb,
-                           po, ntiles);
+        hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, AGPU_STREAM_NT, BLK>), dim3(grid), dim3(BLK),
+                           EwWaveLds<Op>::value ? wave_lds_for(p, EwWaveLds<Op>::value, BLK / AGPU_WAVE) : 0u, p->stream, pa, pb, po, ntiles);
       else
         hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, 4, BLK>), dim3(grid), dim3(BLK), 0, p->stream, pa, pb, po, ntiles);
       agpu_tiles_done(p, &tile_sample);
@@ -1389,9 +1370,11 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
         const uint64_t k = p->tune.cast_tiles > 0 ? (uint64_t)p->tune.cast_tiles
                                                   : agpu_tiles_pick(p, AGPU_TILE_FAMILY_CAST, (int)(sizeof(TI) * 16 + sizeof(TO)), in, out, (sizeof(TI) + sizeof(TO)) * n, &tile_sample);
         const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
-        const int grid = tile_near_host() && k > 1 ? (int)((tile_units(nchunks, k) + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE))
-                                                   : stream_grid_for(p, (blocks + k - 1) / k);
-        hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, po, nchunks);
+        const int grid = stream_grid_for(p, (blocks + k - 1) / k);
+        // occupancy cap (common.hpp): ×2 casts to 32 bits ≈ 24 waves per CU, ×4 ≈ 16; u8 → u16 none (not measured to gain)
+        constexpr unsigned cap = sizeof(TO) == 4 ? (sizeof(TI) == 2 ? AGPU_WAVE_LDS_24 : AGPU_WAVE_LDS_16) : 0u;
+        hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_CVTW_BLOCK), cap ? wave_lds_for(p, cap, AGPU_CVTW_BLOCK / AGPU_WAVE) : 0u,
+                           p->stream, pi, po, nchunks);
         agpu_tiles_done(p, &tile_sample);
       }
       if (nchunks * chunk_rows < n)
@@ -1562,7 +1545,7 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
       agpu_tile_sample tile_sample;
       const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
       const int grid = stream_grid_for(p, tile_units(ntiles, tk));
-      hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, po, ntiles,
+      hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), wave_lds_for(p, AGPU_WAVE_LDS_24, AGPU_LUT8_BLOCK / AGPU_WAVE), p->stream, pi, po, ntiles,
                          static_cast<const float*>(p->dev->lut8_tables) + 256 * Lut8Slot<TI, F>::value);
       agpu_tiles_done(p, &tile_sample);
       done = ntiles * TILE_ROWS;
@@ -2198,7 +2181,8 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
       agpu_tile_sample tile_sample;
       const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
       const int grid = stream_grid_for(p, tile_units(ntiles, tk));
-      hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), 0, p->stream, pi, out, ntiles, static_cast<const float*>(tab));
+      hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), wave_lds_for(p, AGPU_WAVE_LDS_24, AGPU_LUT8_BLOCK / AGPU_WAVE), p->stream, pi, out, ntiles,
+                         static_cast<const float*>(tab));
       agpu_tiles_done(p, &tile_sample);
       if (ntiles * TILE_ROWS < n) {
         const uint64_t rest = n - ntiles * TILE_ROWS;
@@ -2223,8 +2207,7 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
     // light chains: one chunk per wave (tile_run above); chains with a transcendental step are VALU-bound and gain in every run (0.53 → 0.61 at 8)
     const uint64_t kt = (uint64_t)(p->tune.cast_tiles > 0 ? p->tune.cast_tiles : (heavy ? 8 : 1));
     const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
-    const int grid = tile_near_host() && kt > 1 ? (int)((tile_units(nchunks, kt) + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE))
-                                                 : stream_grid_for(p, (blocks + kt - 1) / kt);
+    const int grid = stream_grid_for(p, (blocks + kt - 1) / kt);
 #define AGPU_CCHAIN_CASE(H, A)                                                                                              \
   if (heavy == H && slots == A)                                                                                             \
     hipLaunchKernelGGL((cast_chain_kernel<TI, H, A>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, out, nchunks, n_steps, \

@@ -33,7 +33,7 @@ static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
     /*stream_grid*/ {0}, /*stream_bpc*/ {0}, /*stream_unroll*/ {1}, /*stream_nt*/ {1}, /*cmp_variant*/ {0}, /*reduce_grid*/ {0},
     /*table_tiles*/ {0},  // 0 = each kernel's default (elementwise.hip tab_k: 1 for the HBM-bound table kernels, 3 for pow with a scalar exponent)
     /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}, /*gather_offsets*/ {0},
-    /*heavy_tiles*/ {0}, /*cast_tiles*/ {0}, /*tile_auto*/ {0}};
+    /*heavy_tiles*/ {0}, /*cast_tiles*/ {0}, /*tile_auto*/ {0}, /*wave_lds*/ {0}};
 // DEV SWITCH (tools/probe, docs/experiments.md R5): AGPU_DEVICE_MALLOC_FLAGS=<hipExtMallocWithFlags flags> makes every block the
 // pool, the arenas and the tables take from the driver a hipDeviceMallocContiguous (4) / Uncached (3) / Finegrained (1) one.
 // Unset or 0 = plain hipMalloc, which is what the product ships with.
@@ -46,7 +46,7 @@ static std::atomic<int64_t> g_pool_arena{1};  // 1 = pool blocks of ≥ 1 GiB co
 static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "stream_bpc", "stream_unroll", "stream_nt",
                                                          "cmp_variant", "reduce_grid", "table_tiles", "gather_bucket",
                                                          "h2d_mode", "h2d_threads", "gather_region_bits", "gather_offsets",
-                                                         "heavy_tiles", "cast_tiles", "tile_auto"};
+                                                         "heavy_tiles", "cast_tiles", "tile_auto", "wave_lds"};
 
 agpu_tuning agpu_tuning_defaults() {
   agpu_tuning t;

@@ -239,12 +239,15 @@ agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, con
 
 /* Launch tuning (bench sweeps; defaults are the measured best).  key ∈ {"stream_grid","stream_bpc","stream_unroll",
  * "stream_nt","cmp_variant","reduce_grid","table_tiles","gather_bucket","gather_region_bits","gather_offsets","h2d_mode",
- * "h2d_threads","heavy_tiles","cast_tiles","tile_auto"}; unknown key → AGPU_ERR_ARG.  heavy_tiles / cast_tiles / table_tiles: tiles per block of the
+ * "h2d_threads","heavy_tiles","cast_tiles","tile_auto","wave_lds"}; unknown key → AGPU_ERR_ARG.  heavy_tiles / cast_tiles / table_tiles: tiles per block of the
  * VALU-heavy f32 unary kernels / chunks per wave of the widening casts / tiles per block of the LDS-table kernels, the next one's loads issued
  * before the current one is evaluated; 0 = auto.  tile_auto: 0 (default) = for launches that move >= 256 MiB "auto" is ADAPTIVE — one or two
  * tiles per block, whichever the device measured faster on these buffers (eight timed launches per kernel, size class and buffer
  * region, re-measured every 1024 launches; which of the two wins follows what the driver backed the buffers with and cannot be predicted
- * from addresses: docs/experiments.md R5.4); 1 = static defaults; a value > 1 = adaptive with that many bytes as the threshold (tests).  Results never depend on any of these.  gather_bucket: 0 = auto (size thresholds + the device-side locality probe), 1 = direct
+ * from addresses: docs/experiments.md R5.4); 1 = static defaults; a value > 1 = adaptive with that many bytes as the threshold (tests).  wave_lds: unused dynamic LDS
+ * per wave that caps the waves per CU of sin / cos f32, the widening casts to 32 bits and the 8-bit table kernels (0 = each kernel's measured
+ * default, ≈ 24 or 16 waves per CU instead of 32: +3–9 % on those kernels, docs/experiments.md R5.5; < 0 = no cap; > 0 = that many bytes).
+ * Results never depend on any of these.  gather_bucket: 0 = auto (size thresholds + the device-side locality probe), 1 = direct
  * kernels, 2 = bucketed pipelines whenever the shape qualifies, 3 = like 2 with the round-2 pair pipeline for takes, 4 = like 2 but with the probe (tests);
  * gather_offsets: range starts of the pair pipeline (1 = atomics, 2 = column scans for both passes, 3 = default, 6 = default with one atomic per range, 8 / 4 = round 3's partition / partition + gather passes).  Every pipeline carries its own copy: agpu_set_tuning changes the process default that pipelines
  * created AFTERWARDS start from (atomic, any thread), agpu_pipeline_set_tuning changes one pipeline only — a sweep on one

@@ -81,15 +81,17 @@ def test_every_walk_kernel_is_invariant_under_tiles_per_block(ctx, n):
                     assert np.array_equal(np.isnan(exp), np.isnan(got)) and np.array_equal(got[np.isinf(exp)], exp[np.isinf(exp)]), name
                     d = np.abs(got[fin].view(np.int32).astype(np.int64) - exp[fin].view(np.int32).astype(np.int64))
                     assert d.size == 0 or d.max() <= 1, (name, int(d.max()))
-                for k, grid in ((1, 0), (2, 0), (3, 0), (5, 0), (0, 7), (4, 3)):
+                for k, grid, lds in ((1, 0, 0), (2, 0, -1), (3, 0, 20000), (5, 0, 0), (0, 7, 4096), (4, 3, 0), (0, 0, -1), (0, 0, 70000)):
                     p.set_tuning(key, k)
                     p.set_tuning("stream_grid", grid)
+                    p.set_tuning("wave_lds", lds)  # the occupancy cap (round 5): any value, same results
                     capi.call("agpu_memset", h, vp(out), 0xEE, 4 * n + 16)
                     launch()
                     again = dev.retrive_data(out, 4 * n + 16, pipeline=p)
                     assert again.tobytes() == ref.tobytes(), (name, key, k, grid)
                 p.set_tuning("stream_grid", 0)
+                p.set_tuning("wave_lds", 0)
                 p.set_tuning(key, 0)
     finally:
-        for key in ("heavy_tiles", "cast_tiles", "table_tiles", "stream_grid"):
+        for key in ("heavy_tiles", "cast_tiles", "table_tiles", "stream_grid", "wave_lds"):
             p.set_tuning(key, 0)
