@@ -590,7 +590,8 @@ template <typename Op> struct EwUnroll { static constexpr int value = AGPU_STREA
 template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };  // re-checked after the round-2 trimming: 1 → −5 %, 3 → −5 %
 template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
-template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };
+template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };  // re-checked under the occupancy cap (round 5): 2 → −2 %, 1 → −10 %
+template <> struct EwWaveLds<UnSinh> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };  // 0.70–0.75 → 0.77 on a column in (−30, 30) (the exp path); flat where most rows overflow
 // tiles per block: 1 by default (see tile_run above: 3–4 tiles gain 4 % in lucky allocations — sin 0.785 → 0.82 — and lose 7 % in others)
 template <> struct EwWaveLds<UnSin> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };
 template <> struct EwWaveLds<UnCos> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };
