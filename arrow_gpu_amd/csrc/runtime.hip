@@ -1328,7 +1328,8 @@ static void tile_harvest_locked(agpu_device::TileEntry& e) {
 static constexpr int kTileSamples = 4;
 uint64_t agpu_tiles_pick(agpu_pipeline* p, int family, int kernel, const void* in, const void* out, uint64_t bytes, agpu_tile_sample* sample) {
   sample->entry = sample->slot = -1;
-  if (p->tune.tile_auto == 1 || p->capturing) return 1;
+  // (a wrapped foreign stream may be inside a capture of its owner's that this library cannot see: events recorded there are graph nodes)
+  if (p->tune.tile_auto == 1 || p->capturing || !p->owns_stream) return 1;
   if (bytes < (p->tune.tile_auto > 1 ? (uint64_t)p->tune.tile_auto : AGPU_TILE_AUTO_MIN_BYTES)) return 1;  // > 1: the threshold itself (tests)
   agpu_device* dev = p->dev;
   const uint64_t in_r = reinterpret_cast<uintptr_t>(in) >> 28, out_r = reinterpret_cast<uintptr_t>(out) >> 28;

@@ -118,6 +118,21 @@ def test_small_launches_are_left_alone_and_bursts_converge(ctx):
     assert checksum(dev, q, out, chk, 4 * n2) == ref
 
 
+def test_on_a_wrapped_foreign_stream_nothing_is_timed(ctx):
+    """a wrapped stream may be inside a capture of its owner's that the library cannot see"""
+    dev, p, u8, f, out, chk = ctx
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline
+
+    owner = ArrowComputePipeline(dev, "owner")           # stands in for the foreign owner of the stream
+    w = ArrowComputePipeline(dev, "wrapped", hip_stream=owner.stream())
+    before = entries(dev)
+    n4 = 7 << 24
+    for _ in range(10):
+        capi.call("agpu_cast", w._handle, capi.U8, capi.F32, vp(u8), vp(out), n4)
+        w.sync()
+    assert entries(dev) == before
+
+
 def test_inside_a_captured_graph_nothing_is_timed(ctx):
     dev, p, u8, f, out, chk = ctx
     from arrow_gpu_amd.gpu_utils import ArrowComputePipeline
