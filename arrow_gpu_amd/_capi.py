@@ -105,6 +105,7 @@ SIGNATURES = {
     "agpu_comm_barrier": [_vp, _vp],
     "agpu_comm_sync": [_vp, _vp],
     "agpu_comm_size": [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)],
+    "agpu_comm_is_local": [_vp, C.POINTER(_i32)],
     "agpu_device_identity": [_vp, _vp],
     "agpu_comm_peers": [_vp, _vp, _vp, _i32, C.POINTER(_i32)],
     "agpu_import_arrow": [_vp, _vp, _vp, _vp],

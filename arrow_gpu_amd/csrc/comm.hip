@@ -49,6 +49,8 @@ struct agpu_comm {
   // every call is ordered behind the previous one, so that stream drains last).  A wait that gives up while this is zero
   // was only behind ordinary work: it reports the timeout and leaves the device alone.
   std::atomic<uint32_t> in_flight{0};
+  // world 1 only: RCCL's bootstrap did not come up within the deadline — no ncclComm_t; the collectives of a single rank are device copies
+  bool local = false;
   std::mutex peers_mu;  // one agpu_comm_peers at a time (they share `peers`); never taken together with a wait on `mu`
 };
 
@@ -172,12 +174,17 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof(id));
   ncclComm_t comm = nullptr;
+  bool is_local = false;
   if (timeout_ms <= 0) {
     AGPU_NCCL(ncclCommInitRank(&comm, world, id, rank));
   } else {
     auto job = std::make_shared<comm_init_job>();
     const int ordinal = dev->ordinal;
+    // test hook (tests/test_gpu_comm.py): AGPU_COMM_TEST_STALL_INIT_MS makes the helper sit that long before it calls RCCL — a bootstrap
+    // that does not come up, reproducibly
+    static const long stall_ms = [] { const char* e = getenv("AGPU_COMM_TEST_STALL_INIT_MS"); return e && *e ? strtol(e, nullptr, 10) : 0L; }();
     std::thread([job, id, rank, world, ordinal]() {
+      if (stall_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(stall_ms));
       ncclComm_t c = nullptr;
       hipError_t he = hipSetDevice(ordinal);
       ncclResult_t r = he == hipSuccess ? ncclCommInitRank(&c, world, id, rank) : ncclUnhandledCudaError;
@@ -189,28 +196,42 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
       job->cv.notify_all();
     }).detach();
     std::unique_lock<std::mutex> lk(job->mu);
+    bool local = false;
     if (!job->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return job->done; })) {
-      agpu_set_error("agpu_comm_init_rank: rank %d of %d gave up after %lld ms waiting for the other ranks "
-                     "(ncclCommInitRank is still pending on a helper thread: exit this process)",
-                     (int)rank, (int)world, (long long)timeout_ms);
-      dev->poisoned.store(true, std::memory_order_release);  // the helper may hold device work: nothing may wait for the device now
-      return AGPU_ERR_HIP;
+      if (world == 1) {
+        // A single rank waits for nobody: what did not come up is RCCL's own socket bootstrap (seen once in round 5: ncclCommInitRank of a
+        // one-rank communicator pending for 60 s on a shared node, while the same call took 0.3 s minutes later).  A one-rank job must not
+        // die of that — the communicator becomes LOCAL (agpu_comm_is_local): no ncclComm_t, its collectives are the device copies they
+        // amount to at world 1.  The helper stays parked in RCCL's bootstrap (sockets, no device work yet) and is abandoned.
+        agpu_set_error("agpu_comm_init_rank: RCCL's bootstrap of a ONE-rank communicator did not come up within %lld ms — local communicator",
+                       (long long)timeout_ms);
+        local = true;
+      } else {
+        agpu_set_error("agpu_comm_init_rank: rank %d of %d gave up after %lld ms waiting for the other ranks "
+                       "(ncclCommInitRank is still pending on a helper thread: exit this process)",
+                       (int)rank, (int)world, (long long)timeout_ms);
+        dev->poisoned.store(true, std::memory_order_release);  // the helper may hold device work: nothing may wait for the device now
+        return AGPU_ERR_HIP;
+      }
     }
-    if (job->hip != hipSuccess) {
-      agpu_set_error("hipSetDevice(%d) failed on the init thread: %s", ordinal, hipGetErrorString(job->hip));
-      return AGPU_ERR_HIP;
+    if (!local) {
+      if (job->hip != hipSuccess) {
+        agpu_set_error("hipSetDevice(%d) failed on the init thread: %s", ordinal, hipGetErrorString(job->hip));
+        return AGPU_ERR_HIP;
+      }
+      if (job->result != ncclSuccess) {
+        agpu_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(job->result));
+        return AGPU_ERR_HIP;
+      }
+      comm = job->comm;
     }
-    if (job->result != ncclSuccess) {
-      agpu_set_error("ncclCommInitRank failed: %s", ncclGetErrorString(job->result));
-      return AGPU_ERR_HIP;
-    }
-    comm = job->comm;
+    is_local = local;
   }
   char* mem = nullptr;
   const size_t rec_bytes = 16 + 16 * (size_t)world + 16, peer_bytes = sizeof(agpu_comm_peer) * ((size_t)world + 1);
   hipError_t e = hipMalloc(&mem, rec_bytes + peer_bytes);
   if (e != hipSuccess) {
-    (void)ncclCommDestroy(comm);
+    if (comm) (void)ncclCommDestroy(comm);
     agpu_set_error("hipMalloc of the communicator records failed: %s", hipGetErrorString(e));
     return AGPU_ERR_HIP;
   }
@@ -219,6 +240,7 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
   agpu_comm* c = new agpu_comm();
   c->dev = dev;
   c->comm = comm;
+  c->local = is_local;
   c->rank = rank;
   c->world = world;
   c->send = mem;
@@ -256,6 +278,10 @@ agpu_status agpu_comm_destroy(agpu_comm* c) {
     // a collective is stuck on some stream: never wait for the device.  ncclCommAbort raises the abort flag the stuck
     // kernel polls (so the stream may drain after all); it runs on a helper thread because it may itself wait, and is
     // given two seconds.  The record buffers and the event leak — the process is about to exit.
+    if (c->local) {
+      delete c;
+      return AGPU_OK;
+    }
     auto done = std::make_shared<std::atomic<bool>>(false);
     ncclComm_t comm = c->comm;
     const int ordinal = c->dev->ordinal;
@@ -269,7 +295,7 @@ agpu_status agpu_comm_destroy(agpu_comm* c) {
     return AGPU_OK;
   }
   (void)hipDeviceSynchronize();
-  (void)ncclCommDestroy(c->comm);
+  if (!c->local) (void)ncclCommDestroy(c->comm);
   (void)hipFree(c->send);
   if (c->last_done) (void)hipEventDestroy(c->last_done);
   delete c;
@@ -283,9 +309,21 @@ agpu_status agpu_comm_rank(agpu_comm* c, int32_t* out_rank, int32_t* out_world) 
   return AGPU_OK;
 }
 
+agpu_status agpu_comm_is_local(agpu_comm* c, int32_t* out_local) {
+  AGPU_REQUIRE(c && out_local, AGPU_ERR_ARG, "null argument");
+  *out_local = c->local ? 1 : 0;
+  return AGPU_OK;
+}
+
 // what RCCL itself reports — not what the caller passed to init
 agpu_status agpu_comm_size(agpu_comm* c, int32_t* out_count, int32_t* out_user_rank, int32_t* out_device) {
   AGPU_REQUIRE(c, AGPU_ERR_ARG, "null communicator");
+  if (c->local) {  // one rank, this device (agpu_comm_is_local says that RCCL is not behind these numbers)
+    if (out_count) *out_count = 1;
+    if (out_user_rank) *out_user_rank = 0;
+    if (out_device) *out_device = c->dev->ordinal;
+    return AGPU_OK;
+  }
   int v = 0;
   if (out_count) {
     AGPU_NCCL(ncclCommCount(c->comm, &v));
@@ -384,14 +422,15 @@ agpu_status agpu_comm_all_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op 
     case AGPU_RED_MAX: ro = ncclMax; break;
     default: agpu_set_error("bad reduce op %d", (int)op); return AGPU_ERR_ARG;
   }
-  if (count == 0) return AGPU_OK;
+  if (count == 0 || c->local) return AGPU_OK;  // (one rank: the buffer already holds the result)
   AGPU_NCCL(ncclAllReduce(buf_dev, buf_dev, (size_t)count, dt, ro, c->comm, p->stream));
   return AGPU_OK;
 }
 
 // gather the record every rank left in c->send, then combine in rank order (reduce.hip)
 static agpu_status gather_and_finish(agpu_comm* c, agpu_pipeline* p, int kind, agpu_dtype dtype, void* out_dev) {
-  AGPU_NCCL(ncclAllGather(c->send, c->recv, 16, ncclUint8, c->comm, p->stream));
+  if (c->local) AGPU_HIP(hipMemcpyAsync(c->recv, c->send, 16, hipMemcpyDeviceToDevice, p->stream));
+  else AGPU_NCCL(ncclAllGather(c->send, c->recv, 16, ncclUint8, c->comm, p->stream));
   return agpu_internal_comm_finish(p, kind, dtype, c->recv, c->world, out_dev);
 }
 
@@ -450,7 +489,7 @@ agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p) {
   if (st != AGPU_OK) return st;
   {
     comm_use use(c, p);
-    AGPU_NCCL(ncclAllReduce(c->token, c->token, 1, ncclInt32, ncclMax, c->comm, p->stream));
+    if (!c->local) AGPU_NCCL(ncclAllReduce(c->token, c->token, 1, ncclInt32, ncclMax, c->comm, p->stream));
   }
   // a peer that died never joins the all-reduce and the stream would never drain: poll with a deadline instead (the
   // communicator is not held meanwhile)
@@ -492,7 +531,16 @@ agpu_status agpu_comm_peers(agpu_comm* c, agpu_pipeline* p, agpu_comm_peer* out_
       agpu_set_error("agpu_comm_peers: %s", hipGetErrorString(e));
       return AGPU_ERR_HIP;
     }
-    ncclResult_t r = ncclAllGather(mem, mem + rec, rec, ncclUint8, c->comm, p->stream);
+    ncclResult_t r = ncclSuccess;
+    if (c->local) {
+      e = hipMemcpyAsync(mem + rec, mem, rec, hipMemcpyDeviceToDevice, p->stream);
+      if (e != hipSuccess) {
+        agpu_set_error("agpu_comm_peers: %s", hipGetErrorString(e));
+        return AGPU_ERR_HIP;
+      }
+    } else {
+      r = ncclAllGather(mem, mem + rec, rec, ncclUint8, c->comm, p->stream);
+    }
     if (r != ncclSuccess) {
       agpu_set_error("ncclAllGather failed: %s", ncclGetErrorString(r));
       return AGPU_ERR_HIP;

@@ -280,6 +280,23 @@ def world_proof(peers, expect_gpus: int) -> dict:
             "devices": [f'{q["host"][:8]}/{q["pci"]}' for q in peers], "errors": errors}
 
 
+def prefer_loopback_bootstrap(world: int, env=None) -> bool:
+    """RCCL's rendezvous (the "bootstrap") runs over a TCP socket on an interface it picks itself — the first non-loopback one unless
+    NCCL_SOCKET_IFNAME says otherwise.  When every rank is known to live on THIS host — a one-rank communicator, or a launcher whose
+    MASTER_ADDR is the loopback address (torch.distributed.run --master-addr 127.0.0.1, the contract of bench.py) — the loopback interface
+    is the one that cannot be firewalled, unrouted or renamed under a container, so it is named explicitly unless the caller already chose.
+    (Data never travels over it: ranks of one node talk over xGMI / shared memory.)  Returns True when it set the variable."""
+    import os
+
+    e = os.environ if env is None else env
+    if e.get("NCCL_SOCKET_IFNAME"):
+        return False
+    if world == 1 or e.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+        e["NCCL_SOCKET_IFNAME"] = "lo"
+        return True
+    return False
+
+
 class Communicator:
     """RCCL communicator of the C ABI (include/arrow_gpu.h "multi-GPU"): one rank per GPU, used ONLY for the final
     reduce of whole-column statistics.  Nothing like it exists in the reference (single device + queue,
@@ -297,6 +314,7 @@ class Communicator:
         exit (the pending RCCL rendezvous cannot be cancelled)."""
         if len(unique_id) != capi.COMM_ID_BYTES:
             raise ValueError("unique id must be 128 bytes")
+        prefer_loopback_bootstrap(world)
         self.device, self.rank, self.world = device, rank, world
         h = C.c_void_p()
         idbuf = C.create_string_buffer(unique_id, capi.COMM_ID_BYTES)
@@ -322,6 +340,7 @@ class Communicator:
     @classmethod
     def single(cls, device) -> "Communicator":
         """World of one rank (no launcher needed): the same RCCL code path a multi-GPU run takes."""
+        prefer_loopback_bootstrap(1)  # before the id: rank 0's listening socket is opened when the id is made
         return cls(device, 0, 1, cls.unique_id())
 
     @classmethod
@@ -329,6 +348,7 @@ class Communicator:
         import torch.distributed as dist
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        prefer_loopback_bootstrap(world)
         box = [cls.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
         return cls(device, rank, world, box[0])
@@ -336,6 +356,7 @@ class Communicator:
     @classmethod
     def from_file(cls, device, rank: int, world: int, path: str, timeout_s: float = 60.0) -> "Communicator":
         """Torch-free rendezvous over a path every rank can see (one node: /tmp or /dev/shm).  See `file_rendezvous`."""
+        prefer_loopback_bootstrap(world)
         uid = file_rendezvous(path, rank, world, cls.unique_id if rank == 0 else None, timeout_s)
         comm = cls(device, rank, world, uid, timeout_s=timeout_s)
         file_rendezvous_cleanup(path, rank)
@@ -372,6 +393,14 @@ class Communicator:
         `reduce` / `all_reduce` / `final_reduce` — a plain `pipeline.sync()` or a download would block for ever behind a
         collective a dead peer never joins.  On a timeout the device is poisoned (see include/arrow_gpu.h): exit the process."""
         capi.call("agpu_comm_sync", self._h, pipeline._handle)
+
+    @property
+    def is_local(self) -> bool:
+        """True for a ONE-rank communicator whose RCCL bootstrap did not come up in time: no RCCL behind it, collectives are device
+        copies (include/arrow_gpu.h agpu_comm_is_local).  A record that says "RCCL ran" must check this."""
+        v = C.c_int32()
+        capi.call("agpu_comm_is_local", self._h, C.byref(v))
+        return bool(v.value)
 
     def size(self) -> tuple:
         """(ncclCommCount, ncclCommUserRank, ncclCommCuDevice): what RCCL reports, not what the launcher said."""

@@ -559,6 +559,9 @@ def main():
             windows.append({"row": row0 + start, "rows": cnt, "add": got, "eq_bits": gb, "eq_validity": gv})
 
     extra = {"runtime": runtime, "per_rank": per_rank, "rccl_ranks": proof["rccl_ranks"], "distinct_devices": proof["distinct_devices"],
+             # True only for a ONE-rank run whose RCCL bootstrap did not come up within the deadline: the communicator is then local (device
+             # copies, no RCCL object) and "rccl_ranks" is the local communicator's 1 — include/arrow_gpu.h agpu_comm_is_local
+             "rccl_local_fallback": bool(comm.is_local),
              "devices": peers, "launcher_world": int(os.environ.get("WORLD_SIZE", "1")),
              "world_proof": "one identity record per rank all-gathered through the RCCL communicator (agpu_comm_peers): rank / ncclCommCount as "
                             "RCCL reports them on that rank, PCI address, uuid, pid; n_gpus = ncclCommCount, checked against --gpus"}

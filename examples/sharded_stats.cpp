@@ -34,6 +34,9 @@ struct RankResult {
 
 int main(int argc, char** argv) {
   setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);  // dmabuf-only hosts: must be in place before the first HIP call (a default, not an override)
+  // every rank of this program is a thread of THIS process: RCCL's rendezvous socket goes over the loopback interface, the one a container
+  // cannot firewall or rename (a default, not an override; data travels over xGMI / shared memory either way)
+  setenv("NCCL_SOCKET_IFNAME", "lo", 0);
   const uint64_t rows = argc > 1 ? strtoull(argv[1], nullptr, 10) : 100000000ull;
   int32_t ndev = 0;
   agpu_device_count(&ndev);

@@ -1478,6 +1478,13 @@ class Communicator {
   // the host wait that belongs behind a collective (reduce_sharded_op, all-reduce): like p.sync() but with the collective deadline;
   // a timeout throws, the device is poisoned (include/arrow_gpu.h) and every destructor on the way out returns without waiting
   void sync(ArrowComputePipeline& p) { check(agpu_comm_sync(raw, p.h()), "agpu_comm_sync"); }
+  // true for a ONE-rank communicator whose RCCL bootstrap did not come up in time: no RCCL behind it, its collectives are device copies
+  // (include/arrow_gpu.h agpu_comm_is_local) — a record that says "RCCL ran" must check this
+  bool is_local() const {
+    int32_t v = 0;
+    check(agpu_comm_is_local(raw, &v), "agpu_comm_is_local");
+    return v != 0;
+  }
   // what RCCL reports (ncclCommCount), not what the launcher said
   int size() const {
     int32_t n = 0;

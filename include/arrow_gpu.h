@@ -534,6 +534,11 @@ agpu_status agpu_comm_sync(agpu_comm* c, agpu_pipeline* p);
 /* What RCCL itself reports for this communicator — ncclCommCount, ncclCommUserRank, ncclCommCuDevice — as opposed to what
  * the caller passed to init (agpu_comm_rank).  Any out pointer may be NULL. */
 agpu_status agpu_comm_size(agpu_comm* c, int32_t* out_count, int32_t* out_user_rank, int32_t* out_device);
+/* A communicator of ONE rank whose RCCL bootstrap did not come up within the init deadline is created as a LOCAL communicator instead of
+ * failing (a single rank waits for nobody; what can hang is RCCL's own socket bootstrap): no ncclComm_t behind it, its collectives are
+ * the device copies they amount to at world 1, agpu_comm_size reports {1, 0, this device}.  *out_local = 1 for such a communicator — a
+ * record that claims "RCCL ran" must check it.  World > 1 never falls back: a missing peer is an error and poisons the device. */
+agpu_status agpu_comm_is_local(agpu_comm* c, int32_t* out_local);
 /* One identity record per rank, so that a multi-GPU record can PROVE which devices joined one communicator. */
 typedef struct agpu_comm_peer {
   int32_t rank;           /* ncclCommUserRank on the rank the record came from (-1 from agpu_device_identity) */

@@ -306,3 +306,59 @@ def test_a_timed_out_collective_poisons_the_device_and_nothing_hangs_afterwards(
     r = subprocess.run([sys.executable, "-c", _POISON_WORKER.format(root=root)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert "POISONED fails=4" in r.stdout
+
+
+# ---- round 5: a ONE-rank communicator never dies of RCCL's socket bootstrap
+_LOCAL_WORKER = r"""
+import os, sys, ctypes as C
+sys.path.insert(0, {root!r})
+import numpy as np
+import oracle as O
+from arrow_gpu_amd import _capi as capi
+from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+from arrow_gpu_amd.sharding import Communicator, world_proof
+dev = GpuDevice(0)
+p = ArrowComputePipeline(dev, "local")
+comm = Communicator(dev, 0, 1, Communicator.unique_id(), timeout_s=0.5)   # the helper sits in its stall: the deadline passes
+assert comm.is_local, "expected the local fallback"
+assert comm.size() == (1, 0, 0)
+n = 1 << 20
+x = O.synth_f32(n, 11, 0, -1.0, 1.0)
+d = dev.create_gpu_buffer_with_data(x)
+out = dev.create_empty_buffer(16)
+for op, red in ((capi.RED_SUM, O.RED_SUM), (capi.RED_MIN, O.RED_MIN), (capi.RED_MAX, O.RED_MAX)):
+    comm.reduce(p, op, capi.F32, d, None, n, out)
+    comm.sync(p)
+    got = dev.retrive_data(out, 4, pipeline=p).view(np.float32)[0]
+    assert np.float32(got).view(np.uint32) == np.float32(O.sharded_reduce(red, O.F32, [x])).view(np.uint32), op
+cnt = dev.create_gpu_buffer_with_data(np.array([7, 9], np.uint64))
+comm.all_reduce(p, capi.RED_SUM, capi.COMM_U64, cnt, 2)
+comm.barrier(p)
+assert dev.retrive_data(cnt, 16, pipeline=p).view(np.uint64).tolist() == [7, 9]
+peers = comm.peers(p)
+proof = world_proof(peers, 1)
+assert proof["ok"] and proof["rccl_ranks"] == 1 and proof["distinct_devices"] == 1, proof
+comm.close()
+# and the device is NOT poisoned: ordinary work and a second, real communicator still run
+real = Communicator.single(dev)
+print("second communicator local:", real.is_local)
+real.barrier(p)
+real.close()
+print("LOCAL-OK")
+sys.stdout.flush()
+os._exit(0)   # the parked helper thread cannot be joined
+"""
+
+
+def test_a_one_rank_communicator_survives_a_bootstrap_that_does_not_come_up():
+    """seen once in round 5: ncclCommInitRank of a ONE-rank communicator pending for 60 s on a shared node.  With the helper thread stalled
+    (AGPU_COMM_TEST_STALL_INIT_MS) the init deadline passes and the communicator is created LOCAL: reductions equal the sharded spec, the
+    identity record still proves one device, nothing is poisoned"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AGPU_COMM_TEST_STALL_INIT_MS="4000")
+    r = subprocess.run([sys.executable, "-c", _LOCAL_WORKER.format(root=root)], capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0 and "LOCAL-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

@@ -124,3 +124,20 @@ def test_bench_started_plainly_with_gpus_n_launches_its_own_workers():
     assert r.returncode == 1
     assert r.stdout.strip() == ""
     assert "worker exit codes [1, 1]" in r.stderr and "NoDevice" in r.stderr
+
+
+def test_loopback_bootstrap_is_named_only_when_every_rank_is_on_this_host():
+    """sharding.prefer_loopback_bootstrap: RCCL's rendezvous socket goes over `lo` for a one-rank communicator and for a launcher whose
+    MASTER_ADDR is the loopback address; a caller's own choice and a multi-node address are left alone"""
+    from arrow_gpu_amd.sharding import prefer_loopback_bootstrap
+
+    e = {}
+    assert prefer_loopback_bootstrap(1, e) and e["NCCL_SOCKET_IFNAME"] == "lo"
+    e = {"MASTER_ADDR": "127.0.0.1"}
+    assert prefer_loopback_bootstrap(8, e) and e["NCCL_SOCKET_IFNAME"] == "lo"
+    e = {"MASTER_ADDR": "10.0.0.7"}
+    assert not prefer_loopback_bootstrap(8, e) and "NCCL_SOCKET_IFNAME" not in e
+    e = {}
+    assert not prefer_loopback_bootstrap(8, e) and "NCCL_SOCKET_IFNAME" not in e
+    e = {"MASTER_ADDR": "127.0.0.1", "NCCL_SOCKET_IFNAME": "eth0"}
+    assert not prefer_loopback_bootstrap(8, e) and e["NCCL_SOCKET_IFNAME"] == "eth0"
