@@ -175,6 +175,8 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
   memcpy(&id, unique_id, sizeof(id));
   ncclComm_t comm = nullptr;
   bool is_local = false;
+  // a one-rank communicator waits for nobody: its bootstrap takes a fraction of a second or is not going to come up — 20 s at most
+  if (world == 1 && timeout_ms > 20000) timeout_ms = 20000;
   if (timeout_ms <= 0) {
     AGPU_NCCL(ncclCommInitRank(&comm, world, id, rank));
   } else {
