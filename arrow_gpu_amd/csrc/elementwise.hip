@@ -587,8 +587,11 @@ __global__ __launch_bounds__(AGPU_BLOCK) void ew_kernel_unaligned(const T* a, co
 }
 
 template <typename Op> struct EwUnroll { static constexpr int value = AGPU_STREAM_U; };
-template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };  // re-checked after the round-2 trimming: 1 → −5 %, 3 → −5 %
-template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };
+#ifndef AGPU_SINCOS_U
+#define AGPU_SINCOS_U 2
+#endif
+template <> struct EwUnroll<UnSin> { static constexpr int value = AGPU_SINCOS_U; };  // re-checked after the round-2 trimming: 1 → −5 %, 3 → −5 %
+template <> struct EwUnroll<UnCos> { static constexpr int value = AGPU_SINCOS_U; };
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };  // re-checked under the occupancy cap (round 5): 2 → −2 %, 1 → −10 %
 template <> struct EwWaveLds<UnSinh> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };  // 0.70–0.75 → 0.77 on a column in (−30, 30) (the exp path); flat where most rows overflow
@@ -671,13 +674,15 @@ __device__ __forceinline__ T shift_one(T x, uint32_t sh) {
   else if constexpr (std::is_signed<T>::value) return (T)((int32_t)x >> sh);
   else return (T)((uint32_t)x >> sh);
 }
-// sub-word columns: 4 rows per lane per step — one 16-byte load of amounts, one 4/8-byte load and store of values
-template <typename T, bool LEFT, int MODE>
-__global__ __launch_bounds__(AGPU_BLOCK) void shift_kernel(const T* a, const uint32_t* s, T* out, uint64_t n, int vec_ok) {
+// sub-word columns: 4 rows per lane per step — one 16-byte load of amounts, one 4/8-byte load and store of values.
+// One-wave blocks (round 5: the streaming kernels' shape; 256-thread blocks measured 0.75 / 0.78 of the roof for u8 / u16, tuning
+// stream_unroll = 256 brings them back for the A/B)
+template <typename T, bool LEFT, int MODE, int BLK>
+__global__ __launch_bounds__(BLK) void shift_kernel(const T* a, const uint32_t* s, T* out, uint64_t n, int vec_ok) {
   uint32_t sv = 0;
   if constexpr (MODE == MODE_SCALAR) sv = s[0] & 31u;
-  const uint64_t tid = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * AGPU_BLOCK;
+  const uint64_t tid = (uint64_t)blockIdx.x * BLK + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * BLK;
   const uint64_t npacks = vec_ok ? n / 4 : 0;
   for (uint64_t pk = tid; pk < npacks; pk += stride) {
     const PackN<T, 4> x = load_pack<true, T, 4>(a + pk * 4);
@@ -697,13 +702,20 @@ template <typename T, int MODE>
 static agpu_status launch_shift(agpu_pipeline* p, bool left, const void* a, const void* s, void* out, uint64_t n) {
   if (n == 0) return AGPU_OK;
   const int vec_ok = aligned_to(a, 4 * sizeof(T)) && aligned_to(out, 4 * sizeof(T)) && (MODE == MODE_SCALAR || aligned16(s));
-  const int grid = stream_grid_for(p, (n / 4 + AGPU_BLOCK) / AGPU_BLOCK);
-  if (left)
-    hipLaunchKernelGGL((shift_kernel<T, true, MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
-                       static_cast<const T*>(a), static_cast<const uint32_t*>(s), static_cast<T*>(out), n, vec_ok);
-  else
-    hipLaunchKernelGGL((shift_kernel<T, false, MODE>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream,
-                       static_cast<const T*>(a), static_cast<const uint32_t*>(s), static_cast<T*>(out), n, vec_ok);
+  const bool wide = p->tune.stream_unroll == 256;  // A/B: the 256-thread blocks of rounds 1–4
+  const uint64_t blk = wide ? AGPU_BLOCK : AGPU_WAVE;
+  const int grid = stream_grid_for(p, (n / 4 + blk) / blk);
+#define AGPU_SHIFT_LAUNCH(L, B)                                                                                       \
+  hipLaunchKernelGGL((shift_kernel<T, L, MODE, B>), dim3(grid), dim3(B), 0, p->stream, static_cast<const T*>(a), \
+                     static_cast<const uint32_t*>(s), static_cast<T*>(out), n, vec_ok)
+  if (left) {
+    if (wide) AGPU_SHIFT_LAUNCH(true, AGPU_BLOCK);
+    else AGPU_SHIFT_LAUNCH(true, AGPU_WAVE);
+  } else {
+    if (wide) AGPU_SHIFT_LAUNCH(false, AGPU_BLOCK);
+    else AGPU_SHIFT_LAUNCH(false, AGPU_WAVE);
+  }
+#undef AGPU_SHIFT_LAUNCH
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
 }
