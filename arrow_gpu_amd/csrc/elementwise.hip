@@ -587,11 +587,8 @@ __global__ __launch_bounds__(AGPU_BLOCK) void ew_kernel_unaligned(const T* a, co
 }
 
 template <typename Op> struct EwUnroll { static constexpr int value = AGPU_STREAM_U; };
-#ifndef AGPU_SINCOS_U
-#define AGPU_SINCOS_U 2
-#endif
-template <> struct EwUnroll<UnSin> { static constexpr int value = AGPU_SINCOS_U; };  // re-checked after the round-2 trimming: 1 → −5 %, 3 → −5 %
-template <> struct EwUnroll<UnCos> { static constexpr int value = AGPU_SINCOS_U; };
+template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };  // re-checked after the round-2 trimming: 1 → −5 %, 3 → −5 %; and under the
+template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };  // occupancy cap (round 5, profiles/r05_sincos_unroll_x_cap.txt): 2 @ 6800 B 0.83, 4 @ 10240 B 0.82, 1 @ 4200 B 0.80–0.81, 3 0.78
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };  // re-checked under the occupancy cap (round 5): 2 → −2 %, 1 → −10 %
 template <> struct EwWaveLds<UnSinh> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };  // 0.70–0.75 → 0.77 on a column in (−30, 30) (the exp path); flat where most rows overflow
