@@ -1364,6 +1364,14 @@ __global__ __launch_bounds__(AGPU_WAVE) void cvt_narrow_kernel(const TI* in, TO*
   }
 }
 
+// one small id per instantiation of the widening kernel: the adaptive tile policy keys its table by it (a plain cast and a cast fused with
+// sin want different answers)
+static std::atomic<int> g_cvt_tile_ids{0};
+template <typename TI, typename TO, typename Conv>
+static int cvt_tile_id() {
+  static const int id = (g_cvt_tile_ids.fetch_add(1) % 255) + 1;
+  return id;
+}
 template <typename TI, typename TO, typename Conv>
 static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
   if (n == 0) return AGPU_OK;
@@ -1378,7 +1386,7 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
         // chunks per wave (next chunk prefetched): 1 by default — 2 is +5 % in lucky allocations and −8 % in others (tile_run above)
         agpu_tile_sample tile_sample;
         const uint64_t k = p->tune.cast_tiles > 0 ? (uint64_t)p->tune.cast_tiles
-                                                  : agpu_tiles_pick(p, AGPU_TILE_FAMILY_CAST, (int)(sizeof(TI) * 16 + sizeof(TO)), in, out, (sizeof(TI) + sizeof(TO)) * n, &tile_sample);
+                                                  : agpu_tiles_pick(p, AGPU_TILE_FAMILY_CAST, cvt_tile_id<TI, TO, Conv>(), in, out, (sizeof(TI) + sizeof(TO)) * n, &tile_sample);
         const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
         const int grid = stream_grid_for(p, (blocks + k - 1) / k);
         // occupancy cap (common.hpp): ×2 casts to 32 bits ≈ 24 waves per CU, ×4 ≈ 16; u8 → u16 none (not measured to gain)
@@ -2315,6 +2323,24 @@ agpu_status agpu_fused_cast_chain(agpu_pipeline* p, agpu_dtype from, const void*
     return agpu_unary(p, (agpu_unary_op)steps[0].op, from, in, out, n);
   AGPU_BIND(p);
   if (n == 0) return AGPU_OK;
+  // cast → ONE transcendental step of a 16-bit column: the kernel SPECIALISED on the function (cvt_wide_kernel over CvtThenF32<TI, Op>: the
+  // same functor the chain would call, so the same bits) instead of the generic chain kernel, whose step interpreter costs a VALU-bound
+  // launch 10–15 % (round 5, tools/probe/chain_vs_special.py: cast i16 → sinh 1.22 → 1.05–1.11 ms at 1e9 rows)
+  if (n_steps == 1 && steps[0].kind == AGPU_CHAIN_UNARY && (from == AGPU_U16 || from == AGPU_I16)) {
+#define AGPU_CAST16_THEN(OPCODE, OP)                                                                                        \
+  case OPCODE:                                                                                                              \
+    return from == AGPU_U16 ? launch_cvt<uint16_t, float, CvtThenF32<uint16_t, OP>>(p, in, out, n)                          \
+                            : launch_cvt<int16_t, float, CvtThenF32<int16_t, OP>>(p, in, out, n);
+    switch (steps[0].op) {
+      AGPU_CAST16_THEN(AGPU_UN_SIN, UnSin)
+      AGPU_CAST16_THEN(AGPU_UN_COS, UnCos)
+      AGPU_CAST16_THEN(AGPU_UN_SINH, UnSinh)
+      AGPU_CAST16_THEN(AGPU_UN_EXP, UnExp)
+      AGPU_CAST16_THEN(AGPU_UN_LOG, UnLog)
+      default: break;
+    }
+#undef AGPU_CAST16_THEN
+  }
   ChainPtrs ptrs{};
   uint64_t code = 0;
   bool vec_ok = aligned16(in) && aligned16(out), heavy = false;

@@ -226,6 +226,8 @@ def test_cast_headed_chain_bit_identical_to_cast_then_ops(ag, kind, n):
         "sin": (lambda ch: ch.sin(), lambda x: x.sin()),
         "cos": (lambda ch: ch.cos(), lambda x: x.cos()),
         "sinh": (lambda ch: ch.sinh(), lambda x: x.sinh()),
+        "exp": (lambda ch: ch.exp(), lambda x: x.exp()),   # (16-bit sources: sin / cos / sinh / exp / log alone run the kernel specialised on the function)
+        "log": (lambda ch: ch.log(), lambda x: x.log()),
         "scale+offset": (lambda ch: ch.mul_scalar(s).add_scalar(o), lambda x: x.mul_scalar(s).add_scalar(o)),
         "scalars+heavy": (lambda ch: ch.mul_scalar(s).sin().abs().sqrt().neg(), lambda x: x.mul_scalar(s).sin().abs().sqrt().neg()),
         "arrays": (lambda ch: ch.mul(b).add(c).abs().sqrt(), lambda x: x.mul(b).add(c).abs().sqrt()),
