@@ -557,6 +557,9 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_prefetch_kernel(const float*
   }
 }
 template <typename Op> struct EwPrefetch { static constexpr bool value = false; static constexpr int tiles = 1; static constexpr int id = 0; };
+#ifndef AGPU_CHAIN_HEAVY_LDS
+#define AGPU_CHAIN_HEAVY_LDS 1u  // chains with a transcendental step: no cap by default (1 byte), tuning wave_lds forces one (tools/probe/chain_caps.py)
+#endif
 template <typename Op> struct EwWaveLds { static constexpr unsigned value = 0; };  // occupancy cap (common.hpp wave_lds_for): bytes per wave
 
 // rows [first, n): whole packs while they last, then single elements.  One small block; also serves tiny arrays.
@@ -1862,6 +1865,78 @@ __device__ __forceinline__ T chain_apply_unary(int op, T x) {
 // What bounds this kernel is bytes in flight: one-wave blocks with ONE 16-B load per lane and stream need every wave
 // slot of the CU (8 per SIMD ⇒ ≤ 64 VGPRs) to cover HBM latency.  The first version (one kernel for everything: 8 operand
 // packs + inlined sin/log/exp) needed 86 VGPRs ⇒ 5 waves/SIMD ⇒ 3.7 TB/s on an 8 B/row chain.  So the kernel is
+// The same two switches ONE LEVEL UP: over whole packs.  chain_apply_unary / _binary inside a `for k` loop put a copy of the op switch
+// behind every element — at 4 elements per pack that was 0.3 taken branches and 0.8 SALU instructions per ROW (rocprofv3, round 5:
+// a standalone sin issues 0.02 / 0.08), and a chain with a transcendental step ran at 0.59 of the roof where the standalone function does
+// 0.83.  Here the step's op is decided once per tile and the element loops live inside the case.
+#define AGPU_CHAIN_UN_CASE(CODE, F)                                                        \
+  case CODE:                                                                               \
+    static_for<U>([&](auto u) {                                                            \
+      _Pragma("unroll") for (int k = 0; k < N; k++) acc[u].v[k] = F::ap(acc[u].v[k], acc[u].v[k]); \
+    });                                                                                    \
+    return;
+template <typename T, bool HEAVY, int U, int N>
+__device__ __forceinline__ void chain_apply_unary_packs(int op, PackN<T, N> (&acc)[U]) {
+  if constexpr (std::is_floating_point<T>::value) {
+    switch (op) {
+      AGPU_CHAIN_UN_CASE(AGPU_UN_NEG, UnNeg)
+      AGPU_CHAIN_UN_CASE(AGPU_UN_ABS, UnAbs)
+      AGPU_CHAIN_UN_CASE(AGPU_UN_SQRT, UnSqrt)
+      default: break;
+    }
+    if constexpr (HEAVY) {
+      switch (op) {
+        AGPU_CHAIN_UN_CASE(AGPU_UN_CBRT, UnCbrt)
+        AGPU_CHAIN_UN_CASE(AGPU_UN_EXP, UnExp)
+        AGPU_CHAIN_UN_CASE(AGPU_UN_EXP2, UnExp2)
+        AGPU_CHAIN_UN_CASE(AGPU_UN_LOG, UnLog)
+        AGPU_CHAIN_UN_CASE(AGPU_UN_LOG2, UnLog2)
+        AGPU_CHAIN_UN_CASE(AGPU_UN_SIN, UnSin)
+        AGPU_CHAIN_UN_CASE(AGPU_UN_COS, UnCos)
+        AGPU_CHAIN_UN_CASE(AGPU_UN_ACOS, UnAcos)
+        AGPU_CHAIN_UN_CASE(AGPU_UN_SINH, UnSinh)
+        default: break;
+      }
+    }
+  } else {
+    switch (op) {
+      AGPU_CHAIN_UN_CASE(AGPU_UN_NEG, UnNeg)
+      AGPU_CHAIN_UN_CASE(AGPU_UN_ABS, UnAbs)
+      AGPU_CHAIN_UN_CASE(AGPU_UN_NOT, UnNot)
+      default: break;
+    }
+  }
+}
+#undef AGPU_CHAIN_UN_CASE
+#define AGPU_CHAIN_BIN_CASE(CODE, F)                                                      \
+  case CODE:                                                                              \
+    static_for<U>([&](auto u) {                                                           \
+      _Pragma("unroll") for (int k = 0; k < N; k++) acc[u].v[k] = F::ap(acc[u].v[k], y[u].v[k]); \
+    });                                                                                   \
+    return;
+template <typename T, int U, int N>
+__device__ __forceinline__ void chain_apply_binary_packs(int op, PackN<T, N> (&acc)[U], const PackN<T, N> (&y)[U]) {
+  switch (op) {
+    AGPU_CHAIN_BIN_CASE(AGPU_OP_ADD, OpAdd)
+    AGPU_CHAIN_BIN_CASE(AGPU_OP_SUB, OpSub)
+    AGPU_CHAIN_BIN_CASE(AGPU_OP_MUL, OpMul)
+    AGPU_CHAIN_BIN_CASE(AGPU_OP_DIV, OpDiv)
+    AGPU_CHAIN_BIN_CASE(AGPU_OP_REM, OpRem)
+    AGPU_CHAIN_BIN_CASE(AGPU_OP_MIN, OpMin)
+    AGPU_CHAIN_BIN_CASE(AGPU_OP_MAX, OpMax)
+    default: break;
+  }
+  if constexpr (!std::is_floating_point<T>::value) {
+    switch (op) {
+      AGPU_CHAIN_BIN_CASE(AGPU_OP_AND, OpAnd)
+      AGPU_CHAIN_BIN_CASE(AGPU_OP_OR, OpOr)
+      AGPU_CHAIN_BIN_CASE(AGPU_OP_XOR, OpXor)
+      default: break;
+    }
+  }
+}
+#undef AGPU_CHAIN_BIN_CASE
+
 // specialised on what costs registers: NARR = operand-pack slots (0/2/4/8, smallest that fits the chain's ARRAY steps)
 // and HEAVY = the chain contains a transcendental step (cbrt/exp/exp2/log/log2/sin/cos).  Scalar operands live in SGPRs
 // (readfirstlane).  The APPLY loop is a real (uniform) loop over the steps with a single copy of the op switch —
@@ -1891,12 +1966,17 @@ __device__ __forceinline__ bool chain_cmp_pred(int op, T x, T y) {
 // predicate ran at 4.9 TB/s.  It therefore keeps U = 2 packs per lane and stream in flight (6.x TB/s); the storing
 // form stays at U = 1 (tools/probe/chain_probe.py).
 #define AGPU_CHAIN_CMP_U 2
+// Round 5: the storing form of a chain with a transcendental step keeps TWO packs per lane as well — what the standalone sin / cos run
+// with; the step dispatch and the eight scalar loads of a tile are paid once per 512 rows instead of 256.
+#ifndef AGPU_CHAIN_HEAVY_U
+#define AGPU_CHAIN_HEAVY_U 2
+#endif
 template <typename T, bool HEAVY, int NARR, bool CMP>
 __global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_kernel(const T* in, T* out, uint64_t ntiles, int n_steps,
                                                              int n_arrs, uint64_t code, ChainPtrs ptrs, ChainPtrs arrs,
                                                              int cmp_op) {
   constexpr int N = 4;
-  constexpr int U = CMP ? AGPU_CHAIN_CMP_U : 1;  // a tile = U × 256 rows
+  constexpr int U = CMP ? AGPU_CHAIN_CMP_U : HEAVY ? AGPU_CHAIN_HEAVY_U : 1;  // a tile = U × 256 rows
   for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const uint64_t pk0 = t * (uint64_t)(AGPU_EW_BLOCK * U) + threadIdx.x;
     PackN<T, N> acc[U];
@@ -1939,16 +2019,10 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_kernel(const T* in, T* ou
     for (int s = 0; s < n_steps; s++) {
       const int op = chain_op(code, s), kind = chain_kind(code, s);
       if (kind == AGPU_CHAIN_UNARY) {
-        static_for<U>([&](auto u) {
-#pragma unroll
-          for (int k = 0; k < N; k++) acc[u].v[k] = chain_apply_unary<T, HEAVY>(op, acc[u].v[k]);
-        });
+        chain_apply_unary_packs<T, HEAVY, U, N>(op, acc);
       } else {
         fetch(s, kind);
-        static_for<U>([&](auto u) {
-#pragma unroll
-          for (int k = 0; k < N; k++) acc[u].v[k] = chain_apply_binary<T>(op, acc[u].v[k], y[u].v[k]);
-        });
+        chain_apply_binary_packs<T, U, N>(op, acc, y);
       }
     }
     if constexpr (CMP) {
@@ -1965,7 +2039,7 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_kernel(const T* in, T* ou
           reinterpret_cast<uint32_t*>(out)[(t * U + u) * (AGPU_EW_BLOCK / 8) + threadIdx.x / 8] = v;
       });
     } else {
-      store_pack<true, T, N>(out + pk0 * N, acc[0]);
+      static_for<U>([&](auto u) { store_pack<true, T, N>(out + (pk0 + (uint64_t)u * AGPU_EW_BLOCK) * N, acc[u]); });
     }
   }
 }
@@ -2028,7 +2102,7 @@ template <typename T, bool HEAVY, int NARR, bool CMP>
 static void launch_chain_full(agpu_pipeline* p, const T* pi, T* po, uint64_t ntiles, int n_steps, int n_arrs, uint64_t code,
                               const ChainPtrs& ptrs, const ChainPtrs& arrs, int cmp_op) {
   const int grid = stream_grid_for(p, ntiles);
-  hipLaunchKernelGGL((chain_kernel<T, HEAVY, NARR, CMP>), dim3(grid), dim3(AGPU_EW_BLOCK), 0, p->stream, pi, po, ntiles,
+  hipLaunchKernelGGL((chain_kernel<T, HEAVY, NARR, CMP>), dim3(grid), dim3(AGPU_EW_BLOCK), HEAVY ? wave_lds_for(p, AGPU_CHAIN_HEAVY_LDS, 1) : 0u, p->stream, pi, po, ntiles,
                      n_steps, n_arrs, code, ptrs, arrs, cmp_op);
 }
 
@@ -2041,7 +2115,7 @@ static agpu_status launch_chain(agpu_pipeline* p, const void* in, void* out, uin
   T* po = static_cast<T*>(out);
   const bool cmp = cmp_op >= 0;
   const int n_slots = n_steps + (cmp ? 1 : 0);  // step slots in use, including the compare's operand
-  const uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * 4 * (cmp ? AGPU_CHAIN_CMP_U : 1);
+  const uint64_t tile_rows = (uint64_t)AGPU_EW_BLOCK * 4 * (cmp ? AGPU_CHAIN_CMP_U : (heavy && std::is_floating_point<T>::value) ? AGPU_CHAIN_HEAVY_U : 1);
   const uint64_t ntiles = vec_ok ? n / tile_rows : 0;
   if (ntiles) {
     ChainPtrs arrs{}, scal;
@@ -2126,21 +2200,20 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
         const u32x2 w = {hi ? w2 : w0, hi ? w3 : w1};
         x = __builtin_bit_cast(PackN<TI, NO>, w);
       }
-      PackN<float, NO> acc;
+      PackN<float, NO> acc[1];
 #pragma unroll
-      for (int k = 0; k < NO; k++) acc.v[k] = (float)x.v[k];
+      for (int k = 0; k < NO; k++) acc[0].v[k] = (float)x.v[k];
       int ai = 0;
       for (int s = 0; s < n_steps; s++) {
         const int op = chain_op(code, s), kind = chain_kind(code, s);
         if (kind == AGPU_CHAIN_UNARY) {
-#pragma unroll
-          for (int k = 0; k < NO; k++) acc.v[k] = chain_apply_unary<float, HEAVY>(op, acc.v[k]);
+          chain_apply_unary_packs<float, HEAVY, 1, NO>(op, acc);  // the op switch once per pack, not per element (round 5)
         } else {
-          PackN<float, NO> y;
+          PackN<float, NO> y[1];
           if (kind == AGPU_CHAIN_ARRAY) {
-            y = ya[0];
+            y[0] = ya[0];
             static_for<NARR>([&](auto q) {
-              if (q == ai) y = ya[q];
+              if (q == ai) y[0] = ya[q];
             });
             ai++;
           } else {
@@ -2150,13 +2223,12 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
             });
             const float f = __builtin_bit_cast(float, w);
 #pragma unroll
-            for (int k = 0; k < NO; k++) y.v[k] = f;
+            for (int k = 0; k < NO; k++) y[0].v[k] = f;
           }
-#pragma unroll
-          for (int k = 0; k < NO; k++) acc.v[k] = chain_apply_binary<float>(op, acc.v[k], y.v[k]);
+          chain_apply_binary_packs<float, 1, NO>(op, acc, y);
         }
       }
-      store_pack<(AGPU_STREAM_NT & 2) != 0, float, NO, (R == 2)>(out + at, acc);
+      store_pack<(AGPU_STREAM_NT & 2) != 0, float, NO, (R == 2)>(out + at, acc[0]);
     });
     if (!more) break;
     v = vn;
@@ -2228,7 +2300,7 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
     const int grid = stream_grid_for(p, (blocks + kt - 1) / kt);
 #define AGPU_CCHAIN_CASE(H, A)                                                                                              \
   if (heavy == H && slots == A)                                                                                             \
-    hipLaunchKernelGGL((cast_chain_kernel<TI, H, A>), dim3(grid), dim3(AGPU_CVTW_BLOCK), 0, p->stream, pi, out, nchunks, n_steps, \
+    hipLaunchKernelGGL((cast_chain_kernel<TI, H, A>), dim3(grid), dim3(AGPU_CVTW_BLOCK), H ? wave_lds_for(p, AGPU_CHAIN_HEAVY_LDS, 1) : 0u, p->stream, pi, out, nchunks, n_steps, \
                        n_arrs, code, scal, arrs);
     AGPU_CCHAIN_CASE(false, 0) AGPU_CCHAIN_CASE(false, 2) AGPU_CCHAIN_CASE(false, 4)
     AGPU_CCHAIN_CASE(true, 0) AGPU_CCHAIN_CASE(true, 2) AGPU_CCHAIN_CASE(true, 4)
