@@ -2019,7 +2019,7 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_kernel(const T* in, T* ou
     for (int s = 0; s < n_steps; s++) {
       const int op = chain_op(code, s), kind = chain_kind(code, s);
       if (kind == AGPU_CHAIN_UNARY) {
-        chain_apply_unary_packs<T, HEAVY, U, N>(op, acc);
+        chain_apply_unary_packs<T, HEAVY, U, N>(op, acc);  // the op switch once per tile, not behind every element (round 5)
       } else {
         fetch(s, kind);
         chain_apply_binary_packs<T, U, N>(op, acc, y);
