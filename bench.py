@@ -796,8 +796,22 @@ def main():
 
             fused_row("mul_add_gt_predicate", 16.125, 32.125,
                       lambda: capi.call("agpu_fused_chain_compare", h, capi.F32, vp(fa), C.cast(st_p, C.c_void_p), n_p, capi.CMP_GT, 2, vp(fo), vp(ob), n),
-                      unf_pred, ob, nb, "(a * b + c) > d → bitmap: agpu_fused_chain_compare vs mul, add, compare")
+                      unf_pred, ob, nb, "(a * b + c) > d → bitmap: agpu_fused_chain_compare vs mul, add, compare (three of the four columns in the add's "
+                                        "table, the fourth a block of its own)")
             del tmp
+            # the same predicate with its four columns allocated as ONE table (agpu_malloc_table: the placement DESIGN.md §3 describes) — what the
+            # four read streams run at when nothing about their relative placement is left to chance
+            try:
+                qa, qb, qc, qd, qo = dev.create_table_buffers([4 * n] * 4 + [nb])
+                for k_, col in enumerate((qa, qb, qc, qd)):
+                    capi.call("agpu_synth_f32", h, vp(col), n, SEED + 20 + k_, row0, C.c_float(-1000.0), C.c_float(1000.0))
+                st_q, n_q = chain((capi.OP_MUL, 2, qb), (capi.OP_ADD, 2, qc))
+                ms_q = timed(lambda: capi.call("agpu_fused_chain_compare", h, capi.F32, vp(qa), C.cast(st_q, C.c_void_p), n_q, capi.CMP_GT, 2, vp(qd), vp(qo), n))
+                fused["mul_add_gt_predicate"]["one_table_ms"] = round(ms_q, 4)
+                fused["mul_add_gt_predicate"]["one_table_frac_hbm_peak"] = round(16.125 * n / ms_q / 1e6 / HBM_PEAK_GBPS, 4)
+                del qa, qb, qc, qd, qo
+            except Exception as e:  # noqa: BLE001 — an extra figure: never the reason a bench line is lost
+                fused["mul_add_gt_predicate"]["one_table_error"] = f"{type(e).__name__}: {e}"
             st_c, n_c = chain((capi.OP_MUL, 1, sc2), (capi.OP_ADD, 1, sc))
 
             def unf_cast():
