@@ -158,7 +158,8 @@ struct agpu_device {
   struct TileSlot {  // one timed launch
     hipEvent_t e0 = nullptr, e1 = nullptr;
     uint8_t variant = 0;  // 0 = one tile per block, 1 = two
-    bool pending = false;
+    bool busy = false;     // handed to a launch (agpu_tiles_pick) and not yet harvested: nobody else may take it
+    bool pending = false;  // its stop event is on the stream
     double bytes = 0;
   };
   struct TileEntry {

@@ -1314,6 +1314,7 @@ static void tile_harvest_locked(agpu_device::TileEntry& e) {
       continue;
     }
     s.pending = false;
+    s.busy = false;
     float ms = 0;
     if (q != hipSuccess || hipEventElapsedTime(&ms, s.e0, s.e1) != hipSuccess || !(ms > 0) || !(s.bytes > 0)) {
       (void)hipGetLastError();
@@ -1345,7 +1346,7 @@ uint64_t agpu_tiles_pick(agpu_pipeline* p, int family, int kernel, const void* i
       break;
     }
     bool busy = false;
-    for (const agpu_device::TileSlot& s : e.slot) busy |= s.pending;
+    for (const agpu_device::TileSlot& s : e.slot) busy |= s.busy;
     if (!busy && (victim < 0 || !e.live || (dev->tile_tab[victim].live && e.last_use < dev->tile_tab[victim].last_use))) victim = i;
   }
   if (at < 0) {
@@ -1384,7 +1385,7 @@ uint64_t agpu_tiles_pick(agpu_pipeline* p, int family, int kernel, const void* i
   if (e.issued[v] >= kTileSamples) return e.current;  // all eight are out: wait for them
   int free_slot = -1;
   for (int k = 0; k < 8; k++)
-    if (!e.slot[k].pending) {
+    if (!e.slot[k].busy) {  // (not merely "not pending": another thread's launch may sit between its pick and its done)
       free_slot = k;
       break;
     }
@@ -1402,6 +1403,7 @@ uint64_t agpu_tiles_pick(agpu_pipeline* p, int family, int kernel, const void* i
   }
   s.variant = (uint8_t)v;
   s.bytes = (double)bytes;
+  s.busy = true;
   e.issued[v]++;
   sample->entry = at;
   sample->slot = free_slot;
@@ -1416,6 +1418,7 @@ void agpu_tiles_done(agpu_pipeline* p, agpu_tile_sample* sample) {
   if (hipEventRecord(s.e1, p->stream) == hipSuccess) s.pending = true;
   else {
     (void)hipGetLastError();
+    s.busy = false;
     if (e.issued[s.variant]) e.issued[s.variant]--;
   }
   sample->entry = -1;

@@ -151,3 +151,46 @@ def test_inside_a_captured_graph_nothing_is_timed(ctx):
     q.sync()
     capi.call("agpu_graph_destroy", g)
     assert entries(dev) == before
+
+
+def test_four_host_threads_sampling_the_same_key(ctx):
+    """four pipelines on four host threads launch the same kernel on the same buffers while the policy is still measuring: a sample slot
+    belongs to ONE launch from its pick to its harvest (two launches on one event pair would time garbage), results stay bit-identical
+    and the entry still converges"""
+    import threading
+
+    dev, p, u8, f, out, chk = ctx
+    from arrow_gpu_amd.gpu_utils import ArrowComputePipeline
+
+    n5 = 9 << 23
+    outs = [dev.create_empty_buffer(4 * n5) for _ in range(4)]
+    p.set_tuning("cast_tiles", 1)
+    capi.call("agpu_cast", p._handle, capi.I8, capi.F32, vp(u8), vp(out), n5)
+    ref = checksum(dev, p, out, chk, 4 * n5)
+    p.set_tuning("cast_tiles", 0)
+    errs = []
+
+    def worker(k):
+        try:
+            q = ArrowComputePipeline(dev, f"t{k}")
+            q.set_tuning("tile_auto", 1 << 20)  # every launch of this size is eligible
+            c = dev.create_empty_buffer(8)
+            for _ in range(12):
+                capi.call("agpu_cast", q._handle, capi.I8, capi.F32, vp(u8), vp(outs[k]), n5)
+            q.sync()
+            capi.call("agpu_checksum", q._handle, vp(outs[k]), 4 * n5, vp(c))
+            got = int(dev.retrive_data(c, 8, pipeline=q).view(np.uint64)[0])
+            if got != ref:
+                errs.append((k, got, ref))
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for fam_entries in entries(dev).values():
+        for e in fam_entries:
+            assert e["n"][0] <= 4 and e["n"][1] <= 4, e   # never more samples than slots were handed out for
