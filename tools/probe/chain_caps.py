@@ -23,8 +23,12 @@ vp = lambda b: C.c_void_p(b.ptr)
 c1, n1 = chain((capi.OP_MUL, 1, S), (capi.UN_SIN, 0, None))
 c2, n2 = chain((capi.OP_MUL, 1, S), (capi.OP_ADD, 2, y), (capi.UN_COS, 0, None))
 c3, n3 = chain((capi.OP_MUL, 1, S), (capi.UN_SIN, 0, None))
+c4, n4 = chain((capi.OP_MUL, 1, S), (capi.UN_EXP, 0, None))
+c5, n5 = chain((capi.OP_ADD, 2, y), (capi.UN_ABS, 0, None), (capi.UN_LOG2, 0, None), (capi.OP_MUL, 1, S))
 K = {"(x*s).sin() f32": (8.0, lambda: capi.call("agpu_fused_chain", h, capi.F32, vp(f), C.cast(c1, C.c_void_p), n1, vp(g), n)),
      "(x*s+y).cos() f32": (12.0, lambda: capi.call("agpu_fused_chain", h, capi.F32, vp(f), C.cast(c2, C.c_void_p), n2, vp(g), n)),
+     "(x*s).exp() f32": (8.0, lambda: capi.call("agpu_fused_chain", h, capi.F32, vp(f), C.cast(c4, C.c_void_p), n4, vp(g), n)),
+     "log2(|x+y|)*s f32": (12.0, lambda: capi.call("agpu_fused_chain", h, capi.F32, vp(f), C.cast(c5, C.c_void_p), n5, vp(g), n)),
      "cast(u16)*s -> sin": (6.0, lambda: capi.call("agpu_fused_cast_chain", h, capi.U16, vp(u16), C.cast(c3, C.c_void_p), n3, vp(g), n))}
 def med(fn, bpr):
     for _ in range(4): fn()
@@ -34,6 +38,6 @@ def med(fn, bpr):
     return bpr * n / sorted(ts)[4] / 1e6 / 8000
 for name, (bpr, fn) in K.items():
     row = []
-    for cap in (-1, 4200, 5600, 6800, 8000, 10240, 13600, -1, 6800):
+    for cap in [int(x) for x in os.environ.get("CHAIN_CAPS", "-1,4200,5600,6800,8000,10240,13600,-1,6800").split(",")]:
         p.set_tuning("wave_lds", cap); row.append(f"{cap}:{med(fn, bpr):.3f}")
     print(name.ljust(22), " ".join(row), flush=True)
