@@ -7,6 +7,7 @@
 // the GPU.  Host↔HBM movement has three selectable engines (pageable hipMemcpy — the default, at link rate on this
 // platform —, threaded page-locked staging, hipHostRegister in place); overlap of transfers with compute is the host
 // layer's job (two pipelines + agpu_pipeline_wait_pipeline: arrow_gpu_amd/interop.py map_chunks).
+#include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
@@ -215,7 +216,7 @@ static bool host_range_in_brk_heap(const void* ptr, size_t bytes) {
 // size; size_t mprotect_size; …} (malloc/arena.c, unchanged in these fields from glibc 2.26 to 2.39): the first heap of an arena keeps
 // its malloc_state right behind the header (ar_ptr − A is 32 or 48), later heaps point back (prev is 64 MiB-aligned, ar_ptr lies a
 // header behind ANOTHER 64 MiB boundary); size ≤ mprotect_size ≤ 64 MiB, both page multiples.  A range is staged when the header at A
-// is readable (one pass over /proc/self/maps — the header is only dereferenced inside a readable mapping) and looks like that; any
+// is readable (it is read through the kernel — a pipe write that fails with EFAULT instead of a load that faults) and looks like that; any
 // other memory — numpy, Arrow pools, file mappings, mmap itself — goes to the runtime at the link's rate.  A false "arena" costs
 // bandwidth only; a false "not an arena" would need a glibc whose heap_info no longer starts with these four words.
 #define AGPU_THREAD_ARENA_MAX ((size_t)64 << 20)
@@ -223,24 +224,36 @@ static bool host_range_in_thread_arena(const void* ptr, size_t bytes) {
   const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes, mask = AGPU_THREAD_ARENA_MAX - 1;
   if (((lo ^ (hi - 1)) & ~mask) != 0) return false;  // crosses a 64 MiB boundary: no single heap holds it
   const uintptr_t A = lo & ~mask;
-  FILE* f = fopen("/proc/self/maps", "r");
-  if (!f) return true;  // cannot tell: the safe path
-  char line[512];
-  bool readable = false;
-  while (fgets(line, sizeof line, f)) {
-    unsigned long long a = 0, b = 0;
-    char perms[8] = {0};
-    if (sscanf(line, "%llx-%llx %7s", &a, &b, perms) != 3) continue;
-    if (A >= a && A + 64 <= b) {
-      readable = perms[0] == 'r';
-      break;
-    }
-    if (a > A) break;  // the file is sorted by address: A is not mapped
-  }
-  fclose(f);
-  if (!readable) return false;  // nothing (readable) at the would-be header: not a heap
+  // The would-be header is read THROUGH THE KERNEL: write(2) from address A into a pipe returns EFAULT for an unmapped or unreadable page
+  // where a plain load would raise SIGSEGV (a PROT_NONE reservation of another allocator may well sit at the 64 MiB boundary below a live
+  // buffer, and another thread may unmap it at any time).  Two system calls, ≈ 2 µs — the /proc/self/maps pass this replaces cost 50–200 µs
+  // per copy in a process with a few hundred mappings, as much as a 5 MiB transfer itself.
   uint64_t w[4];
-  memcpy(w, reinterpret_cast<const void*>(A), sizeof w);
+  {
+    static std::mutex pipe_mu;
+    static int fds[2] = {-1, -1};
+    static pid_t owner = 0;
+    std::lock_guard<std::mutex> lk(pipe_mu);
+    const pid_t me = getpid();
+    if (fds[0] >= 0 && owner != me) {  // a forked child must not share the parent's pipe (its reads would take the parent's bytes)
+      (void)close(fds[0]);
+      (void)close(fds[1]);
+      fds[0] = fds[1] = -1;
+    }
+    if (fds[0] < 0) {
+      if (pipe2(fds, O_CLOEXEC | O_NONBLOCK) != 0) return true;  // cannot tell: the safe path
+      owner = me;
+    }
+    const ssize_t put = write(fds[1], reinterpret_cast<const void*>(A), sizeof w);
+    if (put != (ssize_t)sizeof w) {
+      if (put > 0) {  // (cannot happen for 32 bytes; keep the pipe clean anyway)
+        char sink[sizeof w];
+        (void)!read(fds[0], sink, (size_t)put);
+      }
+      return false;  // nothing readable at the would-be header: not a heap
+    }
+    if (read(fds[0], w, sizeof w) != (ssize_t)sizeof w) return true;
+  }
   const uint64_t ar_ptr = w[0], prev = w[1], size = w[2], mprot = w[3];
   const uint64_t ar_off = ar_ptr & mask;
   const bool header = ar_ptr != 0 && (ar_ptr & 7) == 0 && ar_off >= 16 && ar_off <= 256 &&
