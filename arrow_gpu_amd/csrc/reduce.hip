@@ -418,6 +418,15 @@ static agpu_status launch_reduce(agpu_pipeline* p, const void* in, const void* v
                          static_cast<const T*>(in) + nchunks * RED_CHUNK_ROWS, (const uint8_t*)nullptr, tail, partials + nchunks, 1);
       AGPU_LAUNCH_CHECK();
     }
+    // ≤ 4096 partials (columns of up to 64 Mi rows — the reference's own benchmark shapes, 1 Mi and 10 Mi rows, among them): the finishing
+    // block folds them itself, TWO launches instead of three.  Only where the order of the fold cannot matter (wrapping sums, min / max):
+    // the f64 sum keeps its two-level order so that its last bits do not depend on the column's length class.
+    if (m <= 4096 && !std::is_same<A, double>::value) {
+      hipLaunchKernelGGL((reduce_finish_kernel<Red>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, (const A*)partials, (uint32_t)m,
+                         static_cast<typename Red::Out*>(out));
+      AGPU_LAUNCH_CHECK();
+      return AGPU_OK;
+    }
     hipLaunchKernelGGL((reduce_fold_kernel<Red>), dim3(fold), dim3(AGPU_BLOCK), 0, p->stream, (const A*)partials, m, partials + m);
     AGPU_LAUNCH_CHECK();
     hipLaunchKernelGGL((reduce_finish_kernel<Red>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, (const A*)(partials + m), (uint32_t)fold,
