@@ -266,6 +266,12 @@ def test_cast_then_trig_equals_the_fused_narrow_kernels_and_the_oracle(ag, kind)
             assert np.array_equal(np.isfinite(exp), np.isfinite(fused))
             d = np.abs(fused[fin].view(np.int32).astype(np.int64) - exp[fin].view(np.int32).astype(np.int64))
             assert d.max() <= 1, (kind, name, int(d.max()))
+    # exp / log alone behind the cast: for 16-bit sources the kernel specialised on the function (round 5) — every input value, bit for bit
+    # against the unfused pair (log of the non-positive values: -inf / NaN, compared as bits too)
+    for name in ("exp", "log"):
+        fused = getattr(ag.FusedChain(a), name)().finish().raw_values()
+        pair = getattr(a.cast(ag.Float32ArrayGPU), name)().raw_values()
+        assert bits(fused) == bits(pair), (kind, name)
 
 
 def test_fusing_pipeline_collapses_cast_then_sin_into_one_launch(ag):
