@@ -29,6 +29,7 @@
 
 static_assert(AGPU_COMM_ID_BYTES == sizeof(ncclUniqueId), "agpu_comm id blob must hold an ncclUniqueId");
 
+struct comm_init_job;
 struct agpu_comm {
   agpu_device* dev;
   ncclComm_t comm;
@@ -51,6 +52,9 @@ struct agpu_comm {
   std::atomic<uint32_t> in_flight{0};
   // world 1 only: RCCL's bootstrap did not come up within the deadline — no ncclComm_t; the collectives of a single rank are device copies
   bool local = false;
+  // … and the helper that is still inside ncclCommInitRank: if it comes back after all, agpu_comm_destroy (or the helper itself, once the
+  // communicator is gone) destroys the ncclComm_t nobody uses — a live RCCL communicator at process exit is a crash (comm_init_job below)
+  std::shared_ptr<comm_init_job> late_init;
   std::mutex peers_mu;  // one agpu_comm_peers at a time (they share `peers`); never taken together with a wait on `mu`
 };
 
@@ -163,7 +167,25 @@ struct comm_init_job {
   ncclResult_t result = ncclSuccess;
   hipError_t hip = hipSuccess;
   ncclComm_t comm = nullptr;
+  bool orphaned = false;  // one rank, bootstrap late, and the local communicator that stood in for it is gone: the helper cleans up after itself
 };
+// Seen with the test hook (AGPU_COMM_TEST_STALL_INIT_MS=19000, deadline 20 s: the helper's ncclCommInitRank returns a second AFTER the call gave
+// up): the process ran to its end on the local communicator and died with SIGSEGV at exit — RCCL's communicator, with its proxy threads, was
+// still alive.  Whoever sees the late ncclComm_t last destroys it.
+static void comm_reap_late_init(const std::shared_ptr<comm_init_job>& job) {
+  if (!job) return;
+  ncclComm_t late = nullptr;
+  {
+    std::unique_lock<std::mutex> lk(job->mu);
+    if (job->cv.wait_for(lk, std::chrono::milliseconds(2000), [&] { return job->done; })) {
+      late = job->comm;
+      job->comm = nullptr;
+    } else {
+      job->orphaned = true;
+    }
+  }
+  if (late) (void)ncclCommDestroy(late);
+}
 
 agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id, int32_t rank, int32_t world,
                                         int64_t timeout_ms, agpu_comm** out_comm) {
@@ -175,6 +197,7 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
   memcpy(&id, unique_id, sizeof(id));
   ncclComm_t comm = nullptr;
   bool is_local = false;
+  std::shared_ptr<comm_init_job> late;
   // a one-rank communicator waits for nobody: its bootstrap takes a fraction of a second or is not going to come up — 20 s at most
   if (world == 1 && timeout_ms > 20000) timeout_ms = 20000;
   if (timeout_ms <= 0) {
@@ -190,12 +213,17 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
       ncclComm_t c = nullptr;
       hipError_t he = hipSetDevice(ordinal);
       ncclResult_t r = he == hipSuccess ? ncclCommInitRank(&c, world, id, rank) : ncclUnhandledCudaError;
-      std::lock_guard<std::mutex> lk(job->mu);
-      job->comm = c;
-      job->result = r;
-      job->hip = he;
-      job->done = true;
-      job->cv.notify_all();
+      bool orphaned = false;
+      {
+        std::lock_guard<std::mutex> lk(job->mu);
+        orphaned = job->orphaned;
+        job->comm = orphaned ? nullptr : c;
+        job->result = r;
+        job->hip = he;
+        job->done = true;
+        job->cv.notify_all();
+      }
+      if (orphaned && c) (void)ncclCommDestroy(c);
     }).detach();
     std::unique_lock<std::mutex> lk(job->mu);
     bool local = false;
@@ -228,12 +256,14 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
       comm = job->comm;
     }
     is_local = local;
+    if (local) late = job;
   }
   char* mem = nullptr;
   const size_t rec_bytes = 16 + 16 * (size_t)world + 16, peer_bytes = sizeof(agpu_comm_peer) * ((size_t)world + 1);
   hipError_t e = hipMalloc(&mem, rec_bytes + peer_bytes);
   if (e != hipSuccess) {
     if (comm) (void)ncclCommDestroy(comm);
+    comm_reap_late_init(late);
     agpu_set_error("hipMalloc of the communicator records failed: %s", hipGetErrorString(e));
     return AGPU_ERR_HIP;
   }
@@ -243,6 +273,7 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
   c->dev = dev;
   c->comm = comm;
   c->local = is_local;
+  c->late_init = late;
   c->rank = rank;
   c->world = world;
   c->send = mem;
@@ -281,6 +312,7 @@ agpu_status agpu_comm_destroy(agpu_comm* c) {
     // kernel polls (so the stream may drain after all); it runs on a helper thread because it may itself wait, and is
     // given two seconds.  The record buffers and the event leak — the process is about to exit.
     if (c->local) {
+      comm_reap_late_init(c->late_init);
       delete c;
       return AGPU_OK;
     }
@@ -298,6 +330,7 @@ agpu_status agpu_comm_destroy(agpu_comm* c) {
   }
   (void)hipDeviceSynchronize();
   if (!c->local) (void)ncclCommDestroy(c->comm);
+  else comm_reap_late_init(c->late_init);
   (void)hipFree(c->send);
   if (c->last_done) (void)hipEventDestroy(c->last_done);
   delete c;

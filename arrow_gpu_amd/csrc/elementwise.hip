@@ -1281,7 +1281,9 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel_unaligned(const TI* in,
 #define AGPU_CVTW_BLOCK 64
 #endif
 
-template <typename TI, typename TO, typename Conv>
+// SC1: the stores' cache policy.  ×2: always sc1 nt.  ×4: sc1 nt when the launch carries the occupancy cap (u8→f32 / i8→i32 at 1e9 rows,
+// three processes, tools/r05_sc1x4.sh: 0.794–0.817 → 0.808–0.826 of the roof), plain nt without it (0.785–0.800 against 0.760–0.797).
+template <typename TI, typename TO, typename Conv, bool SC1>
 __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in, TO* out, uint64_t nchunks) {
   constexpr int R = sizeof(TO) / sizeof(TI);   // 2 or 4 stores per load
   constexpr int NO = 16 / sizeof(TO);          // output elements per lane per store
@@ -1317,7 +1319,7 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in,
 #pragma unroll
       for (int k = 0; k < NO; k++) r.v[k] = Conv::ap(x.v[k]);
       const uint32_t g = (uint32_t)j * AGPU_WAVE + lane;  // slot of this lane's store inside the chunk
-      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, NO, (R == 2)>(out + (c * (uint64_t)(AGPU_WAVE * R) + g) * NO, r);  // sc1 for ×2 only
+      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, NO, SC1>(out + (c * (uint64_t)(AGPU_WAVE * R) + g) * NO, r);
     });
     if (!more) break;
     v = vn;
@@ -1394,8 +1396,11 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
         const int grid = stream_grid_for(p, (blocks + k - 1) / k);
         // occupancy cap (common.hpp): ×2 casts to 32 bits ≈ 24 waves per CU, ×4 ≈ 16; u8 → u16 none (not measured to gain)
         constexpr unsigned cap = sizeof(TO) == 4 ? (sizeof(TI) == 2 ? AGPU_WAVE_LDS_24 : AGPU_WAVE_LDS_16) : 0u;
-        hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_CVTW_BLOCK), cap ? wave_lds_for(p, cap, AGPU_CVTW_BLOCK / AGPU_WAVE) : 0u,
-                           p->stream, pi, po, nchunks);
+        const unsigned lds = cap ? wave_lds_for(p, cap, AGPU_CVTW_BLOCK / AGPU_WAVE) : 0u;
+        if (sizeof(TO) == 2 * sizeof(TI) || lds >= AGPU_WAVE_LDS_24)
+          hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv, true>), dim3(grid), dim3(AGPU_CVTW_BLOCK), lds, p->stream, pi, po, nchunks);
+        else
+          hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv, false>), dim3(grid), dim3(AGPU_CVTW_BLOCK), lds, p->stream, pi, po, nchunks);
         agpu_tiles_done(p, &tile_sample);
       }
       if (nchunks * chunk_rows < n)
@@ -1490,6 +1495,15 @@ struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders
 // instructions: sin_u8 ran at 0.745 of the roof where the plain u8 → f32 cast ran at 0.79 on the same buffers) — it is built
 // once per device by lut8_build_kernel with the same device functions (agpu_device::lut8_tables) and a block copies its 1 KiB.
 #define AGPU_LUT8_BLOCK 128
+#ifndef AGPU_TRIG16_SC1
+#define AGPU_TRIG16_SC1 1  // sin_u16 / cos_i16: +1 % in 6 of 6 alternations (tools/r05_sc1more.sh)
+#endif
+#ifndef AGPU_CCHAIN_SC1X4
+#define AGPU_CCHAIN_SC1X4 1  // cast(u8)·s+s: 0.78–0.81 → 0.80–0.815, same script
+#endif
+#ifndef AGPU_LUT8_SC1
+#define AGPU_LUT8_SC1 1  // sc1 nt stores: sin_u8 / cos_i8 at 1e9 rows 0.790–0.809 → 0.804–0.830 of the roof (tools/r05_sc1x4.sh, three processes)
+#endif
 template <typename TI, typename F>
 __global__ void lut8_build_kernel(float* tab) {
   const uint32_t e = threadIdx.x;
@@ -1547,7 +1561,11 @@ __global__ __launch_bounds__(AGPU_LUT8_BLOCK) void lut8_kernel(const TI* in, flo
       const uint32_t sel = lane & 3u;
       const uint32_t x = sel == 0 ? w0 : sel == 1 ? w1 : sel == 2 ? w2 : w3;
       f32x4 r = {lut[x & 255u], lut[(x >> 8) & 255u], lut[(x >> 16) & 255u], lut[x >> 24]};
+#if AGPU_LUT8_SC1
+      st_vec_sc1(out4 + c * (AGPU_WAVE * 4) + (uint32_t)j * AGPU_WAVE + lane, r);
+#else
       __builtin_nontemporal_store(r, out4 + c * (AGPU_WAVE * 4) + (uint32_t)j * AGPU_WAVE + lane);
+#endif
     });
   }
 }
@@ -1676,7 +1694,11 @@ __global__ __launch_bounds__(BLOCK) void trig16_kernel(const TI* in, float* out,
         const uint32_t x = hi ? w2 : w0, y = hi ? w3 : w1;
         f32x4 r = {trig16_eval<TI, WANT_COS>(tab, x & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, x >> 16),
                    trig16_eval<TI, WANT_COS>(tab, y & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, y >> 16)};
+#if AGPU_TRIG16_SC1
+        st_vec_sc1(out4 + (c0 + (uint32_t)u) * (AGPU_WAVE * 2) + (uint32_t)j * AGPU_WAVE + lane, r);
+#else
         __builtin_nontemporal_store(r, out4 + (c0 + (uint32_t)u) * (AGPU_WAVE * 2) + (uint32_t)j * AGPU_WAVE + lane);
+#endif
       });
     });
   }
@@ -2228,7 +2250,7 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
           chain_apply_binary_packs<float, 1, NO>(op, acc, y);
         }
       }
-      store_pack<(AGPU_STREAM_NT & 2) != 0, float, NO, (R == 2)>(out + at, acc[0]);
+      store_pack<(AGPU_STREAM_NT & 2) != 0, float, NO, (R == 2 || AGPU_CCHAIN_SC1X4)>(out + at, acc[0]);
     });
     if (!more) break;
     v = vn;

@@ -166,5 +166,6 @@ int main(int argc, char** argv) {
          world, res[0].rccl_ranks, res[0].distinct_devices, strong ? "strong" : "weak", (unsigned long long)total, (unsigned long long)res[0].rows, steps,
          20.5 * (double)total * steps / step_s / 1e9, step_s / steps * 1e3, add_lo, add_hi, eq_lo, eq_hi, res[0].sum, res[0].mn,
          res[0].mx, stats_ms, 3.0 * 4.0 * (double)total / stats_ms / 1e6, Communicator::runtime_info().c_str());
+  fflush(stdout);  // before the static destructors of the runtimes underneath
   return 0;
 }

@@ -100,7 +100,7 @@ def test_sharded_stats_example_matches_the_sharded_spec():
     build_sharded()
     rows = 1 << 24  # 256^3 rows per shard: the sharded f32 Sum equals the reference's whole-column tree bit for bit
     r = subprocess.run([S_EXE, str(rows)], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0, f"exit {r.returncode}: " + r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     world = line["world"]
     assert line["identical_on_all_ranks"] is True and world >= 1 and line["scaling"] == "weak"

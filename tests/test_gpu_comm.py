@@ -362,3 +362,40 @@ def test_a_one_rank_communicator_survives_a_bootstrap_that_does_not_come_up():
     env = dict(os.environ, AGPU_COMM_TEST_STALL_INIT_MS="4000")
     r = subprocess.run([sys.executable, "-c", _LOCAL_WORKER.format(root=root)], capture_output=True, text=True, timeout=180, env=env)
     assert r.returncode == 0 and "LOCAL-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+
+
+_LATE_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import numpy as np
+from arrow_gpu_amd import _capi as capi
+from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, GpuDevice
+from arrow_gpu_amd.sharding import Communicator
+dev = GpuDevice(0)
+p = ArrowComputePipeline(dev, "late")
+comm = Communicator(dev, 0, 1, Communicator.unique_id(), timeout_s=0.5)   # the helper calls RCCL 0.3 s in and returns after the deadline
+assert comm.is_local, "expected the local fallback"
+cnt = dev.create_gpu_buffer_with_data(np.array([7, 9], np.uint64))
+comm.all_reduce(p, capi.RED_SUM, capi.COMM_U64, cnt, 2)
+comm.barrier(p)
+time.sleep({sleep})    # the late ncclComm_t arrives meanwhile (or, with sleep 0, is still on its way when close() looks)
+comm.close()
+print("LATE-OK")
+sys.stdout.flush()
+# a NORMAL interpreter exit: with RCCL's communicator left alive this is where the process died
+"""
+
+
+@pytest.mark.parametrize("sleep", [6, 0])
+def test_a_bootstrap_that_comes_up_late_is_cleaned_up(sleep):
+    """AGPU_COMM_TEST_STALL_INIT_MS=19000 against the 20 s one-rank deadline, examples/sharded_stats: the helper's ncclCommInitRank returned a
+    second after the call had fallen back to the local communicator, and the process died with SIGSEGV at exit (RCCL's communicator and its
+    proxy threads still alive).  agpu_comm_destroy now takes the late communicator down (or tells the helper to)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AGPU_COMM_TEST_STALL_INIT_MS="300")
+    r = subprocess.run([sys.executable, "-c", _LATE_WORKER.format(root=root, sleep=sleep)], capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0 and "LATE-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
