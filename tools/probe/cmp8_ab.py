@@ -6,8 +6,9 @@ from arrow_gpu_amd import _capi as capi
 from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, CmpQuery, GpuDevice
 n = int(os.environ.get("N", 1_000_000_000))
 dev = GpuDevice(0); p = ArrowComputePipeline(dev, "c8"); q = CmpQuery(dev); h = p._handle
-A, B, OB = dev.create_table_buffers([n, n, n // 8 + 64])
-capi.call("agpu_synth_u8", h, C.c_void_p(A.ptr), n, 6, 0); capi.call("agpu_synth_u8", h, C.c_void_p(B.ptr), n, 7, 0); p.sync()
+na = int(os.environ.get("NALLOC", n))   # allocate for NALLOC rows, run on the first n
+A, B, OB = dev.create_table_buffers([na, na, na // 8 + 64])
+capi.call("agpu_synth_u8", h, C.c_void_p(A.ptr), na, 6, 0); capi.call("agpu_synth_u8", h, C.c_void_p(B.ptr), na, 7, 0); p.sync()
 vp = lambda b: C.c_void_p(b.ptr)
 def med(fn):
     for _ in range(4): fn()
