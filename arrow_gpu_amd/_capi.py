@@ -44,6 +44,7 @@ SIGNATURES = {
     "agpu_device_create": [_i32, _pp],
     "agpu_device_destroy": [_vp],
     "agpu_device_sync": [_vp],
+    "agpu_device_download": [_vp, _vp, _vp, _sz],
     "agpu_device_name": [_vp, C.c_char_p, _sz],
     "agpu_device_ordinal": [_vp, C.POINTER(_i32)],
     "agpu_device_mem_info": [_vp, C.POINTER(_u64), C.POINTER(_u64)],

@@ -39,8 +39,9 @@ struct agpu_tuning {
   int64_t cast_tiles;          // chunks per wave of the widening casts and cast-headed chains, next chunk prefetched the same way (0 = auto)
   int64_t tile_auto;           // 0 = the "auto" of heavy_tiles / cast_tiles / table_tiles is ADAPTIVE for big launches (one or two tiles per block, whichever the device measures faster on these buffers: runtime.hip agpu_tiles_pick); 1 = static defaults (one tile); > 1 = adaptive with this many bytes as the threshold instead of 256 MiB (tests)
   int64_t wave_lds;            // unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the ×2 / ×4 widening casts and the 8-bit table kernels: 0 = each kernel's measured default (6800 B ≈ 24 waves per CU; u8 → 32-bit casts 10240 B ≈ 16), < 0 = no cap, > 0 = this many bytes
+  int64_t sync_spin;           // agpu_pipeline_sync and downloads of ≤ 64 bytes wait for a kernel that posts into the pipeline's pinned mailbox instead of hipStreamSynchronize (12 → 7 µs for "one kernel, one scalar back"): 0 = yes, spinning for at most 200 µs before the blocking wait; > 0 = this many µs; < 0 = off
 };
-#define AGPU_TUNE_KEYS 16
+#define AGPU_TUNE_KEYS 17
 agpu_tuning agpu_tuning_defaults();  // snapshot of the process-wide defaults (atomics, runtime.hip)
 bool agpu_mem_pool_enabled();        // process-wide "mem_pool" switch (device-level behaviour, not per pipeline)
 
@@ -66,6 +67,8 @@ struct agpu_stream_slot {
   bool owned = false;
   agpu_scratch_block* scratch = nullptr;  // travels with the stream through the idle pool
   std::atomic<uint64_t> enq{0};           // +1 when an ABI call on this stream starts, +1 when it has enqueued its work (odd = in progress)
+  std::atomic<uint64_t> clean_enq{0};     // value of `enq` up to which the stream is KNOWN to have drained (a completed host wait: pipeline sync, small download, device wait)
+  std::atomic<bool> capturing{false};     // the stream is in graph capture: nothing but its own pipeline may launch on it
   // ---- guarded by agpu_device::mu
   uint64_t mark_seq = 0;                  // value of `enq` the newest marker covers
   agpu_event_ref* mark = nullptr;         // newest marker event recorded on the stream (free / finish / destroy)
@@ -142,6 +145,10 @@ struct agpu_device {
   std::vector<uint32_t*> flag_free;
   std::vector<RetiredFlag> flag_retired;
   std::vector<void*> flag_slabs;
+  // the DEVICE's mailbox (agpu_device_sync / agpu_device_download, runtime.hip device_wait_all): one pinned slot of the same layout, one wait at a time
+  std::mutex mbox_mu;
+  uint32_t* mbox = nullptr;
+  uint64_t mbox_seq = 0;
   // page-locked staging chunks for host↔HBM transfers of pageable memory (arrow_cdata.hip); one transfer at a time
   struct StageSlot {
     void* host;
@@ -218,6 +225,11 @@ struct agpu_pipeline {
   // sticky error word in pinned host memory, written by kernels (bit 0: take/put index out of range), read and cleared
   // by agpu_pipeline_sync — no pre-pass over the index column, no readback, the pipeline stays asynchronous
   uint32_t* flags;
+  // the same 256-byte pinned slot carries the pipeline's MAILBOX (runtime.hip pipeline_wait_mailbox): 64 payload bytes at +64 and a sequence
+  // word at +128 that a one-wave kernel posts behind everything queued so far; the host spins on it.  `dirty`: an ABI call has bound the
+  // pipeline since the last completed wait (an idle stream keeps the plain, cheap hipStreamSynchronize).
+  uint64_t mbox_seq;
+  bool dirty;
   // profiling [ref: CmpQuery compute_query.rs:7-89, insert_debug_marker gpu_device.rs:132]
   uint32_t profile;    // AGPU_PROF_* bits
   int scope_depth;
@@ -225,6 +237,9 @@ struct agpu_pipeline {
   bool t_valid;
   const char* last_name;
 };
+#define AGPU_FLAG_SLOT_BYTES 256
+#define AGPU_MBOX_PAYLOAD 64   // byte offset of the mailbox payload inside a pipeline's pinned slot (64 bytes)
+#define AGPU_MBOX_SEQ 128      // byte offset of the mailbox sequence word
 #define AGPU_FLAG_INDEX_RANGE 1u
 #define AGPU_PROF_ROCTX 1u   // roctx range named after the ABI call / reference entry point around every launch
 #define AGPU_PROF_TIMING 2u  // HIP event pair around every launch (agpu_pipeline_last_kernel_ns)

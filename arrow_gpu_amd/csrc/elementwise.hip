@@ -1561,7 +1561,7 @@ __global__ __launch_bounds__(AGPU_LUT8_BLOCK) void lut8_kernel(const TI* in, flo
       const uint32_t sel = lane & 3u;
       const uint32_t x = sel == 0 ? w0 : sel == 1 ? w1 : sel == 2 ? w2 : w3;
       f32x4 r = {lut[x & 255u], lut[(x >> 8) & 255u], lut[(x >> 16) & 255u], lut[x >> 24]};
-#if AGPU_LUT8_SC1
+#if AGPU_LUT8_SC1 && AGPU_USE_SC1
       st_vec_sc1(out4 + c * (AGPU_WAVE * 4) + (uint32_t)j * AGPU_WAVE + lane, r);
 #else
       __builtin_nontemporal_store(r, out4 + c * (AGPU_WAVE * 4) + (uint32_t)j * AGPU_WAVE + lane);
@@ -1694,7 +1694,7 @@ __global__ __launch_bounds__(BLOCK) void trig16_kernel(const TI* in, float* out,
         const uint32_t x = hi ? w2 : w0, y = hi ? w3 : w1;
         f32x4 r = {trig16_eval<TI, WANT_COS>(tab, x & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, x >> 16),
                    trig16_eval<TI, WANT_COS>(tab, y & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, y >> 16)};
-#if AGPU_TRIG16_SC1
+#if AGPU_TRIG16_SC1 && AGPU_USE_SC1
         st_vec_sc1(out4 + (c0 + (uint32_t)u) * (AGPU_WAVE * 2) + (uint32_t)j * AGPU_WAVE + lane, r);
 #else
         __builtin_nontemporal_store(r, out4 + (c0 + (uint32_t)u) * (AGPU_WAVE * 2) + (uint32_t)j * AGPU_WAVE + lane);

@@ -4,7 +4,9 @@
 // A pipeline is a HIP stream: launches are eager and ordered, `finish` is the (already satisfied) submit point.
 #include <rocprofiler-sdk-roctx/roctx.h>
 
+#include <chrono>
 #include <cstdlib>
+#include <thread>
 #include <memory>
 
 #include <algorithm>
@@ -33,7 +35,7 @@ static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
     /*stream_grid*/ {0}, /*stream_bpc*/ {0}, /*stream_unroll*/ {1}, /*stream_nt*/ {1}, /*cmp_variant*/ {0}, /*reduce_grid*/ {0},
     /*table_tiles*/ {0},  // 0 = each kernel's default (elementwise.hip tab_k: 1 for the HBM-bound table kernels, 3 for pow with a scalar exponent)
     /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}, /*gather_offsets*/ {0},
-    /*heavy_tiles*/ {0}, /*cast_tiles*/ {0}, /*tile_auto*/ {0}, /*wave_lds*/ {0}};
+    /*heavy_tiles*/ {0}, /*cast_tiles*/ {0}, /*tile_auto*/ {0}, /*wave_lds*/ {0}, /*sync_spin*/ {0}};
 // DEV SWITCH (tools/probe, docs/experiments.md R5): AGPU_DEVICE_MALLOC_FLAGS=<hipExtMallocWithFlags flags> makes every block the
 // pool, the arenas and the tables take from the driver a hipDeviceMallocContiguous (4) / Uncached (3) / Finegrained (1) one.
 // Unset or 0 = plain hipMalloc, which is what the product ships with.
@@ -46,7 +48,7 @@ static std::atomic<int64_t> g_pool_arena{1};  // 1 = pool blocks of ≥ 1 GiB co
 static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "stream_bpc", "stream_unroll", "stream_nt",
                                                          "cmp_variant", "reduce_grid", "table_tiles", "gather_bucket",
                                                          "h2d_mode", "h2d_threads", "gather_region_bits", "gather_offsets",
-                                                         "heavy_tiles", "cast_tiles", "tile_auto", "wave_lds"};
+                                                         "heavy_tiles", "cast_tiles", "tile_auto", "wave_lds", "sync_spin"};
 
 agpu_tuning agpu_tuning_defaults() {
   agpu_tuning t;
@@ -485,12 +487,12 @@ agpu_status agpu_device_destroy(agpu_device* dev) {
   return AGPU_OK;
 }
 
+static agpu_status device_wait_all(agpu_device* dev, const void* src_dev, size_t bytes, void* dst_host);  // below, with the mailbox
 agpu_status agpu_device_sync(agpu_device* dev) {
   AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
   AGPU_NOT_POISONED(dev);
   AGPU_HIP(hipSetDevice(dev->ordinal));
-  AGPU_HIP(hipDeviceSynchronize());
-  return AGPU_OK;
+  return device_wait_all(dev, nullptr, 0, nullptr);
 }
 
 agpu_status agpu_device_name(agpu_device* dev, char* out, size_t out_cap) {
@@ -811,23 +813,209 @@ agpu_status agpu_malloc_table(agpu_device* dev, int32_t n_columns, const uint64_
   return AGPU_OK;
 }
 
+static void pipeline_mark_drained(agpu_pipeline* p);  // below, with the mailbox
 agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, size_t bytes) {
   AGPU_BIND(p);
   if (!bytes) return AGPU_OK;
   AGPU_REQUIRE(dst_dev && src_host, AGPU_ERR_ARG, "null pointer");
   // small and medium sources, and anything that lives in the brk heap, go through the library's own page-locked slots
   // (arrow_cdata.hip agpu_internal_host_copy: why); big separate mappings straight from the caller's pageable memory
-  return agpu_internal_host_copy(p, dst_dev, const_cast<void*>(src_host), bytes, true);
+  const agpu_status st = agpu_internal_host_copy(p, dst_dev, const_cast<void*>(src_host), bytes, true);
+  if (st == AGPU_OK && !p->capturing) pipeline_mark_drained(p);  // complete on return: the stream has drained (device-level waits skip it)
+  return st;
+}
+
+// The pipeline's mailbox (round 5, R5.10).  "One small kernel, one scalar back on the host" — the reference's own criterion shape
+// (compare_sum.rs: a u32 sum of 1 Mi rows) — costs 15 µs with hipMemcpyAsync D2H + hipStreamSynchronize and 12 µs with the
+// synchronize alone; a one-wave kernel that copies ≤ 64 bytes into pinned host memory and then posts a sequence number, with the host
+// spinning on that number, is back in 6.7 µs (9.7 µs behind another kernel; tools/probe/latency_probe.hip).  The stream is in order, so
+// the posted number also says that everything queued before it is over: agpu_pipeline_sync uses the same kernel with no payload.
+// The spin is bounded (tuning "sync_spin", 200 µs by default); after that the blocking hipStreamSynchronize takes over — a long queue
+// costs no core, a faulted queue reports its error there.
+__global__ __launch_bounds__(AGPU_WAVE) void mailbox_post_kernel(const unsigned char* src, uint32_t bytes, unsigned char* payload, uint64_t* seq_word,
+                                                              uint64_t seq) {
+  if (threadIdx.x < bytes) payload[threadIdx.x] = src[threadIdx.x];
+  __threadfence_system();  // one wave: its stores are issued in order, the fence and the release below make them visible to the host first
+  if (threadIdx.x == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the host has just waited for everything on p's stream: remember it on the pipeline (its next sync is free) and on the stream slot (device-level
+// waits skip it).  Only the outermost ABI call may say so — a nested one is followed by more work of its caller.
+static void pipeline_mark_drained(agpu_pipeline* p) {
+  p->dirty = false;
+  if (p->scope_depth == 1) p->slot->clean_enq.store(p->slot->enq.load(std::memory_order_relaxed) + 1, std::memory_order_release);  // + 1: this call's own exit
+}
+static bool mailbox_enabled(const agpu_pipeline* p) { return p->tune.sync_spin >= 0 && p->flags && !p->capturing; }
+// waits for everything queued on the pipeline's stream; bytes ≤ 64 of device memory are delivered into dst_host on the way
+static agpu_status pipeline_wait_mailbox(agpu_pipeline* p, const void* src_dev, size_t bytes, void* dst_host) {
+  char* slot = reinterpret_cast<char*>(p->flags);
+  uint64_t* seq_word = reinterpret_cast<uint64_t*>(slot + AGPU_MBOX_SEQ);
+  const uint64_t seq = ++p->mbox_seq;
+  hipLaunchKernelGGL(mailbox_post_kernel, dim3(1), dim3(AGPU_WAVE), 0, p->stream, static_cast<const unsigned char*>(src_dev), (uint32_t)bytes,
+                     reinterpret_cast<unsigned char*>(slot + AGPU_MBOX_PAYLOAD), seq_word, seq);
+  AGPU_LAUNCH_CHECK();
+  const int64_t budget_us = p->tune.sync_spin > 0 ? p->tune.sync_spin : 200;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool arrived = false;
+  for (;;) {
+    for (int i = 0; i < 128 && !arrived; i++) {
+      arrived = __atomic_load_n(seq_word, __ATOMIC_ACQUIRE) == seq;
+      if (!arrived) __builtin_ia32_pause();
+    }
+    if (arrived || std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= budget_us) break;
+  }
+  if (!arrived) {
+    AGPU_HIP(hipStreamSynchronize(p->stream));
+    if (__atomic_load_n(seq_word, __ATOMIC_ACQUIRE) != seq) {
+      agpu_set_error("the pipeline's mailbox was not posted although its stream is idle");
+      return AGPU_ERR_HIP;
+    }
+  }
+  if (bytes) memcpy(dst_host, slot + AGPU_MBOX_PAYLOAD, bytes);
+  pipeline_mark_drained(p);
+  return AGPU_OK;
+}
+
+// Device-level wait (agpu_device_sync, agpu_device_download): everything THIS LIBRARY has queued on the device — every pipeline, pooled stream
+// and wrapped stream.  hipDeviceSynchronize costs 11 µs behind one small kernel; the usual situation of the reference-style host API is ONE
+// stream with work outstanding (the immediate ops of one thread draw the same pooled stream again and again), and then the mailbox kernel
+// posted on THAT stream is back in 6–9 µs, with up to 64 bytes of payload on the way (`values()` of a reduction's result: one wait, not two).
+// No stream outstanding: nothing to wait for (the payload, if any, travels on an idle owned stream).  Two or more: hipDeviceSynchronize as
+// before — unless some pipeline is in graph capture: hipDeviceSynchronize would invalidate that capture (from any thread), so the outstanding
+// streams are then waited for one by one through the mailbox and the capturing stream is left alone (what it had queued before its capture
+// began is not waited for).  sync_spin < 0: hipDeviceSynchronize always.
+static uint32_t* flag_get_locked(agpu_device* dev);  // below, with the pipelines
+static bool slot_listed_locked(agpu_device* dev, agpu_stream_slot* s) {
+  for (agpu_stream_slot* x : dev->slots)
+    if (x == s) return true;
+  return false;
+}
+// posts the device's mailbox behind everything queued on `s` and waits for it; a slot that has left the device or entered a capture meanwhile
+// counts as done.  The launch happens under dev->mu: a stream leaves dev->slots, and a capture begins, under that mutex.
+static agpu_status device_post_and_wait(agpu_device* dev, agpu_stream_slot* s, const void* src_dev, size_t bytes, void* dst_host, int64_t spin) {
+  char* mb = reinterpret_cast<char*>(dev->mbox);
+  uint64_t* seq_word = reinterpret_cast<uint64_t*>(mb + AGPU_MBOX_SEQ);
+  uint64_t seq = 0;
+  {
+    std::lock_guard<std::mutex> lock(dev->mu);
+    if (!slot_listed_locked(dev, s) || s->capturing.load(std::memory_order_acquire)) {
+      if (bytes) AGPU_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));  // (rare: the stream went away between the scan and now)
+      return AGPU_OK;
+    }
+    seq = ++dev->mbox_seq;
+    hipLaunchKernelGGL(mailbox_post_kernel, dim3(1), dim3(AGPU_WAVE), 0, s->stream, static_cast<const unsigned char*>(src_dev), (uint32_t)bytes,
+                       reinterpret_cast<unsigned char*>(mb + AGPU_MBOX_PAYLOAD), seq_word, seq);
+    AGPU_LAUNCH_CHECK();
+  }
+  const int64_t budget_us = spin > 0 ? spin : 200;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool arrived = false;
+  for (;;) {
+    for (int i = 0; i < 128 && !arrived; i++) {
+      arrived = __atomic_load_n(seq_word, __ATOMIC_ACQUIRE) == seq;
+      if (!arrived) __builtin_ia32_pause();
+    }
+    if (arrived || std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= budget_us) break;
+  }
+  // a long queue: sleep-poll (no core burnt, no runtime wait that would hold dev->mu or touch a capture); every 5 ms ask the stream whether it
+  // is still alive — a faulted queue never posts
+  for (int polls = 0; !arrived; polls++) {
+    std::this_thread::sleep_for(std::chrono::microseconds(polls < 20 ? 50 : 200));
+    arrived = __atomic_load_n(seq_word, __ATOMIC_ACQUIRE) == seq;
+    if (arrived || polls % 25 != 24) continue;
+    std::lock_guard<std::mutex> lock(dev->mu);
+    if (!slot_listed_locked(dev, s)) break;
+    const hipError_t q = hipStreamQuery(s->stream);
+    if (q == hipErrorNotReady) continue;
+    arrived = __atomic_load_n(seq_word, __ATOMIC_ACQUIRE) == seq;
+    if (q != hipSuccess || !arrived) {
+      agpu_set_error("device wait: the stream stopped without posting the mailbox: %s", hipGetErrorString(q));
+      return AGPU_ERR_HIP;
+    }
+  }
+  if (bytes) memcpy(dst_host, mb + AGPU_MBOX_PAYLOAD, bytes);
+  return AGPU_OK;
+}
+
+static agpu_status device_wait_all(agpu_device* dev, const void* src_dev, size_t bytes, void* dst_host) {
+  std::lock_guard<std::mutex> one_wait(dev->mbox_mu);
+  struct Seen { agpu_stream_slot* s; uint64_t enq; };
+  std::vector<Seen> seen;
+  std::vector<agpu_stream_slot*> targets;
+  const int64_t spin = g_tune_default[tune_index("sync_spin")].load(std::memory_order_relaxed);  // process-wide: a device has no tuning of its own
+  bool any_capturing = false, have_mbox = false;
+  {
+    std::lock_guard<std::mutex> lock(dev->mu);
+    if (spin >= 0 && !dev->mbox) {
+      dev->mbox = flag_get_locked(dev);
+      if (dev->mbox) dev->mbox_seq = *reinterpret_cast<volatile uint64_t*>(reinterpret_cast<char*>(dev->mbox) + AGPU_MBOX_SEQ);
+    }
+    have_mbox = spin >= 0 && dev->mbox;
+    agpu_stream_slot* idle_owned = nullptr;
+    for (agpu_stream_slot* s : dev->slots) {
+      if (s->capturing.load(std::memory_order_acquire)) {
+        any_capturing = true;
+        continue;
+      }
+      const uint64_t e = s->enq.load(std::memory_order_acquire);
+      seen.push_back(Seen{s, e});
+      // drained: no call since the last completed wait (a wrapped stream also carries work this library never saw: never "drained")
+      if (s->owned && (e & ~1ull) == s->clean_enq.load(std::memory_order_acquire) && !(e & 1)) {
+        if (!idle_owned) idle_owned = s;
+        continue;
+      }
+      targets.push_back(s);
+    }
+    if (targets.empty()) {
+      if (!bytes) return AGPU_OK;
+      if (idle_owned && have_mbox) targets.push_back(idle_owned);
+    }
+  }
+  const bool by_mailbox = have_mbox && !targets.empty() && (targets.size() == 1 || any_capturing);
+  if (by_mailbox) {
+    for (size_t k = 0; k < targets.size(); k++) {
+      const bool last = k + 1 == targets.size();
+      const agpu_status st = device_post_and_wait(dev, targets[k], last ? src_dev : nullptr, last ? bytes : 0, last ? dst_host : nullptr, spin);
+      if (st != AGPU_OK) return st;
+    }
+  } else {
+    AGPU_HIP(hipDeviceSynchronize());
+    if (bytes) AGPU_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  }
+  // what was queued when this wait began is over (an odd count: the call that was in progress may still add work — clean up to the call before it)
+  std::lock_guard<std::mutex> lock(dev->mu);
+  for (agpu_stream_slot* s : dev->slots)  // (a slot may have left the device meanwhile: only those still listed are touched)
+    for (const Seen& x : seen) {
+      if (x.s != s) continue;
+      const uint64_t upto = x.enq & ~1ull;
+      uint64_t cur = s->clean_enq.load(std::memory_order_relaxed);
+      while (cur < upto && !s->clean_enq.compare_exchange_weak(cur, upto, std::memory_order_release)) {}
+    }
+  return AGPU_OK;
+}
+
+agpu_status agpu_device_download(agpu_device* dev, void* dst_host, const void* src_dev, size_t bytes) {
+  AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
+  AGPU_REQUIRE(bytes <= 64, AGPU_ERR_ARG, "at most 64 bytes (a scalar); bigger reads go through agpu_device_sync + agpu_download");
+  AGPU_REQUIRE(!bytes || (dst_host && src_dev), AGPU_ERR_ARG, "null pointer");
+  AGPU_NOT_POISONED(dev);
+  AGPU_HIP(hipSetDevice(dev->ordinal));
+  return device_wait_all(dev, src_dev, bytes, dst_host);
 }
 
 agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev, size_t bytes) {
+  const bool was_dirty = p && p->dirty;
   AGPU_BIND(p);
   if (!bytes) {
+    if (was_dirty && mailbox_enabled(p)) return pipeline_wait_mailbox(p, nullptr, 0, nullptr);
     AGPU_HIP(hipStreamSynchronize(p->stream));
+    pipeline_mark_drained(p);
     return AGPU_OK;
   }
   AGPU_REQUIRE(dst_host && src_dev, AGPU_ERR_ARG, "null pointer");
-  return agpu_internal_host_copy(p, const_cast<void*>(src_dev), dst_host, bytes, false);
+  if (bytes <= 64 && mailbox_enabled(p)) return pipeline_wait_mailbox(p, src_dev, bytes, dst_host);  // a scalar: a reduction's result, a count
+  const agpu_status st = agpu_internal_host_copy(p, const_cast<void*>(src_dev), dst_host, bytes, false);
+  if (st == AGPU_OK && !p->capturing) pipeline_mark_drained(p);  // complete on return: the stream has drained
+  return st;
 }
 
 agpu_status agpu_host_alloc(agpu_device* dev, size_t bytes, void** out_host_ptr) {
@@ -923,14 +1111,14 @@ static uint32_t* flag_get_locked(agpu_device* dev) {
     }
   }
   if (dev->flag_free.empty()) {
-    void* slab = nullptr;  // pinned + device-visible under unified addressing; 64 words, 64 B apart
+    void* slab = nullptr;  // pinned + device-visible under unified addressing; 16 slots of 256 B: error word, mailbox payload, mailbox sequence word
     if (hipHostMalloc(&slab, 4096, hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
       return nullptr;
     }
     memset(slab, 0, 4096);
     dev->flag_slabs.push_back(slab);
-    for (int i = 63; i >= 0; i--) dev->flag_free.push_back(reinterpret_cast<uint32_t*>(static_cast<char*>(slab) + 64 * i));
+    for (int i = 15; i >= 0; i--) dev->flag_free.push_back(reinterpret_cast<uint32_t*>(static_cast<char*>(slab) + AGPU_FLAG_SLOT_BYTES * i));
   }
   uint32_t* w = dev->flag_free.back();
   dev->flag_free.pop_back();
@@ -948,6 +1136,9 @@ static agpu_pipeline* pipeline_new(agpu_device* dev, agpu_stream_slot* slot, boo
   p->seen_gen = 0;  // first call orders the stream behind everything other pipelines have finished so far
   p->tune = agpu_tuning_defaults();
   p->flags = flags;
+  // the slot's sequence word keeps counting across owners (a slot is only handed out again once its previous owner's kernels are over)
+  p->mbox_seq = *reinterpret_cast<volatile uint64_t*>(reinterpret_cast<char*>(flags) + AGPU_MBOX_SEQ);
+  p->dirty = true;
   p->profile = env_profile();
   p->scope_depth = 0;
   p->t0 = p->t1 = nullptr;
@@ -1037,8 +1228,15 @@ agpu_status agpu_pipeline_finish(agpu_pipeline* p) {
 }
 
 agpu_status agpu_pipeline_sync(agpu_pipeline* p) {
+  const bool was_dirty = p && p->dirty;
   AGPU_BIND(p);
-  AGPU_HIP(hipStreamSynchronize(p->stream));
+  if (was_dirty && mailbox_enabled(p)) {
+    const agpu_status st = pipeline_wait_mailbox(p, nullptr, 0, nullptr);
+    if (st != AGPU_OK) return st;
+  } else {
+    AGPU_HIP(hipStreamSynchronize(p->stream));
+    pipeline_mark_drained(p);
+  }
   if (p->flags && *p->flags) {  // sticky kernel-side errors surface here, once
     const uint32_t f = *p->flags;
     *p->flags = 0;
@@ -1067,6 +1265,7 @@ agpu_status agpu_pipeline_destroy(agpu_pipeline* p) {
     if (g) (void)hipGraphDestroy(g);
     (void)hipGetLastError();
     p->capturing = false;
+    p->slot->capturing.store(false, std::memory_order_release);
   }
   if (p->owns_stream && agpu_mem_pool_enabled()) {
     // back to the pool WITHOUT waiting: queued work keeps running, the next owner's launches are ordered behind it.
@@ -1138,7 +1337,17 @@ agpu_status agpu_pipeline_begin_capture(agpu_pipeline* p) {
     AGPU_BIND(p);  // orders the stream behind other pipelines' finished work BEFORE the capture starts
   }
   AGPU_REQUIRE(!p->capturing, AGPU_ERR_ARG, "already capturing");
-  AGPU_HIP(hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal));
+  hipError_t ce;
+  {  // under dev->mu: a device-level wait on another thread checks the flag and launches its post kernel under the same mutex — never into a capture
+    std::lock_guard<std::mutex> lock(p->dev->mu);
+    p->slot->capturing.store(true, std::memory_order_release);
+    ce = hipStreamBeginCapture(p->stream, hipStreamCaptureModeThreadLocal);
+    if (ce != hipSuccess) p->slot->capturing.store(false, std::memory_order_release);
+  }
+  if (ce != hipSuccess) {
+    agpu_set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(ce));
+    return AGPU_ERR_HIP;
+  }
   p->capturing = true;
   return AGPU_OK;
 }
@@ -1150,7 +1359,9 @@ agpu_status agpu_pipeline_end_capture(agpu_pipeline* p, agpu_graph** out_graph) 
   AGPU_REQUIRE(p->capturing, AGPU_ERR_ARG, "not capturing");
   p->capturing = false;
   hipGraph_t g = nullptr;
-  AGPU_HIP(hipStreamEndCapture(p->stream, &g));
+  const hipError_t ee = hipStreamEndCapture(p->stream, &g);
+  p->slot->capturing.store(false, std::memory_order_release);
+  AGPU_HIP(ee);
   hipGraphExec_t ex = nullptr;
   hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   if (e != hipSuccess) {
@@ -1473,6 +1684,7 @@ agpu_status agpu_scope_enter(agpu_pipeline* p, const char* name) {
     }
   }
   if (p->scope_depth++ == 0) p->slot->enq.fetch_add(1, std::memory_order_release);  // odd: call in progress
+  p->dirty = true;
   return AGPU_OK;
 }
 

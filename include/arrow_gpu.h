@@ -128,7 +128,14 @@ size_t agpu_bitmap_bytes(uint64_t n_bits); /* ceil(n_bits/64)*8 : allocation siz
 agpu_status agpu_device_count(int32_t* out_count);
 agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device);
 agpu_status agpu_device_destroy(agpu_device* dev);
+/* agpu_device_sync waits for everything THIS LIBRARY has queued on the device: every pipeline's stream, pooled streams of destroyed pipelines,
+ * wrapped streams (work other runtimes queued on streams of their own is theirs to wait for).  With ONE stream outstanding — the usual
+ * state behind the reference-style immediate ops of one thread — the wait goes through a kernel that posts into pinned host memory
+ * (tuning "sync_spin", docs/experiments.md R5.10: 6–9 µs instead of hipDeviceSynchronize's 11); otherwise it IS hipDeviceSynchronize.
+ * agpu_device_download: the same wait with up to 64 bytes of device memory delivered on the way — `values()` of a reduction's result in one
+ * wait instead of two [ref: GpuDevice::retrive_data gpu_device.rs:232-265 polls the whole queue, then maps the staging buffer]. */
 agpu_status agpu_device_sync(agpu_device* dev);
+agpu_status agpu_device_download(agpu_device* dev, void* dst_host, const void* src_dev, size_t bytes);
 agpu_status agpu_device_name(agpu_device* dev, char* out, size_t out_cap); /* e.g. "gfx950:sramecc+:xnack-" */
 agpu_status agpu_device_ordinal(agpu_device* dev, int32_t* out_ordinal);
 agpu_status agpu_device_mem_info(agpu_device* dev, uint64_t* out_free, uint64_t* out_total);
@@ -239,7 +246,7 @@ agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, con
 
 /* Launch tuning (bench sweeps; defaults are the measured best).  key ∈ {"stream_grid","stream_bpc","stream_unroll",
  * "stream_nt","cmp_variant","reduce_grid","table_tiles","gather_bucket","gather_region_bits","gather_offsets","h2d_mode",
- * "h2d_threads","heavy_tiles","cast_tiles","tile_auto","wave_lds"}; unknown key → AGPU_ERR_ARG.  heavy_tiles / cast_tiles / table_tiles: tiles per block of the
+ * "h2d_threads","heavy_tiles","cast_tiles","tile_auto","wave_lds","sync_spin"}; unknown key → AGPU_ERR_ARG.  heavy_tiles / cast_tiles / table_tiles: tiles per block of the
  * VALU-heavy f32 unary kernels / chunks per wave of the widening casts / tiles per block of the LDS-table kernels, the next one's loads issued
  * before the current one is evaluated; 0 = auto.  tile_auto: 0 (default) = for launches that move >= 256 MiB "auto" is ADAPTIVE — one or two
  * tiles per block, whichever the device measured faster on these buffers (eight timed launches per kernel, size class and buffer
@@ -247,6 +254,10 @@ agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, con
  * from addresses: docs/experiments.md R5.4); 1 = static defaults; a value > 1 = adaptive with that many bytes as the threshold (tests).  wave_lds: unused dynamic LDS
  * per wave that caps the waves per CU of sin / cos f32, the widening casts to 32 bits and the 8-bit table kernels (0 = each kernel's measured
  * default, ≈ 24 or 16 waves per CU instead of 32: +3–9 % on those kernels, docs/experiments.md R5.5; < 0 = no cap; > 0 = that many bytes).
+ * sync_spin: agpu_pipeline_sync and agpu_download of <= 64 bytes wait through the pipeline's pinned MAILBOX — a one-wave kernel queued behind
+ * the pipeline's work copies the bytes into pinned host memory and posts a sequence number the host spins on (one kernel + one scalar back:
+ * 6.7 µs instead of 15; docs/experiments.md R5.10).  0 (default) = on, the host spins for at most 200 µs and then blocks in
+ * hipStreamSynchronize; > 0 = that many µs; < 0 = off (hipMemcpyAsync + hipStreamSynchronize).
  * Results never depend on any of these.  gather_bucket: 0 = auto (size thresholds + the device-side locality probe), 1 = direct
  * kernels, 2 = bucketed pipelines whenever the shape qualifies, 3 = like 2 with the round-2 pair pipeline for takes, 4 = like 2 but with the probe (tests);
  * gather_offsets: range starts of the pair pipeline (1 = atomics, 2 = column scans for both passes, 3 = default, 6 = default with one atomic per range, 8 / 4 = round 3's partition / partition + gather passes).  Every pipeline carries its own copy: agpu_set_tuning changes the process default that pipelines

@@ -7,6 +7,7 @@ import numpy as np
 import arrow_gpu_amd as ag
 from arrow_gpu_amd import _capi as capi
 from arrow_gpu_amd.gpu_utils import ArrowComputePipeline, CmpQuery, GpuDevice
+if os.environ.get("SYNC_SPIN"): capi.call("agpu_set_tuning", b"sync_spin", int(os.environ["SYNC_SPIN"]))   # < 0: the waits without the mailbox (R5.10)
 dev = GpuDevice(0); p = ArrowComputePipeline(dev, "sr"); q = CmpQuery(dev); h = p._handle
 for n in (1 << 20, 10 << 20, 64 << 20):
     a = dev.create_gpu_buffer_with_data(np.arange(n, dtype=np.uint32))
@@ -26,3 +27,11 @@ for n in (1 << 20, 10 << 20, 64 << 20):
     for _ in range(200):
         t0 = time.perf_counter(); s = arr.sum(); dev.sync(); ws.append((time.perf_counter() - t0) * 1e6)
     print(f"host API UInt32ArrayGPU.sum() {n >> 20} Mi rows: best {min(ws):.1f} median {sorted(ws)[100]:.1f} us", flush=True)
+    ws = []
+    for _ in range(200):
+        t0 = time.perf_counter(); f(); v = dev.retrive_data(r, 4, pipeline=p); ws.append((time.perf_counter() - t0) * 1e6)
+    print(f"agpu_reduce + download of the scalar {n >> 20} Mi rows: best {min(ws):.1f} median {sorted(ws)[100]:.1f} us (value {int(v.view(np.uint32)[0]) if False else v.view(np.uint32)[0]})", flush=True)
+    ws = []
+    for _ in range(200):
+        t0 = time.perf_counter(); v = arr.sum().values(); ws.append((time.perf_counter() - t0) * 1e6)
+    print(f"host API UInt32ArrayGPU.sum().values() {n >> 20} Mi rows: best {min(ws):.1f} median {sorted(ws)[100]:.1f} us ({v})", flush=True)
