@@ -976,6 +976,9 @@ def main():
             u = ag.UInt32ArrayGPU.broadcast(2, rows_, dev)
             w[label] = best_ms(lambda u=u: u.sum())
             assert int(u.sum().raw_values()[0]) == 2 * rows_
+            # … and with the VALUE on the host (what the CPU kernel returns): sum() + raw_values(), one device-level wait that carries the
+            # scalar back through the device's pinned mailbox (round 5, R5.10; it was a device sync + a copy + a stream sync)
+            w[label.replace("_ms", "_value_on_host_ms")] = best_ms(lambda u=u: u.sum().raw_values())
         w["what"] = "host API call + device sync per iteration (new pipeline + new output buffer per call, like the reference), best of 15"
         extra["reference_bench_workloads_gpu"] = w
     if rank == 0:
