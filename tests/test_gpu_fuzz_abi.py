@@ -34,7 +34,7 @@ def D(_dev):
     _dev.release()
     _dev.p.set_tuning("gather_bucket", 0)
     _dev.p.set_tuning("gather_offsets", 0)
-    for key in ("heavy_tiles", "cast_tiles", "table_tiles", "tile_auto", "wave_lds"):
+    for key in ("heavy_tiles", "cast_tiles", "table_tiles", "tile_auto", "wave_lds", "sync_spin"):
         _dev.p.set_tuning(key, 0)
 
 
@@ -70,6 +70,7 @@ def test_random_abi_calls_match_the_oracle(D, seed):
         # the adaptive policy behind "auto" with a threshold small enough for the fuzz's sizes: whatever it samples or decides, same results
         D.p.set_tuning("tile_auto", int((0, 1, 4096, 4096)[rng.integers(4)]))
         D.p.set_tuning("wave_lds", int((0, 0, -1, 3000, 40000)[rng.integers(5)]))  # occupancy cap of sin / cos, the widening casts, the 8-bit table kernels
+        D.p.set_tuning("sync_spin", int((0, 0, -1, 1, 30)[rng.integers(5)]))  # the mailbox waits (R5.10): on, off, a spin budget that mostly / sometimes runs out
         # take / put: the direct kernels (auto at these sizes), the forced pipelines (2: merge-back take, pair-pipeline put;
         # 3: pair-pipeline take) and all three range-start variants — small, ragged, mis-aligned inputs through every form
         D.p.set_tuning("gather_bucket", int((0, 2, 3, 4, 4)[rng.integers(5)]))  # 4: pipelines + the device-side probe at any size
