@@ -884,6 +884,17 @@ static agpu_status pipeline_wait_mailbox(agpu_pipeline* p, const void* src_dev, 
 // streams are then waited for one by one through the mailbox and the capturing stream is left alone (what it had queued before its capture
 // began is not waited for).  sync_spin < 0: hipDeviceSynchronize always.
 static uint32_t* flag_get_locked(agpu_device* dev);  // below, with the pipelines
+// in graph capture — by one of this library's pipelines, or (a wrapped stream) by whoever owns it, e.g. torch.cuda.graph
+static bool slot_capturing(agpu_stream_slot* s) {
+  if (s->capturing.load(std::memory_order_acquire)) return true;
+  if (s->owned) return false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s->stream, &st) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return st != hipStreamCaptureStatusNone;
+}
 static bool slot_listed_locked(agpu_device* dev, agpu_stream_slot* s) {
   for (agpu_stream_slot* x : dev->slots)
     if (x == s) return true;
@@ -897,7 +908,7 @@ static agpu_status device_post_and_wait(agpu_device* dev, agpu_stream_slot* s, c
   uint64_t seq = 0;
   {
     std::lock_guard<std::mutex> lock(dev->mu);
-    if (!slot_listed_locked(dev, s) || s->capturing.load(std::memory_order_acquire)) {
+    if (!slot_listed_locked(dev, s) || slot_capturing(s)) {
       if (bytes) AGPU_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));  // (rare: the stream went away between the scan and now)
       return AGPU_OK;
     }
@@ -952,7 +963,7 @@ static agpu_status device_wait_all(agpu_device* dev, const void* src_dev, size_t
     have_mbox = spin >= 0 && dev->mbox;
     agpu_stream_slot* idle_owned = nullptr;
     for (agpu_stream_slot* s : dev->slots) {
-      if (s->capturing.load(std::memory_order_acquire)) {
+      if (slot_capturing(s)) {
         any_capturing = true;
         continue;
       }
