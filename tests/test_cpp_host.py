@@ -250,3 +250,38 @@ def test_ipc_example_on_gpu(tmp_path):
     exp = O.binary(O.OP_ADD, O.F32, a, b)
     assert np.array_equal(s.fill_null(0).to_numpy(zero_copy_only=False).view(np.uint32)[vs], exp.view(np.uint32)[vs])
     assert np.array_equal(np.asarray(e.fill_null(False))[ve], (k == m)[ve])
+
+
+# ---- the reference's criterion shapes from the C++ host, the value on the host at the end of every iteration (examples/latency.cpp)
+L_SRC = os.path.join(ROOT, "examples", "latency.cpp")
+L_EXE = os.path.join(ROOT, "tests", "cpp", "build", "latency")
+
+
+def build_latency():
+    os.makedirs(os.path.dirname(L_EXE), exist_ok=True)
+    deps = [L_SRC, os.path.join(ROOT, "host", "arrow_gpu.hpp"), os.path.join(ROOT, "include", "arrow_gpu.h")]
+    if os.path.exists(L_EXE) and all(os.path.getmtime(L_EXE) >= os.path.getmtime(d) for d in deps):
+        return
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-Wall", "-x", "c++", L_SRC, "-o", L_EXE, f"-L{LIBDIR}", "-larrow_gpu_hip",
+           "-Wl,-rpath," + LIBDIR]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_latency_example_compiles():
+    build_latency()
+
+
+@pytest.mark.gpu
+def test_latency_example_returns_the_sums():
+    """the program checks every sum it reads back (2 n); the times are reported, not asserted — except that a value on the host must not cost a
+    millisecond (a wait that fell through to a blocking path on every iteration would)"""
+    import json
+
+    build_latency()
+    r = subprocess.run([L_EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"exit {r.returncode}: " + r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("u32_sum_1Mi_value_on_host_us", "u32_sum_10Mi_value_on_host_us", "u32_sum_1Mi_device_sync_us", "f32_add_scalar_10Mi_device_sync_us"):
+        assert 1.0 < line[k]["best"] <= line[k]["median"] < 1000.0, (k, line[k])
+    print(json.dumps(line))
