@@ -373,7 +373,10 @@ __device__ __forceinline__ void st_vec(V* p, V v) {
 // nontemporal).  tools/probe/cache_policy.hip tries all eight sc0 / sc1 / nt combinations on both sides of an f32 add (loads:
 // nt is what matters, the scope bits change nothing; stores: "sc1 nt" +0.7 %); in the product it is worth +2 % to the
 // 8 B/row kernels (unary / scalar: 0.831 → 0.848) and +3 % to the ×2 widening casts (i16 → f32 0.785 → 0.81), nothing to
-// the binary kernels, and it COSTS the 8-bit kernels and the ×4 widening casts 1–2 % — so it is opt-in per call site.
+// the binary kernels, and it COSTS the 8-bit kernels and the ×4 widening casts 1–2 % AT 32 WAVES PER CU — so it is opt-in per call site.
+// Round 5: under the occupancy cap (wave_lds_for below) the ×4 answer flips — sc1 nt is +1–2 % for the u8 → 32-bit casts, the 8-bit and 16-bit table
+// kernels and the ×4 cast chain (docs/experiments.md R5.8); nontemporal LOADS stay 4–10 % ahead of plain ones with or without a cap
+// (tools/r05_ldnt.sh: sin 0.82 / 0.77, cos 0.825 / 0.73, add 0.835 / 0.775).
 template <typename V>
 __device__ __forceinline__ void st_vec_sc1(V* p, V v) {
   static_assert(sizeof(V) == 16, "16-byte vectors only");
