@@ -167,3 +167,25 @@ def test_pipeline_slots_are_recycled_with_their_sequence_numbers(dev):
         capi.call("agpu_download", p._handle, C.c_void_p(out.ctypes.data), _vp(a, 4 * (k % 60)), 8)
         assert out.tolist() == [k % 60, k % 60 + 1]
         del p
+
+
+def test_device_wait_behind_a_long_queue_sleeps_instead_of_spinning(dev):
+    """process-wide sync_spin = 1 µs: the device-level wait leaves its spin at once and sleep-polls the sequence word (with the stream's liveness
+    check every few milliseconds) behind ≈ 20 ms of queued kernels; the value it delivers is still the last kernel's"""
+    p = ArrowComputePipeline(dev, "long")
+    n = 200_000_000
+    a = dev.create_empty_buffer(4 * n)
+    out = dev.create_empty_buffer(16)
+    dev.sync()
+    capi.call("agpu_set_tuning", b"sync_spin", 1)
+    try:
+        for r in range(3):
+            for k in range(12):
+                capi.call("agpu_synth_i32", p._handle, _vp(a), n, 31 * r + k, 0, 1 << 20)
+            capi.call("agpu_reduce", p._handle, capi.RED_MAX, capi.I32, _vp(a), None, n, _vp(out))
+            got = dev.retrive_data(out, 4).view(np.int32)[0]
+            exp = np.zeros(1, np.int32)
+            capi.call("agpu_download", p._handle, C.c_void_p(exp.ctypes.data), _vp(out), 4)
+            assert got == exp[0] and 0 < got < (1 << 20)
+    finally:
+        capi.call("agpu_set_tuning", b"sync_spin", 0)
