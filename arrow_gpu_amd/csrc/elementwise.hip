@@ -1480,7 +1480,13 @@ struct CvtF32ToInt {
 };
 template <typename TI, typename F>
 struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders/{u8,i8,u16,i16}/*.wgsl]
-  __device__ static __forceinline__ float ap(TI x) { return F::ap((float)x, 0.0f); }
+  __device__ static __forceinline__ float ap(TI x) {
+    // |x| ≤ 65 535 < 1e6: sin / cos never take the out-of-line |x| ≥ 1e6 path — the compiler sees that for u16 and not for i16 (8 calls to
+    // sincos_f32_slow and their register shuffling per 8 rows stayed in cvt_wide_kernel<short, …>); same bits either way
+    if constexpr (sizeof(TI) <= 2 && std::is_same<F, UnSin>::value) return sincos_f32_fast((float)x, 0);
+    else if constexpr (sizeof(TI) <= 2 && std::is_same<F, UnCos>::value) return sincos_f32_fast((float)x, 1);
+    else return F::ap((float)x, 0.0f);
+  }
 };
 
 // 8-bit sources (sin_u8 / cos_i8 / sinh_u8 …): only 256 distinct inputs exist, so evaluating the function per row
