@@ -10,6 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+MAILBOX_MAX_BYTES = 3840  # AGPU_MAILBOX_MAX_BYTES (include/arrow_gpu.h)
 LIB_PATH = os.environ.get("AGPU_LIB") or os.path.join(_HERE, "lib", "libarrow_gpu_hip.so")  # AGPU_LIB: A/B builds in tools/probe
 
 # status codes

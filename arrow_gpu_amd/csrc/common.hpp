@@ -39,7 +39,7 @@ struct agpu_tuning {
   int64_t cast_tiles;          // chunks per wave of the widening casts and cast-headed chains, next chunk prefetched the same way (0 = auto)
   int64_t tile_auto;           // 0 = the "auto" of heavy_tiles / cast_tiles / table_tiles is ADAPTIVE for big launches (one or two tiles per block, whichever the device measures faster on these buffers: runtime.hip agpu_tiles_pick); 1 = static defaults (one tile); > 1 = adaptive with this many bytes as the threshold instead of 256 MiB (tests)
   int64_t wave_lds;            // unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the ×2 / ×4 widening casts and the 8-bit table kernels: 0 = each kernel's measured default (6800 B ≈ 24 waves per CU; u8 → 32-bit casts 10240 B ≈ 16), < 0 = no cap, > 0 = this many bytes
-  int64_t sync_spin;           // agpu_pipeline_sync and downloads of ≤ 64 bytes wait for a kernel that posts into the pipeline's pinned mailbox instead of hipStreamSynchronize (12 → 7 µs for "one kernel, one scalar back"): 0 = yes, spinning for at most 200 µs before the blocking wait; > 0 = this many µs; < 0 = off
+  int64_t sync_spin;           // agpu_pipeline_sync and uploads / downloads of ≤ 3840 bytes wait for a kernel that posts into the pipeline's pinned mailbox instead of hipStreamSynchronize (12 → 7 µs for "one kernel, one scalar back"): 0 = yes, spinning for at most 200 µs before the blocking wait; > 0 = this many µs; < 0 = off
 };
 #define AGPU_TUNE_KEYS 17
 agpu_tuning agpu_tuning_defaults();  // snapshot of the process-wide defaults (atomics, runtime.hip)
@@ -225,8 +225,8 @@ struct agpu_pipeline {
   // sticky error word in pinned host memory, written by kernels (bit 0: take/put index out of range), read and cleared
   // by agpu_pipeline_sync — no pre-pass over the index column, no readback, the pipeline stays asynchronous
   uint32_t* flags;
-  // the same 256-byte pinned slot carries the pipeline's MAILBOX (runtime.hip pipeline_wait_mailbox): 64 payload bytes at +64 and a sequence
-  // word at +128 that a one-wave kernel posts behind everything queued so far; the host spins on it.  `dirty`: an ABI call has bound the
+  // the same 4 KiB pinned slot carries the pipeline's MAILBOX (runtime.hip pipeline_wait_mailbox): a sequence word at +128 that a one-wave
+  // kernel posts behind everything queued so far — the host spins on it — and 3840 payload bytes at +256 (small downloads AND uploads).  `dirty`: an ABI call has bound the
   // pipeline since the last completed wait (an idle stream keeps the plain, cheap hipStreamSynchronize).
   uint64_t mbox_seq;
   bool dirty;
@@ -237,9 +237,9 @@ struct agpu_pipeline {
   bool t_valid;
   const char* last_name;
 };
-#define AGPU_FLAG_SLOT_BYTES 256
-#define AGPU_MBOX_PAYLOAD 64   // byte offset of the mailbox payload inside a pipeline's pinned slot (64 bytes)
-#define AGPU_MBOX_SEQ 128      // byte offset of the mailbox sequence word
+#define AGPU_FLAG_SLOT_BYTES 4096
+#define AGPU_MBOX_SEQ 128      // byte offset of the mailbox sequence word inside a pipeline's pinned slot
+#define AGPU_MBOX_PAYLOAD 256  // byte offset of the mailbox payload: AGPU_MAILBOX_MAX_BYTES (include/arrow_gpu.h) = 4096 − 256
 #define AGPU_FLAG_INDEX_RANGE 1u
 #define AGPU_PROF_ROCTX 1u   // roctx range named after the ABI call / reference entry point around every launch
 #define AGPU_PROF_TIMING 2u  // HIP event pair around every launch (agpu_pipeline_last_kernel_ns)

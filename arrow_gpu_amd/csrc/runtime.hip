@@ -814,12 +814,17 @@ agpu_status agpu_malloc_table(agpu_device* dev, int32_t n_columns, const uint64_
 }
 
 static void pipeline_mark_drained(agpu_pipeline* p);  // below, with the mailbox
+static bool mailbox_enabled(const agpu_pipeline* p);
+static agpu_status pipeline_wait_mailbox(agpu_pipeline* p, const void* src_dev, size_t bytes, void* dst_host, void* upload_dst_dev, const void* upload_src_host);
 agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, size_t bytes) {
   AGPU_BIND(p);
   if (!bytes) return AGPU_OK;
   AGPU_REQUIRE(dst_dev && src_host, AGPU_ERR_ARG, "null pointer");
   // small and medium sources, and anything that lives in the brk heap, go through the library's own page-locked slots
   // (arrow_cdata.hip agpu_internal_host_copy: why); big separate mappings straight from the caller's pageable memory
+  // a small array (the reference's tests and examples live at 5–100 elements): through the pipeline's mailbox — the host fills the pinned payload,
+  // a one-wave kernel moves it into place and posts; 7 µs instead of the 15 of hipMemcpyAsync + hipStreamSynchronize, complete on return all the same
+  if (bytes <= AGPU_MAILBOX_MAX_BYTES && mailbox_enabled(p)) return pipeline_wait_mailbox(p, nullptr, bytes, nullptr, dst_dev, src_host);
   const agpu_status st = agpu_internal_host_copy(p, dst_dev, const_cast<void*>(src_host), bytes, true);
   if (st == AGPU_OK && !p->capturing) pipeline_mark_drained(p);  // complete on return: the stream has drained (device-level waits skip it)
   return st;
@@ -832,9 +837,16 @@ agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, s
 // the posted number also says that everything queued before it is over: agpu_pipeline_sync uses the same kernel with no payload.
 // The spin is bounded (tuning "sync_spin", 200 µs by default); after that the blocking hipStreamSynchronize takes over — a long queue
 // costs no core, a faulted queue reports its error there.
-__global__ __launch_bounds__(AGPU_WAVE) void mailbox_post_kernel(const unsigned char* src, uint32_t bytes, unsigned char* payload, uint64_t* seq_word,
+__global__ __launch_bounds__(AGPU_WAVE) void mailbox_post_kernel(const unsigned char* src, uint32_t bytes, unsigned char* dst, uint64_t* seq_word,
                                                               uint64_t seq) {
-  if (threadIdx.x < bytes) payload[threadIdx.x] = src[threadIdx.x];
+  // src → dst: device memory → the slot's payload (a download) or the payload → device memory (an upload); 16-byte vectors when both sides allow
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+    const uint32_t nv = bytes / 16;
+    for (uint32_t i = threadIdx.x; i < nv; i += AGPU_WAVE) reinterpret_cast<u32x4*>(dst)[i] = reinterpret_cast<const u32x4*>(src)[i];
+    for (uint32_t i = nv * 16 + threadIdx.x; i < bytes; i += AGPU_WAVE) dst[i] = src[i];
+  } else {
+    for (uint32_t i = threadIdx.x; i < bytes; i += AGPU_WAVE) dst[i] = src[i];
+  }
   __threadfence_system();  // one wave: its stores are issued in order, the fence and the release below make them visible to the host first
   if (threadIdx.x == 0) __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -844,14 +856,27 @@ static void pipeline_mark_drained(agpu_pipeline* p) {
   p->dirty = false;
   if (p->scope_depth == 1) p->slot->clean_enq.store(p->slot->enq.load(std::memory_order_relaxed) + 1, std::memory_order_release);  // + 1: this call's own exit
 }
+static_assert(AGPU_MAILBOX_MAX_BYTES == AGPU_FLAG_SLOT_BYTES - AGPU_MBOX_PAYLOAD, "the public limit is the slot's payload room");
 static bool mailbox_enabled(const agpu_pipeline* p) { return p->tune.sync_spin >= 0 && p->flags && !p->capturing; }
-// waits for everything queued on the pipeline's stream; bytes ≤ 64 of device memory are delivered into dst_host on the way
+// waits for everything queued on the pipeline's stream; bytes ≤ AGPU_MAILBOX_MAX_BYTES travel on the way: device → host (download: the kernel
+// fills the payload, the host copies it out after the post) or host → device (upload: the host fills the payload first, the kernel empties it)
 static agpu_status pipeline_wait_mailbox(agpu_pipeline* p, const void* src_dev, size_t bytes, void* dst_host) {
+  return pipeline_wait_mailbox(p, src_dev, bytes, dst_host, nullptr, nullptr);
+}
+static agpu_status pipeline_wait_mailbox(agpu_pipeline* p, const void* src_dev, size_t bytes, void* dst_host, void* upload_dst_dev,
+                                         const void* upload_src_host) {
   char* slot = reinterpret_cast<char*>(p->flags);
   uint64_t* seq_word = reinterpret_cast<uint64_t*>(slot + AGPU_MBOX_SEQ);
+  unsigned char* payload = reinterpret_cast<unsigned char*>(slot + AGPU_MBOX_PAYLOAD);
   const uint64_t seq = ++p->mbox_seq;
-  hipLaunchKernelGGL(mailbox_post_kernel, dim3(1), dim3(AGPU_WAVE), 0, p->stream, static_cast<const unsigned char*>(src_dev), (uint32_t)bytes,
-                     reinterpret_cast<unsigned char*>(slot + AGPU_MBOX_PAYLOAD), seq_word, seq);
+  if (upload_dst_dev) {
+    memcpy(payload, upload_src_host, bytes);
+    hipLaunchKernelGGL(mailbox_post_kernel, dim3(1), dim3(AGPU_WAVE), 0, p->stream, payload, (uint32_t)bytes, static_cast<unsigned char*>(upload_dst_dev),
+                       seq_word, seq);
+  } else {
+    hipLaunchKernelGGL(mailbox_post_kernel, dim3(1), dim3(AGPU_WAVE), 0, p->stream, static_cast<const unsigned char*>(src_dev), (uint32_t)bytes, payload,
+                       seq_word, seq);
+  }
   AGPU_LAUNCH_CHECK();
   const int64_t budget_us = p->tune.sync_spin > 0 ? p->tune.sync_spin : 200;
   const auto t0 = std::chrono::steady_clock::now();
@@ -870,7 +895,7 @@ static agpu_status pipeline_wait_mailbox(agpu_pipeline* p, const void* src_dev, 
       return AGPU_ERR_HIP;
     }
   }
-  if (bytes) memcpy(dst_host, slot + AGPU_MBOX_PAYLOAD, bytes);
+  if (bytes && !upload_dst_dev) memcpy(dst_host, payload, bytes);
   pipeline_mark_drained(p);
   return AGPU_OK;
 }
@@ -1006,7 +1031,7 @@ static agpu_status device_wait_all(agpu_device* dev, const void* src_dev, size_t
 
 agpu_status agpu_device_download(agpu_device* dev, void* dst_host, const void* src_dev, size_t bytes) {
   AGPU_REQUIRE(dev, AGPU_ERR_ARG, "null device");
-  AGPU_REQUIRE(bytes <= 64, AGPU_ERR_ARG, "at most 64 bytes (a scalar); bigger reads go through agpu_device_sync + agpu_download");
+  AGPU_REQUIRE(bytes <= AGPU_MAILBOX_MAX_BYTES, AGPU_ERR_ARG, "at most AGPU_MAILBOX_MAX_BYTES; bigger reads go through agpu_device_sync + agpu_download");
   AGPU_REQUIRE(!bytes || (dst_host && src_dev), AGPU_ERR_ARG, "null pointer");
   AGPU_NOT_POISONED(dev);
   AGPU_HIP(hipSetDevice(dev->ordinal));
@@ -1023,7 +1048,7 @@ agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev,
     return AGPU_OK;
   }
   AGPU_REQUIRE(dst_host && src_dev, AGPU_ERR_ARG, "null pointer");
-  if (bytes <= 64 && mailbox_enabled(p)) return pipeline_wait_mailbox(p, src_dev, bytes, dst_host);  // a scalar: a reduction's result, a count
+  if (bytes <= AGPU_MAILBOX_MAX_BYTES && mailbox_enabled(p)) return pipeline_wait_mailbox(p, src_dev, bytes, dst_host);  // a scalar, a small array
   const agpu_status st = agpu_internal_host_copy(p, const_cast<void*>(src_dev), dst_host, bytes, false);
   if (st == AGPU_OK && !p->capturing) pipeline_mark_drained(p);  // complete on return: the stream has drained
   return st;
@@ -1122,12 +1147,12 @@ static uint32_t* flag_get_locked(agpu_device* dev) {
     }
   }
   if (dev->flag_free.empty()) {
-    void* slab = nullptr;  // pinned + device-visible under unified addressing; 16 slots of 256 B: error word, mailbox payload, mailbox sequence word
-    if (hipHostMalloc(&slab, 4096, hipHostMallocDefault) != hipSuccess) {
+    void* slab = nullptr;  // pinned + device-visible under unified addressing; 16 slots of 4 KiB: error word, mailbox sequence word, mailbox payload
+    if (hipHostMalloc(&slab, 16 * AGPU_FLAG_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
       return nullptr;
     }
-    memset(slab, 0, 4096);
+    memset(slab, 0, 16 * AGPU_FLAG_SLOT_BYTES);
     dev->flag_slabs.push_back(slab);
     for (int i = 15; i >= 0; i--) dev->flag_free.push_back(reinterpret_cast<uint32_t*>(static_cast<char*>(slab) + AGPU_FLAG_SLOT_BYTES * i));
   }

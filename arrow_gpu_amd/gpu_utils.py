@@ -109,8 +109,8 @@ class GpuDevice:
         """Blocking read-back as bytes.  [ref: retrive_data gpu_device.rs:232-265]"""
         nbytes = buf.nbytes if nbytes is None else nbytes
         out = np.empty(nbytes, dtype=np.uint8)
-        if nbytes <= 64:  # (with or without `pipeline`: the device-level wait covers its stream too)
-            # a scalar (a reduction's result, a count): the device-level wait delivers it on the way — one wait instead of two
+        if nbytes <= capi.MAILBOX_MAX_BYTES:  # (with or without `pipeline`: the device-level wait covers its stream too)
+            # a scalar, a small array: the device-level wait delivers it on the way — one wait instead of two
             capi.call("agpu_device_download", self._handle, C.c_void_p(out.ctypes.data), C.c_void_p(buf.ptr if nbytes else 0), nbytes)
             return out
         self.sync()  # other pipelines may still be writing this buffer (the reference polls the whole queue)

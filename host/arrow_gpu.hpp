@@ -119,7 +119,7 @@ class GpuDevice : public std::enable_shared_from_this<GpuDevice> {
   }
   std::vector<uint8_t> retrive_data(const BufferPtr& b, uint64_t nbytes) {  // the only blocking call [gpu_device.rs:232-265]
     std::vector<uint8_t> out(nbytes);
-    if (nbytes <= 64) {  // a scalar (a reduction's result, a count): the device-level wait delivers it — one wait instead of two
+    if (nbytes <= AGPU_MAILBOX_MAX_BYTES) {  // a scalar, a small array: the device-level wait delivers it — one wait instead of two
       check(agpu_device_download(raw, out.data(), nbytes ? b->ptr : nullptr, nbytes), "agpu_device_download");
       return out;
     }

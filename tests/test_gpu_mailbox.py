@@ -23,22 +23,45 @@ def _vp(b, off=0):
 
 
 @pytest.mark.parametrize("spin", [0, -1, 1])
-def test_small_downloads_deliver_every_byte_at_any_offset(dev, spin):
-    """sizes 1..64 at odd offsets, 300 rounds with fresh contents: the mailbox payload, its fallback (spin = 1 µs ⇒ mostly the blocking path)
-    and the plain copy (spin < 0) agree with what was uploaded"""
+def test_small_copies_deliver_every_byte_at_any_offset(dev, spin):
+    """uploads and downloads of 1 … AGPU_MAILBOX_MAX_BYTES (and a few just above: the ordinary path) at odd device offsets, 200 rounds with
+    fresh contents: the mailbox payload, its fallback (spin = 1 µs ⇒ mostly the blocking path) and the plain copies (spin < 0) move exactly
+    the bytes asked for and nothing beside them"""
     p = ArrowComputePipeline(dev, "mb")
     p.set_tuning("sync_spin", spin)
-    rng = np.random.default_rng(5)
-    buf = dev.create_empty_buffer(4096)
-    for r in range(300):
-        data = rng.integers(0, 256, 4096, dtype=np.uint8)
-        capi.call("agpu_upload", p._handle, _vp(buf), C.c_void_p(data.ctypes.data), 4096)
-        for _ in range(4):
-            n = int(rng.integers(1, 65))
-            off = int(rng.integers(0, 4096 - 64))
-            out = np.zeros(n, np.uint8)
-            capi.call("agpu_download", p._handle, C.c_void_p(out.ctypes.data), _vp(buf, off), n)
-            assert np.array_equal(out, data[off:off + n]), (r, n, off)
+    rng = np.random.default_rng(5 + spin)
+    M = capi.MAILBOX_MAX_BYTES
+    buf = dev.create_empty_buffer(16384)
+    shadow = rng.integers(0, 256, 16384, dtype=np.uint8)
+    capi.call("agpu_upload", p._handle, _vp(buf), C.c_void_p(shadow.ctypes.data), 16384)
+    sizes = [1, 2, 3, 4, 15, 16, 17, 63, 64, 65, 255, 256, 1000, 2048, M - 1, M, M + 1, M + 17]
+    for r in range(200):
+        n = int(sizes[r % len(sizes)]) if r % 3 else int(rng.integers(1, M + 64))
+        off = int(rng.integers(0, 16384 - n)) if r % 2 else 16 * int(rng.integers(0, (16384 - n) // 16))
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        capi.call("agpu_upload", p._handle, _vp(buf, off), C.c_void_p(data.ctypes.data), n)
+        shadow[off:off + n] = data
+        m = int(sizes[(r * 7) % len(sizes)])
+        o2 = int(rng.integers(0, 16384 - m))
+        out = np.zeros(m + 2, np.uint8)
+        out[-2:] = (0xA5, 0x5A)
+        capi.call("agpu_download", p._handle, C.c_void_p(out.ctypes.data), _vp(buf, o2), m)
+        assert np.array_equal(out[:m], shadow[o2:o2 + m]) and out[-2] == 0xA5 and out[-1] == 0x5A, (r, n, off, m, o2)
+    full = dev.retrive_data(buf, 16384, pipeline=p)
+    assert np.array_equal(full, shadow)
+
+
+def test_device_download_of_a_small_array(dev):
+    """retrive_data of up to AGPU_MAILBOX_MAX_BYTES is one device-level wait that carries the bytes; one byte more takes sync + copy"""
+    p = ArrowComputePipeline(dev, "dd")
+    M = capi.MAILBOX_MAX_BYTES
+    x = np.arange(2048, dtype=np.float32)
+    a = dev.create_gpu_buffer_with_data(x)
+    b = dev.create_empty_buffer(4 * 2048)
+    for n in (5, 100, M // 4, M // 4 + 1, 2048):
+        capi.call("agpu_unary", p._handle, capi.UN_NEG, capi.F32, _vp(a), _vp(b), n)
+        got = dev.retrive_data(b, 4 * n).view(np.float32)
+        assert np.array_equal(got, -x[:n]), n
 
 
 def test_a_scalar_download_waits_for_the_kernels_before_it(dev):
