@@ -824,7 +824,8 @@ agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, s
   // (arrow_cdata.hip agpu_internal_host_copy: why); big separate mappings straight from the caller's pageable memory
   // a small array (the reference's tests and examples live at 5–100 elements): through the pipeline's mailbox — the host fills the pinned payload,
   // a one-wave kernel moves it into place and posts; 7 µs instead of the 15 of hipMemcpyAsync + hipStreamSynchronize, complete on return all the same
-  if (bytes <= AGPU_MAILBOX_MAX_BYTES && mailbox_enabled(p)) return pipeline_wait_mailbox(p, nullptr, bytes, nullptr, dst_dev, src_host);
+  // (up to 1 KiB: at 3.6 KB the kernel's reads from host memory cost what the DMA's set-up did — 17.9–20 µs against 17.7, tools/probe/small_arrays.py)
+  if (bytes <= 1024 && mailbox_enabled(p)) return pipeline_wait_mailbox(p, nullptr, bytes, nullptr, dst_dev, src_host);
   const agpu_status st = agpu_internal_host_copy(p, dst_dev, const_cast<void*>(src_host), bytes, true);
   if (st == AGPU_OK && !p->capturing) pipeline_mark_drained(p);  // complete on return: the stream has drained (device-level waits skip it)
   return st;

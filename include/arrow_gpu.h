@@ -135,7 +135,7 @@ agpu_status agpu_device_destroy(agpu_device* dev);
  * agpu_device_download: the same wait with up to AGPU_MAILBOX_MAX_BYTES of device memory delivered on the way — `values()` of a reduction's result or of a small array in one
  * wait instead of two [ref: GpuDevice::retrive_data gpu_device.rs:232-265 polls the whole queue, then maps the staging buffer]. */
 agpu_status agpu_device_sync(agpu_device* dev);
-#define AGPU_MAILBOX_MAX_BYTES 3840 /* what a pinned mailbox carries: agpu_device_download's limit; agpu_upload / agpu_download up to this size take the same route */
+#define AGPU_MAILBOX_MAX_BYTES 3840 /* what a pinned mailbox carries: agpu_device_download's limit; agpu_download up to this size and agpu_upload up to 1 KiB take the same route */
 agpu_status agpu_device_download(agpu_device* dev, void* dst_host, const void* src_dev, size_t bytes);
 agpu_status agpu_device_name(agpu_device* dev, char* out, size_t out_cap); /* e.g. "gfx950:sramecc+:xnack-" */
 agpu_status agpu_device_ordinal(agpu_device* dev, int32_t* out_ordinal);
@@ -255,7 +255,7 @@ agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, con
  * from addresses: docs/experiments.md R5.4); 1 = static defaults; a value > 1 = adaptive with that many bytes as the threshold (tests).  wave_lds: unused dynamic LDS
  * per wave that caps the waves per CU of sin / cos f32, the widening casts to 32 bits and the 8-bit table kernels (0 = each kernel's measured
  * default, ≈ 24 or 16 waves per CU instead of 32: +3–9 % on those kernels, docs/experiments.md R5.5; < 0 = no cap; > 0 = that many bytes).
- * sync_spin: agpu_pipeline_sync and agpu_upload / agpu_download of <= AGPU_MAILBOX_MAX_BYTES wait through the pipeline's pinned MAILBOX — a one-wave
+ * sync_spin: agpu_pipeline_sync, agpu_download of <= AGPU_MAILBOX_MAX_BYTES and agpu_upload of <= 1 KiB wait through the pipeline's pinned MAILBOX — a one-wave
  * kernel queued behind the pipeline's work copies the bytes into (out of) pinned host memory and posts a sequence number the host spins on
  * (one kernel + one scalar back: 6.7 µs instead of 15; docs/experiments.md R5.10).  0 (default) = on, the host spins for at most 200 µs and then blocks in
  * hipStreamSynchronize; > 0 = that many µs; < 0 = off (hipMemcpyAsync + hipStreamSynchronize).
