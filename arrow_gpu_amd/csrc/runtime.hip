@@ -974,7 +974,6 @@ static agpu_status device_post_and_wait(agpu_device* dev, agpu_stream_slot* s, c
 }
 
 static agpu_status device_wait_all(agpu_device* dev, const void* src_dev, size_t bytes, void* dst_host) {
-  std::lock_guard<std::mutex> one_wait(dev->mbox_mu);
   struct Seen { agpu_stream_slot* s; uint64_t enq; };
   std::vector<Seen> seen;
   std::vector<agpu_stream_slot*> targets;
@@ -1009,6 +1008,7 @@ static agpu_status device_wait_all(agpu_device* dev, const void* src_dev, size_t
   }
   const bool by_mailbox = have_mbox && !targets.empty() && (targets.size() == 1 || any_capturing);
   if (by_mailbox) {
+    std::lock_guard<std::mutex> one_wait(dev->mbox_mu);  // the device has ONE mailbox: one posted wait at a time (runtime waits below need no turn)
     for (size_t k = 0; k < targets.size(); k++) {
       const bool last = k + 1 == targets.size();
       const agpu_status st = device_post_and_wait(dev, targets[k], last ? src_dev : nullptr, last ? bytes : 0, last ? dst_host : nullptr, spin);

@@ -212,3 +212,38 @@ def test_device_wait_behind_a_long_queue_sleeps_instead_of_spinning(dev):
             assert got == exp[0] and 0 < got < (1 << 20)
     finally:
         capi.call("agpu_set_tuning", b"sync_spin", 0)
+
+
+def test_device_waits_from_every_thread_while_pipelines_come_and_go(dev):
+    """six threads, each: a short-lived pipeline per round (its stream goes back to the pool with work outstanding), a reduction, the result
+    through the DEVICE-level download — which may find one, several or no streams outstanding, and posts on whichever it finds"""
+    n = 1 << 21
+    errs = []
+    srcs = []
+    for k in range(6):
+        x = (np.arange(n, dtype=np.uint64) * (2 * k + 5) + k).astype(np.uint32)
+        srcs.append((dev.create_gpu_buffer_with_data(x), int(x.astype(np.uint64).sum() & 0xFFFFFFFF), int(x.max())))
+
+    def work(k):
+        try:
+            buf, s_exp, m_exp = srcs[k]
+            out = dev.create_empty_buffer(16)
+            for r in range(120):
+                p = ArrowComputePipeline(dev, f"churn{k}")
+                op, exp = (capi.RED_SUM, s_exp) if r % 2 == 0 else (capi.RED_MAX, m_exp)
+                capi.call("agpu_reduce", p._handle, op, capi.U32, _vp(buf), None, n, _vp(out))
+                capi.call("agpu_pipeline_finish", p._handle)
+                del p
+                got = int(dev.retrive_data(out, 4).view(np.uint32)[0])
+                assert got == exp, (k, r, got, exp)
+                if r % 40 == 39:
+                    dev.sync()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
