@@ -180,6 +180,14 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
     return AGPU_ERR_NO_DEVICE;
   }
   AGPU_REQUIRE(ordinal >= 0 && ordinal < n, AGPU_ERR_ARG, "device ordinal out of range");
+  {  // AGPU_SYNC_SPIN=<n>: the process-wide default of tuning "sync_spin" without a code change (−1 = every wait through the runtime, as before round 5)
+    static const bool once = [] {
+      const char* e = getenv("AGPU_SYNC_SPIN");
+      if (e && *e) g_tune_default[tune_index("sync_spin")].store(strtoll(e, nullptr, 10), std::memory_order_relaxed);
+      return true;
+    }();
+    (void)once;
+  }
   std::unique_ptr<agpu_device> d(new agpu_device());  // released on every early-error return below
   d->ordinal = ordinal;
   AGPU_HIP(hipSetDevice(ordinal));

@@ -258,7 +258,8 @@ agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, con
  * sync_spin: agpu_pipeline_sync, agpu_download of <= AGPU_MAILBOX_MAX_BYTES and agpu_upload of <= 1 KiB wait through the pipeline's pinned MAILBOX — a one-wave
  * kernel queued behind the pipeline's work copies the bytes into (out of) pinned host memory and posts a sequence number the host spins on
  * (one kernel + one scalar back: 6.7 µs instead of 15; docs/experiments.md R5.10).  0 (default) = on, the host spins for at most 200 µs and then blocks in
- * hipStreamSynchronize; > 0 = that many µs; < 0 = off (hipMemcpyAsync + hipStreamSynchronize).
+ * hipStreamSynchronize; > 0 = that many µs; < 0 = off (hipMemcpyAsync + hipStreamSynchronize).  AGPU_SYNC_SPIN=<n> in the environment sets the
+ * process-wide default before the first device is created.
  * Results never depend on any of these.  gather_bucket: 0 = auto (size thresholds + the device-side locality probe), 1 = direct
  * kernels, 2 = bucketed pipelines whenever the shape qualifies, 3 = like 2 with the round-2 pair pipeline for takes, 4 = like 2 but with the probe (tests);
  * gather_offsets: range starts of the pair pipeline (1 = atomics, 2 = column scans for both passes, 3 = default, 6 = default with one atomic per range, 8 / 4 = round 3's partition / partition + gather passes).  Every pipeline carries its own copy: agpu_set_tuning changes the process default that pipelines
