@@ -120,6 +120,10 @@ def test_device_sync_leaves_a_capturing_stream_alone(dev):
     """a pipeline in graph capture has 'work outstanding' as far as the counters go: a device-level wait (from another thread — the capturing
     thread itself may not synchronise) must not launch its post kernel into the capture: it would become a node of the graph and the host
     would wait for a kernel that never runs ('the device's mailbox was not posted')"""
+    import os
+
+    if int(os.environ.get("AGPU_SYNC_SPIN", "0") or 0) < 0:
+        pytest.skip("AGPU_SYNC_SPIN < 0: device waits are hipDeviceSynchronize, which invalidates an open capture (the behaviour before round 5)")
     p = ArrowComputePipeline(dev, "cap")
     n = 1 << 20
     a = dev.create_gpu_buffer_with_data(np.arange(n, dtype=np.float32))
