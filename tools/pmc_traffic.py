@@ -33,9 +33,9 @@ def short(name: str) -> str:
     return name[:140]
 
 
-def kernel_stats(round_):
+def kernel_stats(round_, which="trace"):
     rows = []
-    for f in find(f"prof_trace_{round_}/**/*kernel_stats.csv"):
+    for f in find(f"prof_{which}_{round_}/**/*kernel_stats.csv"):
         with open(f) as fh:
             rows.extend(list(csv.DictReader(fh)))
     return rows
@@ -63,6 +63,13 @@ def main():
             w = csv.DictWriter(fh, fieldnames=keys)
             w.writeheader()
             for r in stats:
+                w.writerow(r)
+    head = kernel_stats(round_, "trace_headline")  # the headline step alone (tools/profile_bench.sh pass 1b)
+    if head:
+        with open(os.path.join(ROOT, "profiles", f"{round_}_kernel_stats_headline.csv"), "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=list(head[0].keys()))
+            w.writeheader()
+            for r in head:
                 w.writerow(r)
     fetch = pmc(round_, "fetch", "FETCH_SIZE")
     write = pmc(round_, "write", "WRITE_SIZE")
