@@ -14,7 +14,7 @@ def med(fn, k=300):
     for _ in range(k):
         t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e6)
     return sorted(ts)[k // 2]
-for n in (5, 100, 900):
+for n in (5, 100, 900, 10_000, 60_000):
     x = np.arange(n, dtype=np.float32); y = x + 1
     a = ag.Float32ArrayGPU.from_slice(x, dev); b = ag.Float32ArrayGPU.from_slice(y, dev)
     r = a.add(b)
