@@ -230,6 +230,9 @@ struct agpu_pipeline {
   // pipeline since the last completed wait (an idle stream keeps the plain, cheap hipStreamSynchronize).
   uint64_t mbox_seq;
   bool dirty;
+  // the last thing queued is a runtime copy (agpu_upload_async / agpu_download_async): a kernel posted behind a copy-engine transfer waits for
+  // the engine's signal through a barrier packet — 10–15 µs more than the runtime's own wait on that signal (R5.10) — so the next sync is the runtime's
+  bool copy_tail;
   // profiling [ref: CmpQuery compute_query.rs:7-89, insert_debug_marker gpu_device.rs:132]
   uint32_t profile;    // AGPU_PROF_* bits
   int scope_depth;

@@ -1085,6 +1085,7 @@ agpu_status agpu_upload_async(agpu_pipeline* p, void* dst_dev, const void* src_p
   if (!bytes) return AGPU_OK;
   AGPU_REQUIRE(dst_dev && src_pinned, AGPU_ERR_ARG, "null pointer");
   AGPU_HIP(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, p->stream));
+  p->copy_tail = true;
   return AGPU_OK;
 }
 
@@ -1093,6 +1094,7 @@ agpu_status agpu_download_async(agpu_pipeline* p, void* dst_pinned, const void* 
   if (!bytes) return AGPU_OK;
   AGPU_REQUIRE(dst_pinned && src_dev, AGPU_ERR_ARG, "null pointer");
   AGPU_HIP(hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, p->stream));
+  p->copy_tail = true;
   return AGPU_OK;
 }
 
@@ -1273,9 +1275,9 @@ agpu_status agpu_pipeline_finish(agpu_pipeline* p) {
 }
 
 agpu_status agpu_pipeline_sync(agpu_pipeline* p) {
-  const bool was_dirty = p && p->dirty;
+  const bool was_dirty = p && p->dirty, copy_tail = p && p->copy_tail;
   AGPU_BIND(p);
-  if (was_dirty && mailbox_enabled(p)) {
+  if (was_dirty && !copy_tail && mailbox_enabled(p)) {
     const agpu_status st = pipeline_wait_mailbox(p, nullptr, 0, nullptr);
     if (st != AGPU_OK) return st;
   } else {
@@ -1730,6 +1732,7 @@ agpu_status agpu_scope_enter(agpu_pipeline* p, const char* name) {
   }
   if (p->scope_depth++ == 0) p->slot->enq.fetch_add(1, std::memory_order_release);  // odd: call in progress
   p->dirty = true;
+  p->copy_tail = false;
   return AGPU_OK;
 }
 
