@@ -934,23 +934,27 @@ static bool slot_listed_locked(agpu_device* dev, agpu_stream_slot* s) {
     if (x == s) return true;
   return false;
 }
-// posts the device's mailbox behind everything queued on `s` and waits for it; a slot that has left the device or entered a capture meanwhile
-// counts as done.  The launch happens under dev->mu: a stream leaves dev->slots, and a capture begins, under that mutex.
-static agpu_status device_post_and_wait(agpu_device* dev, agpu_stream_slot* s, const void* src_dev, size_t bytes, void* dst_host, int64_t spin) {
+// The device's mailbox has FOUR sequence words (slot bytes 128 … 159): up to three posts can be out at once — one per outstanding stream, waited
+// for together — plus the word the payload's post uses.
+// device_post: queues the post behind everything on `s` (payload optional: src → the slot's payload); *posted = false when the slot has left the
+// device or entered a capture meanwhile (it then counts as done).  The launch happens under dev->mu: a stream leaves dev->slots, and a
+// capture begins, under that mutex.
+static agpu_status device_post(agpu_device* dev, agpu_stream_slot* s, int word, const void* src_dev, size_t bytes, uint64_t* seq_out, bool* posted) {
   char* mb = reinterpret_cast<char*>(dev->mbox);
-  uint64_t* seq_word = reinterpret_cast<uint64_t*>(mb + AGPU_MBOX_SEQ);
-  uint64_t seq = 0;
-  {
-    std::lock_guard<std::mutex> lock(dev->mu);
-    if (!slot_listed_locked(dev, s) || slot_capturing(s)) {
-      if (bytes) AGPU_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));  // (rare: the stream went away between the scan and now)
-      return AGPU_OK;
-    }
-    seq = ++dev->mbox_seq;
-    hipLaunchKernelGGL(mailbox_post_kernel, dim3(1), dim3(AGPU_WAVE), 0, s->stream, static_cast<const unsigned char*>(src_dev), (uint32_t)bytes,
-                       reinterpret_cast<unsigned char*>(mb + AGPU_MBOX_PAYLOAD), seq_word, seq);
-    AGPU_LAUNCH_CHECK();
-  }
+  uint64_t* seq_word = reinterpret_cast<uint64_t*>(mb + AGPU_MBOX_SEQ) + word;
+  std::lock_guard<std::mutex> lock(dev->mu);
+  *posted = false;
+  if (!slot_listed_locked(dev, s) || slot_capturing(s)) return AGPU_OK;
+  *seq_out = ++dev->mbox_seq;
+  hipLaunchKernelGGL(mailbox_post_kernel, dim3(1), dim3(AGPU_WAVE), 0, s->stream, static_cast<const unsigned char*>(src_dev), (uint32_t)bytes,
+                     reinterpret_cast<unsigned char*>(mb + AGPU_MBOX_PAYLOAD), seq_word, *seq_out);
+  AGPU_LAUNCH_CHECK();
+  *posted = true;
+  return AGPU_OK;
+}
+// device_await: spin, then sleep-poll, until word `word` shows `seq`
+static agpu_status device_await(agpu_device* dev, agpu_stream_slot* s, int word, uint64_t seq, int64_t spin) {
+  uint64_t* seq_word = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(dev->mbox) + AGPU_MBOX_SEQ) + word;
   const int64_t budget_us = spin > 0 ? spin : 200;
   const auto t0 = std::chrono::steady_clock::now();
   bool arrived = false;
@@ -977,7 +981,6 @@ static agpu_status device_post_and_wait(agpu_device* dev, agpu_stream_slot* s, c
       return AGPU_ERR_HIP;
     }
   }
-  if (bytes) memcpy(dst_host, mb + AGPU_MBOX_PAYLOAD, bytes);
   return AGPU_OK;
 }
 
@@ -1014,15 +1017,39 @@ static agpu_status device_wait_all(agpu_device* dev, const void* src_dev, size_t
       if (idle_owned && have_mbox) targets.push_back(idle_owned);
     }
   }
-  // one stream: the post.  Two (three when bytes travel along): still posts, one after the other — 13 µs against hipDeviceSynchronize's 11 plus
-  // a 12 µs hipMemcpy for the bytes (tools/probe/two_streams.py).  More: the runtime's device-wide wait.
-  const bool by_mailbox = have_mbox && !targets.empty() && (targets.size() <= (bytes ? 3u : 2u) || any_capturing);
+  // up to three streams: posts, out together and waited for together (tools/probe/two_streams.py).  More: the runtime's device-wide wait.
+  const bool by_mailbox = have_mbox && !targets.empty() && (targets.size() <= 3 || any_capturing);
   if (by_mailbox) {
     std::lock_guard<std::mutex> one_wait(dev->mbox_mu);  // the device has ONE mailbox: one posted wait at a time (runtime waits below need no turn)
-    for (size_t k = 0; k < targets.size(); k++) {
-      const bool last = k + 1 == targets.size();
-      const agpu_status st = device_post_and_wait(dev, targets[k], last ? src_dev : nullptr, last ? bytes : 0, last ? dst_host : nullptr, spin);
+    // every outstanding stream but the last gets its post at once and they are waited for together; the LAST stream's post carries the bytes and
+    // goes out only when the others have drained — whichever stream produced the bytes, they are final when that kernel copies them
+    const size_t nt = targets.size();
+    uint64_t seqs[3] = {0, 0, 0};
+    bool posted[3] = {false, false, false};
+    size_t early = bytes ? nt - 1 : nt;  // no payload: all of them at once
+    if (early > 3) early = 3;
+    for (size_t k = 0; k < early; k++) {
+      const agpu_status st = device_post(dev, targets[k], (int)k, nullptr, 0, &seqs[k], &posted[k]);
       if (st != AGPU_OK) return st;
+    }
+    for (size_t k = 0; k < early; k++)
+      if (posted[k]) {
+        const agpu_status st = device_await(dev, targets[k], (int)k, seqs[k], spin);
+        if (st != AGPU_OK) return st;
+      }
+    for (size_t k = early; k < nt; k++) {  // the payload's post (and, with a capture open, streams beyond the third)
+      const bool last = k + 1 == nt;
+      uint64_t seq = 0;
+      bool ok = false;
+      agpu_status st = device_post(dev, targets[k], 3, last ? src_dev : nullptr, last ? bytes : 0, &seq, &ok);
+      if (st != AGPU_OK) return st;
+      if (ok) {
+        st = device_await(dev, targets[k], 3, seq, spin);
+        if (st != AGPU_OK) return st;
+        if (last && bytes) memcpy(dst_host, reinterpret_cast<char*>(dev->mbox) + AGPU_MBOX_PAYLOAD, bytes);
+      } else if (last && bytes) {
+        AGPU_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));  // (rare: the stream went away between the scan and now)
+      }
     }
   } else {
     AGPU_HIP(hipDeviceSynchronize());

@@ -130,7 +130,7 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device);
 agpu_status agpu_device_destroy(agpu_device* dev);
 /* agpu_device_sync waits for everything THIS LIBRARY has queued on the device: every pipeline's stream, pooled streams of destroyed pipelines,
  * wrapped streams (work other runtimes queued on streams of their own is theirs to wait for).  With ONE stream outstanding — the usual
- * state behind the reference-style immediate ops of one thread — or two (three when agpu_device_download carries bytes) the wait goes through a
+ * state behind the reference-style immediate ops of one thread — or up to three the wait goes through a
  * kernel per stream that posts into pinned host memory (tuning "sync_spin", docs/experiments.md R5.10: 6–9 µs instead of hipDeviceSynchronize's
  * 11); with more it IS hipDeviceSynchronize.
  * agpu_device_download: the same wait with up to AGPU_MAILBOX_MAX_BYTES of device memory delivered on the way — `values()` of a reduction's result or of a small array in one
