@@ -222,3 +222,26 @@ def test_rust_host_modules_call_only_existing_ffi_functions_with_the_right_arity
                  "apply_broadcast_function", "finish", "clone_buffer", "copy_buffer_to_buffer"):
         assert re.search(r"pub fn %s\b" % name, pipe), name
     assert "fn apply_take_op" in pipe and "fn apply_put_op" in pipe and "fn apply_boolean_unary_function" in pipe
+
+
+def test_the_hosts_share_the_headers_limits():
+    """constants the host layers repeat (the header is C, the hosts are Python / C++): they must say what include/arrow_gpu.h says"""
+    import re
+
+    from arrow_gpu_amd import _capi as capi
+    from arrow_gpu_amd import gpu_utils
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "arrow_gpu.h")).read()
+
+    def define(name):
+        m = re.search(r"#define\s+" + name + r"\s+(\d+)", text)
+        assert m, name
+        return int(m.group(1))
+
+    assert capi.MAILBOX_MAX_BYTES == define("AGPU_MAILBOX_MAX_BYTES")
+    assert gpu_utils._CAST_CHAIN_MAX_ARRAYS == define("AGPU_CAST_CHAIN_MAX_ARRAYS")
+    common = open(os.path.join(root, "arrow_gpu_amd", "csrc", "common.hpp")).read()
+    slot = int(re.search(r"#define\s+AGPU_FLAG_SLOT_BYTES\s+(\d+)", common).group(1))
+    payload = int(re.search(r"#define\s+AGPU_MBOX_PAYLOAD\s+(\d+)", common).group(1))
+    assert slot - payload == define("AGPU_MAILBOX_MAX_BYTES")
