@@ -185,6 +185,11 @@ agpu_status agpu_malloc_like(agpu_device* dev, size_t bytes, int32_t zero_fill, 
  * an ordinary buffer: free each with agpu_free (any order); the block returns to the pool with the last one.
  * Not in the reference (wgpu places buffers). */
 agpu_status agpu_malloc_table(agpu_device* dev, int32_t n_columns, const uint64_t* bytes, int32_t zero_fill, void** out_ptrs);
+/* Blocking copies: complete on return, and everything enqueued on the pipeline before them is over.  [ref: create_gpu_buffer_with_data
+ * gpu_device.rs:145-156 / retrive_data :232-265]  Small ones — uploads of <= 1 KiB, downloads of <= AGPU_MAILBOX_MAX_BYTES: the
+ * reference's tests and examples live at 5-100 elements — never reach the runtime's copy engine or its stream wait: a one-wave kernel moves
+ * the bytes between device memory and the pipeline's pinned mailbox and posts a sequence number the host spins on (7-9 us instead of 15;
+ * tuning "sync_spin" below).  agpu_download of 0 bytes is a pipeline sync. */
 agpu_status agpu_upload(agpu_pipeline* p, void* dst_dev, const void* src_host, size_t bytes);
 agpu_status agpu_download(agpu_pipeline* p, void* dst_host, const void* src_dev, size_t bytes);
 agpu_status agpu_copy(agpu_pipeline* p, void* dst_dev, const void* src_dev, size_t bytes);
