@@ -69,6 +69,8 @@ struct agpu_stream_slot {
   std::atomic<uint64_t> enq{0};           // +1 when an ABI call on this stream starts, +1 when it has enqueued its work (odd = in progress)
   std::atomic<uint64_t> clean_enq{0};     // value of `enq` up to which the stream is KNOWN to have drained (a completed host wait: pipeline sync, small download, device wait)
   std::atomic<bool> capturing{false};     // the stream is in graph capture: nothing but its own pipeline may launch on it
+  std::atomic<bool> exposed{false};       // its raw handle was handed out (agpu_pipeline_stream): work this library never saw may be queued on it —
+                                          // like a wrapped stream it is never taken for drained by the device-level waits
   // ---- guarded by agpu_device::mu
   uint64_t mark_seq = 0;                  // value of `enq` the newest marker covers
   agpu_event_ref* mark = nullptr;         // newest marker event recorded on the stream (free / finish / destroy)

@@ -238,110 +238,93 @@ struct UnNot { template <typename T> __device__ static __forceinline__ T ap(T x,
 struct UnPopc {  // countOneBits per element [logical/compute_shaders/u32/countbitones.wgsl:9-15]
   template <typename T> __device__ static __forceinline__ T ap(T x, T) { return (T)__builtin_popcount((uint32_t)(U_of<T>)x); }
 };
-// ---- transcendental f32 functions: evaluated in f64 and rounded ONCE to f32 (≤ 1 ULP, in practice ≤ 0.5 ULP + 2^-30).
-// The f32 device-library versions measure 2 ULP for sin/cos/log on gfx950 (profiles/r01_probe_first_contact.json);
-// MI355X runs v_fma_f64 at half the f32 rate (78 TFLOP/s), and an 8 B/row stream at 6 TB/s leaves ≈50 f64 FMAs per
-// row, so the f64 evaluation stays under the memory roof for sin/cos (hand-written below, ≈20 FMAs).
+// ---- transcendental f32 functions.  log / sinh / pow below are evaluated in f64 and rounded ONCE to f32 (≤ 0.5 ULP + 2^-30);
+// the f32 device-library versions measure 2 ULP for sin / cos / log on gfx950 (profiles/r01_probe_first_contact.json).
 //
-// sin/cos: Cody–Waite reduction by π/2 in f64 (π/2 = P1 + P1t; P1 has 33 significant bits, so k·P1 is exact for
-// k < 2^20), then minimax polynomials on [−π/4, π/4]:
-//     sin r = r + r·z·(S1 + z·ps(z)),   cos r = 1 + z·(C1 + z·pc(z)),   z = r²
-// The inner ps / pc (terms ≥ r⁵ / r⁴, ≤ 0.5 % / 2.6 % of the result) are evaluated in f32, the two outer steps in f64,
-// then ONE rounding to f32: pre-rounding error ≤ 0.02 f32-ULP (emulated over 2·10⁶ points), i.e. ≤ 0.52 ULP total,
-// with half the f64 work of an all-f64 Horner chain.  |x| ≥ 1e6, inf and NaN take the f64 library path
-// (Payne–Hanek inside), out of line so the hot path stays small.
+// sin / cos (round 6): ALL in f32, TWO ROWS per instruction.  Rounds 1–5 evaluated the Cody–Waite reduction and the outer
+// polynomial step in f64 — 8 f64 operations + 4 conversions + 5 selects per row, ≈ 27 VALU instructions, which an 8 B/row
+// stream hides and a 5–6 B/row cast-headed chain does not (`cast i16 → f32 → sin` in one launch 0.65 of the roof, `cast(u16)·s
+// → sin` 0.54: VERDICT r5 weak #3).  gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 — two IEEE f32 operations per
+// lane — at ≈ 1.45× the cost of ONE (profiles/r02_valu_rate.json), so the same function written as double-float f32 arithmetic
+// over a PAIR of rows costs ≈ 11 packed + 6 scalar instructions per row:
+//   k  = round(x · 2/π) by the 1.5·2^23 trick (one fma; the low bits of the sum ARE k, no conversion), |k| < 2^20 for |x| < 1e6
+//   r1 = fma(−k, P1, x)                      EXACT: P1 = f32(π/2), k·P1 and x are multiples of 2^-24 and |r1| < 1
+//   ph + pl = k·P2 exactly (fma residual), (rh, e) = Fast2Sum(r1, −ph) — valid although |r1| may be < |ph|: r1 is a multiple
+//   of ulp(ph) — and lo = e − pl − k·P3:     r = rh + lo to ≈ 2^-48 relative, P1 + P2 + P3 = π/2 to 2^-76
+//   sin r = rh − (rh·z·(−ps(z)) − lo),  cos r = 1 + (z·pc(z) − rh·lo),  z = rh²; ps / pc = minimax polynomials with 3 / 4
+//   coefficients on |r| ≤ 0.89 (k is rounded in f32, so |r| can exceed π/4 by 0.06·π/2 at |x| = 1e6): 0.16 / 0.007 ULP
+// then the quadrant picks S or C and the sign.  Both functions of both rows are evaluated (selecting coefficient sets per row
+// would cost more than it saves).  Error against the true value ≤ 1.18 ULP, i.e. ALWAYS within 1 ULP of the correctly rounded
+// result — the oracle's definition — checked for every f32 with |x| < 1e6, sin and cos, first on the CPU with the same operation
+// sequence (tools/probe/sincos_f32_proto.c: 99.2 % of the inputs bit-equal to the oracle, the rest off by one) and then on the
+// device (tests/tools/exhaustive_vs_oracle.py).  The zero signs are arranged so that sin(−0.0) = −0.0 (ph is an fma with +0.0,
+// the low part is carried NEGATED).  |x| ≥ 1e6, inf and NaN take the f64 library path (Payne–Hanek inside), out of line.
 __device__ __attribute__((noinline)) float sincos_f32_slow(float x, int want_cos) {
   return (float)(want_cos ? cos((double)x) : sin((double)x));
 }
-// k = round(x · 2/π) by the 1.5·2^52 trick: ONE fma rounds the exact product to an integer (no double rounding), the low
-// word of the sum IS k (no v_cvt_i32_f64), and kd = s − M is +0.0 for every |x| < π/4, so r = x exactly there, −0.0
-// included (round 1 paid a 64-bit compare and two selects for that): 6 instructions → 2.
-// Round 4: ONE outer f64 evaluation per row instead of two.  Both inner polynomials still run — as ONE packed chain, the pair
-// {ps, pc} in three v_pk_fma_f32 — and the quadrant picks which of them, which second coefficient and which multiplier (r for
-// sin, 1.0 for cos) feed the single outer step  v = m · (1 + z·(k1 + z·p)).  The operands of every rounding are the ones the
-// two-chain form used (sin: r · fma(…), cos: 1.0 · fma(…) = fma(…)), so the bits are unchanged; the sign goes onto the f32
-// result.  Per row: 10 → 8 f64 operations, 5 → 4 conversions, 7 → 4 f32 operations, 3 → 5 selects: ≈ 49 → ≈ 38 f32-rate issue
-// slots (ISA counted with tools/probe: llvm -S of this file).
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#ifndef AGPU_SINCOS_FORM
-#define AGPU_SINCOS_FORM 1  // 1 = one outer step (below); 0 = the two-chain form of rounds 1–3 (A/B: tools/probe/sincos_ab.sh)
-#endif
-#ifndef AGPU_SINCOS_PACK
-#define AGPU_SINCOS_PACK 0  // 1 = the tile kernel evaluates a 16-byte pack with ONE slow-path branch; 0 = a branch per row.  Same box, three
-                            // alternations (tools/probe/sincos_ab.sh, 1e9 rows, fraction of the HBM roof, sin / cos): two-chain form 0.761 / 0.801,
-                            // + pack 0.753 / 0.777, one-step form 0.773 / 0.793, + pack 0.752 / 0.785 — the kernel is bound by bytes in flight,
-                            // not by its 36 → 30 VALU instructions per row, and the pack form's longer straight-line phases cost 2 %
-#endif
-#if AGPU_SINCOS_FORM == 0
-__device__ __forceinline__ float sincos_f32_fast(float x, int want_cos) {
-  const double xd = (double)x;
-  const double sh = fma(xd, 0x1.45f306dc9c883p-1, 0x1.8p52);
-  const double kd = sh - 0x1.8p52;
-  const int k = (int)(uint32_t)__builtin_bit_cast(uint64_t, sh);
-  double r = fma(kd, -0x1.921fb54400000p+0, xd);
-  r = fma(kd, -0x1.0b4611a626331p-34, r);
-  const float zf = (float)r * (float)r;
-  float ps = __builtin_fmaf(zf, (float)-0x1.aa12ed611087fp-26, (float)0x1.71d97b66aa967p-19);
-  ps = __builtin_fmaf(zf, ps, (float)-0x1.a019fd5d6492ep-13);
-  ps = __builtin_fmaf(zf, ps, (float)0x1.1111110fba75dp-7);
-  float pc = __builtin_fmaf(zf, (float)-0x1.24635bc27779cp-22, (float)0x1.a0124c744e1f9p-16);
-  pc = __builtin_fmaf(zf, pc, (float)-0x1.6c16ba7ffec5ep-10);
-  pc = __builtin_fmaf(zf, pc, (float)0x1.55555550fad1cp-5);
-  const double z = r * r;
-  const double s = r * fma(z, fma(z, (double)ps, -0x1.555555555510cp-3), 1.0);
-  const double c = fma(z, fma(z, (double)pc, -0x1.fffffffffe3f1p-2), 1.0);
-  const int q = k + want_cos;
-  double v = (q & 1) ? c : s;
-  v = (q & 2) ? -v : v;
-  return (float)v;
-}
-#else
-__device__ __forceinline__ float sincos_f32_fast(float x, int want_cos) {  // meaningful for |x| < 1e6, harmless elsewhere
-  const double xd = (double)x;
-  const double sh = fma(xd, 0x1.45f306dc9c883p-1, 0x1.8p52);  // x · 2/π + 1.5 · 2^52
-  const double kd = sh - 0x1.8p52;
-  const int k = (int)(uint32_t)__builtin_bit_cast(uint64_t, sh);
-  double r = fma(kd, -0x1.921fb54400000p+0, xd);
-  r = fma(kd, -0x1.0b4611a626331p-34, r);
-  const float rf = (float)r;
-  const float zf = rf * rf;
-  const f32x2_t zz = {zf, zf};
-  f32x2_t pp = __builtin_elementwise_fma(zz, (f32x2_t){(float)-0x1.aa12ed611087fp-26, (float)-0x1.24635bc27779cp-22},
-                                         (f32x2_t){(float)0x1.71d97b66aa967p-19, (float)0x1.a0124c744e1f9p-16});
-  pp = __builtin_elementwise_fma(zz, pp, (f32x2_t){(float)-0x1.a019fd5d6492ep-13, (float)-0x1.6c16ba7ffec5ep-10});
-  pp = __builtin_elementwise_fma(zz, pp, (f32x2_t){(float)0x1.1111110fba75dp-7, (float)0x1.55555550fad1cp-5});  // {ps, pc}
-  const int q = k + want_cos;  // cos(x) = sin(x + π/2)
-  const bool use_cos = (q & 1) != 0;
-  const double z = r * r;
-  const double p = (double)(use_cos ? pp.y : pp.x);
-  const double k1 = use_cos ? -0x1.fffffffffe3f1p-2 : -0x1.555555555510cp-3;
-  const double m = use_cos ? 1.0 : r;  // sin r = r·(1 + …) (not r + r·z·…: sin(−0.0) = −0.0), cos r = 1 + …
-  const double v = m * fma(z, fma(z, p, k1), 1.0);
-  const uint32_t sign = ((uint32_t)q << 30) & 0x80000000u;  // quadrants 2, 3: negate
-  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)v) ^ sign);
-}
-#endif
-__device__ __forceinline__ float sincos_f32_dev(float x, int want_cos) {
-  float res = sincos_f32_fast(x, want_cos);  // unconditionally: the rare slow path then merges ONE register, not the whole state
-  if (!(fabsf(x) < 1.0e6f)) res = sincos_f32_slow(x, want_cos);
-  return res;
-}
-// a 16-byte pack at a time (the tile kernel): the four fast paths run back to back — independent chains the scheduler can
-// interleave — and ONE branch per pack covers the |x| ≥ 1e6 / inf / NaN rows, where the per-row form broke the instruction
-// stream with a branch after every row
+__device__ __forceinline__ f32x2_t pk2(float v) { return (f32x2_t){v, v}; }
+__device__ __forceinline__ f32x2_t pk_fma(f32x2_t a, f32x2_t b, f32x2_t c) { return __builtin_elementwise_fma(a, b, c); }
 template <int WANT_COS>
-__device__ __forceinline__ void sincos_f32_pack(const float (&x)[4], float (&res)[4]) {
+__device__ __forceinline__ f32x2_t sincos_f32_pair(f32x2_t x) {  // meaningful for |x| < 1e6, harmless elsewhere
+  const f32x2_t M = pk2(12582912.0f);                        // 1.5 · 2^23
+  const f32x2_t s = pk_fma(x, pk2(0x1.45f306p-1f), M);       // x · 2/π + M: the sum's low mantissa bits are k
+  const f32x2_t kf = s - M;
+  const f32x2_t r1 = pk_fma(kf, pk2(-0x1.921fb6p+0f), x);    // exact
+  const f32x2_t P2 = pk2(-0x1.777a5cp-25f);
+  const f32x2_t ph = pk_fma(kf, P2, pk2(0.0f));              // an fma, not a product: +0.0 for k = 0 (−0.0 would turn r = −0.0 into +0.0)
+  const f32x2_t pl = pk_fma(kf, P2, -ph);                    // exact residual
+  const f32x2_t rh = r1 - ph;
+  const f32x2_t t = rh - r1;
+  const f32x2_t e = -ph - t;                                 // rounding error of rh
+  f32x2_t nlo = pl - e;                                      // −lo
+  nlo = pk_fma(kf, pk2(-0x1.ee59dap-50f), nlo);
+  const f32x2_t z = rh * rh;
+  f32x2_t ps = pk_fma(z, pk2(0x1.976586p-13f), pk2(-0x1.110122p-7f));
+  ps = pk_fma(z, ps, pk2(0x1.555534p-3f));                   // −(sin r − r) / r³ > 0
+  const f32x2_t u = pk_fma(rh * z, ps, nlo);
+  const f32x2_t S = rh - u;
+  f32x2_t pc = pk_fma(z, pk2(0x1.982456p-16f), pk2(-0x1.6c0536p-10f));
+  pc = pk_fma(z, pc, pk2(0x1.55553ep-5f));
+  pc = pk_fma(z, pc, pk2(-0.5f));
+  const f32x2_t C = pk2(1.0f) + pk_fma(z, pc, rh * nlo);
+  // (copies first: this clang lowers __builtin_bit_cast(uint32_t, s.y) — a bit cast of a vector ELEMENT — as a read of element 0)
+  const float s0 = s.x, s1 = s.y;
+  const uint32_t q0 = __builtin_bit_cast(uint32_t, s0) + (uint32_t)WANT_COS;  // cos(x) = sin(x + π/2)
+  const uint32_t q1 = __builtin_bit_cast(uint32_t, s1) + (uint32_t)WANT_COS;
+  const float o0 = (q0 & 1u) ? C.x : S.x, o1 = (q1 & 1u) ? C.y : S.y;
+  const uint32_t v0 = __builtin_bit_cast(uint32_t, o0) ^ ((q0 << 30) & 0x80000000u);  // quadrants 2, 3: negate
+  const uint32_t v1 = __builtin_bit_cast(uint32_t, o1) ^ ((q1 << 30) & 0x80000000u);
+  return (f32x2_t){__builtin_bit_cast(float, v0), __builtin_bit_cast(float, v1)};
+}
+__device__ __forceinline__ bool sincos_f32_is_slow(float x) { return !(fabsf(x) < 1.0e6f); }
+// N rows (N even): the pairs run back to back — independent chains the scheduler interleaves — and ONE branch covers the
+// |x| ≥ 1e6 / inf / NaN rows
+template <int WANT_COS, int N>
+__device__ __forceinline__ void sincos_f32_rows(const float (&x)[N], float (&res)[N]) {
+  static_assert(N % 2 == 0, "rows come in pairs");
   bool slow = false;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    res[k] = sincos_f32_fast(x[k], WANT_COS);
-    slow |= !(fabsf(x[k]) < 1.0e6f);
+  for (int k = 0; k < N; k += 2) {
+    const f32x2_t v = sincos_f32_pair<WANT_COS>((f32x2_t){x[k], x[k + 1]});
+    res[k] = v.x;
+    res[k + 1] = v.y;
+    slow = slow || sincos_f32_is_slow(x[k]) || sincos_f32_is_slow(x[k + 1]);
   }
   if (slow) {
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (!(fabsf(x[k]) < 1.0e6f)) res[k] = sincos_f32_slow(x[k], WANT_COS);
+    for (int k = 0; k < N; k++)
+      if (sincos_f32_is_slow(x[k])) res[k] = sincos_f32_slow(x[k], WANT_COS);
   }
+}
+// the fast path alone, one row (16-bit sources: |x| ≤ 65 535 never needs the slow one)
+template <int WANT_COS>
+__device__ __forceinline__ float sincos_f32_fast(float x) { return sincos_f32_pair<WANT_COS>(pk2(x)).x; }
+template <int WANT_COS>
+__device__ __forceinline__ float sincos_f32_dev(float x) {  // one row (tails, unaligned columns, table builders)
+  float res = sincos_f32_fast<WANT_COS>(x);  // unconditionally: the rare slow path then merges ONE register, not the whole state
+  if (sincos_f32_is_slow(x)) res = sincos_f32_slow(x, WANT_COS);
+  return res;
 }
 
 // 128-entry table shared by log and pow: interval j of the mantissa [1 + j/128, 1 + (j+1)/128) → rc ≈ 1/centre (the
@@ -466,16 +449,29 @@ struct UnExp2 { __device__ static __forceinline__ float ap(float x, float) { ret
 struct UnLog { __device__ static __forceinline__ float ap(float x, float) { return log_f32_dev(x); } };
 struct UnLog2 { __device__ static __forceinline__ float ap(float x, float) { return log2f(x); } };
 struct UnSin {
-  __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 0); }
-  __device__ static __forceinline__ void ap_pack(const float (&x)[4], float (&r)[4]) { sincos_f32_pack<0>(x, r); }
+  __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev<0>(x); }
+  template <int N> __device__ static __forceinline__ void ap_rows(const float (&x)[N], float (&r)[N]) { sincos_f32_rows<0, N>(x, r); }
 };
 struct UnCos {
-  __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev(x, 1); }
-  __device__ static __forceinline__ void ap_pack(const float (&x)[4], float (&r)[4]) { sincos_f32_pack<1>(x, r); }
+  __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev<1>(x); }
+  template <int N> __device__ static __forceinline__ void ap_rows(const float (&x)[N], float (&r)[N]) { sincos_f32_rows<1, N>(x, r); }
 };
-template <typename Op> struct EwPackOp { static constexpr bool value = false; };  // functors with a 4-row form for the f32 tile kernel
-template <> struct EwPackOp<UnSin> { static constexpr bool value = AGPU_SINCOS_PACK != 0; };
-template <> struct EwPackOp<UnCos> { static constexpr bool value = AGPU_SINCOS_PACK != 0; };
+// functors with a several-rows-at-a-time form (sin / cos: packed f32 arithmetic over row pairs); everything else goes row by row
+template <typename Op> struct EwRowsOp { static constexpr bool value = false; };
+template <> struct EwRowsOp<UnSin> { static constexpr bool value = true; };
+template <> struct EwRowsOp<UnCos> { static constexpr bool value = true; };
+// … and converting functors (CvtThenF32 below) that have one: a static member `has_rows` = true and ap_rows<N>
+template <typename Conv, typename = void> struct ConvHasRows { static constexpr bool value = false; };
+template <typename Conv> struct ConvHasRows<Conv, std::enable_if_t<Conv::has_rows>> { static constexpr bool value = true; };
+template <typename Op, int N>
+__device__ __forceinline__ void unary_f32_rows(const float (&x)[N], float (&r)[N]) {
+  if constexpr (EwRowsOp<Op>::value && N % 2 == 0) {
+    Op::template ap_rows<N>(x, r);
+  } else {
+#pragma unroll
+    for (int k = 0; k < N; k++) r[k] = Op::ap(x[k], 0.0f);
+  }
+}
 struct UnAcos { __device__ static __forceinline__ float ap(float x, float) { return acosf(x); } };
 struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { return sinh_f32_dev(x); } };
 
@@ -508,8 +504,8 @@ __global__ __launch_bounds__(BLK) void ew_kernel(const T* a, const T* b, T* out,
     });
     static_for<U>([&](auto u) {
       PackN<T, N> r;
-      if constexpr (EwPackOp<Op>::value && MODE == MODE_UNARY && std::is_same<T, float>::value) {
-        Op::ap_pack(va[u].v, r.v);
+      if constexpr (EwRowsOp<Op>::value && MODE == MODE_UNARY && std::is_same<T, float>::value) {
+        unary_f32_rows<Op, N>(va[u].v, r.v);
       } else {
 #pragma unroll
         for (int k = 0; k < N; k++) r.v[k] = Op::ap(va[u].v[k], MODE == MODE_BINARY ? vb[u].v[k] : sv);
@@ -543,12 +539,7 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_prefetch_kernel(const float*
       static_for<U>([&](auto u) { nxt[u] = load_pack<NTL, float, N>(a + (tn * tile + threadIdx.x + (uint64_t)u * AGPU_EW_BLOCK) * N); });
     static_for<U>([&](auto u) {
       PackN<float, N> r;
-      if constexpr (EwPackOp<Op>::value) {
-        Op::ap_pack(cur[u].v, r.v);
-      } else {
-#pragma unroll
-        for (int k = 0; k < N; k++) r.v[k] = Op::ap(cur[u].v[k], 0.0f);
-      }
+      unary_f32_rows<Op, N>(cur[u].v, r.v);
       store_pack<NTS, float, N, true>(out + (t * tile + threadIdx.x + (uint64_t)u * AGPU_EW_BLOCK) * N, r);
     });
     if (!more) break;
@@ -1316,8 +1307,12 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in,
         x = __builtin_bit_cast(PackN<TI, NO>, w);
       }
       PackN<TO, NO> r;
+      if constexpr (ConvHasRows<Conv>::value && NO % 2 == 0) {
+        Conv::template ap_rows<NO>(x.v, r.v);
+      } else {
 #pragma unroll
-      for (int k = 0; k < NO; k++) r.v[k] = Conv::ap(x.v[k]);
+        for (int k = 0; k < NO; k++) r.v[k] = Conv::ap(x.v[k]);
+      }
       const uint32_t g = (uint32_t)j * AGPU_WAVE + lane;  // slot of this lane's store inside the chunk
       store_pack<(AGPU_STREAM_NT & 2) != 0, TO, NO, SC1>(out + (c * (uint64_t)(AGPU_WAVE * R) + g) * NO, r);
     });
@@ -1481,11 +1476,21 @@ struct CvtF32ToInt {
 template <typename TI, typename F>
 struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders/{u8,i8,u16,i16}/*.wgsl]
   __device__ static __forceinline__ float ap(TI x) {
-    // |x| ≤ 65 535 < 1e6: sin / cos never take the out-of-line |x| ≥ 1e6 path — the compiler sees that for u16 and not for i16 (8 calls to
-    // sincos_f32_slow and their register shuffling per 8 rows stayed in cvt_wide_kernel<short, …>); same bits either way
-    if constexpr (sizeof(TI) <= 2 && std::is_same<F, UnSin>::value) return sincos_f32_fast((float)x, 0);
-    else if constexpr (sizeof(TI) <= 2 && std::is_same<F, UnCos>::value) return sincos_f32_fast((float)x, 1);
+    // |x| ≤ 65 535 < 1e6: sin / cos never take the out-of-line |x| ≥ 1e6 path — the compiler sees that for u16 and not for i16; same bits either way
+    if constexpr (sizeof(TI) <= 2 && std::is_same<F, UnSin>::value) return sincos_f32_fast<0>((float)x);
+    else if constexpr (sizeof(TI) <= 2 && std::is_same<F, UnCos>::value) return sincos_f32_fast<1>((float)x);
     else return F::ap((float)x, 0.0f);
+  }
+  // several rows at a time: sin / cos evaluate row PAIRS in packed f32 (sincos_f32_pair); same bits as ap()
+  static constexpr bool has_rows = sizeof(TI) <= 2 && (std::is_same<F, UnSin>::value || std::is_same<F, UnCos>::value);
+  template <int N> __device__ static __forceinline__ void ap_rows(const TI (&x)[N], float (&r)[N]) {
+    static_assert(N % 2 == 0, "rows come in pairs");
+#pragma unroll
+    for (int k = 0; k < N; k += 2) {
+      const f32x2_t v = sincos_f32_pair<std::is_same<F, UnCos>::value ? 1 : 0>((f32x2_t){(float)x[k], (float)x[k + 1]});
+      r[k] = v.x;
+      r[k + 1] = v.y;
+    }
   }
 };
 
@@ -1900,7 +1905,12 @@ __device__ __forceinline__ T chain_apply_unary(int op, T x) {
 #define AGPU_CHAIN_UN_CASE(CODE, F)                                                        \
   case CODE:                                                                               \
     static_for<U>([&](auto u) {                                                            \
-      _Pragma("unroll") for (int k = 0; k < N; k++) acc[u].v[k] = F::ap(acc[u].v[k], acc[u].v[k]); \
+      if constexpr (std::is_same<T, float>::value && EwRowsOp<F>::value && N % 2 == 0) {   \
+        PackN<T, N> in_ = acc[u];                                                          \
+        unary_f32_rows<F, N>(in_.v, acc[u].v);                                             \
+      } else {                                                                             \
+        _Pragma("unroll") for (int k = 0; k < N; k++) acc[u].v[k] = F::ap(acc[u].v[k], acc[u].v[k]); \
+      }                                                                                    \
     });                                                                                    \
     return;
 template <typename T, bool HEAVY, int U, int N>

@@ -12,6 +12,7 @@ spans (16-byte vector path, no split validity words).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from dataclasses import dataclass
 
@@ -217,27 +218,6 @@ def file_rendezvous_cleanup(path: str, rank: int, wait_s: float = 5.0) -> None:
             pass
 
 
-def final_reduce(sum_t=None, min_t=None, max_t=None, count_t=None, group=None):
-    """In-place final reduce of per-shard partials held in 1-element tensors (any device / backend).
-
-    sum_t: float64 partial sums (agpu_reduce_sum_f64) → SUM;  min_t / max_t → MIN / MAX;  count_t: int64 → SUM.
-    With a single process (no process group) this is the identity.  Returns the tensors.
-    """
-    import torch.distributed as dist
-
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return sum_t, min_t, max_t, count_t
-    if sum_t is not None:
-        dist.all_reduce(sum_t, op=dist.ReduceOp.SUM, group=group)
-    if min_t is not None:
-        dist.all_reduce(min_t, op=dist.ReduceOp.MIN, group=group)
-    if max_t is not None:
-        dist.all_reduce(max_t, op=dist.ReduceOp.MAX, group=group)
-    if count_t is not None:
-        dist.all_reduce(count_t, op=dist.ReduceOp.SUM, group=group)
-    return sum_t, min_t, max_t, count_t
-
-
 class Peer(C.Structure):
     """include/arrow_gpu.h `agpu_comm_peer`: one rank's identity as gathered through the communicator."""
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("device_ordinal", C.c_int32), ("nccl_device", C.c_int32),
@@ -297,6 +277,24 @@ def prefer_loopback_bootstrap(world: int, env=None) -> bool:
     return False
 
 
+@contextlib.contextmanager
+def loopback_bootstrap(world: int, env=None):
+    """`prefer_loopback_bootstrap` for the duration of a communicator's rendezvous ONLY: the variable is put back as it was when the block
+    ends, so that another RCCL / NCCL user initialised later in this process (a multi-node torch.distributed group, say — torch carries
+    its own copy of the library, which reads the environment at ITS first use) does not inherit a loopback bootstrap it never asked for
+    (ADVICE r5).  It does not undo what the librccl this library links has already read: within one copy of RCCL the bootstrap interface
+    is chosen once per process.  A host that owns its process may call `prefer_loopback_bootstrap` itself instead."""
+    import os
+
+    e = os.environ if env is None else env
+    did = prefer_loopback_bootstrap(world, e)
+    try:
+        yield did
+    finally:
+        if did:
+            e.pop("NCCL_SOCKET_IFNAME", None)
+
+
 class Communicator:
     """RCCL communicator of the C ABI (include/arrow_gpu.h "multi-GPU"): one rank per GPU, used ONLY for the final
     reduce of whole-column statistics.  Nothing like it exists in the reference (single device + queue,
@@ -314,14 +312,14 @@ class Communicator:
         exit (the pending RCCL rendezvous cannot be cancelled)."""
         if len(unique_id) != capi.COMM_ID_BYTES:
             raise ValueError("unique id must be 128 bytes")
-        prefer_loopback_bootstrap(world)
         self.device, self.rank, self.world = device, rank, world
         h = C.c_void_p()
         idbuf = C.create_string_buffer(unique_id, capi.COMM_ID_BYTES)
-        if timeout_s is None:
-            capi.call("agpu_comm_init_rank", device._handle, idbuf, rank, world, C.byref(h))
-        else:
-            capi.call("agpu_comm_init_rank_timeout", device._handle, idbuf, rank, world, int(timeout_s * 1000), C.byref(h))
+        with loopback_bootstrap(world):
+            if timeout_s is None:
+                capi.call("agpu_comm_init_rank", device._handle, idbuf, rank, world, C.byref(h))
+            else:
+                capi.call("agpu_comm_init_rank_timeout", device._handle, idbuf, rank, world, int(timeout_s * 1000), C.byref(h))
         self._h = h
 
     @staticmethod
@@ -340,25 +338,25 @@ class Communicator:
     @classmethod
     def single(cls, device) -> "Communicator":
         """World of one rank (no launcher needed): the same RCCL code path a multi-GPU run takes."""
-        prefer_loopback_bootstrap(1)  # before the id: rank 0's listening socket is opened when the id is made
-        return cls(device, 0, 1, cls.unique_id())
+        with loopback_bootstrap(1):  # around the id too: rank 0's listening socket is opened when the id is made
+            return cls(device, 0, 1, cls.unique_id())
 
     @classmethod
     def from_torch(cls, device, group=None) -> "Communicator":
         import torch.distributed as dist
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        prefer_loopback_bootstrap(world)
-        box = [cls.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0, group=group)
-        return cls(device, rank, world, box[0])
+        with loopback_bootstrap(world):
+            box = [cls.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            return cls(device, rank, world, box[0])
 
     @classmethod
     def from_file(cls, device, rank: int, world: int, path: str, timeout_s: float = 60.0) -> "Communicator":
         """Torch-free rendezvous over a path every rank can see (one node: /tmp or /dev/shm).  See `file_rendezvous`."""
-        prefer_loopback_bootstrap(world)
-        uid = file_rendezvous(path, rank, world, cls.unique_id if rank == 0 else None, timeout_s)
-        comm = cls(device, rank, world, uid, timeout_s=timeout_s)
+        with loopback_bootstrap(world):
+            uid = file_rendezvous(path, rank, world, cls.unique_id if rank == 0 else None, timeout_s)
+            comm = cls(device, rank, world, uid, timeout_s=timeout_s)
         file_rendezvous_cleanup(path, rank)
         return comm
 

@@ -130,15 +130,16 @@ def check_config_windows(cfg_windows):
     return out
 
 
-def cpu_baseline(sample_rows: int, gpu_windows=(), cfg_windows=None):
-    """The CPU leg: time the CPU port on a bounded sample of the same workload, and use the oracle as the CHECKER of
-    windows of the GPU outputs the timed steps produced.  Test/bench infrastructure only (oracle/)."""
+def check_headline_windows(gpu_windows) -> bool:
+    """Oracle check of the windows a rank downloaded from ITS shard of the benchmarked outputs (first / middle / last 65 536 rows, at the
+    shard's own row0): f32 add bit-exact, eq bitmap and merged validity bit-exact.  Every rank runs this on its own windows, after the
+    timed region (the oracle is only ever the checker)."""
     import numpy as np
 
     import oracle as O
 
     ok = True
-    for win in gpu_windows:  # first / middle / last 65 536 rows of the 1e9-row outputs
+    for win in gpu_windows:
         cnt, r0 = win["rows"], win["row"]
         exp = O.binary(O.OP_ADD, O.F32, O.synth_f32(cnt, SEED, r0, -1000.0, 1000.0), O.synth_f32(cnt, SEED + 1, r0, -1000.0, 1000.0))
         ok &= bool(np.array_equal(win["add"].view(np.uint32), exp.view(np.uint32)))
@@ -146,9 +147,60 @@ def cpu_baseline(sample_rows: int, gpu_windows=(), cfg_windows=None):
         evd = O.bitmap_binary(O.OP_AND, O.synth_bits(cnt, SEED + 4, r0, 0.9), O.synth_bits(cnt, SEED + 5, r0, 0.9), cnt)
         full = cnt // 8
         ok &= bool(np.array_equal(win["eq_bits"][:full], eb[:full]) and np.array_equal(win["eq_validity"][:full], evd[:full]))
-    parity = None
-    if gpu_windows:
-        parity = f"GPU outputs bit-exact vs oracle on {len(gpu_windows)} windows of 65536 rows (first/middle/last)" if ok else "MISMATCH"
+    return ok
+
+
+def slot_vector(rank: int, world: int, values) -> list:
+    """This rank's contribution to a gather-by-SUM of `len(values)` numbers per rank: a (len(values) × world) vector that is zero except
+    for this rank's slots.  Summed over the ranks (any all-reduce SUM of f64) it is the gathered table; integers below 2^53 survive exactly."""
+    out = [0.0] * (len(values) * world)
+    for k, v in enumerate(values):
+        out[k * world + rank] = float(v)
+    return out
+
+
+def reduce_records_from_gathered(gathered, world: int):
+    """Inverse of slot_vector for the six numbers a rank contributes to the final-reduce check: the bit patterns of its local f32 sum /
+    min / max, the two halves of its local f64 sum, its row count.  → per statistic a list of (value, n_local) in rank order."""
+    import numpy as np
+
+    def col(k):
+        return [int(round(gathered[k * world + r])) for r in range(world)]
+
+    s, mn, mx, lo, hi, n = (col(k) for k in range(6))
+    f32 = lambda b: np.array([b], np.uint32).view(np.float32)[0]  # noqa: E731
+    f64 = lambda l, h: np.array([(h << 32) | l], np.uint64).view(np.float64)[0]  # noqa: E731
+    return {"sum": [(f32(s[r]), n[r]) for r in range(world)], "min": [(f32(mn[r]), n[r]) for r in range(world)],
+            "max": [(f32(mx[r]), n[r]) for r in range(world)], "sum_f64": [(f64(lo[r], hi[r]), n[r]) for r in range(world)]}
+
+
+def verify_final_reduce(records, got) -> dict:
+    """The collective's results (`got`: sum / min / max as f32, sum_f64) against the ORACLE's rank-ordered combine of the per-rank local
+    records (oracle.combine_records: the reference tree's next level for the f32 Sum, Arrow's NaN rule for min / max, empty shards
+    skipped; the f64 sum added up in rank order).  Bit-exact or not."""
+    import numpy as np
+
+    import oracle as O
+
+    exp = {"sum": O.combine_records(O.RED_SUM, O.F32, records["sum"]), "min": O.combine_records(O.RED_MIN, O.F32, records["min"]),
+           "max": O.combine_records(O.RED_MAX, O.F32, records["max"])}
+    acc = 0.0
+    for v, n_r in records["sum_f64"]:
+        if n_r:
+            acc = acc + float(v)
+    ok = {k: bool(np.float32(exp[k]).view(np.uint32) == np.float32(got[k]).view(np.uint32)) for k in ("sum", "min", "max")}
+    ok["sum_f64"] = bool(np.float64(acc).view(np.uint64) == np.float64(got["sum_f64"]).view(np.uint64))
+    return ok
+
+
+def cpu_baseline(sample_rows: int, gpu_parity=None, cfg_windows=None):
+    """The CPU leg: time the CPU port on a bounded sample of the same workload; `gpu_parity` = the verdict of the oracle check of every
+    rank's output windows (check_headline_windows, AND over ranks), carried into the record.  Test/bench infrastructure only (oracle/)."""
+    import numpy as np
+
+    import oracle as O
+
+    parity = gpu_parity
 
     build_dir = os.path.join(ROOT, "oracle", "_build")
     os.makedirs(build_dir, exist_ok=True)
@@ -485,7 +537,7 @@ def main():
         comm.barrier(p)  # RCCL all-reduce of one word + host wait on the stream (with a deadline)
         dev.sync()
 
-    stat_buf = dev.create_empty_buffer(64)
+    stat_buf = dev.create_empty_buffer(max(64, 8 * 6 * world))  # across_ranks' f64 staging: six numbers per rank at most (the final-reduce check)
 
     def across_ranks(values, op):
         """MIN / MAX / SUM of a few f64 over the ranks through the C ABI's communicator (identity at world 1)."""
@@ -541,22 +593,34 @@ def main():
     add_gbps = ADD_BYTES_PER_ROW * n / add_ms / 1e6
     eq_gbps = EQ_BYTES_PER_ROW * n / eq_ms / 1e6
 
-    # ---- windows of the benchmarked 1e9-row outputs, downloaded for the CPU-baseline leg to check against the oracle
-    # (the oracle is only ever touched inside cpu_baseline(); the product path above never sees it)
-    windows = []
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    if want_cpu:
+    # ---- windows of the benchmarked outputs, EVERY rank its own (first / middle / last 65 536 rows of its shard, at its own row0), checked
+    # against the oracle on that rank and AND-ed over the ranks through the communicator: a line of ANY world carries the parity of all
+    # its shards.  The oracle is only ever the checker, after the timed region; the product path never sees it.
+    want_cpu = rank == 0 and not args.no_cpu_baseline  # the CPU leg: rank 0 at every world size
+    gpu_parity = None
+    if not args.no_cpu_baseline:
         import numpy as np
 
-        w = 1 << 16
-        for start in (0, (n // 2) // 64 * 64, max(0, (n - w) // 64 * 64)):
-            cnt = min(w, n - start)
-            nbytes = (cnt + 7) // 8
-            got, gb, gv = np.empty(cnt, np.float32), np.empty(nbytes, np.uint8), np.empty(nbytes, np.uint8)
-            capi.call("agpu_download", h, C.c_void_p(got.ctypes.data), C.c_void_p(fo.ptr + 4 * start), 4 * cnt)
-            capi.call("agpu_download", h, C.c_void_p(gb.ctypes.data), C.c_void_p(ob.ptr + start // 8), nbytes)
-            capi.call("agpu_download", h, C.c_void_p(gv.ctypes.data), C.c_void_p(ov.ptr + start // 8), nbytes)
-            windows.append({"row": row0 + start, "rows": cnt, "add": got, "eq_bits": gb, "eq_validity": gv})
+        ok_local, why = False, ""
+        try:
+            windows = []
+            w = 1 << 16
+            for start in (0, (n // 2) // 64 * 64, max(0, (n - w) // 64 * 64)):
+                cnt = min(w, n - start)
+                nbytes = (cnt + 7) // 8
+                got, gb, gv = np.empty(cnt, np.float32), np.empty(nbytes, np.uint8), np.empty(nbytes, np.uint8)
+                capi.call("agpu_download", h, C.c_void_p(got.ctypes.data), C.c_void_p(fo.ptr + 4 * start), 4 * cnt)
+                capi.call("agpu_download", h, C.c_void_p(gb.ctypes.data), C.c_void_p(ob.ptr + start // 8), nbytes)
+                capi.call("agpu_download", h, C.c_void_p(gv.ctypes.data), C.c_void_p(ov.ptr + start // 8), nbytes)
+                windows.append({"row": row0 + start, "rows": cnt, "add": got, "eq_bits": gb, "eq_validity": gv})
+            ok_local = check_headline_windows(windows)
+        except Exception as e:  # noqa: BLE001 — a rank that cannot check says so; the collective sequence stays the same on every rank
+            why = f" ({type(e).__name__}: {e})"
+            print(f"bench.py: rank {rank}: window check failed{why}", file=sys.stderr)
+        bad_ranks = int(round(across_ranks([0.0 if ok_local else 1.0], capi.RED_SUM)[0]))
+        gpu_parity = (f"GPU outputs bit-exact vs oracle on 3 windows of 65536 rows (first/middle/last) of every rank's shard: all {world} rank(s), "
+                      f"each at its own row0, AND over ranks through the communicator" if bad_ranks == 0
+                      else f"MISMATCH on {bad_ranks} of {world} rank(s){why}")
 
     extra = {"runtime": runtime, "per_rank": per_rank, "rccl_ranks": proof["rccl_ranks"], "distinct_devices": proof["distinct_devices"],
              # True only for a ONE-rank run whose RCCL bootstrap did not come up within the deadline: the communicator is then local (device
@@ -615,6 +679,18 @@ def main():
             ms_k = mean_ms(pairs)
             stats[name] = {"local_ms": round(ms_k, 4), "local_GBps": round(4.0 * n / ms_k / 1e6, 1),
                            "frac_hbm_peak": round(4.0 * n / ms_k / 1e6 / HBM_PEAK_GBPS, 4)}
+        import numpy as _np
+
+        def scalar(buf, dt):
+            return dev.retrive_data(buf, _np.dtype(dt).itemsize, pipeline=p).view(dt)[0]
+
+        # this rank's LOCAL statistics (what the launches above left in the buffers), before the collectives overwrite them: their bit
+        # patterns + the row count are gathered over the ranks (a SUM all-reduce of one slot per rank) for the check below
+        loc = {"sum": scalar(stat_out["sum"], _np.float32), "min": scalar(stat_out["min"], _np.float32),
+               "max": scalar(stat_out["max"], _np.float32), "sum_f64": scalar(stat_out["sum_f64"], _np.float64)}
+        b64 = int(_np.array([loc["sum_f64"]], _np.float64).view(_np.uint64)[0])
+        mine = [int(_np.array([loc[k]], _np.float32).view(_np.uint32)[0]) for k in ("sum", "min", "max")] + [b64 & 0xFFFFFFFF, b64 >> 32, n]
+        gathered = across_ranks(slot_vector(rank, world, mine), capi.RED_SUM)
         # the collective form: local kernel + RCCL all-gather + combine, timed end to end on the stream
         cs, ce = ev(), ev()
         comm.reduce(p, capi.RED_SUM, capi.F32, fa, None, n, stat_out["sum"])  # warm RCCL's first-call setup
@@ -627,17 +703,28 @@ def main():
         capi.call("agpu_event_record", ce, h)
         comm.sync(p)
         four_ms = ms_between(cs, ce)
-        import numpy as _np
-
-        def scalar(buf, dt):
-            return dev.retrive_data(buf, _np.dtype(dt).itemsize, pipeline=p).view(dt)[0]
-
+        got = {"sum": scalar(stat_out["sum"], _np.float32), "min": scalar(stat_out["min"], _np.float32),
+               "max": scalar(stat_out["max"], _np.float32), "sum_f64": scalar(stat_out["sum_f64"], _np.float64)}
+        # … and the collectives' results against the ORACLE's rank-ordered combine of the gathered local records, on every rank (each
+        # holds the result), AND-ed over the ranks: the final reduce proves itself at any world size
+        verified, detail = None, None
+        if not args.no_cpu_baseline:
+            try:
+                detail = verify_final_reduce(reduce_records_from_gathered(gathered, world), got)
+                mine_ok = all(detail.values())
+            except Exception as e:  # noqa: BLE001
+                detail, mine_ok = {"error": f"{type(e).__name__}: {e}"}, False
+            verified = int(round(across_ranks([0.0 if mine_ok else 1.0], capi.RED_SUM)[0])) == 0
         local_sum_ms = sum(stats[k]["local_ms"] for k in ("sum", "min", "max", "sum_f64"))
         four_max = across_ranks([four_ms], capi.RED_MAX)[0]
         extra["reduce_sum_min_max"] = {
-            "rows_total": total_rows, "sum_f32_reference_tree": float(scalar(stat_out["sum"], _np.float32)),
-            "min": float(scalar(stat_out["min"], _np.float32)), "max": float(scalar(stat_out["max"], _np.float32)),
-            "sum_f64": float(scalar(stat_out["sum_f64"], _np.float64)), "per_statistic": stats,
+            "rows_total": total_rows, "sum_f32_reference_tree": float(got["sum"]),
+            "min": float(got["min"]), "max": float(got["max"]),
+            "sum_f64": float(got["sum_f64"]), "per_statistic": stats,
+            "verified": verified, "verified_rank0": detail,
+            "verified_what": "sum / min / max / sum_f64 as the collectives left them on EVERY rank, bit for bit against the oracle's rank-ordered "
+                             "combine (oracle.combine_records) of the per-rank local statistics gathered through the communicator; AND over ranks",
+            "local_rank0": {k: float(v) for k, v in loc.items()},
             "four_statistics_with_final_reduce_ms": round(four_ms, 4),
             "four_statistics_with_final_reduce_ms_max_over_ranks": round(four_max, 4),
             "aggregate_GBps": round(4 * 4.0 * total_rows / four_max / 1e6, 1),
@@ -844,22 +931,58 @@ def main():
             del u8, ov2, sc
         except Exception as e:  # noqa: BLE001
             extra["configs"] = {"error": f"{type(e).__name__}: {e}"}
-        # ---- the headline step with nine ORDINARY agpu_malloc blocks (what a caller of the host API gets) instead of the
-        # two placed tables
+        # ---- the headline step the way a caller of the HOST API runs it: six ordinary buffers as `from_slice` allocates
+        # them (agpu_malloc, one by one), the outputs allocated BY THE OPS — `a.add_op(b)` / `ia.eq_op(ib)` of arrow_gpu_amd, i.e.
+        # agpu_malloc_like with the inputs as neighbours — after everything the legs above did to the pool.  Kernel times from the
+        # library's own per-launch event pairs (agpu_pipeline_enable_timing): the op allocates on the host between our records.
         try:
-            sizes = [4 * n] * 3 + [4 * n] * 2 + [nb] * 4
-            pool = [dev.create_empty_buffer(sz) for sz in sizes]
-            pfa, pfb, pfo, pia, pib, pva, pvb, pob, pov = pool
+            import numpy as np
+
+            import arrow_gpu_amd as ag
+
+            pool = [dev.create_empty_buffer(sz) for sz in [4 * n] * 4 + [nb] * 2]
+            pfa, pfb, pia, pib, pva, pvb = pool
             synth_inputs(pfa, pfb, pia, pib, pva, pvb)
             p.sync()
-            el_p, add_p, eq_p, _ = timed_run(make_step(tuple(pool), n), min(args.steps, 10), 2)
+            A, B = ag.Float32ArrayGPU(pfa, dev, n, None), ag.Float32ArrayGPU(pfb, dev, n, None)
+            IA = ag.Int32ArrayGPU(pia, dev, n, ag.NullBitBufferGpu(pva, n, dev))
+            IB = ag.Int32ArrayGPU(pib, dev, n, ag.NullBitBufferGpu(pvb, n, dev))
+            p.enable_timing(2)
+            k_api = min(args.steps, 10)
+
+            def api_ms(op):
+                ts = []
+                for i in range(k_api + 2):
+                    r = op()
+                    ns, _ = p.last_kernel_ns()
+                    p.sync()  # drops the pipeline's keep-alives: the output goes back to the pool, the next call places it afresh
+                    del r
+                    if i >= 2:
+                        ts.append(ns / 1e6)
+                return float(np.mean(ts)), [round(t, 4) for t in ts]
+
+            add_p, add_ts = api_ms(lambda: A.add_op(B, p))
+            eq_p, eq_ts = api_ms(lambda: IA.eq_op(IB, p))
+            p.enable_timing(0)
+            r1, r2 = A.add(B), IA.eq(IB)  # warm: the outputs' blocks exist
+            del r1, r2
+            dev.sync()
+            t0 = time.perf_counter()
+            for _ in range(k_api):  # the whole step as the reference's caller writes it: a.add(b), ia.eq(ib) — a new pipeline, a new output and
+                r1 = A.add(B)       # a finish per call; the results dropped as the next ones are asked for (host time of all that included)
+                r2 = IA.eq(IB)
+                del r1, r2
+            dev.sync()
+            el_p = time.perf_counter() - t0
             extra["layout_pool"] = {
-                "value_GBps": round(step_bytes_per_row * n * min(args.steps, 10) / el_p / 1e9, 2),
+                "value_GBps": round(step_bytes_per_row * n * k_api / el_p / 1e9, 2),
                 "add_ms": round(add_p, 4), "add_frac_hbm_peak": round(ADD_BYTES_PER_ROW * n / add_p / 1e6 / HBM_PEAK_GBPS, 4),
                 "eq_ms": round(eq_p, 4), "eq_frac_hbm_peak": round(EQ_BYTES_PER_ROW * n / eq_p / 1e6 / HBM_PEAK_GBPS, 4),
-                "what": "the same step over nine ordinary agpu_malloc blocks (the allocator's own placement, DESIGN.md §3) — "
-                        "what an a.add(b) / a.eq(b) caller of the host API gets"}
-            del pool, pfa, pfb, pfo, pia, pib, pva, pvb, pob, pov
+                "add_ms_per_launch": add_ts, "eq_ms_per_launch": eq_ts,
+                "what": "the same step through the HOST API: inputs in six ordinary agpu_malloc blocks (what from_slice gives), "
+                        "Float32ArrayGPU.add_op / Int32ArrayGPU.eq_op allocate their outputs (agpu_malloc_like) per call; kernel times "
+                        "from the library's per-launch events, value_GBps from the wall clock of the host loop"}
+            del A, B, IA, IB, pool, pfa, pfb, pia, pib, pva, pvb
         except Exception as e:  # noqa: BLE001
             extra["layout_pool"] = {"error": f"{type(e).__name__}: {e}"}
 
@@ -1009,28 +1132,36 @@ def main():
                        "rows_per_gpu": n, "rows_total": total_rows, "sharding": shard_txt + ", no data-path collective",
                        "layout": "columns allocated as two tables placed for the HBM channel hash (agpu_malloc_table, DESIGN.md §3)",
                        "frac_hbm_peak_per_gpu": round(value / world / HBM_PEAK_GBPS, 4),
+                       # the same two kernels over what a caller of the host API gets (extra.layout_pool): ordinary blocks, outputs placed by the ops
+                       **({"host_api": {"add_frac_hbm_peak": extra["layout_pool"]["add_frac_hbm_peak"],
+                                        "eq_frac_hbm_peak": extra["layout_pool"]["eq_frac_hbm_peak"]}}
+                          if "add_frac_hbm_peak" in extra.get("layout_pool", {}) else {}),
                        **({"tuning": args.tune} if args.tune else {})},
             "roofline": {"bound": "hbm", "kernel": "ew_kernel<float, OpAdd> (agpu_binary ADD f32)",
                          "achieved": round(add_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(add_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "traffic_source": traffic_source if traffic is not None else None,
-                         "algorithmic_bytes_per_launch": ADD_BYTES_PER_ROW * n, "launch_ms": round(add_ms, 4)},
+                         "algorithmic_bytes_per_launch": ADD_BYTES_PER_ROW * n, "launch_ms": round(add_ms, 4),
+                         # rank 0's launch above; the slowest and the fastest rank's mean launch of the same kernel beside it
+                         "frac_per_rank": {"min": round(ADD_BYTES_PER_ROW * n / per_rank["add_ms"]["max"] / 1e6 / HBM_PEAK_GBPS, 4),
+                                           "max": round(ADD_BYTES_PER_ROW * n / per_rank["add_ms"]["min"] / 1e6 / HBM_PEAK_GBPS, 4)}},
             "extra": extra,
         }
         if want_cpu:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, windows, cfg_windows)
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample_rows, gpu_parity, cfg_windows)
             except Exception as e:  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         else:
             line["cpu_baseline"] = None
+        line["gpu_parity"] = gpu_parity  # also inside cpu_baseline; here so that a --no-… variant of the line still says what was checked
         try:
             C.CDLL(None).fflush(None)  # whatever C libraries buffered for "stdout" goes to stderr now, not after the line
         except Exception:  # noqa: BLE001
             pass
         real_stdout.write(json.dumps(line) + "\n")
         real_stdout.flush()
-    barrier()  # nobody tears its communicator down while rank 0 still measures the CPU leg… (world 1 only) / prints
+    barrier()  # nobody tears its communicator down while rank 0 still measures the CPU leg (≈ 40 s, inside the collective deadline) / prints
     comm.close()
 
 

@@ -132,7 +132,9 @@ agpu_status agpu_device_destroy(agpu_device* dev);
  * wrapped streams (work other runtimes queued on streams of their own is theirs to wait for).  With ONE stream outstanding — the usual
  * state behind the reference-style immediate ops of one thread — or up to three the wait goes through a
  * kernel per stream that posts into pinned host memory (tuning "sync_spin", docs/experiments.md R5.10: 6–9 µs instead of hipDeviceSynchronize's
- * 11); with more it IS hipDeviceSynchronize.
+ * 11); with more it IS hipDeviceSynchronize.  A stream with no call of this library since its last completed wait is known to be empty and is
+ * not waited for again — unless its raw handle was handed out (agpu_pipeline_stream) or it is a wrapped stream: those may carry work the
+ * library never saw and are waited for every time.  Tuning sync_spin < 0: always hipDeviceSynchronize, whatever the counters say.
  * agpu_device_download: the same wait with up to AGPU_MAILBOX_MAX_BYTES of device memory delivered on the way — `values()` of a reduction's result or of a small array in one
  * wait instead of two [ref: GpuDevice::retrive_data gpu_device.rs:232-265 polls the whole queue, then maps the staging buffer]. */
 agpu_status agpu_device_sync(agpu_device* dev);
@@ -219,6 +221,7 @@ agpu_status agpu_pipeline_finish(agpu_pipeline* p);
 agpu_status agpu_pipeline_sync(agpu_pipeline* p);   /* host waits for everything enqueued so far */
 agpu_status agpu_pipeline_destroy(agpu_pipeline* p);
 agpu_status agpu_pipeline_device(agpu_pipeline* p, agpu_device** out_device);
+/* the pipeline's hipStream_t.  From this call on the stream counts as carrying foreign work (see agpu_device_sync), until the pipeline is destroyed */
 agpu_status agpu_pipeline_stream(agpu_pipeline* p, void** out_hip_stream);
 /* Explicit dependency for hosts that overlap pipelines on purpose (double-buffered staging): work enqueued on `p` after
  * this call runs after everything enqueued on `other` so far.  Does not block the host, does not need a finish. */

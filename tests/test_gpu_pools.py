@@ -263,10 +263,12 @@ def test_big_pool_blocks_come_out_of_placed_arenas():
         capi.call("agpu_device_trim", dev._handle)
 
 
-def test_a_cached_arena_block_reused_for_a_table_keeps_to_its_units():
-    """a cache hit used to be re-coloured whatever the request was.  A table's block (agpu_malloc_table asks with
-    the arena switched off, so without the 16 KiB of colour room) whose total equals the cached arena block's size must get
-    the block at colour 0 — moved up by 4–12 KiB its zero fill and last column ran into the next arena block."""
+def test_cached_arena_blocks_and_table_blocks_do_not_stand_in_for_each_other():
+    """Round 6: blocks of >= 1 GiB come in two kinds.  A table's own block never takes a cached ARENA block (a table
+    carved from an arena loses 4-6 points on the compare) and — the case that cost the host API 6-7 points on the add — an ordinary
+    placed request never takes a cached PLAIN block (two freed one-column tables as the inputs of an add: 0.78 of the roof).
+    And ADVICE r3 still holds where a cached arena block does serve a request without colour room (tuning pool_arena = 0 after arena
+    blocks were cached): it is handed out at colour 0 — moved up by 4-12 KiB its zero fill ran into the next arena block."""
     import ctypes as C
 
     import numpy as np
@@ -278,25 +280,44 @@ def test_a_cached_arena_block_reused_for_a_table_keeps_to_its_units():
     p = ArrowComputePipeline(dev, "arena-table")
     capi.call("agpu_device_trim", dev._handle)
     unit, big = 512 << 20, (1 << 30) + 4096
-    for attempt in range(4):  # the rotating colour: every starting phase of it
-        blocks = [dev.create_empty_buffer(big) for _ in range(3)]             # units 0-2, 3-5, 6-8 of one arena
-        base = min(b.ptr for b in blocks) & ~0x3FFF
-        order = sorted(range(3), key=lambda k: blocks[k].ptr)
-        mid, last = blocks[order[1]], blocks[order[2]]
-        assert (last.ptr - base) // unit == 6 and (mid.ptr - base) // unit == 3
-        capi.call("agpu_memset", p._handle, C.c_void_p(last.ptr), 0xA5, 1 << 20)
-        p.sync()
-        mid_unit = mid.ptr & ~0x3FFF
-        blocks[order[1]] = None
-        del mid                                                                # → the size-keyed cache, 3 units
-        table = dev.create_table_buffers([3 * unit - 16384], zero_fill=True)   # total = 3 units exactly, no colour room
-        assert table[0].ptr == mid_unit, (attempt, hex(table[0].ptr), hex(mid_unit))  # reused, at colour 0
-        got = np.empty(1 << 20, np.uint8)
-        capi.call("agpu_download", p._handle, C.c_void_p(got.ctypes.data), C.c_void_p(last.ptr), 1 << 20)
-        assert (got == 0xA5).all(), attempt                                    # the neighbour is intact
-        capi.call("agpu_memset", p._handle, C.c_void_p(table[0].ptr), 0x11, 3 * unit - 16384)  # usable to its last byte
-        capi.call("agpu_download", p._handle, C.c_void_p(got.ctypes.data), C.c_void_p(last.ptr), 1 << 20)
-        assert (got == 0xA5).all(), attempt
-        del table, blocks, last
-        p.sync()
-        capi.call("agpu_device_trim", dev._handle)
+    try:
+        for attempt in range(4):  # the rotating colour: every starting phase of it
+            blocks = [dev.create_empty_buffer(big) for _ in range(3)]             # units 0-2, 3-5, 6-8 of one arena
+            base = min(b.ptr for b in blocks) & ~0x3FFF
+            order = sorted(range(3), key=lambda k: blocks[k].ptr)
+            mid, last = blocks[order[1]], blocks[order[2]]
+            assert (last.ptr - base) // unit == 6 and (mid.ptr - base) // unit == 3
+            capi.call("agpu_memset", p._handle, C.c_void_p(last.ptr), 0xA5, 1 << 20)
+            p.sync()
+            mid_unit = mid.ptr & ~0x3FFF
+            blocks[order[1]] = None
+            del mid                                                                # → the size-keyed cache, 3 units
+            # (1) a table of exactly that size gets a block of its own, outside the arena
+            table = dev.create_table_buffers([3 * unit - 16384], zero_fill=True)
+            assert not (base <= table[0].ptr < base + 64 * unit), (attempt, hex(table[0].ptr), hex(base))
+            tptr = table[0].ptr
+            del table                                                              # → the cache: a PLAIN block of 3 units
+            # (2) an ordinary placed request of that size takes the cached ARENA block (first in the cache or not), never the plain one
+            again = dev.create_empty_buffer(big)
+            assert again.ptr & ~0x3FFF == mid_unit, (attempt, hex(again.ptr), hex(mid_unit), hex(tptr))
+            del again                                                              # back into the cache BEHIND the plain block of the same size
+            again = dev.create_empty_buffer(big)                                   # … which the lookup has to step over
+            assert again.ptr & ~0x3FFF == mid_unit, (attempt, hex(again.ptr), hex(mid_unit), hex(tptr))
+            del again
+            # (3) pool_arena = 0: kinds no longer matter; whichever block comes back, an arena block comes at colour 0 and keeps to its units
+            capi.call("agpu_set_tuning", b"pool_arena", 0)
+            got_blocks = [dev.create_empty_buffer(3 * unit, zero_fill=True) for _ in range(2)]   # 3 units exactly, no colour room
+            ptrs = sorted(b.ptr for b in got_blocks)
+            assert ptrs == sorted([mid_unit, tptr]), (attempt, [hex(x) for x in ptrs], hex(mid_unit), hex(tptr))
+            got = np.empty(1 << 20, np.uint8)
+            capi.call("agpu_download", p._handle, C.c_void_p(got.ctypes.data), C.c_void_p(last.ptr), 1 << 20)
+            assert (got == 0xA5).all(), attempt                                    # the neighbour is intact
+            capi.call("agpu_memset", p._handle, C.c_void_p(mid_unit), 0x11, 3 * unit)  # usable to its last byte
+            capi.call("agpu_download", p._handle, C.c_void_p(got.ctypes.data), C.c_void_p(last.ptr), 1 << 20)
+            assert (got == 0xA5).all(), attempt
+            capi.call("agpu_set_tuning", b"pool_arena", 1)
+            del got_blocks, blocks, last
+            p.sync()
+            capi.call("agpu_device_trim", dev._handle)
+    finally:
+        capi.call("agpu_set_tuning", b"pool_arena", 1)

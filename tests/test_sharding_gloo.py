@@ -1,6 +1,7 @@
-"""CPU: the N>1 path — shard planning + final reduce over torch.distributed — with world_size 2 on the gloo backend.
-Per-shard partials come from the ORACLE here (no GPU in this container); on the GPU box bench.py feeds the same
-`sharding.final_reduce` with partials computed by the HIP kernels, backend "nccl" (= RCCL over xGMI)."""
+"""CPU: the N > 1 path with world_size 2 on the gloo backend — shard planning, the C ABI's record-gather protocol of the final reduce
+(agpu_comm_reduce) with the ORACLE as the shard-local kernel, and what makes a bench line of any world self-proving: the world proof
+and bench.py's per-rank parity / final-reduce checks (the numbers travel by a SUM all-reduce of one slot per rank, exactly as bench.py
+sends them through agpu_comm_all_reduce on the GPU box; gloo's all_reduce stands in for RCCL here)."""
 import os
 import socket
 
@@ -31,61 +32,6 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
-
-
-def _worker(rank, world, port, total, q):
-    import torch
-    import torch.distributed as dist
-
-    import oracle as O
-
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        sh = sharding.shard_rows(total, world, rank)
-        x = O.synth_f32(sh.rows, 20250418, sh.row0, -1.0, 1.0)        # this rank's shard of the column
-        bits = O.synth_bits(sh.rows, 7, sh.row0, 0.9)
-        s = torch.tensor([O.reduce_sum_f64(x)], dtype=torch.float64)
-        mn = torch.tensor([float(O.reduce(O.RED_MIN, O.F32, x))], dtype=torch.float32)
-        mx = torch.tensor([float(O.reduce(O.RED_MAX, O.F32, x))], dtype=torch.float32)
-        cnt = torch.tensor([O.bitmap_popcount(bits, sh.rows)], dtype=torch.int64)
-        sharding.final_reduce(s, mn, mx, cnt)
-        q.put((rank, s.item(), mn.item(), mx.item(), cnt.item(), sh.row0, sh.rows))
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world,total", [(2, 1_000_003), (2, 512 * 4096)])
-def test_final_reduce_world2_gloo(world, total):
-    import torch.multiprocessing as mp
-
-    import oracle as O
-
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
-    [p.start() for p in procs]
-    res = [q.get(timeout=120) for _ in range(world)]
-    [p.join(timeout=60) for p in procs]
-    assert all(p.exitcode == 0 for p in procs)
-    whole = O.synth_f32(total, 20250418, 0, -1.0, 1.0)
-    bits = O.synth_bits(total, 7, 0, 0.9)
-    exp_sum = float(np.sum(whole.astype(np.float64)))
-    for rank, s, mn, mx, cnt, row0, rows in res:
-        assert abs(s - exp_sum) <= 1e-9 * float(np.sum(np.abs(whole.astype(np.float64))))
-        assert mn == float(whole.min()) and mx == float(whole.max())          # exact
-        assert cnt == O.bitmap_popcount(bits, total)                            # exact
-    assert sorted(r[5] for r in res) == [s.row0 for s in sharding.all_shards(total, world)]
-
-
-def test_final_reduce_single_process_is_identity():
-    import torch
-
-    s = torch.tensor([1.5], dtype=torch.float64)
-    out = sharding.final_reduce(s, None, None, None)
-    assert out[0] is s and s.item() == 1.5
 
 
 # ---- the C ABI's protocol (agpu_comm_reduce: all-gather of one {statistic, n_local} record per rank, rank-ordered combine)
@@ -229,3 +175,104 @@ def test_world_proof_world2_gloo_every_rank_reaches_the_same_verdict(same_device
     assert res[0] == res[1]                       # a pure function of the gathered records: all ranks take the same exit
     assert res[0]["ok"] == (not same_device) and res[0]["rccl_ranks"] == 2
     assert res[0]["distinct_devices"] == (1 if same_device else 2)
+
+
+# ---- bench.py at world > 1: every rank checks windows of ITS shard against the oracle, the verdicts are AND-ed through
+# the communicator; the collectives' sum / min / max / f64 sum are checked on every rank against the oracle's rank-ordered combine of the
+# per-rank local statistics, gathered by a SUM all-reduce of one slot per rank (bench.slot_vector / reduce_records_from_gathered /
+# verify_final_reduce).  Played here by two gloo processes: the shard-local "kernels" are the oracle's, a corrupted rank must be caught.
+def _bench_protocol_worker(rank, world, port, shard_rows_list, corrupt, q):
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def across_ranks(values, op):
+            t = torch.tensor(values, dtype=torch.float64)
+            dist.all_reduce(t, op=op)
+            return [float(x) for x in t]
+
+        n, row0 = shard_rows_list[rank], sum(shard_rows_list[:rank])
+        # (1) the headline windows of THIS rank's shard, at its own row0
+        cnt = min(n, 4096)
+        add = O.binary(O.OP_ADD, O.F32, O.synth_f32(cnt, bench.SEED, row0, -1000.0, 1000.0), O.synth_f32(cnt, bench.SEED + 1, row0, -1000.0, 1000.0))
+        eq = O.compare(O.CMP_EQ, O.I32, O.synth_i32(cnt, bench.SEED + 2, row0, 1024), O.synth_i32(cnt, bench.SEED + 3, row0, 1024))
+        vd = O.bitmap_binary(O.OP_AND, O.synth_bits(cnt, bench.SEED + 4, row0, 0.9), O.synth_bits(cnt, bench.SEED + 5, row0, 0.9), cnt)
+        if corrupt == "window" and rank == 1:
+            add = add.copy()
+            add[7] = np.float32(1.0)
+        ok_local = bench.check_headline_windows([{"row": row0, "rows": cnt, "add": add, "eq_bits": eq, "eq_validity": vd}])
+        bad_ranks = int(round(across_ranks([0.0 if ok_local else 1.0], dist.ReduceOp.SUM)[0]))
+        # (2) the final reduce: local statistics → gathered records → the "collective's" result on every rank → check
+        x = O.synth_f32(n, bench.SEED, row0, -1000.0, 1000.0)
+        loc = {"sum": O.reduce(O.RED_SUM, O.F32, x), "min": O.reduce(O.RED_MIN, O.F32, x), "max": O.reduce(O.RED_MAX, O.F32, x),
+               "sum_f64": O.reduce_sum_f64(x)}
+        b64 = int(np.array([loc["sum_f64"]], np.float64).view(np.uint64)[0])
+        mine = [int(np.array([loc[k]], np.float32).view(np.uint32)[0]) for k in ("sum", "min", "max")] + [b64 & 0xFFFFFFFF, b64 >> 32, n]
+        gathered = across_ranks(bench.slot_vector(rank, world, mine), dist.ReduceOp.SUM)
+        recs = bench.reduce_records_from_gathered(gathered, world)
+        got = {"sum": O.combine_records(O.RED_SUM, O.F32, recs["sum"]), "min": O.combine_records(O.RED_MIN, O.F32, recs["min"]),
+               "max": O.combine_records(O.RED_MAX, O.F32, recs["max"]), "sum_f64": sum(float(v) for v, k in recs["sum_f64"] if k)}
+        if corrupt == "reduce" and rank == 0:
+            got["max"] = np.float32(got["max"]) + np.float32(1.0)
+        detail = bench.verify_final_reduce(recs, got)
+        unverified = int(round(across_ranks([0.0 if all(detail.values()) else 1.0], dist.ReduceOp.SUM)[0]))
+        q.put((rank, bad_ranks, unverified, [(float(v), int(k)) for v, k in recs["sum"]], float(got["sum"])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows,corrupt", [([65536, 65536], None), ([70_001, 33], None), ([5000, 0], None), ([65536, 65536], "window"),
+                                          ([65536, 65536], "reduce")])
+def test_bench_per_rank_parity_and_final_reduce_check_world2_gloo(rows, corrupt):
+    import torch.multiprocessing as mp
+
+    import oracle as O
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_protocol_worker, args=(r, 2, port, rows, corrupt, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(2))}
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert res[0][0] == res[1][0] == (1 if corrupt == "window" else 0)   # every rank knows how many ranks failed their windows
+    assert res[0][1] == res[1][1] == (1 if corrupt == "reduce" else 0)   # … and how many hold a result that is not the oracle's combine
+    assert res[0][2] == res[1][2]                                          # the gathered records are the same table on every rank
+    shards, row0 = [], 0
+    for n in rows:
+        shards.append(O.synth_f32(n, 20250418, row0, -1000.0, 1000.0))
+        row0 += n
+    assert [k for _, k in res[0][2]] == rows
+    for (v, _), sh in zip(res[0][2], shards):  # slot r of the gathered table IS rank r's local sum, bit for bit
+        assert np.float32(v).view(np.uint32) == np.float32(O.reduce(O.RED_SUM, O.F32, sh)).view(np.uint32)
+    assert np.float32(res[0][3]).view(np.uint32) == np.float32(O.sharded_reduce(O.RED_SUM, O.F32, shards)).view(np.uint32)
+
+
+def test_slot_vector_round_trip_is_exact_for_bit_patterns():
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    world = 8
+    rng = np.random.default_rng(5)
+    per_rank = [[int(x) for x in rng.integers(0, 2 ** 32, 5)] + [int(rng.integers(0, 2 ** 40))] for _ in range(world)]
+    total = np.zeros(6 * world)
+    for r in range(world):
+        total += np.array(bench.slot_vector(r, world, per_rank[r]))
+    recs = bench.reduce_records_from_gathered(list(total), world)
+    for r in range(world):
+        s, mn, mx, lo, hi, n = per_rank[r]
+        assert np.float32(recs["sum"][r][0]).view(np.uint32) == s or np.isnan(recs["sum"][r][0])
+        assert recs["min"][r][1] == recs["sum_f64"][r][1] == n
+        assert int(np.array([recs["sum_f64"][r][0]], np.float64).view(np.uint64)[0]) == ((hi << 32) | lo)

@@ -103,11 +103,88 @@ def test_north_star_bandwidth_targets_at_one_gpu(ctx):
     gb = np.empty(cnt // 8, np.uint8)
     capi.call("agpu_download", h, C.c_void_p(gb.ctypes.data), vp(ob, r0 // 8), cnt // 8)
     assert bits(gb) == bits(O.compare(O.CMP_EQ, O.I32, O.synth_i32(cnt, SEED + 2, r0, 1024), O.synth_i32(cnt, SEED + 3, r0, 1024))[: cnt // 8])
-    # a hard floor with margin under the north-star target: every box of rounds 1-4 measured >= 0.78 on both; a build that
-    # drops below 0.60 is broken, not unlucky.  Between 0.60 and 0.70 the miss is reported (and asserted under AGPU_PERF_STRICT=1).
-    assert add_frac >= 0.60 and eq_frac >= 0.60, (add_frac, eq_frac)
-    expect(add_frac >= 0.70 and eq_frac >= 0.70, "north_star: >= 0.70 of HBM peak on 1e9-row f32 add and i32 eq + validity",
+    # the HARD floor is the north-star target itself (it was 0.60): every box of rounds 1-5 measured >= 0.78 on both, so a
+    # build below 0.70 is broken, not unlucky.  The tighter expectation — what the kernels deliver on every box measured so far — stays soft
+    # (reported; asserted under AGPU_PERF_STRICT=1).
+    assert add_frac >= 0.70 and eq_frac >= 0.70, (add_frac, eq_frac)
+    expect(add_frac >= 0.82 and eq_frac >= 0.82, "headline kernels over tables: >= 0.82 of HBM peak on 1e9-row f32 add and i32 eq + validity",
            add_ms=round(add_ms, 4), add_frac=round(add_frac, 4), eq_ms=round(eq_ms, 4), eq_frac=round(eq_frac, 4))
+
+
+def test_north_star_targets_through_the_host_api_after_pool_churn(ctx):
+    """The same two kernels as an ORDINARY caller of the host API gets them: inputs in blocks allocated one by one
+    (agpu_malloc, what from_slice does), the outputs allocated by `add_op` / `eq_op` themselves (agpu_malloc_like) — after a thousand
+    alloc / free cycles of assorted sizes AND with freed one-column tables (plain 4 GiB blocks) sitting in the pool's cache: the state in
+    which round 5's bench handed two such blocks to the add and it ran at 0.78 of the roof.  Hard floor = the north-star 0.70; the soft
+    expectation is what the placed arenas deliver (>= 0.82)."""
+    import arrow_gpu_amd as ag
+
+    dev, p = ctx
+    h = p._handle
+    nb = (N + 63) // 64 * 8
+    rng = np.random.default_rng(11)
+    t1, = dev.create_table_buffers([4 * N])  # two freed one-column tables: plain blocks of the size an ordinary 4e9-byte request rounds to
+    t2, = dev.create_table_buffers([4 * N])
+    del t1, t2
+    live = []
+    for i in range(1000):
+        size = int(rng.choice([64, 4096, 1 << 16, 1 << 20, 3 << 20, 40 << 20, 300 << 20, (1 << 30) + 4096, 4 * N]))
+        live.append(dev.create_empty_buffer(size))
+        if len(live) > 6 or size >= (1 << 30):
+            live.pop(int(rng.integers(0, len(live))))
+    del live
+    p.sync()
+    fa, fb, ia, ib = (dev.create_empty_buffer(4 * N) for _ in range(4))
+    va, vb = dev.create_empty_buffer(nb), dev.create_empty_buffer(nb)
+    capi.call("agpu_synth_f32", h, vp(fa), N, SEED, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_f32", h, vp(fb), N, SEED + 1, 0, C.c_float(-1000.0), C.c_float(1000.0))
+    capi.call("agpu_synth_i32", h, vp(ia), N, SEED + 2, 0, 1024)
+    capi.call("agpu_synth_i32", h, vp(ib), N, SEED + 3, 0, 1024)
+    capi.call("agpu_synth_bits", h, vp(va), N, SEED + 4, 0, C.c_double(0.9))
+    capi.call("agpu_synth_bits", h, vp(vb), N, SEED + 5, 0, C.c_double(0.9))
+    p.sync()
+    A, B = ag.Float32ArrayGPU(fa, dev, N, None), ag.Float32ArrayGPU(fb, dev, N, None)
+    IA = ag.Int32ArrayGPU(ia, dev, N, ag.NullBitBufferGpu(va, N, dev))
+    IB = ag.Int32ArrayGPU(ib, dev, N, ag.NullBitBufferGpu(vb, N, dev))
+    p.enable_timing(2)
+
+    def median_ms(op, check):
+        ts = []
+        for i in range(9):
+            r = op()
+            ns, _ = p.last_kernel_ns()
+            if i == 8:
+                check(r)
+            p.sync()
+            del r
+            if i >= 2:
+                ts.append(ns / 1e6)
+        return float(np.median(ts))
+
+    r0, cnt = (N // 2) // 64 * 64, 1 << 16
+
+    def check_add(r):
+        got = np.empty(cnt, np.float32)
+        capi.call("agpu_download", h, C.c_void_p(got.ctypes.data), vp(r.data, 4 * r0), 4 * cnt)
+        assert bits(got) == bits(O.binary(O.OP_ADD, O.F32, O.synth_f32(cnt, SEED, r0, -1000.0, 1000.0), O.synth_f32(cnt, SEED + 1, r0, -1000.0, 1000.0)))
+
+    def check_eq(r):
+        gb = np.empty(cnt // 8, np.uint8)
+        capi.call("agpu_download", h, C.c_void_p(gb.ctypes.data), vp(r.data, r0 // 8), cnt // 8)
+        assert bits(gb) == bits(O.compare(O.CMP_EQ, O.I32, O.synth_i32(cnt, SEED + 2, r0, 1024), O.synth_i32(cnt, SEED + 3, r0, 1024))[: cnt // 8])
+
+    try:
+        add_ms = median_ms(lambda: A.add_op(B, p), check_add)
+        eq_ms = median_ms(lambda: IA.eq_op(IB, p), check_eq)
+    finally:
+        p.enable_timing(0)
+    add_frac, eq_frac = 12.0 * N / add_ms / 1e6 / 8000.0, 8.5 * N / eq_ms / 1e6 / 8000.0
+    assert add_frac >= 0.70 and eq_frac >= 0.70, (add_frac, eq_frac)
+    expect(add_frac >= 0.82 and eq_frac >= 0.82, "host API over ordinary pool blocks after churn: >= 0.82 of HBM peak on f32 add and i32 eq + validity",
+           add_ms=round(add_ms, 4), add_frac=round(add_frac, 4), eq_ms=round(eq_ms, 4), eq_frac=round(eq_frac, 4))
+    del A, B, IA, IB, fa, fb, ia, ib, va, vb
+    p.sync()
+    capi.call("agpu_device_trim", dev._handle)
 
 
 class _Step(C.Structure):
