@@ -27,8 +27,8 @@
 // (21 / 16) — every piece costs an event wait of ≈ 150 µs on the shared stream, which is what bounds the engine, not the copies.
 static size_t stage_chunk_for(size_t bytes) { (void)bytes; return AGPU_STAGE_CHUNK; }
 static int stage_threads_for(const agpu_pipeline* p, size_t bytes) {
-  int64_t t = p->tune.h2d_threads;
-  if (t <= 0) t = 8;
+  (void)p;
+  int64_t t = 8;
   const size_t chunks = (bytes + stage_chunk_for(bytes) - 1) / stage_chunk_for(bytes);
   if ((size_t)t > chunks) t = (int64_t)chunks;
   if (t > 32) t = 32;

@@ -23,25 +23,18 @@
 // A pipeline carries its OWN copy (taken from the process defaults when it is created, changed by
 // agpu_pipeline_set_tuning), so one thread's sweep never changes the kernels another pipeline launches.
 struct agpu_tuning {
-  int64_t stream_grid;    // blocks for streaming kernels (0 = auto: one tile per block)
-  int64_t stream_bpc;     // blocks per CU when stream_grid == 0
-  int64_t stream_unroll;  // 16-byte vectors in flight per lane per array: 1, 2, 4 or 8
-  int64_t stream_nt;      // bit0: nontemporal loads, bit1: nontemporal stores
+  int64_t stream_grid;    // blocks for streaming kernels (0 = auto: one tile per block); > 0 forces a persistent grid-stride launch (tests: the loop paths)
   int64_t cmp_variant;    // 0 = ballot (dword loads), 1 = vector loads + nibble shuffle
-  int64_t reduce_grid;    // blocks for reductions (0 = auto)
-  int64_t table_tiles;    // tiles per block for kernels that stage a lookup table in LDS (lut8 / trig16 / pow)
-  int64_t gather_bucket;  // take/put: 0 = auto (bucketed above the measured crossover), 1 = always direct, 2 = always bucketed
+  int64_t gather_bucket;  // take/put: 0 = auto (size thresholds + the device-side locality probe), 1 = always direct, 2 = always bucketed, 4 = like 2 but with the probe (tests)
   int64_t h2d_mode;       // host↔device staging of agpu_import/export_arrow: 0 = auto, 1 = pageable hipMemcpy, 2 = threaded pinned staging, 3 = hipHostRegister in place
-  int64_t h2d_threads;    // staging threads for mode 2 (0 = auto)
-  int64_t gather_region_bits;  // bucketed take/put: log2(elements) of a source region (0 = auto: 512 KiB regions)
-  int64_t gather_offsets;      // bucketed pair pipeline: 0 = auto (= 3), 1 = ranges reserved with global atomics, 2 = from column scans of per-tile counts (P and G), 3 = scan for P, atomics for G (two ranges per 64-bit atomic), 6 = the same with one 32-bit atomic per range, 8 = 16 Ki-row partition tiles, 4 = round 3's partition and gather passes
-  int64_t heavy_tiles;         // tiles per block of the VALU-heavy f32 unary kernels (sin / cos / sinh / log): the next tile's loads are issued before the current tile is evaluated (0 = auto)
-  int64_t cast_tiles;          // chunks per wave of the widening casts and cast-headed chains, next chunk prefetched the same way (0 = auto)
-  int64_t tile_auto;           // 0 = the "auto" of heavy_tiles / cast_tiles / table_tiles is ADAPTIVE for big launches (one or two tiles per block, whichever the device measures faster on these buffers: runtime.hip agpu_tiles_pick); 1 = static defaults (one tile); > 1 = adaptive with this many bytes as the threshold instead of 256 MiB (tests)
-  int64_t wave_lds;            // unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the ×2 / ×4 widening casts and the 8-bit table kernels: 0 = each kernel's measured default (6800 B ≈ 24 waves per CU; u8 → 32-bit casts 10240 B ≈ 16), < 0 = no cap, > 0 = this many bytes
-  int64_t sync_spin;           // agpu_pipeline_sync and uploads / downloads of ≤ 3840 bytes wait for a kernel that posts into the pipeline's pinned mailbox instead of hipStreamSynchronize (12 → 7 µs for "one kernel, one scalar back"): 0 = yes, spinning for at most 200 µs before the blocking wait; > 0 = this many µs; < 0 = off
+  int64_t tiles;          // tiles per block of the kernels that issue the NEXT tile's loads before they evaluate the current one — the VALU-heavy f32 unary
+                          // kernels, the widening casts and cast-headed chains, the LDS-table kernels (lut8 / trig16 / log / pow): 0 = auto (each kernel's default,
+                          // adaptive for big launches: tile_auto), > 0 = this many (round 6: one key instead of heavy_tiles / cast_tiles / table_tiles)
+  int64_t tile_auto;      // 0 = the "auto" of `tiles` is ADAPTIVE for big launches (one or two tiles per block, whichever the device measures faster on these buffers: runtime.hip agpu_tiles_pick); 1 = static defaults (one tile); > 1 = adaptive with this many bytes as the threshold instead of 256 MiB (tests)
+  int64_t wave_lds;       // unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the ×2 / ×4 widening casts and the 8-bit table kernels: 0 = each kernel's measured default (6800 B ≈ 24 waves per CU; sin / cos and the u8 → 32-bit casts 10240 B ≈ 16), < 0 = no cap, > 0 = this many bytes
+  int64_t sync_spin;      // agpu_pipeline_sync and uploads / downloads of ≤ 3840 bytes wait for a kernel that posts into the pipeline's pinned mailbox instead of hipStreamSynchronize (12 → 7 µs for "one kernel, one scalar back"): 0 = yes, spinning for at most 200 µs before the blocking wait; > 0 = this many µs; < 0 = off
 };
-#define AGPU_TUNE_KEYS 17
+#define AGPU_TUNE_KEYS 8
 agpu_tuning agpu_tuning_defaults();  // snapshot of the process-wide defaults (atomics, runtime.hip)
 bool agpu_mem_pool_enabled();        // process-wide "mem_pool" switch (device-level behaviour, not per pipeline)
 
@@ -331,12 +324,11 @@ static inline unsigned wave_lds_for(const agpu_pipeline* p, unsigned dflt_bytes_
 
 // Grid for a streaming kernel that owns `tiles` block-tiles.  Measured on MI355X at 1e9 rows (profiles/
 // r01_sweep_add_f32_1e9.json): ONE tile per block beats every persistent grid (6.54 vs ≤6.52 TB/s at 32768 blocks,
-// 5.3 TB/s at 2048), so the default is grid = tiles; stream_grid > 0 forces a persistent grid-stride launch and
-// stream_bpc > 0 a blocks-per-CU one (both kept for sweeps).  Kernels still grid-stride, so any grid is correct.
+// 5.3 TB/s at 2048), so the default is grid = tiles; stream_grid > 0 forces a persistent grid-stride launch (kept for
+// sweeps and for the tests of the loop paths).  Kernels still grid-stride, so any grid is correct.
 static inline int stream_grid_for(const agpu_pipeline* p, uint64_t tiles) {
   uint64_t g = tiles;
   if (p->tune.stream_grid > 0) g = (uint64_t)p->tune.stream_grid;
-  else if (p->tune.stream_bpc > 0) g = (uint64_t)p->dev->num_cus * (uint64_t)p->tune.stream_bpc;
   if (g > tiles) g = tiles;
   if (g > 0x3FFFFFFFull) g = 0x3FFFFFFFull;  // hipDim3.x limit headroom
   if (g < 1) g = 1;
@@ -381,7 +373,7 @@ __device__ __forceinline__ void st_vec(V* p, V v) {
 // the binary kernels, and it COSTS the 8-bit kernels and the ×4 widening casts 1–2 % AT 32 WAVES PER CU — so it is opt-in per call site.
 // Round 5: under the occupancy cap (wave_lds_for below) the ×4 answer flips — sc1 nt is +1–2 % for the u8 → 32-bit casts, the 8-bit and 16-bit table
 // kernels and the ×4 cast chain (docs/experiments.md R5.8); nontemporal LOADS stay 4–10 % ahead of plain ones with or without a cap
-// (tools/r05_ldnt.sh: sin 0.82 / 0.77, cos 0.825 / 0.73, add 0.835 / 0.775).
+// (tools/archive/r05_ldnt.sh: sin 0.82 / 0.77, cos 0.825 / 0.73, add 0.835 / 0.775).
 template <typename V>
 __device__ __forceinline__ void st_vec_sc1(V* p, V v) {
   static_assert(sizeof(V) == 16, "16-byte vectors only");

@@ -248,7 +248,7 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
   const T* pa = static_cast<const T*>(a);
   const T* pb = static_cast<const T*>(b);
   const bool use_ballot = sizeof(T) == 4 && p->tune.cmp_variant == 0;
-  const bool nt = (p->tune.stream_nt & 1) != 0;  // inputs are read exactly once: nontemporal loads
+  const bool nt = true;  // inputs are read exactly once: nontemporal loads
   const uint64_t* va64 = static_cast<const uint64_t*>(va);
   const uint64_t* vb64 = static_cast<const uint64_t*>(vb);
   uint64_t* out64 = static_cast<uint64_t*>(out);
@@ -276,13 +276,9 @@ static agpu_status launch_cmp(agpu_pipeline* p, const void* a, const void* b, co
     }
     done_rows = ntiles * TILE;
   } else if (aligned16(a) && aligned16(b)) {
-    // packs per lane and array in flight: TWO by default (round 3, tools/probe/narrow_tunings.py, one process: u8 eq 0.755–0.786
-    // of the roof with one pack, 0.81–0.82 with two, 0.80–0.81 with four; u16 lt 0.81–0.84 / 0.84–0.85 / 0.84); "stream_unroll" = 1 / 4
-    // ("stream_unroll" = 4: four packs; = 8: the old single pack, for sweeps — the knob's own default of 1 means "the default")
-    const int u = p->tune.stream_unroll == 4 ? 4 : p->tune.stream_unroll == 8 ? 1 : 2;
-    if (u == 4) done_rows = launch_cmp_vec<T, OP, 4>(p, pa, pb, va, vb, out, outv, n, nt, vec16, vcount, &n_vcount);
-    else if (u == 2) done_rows = launch_cmp_vec<T, OP, 2>(p, pa, pb, va, vb, out, outv, n, nt, vec16, vcount, &n_vcount);
-    else done_rows = launch_cmp_vec<T, OP, 1>(p, pa, pb, va, vb, out, outv, n, nt, vec16, vcount, &n_vcount);
+    // packs per lane and array in flight: TWO (round 3, tools/probe/narrow_tunings.py, one process: u8 eq 0.755–0.786
+    // of the roof with one pack, 0.81–0.82 with two, 0.80–0.81 with four; u16 lt 0.81–0.84 / 0.84–0.85 / 0.84)
+    done_rows = launch_cmp_vec<T, OP, 2>(p, pa, pb, va, vb, out, outv, n, nt, vec16, vcount, &n_vcount);
   }
   if (done_rows < n) {
     const uint64_t first_word = done_rows / 64, nwords = (n + 63) / 64;

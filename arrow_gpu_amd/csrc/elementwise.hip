@@ -22,7 +22,7 @@
 
 #include "common.hpp"
 
-// tiles per block for the kernels that stage a table in LDS (lut8, trig16, pow): tuning key "table_tiles"
+// tiles per block for the kernels that stage a table in LDS (lut8, trig16, pow): tuning key "tiles"
 // tiles per block of the kernels that stage a table in LDS; `dflt` = the kernel's default: 1 for the HBM-bound ones (lut8, trig16, log,
 // pow array ∘ array — see tile_run below), 3 for pow with a scalar exponent (launch_pow_f32)
 // A block that takes several tiles walks them A GRID APART (tile b, b + G, b + 2G …) and issues the next tile's loads before it
@@ -34,8 +34,8 @@
 //     allocations (cast u8→f32 0.80 → 0.84, sin_u8 0.77 → 0.84, sin f32 0.785 → 0.82) and LOSE 7–9 % in others — the same library,
 //     the same box, another process: it follows what the driver backed the buffers with (the allocation lottery of DESIGN.md §3), not
 //     the distance between the windows (every G from +1 to +2^19 tiles behaves alike), the relative position of input and output,
-//     the timing method or the clock state.  One tile per block is insensitive to it (±1 %), so that is their default; the tunings
-//     "heavy_tiles" / "cast_tiles" / "table_tiles" stay for callers who measure their own allocation;
+//     the timing method or the clock state.  One tile per block is insensitive to it (±1 %), so that is their default; the tuning
+//     "tiles" stays for callers who measure their own allocation;
 //   * CONTIGUOUS runs (block b owns [b·k, b·k + k)) lose 10–13 % everywhere: neighbouring waves then write every k-th 1–4 KiB tile at a
 //     time, and address bits 12 / 13 feed the channel hash (profiles/r04_prefetch_sweep_contiguous_runs.json).
 struct TileRun {
@@ -46,7 +46,7 @@ __device__ __forceinline__ TileRun tile_run(uint64_t unit, uint64_t n_units, uin
 }
 // units a launch needs for `tiles` tiles at k tiles per unit
 static inline uint64_t tile_units(uint64_t tiles, uint64_t k) { return (tiles + k - 1) / k; }
-static inline uint64_t tab_k(const agpu_pipeline* p, uint64_t dflt = 1) { return p->tune.table_tiles > 0 ? (uint64_t)p->tune.table_tiles : dflt; }
+static inline uint64_t tab_k(const agpu_pipeline* p, uint64_t dflt = 1) { return p->tune.tiles > 0 ? (uint64_t)p->tune.tiles : dflt; }
 
 #ifndef AGPU_STREAM_U
 #define AGPU_STREAM_U 1  // 16-byte vectors per lane per input array per tile (measured best: profiles/r01_sweep_add_f32_1e9.json)
@@ -292,9 +292,17 @@ __device__ __forceinline__ f32x2_t sincos_f32_pair(f32x2_t x) {  // meaningful f
   const float s0 = s.x, s1 = s.y;
   const uint32_t q0 = __builtin_bit_cast(uint32_t, s0) + (uint32_t)WANT_COS;  // cos(x) = sin(x + π/2)
   const uint32_t q1 = __builtin_bit_cast(uint32_t, s1) + (uint32_t)WANT_COS;
-  const float o0 = (q0 & 1u) ? C.x : S.x, o1 = (q1 & 1u) ? C.y : S.y;
-  const uint32_t v0 = __builtin_bit_cast(uint32_t, o0) ^ ((q0 << 30) & 0x80000000u);  // quadrants 2, 3: negate
-  const uint32_t v1 = __builtin_bit_cast(uint32_t, o1) ^ ((q1 << 30) & 0x80000000u);
+  // odd quadrant: C, else S — as a bit select under a 0 / ~0 mask (v_bfe_i32 + v_bfi_b32: two instructions; and / compare / cndmask are three);
+  // quadrants 2, 3: negate — ADDING 2^31 flips the sign bit and nothing else (v_and + v_lshl_add_u32: two; shift / and / xor are three)
+  const float Sx = S.x, Sy = S.y, Cx = C.x, Cy = C.y;
+  // (the empty asm statements keep the compiler from canonicalising the two forms back into the three-instruction ones)
+  uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)q0, 0, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)q1, 0, 1);
+  uint32_t n0 = q0 & 2u, n1 = q1 & 2u;
+  asm("" : "+v"(m0), "+v"(m1), "+v"(n0), "+v"(n1));
+  const uint32_t s0b = __builtin_bit_cast(uint32_t, Sx), s1b = __builtin_bit_cast(uint32_t, Sy);
+  const uint32_t o0 = s0b ^ ((__builtin_bit_cast(uint32_t, Cx) ^ s0b) & m0);  // the form the back end turns into ONE v_bfi_b32
+  const uint32_t o1 = s1b ^ ((__builtin_bit_cast(uint32_t, Cy) ^ s1b) & m1);
+  const uint32_t v0 = (n0 << 30) + o0, v1 = (n1 << 30) + o1;
   return (f32x2_t){__builtin_bit_cast(float, v0), __builtin_bit_cast(float, v1)};
 }
 __device__ __forceinline__ bool sincos_f32_is_slow(float x) { return !(fabsf(x) < 1.0e6f); }
@@ -581,14 +589,18 @@ __global__ __launch_bounds__(AGPU_BLOCK) void ew_kernel_unaligned(const T* a, co
 }
 
 template <typename Op> struct EwUnroll { static constexpr int value = AGPU_STREAM_U; };
-template <> struct EwUnroll<UnSin> { static constexpr int value = 2; };  // re-checked after the round-2 trimming: 1 → −5 %, 3 → −5 %; and under the
-template <> struct EwUnroll<UnCos> { static constexpr int value = 2; };  // occupancy cap (round 5, profiles/r05_sincos_unroll_x_cap.txt): 2 @ 6800 B 0.83, 4 @ 10240 B 0.82, 1 @ 4200 B 0.80–0.81, 3 0.78
+#ifndef AGPU_SINCOS_U
+#define AGPU_SINCOS_U 2  // 16-byte packs per lane of the f32 sin / cos tile kernel (A/B builds: tools/r06_sincos_variants.sh)
+#endif
+template <> struct EwUnroll<UnSin> { static constexpr int value = AGPU_SINCOS_U; };  // re-checked after the round-2 trimming: 1 → −5 %, 3 → −5 %; and under the
+template <> struct EwUnroll<UnCos> { static constexpr int value = AGPU_SINCOS_U; };  // occupancy cap (round 5, profiles/r05_sincos_unroll_x_cap.txt): 2 @ 6800 B 0.83, 4 @ 10240 B 0.82, 1 @ 4200 B 0.80–0.81, 3 0.78
 template <> struct EwUnroll<UnLog> { static constexpr int value = 2; };
 template <> struct EwUnroll<UnSinh> { static constexpr int value = 4; };  // re-checked under the occupancy cap (round 5): 2 → −2 %, 1 → −10 %
 template <> struct EwWaveLds<UnSinh> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };  // 0.70–0.75 → 0.77 on a column in (−30, 30) (the exp path); flat where most rows overflow
 // tiles per block: 1 by default (see tile_run above: 3–4 tiles gain 4 % in lucky allocations — sin 0.785 → 0.82 — and lose 7 % in others)
-template <> struct EwWaveLds<UnSin> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };
-template <> struct EwWaveLds<UnCos> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };
+// round 6, the packed-f32 form (tools/probe/r06_sincos_sweep.py, two processes, tiles × cap): ≈ 16 waves per CU 0.84–0.85 of the roof, ≈ 24 0.81–0.84, none 0.76–0.79
+template <> struct EwWaveLds<UnSin> { static constexpr unsigned value = AGPU_WAVE_LDS_16; };
+template <> struct EwWaveLds<UnCos> { static constexpr unsigned value = AGPU_WAVE_LDS_16; };
 template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 1; };
 template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 2; };
 template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 3; };
@@ -627,10 +639,10 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
       bool done = false;
       agpu_tile_sample tile_sample;
       if constexpr (EwPrefetch<Op>::value && MODE == MODE_UNARY && std::is_same<T, float>::value && BLK == AGPU_EW_BLOCK) {
-        int64_t k = p->tune.heavy_tiles > 0 ? p->tune.heavy_tiles : EwPrefetch<Op>::tiles;
-        const bool shape_ok = (bits & 127u) == 0 && p->tune.stream_grid == 0 && p->tune.stream_bpc == 0;
+        int64_t k = p->tune.tiles > 0 ? p->tune.tiles : EwPrefetch<Op>::tiles;
+        const bool shape_ok = (bits & 127u) == 0 && p->tune.stream_grid == 0;
         // auto: one or two tiles per block, whichever this device measures faster on these buffers (common.hpp, adaptive tiles)
-        if (p->tune.heavy_tiles <= 0 && shape_ok) k = (int64_t)agpu_tiles_pick(p, AGPU_TILE_FAMILY_HEAVY, EwPrefetch<Op>::id, a, out, 2 * sizeof(T) * n, &tile_sample);
+        if (p->tune.tiles <= 0 && shape_ok) k = (int64_t)agpu_tiles_pick(p, AGPU_TILE_FAMILY_HEAVY, EwPrefetch<Op>::id, a, out, 2 * sizeof(T) * n, &tile_sample);
         if (k > 1 && shape_ok) {
           const int g = stream_grid_for(p, tile_units(ntiles, (uint64_t)k));
           hipLaunchKernelGGL((ew_prefetch_kernel<Op, U, AGPU_STREAM_NT>), dim3(g), dim3(AGPU_EW_BLOCK), wave_lds_for(p, EwWaveLds<Op>::value, 1), p->stream, pa, po, ntiles);
@@ -666,8 +678,7 @@ __device__ __forceinline__ T shift_one(T x, uint32_t sh) {
   else return (T)((uint32_t)x >> sh);
 }
 // sub-word columns: 4 rows per lane per step — one 16-byte load of amounts, one 4/8-byte load and store of values.
-// One-wave blocks (round 5: the streaming kernels' shape; 256-thread blocks measured 0.75 / 0.78 of the roof for u8 / u16, tuning
-// stream_unroll = 256 brings them back for the A/B)
+// One-wave blocks (round 5: the streaming kernels' shape; 256-thread blocks measured 0.75 / 0.78 of the roof for u8 / u16)
 template <typename T, bool LEFT, int MODE, int BLK>
 __global__ __launch_bounds__(BLK) void shift_kernel(const T* a, const uint32_t* s, T* out, uint64_t n, int vec_ok) {
   uint32_t sv = 0;
@@ -693,19 +704,13 @@ template <typename T, int MODE>
 static agpu_status launch_shift(agpu_pipeline* p, bool left, const void* a, const void* s, void* out, uint64_t n) {
   if (n == 0) return AGPU_OK;
   const int vec_ok = aligned_to(a, 4 * sizeof(T)) && aligned_to(out, 4 * sizeof(T)) && (MODE == MODE_SCALAR || aligned16(s));
-  const bool wide = p->tune.stream_unroll == 256;  // A/B: the 256-thread blocks of rounds 1–4
-  const uint64_t blk = wide ? AGPU_BLOCK : AGPU_WAVE;
+  const uint64_t blk = AGPU_WAVE;
   const int grid = stream_grid_for(p, (n / 4 + blk) / blk);
 #define AGPU_SHIFT_LAUNCH(L, B)                                                                                       \
   hipLaunchKernelGGL((shift_kernel<T, L, MODE, B>), dim3(grid), dim3(B), 0, p->stream, static_cast<const T*>(a), \
                      static_cast<const uint32_t*>(s), static_cast<T*>(out), n, vec_ok)
-  if (left) {
-    if (wide) AGPU_SHIFT_LAUNCH(true, AGPU_BLOCK);
-    else AGPU_SHIFT_LAUNCH(true, AGPU_WAVE);
-  } else {
-    if (wide) AGPU_SHIFT_LAUNCH(false, AGPU_BLOCK);
-    else AGPU_SHIFT_LAUNCH(false, AGPU_WAVE);
-  }
+  if (left) AGPU_SHIFT_LAUNCH(true, AGPU_WAVE);
+  else AGPU_SHIFT_LAUNCH(false, AGPU_WAVE);
 #undef AGPU_SHIFT_LAUNCH
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
@@ -846,7 +851,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void pow_kernel(const float* a, const f
   __syncthreads();
   while (t < ntiles_end) {
     const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
-    // the next tile's loads go out BEFORE this tile is evaluated (table_tiles > 1): they ride under the arithmetic
+    // the next tile's loads go out BEFORE this tile is evaluated (tiles > 1): they ride under the arithmetic
     const uint64_t tn = t + run.step;
     f32x4 na[U], nb[U];
     if (tn < ntiles_end)
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void log_kernel(const float* a, float* 
   __syncthreads();
   while (t < ntiles_end) {
     const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
-    // the next tile's loads go out BEFORE this tile is evaluated (table_tiles > 1): they ride under the arithmetic
+    // the next tile's loads go out BEFORE this tile is evaluated (tiles > 1): they ride under the arithmetic
     const uint64_t tn = t + run.step;
     f32x4 na[U];
     if (tn < ntiles_end)
@@ -995,7 +1000,7 @@ static agpu_status launch_log_f32(agpu_pipeline* p, const void* a, void* out, ui
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
       agpu_tile_sample tile_sample;
-      const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LOG, 0, a, out, 8 * n, &tile_sample);
+      const uint64_t tk = p->tune.tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LOG, 0, a, out, 8 * n, &tile_sample);
       hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, tile_units(ntiles, tk))), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
                          static_cast<const PowTab*>(p->dev->pow_table));
       agpu_tiles_done(p, &tile_sample);
@@ -1273,7 +1278,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel_unaligned(const TI* in,
 #endif
 
 // SC1: the stores' cache policy.  ×2: always sc1 nt.  ×4: sc1 nt when the launch carries the occupancy cap (u8→f32 / i8→i32 at 1e9 rows,
-// three processes, tools/r05_sc1x4.sh: 0.794–0.817 → 0.808–0.826 of the roof), plain nt without it (0.785–0.800 against 0.760–0.797).
+// three processes, tools/archive/r05_sc1x4.sh: 0.794–0.817 → 0.808–0.826 of the roof), plain nt without it (0.785–0.800 against 0.760–0.797).
 template <typename TI, typename TO, typename Conv, bool SC1>
 __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in, TO* out, uint64_t nchunks) {
   constexpr int R = sizeof(TO) / sizeof(TI);   // 2 or 4 stores per load
@@ -1283,7 +1288,7 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in,
   const TileRun run = tile_run((uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE, (uint64_t)gridDim.x * WAVES, nchunks);
   uint64_t c = run.t;
   if (c >= run.end) return;
-  // the next chunk's load is issued before the current chunk's four stores (tuning cast_tiles > 1: a wave walks several chunks)
+  // the next chunk's load is issued before the current chunk's four stores (tuning tiles > 1: a wave walks several chunks)
   u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
   for (;;) {
     const uint64_t cn = c + run.step;
@@ -1385,12 +1390,13 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
       if (nchunks) {
         // chunks per wave (next chunk prefetched): 1 by default — 2 is +5 % in lucky allocations and −8 % in others (tile_run above)
         agpu_tile_sample tile_sample;
-        const uint64_t k = p->tune.cast_tiles > 0 ? (uint64_t)p->tune.cast_tiles
+        const uint64_t k = p->tune.tiles > 0 ? (uint64_t)p->tune.tiles
                                                   : agpu_tiles_pick(p, AGPU_TILE_FAMILY_CAST, cvt_tile_id<TI, TO, Conv>(), in, out, (sizeof(TI) + sizeof(TO)) * n, &tile_sample);
         const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
         const int grid = stream_grid_for(p, (blocks + k - 1) / k);
         // occupancy cap (common.hpp): ×2 casts to 32 bits ≈ 24 waves per CU, ×4 ≈ 16; u8 → u16 none (not measured to gain)
-        constexpr unsigned cap = sizeof(TO) == 4 ? (sizeof(TI) == 2 ? AGPU_WAVE_LDS_24 : AGPU_WAVE_LDS_16) : 0u;
+        // (round 6: none for cast → sin / cos of a 16-bit column — with sin / cos in packed f32 the kernel wants all its waves: 0.79–0.80 against 0.75)
+        constexpr unsigned cap = ConvHasRows<Conv>::value ? 0u : sizeof(TO) == 4 ? (sizeof(TI) == 2 ? AGPU_WAVE_LDS_24 : AGPU_WAVE_LDS_16) : 0u;
         const unsigned lds = cap ? wave_lds_for(p, cap, AGPU_CVTW_BLOCK / AGPU_WAVE) : 0u;
         if (sizeof(TO) == 2 * sizeof(TI) || lds >= AGPU_WAVE_LDS_24)
           hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv, true>), dim3(grid), dim3(AGPU_CVTW_BLOCK), lds, p->stream, pi, po, nchunks);
@@ -1507,13 +1513,13 @@ struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders
 // once per device by lut8_build_kernel with the same device functions (agpu_device::lut8_tables) and a block copies its 1 KiB.
 #define AGPU_LUT8_BLOCK 128
 #ifndef AGPU_TRIG16_SC1
-#define AGPU_TRIG16_SC1 1  // sin_u16 / cos_i16: +1 % in 6 of 6 alternations (tools/r05_sc1more.sh)
+#define AGPU_TRIG16_SC1 1  // sin_u16 / cos_i16: +1 % in 6 of 6 alternations (tools/archive/r05_sc1more.sh)
 #endif
 #ifndef AGPU_CCHAIN_SC1X4
 #define AGPU_CCHAIN_SC1X4 1  // cast(u8)·s+s: 0.78–0.81 → 0.80–0.815, same script
 #endif
 #ifndef AGPU_LUT8_SC1
-#define AGPU_LUT8_SC1 1  // sc1 nt stores: sin_u8 / cos_i8 at 1e9 rows 0.790–0.809 → 0.804–0.830 of the roof (tools/r05_sc1x4.sh, three processes)
+#define AGPU_LUT8_SC1 1  // sc1 nt stores: sin_u8 / cos_i8 at 1e9 rows 0.790–0.809 → 0.804–0.830 of the roof (tools/archive/r05_sc1x4.sh, three processes)
 #endif
 template <typename TI, typename F>
 __global__ void lut8_build_kernel(float* tab) {
@@ -1593,7 +1599,7 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
       agpu_tile_sample tile_sample;
-      const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
+      const uint64_t tk = p->tune.tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
       const int grid = stream_grid_for(p, tile_units(ntiles, tk));
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), wave_lds_for(p, AGPU_WAVE_LDS_24, AGPU_LUT8_BLOCK / AGPU_WAVE), p->stream, pi, po, ntiles,
                          static_cast<const float*>(p->dev->lut8_tables) + 256 * Lut8Slot<TI, F>::value);
@@ -1738,7 +1744,7 @@ static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, ui
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
       agpu_tile_sample tile_sample;
-      const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_TRIG16, 0, in, out, 6 * n, &tile_sample);
+      const uint64_t tk = p->tune.tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_TRIG16, 0, in, out, 6 * n, &tile_sample);
       const dim3 grid(stream_grid_for(p, tile_units(ntiles, tk)));
       if (blk == 1024) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 1024>), grid, dim3(1024), 0, p->stream, pi, po, ntiles, tab);
       else if (blk == 512) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 512>), grid, dim3(512), 0, p->stream, pi, po, ntiles, tab);
@@ -2217,11 +2223,15 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
     const bool more = cn < run.end;
     u32x4 vn = v;
     if (more) vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + cn * AGPU_WAVE + lane);
+    // all R packs of the chunk go through the chain TOGETHER (round 6): the step interpreter — op / kind extraction, the op switch — runs once
+    // per chunk and lane (8 or 16 rows) instead of once per store (4 rows); its scalar instructions and branches were a third of what a
+    // VALU-bound chain issued per row once sin / cos themselves had shrunk (cast(u16)·s → sin 0.62 of the roof)
+    PackN<float, NO> acc[R];
+    PackN<float, NO> ya[NARR > 0 ? NARR : 1][R];
     static_for<R>([&](auto j) {
       const uint64_t at = (c * (uint64_t)(AGPU_WAVE * R) + (uint32_t)j * AGPU_WAVE + lane) * NO;  // first row of this lane's store
-      PackN<float, NO> ya[NARR > 0 ? NARR : 1];
       static_for<NARR>([&](auto a) {
-        if (a < n_arrs) ya[a] = load_pack<true, float, NO>(static_cast<const float*>(arrs.p[a]) + at);
+        if (a < n_arrs) ya[a][j] = load_pack<true, float, NO>(static_cast<const float*>(arrs.p[a]) + at);
       });
       const int src = (int)(((uint32_t)j * (AGPU_WAVE / R) + lane / R) * 4);
       const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.x);
@@ -2238,35 +2248,39 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
         const u32x2 w = {hi ? w2 : w0, hi ? w3 : w1};
         x = __builtin_bit_cast(PackN<TI, NO>, w);
       }
-      PackN<float, NO> acc[1];
 #pragma unroll
-      for (int k = 0; k < NO; k++) acc[0].v[k] = (float)x.v[k];
-      int ai = 0;
-      for (int s = 0; s < n_steps; s++) {
-        const int op = chain_op(code, s), kind = chain_kind(code, s);
-        if (kind == AGPU_CHAIN_UNARY) {
-          chain_apply_unary_packs<float, HEAVY, 1, NO>(op, acc);  // the op switch once per pack, not per element (round 5)
+      for (int k = 0; k < NO; k++) acc[j].v[k] = (float)x.v[k];
+    });
+    int ai = 0;
+    for (int s = 0; s < n_steps; s++) {
+      const int op = chain_op(code, s), kind = chain_kind(code, s);
+      if (kind == AGPU_CHAIN_UNARY) {
+        chain_apply_unary_packs<float, HEAVY, R, NO>(op, acc);  // the op switch once per chunk, not per element (round 5) or per store (round 6)
+      } else {
+        PackN<float, NO> y[R];
+        if (kind == AGPU_CHAIN_ARRAY) {
+          static_for<R>([&](auto j) { y[j] = ya[0][j]; });
+          static_for<NARR>([&](auto q) {
+            if (q == ai) static_for<R>([&](auto j) { y[j] = ya[q][j]; });
+          });
+          ai++;
         } else {
-          PackN<float, NO> y[1];
-          if (kind == AGPU_CHAIN_ARRAY) {
-            y[0] = ya[0];
-            static_for<NARR>([&](auto q) {
-              if (q == ai) y[0] = ya[q];
-            });
-            ai++;
-          } else {
-            uint32_t w = 0;
-            static_for<AGPU_CHAIN_MAX_STEPS>([&](auto q) {
-              if (q == s) w = sc[q];
-            });
-            const float f = __builtin_bit_cast(float, w);
+          uint32_t w = 0;
+          static_for<AGPU_CHAIN_MAX_STEPS>([&](auto q) {
+            if (q == s) w = sc[q];
+          });
+          const float f = __builtin_bit_cast(float, w);
+          static_for<R>([&](auto j) {
 #pragma unroll
-            for (int k = 0; k < NO; k++) y[0].v[k] = f;
-          }
-          chain_apply_binary_packs<float, 1, NO>(op, acc, y);
+            for (int k = 0; k < NO; k++) y[j].v[k] = f;
+          });
         }
+        chain_apply_binary_packs<float, R, NO>(op, acc, y);
       }
-      store_pack<(AGPU_STREAM_NT & 2) != 0, float, NO, (R == 2 || AGPU_CCHAIN_SC1X4)>(out + at, acc[0]);
+    }
+    static_for<R>([&](auto j) {
+      const uint64_t at = (c * (uint64_t)(AGPU_WAVE * R) + (uint32_t)j * AGPU_WAVE + lane) * NO;
+      store_pack<(AGPU_STREAM_NT & 2) != 0, float, NO, (R == 2 || AGPU_CCHAIN_SC1X4)>(out + at, acc[j]);
     });
     if (!more) break;
     v = vn;
@@ -2307,7 +2321,7 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
       hipLaunchKernelGGL((lut8_chain_build_kernel<TI>), dim3(1), dim3(256), 0, p->stream, static_cast<float*>(tab), n_steps, code, ptrs);
       const uint64_t ntiles = n / TILE_ROWS;
       agpu_tile_sample tile_sample;
-      const uint64_t tk = p->tune.table_tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
+      const uint64_t tk = p->tune.tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
       const int grid = stream_grid_for(p, tile_units(ntiles, tk));
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), wave_lds_for(p, AGPU_WAVE_LDS_24, AGPU_LUT8_BLOCK / AGPU_WAVE), p->stream, pi, out, ntiles,
                          static_cast<const float*>(tab));
@@ -2333,7 +2347,8 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
     }
     const int slots = n_arrs == 0 ? 0 : n_arrs <= 2 ? 2 : 4;
     // light chains: one chunk per wave (tile_run above); chains with a transcendental step are VALU-bound and gain in every run (0.53 → 0.61 at 8)
-    const uint64_t kt = (uint64_t)(p->tune.cast_tiles > 0 ? p->tune.cast_tiles : (heavy ? 8 : 1));
+    // (round 6, the chain interpreted once per chunk: 4 chunks per wave 0.74–0.75 on cast(u16)·s → sin, 8 0.73, 1 0.71)
+    const uint64_t kt = (uint64_t)(p->tune.tiles > 0 ? p->tune.tiles : (heavy ? 4 : 1));
     const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
     const int grid = stream_grid_for(p, (blocks + kt - 1) / kt);
 #define AGPU_CCHAIN_CASE(H, A)                                                                                              \

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void reduce_finish_kernel(const typenam
 // of columns without validity take that shape too (reduce_wave_kernel: min / max 0.826 → 0.840, f64 sum 0.830 → 0.847 in
 // bench.py's 1e9-row shard) and keep this grid for everything else.
 static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks, int blocks_per_cu) {
-  int64_t g = p->tune.reduce_grid > 0 ? p->tune.reduce_grid : (int64_t)p->dev->num_cus * blocks_per_cu;
+  int64_t g = (int64_t)p->dev->num_cus * blocks_per_cu;
   if ((uint64_t)g > work_blocks) g = (int64_t)work_blocks;
   if (g < 1) g = 1;
   return (int)g;
@@ -401,7 +401,7 @@ template <typename T, typename Red>
 static agpu_status launch_reduce(agpu_pipeline* p, const void* in, const void* validity, uint64_t n, void* out) {
   typedef typename Red::Acc A;
   constexpr int U = 4;
-  if (AGPU_REDUCE_WAVE && !validity && aligned16(in) && n >= 64 * RED_CHUNK_ROWS && p->tune.reduce_grid <= 0) {
+  if (AGPU_REDUCE_WAVE && !validity && aligned16(in) && n >= 64 * RED_CHUNK_ROWS) {
     const uint64_t nchunks = n / RED_CHUNK_ROWS, tail = n - nchunks * RED_CHUNK_ROWS;
     const uint64_t m = nchunks + (tail ? 1 : 0);
     const unsigned fold = (unsigned)((m + 4095) / 4096 < 256 ? (m + 4095) / 4096 : 256);

@@ -31,11 +31,8 @@ void agpu_set_error(const char* fmt, ...) {
 
 // ---------------------------------------------------------------- process-wide tuning defaults
 // Plain atomics: agpu_set_tuning may be called from any thread; a pipeline snapshots them when it is created.
-static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {
-    /*stream_grid*/ {0}, /*stream_bpc*/ {0}, /*stream_unroll*/ {1}, /*stream_nt*/ {1}, /*cmp_variant*/ {0}, /*reduce_grid*/ {0},
-    /*table_tiles*/ {0},  // 0 = each kernel's default (elementwise.hip tab_k: 1 for the HBM-bound table kernels, 3 for pow with a scalar exponent)
-    /*gather_bucket*/ {0}, /*h2d_mode*/ {0}, /*h2d_threads*/ {0}, /*gather_region_bits*/ {0}, /*gather_offsets*/ {0},
-    /*heavy_tiles*/ {0}, /*cast_tiles*/ {0}, /*tile_auto*/ {0}, /*wave_lds*/ {0}, /*sync_spin*/ {0}};
+static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {/*stream_grid*/ {0}, /*cmp_variant*/ {0}, /*gather_bucket*/ {0}, /*h2d_mode*/ {0},
+                                                                 /*tiles*/ {0}, /*tile_auto*/ {0}, /*wave_lds*/ {0}, /*sync_spin*/ {0}};
 // DEV SWITCH (tools/probe, docs/experiments.md R5): AGPU_DEVICE_MALLOC_FLAGS=<hipExtMallocWithFlags flags> makes every block the
 // pool, the arenas and the tables take from the driver a hipDeviceMallocContiguous (4) / Uncached (3) / Finegrained (1) one.
 // Unset or 0 = plain hipMalloc, which is what the product ships with.
@@ -50,10 +47,7 @@ static bool alloc_trace() {
 }
 static std::atomic<int64_t> g_mem_pool{1};  // 1 = recycle device blocks and idle streams (default), 0 = hipMalloc/hipFree every time
 static std::atomic<int64_t> g_pool_arena{1};  // 1 = pool blocks of ≥ 1 GiB come out of placed arenas (default), 0 = one hipMalloc each
-static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "stream_bpc", "stream_unroll", "stream_nt",
-                                                         "cmp_variant", "reduce_grid", "table_tiles", "gather_bucket",
-                                                         "h2d_mode", "h2d_threads", "gather_region_bits", "gather_offsets",
-                                                         "heavy_tiles", "cast_tiles", "tile_auto", "wave_lds", "sync_spin"};
+static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "cmp_variant", "gather_bucket", "h2d_mode", "tiles", "tile_auto", "wave_lds", "sync_spin"};
 
 agpu_tuning agpu_tuning_defaults() {
   agpu_tuning t;
@@ -590,7 +584,7 @@ static agpu_status malloc_impl(agpu_device* dev, size_t bytes, int32_t zero_fill
                                void** out_ptr);
 // agpu_malloc_table lays its columns out itself inside ONE fresh hipMalloc block: keep that block out of the arenas (a table
 // carved from an arena ran its compare at 0.80–0.83 of the roof where the same layout in its own block runs 0.85–0.89:
-// tools/r03_ab.sh, three boxes — inside a 32 GiB arena the physical placement of a 9 GiB span is not what a fresh 9 GiB
+// tools/archive/r03_ab.sh, three boxes — inside a 32 GiB arena the physical placement of a 9 GiB span is not what a fresh 9 GiB
 // allocation gets)
 static thread_local bool t_no_arena = false;
 agpu_status agpu_malloc(agpu_device* dev, size_t bytes, int32_t zero_fill, void** out_ptr) {
@@ -1822,3 +1816,4 @@ agpu_status agpu_scratch(agpu_pipeline* p, size_t bytes, void** out) {
   *out = s->scratch->ptr;
   return AGPU_OK;
 }
+

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void idx_locality_kernel(const uint32_t* idx0,
   }
 }
 
-// H.  take: di == nullptr (destination = the row number itself).  Source side: the count of every (tile, region) pair
+// H of a put.  Source side: the count of every (tile, region) pair
 // goes to `counts` (u16, row stride nbp) — the partition pass gets its range starts from a column scan over these
 // instead of reserving them with global atomics: one reservation per (tile, region) is n/8 device-scope atomics per
 // pass, and the chip retires ≈ 26 G of them per second (2^28 rows: 33.5 M atomics = 1.3 ms, 57 % of the pass —
@@ -321,54 +321,39 @@ __global__ __launch_bounds__(BKT_T) void bkt_hist_kernel(const uint32_t* si, con
   for (uint32_t b = threadIdx.x; b <= BKT_MAX; b += BKT_T) ld[b] = 0;
   bool bad = false;
   auto count = [&](uint32_t s, uint32_t d) {
-    if (di) {
-      if (s < n_src && d < n_dst) {
-        atomicAdd(&ls[s >> rs], 1u);
-        atomicAdd(&ld[d >> rd], 1u);
-      } else {
-        bad = true;
-      }
-    } else if (s < n_src) {
+    if (s < n_src && d < n_dst) {
       atomicAdd(&ls[s >> rs], 1u);
+      atomicAdd(&ld[d >> rd], 1u);
     } else {
-      atomicAdd(&ls[bs], 1u);
       bad = true;
     }
   };
   for (uint32_t b = threadIdx.x; b <= BKT_MAX; b += BKT_T) ls[b] = 0;
   __syncthreads();
   for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (counts) {
-      for (uint32_t b = threadIdx.x; b < nbp; b += BKT_T) ls[b] = 0;
-      __syncthreads();
-    }
+    for (uint32_t b = threadIdx.x; b < nbp; b += BKT_T) ls[b] = 0;
+    __syncthreads();
     const uint64_t base = (uint64_t)tile * ((uint64_t)tile_quads * 4 * BKT_T);
 #pragma unroll 4
     for (int q = 0; q < tile_quads; q++) {
       const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 4;
       if (i0 + 4 <= n) {
         const u32x4 sv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
-        u32x4 dv = {0, 0, 0, 0};
-        if (di) dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + i0));
+        const u32x4 dv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + i0));
         count(sv.x, dv.x); count(sv.y, dv.y); count(sv.z, dv.z); count(sv.w, dv.w);
       } else {
         for (int k = 0; k < 4; k++)
-          if (i0 + k < n) count(si[i0 + k], di ? di[i0 + k] : 0u);
+          if (i0 + k < n) count(si[i0 + k], di[i0 + k]);
       }
     }
-    if (counts) {
-      __syncthreads();
-      for (uint32_t b = threadIdx.x; b < nbp; b += BKT_T) counts[(uint64_t)tile * nbp + b] = (uint16_t)ls[b];
-      __syncthreads();
-    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nbp; b += BKT_T) counts[(uint64_t)tile * nbp + b] = (uint16_t)ls[b];
+    __syncthreads();
   }
   __syncthreads();
-  if (!counts)  // region totals straight from the block's LDS histogram (one atomic per region and block)
-    for (uint32_t b = threadIdx.x; b <= bs; b += BKT_T)
-      if (ls[b]) atomicAdd(&ctl->hist_s[b], ls[b]);
-  if (di)
-    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T)
-      if (ld[b]) atomicAdd(&ctl->hist_d[b], ld[b]);
+  for (uint32_t b = threadIdx.x; b < bd; b += BKT_T)
+    if (ld[b]) atomicAdd(&ctl->hist_d[b], ld[b]);
+  (void)bs;
   if (bad) *reinterpret_cast<volatile uint32_t*>(flags) = AGPU_FLAG_INDEX_RANGE;
 }
 
@@ -418,8 +403,7 @@ __host__ __device__ __forceinline__ uint32_t bkt_cur_index(uint32_t b, uint32_t 
   return (stride & BKT_CUR_PAIRED) ? (b >> 1) * (stride & ~BKT_CUR_PAIRED) + (b & 1u) : b * stride;
 }
 // exclusive scans → range start of every bucket; one workgroup
-__global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t bs, uint32_t bd, int rd, int is_put,
-                                                        uint32_t stride_s, uint32_t stride_d) {
+__global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t bs, uint32_t bd, uint32_t stride_s, uint32_t stride_d) {
   if (ctl->use_direct) return;
   __shared__ uint32_t sh[BKT_MAX + 2];
   __shared__ uint32_t wtot[BKT_T / AGPU_WAVE];
@@ -465,7 +449,7 @@ __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t b
     ctl->cur_s[bkt_cur_index(b, stride_s)] = sh[b];
   }
   __syncthreads();
-  if (is_put) {  // the same scan over hist_d[0 .. bd-1] (bd ≤ BKT_MAX)
+  if (bd) {  // the same scan over hist_d[0 .. bd-1] (bd ≤ BKT_MAX); bd == 0: the caller has no destination side (the take pipelines)
     uint32_t c[4], sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -494,11 +478,6 @@ __global__ __launch_bounds__(BKT_T) void bkt_scan_kernel(BktCtl* ctl, uint32_t b
       }
       run += c[k];
     }
-  } else {  // take: the destinations are 0..n-1, every destination bucket is full — its range is its own region
-    for (uint32_t b = threadIdx.x; b < bd; b += BKT_T) {
-      ctl->cur_d[bkt_cur_index(b, stride_d)] = b << rd;
-      ctl->base_d[b] = b << rd;
-    }
   }
 }
 
@@ -512,27 +491,15 @@ struct BktRow {
   uint32_t a, b, key;
 };
 static_assert(offsetof(BktCtl, cur_d) % 8 == 0 && offsetof(BktCtl, cur_s) % 8 == 0 && BKT_CUR_STRIDE % 2 == 0, "paired cursors are 8-byte words");
-#ifdef BKT_PROFILE
-// tools/probe: per-phase cycle stamps of workgroup 0's thread 0 (s_memtime), dumped through a global debug buffer
-__device__ unsigned long long g_bkt_stamps[4][16];
-#define BKT_STAMP(k, i)                                                         \
-  do {                                                                          \
-    if (blockIdx.x == 64 && threadIdx.x == 0) g_bkt_stamps[k][i] = __builtin_readcyclecounter(); \
-  } while (0)
-#else
-#define BKT_STAMP(k, i) do {} while (0)
-#endif
 __device__ __forceinline__ void bkt_tile_sort(BktRow (&row)[BKT_E], uint32_t nkeys, uint32_t* lcnt, u32x2* sorted,
-                                              uint32_t* wave_tot, uint32_t* tile_rows, int kid = 3) {
+                                              uint32_t* wave_tot, uint32_t* tile_rows) {
   // nkeys ≤ BKT_MAX = 4 · BKT_T: thread t owns counters 4t .. 4t+3
-  BKT_STAMP(kid, 1);  // rows are in registers (loads waited for by the first use below)
   for (uint32_t k = threadIdx.x; k < BKT_MAX; k += BKT_T) lcnt[k] = 0;
   __syncthreads();
   uint32_t rank[BKT_E];
 #pragma unroll
   for (int e = 0; e < BKT_E; e++) rank[e] = row[e].key != BKT_INVALID ? atomicAdd(&lcnt[row[e].key], 1u) : 0u;
   __syncthreads();
-  BKT_STAMP(kid, 2);  // ranks done
   // exclusive scan of the counters
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   uint32_t c[4], sum = 0;
@@ -559,7 +526,6 @@ __device__ __forceinline__ void bkt_tile_sort(BktRow (&row)[BKT_E], uint32_t nke
   }
   if (threadIdx.x == BKT_T - 1) *tile_rows = run;
   __syncthreads();
-  BKT_STAMP(kid, 3);  // scan done
 #pragma unroll
   for (int e = 0; e < BKT_E; e++)
     if (row[e].key != BKT_INVALID) {
@@ -567,16 +533,15 @@ __device__ __forceinline__ void bkt_tile_sort(BktRow (&row)[BKT_E], uint32_t nke
       sorted[lcnt[row[e].key] + rank[e]] = v;
     }
   __syncthreads();
-  BKT_STAMP(kid, 4);  // LDS scatter done
   (void)nkeys;
 }
 
-// copy the sorted tile out: key k's rows go to out_pairs[gstart[k] ...], gstart reserved with ONE global atomic per
-// non-empty (tile, key).  On entry lcnt = exclusive starts; on exit lcnt[k] = gstart[k] − start[k] (wrapping).
+// copy the sorted tile out: key k's rows go to out_pairs[tile_starts[k] ...] — the range starts come from the column scan of H's counts
+// (deterministic; rounds 2–5 also carried a form that reserved them with global atomics: n/8 device-scope atomics per pass at ≈ 26 G/s, and
+// never faster).  On entry lcnt = exclusive starts inside the tile; on exit lcnt[k] = tile_starts[k] − start[k] (wrapping).
 template <typename KeyOf>
-__device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, const u32x2* sorted, uint32_t tile_rows,
-                                             uint32_t* cursors, uint32_t cur_stride, u32x2* out_pairs, KeyOf key_of,
-                                             int kid = 3, const uint32_t* tile_starts = nullptr) {
+__device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, const u32x2* sorted, uint32_t tile_rows, u32x2* out_pairs,
+                                             KeyOf key_of, const uint32_t* tile_starts) {
   uint32_t st[4], cnt[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) st[k] = lcnt[threadIdx.x * 4 + k];
@@ -587,45 +552,16 @@ __device__ __forceinline__ void bkt_copy_out(uint32_t nkeys, uint32_t* lcnt, con
     cnt[k] = nxt - st[k];
   }
   __syncthreads();
-  // all four reservations are issued before any result is consumed: four dependent round trips to the memory-side
-  // atomic unit per thread were most of this phase
-  uint32_t g[4];
-  if (!tile_starts && (cur_stride & BKT_CUR_PAIRED)) {  // two ranges per 64-bit atomic (keys 4t, 4t+1 | 4t+2, 4t+3)
-    const uint32_t S = cur_stride & ~BKT_CUR_PAIRED;
-    unsigned long long old[2] = {0ull, 0ull};
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const uint32_t kk = threadIdx.x * 4 + 2 * q;
-      const uint32_t c0 = kk < nkeys ? cnt[2 * q] : 0u, c1 = kk + 1 < nkeys ? cnt[2 * q + 1] : 0u;
-      if (c0 | c1)
-        old[q] = __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cursors + (size_t)(kk >> 1) * S), (unsigned long long)c0 | ((unsigned long long)c1 << 32),
-                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    g[0] = (uint32_t)old[0]; g[1] = (uint32_t)(old[0] >> 32);
-    g[2] = (uint32_t)old[1]; g[3] = (uint32_t)(old[1] >> 32);
-  } else
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const uint32_t kk = threadIdx.x * 4 + k;
-#ifdef BKT_FAKE_RESERVE  // tools/probe only: what would the pass cost without the reservation atomics? (results are wrong)
-    g[k] = (uint32_t)(blockIdx.x % 8192u) * BKT_TILE;
-#else
-    if (tile_starts) g[k] = kk < nkeys ? tile_starts[kk] : 0u;  // deterministic: the column scan of H's counts
-    else g[k] = (kk < nkeys && cnt[k]) ? __hip_atomic_fetch_add(&cursors[bkt_cur_index(kk, cur_stride)], cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#endif
-  }
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const uint32_t kk = threadIdx.x * 4 + k;
-    if (kk < nkeys && cnt[k]) lcnt[kk] = g[k] - st[k];
+    if (kk < nkeys && cnt[k]) lcnt[kk] = tile_starts[kk] - st[k];
   }
   __syncthreads();
-  BKT_STAMP(kid, 5);  // ranges reserved
   for (uint32_t j = threadIdx.x; j < tile_rows; j += BKT_T) {
     const u32x2 v = sorted[j];
     out_pairs[(uint64_t)(uint32_t)(lcnt[key_of(v)] + j)] = v;
   }
-  BKT_STAMP(kid, 6);  // stores issued
 }
 
 #define BKT_LDS_DECL                                                   \
@@ -643,15 +579,15 @@ __device__ __forceinline__ bool bkt_tile_of_block(uint32_t ntiles, uint64_t* til
   return (blockIdx.x / 8) < per && t < ntiles;
 }
 
-// P: rows in natural order → pairs {source index, destination} in source-bucket order (take's out-of-range rows in the
-// extra bucket `bs`: they still produce an output, the value 0)
+// P over 16 Ki-row tiles: rows in natural order → pairs {source index, destination} in source-bucket order; rows with either index out of
+// range are dropped.  What is left of it since round 4 is the DESTINATION-ONLY pipeline of a put (the full pipeline partitions with
+// bkt_partition2_kernel): `si` is then the destination column, `di` the (local) source column, and the pair carries the VALUE (gvals).
 __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si, const uint32_t* di, uint64_t n,
                                                              uint64_t n_src, uint64_t n_dst, int rs, uint32_t bs,
                                                              BktCtl* ctl, u32x2* pairs, const uint32_t* offsets, uint32_t nbp,
-                                                             uint32_t cur_stride, uint32_t ntiles, const void* gvals = nullptr, int gw = 0) {
+                                                             uint32_t ntiles, const void* gvals = nullptr, int gw = 0) {
   if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
   BKT_LDS_DECL;
-  BKT_STAMP(0, 0);
   // XCD-contiguous tiles (round 3): with range starts from the column scan, the runs of tiles t and t + 1 are neighbours in
   // every region's range — one XCD handles both a few dispatches apart and their 64-byte halves meet in its L2
   uint64_t tile64;
@@ -665,15 +601,13 @@ __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si
     if (i0 + 4 <= n) {
       const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(si + i0));
       s[0] = t.x; s[1] = t.y; s[2] = t.z; s[3] = t.w;
-      if (di) {
-        const u32x4 u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + i0));
-        d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w;
-      }
+      const u32x4 u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(di + i0));
+      d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w;
     } else {
       for (int k = 0; k < 4; k++)
         if (i0 + k < n) {
           s[k] = si[i0 + k];
-          if (di) d[k] = di[i0 + k];
+          d[k] = di[i0 + k];
         }
     }
 #pragma unroll
@@ -681,10 +615,8 @@ __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si
       BktRow& r = row[q * 4 + k];
       const uint64_t i = i0 + k;
       r.a = s[k];
-      r.b = di ? d[k] : (uint32_t)i;
-      if (i >= n) r.key = BKT_INVALID;
-      else if (di) r.key = (s[k] < n_src && d[k] < n_dst) ? (s[k] >> rs) : BKT_INVALID;
-      else r.key = s[k] < n_src ? (s[k] >> rs) : bs;
+      r.b = d[k];
+      r.key = (i < n && s[k] < n_src && d[k] < n_dst) ? (s[k] >> rs) : BKT_INVALID;
       if (gvals && r.key != BKT_INVALID) {  // the destination-only pipeline of a put: `si` is the DESTINATION column here, `di` the (local)
                                             // source column — the pair carries the value itself, fetched with a near-streaming gather
         r.b = gw == 4 ? static_cast<const uint32_t*>(gvals)[d[k]] : gw == 2 ? (uint32_t)static_cast<const uint16_t*>(gvals)[d[k]]
@@ -692,11 +624,9 @@ __global__ __launch_bounds__(BKT_T) void bkt_partition_kernel(const uint32_t* si
       }
     }
   }
-  bkt_tile_sort(row, bs + 1, lcnt, sorted, wave_tot, &tile_rows, 0);
+  bkt_tile_sort(row, bs + 1, lcnt, sorted, wave_tot, &tile_rows);
   const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
-  bkt_copy_out(bs + 1, lcnt, sorted, tile_rows, ctl->cur_s, cur_stride, pairs,
-               [=](const u32x2& v) { return v.x < n_src32 ? (v.x >> rs) : bs; }, 0,
-               offsets ? offsets + tile64 * nbp : nullptr);
+  bkt_copy_out(bs + 1, lcnt, sorted, tile_rows, pairs, [=](const u32x2& v) { return v.x < n_src32 ? (v.x >> rs) : bs; }, offsets + tile64 * nbp);
 }
 
 __device__ __forceinline__ void bkt_load_tile(const u32x2* pairs_in, uint64_t base, uint64_t total, uint32_t (&pa)[BKT_E],
@@ -715,81 +645,8 @@ __device__ __forceinline__ void bkt_load_tile(const u32x2* pairs_in, uint64_t ba
   }
 }
 
-// C (round 3): counts2[k][d] = pairs of G's tile k (the same tiles, the same XCD-contiguous walk) whose destination falls
-// into region d.  With a column scan over these, G gets the start of every (tile, destination region) run instead of
-// reserving it with a device-scope atomic: the reservations were 35 000 of G's 75 000 cycles per tile
-// (tools/probe/bkt_phases.py: n/8 atomics per pass at ≈ 26 G/s, nothing to overlap them with at one workgroup per CU), and
-// runs placed by a scan are tile-adjacent, so their 64-byte halves merge in the XCD's L2 like P's do.  8 B/row read.
-__global__ __launch_bounds__(BKT_T) void bkt_count_dst_kernel(const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles, const BktCtl* ctl,
-                                                             uint16_t* counts2, uint32_t nbp2) {
-  if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
-  __shared__ uint32_t ld[BKT_MAX];
-  uint64_t tile;
-  if (!bkt_tile_of_block(ntiles, &tile)) return;
-  const uint64_t total = ctl->total, base = tile * BKT_TILE;
-  for (uint32_t b = threadIdx.x; b < nbp2; b += BKT_T) ld[b] = 0;
-  __syncthreads();
-  if (base < total) {
-#pragma unroll
-    for (int q = 0; q < BKT_E / 2; q++) {
-      const uint64_t i0 = base + ((uint64_t)q * BKT_T + threadIdx.x) * 2;
-      if (i0 + 2 <= total) {
-        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(pairs_in + i0));
-        atomicAdd(&ld[t.y >> rd], 1u);
-        atomicAdd(&ld[t.w >> rd], 1u);
-      } else if (i0 < total) {
-        atomicAdd(&ld[pairs_in[i0].y >> rd], 1u);
-      }
-    }
-  }
-  __syncthreads();
-  for (uint32_t b = threadIdx.x; b < nbp2; b += BKT_T) counts2[tile * nbp2 + b] = (uint16_t)ld[b];
-  (void)bd;
-}
-
-// G: pairs in source-bucket order → {destination, value} in destination-bucket order
-template <int W>
-__global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf<W>::type* values, uint64_t n_src,
-                                                          const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles,
-                                                          int src_line_shift, BktCtl* ctl, u32x2* pairs_out, uint32_t cur_stride,
-                                                          const uint32_t* offsets2, uint32_t nbp2) {
-  if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
-  BKT_LDS_DECL;
-  uint64_t tile;
-  if (!bkt_tile_of_block(ntiles, &tile)) return;
-  const uint64_t total = ctl->total, base = tile * BKT_TILE;
-  if (base >= total) return;
-  uint32_t pa[BKT_E], pb[BKT_E];
-  bool live[BKT_E];
-  bkt_load_tile(pairs_in, base, total, pa, pb, live);
-  BktRow row[BKT_E];
-  // order the tile by SOURCE line first: the rows of a tile fall into one or two source regions at a density of a few
-  // rows per 128-byte line, and only neighbouring lanes of one load instruction are merged into one L2 request
-#pragma unroll
-  for (int e = 0; e < BKT_E; e++) {
-    row[e].a = pa[e];
-    row[e].b = pb[e];
-    row[e].key = live[e] ? ((pa[e] >> src_line_shift) & (BKT_MAX - 1)) : BKT_INVALID;
-  }
-  bkt_tile_sort(row, BKT_MAX, lcnt, sorted, wave_tot, &tile_rows);
-  const uint32_t rows_here = tile_rows;
-#pragma unroll
-  for (int e = 0; e < BKT_E; e++) {
-    const uint32_t j = (uint32_t)e * BKT_T + threadIdx.x;
-    const bool ok = j < rows_here;
-    const u32x2 v = ok ? sorted[j] : u32x2{0u, 0u};
-    row[e].a = v.y;                                                     // destination
-    row[e].b = (ok && v.x < n_src) ? (uint32_t)values[v.x] : 0u;        // the L2-resident gather
-    row[e].key = ok ? (v.y >> rd) : BKT_INVALID;
-  }
-  __syncthreads();  // everyone has read `sorted` before the second sort overwrites it
-  BKT_STAMP(1, 0);  // gathers issued
-  bkt_tile_sort(row, bd, lcnt, sorted, wave_tot, &tile_rows, 1);
-  bkt_copy_out(bd, lcnt, sorted, tile_rows, ctl->cur_d, cur_stride, pairs_out, [=](const u32x2& v) { return v.x >> rd; }, 1,
-               offsets2 ? offsets2 + tile * nbp2 : nullptr);
-}
-
-// G over 32 Ki-pair tiles (round 4): the same inputs and outputs as bkt_gather_kernel, twice its tile.  A 32 Ki-pair tile does not fit LDS as
+// G: pairs in source-bucket order → {destination, value} in destination-bucket order, over 32 Ki-pair tiles (round 4; rounds 2–3 ran a
+// 16 Ki-pair form through two tile sorts of 8-byte pairs, removed in round 6 with the pair-pipeline take it still served).  A 32 Ki-pair tile does not fit LDS as
 // 8-byte pairs; it does as ONE 4-byte array (128 KiB + 16 KiB of counters), 1024 threads holding 32 rows each:
 //   sort 1 (by source line)       the array receives the SOURCE INDEX only; every thread remembers where its rows went; the lane that
 //                                 finds an index at position j gathers the value and puts it back at j; the owner picks it up from there;
@@ -798,7 +655,7 @@ __global__ __launch_bounds__(BKT_T) void bkt_gather_kernel(const typename ElemOf
 // Ranks, positions and range deltas live in the one counter array, one after the other.  What the bigger tile buys: a (tile, region) run is
 // 16 pairs = one full 128-byte line instead of half of one, half as many range reservations per row, eight rows per source line and
 // gather instruction instead of four.  (The form was first built for 16 Ki-pair tiles at two workgroups per CU — 13 % SLOWER than
-// bkt_gather_kernel: docs/experiments.md R4.4, tools/probe/patches/.)  117–119 VGPRs, no scratch — see BK2_PIN.
+// the two-sort kernel: docs/experiments.md R4.4, tools/probe/patches/.)  117–119 VGPRs, no scratch — see BK2_PIN.
 #define BK2_T 1024
 #define BK2_TILE 32768  // pairs per tile: twice P's and F's
 #define BK2_E (BK2_TILE / BK2_T)
@@ -839,11 +696,9 @@ __device__ __forceinline__ void bk2_scan(uint32_t* C, uint32_t* scratch) {
 // one tile; FULL: all BK2_TILE pairs are live (every tile but the list's last one) — no per-row predicates
 template <int W, bool FULL>
 __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values, uint32_t n_src32, const u32x2* pairs_in, uint32_t rows, int rd,
-                                         uint32_t bd, int src_line_shift, uint32_t* cursors, uint32_t cur_stride, u32x2* pairs_out,
-                                         const uint32_t* tile_starts, uint32_t* A, uint32_t* C) {
+                                         uint32_t bd, int src_line_shift, uint32_t* cursors, uint32_t cur_stride, u32x2* pairs_out, uint32_t* A, uint32_t* C) {
   uint32_t s[BK2_E], d[BK2_E], r[BK2_E / 2];  // r: two 14-bit ranks / positions per register (rows 2q and 2q + 1)
   auto live = [&](int e) { return FULL || (((uint32_t)(e / 2) * BK2_T + threadIdx.x) * 2 + (uint32_t)(e % 2)) < rows; };
-  BKT_STAMP(1, 0);
   for (uint32_t k = threadIdx.x; k < BKT_MAX; k += BK2_T) C[k] = 0;
   // row e of this thread is pair (e / 2 · BK2_T + thread) · 2 + e % 2 of the tile
 #pragma unroll
@@ -872,7 +727,6 @@ __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values,
 #pragma unroll
   for (int e = 0; e < BK2_E; e++) BK2_PIN(s[e]);
   __syncthreads();
-  BKT_STAMP(1, 1);
   bk2_scan(C, A);
 #pragma unroll
   for (int q = 0; q < BK2_E / 2; q++) {
@@ -881,12 +735,10 @@ __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values,
     BK2_PIN(r[q]);
   }
   __syncthreads();  // the scan's scratch words (A[0 .. 8)) have been read by everyone
-  BKT_STAMP(1, 2);
 #pragma unroll
   for (int e = 0; e < BK2_E; e++)
     if (live(e)) A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu] = s[e];
   __syncthreads();
-  BKT_STAMP(1, 3);
   // the L2-resident gather, in line order; the value replaces the index at its place.  Eight rows per step: thirty-two 64-bit addresses
   // at once would not fit beside the rows' destinations in 128 registers (all 32 in flight through a scalar base + 32-bit offsets was
   // built and measured: no faster — the phase is not waiting on the round trips)
@@ -908,7 +760,6 @@ __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values,
     }
   }
   __syncthreads();
-  BKT_STAMP(1, 4);
 #pragma unroll
   for (int e = 0; e < BK2_E; e++)
     if (live(e)) s[e] = A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu];  // the value of MY row e
@@ -923,9 +774,7 @@ __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values,
 #pragma unroll
   for (int e = 0; e < BK2_E; e++) BK2_PIN(d[e]);
   __syncthreads();  // … which also ends the reads of A above: the scan may use its first words
-  BKT_STAMP(1, 5);
   bk2_scan(C, A);
-  BKT_STAMP(1, 6);
   // ranges of the tile's runs in the output: thread t owns keys BK2_K·t …; one reservation per non-empty (tile, region), all of them in
   // flight while the tile is moved
   uint32_t g[BK2_K];
@@ -940,10 +789,7 @@ __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values,
       const uint32_t nxt = k < BK2_K - 1 ? st[k + 1] : (kk + 1 < BKT_MAX ? C[kk + 1] : rows);
       cnt[k] = kk < bd ? nxt - st[k] : 0u;
     }
-    if (tile_starts) {
-#pragma unroll
-      for (int k = 0; k < BK2_K; k++) g[k] = threadIdx.x * BK2_K + k < bd ? tile_starts[threadIdx.x * BK2_K + k] - st[k] : 0u;
-    } else if (cur_stride & BKT_CUR_PAIRED) {  // two ranges per 64-bit atomic (bkt_copy_out)
+    {  // two ranges per 64-bit atomic (keys 4t, 4t+1 | 4t+2, 4t+3: cursors 2j and 2j + 1 share one aligned 8-byte word — bkt_cur_index)
       const uint32_t S = cur_stride & ~BKT_CUR_PAIRED;
       unsigned long long old[2] = {0ull, 0ull};
 #pragma unroll
@@ -955,12 +801,6 @@ __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values,
       }
       g[0] = (uint32_t)old[0] - st[0]; g[1] = (uint32_t)(old[0] >> 32) - st[1];
       g[2] = (uint32_t)old[1] - st[2]; g[3] = (uint32_t)(old[1] >> 32) - st[3];
-    } else {
-#pragma unroll
-      for (int k = 0; k < BK2_K; k++) {
-        const uint32_t kk = threadIdx.x * BK2_K + k;
-        g[k] = cnt[k] ? __hip_atomic_fetch_add(&cursors[bkt_cur_index(kk, cur_stride)], cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - st[k] : 0u;
-      }
     }
   }
 #pragma unroll
@@ -970,23 +810,19 @@ __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values,
     BK2_PIN(r[q]);
   }
   __syncthreads();  // everyone has its positions and starts
-  BKT_STAMP(1, 7);
 #pragma unroll
   for (int e = 0; e < BK2_E; e++)
     if (live(e)) A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu] = s[e];  // values first …
 #pragma unroll
   for (int k = 0; k < BK2_K; k++) C[threadIdx.x * BK2_K + k] = g[k];  // the counters turn into deltas: range start − start inside the tile
   __syncthreads();
-  BKT_STAMP(1, 8);
 #pragma unroll
   for (int e = 0; e < BK2_E; e++) s[e] = A[(uint32_t)e * BK2_T + threadIdx.x];  // … value j of the sorted tile stays with lane j
   __syncthreads();
-  BKT_STAMP(1, 9);
 #pragma unroll
   for (int e = 0; e < BK2_E; e++)
     if (live(e)) A[(r[e / 2] >> (16 * (e % 2))) & 0xFFFFu] = d[e];  // … then the destinations
   __syncthreads();
-  BKT_STAMP(1, 10);
 #pragma unroll
   for (int e = 0; e < BK2_E; e++) {
     const uint32_t j = (uint32_t)e * BK2_T + threadIdx.x;
@@ -997,14 +833,12 @@ __device__ __forceinline__ void bk2_tile(const typename ElemOf<W>::type* values,
     }
     if (e % 8 == 7) __builtin_amdgcn_sched_barrier(0);  // (eight addresses at a time)
   }
-  BKT_STAMP(1, 11);
 }
 
 template <int W>
 __global__ __launch_bounds__(BK2_T, 4) void bkt_gather2_kernel(const typename ElemOf<W>::type* values, uint64_t n_src,
                                                               const u32x2* pairs_in, int rd, uint32_t bd, uint32_t ntiles,
-                                                              int src_line_shift, BktCtl* ctl, u32x2* pairs_out, uint32_t cur_stride,
-                                                              const uint32_t* offsets2, uint32_t nbp2) {
+                                                              int src_line_shift, BktCtl* ctl, u32x2* pairs_out, uint32_t cur_stride) {
   if (ctl->use_direct) return;  // the locality probe chose the direct kernel launched behind this pipeline
   static_assert(BK2_T * BK2_E == BK2_TILE && BK2_K % 4 == 0 && BK2_E % 2 == 0 && BK2_TILE <= 65536, "tile shape (positions travel as 16-bit halves)");
   __shared__ __attribute__((aligned(16))) uint32_t A[BK2_TILE];
@@ -1014,11 +848,10 @@ __global__ __launch_bounds__(BK2_T, 4) void bkt_gather2_kernel(const typename El
   const uint64_t total = ctl->total, base = tile * BK2_TILE;
   if (base >= total) return;
   const uint32_t n_src32 = (uint32_t)(n_src > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_src);
-  const uint32_t* ts = offsets2 ? offsets2 + tile * nbp2 : nullptr;
   if (total - base >= BK2_TILE)  // every pair of P's output is a live row: only the list's last tile is ragged
-    bk2_tile<W, true>(values, n_src32, pairs_in + base, BK2_TILE, rd, bd, src_line_shift, ctl->cur_d, cur_stride, pairs_out, ts, A, C);
+    bk2_tile<W, true>(values, n_src32, pairs_in + base, BK2_TILE, rd, bd, src_line_shift, ctl->cur_d, cur_stride, pairs_out, A, C);
   else
-    bk2_tile<W, false>(values, n_src32, pairs_in + base, (uint32_t)(total - base), rd, bd, src_line_shift, ctl->cur_d, cur_stride, pairs_out, ts, A, C);
+    bk2_tile<W, false>(values, n_src32, pairs_in + base, (uint32_t)(total - base), rd, bd, src_line_shift, ctl->cur_d, cur_stride, pairs_out, A, C);
 }
 
 // P over 32 Ki-row tiles (round 4; put only): rows in natural order → pairs {source index, destination} in source-region order, the tile
@@ -1135,22 +968,19 @@ __global__ __launch_bounds__(BKT_T) void bkt_store_kernel(const u32x2* pairs, ui
     row[e].b = pb[e];
     row[e].key = live[e] ? ((pa[e] >> line_shift) & (BKT_MAX - 1)) : BKT_INVALID;
   }
-  BKT_STAMP(2, 0);
-  bkt_tile_sort(row, BKT_MAX, lcnt, sorted, wave_tot, &tile_rows, 2);
+  bkt_tile_sort(row, BKT_MAX, lcnt, sorted, wave_tot, &tile_rows);
   for (uint32_t j = threadIdx.x; j < tile_rows; j += BKT_T) {
     const u32x2 v = sorted[j];
     dst[v.x] = (E)v.y;
   }
-  BKT_STAMP(2, 6);
 }
 
 // region = 2^r elements = 512 KiB on both sides: an XCD has 32 tiles (2^19 rows) in flight, i.e. two or three regions,
 // beside the pair streams in its 4 MiB L2.  Measured at 2^28 rows (tools/probe/bucket_sweep.py --region-bits): 512 KiB
-// regions 4.8 / 5.5 ms (take / put), 1 MiB 5.2 / 5.8, 2 MiB 5.5 / 5.8, 4 MiB 5.8 / 6.4.  "gather_region_bits" overrides.
+// regions 4.8 / 5.5 ms (take / put), 1 MiB 5.2 / 5.8, 2 MiB 5.5 / 5.8, 4 MiB 5.8 / 6.4.
 static int bkt_region_bits(const agpu_pipeline* p, uint64_t n_elems, int width) {
+  (void)p;
   int r = 17 + (width == 2 ? 1 : width == 1 ? 2 : 0);
-  if (p->tune.gather_region_bits > 0) r = (int)p->tune.gather_region_bits;
-  if (r < 10) r = 10;
   while (((n_elems + ((uint64_t)1 << r) - 1) >> r) > BKT_MAX - 1) r++;
   return r;
 }
@@ -1189,7 +1019,9 @@ static int probe_decide(agpu_pipeline* p, const uint32_t* idx0, const uint32_t* 
   return result;
 }
 
-// di == nullptr: take (dst = out, n_dst = n).  Returns AGPU_ERR_UNSUPPORTED when the shape does not qualify.
+// The pair pipeline of a PUT (both index columns are data).  Returns AGPU_ERR_UNSUPPORTED when the shape does not qualify.
+// (Rounds 2–5 also ran takes through it — di == nullptr, tuning gather_bucket = 3 — and carried four ways of getting the range starts,
+// tuning gather_offsets; the merge-back pipeline below is 1.5× faster for takes and the defaults were never beaten: removed in round 6.)
 static agpu_status launch_put_through_take(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* si, void* dst, uint64_t n,
                                            const uint32_t* di, uint64_t n_dst, const BktCtl* gate);
 // the rare case in which the destination-local variant of a put could not be enqueued after the probe was told about it: whatever
@@ -1199,21 +1031,20 @@ __global__ void bkt_flag_or_kernel(const BktCtl* rl, BktCtl* main) {
 }
 static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src, uint64_t n_src, const uint32_t* si,
                                    void* dst, uint64_t n_dst, const uint32_t* di, uint64_t n, bool adaptive = false) {
-  if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || n_dst > 0xFFFFFFFFull || !aligned16(si) || (di && !aligned16(di)) ||
-      p->capturing)
+  if (n >= 0xFFFF0000ull || n_src > 0xFFFFFFFFull || n_dst > 0xFFFFFFFFull || !aligned16(si) || !di || !aligned16(di) || p->capturing)
     return AGPU_ERR_UNSUPPORTED;
   // A put's SOURCE regions (round 4, tools/probe/put_tile_sweep.py with the region size forced, 2^25 … 2^28 rows): about a thousand of them is
   // the optimum at every size — 32-pair runs out of P's 32 Ki-row tiles, a count matrix half the size — between 256 KiB and 1 MiB each
   // (2^28 rows 4.41 → 4.34 ms, 2^26 1.11 → 1.09, 2^25 0.61 → 0.59; 2^27 rows have it already).  The destination regions keep their 512 KiB.
-  int rs = bkt_region_bits(p, n_src, width);
-  if (di && p->tune.gather_region_bits <= 0) {
+  int rs;
+  {
     const uint64_t bytes = n_src * (uint64_t)width;
     int rb = 18;  // log2 of the region's bytes
     while (rb < 20 && (bytes >> rb) > 1024) rb++;
     rs = rb - (width == 4 ? 2 : width == 2 ? 1 : 0);
     while (((n_src + ((uint64_t)1 << rs) - 1) >> rs) > BKT_MAX - 1) rs++;
   }
-  const int rd = bkt_region_bits(p, n_dst, width) + (di ? BKT_RD_EXTRA : 0);
+  const int rd = bkt_region_bits(p, n_dst, width) + BKT_RD_EXTRA;
   // F orders a tile by destination line: 128-byte lines, widened until a region's lines fit the BKT_MAX keys
   int line_shift = width == 4 ? 5 : width == 2 ? 6 : 7;
   while ((1 << (rd - line_shift)) > BKT_MAX) line_shift++;
@@ -1222,43 +1053,31 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
   const uint32_t bs = (uint32_t)((n_src + ((uint64_t)1 << rs) - 1) >> rs), bd = (uint32_t)((n_dst + ((uint64_t)1 << rd) - 1) >> rd);
   agpu_device* dev = p->dev;
   void *ctl_v = nullptr, *p1 = nullptr, *p2 = nullptr, *cnt_v = nullptr, *off_v = nullptr, *csum_v = nullptr, *ctlb_v = nullptr, *ctlc_v = nullptr;
-  const uint32_t ntiles = (uint32_t)((n + BKT_TILE - 1) / BKT_TILE);
-  const uint32_t nbp = (bs + 1 + 3) & ~3u;  // padded row stride of the (tile × region) matrices
-  const uint32_t nbp2 = (bd + 3) & ~3u;      // … of G's (tile × destination region) matrices: the same blocks, used after P is through
+  const uint32_t ntiles = (uint32_t)((n + BKT_TILE - 1) / BKT_TILE);  // F's tiles, and P's in the destination-only pipeline (16 Ki rows)
+  const uint32_t nbp = (bs + 1 + 3) & ~3u;   // padded row stride of the (tile × source region) matrix
   const uint32_t nbpB = (bd + 1 + 3) & ~3u;  // … of the destination-only pipeline's (tile × destination region) matrix
-  const uint32_t nbpm = (nbp > nbp2 ? nbp : nbp2) > nbpB ? (nbp > nbp2 ? nbp : nbp2) : nbpB;
+  const uint32_t nbpm = nbp > nbpB ? nbp : nbpB;
   const uint32_t nchunks = (ntiles + BKT_CHUNK - 1) / BKT_CHUNK;
-  // Range starts of the partition pass: from a column scan of per-tile counts (default since round 3; "gather_offsets" = 1
-  // brings the global-atomic reservations back).  Under round-robin tiles the scan form was never faster — the pass is
-  // bound by its 64-byte runs landing all over a 2 GiB array, not by the 33 M atomics — but with XCD-CONTIGUOUS tiles the
-  // deterministic layout puts the runs of tiles t and t + 1 side by side in every region's range, the two halves of a line
-  // meet in one L2, and the pass gains what the atomics could never give: put 5.42 → 5.07 ms, pair-pipeline take 4.90 → 4.36
-  // at 2^28 rows (tools/probe/put_offsets_ab.py, one process, alternating).
-  const bool det = p->tune.gather_offsets != 1;
+  // Range starts of the partition pass: from a column scan of per-tile counts (round 3).  With XCD-CONTIGUOUS tiles the deterministic
+  // layout puts the runs of tiles t and t + 1 side by side in every region's range, the two halves of a line meet in one L2, and the pass
+  // gains what reserving the ranges with global atomics could never give: put 5.42 → 5.07 ms at 2^28 rows.  G's range starts ARE reserved
+  // with atomics — two ranges per 64-bit fetch-add (round 4: 5.05 → 4.77 ms) — because a count pass over P's output costs more than it
+  // saves (0.52 + 0.11 ms against G 2.10 → 1.77: docs/experiments.md §4).
   agpu_status st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctl_v);
   if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p1);
   if (st == AGPU_OK) st = agpu_malloc(dev, 8 * n + 16, 0, &p2);
-  if (det) {
-    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbpm * 2, 0, &cnt_v);
-    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbpm * 4, 0, &off_v);
-    if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)nchunks * nbpm * 4, 0, &csum_v);
-  }
-  // G's range starts: reserved with atomics (default), or — "gather_offsets" = 2 — from a count pass over P's output + the same
-  // column scan.  Measured at 2^28 rows (tools/probe/put_offsets_ab.py under rocprofv3): G 2.10 → 1.77 ms, but the count pass costs
-  // 0.52 ms and its scans 0.11: put 5.05 → 5.00 ms, pair-pipeline take 4.42 → 5.1.  The per-tile stamps had promised more (35 000 of
-  // G's 75 000 cycles in the reservation phase) — at one workgroup per CU a tile's phases add up, but chip-wide the atomic unit's
-  // 1.3 ms overlap with the other CUs' sorts; what is left of G is its own chain of phases (load → sort → gather → sort → store).
-  const bool det2 = det && p->tune.gather_offsets == 2;
-  // G over 32 Ki-pair tiles through ONE 4-byte LDS array (bkt_gather2_kernel: put of 2^28 random rows 4.78 → 4.47 ms, one process, alternating)
-  // unless its ranges come from the count pass (whose tiles are P's) or "gather_offsets" = 4 asks for round 3's 16 Ki-pair G, for A/B
-  const bool g_one_wg = p->tune.gather_offsets == 4 || det2 || !di;  // (the pair-pipeline TAKE — sequential destinations — is faster on the old G: 4.42 vs 4.65 ms)
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbpm * 2, 0, &cnt_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)ntiles * nbpm * 4, 0, &off_v);
+  if (st == AGPU_OK) st = agpu_malloc(dev, (size_t)nchunks * nbpm * 4, 0, &csum_v);
+  // P, H and G over 32 Ki-row tiles through ONE 4-byte LDS array (bkt_partition2_kernel / bkt_gather2_kernel: put of 2^28 random rows
+  // 4.78 → 4.33 ms, one process, alternating)
   const uint32_t ntiles2 = (uint32_t)((n + BK2_TILE - 1) / BK2_TILE), nblk2 = (ntiles2 + 7) / 8 * 8;
   // put under the auto policy, three ways (idx_locality_kernel): both columns local → the direct scatter; SOURCE local only (the scatter
   // of a contiguous or sorted selection) → the destination-only pipeline below: the values are fetched by a near-streaming gather inside
   // the partition pass, pairs {destination, value} are partitioned by destination region once and stored by F — no source-side
   // partition, no G; otherwise the full pipeline.  All three are enqueued over the same temporaries, two return at once.
   // (from 2^26 rows: every variant costs a handful of empty launches when it stands down — ≈ 0.1 ms for both, too much for a 0.4 ms put)
-  const bool lr = adaptive && di && det && (n >= ((uint64_t)1 << 26) || p->tune.gather_bucket == 4);  // (4: tests, any size)
+  const bool lr = adaptive && (n >= ((uint64_t)1 << 26) || p->tune.gather_bucket == 4);  // (4: tests, any size)
   if (lr && st == AGPU_OK) st = agpu_malloc(dev, sizeof(BktCtl), 0, &ctlb_v);
   // … and DESTINATION local only (a gather into a contiguous or sorted selection): the take's merge-back pipeline with its merge pass
   // storing through the destination column — no pairs at all
@@ -1275,64 +1094,37 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       agpu_set_error("hipMemsetAsync failed: %s", hipGetErrorString(e));
       st = AGPU_ERR_HIP;
     } else {
-      // P (and H with it) over 32 Ki-row tiles for a put whose range starts come from the column scan ("gather_offsets" = 4 / 8: round 3's
-      // 16 Ki-row P, for A/B)
-      const bool p_big = di && det && p->tune.gather_offsets != 4 && p->tune.gather_offsets != 8;
-      const uint32_t ntiles_p = p_big ? ntiles2 : ntiles, nchunks_p = (ntiles_p + BKT_CHUNK - 1) / BKT_CHUNK;
+      const uint32_t nchunks_p = (ntiles2 + BKT_CHUNK - 1) / BKT_CHUNK;
       uint64_t hg = (uint64_t)dev->num_cus * 2;
-      if (hg > ntiles_p) hg = ntiles_p;
+      if (hg > ntiles2) hg = ntiles2;
       const dim3 cgrid_p((nbp + 255) / 256, nchunks_p);
       uint16_t* counts = static_cast<uint16_t*>(cnt_v);
       uint32_t* offsets = static_cast<uint32_t*>(off_v);
       uint32_t* csum = static_cast<uint32_t*>(csum_v);
-      const dim3 cgrid((nbp + 255) / 256, nchunks);
       // adaptive (put under the auto policy): BOTH index columns local ⇒ the direct scatter launched behind the pipeline does the work
       // (tools/probe/put_distributions.py: sorted → sorted 2.1 ms bucketed, 1.2 direct; sequential → sequential 1.8 vs 0.23; with either
       // side random the pipeline wins)
-      adaptive = adaptive && di;
       const BktCtl* gate = adaptive ? ctl : nullptr;
       if (adaptive) {
         const int sh = width == 4 ? 5 : width == 2 ? 6 : 7;
         hipLaunchKernelGGL(idx_locality_kernel, dim3(2 * LOC_BLOCKS), dim3(256), 0, p->stream, si, di, n, sh, sh, ctl, static_cast<BktCtl*>(ctlb_v), static_cast<BktCtl*>(ctlc_v));
       }
-      hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags, counts, nbp, ntiles_p,
-                         p_big ? BK2_TILE / (4 * BKT_T) : BKT_E / 4);
-      if (det) {
-        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid_p, dim3(256), 0, p->stream, counts, nbp, ntiles_p, csum, gate);
-        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks_p, ctl->hist_s, gate);
-      }
-      // one cursor per 128-byte line while the regions are few (the atomics spread over the L2 channels: −10…15 % per
-      // call at ≤ 1024 regions, same-box A/B), packed cursors beyond (a 256 KiB cursor array costs more than it spreads)
-      // G's cursors (the one pass that still reserves with atomics): 32 bytes apart beyond 1024 regions (round 4, tools/probe/cur_stride_probe.py,
-      // fresh processes: put of 2^28 rows 5.01–5.05 ms packed, 4.92–4.95 at 8 / 16 / 32 words — reservations to one 128-byte line queue up
-      // behind each other; 8 words keep the array at 64–128 KiB)
+      hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, rd, bs, bd, ctl, p->flags, counts, nbp, ntiles2,
+                         BK2_TILE / (4 * BKT_T));
+      hipLaunchKernelGGL(bkt_colsum_kernel, cgrid_p, dim3(256), 0, p->stream, counts, nbp, ntiles2, csum, gate);
+      hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks_p, ctl->hist_s, gate);
+      // G's cursors (the one pass that reserves with atomics): cursors of adjacent regions share an 8-byte word, the words one per 128-byte
+      // line while the regions are few (the atomics spread over the L2 channels), 64 bytes apart beyond 1024 regions (round 4,
+      // tools/probe/cur_stride_probe.py: reservations to one line queue up behind each other)
       const uint32_t stride_s = bs + 1 <= 1024 ? BKT_CUR_STRIDE : 1;
-      uint32_t stride_d = bd <= 1024 ? BKT_CUR_STRIDE : 8;
-      if (p->tune.gather_offsets != 6) stride_d = (bd <= 1024 ? BKT_CUR_STRIDE : 16) | BKT_CUR_PAIRED;  // ("gather_offsets" = 6: one atomic per range, for A/B)
-      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, rd, di ? 1 : 0, stride_s, stride_d);
-      if (det) hipLaunchKernelGGL(bkt_offsets_kernel, cgrid_p, dim3(256), 0, p->stream, counts, csum, nbp, ntiles_p, ctl->base_s, offsets, gate);
-      if (p_big)
-        hipLaunchKernelGGL(bkt_partition2_kernel, dim3(nblk2), dim3(BK2_T), 0, p->stream, si, di, n, n_src, n_dst, rs, ctl, static_cast<u32x2*>(p1), offsets, nbp, ntiles2);
-      else
-        hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, si, di, n, n_src, n_dst, rs, bs, ctl, static_cast<u32x2*>(p1),
-                           det ? offsets : static_cast<uint32_t*>(nullptr), nbp, stride_s, ntiles);
-      if (det2) {  // C + the column scan again, over the blocks P has just finished with
-        const dim3 cgrid2((nbp2 + 255) / 256, nchunks);
-        hipLaunchKernelGGL(bkt_count_dst_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), rd, bd, ntiles, ctl, counts, nbp2);
-        hipLaunchKernelGGL(bkt_colsum_kernel, cgrid2, dim3(256), 0, p->stream, counts, nbp2, ntiles, csum, gate);
-        hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp2 + 255) / 256), dim3(256), 0, p->stream, csum, nbp2, nchunks, static_cast<uint32_t*>(nullptr), gate);
-        hipLaunchKernelGGL(bkt_offsets_kernel, cgrid2, dim3(256), 0, p->stream, counts, csum, nbp2, ntiles, ctl->base_d, offsets, gate);
-      }
+      const uint32_t stride_d = (bd <= 1024 ? BKT_CUR_STRIDE : 16) | BKT_CUR_PAIRED;
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, bd, stride_s, stride_d);
+      hipLaunchKernelGGL(bkt_offsets_kernel, cgrid_p, dim3(256), 0, p->stream, counts, csum, nbp, ntiles2, ctl->base_s, offsets, gate);
+      hipLaunchKernelGGL(bkt_partition2_kernel, dim3(nblk2), dim3(BK2_T), 0, p->stream, si, di, n, n_src, n_dst, rs, ctl, static_cast<u32x2*>(p1), offsets, nbp, ntiles2);
 #define BKT_GF(W, E)                                                                                                         \
   case W:                                                                                                                    \
-    if (g_one_wg)                                                                                                            \
-      hipLaunchKernelGGL((bkt_gather_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const E*>(src), n_src,   \
-                         static_cast<const u32x2*>(p1), rd, bd, ntiles, src_line_shift, ctl, static_cast<u32x2*>(p2), stride_d, \
-                         det2 ? offsets : static_cast<const uint32_t*>(nullptr), nbp2);                                        \
-    else                                                                                                                     \
-      hipLaunchKernelGGL((bkt_gather2_kernel<W>), dim3(nblk2), dim3(BK2_T), 0, p->stream, static_cast<const E*>(src), n_src, \
-                         static_cast<const u32x2*>(p1), rd, bd, ntiles2, src_line_shift, ctl, static_cast<u32x2*>(p2), stride_d, \
-                         static_cast<const uint32_t*>(nullptr), nbp2);                                                         \
+    hipLaunchKernelGGL((bkt_gather2_kernel<W>), dim3(nblk2), dim3(BK2_T), 0, p->stream, static_cast<const E*>(src), n_src,   \
+                       static_cast<const u32x2*>(p1), rd, bd, ntiles2, src_line_shift, ctl, static_cast<u32x2*>(p2), stride_d); \
     hipLaunchKernelGGL((bkt_store_kernel<W>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p2), ntiles,  \
                        ctl, line_shift, static_cast<E*>(dst));                                                               \
     break;
@@ -1346,14 +1138,16 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       if (st == AGPU_OK && lr) {  // the destination-only pipeline: H, P and F with the two index columns in each other's roles
         BktCtl* cb = static_cast<BktCtl*>(ctlb_v);
         const dim3 cgridB((nbpB + 255) / 256, nchunks);
+        uint64_t hgB = (uint64_t)dev->num_cus * 2;
+        if (hgB > ntiles) hgB = ntiles;
         const uint32_t stride_b = bd + 1 <= 1024 ? BKT_CUR_STRIDE : 1, stride_b2 = bs <= 1024 ? BKT_CUR_STRIDE : 1;
-        hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, rs, bd, bs, cb, p->flags, counts, nbpB, ntiles);
+        hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hgB), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, rs, bd, bs, cb, p->flags, counts, nbpB, ntiles, BKT_E / 4);
         hipLaunchKernelGGL(bkt_colsum_kernel, cgridB, dim3(256), 0, p->stream, counts, nbpB, ntiles, csum, cb);
         hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbpB + 255) / 256), dim3(256), 0, p->stream, csum, nbpB, nchunks, cb->hist_s, cb);
-        hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, cb, bd, bs, rs, 1, stride_b, stride_b2);
+        hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, cb, bd, bs, stride_b, stride_b2);
         hipLaunchKernelGGL(bkt_offsets_kernel, cgridB, dim3(256), 0, p->stream, counts, csum, nbpB, ntiles, cb->base_s, offsets, cb);
         hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, bd, cb, static_cast<u32x2*>(p1), offsets, nbpB,
-                           stride_b, ntiles, src, width);
+                           ntiles, src, width);
         switch (width) {
           case 4: hipLaunchKernelGGL((bkt_store_kernel<4>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), ntiles, cb, line_shift, static_cast<uint32_t*>(dst)); break;
           case 2: hipLaunchKernelGGL((bkt_store_kernel<2>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), ntiles, cb, line_shift, static_cast<uint16_t*>(dst)); break;
@@ -1370,20 +1164,14 @@ static agpu_status launch_bucketed(agpu_pipeline* p, int width, const void* src,
       }
       if (st == AGPU_OK && adaptive) (void)launch_put_direct(p, width, src, n_src, si, dst, n_dst, di, n, &ctl->run_direct);
       if (st == AGPU_OK && hipGetLastError() != hipSuccess) {
-        agpu_set_error("bucketed take/put launch failed");
+        agpu_set_error("bucketed put launch failed");
         st = AGPU_ERR_HIP;
       }
     }
   }
   // the pool hands these blocks out again only after the stream has passed the kernels above (runtime.hip markers)
-  if (csum_v) (void)agpu_free(dev, csum_v);
-  if (off_v) (void)agpu_free(dev, off_v);
-  if (cnt_v) (void)agpu_free(dev, cnt_v);
-  if (p2) (void)agpu_free(dev, p2);
-  if (p1) (void)agpu_free(dev, p1);
-  if (ctl_v) (void)agpu_free(dev, ctl_v);
-  if (ctlb_v) (void)agpu_free(dev, ctlb_v);
-  if (ctlc_v) (void)agpu_free(dev, ctlc_v);
+  for (void* q : {csum_v, off_v, cnt_v, p2, p1, ctl_v, ctlb_v, ctlc_v})
+    if (q) (void)agpu_free(dev, q);
   return st;
 }
 
@@ -1422,9 +1210,9 @@ static agpu_status launch_put_dst_only(agpu_pipeline* p, int width, const void* 
       hipLaunchKernelGGL(bkt_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, rs, bd, bs, cb, p->flags, counts, nbpB, ntiles);
       hipLaunchKernelGGL(bkt_colsum_kernel, cgridB, dim3(256), 0, p->stream, counts, nbpB, ntiles, csum, static_cast<const BktCtl*>(nullptr));
       hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbpB + 255) / 256), dim3(256), 0, p->stream, csum, nbpB, nchunks, cb->hist_s, static_cast<const BktCtl*>(nullptr));
-      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, cb, bd, bs, rs, 1, stride_b, stride_b2);
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, cb, bd, bs, stride_b, stride_b2);
       hipLaunchKernelGGL(bkt_offsets_kernel, cgridB, dim3(256), 0, p->stream, counts, csum, nbpB, ntiles, cb->base_s, offsets, static_cast<const BktCtl*>(nullptr));
-      hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, bd, cb, static_cast<u32x2*>(p1), offsets, nbpB, stride_b,
+      hipLaunchKernelGGL(bkt_partition_kernel, dim3(nblk), dim3(BKT_T), 0, p->stream, di, si, n, n_dst, n_src, rd, bd, cb, static_cast<u32x2*>(p1), offsets, nbpB,
                          ntiles, src, width);
       switch (width) {
         case 4: hipLaunchKernelGGL((bkt_store_kernel<4>), dim3(nblk), dim3(BKT_T), 0, p->stream, static_cast<const u32x2*>(p1), ntiles, cb, line_shift, static_cast<uint32_t*>(dst)); break;
@@ -2296,7 +2084,7 @@ static agpu_status launch_take_bits_mergeback(agpu_pipeline* p, const uint32_t* 
       hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, p->flags, counts, nbp, ntiles, gate);
       hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum, gate);
       hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s, gate);
-      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 0, 0, 1u, 1u);
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 1u, 1u);
       hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets, gate);
       hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_bits, rs, bs, offsets, nbp,
                          ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v), gate);
@@ -2391,7 +2179,7 @@ static agpu_status launch_take_mergeback(agpu_pipeline* p, int width, const void
       hipLaunchKernelGGL(tk2_hist_kernel, dim3(ntiles), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, p->flags, counts, nbp, ntiles, gate);
       hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum, gate);
       hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s, gate);
-      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 0, 0, 1u, 1u);
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 1u, 1u);
       hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets, gate);
       hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, si, n, n_src, rs, bs, offsets, nbp,
                          ntiles, static_cast<uint32_t*>(srcs_v), static_cast<uint16_t*>(rank_v), gate);
@@ -2450,7 +2238,7 @@ static agpu_status launch_put_through_take(agpu_pipeline* p, int width, const vo
 }
 
 // tuning "gather_bucket": 0 = auto, 1 = always direct, 2 = bucketed whenever the shape qualifies (take: the merge-back
-// pipeline), 3 = like 2 but takes keep the pair pipeline (A/B), 4 = like 2 plus the device-side locality probe (tests).
+// pipeline), 4 = like 2 plus the device-side locality probe (tests).
 // Auto is two decisions: THIS one, on the host, by size and sparsity — is a pipeline worth enqueuing at all? — and the probe's,
 // on the device, by what the index columns look like (idx_locality_kernel) — which of the enqueued forms does the work.
 // The size thresholds, from one-process A/B sweeps on MI355X (tools/probe/bucket_sweep.py --crossover3 → profiles/r03_gather_crossover.json,
@@ -2463,7 +2251,7 @@ static agpu_status launch_put_through_take(agpu_pipeline* p, int width, const vo
 static bool want_bucketed(const agpu_pipeline* p, int width, uint64_t n, uint64_t n_src, uint64_t n_dst, bool is_put) {
   const int64_t mode = p->tune.gather_bucket;
   if (mode == 1) return false;
-  if (mode == 2 || mode == 3 || mode == 4) return n >= BKT_TILE;  // 4: like 2, but with the device-side probe (tests: both outcomes at small sizes)
+  if (mode == 2 || mode == 4) return n >= BKT_TILE;  // 4: like 2, but with the device-side probe (tests: both outcomes at small sizes)
   if (n_src / 8 > n || n_dst / 8 > n) return false;
   if (is_put) return n >= ((uint64_t)1 << 24);
   return n >= ((uint64_t)1 << 25) && n_src * (uint64_t)width >= ((uint64_t)16 << 20);
@@ -2541,11 +2329,6 @@ static agpu_status launch_take_bits_direct(agpu_pipeline* p, const void* bits, u
 }
 
 
-#ifdef BKT_PROFILE
-extern "C" int agpu_debug_bkt_stamps(unsigned long long* out64) {  // 4 x 16 stamps
-  return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_bkt_stamps), sizeof(unsigned long long) * 64, 0, hipMemcpyDeviceToHost);
-}
-#endif
 
 extern "C" {
 
@@ -2556,7 +2339,7 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   AGPU_REQUIRE(values && idx && out, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
   if ((width == 1 || width == 2 || width == 4) && n_values != UINT64_MAX && want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
-    if (p->tune.gather_bucket != 3 && n_idx >= TK2_TILE) {  // "gather_bucket" = 3: the pair pipeline, for A/B
+    if (n_idx >= TK2_TILE) {
       bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;
       if (p->tune.gather_bucket == 0) {  // the probe's answer on the host, if it comes in time: only the chosen form is enqueued
         const int d = probe_decide(p, idx, nullptr, n_idx, width == 4 ? 5 : width == 2 ? 6 : 7, 0);
@@ -2566,8 +2349,6 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
       const agpu_status ms = launch_take_mergeback(p, width, values, n_values, idx, out, n_idx, nullptr, nullptr, adaptive);
       if (ms != AGPU_ERR_UNSUPPORTED) return ms;
     }
-    const agpu_status bs = launch_bucketed(p, width, values, n_values, idx, out, n_idx, nullptr, n_idx);
-    if (bs != AGPU_ERR_UNSUPPORTED) return bs;
   }
   return launch_take_direct(p, width, values, n_values, idx, out, n_idx, nullptr);
 }
@@ -2582,7 +2363,7 @@ agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* valu
     AGPU_REQUIRE(values && idx && out, AGPU_ERR_ARG, "null pointer");
     AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
     AGPU_REQUIRE(aligned_to(validity, 4) && aligned_to(out_validity, 8), AGPU_ERR_SHAPE, "bitmap alignment");
-    if ((width == 4 || width == 2 || width == 1) && n_values != UINT64_MAX && p->tune.gather_bucket != 3 && n_idx >= TK2_TILE &&
+    if ((width == 4 || width == 2 || width == 1) && n_values != UINT64_MAX && n_idx >= TK2_TILE &&
         want_bucketed(p, width, n_idx, n_values, n_idx, false)) {
       bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;
       bool go_direct = false;
@@ -2611,7 +2392,7 @@ static agpu_status take_bits_impl(agpu_pipeline* p, const void* bits, uint64_t n
   AGPU_REQUIRE(bits && idx && out_bits, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(n_bits > 0, AGPU_ERR_SHAPE, "take from an empty bitmap");
   AGPU_REQUIRE(aligned_to(bits, 4) && aligned_to(out_bits, 8), AGPU_ERR_SHAPE, "bitmap alignment");
-  if (n_bits != UINT64_MAX && n_idx >= TK2_TILE && p->tune.gather_bucket != 1 && p->tune.gather_bucket != 3 &&
+  if (n_bits != UINT64_MAX && n_idx >= TK2_TILE && p->tune.gather_bucket != 1 &&
       (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 4 ||
        (n_idx >= ((uint64_t)1 << 25) && n_bits >= ((uint64_t)1 << 27) && n_bits / 8 <= n_idx))) {
     // round 3: the merge-back pipeline with the bitmap's words as the elements (auto: ≥ 2^25 rows from a bitmap of ≥ 16 MiB)
@@ -2735,7 +2516,7 @@ static agpu_status launch_put_bits_bucketed(agpu_pipeline* p, const uint32_t* sr
       hipLaunchKernelGGL(tk2_hist_kernel, dim3((uint32_t)hg), dim3(BKT_T), 0, p->stream, ent, n, n_ent, rs, bs, p->flags, counts, nbp, ntiles);
       hipLaunchKernelGGL(bkt_colsum_kernel, cgrid, dim3(256), 0, p->stream, counts, nbp, ntiles, csum);
       hipLaunchKernelGGL(bkt_colscan_kernel, dim3((nbp + 255) / 256), dim3(256), 0, p->stream, csum, nbp, nchunks, ctl->hist_s);
-      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 0, 0, 1u, 1u);
+      hipLaunchKernelGGL(bkt_scan_kernel, dim3(1), dim3(BKT_T), 0, p->stream, ctl, bs, 0u, 1u, 1u);
       hipLaunchKernelGGL(bkt_offsets_kernel, cgrid, dim3(256), 0, p->stream, counts, csum, nbp, ntiles, ctl->base_s, offsets);
       hipLaunchKernelGGL(tk2_partition_kernel, dim3((ntiles + 7) / 8 * 8), dim3(BKT_T), 0, p->stream, ent, n, n_ent, rs, bs, offsets, nbp, ntiles,
                          static_cast<uint32_t*>(srt_v), static_cast<uint16_t*>(nullptr));
@@ -2793,7 +2574,7 @@ agpu_status agpu_put_bits_bounded(agpu_pipeline* p, const void* src_bits, uint64
   AGPU_REQUIRE(src_bits && src_idx && dst_bits && dst_idx, AGPU_ERR_ARG, "null pointer");
   AGPU_REQUIRE(aligned_to(src_bits, 4) && aligned_to(dst_bits, 4), AGPU_ERR_SHAPE, "bitmap alignment");
   if (n_src_bits != UINT64_MAX && n_dst_bits != UINT64_MAX && n_src_bits > 0 && n_dst_bits > 0 && p->tune.gather_bucket != 1 &&
-      (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 3 || p->tune.gather_bucket == 4 ||
+      (p->tune.gather_bucket == 2 || p->tune.gather_bucket == 4 ||
        (n >= ((uint64_t)1 << 24) && n_dst_bits >= ((uint64_t)1 << 22)))) {
     // (a destination of fewer than 16 regions leaves the apply pass with too few workgroups: the direct kernel keeps those)
     // round 3: bucketed by destination region, no global atomics (auto from 2^24 rows: 0.67 → 0.46 ms there, 10.4 → 3.6 at 2^28)

@@ -447,7 +447,7 @@ def main():
               f"(launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)",
               file=sys.stderr)
     if os.environ.get("AGPU_BENCH_DEVICE_OVERRIDE") is not None:
-        # rehearsal on a 1-GPU box only (tools/r03_bootstrap_rehearsal.sh): every rank names the same GPU, so RCCL's bootstrap between
+        # rehearsal on a 1-GPU box only (tools/archive/r03_bootstrap_rehearsal.sh): every rank names the same GPU, so RCCL's bootstrap between
         # the processes runs for real and its init then refuses the duplicate device — a clean failure, never a measurement
         local_rank = int(os.environ["AGPU_BENCH_DEVICE_OVERRIDE"])
     dev = GpuDevice(local_rank)  # ArrowErrorGPU(NoDevice) without an MI355X: the HIP path has no CPU fallback

@@ -254,27 +254,30 @@ agpu_status agpu_event_destroy(agpu_event* e);
 agpu_status agpu_pipeline_enable_timing(agpu_pipeline* p, int32_t profile_bits);
 agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, const char** out_name);
 
-/* Launch tuning (bench sweeps; defaults are the measured best).  key ∈ {"stream_grid","stream_bpc","stream_unroll",
- * "stream_nt","cmp_variant","reduce_grid","table_tiles","gather_bucket","gather_region_bits","gather_offsets","h2d_mode",
- * "h2d_threads","heavy_tiles","cast_tiles","tile_auto","wave_lds","sync_spin"}; unknown key → AGPU_ERR_ARG.  heavy_tiles / cast_tiles / table_tiles: tiles per block of the
- * VALU-heavy f32 unary kernels / chunks per wave of the widening casts / tiles per block of the LDS-table kernels, the next one's loads issued
- * before the current one is evaluated; 0 = auto.  tile_auto: 0 (default) = for launches that move >= 256 MiB "auto" is ADAPTIVE — one or two
- * tiles per block, whichever the device measured faster on these buffers (eight timed launches per kernel, size class and buffer
- * region, re-measured every 1024 launches; which of the two wins follows what the driver backed the buffers with and cannot be predicted
- * from addresses: docs/experiments.md R5.4); 1 = static defaults; a value > 1 = adaptive with that many bytes as the threshold (tests).  wave_lds: unused dynamic LDS
- * per wave that caps the waves per CU of sin / cos f32, the widening casts to 32 bits and the 8-bit table kernels (0 = each kernel's measured
- * default, ≈ 24 or 16 waves per CU instead of 32: +3–9 % on those kernels, docs/experiments.md R5.5; < 0 = no cap; > 0 = that many bytes).
- * sync_spin: agpu_pipeline_sync, agpu_download of <= AGPU_MAILBOX_MAX_BYTES and agpu_upload of <= 1 KiB wait through the pipeline's pinned MAILBOX — a one-wave
- * kernel queued behind the pipeline's work copies the bytes into (out of) pinned host memory and posts a sequence number the host spins on
- * (one kernel + one scalar back: 6.7 µs instead of 15; docs/experiments.md R5.10).  0 (default) = on, the host spins for at most 200 µs and then blocks in
- * hipStreamSynchronize; > 0 = that many µs; < 0 = off (hipMemcpyAsync + hipStreamSynchronize).  AGPU_SYNC_SPIN=<n> in the environment sets the
- * process-wide default before the first device is created.
- * Results never depend on any of these.  gather_bucket: 0 = auto (size thresholds + the device-side locality probe), 1 = direct
- * kernels, 2 = bucketed pipelines whenever the shape qualifies, 3 = like 2 with the round-2 pair pipeline for takes, 4 = like 2 but with the probe (tests);
- * gather_offsets: range starts of the pair pipeline (1 = atomics, 2 = column scans for both passes, 3 = default, 6 = default with one atomic per range, 8 / 4 = round 3's partition / partition + gather passes).  Every pipeline carries its own copy: agpu_set_tuning changes the process default that pipelines
- * created AFTERWARDS start from (atomic, any thread), agpu_pipeline_set_tuning changes one pipeline only — a sweep on one
- * thread never changes the kernels another pipeline launches.  "mem_pool" (0/1, agpu_set_tuning only) switches the
- * device-level block and stream pools, "pool_arena" (0/1, agpu_set_tuning only) the placed arenas behind blocks of >= 1 GiB. */
+/* Launch tuning (sweeps and tests; defaults are the measured best).  EIGHT keys (round 6 removed nine whose other values were never better):
+ *   "stream_grid"   blocks of the streaming kernels: 0 = one tile per block (default), > 0 = that many, grid-striding (tests: the loop paths)
+ *   "cmp_variant"   4-byte compares: 0 = ballot (default), 1 = vector loads + nibble shuffle
+ *   "gather_bucket" take / put: 0 = auto (size thresholds + the device-side locality probe), 1 = direct kernels, 2 = bucketed pipelines
+ *                   whenever the shape qualifies, 4 = like 2 but with the probe (tests)
+ *   "h2d_mode"      host staging of agpu_import_arrow / agpu_export_arrow: 0 = auto, 1 = pageable copy, 2 = threaded pinned staging, 3 = hipHostRegister
+ *   "tiles"         tiles per block of the kernels that issue the NEXT tile's loads before they evaluate the current one — the VALU-heavy f32
+ *                   unary kernels, the widening casts and cast-headed chains, the LDS-table kernels: 0 = auto, > 0 = that many
+ *   "tile_auto"     0 (default) = for launches that move >= 256 MiB the "auto" of "tiles" is ADAPTIVE — one or two tiles per block, whichever
+ *                   the device measured faster on these buffers (eight timed launches per kernel, size class and buffer region, re-measured
+ *                   every 1024 launches; which of the two wins follows what the driver backed the buffers with: docs/experiments.md R5.4);
+ *                   1 = static defaults; a value > 1 = adaptive with that many bytes as the threshold (tests)
+ *   "wave_lds"      unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the widening casts to 32 bits and the 8-bit table
+ *                   kernels: 0 = each kernel's measured default (≈ 24 or 16 waves per CU instead of 32: +3–9 % on those kernels,
+ *                   docs/experiments.md R5.5, R6.2), < 0 = no cap, > 0 = that many bytes
+ *   "sync_spin"     agpu_pipeline_sync, agpu_download of <= AGPU_MAILBOX_MAX_BYTES and agpu_upload of <= 1 KiB wait through the pipeline's pinned
+ *                   MAILBOX — a one-wave kernel queued behind the pipeline's work copies the bytes into (out of) pinned host memory and posts a
+ *                   sequence number the host spins on (one kernel + one scalar back: 6.7 µs instead of 15; docs/experiments.md R5.10): 0 (default) =
+ *                   on, spinning for at most 200 µs before the blocking wait; > 0 = that many µs; < 0 = off (runtime copies and waits).
+ *                   AGPU_SYNC_SPIN=<n> in the environment sets the process-wide default before the first device is created.
+ * Unknown key → AGPU_ERR_ARG.  Results never depend on any of these.  Every pipeline carries its own copy: agpu_set_tuning changes the
+ * process default that pipelines created AFTERWARDS start from (atomic, any thread), agpu_pipeline_set_tuning changes one pipeline only — a
+ * sweep on one thread never changes the kernels another pipeline launches.  "mem_pool" (0/1, agpu_set_tuning only) switches the device-level
+ * block and stream pools, "pool_arena" (0/1, agpu_set_tuning only) the placed arenas behind blocks of >= 1 GiB. */
 agpu_status agpu_set_tuning(const char* key, int64_t value);
 agpu_status agpu_get_tuning(const char* key, int64_t* out_value);
 agpu_status agpu_pipeline_set_tuning(agpu_pipeline* p, const char* key, int64_t value);
@@ -642,7 +645,7 @@ typedef struct {
  * `offset` (sliced arrays) is honoured: values are copied from `offset` on, bitmaps are re-aligned on the GPU
  * (agpu_bitmap_copy_bits).  null_count == 0 or no validity buffer ⇒ out->validity = NULL.
  * Host→HBM movement: tuning "h2d_mode" = 1 pageable hipMemcpy (default: 56 GB/s measured, the link's rate), 2 = page-locked
- * 4 MiB chunks filled by "h2d_threads" host threads while earlier chunks are on the link (45 GB/s), 3 = hipHostRegister
+ * 4 MiB chunks filled by up to eight host threads while earlier chunks are on the link (45 GB/s), 3 = hipHostRegister
  * in place (57 GB/s).  The device-side work is ordered on p's stream and the call returns as soon as the SOURCE has been
  * read completely — the caller may release `array` immediately and keeps ownership of it (this call never calls
  * array->release). */

@@ -333,16 +333,14 @@ def test_take_bits_at_2_28_rows_merge_back_equals_direct(ctx):
     assert np.array_equal(np.unpackbits(outs[0], bitorder="little")[sample], src[idx[sample]])
 
 
-# ---- the pair pipeline's range starts: by atomics (1), from column scans for P and G (2), scan for P + atomics for G (3 = default: two
-# ranges per 64-bit atomic and P / G over 32 Ki-row tiles since round 4; 6 = one 32-bit atomic per range; 8 = round 3's 16 Ki-row P under the new
-# G; 4 = round 3's P and G)
-@pytest.mark.parametrize("offsets", [1, 2, 3, 4, 6, 8])
+# ---- the put's pair pipeline with ragged tiles (dropped rows), 4- and 1-byte values, and the bucketed take beside it over the same columns
+# (rounds 3-5 ran this over six ways of getting the pipeline's range starts — tuning gather_offsets — and the pair-pipeline take,
+# gather_bucket = 3; round 6 removed the variants that never beat the default)
 @pytest.mark.parametrize("width", [4, 1])
-def test_pair_pipeline_range_start_variants(ctx, offsets, width):
+def test_pair_pipeline_with_dropped_rows_and_the_bucketed_take(ctx, width):
     dev, p = ctx
-    p.set_tuning("gather_offsets", offsets)
     try:
-        rng = np.random.default_rng(offsets * 7 + width)
+        rng = np.random.default_rng(21 + width)
         n, n_src, n_dst = 3 * 16384 + 77, 2_000_003, (1 << 21) + 9
         src = rng.integers(0, 1 << (8 * width), n_src, dtype=np.uint64).astype(NPW[width])
         dst = rng.integers(0, 1 << (8 * width), n_dst, dtype=np.uint64).astype(NPW[width])
@@ -352,6 +350,7 @@ def test_pair_pipeline_range_start_variants(ctx, offsets, width):
         ok = si < n_src
         ds, dd = dev.create_gpu_buffer_with_data(src), dev.create_gpu_buffer_with_data(dst)
         dsi, ddi = dev.create_gpu_buffer_with_data(si), dev.create_gpu_buffer_with_data(di)
+        p.set_tuning("gather_bucket", 2)
         capi.call("agpu_put_bounded", p._handle, width, vp(ds), n_src, vp(dsi), vp(dd), n_dst, vp(ddi), n)
         import arrow_gpu_amd as ag
 
@@ -361,8 +360,6 @@ def test_pair_pipeline_range_start_variants(ctx, offsets, width):
         exp = dst.copy()
         exp[di[ok]] = src[si[ok]]
         assert np.array_equal(got, exp)
-        # the pair-pipeline take (mode 3 for 4-byte values, the only bucketed form for 1-byte ones)
-        p.set_tuning("gather_bucket", 3 if width == 4 else 2)
         out = dev.create_empty_buffer(n * width + 16)
         capi.call("agpu_take", p._handle, width, vp(ds), n_src, vp(dsi), vp(out), n)
         with pytest.raises(ag.ArrowErrorGPU):
@@ -370,7 +367,6 @@ def test_pair_pipeline_range_start_variants(ctx, offsets, width):
         got = dev.retrive_data(out, n * width, pipeline=p).view(NPW[width])
         assert np.array_equal(got, np.where(ok, src[np.minimum(si, n_src - 1)], 0).astype(NPW[width]))
     finally:
-        p.set_tuning("gather_offsets", 0)
         p.set_tuning("gather_bucket", 2)
 
 

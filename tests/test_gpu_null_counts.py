@@ -97,14 +97,14 @@ def test_compare_validity_null_count(D, dtype, n):
 
 
 def test_compare_count_under_a_capped_grid_and_sweep_tunings(D):
-    """grid-stride launches (stream_grid / stream_bpc tunings) visit the same VIRTUAL validity blocks: same count"""
+    """grid-stride launches (the stream_grid tuning) visit the same VIRTUAL validity blocks: same count"""
     n = 3_000_000 + 77
     a, b = rand_values(capi.I32, n, 1), rand_values(capi.I32, n, 2)
     va, vb = dirty_bitmap(n, 7, 0.9), dirty_bitmap(n, 8, 0.9)
     want = n - O.bitmap_popcount(O.validity_and(va, vb, n), n)
     nb = O.bitmap_bytes(n) + 8
     da, db, dva, dvb = D.up(a), D.up(b), D.up(va), D.up(vb)
-    for key, val in (("stream_grid", 7), ("stream_grid", 1024), ("stream_bpc", 2), ("cmp_variant", 1)):
+    for key, val in (("stream_grid", 7), ("stream_grid", 1024), ("stream_grid", 512), ("cmp_variant", 1)):
         capi.call("agpu_pipeline_set_tuning", D.p._h, key.encode(), val)
         ob, ov, cnt = D.empty(nb), D.empty(nb), D.empty(8, fill=0xEE)
         D.call("agpu_compare_validity_count", capi.CMP_EQ, capi.I32, da.vp, db.vp, dva.vp, dvb.vp, ob.vp, ov.vp, n, cnt.vp)

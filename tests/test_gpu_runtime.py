@@ -162,15 +162,15 @@ def test_tuning_is_per_pipeline(ag):
     assert v.value == 1
     assert capi.lib().agpu_pipeline_set_tuning(p1._handle, b"no_such_key", 1) == capi.ERR_ARG
     # a new default reaches pipelines created afterwards only
-    capi.call("agpu_set_tuning", b"table_tiles", 2)
+    capi.call("agpu_set_tuning", b"tiles", 2)
     try:
         p3 = ag.ArrowComputePipeline(dev, "c")
-        capi.call("agpu_pipeline_get_tuning", p3._handle, b"table_tiles", C.byref(v))
+        capi.call("agpu_pipeline_get_tuning", p3._handle, b"tiles", C.byref(v))
         assert v.value == 2
-        capi.call("agpu_pipeline_get_tuning", p2._handle, b"table_tiles", C.byref(v))
+        capi.call("agpu_pipeline_get_tuning", p2._handle, b"tiles", C.byref(v))
         assert v.value == 0  # 0 = each kernel's measured best
     finally:
-        capi.call("agpu_set_tuning", b"table_tiles", 0)
+        capi.call("agpu_set_tuning", b"tiles", 0)
 
 
 # ------------------------------------------------------------------ profiling hooks [ref: compute_query.rs, gpu_device.rs:132]

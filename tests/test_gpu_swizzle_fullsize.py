@@ -134,7 +134,6 @@ def cols(request):
     c = Cols(dev, p, **CASES[request.param])
     yield c
     p.set_tuning("gather_bucket", 0)
-    p.set_tuning("gather_offsets", 3)
     c.verified.clear()
     del c
     capi.call("agpu_device_trim", dev._handle)
@@ -260,17 +259,15 @@ def test_put_all_four_corners_pinned_through_the_inverse_take(cols, width):
                 expect = taken
             else:  # src_idx = iota: the source column itself
                 expect = c.values
-            forms = [(0, 3), (2, 3), (1, 3)] + ([(2, 1), (2, 2), (2, 4), (2, 6)] if (src_kind, dst_kind) == ("random", "random") else [])
-            for mode, offsets in forms:
+            for mode in (0, 2, 1):  # auto (the probe decides), the forced pipeline, the direct scatter
                 c.p.set_tuning("gather_bucket", mode)
-                c.p.set_tuning("gather_offsets", offsets)
                 capi.call("agpu_memset", h, vp(dst), pattern, width * c.n_dst + 16)
                 capi.call("agpu_put_bounded", h, width, vp(c.values), c.n_values, vp(src_idx), vp(dst), c.n_dst, vp(dst_idx), n)
                 c.p.sync()
                 c.p.set_tuning("gather_bucket", 1)  # the inverse through the direct kernel (verified against numpy at this size)
                 capi.call("agpu_take", h, width, vp(dst), c.n_dst, vp(dst_idx), vp(back), n)
                 c.p.sync()
-                tag = (width, src_kind, dst_kind, mode, offsets)
+                tag = (width, src_kind, dst_kind, mode)
                 assert c.count_equal(dt, back, expect, n) == n, tag
                 assert (c.download(dst, width * c.n_dst, 16) == pattern).all(), tag
                 if width == 4:  # untouched slots: sum(dst) == sum(put values) + pattern word · (n_dst − n)  (mod 2^32)
@@ -282,7 +279,6 @@ def test_put_all_four_corners_pinned_through_the_inverse_take(cols, width):
                     assert (tail == pattern).all(), tag
     finally:
         c.p.set_tuning("gather_bucket", 0)
-        c.p.set_tuning("gather_offsets", 3)
 
 
 def test_put_bits_pinned_through_the_inverse_bit_take(cols):

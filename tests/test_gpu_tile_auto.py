@@ -51,11 +51,11 @@ def checksum(dev, p, out, chk, nbytes):
 
 
 LAUNCHES = {
-    "cast": ("cast_tiles", lambda h, u8, f, out: capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u8), vp(out), N)),
-    "heavy": ("heavy_tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_SIN, capi.F32, vp(f), vp(out), N)),
-    "lut8": ("table_tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_COS, capi.U8, vp(u8), vp(out), N)),
-    "trig16": ("table_tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_SIN, capi.I16, vp(u8), vp(out), N)),
-    "log": ("table_tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(f), vp(out), N)),
+    "cast": ("tiles", lambda h, u8, f, out: capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u8), vp(out), N)),
+    "heavy": ("tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_SIN, capi.F32, vp(f), vp(out), N)),
+    "lut8": ("tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_COS, capi.U8, vp(u8), vp(out), N)),
+    "trig16": ("tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_SIN, capi.I16, vp(u8), vp(out), N)),
+    "log": ("tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(f), vp(out), N)),
 }
 
 
@@ -113,7 +113,7 @@ def test_small_launches_are_left_alone_and_bursts_converge(ctx):
     mine = [x for x in entries(dev)["cast"] if x["lg"] == (5 * n2).bit_length() - 1]
     assert len(mine) == 1 and mine[0]["tiles"] in (1, 2) and mine[0]["n"] == (4, 4), entries(dev)
     ref = checksum(dev, q, out, chk, 4 * n2)
-    q.set_tuning("cast_tiles", 1)
+    q.set_tuning("tiles", 1)
     capi.call("agpu_cast", q._handle, capi.U8, capi.F32, vp(u8), vp(out), n2)
     assert checksum(dev, q, out, chk, 4 * n2) == ref
 
@@ -164,10 +164,10 @@ def test_four_host_threads_sampling_the_same_key(ctx):
 
     n5 = 9 << 23
     outs = [dev.create_empty_buffer(4 * n5) for _ in range(4)]
-    p.set_tuning("cast_tiles", 1)
+    p.set_tuning("tiles", 1)
     capi.call("agpu_cast", p._handle, capi.I8, capi.F32, vp(u8), vp(out), n5)
     ref = checksum(dev, p, out, chk, 4 * n5)
-    p.set_tuning("cast_tiles", 0)
+    p.set_tuning("tiles", 0)
     errs = []
 
     def worker(k):

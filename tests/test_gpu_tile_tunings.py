@@ -1,4 +1,4 @@
-"""GPU: the tiles-per-block tunings (heavy_tiles / cast_tiles / table_tiles: a block walks k tiles a grid apart and issues the next tile's loads
+"""GPU: the tiles-per-block tuning ("tiles"; heavy_tiles / cast_tiles / table_tiles until round 6: a block walks k tiles a grid apart and issues the next tile's loads
 before it evaluates the current one — elementwise.hip tile_run) never change a result: every kernel that has the walk, at k = 1 … 5 and with a
 forced small grid, against its own k = default output bit for bit and against the oracle, at sizes around the tile boundaries."""
 import ctypes as C
@@ -48,16 +48,16 @@ def test_every_walk_kernel_is_invariant_under_tiles_per_block(ctx, n):
     st[0].op, st[0].kind, st[0].operand = capi.OP_MUL, 1, sc.ptr
     st[1].op, st[1].kind, st[1].operand = capi.UN_SIN, 0, None
     kernels = {
-        "heavy_tiles": [("sin_f32", lambda: capi.call("agpu_unary", h, capi.UN_SIN, capi.F32, vp(df), vp(out), n), lambda: O.unary(O.UN_SIN, O.F32, f), 1),
+        "heavy": [("sin_f32", lambda: capi.call("agpu_unary", h, capi.UN_SIN, capi.F32, vp(df), vp(out), n), lambda: O.unary(O.UN_SIN, O.F32, f), 1),
                         ("cos_f32", lambda: capi.call("agpu_unary", h, capi.UN_COS, capi.F32, vp(df), vp(out), n), lambda: O.unary(O.UN_COS, O.F32, f), 1),
                         ("sinh_f32", lambda: capi.call("agpu_unary", h, capi.UN_SINH, capi.F32, vp(df2), vp(out), n), lambda: O.unary(O.UN_SINH, O.F32, f2), 1)],
-        "table_tiles": [("log_f32", lambda: capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(dpos), vp(out), n), lambda: O.unary(O.UN_LOG, O.F32, fpos), 1),
+        "table": [("log_f32", lambda: capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(dpos), vp(out), n), lambda: O.unary(O.UN_LOG, O.F32, fpos), 1),
                         ("pow_f32", lambda: capi.call("agpu_binary", h, capi.OP_POW, capi.F32, vp(dpos), vp(df2), vp(out), n), lambda: O.binary(O.OP_POW, O.F32, fpos, f2), 1),
                         ("pow_f32_scalar", lambda: capi.call("agpu_scalar", h, capi.OP_POW, capi.F32, vp(dpos), vp(sc), vp(out), n),
                          lambda: O.scalar(O.OP_POW, O.F32, fpos, np.array([0.37], np.float32)), 1),
                         ("sin_u8", lambda: capi.call("agpu_unary", h, capi.UN_SIN, capi.U8, vp(du8), vp(out), n), lambda: O.unary(O.UN_SIN, O.U8, u8), 1),
                         ("cos_i16", lambda: capi.call("agpu_unary", h, capi.UN_COS, capi.I16, vp(di16), vp(out), n), lambda: O.unary(O.UN_COS, O.I16, i16), 1)],
-        "cast_tiles": [("cast_u8_f32", lambda: capi.call("agpu_cast", h, capi.U8, capi.F32, vp(du8), vp(out), n), lambda: u8.astype(np.float32), 0),
+        "cast": [("cast_u8_f32", lambda: capi.call("agpu_cast", h, capi.U8, capi.F32, vp(du8), vp(out), n), lambda: u8.astype(np.float32), 0),
                        ("cast_i16_f32", lambda: capi.call("agpu_cast", h, capi.I16, capi.F32, vp(di16), vp(out), n), lambda: i16.astype(np.float32), 0),
                        ("cast_i16_chain", lambda: capi.call("agpu_fused_cast_chain", h, capi.I16, vp(di16), C.cast(st, C.c_void_p), 2, vp(out), n),
                         lambda: O.unary(O.UN_SIN, O.F32, O.scalar(O.OP_MUL, O.F32, i16.astype(np.float32), np.array([0.37], np.float32))), 1),
@@ -65,7 +65,8 @@ def test_every_walk_kernel_is_invariant_under_tiles_per_block(ctx, n):
                         lambda: O.unary(O.UN_SIN, O.F32, O.scalar(O.OP_MUL, O.F32, u8.astype(np.float32), np.array([0.37], np.float32))), 1)],
     }
     try:
-        for key, rows in kernels.items():
+        key = "tiles"
+        for family, rows in kernels.items():
             for name, launch, oracle, ulp in rows:
                 p.set_tuning(key, 0)
                 capi.call("agpu_memset", h, vp(out), 0xEE, 4 * n + 16)
@@ -93,5 +94,5 @@ def test_every_walk_kernel_is_invariant_under_tiles_per_block(ctx, n):
                 p.set_tuning("wave_lds", 0)
                 p.set_tuning(key, 0)
     finally:
-        for key in ("heavy_tiles", "cast_tiles", "table_tiles", "stream_grid", "wave_lds"):
+        for key in ("tiles", "stream_grid", "wave_lds"):
             p.set_tuning(key, 0)

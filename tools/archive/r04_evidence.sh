@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4: ONE box, one call — the whole GPU suite (timing expectations asserted), smoke, the plain bench line, the bench and the kernel table
 # under rocprofv3 (trace + the two PMC passes each), the take / put passes.  Outputs under gpurun_out/; the summaries are copied into profiles/.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export AGPU_PERF_STRICT=1
 timeout 3000 python -m pytest tests/ -x -q -m gpu --durations=10 > gpurun_out/r04_gpu_suite.log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, first GPU contact: the new tests (arena reuse, comm proof / poison, swizzle at BASELINE scale) + a bench line
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export AGPU_PERF_STRICT=0
 timeout 1500 python -m pytest tests/test_gpu_pools.py tests/test_gpu_comm.py -x -q -m gpu > gpurun_out/r04_t1.log 2>&1

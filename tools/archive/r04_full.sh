@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4: the whole GPU suite + the bench under the profiler passes that back the committed numbers
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export AGPU_PERF_STRICT=${AGPU_PERF_STRICT:-1}  # the runs that produce committed evidence assert the timing expectations
 timeout 3000 python -m pytest tests/ -x -q -m gpu --durations=15 > gpurun_out/r04_gpu_suite.log 2>&1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 4 rehearsals on a 1-GPU box: the torchrun launch at world 1 (weak + the strong leg), the self-launcher refusing a world that is not
 # `--gpus` distinct devices (two workers naming GPU 0), and the whole GPU suite with every pipeline fusing (AGPU_FUSE=1)
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 AGPU_BENCH_STRONG_LEG=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/r04_bench_torchrun_world1.json 2> gpurun_out/r04_bench_torchrun_world1.err
 echo "torchrun world1 rc=$?"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 4, second GPU contact: cast-headed chains, the one-outer-step sin / cos, the LDS counters of the narrow trig kernels
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 timeout 1200 python -m pytest tests/test_gpu_fused.py tests/test_gpu_sc1.py tests/test_cpp_host.py -x -q -m gpu > gpurun_out/r04_s1.log 2>&1
 echo "fused+sc1+cpp rc=$?" >> gpurun_out/r04_s1.log

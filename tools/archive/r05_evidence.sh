@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5: ONE box, one call — the whole GPU suite (timing expectations asserted), smoke, the plain bench line, the bench and the kernel table
 # under rocprofv3 (trace + the two PMC passes each), the take / put passes.  Outputs under gpurun_out/; the summaries are copied into profiles/.
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 bash tools/probe/box_fingerprint.sh > gpurun_out/r05_box_evidence.txt 2>&1; tail -1 gpurun_out/r05_box_evidence.txt
 export AGPU_PERF_STRICT=1

@@ -25,4 +25,4 @@ for name, dt, op, bpr in (("u8 shl", capi.U8, capi.OP_SHL, 6.0), ("i8 shr", capi
         p.set_tuning("stream_unroll", blk); row.append(f"{'256-thread' if blk == 256 else 'one-wave'} {med(dt, op, bpr):.3f}")
     print(name, "  ".join(row), flush=True)
 PY
-bash tools/r05_sincos_u.sh 2>&1 | grep -E '^(==|sin|cos)'
+bash tools/archive/r05_sincos_u.sh 2>&1 | grep -E '^(==|sin|cos)'

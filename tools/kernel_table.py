@@ -164,10 +164,6 @@ def main():
     t("take f32, random idx, default = merge-back pipeline (2^28 rows)", 12 * m / n, lambda: capi.call("agpu_take", h, 4, vp(A), m, vp(IDX), vp(O), m),
       note="auto policy picks the bucketed form at this size; round 3: ranks recorded, runs merged back (tk2_* kernels)")
     fix(12)
-    p.set_tuning("gather_bucket", 3)
-    t("take f32, random idx, pair pipeline (2^28 rows)", 12 * m / n, lambda: capi.call("agpu_take", h, 4, vp(A), m, vp(IDX), vp(O), m),
-      note="tuning gather_bucket=3: round 2's form, now with range starts from the column scan and XCD-contiguous partition tiles")
-    fix(12)
     OV = dev.create_empty_buffer(m // 8 + 64)
     p.set_tuning("gather_bucket", 0)
     t("take f32 WITH validity, random idx, default = one merge-back pipeline (2^28 rows)", 12.25 * m / n,
