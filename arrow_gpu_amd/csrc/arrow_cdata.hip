@@ -218,7 +218,8 @@ static bool host_range_in_brk_heap(const void* ptr, size_t bytes) {
 // header behind ANOTHER 64 MiB boundary); size ≤ mprotect_size ≤ 64 MiB, both page multiples.  A range is staged when the header at A
 // is readable (it is read through the kernel — a pipe write that fails with EFAULT instead of a load that faults) and looks like that; any
 // other memory — numpy, Arrow pools, file mappings, mmap itself — goes to the runtime at the link's rate.  A false "arena" costs
-// bandwidth only; a false "not an arena" would need a glibc whose heap_info no longer starts with these four words.
+// bandwidth only; a false "not an arena" needs a glibc whose heap_info no longer starts with these four words, heaps that are not 64 MiB
+// (glibc.malloc.hugetlb = 2) or another allocator altogether — host_allocator_unknown() below sends those processes down the safe path.
 #define AGPU_THREAD_ARENA_MAX ((size_t)64 << 20)
 static bool host_range_in_thread_arena(const void* ptr, size_t bytes) {
   const uintptr_t lo = reinterpret_cast<uintptr_t>(ptr), hi = lo + bytes, mask = AGPU_THREAD_ARENA_MAX - 1;
@@ -261,9 +262,27 @@ static bool host_range_in_thread_arena(const void* ptr, size_t bytes) {
                       size >= 4096 && (size & 4095) == 0 && mprot >= size && (mprot & 4095) == 0 && mprot <= AGPU_THREAD_ARENA_MAX;
   return header;
 }
+// The header test above knows glibc's DEFAULT heaps.  Two set-ups it cannot vouch for: glibc.malloc.hugetlb = 2 makes the heaps
+// 4 × the huge page size instead of 64 MiB, and a preloaded allocator (jemalloc, tcmalloc, mimalloc as LD_PRELOAD) trims and unmaps extents of
+// its own that carry no heap_info at all.  In such a process every range below 64 MiB takes the staged path — bandwidth, not safety, is what
+// that costs (14–40 GB/s instead of 33–56).
+static bool host_allocator_unknown() {
+  static const bool unknown = [] {
+    const char* t = getenv("GLIBC_TUNABLES");
+    if (t) {
+      const char* h = strstr(t, "glibc.malloc.hugetlb=");
+      if (h && h[21] != '0') return true;
+    }
+    const char* pre = getenv("LD_PRELOAD");
+    if (pre && (strstr(pre, "jemalloc") || strstr(pre, "tcmalloc") || strstr(pre, "mimalloc") || strstr(pre, "malloc"))) return true;
+    return false;
+  }();
+  return unknown;
+}
 static bool host_range_needs_staging(const void* ptr, size_t bytes) {
   if (host_range_in_brk_heap(ptr, bytes)) return true;
   if (bytes >= AGPU_THREAD_ARENA_MAX) return false;
+  if (host_allocator_unknown()) return true;
   return host_range_in_thread_arena(ptr, bytes);
 }
 

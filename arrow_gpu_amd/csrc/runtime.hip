@@ -964,7 +964,9 @@ static agpu_status device_post(agpu_device* dev, agpu_stream_slot* s, int word, 
   return AGPU_OK;
 }
 // device_await: spin, then sleep-poll, until word `word` shows `seq`
-static agpu_status device_await(agpu_device* dev, agpu_stream_slot* s, int word, uint64_t seq, int64_t spin) {
+// *arrived_out = false with AGPU_OK: the post can no longer be waited for here (its slot left the device, or its stream entered a graph capture
+// — asking a capturing stream anything invalidates the capture): the caller finishes with a runtime wait / copy instead
+static agpu_status device_await(agpu_device* dev, agpu_stream_slot* s, int word, uint64_t seq, int64_t spin, bool* arrived_out) {
   uint64_t* seq_word = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(dev->mbox) + AGPU_MBOX_SEQ) + word;
   const int64_t budget_us = spin > 0 ? spin : 200;
   const auto t0 = std::chrono::steady_clock::now();
@@ -983,7 +985,7 @@ static agpu_status device_await(agpu_device* dev, agpu_stream_slot* s, int word,
     arrived = __atomic_load_n(seq_word, __ATOMIC_ACQUIRE) == seq;
     if (arrived || polls % 25 != 24) continue;
     std::lock_guard<std::mutex> lock(dev->mu);
-    if (!slot_listed_locked(dev, s)) break;
+    if (!slot_listed_locked(dev, s) || slot_capturing(s)) break;
     const hipError_t q = hipStreamQuery(s->stream);
     if (q == hipErrorNotReady) continue;
     arrived = __atomic_load_n(seq_word, __ATOMIC_ACQUIRE) == seq;
@@ -992,6 +994,7 @@ static agpu_status device_await(agpu_device* dev, agpu_stream_slot* s, int word,
       return AGPU_ERR_HIP;
     }
   }
+  *arrived_out = arrived;
   return AGPU_OK;
 }
 
@@ -1043,10 +1046,14 @@ static agpu_status device_wait_all(agpu_device* dev, const void* src_dev, size_t
       const agpu_status st = device_post(dev, targets[k], (int)k, nullptr, 0, &seqs[k], &posted[k]);
       if (st != AGPU_OK) return st;
     }
+    bool fallback = false;  // a post that could not be waited for: the runtime's device-wide wait finishes the job (no capture is open then, or
+                            // the stream that opened one is simply skipped by it — its work is not ours to wait for mid-capture)
     for (size_t k = 0; k < early; k++)
       if (posted[k]) {
-        const agpu_status st = device_await(dev, targets[k], (int)k, seqs[k], spin);
+        bool got = false;
+        const agpu_status st = device_await(dev, targets[k], (int)k, seqs[k], spin, &got);
         if (st != AGPU_OK) return st;
+        if (!got) fallback = true;
       }
     for (size_t k = early; k < nt; k++) {  // the payload's post (and, with a capture open, streams beyond the third)
       const bool last = k + 1 == nt;
@@ -1054,14 +1061,20 @@ static agpu_status device_wait_all(agpu_device* dev, const void* src_dev, size_t
       bool ok = false;
       agpu_status st = device_post(dev, targets[k], 3, last ? src_dev : nullptr, last ? bytes : 0, &seq, &ok);
       if (st != AGPU_OK) return st;
+      bool got = false;
       if (ok) {
-        st = device_await(dev, targets[k], 3, seq, spin);
+        st = device_await(dev, targets[k], 3, seq, spin, &got);
         if (st != AGPU_OK) return st;
+        if (!got) fallback = true;
+      }
+      if (ok && got) {
         if (last && bytes) memcpy(dst_host, reinterpret_cast<char*>(dev->mbox) + AGPU_MBOX_PAYLOAD, bytes);
-      } else if (last && bytes) {
+      } else if (last && bytes) {  // never posted, or the post never arrived: the payload is NOT in the mailbox — a blocking copy reads it
+        if (!any_capturing) AGPU_HIP(hipDeviceSynchronize());  // whatever produced the bytes is through before they are read
         AGPU_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));  // (rare: the stream went away between the scan and now)
       }
     }
+    if (fallback && !any_capturing) AGPU_HIP(hipDeviceSynchronize());
   } else {
     AGPU_HIP(hipDeviceSynchronize());
     if (bytes) AGPU_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
