@@ -135,6 +135,10 @@ def main():
       note="same table route: a transcendental step costs nothing per row")
     t("cast i16→f32 then sin, ONE launch", 6, lambda: capi.call("agpu_fused_cast_chain", h, capi.I16, vp(B), C.cast(c_sin, C.c_void_p), n_sin, vp(O), n),
       note="16-bit source: sin evaluated per row (VALU-bound); bit-identical to the pair, which the table kernel sin_i16 is not")
+    t("cast u16→f32 · s then sin, ONE launch", 6, lambda: capi.call("agpu_fused_cast_chain", h, capi.U16, vp(B), C.cast(c_hv, C.c_void_p), n_hv, vp(O), n),
+      note="the generic cast-headed chain kernel (round 6: the chain interpreted once per chunk, sin in packed f32)")
+    t("(x · s).sin() f32, ONE launch", 8, lambda: capi.call("agpu_fused_chain", h, F32, vp(A), C.cast(c_hv, C.c_void_p), n_hv, vp(O), n),
+      note="agpu_fused_chain with a transcendental step")
     t("fused sin_u16", 6, lambda: capi.call("agpu_unary", h, capi.UN_SIN, capi.U16, vp(B), vp(O), n))
     t("broadcast f32", 4, lambda: capi.call("agpu_broadcast", h, F32, 0x40400000, vp(O), n))
     t("f32 sum (reference tree order)", 4, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, F32, vp(A), None, n, vp(R)))
