@@ -348,7 +348,7 @@ __device__ const PowTab* g_pow_tab = nullptr;
 // f32 (it weighs < 1 % of the result), the division as an f32 reciprocal + one f64 Newton step, the rest in f64, ONE
 // rounding to f32.  (The f32 library logf measures 2 ULP on gfx950; the f64 library log is VALU-bound at 37 % of HBM —
 // tests/tools/math_ulp.py, profiles/r01_kernel_table.json.)
-__device__ __forceinline__ float log_f32_general(float x) {  // any operand: 0, negatives, NaN, inf, denormals
+__device__ __attribute__((noinline)) float log_f32_general(float x) {  // any operand: 0, negatives, NaN, inf, denormals
   if (!(x > 0.0f) || !(x < __builtin_inff())) {  // 0, negatives, NaN, +inf
     if (x == 0.0f) return -__builtin_inff();
     if (x < 0.0f || x != x) return __builtin_nanf("");
@@ -374,12 +374,59 @@ __device__ __forceinline__ float log_f32_general(float x) {  // any operand: 0, 
   return (float)fma((double)e, 0x1.62e42fefa39efp-1, t);
 }
 
-// Positive normal finite x — what a wave of ordinary data consists of: ln x = (e + lc_j)·ln2 + log1p(u), u = m·rc_j − 1
-// (|u| < 2^-7, exact in f64), log1p(u) = u − u²/2 + u³·q(u) with the quadratic q in f32 — the table form of pow's logarithm:
-// no division, no frexp, 11 f64-class instructions instead of 21 (the atanh form above is VALU-bound at 8 B/row:
-// 45 VALU instructions per row, 0.76 of the HBM roof).  ≤ 1 ULP like the general form (log2 to 2^-33 relative).
+// Positive normal finite x — what a wave of ordinary data consists of.  Rounds 2–5: the table form of pow's logarithm in f64 (ln x = (e + lc_j)·ln2 +
+// log1p(m·rc_j − 1): 11 f64-class instructions + a 16-byte LDS read per row, its own 256-thread kernel to stage the table, 0.78–0.80 of the roof).
+// Round 6: ALL in f32, two rows per instruction like sin / cos (sincos_f32_pair above):
+//   x = 2^e · m, m ∈ [√½, √2) by integer arithmetic on the bits; f = m − 1 exact;
+//   log m = f − f²/2 + f³·P(f), P = the degree-7 minimax polynomial of (log1p f − f + f²/2) / f³ on [√½ − 1, √2 − 1] (0.10 ULP of the result;
+//   tools/probe/log_f32_proto.c prints the fit); ln x = fma(e, LN2_HI, fma(e, LN2_LO, log m)) with LN2_HI of 15 bits, so e · LN2_HI is exact.
+// Every positive normal f32 is within 1 ULP of f64 libm rounded once — 12 408 324 of 2 122 317 824 inputs differ, all by one; largest error against
+// the true value 0.874 ULP — checked on the CPU with this operation sequence (tools/probe/log_f32_proto.c, 15 s) and on the device
+// (tests/tools/exhaustive_vs_oracle.py log).  7.5 packed + 5 scalar instructions per row, no table, no LDS: the generic f32 tile kernel runs it.
 __device__ __forceinline__ bool log_ordinary(float x) {
   return __builtin_amdgcn_classf(x, 0x100);  // +normal: one v_cmp_class_f32
+}
+__device__ __forceinline__ f32x2_t log_f32_pair(f32x2_t x) {  // meaningful for positive normal x, harmless elsewhere
+  const float x0 = x.x, x1 = x.y;  // (copies: this clang mis-lowers a bit cast of a vector ELEMENT — see sincos_f32_pair)
+  const uint32_t b0 = __builtin_bit_cast(uint32_t, x0), b1 = __builtin_bit_cast(uint32_t, x1);
+  const int32_t e0 = (int32_t)(b0 - 0x3f3504f3u) >> 23, e1 = (int32_t)(b1 - 0x3f3504f3u) >> 23;  // 0x3f3504f3 = √½: m ∈ [√½, √2)
+  const float m0 = __builtin_bit_cast(float, b0 - ((uint32_t)e0 << 23)), m1 = __builtin_bit_cast(float, b1 - ((uint32_t)e1 << 23));
+  const f32x2_t ef = {(float)e0, (float)e1};
+  const f32x2_t f = (f32x2_t){m0, m1} - pk2(1.0f);
+  const f32x2_t f2 = f * f;
+  f32x2_t p = pk_fma(f, pk2(-0x1.38b586p-4f), pk2(0x1.055b6cp-3f));
+  p = pk_fma(f, p, pk2(-0x1.0d8542p-3f));
+  p = pk_fma(f, p, pk2(0x1.22da1cp-3f));
+  p = pk_fma(f, p, pk2(-0x1.547244p-3f));
+  p = pk_fma(f, p, pk2(0x1.99a008p-3f));
+  p = pk_fma(f, p, pk2(-0x1.000226p-2f));
+  p = pk_fma(f, p, pk2(0x1.555554p-2f));
+  const f32x2_t q = pk_fma(f2 * f, p, -(f2 * pk2(0.5f)));  // f³·P − f²/2
+  const f32x2_t r = f + q;
+  const f32x2_t t = pk_fma(ef, pk2(0x1.7f7d1cp-20f), r);
+  return pk_fma(ef, pk2(0x1.62e4p-1f), t);
+}
+template <int N>
+__device__ __forceinline__ void log_f32_rows(const float (&x)[N], float (&res)[N]) {
+  static_assert(N % 2 == 0, "rows come in pairs");
+  bool slow = false;
+#pragma unroll
+  for (int k = 0; k < N; k += 2) {
+    const f32x2_t v = log_f32_pair((f32x2_t){x[k], x[k + 1]});
+    res[k] = v.x;
+    res[k + 1] = v.y;
+    slow = slow || !log_ordinary(x[k]) || !log_ordinary(x[k + 1]);
+  }
+  if (slow) {  // 0, negatives, NaN, inf, denormals
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      if (!log_ordinary(x[k])) res[k] = log_f32_general(x[k]);
+  }
+}
+__device__ __forceinline__ float log_f32_dev(float x) {  // one row (tails, unaligned columns)
+  float res = log_f32_pair(pk2(x)).x;
+  if (!log_ordinary(x)) res = log_f32_general(x);
+  return res;
 }
 // x = 2^e · m for a positive normal x, m ∈ [0.707, 1.414) as an f64 and j = the table interval of its mantissa.  Adding
 // (128 − 53) << 16 carries into the exponent field exactly when j ≥ 53 (m ≥ 1.414 → halved), so e, the "big" bit and
@@ -405,18 +452,6 @@ __device__ __forceinline__ float log1p_q(float uf) {
   float q = __builtin_fmaf(uf, 0x1.999f5p-3f, -0x1.0002p-2f);
   return __builtin_fmaf(uf, q, 0x1.555556p-2f);
 }
-template <typename TabPtr>
-__device__ __forceinline__ float log_f32_fast(TabPtr tab, float x) {
-  const MantSplit sp = split_normal_f32(x);
-  const PowTab T = tab[sp.j];
-  const double u = fma(sp.m, T.rc, -1.0);
-  const double l1p = fma(u * u, fma(u, (double)log1p_q((float)u), -0.5), u);
-  return (float)fma((double)sp.e + T.lc, 0x1.62e42fefa39efp-1, l1p);
-}
-__device__ __forceinline__ float log_f32_dev(float x) {
-  return log_ordinary(x) ? log_f32_fast(g_pow_tab, x) : log_f32_general(x);
-}
-
 // sinh: a = |x| = k·ln2 + r (|r| ≤ ln2/2); cosh r = C and sinh r = S from the even / odd Taylor halves (inner terms in
 // f32, they weigh < 6 % of C and < 2 % of S; outer step in f64), then sinh a = 2^(k−1)(C+S) − 2^(−k−1)(C−S) in f64 and
 // ONE rounding to f32.  k = 0 returns S itself (no cancellation for tiny |x|, keeps ±0 and denormals).  |x| is clamped
@@ -454,7 +489,10 @@ struct UnSqrt { __device__ static __forceinline__ float ap(float x, float) { ret
 struct UnCbrt { __device__ static __forceinline__ float ap(float x, float) { return cbrtf(x); } };
 struct UnExp { __device__ static __forceinline__ float ap(float x, float) { return expf(x); } };
 struct UnExp2 { __device__ static __forceinline__ float ap(float x, float) { return exp2f(x); } };
-struct UnLog { __device__ static __forceinline__ float ap(float x, float) { return log_f32_dev(x); } };
+struct UnLog {
+  __device__ static __forceinline__ float ap(float x, float) { return log_f32_dev(x); }
+  template <int N> __device__ static __forceinline__ void ap_rows(const float (&x)[N], float (&r)[N]) { log_f32_rows<N>(x, r); }
+};
 struct UnLog2 { __device__ static __forceinline__ float ap(float x, float) { return log2f(x); } };
 struct UnSin {
   __device__ static __forceinline__ float ap(float x, float) { return sincos_f32_dev<0>(x); }
@@ -468,6 +506,7 @@ struct UnCos {
 template <typename Op> struct EwRowsOp { static constexpr bool value = false; };
 template <> struct EwRowsOp<UnSin> { static constexpr bool value = true; };
 template <> struct EwRowsOp<UnCos> { static constexpr bool value = true; };
+template <> struct EwRowsOp<UnLog> { static constexpr bool value = true; };
 // … and converting functors (CvtThenF32 below) that have one: a static member `has_rows` = true and ap_rows<N>
 template <typename Conv, typename = void> struct ConvHasRows { static constexpr bool value = false; };
 template <typename Conv> struct ConvHasRows<Conv, std::enable_if_t<Conv::has_rows>> { static constexpr bool value = true; };
@@ -555,7 +594,7 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_prefetch_kernel(const float*
     t = tn;
   }
 }
-template <typename Op> struct EwPrefetch { static constexpr bool value = false; static constexpr int tiles = 1; static constexpr int id = 0; };
+template <typename Op> struct EwPrefetch { static constexpr bool value = false; static constexpr int tiles = 1; static constexpr int id = 0; static constexpr int family = AGPU_TILE_FAMILY_HEAVY; };
 #ifndef AGPU_CHAIN_HEAVY_LDS
 #define AGPU_CHAIN_HEAVY_LDS 1u  // chains with a transcendental step: no cap by default (1 byte), tuning wave_lds forces one (tools/probe/chain_caps.py)
 #endif
@@ -601,9 +640,12 @@ template <> struct EwWaveLds<UnSinh> { static constexpr unsigned value = AGPU_WA
 // round 6, the packed-f32 form (tools/probe/r06_sincos_sweep.py, two processes, tiles × cap): ≈ 16 waves per CU 0.84–0.85 of the roof, ≈ 24 0.81–0.84, none 0.76–0.79
 template <> struct EwWaveLds<UnSin> { static constexpr unsigned value = AGPU_WAVE_LDS_16; };
 template <> struct EwWaveLds<UnCos> { static constexpr unsigned value = AGPU_WAVE_LDS_16; };
-template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 1; };
-template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 2; };
-template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 3; };
+template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 1; static constexpr int family = AGPU_TILE_FAMILY_HEAVY; };
+template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 2; static constexpr int family = AGPU_TILE_FAMILY_HEAVY; };
+template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 3; static constexpr int family = AGPU_TILE_FAMILY_HEAVY; };
+// log (round 6: packed f32, no table — the generic tile kernel instead of a kernel of its own); its adaptive-tiles entries keep their own family
+template <> struct EwPrefetch<UnLog> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 0; static constexpr int family = AGPU_TILE_FAMILY_LOG; };
+template <> struct EwWaveLds<UnLog> { static constexpr unsigned value = AGPU_WAVE_LDS_16; };
 // Threads per block: one wave for everything.  (The LDS-table kernels pow / log run best at 256 threads × 1 pack, but
 // sin / cos / sinh lose 4–10 % in that shape and 5 % at 64 × 1: tools/probe/heavy_shape.py, profiles/r02_heavy_shape.txt.)
 #ifndef AGPU_EW_DEFAULT_BLK
@@ -642,7 +684,7 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
         int64_t k = p->tune.tiles > 0 ? p->tune.tiles : EwPrefetch<Op>::tiles;
         const bool shape_ok = (bits & 127u) == 0 && p->tune.stream_grid == 0;
         // auto: one or two tiles per block, whichever this device measures faster on these buffers (common.hpp, adaptive tiles)
-        if (p->tune.tiles <= 0 && shape_ok) k = (int64_t)agpu_tiles_pick(p, AGPU_TILE_FAMILY_HEAVY, EwPrefetch<Op>::id, a, out, 2 * sizeof(T) * n, &tile_sample);
+        if (p->tune.tiles <= 0 && shape_ok) k = (int64_t)agpu_tiles_pick(p, EwPrefetch<Op>::family, EwPrefetch<Op>::id, a, out, 2 * sizeof(T) * n, &tile_sample);
         if (k > 1 && shape_ok) {
           const int g = stream_grid_for(p, tile_units(ntiles, (uint64_t)k));
           hipLaunchKernelGGL((ew_prefetch_kernel<Op, U, AGPU_STREAM_NT>), dim3(g), dim3(AGPU_EW_BLOCK), wave_lds_for(p, EwWaveLds<Op>::value, 1), p->stream, pa, po, ntiles);
@@ -939,81 +981,6 @@ static agpu_status launch_pow_f32(agpu_pipeline* p, const void* a, const void* b
   return AGPU_OK;
 }
 
-// f32 log: the same tile shape as pow_kernel (256-thread workgroups, the 2 KiB table staged in LDS once per workgroup,
-// one pack per lane, one vote per wave and tile between the table form and the general form).
-__global__ __launch_bounds__(AGPU_BLOCK) void log_kernel(const float* a, float* out, uint64_t ntiles, const PowTab* gtab) {
-  constexpr int U = AGPU_POW_U;
-  constexpr uint64_t TILE_PACKS = (uint64_t)AGPU_BLOCK * U;
-  __shared__ PowTab tab[128];
-  const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
-  f32x4* o4 = reinterpret_cast<f32x4*>(out);
-  const TileRun run = tile_run(blockIdx.x, gridDim.x, ntiles);
-  const uint64_t ntiles_end = run.end;
-  uint64_t t = run.t;
-  f32x4 xa[U];
-  auto load_tile = [&](uint64_t tile) {
-    static_for<U>([&](auto u) { xa[u] = __builtin_nontemporal_load(a4 + tile * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
-  };
-  if (t < ntiles_end) load_tile(t);
-  if (threadIdx.x < 128) reinterpret_cast<u32x4*>(tab)[threadIdx.x] = reinterpret_cast<const u32x4*>(gtab)[threadIdx.x];
-  __syncthreads();
-  while (t < ntiles_end) {
-    const uint64_t p0 = t * TILE_PACKS + threadIdx.x;
-    // the next tile's loads go out BEFORE this tile is evaluated (tiles > 1): they ride under the arithmetic
-    const uint64_t tn = t + run.step;
-    f32x4 na[U];
-    if (tn < ntiles_end)
-      static_for<U>([&](auto u) { na[u] = __builtin_nontemporal_load(a4 + tn * TILE_PACKS + threadIdx.x + (uint64_t)u * AGPU_BLOCK); });
-    bool ok = true;
-    static_for<U>([&](auto u) { ok = ok && log_ordinary(xa[u].x) && log_ordinary(xa[u].y) && log_ordinary(xa[u].z) && log_ordinary(xa[u].w); });
-    if (__all(ok)) {
-      static_for<U>([&](auto u) {
-        const f32x4 r = f32x4{log_f32_fast(tab, xa[u].x), log_f32_fast(tab, xa[u].y), log_f32_fast(tab, xa[u].z), log_f32_fast(tab, xa[u].w)};
-        __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
-      });
-    } else {  // the table form for every lane (same bits as above; harmless on any bit pattern), then the general form
-              // over the lanes it does not apply to — negatives, NaN, 0 and inf leave that on its first branch
-      static_for<U>([&](auto u) {
-        f32x4 r = f32x4{log_f32_fast(tab, xa[u].x), log_f32_fast(tab, xa[u].y), log_f32_fast(tab, xa[u].z), log_f32_fast(tab, xa[u].w)};
-        if (!log_ordinary(xa[u].x)) r.x = log_f32_general(xa[u].x);
-        if (!log_ordinary(xa[u].y)) r.y = log_f32_general(xa[u].y);
-        if (!log_ordinary(xa[u].z)) r.z = log_f32_general(xa[u].z);
-        if (!log_ordinary(xa[u].w)) r.w = log_f32_general(xa[u].w);
-        __builtin_nontemporal_store(r, o4 + p0 + (uint64_t)u * AGPU_BLOCK);
-      });
-    }
-    if (tn < ntiles_end) static_for<U>([&](auto u) { xa[u] = na[u]; });
-    t = tn;
-  }
-}
-__global__ __launch_bounds__(AGPU_BLOCK) void log_tail_kernel(const float* a, float* out, uint64_t first, uint64_t n) {
-  for (uint64_t i = first + (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_BLOCK)
-    out[i] = log_f32_dev(a[i]);
-}
-static agpu_status launch_log_f32(agpu_pipeline* p, const void* a, void* out, uint64_t n) {
-  if (n == 0) return AGPU_OK;
-  const float* pa = static_cast<const float*>(a);
-  float* po = static_cast<float*>(out);
-  constexpr uint64_t TILE_ROWS = (uint64_t)AGPU_BLOCK * AGPU_POW_U * 4;
-  uint64_t done = 0;
-  if (aligned16(a) && aligned16(out)) {
-    const uint64_t ntiles = n / TILE_ROWS;
-    if (ntiles) {
-      agpu_tile_sample tile_sample;
-      const uint64_t tk = p->tune.tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LOG, 0, a, out, 8 * n, &tile_sample);
-      hipLaunchKernelGGL(log_kernel, dim3(stream_grid_for(p, tile_units(ntiles, tk))), dim3(AGPU_BLOCK), 0, p->stream, pa, po, ntiles,
-                         static_cast<const PowTab*>(p->dev->pow_table));
-      agpu_tiles_done(p, &tile_sample);
-      done = ntiles * TILE_ROWS;
-    }
-  }
-  if (done < n) {
-    const int grid = stream_grid_for(p, (n - done + AGPU_BLOCK - 1) / AGPU_BLOCK);
-    hipLaunchKernelGGL(log_tail_kernel, dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pa, po, done, n);
-  }
-  AGPU_LAUNCH_CHECK();
-  return AGPU_OK;
-}
 
 // ---------------------------------------------------------------- self-test of the f32 functions (agpu_selftest_unary_f32)
 // Every f32 bit pattern in [first, first + count) through the product's functor and through the f64 device library
@@ -1488,14 +1455,21 @@ struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders
     else return F::ap((float)x, 0.0f);
   }
   // several rows at a time: sin / cos evaluate row PAIRS in packed f32 (sincos_f32_pair); same bits as ap()
-  static constexpr bool has_rows = sizeof(TI) <= 2 && (std::is_same<F, UnSin>::value || std::is_same<F, UnCos>::value);
+  static constexpr bool has_rows = sizeof(TI) <= 2 && (std::is_same<F, UnSin>::value || std::is_same<F, UnCos>::value || std::is_same<F, UnLog>::value);
   template <int N> __device__ static __forceinline__ void ap_rows(const TI (&x)[N], float (&r)[N]) {
     static_assert(N % 2 == 0, "rows come in pairs");
+    if constexpr (std::is_same<F, UnLog>::value) {  // (zeros and negatives of the integer column take log's general form inside)
+      float xf[N];
 #pragma unroll
-    for (int k = 0; k < N; k += 2) {
-      const f32x2_t v = sincos_f32_pair<std::is_same<F, UnCos>::value ? 1 : 0>((f32x2_t){(float)x[k], (float)x[k + 1]});
-      r[k] = v.x;
-      r[k + 1] = v.y;
+      for (int k = 0; k < N; k++) xf[k] = (float)x[k];
+      log_f32_rows<N>(xf, r);
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; k += 2) {
+        const f32x2_t v = sincos_f32_pair<std::is_same<F, UnCos>::value ? 1 : 0>((f32x2_t){(float)x[k], (float)x[k + 1]});
+        r[k] = v.x;
+        r[k + 1] = v.y;
+      }
     }
   }
 };
@@ -2535,7 +2509,7 @@ agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, con
         case AGPU_UN_CBRT: UN_F32(UnCbrt);
         case AGPU_UN_EXP: UN_F32(UnExp);
         case AGPU_UN_EXP2: UN_F32(UnExp2);
-        case AGPU_UN_LOG: return launch_log_f32(p, in, out, n);  // (through ew_kernel with the table in global memory: 0.63 against 0.80)
+        case AGPU_UN_LOG: UN_F32(UnLog);
         case AGPU_UN_LOG2: UN_F32(UnLog2);
         case AGPU_UN_SIN: UN_F32(UnSin);
         case AGPU_UN_COS: UN_F32(UnCos);

@@ -97,7 +97,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "arrow_gpu_amd")
     for dp, _, fns in os.walk(pkg):
         for fn in fns:
-            if fn.endswith((".py", ".hip", ".hpp", ".h")):
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".inc")):
                 text = open(os.path.join(dp, fn)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f"{fn} imports the oracle"
                 assert "liboracle" not in text and "agpu_oracle" not in text.replace("oracle/agpu_oracle.c", ""), fn

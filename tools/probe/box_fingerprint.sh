@@ -30,7 +30,7 @@ me = Peer(); capi.call("agpu_device_identity", dev._handle, C.byref(me)); print(
 u8, g = dev.create_table_buffers([n, 4 * n])
 capi.call("agpu_synth_u8", h, C.c_void_p(u8.ptr), n, 6, 0); p.sync()
 def med(k):
-    p.set_tuning("cast_tiles", k)
+    p.set_tuning("tiles", k)
     f = lambda: capi.call("agpu_cast", h, capi.U8, capi.F32, C.c_void_p(u8.ptr), C.c_void_p(g.ptr), n)
     f(); f(); ts = []
     for _ in range(7):

@@ -25,7 +25,13 @@ def chain(*items):
 vp = lambda b: C.c_void_p(b.ptr)
 c_sin, n_sin = chain((capi.UN_SIN, 0, None))
 c_ms, n_ms = chain((capi.OP_MUL, 1, S), (capi.UN_SIN, 0, None))
-K = {"f32 sin": (8.0, lambda: capi.call("agpu_unary", h, capi.UN_SIN, capi.F32, vp(f), vp(g), n)),
+capi.call("agpu_synth_f32", h, C.c_void_p(g.ptr), n, 3, 0, C.c_float(0.001), C.c_float(1000.0)); p.sync()  # positive column for log
+fpos = dev.create_empty_buffer(4 * n)
+capi.call("agpu_synth_f32", h, C.c_void_p(fpos.ptr), n, 3, 0, C.c_float(0.001), C.c_float(1000.0)); p.sync()
+c_log, n_log = chain((capi.UN_LOG, 0, None))
+K = {"f32 log": (8.0, lambda: capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(fpos), vp(g), n)),
+     "cast u16 -> log": (6.0, lambda: capi.call("agpu_fused_cast_chain", h, capi.U16, vp(u16), C.cast(c_log, C.c_void_p), n_log, vp(g), n)),
+     "f32 sin": (8.0, lambda: capi.call("agpu_unary", h, capi.UN_SIN, capi.F32, vp(f), vp(g), n)),
      "f32 cos": (8.0, lambda: capi.call("agpu_unary", h, capi.UN_COS, capi.F32, vp(f), vp(g), n)),
      "(x*s).sin()": (8.0, lambda: capi.call("agpu_fused_chain", h, capi.F32, vp(f), C.cast(c_ms, C.c_void_p), n_ms, vp(g), n)),
      "cast i16 -> sin": (6.0, lambda: capi.call("agpu_fused_cast_chain", h, capi.I16, vp(u16), C.cast(c_sin, C.c_void_p), n_sin, vp(g), n)),
