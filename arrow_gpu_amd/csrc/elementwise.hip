@@ -645,7 +645,7 @@ template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; stati
 template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 3; static constexpr int family = AGPU_TILE_FAMILY_HEAVY; };
 // log (round 6: packed f32, no table — the generic tile kernel instead of a kernel of its own); its adaptive-tiles entries keep their own family
 template <> struct EwPrefetch<UnLog> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 0; static constexpr int family = AGPU_TILE_FAMILY_LOG; };
-template <> struct EwWaveLds<UnLog> { static constexpr unsigned value = AGPU_WAVE_LDS_16; };
+template <> struct EwWaveLds<UnLog> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };  // (tools/probe/r06_sincos_sweep.py: ≈ 24 waves 0.83–0.84, ≈ 16 0.77–0.78, no cap 0.79–0.83)
 // Threads per block: one wave for everything.  (The LDS-table kernels pow / log run best at 256 threads × 1 pack, but
 // sin / cos / sinh lose 4–10 % in that shape and 5 % at 64 × 1: tools/probe/heavy_shape.py, profiles/r02_heavy_shape.txt.)
 #ifndef AGPU_EW_DEFAULT_BLK
