@@ -28,7 +28,7 @@ struct agpu_tuning {
   int64_t gather_bucket;  // take/put: 0 = auto (size thresholds + the device-side locality probe), 1 = always direct, 2 = always bucketed, 4 = like 2 but with the probe (tests)
   int64_t h2d_mode;       // host↔device staging of agpu_import/export_arrow: 0 = auto, 1 = pageable hipMemcpy, 2 = threaded pinned staging, 3 = hipHostRegister in place
   int64_t tiles;          // tiles per block of the kernels that issue the NEXT tile's loads before they evaluate the current one — the VALU-heavy f32 unary
-                          // kernels, the widening casts and cast-headed chains, the LDS-table kernels (lut8 / trig16 / log / pow): 0 = auto (each kernel's default,
+                          // kernels, the widening casts and cast-headed chains, the LDS-table kernels (lut8 / pow): 0 = auto (each kernel's default,
                           // adaptive for big launches: tile_auto), > 0 = this many (round 6: one key instead of heavy_tiles / cast_tiles / table_tiles)
   int64_t tile_auto;      // 0 = the "auto" of `tiles` is ADAPTIVE for big launches (one or two tiles per block, whichever the device measures faster on these buffers: runtime.hip agpu_tiles_pick); 1 = static defaults (one tile); > 1 = adaptive with this many bytes as the threshold instead of 256 MiB (tests)
   int64_t wave_lds;       // unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the ×2 / ×4 widening casts and the 8-bit table kernels: 0 = each kernel's measured default (6800 B ≈ 24 waves per CU; sin / cos and the u8 → 32-bit casts 10240 B ≈ 16), < 0 = no cap, > 0 = this many bytes
@@ -78,10 +78,7 @@ struct agpu_device {
   // set when a deadline-aware collective wait gave up (comm.hip): a collective nobody will ever join is queued on some
   // stream, so nothing may wait for the device any more — calls fail fast, destroy calls leak, the process should exit
   std::atomic<bool> poisoned{false};
-  // 8 KiB of f64 {sin, cos} pairs for the 16-bit fused trig kernels (elementwise.hip: trig16_kernel), built once at
-  // device creation: [l] = sincos(l), [256 + h] = sincos(256·h), l, h ∈ 0..255
-  void* trig16_table = nullptr;
-  // 2 KiB of f64 {1/c, −log2(1/c)} pairs for f32 pow (elementwise.hip: pow_f32_dev); same allocation, + 8 KiB
+  // 2 KiB of f64 {1/c, −log2(1/c)} pairs for f32 pow (elementwise.hip: pow_f32_dev), built once at device creation
   void* pow_table = nullptr;
   // 6 KiB behind it: f32 results of sin / cos / sinh for every u8 and every i8 value, by the SAME device functions as the f32
   // kernels (identical bits), built once per device — a block copies its 1 KiB instead of evaluating 256 functions
@@ -182,15 +179,15 @@ struct agpu_device {
   TileEntry tile_tab[kTileEntries];
   uint64_t tile_clock = 0;
 };
-// Adaptive tiles per block (round 5).  The kernels that prefetch the next tile (ew_prefetch_kernel, cvt_wide_kernel, lut8_kernel, trig16_kernel,
-// log_kernel) run 3–7 % faster with TWO tiles per block in some processes and 5–9 % slower in others — it follows what the driver backed the
+// Adaptive tiles per block (round 5).  The kernels that prefetch the next tile (ew_prefetch_kernel, cvt_wide_kernel,
+// lut8_kernel) run 3–7 % faster with TWO tiles per block in some processes and 5–9 % slower in others — it follows what the driver backed the
 // buffers with (docs/experiments.md R4.1, R5.4), which no address a process can see predicts.  So the device MEASURES: for a launch whose
 // tiles-per-block tuning is 0 (auto) and that moves ≥ AGPU_TILE_AUTO_MIN_BYTES, the first eight launches per (kernel, size class, input
 // region, output region) alternate one and two tiles with a HIP event pair around each; with four samples of both the faster form (two tiles
 // must win by 2.5 % on the fastest sample of each: single samples scatter by ±2 %) is used from then on and re-measured every 1024 launches.  Results never depend on the tile count (tests/test_gpu_tile_auto.py,
 // the ABI fuzz draws the tunings at random).  Off: tuning tile_auto = 1, or any explicit tile count.
 #define AGPU_TILE_AUTO_MIN_BYTES ((uint64_t)256 << 20)
-enum { AGPU_TILE_FAMILY_HEAVY = 1, AGPU_TILE_FAMILY_CAST = 2, AGPU_TILE_FAMILY_LUT8 = 3, AGPU_TILE_FAMILY_TRIG16 = 4, AGPU_TILE_FAMILY_LOG = 5 };
+enum { AGPU_TILE_FAMILY_HEAVY = 1, AGPU_TILE_FAMILY_CAST = 2, AGPU_TILE_FAMILY_LUT8 = 3, AGPU_TILE_FAMILY_LOG = 5 };  // (4 was the 16-bit trig table kernel: gone in round 6)
 struct agpu_pipeline;
 struct agpu_tile_sample {
   int entry = -1, slot = -1;
@@ -205,8 +202,8 @@ agpu_status agpu_internal_bounce_copy(agpu_pipeline* p, void* dev_ptr, void* hos
 agpu_status agpu_internal_host_copy(agpu_pipeline* p, void* dev_ptr, void* host_ptr, size_t bytes, bool to_device);    // arrow_cdata.hip: complete on return
 // + 6 result tables of 256 f32 for the fused 8-bit kernels (elementwise.hip lut8_kernel): {u8, i8} × {sin, cos, sinh}
 #define AGPU_LUT8_TABLES 6
-#define AGPU_TABLE_BYTES (512 * 16 + 128 * 16 + AGPU_LUT8_TABLES * 256 * 4)
-agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table);  // elementwise.hip; synchronous
+#define AGPU_TABLE_BYTES (128 * 16 + AGPU_LUT8_TABLES * 256 * 4)
+agpu_status agpu_internal_build_tables(void* pow_table);  // elementwise.hip; synchronous
 agpu_status agpu_internal_fill_bytes(struct agpu_pipeline* p, void* out, uint32_t pattern, uint64_t bytes);  // elementwise.hip: fill_kernel, out 16-byte aligned
 
 struct agpu_pipeline {

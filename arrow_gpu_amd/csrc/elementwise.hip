@@ -22,8 +22,8 @@
 
 #include "common.hpp"
 
-// tiles per block for the kernels that stage a table in LDS (lut8, trig16, pow): tuning key "tiles"
-// tiles per block of the kernels that stage a table in LDS; `dflt` = the kernel's default: 1 for the HBM-bound ones (lut8, trig16, log,
+// tiles per block for the kernels that stage a table in LDS (lut8, pow): tuning key "tiles"
+// tiles per block of the kernels that stage a table in LDS; `dflt` = the kernel's default: 1 for the HBM-bound ones (lut8,
 // pow array ∘ array — see tile_run below), 3 for pow with a scalar exponent (launch_pow_f32)
 // A block that takes several tiles walks them A GRID APART (tile b, b + G, b + 2G …) and issues the next tile's loads before it
 // evaluates the current one.  What that buys was measured at length in round 4 (tools/probe/prefetch_sweep.py, prefetch_context.py,
@@ -1486,9 +1486,6 @@ struct CvtThenF32 {  // fused sin_u8-style kernels [trigonometry/compute_shaders
 // instructions: sin_u8 ran at 0.745 of the roof where the plain u8 → f32 cast ran at 0.79 on the same buffers) — it is built
 // once per device by lut8_build_kernel with the same device functions (agpu_device::lut8_tables) and a block copies its 1 KiB.
 #define AGPU_LUT8_BLOCK 128
-#ifndef AGPU_TRIG16_SC1
-#define AGPU_TRIG16_SC1 1  // sin_u16 / cos_i16: +1 % in 6 of 6 alternations (tools/archive/r05_sc1more.sh)
-#endif
 #ifndef AGPU_CCHAIN_SC1X4
 #define AGPU_CCHAIN_SC1X4 1  // cast(u8)·s+s: 0.78–0.81 → 0.80–0.815, same script
 #endif
@@ -1592,146 +1589,22 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
   return AGPU_OK;
 }
 
-// 16-bit sources (sin_u16 / cos_i16 …): 65 536 distinct inputs — too many for an LDS result table, and evaluating sin
-// per row is VALU-bound (4.6 TB/s of a 6 B/row stream).  The inputs are INTEGERS, so |x| = 256·h + l and
-//   sin x = sin(256h)·cos l + cos(256h)·sin l,   cos x = cos(256h)·cos l − sin(256h)·sin l
-// need two 16-byte LDS reads ({sin, cos} pairs in f64 — 8 KiB, copied per block from the table built once at device
-// creation) and three f64 operations, then ONE rounding to f32: |error| ≲ 2⁻⁵² absolute, and |sin n|, |cos n| ≥ 1e-6
-// for integer |n| ≤ 65 535, so the result is correctly rounded except in 1-in-10⁷-style ties (≤ 1 ULP always).
-struct alignas(16) SinCos64 {
-  double s, c;
-};
-__global__ void trig16_build_kernel(SinCos64* tab) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 512) return;
-  const double a = i < 256 ? (double)i : (double)((i - 256) * 256);
-  tab[i].s = sin(a);
-  tab[i].c = cos(a);
-}
+// 16-bit sources (sin_u16 / cos_i16 …): 65 536 distinct inputs — too many for an LDS result table.  Rounds 1–5 split the integer as
+// 256·h + l and combined two f64 {sin, cos} table entries per row (trig16_kernel: an 8 KiB LDS table per block, 0.74–0.78 of the roof, and
+// ≈ 65 of the 65 536 results 1 ULP away from what cast → sin gives).  With sin / cos in packed f32 (round 6) evaluating the function per row
+// is FASTER than the table — cvt_wide_kernel over CvtThenF32<TI, UnSin>: 0.79–0.81 — and the fused kernel is bit-identical to the unfused pair
+// by construction, so the table form is gone (launch_cvt below serves agpu_unary(SIN / COS, u16 / i16)).
 agpu_status agpu_internal_build_lut8(void* tables);
-agpu_status agpu_internal_build_tables(void* trig16_table, void* pow_table) {
+agpu_status agpu_internal_build_tables(void* pow_table) {
   {  // the 8-bit result tables live right behind the pow table (common.hpp AGPU_TABLE_BYTES)
     const agpu_status ls = agpu_internal_build_lut8(static_cast<char*>(pow_table) + 128 * 16);
     if (ls != AGPU_OK) return ls;
   }
-  hipLaunchKernelGGL(trig16_build_kernel, dim3(2), dim3(256), 0, nullptr, static_cast<SinCos64*>(trig16_table));
   hipLaunchKernelGGL(pow_build_kernel, dim3(1), dim3(128), 0, nullptr, static_cast<PowTab*>(pow_table));
   AGPU_HIP(hipGetLastError());
   AGPU_HIP(hipStreamSynchronize(nullptr));
   const PowTab* tp = static_cast<const PowTab*>(pow_table);  // this device's copy of the module gets this device's table
   AGPU_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_pow_tab), &tp, sizeof(tp), 0, hipMemcpyHostToDevice));
-  return AGPU_OK;
-}
-
-template <typename TI, int WANT_COS, typename TabPtr>
-__device__ __forceinline__ float trig16_eval(TabPtr tab, uint32_t raw16) {
-  const int v = (int)(TI)(uint16_t)raw16;  // sign- or zero-extends by the source type
-  const uint32_t a = (uint32_t)(v < 0 ? -v : v);
-  const SinCos64 L = tab[a & 255u], H = tab[256u + (a >> 8)];
-  double r;
-  if constexpr (WANT_COS) {
-    r = fma(H.c, L.c, -(H.s * L.s));
-  } else {
-    r = fma(H.s, L.c, H.c * L.s);
-    r = v < 0 ? -r : r;
-  }
-  return (float)r;
-}
-
-// 4096-row tiles per 256-thread block: every wave takes two contiguous 1 KiB chunks (512 rows each) with 16-byte loads and
-// transposes each inside the wave (ds_bpermute, as cvt_wide_kernel) so that both stores of a chunk are coalesced 1 KiB rows.
-// one chunk per wave and tile: two stores per lane (two chunks, i.e. four stores: 0.72 → 0.75 of the roof; a store stream
-// likes few stores per lane, tools/probe/store_probe.hip)
-#define AGPU_TRIG16_U 1
-#ifndef AGPU_TRIG16_BLOCK
-#define AGPU_TRIG16_BLOCK 512  // 256: 0.71 of the roof, 512: 0.73–0.74, 1024: 0.72–0.73 (tools/probe/narrow_tunings.py, AGPU_TRIG16_BLOCK env for the A/B)
-#endif
-template <typename TI, int WANT_COS, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trig16_kernel(const TI* in, float* out, uint64_t ntiles,
-                                                      const SinCos64* gtab) {
-  constexpr int U = AGPU_TRIG16_U;  // chunks per wave per tile
-  constexpr uint32_t WAVES = BLOCK / AGPU_WAVE;
-  __shared__ SinCos64 tab[512];
-  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
-  const u32x4* in16 = reinterpret_cast<const u32x4*>(in);
-  f32x4* out4 = reinterpret_cast<f32x4*>(out);
-  const TileRun run = tile_run(blockIdx.x, gridDim.x, ntiles);
-  const uint64_t ntiles_end = run.end;
-  uint64_t t = run.t;
-  u32x4 w[U];
-  if (t < ntiles_end)  // the first tile's loads go out before the table copy so the two latencies overlap
-    static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in16 + ((t * WAVES + wave) * U + (uint32_t)u) * AGPU_WAVE + lane); });
-  {
-    const u32x4* g = reinterpret_cast<const u32x4*>(gtab);
-    u32x4* l = reinterpret_cast<u32x4*>(tab);
-    for (uint32_t k = threadIdx.x; k < 512; k += BLOCK) l[k] = g[k];
-  }
-  __syncthreads();
-  while (t < ntiles_end) {
-    const uint64_t c0 = (t * WAVES + wave) * U;
-    u32x4 cur[U];
-    static_for<U>([&](auto u) { cur[u] = w[u]; });
-    t += run.step;
-    if (t < ntiles_end)
-      static_for<U>([&](auto u) { w[u] = __builtin_nontemporal_load(in16 + ((t * WAVES + wave) * U + (uint32_t)u) * AGPU_WAVE + lane); });
-    static_for<U>([&](auto u) {
-      static_for<2>([&](auto j) {
-        const int src = (int)(((uint32_t)j * 32u + (lane >> 1)) * 4u);
-        const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur[u].x);
-        const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur[u].y);
-        const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur[u].z);
-        const uint32_t w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)cur[u].w);
-        const bool hi = (lane & 1u) != 0;
-        const uint32_t x = hi ? w2 : w0, y = hi ? w3 : w1;
-        f32x4 r = {trig16_eval<TI, WANT_COS>(tab, x & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, x >> 16),
-                   trig16_eval<TI, WANT_COS>(tab, y & 0xFFFFu), trig16_eval<TI, WANT_COS>(tab, y >> 16)};
-#if AGPU_TRIG16_SC1 && AGPU_USE_SC1
-        st_vec_sc1(out4 + (c0 + (uint32_t)u) * (AGPU_WAVE * 2) + (uint32_t)j * AGPU_WAVE + lane, r);
-#else
-        __builtin_nontemporal_store(r, out4 + (c0 + (uint32_t)u) * (AGPU_WAVE * 2) + (uint32_t)j * AGPU_WAVE + lane);
-#endif
-      });
-    });
-  }
-}
-// rows [first, n), one per lane, same arithmetic straight from the global table (tails and unaligned columns)
-template <typename TI, int WANT_COS>
-__global__ __launch_bounds__(AGPU_BLOCK) void trig16_tail_kernel(const TI* in, float* out, uint64_t first, uint64_t n,
-                                                                const SinCos64* gtab) {
-  for (uint64_t i = first + (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * AGPU_BLOCK)
-    out[i] = trig16_eval<TI, WANT_COS>(gtab, (uint32_t)(uint16_t)in[i]);
-}
-
-template <typename TI, int WANT_COS>
-static agpu_status launch_trig16(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
-  static_assert(sizeof(TI) == 2, "16-bit sources only");
-  if (n == 0) return AGPU_OK;
-  // the 8 KiB table is copied into LDS by every block: with 256-thread blocks (2048-row tiles) that is 4 B/row of L2 → LDS
-  // traffic beside the 6 B/row of the stream; bigger blocks keep the two stores per lane and pay the copy once per 4096 / 8192 rows
-  static const int blk = [] { const char* e = getenv("AGPU_TRIG16_BLOCK"); const int v = e ? atoi(e) : 0; return v == 256 || v == 512 || v == 1024 ? v : AGPU_TRIG16_BLOCK; }();
-  const uint64_t TILE_ROWS = (uint64_t)blk * 8 * AGPU_TRIG16_U;
-  const TI* pi = static_cast<const TI*>(in);
-  float* po = static_cast<float*>(out);
-  const SinCos64* tab = static_cast<const SinCos64*>(p->dev->trig16_table);
-  uint64_t done = 0;
-  if (aligned16(in) && aligned16(out)) {
-    const uint64_t ntiles = n / TILE_ROWS;
-    if (ntiles) {
-      agpu_tile_sample tile_sample;
-      const uint64_t tk = p->tune.tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_TRIG16, 0, in, out, 6 * n, &tile_sample);
-      const dim3 grid(stream_grid_for(p, tile_units(ntiles, tk)));
-      if (blk == 1024) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 1024>), grid, dim3(1024), 0, p->stream, pi, po, ntiles, tab);
-      else if (blk == 512) hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 512>), grid, dim3(512), 0, p->stream, pi, po, ntiles, tab);
-      else hipLaunchKernelGGL((trig16_kernel<TI, WANT_COS, 256>), grid, dim3(256), 0, p->stream, pi, po, ntiles, tab);
-      agpu_tiles_done(p, &tile_sample);
-      done = ntiles * TILE_ROWS;
-    }
-  }
-  if (done < n) {
-    const int grid = stream_grid_for(p, (n - done + AGPU_BLOCK - 1) / AGPU_BLOCK);
-    hipLaunchKernelGGL((trig16_tail_kernel<TI, WANT_COS>), dim3(grid), dim3(AGPU_BLOCK), 0, p->stream, pi, po, done, n, tab);
-  }
-  AGPU_LAUNCH_CHECK();
   return AGPU_OK;
 }
 
@@ -2495,8 +2368,8 @@ agpu_status agpu_unary(agpu_pipeline* p, agpu_unary_op op, agpu_dtype dtype, con
   }
 #define UN_FUSED(T)                                                                          \
   switch (op) {                                                                              \
-    case AGPU_UN_SIN: return launch_trig16<T, 0>(p, in, out, n);                             \
-    case AGPU_UN_COS: return launch_trig16<T, 1>(p, in, out, n);                             \
+    case AGPU_UN_SIN: return launch_cvt<T, float, CvtThenF32<T, UnSin>>(p, in, out, n);      \
+    case AGPU_UN_COS: return launch_cvt<T, float, CvtThenF32<T, UnCos>>(p, in, out, n);      \
     case AGPU_UN_SINH: return launch_cvt<T, float, CvtThenF32<T, UnSinh>>(p, in, out, n);    \
     default: break;                                                                          \
   }

@@ -211,15 +211,14 @@ agpu_status agpu_device_create(int32_t ordinal, agpu_device** out_device) {
         agpu_set_error("hipMalloc of the function tables failed: %s", hipGetErrorString(me));
         return AGPU_ERR_HIP;
       }
-      agpu_status ts = agpu_internal_build_tables(t, static_cast<char*>(t) + 512 * 16);
+      agpu_status ts = agpu_internal_build_tables(t);
       if (ts != AGPU_OK) {
         (void)hipFree(t);
         return ts;
       }
       tab_of[slot] = t;
     }
-    d->trig16_table = tab_of[slot];
-    d->pow_table = static_cast<char*>(d->trig16_table) + 512 * 16;
+    d->pow_table = tab_of[slot];
     d->lut8_tables = static_cast<char*>(d->pow_table) + 128 * 16;
   }
   d->cache_cap = d->props.totalGlobalMem / 2;  // cached (idle) blocks never hold more than half of HBM

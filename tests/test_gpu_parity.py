@@ -775,7 +775,7 @@ def test_width_changing_casts_on_slices_and_chunk_boundaries(D, frm, to):
 @pytest.mark.parametrize("dtype", [capi.U8, capi.I8, capi.U16, capi.I16])
 @pytest.mark.parametrize("op", [capi.UN_SIN, capi.UN_COS])
 def test_fused_small_int_trig_on_slices(D, dtype, op):
-    """lut8_kernel / trig16_kernel in the wave-transposed form: 16-byte loads, so slices that start at any element and
+    """lut8_kernel / the 16-bit cast-then-function kernel (cvt_wide_kernel) in the wave-transposed form: 16-byte loads, so slices that start at any element and
     ragged sizes take the tail kernels — identical bits."""
     w = NP[dtype]().itemsize
     base = rand_values(dtype, 40_000, 9)

@@ -54,7 +54,6 @@ LAUNCHES = {
     "cast": ("tiles", lambda h, u8, f, out: capi.call("agpu_cast", h, capi.U8, capi.F32, vp(u8), vp(out), N)),
     "heavy": ("tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_SIN, capi.F32, vp(f), vp(out), N)),
     "lut8": ("tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_COS, capi.U8, vp(u8), vp(out), N)),
-    "trig16": ("tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_SIN, capi.I16, vp(u8), vp(out), N)),
     "log": ("tiles", lambda h, u8, f, out: capi.call("agpu_unary", h, capi.UN_LOG, capi.F32, vp(f), vp(out), N)),
 }
 
