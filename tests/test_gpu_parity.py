@@ -236,7 +236,7 @@ def test_f32_functions_exhaustive_over_all_bit_patterns(D, op, name):
 def test_f32_trig_exhaustive_against_the_cpu_oracle():
     """ALL 2^32 bit patterns through agpu_unary against the CPU ORACLE (f64 libm rounded once) — not the device's own f64 library:
     tests/tools/exhaustive_vs_oracle.py in a fresh process (its oracle workers are forked before that process touches the GPU).
-    sin, cos (BASELINE config 4) and the reference's f32 → u8 cast (bit-exact) by default, ≈ 30 s; AGPU_EXHAUSTIVE=1: all ten functions,
+    sin, cos (BASELINE config 4), log and the reference's f32 → u8 cast (bit-exact) by default, ≈ 40 s; AGPU_EXHAUSTIVE=1: all ten functions,
     pow on 2^30 pairs and the six f32 → integer casts (profiles/r03_exhaustive_vs_oracle.json)."""
     import json
     import os
@@ -244,7 +244,7 @@ def test_f32_trig_exhaustive_against_the_cpu_oracle():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    names = [] if os.environ.get("AGPU_EXHAUSTIVE") == "1" else ["sin", "cos", "cast_f32_u8"]
+    names = [] if os.environ.get("AGPU_EXHAUSTIVE") == "1" else ["sin", "cos", "log", "cast_f32_u8"]  # sin / cos / log: the packed-f32 forms of round 6
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "exhaustive_vs_oracle.py")] + names, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     res = json.load(open(os.path.join(root, "gpurun_out", "r03_exhaustive_vs_oracle.json")))["functions"]
