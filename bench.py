@@ -26,10 +26,16 @@ Also printed in the same JSON line:
                  MEASURED in this run (N = 1): two child `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE) over a
                  short run of the same workload after the timed region (≈ 6 s; falls back to profiles/hbm_traffic.json
                  and says so when rocprofv3 is not usable).
+                 frac_per_rank = the slowest and the fastest rank's launch of the same kernel.
   cpu_baseline — the CPU port (oracle/cpu_baseline.c, arrow-rs-style single pass) timed on this box's host cores on
-                 a bounded sample (rank 0, N=1 only), a pyarrow (Arrow C++) sanity line, and `gpu_parity`: windows of
-                 the benchmarked GPU outputs checked bit-exact against the oracle.  This leg is the only place the
-                 oracle is imported; the measured path never touches it.
+                 a bounded sample (rank 0, at every world size), a pyarrow (Arrow C++) sanity line, and `gpu_parity`.
+  gpu_parity   — EVERY rank downloads three 65 536-row windows of its shard of the benchmarked outputs and checks them bit-exact
+                 against the oracle at its own row0; the verdicts are summed over the ranks through the communicator.  Likewise
+                 extra.reduce_sum_min_max.verified: what the collectives left on every rank against the oracle's rank-ordered
+                 combine of the gathered per-rank local statistics.  A line of any world size proves its own numbers.
+  config.host_api — the fractions of the roof of the same two kernels as an ordinary caller of the host API gets them (inputs allocated one
+                 by one, the op allocates its output): extra.layout_pool.
+The oracle is imported only by these checks and the CPU leg, AFTER the timed region; the measured path never touches it.
 """
 from __future__ import annotations
 

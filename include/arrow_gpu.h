@@ -303,7 +303,9 @@ agpu_status agpu_scalar(agpu_pipeline* p, agpu_binary_op op, agpu_dtype dtype, c
                         void* out, uint64_t n);
 
 /* out[i] = op(in[i]).  Output dtype = input dtype, except SIN/COS/SINH on u8/i8/u16/i16 which write f32[n]
- * (the reference's fused sin_u8-style kernels).
+ * (the reference's fused sin_u8-style kernels) — every one of them bit-identical to the cast followed by the f32 function.
+ * Accuracy of the f32 transcendentals: within 1 ULP of f64 libm rounded once on EVERY bit pattern (SIN / COS / LOG are evaluated in
+ * packed f32 since round 6 and proven exhaustively; the reference pins them to 0.01 absolute only).
  * [ref: apply_unary_function compute_pipeline.rs:24-66 as called by Neg arithmetic_kernels.rs:270-319, bitwise_not
  *  logical/src/lib.rs:135-158, apply_unary_function_op! crates/math/src/lib.rs:138-193 and
  *  crates/trigonometry/src/lib.rs:85-137]. */

@@ -14,7 +14,7 @@ echo "smoke rc=$?" | tee -a gpurun_out/r06_smoke.log
 timeout 900 python bench.py > gpurun_out/r06_bench_plain.json 2> gpurun_out/r06_bench_plain.err
 echo "bench rc=$?"
 for i in 1 2 3 4 5; do timeout 600 python bench.py --no-traffic > gpurun_out/r06_bench_repeat_$i.json 2> gpurun_out/r06_bench_repeat_$i.err; done
-timeout 1500 python tests/tools/exhaustive_vs_oracle.py sin cos > gpurun_out/r06_exhaustive.log 2>&1
+timeout 1500 python tests/tools/exhaustive_vs_oracle.py log sin cos > gpurun_out/r06_exhaustive.log 2>&1
 echo "exhaustive rc=$?"; cp gpurun_out/r03_exhaustive_vs_oracle.json gpurun_out/r06_exhaustive_sincos.json
 timeout 1500 bash tools/profile_bench.sh r06 5 > gpurun_out/r06_profile_bench.log 2>&1
 echo "profile_bench rc=$?"
