@@ -251,3 +251,36 @@ def test_device_waits_from_every_thread_while_pipelines_come_and_go(dev):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_device_wait_covers_foreign_work_on_a_stream_whose_handle_was_handed_out(dev):
+    """the device-level waits skip owned streams with no ABI call since their last completed wait.  A stream whose raw handle was
+    handed out (agpu_pipeline_stream) may carry work the library never saw: it must be waited for EVERY time.  Here: a pipeline is drained,
+    its handle taken, a 2 GiB hipMemsetAsync queued on it behind the library's back — agpu_device_download of the buffer's last bytes must
+    see the new value (before the fix the stream counted as empty and the bytes came back stale), and with sync_spin < 0 agpu_device_sync
+    calls the runtime's wait whatever the counters say."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    hip.hipMemsetAsync.restype = C.c_int
+    n = 2 << 30
+    p = ArrowComputePipeline(dev, "exposed")
+    buf = dev.create_empty_buffer(n)
+    for round_, spin in enumerate((0, -1)):
+        capi.call("agpu_set_tuning", b"sync_spin", spin)
+        try:
+            capi.call("agpu_memset", p._handle, C.c_void_p(buf.ptr), 0x11 + round_, n)
+            p.sync()
+            dev.sync()  # everything this library queued is through and KNOWN to be: the stream counts as drained
+            stream = p.stream()  # … and from here on as carrying foreign work
+            assert hip.hipMemsetAsync(C.c_void_p(buf.ptr), 0x77 + round_, n, C.c_void_p(stream)) == 0
+            if spin < 0:
+                dev.sync()
+                got = np.empty(64, np.uint8)
+                capi.call("agpu_download", p._handle, C.c_void_p(got.ctypes.data), C.c_void_p(buf.ptr + n - 64), 64)
+            else:
+                got = np.empty(64, np.uint8)
+                capi.call("agpu_device_download", dev._handle, C.c_void_p(got.ctypes.data), C.c_void_p(buf.ptr + n - 64), 64)
+            assert (got == 0x77 + round_).all(), (spin, got[:8])
+        finally:
+            capi.call("agpu_set_tuning", b"sync_spin", 0)
+    p.sync()
