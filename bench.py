@@ -457,7 +457,7 @@ def main():
         # the processes runs for real and its init then refuses the duplicate device — a clean failure, never a measurement
         local_rank = int(os.environ["AGPU_BENCH_DEVICE_OVERRIDE"])
     dev = GpuDevice(local_rank)  # ArrowErrorGPU(NoDevice) without an MI355X: the HIP path has no CPU fallback
-    p = ArrowComputePipeline(dev, "bench")
+    p = ArrowComputePipeline(dev, "bench", fuse=False)  # (AGPU_FUSE=1 in the environment must not turn the timed ops into recordings)
     h = p._handle
     # the same communicator code path at every world size (world 1 = a one-rank RCCL communicator): init, barrier,
     # all-reduce are exercised on a single-GPU box too
