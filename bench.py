@@ -461,6 +461,9 @@ def main():
     h = p._handle
     # the same communicator code path at every world size (world 1 = a one-rank RCCL communicator): init, barrier,
     # all-reduce are exercised on a single-GPU box too
+    # this process is the bench's own: the loopback bootstrap may stay in its environment for good (the library itself only sets it for the
+    # duration of a rendezvous — sharding.loopback_bootstrap — so that it never leaks into another RCCL user of a host process)
+    sharding.prefer_loopback_bootstrap(world)
     comm = sharding.Communicator.from_env(dev, timeout_s=args.rendezvous_timeout)
     runtime = sharding.Communicator.runtime_info()
     # ---- what the line may claim as n_gpus is what RCCL says, proven by one identity record per rank gathered THROUGH the
