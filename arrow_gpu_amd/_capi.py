@@ -52,7 +52,6 @@ SIGNATURES = {
     "agpu_device_trim": [_vp],
     "agpu_device_pool_info": [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)],
     "agpu_device_small_pool_info": [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)],
-    "agpu_device_tile_auto_info": [_vp, C.c_char_p, _sz],
     "agpu_malloc": [_vp, _sz, _i32, _pp],
     "agpu_malloc_like": [_vp, _sz, _i32, _pp, _i32, _pp],
     "agpu_free": [_vp, _vp],

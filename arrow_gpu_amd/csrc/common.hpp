@@ -28,13 +28,13 @@ struct agpu_tuning {
   int64_t gather_bucket;  // take/put: 0 = auto (size thresholds + the device-side locality probe), 1 = always direct, 2 = always bucketed, 4 = like 2 but with the probe (tests)
   int64_t h2d_mode;       // host↔device staging of agpu_import/export_arrow: 0 = auto, 1 = pageable hipMemcpy, 2 = threaded pinned staging, 3 = hipHostRegister in place
   int64_t tiles;          // tiles per block of the kernels that issue the NEXT tile's loads before they evaluate the current one — the VALU-heavy f32 unary
-                          // kernels, the widening casts and cast-headed chains, the LDS-table kernels (lut8 / pow): 0 = auto (each kernel's default,
-                          // adaptive for big launches: tile_auto), > 0 = this many (round 6: one key instead of heavy_tiles / cast_tiles / table_tiles)
-  int64_t tile_auto;      // 0 = the "auto" of `tiles` is ADAPTIVE for big launches (one or two tiles per block, whichever the device measures faster on these buffers: runtime.hip agpu_tiles_pick); 1 = static defaults (one tile); > 1 = adaptive with this many bytes as the threshold instead of 256 MiB (tests)
+                          // kernels, the widening casts and cast-headed chains, the LDS-table kernels (lut8 / pow): 0 = each kernel's static default (one; log two; pow
+                          // with a scalar exponent three; cast-headed chains with a transcendental step four), > 0 = this many (round 6: one key instead of heavy_tiles /
+                          // cast_tiles / table_tiles, and no adaptive policy behind "auto" any more: docs/experiments.md R6.9)
   int64_t wave_lds;       // unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the ×2 / ×4 widening casts and the 8-bit table kernels: 0 = each kernel's measured default (6800 B ≈ 24 waves per CU; sin / cos and the u8 → 32-bit casts 10240 B ≈ 16), < 0 = no cap, > 0 = this many bytes
   int64_t sync_spin;      // agpu_pipeline_sync and uploads / downloads of ≤ 3840 bytes wait for a kernel that posts into the pipeline's pinned mailbox instead of hipStreamSynchronize (12 → 7 µs for "one kernel, one scalar back"): 0 = yes, spinning for at most 200 µs before the blocking wait; > 0 = this many µs; < 0 = off
 };
-#define AGPU_TUNE_KEYS 8
+#define AGPU_TUNE_KEYS 7
 agpu_tuning agpu_tuning_defaults();  // snapshot of the process-wide defaults (atomics, runtime.hip)
 bool agpu_mem_pool_enabled();        // process-wide "mem_pool" switch (device-level behaviour, not per pipeline)
 
@@ -153,47 +153,8 @@ struct agpu_device {
   // from two host threads do not serialise
   std::mutex bounce_mu[2];
   StageSlot bounce[2] = {{nullptr, nullptr, false}, {nullptr, nullptr, false}};
-  // ---- adaptive tiles per block (runtime.hip agpu_tiles_pick).  Guarded by tile_mu.
-  struct TileSlot {  // one timed launch
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    uint8_t variant = 0;  // 0 = one tile per block, 1 = two
-    bool busy = false;     // handed to a launch (agpu_tiles_pick) and not yet harvested: nobody else may take it
-    bool pending = false;  // its stop event is on the stream
-    double bytes = 0;
-  };
-  struct TileEntry {
-    bool live = false;
-    uint16_t family = 0;  // AGPU_TILE_FAMILY_* << 8 | the kernel inside the family (sin ≠ sinh: their answers differ)
-    uint8_t lg_bytes = 0;
-    uint64_t in_region = 0, out_region = 0;  // pointers >> 28: the answer follows what the driver backed the buffers with
-    uint8_t choice = 0;                      // 0 = still measuring, 1 / 2 = tiles per block
-    uint8_t current = 1;                     // what launches use while measuring (the last decision, one tile at first)
-    uint8_t n[2] = {0, 0}, issued[2] = {0, 0};
-    double best[2] = {0, 0};                 // fastest sample, ns per byte
-    uint32_t launches = 0;                   // since the last decision
-    uint64_t last_use = 0;
-    TileSlot slot[8];
-  };
-  static constexpr int kTileEntries = 32;
-  std::mutex tile_mu;
-  TileEntry tile_tab[kTileEntries];
-  uint64_t tile_clock = 0;
 };
-// Adaptive tiles per block (round 5).  The kernels that prefetch the next tile (ew_prefetch_kernel, cvt_wide_kernel,
-// lut8_kernel) run 3–7 % faster with TWO tiles per block in some processes and 5–9 % slower in others — it follows what the driver backed the
-// buffers with (docs/experiments.md R4.1, R5.4), which no address a process can see predicts.  So the device MEASURES: for a launch whose
-// tiles-per-block tuning is 0 (auto) and that moves ≥ AGPU_TILE_AUTO_MIN_BYTES, the first eight launches per (kernel, size class, input
-// region, output region) alternate one and two tiles with a HIP event pair around each; with four samples of both the faster form (two tiles
-// must win by 2.5 % on the fastest sample of each: single samples scatter by ±2 %) is used from then on and re-measured every 1024 launches.  Results never depend on the tile count (tests/test_gpu_tile_auto.py,
-// the ABI fuzz draws the tunings at random).  Off: tuning tile_auto = 1, or any explicit tile count.
-#define AGPU_TILE_AUTO_MIN_BYTES ((uint64_t)256 << 20)
-enum { AGPU_TILE_FAMILY_HEAVY = 1, AGPU_TILE_FAMILY_CAST = 2, AGPU_TILE_FAMILY_LUT8 = 3, AGPU_TILE_FAMILY_LOG = 5 };  // (4 was the 16-bit trig table kernel: gone in round 6)
 struct agpu_pipeline;
-struct agpu_tile_sample {
-  int entry = -1, slot = -1;
-};
-uint64_t agpu_tiles_pick(agpu_pipeline* p, int family, int kernel, const void* in, const void* out, uint64_t bytes, agpu_tile_sample* sample);  // 1 or 2
-void agpu_tiles_done(agpu_pipeline* p, agpu_tile_sample* sample);
 #define AGPU_STAGE_CHUNK ((size_t)4 << 20)
 void agpu_internal_free_staging(agpu_device* dev);  // arrow_cdata.hip
 #define AGPU_BOUNCE_MAX_BYTES ((size_t)4 << 20)  // = one stage slot

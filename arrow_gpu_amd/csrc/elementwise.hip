@@ -594,7 +594,7 @@ __global__ __launch_bounds__(AGPU_EW_BLOCK) void ew_prefetch_kernel(const float*
     t = tn;
   }
 }
-template <typename Op> struct EwPrefetch { static constexpr bool value = false; static constexpr int tiles = 1; static constexpr int id = 0; static constexpr int family = AGPU_TILE_FAMILY_HEAVY; };
+template <typename Op> struct EwPrefetch { static constexpr bool value = false; static constexpr int tiles = 1; };
 #ifndef AGPU_CHAIN_HEAVY_LDS
 #define AGPU_CHAIN_HEAVY_LDS 1u  // chains with a transcendental step: no cap by default (1 byte), tuning wave_lds forces one (tools/probe/chain_caps.py)
 #endif
@@ -640,11 +640,12 @@ template <> struct EwWaveLds<UnSinh> { static constexpr unsigned value = AGPU_WA
 // round 6, the packed-f32 form (tools/probe/r06_sincos_sweep.py, two processes, tiles × cap): ≈ 16 waves per CU 0.84–0.85 of the roof, ≈ 24 0.81–0.84, none 0.76–0.79
 template <> struct EwWaveLds<UnSin> { static constexpr unsigned value = AGPU_WAVE_LDS_16; };
 template <> struct EwWaveLds<UnCos> { static constexpr unsigned value = AGPU_WAVE_LDS_16; };
-template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 1; static constexpr int family = AGPU_TILE_FAMILY_HEAVY; };
-template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 2; static constexpr int family = AGPU_TILE_FAMILY_HEAVY; };
-template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 3; static constexpr int family = AGPU_TILE_FAMILY_HEAVY; };
-// log (round 6: packed f32, no table — the generic tile kernel instead of a kernel of its own); its adaptive-tiles entries keep their own family
-template <> struct EwPrefetch<UnLog> { static constexpr bool value = true; static constexpr int tiles = 1; static constexpr int id = 0; static constexpr int family = AGPU_TILE_FAMILY_LOG; };
+template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; };
+template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; };
+template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; };
+// log (round 6: packed f32, no table — the generic tile kernel instead of a kernel of its own).  Two tiles per block: 0.83–0.84 against 0.83 on an
+// ordinary column, +7 % on a column whose rows half take the general form (tools/probe/r06_sincos_sweep.py; profiles/r06_kernel_table.json tile_auto)
+template <> struct EwPrefetch<UnLog> { static constexpr bool value = true; static constexpr int tiles = 2; };
 template <> struct EwWaveLds<UnLog> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };  // (tools/probe/r06_sincos_sweep.py: ≈ 24 waves 0.83–0.84, ≈ 16 0.77–0.78, no cap 0.79–0.83)
 // Threads per block: one wave for everything.  (The LDS-table kernels pow / log run best at 256 threads × 1 pack, but
 // sin / cos / sinh lose 4–10 % in that shape and 5 % at 64 × 1: tools/probe/heavy_shape.py, profiles/r02_heavy_shape.txt.)
@@ -679,12 +680,9 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
       const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(out) |
                              (MODE == MODE_BINARY ? reinterpret_cast<uintptr_t>(b) : 0);
       bool done = false;
-      agpu_tile_sample tile_sample;
       if constexpr (EwPrefetch<Op>::value && MODE == MODE_UNARY && std::is_same<T, float>::value && BLK == AGPU_EW_BLOCK) {
-        int64_t k = p->tune.tiles > 0 ? p->tune.tiles : EwPrefetch<Op>::tiles;
+        const int64_t k = p->tune.tiles > 0 ? p->tune.tiles : EwPrefetch<Op>::tiles;  // static defaults since round 6 (the adaptive policy of round 5 decided "one" everywhere)
         const bool shape_ok = (bits & 127u) == 0 && p->tune.stream_grid == 0;
-        // auto: one or two tiles per block, whichever this device measures faster on these buffers (common.hpp, adaptive tiles)
-        if (p->tune.tiles <= 0 && shape_ok) k = (int64_t)agpu_tiles_pick(p, EwPrefetch<Op>::family, EwPrefetch<Op>::id, a, out, 2 * sizeof(T) * n, &tile_sample);
         if (k > 1 && shape_ok) {
           const int g = stream_grid_for(p, tile_units(ntiles, (uint64_t)k));
           hipLaunchKernelGGL((ew_prefetch_kernel<Op, U, AGPU_STREAM_NT>), dim3(g), dim3(AGPU_EW_BLOCK), wave_lds_for(p, EwWaveLds<Op>::value, 1), p->stream, pa, po, ntiles);
@@ -697,7 +695,6 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
                            EwWaveLds<Op>::value ? wave_lds_for(p, EwWaveLds<Op>::value, BLK / AGPU_WAVE) : 0u, p->stream, pa, pb, po, ntiles);
       else
         hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, 4, BLK>), dim3(grid), dim3(BLK), 0, p->stream, pa, pb, po, ntiles);
-      agpu_tiles_done(p, &tile_sample);
     }
     if (ntiles * tile_rows < n)
       hipLaunchKernelGGL((ew_tail_kernel<T, Op, MODE>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
@@ -1336,14 +1333,6 @@ __global__ __launch_bounds__(AGPU_WAVE) void cvt_narrow_kernel(const TI* in, TO*
   }
 }
 
-// one small id per instantiation of the widening kernel: the adaptive tile policy keys its table by it (a plain cast and a cast fused with
-// sin want different answers)
-static std::atomic<int> g_cvt_tile_ids{0};
-template <typename TI, typename TO, typename Conv>
-static int cvt_tile_id() {
-  static const int id = (g_cvt_tile_ids.fetch_add(1) % 255) + 1;
-  return id;
-}
 template <typename TI, typename TO, typename Conv>
 static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint64_t n) {
   if (n == 0) return AGPU_OK;
@@ -1356,9 +1345,7 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
       const uint64_t nchunks = n / chunk_rows;
       if (nchunks) {
         // chunks per wave (next chunk prefetched): 1 by default — 2 is +5 % in lucky allocations and −8 % in others (tile_run above)
-        agpu_tile_sample tile_sample;
-        const uint64_t k = p->tune.tiles > 0 ? (uint64_t)p->tune.tiles
-                                                  : agpu_tiles_pick(p, AGPU_TILE_FAMILY_CAST, cvt_tile_id<TI, TO, Conv>(), in, out, (sizeof(TI) + sizeof(TO)) * n, &tile_sample);
+        const uint64_t k = p->tune.tiles > 0 ? (uint64_t)p->tune.tiles : 1;
         const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
         const int grid = stream_grid_for(p, (blocks + k - 1) / k);
         // occupancy cap (common.hpp): ×2 casts to 32 bits ≈ 24 waves per CU, ×4 ≈ 16; u8 → u16 none (not measured to gain)
@@ -1369,7 +1356,6 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
           hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv, true>), dim3(grid), dim3(AGPU_CVTW_BLOCK), lds, p->stream, pi, po, nchunks);
         else
           hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv, false>), dim3(grid), dim3(AGPU_CVTW_BLOCK), lds, p->stream, pi, po, nchunks);
-        agpu_tiles_done(p, &tile_sample);
       }
       if (nchunks * chunk_rows < n)
         hipLaunchKernelGGL((cvt_tail_kernel<TI, TO, Conv>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pi, po,
@@ -1569,12 +1555,10 @@ static agpu_status launch_lut8(agpu_pipeline* p, const void* in, void* out, uint
   if (aligned16(in) && aligned16(out)) {
     const uint64_t ntiles = n / TILE_ROWS;
     if (ntiles) {
-      agpu_tile_sample tile_sample;
-      const uint64_t tk = p->tune.tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
+      const uint64_t tk = tab_k(p);
       const int grid = stream_grid_for(p, tile_units(ntiles, tk));
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), wave_lds_for(p, AGPU_WAVE_LDS_24, AGPU_LUT8_BLOCK / AGPU_WAVE), p->stream, pi, po, ntiles,
                          static_cast<const float*>(p->dev->lut8_tables) + 256 * Lut8Slot<TI, F>::value);
-      agpu_tiles_done(p, &tile_sample);
       done = ntiles * TILE_ROWS;
     }
     if (done < n)
@@ -2167,12 +2151,10 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
       if (st != AGPU_OK) return st;
       hipLaunchKernelGGL((lut8_chain_build_kernel<TI>), dim3(1), dim3(256), 0, p->stream, static_cast<float*>(tab), n_steps, code, ptrs);
       const uint64_t ntiles = n / TILE_ROWS;
-      agpu_tile_sample tile_sample;
-      const uint64_t tk = p->tune.tiles > 0 ? tab_k(p) : agpu_tiles_pick(p, AGPU_TILE_FAMILY_LUT8, 0, in, out, 5 * n, &tile_sample);
+      const uint64_t tk = tab_k(p);
       const int grid = stream_grid_for(p, tile_units(ntiles, tk));
       hipLaunchKernelGGL((lut8_kernel<TI>), dim3(grid), dim3(AGPU_LUT8_BLOCK), wave_lds_for(p, AGPU_WAVE_LDS_24, AGPU_LUT8_BLOCK / AGPU_WAVE), p->stream, pi, out, ntiles,
                          static_cast<const float*>(tab));
-      agpu_tiles_done(p, &tile_sample);
       if (ntiles * TILE_ROWS < n) {
         const uint64_t rest = n - ntiles * TILE_ROWS;
         const int g2 = stream_grid_for(p, (rest + AGPU_EW_BLOCK - 1) / AGPU_EW_BLOCK);

@@ -32,7 +32,7 @@ void agpu_set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------- process-wide tuning defaults
 // Plain atomics: agpu_set_tuning may be called from any thread; a pipeline snapshots them when it is created.
 static std::atomic<int64_t> g_tune_default[AGPU_TUNE_KEYS] = {/*stream_grid*/ {0}, /*cmp_variant*/ {0}, /*gather_bucket*/ {0}, /*h2d_mode*/ {0},
-                                                                 /*tiles*/ {0}, /*tile_auto*/ {0}, /*wave_lds*/ {0}, /*sync_spin*/ {0}};
+                                                                 /*tiles*/ {0}, /*wave_lds*/ {0}, /*sync_spin*/ {0}};
 // DEV SWITCH (tools/probe, docs/experiments.md R5): AGPU_DEVICE_MALLOC_FLAGS=<hipExtMallocWithFlags flags> makes every block the
 // pool, the arenas and the tables take from the driver a hipDeviceMallocContiguous (4) / Uncached (3) / Finegrained (1) one.
 // Unset or 0 = plain hipMalloc, which is what the product ships with.
@@ -47,7 +47,7 @@ static bool alloc_trace() {
 }
 static std::atomic<int64_t> g_mem_pool{1};  // 1 = recycle device blocks and idle streams (default), 0 = hipMalloc/hipFree every time
 static std::atomic<int64_t> g_pool_arena{1};  // 1 = pool blocks of ≥ 1 GiB come out of placed arenas (default), 0 = one hipMalloc each
-static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "cmp_variant", "gather_bucket", "h2d_mode", "tiles", "tile_auto", "wave_lds", "sync_spin"};
+static const char* const g_tune_keys[AGPU_TUNE_KEYS] = {"stream_grid", "cmp_variant", "gather_bucket", "h2d_mode", "tiles", "wave_lds", "sync_spin"};
 
 agpu_tuning agpu_tuning_defaults() {
   agpu_tuning t;
@@ -480,11 +480,6 @@ agpu_status agpu_device_destroy(agpu_device* dev) {
     }
     for (hipEvent_t e : dev->event_pool) (void)hipEventDestroy(e);
     dev->event_pool.clear();
-    for (agpu_device::TileEntry& te : dev->tile_tab)
-      for (agpu_device::TileSlot& ts : te.slot) {
-        if (ts.e0) (void)hipEventDestroy(ts.e0);
-        if (ts.e1) (void)hipEventDestroy(ts.e1);
-      }
     for (void* f : dev->flag_slabs) (void)hipHostFree(f);
     dev->flag_slabs.clear();
   }
@@ -1615,143 +1610,6 @@ agpu_status agpu_pipeline_get_tuning(agpu_pipeline* p, const char* key, int64_t*
 }
 
 }  // extern "C"
-
-// ---------------------------------------------------------------- adaptive tiles per block (common.hpp)
-static void tile_harvest_locked(agpu_device::TileEntry& e) {
-  for (agpu_device::TileSlot& s : e.slot) {
-    if (!s.pending) continue;
-    const hipError_t q = hipEventQuery(s.e1);
-    if (q == hipErrorNotReady) {
-      (void)hipGetLastError();
-      continue;
-    }
-    s.pending = false;
-    s.busy = false;
-    float ms = 0;
-    if (q != hipSuccess || hipEventElapsedTime(&ms, s.e0, s.e1) != hipSuccess || !(ms > 0) || !(s.bytes > 0)) {
-      (void)hipGetLastError();
-      if (e.issued[s.variant]) e.issued[s.variant]--;  // a lost sample is issued again
-      continue;
-    }
-    const double ns_per_byte = (double)ms * 1e6 / s.bytes;
-    if (e.n[s.variant] == 0 || ns_per_byte < e.best[s.variant]) e.best[s.variant] = ns_per_byte;
-    e.n[s.variant]++;
-  }
-}
-static constexpr int kTileSamples = 4;
-uint64_t agpu_tiles_pick(agpu_pipeline* p, int family, int kernel, const void* in, const void* out, uint64_t bytes, agpu_tile_sample* sample) {
-  sample->entry = sample->slot = -1;
-  // (a wrapped foreign stream may be inside a capture of its owner's that this library cannot see: events recorded there are graph nodes)
-  if (p->tune.tile_auto == 1 || p->capturing || !p->owns_stream) return 1;
-  if (bytes < (p->tune.tile_auto > 1 ? (uint64_t)p->tune.tile_auto : AGPU_TILE_AUTO_MIN_BYTES)) return 1;  // > 1: the threshold itself (tests)
-  agpu_device* dev = p->dev;
-  const uint64_t in_r = reinterpret_cast<uintptr_t>(in) >> 28, out_r = reinterpret_cast<uintptr_t>(out) >> 28;
-  const uint8_t lg = (uint8_t)(63 - __builtin_clzll(bytes));
-  const uint16_t fam = (uint16_t)((family << 8) | (kernel & 255));
-  std::lock_guard<std::mutex> lock(dev->tile_mu);
-  const uint64_t now = ++dev->tile_clock;
-  int at = -1, victim = -1;
-  for (int i = 0; i < agpu_device::kTileEntries; i++) {
-    agpu_device::TileEntry& e = dev->tile_tab[i];
-    if (e.live && e.family == fam && e.lg_bytes == lg && e.in_region == in_r && e.out_region == out_r) {
-      at = i;
-      break;
-    }
-    bool busy = false;
-    for (const agpu_device::TileSlot& s : e.slot) busy |= s.busy;
-    if (!busy && (victim < 0 || !e.live || (dev->tile_tab[victim].live && e.last_use < dev->tile_tab[victim].last_use))) victim = i;
-  }
-  if (at < 0) {
-    if (victim < 0) return 1;  // every entry has samples in flight
-    agpu_device::TileEntry& e = dev->tile_tab[victim];
-    agpu_device::TileSlot keep[8];
-    for (int k = 0; k < 8; k++) keep[k] = e.slot[k];  // the events are reused
-    e = agpu_device::TileEntry{};
-    for (int k = 0; k < 8; k++) {
-      e.slot[k].e0 = keep[k].e0;
-      e.slot[k].e1 = keep[k].e1;
-    }
-    e.live = true;
-    e.family = fam;
-    e.lg_bytes = lg;
-    e.in_region = in_r;
-    e.out_region = out_r;
-    at = victim;
-  }
-  agpu_device::TileEntry& e = dev->tile_tab[at];
-  e.last_use = now;
-  tile_harvest_locked(e);
-  if (e.choice == 0 && e.n[0] >= kTileSamples && e.n[1] >= kTileSamples) {
-    e.choice = e.best[1] * 1.025 < e.best[0] ? 2 : 1;
-    e.current = e.choice;
-    e.launches = 0;
-  }
-  if (e.choice != 0) {
-    if (++e.launches >= 1024) {  // measure again: pools recycle blocks, other tenants come and go
-      e.choice = 0;
-      e.n[0] = e.n[1] = e.issued[0] = e.issued[1] = 0;
-    }
-    return e.current;
-  }
-  const int v = e.issued[0] <= e.issued[1] ? 0 : 1;
-  if (e.issued[v] >= kTileSamples) return e.current;  // all eight are out: wait for them
-  int free_slot = -1;
-  for (int k = 0; k < 8; k++)
-    if (!e.slot[k].busy) {  // (not merely "not pending": another thread's launch may sit between its pick and its done)
-      free_slot = k;
-      break;
-    }
-  if (free_slot < 0) return e.current;
-  agpu_device::TileSlot& s = e.slot[free_slot];
-  if (!s.e0 && (hipEventCreate(&s.e0) != hipSuccess || hipEventCreate(&s.e1) != hipSuccess)) {
-    (void)hipGetLastError();
-    if (s.e0) (void)hipEventDestroy(s.e0);
-    s.e0 = s.e1 = nullptr;
-    return e.current;
-  }
-  if (hipEventRecord(s.e0, p->stream) != hipSuccess) {
-    (void)hipGetLastError();
-    return e.current;
-  }
-  s.variant = (uint8_t)v;
-  s.bytes = (double)bytes;
-  s.busy = true;
-  e.issued[v]++;
-  sample->entry = at;
-  sample->slot = free_slot;
-  return v == 0 ? 1 : 2;
-}
-void agpu_tiles_done(agpu_pipeline* p, agpu_tile_sample* sample) {
-  if (sample->entry < 0) return;
-  agpu_device* dev = p->dev;
-  std::lock_guard<std::mutex> lock(dev->tile_mu);
-  agpu_device::TileEntry& e = dev->tile_tab[sample->entry];
-  agpu_device::TileSlot& s = e.slot[sample->slot];
-  if (hipEventRecord(s.e1, p->stream) == hipSuccess) s.pending = true;
-  else {
-    (void)hipGetLastError();
-    s.busy = false;
-    if (e.issued[s.variant]) e.issued[s.variant]--;
-  }
-  sample->entry = -1;
-}
-
-extern "C" agpu_status agpu_device_tile_auto_info(agpu_device* dev, char* out, size_t out_cap) {
-  AGPU_REQUIRE(dev && out && out_cap > 0, AGPU_ERR_ARG, "null argument");
-  static const char* const fam[] = {"?", "heavy", "cast", "lut8", "trig16", "log"};
-  std::lock_guard<std::mutex> lock(dev->tile_mu);
-  size_t at = 0;
-  out[0] = 0;
-  for (agpu_device::TileEntry& e : dev->tile_tab) {
-    if (!e.live) continue;
-    tile_harvest_locked(e);
-    const int w = snprintf(out + at, out_cap - at, "%s%s.%d lg=%d tiles=%d samples=%d/%d ns_per_GB=%.0f/%.0f", at ? "; " : "",
-                           fam[(e.family >> 8) < 6 ? (e.family >> 8) : 0], (int)(e.family & 255), (int)e.lg_bytes, (int)(e.choice ? e.choice : 0), (int)e.n[0], (int)e.n[1], e.best[0] * 1e9, e.best[1] * 1e9);
-    if (w < 0 || (size_t)w >= out_cap - at) break;
-    at += (size_t)w;
-  }
-  return AGPU_OK;
-}
 
 // ---------------------------------------------------------------- call scope (AGPU_BIND)
 agpu_status agpu_scope_enter(agpu_pipeline* p, const char* name) {

@@ -132,12 +132,6 @@ class GpuDevice:
     def sync(self) -> None:
         capi.call("agpu_device_sync", self._handle)
 
-    def tile_auto_info(self) -> str:
-        """What the adaptive tiles-per-block policy has measured / decided so far (include/arrow_gpu.h agpu_device_tile_auto_info)."""
-        buf = C.create_string_buffer(8192)
-        capi.call("agpu_device_tile_auto_info", self._handle, buf, len(buf))
-        return buf.value.decode()
-
     def mem_info(self):
         f, t = C.c_uint64(), C.c_uint64()
         capi.call("agpu_device_mem_info", self._handle, C.byref(f), C.byref(t))

@@ -757,7 +757,7 @@ def main():
                         "eq_i32_validity": {"ms": round(eq_ms, 4), "GBps": round(eq_gbps, 1), "frac_hbm_peak": round(eq_gbps / HBM_PEAK_GBPS, 4)}}
 
     # ---- every other kernel BASELINE.json's configs 2–4 name, at the same 1e9 rows: median of 9 HIP-event timings after
-    # 10 untimed launches (the adaptive tile policy decides in them), algorithmic bytes per row, fraction of the 8 TB/s roof; one 65 536-row window each goes to the
+    # 10 untimed launches, algorithmic bytes per row, fraction of the 8 TB/s roof; one 65 536-row window each goes to the
     # cpu_baseline leg for the oracle.  Reported beside the headline; not part of `value`.
     cfg_windows = {}
     if rank == 0 and world == 1 and not args.no_extra_configs:
@@ -778,8 +778,7 @@ def main():
                 return got.view(dtype)
 
             def timed(launch, reps=9):
-                # 10 untimed launches with a sync before the last: the library's adaptive tiles-per-block policy (tuning tile_auto) times its
-                # eight samples per kernel and buffer pair in these and has decided before the first timed launch
+                # 10 untimed launches with a sync before the last, then the timed ones
                 for _ in range(9):
                     launch()
                 p.sync()
@@ -934,9 +933,6 @@ def main():
             cfgs["what"] = ("BASELINE.json configs 2-4 beyond the headline pair, same rows, table-placed buffers: median of 9 HIP-event "
                             "timings after 10 untimed launches; parity of one 65536-row window each in cpu_baseline.configs_parity")
             extra["configs"] = cfgs
-            extra["tile_auto"] = {"decisions": dev.tile_auto_info(),
-                                  "what": "adaptive tiles per block (include/arrow_gpu.h, tuning tile_auto): per kernel family and size class, tiles = the "
-                                          "form the device measured faster on these buffers (samples one / two tiles, best ns per GB of each)"}
             del u8, ov2, sc
         except Exception as e:  # noqa: BLE001
             extra["configs"] = {"error": f"{type(e).__name__}: {e}"}

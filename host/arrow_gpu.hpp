@@ -88,12 +88,6 @@ class GpuDevice : public std::enable_shared_from_this<GpuDevice> {
     b->dev = shared_from_this();
     return b;
   }
-  // what the adaptive tiles-per-block policy (tuning "tile_auto") has measured / decided so far (include/arrow_gpu.h)
-  std::string tile_auto_info() const {
-    char buf[8192];
-    check(agpu_device_tile_auto_info(raw, buf, sizeof buf), "agpu_device_tile_auto_info");
-    return std::string(buf);
-  }
   // the buffers of one table in ONE block, placed for the HBM channel hash (agpu_malloc_table); each is freed on its own
   std::vector<BufferPtr> create_table_buffers(const std::vector<uint64_t>& sizes) {
     std::vector<void*> ptrs(sizes.size(), nullptr);

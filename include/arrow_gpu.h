@@ -156,9 +156,6 @@ agpu_status agpu_device_pool_info(agpu_device* dev, uint64_t* out_cached_bytes, 
                                   uint64_t* out_idle_streams); /* the > 1 MiB cache and the idle streams */
 agpu_status agpu_device_small_pool_info(agpu_device* dev, uint64_t* out_slab_bytes, uint64_t* out_free_blocks,
                                         uint64_t* out_live_blocks); /* the <= 1 MiB slab pool */
-/* What the adaptive tiles-per-block policy (tuning "tile_auto") has measured and decided so far, as text:
- * "<family>.<kernel> lg=<log2 bytes> tiles=<0 measuring | 1 | 2> samples=<n1>/<n2> ns_per_GB=<best1>/<best2>; …" (truncated to out_cap). */
-agpu_status agpu_device_tile_auto_info(agpu_device* dev, char* out, size_t out_cap);
 
 /* ---------------------------------------------------------------- buffers (raw HBM pointers)
  * agpu_malloc          [ref: GpuDevice::create_empty_buffer gpu_device.rs:183-192] — zero_fill!=0 reproduces wgpu's
@@ -254,18 +251,15 @@ agpu_status agpu_event_destroy(agpu_event* e);
 agpu_status agpu_pipeline_enable_timing(agpu_pipeline* p, int32_t profile_bits);
 agpu_status agpu_pipeline_last_kernel_ns(agpu_pipeline* p, uint64_t* out_ns, const char** out_name);
 
-/* Launch tuning (sweeps and tests; defaults are the measured best).  EIGHT keys (round 6 removed nine whose other values were never better):
+/* Launch tuning (sweeps and tests; defaults are the measured best).  SEVEN keys (round 6 removed ten whose other values were never better,
+ * the adaptive tiles-per-block policy of round 5 among them — "tile_auto": with the occupancy caps in place it decided "one tile" everywhere):
  *   "stream_grid"   blocks of the streaming kernels: 0 = one tile per block (default), > 0 = that many, grid-striding (tests: the loop paths)
  *   "cmp_variant"   4-byte compares: 0 = ballot (default), 1 = vector loads + nibble shuffle
  *   "gather_bucket" take / put: 0 = auto (size thresholds + the device-side locality probe), 1 = direct kernels, 2 = bucketed pipelines
  *                   whenever the shape qualifies, 4 = like 2 but with the probe (tests)
  *   "h2d_mode"      host staging of agpu_import_arrow / agpu_export_arrow: 0 = auto, 1 = pageable copy, 2 = threaded pinned staging, 3 = hipHostRegister
  *   "tiles"         tiles per block of the kernels that issue the NEXT tile's loads before they evaluate the current one — the VALU-heavy f32
- *                   unary kernels, the widening casts and cast-headed chains, the LDS-table kernels: 0 = auto, > 0 = that many
- *   "tile_auto"     0 (default) = for launches that move >= 256 MiB the "auto" of "tiles" is ADAPTIVE — one or two tiles per block, whichever
- *                   the device measured faster on these buffers (eight timed launches per kernel, size class and buffer region, re-measured
- *                   every 1024 launches; which of the two wins follows what the driver backed the buffers with: docs/experiments.md R5.4);
- *                   1 = static defaults; a value > 1 = adaptive with that many bytes as the threshold (tests)
+ *                   unary kernels, the widening casts and cast-headed chains, the LDS-table kernels: 0 = each kernel's static default, > 0 = that many
  *   "wave_lds"      unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the widening casts to 32 bits and the 8-bit table
  *                   kernels: 0 = each kernel's measured default (≈ 24 or 16 waves per CU instead of 32: +3–9 % on those kernels,
  *                   docs/experiments.md R5.5, R6.2), < 0 = no cap, > 0 = that many bytes

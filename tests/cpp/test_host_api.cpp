@@ -108,7 +108,6 @@ static void run_compute_pipeline_ops(const DevicePtr& device) {
     CHECK(kp.stats.kernels == 2 && kp.stats.fused_chains == 1 && kp.stats.fused_ops == 3);
     CHECK(kept.raw_values() == w.cast<Float32ArrayGPU>().raw_values());
     CHECK(q.raw_values() == w.cast<Float32ArrayGPU>().mul_scalar(scale).cos().raw_values());
-    CHECK(device->tile_auto_info().size() < 8192);  // (small launches: nothing measured; the accessor itself works)
     // more than AGPU_CAST_CHAIN_MAX_ARRAYS array operands behind a cast head — the fusing pipeline cuts the chain
     // there instead of failing at finish()
     std::vector<float> col(3000);

@@ -55,9 +55,9 @@ def test_misc_queries_work_without_gpu():
     assert lib.agpu_set_tuning(b"no_such_key", 1) == capi.ERR_ARG
 
 
-def test_the_tuning_keys_are_the_eight_the_header_lists():
+def test_the_tuning_keys_are_the_seven_the_header_lists():
     """the public tuning surface was 17 keys, nine of which never beat their default.  The header's list, the library's
-    table and the set the ABI fuzz draws (tests/test_gpu_fuzz_abi.py TUNING_KEYS) are the same eight; the removed ones are argument errors."""
+    table and the set the ABI fuzz draws (tests/test_gpu_fuzz_abi.py TUNING_KEYS) are the same seven; the removed ones are argument errors."""
     import re
 
     from arrow_gpu_amd import _capi as capi
@@ -66,12 +66,12 @@ def test_the_tuning_keys_are_the_eight_the_header_lists():
     header = open(os.path.join(ROOT, "include", "arrow_gpu.h"), encoding="utf-8").read()
     doc = header[header.index("/* Launch tuning"):header.index("agpu_status agpu_set_tuning")]
     listed = re.findall(r'^ \*   "([a-z0-9_]+)"', doc, flags=re.M)
-    assert len(listed) == 8 and len(set(listed)) == 8, listed
+    assert len(listed) == 7 and len(set(listed)) == 7, listed
     v = C.c_int64(-1)
     for key in listed:
         assert lib.agpu_get_tuning(key.encode(), C.byref(v)) == 0 and v.value == 0, key
     for gone in ("stream_bpc", "stream_unroll", "stream_nt", "reduce_grid", "gather_region_bits", "gather_offsets", "h2d_threads",
-                 "heavy_tiles", "cast_tiles", "table_tiles"):
+                 "heavy_tiles", "cast_tiles", "table_tiles", "tile_auto"):
         assert lib.agpu_get_tuning(gone.encode(), C.byref(v)) == capi.ERR_ARG, gone
     fuzz = open(os.path.join(ROOT, "tests", "test_gpu_fuzz_abi.py"), encoding="utf-8").read()
     drawn = re.search(r"^TUNING_KEYS = \(([^)]*)\)", fuzz, flags=re.M).group(1)

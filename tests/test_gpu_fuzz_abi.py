@@ -23,7 +23,7 @@ CASTS = [(capi.I8, t) for t in (capi.U8, capi.U16, capi.U32, capi.I16, capi.I32,
         [(capi.U16, t) for t in (capi.U32, capi.I16, capi.I32, capi.F32)] + [(capi.F32, capi.U8)]
 
 
-TUNING_KEYS = ("stream_grid", "cmp_variant", "gather_bucket", "h2d_mode", "tiles", "tile_auto", "wave_lds", "sync_spin")  # all of them
+TUNING_KEYS = ("stream_grid", "cmp_variant", "gather_bucket", "h2d_mode", "tiles", "wave_lds", "sync_spin")  # all of them
 
 
 @pytest.fixture(scope="module")
@@ -65,14 +65,12 @@ def test_random_abi_calls_match_the_oracle(D, seed):
     for it in range(12):
         fam = ("binary", "scalar", "unary", "compare", "compare_validity", "cast", "bitmap", "reduce", "take", "merge",
                "chain", "shift", "put", "take_bits", "take_validity", "put_bits", "cast_chain")[rng.integers(17)]
-        # EVERY tuning key the ABI has (include/arrow_gpu.h: eight since round 6) is drawn in every iteration: results never depend on them.
+        # EVERY tuning key the ABI has (include/arrow_gpu.h: seven since round 6) is drawn in every iteration: results never depend on them.
         # tiles per block of the prefetching kernels (heavy unary kernels, casts, cast-headed chains, table kernels): any value, same results
         D.p.set_tuning("tiles", int(rng.integers(0, 9)) if rng.random() < 0.5 else 0)
         D.p.set_tuning("stream_grid", int((0, 0, 0, 7, 1024)[rng.integers(5)]))  # persistent grids: the kernels' grid-stride loops
         D.p.set_tuning("cmp_variant", int(rng.integers(0, 2)))                    # ballot compare / vector compare
         D.p.set_tuning("h2d_mode", int(rng.integers(0, 4)))                       # (staging route of Arrow imports: no call of the fuzz reads it)
-        # the adaptive policy behind "auto" with a threshold small enough for the fuzz's sizes: whatever it samples or decides, same results
-        D.p.set_tuning("tile_auto", int((0, 1, 4096, 4096)[rng.integers(4)]))
         D.p.set_tuning("wave_lds", int((0, 0, -1, 3000, 40000)[rng.integers(5)]))  # occupancy cap of sin / cos, the widening casts, the 8-bit table kernels
         D.p.set_tuning("sync_spin", int((0, 0, -1, 1, 30)[rng.integers(5)]))  # the mailbox waits (R5.10): on, off, a spin budget that mostly / sometimes runs out
         # take / put: the direct kernels (auto at these sizes; 1), the forced pipelines (2: merge-back take, pair-pipeline put) — small, ragged,

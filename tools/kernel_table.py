@@ -293,7 +293,7 @@ def main():
     os.makedirs(outdir, exist_ok=True)
     with open(os.path.join(outdir, f"kernel_table_{args.tag}.json"), "w") as f:
         json.dump({"rows": n, "device": dev.name, "kernels": rows, "reference_bench_shapes": ref_rows, "host_link": pcie,
-                   "small_n": small_n, "tile_auto": dev.tile_auto_info()}, f, indent=1)
+                   "small_n": small_n}, f, indent=1)
     print("\n| kernel | alg. B/row | ms @1e9 | GB/s | frac of 8 TB/s |\n|---|---|---|---|---|")
     for r in rows:
         print(f"| {r['kernel']} | {r['alg_B_per_row']:.4g} | {r['ms']} | {r['GBps']} | {r['frac_8TBs']} |")
