@@ -49,7 +49,7 @@ def main():
     def t(label, bytes_per_row, f, note=""):
         # 6 untimed launches first: the VALU-heavy kernels (pow above all) run their first 4–5 launches after a
         # memory-bound or idle phase at 1.3–1.5 GHz before the shader clock has ramped (tools/probe/pow_clock.py)
-        # (10 since round 5, with a sync before the last: the adaptive tiles-per-block policy times eight of them and decides)
+        # (10 warm-up launches, a sync before the last)
         for _ in range(9):
             f()
         p.sync()
@@ -214,7 +214,7 @@ def main():
             ("ref bench: f32 add_scalar, 10 Mi rows", 10 << 20, 8, lambda: capi.call("agpu_scalar", h, capi.OP_ADD, F32, vp(A), vp(S), vp(O), 10 << 20)),
             ("ref bench: u32 sum, 1 Mi rows", 1 << 20, 4, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, capi.U32, vp(A), None, 1 << 20, vp(R))),
             ("ref bench: u32 sum, 10 Mi rows", 10 << 20, 4, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, capi.U32, vp(A), None, 10 << 20, vp(R)))):
-        # (10 since round 5, with a sync before the last: the adaptive tiles-per-block policy times eight of them and decides)
+        # (10 warm-up launches, a sync before the last)
         for _ in range(9):
             f()
         p.sync()
