@@ -28,7 +28,7 @@ struct agpu_tuning {
   int64_t gather_bucket;  // take/put: 0 = auto (size thresholds + the device-side locality probe), 1 = always direct, 2 = always bucketed, 4 = like 2 but with the probe (tests)
   int64_t h2d_mode;       // host↔device staging of agpu_import/export_arrow: 0 = auto, 1 = pageable hipMemcpy, 2 = threaded pinned staging, 3 = hipHostRegister in place
   int64_t tiles;          // tiles per block of the kernels that issue the NEXT tile's loads before they evaluate the current one — the VALU-heavy f32 unary
-                          // kernels, the widening casts and cast-headed chains, the LDS-table kernels (lut8 / pow): 0 = each kernel's static default (one; log two; pow
+                          // kernels, the widening casts and cast-headed chains, the LDS-table kernels (lut8 / pow): 0 = each kernel's static default (one; pow
                           // with a scalar exponent three; cast-headed chains with a transcendental step four), > 0 = this many (round 6: one key instead of heavy_tiles /
                           // cast_tiles / table_tiles, and no adaptive policy behind "auto" any more: docs/experiments.md R6.9)
   int64_t wave_lds;       // unused dynamic LDS per wave that caps the waves per CU of sin / cos f32, the ×2 / ×4 widening casts and the 8-bit table kernels: 0 = each kernel's measured default (6800 B ≈ 24 waves per CU; sin / cos and the u8 → 32-bit casts 10240 B ≈ 16), < 0 = no cap, > 0 = this many bytes

@@ -643,9 +643,9 @@ template <> struct EwWaveLds<UnCos> { static constexpr unsigned value = AGPU_WAV
 template <> struct EwPrefetch<UnSin> { static constexpr bool value = true; static constexpr int tiles = 1; };
 template <> struct EwPrefetch<UnCos> { static constexpr bool value = true; static constexpr int tiles = 1; };
 template <> struct EwPrefetch<UnSinh> { static constexpr bool value = true; static constexpr int tiles = 1; };
-// log (round 6: packed f32, no table — the generic tile kernel instead of a kernel of its own).  Two tiles per block: 0.83–0.84 against 0.83 on an
-// ordinary column, +7 % on a column whose rows half take the general form (tools/probe/r06_sincos_sweep.py; profiles/r06_kernel_table.json tile_auto)
-template <> struct EwPrefetch<UnLog> { static constexpr bool value = true; static constexpr int tiles = 2; };
+// log (round 6: packed f32, no table — the generic tile kernel instead of a kernel of its own).  One tile per block like the others: two were level
+// or 1 % ahead in one process and 5 % behind in the next (0.84 / 0.79 — the by-process effect of R4.1 / R5.4), one tile is 0.83 everywhere
+template <> struct EwPrefetch<UnLog> { static constexpr bool value = true; static constexpr int tiles = 1; };
 template <> struct EwWaveLds<UnLog> { static constexpr unsigned value = AGPU_WAVE_LDS_24; };  // (tools/probe/r06_sincos_sweep.py: ≈ 24 waves 0.83–0.84, ≈ 16 0.77–0.78, no cap 0.79–0.83)
 // Threads per block: one wave for everything.  (The LDS-table kernels pow / log run best at 256 threads × 1 pack, but
 // sin / cos / sinh lose 4–10 % in that shape and 5 % at 64 × 1: tools/probe/heavy_shape.py, profiles/r02_heavy_shape.txt.)
