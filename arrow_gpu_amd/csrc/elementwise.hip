@@ -406,6 +406,16 @@ __device__ __forceinline__ f32x2_t log_f32_pair(f32x2_t x) {  // meaningful for 
   const f32x2_t t = pk_fma(ef, pk2(0x1.7f7d1cp-20f), r);
   return pk_fma(ef, pk2(0x1.62e4p-1f), t);
 }
+// Anything that is not a positive normal.  0, negatives, NaN and +inf are three selects in line — a column with zeros or negatives in it
+// (rows that come out −inf / NaN) used to send every wave through the out-of-line general form: 0.73 of the roof with half the rows negative;
+// only positive DENORMALS (rare in any column) still need the general form's arithmetic.
+__device__ __forceinline__ float log_f32_special(float x) {
+  float r = x;  // +inf and NaN pass through
+  r = (x == 0.0f) ? -__builtin_inff() : r;
+  r = (x < 0.0f) ? __builtin_nanf("") : r;
+  if (__builtin_amdgcn_classf(x, 0x080)) r = log_f32_general(x);  // +denormal
+  return r;
+}
 template <int N>
 __device__ __forceinline__ void log_f32_rows(const float (&x)[N], float (&res)[N]) {
   static_assert(N % 2 == 0, "rows come in pairs");
@@ -420,12 +430,12 @@ __device__ __forceinline__ void log_f32_rows(const float (&x)[N], float (&res)[N
   if (slow) {  // 0, negatives, NaN, inf, denormals
 #pragma unroll
     for (int k = 0; k < N; k++)
-      if (!log_ordinary(x[k])) res[k] = log_f32_general(x[k]);
+      if (!log_ordinary(x[k])) res[k] = log_f32_special(x[k]);
   }
 }
 __device__ __forceinline__ float log_f32_dev(float x) {  // one row (tails, unaligned columns)
   float res = log_f32_pair(pk2(x)).x;
-  if (!log_ordinary(x)) res = log_f32_general(x);
+  if (!log_ordinary(x)) res = log_f32_special(x);
   return res;
 }
 // x = 2^e · m for a positive normal x, m ∈ [0.707, 1.414) as an f64 and j = the table interval of its mantissa.  Adding

@@ -84,7 +84,7 @@ def main():
         t(f"f32 {name}", 8, lambda op=op: capi.call("agpu_unary", h, op, F32, vp(IA if name == "log" else A), vp(O), n),
           note="positive column" if name == "log" else "")
     t("f32 log, half the column negative (NaN rows)", 8, lambda: capi.call("agpu_unary", h, capi.UN_LOG, F32, vp(A), vp(O), n),
-      note="mixed waves: table form for every lane + general form over the rest")
+      note="0 / negatives / NaN / inf: three selects in line; only positive denormals take the general form")
     t("f32 power", 12, lambda: capi.call("agpu_binary", h, capi.OP_POW, F32, vp(A), vp(B), vp(O), n))
     for name, op in (("eq", capi.CMP_EQ), ("lt", capi.CMP_LT), ("gt", capi.CMP_GT)):
         t(f"i32 {name} → bitmap + validity AND (fused)", 8.5,
