@@ -26,6 +26,7 @@
 
 #define SPAN_ROWS 65536u   // rows per workgroup span (256 * 256)
 #define WAVE_ROWS 16384u   // rows per wave inside a span (64 blocks of 256)
+#define AGPU_FOLD_BLOCK_SUM 1024
 
 __device__ __forceinline__ float wave_tree_sum(float v) {  // lane 0 gets the adjacent-pair tree sum of the 64 lanes
 #pragma unroll
@@ -171,6 +172,46 @@ __global__ __launch_bounds__(AGPU_WAVE) void sum_tree_combine_kernel(const float
   if (lane == 0) out[blockIdx.x] = t;
 }
 
+// second AND last launch for 257 … 65 536 spans (16.8 M … 4.29e9 rows): one 1024-thread workgroup does what the combine launch's ≤ 256
+// one-wave blocks did — wave w takes the groups w, w + 16, …, four groups' sixteen 16-byte loads per lane in flight together — parks the
+// group sums in LDS (zero-padded to 256, the reference's padding) and its first wave runs the reference's next 256-ary level over them:
+// (e0+e1)+(e2+e3) per lane + 6 shuffle steps, the same adjacent-pair tree sum_tree_finish_kernel walks through LDS.  One launch boundary
+// and ≈ 5 µs less behind a 0.57 ms read.
+__global__ __launch_bounds__(AGPU_FOLD_BLOCK_SUM) void sum_tree_combine_finish_kernel(const float* quarters, uint64_t nspans, uint32_t ngroups,
+                                                                                   float* out) {
+  __shared__ float sh[256];
+  const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
+  constexpr uint32_t NW = AGPU_FOLD_BLOCK_SUM / AGPU_WAVE;
+  if (threadIdx.x < 256) sh[threadIdx.x] = 0.0f;
+  __syncthreads();
+  for (uint32_t g0 = wave; g0 < ngroups; g0 += 4 * NW) {
+    f32x4 w[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint64_t sp0 = ((uint64_t)(g0 + r * NW) * AGPU_WAVE + lane) * 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (g0 + r * NW < ngroups && sp0 + (uint64_t)k < nspans) w[r][k] = *reinterpret_cast<const f32x4*>(quarters + (sp0 + (uint64_t)k) * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const uint32_t g = g0 + r * NW;
+      if (g >= ngroups) break;  // wave-uniform
+      const uint64_t sp0 = ((uint64_t)g * AGPU_WAVE + lane) * 4;
+      float s[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) s[k] = sp0 + (uint64_t)k < nspans ? (w[r][k].x + w[r][k].y) + (w[r][k].z + w[r][k].w) : 0.0f;
+      const float t = wave_tree_sum((s[0] + s[1]) + (s[2] + s[3]));
+      if (lane == 0) sh[g] = t;
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float t = wave_tree_sum((sh[4 * lane] + sh[4 * lane + 1]) + (sh[4 * lane + 2] + sh[4 * lane + 3]));
+    if (lane == 0) out[0] = t;
+  }
+}
+
 // remaining 256-ary levels over m values, exactly the reference's workgroup tree (aggregate.wgsl:21-41); one workgroup
 __global__ __launch_bounds__(AGPU_BLOCK) void sum_tree_finish_kernel(const float* first, const uint8_t* validity,
                                                                     float* buf0, float* buf1, uint64_t m, float* out,
@@ -219,6 +260,9 @@ template <typename T> struct RedSumWrap {  // wrapping integer sum [aggregate.wg
   __device__ static Acc combine(Acc a, Acc b) { return a + b; }
   __device__ static T finish(Acc a) { return (T)a; }
   typedef T Out;
+  typedef Acc Part;
+  __device__ static Part to_part(Acc a) { return a; }
+  __device__ static Acc from_part(Part q) { return q; }
 };
 struct RedSumF64 {
   typedef double Acc;
@@ -227,6 +271,9 @@ struct RedSumF64 {
   __device__ static Acc load(float x) { return (double)x; }
   __device__ static Acc combine(Acc a, Acc b) { return a + b; }
   __device__ static Out finish(Acc a) { return a; }
+  typedef Acc Part;
+  __device__ static Part to_part(Acc a) { return a; }
+  __device__ static Acc from_part(Part q) { return q; }
 };
 template <typename T, bool MAX> struct RedMinMaxInt {
   typedef T Acc;
@@ -238,6 +285,9 @@ template <typename T, bool MAX> struct RedMinMaxInt {
   __device__ static Acc load(T x) { return x; }
   __device__ static Acc combine(Acc a, Acc b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); }
   __device__ static Out finish(Acc a) { return a; }
+  typedef Acc Part;
+  __device__ static Part to_part(Acc a) { return a; }
+  __device__ static Acc from_part(Part q) { return q; }
 };
 template <bool MAX> struct RedMinMaxF32 {  // Arrow min_max: NaN skipped unless every value is NaN; -0 < +0
   typedef MinMaxF32 Acc;
@@ -266,6 +316,12 @@ template <bool MAX> struct RedMinMaxF32 {  // Arrow min_max: NaN skipped unless 
     if (!(a.flags & 1u) && (a.flags & 2u)) return __builtin_nanf("");
     return a.r;
   }
+  // what a NON-EMPTY chunk leaves for the fold: its finished value — NaN exactly when every row of the chunk was NaN, which load() turns
+  // back into {identity, saw a NaN}.  Four bytes per chunk instead of eight: the folding workgroup reads 244 KB at 1e9 rows in ONE round
+  // of loads (11.7 → 4.6 µs)
+  typedef float Part;
+  __device__ static Part to_part(Acc a) { return finish(a); }
+  __device__ static Acc from_part(Part q) { return load(q); }
 };
 
 template <typename A> __device__ __forceinline__ A shfl_down_acc(A v, int off) {
@@ -360,7 +416,7 @@ static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks, int blo
 #define AGPU_REDUCE_WAVE 1
 constexpr uint64_t RED_CHUNK_ROWS = 16384;
 template <typename T, typename Red>
-__global__ __launch_bounds__(AGPU_WAVE) void reduce_wave_kernel(const T* in, typename Red::Acc* partials, uint64_t nchunks) {
+__global__ __launch_bounds__(AGPU_WAVE) void reduce_wave_kernel(const T* in, typename Red::Part* partials, uint64_t nchunks) {
   typedef typename Red::Acc A;
   const uint32_t lane = threadIdx.x;
   for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -382,19 +438,61 @@ __global__ __launch_bounds__(AGPU_WAVE) void reduce_wave_kernel(const T* in, typ
     A acc = Red::combine(Red::combine(a0, a1), Red::combine(a2, a3));
 #pragma unroll
     for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) acc = Red::combine(acc, shfl_down_acc(acc, off));
-    if (lane == 0) partials[c] = acc;
+    if (lane == 0) partials[c] = Red::to_part(acc);
   }
 }
-template <typename Red>
-__global__ __launch_bounds__(AGPU_BLOCK) void reduce_fold_kernel(const typename Red::Acc* partials, uint64_t m,
-                                                                typename Red::Acc* out) {  // out[blockIdx.x]
+// The wave kernel's second (and last) launch: ONE 1024-thread workgroup folds the < 1-chunk tail of the column and all the partials
+// and writes the result.  Rounds 3–6a ran three launches here (a 256-thread block over the tail, ≤ 256 blocks folding the partials, one
+// block finishing: 4.6 + 5.5 + 4.2 µs of kernels and three boundaries behind a 0.57–0.59 ms read of 1e9 rows — the whole distance
+// between the reductions at 0.82–0.85 of the roof and a bare read-only kernel of the same shape at 0.87, tools/probe/stream_split.hip).
+// 61 035 partials are 244 KB (488 for the f64 sum): every thread issues all its 16-byte loads at once (≤ 16 in flight, two rounds for 8-byte partials)
+// and the workgroup pays one memory latency, not sixty.  The order of the fold is a function of the number of partials alone (and with it
+// the workgroup's size: 256 threads up to 16 384 partials, 1024 beyond), so the f64 sum's last bits depend on the column's length only.
+#define AGPU_FOLD_BLOCK 1024
+template <typename T, typename Red>
+__global__ __launch_bounds__(AGPU_FOLD_BLOCK) void reduce_fold_finish_kernel(const typename Red::Part* partials, uint64_t m, const T* tail_in,
+                                                                            uint32_t tail, typename Red::Out* out) {
   typedef typename Red::Acc A;
-  __shared__ A lds[AGPU_BLOCK / AGPU_WAVE];
+  typedef typename Red::Part Q;
+  constexpr int PER = 16 / (int)sizeof(Q);  // partials per 16-byte vector: 4 or 2
+  constexpr int B = 16;                     // vectors in flight per thread
+  struct Pack {
+    Q a[PER];
+  };
+  static_assert(sizeof(Pack) == 16, "partials tile a 16-byte vector");
+  __shared__ A lds[AGPU_FOLD_BLOCK / AGPU_WAVE];
+  const uint32_t nthr = blockDim.x;  // 1024, or 256 for short partial lists (columns of < 268 M rows: a smaller workgroup starts sooner)
   A acc = Red::identity();
-  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_BLOCK + threadIdx.x; i < m; i += (uint64_t)gridDim.x * AGPU_BLOCK)
-    acc = Red::combine(acc, partials[i]);
-  const A r = block_reduce<Red, A>(acc, lds);
-  if (threadIdx.x == 0) out[blockIdx.x] = r;
+  for (uint32_t i = threadIdx.x; i < tail; i += nthr) acc = Red::combine(acc, Red::load(tail_in[i]));
+  const uint64_t nvec = m / PER;
+  const u32x4* pv = reinterpret_cast<const u32x4*>(partials);
+  for (uint64_t v0 = 0; v0 < nvec; v0 += (uint64_t)nthr * B) {
+    u32x4 v[B];
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      const uint64_t idx = v0 + (uint64_t)u * nthr + threadIdx.x;
+      if (idx < nvec) v[u] = pv[idx];
+    }
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      const uint64_t idx = v0 + (uint64_t)u * nthr + threadIdx.x;
+      if (idx < nvec) {
+        const Pack pk = __builtin_bit_cast(Pack, v[u]);
+#pragma unroll
+        for (int k = 0; k < PER; k++) acc = Red::combine(acc, Red::from_part(pk.a[k]));
+      }
+    }
+  }
+  for (uint64_t i = nvec * PER + threadIdx.x; i < m; i += nthr) acc = Red::combine(acc, Red::from_part(partials[i]));
+#pragma unroll
+  for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) acc = Red::combine(acc, shfl_down_acc(acc, off));
+  if ((threadIdx.x & (AGPU_WAVE - 1)) == 0) lds[threadIdx.x / AGPU_WAVE] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    A r = lds[0];
+    for (uint32_t k = 1; k < nthr / AGPU_WAVE; k++) r = Red::combine(r, lds[k]);
+    out[0] = Red::finish(r);
+  }
 }
 
 template <typename T, typename Red>
@@ -403,34 +501,17 @@ static agpu_status launch_reduce(agpu_pipeline* p, const void* in, const void* v
   constexpr int U = 4;
   if (AGPU_REDUCE_WAVE && !validity && aligned16(in) && n >= 64 * RED_CHUNK_ROWS) {
     const uint64_t nchunks = n / RED_CHUNK_ROWS, tail = n - nchunks * RED_CHUNK_ROWS;
-    const uint64_t m = nchunks + (tail ? 1 : 0);
-    const unsigned fold = (unsigned)((m + 4095) / 4096 < 256 ? (m + 4095) / 4096 : 256);
     void* scratch = nullptr;
-    agpu_status st = agpu_scratch(p, sizeof(A) * (size_t)(m + fold), &scratch);
+    typedef typename Red::Part Q;
+    agpu_status st = agpu_scratch(p, sizeof(Q) * (size_t)nchunks + 16, &scratch);
     if (st != AGPU_OK) return st;
-    A* partials = static_cast<A*>(scratch);
+    Q* partials = static_cast<Q*>(scratch);
     const uint64_t g = nchunks < 0x3FFFFFFFull ? nchunks : 0x3FFFFFFFull;
     hipLaunchKernelGGL((reduce_wave_kernel<T, Red>), dim3((unsigned)g), dim3(AGPU_WAVE), 0, p->stream, static_cast<const T*>(in),
                        partials, nchunks);
     AGPU_LAUNCH_CHECK();
-    if (tail) {
-      hipLaunchKernelGGL((reduce_partial_kernel<T, Red, U>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream,
-                         static_cast<const T*>(in) + nchunks * RED_CHUNK_ROWS, (const uint8_t*)nullptr, tail, partials + nchunks, 1);
-      AGPU_LAUNCH_CHECK();
-    }
-    // ≤ 4096 partials (columns of up to 64 Mi rows — the reference's own benchmark shapes, 1 Mi and 10 Mi rows, among them): the finishing
-    // block folds them itself, TWO launches instead of three.  Only where the order of the fold cannot matter (wrapping sums, min / max):
-    // the f64 sum keeps its two-level order so that its last bits do not depend on the column's length class.
-    if (m <= 4096 && !std::is_same<A, double>::value) {
-      hipLaunchKernelGGL((reduce_finish_kernel<Red>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, (const A*)partials, (uint32_t)m,
-                         static_cast<typename Red::Out*>(out));
-      AGPU_LAUNCH_CHECK();
-      return AGPU_OK;
-    }
-    hipLaunchKernelGGL((reduce_fold_kernel<Red>), dim3(fold), dim3(AGPU_BLOCK), 0, p->stream, (const A*)partials, m, partials + m);
-    AGPU_LAUNCH_CHECK();
-    hipLaunchKernelGGL((reduce_finish_kernel<Red>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, (const A*)(partials + m), (uint32_t)fold,
-                       static_cast<typename Red::Out*>(out));
+    hipLaunchKernelGGL((reduce_fold_finish_kernel<T, Red>), dim3(1), dim3(nchunks > 16384 ? AGPU_FOLD_BLOCK : 256), 0, p->stream, (const Q*)partials, nchunks,
+                       static_cast<const T*>(in) + nchunks * RED_CHUNK_ROWS, (uint32_t)tail, static_cast<typename Red::Out*>(out));
     AGPU_LAUNCH_CHECK();
     return AGPU_OK;
   }
@@ -475,6 +556,12 @@ static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const 
   else
     hipLaunchKernelGGL((sum_tree_quarter_kernel<false>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, in, validity, n, quarters, nquarters, vec_ok);
   AGPU_LAUNCH_CHECK();
+  if (ngroups > 1 && ngroups <= 256) {  // 16.8 M … 4.29e9 rows: combine + the last level in ONE workgroup
+    hipLaunchKernelGGL(sum_tree_combine_finish_kernel, dim3(1), dim3(AGPU_FOLD_BLOCK_SUM), 0, p->stream, (const float*)quarters, nspans,
+                       (uint32_t)ngroups, out);
+    AGPU_LAUNCH_CHECK();
+    return AGPU_OK;
+  }
   // ≤ 256 spans (16.7 M rows): the combine launch produces the result itself
   hipLaunchKernelGGL(sum_tree_combine_kernel, dim3((unsigned)ngroups), dim3(AGPU_WAVE), 0, p->stream, (const float*)quarters, nspans,
                      ngroups == 1 ? out : groups);

@@ -427,7 +427,7 @@ def test_bitmap_copy_bits_realigns_sliced_bitmaps(D):
 
 
 # ------------------------------------------------------------------ reductions
-@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 511, 65535, 65536, 65537, 131072, 200001, 16777216 + 7])
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 511, 65535, 65536, 65537, 131072, 200001, 16777216 + 7, 3 * 16777216 + 70001])
 def test_f32_sum_is_bit_identical_to_the_reference_tree(D, n):
     x = O.synth_f32(n, 77, 0, -1000.0, 1000.0)
     out = D.empty(16)
@@ -479,6 +479,38 @@ def test_reduce_all_nan_and_unaligned(D):
     for op in (capi.RED_SUM, capi.RED_MIN, capi.RED_MAX):
         D.call("agpu_reduce", op, capi.F32, D.up(y, 4).vp, None, len(y), out.vp)
         assert bits_equal(D.down(out, np.float32, 1), np.array([O.reduce(op, O.F32, y)], np.float32)), op
+
+
+def test_reduce_wave_path_with_nan_chunks_and_tails(D):
+    """The one-wave-per-chunk form (aligned columns of >= 1 Mi rows without validity) + its ONE finishing workgroup: a chunk of NaNs
+    leaves a NaN partial that the fold must skip; an all-NaN column is NaN; -0.0 orders below +0.0 across partials; the < 1-chunk tail
+    and a tail that holds the extreme; wrapping sums over the same shapes."""
+    out = D.empty(16)
+    for n in (1 << 20, (1 << 20) + 1, (1 << 20) + 16383, 3 * (1 << 20) + 5000, (1 << 23) + 77):
+        x = rand_values(capi.F32, n, 91)
+        x[np.isnan(x)] = 1.0
+        x[:16384] = np.nan                      # chunk 0: all NaN
+        x[16384 * 7: 16384 * 8] = np.nan        # another one
+        x[16384 * 9 + 5] = np.nan               # a NaN inside an ordinary chunk
+        variants = [x]
+        y = x.copy(); y[-1] = np.float32(3.0e38); y[-2] = np.float32(-3.0e38)  # the extremes sit in the tail (or the last chunk)
+        variants.append(y)
+        z = np.full(n, np.nan, np.float32)      # nothing but NaN
+        variants.append(z)
+        w = np.full(n, 0.0, np.float32); w[16384 * 3 + 1] = -0.0  # -0.0 < +0.0, one of them in one chunk
+        variants.append(w)
+        for v in variants:
+            dv = D.up(v)
+            for op in (capi.RED_MIN, capi.RED_MAX):
+                D.call("agpu_reduce", op, capi.F32, dv.vp, None, n, out.vp)
+                got = D.down(out, np.float32, 1)
+                assert nan_aware_bits_equal(got, np.array([O.reduce(op, O.F32, v)], np.float32)), (op, n, got)
+        for dtype in (capi.I32, capi.U32):
+            xi = rand_values(dtype, n, 92)
+            di = D.up(xi)
+            for op in (capi.RED_SUM, capi.RED_MIN, capi.RED_MAX):
+                D.call("agpu_reduce", op, dtype, di.vp, None, n, out.vp)
+                assert bits_equal(D.down(out, NP[dtype], 1), np.array([O.reduce(op, dtype, xi)], NP[dtype])), (op, dtype, n)
 
 
 def test_sum_f64_accumulator(D):
