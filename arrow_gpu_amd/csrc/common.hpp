@@ -293,6 +293,25 @@ static inline int stream_grid_for(const agpu_pipeline* p, uint64_t tiles) {
   return (int)g;
 }
 
+// TWO LOCK-STEP STREAMS (round 6b).  A kernel with ONE input and ONE output stream over a big column runs 1.2–4.7 % faster when its
+// blocks walk the tiles as two streams half a column apart — even blocks the first half, odd blocks the second — than front to back,
+// measured by alternating the two orders in one process on the same table-placed buffers at 1e9 rows (tools/probe/two_streams_ab.py,
+// two_streams_ab2.py → profiles/r06b_two_streams_ab*.json): add_scalar 0.853 → 0.863 of the roof, neg 0.852 → 0.865, sqrt 0.849 → 0.866,
+// exp 0.851 → 0.865, sin 0.850 → 0.871, u16 → f32 0.836 → 0.857, u8 → u16 0.80 → 0.83, f32 → i16 0.845 → 0.858, (a + s)·t in one launch
+// 0.794 → 0.832; from 128 MiB columns on (2^25 f32 rows +0.9 %, 2^27 +1.5 %, 2^29 +2.0 %).  Any distance of ≥ 64 MiB between the streams
+// does and no bit of the channel hash matters (tools/probe/stream_split.hip: 64 MiB … 1.5 GiB alike; 2 MiB −7 %).  What does NOT gain:
+// two-input kernels (f32 add −0.5 %: three placed streams already interleave), read-only kernels (a column reads at 0.87 in any order),
+// ×4 width changes (u8 → f32, the 8-bit table kernels, f32 → u8: level), in-place kernels (level), four streams (level) and eight (−2 %).
+// logical tile t → the tile it touches; half = 0 keeps the sequential order (SALU only: the block index is uniform)
+__device__ __forceinline__ uint64_t two_streams(uint64_t t, uint64_t half) {
+  return t < 2 * half ? (t >> 1) + ((t & 1) ? half : 0) : t;
+}
+// host side: the `half` argument of a launch over `ntiles` tiles whose bigger stream moves `tile_bytes` per tile — one tile per block only
+// (an explicit grid or several tiles per block keep their own order)
+static inline uint64_t two_streams_half(const agpu_pipeline* p, uint64_t ntiles, uint64_t tile_bytes) {
+  return (p->tune.stream_grid == 0 && p->tune.tiles <= 1 && ntiles * tile_bytes >= (128ull << 20)) ? ntiles / 2 : 0;
+}
+
 // Grid for kernels that finish with an atomic on ONE word per block/wave (popcount, any, index max, checksum):
 // same-address atomics serialise at ≈12 ns each, so the block count is capped and the kernels grid-stride.
 static inline int atomic_grid_for(const agpu_pipeline* p, uint64_t work_blocks) {

@@ -540,7 +540,7 @@ struct UnSinh { __device__ static __forceinline__ float ap(float x, float) { ret
 #define AGPU_EW_BLOCK 64
 
 template <typename T, typename Op, int MODE, int U, int NT, int BLK = AGPU_EW_BLOCK>
-__global__ __launch_bounds__(BLK) void ew_kernel(const T* a, const T* b, T* out, uint64_t ntiles) {
+__global__ __launch_bounds__(BLK) void ew_kernel(const T* a, const T* b, T* out, uint64_t ntiles, uint64_t half) {
   constexpr int N = 16 / sizeof(T);
   constexpr bool NTL = (NT & 1) != 0, NTS = (NT & 2) != 0, XCD = (NT & 4) != 0;
   constexpr uint64_t tile = (uint64_t)BLK * U;
@@ -552,6 +552,8 @@ __global__ __launch_bounds__(BLK) void ew_kernel(const T* a, const T* b, T* out,
     if constexpr (XCD) {  // blocks are dealt round-robin to the 8 XCDs: give XCD x the x-th contiguous eighth of the tiles
       const uint64_t per = ntiles / 8;
       if (t0 < per * 8) t = (t0 & 7) * per + (t0 >> 3);
+    } else if (t0 < 2 * half) {  // two lock-step streams half a column apart (launch_ew: one-input kernels over big columns)
+      t = (t0 >> 1) + ((t0 & 1) ? half : 0);
     }
     const uint64_t p0 = t * tile + threadIdx.x;
     PackN<T, N> va[U], vb[U];
@@ -689,6 +691,9 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
       // round-robin + nontemporal shape (the XCD mapping costs them 1.4 %).
       const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(out) |
                              (MODE == MODE_BINARY ? reinterpret_cast<uintptr_t>(b) : 0);
+      // one-input kernels (unary, scalar) over big columns: two lock-step streams (common.hpp two_streams); two-input kernels lose 0.5 % by it
+      // (sinh, the one f64-heavy functor left, LOSES 3.6 % by it: 0.755 → 0.728, tools/probe/two_streams_ab3.py)
+      const uint64_t half = (MODE != MODE_BINARY && !std::is_same<Op, UnSinh>::value) ? two_streams_half(p, ntiles, 16 * (uint64_t)BLK * U) : 0;
       bool done = false;
       if constexpr (EwPrefetch<Op>::value && MODE == MODE_UNARY && std::is_same<T, float>::value && BLK == AGPU_EW_BLOCK) {
         const int64_t k = p->tune.tiles > 0 ? p->tune.tiles : EwPrefetch<Op>::tiles;  // static defaults since round 6 (the adaptive policy of round 5 decided "one" everywhere)
@@ -702,9 +707,9 @@ static agpu_status launch_ew(agpu_pipeline* p, const void* a, const void* b, voi
       if (done) {
       } else if ((bits & 127u) == 0)
         hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, AGPU_STREAM_NT, BLK>), dim3(grid), dim3(BLK),
-                           EwWaveLds<Op>::value ? wave_lds_for(p, EwWaveLds<Op>::value, BLK / AGPU_WAVE) : 0u, p->stream, pa, pb, po, ntiles);
+                           EwWaveLds<Op>::value ? wave_lds_for(p, EwWaveLds<Op>::value, BLK / AGPU_WAVE) : 0u, p->stream, pa, pb, po, ntiles, half);
       else
-        hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, 4, BLK>), dim3(grid), dim3(BLK), 0, p->stream, pa, pb, po, ntiles);
+        hipLaunchKernelGGL((ew_kernel<T, Op, MODE, U, 4, BLK>), dim3(grid), dim3(BLK), 0, p->stream, pa, pb, po, ntiles, (uint64_t)0);
     }
     if (ntiles * tile_rows < n)
       hipLaunchKernelGGL((ew_tail_kernel<T, Op, MODE>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pa, pb, po,
@@ -1254,7 +1259,7 @@ __global__ __launch_bounds__(AGPU_BLOCK) void cvt_kernel_unaligned(const TI* in,
 // SC1: the stores' cache policy.  ×2: always sc1 nt.  ×4: sc1 nt when the launch carries the occupancy cap (u8→f32 / i8→i32 at 1e9 rows,
 // three processes, tools/archive/r05_sc1x4.sh: 0.794–0.817 → 0.808–0.826 of the roof), plain nt without it (0.785–0.800 against 0.760–0.797).
 template <typename TI, typename TO, typename Conv, bool SC1>
-__global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in, TO* out, uint64_t nchunks) {
+__global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in, TO* out, uint64_t nchunks, uint64_t half) {
   constexpr int R = sizeof(TO) / sizeof(TI);   // 2 or 4 stores per load
   constexpr int NO = 16 / sizeof(TO);          // output elements per lane per store
   constexpr uint32_t WAVES = AGPU_CVTW_BLOCK / AGPU_WAVE;
@@ -1263,12 +1268,13 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in,
   uint64_t c = run.t;
   if (c >= run.end) return;
   // the next chunk's load is issued before the current chunk's four stores (tuning tiles > 1: a wave walks several chunks)
-  u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
+  u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + two_streams(c, half) * AGPU_WAVE + lane);
   for (;;) {
     const uint64_t cn = c + run.step;
     const bool more = cn < run.end;
+    const uint64_t cp = two_streams(c, half);  // the chunk this round stores
     u32x4 vn = v;
-    if (more) vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + cn * AGPU_WAVE + lane);
+    if (more) vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + two_streams(cn, half) * AGPU_WAVE + lane);
     static_for<R>([&](auto j) {
       const int src = (int)(((uint32_t)j * (AGPU_WAVE / R) + lane / R) * 4);  // byte address of the source lane
       const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)v.x);
@@ -1293,7 +1299,7 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in,
         for (int k = 0; k < NO; k++) r.v[k] = Conv::ap(x.v[k]);
       }
       const uint32_t g = (uint32_t)j * AGPU_WAVE + lane;  // slot of this lane's store inside the chunk
-      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, NO, SC1>(out + (c * (uint64_t)(AGPU_WAVE * R) + g) * NO, r);
+      store_pack<(AGPU_STREAM_NT & 2) != 0, TO, NO, SC1>(out + (cp * (uint64_t)(AGPU_WAVE * R) + g) * NO, r);
     });
     if (!more) break;
     v = vn;
@@ -1308,7 +1314,7 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cvt_wide_kernel(const TI* in,
 // ONE coalesced 1 KiB store per wave.  cast f32→u8 at 1e9 rows, same process (tools/probe/narrow_sweep.py,
 // profiles/r02_sweep_narrow.json): 4-byte stores 0.77–0.79 of the HBM roof in every block shape, this form 0.83.
 template <typename TI, typename TO, typename Conv>
-__global__ __launch_bounds__(AGPU_WAVE) void cvt_narrow_kernel(const TI* in, TO* out, uint64_t nchunks) {
+__global__ __launch_bounds__(AGPU_WAVE) void cvt_narrow_kernel(const TI* in, TO* out, uint64_t nchunks, uint64_t half) {
   constexpr int R = sizeof(TI) / sizeof(TO);  // 2 or 4 loads per store
   constexpr int NI = 16 / sizeof(TI);         // elements per loaded vector = elements per piece
   constexpr int PD = 4 / R;                   // dwords per piece: 1 (R = 4) or 2 (R = 2)
@@ -1316,7 +1322,8 @@ __global__ __launch_bounds__(AGPU_WAVE) void cvt_narrow_kernel(const TI* in, TO*
     uint32_t d[PD];
   };
   const uint32_t lane = threadIdx.x;
-  for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+  for (uint64_t c0 = blockIdx.x; c0 < nchunks; c0 += gridDim.x) {
+    const uint64_t c = two_streams(c0, half);
     Piece w[R];
     static_for<R>([&](auto j) {
       const PackN<TI, NI> x = load_pack<(AGPU_STREAM_NT & 1) != 0, TI, NI>(in + ((c * R + (uint32_t)j) * AGPU_WAVE + lane) * NI);
@@ -1362,10 +1369,13 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
         // (round 6: none for cast → sin / cos of a 16-bit column — with sin / cos in packed f32 the kernel wants all its waves: 0.79–0.80 against 0.75)
         constexpr unsigned cap = ConvHasRows<Conv>::value ? 0u : sizeof(TO) == 4 ? (sizeof(TI) == 2 ? AGPU_WAVE_LDS_24 : AGPU_WAVE_LDS_16) : 0u;
         const unsigned lds = cap ? wave_lds_for(p, cap, AGPU_CVTW_BLOCK / AGPU_WAVE) : 0u;
+        // ×2 casts walk the chunks as two lock-step streams (common.hpp two_streams: u16 → f32 0.836 → 0.857, u8 → u16 0.80 → 0.83, sin_u16 0.78 → 0.79);
+        // the ×4 ones do not gain (u8 → f32 0.811 / 0.806)
+        const uint64_t half = sizeof(TO) == 2 * sizeof(TI) ? two_streams_half(p, nchunks, 2048) : 0;
         if (sizeof(TO) == 2 * sizeof(TI) || lds >= AGPU_WAVE_LDS_24)
-          hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv, true>), dim3(grid), dim3(AGPU_CVTW_BLOCK), lds, p->stream, pi, po, nchunks);
+          hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv, true>), dim3(grid), dim3(AGPU_CVTW_BLOCK), lds, p->stream, pi, po, nchunks, half);
         else
-          hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv, false>), dim3(grid), dim3(AGPU_CVTW_BLOCK), lds, p->stream, pi, po, nchunks);
+          hipLaunchKernelGGL((cvt_wide_kernel<TI, TO, Conv, false>), dim3(grid), dim3(AGPU_CVTW_BLOCK), lds, p->stream, pi, po, nchunks, half);
       }
       if (nchunks * chunk_rows < n)
         hipLaunchKernelGGL((cvt_tail_kernel<TI, TO, Conv>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pi, po,
@@ -1380,7 +1390,8 @@ static agpu_status launch_cvt(agpu_pipeline* p, const void* in, void* out, uint6
       const uint64_t nchunks = n / chunk_rows;
       if (nchunks) {
         const int grid = stream_grid_for(p, nchunks);
-        hipLaunchKernelGGL((cvt_narrow_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, pi, po, nchunks);
+        hipLaunchKernelGGL((cvt_narrow_kernel<TI, TO, Conv>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, pi, po, nchunks,
+                           sizeof(TI) == 2 * sizeof(TO) ? two_streams_half(p, nchunks, 2048) : 0);  // f32 → i16 0.845 → 0.858; f32 → u8 level
       }
       if (nchunks * chunk_rows < n)
         hipLaunchKernelGGL((cvt_tail_kernel<TI, TO, Conv>), dim3(1), dim3(AGPU_BLOCK), 0, p->stream, pi, po,
@@ -1859,10 +1870,11 @@ __device__ __forceinline__ bool chain_cmp_pred(int op, T x, T y) {
 template <typename T, bool HEAVY, int NARR, bool CMP>
 __global__ __launch_bounds__(AGPU_EW_BLOCK) void chain_kernel(const T* in, T* out, uint64_t ntiles, int n_steps,
                                                              int n_arrs, uint64_t code, ChainPtrs ptrs, ChainPtrs arrs,
-                                                             int cmp_op) {
+                                                             int cmp_op, uint64_t half) {
   constexpr int N = 4;
   constexpr int U = CMP ? AGPU_CHAIN_CMP_U : HEAVY ? AGPU_CHAIN_HEAVY_U : 1;  // a tile = U × 256 rows
-  for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  for (uint64_t t0 = blockIdx.x; t0 < ntiles; t0 += gridDim.x) {
+    const uint64_t t = two_streams(t0, half);
     const uint64_t pk0 = t * (uint64_t)(AGPU_EW_BLOCK * U) + threadIdx.x;
     PackN<T, N> acc[U];
     static_for<U>([&](auto u) { acc[u] = load_pack<true, T, N>(in + (pk0 + (uint64_t)u * AGPU_EW_BLOCK) * N); });
@@ -1988,7 +2000,10 @@ static void launch_chain_full(agpu_pipeline* p, const T* pi, T* po, uint64_t nti
                               const ChainPtrs& ptrs, const ChainPtrs& arrs, int cmp_op) {
   const int grid = stream_grid_for(p, ntiles);
   hipLaunchKernelGGL((chain_kernel<T, HEAVY, NARR, CMP>), dim3(grid), dim3(AGPU_EW_BLOCK), HEAVY ? wave_lds_for(p, AGPU_CHAIN_HEAVY_LDS, 1) : 0u, p->stream, pi, po, ntiles,
-                     n_steps, n_arrs, code, ptrs, arrs, cmp_op);
+                     n_steps, n_arrs, code, ptrs, arrs, cmp_op,
+                     // one input, one output, no transcendental step: two lock-step streams ((a + s)·t 0.794 → 0.832: common.hpp two_streams);
+                     // (x·s).sin() gained 1.6 % in one process and lost 3.7 % in the next — the VALU-bound chains keep the sequential order
+                     (NARR == 0 && !CMP && !HEAVY) ? two_streams_half(p, ntiles, (uint64_t)AGPU_EW_BLOCK * (HEAVY ? AGPU_CHAIN_HEAVY_U : 1) * 16) : (uint64_t)0);
 }
 
 // cmp_op < 0: plain chain, `out` is a T column.  cmp_op ≥ 0: slot n_steps of code / ptrs describes the compare's operand
@@ -2048,7 +2063,7 @@ static agpu_status launch_chain(agpu_pipeline* p, const void* in, void* out, uin
 // are f32 columns read at the store position.
 template <typename TI, bool HEAVY, int NARR>
 __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* in, float* out, uint64_t nchunks, int n_steps,
-                                                                     int n_arrs, uint64_t code, ChainPtrs ptrs, ChainPtrs arrs) {
+                                                                     int n_arrs, uint64_t code, ChainPtrs ptrs, ChainPtrs arrs, uint64_t half) {
   constexpr int R = 4 / sizeof(TI);  // 4 (8-bit) or 2 (16-bit) stores per load
   constexpr int NO = 4;
   constexpr uint32_t WAVES = AGPU_CVTW_BLOCK / AGPU_WAVE;
@@ -2058,19 +2073,20 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
   const TileRun run = tile_run((uint64_t)blockIdx.x * WAVES + threadIdx.x / AGPU_WAVE, (uint64_t)gridDim.x * WAVES, nchunks);
   uint64_t c = run.t;
   if (c >= run.end) return;
-  u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + c * AGPU_WAVE + lane);
+  u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + two_streams(c, half) * AGPU_WAVE + lane);
   for (;;) {
     const uint64_t cn = c + run.step;
     const bool more = cn < run.end;
+    const uint64_t cp = two_streams(c, half);  // the chunk this round stores
     u32x4 vn = v;
-    if (more) vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + cn * AGPU_WAVE + lane);
+    if (more) vn = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + two_streams(cn, half) * AGPU_WAVE + lane);
     // all R packs of the chunk go through the chain TOGETHER (round 6): the step interpreter — op / kind extraction, the op switch — runs once
     // per chunk and lane (8 or 16 rows) instead of once per store (4 rows); its scalar instructions and branches were a third of what a
     // VALU-bound chain issued per row once sin / cos themselves had shrunk (cast(u16)·s → sin 0.62 of the roof)
     PackN<float, NO> acc[R];
     PackN<float, NO> ya[NARR > 0 ? NARR : 1][R];
     static_for<R>([&](auto j) {
-      const uint64_t at = (c * (uint64_t)(AGPU_WAVE * R) + (uint32_t)j * AGPU_WAVE + lane) * NO;  // first row of this lane's store
+      const uint64_t at = (cp * (uint64_t)(AGPU_WAVE * R) + (uint32_t)j * AGPU_WAVE + lane) * NO;  // first row of this lane's store
       static_for<NARR>([&](auto a) {
         if (a < n_arrs) ya[a][j] = load_pack<true, float, NO>(static_cast<const float*>(arrs.p[a]) + at);
       });
@@ -2120,7 +2136,7 @@ __global__ __launch_bounds__(AGPU_CVTW_BLOCK) void cast_chain_kernel(const TI* i
       }
     }
     static_for<R>([&](auto j) {
-      const uint64_t at = (c * (uint64_t)(AGPU_WAVE * R) + (uint32_t)j * AGPU_WAVE + lane) * NO;
+      const uint64_t at = (cp * (uint64_t)(AGPU_WAVE * R) + (uint32_t)j * AGPU_WAVE + lane) * NO;
       store_pack<(AGPU_STREAM_NT & 2) != 0, float, NO, (R == 2 || AGPU_CCHAIN_SC1X4)>(out + at, acc[j]);
     });
     if (!more) break;
@@ -2190,10 +2206,12 @@ static agpu_status launch_cast_chain(agpu_pipeline* p, const void* in, float* ou
     const uint64_t kt = (uint64_t)(p->tune.tiles > 0 ? p->tune.tiles : (heavy ? 4 : 1));
     const uint64_t blocks = (nchunks + AGPU_CVTW_BLOCK / AGPU_WAVE - 1) / (AGPU_CVTW_BLOCK / AGPU_WAVE);
     const int grid = stream_grid_for(p, (blocks + kt - 1) / kt);
+    // 16-bit sources without array operands: two lock-step streams (cast(u16)·s + s 0.824 → 0.839); 8-bit sources do not gain
+    const uint64_t half2 = (sizeof(TI) == 2 && n_arrs == 0 && kt == 1) ? two_streams_half(p, nchunks, 2048) : 0;
 #define AGPU_CCHAIN_CASE(H, A)                                                                                              \
   if (heavy == H && slots == A)                                                                                             \
     hipLaunchKernelGGL((cast_chain_kernel<TI, H, A>), dim3(grid), dim3(AGPU_CVTW_BLOCK), H ? wave_lds_for(p, AGPU_CHAIN_HEAVY_LDS, 1) : 0u, p->stream, pi, out, nchunks, n_steps, \
-                       n_arrs, code, scal, arrs);
+                       n_arrs, code, scal, arrs, half2);
     AGPU_CCHAIN_CASE(false, 0) AGPU_CCHAIN_CASE(false, 2) AGPU_CCHAIN_CASE(false, 4)
     AGPU_CCHAIN_CASE(true, 0) AGPU_CCHAIN_CASE(true, 2) AGPU_CCHAIN_CASE(true, 4)
 #undef AGPU_CCHAIN_CASE

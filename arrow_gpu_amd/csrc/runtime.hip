@@ -1150,9 +1150,11 @@ agpu_status agpu_download_async(agpu_pipeline* p, void* dst_pinned, const void* 
 // where a plain stream of nontemporal 16-byte loads and stores in one-wave blocks — the element-wise kernels' shape —
 // moves the same bytes at 6.7.  Big, 16-byte-aligned, non-overlapping copies take that kernel; everything else (small
 // copies: the launch dominates either way) stays with the runtime.
-__global__ __launch_bounds__(AGPU_WAVE) void copy_kernel(const u32x4* src, u32x4* dst, uint64_t nvec) {
-  for (uint64_t i = (uint64_t)blockIdx.x * AGPU_WAVE + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x * AGPU_WAVE)
-    __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+__global__ __launch_bounds__(AGPU_WAVE) void copy_kernel(const u32x4* src, u32x4* dst, uint64_t nvec, uint64_t nblocks, uint64_t half) {
+  for (uint64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const uint64_t i = two_streams(b, half) * AGPU_WAVE + threadIdx.x;  // big copies: two lock-step streams (common.hpp)
+    if (i < nvec) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  }
 }
 
 agpu_status agpu_copy(agpu_pipeline* p, void* dst_dev, const void* src_dev, size_t bytes) {
@@ -1165,7 +1167,7 @@ agpu_status agpu_copy(agpu_pipeline* p, void* dst_dev, const void* src_dev, size
     const uint64_t nvec = bytes / 16;
     const uint64_t blocks = (nvec + AGPU_WAVE - 1) / AGPU_WAVE;
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)(blocks < 0x3FFFFFFFull ? blocks : 0x3FFFFFFFull)), dim3(AGPU_WAVE), 0, p->stream,
-                       static_cast<const u32x4*>(src_dev), static_cast<u32x4*>(dst_dev), nvec);
+                       static_cast<const u32x4*>(src_dev), static_cast<u32x4*>(dst_dev), nvec, blocks, two_streams_half(p, blocks, 1024));
     AGPU_LAUNCH_CHECK();
     const size_t done = (size_t)nvec * 16;
     if (done < bytes)
