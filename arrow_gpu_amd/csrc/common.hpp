@@ -300,7 +300,8 @@ static inline int stream_grid_for(const agpu_pipeline* p, uint64_t tiles) {
 // exp 0.851 → 0.865, sin 0.850 → 0.871, u16 → f32 0.836 → 0.857, u8 → u16 0.80 → 0.83, f32 → i16 0.845 → 0.858, (a + s)·t in one launch
 // 0.794 → 0.832; from 128 MiB columns on (2^25 f32 rows +0.9 %, 2^27 +1.5 %, 2^29 +2.0 %).  Any distance of ≥ 64 MiB between the streams
 // does and no bit of the channel hash matters (tools/probe/stream_split.hip: 64 MiB … 1.5 GiB alike; 2 MiB −7 %).  What does NOT gain:
-// two-input kernels (f32 add −0.5 %: three placed streams already interleave), read-only kernels (a column reads at 0.87 in any order),
+// two-input kernels (f32 add −0.5 %: three placed streams already interleave; the 32-bit compare −2 %: 0.88 → 0.865 in three allocations),
+// read-only kernels (a column reads at 0.87 in any order), sinh (−3.6 %) and chains with a transcendental step (+1.6 % / −3.7 % by process),
 // ×4 width changes (u8 → f32, the 8-bit table kernels, f32 → u8: level), in-place kernels (level), four streams (level) and eight (−2 %).
 // logical tile t → the tile it touches; half = 0 keeps the sequential order (SALU only: the block index is uniform)
 __device__ __forceinline__ uint64_t two_streams(uint64_t t, uint64_t half) {
