@@ -172,9 +172,15 @@ struct comm_init_job {
 // Seen with the test hook (AGPU_COMM_TEST_STALL_INIT_MS=19000, deadline 20 s: the helper's ncclCommInitRank returns a second AFTER the call gave
 // up): the process ran to its end on the local communicator and died with SIGSEGV at exit — RCCL's communicator, with its proxy threads, was
 // still alive.  Whoever sees the late ncclComm_t last destroys it.
+// A helper that is STILL inside ncclCommInitRank when its communicator is destroyed is orphaned: it cleans up after itself when RCCL lets it
+// go.  Its job stays on this list so that agpu_device_destroy can wait for it (bounded): a helper that creates and destroys an RCCL
+// communicator while the process tears the runtime down is the exit crash described above.
+static std::mutex g_orphans_mu;
+static std::vector<std::shared_ptr<comm_init_job>> g_orphans;
 static void comm_reap_late_init(const std::shared_ptr<comm_init_job>& job) {
   if (!job) return;
   ncclComm_t late = nullptr;
+  bool orphan = false;
   {
     std::unique_lock<std::mutex> lk(job->mu);
     if (job->cv.wait_for(lk, std::chrono::milliseconds(2000), [&] { return job->done; })) {
@@ -182,9 +188,37 @@ static void comm_reap_late_init(const std::shared_ptr<comm_init_job>& job) {
       job->comm = nullptr;
     } else {
       job->orphaned = true;
+      orphan = true;
     }
   }
   if (late) (void)ncclCommDestroy(late);
+  if (orphan) {
+    std::lock_guard<std::mutex> lk(g_orphans_mu);
+    g_orphans.push_back(job);
+  }
+}
+// runtime.hip agpu_device_destroy: wait (at most wait_ms in all) for the orphaned init helpers to leave RCCL; true when none is left inside
+bool agpu_internal_comm_wait_orphans(int64_t wait_ms) {
+  std::vector<std::shared_ptr<comm_init_job>> jobs;
+  {
+    std::lock_guard<std::mutex> lk(g_orphans_mu);
+    jobs.swap(g_orphans);
+  }
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::milliseconds(wait_ms);
+  bool all = true;
+  for (auto& job : jobs) {
+    std::unique_lock<std::mutex> lk(job->mu);
+    if (!job->cv.wait_until(lk, deadline, [&] { return job->done; })) {
+      all = false;
+      lk.unlock();
+      std::lock_guard<std::mutex> g(g_orphans_mu);
+      g_orphans.push_back(job);  // still pending: a later destroy may wait again
+    }
+  }
+  if (!all)
+    fprintf(stderr, "arrow_gpu_hip: an RCCL bootstrap that never came up is still pending on a helper thread at device teardown "
+                    "(waited %lld ms); the process may not exit cleanly\n", (long long)wait_ms);
+  return all;
 }
 
 agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id, int32_t rank, int32_t world,
@@ -205,9 +239,14 @@ agpu_status agpu_comm_init_rank_timeout(agpu_device* dev, const void* unique_id,
   } else {
     auto job = std::make_shared<comm_init_job>();
     const int ordinal = dev->ordinal;
-    // test hook (tests/test_gpu_comm.py): AGPU_COMM_TEST_STALL_INIT_MS makes the helper sit that long before it calls RCCL — a bootstrap
-    // that does not come up, reproducibly
+    // test hook, compiled into the TEST build of the library only (csrc/Makefile `hooks`: libarrow_gpu_hip_hooks.so, -DAGPU_TEST_HOOKS;
+    // tests/test_gpu_comm.py loads it through AGPU_LIB): AGPU_COMM_TEST_STALL_INIT_MS makes the helper sit that long before it calls RCCL — a
+    // bootstrap that does not come up, reproducibly.  The product library has no such switch.
+#ifdef AGPU_TEST_HOOKS
     static const long stall_ms = [] { const char* e = getenv("AGPU_COMM_TEST_STALL_INIT_MS"); return e && *e ? strtol(e, nullptr, 10) : 0L; }();
+#else
+    static const long stall_ms = 0;
+#endif
     std::thread([job, id, rank, world, ordinal]() {
       if (stall_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(stall_ms));
       ncclComm_t c = nullptr;

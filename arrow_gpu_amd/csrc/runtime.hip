@@ -446,9 +446,12 @@ agpu_status agpu_device_small_pool_info(agpu_device* dev, uint64_t* out_slab_byt
   return AGPU_OK;
 }
 
+bool agpu_internal_comm_wait_orphans(int64_t wait_ms);  // comm.hip
 agpu_status agpu_device_destroy(agpu_device* dev) {
   if (!dev) return AGPU_OK;
   (void)hipSetDevice(dev->ordinal);
+  // init helpers of one-rank communicators whose RCCL bootstrap came up late (or not yet): they must be out of RCCL before the runtime goes
+  (void)agpu_internal_comm_wait_orphans(5000);
   // a stuck collective blocks every hipFree / hipStreamDestroy: leak the lot, the process is on its way out
   if (dev->poisoned.load(std::memory_order_acquire)) return AGPU_OK;
   {

@@ -93,6 +93,17 @@ def test_no_cpu_fallback():
     assert ei.value.status == 5  # AGPU_ERR_NO_DEVICE
 
 
+def test_the_product_library_carries_no_test_hook():
+    """comm.hip's stall hook (an RCCL bootstrap that does not come up, reproducibly) is compiled into the TEST build only
+    (libarrow_gpu_hip_hooks.so, -DAGPU_TEST_HOOKS; tests/test_gpu_comm.py loads it through AGPU_LIB) — ADVICE r5."""
+    lib_dir = os.path.join(ROOT, "arrow_gpu_amd", "lib")
+    product = open(os.path.join(lib_dir, "libarrow_gpu_hip.so"), "rb").read()
+    assert b"AGPU_COMM_TEST_STALL_INIT_MS" not in product
+    hooks = os.path.join(lib_dir, "libarrow_gpu_hip_hooks.so")
+    assert os.path.exists(hooks), "build() makes the test build too (csrc/Makefile `hooks`)"
+    assert b"AGPU_COMM_TEST_STALL_INIT_MS" in open(hooks, "rb").read()
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "arrow_gpu_amd")
     for dp, _, fns in os.walk(pkg):

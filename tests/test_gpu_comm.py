@@ -359,7 +359,7 @@ def test_a_one_rank_communicator_survives_a_bootstrap_that_does_not_come_up():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, AGPU_COMM_TEST_STALL_INIT_MS="4000")
+    env = dict(os.environ, AGPU_COMM_TEST_STALL_INIT_MS="4000", AGPU_LIB=os.path.join(root, "arrow_gpu_amd", "lib", "libarrow_gpu_hip_hooks.so"))
     r = subprocess.run([sys.executable, "-c", _LOCAL_WORKER.format(root=root)], capture_output=True, text=True, timeout=180, env=env)
     assert r.returncode == 0 and "LOCAL-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
 
@@ -396,6 +396,6 @@ def test_a_bootstrap_that_comes_up_late_is_cleaned_up(sleep):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, AGPU_COMM_TEST_STALL_INIT_MS="300")
+    env = dict(os.environ, AGPU_COMM_TEST_STALL_INIT_MS="300", AGPU_LIB=os.path.join(root, "arrow_gpu_amd", "lib", "libarrow_gpu_hip_hooks.so"))
     r = subprocess.run([sys.executable, "-c", _LATE_WORKER.format(root=root, sleep=sleep)], capture_output=True, text=True, timeout=180, env=env)
     assert r.returncode == 0 and "LATE-OK" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
