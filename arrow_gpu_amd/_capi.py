@@ -100,6 +100,7 @@ SIGNATURES = {
     "agpu_comm_rank": [_vp, C.POINTER(_i32), C.POINTER(_i32)],
     "agpu_comm_reduce": [_vp, _vp, _i32, _i32, _vp, _vp, _u64, _vp],
     "agpu_comm_reduce_sum_f64": [_vp, _vp, _vp, _vp, _u64, _vp],
+    "agpu_comm_reduce_stats_f32": [_vp, _vp, _vp, _vp, _u64, _vp],
     "agpu_comm_final_reduce": [_vp, _vp, _i32, _i32, _i32, _vp, _u64, _vp],
     "agpu_reduce_combine": [_vp, _i32, _i32, _i32, _vp, _i32, _vp],
     "agpu_comm_all_reduce": [_vp, _vp, _i32, _i32, _vp, _u64],
@@ -151,6 +152,7 @@ SIGNATURES = {
     "agpu_bitmap_merge_validity": [_vp, _vp, _vp, _vp, _vp, _vp, _u64],
     "agpu_reduce": [_vp, _i32, _i32, _vp, _vp, _u64, _vp],
     "agpu_reduce_sum_f64": [_vp, _vp, _vp, _u64, _vp],
+    "agpu_reduce_stats_f32": [_vp, _vp, _vp, _u64, _vp],
     "agpu_take": [_vp, _i32, _vp, _u64, _vp, _vp, _u64],
     "agpu_take_bits": [_vp, _vp, _u64, _vp, _vp, _u64],
     "agpu_put_bounded": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _vp, _u64],

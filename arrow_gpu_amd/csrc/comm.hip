@@ -557,6 +557,19 @@ agpu_status agpu_comm_final_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_o
   return gather_and_finish(c, p, kind_f64 ? 3 : (int)op, dtype, out_dev);
 }
 
+// One pass over the shard for all four statistics (reduce.hip launch_stats_f32 behind agpu_reduce_stats_f32), then the four final reduces
+// — each exactly agpu_comm_final_reduce — in place on the record's fields.
+agpu_status agpu_comm_reduce_stats_f32(agpu_comm* c, agpu_pipeline* p, const float* in, const void* validity, uint64_t n_local,
+                                       agpu_f32_stats* out_dev) {
+  agpu_status st = agpu_reduce_stats_f32(p, in, validity, n_local, out_dev);
+  if (st != AGPU_OK) return st;
+  st = agpu_comm_final_reduce(c, p, AGPU_RED_SUM, AGPU_F32, 0, &out_dev->sum, n_local, &out_dev->sum);
+  if (st == AGPU_OK) st = agpu_comm_final_reduce(c, p, AGPU_RED_MIN, AGPU_F32, 0, &out_dev->min, n_local, &out_dev->min);
+  if (st == AGPU_OK) st = agpu_comm_final_reduce(c, p, AGPU_RED_MAX, AGPU_F32, 0, &out_dev->max, n_local, &out_dev->max);
+  if (st == AGPU_OK) st = agpu_comm_final_reduce(c, p, AGPU_RED_SUM, AGPU_F32, 1, &out_dev->sum_f64, n_local, &out_dev->sum_f64);
+  return st;
+}
+
 agpu_status agpu_comm_barrier(agpu_comm* c, agpu_pipeline* p) {
   AGPU_BIND(p);
   agpu_status st = comm_check(c, p);

@@ -138,8 +138,8 @@ __device__ __forceinline__ float quarter_tree_sum(const float* in, const uint8_t
 // reference's zero padding of the last workgroup)
 template <bool HASV>
 __global__ __launch_bounds__(AGPU_WAVE) void sum_tree_quarter_kernel(const float* in, const uint8_t* validity, uint64_t n,
-                                                                    float* quarters, uint64_t nquarters, int vec_ok) {
-  for (uint64_t q = blockIdx.x; q < nquarters; q += gridDim.x) {
+                                                                    float* quarters, uint64_t nquarters, int vec_ok, uint64_t q0) {
+  for (uint64_t q = q0 + blockIdx.x; q < nquarters; q += gridDim.x) {
     const uint64_t base = q * WAVE_ROWS;
     float r;
     if (vec_ok && base + WAVE_ROWS <= n) r = quarter_tree_sum<false, HASV>(in, validity, base, n);
@@ -177,9 +177,7 @@ __global__ __launch_bounds__(AGPU_WAVE) void sum_tree_combine_kernel(const float
 // group sums in LDS (zero-padded to 256, the reference's padding) and its first wave runs the reference's next 256-ary level over them:
 // (e0+e1)+(e2+e3) per lane + 6 shuffle steps, the same adjacent-pair tree sum_tree_finish_kernel walks through LDS.  One launch boundary
 // and ≈ 5 µs less behind a 0.57 ms read.
-__global__ __launch_bounds__(AGPU_FOLD_BLOCK_SUM) void sum_tree_combine_finish_kernel(const float* quarters, uint64_t nspans, uint32_t ngroups,
-                                                                                   float* out) {
-  __shared__ float sh[256];
+__device__ __forceinline__ void sum_combine_finish_body(const float* quarters, uint64_t nspans, uint32_t ngroups, float* out, float* sh /* [256] */) {
   const uint32_t lane = threadIdx.x & (AGPU_WAVE - 1), wave = threadIdx.x / AGPU_WAVE;
   constexpr uint32_t NW = AGPU_FOLD_BLOCK_SUM / AGPU_WAVE;
   if (threadIdx.x < 256) sh[threadIdx.x] = 0.0f;
@@ -210,6 +208,11 @@ __global__ __launch_bounds__(AGPU_FOLD_BLOCK_SUM) void sum_tree_combine_finish_k
     const float t = wave_tree_sum((sh[4 * lane] + sh[4 * lane + 1]) + (sh[4 * lane + 2] + sh[4 * lane + 3]));
     if (lane == 0) out[0] = t;
   }
+}
+__global__ __launch_bounds__(AGPU_FOLD_BLOCK_SUM) void sum_tree_combine_finish_kernel(const float* quarters, uint64_t nspans, uint32_t ngroups,
+                                                                                   float* out) {
+  __shared__ float sh[256];
+  sum_combine_finish_body(quarters, nspans, ngroups, out, sh);
 }
 
 // remaining 256-ary levels over m values, exactly the reference's workgroup tree (aggregate.wgsl:21-41); one workgroup
@@ -449,9 +452,10 @@ __global__ __launch_bounds__(AGPU_WAVE) void reduce_wave_kernel(const T* in, typ
 // and the workgroup pays one memory latency, not sixty.  The order of the fold is a function of the number of partials alone (and with it
 // the workgroup's size: 256 threads up to 16 384 partials, 1024 beyond), so the f64 sum's last bits depend on the column's length only.
 #define AGPU_FOLD_BLOCK 1024
+// the body: every thread of the block calls it; the first `nthr` of them (a multiple of 64) do the work — the order of the fold is nthr's
 template <typename T, typename Red>
-__global__ __launch_bounds__(AGPU_FOLD_BLOCK) void reduce_fold_finish_kernel(const typename Red::Part* partials, uint64_t m, const T* tail_in,
-                                                                            uint32_t tail, typename Red::Out* out) {
+__device__ __forceinline__ void fold_finish_body(const typename Red::Part* partials, uint64_t m, const T* tail_in, uint32_t tail, typename Red::Out* out,
+                                                 uint32_t nthr, typename Red::Acc* lds /* [AGPU_FOLD_BLOCK / AGPU_WAVE] */) {
   typedef typename Red::Acc A;
   typedef typename Red::Part Q;
   constexpr int PER = 16 / (int)sizeof(Q);  // partials per 16-byte vector: 4 or 2
@@ -460,39 +464,45 @@ __global__ __launch_bounds__(AGPU_FOLD_BLOCK) void reduce_fold_finish_kernel(con
     Q a[PER];
   };
   static_assert(sizeof(Pack) == 16, "partials tile a 16-byte vector");
-  __shared__ A lds[AGPU_FOLD_BLOCK / AGPU_WAVE];
-  const uint32_t nthr = blockDim.x;  // 1024, or 256 for short partial lists (columns of < 268 M rows: a smaller workgroup starts sooner)
   A acc = Red::identity();
-  for (uint32_t i = threadIdx.x; i < tail; i += nthr) acc = Red::combine(acc, Red::load(tail_in[i]));
-  const uint64_t nvec = m / PER;
-  const u32x4* pv = reinterpret_cast<const u32x4*>(partials);
-  for (uint64_t v0 = 0; v0 < nvec; v0 += (uint64_t)nthr * B) {
-    u32x4 v[B];
+  if (threadIdx.x < nthr) {
+    for (uint32_t i = threadIdx.x; i < tail; i += nthr) acc = Red::combine(acc, Red::load(tail_in[i]));
+    const uint64_t nvec = m / PER;
+    const u32x4* pv = reinterpret_cast<const u32x4*>(partials);
+    for (uint64_t v0 = 0; v0 < nvec; v0 += (uint64_t)nthr * B) {
+      u32x4 v[B];
 #pragma unroll
-    for (int u = 0; u < B; u++) {
-      const uint64_t idx = v0 + (uint64_t)u * nthr + threadIdx.x;
-      if (idx < nvec) v[u] = pv[idx];
-    }
+      for (int u = 0; u < B; u++) {
+        const uint64_t idx = v0 + (uint64_t)u * nthr + threadIdx.x;
+        if (idx < nvec) v[u] = pv[idx];
+      }
 #pragma unroll
-    for (int u = 0; u < B; u++) {
-      const uint64_t idx = v0 + (uint64_t)u * nthr + threadIdx.x;
-      if (idx < nvec) {
-        const Pack pk = __builtin_bit_cast(Pack, v[u]);
+      for (int u = 0; u < B; u++) {
+        const uint64_t idx = v0 + (uint64_t)u * nthr + threadIdx.x;
+        if (idx < nvec) {
+          const Pack pk = __builtin_bit_cast(Pack, v[u]);
 #pragma unroll
-        for (int k = 0; k < PER; k++) acc = Red::combine(acc, Red::from_part(pk.a[k]));
+          for (int k = 0; k < PER; k++) acc = Red::combine(acc, Red::from_part(pk.a[k]));
+        }
       }
     }
-  }
-  for (uint64_t i = nvec * PER + threadIdx.x; i < m; i += nthr) acc = Red::combine(acc, Red::from_part(partials[i]));
+    for (uint64_t i = nvec * PER + threadIdx.x; i < m; i += nthr) acc = Red::combine(acc, Red::from_part(partials[i]));
 #pragma unroll
-  for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) acc = Red::combine(acc, shfl_down_acc(acc, off));
-  if ((threadIdx.x & (AGPU_WAVE - 1)) == 0) lds[threadIdx.x / AGPU_WAVE] = acc;
+    for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) acc = Red::combine(acc, shfl_down_acc(acc, off));
+    if ((threadIdx.x & (AGPU_WAVE - 1)) == 0) lds[threadIdx.x / AGPU_WAVE] = acc;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     A r = lds[0];
     for (uint32_t k = 1; k < nthr / AGPU_WAVE; k++) r = Red::combine(r, lds[k]);
     out[0] = Red::finish(r);
   }
+}
+template <typename T, typename Red>
+__global__ __launch_bounds__(AGPU_FOLD_BLOCK) void reduce_fold_finish_kernel(const typename Red::Part* partials, uint64_t m, const T* tail_in,
+                                                                            uint32_t tail, typename Red::Out* out) {
+  __shared__ typename Red::Acc lds[AGPU_FOLD_BLOCK / AGPU_WAVE];
+  fold_finish_body<T, Red>(partials, m, tail_in, tail, out, blockDim.x, lds);
 }
 
 template <typename T, typename Red>
@@ -529,6 +539,8 @@ static agpu_status launch_reduce(agpu_pipeline* p, const void* in, const void* v
   return AGPU_OK;
 }
 
+static agpu_status sum_tree_after_quarters(agpu_pipeline* p, const float* quarters, uint64_t nspans, float* groups, float* buf0, float* buf1,
+                                           float* out);
 static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const uint8_t* validity, uint64_t n,
                                        float* out) {
   const uint64_t nspans = (n + SPAN_ROWS - 1) / SPAN_ROWS, nquarters = nspans * 4;
@@ -552,10 +564,17 @@ static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const 
   const int grid = reduce_grid_for(p, nquarters, 1 << 16);  // one-wave blocks: as many as there are quarters (sum_probe.py)
   const int vec_ok = (aligned16(in) && (!validity || aligned_to(validity, 4))) ? 1 : 0;
   if (validity)
-    hipLaunchKernelGGL((sum_tree_quarter_kernel<true>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, in, validity, n, quarters, nquarters, vec_ok);
+    hipLaunchKernelGGL((sum_tree_quarter_kernel<true>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, in, validity, n, quarters, nquarters, vec_ok, (uint64_t)0);
   else
-    hipLaunchKernelGGL((sum_tree_quarter_kernel<false>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, in, validity, n, quarters, nquarters, vec_ok);
+    hipLaunchKernelGGL((sum_tree_quarter_kernel<false>), dim3(grid), dim3(AGPU_WAVE), 0, p->stream, in, validity, n, quarters, nquarters, vec_ok, (uint64_t)0);
   AGPU_LAUNCH_CHECK();
+  return sum_tree_after_quarters(p, quarters, nspans, groups, buf0, buf1, out);
+}
+
+// the levels behind the quarter sums (launch_sum_tree_f32 and the one-pass statistics share them)
+static agpu_status sum_tree_after_quarters(agpu_pipeline* p, const float* quarters, uint64_t nspans, float* groups, float* buf0, float* buf1,
+                                           float* out) {
+  const uint64_t ngroups = (nspans + 255) / 256;
   if (ngroups > 1 && ngroups <= 256) {  // 16.8 M … 4.29e9 rows: combine + the last level in ONE workgroup
     hipLaunchKernelGGL(sum_tree_combine_finish_kernel, dim3(1), dim3(AGPU_FOLD_BLOCK_SUM), 0, p->stream, (const float*)quarters, nspans,
                        (uint32_t)ngroups, out);
@@ -571,6 +590,152 @@ static agpu_status launch_sum_tree_f32(agpu_pipeline* p, const float* in, const 
                        (const uint8_t*)nullptr, buf0, buf1, ngroups, out, 0);
     AGPU_LAUNCH_CHECK();
   }
+  return AGPU_OK;
+}
+
+// ---------------------------------------------------------------- whole-column f32 statistics in ONE pass
+// north_star config 5 wants sum / min / max of one f32 column (the bench adds the f64-accumulated sum): four agpu_reduce calls read the
+// column four times — 4 × 0.58 ms at 1e9 rows.  Here one wave retires one FULL aligned 16 384-row quarter for all four statistics from the
+// same registers: the tree sum exactly as quarter_tree_sum does it (→ quarters[q]), min and max with NaN rows mapped to the identities
+// (partial = NaN exactly when the whole quarter was NaN: RedMinMaxF32's 4-byte partial), the f64 sum in reduce_wave_kernel's order (four
+// interleaved accumulators per lane over the lane's 64 vectors, (a0+a1)+(a2+a3), shift-down shuffles) — so every partial, and with the
+// SAME finishing launches behind them every result, is bit-identical to what the four separate reductions give.  4 B/row, HBM-bound: ≈ 8
+// VALU instructions per row (two of them f64) ride under the loads.
+__global__ __launch_bounds__(AGPU_WAVE) void stats_quarter_kernel(const float* in, float* quarters, float* mins, float* maxs, double* dsums,
+                                                                 uint64_t nfull) {
+  constexpr int UNR = 8;
+  const uint32_t lane = threadIdx.x;
+  for (uint64_t q = blockIdx.x; q < nfull; q += gridDim.x) {
+    const uint64_t base = q * WAVE_ROWS;
+    float acc = 0.0f;
+    float mn = __builtin_inff(), mx = -__builtin_inff();  // the identities: mn > mx for as long as no non-NaN row has been seen
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int j0 = 0; j0 < AGPU_WAVE; j0 += UNR) {
+      f32x4 v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(in + base + (uint64_t)(j0 + u) * 256 + lane * 4));
+      float s[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) {
+        const float x0 = v[u].x, x1 = v[u].y, x2 = v[u].z, x3 = v[u].w;
+        s[u] = (x0 + x1) + (x2 + x3);
+        a0 += (double)x0;
+        a1 += (double)x1;
+        a2 += (double)x2;
+        a3 += (double)x3;
+        // NaN rows: a QUIET NaN operand makes v_min_f32 / v_max_f32 return the other one (IEEE mode), so one canonicalising v_max_f32 x, x per
+        // row (it quiets a signalling NaN) replaces the compare and the two selects that map NaN to the identities — same result: the
+        // extremes of the non-NaN rows, −0.0 below +0.0
+        const float c0 = __builtin_canonicalizef(x0), c1 = __builtin_canonicalizef(x1), c2 = __builtin_canonicalizef(x2), c3 = __builtin_canonicalizef(x3);
+        mn = RedMinMaxF32<false>::pick(RedMinMaxF32<false>::pick(mn, c0), RedMinMaxF32<false>::pick(c1, c2));
+        mn = RedMinMaxF32<false>::pick(mn, c3);
+        mx = RedMinMaxF32<true>::pick(RedMinMaxF32<true>::pick(mx, c0), RedMinMaxF32<true>::pick(c1, c2));
+        mx = RedMinMaxF32<true>::pick(mx, c3);
+      }
+      const float t = transpose_reduce8(s, lane);
+      if ((lane >> 3) == (uint32_t)(j0 >> 3)) acc = t;
+    }
+    const float r = wave_tree_sum(acc);
+    double d = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) {
+      d = d + __shfl_down(d, off);
+      mn = RedMinMaxF32<false>::pick(mn, __shfl_down(mn, off));
+      mx = RedMinMaxF32<true>::pick(mx, __shfl_down(mx, off));
+    }
+    if (lane == 0) {
+      const bool seen = mn <= mx;  // any non-NaN row v leaves mn ≤ v ≤ mx; the untouched identities are +inf > −inf
+      quarters[q] = r;
+      mins[q] = seen ? mn : __builtin_nanf("");
+      maxs[q] = seen ? mx : __builtin_nanf("");
+      dsums[q] = d;
+    }
+  }
+}
+
+// ONE finishing launch behind stats_quarter_kernel, four workgroups side by side: block 0 the tree sum (the quarters at and beyond the end of
+// the column in the tree sum's guarded form, one wave each, then sum_tree_combine_finish_kernel's body), blocks 1 / 2 / 3 min / max / the f64
+// sum through reduce_fold_finish_kernel's body with the SAME thread count that kernel would be launched with (the fold's order, hence the f64
+// sum's last bits, is a function of it).  do_sum = 0 (≤ 256 or > 65 536 spans): the host runs the tree sum's own launches instead.
+__global__ __launch_bounds__(AGPU_FOLD_BLOCK) void stats_finish_kernel(const float* in, uint64_t n, float* quarters, uint64_t nfull, uint64_t nquarters,
+                                                                      uint64_t nspans, uint32_t ngroups, int do_sum, const float* mins, const float* maxs,
+                                                                      const double* dsums, const float* tail_in, uint32_t tail, uint32_t nthr,
+                                                                      agpu_f32_stats* out) {
+  __shared__ float sh[256];
+  __shared__ MinMaxF32 ldsm[AGPU_FOLD_BLOCK / AGPU_WAVE];
+  __shared__ double ldsd[AGPU_FOLD_BLOCK / AGPU_WAVE];
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) out->reserved = 0;
+    if (do_sum) {
+      const uint32_t wave = threadIdx.x / AGPU_WAVE;
+      if (nfull + wave < nquarters) {  // ≤ 4 quarters: the one that crosses the end of the column and the span's zero padding
+        const float r = quarter_tree_sum<true, false>(in, nullptr, (nfull + wave) * WAVE_ROWS, n);
+        if ((threadIdx.x & (AGPU_WAVE - 1)) == 0) quarters[nfull + wave] = r;
+      }
+      __threadfence_block();
+      __syncthreads();
+      sum_combine_finish_body(quarters, nspans, ngroups, &out->sum, sh);
+    }
+  } else if (blockIdx.x == 1) {
+    fold_finish_body<float, RedMinMaxF32<false>>(mins, nfull, tail_in, tail, &out->min, nthr, ldsm);
+  } else if (blockIdx.x == 2) {
+    fold_finish_body<float, RedMinMaxF32<true>>(maxs, nfull, tail_in, tail, &out->max, nthr, ldsm);
+  } else {
+    fold_finish_body<float, RedSumF64>(dsums, nfull, tail_in, tail, &out->sum_f64, nthr, ldsd);
+  }
+}
+
+static agpu_status launch_stats_f32(agpu_pipeline* p, const float* in, const uint8_t* validity, uint64_t n, agpu_f32_stats* out) {
+  float* o_sum = &out->sum;
+  float* o_min = &out->min;
+  float* o_max = &out->max;
+  double* o_f64 = &out->sum_f64;
+  const uint64_t nfull = n / WAVE_ROWS;
+  if (validity || !aligned16(in) || nfull < 64) {  // null-aware, unaligned or small columns: the four reductions one after the other
+    AGPU_HIP(hipMemsetAsync(&out->reserved, 0, sizeof(out->reserved), p->stream));
+    agpu_status st = launch_sum_tree_f32(p, in, validity, n, o_sum);
+    if (st == AGPU_OK) st = launch_reduce<float, RedMinMaxF32<false>>(p, in, validity, n, o_min);
+    if (st == AGPU_OK) st = launch_reduce<float, RedMinMaxF32<true>>(p, in, validity, n, o_max);
+    if (st == AGPU_OK) st = launch_reduce<float, RedSumF64>(p, in, validity, n, o_f64);
+    return st;
+  }
+  const uint64_t nspans = (n + SPAN_ROWS - 1) / SPAN_ROWS, nquarters = nspans * 4;
+  const uint64_t ngroups = (nspans + 255) / 256;
+  const size_t level_cap = (size_t)((ngroups + 255) / 256 + 1);
+  // scratch: the tree sum's layout (launch_sum_tree_f32) + mins[nfull] + maxs[nfull] + dsums[nfull], every piece 16-byte aligned
+  const size_t f_tree = ((size_t)nquarters + 4 + (size_t)ngroups + 4 + 2 * level_cap + 8 + 3) & ~(size_t)3;
+  const size_t f_part = ((size_t)nfull + 3) & ~(size_t)3;
+  void* scratch = nullptr;
+  agpu_status st = agpu_scratch(p, (f_tree + 2 * f_part) * sizeof(float) + (size_t)nfull * sizeof(double) + 16, &scratch);
+  if (st != AGPU_OK) return st;
+  float* quarters = static_cast<float*>(scratch);
+  float* groups = quarters + nquarters + 4;
+  float* buf0 = groups + ngroups + 4;
+  float* buf1 = buf0 + level_cap;
+  float* mins = quarters + f_tree;
+  float* maxs = mins + f_part;
+  double* dsums = reinterpret_cast<double*>(maxs + f_part);
+  const uint64_t g = nfull < 0x3FFFFFFFull ? nfull : 0x3FFFFFFFull;
+  hipLaunchKernelGGL(stats_quarter_kernel, dim3((unsigned)g), dim3(AGPU_WAVE), 0, p->stream, in, quarters, mins, maxs, dsums, nfull);
+  AGPU_LAUNCH_CHECK();
+  const bool fused_sum = ngroups > 1 && ngroups <= 256 && nquarters - nfull <= AGPU_FOLD_BLOCK / AGPU_WAVE;
+  if (!fused_sum) {  // ≤ 16.7 M or > 4.29e9 rows: the tree sum's own launches behind the quarters
+    if (nfull < nquarters) {
+      hipLaunchKernelGGL((sum_tree_quarter_kernel<false>), dim3((unsigned)(nquarters - nfull)), dim3(AGPU_WAVE), 0, p->stream, in, (const uint8_t*)nullptr, n,
+                         quarters, nquarters, 1, nfull);
+      AGPU_LAUNCH_CHECK();
+    }
+    st = sum_tree_after_quarters(p, quarters, nspans, groups, buf0, buf1, o_sum);
+    if (st != AGPU_OK) return st;
+  }
+  // min / max / f64 sum: reduce_wave_kernel's finishing workgroup over the same partials (the < 1-quarter tail's rows included), with the thread
+  // count launch_reduce would give it
+  const float* tail_in = in + nfull * WAVE_ROWS;
+  const uint32_t tail = (uint32_t)(n - nfull * WAVE_ROWS);
+  const uint32_t nthr = nfull > 16384 ? AGPU_FOLD_BLOCK : 256;
+  hipLaunchKernelGGL(stats_finish_kernel, dim3(4), dim3(AGPU_FOLD_BLOCK), 0, p->stream, in, n, quarters, nfull, nquarters, nspans, (uint32_t)ngroups,
+                     fused_sum ? 1 : 0, (const float*)mins, (const float*)maxs, (const double*)dsums, tail_in, tail, nthr, out);
+  AGPU_LAUNCH_CHECK();
   return AGPU_OK;
 }
 
@@ -762,6 +927,14 @@ agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* v
   AGPU_BIND(p);
   AGPU_REQUIRE(out_dev && (n == 0 || in), AGPU_ERR_ARG, "null pointer");
   return launch_reduce<float, RedSumF64>(p, in, validity, n, out_dev);
+}
+
+agpu_status agpu_reduce_stats_f32(agpu_pipeline* p, const float* in, const void* validity, uint64_t n, agpu_f32_stats* out_dev) {
+  AGPU_BIND(p);
+  AGPU_REQUIRE(out_dev && (n == 0 || in), AGPU_ERR_ARG, "null pointer");
+  AGPU_REQUIRE(n == 0 || aligned_to(in, 4), AGPU_ERR_SHAPE, "input must be 4-byte aligned");
+  AGPU_REQUIRE(aligned_to(out_dev, 8), AGPU_ERR_SHAPE, "the statistics record must be 8-byte aligned");
+  return launch_stats_f32(p, in, static_cast<const uint8_t*>(validity), n, out_dev);
 }
 
 }  // extern "C"

@@ -45,6 +45,35 @@ def _sum_op(self, pipeline: ArrowComputePipeline):
 
 impl((Float32ArrayGPU, Int32ArrayGPU, UInt32ArrayGPU), "sum", _sum_op)
 
+
+# ---- whole-column statistics in ONE pass (no counterpart in the reference: its only reduction is Sum; north_star config 5 names sum / min /
+# max of one f32 column).  `col.stats_op(p)` / `col.stats()` → Float32Stats: the 24-byte record stays on the device until values() asks.
+class Float32Stats:
+    """agpu_reduce_stats_f32's record {sum (the reference's tree order), min, max (Arrow's NaN rule), sum_f64}: every field bit-identical
+    to the separate reduction of the same column; the column is read once."""
+
+    def __init__(self, buf, gpu_device):
+        self.data, self.gpu_device = buf, gpu_device
+
+    def values(self) -> dict:
+        import numpy as np
+
+        raw = self.gpu_device.retrive_data(self.data, 24)
+        f = raw[:12].view(np.float32)
+        return {"sum": f[0], "min": f[1], "max": f[2], "sum_f64": raw[16:24].view(np.float64)[0]}
+
+
+def _stats_op(self, pipeline: ArrowComputePipeline):
+    dev = self.gpu_device
+    out = dev.create_empty_buffer(32)
+    validity = vp(self.null_buffer.bit_buffer) if getattr(self, "null_buffer", None) is not None else None
+    capi.call("agpu_reduce_stats_f32", pipeline._handle, vp(self.data), validity, self.len, vp(out))
+    pipeline.keep(self.data, out)
+    return Float32Stats(out, dev)
+
+
+impl(_F32, "stats", _stats_op)
+
 # ---- dyn dispatch  [arithmetic_kernels.rs:122-175]
 _date_mix = ((Int32ArrayGPU, Date32ArrayGPU), (Date32ArrayGPU, Int32ArrayGPU))
 add_scalar_dyn, add_scalar_op_dyn = dyn_binary(

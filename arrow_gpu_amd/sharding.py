@@ -377,6 +377,11 @@ class Communicator:
     def reduce_sum_f64(self, pipeline, values, validity, n_local: int, out) -> None:
         capi.call("agpu_comm_reduce_sum_f64", self._h, pipeline._handle, _ptr(values), _ptr(validity), n_local, _ptr(out))
 
+    def reduce_stats_f32(self, pipeline, values, validity, n_local: int, out) -> None:
+        """sum / min / max / f64 sum of a sharded f32 column with ONE pass over this rank's shard (agpu_comm_reduce_stats_f32): `out` = a
+        24-byte agpu_f32_stats record on the device, every field what `reduce` / `reduce_sum_f64` give for that statistic."""
+        capi.call("agpu_comm_reduce_stats_f32", self._h, pipeline._handle, _ptr(values), _ptr(validity), n_local, _ptr(out))
+
     def final_reduce(self, pipeline, op: int, dtype: int, partial, n_local: int, out, f64: bool = False) -> None:
         capi.call("agpu_comm_final_reduce", self._h, pipeline._handle, op, dtype, 1 if f64 else 0, _ptr(partial), n_local, _ptr(out))
 

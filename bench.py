@@ -724,7 +724,46 @@ def main():
             except Exception as e:  # noqa: BLE001
                 detail, mine_ok = {"error": f"{type(e).__name__}: {e}"}, False
             verified = int(round(across_ranks([0.0 if mine_ok else 1.0], capi.RED_SUM)[0])) == 0
+        # ---- the same four statistics in ONE pass over the shard (agpu_reduce_stats_f32 / agpu_comm_reduce_stats_f32: the column is read once,
+        # every field bit-identical to the separate reduction) — local kernel timed like the others, then the collective form end to end
+        one = {}
+        rec_loc, rec_all = dev.create_empty_buffer(32), dev.create_empty_buffer(32)
+        one_launch = lambda: capi.call("agpu_reduce_stats_f32", h, vp(fa), None, n, vp(rec_loc))  # noqa: E731
+        one_launch()
+        pairs = [(ev(), ev()) for _ in range(5)]
+        for s_, e_ in pairs:
+            capi.call("agpu_event_record", s_, h)
+            one_launch()
+            capi.call("agpu_event_record", e_, h)
+        one_ms = mean_ms(pairs)
+
+        def record_of(buf):
+            raw = dev.retrive_data(buf, 24, pipeline=p)
+            f_ = raw[:12].view(_np.float32)
+            return {"sum": f_[0], "min": f_[1], "max": f_[2], "sum_f64": raw[16:24].view(_np.float64)[0]}
+
+        def same_bits(a_, b_):
+            return all(_np.array([a_[k]]).tobytes() == _np.array([b_[k]], _np.array([a_[k]]).dtype).tobytes() for k in ("sum", "min", "max", "sum_f64"))
+
+        one_local_same = same_bits(record_of(rec_loc), loc)
+        comm.reduce_stats_f32(p, fa, None, n, rec_all)  # warm
+        barrier()
+        os_, oe_ = ev(), ev()
+        capi.call("agpu_event_record", os_, h)
+        comm.reduce_stats_f32(p, fa, None, n, rec_all)
+        capi.call("agpu_event_record", oe_, h)
+        comm.sync(p)
+        one_all_ms = ms_between(os_, oe_)
+        one_all_same = same_bits(record_of(rec_all), got)
+        one_all_max = across_ranks([one_all_ms], capi.RED_MAX)[0]
+        one_ok = int(round(across_ranks([0.0 if (one_local_same and one_all_same) else 1.0], capi.RED_SUM)[0])) == 0
+        one = {"local_ms": round(one_ms, 4), "local_GBps": round(4.0 * n / one_ms / 1e6, 1), "frac_hbm_peak": round(4.0 * n / one_ms / 1e6 / HBM_PEAK_GBPS, 4),
+               "with_final_reduce_ms": round(one_all_ms, 4), "with_final_reduce_ms_max_over_ranks": round(one_all_max, 4),
+               "bit_identical_to_the_four_reductions_all_ranks": one_ok,
+               "what": "agpu_reduce_stats_f32 / agpu_comm_reduce_stats_f32: sum (reference tree), min, max and the f64 sum from ONE read of the shard "
+                       "(4 B/row) + the same finishing launches and final reduces; every field compared bit for bit with the separate reductions above"}
         local_sum_ms = sum(stats[k]["local_ms"] for k in ("sum", "min", "max", "sum_f64"))
+        one["speedup_vs_four_local_launches"] = round(local_sum_ms / one_ms, 3)
         four_max = across_ranks([four_ms], capi.RED_MAX)[0]
         extra["reduce_sum_min_max"] = {
             "rows_total": total_rows, "sum_f32_reference_tree": float(got["sum"]),
@@ -739,6 +778,7 @@ def main():
             "aggregate_GBps": round(4 * 4.0 * total_rows / four_max / 1e6, 1),
             "final_reduce_overhead_ms": round(four_ms - local_sum_ms, 4),
             "final_reduce": f"C ABI agpu_comm_reduce: RCCL all-gather of one 16-byte record per rank (world {world}) + rank-ordered combine",
+            "one_pass": one,
         }
     except Exception as e:  # noqa: BLE001
         extra["reduce_sum_min_max"] = {"error": f"{type(e).__name__}: {e}"}

@@ -611,6 +611,32 @@ class PrimitiveArrayGpu {  // [crates/array/src/array/primitive_array_gpu.rs:12-
     return PrimitiveArrayGpu(out, gpu_device, 1, std::nullopt);
   }
   AGPU_DEFAULT_IMPL(sum, (), (p))
+  // sum (the reference's tree order) / min / max (Arrow's NaN rule) / f64-accumulated sum in ONE pass over the column (agpu_reduce_stats_f32:
+  // no counterpart in the reference, whose only reduction is Sum); null slots contribute the identities.  The record stays on the device.
+  struct Stats {
+    BufferPtr data;
+    DevicePtr gpu_device;
+    agpu_f32_stats values() const {  // blocking
+      const auto raw = gpu_device->retrive_data(data, sizeof(agpu_f32_stats));
+      agpu_f32_stats s;
+      std::memcpy(&s, raw.data(), sizeof(s));
+      return s;
+    }
+  };
+  Stats stats_op(ArrowComputePipeline& p) const {
+    static_assert(std::is_same_v<T, float>, "one-pass statistics: f32");
+    auto out = gpu_device->create_empty_buffer(32);
+    const void* validity = null_buffer ? null_buffer->bit_buffer->ptr : nullptr;
+    check(agpu_reduce_stats_f32(p.h(), static_cast<const float*>(data->ptr), validity, len, static_cast<agpu_f32_stats*>(out->ptr)), "agpu_reduce_stats_f32");
+    p.keep.insert(p.keep.end(), {data, out});
+    return Stats{out, gpu_device};
+  }
+  Stats stats() const {
+    ArrowComputePipeline p(gpu_device);
+    auto out = stats_op(p);
+    p.finish();
+    return out;
+  }
 
   // ---- arrow_gpu_compare [crates/compare/src/lib.rs:41-172]
 #define AGPU_CMP(NAME, OP)                                                                                  \
@@ -1525,6 +1551,16 @@ template <typename T> PrimitiveArrayGpu<T> min_sharded_op(const PrimitiveArrayGp
 }
 template <typename T> PrimitiveArrayGpu<T> max_sharded_op(const PrimitiveArrayGpu<T>& s, Communicator& c, ArrowComputePipeline& p) {
   return reduce_sharded_op(s, AGPU_RED_MAX, c, p);
+}
+// sum / min / max / f64 sum of a sharded f32 column with ONE pass over this rank's shard (agpu_comm_reduce_stats_f32)
+inline PrimitiveArrayGpu<float>::Stats stats_sharded_op(const PrimitiveArrayGpu<float>& shard, Communicator& comm, ArrowComputePipeline& p,
+                                                        bool use_validity = false) {
+  auto out = shard.gpu_device->create_empty_buffer(32);
+  const void* validity = use_validity && shard.null_buffer ? shard.null_buffer->bit_buffer->ptr : nullptr;
+  check(agpu_comm_reduce_stats_f32(comm.raw, p.h(), static_cast<const float*>(shard.data->ptr), validity, shard.len,
+                                   static_cast<agpu_f32_stats*>(out->ptr)), "agpu_comm_reduce_stats_f32");
+  p.keep.insert(p.keep.end(), {shard.data, out});
+  return PrimitiveArrayGpu<float>::Stats{out, shard.gpu_device};
 }
 #define AGPU_SHARDED_DEFAULT(NAME)                                                                 \
   template <typename T> PrimitiveArrayGpu<T> NAME(const PrimitiveArrayGpu<T>& s, Communicator& c) { \

@@ -435,6 +435,19 @@ agpu_status agpu_bitmap_merge_validity_count(agpu_pipeline* p, const void* va, c
 agpu_status agpu_reduce(agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, const void* in, const void* validity,
                         uint64_t n, void* out_dev);
 agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* validity, uint64_t n, double* out_dev);
+/* Whole-column f32 statistics in ONE pass (no counterpart in the reference, whose only reduction is `sum` [aggregate_kernels.rs:24-51];
+ * north_star config 5 wants sum / min / max of one column — three agpu_reduce calls read it three times).  out_dev receives one record:
+ * sum = agpu_reduce(SUM) — the reference's tree order —, min / max = agpu_reduce(MIN / MAX) (Arrow's NaN rule), sum_f64 =
+ * agpu_reduce_sum_f64, each BIT-IDENTICAL to the separate call on the same column; the column is read once (4 B/row) when it is 16-byte
+ * aligned, has no validity bitmap and at least 2^20 rows, otherwise the four reductions run one after the other.  8-byte aligned out_dev. */
+typedef struct agpu_f32_stats {
+  float sum;
+  float min;
+  float max;
+  uint32_t reserved; /* 0 */
+  double sum_f64;
+} agpu_f32_stats;    /* 24 bytes */
+agpu_status agpu_reduce_stats_f32(agpu_pipeline* p, const float* in, const void* validity, uint64_t n, agpu_f32_stats* out_dev);
 
 /* ---------------------------------------------------------------- swizzle: take / put / merge
  * width = bytes per element (1, 2 or 4; the reference implements 4 and Boolean only).
@@ -527,6 +540,10 @@ agpu_status agpu_comm_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, 
 /* f32 column summed in f64 per shard, shard sums added in rank order in f64 (order-robust statistic for huge columns) */
 agpu_status agpu_comm_reduce_sum_f64(agpu_comm* c, agpu_pipeline* p, const float* in, const void* validity,
                                      uint64_t n_local, double* out_dev);
+/* agpu_reduce_stats_f32 over this rank's shard + the four final reduces (one 16-byte record per rank and statistic, combined in rank
+ * order): every field equals what agpu_comm_reduce / agpu_comm_reduce_sum_f64 give for that statistic; the shard is read ONCE. */
+agpu_status agpu_comm_reduce_stats_f32(agpu_comm* c, agpu_pipeline* p, const float* in, const void* validity, uint64_t n_local,
+                                       agpu_f32_stats* out_dev);
 /* the same final reduce for a per-shard statistic the caller already holds on the device (1 element of dtype at
  * partial_dev; kind_f64 != 0: an f64 sum) */
 agpu_status agpu_comm_final_reduce(agpu_comm* c, agpu_pipeline* p, agpu_reduce_op op, agpu_dtype dtype, int32_t kind_f64,
