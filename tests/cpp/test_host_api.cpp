@@ -240,6 +240,11 @@ int main() {
     CHECK(Float32ArrayGPU::broadcast(5.0f, 256 * 256, device).sum().raw_values() == std::vector<float>{327680.0f});
     CHECK(Float32ArrayGPU::broadcast(5.0f, 4 * 1024 * 1024, device).sum().raw_values() == std::vector<float>{20971520.0f});
     CHECK(Int32ArrayGPU::broadcast(-5, 256 * 256, device).sum().raw_values() == std::vector<int32_t>{-327680});
+    // the same column's statistics in ONE pass (agpu_reduce_stats_f32; beyond the reference): sum bit-identical to sum()
+    const auto st = Float32ArrayGPU::broadcast(5.0f, 4 * 1024 * 1024, device).stats().values();
+    CHECK(st.sum == 20971520.0f && st.min == 5.0f && st.max == 5.0f && st.sum_f64 == 20971520.0 && st.reserved == 0);
+    const auto sn = Float32ArrayGPU::from_optional_slice({1.0f, N, -2.0f, 7.5f}, device).stats().values();  // null slots contribute the identities
+    CHECK(sn.sum == 6.5f && sn.min == -2.0f && sn.max == 7.5f && sn.sum_f64 == 6.5);
   }
   {  // crates/compare/src/i32.rs:250-293 — eq with nulls (fused validity AND); f32.rs NaN table
     auto a = Int32ArrayGPU::from_optional_slice({0, 3, 3, 0, 3, N, N, 4, 40, 7}, device);
