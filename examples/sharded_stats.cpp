@@ -26,7 +26,8 @@ using namespace arrow_gpu;
 
 struct RankResult {
   float sum = 0, mn = 0, mx = 0;
-  double stats_ms = 0, step_s = 0, add_ms = 0, eq_ms = 0;
+  double stats_ms = 0, step_s = 0, add_ms = 0, eq_ms = 0, one_pass_ms = 0;
+  bool one_pass_same = false;
   uint64_t rows = 0;
   int rccl_ranks = 0, distinct_devices = 0;
   std::string error;
@@ -128,6 +129,17 @@ int main(int argc, char** argv) {
         out.sum = s.raw_values()[0];
         out.mn = lo.raw_values()[0];
         out.mx = hi.raw_values()[0];
+        // … and the same statistics (+ the f64-accumulated sum) from ONE read of the shard: every field must be what the calls above gave
+        (void)stats_sharded_op(shard, comm, p);
+        comm.sync(p);
+        comm.barrier(p);
+        t0 = std::chrono::steady_clock::now();
+        auto one = stats_sharded_op(shard, comm, p);
+        comm.sync(p);
+        comm.barrier(p);
+        out.one_pass_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        const agpu_f32_stats st = one.values();
+        out.one_pass_same = memcmp(&st.sum, &out.sum, 4) == 0 && memcmp(&st.min, &out.mn, 4) == 0 && memcmp(&st.max, &out.mx, 4) == 0;
       }
       for (int k = 1; k < 3; k++) agpu_free(dev->raw, f[k]);
       for (int k = 0; k < 6; k++) agpu_free(dev->raw, c[k]);
@@ -140,7 +152,8 @@ int main(int argc, char** argv) {
   rank_main(0);
   for (auto& t : ts) t.join();
   bool ok = true;
-  double stats_ms = 0, step_s = 0, add_lo = 1e30, add_hi = 0, eq_lo = 1e30, eq_hi = 0;
+  double stats_ms = 0, step_s = 0, add_lo = 1e30, add_hi = 0, eq_lo = 1e30, eq_hi = 0, one_ms = 0;
+  bool one_same = true;
   for (int r = 0; r < world; r++) {
     const RankResult& x = res[(size_t)r];
     if (!x.error.empty()) {
@@ -149,6 +162,8 @@ int main(int argc, char** argv) {
     }
     ok = ok && memcmp(&x.sum, &res[0].sum, 4) == 0 && x.mn == res[0].mn && x.mx == res[0].mx;
     stats_ms = std::max(stats_ms, x.stats_ms);
+    one_ms = std::max(one_ms, x.one_pass_ms);
+    one_same = one_same && x.one_pass_same;
     step_s = std::max(step_s, x.step_s);
     add_lo = std::min(add_lo, x.add_ms), add_hi = std::max(add_hi, x.add_ms);
     eq_lo = std::min(eq_lo, x.eq_ms), eq_hi = std::max(eq_hi, x.eq_ms);
@@ -162,10 +177,10 @@ int main(int argc, char** argv) {
          "sum/min/max with the RCCL final reduce\", \"world\": %d, \"rccl_ranks\": %d, \"distinct_devices\": %d, \"scaling\": \"%s\", \"rows_total\": %llu, \"rows_rank0\": %llu, "
          "\"steps\": %d, \"value_GBps\": %.2f, \"ms_per_step\": %.4f, \"add_ms\": {\"min\": %.4f, \"max\": %.4f}, "
          "\"eq_ms\": {\"min\": %.4f, \"max\": %.4f}, \"sum\": %.9g, \"min\": %.9g, \"max\": %.9g, \"ms_3_statistics\": %.4f, "
-         "\"statistics_aggregate_GBps\": %.1f, \"identical_on_all_ranks\": true, \"runtime\": \"%s\"}\n",
+         "\"statistics_aggregate_GBps\": %.1f, \"ms_one_pass_statistics\": %.4f, \"one_pass_identical\": %s, \"identical_on_all_ranks\": true, \"runtime\": \"%s\"}\n",
          world, res[0].rccl_ranks, res[0].distinct_devices, strong ? "strong" : "weak", (unsigned long long)total, (unsigned long long)res[0].rows, steps,
          20.5 * (double)total * steps / step_s / 1e9, step_s / steps * 1e3, add_lo, add_hi, eq_lo, eq_hi, res[0].sum, res[0].mn,
-         res[0].mx, stats_ms, 3.0 * 4.0 * (double)total / stats_ms / 1e6, Communicator::runtime_info().c_str());
+         res[0].mx, stats_ms, 3.0 * 4.0 * (double)total / stats_ms / 1e6, one_ms, one_same ? "true" : "false", Communicator::runtime_info().c_str());
   fflush(stdout);  // before the static destructors of the runtimes underneath
   return 0;
 }

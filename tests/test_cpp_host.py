@@ -106,6 +106,7 @@ def test_sharded_stats_example_matches_the_sharded_spec():
     assert line["identical_on_all_ranks"] is True and world >= 1 and line["scaling"] == "weak"
     assert line["value_GBps"] > 0 and line["add_ms"]["min"] > 0 and line["eq_ms"]["max"] >= line["eq_ms"]["min"] > 0
     assert "librccl" in line["runtime"]
+    assert line["one_pass_identical"] is True and line["ms_one_pass_statistics"] > 0  # stats_sharded_op: the three statistics from ONE read of the shard
     shards = [O.synth_f32(rows, 20250418, k * rows, -1000.0, 1000.0) for k in range(world)]
     exp = O.sharded_reduce(O.RED_SUM, O.F32, shards)
     assert np.float32(line["sum"]).view(np.uint32) == np.float32(exp).view(np.uint32), (line["sum"], exp)
