@@ -308,6 +308,50 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
   return launch_take_direct(p, width, values, n_values, idx, out, n_idx, nullptr);
 }
 
+// The columns of one table by ONE index column.  At pipeline sizes the index work of the merge-back take (a third of its time) is done once
+// for all of them (launch_take_mergeback's `more`); otherwise — small takes, sorted / local indices (the probe), unsupported widths — column
+// by column through agpu_take.  The first column decides (width of the probe's threshold, want_bucketed): the columns share n_values.
+agpu_status agpu_take_columns(agpu_pipeline* p, int32_t n_cols, const int32_t* widths, const void* const* values, uint64_t n_values,
+                              const uint32_t* idx, void* const* outs, uint64_t n_idx) {
+  {
+    AGPU_BIND(p);
+    AGPU_REQUIRE(n_cols >= 0 && n_cols <= 64, AGPU_ERR_ARG, "0..64 columns");
+    if (n_cols == 0 || n_idx == 0) return AGPU_OK;
+    AGPU_REQUIRE(widths && values && outs && idx, AGPU_ERR_ARG, "null pointer");
+    for (int32_t c = 0; c < n_cols; c++) AGPU_REQUIRE(values[c] && outs[c], AGPU_ERR_ARG, "null column pointer");
+    AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
+    const int w0 = widths[0];
+    if (n_cols > 1 && (w0 == 1 || w0 == 2 || w0 == 4) && n_values != UINT64_MAX && n_idx >= TK2_TILE &&
+        want_bucketed(p, w0, n_idx, n_values, n_idx, false)) {
+      bool adaptive = p->tune.gather_bucket == 0 || p->tune.gather_bucket == 4;
+      bool go_direct = false;
+      if (p->tune.gather_bucket == 0) {
+        const int d = probe_decide(p, idx, nullptr, n_idx, w0 == 4 ? 5 : w0 == 2 ? 6 : 7, 0);
+        if (d >= 0 && (d & 1)) go_direct = true;
+        else if (d >= 0) adaptive = false;
+      }
+      if (!go_direct) {
+        TakeCol more[64];
+        for (int32_t c = 1; c < n_cols; c++) more[c - 1] = TakeCol{widths[c], values[c], outs[c]};
+        const agpu_status ms = launch_take_mergeback(p, w0, values[0], n_values, idx, outs[0], n_idx, nullptr, nullptr, adaptive, nullptr, 0, nullptr,
+                                                     more, n_cols - 1);
+        if (ms != AGPU_ERR_UNSUPPORTED) return ms;
+      } else {
+        for (int32_t c = 0; c < n_cols; c++) {
+          const agpu_status st = launch_take_direct(p, widths[c], values[c], n_values, idx, outs[c], n_idx, nullptr);
+          if (st != AGPU_OK) return st;
+        }
+        return AGPU_OK;
+      }
+    }
+  }
+  for (int32_t c = 0; c < n_cols; c++) {
+    const agpu_status st = agpu_take(p, widths[c], values[c], n_values, idx, outs[c], n_idx);
+    if (st != AGPU_OK) return st;
+  }
+  return AGPU_OK;
+}
+
 agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const void* validity,
                                const uint32_t* idx, void* out, void* out_validity, uint64_t n_idx) {
   if (!validity) return agpu_take(p, width, values, n_values, idx, out, n_idx);

@@ -201,6 +201,39 @@ def take_dyn(operand_1, indexes):
     return out
 
 
+def take_columns_op(columns, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipeline) -> list:
+    """take of the columns of ONE table (primitive arrays of equal length, 1 / 2 / 4-byte values) by one index column — what
+    `[c.take_op(indexes, p) for c in columns]` gives, through agpu_take_columns: at pipeline sizes everything the merge-back take does to the
+    INDEX column runs once for all columns (no counterpart in the reference, which takes array by array: routines/src/lib.rs:122-143).
+    Validity bitmaps are taken per column (take_null_buffer)."""
+    import ctypes as C
+
+    if not columns:
+        return []
+    n_src = columns[0].len
+    for c in columns:
+        if not isinstance(c, PrimitiveArrayGpu) or c.len != n_src:
+            raise capi.ArrowErrorGPU("ShapeError", "take_columns: primitive columns of one length", capi.ERR_SHAPE)
+    dev = columns[0].gpu_device
+    outs = [dev.create_empty_buffer(max(indexes.len * c.ITEM_SIZE, 1)) for c in columns]
+    k = len(columns)
+    widths = (C.c_int32 * k)(*[c.ITEM_SIZE for c in columns])
+    vals = (C.c_void_p * k)(*[c.data.ptr for c in columns])
+    outp = (C.c_void_p * k)(*[o.ptr for o in outs])
+    capi.call("agpu_take_columns", pipeline._handle, k, widths, vals, n_src, vp(indexes.data), outp, indexes.len)
+    pipeline.keep(indexes.data, *[c.data for c in columns], *outs)
+    return [type(c)(o, dev, indexes.len, take_null_buffer(c.null_buffer, indexes, pipeline)) for c, o in zip(columns, outs)]
+
+
+def take_columns(columns, indexes: UInt32ArrayGPU) -> list:
+    if not columns:
+        return []
+    p = ArrowComputePipeline(columns[0].gpu_device)
+    out = take_columns_op(columns, indexes, p)
+    p.finish()
+    return out
+
+
 def put_op_dyn(src: ArrowArrayGPU, src_indexes, dst: ArrowArrayGPU, dst_indexes, pipeline) -> None:
     if type(src) is type(dst) and type(src) in _PUT_DYN:
         return src.put_op(src_indexes, dst, dst_indexes, pipeline)
@@ -215,4 +248,4 @@ def put_dyn(src, src_indexes, dst, dst_indexes) -> None:
     p.sync()
 
 
-__all__ = ["merge_dyn", "merge_op_dyn", "take_dyn", "take_op_dyn", "put_dyn", "put_op_dyn", "merge_null_buffers_op"]
+__all__ = ["merge_dyn", "merge_op_dyn", "take_dyn", "take_op_dyn", "put_dyn", "put_op_dyn", "merge_null_buffers_op", "take_columns", "take_columns_op"]

@@ -88,7 +88,7 @@ def check_config_windows(cfg_windows):
             idx = O.synth_i32(rows, SEED + 8, w0, m).view(np.uint32)
             ok = True
             if "got" in w:
-                exp = np.array([O.synth_i32(1, SEED + 7, int(i), 0)[0] for i in idx], np.int32).view(np.uint32)
+                exp = np.array([O.synth_i32(1, w.get("values_seed", SEED + 7), int(i), 0)[0] for i in idx], np.int32).view(np.uint32)
                 ok &= bool(np.array_equal(np.asarray(w["got"]).view(np.uint32), exp))
             if "bits" in w:
                 eb = np.array([O.synth_bits(1, SEED + 10, int(i), 0.5)[0] & 1 for i in idx], np.uint8)
@@ -1090,6 +1090,27 @@ def main():
                 "local source, random destination (the scatter of a contiguous selection; duplicate destinations: unspecified winner)")
             rec("put_f32_random_to_random", lambda: capi.call("agpu_put_bounded", h, 4, vp(V), m, vp(I1), vp(OUT), m, vp(I2), m), "both index columns random")
             rec("put_bits_random_to_random", lambda: capi.call("agpu_put_bits_bounded", h, vp(VB), m, vp(I1), vp(OB), m, vp(I2), m), "Boolean put, both index columns random")
+            # the columns of one table by one index column (agpu_take_columns): the pipeline's index work — a third of a take — runs once
+            try:
+                V4 = [V] + [dev.create_empty_buffer(4 * m) for _ in range(3)]
+                O4 = [OUT] + [dev.create_empty_buffer(4 * m) for _ in range(3)]
+                for k_, v_ in enumerate(V4[1:]):
+                    capi.call("agpu_synth_i32", h, vp(v_), m, SEED + 30 + k_, 0, 0)
+                p.sync()
+                w4 = (C.c_int32 * 4)(4, 4, 4, 4)
+                v4 = (C.c_void_p * 4)(*[b_.ptr for b_ in V4])
+                o4 = (C.c_void_p * 4)(*[b_.ptr for b_ in O4])
+                ms4 = med5(lambda: capi.call("agpu_take_columns", h, 4, w4, v4, m, vp(I1), o4, m))
+                swz["take_4_columns_f32_random"] = {"ms": round(ms4, 4), "G_rows_per_s_per_column": round(4 * m / ms4 / 1e6, 1),
+                                                    "vs_four_takes": round(4 * swz["take_f32_random"]["ms"] / ms4, 3),
+                                                    "what": "agpu_take_columns: four 4-byte columns of one table by one random index column — histogram, "
+                                                            "scans and partition of the index once, gather + merge-back per column"}
+                if want_cpu:
+                    cfg_windows["swz_take_4_columns_f32_random"] = {"kind": "take", "got": win(O4[3], 4 * wn, 4 * w0).view(np.uint32), "w0": w0, "rows": wn, "m": m,
+                                                                    "values_seed": SEED + 32}
+                del V4, O4
+            except Exception as e:  # noqa: BLE001 — an extra figure
+                swz["take_4_columns_f32_random"] = {"error": f"{type(e).__name__}: {e}"}
             p.set_tuning("gather_bucket", 1)
             rec("take_f32_random_direct_kernel", lambda: capi.call("agpu_take", h, 4, vp(V), m, vp(I1), vp(OUT), m), "tuning gather_bucket = 1: one 128-byte line fetched per row")
             p.set_tuning("gather_bucket", 0)
