@@ -979,6 +979,45 @@ PrimitiveArrayGpu<T> PrimitiveArrayGpu<T>::take_op(const UInt32ArrayGPU& indexes
   p.keep.insert(p.keep.end(), {data, null_buffer->bit_buffer, indexes.data, out, outv});
   return PrimitiveArrayGpu(out, gpu_device, indexes.len, NullBitBufferGpu{outv, indexes.len, gpu_device});
 }
+// take of the columns of ONE table (equal length, no validity bitmaps) by one index column: what `c.take_op(indexes, p)` per column gives,
+// through agpu_take_columns — at pipeline sizes the index column's part of the merge-back take runs once for all columns (no counterpart in
+// the reference, which takes array by array [routines/src/lib.rs:122-143]).  Columns with nulls: take_op per column.
+template <typename T>
+std::vector<PrimitiveArrayGpu<T>> take_columns_op(const std::vector<PrimitiveArrayGpu<T>>& columns, const UInt32ArrayGPU& indexes,
+                                                  ArrowComputePipeline& p) {
+  using Native = typename PrimitiveArrayGpu<T>::Native;
+  std::vector<PrimitiveArrayGpu<T>> out;
+  if (columns.empty()) return out;
+  std::vector<int32_t> widths;
+  std::vector<const void*> vals;
+  std::vector<void*> outs;
+  std::vector<BufferPtr> bufs;
+  for (const auto& c : columns) {
+    if (c.null_buffer || c.len != columns[0].len)
+      throw ArrowErrorGPU(ArrowErrorGPU::OperationNotSupported, "take_columns: columns of one length without validity bitmaps");
+    bufs.push_back(c.gpu_device->create_empty_buffer(indexes.len * sizeof(Native)));
+    widths.push_back((int32_t)sizeof(Native));
+    vals.push_back(c.data->ptr);
+    outs.push_back(bufs.back()->ptr);
+  }
+  check(agpu_take_columns(p.h(), (int32_t)columns.size(), widths.data(), vals.data(), columns[0].len, (const uint32_t*)indexes.data->ptr,
+                          outs.data(), indexes.len), "agpu_take_columns");
+  p.keep.push_back(indexes.data);
+  for (size_t c = 0; c < columns.size(); c++) {
+    p.keep.insert(p.keep.end(), {columns[c].data, bufs[c]});
+    out.emplace_back(bufs[c], columns[c].gpu_device, indexes.len, std::nullopt);
+  }
+  return out;
+}
+template <typename T>
+std::vector<PrimitiveArrayGpu<T>> take_columns(const std::vector<PrimitiveArrayGpu<T>>& columns, const UInt32ArrayGPU& indexes) {
+  if (columns.empty()) return {};
+  ArrowComputePipeline p(columns[0].gpu_device);
+  auto out = take_columns_op(columns, indexes, p);
+  p.finish();
+  p.sync();
+  return out;
+}
 // validity of merge: ((v1 & m) | (v2 & ~m)) & v_mask in one kernel [crates/routines/src/merge.rs:17-86]
 inline std::optional<NullBitBufferGpu> merge_null_buffers_op(const std::optional<NullBitBufferGpu>& a,
                                                              const std::optional<NullBitBufferGpu>& b,

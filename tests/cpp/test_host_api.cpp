@@ -317,6 +317,12 @@ int main() {
     auto v = Float32ArrayGPU::from_optional_slice({0.f, 1.f, N, 3.f}, device);
     auto idx = UInt32ArrayGPU::from_slice({0, 1, 2, 3, 0, 1, 2, 3}, device);
     CHECK(same(v.take(idx).values(), {Opt<float>(0.f), 1.f, N, 3.f, 0.f, 1.f, N, 3.f}));
+    {  // the columns of one table by one index column (agpu_take_columns; beyond the reference): what take() per column gives
+      std::vector<Float32ArrayGPU> table{Float32ArrayGPU::from_slice({0.f, 1.f, 2.f, 3.f}, device), Float32ArrayGPU::from_slice({10.f, 11.f, 12.f, 13.f}, device)};
+      const auto taken = take_columns(table, idx);
+      CHECK(taken.size() == 2 && taken[0].raw_values() == table[0].take(idx).raw_values() && taken[1].raw_values() == table[1].take(idx).raw_values());
+      CHECK((taken[1].raw_values() == std::vector<float>{10.f, 11.f, 12.f, 13.f, 10.f, 11.f, 12.f, 13.f}));
+    }
     auto src = Float32ArrayGPU::from_slice({10.f, 1.f, 2.f, 3.f}, device);
     auto dst = Float32ArrayGPU::from_slice({100.f, 0.f, 101.f, 0.f, 102.f, 0.f, 103.f, 0.f}, device);
     src.put(UInt32ArrayGPU::from_slice({0, 1, 2, 3}, device), dst, UInt32ArrayGPU::from_slice({1, 3, 5, 7}, device));
