@@ -155,6 +155,7 @@ SIGNATURES = {
     "agpu_reduce_stats_f32": [_vp, _vp, _vp, _u64, _vp],
     "agpu_take": [_vp, _i32, _vp, _u64, _vp, _vp, _u64],
     "agpu_take_columns": [_vp, _i32, _vp, _vp, _u64, _vp, _vp, _u64],
+    "agpu_take_columns_validity": [_vp, _i32, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _u64],
     "agpu_take_bits": [_vp, _vp, _u64, _vp, _vp, _u64],
     "agpu_put_bounded": [_vp, _i32, _vp, _u64, _vp, _vp, _u64, _vp, _u64],
     "agpu_put_bits_bounded": [_vp, _vp, _u64, _vp, _vp, _u64, _vp, _u64],

@@ -310,15 +310,21 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
 
 // The columns of one table by ONE index column.  At pipeline sizes the index work of the merge-back take (a third of its time) is done once
 // for all of them (launch_take_mergeback's `more`); otherwise — small takes, sorted / local indices (the probe), unsupported widths — column
-// by column through agpu_take.  The first column decides (width of the probe's threshold, want_bucketed): the columns share n_values.
-agpu_status agpu_take_columns(agpu_pipeline* p, int32_t n_cols, const int32_t* widths, const void* const* values, uint64_t n_values,
-                              const uint32_t* idx, void* const* outs, uint64_t n_idx) {
+// by column through agpu_take / agpu_take_validity.  The first column decides (width of the probe's threshold, want_bucketed): the columns
+// share n_values.  validities / out_validities may be NULL (no column has nulls); entry c NULL: column c has none.
+static agpu_status take_columns_impl(agpu_pipeline* p, int32_t n_cols, const int32_t* widths, const void* const* values, const void* const* validities,
+                                     uint64_t n_values, const uint32_t* idx, void* const* outs, void* const* out_validities, uint64_t n_idx) {
+  auto vb = [&](int32_t c) -> const void* { return validities ? validities[c] : nullptr; };
   {
     AGPU_BIND(p);
     AGPU_REQUIRE(n_cols >= 0 && n_cols <= 64, AGPU_ERR_ARG, "0..64 columns");
     if (n_cols == 0 || n_idx == 0) return AGPU_OK;
     AGPU_REQUIRE(widths && values && outs && idx, AGPU_ERR_ARG, "null pointer");
-    for (int32_t c = 0; c < n_cols; c++) AGPU_REQUIRE(values[c] && outs[c], AGPU_ERR_ARG, "null column pointer");
+    for (int32_t c = 0; c < n_cols; c++) {
+      AGPU_REQUIRE(values[c] && outs[c], AGPU_ERR_ARG, "null column pointer");
+      AGPU_REQUIRE(!vb(c) || (out_validities && out_validities[c]), AGPU_ERR_ARG, "out_validity required for a column with a validity bitmap");
+      AGPU_REQUIRE(!vb(c) || (aligned_to(vb(c), 4) && aligned_to(out_validities[c], 8)), AGPU_ERR_SHAPE, "bitmap alignment");
+    }
     AGPU_REQUIRE(n_values > 0, AGPU_ERR_SHAPE, "take from an empty array");
     const int w0 = widths[0];
     if (n_cols > 1 && (w0 == 1 || w0 == 2 || w0 == 4) && n_values != UINT64_MAX && n_idx >= TK2_TILE &&
@@ -332,13 +338,16 @@ agpu_status agpu_take_columns(agpu_pipeline* p, int32_t n_cols, const int32_t* w
       }
       if (!go_direct) {
         TakeCol more[64];
-        for (int32_t c = 1; c < n_cols; c++) more[c - 1] = TakeCol{widths[c], values[c], outs[c]};
-        const agpu_status ms = launch_take_mergeback(p, w0, values[0], n_values, idx, outs[0], n_idx, nullptr, nullptr, adaptive, nullptr, 0, nullptr,
-                                                     more, n_cols - 1);
+        for (int32_t c = 1; c < n_cols; c++)
+          more[c - 1] = TakeCol{widths[c], values[c], outs[c], static_cast<const uint32_t*>(vb(c)), vb(c) ? static_cast<uint64_t*>(out_validities[c]) : nullptr};
+        const agpu_status ms = launch_take_mergeback(p, w0, values[0], n_values, idx, outs[0], n_idx, static_cast<const uint32_t*>(vb(0)),
+                                                     vb(0) ? static_cast<uint64_t*>(out_validities[0]) : nullptr, adaptive, nullptr, 0, nullptr, more,
+                                                     n_cols - 1);
         if (ms != AGPU_ERR_UNSUPPORTED) return ms;
       } else {
         for (int32_t c = 0; c < n_cols; c++) {
-          const agpu_status st = launch_take_direct(p, widths[c], values[c], n_values, idx, outs[c], n_idx, nullptr);
+          agpu_status st = launch_take_direct(p, widths[c], values[c], n_values, idx, outs[c], n_idx, nullptr);
+          if (st == AGPU_OK && vb(c)) st = launch_take_bits_direct(p, vb(c), n_values, idx, out_validities[c], n_idx, nullptr);
           if (st != AGPU_OK) return st;
         }
         return AGPU_OK;
@@ -346,10 +355,20 @@ agpu_status agpu_take_columns(agpu_pipeline* p, int32_t n_cols, const int32_t* w
     }
   }
   for (int32_t c = 0; c < n_cols; c++) {
-    const agpu_status st = agpu_take(p, widths[c], values[c], n_values, idx, outs[c], n_idx);
+    const agpu_status st = vb(c) ? agpu_take_validity(p, widths[c], values[c], n_values, vb(c), idx, outs[c], out_validities[c], n_idx)
+                                 : agpu_take(p, widths[c], values[c], n_values, idx, outs[c], n_idx);
     if (st != AGPU_OK) return st;
   }
   return AGPU_OK;
+}
+agpu_status agpu_take_columns(agpu_pipeline* p, int32_t n_cols, const int32_t* widths, const void* const* values, uint64_t n_values,
+                              const uint32_t* idx, void* const* outs, uint64_t n_idx) {
+  return take_columns_impl(p, n_cols, widths, values, nullptr, n_values, idx, outs, nullptr, n_idx);
+}
+agpu_status agpu_take_columns_validity(agpu_pipeline* p, int32_t n_cols, const int32_t* widths, const void* const* values,
+                                       const void* const* validities, uint64_t n_values, const uint32_t* idx, void* const* outs,
+                                       void* const* out_validities, uint64_t n_idx) {
+  return take_columns_impl(p, n_cols, widths, values, validities, n_values, idx, outs, out_validities, n_idx);
 }
 
 agpu_status agpu_take_validity(agpu_pipeline* p, int32_t width, const void* values, uint64_t n_values, const void* validity,

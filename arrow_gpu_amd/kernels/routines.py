@@ -202,10 +202,10 @@ def take_dyn(operand_1, indexes):
 
 
 def take_columns_op(columns, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipeline) -> list:
-    """take of the columns of ONE table (primitive arrays of equal length, 1 / 2 / 4-byte values) by one index column — what
-    `[c.take_op(indexes, p) for c in columns]` gives, through agpu_take_columns: at pipeline sizes everything the merge-back take does to the
-    INDEX column runs once for all columns (no counterpart in the reference, which takes array by array: routines/src/lib.rs:122-143).
-    Validity bitmaps are taken per column (take_null_buffer)."""
+    """take of the columns of ONE table (primitive arrays of equal length, 1 / 2 / 4-byte values, with or without nulls) by one index
+    column — what `[c.take_op(indexes, p) for c in columns]` gives, through agpu_take_columns(_validity): at pipeline sizes everything the
+    merge-back take does to the INDEX column runs once for all columns, and a column's validity bit travels with its value (no counterpart
+    in the reference, which takes array by array: routines/src/lib.rs:122-143)."""
     import ctypes as C
 
     if not columns:
@@ -215,14 +215,24 @@ def take_columns_op(columns, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipe
         if not isinstance(c, PrimitiveArrayGpu) or c.len != n_src:
             raise capi.ArrowErrorGPU("ShapeError", "take_columns: primitive columns of one length", capi.ERR_SHAPE)
     dev = columns[0].gpu_device
-    outs = [dev.create_empty_buffer(max(indexes.len * c.ITEM_SIZE, 1)) for c in columns]
     k = len(columns)
+    outs = [dev.create_empty_buffer(max(indexes.len * c.ITEM_SIZE, 1)) for c in columns]
     widths = (C.c_int32 * k)(*[c.ITEM_SIZE for c in columns])
     vals = (C.c_void_p * k)(*[c.data.ptr for c in columns])
     outp = (C.c_void_p * k)(*[o.ptr for o in outs])
-    capi.call("agpu_take_columns", pipeline._handle, k, widths, vals, n_src, vp(indexes.data), outp, indexes.len)
-    pipeline.keep(indexes.data, *[c.data for c in columns], *outs)
-    return [type(c)(o, dev, indexes.len, take_null_buffer(c.null_buffer, indexes, pipeline)) for c, o in zip(columns, outs)]
+    keep = [indexes.data] + [c.data for c in columns] + outs
+    if any(c.null_buffer is not None for c in columns):
+        outv = [dev.create_empty_buffer(max(bitmap_bytes(indexes.len), 8)) if c.null_buffer is not None else None for c in columns]
+        vbits = (C.c_void_p * k)(*[c.null_buffer.bit_buffer.ptr if c.null_buffer is not None else None for c in columns])
+        voutp = (C.c_void_p * k)(*[o.ptr if o is not None else None for o in outv])
+        capi.call("agpu_take_columns_validity", pipeline._handle, k, widths, vals, vbits, n_src, vp(indexes.data), outp, voutp, indexes.len)
+        keep += [c.null_buffer.bit_buffer for c in columns if c.null_buffer is not None] + [o for o in outv if o is not None]
+        nulls = [NullBitBufferGpu(o, indexes.len, dev) if o is not None else None for o in outv]
+    else:
+        capi.call("agpu_take_columns", pipeline._handle, k, widths, vals, n_src, vp(indexes.data), outp, indexes.len)
+        nulls = [None] * k
+    pipeline.keep(*keep)
+    return [type(c)(o, dev, indexes.len, nb) for c, o, nb in zip(columns, outs, nulls)]
 
 
 def take_columns(columns, indexes: UInt32ArrayGPU) -> list:

@@ -473,6 +473,12 @@ agpu_status agpu_take(agpu_pipeline* p, int32_t width, const void* values, uint6
  * those of n_cols agpu_take calls; below the pipeline's sizes, for local indices and for other widths that is what runs. */
 agpu_status agpu_take_columns(agpu_pipeline* p, int32_t n_cols, const int32_t* widths, const void* const* values, uint64_t n_values,
                               const uint32_t* idx, void* const* outs, uint64_t n_idx);
+/* … with validity bitmaps: validities[c] = column c's bitmap (n_values bits) or NULL; out_validities[c] receives bit i = validities[c] bit
+ * idx[i] (agpu_bitmap_bytes(n_idx) bytes, padding bits 0), like agpu_take_validity — the bit travels with the value through the column's
+ * gather + merge passes.  validities == NULL: agpu_take_columns. */
+agpu_status agpu_take_columns_validity(agpu_pipeline* p, int32_t n_cols, const int32_t* widths, const void* const* values,
+                                       const void* const* validities, uint64_t n_values, const uint32_t* idx, void* const* outs,
+                                       void* const* out_validities, uint64_t n_idx);
 /* take of an array WITH NULLS in one call: out[i] = values[idx[i]] and out_validity bit i = validity bit idx[i] (n_values
  * bits; out_validity: agpu_bitmap_bytes(n_idx) bytes, padding bits 0) [ref: Swizzle::take_op crates/routines/src/lib.rs:122-143
  * = apply_take_op (take.rs:9-55) for the values + take_null_buffer (bool.rs:33-46) for the validity: two dispatches].  For

@@ -64,6 +64,32 @@ def test_take_columns_auto_policy_random_and_sorted_indices(D):
         D.release()
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2, 4])
+def test_take_columns_with_validity_bitmaps(D, mode):
+    """columns with and without nulls in one call: values as above, out_validity bit i = validity bit idx[i] (agpu_take_validity's rule)"""
+    rng = np.random.default_rng(40 + mode)
+    n_src, n_idx = 3_000_017, 2_500_003
+    cols = _table(rng, n_src, [np.uint32, np.uint32, np.uint16, np.uint8])
+    vbits = [O.synth_bits(n_src, 50, 0, 0.8), None, O.synth_bits(n_src, 51, 0, 0.5), O.synth_bits(n_src, 52, 0, 0.95)]
+    idx = rng.integers(0, n_src, n_idx, dtype=np.uint32)
+    D.p.set_tuning("gather_bucket", mode)
+    k = len(cols)
+    dcols, didx = [D.up(c) for c in cols], D.up(idx)
+    dv = [D.up(v) if v is not None else None for v in vbits]
+    outs = [D.empty(n_idx * c.dtype.itemsize) for c in cols]
+    outv = [D.empty(O.bitmap_bytes(n_idx)) if v is not None else None for v in vbits]
+    widths = (C.c_int32 * k)(*[c.dtype.itemsize for c in cols])
+    vals = (C.c_void_p * k)(*[d.vp.value for d in dcols])
+    vb = (C.c_void_p * k)(*[d.vp.value if d is not None else None for d in dv])
+    outp = (C.c_void_p * k)(*[o.vp.value for o in outs])
+    voutp = (C.c_void_p * k)(*[o.vp.value if o is not None else None for o in outv])
+    D.call("agpu_take_columns_validity", k, widths, vals, vb, n_src, didx.vp, outp, voutp, n_idx)
+    for c, o, v, ov in zip(cols, outs, vbits, outv):
+        assert bits_equal(D.down(o, c.dtype, n_idx), O.take(c.dtype.itemsize, c, idx)), (mode, c.dtype)
+        if v is not None:
+            assert bits_equal(D.down(ov, np.uint8, O.bitmap_bytes(n_idx)), O.take_bits(v, n_src, idx)), (mode, "validity", c.dtype)
+
+
 def test_take_columns_edges(D):
     rng = np.random.default_rng(6)
     cols = _table(rng, 5000, [np.uint32])
@@ -87,3 +113,4 @@ def test_take_columns_through_the_python_host_with_nulls(D):
     assert ta.values() == a.take(idx).values()
     assert tb.values() == b.take(idx).values()
     assert tc.values() == c.take(idx).values()
+    assert ta.null_buffer is not None and tb.null_buffer is None
