@@ -77,6 +77,8 @@ def test_stats_specials_on_the_fused_path(D):
     _check(D, np.full(n, np.nan, np.float32))          # nothing but NaN: min = max = NaN
     w = np.zeros(n, np.float32); w[16384 * 3 + 1] = -0.0
     _check(D, w)                                      # -0.0 < +0.0
+    dn = (np.arange(n, dtype=np.int64) % 2001 - 1000).astype(np.float32) * np.float32(1e-42)   # nothing but denormals and zeros: kept, not flushed
+    _check(D, dn)
     y = O.synth_f32(n, 32, 0, -1.0, 1.0); y[-1] = np.float32(3.0e38); y[-2] = np.float32(-3.0e38)
     _check(D, y)                                      # the extremes in the < 1-quarter tail
 
