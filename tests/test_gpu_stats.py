@@ -134,3 +134,44 @@ def test_stats_at_1e9_rows_equal_the_four_reductions_and_read_the_column_once(D)
         assert nan_aware_bits_equal(got[key], sep[key]), (key, got[key], sep[key])
     assert got["sum_f64"].view(np.uint64)[0] == sep["sum_f64"].view(np.uint64)[0]
     assert -1.0 <= float(got["min"][0]) < -0.999999 and 0.999999 < float(got["max"][0]) < 1.0
+
+
+def test_stats_two_stream_kernels_and_take_columns_inside_a_captured_graph(D):
+    """this session's forms under hipGraph capture: a one-input kernel over a column big enough for the two-stream order, the reductions'
+    single finishing launch, the one-pass statistics, agpu_take_columns (direct kernels while capturing) — replayed with new inputs in the
+    same buffers"""
+    n = (1 << 25) + 256 * 3 + 7
+    x = O.synth_f32(n, 51, 0, -5.0, 5.0)
+    dx, neg, red, rec = D.up(x), D.empty(4 * n), D.empty(16), D.empty(32)
+    idx = np.random.default_rng(9).integers(0, n, 50_000).astype(np.uint32)
+    didx, t0, t1 = D.up(idx), D.empty(4 * len(idx)), D.empty(4 * len(idx))
+    widths = (C.c_int32 * 2)(4, 4)
+    vals = (C.c_void_p * 2)(dx.vp.value, neg.vp.value)
+    outs = (C.c_void_p * 2)(t0.vp.value, t1.vp.value)
+
+    def enqueue():
+        D.call("agpu_unary", capi.UN_NEG, capi.F32, dx.vp, neg.vp, n)
+        D.call("agpu_reduce", capi.RED_MAX, capi.F32, neg.vp, None, n, red.vp)
+        D.call("agpu_reduce_stats_f32", dx.vp, None, n, rec.vp)
+        D.call("agpu_take_columns", 2, widths, vals, n, didx.vp, outs, len(idx))
+
+    enqueue()  # warm-up: scratch grows here, not during capture
+    D.p.sync()
+    g = C.c_void_p()
+    D.call("agpu_pipeline_begin_capture")
+    enqueue()
+    D.call("agpu_pipeline_end_capture", C.byref(g))
+    for rep in range(3):
+        if rep:
+            x = O.synth_f32(n, 60 + rep, 0, -5.0 - rep, 5.0)
+            capi.call("agpu_upload", D.h, dx.vp, x.ctypes.data_as(C.c_void_p), x.nbytes)
+        capi.call("agpu_memset", D.h, rec.vp, 0xCD, 32)
+        capi.call("agpu_graph_launch", g, D.h)
+        assert nan_aware_bits_equal(D.down(neg, np.float32, n), -x)
+        assert D.down(red, np.float32, 1)[0] == np.float32(-x.min())
+        got = _record(D, rec)
+        assert got["reserved"] == 0
+        assert nan_aware_bits_equal(got["sum"], np.array([O.reduce(O.RED_SUM, O.F32, x)], np.float32))
+        assert got["min"][0] == x.min() and got["max"][0] == x.max()
+        assert nan_aware_bits_equal(D.down(t0, np.float32, len(idx)), x[idx]) and nan_aware_bits_equal(D.down(t1, np.float32, len(idx)), -x[idx])
+    capi.call("agpu_graph_destroy", g)
