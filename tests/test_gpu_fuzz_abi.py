@@ -2,6 +2,7 @@
 oracle.  Lengths are drawn around every tile boundary of the kernels (64 / 256 / 1024 / 4096 / 65536 rows) and pointers
 are offset by whole elements, so every launch mixes the vector path, its tails and the element-granular fallbacks.
 Everything is bit-exact (transcendentals are excluded here; they have their own ULP sweeps)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -64,7 +65,7 @@ def test_random_abi_calls_match_the_oracle(D, seed):
     rng = np.random.default_rng(5000 + seed)
     for it in range(12):
         fam = ("binary", "scalar", "unary", "compare", "compare_validity", "cast", "bitmap", "reduce", "take", "merge",
-               "chain", "shift", "put", "take_bits", "take_validity", "put_bits", "cast_chain")[rng.integers(17)]
+               "chain", "shift", "put", "take_bits", "take_validity", "put_bits", "cast_chain", "stats", "take_columns")[rng.integers(19)]
         # EVERY tuning key the ABI has (include/arrow_gpu.h: seven since round 6) is drawn in every iteration: results never depend on them.
         # tiles per block of the prefetching kernels (heavy unary kernels, casts, cast-headed chains, table kernels): any value, same results
         D.p.set_tuning("tiles", int(rng.integers(0, 9)) if rng.random() < 0.5 else 0)
@@ -138,6 +139,44 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             out = D.empty(16)
             D.call("agpu_reduce", op, rt, D.up(x, off(rng, 4)).vp, D.up(v).vp if v is not None else None, n, out.vp)
             assert nan_aware_bits_equal(D.down(out, NP[rt], 1), np.atleast_1d(O.reduce(op, rt, x, v)).astype(NP[rt])), what
+        elif fam == "stats":  # the one-pass statistics against the four reductions' oracle values (small sizes: the fallback; the fused form: test_gpu_stats.py)
+            x = rand_values(capi.F32, n, seed * 3 + it, special=False)
+            v = O.synth_bits(n, seed, it + 3, 0.7) if rng.random() < 0.5 else None
+            if n == 0 or (v is not None and not np.unpackbits(v, bitorder="little")[:n].any()):
+                continue
+            rec = D.empty(32)
+            D.call("agpu_reduce_stats_f32", D.up(x, off(rng, 4)).vp, D.up(v).vp if v is not None else None, n, rec.vp)
+            raw = D.down(rec, np.uint8, 24)
+            f3 = raw[:12].view(np.float32)
+            for j, op in enumerate((capi.RED_SUM, capi.RED_MIN, capi.RED_MAX)):
+                assert nan_aware_bits_equal(f3[j:j + 1], np.atleast_1d(O.reduce(op, capi.F32, x, v)).astype(np.float32)), (what, op)
+            assert int(raw[12:16].view(np.uint32)[0]) == 0, what
+        elif fam == "take_columns":
+            if n == 0:
+                continue
+            k = pick_n(rng)
+            idx = rng.integers(0, n, k).astype(np.uint32)
+            if rng.random() < 0.4:
+                idx = np.sort(idx)
+            ncol = int(rng.integers(1, 5))
+            cdt = [(capi.U32, capi.U16, capi.U8, capi.I32, capi.F32)[rng.integers(5)] for _ in range(ncol)]
+            cols = [rand_values(t, n, seed * 23 + it + j, special=False) for j, t in enumerate(cdt)]
+            vbs = [O.synth_bits(n, seed, it + 9 + j, 0.8) if rng.random() < 0.4 else None for j in range(ncol)]
+            dcols = [D.up(c) for c in cols]
+            dvb = [D.up(vb) if vb is not None else None for vb in vbs]
+            outs = [D.empty(max(k * c.dtype.itemsize, 1)) for c in cols]
+            outv = [D.empty(O.bitmap_bytes(k) + 8) if vb is not None else None for vb in vbs]
+            widths = (C.c_int32 * ncol)(*[c.dtype.itemsize for c in cols])
+            vals = (C.c_void_p * ncol)(*[d.vp.value for d in dcols])
+            vbp = (C.c_void_p * ncol)(*[d.vp.value if d is not None else None for d in dvb])
+            outp = (C.c_void_p * ncol)(*[o.vp.value for o in outs])
+            ovp = (C.c_void_p * ncol)(*[o.vp.value if o is not None else None for o in outv])
+            D.call("agpu_take_columns_validity", ncol, widths, vals, vbp, n, D.up(idx).vp, outp, ovp, k)
+            for c, o, vb, ov in zip(cols, outs, vbs, outv):
+                assert bits_equal(D.down(o, c.dtype, k), O.take(c.dtype.itemsize, c, idx)), what
+                if vb is not None and k:
+                    assert bits_equal(D.down(ov, np.uint8, O.bitmap_bytes(k)), O.take_bits(vb, n, idx)), what
+            assert D.status("agpu_pipeline_sync") == capi.OK
         elif fam == "take":
             if n == 0:
                 continue
@@ -223,7 +262,6 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             D.call("agpu_take_bits", D.up(bits_in).vp, n, D.up(idx, off(rng, 4)).vp, outb.vp, k)
             assert bits_equal(D.down(outb, np.uint8, O.bitmap_bytes(k)), O.take_bits(bits_in, n, idx)), what
         elif fam == "cast_chain":  # a widening cast at the head of 0–4 exact f32 steps, one launch (8-bit sources of ≥ 65 536 rows: the table route)
-            import ctypes as C
 
             frm = (capi.U8, capi.I8, capi.U16, capi.I16)[rng.integers(4)]
             wi = NP[frm]().itemsize
@@ -251,7 +289,6 @@ def test_random_abi_calls_match_the_oracle(D, seed):
             D.call("agpu_fused_cast_chain", frm, D.up(x, off(rng, wi)).vp, C.cast(steps, C.c_void_p), k, out.vp, n)
             assert nan_aware_bits_equal(D.down(out, np.float32, n), exp), what
         else:  # chain of 2–5 exact steps on a 32-bit column, with or without a terminal compare
-            import ctypes as C
 
             ct = (capi.F32, capi.I32, capi.U32)[rng.integers(3)]
             x = rand_values(ct, n, seed * 11 + it)
