@@ -327,6 +327,17 @@ template <bool MAX> struct RedMinMaxF32 {  // Arrow min_max: NaN skipped unless 
   __device__ static Acc from_part(Part q) { return load(q); }
 };
 
+// … with a validity bitmap a chunk may hold NO valid row at all, which its partial must keep apart from "every valid row was NaN": the
+// null-aware launches fold the accumulator itself ({value, flags}, 8 bytes per chunk)
+template <bool MAX> struct RedMinMaxF32V : RedMinMaxF32<MAX> {
+  typedef MinMaxF32 Part;
+  __device__ static Part to_part(MinMaxF32 a) { return a; }
+  __device__ static MinMaxF32 from_part(Part q) { return q; }
+};
+// the reduction a column WITH validity takes through the wave kernel (same results; only RedMinMaxF32's partial differs)
+template <typename Red> struct NullAwareRed { typedef Red type; };
+template <bool MAX> struct NullAwareRed<RedMinMaxF32<MAX>> { typedef RedMinMaxF32V<MAX> type; };
+
 template <typename A> __device__ __forceinline__ A shfl_down_acc(A v, int off) {
   if constexpr (std::is_same<A, MinMaxF32>::value) return MinMaxF32{__shfl_down(v.r, off), (uint32_t)__shfl_down((int)v.flags, off)};
   else if constexpr (std::is_same<A, uint32_t>::value) return (uint32_t)__shfl_down((int)v, off);
@@ -418,8 +429,10 @@ static int reduce_grid_for(const agpu_pipeline* p, uint64_t work_blocks, int blo
 // partials.  The grid-stride form above stays for columns with validity, unaligned columns and the < 1-chunk tail.
 #define AGPU_REDUCE_WAVE 1
 constexpr uint64_t RED_CHUNK_ROWS = 16384;
-template <typename T, typename Red>
-__global__ __launch_bounds__(AGPU_WAVE) void reduce_wave_kernel(const T* in, typename Red::Part* partials, uint64_t nchunks) {
+// HASV (round 6b): null-aware — the validity bits of an iteration's 8 × 256 rows are ONE 4-byte load per lane (256 contiguous bytes per wave);
+// lane l's nibble for vector u sits in the word lane 8 u + l / 8 holds (quarter_tree_sum's scheme); invalid rows are skipped.
+template <typename T, typename Red, bool HASV = false>
+__global__ __launch_bounds__(AGPU_WAVE) void reduce_wave_kernel(const T* in, const uint8_t* validity, typename Red::Part* partials, uint64_t nchunks) {
   typedef typename Red::Acc A;
   const uint32_t lane = threadIdx.x;
   for (uint64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
@@ -427,15 +440,25 @@ __global__ __launch_bounds__(AGPU_WAVE) void reduce_wave_kernel(const T* in, typ
     A a0 = Red::identity(), a1 = Red::identity(), a2 = Red::identity(), a3 = Red::identity();
     for (int j0 = 0; j0 < 64; j0 += 8) {
       u32x4 v[8];
+      uint32_t vword = 0;
+      if constexpr (HASV) vword = reinterpret_cast<const uint32_t*>(validity)[(c * RED_CHUNK_ROWS + (uint64_t)j0 * 256) / 32 + lane];
 #pragma unroll
       for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(base + (j0 + u) * AGPU_WAVE);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const uint32_t e0 = v[u].x, e1 = v[u].y, e2 = v[u].z, e3 = v[u].w;
-        a0 = Red::combine(a0, Red::load(word_as<T>(e0)));
-        a1 = Red::combine(a1, Red::load(word_as<T>(e1)));
-        a2 = Red::combine(a2, Red::load(word_as<T>(e2)));
-        a3 = Red::combine(a3, Red::load(word_as<T>(e3)));
+        if constexpr (HASV) {
+          const uint32_t nib = ((uint32_t)__shfl((int)vword, u * 8 + (int)(lane >> 3)) >> ((lane & 7u) * 4)) & 0xFu;
+          if (nib & 1) a0 = Red::combine(a0, Red::load(word_as<T>(e0)));
+          if (nib & 2) a1 = Red::combine(a1, Red::load(word_as<T>(e1)));
+          if (nib & 4) a2 = Red::combine(a2, Red::load(word_as<T>(e2)));
+          if (nib & 8) a3 = Red::combine(a3, Red::load(word_as<T>(e3)));
+        } else {
+          a0 = Red::combine(a0, Red::load(word_as<T>(e0)));
+          a1 = Red::combine(a1, Red::load(word_as<T>(e1)));
+          a2 = Red::combine(a2, Red::load(word_as<T>(e2)));
+          a3 = Red::combine(a3, Red::load(word_as<T>(e3)));
+        }
       }
     }
     A acc = Red::combine(Red::combine(a0, a1), Red::combine(a2, a3));
@@ -455,7 +478,8 @@ __global__ __launch_bounds__(AGPU_WAVE) void reduce_wave_kernel(const T* in, typ
 // the body: every thread of the block calls it; the first `nthr` of them (a multiple of 64) do the work — the order of the fold is nthr's
 template <typename T, typename Red>
 __device__ __forceinline__ void fold_finish_body(const typename Red::Part* partials, uint64_t m, const T* tail_in, uint32_t tail, typename Red::Out* out,
-                                                 uint32_t nthr, typename Red::Acc* lds /* [AGPU_FOLD_BLOCK / AGPU_WAVE] */) {
+                                                 uint32_t nthr, typename Red::Acc* lds /* [AGPU_FOLD_BLOCK / AGPU_WAVE] */,
+                                                 const uint8_t* validity = nullptr, uint64_t tail_row0 = 0) {
   typedef typename Red::Acc A;
   typedef typename Red::Part Q;
   constexpr int PER = 16 / (int)sizeof(Q);  // partials per 16-byte vector: 4 or 2
@@ -466,7 +490,10 @@ __device__ __forceinline__ void fold_finish_body(const typename Red::Part* parti
   static_assert(sizeof(Pack) == 16, "partials tile a 16-byte vector");
   A acc = Red::identity();
   if (threadIdx.x < nthr) {
-    for (uint32_t i = threadIdx.x; i < tail; i += nthr) acc = Red::combine(acc, Red::load(tail_in[i]));
+    for (uint32_t i = threadIdx.x; i < tail; i += nthr) {
+      const uint64_t row = tail_row0 + i;
+      if (!validity || ((validity[row >> 3] >> (row & 7)) & 1)) acc = Red::combine(acc, Red::load(tail_in[i]));
+    }
     const uint64_t nvec = m / PER;
     const u32x4* pv = reinterpret_cast<const u32x4*>(partials);
     for (uint64_t v0 = 0; v0 < nvec; v0 += (uint64_t)nthr * B) {
@@ -500,28 +527,43 @@ __device__ __forceinline__ void fold_finish_body(const typename Red::Part* parti
 }
 template <typename T, typename Red>
 __global__ __launch_bounds__(AGPU_FOLD_BLOCK) void reduce_fold_finish_kernel(const typename Red::Part* partials, uint64_t m, const T* tail_in,
-                                                                            uint32_t tail, typename Red::Out* out) {
+                                                                            uint32_t tail, typename Red::Out* out, const uint8_t* validity,
+                                                                            uint64_t tail_row0) {
   __shared__ typename Red::Acc lds[AGPU_FOLD_BLOCK / AGPU_WAVE];
-  fold_finish_body<T, Red>(partials, m, tail_in, tail, out, blockDim.x, lds);
+  fold_finish_body<T, Red>(partials, m, tail_in, tail, out, blockDim.x, lds, validity, tail_row0);
 }
 
 template <typename T, typename Red>
 static agpu_status launch_reduce(agpu_pipeline* p, const void* in, const void* validity, uint64_t n, void* out) {
   typedef typename Red::Acc A;
   constexpr int U = 4;
-  if (AGPU_REDUCE_WAVE && !validity && aligned16(in) && n >= 64 * RED_CHUNK_ROWS) {
+  if (AGPU_REDUCE_WAVE && aligned16(in) && n >= 64 * RED_CHUNK_ROWS && (!validity || aligned_to(validity, 4))) {
     const uint64_t nchunks = n / RED_CHUNK_ROWS, tail = n - nchunks * RED_CHUNK_ROWS;
-    void* scratch = nullptr;
-    typedef typename Red::Part Q;
-    agpu_status st = agpu_scratch(p, sizeof(Q) * (size_t)nchunks + 16, &scratch);
-    if (st != AGPU_OK) return st;
-    Q* partials = static_cast<Q*>(scratch);
     const uint64_t g = nchunks < 0x3FFFFFFFull ? nchunks : 0x3FFFFFFFull;
-    hipLaunchKernelGGL((reduce_wave_kernel<T, Red>), dim3((unsigned)g), dim3(AGPU_WAVE), 0, p->stream, static_cast<const T*>(in),
-                       partials, nchunks);
-    AGPU_LAUNCH_CHECK();
-    hipLaunchKernelGGL((reduce_fold_finish_kernel<T, Red>), dim3(1), dim3(nchunks > 16384 ? AGPU_FOLD_BLOCK : 256), 0, p->stream, (const Q*)partials, nchunks,
-                       static_cast<const T*>(in) + nchunks * RED_CHUNK_ROWS, (uint32_t)tail, static_cast<typename Red::Out*>(out));
+    const unsigned fb = nchunks > 16384 ? AGPU_FOLD_BLOCK : 256;
+    const T* tin = static_cast<const T*>(in);
+    const uint8_t* vb = static_cast<const uint8_t*>(validity);
+    void* scratch = nullptr;
+    if (!validity) {
+      typedef typename Red::Part Q;
+      agpu_status st = agpu_scratch(p, sizeof(Q) * (size_t)nchunks + 16, &scratch);
+      if (st != AGPU_OK) return st;
+      Q* partials = static_cast<Q*>(scratch);
+      hipLaunchKernelGGL((reduce_wave_kernel<T, Red, false>), dim3((unsigned)g), dim3(AGPU_WAVE), 0, p->stream, tin, vb, partials, nchunks);
+      AGPU_LAUNCH_CHECK();
+      hipLaunchKernelGGL((reduce_fold_finish_kernel<T, Red>), dim3(1), dim3(fb), 0, p->stream, (const Q*)partials, nchunks,
+                         tin + nchunks * RED_CHUNK_ROWS, (uint32_t)tail, static_cast<typename Red::Out*>(out), vb, nchunks * RED_CHUNK_ROWS);
+    } else {  // null-aware (round 6b): the same two launches, the validity bits read beside the values
+      typedef typename NullAwareRed<Red>::type RedV;
+      typedef typename RedV::Part Q;
+      agpu_status st = agpu_scratch(p, sizeof(Q) * (size_t)nchunks + 16, &scratch);
+      if (st != AGPU_OK) return st;
+      Q* partials = static_cast<Q*>(scratch);
+      hipLaunchKernelGGL((reduce_wave_kernel<T, RedV, true>), dim3((unsigned)g), dim3(AGPU_WAVE), 0, p->stream, tin, vb, partials, nchunks);
+      AGPU_LAUNCH_CHECK();
+      hipLaunchKernelGGL((reduce_fold_finish_kernel<T, RedV>), dim3(1), dim3(fb), 0, p->stream, (const Q*)partials, nchunks,
+                         tin + nchunks * RED_CHUNK_ROWS, (uint32_t)tail, static_cast<typename RedV::Out*>(out), vb, nchunks * RED_CHUNK_ROWS);
+    }
     AGPU_LAUNCH_CHECK();
     return AGPU_OK;
   }

@@ -513,6 +513,52 @@ def test_reduce_wave_path_with_nan_chunks_and_tails(D):
                 assert bits_equal(D.down(out, NP[dtype], 1), np.array([O.reduce(op, dtype, xi)], NP[dtype])), (op, dtype, n)
 
 
+def test_null_aware_reductions_through_the_wave_kernel(D):
+    """columns of >= 1 Mi rows WITH a validity bitmap (round 6b: the one-wave-per-chunk kernel reads the bits beside the values): chunks
+    without a single valid row, chunks whose valid rows are all NaN, both together (the fold must keep "nothing seen" apart from "only NaN
+    seen"), a column without any valid row, the tail under the bitmap"""
+    out = D.empty(16)
+    for n in (1 << 20, (1 << 20) + 16383 + 5, 3 * (1 << 20) + 777):
+        rng = np.random.default_rng(n)
+        x = rand_values(capi.F32, n, 93)
+        x[np.isnan(x)] = 2.0
+        v = np.unpackbits(O.synth_bits(n, 94, 0, 0.7), bitorder="little")[:n].astype(bool)
+        v[:16384] = False                              # chunk 0: no valid row
+        x[16384 * 2: 16384 * 3] = np.nan               # chunk 2: its valid rows are all NaN
+        v[16384 * 4: 16384 * 5] = True; x[16384 * 4: 16384 * 5] = np.nan
+        cases = [(x, v)]
+        allnan = x.copy(); allnan[v] = np.nan          # every VALID row NaN (some chunks hold no valid row at all): the answer is NaN
+        cases.append((allnan, v))
+        cases.append((x, np.zeros(n, bool)))           # no valid row anywhere: the identities
+        tailv = v.copy(); tailv[-(n % 16384 or 1):] = True
+        y = x.copy(); y[-1] = np.float32(-3.0e38)      # the extreme in the tail, valid
+        cases.append((y, tailv))
+        for xs, vs in cases:
+            bits = O.pack_bits(vs)
+            dx, dv = D.up(xs), D.up(bits)
+            for op in (capi.RED_MIN, capi.RED_MAX, capi.RED_SUM):
+                xx = np.where(np.isnan(xs), np.float32(1.0), xs) if op == capi.RED_SUM else xs
+                if op == capi.RED_SUM:
+                    dx2 = D.up(xx)
+                    D.call("agpu_reduce", op, capi.F32, dx2.vp, dv.vp, n, out.vp)
+                else:
+                    D.call("agpu_reduce", op, capi.F32, dx.vp, dv.vp, n, out.vp)
+                got = D.down(out, np.float32, 1)
+                assert nan_aware_bits_equal(got, np.array([O.reduce(op, O.F32, xx, bits)], np.float32)), (op, n, got)
+            finite = np.where(np.isfinite(xs), xs, np.float32(0.5))   # (the f64 leg: finite rows, so that the comparison says something)
+            D.call("agpu_reduce_sum_f64", D.up(finite).vp, dv.vp, n, out.vp)
+            xs64 = finite.astype(np.float64)
+            assert abs(float(D.down(out, np.float64, 1)[0]) - float(xs64[vs].sum())) <= 1e-9 * max(1.0, float(np.abs(xs64[vs]).sum()))
+        for dtype in (capi.I32, capi.U32):
+            xi = rand_values(dtype, n, 95)
+            bits = O.pack_bits(v)
+            di, dv = D.up(xi), D.up(bits)
+            for op in (capi.RED_SUM, capi.RED_MIN, capi.RED_MAX):
+                D.call("agpu_reduce", op, dtype, di.vp, dv.vp, n, out.vp)
+                assert bits_equal(D.down(out, NP[dtype], 1), np.array([O.reduce(op, dtype, xi, bits)], NP[dtype])), (op, dtype, n)
+            D.release()
+
+
 def test_sum_f64_accumulator(D):
     out = D.empty(16)
     for n in (0, 1, 4097, 1 << 22):
