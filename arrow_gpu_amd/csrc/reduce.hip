@@ -643,32 +643,56 @@ static agpu_status sum_tree_after_quarters(agpu_pipeline* p, const float* quarte
 // interleaved accumulators per lane over the lane's 64 vectors, (a0+a1)+(a2+a3), shift-down shuffles) — so every partial, and with the
 // SAME finishing launches behind them every result, is bit-identical to what the four separate reductions give.  4 B/row, HBM-bound: ≈ 8
 // VALU instructions per row (two of them f64) ride under the loads.
-__global__ __launch_bounds__(AGPU_WAVE) void stats_quarter_kernel(const float* in, float* quarters, float* mins, float* maxs, double* dsums,
-                                                                 uint64_t nfull) {
+// HASV (null-aware): the validity bits as reduce_wave_kernel<…, true> / quarter_tree_sum<false, true> read them; an invalid row counts as +0.0
+// in the two sums and is skipped by min / max, whose partials are then RedMinMaxF32V's {value, flags} (a quarter may hold no valid row at all).
+template <bool HASV>
+__global__ __launch_bounds__(AGPU_WAVE) void stats_quarter_kernel(const float* in, const uint8_t* validity, float* quarters, void* mins_v, void* maxs_v,
+                                                                 double* dsums, uint64_t nfull) {
   constexpr int UNR = 8;
   const uint32_t lane = threadIdx.x;
   for (uint64_t q = blockIdx.x; q < nfull; q += gridDim.x) {
     const uint64_t base = q * WAVE_ROWS;
     float acc = 0.0f;
-    float mn = __builtin_inff(), mx = -__builtin_inff();  // the identities: mn > mx for as long as no non-NaN row has been seen
+    float mn = __builtin_inff(), mx = -__builtin_inff();  // the identities: mn > mx for as long as no (valid) non-NaN row has been seen
+    bool saw_nan = false;                                 // HASV only: a VALID NaN row (without validity: "nothing seen" = "only NaN seen")
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int j0 = 0; j0 < AGPU_WAVE; j0 += UNR) {
       f32x4 v[UNR];
+      uint32_t vword = 0;
+      if constexpr (HASV) vword = reinterpret_cast<const uint32_t*>(validity)[(base + (uint64_t)j0 * 256) / 32 + lane];
 #pragma unroll
       for (int u = 0; u < UNR; u++) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(in + base + (uint64_t)(j0 + u) * 256 + lane * 4));
       float s[UNR];
 #pragma unroll
       for (int u = 0; u < UNR; u++) {
-        const float x0 = v[u].x, x1 = v[u].y, x2 = v[u].z, x3 = v[u].w;
+        float x0 = v[u].x, x1 = v[u].y, x2 = v[u].z, x3 = v[u].w;
+        float c0, c1, c2, c3;
+        if constexpr (HASV) {
+          const uint32_t nib = ((uint32_t)__shfl((int)vword, u * 8 + (int)(lane >> 3)) >> ((lane & 7u) * 4)) & 0xFu;
+          const bool v0 = nib & 1, v1 = nib & 2, v2 = nib & 4, v3 = nib & 8;
+          const float qnan = __builtin_nanf("");
+          // min / max see an invalid row as a (quiet) NaN — skipped; a valid NaN row is remembered
+          c0 = v0 ? __builtin_canonicalizef(x0) : qnan;
+          c1 = v1 ? __builtin_canonicalizef(x1) : qnan;
+          c2 = v2 ? __builtin_canonicalizef(x2) : qnan;
+          c3 = v3 ? __builtin_canonicalizef(x3) : qnan;
+          saw_nan = saw_nan || (v0 && x0 != x0) || (v1 && x1 != x1) || (v2 && x2 != x2) || (v3 && x3 != x3);
+          x0 = v0 ? x0 : 0.0f;  // the sums: load4_tree<…, true>'s rule
+          x1 = v1 ? x1 : 0.0f;
+          x2 = v2 ? x2 : 0.0f;
+          x3 = v3 ? x3 : 0.0f;
+          // (reduce_wave_kernel skips an invalid row where this adds +0.0: the same bits — an accumulator that starts at +0.0 never holds −0.0)
+        } else {
+          // NaN rows: a QUIET NaN operand makes v_min_f32 / v_max_f32 return the other one (IEEE mode), so one canonicalising v_max_f32 x, x per
+          // row (it quiets a signalling NaN) replaces the compare and the two selects that map NaN to the identities — same result: the
+          // extremes of the non-NaN rows, −0.0 below +0.0
+          c0 = __builtin_canonicalizef(x0), c1 = __builtin_canonicalizef(x1), c2 = __builtin_canonicalizef(x2), c3 = __builtin_canonicalizef(x3);
+        }
         s[u] = (x0 + x1) + (x2 + x3);
         a0 += (double)x0;
         a1 += (double)x1;
         a2 += (double)x2;
         a3 += (double)x3;
-        // NaN rows: a QUIET NaN operand makes v_min_f32 / v_max_f32 return the other one (IEEE mode), so one canonicalising v_max_f32 x, x per
-        // row (it quiets a signalling NaN) replaces the compare and the two selects that map NaN to the identities — same result: the
-        // extremes of the non-NaN rows, −0.0 below +0.0
-        const float c0 = __builtin_canonicalizef(x0), c1 = __builtin_canonicalizef(x1), c2 = __builtin_canonicalizef(x2), c3 = __builtin_canonicalizef(x3);
         mn = RedMinMaxF32<false>::pick(RedMinMaxF32<false>::pick(mn, c0), RedMinMaxF32<false>::pick(c1, c2));
         mn = RedMinMaxF32<false>::pick(mn, c3);
         mx = RedMinMaxF32<true>::pick(RedMinMaxF32<true>::pick(mx, c0), RedMinMaxF32<true>::pick(c1, c2));
@@ -679,18 +703,26 @@ __global__ __launch_bounds__(AGPU_WAVE) void stats_quarter_kernel(const float* i
     }
     const float r = wave_tree_sum(acc);
     double d = (a0 + a1) + (a2 + a3);
+    uint32_t sn = saw_nan ? 1u : 0u;
 #pragma unroll
     for (int off = AGPU_WAVE / 2; off > 0; off >>= 1) {
       d = d + __shfl_down(d, off);
       mn = RedMinMaxF32<false>::pick(mn, __shfl_down(mn, off));
       mx = RedMinMaxF32<true>::pick(mx, __shfl_down(mx, off));
+      if constexpr (HASV) sn |= (uint32_t)__shfl_down((int)sn, off);
     }
     if (lane == 0) {
       const bool seen = mn <= mx;  // any non-NaN row v leaves mn ≤ v ≤ mx; the untouched identities are +inf > −inf
       quarters[q] = r;
-      mins[q] = seen ? mn : __builtin_nanf("");
-      maxs[q] = seen ? mx : __builtin_nanf("");
       dsums[q] = d;
+      if constexpr (HASV) {
+        const uint32_t flags = (seen ? 1u : 0u) | (sn ? 2u : 0u);
+        static_cast<MinMaxF32*>(mins_v)[q] = MinMaxF32{mn, flags};
+        static_cast<MinMaxF32*>(maxs_v)[q] = MinMaxF32{mx, flags};
+      } else {
+        static_cast<float*>(mins_v)[q] = seen ? mn : __builtin_nanf("");
+        static_cast<float*>(maxs_v)[q] = seen ? mx : __builtin_nanf("");
+      }
     }
   }
 }
@@ -699,10 +731,15 @@ __global__ __launch_bounds__(AGPU_WAVE) void stats_quarter_kernel(const float* i
 // the column in the tree sum's guarded form, one wave each, then sum_tree_combine_finish_kernel's body), blocks 1 / 2 / 3 min / max / the f64
 // sum through reduce_fold_finish_kernel's body with the SAME thread count that kernel would be launched with (the fold's order, hence the f64
 // sum's last bits, is a function of it).  do_sum = 0 (≤ 256 or > 65 536 spans): the host runs the tree sum's own launches instead.
-__global__ __launch_bounds__(AGPU_FOLD_BLOCK) void stats_finish_kernel(const float* in, uint64_t n, float* quarters, uint64_t nfull, uint64_t nquarters,
-                                                                      uint64_t nspans, uint32_t ngroups, int do_sum, const float* mins, const float* maxs,
-                                                                      const double* dsums, const float* tail_in, uint32_t tail, uint32_t nthr,
-                                                                      agpu_f32_stats* out) {
+template <bool HASV>
+__global__ __launch_bounds__(AGPU_FOLD_BLOCK) void stats_finish_kernel(const float* in, const uint8_t* validity, uint64_t n, float* quarters, uint64_t nfull,
+                                                                      uint64_t nquarters, uint64_t nspans, uint32_t ngroups, int do_sum, const void* mins,
+                                                                      const void* maxs, const double* dsums, const float* tail_in, uint32_t tail,
+                                                                      uint32_t nthr, agpu_f32_stats* out) {
+  typedef typename std::conditional<HASV, RedMinMaxF32V<false>, RedMinMaxF32<false>>::type RMin;
+  typedef typename std::conditional<HASV, RedMinMaxF32V<true>, RedMinMaxF32<true>>::type RMax;
+  const uint8_t* vb = HASV ? validity : nullptr;
+  const uint64_t tail_row0 = nfull * WAVE_ROWS;
   __shared__ float sh[256];
   __shared__ MinMaxF32 ldsm[AGPU_FOLD_BLOCK / AGPU_WAVE];
   __shared__ double ldsd[AGPU_FOLD_BLOCK / AGPU_WAVE];
@@ -711,7 +748,7 @@ __global__ __launch_bounds__(AGPU_FOLD_BLOCK) void stats_finish_kernel(const flo
     if (do_sum) {
       const uint32_t wave = threadIdx.x / AGPU_WAVE;
       if (nfull + wave < nquarters) {  // ≤ 4 quarters: the one that crosses the end of the column and the span's zero padding
-        const float r = quarter_tree_sum<true, false>(in, nullptr, (nfull + wave) * WAVE_ROWS, n);
+        const float r = quarter_tree_sum<true, HASV>(in, vb, (nfull + wave) * WAVE_ROWS, n);
         if ((threadIdx.x & (AGPU_WAVE - 1)) == 0) quarters[nfull + wave] = r;
       }
       __threadfence_block();
@@ -719,11 +756,11 @@ __global__ __launch_bounds__(AGPU_FOLD_BLOCK) void stats_finish_kernel(const flo
       sum_combine_finish_body(quarters, nspans, ngroups, &out->sum, sh);
     }
   } else if (blockIdx.x == 1) {
-    fold_finish_body<float, RedMinMaxF32<false>>(mins, nfull, tail_in, tail, &out->min, nthr, ldsm);
+    fold_finish_body<float, RMin>(static_cast<const typename RMin::Part*>(mins), nfull, tail_in, tail, &out->min, nthr, ldsm, vb, tail_row0);
   } else if (blockIdx.x == 2) {
-    fold_finish_body<float, RedMinMaxF32<true>>(maxs, nfull, tail_in, tail, &out->max, nthr, ldsm);
+    fold_finish_body<float, RMax>(static_cast<const typename RMax::Part*>(maxs), nfull, tail_in, tail, &out->max, nthr, ldsm, vb, tail_row0);
   } else {
-    fold_finish_body<float, RedSumF64>(dsums, nfull, tail_in, tail, &out->sum_f64, nthr, ldsd);
+    fold_finish_body<float, RedSumF64>(dsums, nfull, tail_in, tail, &out->sum_f64, nthr, ldsd, vb, tail_row0);
   }
 }
 
@@ -733,7 +770,7 @@ static agpu_status launch_stats_f32(agpu_pipeline* p, const float* in, const uin
   float* o_max = &out->max;
   double* o_f64 = &out->sum_f64;
   const uint64_t nfull = n / WAVE_ROWS;
-  if (validity || !aligned16(in) || nfull < 64) {  // null-aware, unaligned or small columns: the four reductions one after the other
+  if (!aligned16(in) || nfull < 64 || (validity && !aligned_to(validity, 4))) {  // unaligned or small columns: the four reductions one after the other
     AGPU_HIP(hipMemsetAsync(&out->reserved, 0, sizeof(out->reserved), p->stream));
     agpu_status st = launch_sum_tree_f32(p, in, validity, n, o_sum);
     if (st == AGPU_OK) st = launch_reduce<float, RedMinMaxF32<false>>(p, in, validity, n, o_min);
@@ -745,8 +782,9 @@ static agpu_status launch_stats_f32(agpu_pipeline* p, const float* in, const uin
   const uint64_t ngroups = (nspans + 255) / 256;
   const size_t level_cap = (size_t)((ngroups + 255) / 256 + 1);
   // scratch: the tree sum's layout (launch_sum_tree_f32) + mins[nfull] + maxs[nfull] + dsums[nfull], every piece 16-byte aligned
+  // (null-aware: the min / max partials are {value, flags} pairs, two floats each)
   const size_t f_tree = ((size_t)nquarters + 4 + (size_t)ngroups + 4 + 2 * level_cap + 8 + 3) & ~(size_t)3;
-  const size_t f_part = ((size_t)nfull + 3) & ~(size_t)3;
+  const size_t f_part = ((size_t)nfull * (validity ? 2 : 1) + 3) & ~(size_t)3;
   void* scratch = nullptr;
   agpu_status st = agpu_scratch(p, (f_tree + 2 * f_part) * sizeof(float) + (size_t)nfull * sizeof(double) + 16, &scratch);
   if (st != AGPU_OK) return st;
@@ -758,13 +796,18 @@ static agpu_status launch_stats_f32(agpu_pipeline* p, const float* in, const uin
   float* maxs = mins + f_part;
   double* dsums = reinterpret_cast<double*>(maxs + f_part);
   const uint64_t g = nfull < 0x3FFFFFFFull ? nfull : 0x3FFFFFFFull;
-  hipLaunchKernelGGL(stats_quarter_kernel, dim3((unsigned)g), dim3(AGPU_WAVE), 0, p->stream, in, quarters, mins, maxs, dsums, nfull);
+  if (validity) hipLaunchKernelGGL((stats_quarter_kernel<true>), dim3((unsigned)g), dim3(AGPU_WAVE), 0, p->stream, in, validity, quarters, (void*)mins, (void*)maxs, dsums, nfull);
+  else hipLaunchKernelGGL((stats_quarter_kernel<false>), dim3((unsigned)g), dim3(AGPU_WAVE), 0, p->stream, in, validity, quarters, (void*)mins, (void*)maxs, dsums, nfull);
   AGPU_LAUNCH_CHECK();
   const bool fused_sum = ngroups > 1 && ngroups <= 256 && nquarters - nfull <= AGPU_FOLD_BLOCK / AGPU_WAVE;
   if (!fused_sum) {  // ≤ 16.7 M or > 4.29e9 rows: the tree sum's own launches behind the quarters
     if (nfull < nquarters) {
-      hipLaunchKernelGGL((sum_tree_quarter_kernel<false>), dim3((unsigned)(nquarters - nfull)), dim3(AGPU_WAVE), 0, p->stream, in, (const uint8_t*)nullptr, n,
-                         quarters, nquarters, 1, nfull);
+      if (validity)
+        hipLaunchKernelGGL((sum_tree_quarter_kernel<true>), dim3((unsigned)(nquarters - nfull)), dim3(AGPU_WAVE), 0, p->stream, in, validity, n, quarters,
+                           nquarters, 1, nfull);
+      else
+        hipLaunchKernelGGL((sum_tree_quarter_kernel<false>), dim3((unsigned)(nquarters - nfull)), dim3(AGPU_WAVE), 0, p->stream, in, validity, n, quarters,
+                           nquarters, 1, nfull);
       AGPU_LAUNCH_CHECK();
     }
     st = sum_tree_after_quarters(p, quarters, nspans, groups, buf0, buf1, o_sum);
@@ -775,8 +818,12 @@ static agpu_status launch_stats_f32(agpu_pipeline* p, const float* in, const uin
   const float* tail_in = in + nfull * WAVE_ROWS;
   const uint32_t tail = (uint32_t)(n - nfull * WAVE_ROWS);
   const uint32_t nthr = nfull > 16384 ? AGPU_FOLD_BLOCK : 256;
-  hipLaunchKernelGGL(stats_finish_kernel, dim3(4), dim3(AGPU_FOLD_BLOCK), 0, p->stream, in, n, quarters, nfull, nquarters, nspans, (uint32_t)ngroups,
-                     fused_sum ? 1 : 0, (const float*)mins, (const float*)maxs, (const double*)dsums, tail_in, tail, nthr, out);
+  if (validity)
+    hipLaunchKernelGGL((stats_finish_kernel<true>), dim3(4), dim3(AGPU_FOLD_BLOCK), 0, p->stream, in, validity, n, quarters, nfull, nquarters, nspans,
+                       (uint32_t)ngroups, fused_sum ? 1 : 0, (const void*)mins, (const void*)maxs, (const double*)dsums, tail_in, tail, nthr, out);
+  else
+    hipLaunchKernelGGL((stats_finish_kernel<false>), dim3(4), dim3(AGPU_FOLD_BLOCK), 0, p->stream, in, validity, n, quarters, nfull, nquarters, nspans,
+                       (uint32_t)ngroups, fused_sum ? 1 : 0, (const void*)mins, (const void*)maxs, (const double*)dsums, tail_in, tail, nthr, out);
   AGPU_LAUNCH_CHECK();
   return AGPU_OK;
 }

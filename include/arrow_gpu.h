@@ -438,8 +438,9 @@ agpu_status agpu_reduce_sum_f64(agpu_pipeline* p, const float* in, const void* v
 /* Whole-column f32 statistics in ONE pass (no counterpart in the reference, whose only reduction is `sum` [aggregate_kernels.rs:24-51];
  * north_star config 5 wants sum / min / max of one column — three agpu_reduce calls read it three times).  out_dev receives one record:
  * sum = agpu_reduce(SUM) — the reference's tree order —, min / max = agpu_reduce(MIN / MAX) (Arrow's NaN rule), sum_f64 =
- * agpu_reduce_sum_f64, each BIT-IDENTICAL to the separate call on the same column; the column is read once (4 B/row) when it is 16-byte
- * aligned, has no validity bitmap and at least 2^20 rows, otherwise the four reductions run one after the other.  8-byte aligned out_dev. */
+ * agpu_reduce_sum_f64, each BIT-IDENTICAL to the separate call on the same column (null-aware like them when `validity` is given: null
+ * slots contribute the identities); the column is read once (4 B/row, + its bitmap) when it is 16-byte aligned (the bitmap 4-byte) and has
+ * at least 2^20 rows, otherwise the four reductions run one after the other.  8-byte aligned out_dev. */
 typedef struct agpu_f32_stats {
   float sum;
   float min;

@@ -83,10 +83,21 @@ def test_stats_specials_on_the_fused_path(D):
     _check(D, y)                                      # the extremes in the < 1-quarter tail
 
 
-def test_stats_fallbacks_null_aware_and_unaligned(D):
+def test_stats_null_aware_in_one_pass_and_the_unaligned_fallback(D):
     n = (1 << 21) + 999
     x = O.synth_f32(n, 33, 0, -10.0, 10.0)
     _check(D, x, validity_bits=O.synth_bits(n, 34, 0, 0.8))
+    # quarters without a valid row, quarters whose valid rows are all NaN, both in one column; no valid row at all; a valid extreme in the tail
+    v = np.unpackbits(O.synth_bits(n, 35, 0, 0.6), bitorder="little")[:n].astype(bool)
+    v[:16384] = False
+    y = x.copy(); y[16384 * 2: 16384 * 3] = np.nan; v[16384 * 4: 16384 * 5] = True; y[16384 * 4: 16384 * 5] = np.nan
+    _check(D, y, validity_bits=O.pack_bits(v))
+    only_nan = y.copy(); only_nan[v] = np.nan
+    _check(D, only_nan, validity_bits=O.pack_bits(v))      # every valid row NaN → min = max = NaN (the null quarters must not turn that into ±inf)
+    _check(D, x, validity_bits=O.pack_bits(np.zeros(n, bool)))  # nothing valid: sum 0, min +inf, max −inf
+    t = v.copy(); t[-1] = True
+    z = x.copy(); z[-1] = np.float32(-3.0e38)
+    _check(D, z, validity_bits=O.pack_bits(t))
     _check(D, x[: 1 << 20], offset=4)     # only 4-byte aligned: the four reductions one after the other
 
 

@@ -149,6 +149,9 @@ def main():
     t("i32 sum (wrapping)", 4, lambda: capi.call("agpu_reduce", h, capi.RED_SUM, I32, vp(A), None, n, vp(R)))
     t("f32 sum + min + max + f64 sum in ONE pass (agpu_reduce_stats_f32)", 4, lambda: capi.call("agpu_reduce_stats_f32", h, vp(A), None, n, vp(R)),
       note="config 5's four statistics from one read of the column; every field bit-identical to the separate reduction (four launches: 4 x the time of one)")
+    t("… null-aware (validity bitmap read beside the values)", 4.125, lambda: capi.call("agpu_reduce_stats_f32", h, vp(A), vp(VA), n, vp(R)))
+    t("f32 min, null-aware", 4.125, lambda: capi.call("agpu_reduce", h, capi.RED_MIN, F32, vp(A), vp(VA), n, vp(R)),
+      note="round 6b: the one-wave-per-chunk kernel reads the bits beside the values (rounds 1-6a: the grid-stride form)")
     t("merge f32 by mask", 12.125, lambda: capi.call("agpu_merge", h, 4, vp(A), vp(B), vp(M), vp(O), n))
     # gather / scatter: sequential indices (best case) and a pseudo-random permutation (worst case)
     m = min(n, 1 << 28)
