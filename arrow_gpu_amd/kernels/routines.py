@@ -212,8 +212,12 @@ def take_columns_op(columns, indexes: UInt32ArrayGPU, pipeline: ArrowComputePipe
         return []
     n_src = columns[0].len
     for c in columns:
-        if not isinstance(c, PrimitiveArrayGpu) or c.len != n_src:
-            raise capi.ArrowErrorGPU("ShapeError", "take_columns: primitive columns of one length", capi.ERR_SHAPE)
+        if not isinstance(c, (PrimitiveArrayGpu, BooleanArrayGPU)) or c.len != n_src:
+            raise capi.ArrowErrorGPU("ShapeError", "take_columns: primitive or Boolean columns of one length", capi.ERR_SHAPE)
+    if any(isinstance(c, BooleanArrayGPU) for c in columns):  # Boolean columns are bitmaps: taken on their own (their pipeline partitions by word)
+        prims = [c for c in columns if isinstance(c, PrimitiveArrayGpu)]
+        taken = iter(take_columns_op(prims, indexes, pipeline))
+        return [c.take_op(indexes, pipeline) if isinstance(c, BooleanArrayGPU) else next(taken) for c in columns]
     dev = columns[0].gpu_device
     k = len(columns)
     outs = [dev.create_empty_buffer(max(indexes.len * c.ITEM_SIZE, 1)) for c in columns]

@@ -109,7 +109,9 @@ def test_take_columns_through_the_python_host_with_nulls(D):
     b = ag.Float32ArrayGPU.from_slice(rng.standard_normal(n).astype(np.float32), dev)
     c = ag.UInt16ArrayGPU.from_slice(rng.integers(0, 65535, n).astype(np.uint16), dev)
     idx = ag.UInt32ArrayGPU.from_slice(rng.integers(0, n, 30_000).astype(np.uint32), dev)
-    ta, tb, tc = ag.take_columns([a, b, c], idx)
+    m = ag.BooleanArrayGPU.from_optional_slice([None if rng.random() < 0.05 else bool(v) for v in rng.integers(0, 2, n)], dev)
+    ta, tm, tb, tc = ag.take_columns([a, m, b, c], idx)      # a Boolean column among them: taken on its own, in its place
+    assert tm.values() == m.take(idx).values()
     assert ta.values() == a.take(idx).values()
     assert tb.values() == b.take(idx).values()
     assert tc.values() == c.take(idx).values()
